@@ -1,0 +1,282 @@
+"""Crystal-graph batch container, collate and CSR metadata.
+
+This is the build's counterpart of the PyG ``Batch`` object that the reference's
+models receive (`main_eDOS.py:54,104-109`, `main_phDOS.py:53,104-107`): a bag of
+concatenated per-crystal tensors that exposes BOTH attribute access (``g.x``,
+``g.batch``, ``g.system`` — `DOSTransformer_phonon.py:79,86,105`) and mapping
+access (``'batch' in data``, ``data['edge_index']`` —
+`DOSTransformer_phonon.py:48-56`).
+
+On top of the reference schema it carries the graph metadata the HIP kernels
+want, computed once at collate time on the host so that the forward pass has no
+host synchronisation (the reference syncs on ``batch.unique()``
+`DOSTransformer_phonon.py:143` and inside ``to_dense_batch`` `:86`):
+
+* edges physically sorted by destination (``col = edge_index[1]``) so the
+  edge->node aggregation (`DOSTransformer_phonon.py:209`, `DOSTransformer.py:187`)
+  is a contiguous CSR segment reduction (no atomics, bitwise reproducible);
+* ``rowptr_dst [N+1]``, and the source-sorted inverse index
+  ``perm_src [E]`` / ``rowptr_src [N+1]`` for the gather-backward scatter-add;
+* ``graph_ptr [B+1]``, per-node graph id / position, ``n_max`` (global max atoms
+  per crystal — it changes the numerics because the reference attends over the
+  zero-padded rows).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Iterable, List, Optional
+
+import numpy as np
+import torch
+
+_META_KEY = "_dosx_meta"
+
+
+@dataclass
+class GraphMeta:
+    """Index metadata for one batch, int32, resident on the batch's device."""
+    num_nodes: int
+    num_edges: int
+    num_graphs: int
+    n_max: int
+    src: torch.Tensor          # [E] int32, edge source  (row = edge_index[0]) in dst-sorted order
+    dst: torch.Tensor          # [E] int32, edge dest    (col = edge_index[1]) non-decreasing
+    edge_perm: Optional[torch.Tensor]  # [E] int64: dst-sorted position -> position in the caller's edge arrays (None = identity)
+    rowptr_dst: torch.Tensor   # [N+1] int32
+    perm_src: torch.Tensor     # [E] int32: ids (in dst-sorted numbering) ordered by src
+    rowptr_src: torch.Tensor   # [N+1] int32
+    graph_ptr: torch.Tensor    # [B+1] int32
+    node_graph: torch.Tensor   # [N] int32
+    dense_row: torch.Tensor    # [N] int32: row of node n in the [Nmax*B] dense layout = pos*B + graph
+    inv_deg: torch.Tensor      # [N] float32: 1/max(in-degree,1)  (scatter_mean divisor)
+
+    def to(self, device) -> "GraphMeta":
+        kw = {}
+        for k, v in self.__dict__.items():
+            kw[k] = v.to(device) if isinstance(v, torch.Tensor) else v
+        return GraphMeta(**kw)
+
+
+def _build_meta_host(edge_index: np.ndarray, batch: np.ndarray, num_graphs: int,
+                     n_max: Optional[int], presorted: bool) -> GraphMeta:
+    n = int(batch.shape[0])
+    e = int(edge_index.shape[1])
+    src = edge_index[0].astype(np.int64)
+    dst = edge_index[1].astype(np.int64)
+    if presorted:
+        perm = None
+    else:
+        perm = np.argsort(dst, kind="stable")
+        src, dst = src[perm], dst[perm]
+    deg_in = np.bincount(dst, minlength=n) if e else np.zeros(n, np.int64)
+    rowptr_dst = np.zeros(n + 1, np.int64)
+    np.cumsum(deg_in, out=rowptr_dst[1:])
+    perm_src = np.argsort(src, kind="stable")
+    deg_out = np.bincount(src, minlength=n) if e else np.zeros(n, np.int64)
+    rowptr_src = np.zeros(n + 1, np.int64)
+    np.cumsum(deg_out, out=rowptr_src[1:])
+    counts = np.bincount(batch, minlength=num_graphs)
+    graph_ptr = np.zeros(num_graphs + 1, np.int64)
+    np.cumsum(counts, out=graph_ptr[1:])
+    true_max = int(counts.max()) if num_graphs else 0
+    if n_max is None:
+        n_max = true_max
+    elif n_max < true_max:
+        raise ValueError(f"n_max={n_max} smaller than the largest crystal ({true_max} atoms)")
+    pos = np.arange(n, dtype=np.int64) - graph_ptr[batch]
+    dense_row = pos * num_graphs + batch
+    i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(np.int32)))
+    return GraphMeta(
+        num_nodes=n, num_edges=e, num_graphs=num_graphs, n_max=int(n_max),
+        src=i32(src), dst=i32(dst),
+        edge_perm=None if perm is None else torch.from_numpy(perm.astype(np.int64)),
+        rowptr_dst=i32(rowptr_dst), perm_src=i32(perm_src), rowptr_src=i32(rowptr_src),
+        graph_ptr=i32(graph_ptr), node_graph=i32(batch), dense_row=i32(dense_row),
+        inv_deg=torch.from_numpy((1.0 / np.maximum(deg_in, 1)).astype(np.float32)),
+    )
+
+
+class CrystalBatch:
+    """Attribute + mapping bag of batched crystal-graph tensors (see module doc)."""
+
+    def __init__(self, fields: Dict[str, object], num_graphs: int, meta: Optional[GraphMeta] = None):
+        object.__setattr__(self, "_fields", dict(fields))
+        object.__setattr__(self, "num_graphs", int(num_graphs))
+        object.__setattr__(self, _META_KEY, meta)
+
+    # --- mapping protocol (`'batch' in data`, `data['edge_index']`) ---
+    def __contains__(self, key):
+        return key in self._fields
+
+    def __getitem__(self, key):
+        return self._fields[key]
+
+    def __setitem__(self, key, value):
+        self._fields[key] = value
+
+    def keys(self):
+        return self._fields.keys()
+
+    # --- attribute protocol (`g.x`, `g.batch`) ---
+    def __getattr__(self, name):
+        f = object.__getattribute__(self, "_fields")
+        if name in f:
+            return f[name]
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        if name in ("num_graphs", _META_KEY):
+            object.__setattr__(self, name, value)
+        else:
+            self._fields[name] = value
+
+    @property
+    def meta(self) -> Optional[GraphMeta]:
+        return object.__getattribute__(self, _META_KEY)
+
+    def to(self, device, dtype: Optional[torch.dtype] = None) -> "CrystalBatch":
+        """In-place move like PyG's ``batch.to(device)`` (`main_eDOS.py:106`); returns self."""
+        for k, v in list(self._fields.items()):
+            if isinstance(v, torch.Tensor):
+                if dtype is not None and v.is_floating_point():
+                    v = v.to(dtype)
+                self._fields[k] = v.to(device)
+        m = self.meta
+        if m is not None:
+            object.__setattr__(self, _META_KEY, m.to(device))
+        return self
+
+    def clone(self) -> "CrystalBatch":
+        f = {k: (v.clone() if isinstance(v, torch.Tensor) else list(v) if isinstance(v, list) else v)
+             for k, v in self._fields.items()}
+        return CrystalBatch(f, self.num_graphs, self.meta)
+
+    def __repr__(self):
+        parts = []
+        for k, v in self._fields.items():
+            parts.append(f"{k}={list(v.shape)}" if isinstance(v, torch.Tensor) else f"{k}=[{len(v)}]")
+        return f"CrystalBatch(num_graphs={self.num_graphs}, {', '.join(parts)})"
+
+
+_EDGE_FIELDS = ("edge_vec", "edge_attr", "edge_shift", "edge_len")
+_GRAPH_CAT_FIELDS = ("glob", "y_ft", "y")            # 1-D per crystal, concatenated (`mat2graph.py:84-93`)
+_GRAPH_STACK_FIELDS = ("system",)                     # 0-D per crystal -> [B]
+
+
+def collate(crystals: Iterable[Dict[str, object]], sort_edges: bool = True,
+            n_max: Optional[int] = None) -> CrystalBatch:
+    """Concatenate per-crystal dicts into one batch (counterpart of PyG collate).
+
+    Per crystal: ``x [n,Fa]``, ``edge_index [2,e]`` (local ids), and any of
+    ``edge_vec [e,3]`` / ``edge_attr [e,Fb]``, ``glob [2]``, ``system`` scalar,
+    ``phdos [1,51]``, ``y_ft [201]``, ``mp_id`` str (`utils.py:291-301`,
+    `mat2graph.py:81-107`).  ``n_max`` may be forced larger than this batch's own
+    maximum: data-parallel shards must pad to the GLOBAL batch's maximum to
+    reproduce the single-process result.
+    """
+    crystals = list(crystals)
+    if not crystals:
+        raise ValueError("collate() needs at least one crystal")
+    xs, eis, bvec, offs = [], [], [], 0
+    for b, c in enumerate(crystals):
+        n = c["x"].shape[0]
+        xs.append(c["x"])
+        eis.append(c["edge_index"].to(torch.int64) + offs)
+        bvec.append(torch.full((n,), b, dtype=torch.int64))
+        offs += n
+    fields: Dict[str, object] = {
+        "x": torch.cat(xs, 0),
+        "edge_index": torch.cat(eis, 1),
+        "batch": torch.cat(bvec, 0),
+    }
+    for k in _EDGE_FIELDS:
+        if k in crystals[0] and isinstance(crystals[0][k], torch.Tensor):
+            fields[k] = torch.cat([c[k] for c in crystals], 0)
+    for k in _GRAPH_CAT_FIELDS:
+        if k in crystals[0]:
+            fields[k] = torch.cat([c[k].reshape(-1) for c in crystals], 0)
+    for k in _GRAPH_STACK_FIELDS:
+        if k in crystals[0]:
+            fields[k] = torch.stack([torch.as_tensor(c[k]).reshape(()) for c in crystals]).to(torch.int64)
+    if "phdos" in crystals[0]:
+        fields["phdos"] = torch.cat([c["phdos"].reshape(1, -1) for c in crystals], 0)
+    if "mp_id" in crystals[0]:
+        fields["mp_id"] = [c["mp_id"] for c in crystals]
+
+    ei = fields["edge_index"].numpy()
+    meta = _build_meta_host(ei, fields["batch"].numpy(), len(crystals), n_max, presorted=False)
+    if sort_edges and meta.edge_perm is not None:
+        p = meta.edge_perm
+        fields["edge_index"] = fields["edge_index"][:, p]
+        for k in _EDGE_FIELDS:
+            if k in fields:
+                fields[k] = fields[k][p]
+        meta.edge_perm = None
+    return CrystalBatch(fields, len(crystals), meta)
+
+
+def graph_meta(g, device=None, n_max: Optional[int] = None) -> GraphMeta:
+    """Return (and cache on ``g``) the GraphMeta of a batch object.
+
+    For a :class:`CrystalBatch` built by :func:`collate` this is free.  For a
+    foreign object (e.g. a PyG ``Batch``) the metadata is derived from
+    ``g.edge_index`` / ``g.batch`` with one device->host copy of the index
+    arrays — the same host round trip the reference pays in ``to_dense_batch``.
+    """
+    m = getattr(g, _META_KEY, None) if not isinstance(g, CrystalBatch) else g.meta
+    if m is None or (n_max is not None and m.n_max != n_max):
+        ei = g.edge_index.detach().cpu().numpy()
+        bv = g.batch.detach().cpu().numpy()
+        nb = int(g.system.shape[0]) if hasattr(g, "system") and torch.is_tensor(g.system) and g.system.dim() > 0 \
+            else (int(bv.max()) + 1 if bv.size else 0)
+        presorted = bool(ei.shape[1] == 0 or np.all(ei[1, 1:] >= ei[1, :-1]))
+        m = _build_meta_host(ei, bv, nb, n_max, presorted)
+        try:
+            if isinstance(g, CrystalBatch):
+                object.__setattr__(g, _META_KEY, m)
+            else:
+                setattr(g, _META_KEY, m)
+        except Exception:
+            pass
+    if device is not None and m.src.device != torch.device(device):
+        m = m.to(device)
+        try:
+            if isinstance(g, CrystalBatch):
+                object.__setattr__(g, _META_KEY, m)
+            else:
+                setattr(g, _META_KEY, m)
+        except Exception:
+            pass
+    return m
+
+
+def split_crystals(g: CrystalBatch) -> List[Dict[str, object]]:
+    """Inverse of :func:`collate` (used by the data-parallel sharder)."""
+    bv = g.batch.cpu()
+    ei = g.edge_index.cpu()
+    counts = torch.bincount(bv, minlength=g.num_graphs)
+    ptr = torch.zeros(g.num_graphs + 1, dtype=torch.int64)
+    ptr[1:] = torch.cumsum(counts, 0)
+    egraph = bv[ei[1]] if ei.shape[1] else ei[1]
+    out = []
+    for b in range(g.num_graphs):
+        sel = (egraph == b).nonzero().reshape(-1)
+        c: Dict[str, object] = {
+            "x": g.x[ptr[b]:ptr[b + 1]].cpu(),
+            "edge_index": ei[:, sel] - ptr[b],
+        }
+        for k in _EDGE_FIELDS:
+            if k in g and isinstance(g[k], torch.Tensor):
+                c[k] = g[k].cpu()[sel]
+        if "glob" in g:
+            c["glob"] = g.glob.cpu().reshape(g.num_graphs, -1)[b]
+        if "y_ft" in g:
+            c["y_ft"] = g.y_ft.cpu().reshape(g.num_graphs, -1)[b]
+        if "system" in g:
+            c["system"] = g.system.cpu()[b]
+        if "phdos" in g:
+            c["phdos"] = g.phdos.cpu()[b:b + 1]
+        if "mp_id" in g:
+            c["mp_id"] = g.mp_id[b]
+        out.append(c)
+    return out

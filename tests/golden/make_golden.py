@@ -1,0 +1,340 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference; never on the GPU box).
+The reference's model files are imported UNMODIFIED from /root/reference; the five
+third-party symbols they import that are not installed here (torch_scatter,
+torch_geometric.utils.to_dense_batch, e3nn spherical harmonics / smooth_cutoff,
+torch_cluster.radius_graph — SURVEY.md §8c) are provided as in-process stand-ins
+that follow those libraries' documented semantics (restated in
+oracle/dos_oracle.py).  Everything with learned parameters (Linear, LayerNorm,
+PReLU, Embedding, bmm, softmax, AdamW) is the reference's own code on real torch.
+
+Output: small .npz files (inputs, weights, outputs, grads, post-AdamW weights).
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("DOSX_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+
+from oracle import dos_oracle as O          # noqa: E402  (third-party semantics only)
+from dostransformer_amd import synth        # noqa: E402
+from dostransformer_amd.batch import collate  # noqa: E402
+
+
+def install_standins():
+    ts = types.ModuleType("torch_scatter")
+    ts.scatter_sum = lambda src, index, dim=0, dim_size=None: O.scatter_sum(
+        src, index, int(index.max()) + 1 if dim_size is None else dim_size)
+    ts.scatter_mean = lambda src, index, dim=0, dim_size=None: O.scatter_mean(
+        src, index, int(index.max()) + 1 if dim_size is None else dim_size)
+    sys.modules["torch_scatter"] = ts
+
+    tg = types.ModuleType("torch_geometric")
+    tgu = types.ModuleType("torch_geometric.utils")
+
+    def to_dense_batch(x, batch=None):
+        nb = int(batch.max()) + 1
+        counts = torch.bincount(batch, minlength=nb)
+        n_max = int(counts.max())
+        dense = O.to_dense_batch(x, batch, nb, n_max)
+        ptr = torch.zeros(nb + 1, dtype=torch.long)
+        ptr[1:] = torch.cumsum(counts, 0)
+        mask = torch.zeros(nb * n_max, dtype=torch.bool)
+        mask[batch * n_max + (torch.arange(x.shape[0]) - ptr[batch])] = True
+        return dense, mask.reshape(nb, n_max)
+
+    tgu.to_dense_batch = to_dense_batch
+    tg.utils = tgu
+    sys.modules["torch_geometric"] = tg
+    sys.modules["torch_geometric.utils"] = tgu
+
+    e3 = types.ModuleType("e3nn")
+    o3 = types.ModuleType("e3nn.o3")
+
+    class Irreps:
+        @staticmethod
+        def spherical_harmonics(lmax):
+            assert lmax == 1
+            return "1x0e+1x1o"
+
+    def spherical_harmonics(irreps, vec, normalize, normalization="integral"):
+        assert irreps == "1x0e+1x1o" and normalize is True and normalization == "component"
+        return O.spherical_harmonics_l1(vec)
+
+    o3.Irreps = Irreps
+    o3.spherical_harmonics = spherical_harmonics
+    e3.o3 = o3
+    nn_ = types.ModuleType("e3nn.nn")
+    models = types.ModuleType("e3nn.nn.models")
+    gp = types.ModuleType("e3nn.nn.models.gate_points_2101")
+    gp.smooth_cutoff = O.smooth_cutoff
+    sys.modules.update({"e3nn": e3, "e3nn.o3": o3, "e3nn.nn": nn_, "e3nn.nn.models": models,
+                        "e3nn.nn.models.gate_points_2101": gp})
+    tc = types.ModuleType("torch_cluster")
+
+    def radius_graph(*a, **k):
+        raise RuntimeError("dead branch in the reference (self.max_radius is never set)")
+
+    tc.radius_graph = radius_graph
+    sys.modules["torch_cluster"] = tc
+
+
+def np_(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def pack_batch(out, g, prefix="b/"):
+    for k in g.keys():
+        v = g[k]
+        if isinstance(v, torch.Tensor):
+            out[prefix + k] = np_(v)
+    out[prefix + "num_graphs"] = np.int64(g.num_graphs)
+
+
+def pack_sd(out, sd, prefix):
+    for k, v in sd.items():
+        out[prefix + k] = np_(v)
+
+
+def run_train(model, g, kind, beta, steps, out):
+    """Reference train-step body: main_phDOS.py:104-118 / main_eDOS.py:104-127."""
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-2)
+    pack_sd(out, model.state_dict(), "p0/")
+    for step in range(1, steps + 1):
+        model.train()
+        pg, xn, ps = model(g)
+        if kind == "phonon":
+            crit = torch.nn.MSELoss()
+            loss = torch.sqrt(crit(pg, g.phdos).cpu()).mean() + beta * torch.sqrt(crit(ps, g.phdos).cpu()).mean()
+        else:
+            zero = torch.tensor(0, dtype=torch.float)
+            y_ft = torch.where(g.y_ft < 0, zero, g.y_ft)
+            y = y_ft.reshape(len(g.mp_id), -1)
+            loss = torch.sqrt(((y - pg) ** 2).mean(dim=1)).mean() + beta * torch.sqrt(((y - ps) ** 2).mean(dim=1)).mean()
+        opt.zero_grad()
+        loss.backward()
+        if step == 1:
+            out["dos_global"], out["x_nodes"], out["dos_system"] = np_(pg), np_(xn), np_(ps)
+            out["loss"] = np_(loss)
+            dead = []
+            for k, p in model.named_parameters():
+                if p.grad is None:
+                    dead.append(k)
+                else:
+                    out["g/" + k] = np_(p.grad)
+            out["dead_params"] = np.array(dead)
+        opt.step()
+        if step in (1, 3):
+            pack_sd(out, model.state_dict(), f"p{step}/")
+    return out
+
+
+def main():
+    install_standins()
+    sys.path.insert(0, REF)
+    from layers.multihead_attention import MultiheadAttention
+    from layers.transformer import TransformerEncoder
+    from embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon, Processor as PhProcessor, \
+        EdgeModel as PhEdge, NodeModel as PhNode
+    from embedder_eDOS.DOSTransformer import DOSTransformer, Processor as EProcessor, EdgeModel as EEdge, \
+        NodeModel as ENode
+    from embedder_phDOS.graphnetwork_phonon import Graphnetwork_phonon
+    from embedder_eDOS.graphnetwork import Graphnetwork
+
+    dev = torch.device("cpu")
+
+    # ---- G1: MultiheadAttention, fp32 and fp64, zero-padded key rows ------------------
+    out = {}
+    for name, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        gen = torch.Generator().manual_seed(101)
+        q = torch.randn(51, 3, 16, generator=gen, dtype=torch.float64).to(dt)
+        kv = torch.randn(5, 3, 16, generator=gen, dtype=torch.float64).to(dt)
+        kv[3:, 1] = 0.0
+        kv[1:, 2] = 0.0
+        torch.manual_seed(0)
+        mha = MultiheadAttention(16, 1).to(dt)
+        out[f"{name}/q"], out[f"{name}/kv"] = np_(q), np_(kv)
+        out[f"{name}/out"] = np_(mha(q, kv, kv))
+    np.savez_compressed(os.path.join(HERE, "g1_mha.npz"), **out)
+
+    # ---- G2: TransformerEncoder(T=2) cross and self, fp32, with grads -----------------
+    out = {}
+    torch.manual_seed(0)
+    enc = TransformerEncoder(embed_dim=16, num_heads=1, layers=2, attn_dropout=0.0)
+    gen = torch.Generator().manual_seed(102)
+    with torch.no_grad():   # make LN affine / biases non-trivial so their grads are exercised
+        for k, p in enc.named_parameters():
+            if "layer_norm" in k or k.endswith("fc1.bias") or k.endswith("fc2.bias"):
+                p.add_(0.1 * torch.randn(p.shape, generator=gen))
+    pack_sd(out, enc.state_dict(), "p/")
+    for mode in ("cross", "self"):
+        x = torch.randn(7, 3, 16, generator=gen).requires_grad_(True)
+        if mode == "cross":
+            kv = torch.randn(5, 3, 16, generator=gen)
+            kv[2:, 0] = 0.0
+            kv = kv.requires_grad_(True)
+            y = enc(x, kv, kv)
+        else:
+            kv = x
+            y = enc(x, x, x)
+        w = torch.randn(y.shape, generator=gen)
+        enc.zero_grad()
+        (y * w).sum().backward()
+        out[f"{mode}/x"], out[f"{mode}/w"], out[f"{mode}/y"] = np_(x), np_(w), np_(y)
+        out[f"{mode}/dx"] = np_(x.grad)
+        if mode == "cross":
+            out["cross/kv"], out["cross/dkv"] = np_(kv), np_(kv.grad)
+        dead = []
+        for k, p in enc.named_parameters():
+            if p.grad is None:
+                dead.append(k)
+            else:
+                out[f"{mode}/g/{k}"] = np_(p.grad)
+        out[f"{mode}/dead"] = np.array(dead)
+    np.savez_compressed(os.path.join(HERE, "g2_encoder.npz"), **out)
+
+    # ---- G3: one Processor layer, mean and sum, isolated node + duplicate edges -------
+    out = {}
+    gen = torch.Generator().manual_seed(103)
+    n, h = 6, 8
+    ei = torch.tensor([[0, 1, 1, 2, 3, 3, 0, 4, 4, 2],
+                       [1, 0, 0, 3, 2, 2, 0, 1, 3, 2]])      # node 5 isolated; node 4 has no in-edge; dups (1->0),(3->2)
+    x = torch.randn(n, h, generator=gen)
+    e = torch.randn(ei.shape[1], h, generator=gen)
+    out["x"], out["e"], out["edge_index"] = np_(x), np_(e), np_(ei)
+    for name, Proc, Edge, Node in (("mean", PhProcessor, PhEdge, PhNode), ("sum", EProcessor, EEdge, ENode)):
+        torch.manual_seed(0)
+        proc = Proc(Edge(h), Node(h))
+        with torch.no_grad():
+            for k, p in proc.named_parameters():
+                if ".1." in k:      # LayerNorm affine
+                    p.add_(0.1 * torch.randn(p.shape, generator=gen))
+        pack_sd(out, proc.state_dict(), f"{name}/p/")
+        xx = x.clone().requires_grad_(True)
+        ee = e.clone().requires_grad_(True)
+        ox, oe = proc(x=xx, edge_index=ei, edge_attr=ee)
+        wx = torch.randn(ox.shape, generator=gen)
+        we = torch.randn(oe.shape, generator=gen)
+        ((ox * wx).sum() + (oe * we).sum()).backward()
+        out[f"{name}/ox"], out[f"{name}/oe"] = np_(ox), np_(oe)
+        out[f"{name}/wx"], out[f"{name}/we"] = np_(wx), np_(we)
+        out[f"{name}/dx"], out[f"{name}/de"] = np_(xx.grad), np_(ee.grad)
+        dead = []
+        for k, p in proc.named_parameters():
+            if p.grad is None:
+                dead.append(k)
+            else:
+                out[f"{name}/g/{k}"] = np_(p.grad)
+        out[f"{name}/dead"] = np.array(dead)
+    np.savez_compressed(os.path.join(HERE, "g3_processor.npz"), **out)
+
+    # ---- G4: edge-feature prep edge cases (through the reference forward's own lines) --
+    # DOSTransformer_phonon.py:74-77 calls the (stand-in) e3nn functions; this fixture pins
+    # the composition and the regimes: zero vector, x<0.5, 0.5<x<1, x>1 (r_max = 4).
+    out = {}
+    vec = torch.tensor([[0.0, 0.0, 0.0], [0.5, -0.2, 0.1], [1.0, 1.0, 0.5], [2.0, -1.5, 1.0],
+                        [2.2, 2.2, 0.5], [-3.0, 2.5, 1.0], [4.0, 0.0, 0.0], [0.0, -2.0, 0.0],
+                        [1e-13, 0.0, 0.0]], dtype=torch.float64)
+    sh = sys.modules["e3nn.o3"].spherical_harmonics("1x0e+1x1o", vec, True, normalization="component")
+    feat = sys.modules["e3nn.nn.models.gate_points_2101"].smooth_cutoff(vec.norm(dim=1) / 4.)[:, None] * sh
+    out["edge_vec"], out["edge_attr"] = np_(vec), np_(feat)
+    np.savez_compressed(os.path.join(HERE, "g4_edge_features.npz"), **out)
+
+    # ---- G5: full DOSTransformer_phonon fp64, B=3 unequal graphs (1, 4, 9 atoms) ------
+    torch.set_default_dtype(torch.float64)          # main_phDOS.py:15-16
+    out = {}
+    g = synth.phonon_batch(3, seed=5, dtype=torch.float64, sort_edges=False, n_atoms=[1, 4, 9])
+    pack_batch(out, g)
+    torch.manual_seed(0)
+    model = DOSTransformer_phonon(3, 1, 118, 4, 16, dev, 0.0)
+    run_train(model, g, "phonon", 1.0, 3, out)
+    np.savez_compressed(os.path.join(HERE, "g5_phonon.npz"), **out)
+
+    # ---- G7 (phonon part): same crystal alone vs batched with a bigger one -------------
+    out = {}
+    cs = synth.phonon_crystals(2, seed=7, dtype=torch.float64)
+    gen = torch.Generator().manual_seed(77)
+    cs[0] = synth.phonon_crystal(gen, n_atoms=3, dtype=torch.float64)
+    cs[1] = synth.phonon_crystal(gen, n_atoms=11, dtype=torch.float64)
+    alone = collate([cs[0]], sort_edges=False)
+    both = collate(cs, sort_edges=False)
+    pack_batch(out, alone, "alone/b/")
+    pack_batch(out, both, "both/b/")
+    torch.manual_seed(0)
+    model = DOSTransformer_phonon(3, 1, 118, 4, 16, dev, 0.0)
+    pack_sd(out, model.state_dict(), "p0/")
+    model.eval()
+    with torch.no_grad():
+        a = model(alone)
+        b = model(both)
+    out["alone/dos_global"], out["alone/dos_system"] = np_(a[0]), np_(a[2])
+    out["both/dos_global"], out["both/dos_system"] = np_(b[0]), np_(b[2])
+    np.savez_compressed(os.path.join(HERE, "g7_batch_composition.npz"), **out)
+
+    # ---- G8a: Graphnetwork_phonon fp64 --------------------------------------------------
+    out = {}
+    g = synth.phonon_batch(3, seed=8, dtype=torch.float64, sort_edges=False, n_atoms=[2, 5, 3])
+    pack_batch(out, g)
+    torch.manual_seed(0)
+    model = Graphnetwork_phonon(3, 118, 4, 16, 51, dev)
+    pack_sd(out, model.state_dict(), "p0/")
+    dos = model(g)
+    w = torch.randn(dos.shape, generator=torch.Generator().manual_seed(88))
+    (dos * w).sum().backward()
+    out["dos"], out["w"] = np_(dos), np_(w)
+    dead = []
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            dead.append(k)
+        else:
+            out["g/" + k] = np_(p.grad)
+    out["dead_params"] = np.array(dead)
+    np.savez_compressed(os.path.join(HERE, "g8_graphnetwork_phonon.npz"), **out)
+    torch.set_default_dtype(torch.float32)
+
+    # ---- G6: full DOSTransformer (eDOS) fp32, phantom zero node per graph --------------
+    out = {}
+    g = synth.edos_batch(3, seed=6, dtype=torch.float32, sort_edges=False, n_atoms=[2, 7, 4])
+    pack_batch(out, g)
+    out["b/mp_id"] = np.array(g.mp_id)
+    torch.manual_seed(0)
+    model = DOSTransformer(3, 2, 200, 41, 2, 16, dev, 0.0)
+    run_train(model, g, "edos", 1.0, 3, out)
+    np.savez_compressed(os.path.join(HERE, "g6_edos.npz"), **out)
+
+    # ---- G8b: Graphnetwork (eDOS) fp32 -------------------------------------------------
+    out = {}
+    g = synth.edos_batch(2, seed=9, dtype=torch.float32, sort_edges=False, n_atoms=[3, 6])
+    pack_batch(out, g)
+    torch.manual_seed(0)
+    model = Graphnetwork(3, 200, 41, 2, 16, 201, dev)
+    pack_sd(out, model.state_dict(), "p0/")
+    dos, xn = model(g)
+    w = torch.randn(dos.shape, generator=torch.Generator().manual_seed(99))
+    (dos * w).sum().backward()
+    out["dos"], out["w"], out["x_nodes"] = np_(dos), np_(w), np_(xn)
+    dead = []
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            dead.append(k)
+        else:
+            out["g/" + k] = np_(p.grad)
+    out["dead_params"] = np.array(dead)
+    np.savez_compressed(os.path.join(HERE, "g8_graphnetwork_edos.npz"), **out)
+
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()
