@@ -1,0 +1,154 @@
+"""ctypes binding of ``csrc/libdosx.so`` (C ABI declared in ``include/dosx.h``).
+
+There is NO fallback: if the HIP library is missing or fails to load, every op raises
+:class:`DosxUnavailable` — the product path never routes through a CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdosx.so")
+
+c_float_p = C.POINTER(C.c_float)
+c_int_p = C.POINTER(C.c_int32)
+BIG = 1 << 30
+
+
+class DosxUnavailable(RuntimeError):
+    pass
+
+
+class DosxError(RuntimeError):
+    pass
+
+
+class RowMap(C.Structure):
+    _fields_ = [("d", C.c_int32), ("m", C.c_int32), ("c", C.c_int32), ("off", C.c_int32), ("idx", C.c_void_p)]
+
+
+class Seg(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("ld", C.c_int32), ("width", C.c_int32), ("map", RowMap)]
+
+
+class Gemm(C.Structure):
+    _fields_ = [
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("nseg", C.c_int32),
+        ("a", Seg * 3),
+        ("pro", C.c_int32),
+        ("pro_gamma", C.c_void_p), ("pro_beta", C.c_void_p), ("pro_alpha", C.c_void_p), ("pro_stats", C.c_void_p),
+        ("w", C.c_void_p), ("ldw", C.c_int32), ("w_layout", C.c_int32),
+        ("epi", C.c_int32), ("act", C.c_int32), ("act_slope", C.c_float),
+        ("bias", C.c_void_p),
+        ("out", C.c_void_p), ("ldo", C.c_int32), ("out_map", RowMap),
+        ("res", C.c_void_p), ("ldr", C.c_int32), ("res_map", RowMap),
+        ("stats_out", C.c_void_p), ("aux_out", C.c_void_p),
+        ("aux", C.c_void_p), ("ldaux", C.c_int32),
+        ("aux_stats", C.c_void_p),
+        ("epi_gamma", C.c_void_p), ("epi_beta", C.c_void_p), ("epi_alpha", C.c_void_p),
+        ("partials", C.c_void_p), ("partial_ld", C.c_int32),
+    ]
+
+
+class Wgrad(C.Structure):
+    _fields_ = [
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("dy", Seg),
+        ("nseg", C.c_int32),
+        ("a", Seg * 3),
+        ("pro", C.c_int32),
+        ("pro_gamma", C.c_void_p), ("pro_beta", C.c_void_p), ("pro_alpha", C.c_void_p), ("pro_stats", C.c_void_p),
+        ("slab", C.c_void_p), ("slab_bias", C.c_void_p),
+        ("nsplit", C.c_int32),
+    ]
+
+
+class ReduceJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("nsplit", C.c_int32), ("stride", C.c_int32),
+                ("count", C.c_int32), ("accumulate", C.c_int32)]
+
+
+class Attn(C.Structure):
+    _fields_ = [
+        ("Sq", C.c_int32), ("Bq", C.c_int32), ("Nk", C.c_int32), ("Bk", C.c_int32), ("H", C.c_int32),
+        ("q_stride_s", C.c_int32), ("q_stride_b", C.c_int32),
+        ("x", C.c_void_p), ("kvhat", C.c_void_p), ("gamma0", C.c_void_p), ("beta0", C.c_void_p),
+        ("out", C.c_void_p), ("probs", C.c_void_p), ("qstats", C.c_void_p), ("out_stats", C.c_void_p),
+        ("dout", C.c_void_p), ("dx", C.c_void_p), ("dscores", C.c_void_p), ("dkvhat", C.c_void_p),
+        ("dkv_accumulate", C.c_int32),
+        ("partials_q", C.c_void_p), ("partials_kv", C.c_void_p),
+    ]
+
+
+# name -> argtypes  (restype is int unless listed in _RESTYPES)
+_P, _I, _F, _L, _D = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_double
+_SIGS = {
+    "dosx_gemm_partial_rows": [_I, _I],
+    "dosx_gemm": [C.POINTER(Gemm), _P],
+    "dosx_wgrad_splits": [_I, _I, _I],
+    "dosx_wgrad": [C.POINTER(Wgrad), _P],
+    "dosx_reduce_partials": [_P, _I, _I, _P],
+    "dosx_edge_feat_sh1": [_P, _P, _I, _F, _P],
+    "dosx_segment_reduce": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "dosx_edge_grad_combine": [_P, _P, _I, _P, _P, _P, _I, _I, _P],
+    "dosx_gather_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "dosx_graph_pool": [_P, _P, _P, _I, _I, _I, _P],
+    "dosx_graph_pool_bwd": [_P, _I, _P, _P, _I, _I, _I, _P],
+    "dosx_dense_normalize": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "dosx_dense_normalize_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "dosx_rownorm": [_P, _P, _P, _I, _I, _P],
+    "dosx_rownorm_bwd": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "dosx_layernorm": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "dosx_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "dosx_attention_fwd": [C.POINTER(Attn), _P],
+    "dosx_attention_bwd": [C.POINTER(Attn), _P],
+    "dosx_ln_rowdot": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "dosx_ln_rowdot_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "dosx_rowdot": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "dosx_rowdot_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "dosx_sse2": [_P, _P, _P, _P, _I, _P],
+    "dosx_loss_phonon_bwd": [_P, _P, _P, _P, _F, _D, _P, _P, _P, _I, _P],
+    "dosx_loss_edos": [_P, _P, _P, _F, _I, _I, _I, _P, _P, _P, _P],
+    "dosx_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
+    "dosx_fill": [_P, _F, _L, _P],
+    "dosx_embed_rows": [_P, _P, _P, _I, _I, _P],
+    "dosx_embed_rows_bwd": [_P, _I, _P, _P, _I, _I, _I, _P],
+    "dosx_reduce_rows": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "dosx_act_bwd": [_P, _P, _F, _P, _L, _P],
+    "dosx_last_error": [],
+    "dosx_version": [],
+}
+_RESTYPES = {"dosx_last_error": C.c_char_p}
+EXPORTS = tuple(_SIGS)
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libdosx.so once; raise DosxUnavailable (never fall back) if that is impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DosxUnavailable(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C dostransformer_amd/csrc` (needs hipcc, --offload-arch=gfx950). "
+            f"dostransformer_amd has no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise DosxUnavailable(f"cannot load {LIB_PATH}: {e}") from e
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().dosx_last_error()
+        raise DosxError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")

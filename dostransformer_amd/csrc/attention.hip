@@ -1,0 +1,544 @@
+// Pre-norm energy-vs-atom attention block of the reference encoder layer (gfx950, fp32 MFMA).
+//
+//   x1 = x + softmax_fp32( LN0(x) K^T / sqrt(H) ) K ,   K = V = kvhat * gamma0 + beta0
+//
+// (layers/transformer.py:131-138 + layers/multihead_attention.py:68-74: no q/k/v/out projection,
+//  no mask, no head split; zero-padded atoms are real keys with value beta0 — SURVEY.md §0.2-0.3.)
+// One workgroup (4 waves) owns a 32-query tile of one crystal; the whole key set of a crystal
+// (Nk <= 320: atoms <= Nmax, or the 51/201 energy bins for self attention) lives in LDS, so the
+// softmax is exact (no online rescaling).  QK^T and PV run on v_mfma_f32_32x32x2_f32.
+#include "common.h"
+
+namespace {
+
+constexpr int QT = 32;           // query rows per workgroup
+constexpr int KC = 32;           // k-chunk (features) for QK^T, key-chunk for PV
+constexpr int LDK = KC + 4;      // 36
+constexpr int MAX_KT = 3;        // key tiles (32 keys) per wave in QK^T  -> Nk <= 4*3*32 = 384
+constexpr int MAX_CT = 2;        // output column tiles per wave in PV    -> H  <= 4*2*32 = 256
+
+struct Geo {
+  int HP;    // H rounded up to 32
+  int LDH;   // HP + 4
+  int NKP;   // Nk rounded up to 32
+  int LDS_;  // NKP + 4
+};
+__host__ __device__ inline Geo make_geo(int H, int Nk) {
+  Geo g;
+  g.HP = (H + 31) / 32 * 32;
+  g.LDH = g.HP + 4;
+  g.NKP = (Nk + 31) / 32 * 32;
+  g.LDS_ = g.NKP + 4;
+  return g;
+}
+
+// Load 32 rows x H (float4) of a row-strided matrix into LDS [32][LDH], zero padded.
+// row pointer for tile row i: base + rowoff(i) (nullptr -> zeros).  Optional affine LN on load:
+//   v = (v - mean)*rstd*gamma + beta   (stats == nullptr: plain copy)
+template <class RowPtr>
+__device__ __forceinline__ void load_rows(float* dst, int LDH, int HP, int H, RowPtr rowptr, int tid) {
+  const int row = tid >> 3;
+  const float* p = rowptr(row);
+  for (int c = (tid & 7) * 4; c < HP; c += 32) {
+    float4 v = f4zero();
+    if (p && c < H) v = ld4(p + c);
+    st4(dst + row * LDH + c, v);
+  }
+}
+
+// K chunk for the NT products: Ks[j][0..31] = kvhat[(j*Bk+bk)][kc..kc+31]*gamma+beta, j < Nk else 0
+__device__ __forceinline__ void stage_k_chunk(float* Ks, const float* __restrict__ kvhat, const float* __restrict__ gamma,
+                                              const float* __restrict__ beta, int Nk, int NKP, int Bk, int bk, int H,
+                                              int kc, int tid) {
+  const int kq = (tid & 7) * 4, k = kc + kq;
+  float4 g = f4zero(), b = f4zero();
+  if (k < H) { g = ld4(gamma + k); b = ld4(beta + k); }
+  for (int j = tid >> 3; j < NKP; j += 32) {
+    float4 v = f4zero();
+    if (j < Nk && k < H) {
+      const float4 h = ld4(kvhat + ((size_t)j * Bk + bk) * H + k);
+      v = make_float4(h.x * g.x + b.x, h.y * g.y + b.y, h.z * g.z + b.z, h.w * g.w + b.w);
+    }
+    st4(Ks + j * LDK + kq, v);
+  }
+}
+
+// V chunk for the NN products: Vs[jj][0..HP) = K rows j0..j0+31 (affine), zero beyond Nk / H
+__device__ __forceinline__ void stage_v_chunk(float* Vs, const float* __restrict__ kvhat, const float* __restrict__ gamma,
+                                              const float* __restrict__ beta, int Nk, int Bk, int bk, int H, int HP,
+                                              int LDH, int j0, int tid) {
+  const int jj = tid >> 3, j = j0 + jj;
+  for (int c = (tid & 7) * 4; c < HP; c += 32) {
+    float4 v = f4zero();
+    if (j < Nk && c < H) {
+      const float4 h = ld4(kvhat + ((size_t)j * Bk + bk) * H + c), g = ld4(gamma + c), b = ld4(beta + c);
+      v = make_float4(h.x * g.x + b.x, h.y * g.y + b.y, h.z * g.z + b.z, h.w * g.w + b.w);
+    }
+    st4(Vs + jj * LDH + c, v);
+  }
+}
+
+// S[32][NKP] (+)= A[32][H] . K^T : A tile resident in LDS (As, stride LDH), K streamed in k-chunks.
+__device__ __forceinline__ void qk_product(f32x16 (&acc)[MAX_KT], const float* As, int LDH, float* Ks,
+                                           const float* kvhat, const float* gamma, const float* beta, int Nk, int NKP,
+                                           int Bk, int bk, int H, int HP, int tid) {
+  const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int nkt = NKP / 32;
+#pragma unroll
+  for (int t = 0; t < MAX_KT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  for (int kc = 0; kc < HP; kc += KC) {
+    stage_k_chunk(Ks, kvhat, gamma, beta, Nk, NKP, Bk, bk, H, kc, tid);
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < KC; kk += 8) {
+      const float4 a = ld4(As + l31 * LDH + kc + kk + 4 * hh);
+#pragma unroll
+      for (int t = 0; t < MAX_KT; ++t) {
+        const int jt = wave + 4 * t;
+        if (jt >= nkt) continue;
+        const float4 b = ld4(Ks + (jt * 32 + l31) * LDK + kk + 4 * hh);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// store the QK^T accumulators (times scale) into Ss[32][LDS_]
+__device__ __forceinline__ void store_scores(const f32x16 (&acc)[MAX_KT], float* Ss, int LDS_, int NKP, float scale,
+                                             int tid) {
+  const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int nkt = NKP / 32;
+#pragma unroll
+  for (int t = 0; t < MAX_KT; ++t) {
+    const int jt = wave + 4 * t;
+    if (jt >= nkt) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      Ss[row * LDS_ + jt * 32 + l31] = acc[t][r] * scale;
+    }
+  }
+}
+
+// O[32][HP] = P[32][NKP] . V : P resident in LDS (Ps, stride LDS_), V streamed in 32-key chunks.
+__device__ __forceinline__ void pv_product(f32x16 (&acc)[MAX_CT], const float* Ps, int LDS_, float* Vs,
+                                           const float* kvhat, const float* gamma, const float* beta, int Nk, int NKP,
+                                           int Bk, int bk, int H, int HP, int LDH, int tid) {
+  const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int nct = HP / 32;
+#pragma unroll
+  for (int t = 0; t < MAX_CT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  for (int j0 = 0; j0 < NKP; j0 += KC) {
+    stage_v_chunk(Vs, kvhat, gamma, beta, Nk, Bk, bk, H, HP, LDH, j0, tid);
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < KC; kk += 8) {
+      const float4 a = ld4(Ps + l31 * LDS_ + j0 + kk + 4 * hh);
+#pragma unroll
+      for (int t = 0; t < MAX_CT; ++t) {
+        const int ct = wave + 4 * t;
+        if (ct >= nct) continue;
+        const float* bp = Vs + (kk + 4 * hh) * LDH + ct * 32 + l31;
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bp[0], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bp[LDH], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bp[2 * LDH], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bp[3 * LDH], acc[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ void store_out_tile(const f32x16 (&acc)[MAX_CT], float* Os, int LDH, int HP, int tid) {
+  const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int nct = HP / 32;
+#pragma unroll
+  for (int t = 0; t < MAX_CT; ++t) {
+    const int ct = wave + 4 * t;
+    if (ct >= nct) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      Os[row * LDH + ct * 32 + l31] = acc[t][r];
+    }
+  }
+}
+
+// In-place LayerNorm (affine) of the 32 rows of an LDS tile; wave w owns rows 8w..8w+7.
+// Writes (mean, rstd) to stats[(row)] when the row is valid.
+__device__ __forceinline__ void ln_rows_inplace(float* T, int LDH, int H, const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, float* stats_out, int s0, int Sq,
+                                                int Bq, int bq, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int i = 0; i < 8; ++i) {
+    const int lr = wave * 8 + i;
+    float* row = T + lr * LDH;
+    float s1 = 0.f;
+    for (int c = lane * 4; c < H; c += 256) {
+      const float4 v = ld4(row + c);
+      s1 += v.x + v.y + v.z + v.w;
+    }
+    const float mean = wave_sum(s1) / (float)H;
+    float s2 = 0.f;
+    for (int c = lane * 4; c < H; c += 256) {
+      const float4 v = ld4(row + c);
+      const float a = v.x - mean, b = v.y - mean, c2 = v.z - mean, d = v.w - mean;
+      s2 += a * a + b * b + c2 * c2 + d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(s2) / (float)H + DOSX_LN_EPS);
+    for (int c = lane * 4; c < H; c += 256) {
+      const float4 v = ld4(row + c), g = ld4(gamma + c), b = ld4(beta + c);
+      st4(row + c, make_float4((v.x - mean) * rstd * g.x + b.x, (v.y - mean) * rstd * g.y + b.y,
+                               (v.z - mean) * rstd * g.z + b.z, (v.w - mean) * rstd * g.w + b.w));
+    }
+    const int s = s0 + lr;
+    if (stats_out && lane == 0 && s < Sq) {
+      stats_out[2 * ((size_t)s * Bq + bq)] = mean;
+      stats_out[2 * ((size_t)s * Bq + bq) + 1] = rstd;
+    }
+  }
+}
+
+// ================================== forward =====================================================
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const DosxAttn a) {
+  extern __shared__ __align__(16) float sm[];
+  const Geo g = make_geo(a.H, a.Nk);
+  float* Qs = sm;                                   // [32][LDH]   (later: output tile)
+  float* Ss = Qs + QT * g.LDH;                      // [32][LDS_]
+  float* KV = Ss + QT * g.LDS_;                     // max(NKP*36, 32*LDH)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s0 = blockIdx.x * QT, bq = blockIdx.y, bk = bq % a.Bk;
+  const int H = a.H, Sq = a.Sq, Nk = a.Nk;
+
+  load_rows(Qs, g.LDH, g.HP, H, [&](int i) -> const float* {
+    const int s = s0 + i;
+    return s < Sq ? a.x + ((size_t)s * a.q_stride_s + (size_t)bq * a.q_stride_b) * H : nullptr;
+  }, tid);
+  __syncthreads();
+  ln_rows_inplace(Qs, g.LDH, H, a.gamma0, a.beta0, a.qstats, s0, Sq, a.Bq, bq, tid);
+  __syncthreads();
+
+  f32x16 sacc[MAX_KT];
+  qk_product(sacc, Qs, g.LDH, KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, tid);
+  store_scores(sacc, Ss, g.LDS_, g.NKP, rsqrtf((float)H), tid);
+  __syncthreads();
+
+  // exact fp32 softmax over the Nk keys (padded atoms included, like the reference)
+  for (int i = 0; i < 8; ++i) {
+    const int lr = wave * 8 + i, s = s0 + lr;
+    float* row = Ss + lr * g.LDS_;
+    float mx = -INFINITY;
+    for (int j = lane; j < Nk; j += 64) mx = fmaxf(mx, row[j]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < Nk; j += 64) {
+      const float e = expf(row[j] - mx);
+      row[j] = e;
+      sum += e;
+    }
+    const float inv = 1.f / wave_sum(sum);
+    for (int j = lane; j < g.NKP; j += 64) {
+      const float p = j < Nk ? row[j] * inv : 0.f;
+      row[j] = p;
+      if (j < Nk && s < Sq) a.probs[((size_t)bq * Sq + s) * Nk + j] = p;
+    }
+  }
+  __syncthreads();
+
+  f32x16 oacc[MAX_CT];
+  pv_product(oacc, Ss, g.LDS_, KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, g.LDH, tid);
+  store_out_tile(oacc, Qs, g.LDH, g.HP, tid);
+  __syncthreads();
+
+  // epilogue: residual add, optional statistics of the output rows (feeds the following LN1)
+  for (int i = 0; i < 8; ++i) {
+    const int lr = wave * 8 + i, s = s0 + lr;
+    if (s >= Sq) break;
+    const float* xr = a.x + ((size_t)s * a.q_stride_s + (size_t)bq * a.q_stride_b) * H;
+    float* orow = a.out + ((size_t)s * a.Bq + bq) * H;
+    float s1 = 0.f;
+    for (int c = lane * 4; c < H; c += 256) {
+      const float4 v = f4add(ld4(Qs + lr * g.LDH + c), ld4(xr + c));
+      st4(orow + c, v);
+      st4(Qs + lr * g.LDH + c, v);
+      s1 += v.x + v.y + v.z + v.w;
+    }
+    if (a.out_stats) {
+      const float mean = wave_sum(s1) / (float)H;
+      float s2 = 0.f;
+      for (int c = lane * 4; c < H; c += 256) {
+        const float4 v = ld4(Qs + lr * g.LDH + c);
+        const float p = v.x - mean, q = v.y - mean, r2 = v.z - mean, t = v.w - mean;
+        s2 += p * p + q * q + r2 * r2 + t * t;
+      }
+      const float rstd = rsqrtf(wave_sum(s2) / (float)H + DOSX_LN_EPS);
+      if (lane == 0) {
+        a.out_stats[2 * ((size_t)s * a.Bq + bq)] = mean;
+        a.out_stats[2 * ((size_t)s * a.Bq + bq) + 1] = rstd;
+      }
+    }
+  }
+}
+
+// ================================== backward: dq / dx ============================================
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const DosxAttn a) {
+  extern __shared__ __align__(16) float sm[];
+  const Geo g = make_geo(a.H, a.Nk);
+  float* Ds = sm;                                   // [32][LDH]  dOut tile, later dq tile
+  float* Ps = Ds + QT * g.LDH;                      // [32][LDS_] probabilities
+  float* Ss = Ps + QT * g.LDS_;                     // [32][LDS_] dP -> dS
+  float* KV = Ss + QT * g.LDS_;                     // chunk staging
+  float* Pp = KV + max(g.NKP * LDK, KC * g.LDH);    // [4][2][HP] partial column sums
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s0 = blockIdx.x * QT, bq = blockIdx.y, bk = bq % a.Bk;
+  const int H = a.H, Sq = a.Sq, Nk = a.Nk;
+
+  load_rows(Ds, g.LDH, g.HP, H, [&](int i) -> const float* {
+    const int s = s0 + i;
+    return s < Sq ? a.dout + ((size_t)s * a.Bq + bq) * H : nullptr;
+  }, tid);
+  // probabilities tile (zero padded)
+  for (int i = wave; i < QT; i += 4) {
+    const int s = s0 + i;
+    for (int j = lane; j < g.NKP; j += 64)
+      Ps[i * g.LDS_ + j] = (s < Sq && j < Nk) ? a.probs[((size_t)bq * Sq + s) * Nk + j] : 0.f;
+  }
+  __syncthreads();
+
+  // dP = dO . V^T
+  f32x16 sacc[MAX_KT];
+  qk_product(sacc, Ds, g.LDH, KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, tid);
+  store_scores(sacc, Ss, g.LDS_, g.NKP, 1.f, tid);
+  __syncthreads();
+
+  // dS = P * (dP - rowsum(P*dP)) * scale
+  const float scale = rsqrtf((float)H);
+  for (int i = 0; i < 8; ++i) {
+    const int lr = wave * 8 + i, s = s0 + lr;
+    float* drow = Ss + lr * g.LDS_;
+    const float* prow = Ps + lr * g.LDS_;
+    float dot = 0.f;
+    for (int j = lane; j < Nk; j += 64) dot += prow[j] * drow[j];
+    dot = wave_sum(dot);
+    for (int j = lane; j < g.NKP; j += 64) {
+      const float ds = j < Nk ? prow[j] * (drow[j] - dot) * scale : 0.f;
+      drow[j] = ds;
+      if (j < Nk && s < Sq) a.dscores[((size_t)bq * Sq + s) * Nk + j] = ds;
+    }
+  }
+  __syncthreads();
+
+  // dq_ln = dS . K
+  f32x16 oacc[MAX_CT];
+  pv_product(oacc, Ss, g.LDS_, KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, g.LDH, tid);
+  store_out_tile(oacc, Ds, g.LDH, g.HP, tid);
+  __syncthreads();
+
+  // LN0 backward on the query rows + residual;  partial dgamma0 / dbeta0 (query side)
+  for (int c = lane; c < 2 * g.HP; c += 64) Pp[wave * 2 * g.HP + c] = 0.f;
+  for (int i = 0; i < 8; ++i) {
+    const int lr = wave * 8 + i, s = s0 + lr;
+    if (s >= Sq) break;
+    const float* xr = a.x + ((size_t)s * a.q_stride_s + (size_t)bq * a.q_stride_b) * H;
+    const size_t orow = ((size_t)s * a.Bq + bq);
+    const float mean = a.qstats[2 * orow], rstd = a.qstats[2 * orow + 1];
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane * 4; c < H; c += 256) {
+      const float4 xv = ld4(xr + c), d = ld4(Ds + lr * g.LDH + c), gm = ld4(a.gamma0 + c);
+      const float4 xh = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+      float* pgm = Pp + wave * 2 * g.HP + c;
+      pgm[0] += d.x * xh.x; pgm[1] += d.y * xh.y; pgm[2] += d.z * xh.z; pgm[3] += d.w * xh.w;
+      float* pbt = pgm + g.HP;
+      pbt[0] += d.x; pbt[1] += d.y; pbt[2] += d.z; pbt[3] += d.w;
+      const float4 dh = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
+      s1 += dh.x + dh.y + dh.z + dh.w;
+      s2 += dh.x * xh.x + dh.y * xh.y + dh.z * xh.z + dh.w * xh.w;
+    }
+    const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
+    for (int c = lane * 4; c < H; c += 256) {
+      const float4 xv = ld4(xr + c), d = ld4(Ds + lr * g.LDH + c), gm = ld4(a.gamma0 + c);
+      const float4 go = ld4(a.dout + orow * H + c);
+      const float4 xh = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+      st4(a.dx + orow * H + c,
+          make_float4(go.x + rstd * (d.x * gm.x - m1 - xh.x * m2), go.y + rstd * (d.y * gm.y - m1 - xh.y * m2),
+                      go.z + rstd * (d.z * gm.z - m1 - xh.z * m2), go.w + rstd * (d.w * gm.w - m1 - xh.w * m2)));
+    }
+  }
+  __syncthreads();
+  float* prow = a.partials_q + ((size_t)bq * gridDim.x + blockIdx.x) * 2 * H;
+  for (int c = tid; c < 2 * H; c += 256) {
+    const int which = c / H, col = c % H;
+    const int o = which * g.HP + col;
+    prow[c] = Pp[o] + Pp[2 * g.HP + o] + Pp[4 * g.HP + o] + Pp[6 * g.HP + o];
+  }
+}
+
+// ================================== backward: dk + dv ============================================
+// One workgroup per (32-key tile, crystal): dkv_ln[keys,H] = sum_q P^T dO + dS^T LN0(x) over every
+// query row of every query batch entry that maps to this crystal (bq = bk + i*Bk).
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const DosxAttn a) {
+  extern __shared__ __align__(16) float sm[];
+  const Geo g = make_geo(a.H, a.Nk);
+  float* dOs = sm;                                  // [32 q][LDH]
+  float* Qs = dOs + QT * g.LDH;                     // [32 q][LDH]  (later: result tile)
+  float* Pc = Qs + QT * g.LDH;                      // [32 q][36]   P   chunk (cols = keys of this tile)
+  float* Sc = Pc + QT * LDK;                        // [32 q][36]   dS  chunk
+  float* Pp = Sc + QT * LDK;                        // [4][2][HP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int j0 = blockIdx.x * 32, bk = blockIdx.y;
+  const int H = a.H, Sq = a.Sq, Nk = a.Nk;
+  const int nct = g.HP / 32;
+
+  f32x16 acc[MAX_CT];
+#pragma unroll
+  for (int t = 0; t < MAX_CT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  for (int bq = bk; bq < a.Bq; bq += a.Bk) {
+    for (int s0 = 0; s0 < Sq; s0 += QT) {
+      load_rows(dOs, g.LDH, g.HP, H, [&](int i) -> const float* {
+        const int s = s0 + i;
+        return s < Sq ? a.dout + ((size_t)s * a.Bq + bq) * H : nullptr;
+      }, tid);
+      load_rows(Qs, g.LDH, g.HP, H, [&](int i) -> const float* {
+        const int s = s0 + i;
+        return s < Sq ? a.x + ((size_t)s * a.q_stride_s + (size_t)bq * a.q_stride_b) * H : nullptr;
+      }, tid);
+      {
+        const int i = tid >> 3, s = s0 + i;
+        for (int jj = (tid & 7); jj < 32; jj += 8) {
+          const int j = j0 + jj;
+          const bool ok = (s < Sq) && (j < Nk);
+          const size_t o = ((size_t)bq * Sq + s) * Nk + j;
+          Pc[i * LDK + jj] = ok ? a.probs[o] : 0.f;
+          Sc[i * LDK + jj] = ok ? a.dscores[o] : 0.f;
+        }
+      }
+      __syncthreads();
+      // recompute LN0(x) for the query rows in place (rows beyond Sq are zero rows: their P/dS are 0)
+      for (int i = 0; i < 8; ++i) {
+        const int lr = wave * 8 + i, s = s0 + lr;
+        if (s >= Sq) break;
+        const size_t orow = (size_t)s * a.Bq + bq;
+        const float mean = a.qstats[2 * orow], rstd = a.qstats[2 * orow + 1];
+        float* row = Qs + lr * g.LDH;
+        for (int c = lane * 4; c < H; c += 256) {
+          const float4 v = ld4(row + c), gm = ld4(a.gamma0 + c), bt = ld4(a.beta0 + c);
+          st4(row + c, make_float4((v.x - mean) * rstd * gm.x + bt.x, (v.y - mean) * rstd * gm.y + bt.y,
+                                   (v.z - mean) * rstd * gm.z + bt.z, (v.w - mean) * rstd * gm.w + bt.w));
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int mm = 0; mm < QT; mm += 2) {
+        const float pa = Pc[(mm + hh) * LDK + l31];
+        const float sa = Sc[(mm + hh) * LDK + l31];
+#pragma unroll
+        for (int t = 0; t < MAX_CT; ++t) {
+          const int ct = wave + 4 * t;
+          if (ct >= nct) continue;
+          const float b1 = dOs[(mm + hh) * g.LDH + ct * 32 + l31];
+          const float b2 = Qs[(mm + hh) * g.LDH + ct * 32 + l31];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa, b1, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa, b2, acc[t], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  store_out_tile(acc, Qs, g.LDH, g.HP, tid);
+  for (int c = lane; c < 2 * g.HP; c += 64) Pp[wave * 2 * g.HP + c] = 0.f;
+  __syncthreads();
+  for (int i = 0; i < 8; ++i) {
+    const int lr = wave * 8 + i, j = j0 + lr;
+    if (j >= Nk) break;
+    const size_t krow = ((size_t)j * a.Bk + bk) * H;
+    for (int c = lane * 4; c < H; c += 256) {
+      const float4 d = ld4(Qs + lr * g.LDH + c), xh = ld4(a.kvhat + krow + c), gm = ld4(a.gamma0 + c);
+      float* pgm = Pp + wave * 2 * g.HP + c;
+      pgm[0] += d.x * xh.x; pgm[1] += d.y * xh.y; pgm[2] += d.z * xh.z; pgm[3] += d.w * xh.w;
+      float* pbt = pgm + g.HP;
+      pbt[0] += d.x; pbt[1] += d.y; pbt[2] += d.z; pbt[3] += d.w;
+      float4 o = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
+      if (a.dkv_accumulate) o = f4add(o, ld4(a.dkvhat + krow + c));
+      st4(a.dkvhat + krow + c, o);
+    }
+  }
+  __syncthreads();
+  float* prow = a.partials_kv + ((size_t)bk * gridDim.x + blockIdx.x) * 2 * H;
+  for (int c = tid; c < 2 * H; c += 256) {
+    const int which = c / H, col = c % H;
+    const int o = which * g.HP + col;
+    prow[c] = Pp[o] + Pp[2 * g.HP + o] + Pp[4 * g.HP + o] + Pp[6 * g.HP + o];
+  }
+}
+
+size_t fwd_smem(const Geo& g) {
+  return sizeof(float) * (size_t)(QT * g.LDH + QT * g.LDS_ + max(g.NKP * LDK, KC * g.LDH));
+}
+size_t dq_smem(const Geo& g) {
+  return sizeof(float) * (size_t)(QT * g.LDH + 2 * QT * g.LDS_ + max(g.NKP * LDK, KC * g.LDH) + 8 * g.HP);
+}
+size_t dkv_smem(const Geo& g) { return sizeof(float) * (size_t)(2 * QT * g.LDH + 2 * QT * LDK + 8 * g.HP); }
+
+int check_attn(const DosxAttn& a, const char* who) {
+  DOSX_CHECK_ARG(a.H > 0 && (a.H & 3) == 0 && a.H <= 32 * 4 * MAX_CT, "%s: H=%d unsupported (multiple of 4, <= 256)", who, a.H);
+  DOSX_CHECK_ARG(a.Nk > 0 && a.Nk <= 320, "%s: Nk=%d unsupported (1..320 keys per crystal)", who, a.Nk);
+  DOSX_CHECK_ARG(a.Sq > 0 && a.Bq > 0 && a.Bk > 0 && a.Bq % a.Bk == 0, "%s: bad Sq/Bq/Bk = %d/%d/%d", who, a.Sq, a.Bq, a.Bk);
+  DOSX_CHECK_ARG(a.x && a.kvhat && a.gamma0 && a.beta0 && a.probs && a.qstats, "%s: null operand", who);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int dosx_attention_fwd(const DosxAttn* ap, dosx_stream_t stream) {
+  DOSX_CHECK_ARG(ap, "dosx_attention_fwd: null");
+  const DosxAttn& a = *ap;
+  if (int rc = check_attn(a, "dosx_attention_fwd")) return rc;
+  DOSX_CHECK_ARG(a.out, "dosx_attention_fwd: null out");
+  const Geo g = make_geo(a.H, a.Nk);
+  const size_t smem = fwd_smem(g);
+  DOSX_CHECK_ARG(smem <= 160 * 1024, "dosx_attention_fwd: LDS need %zu > 160 KiB", smem);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(ceil_div(a.Sq, QT), a.Bq), dim3(256), smem, to_stream(stream), a);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_attention_bwd(const DosxAttn* ap, dosx_stream_t stream) {
+  DOSX_CHECK_ARG(ap, "dosx_attention_bwd: null");
+  const DosxAttn& a = *ap;
+  if (int rc = check_attn(a, "dosx_attention_bwd")) return rc;
+  DOSX_CHECK_ARG(a.dout && a.dx && a.dscores && a.dkvhat && a.partials_q && a.partials_kv, "dosx_attention_bwd: null operand");
+  const Geo g = make_geo(a.H, a.Nk);
+  const size_t s1 = dq_smem(g), s2 = dkv_smem(g);
+  DOSX_CHECK_ARG(s1 <= 160 * 1024 && s2 <= 160 * 1024, "dosx_attention_bwd: LDS need %zu/%zu > 160 KiB", s1, s2);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(ceil_div(a.Sq, QT), a.Bq), dim3(256), s1, to_stream(stream), a);
+  DOSX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(ceil_div(a.Nk, 32), a.Bk), dim3(256), s2, to_stream(stream), a);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}

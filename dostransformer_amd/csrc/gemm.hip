@@ -1,0 +1,684 @@
+// fp32 MFMA GEMM family for the DOSTransformer hot path (gfx950).
+//
+//   dosx_gemm   : C[M,N] = epilogue( prologue(A)[M,K] . B )       (nn.Linear fwd / dgrad)
+//   dosx_wgrad  : slab[s][N,K] = dY[ms:me]^T . prologue(A)[ms:me]  (nn.Linear wgrad, split over M)
+//   dosx_reduce_partials : deterministic sum of the split slabs
+//
+// One workgroup = 4 waves (one per SIMD); v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma
+// chain) so results track an fp32 torch reference to rounding.  A is gathered / concatenated /
+// normalised on the fly while it is staged into LDS, so torch.cat([x[row], x[col], e]) and the
+// LayerNorm/PReLU between the two Linear layers of every MLP never exist in HBM.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 32;
+constexpr int BK = 32;
+constexpr int LDA = BK + 4;  // 36 floats: 16-B aligned rows, conflict-free ds_read_b128
+
+struct GemmLaunch {
+  DosxGemm g;
+  int vecA;
+  int vecW;
+};
+
+__device__ __forceinline__ float prelu_f(float v, float a) { return v >= 0.f ? v : a * v; }
+
+// ---- A-operand staging: this thread owns row `arow` of the tile and 4 consecutive k ----------
+struct AState {
+  const float* rp[3];
+  int w0, w01;
+  float mean, rstd, alpha;
+  bool ok;
+};
+
+__device__ __forceinline__ void a_state_init(AState& st, const DosxSeg* segs, int nseg, int pro,
+                                              const float* pro_stats, const float* pro_alpha, int gm,
+                                              bool ok) {
+  st.ok = ok;
+  st.rp[0] = st.rp[1] = st.rp[2] = nullptr;
+  if (ok) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+      if (s < nseg) st.rp[s] = segs[s].p + (size_t)dosx_map_row(segs[s].map, gm) * (size_t)segs[s].ld;
+  }
+  st.w0 = segs[0].width;
+  st.w01 = nseg > 1 ? st.w0 + segs[1].width : 0x7fffffff;
+  if (nseg == 1) st.w0 = 0x7fffffff;
+  st.mean = 0.f;
+  st.rstd = 0.f;
+  st.alpha = 0.f;
+  if (pro == DOSX_PRO_ROWLN && ok) {
+    st.mean = pro_stats[2 * (size_t)gm];
+    st.rstd = pro_stats[2 * (size_t)gm + 1];
+  }
+  if (pro == DOSX_PRO_PRELU || pro == DOSX_PRO_LN_PRELU) st.alpha = *pro_alpha;
+}
+
+__device__ __forceinline__ float a_xform1(const AState& st, int pro, float v, int k, const float* gamma,
+                                          const float* beta) {
+  if (pro == DOSX_PRO_PRELU) return prelu_f(v, st.alpha);
+  if (pro == DOSX_PRO_LN_PRELU) return prelu_f(v * gamma[k] + beta[k], st.alpha);
+  if (pro == DOSX_PRO_ROWLN) return (v - st.mean) * st.rstd * gamma[k] + beta[k];
+  return v;
+}
+
+__device__ __forceinline__ float4 a_load4(const AState& st, int pro, int k, int K, int vec, const float* gamma,
+                                          const float* beta) {
+  float4 v = f4zero();
+  if (!st.ok || k >= K) return v;
+  if (vec) {
+    const float* p;
+    if (k < st.w0) p = st.rp[0] + k;
+    else if (k < st.w01) p = st.rp[1] + (k - st.w0);
+    else p = st.rp[2] + (k - st.w01);
+    v = ld4(p);
+    if (pro == DOSX_PRO_PRELU) {
+      v.x = prelu_f(v.x, st.alpha); v.y = prelu_f(v.y, st.alpha);
+      v.z = prelu_f(v.z, st.alpha); v.w = prelu_f(v.w, st.alpha);
+    } else if (pro == DOSX_PRO_LN_PRELU) {
+      float4 g = ld4(gamma + k), b = ld4(beta + k);
+      v.x = prelu_f(v.x * g.x + b.x, st.alpha); v.y = prelu_f(v.y * g.y + b.y, st.alpha);
+      v.z = prelu_f(v.z * g.z + b.z, st.alpha); v.w = prelu_f(v.w * g.w + b.w, st.alpha);
+    } else if (pro == DOSX_PRO_ROWLN) {
+      float4 g = ld4(gamma + k), b = ld4(beta + k);
+      v.x = (v.x - st.mean) * st.rstd * g.x + b.x; v.y = (v.y - st.mean) * st.rstd * g.y + b.y;
+      v.z = (v.z - st.mean) * st.rstd * g.z + b.z; v.w = (v.w - st.mean) * st.rstd * g.w + b.w;
+    }
+  } else {
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int kk = k + i;
+      if (kk < K) {
+        float x;
+        if (kk < st.w0) x = st.rp[0][kk];
+        else if (kk < st.w01) x = st.rp[1][kk - st.w0];
+        else x = st.rp[2][kk - st.w01];
+        t[i] = a_xform1(st, pro, x, kk, gamma, beta);
+      }
+    }
+    v = make_float4(t[0], t[1], t[2], t[3]);
+  }
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// C = prologue(A) . B  with fused row-wise epilogues.   NTW = 32-wide MFMA tiles per wave,
+// BN = 128*NTW columns per workgroup.  WL: 0 = W[N,K] (k-contiguous), 1 = W[K,N] (n-contiguous).
+// ---------------------------------------------------------------------------------------------
+template <int NTW, int WL>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmLaunch L) {
+  const DosxGemm& g = L.g;
+  constexpr int BN = 128 * NTW;
+  constexpr int LDWT = (WL == 0) ? (BK + 4) : (BN + 4);
+  constexpr int WROWS = (WL == 0) ? BN : BK;
+  constexpr int LDC = BN + 4;
+  constexpr int STAGE = BM * LDA + WROWS * LDWT;
+  constexpr int CTILE = BM * LDC;
+  constexpr int MAINF = STAGE > CTILE ? STAGE : CTILE;
+  constexpr int CG = (BN + 255) / 256;   // float4 column groups per lane in the row-wise epilogue
+  constexpr int NW4 = BN / 32;           // float4 W loads per thread per k-chunk
+
+  extern __shared__ __align__(16) float smem[];
+  float* As = smem;
+  float* Ws = smem + BM * LDA;
+  float* Cs = smem;
+  float* Ps = smem + MAINF;              // [4][2][BN] + 4
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int M = g.M, N = g.N, K = g.K;
+
+  // ---- staging setup ----
+  const int arow = tid >> 3, akq = (tid & 7) * 4;
+  AState ast;
+  a_state_init(ast, g.a, g.nseg, g.pro, g.pro_stats, g.pro_alpha, m0 + arow, (m0 + arow) < M);
+
+  auto loadW = [&](int k0, float4(&wr)[NW4]) {
+#pragma unroll
+    for (int i = 0; i < NW4; ++i) {
+      float4 v = f4zero();
+      if (WL == 0) {
+        const int n = n0 + (tid >> 3) + 32 * i, k = k0 + (tid & 7) * 4;
+        if (n < N && k < K) {
+          const float* p = g.w + (size_t)n * g.ldw + k;
+          if (L.vecW) v = ld4(p);
+          else {
+            v.x = p[0];
+            if (k + 1 < K) v.y = p[1];
+            if (k + 2 < K) v.z = p[2];
+            if (k + 3 < K) v.w = p[3];
+          }
+        }
+      } else {
+        const int lin = tid + 256 * i;
+        const int r = lin / (BN / 4), c4 = (lin % (BN / 4)) * 4;
+        const int k = k0 + r, n = n0 + c4;
+        if (k < K && n < N) {
+          const float* p = g.w + (size_t)k * g.ldw + n;
+          if (L.vecW) v = ld4(p);
+          else {
+            v.x = p[0];
+            if (n + 1 < N) v.y = p[1];
+            if (n + 2 < N) v.z = p[2];
+            if (n + 3 < N) v.w = p[3];
+          }
+        }
+      }
+      wr[i] = v;
+    }
+  };
+  auto storeW = [&](const float4(&wr)[NW4]) {
+#pragma unroll
+    for (int i = 0; i < NW4; ++i) {
+      if (WL == 0) {
+        st4(&Ws[((tid >> 3) + 32 * i) * LDWT + (tid & 7) * 4], wr[i]);
+      } else {
+        const int lin = tid + 256 * i;
+        st4(&Ws[(lin / (BN / 4)) * LDWT + (lin % (BN / 4)) * 4], wr[i]);
+      }
+    }
+  };
+
+  f32x16 acc[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  bool tile_on[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) tile_on[t] = (n0 + (wave * NTW + t) * 32) < N;
+
+  const int nk = (K + BK - 1) / BK;
+  float4 areg = a_load4(ast, g.pro, akq, K, L.vecA, g.pro_gamma, g.pro_beta);
+  float4 wreg[NW4];
+  loadW(0, wreg);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    st4(&As[arow * LDA + akq], areg);
+    storeW(wreg);
+    __syncthreads();
+    if (kt + 1 < nk) {
+      areg = a_load4(ast, g.pro, (kt + 1) * BK + akq, K, L.vecA, g.pro_gamma, g.pro_beta);
+      loadW((kt + 1) * BK, wreg);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 8) {
+      const float4 a = ld4(&As[l31 * LDA + kk + 4 * hh]);
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        if (!tile_on[t]) continue;
+        const int col = (wave * NTW + t) * 32 + l31;
+        if (WL == 0) {
+          const float4 b = ld4(&Ws[col * LDWT + kk + 4 * hh]);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+        } else {
+          const float* bp = &Ws[(kk + 4 * hh) * LDWT + col];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bp[0], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bp[LDWT], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bp[2 * LDWT], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bp[3 * LDWT], acc[t], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- accumulators -> LDS C tile (aliases the staging buffers; loop ended with a barrier) ----
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    const int col = (wave * NTW + t) * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      Cs[row * LDC + col] = acc[t][r];
+    }
+  }
+  __syncthreads();
+
+  // ---- row-wise epilogue: wave w owns rows 8w..8w+7, lanes sweep the columns as float4 --------
+  const int ncols = min(BN, N - n0);
+  const float invN = 1.f / (float)N;
+  const int epi = g.epi;
+  float4 pg[CG], pb[CG];   // column partial sums (dgamma, dbeta)
+  float pal = 0.f;         // dalpha partial
+#pragma unroll
+  for (int j = 0; j < CG; ++j) { pg[j] = f4zero(); pb[j] = f4zero(); }
+  float e_alpha = 0.f;
+  if (epi == DOSX_EPI_PRELU_LN_BWD || epi == DOSX_EPI_PRELU_BWD) e_alpha = *g.epi_alpha;
+
+  for (int i = 0; i < 8; ++i) {
+    const int lr = wave * 8 + i, r = m0 + lr;
+    if (r >= M) break;
+    float4 v[CG];
+    bool on[CG];
+#pragma unroll
+    for (int j = 0; j < CG; ++j) {
+      const int c = lane * 4 + 256 * j;
+      on[j] = c < ncols;
+      v[j] = on[j] ? ld4(&Cs[lr * LDC + c]) : f4zero();
+    }
+    if (epi == DOSX_EPI_BIAS_ACT) {
+      const size_t orow = (size_t)dosx_map_row(g.out_map, r) * g.ldo;
+      const size_t rrow = g.res ? (size_t)dosx_map_row(g.res_map, r) * g.ldr : 0;
+      float s1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < CG; ++j) {
+        if (!on[j]) continue;
+        const int c = n0 + lane * 4 + 256 * j;
+        if (g.bias) v[j] = f4add(v[j], ld4(g.bias + c));
+        if (g.act == 1) {
+          v[j].x = fmaxf(v[j].x, 0.f); v[j].y = fmaxf(v[j].y, 0.f);
+          v[j].z = fmaxf(v[j].z, 0.f); v[j].w = fmaxf(v[j].w, 0.f);
+        } else if (g.act == 2) {
+          const float sl = g.act_slope;
+          v[j].x = v[j].x >= 0.f ? v[j].x : sl * v[j].x; v[j].y = v[j].y >= 0.f ? v[j].y : sl * v[j].y;
+          v[j].z = v[j].z >= 0.f ? v[j].z : sl * v[j].z; v[j].w = v[j].w >= 0.f ? v[j].w : sl * v[j].w;
+        }
+        if (g.res) v[j] = f4add(v[j], ld4(g.res + rrow + c));
+        st4(g.out + orow + c, v[j]);
+        s1 += v[j].x + v[j].y + v[j].z + v[j].w;
+      }
+      if (g.stats_out) {
+        const float mean = wave_sum(s1) * invN;
+        float s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < CG; ++j) {
+          if (!on[j]) continue;
+          const float a = v[j].x - mean, b = v[j].y - mean, c2 = v[j].z - mean, d = v[j].w - mean;
+          s2 += a * a + b * b + c2 * c2 + d * d;
+        }
+        const float var = wave_sum(s2) * invN;
+        if (lane == 0) {
+          g.stats_out[2 * (size_t)r] = mean;
+          g.stats_out[2 * (size_t)r + 1] = rsqrtf(var + DOSX_LN_EPS);
+        }
+      }
+    } else if (epi == DOSX_EPI_LN) {
+      float s1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < CG; ++j) {
+        if (!on[j]) continue;
+        const int c = n0 + lane * 4 + 256 * j;
+        if (g.bias) v[j] = f4add(v[j], ld4(g.bias + c));
+        s1 += v[j].x + v[j].y + v[j].z + v[j].w;
+      }
+      const float mean = wave_sum(s1) * invN;
+      float s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < CG; ++j) {
+        if (!on[j]) continue;
+        v[j].x -= mean; v[j].y -= mean; v[j].z -= mean; v[j].w -= mean;
+        s2 += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
+      }
+      const float rstd = rsqrtf(wave_sum(s2) * invN + DOSX_LN_EPS);
+      const size_t orow = (size_t)r * g.ldo;
+#pragma unroll
+      for (int j = 0; j < CG; ++j) {
+        if (!on[j]) continue;
+        const int c = n0 + lane * 4 + 256 * j;
+        st4(g.out + orow + c, make_float4(v[j].x * rstd, v[j].y * rstd, v[j].z * rstd, v[j].w * rstd));
+      }
+      if (lane == 0) g.aux_out[r] = rstd;
+    } else if (epi == DOSX_EPI_RELU_MASK) {
+      const size_t orow = (size_t)r * g.ldo, arow_ = (size_t)r * g.ldaux;
+#pragma unroll
+      for (int j = 0; j < CG; ++j) {
+        if (!on[j]) continue;
+        const int c = n0 + lane * 4 + 256 * j;
+        const float4 h = ld4(g.aux + arow_ + c);
+        st4(g.out + orow + c, make_float4(h.x > 0.f ? v[j].x : 0.f, h.y > 0.f ? v[j].y : 0.f,
+                                          h.z > 0.f ? v[j].z : 0.f, h.w > 0.f ? v[j].w : 0.f));
+      }
+    } else if (epi == DOSX_EPI_PRELU_BWD) {
+      const size_t orow = (size_t)r * g.ldo, arow_ = (size_t)r * g.ldaux;
+#pragma unroll
+      for (int j = 0; j < CG; ++j) {
+        if (!on[j]) continue;
+        const int c = n0 + lane * 4 + 256 * j;
+        const float4 z = ld4(g.aux + arow_ + c);
+        float4 o;
+        o.x = z.x >= 0.f ? v[j].x : e_alpha * v[j].x; if (z.x < 0.f) pal += v[j].x * z.x;
+        o.y = z.y >= 0.f ? v[j].y : e_alpha * v[j].y; if (z.y < 0.f) pal += v[j].y * z.y;
+        o.z = z.z >= 0.f ? v[j].z : e_alpha * v[j].z; if (z.z < 0.f) pal += v[j].z * z.z;
+        o.w = z.w >= 0.f ? v[j].w : e_alpha * v[j].w; if (z.w < 0.f) pal += v[j].w * z.w;
+        st4(g.out + orow + c, o);
+      }
+    } else {  // DOSX_EPI_PRELU_LN_BWD or DOSX_EPI_ROWLN_BWD : LayerNorm backward over the full row
+      const bool is_prelu = (epi == DOSX_EPI_PRELU_LN_BWD);
+      float mean = 0.f, rstd;
+      if (is_prelu) rstd = g.aux_stats[r];
+      else { mean = g.aux_stats[2 * (size_t)r]; rstd = g.aux_stats[2 * (size_t)r + 1]; }
+      const size_t arow_ = (size_t)r * g.ldaux;
+      float4 xh[CG], dxh[CG];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < CG; ++j) {
+        xh[j] = f4zero(); dxh[j] = f4zero();
+        if (!on[j]) continue;
+        const int c = n0 + lane * 4 + 256 * j;
+        float4 a = ld4(g.aux + arow_ + c);
+        const float4 gm = ld4(g.epi_gamma + c);
+        float4 dy = v[j];
+        if (is_prelu) {
+          const float4 bt = ld4(g.epi_beta + c);
+          const float y0 = a.x * gm.x + bt.x, y1 = a.y * gm.y + bt.y, y2 = a.z * gm.z + bt.z,
+                      y3 = a.w * gm.w + bt.w;
+          if (y0 < 0.f) { pal += dy.x * y0; dy.x *= e_alpha; }
+          if (y1 < 0.f) { pal += dy.y * y1; dy.y *= e_alpha; }
+          if (y2 < 0.f) { pal += dy.z * y2; dy.z *= e_alpha; }
+          if (y3 < 0.f) { pal += dy.w * y3; dy.w *= e_alpha; }
+        } else {
+          a.x = (a.x - mean) * rstd; a.y = (a.y - mean) * rstd;
+          a.z = (a.z - mean) * rstd; a.w = (a.w - mean) * rstd;
+        }
+        xh[j] = a;
+        pg[j].x += dy.x * a.x; pg[j].y += dy.y * a.y; pg[j].z += dy.z * a.z; pg[j].w += dy.w * a.w;
+        pb[j] = f4add(pb[j], dy);
+        dxh[j] = make_float4(dy.x * gm.x, dy.y * gm.y, dy.z * gm.z, dy.w * gm.w);
+        s1 += dxh[j].x + dxh[j].y + dxh[j].z + dxh[j].w;
+        s2 += dxh[j].x * a.x + dxh[j].y * a.y + dxh[j].z * a.z + dxh[j].w * a.w;
+      }
+      const float m1 = wave_sum(s1) * invN, m2 = wave_sum(s2) * invN;
+      const size_t orow = (size_t)r * g.ldo;
+      const size_t rrow = g.res ? (size_t)dosx_map_row(g.res_map, r) * g.ldr : 0;
+#pragma unroll
+      for (int j = 0; j < CG; ++j) {
+        if (!on[j]) continue;
+        const int c = n0 + lane * 4 + 256 * j;
+        float4 o = make_float4(rstd * (dxh[j].x - m1 - xh[j].x * m2), rstd * (dxh[j].y - m1 - xh[j].y * m2),
+                               rstd * (dxh[j].z - m1 - xh[j].z * m2), rstd * (dxh[j].w - m1 - xh[j].w * m2));
+        if (g.res) o = f4add(o, ld4(g.res + rrow + c));
+        st4(g.out + orow + c, o);
+      }
+    }
+  }
+
+  // ---- per-workgroup partial sums for the parameter gradients of the fused LN / PReLU ----------
+  if (g.partials && (epi == DOSX_EPI_PRELU_LN_BWD || epi == DOSX_EPI_ROWLN_BWD || epi == DOSX_EPI_PRELU_BWD)) {
+    float* prow = g.partials + (size_t)(blockIdx.x * gridDim.y + blockIdx.y) * g.partial_ld;
+    if (epi != DOSX_EPI_PRELU_BWD) {
+#pragma unroll
+      for (int j = 0; j < CG; ++j) {
+        const int c = lane * 4 + 256 * j;
+        if (c < BN) {
+          st4(&Ps[(wave * 2 + 0) * BN + c], pg[j]);
+          st4(&Ps[(wave * 2 + 1) * BN + c], pb[j]);
+        }
+      }
+    }
+    if (epi != DOSX_EPI_ROWLN_BWD) {
+      const float s = wave_sum(pal);
+      if (lane == 0) Ps[8 * BN + wave] = s;
+    }
+    __syncthreads();
+    if (epi != DOSX_EPI_PRELU_BWD) {
+      for (int c = tid; c < 2 * BN; c += 256) {
+        const int which = c / BN, col = c % BN;
+        if (col < ncols) {
+          const float s = Ps[(0 * 2 + which) * BN + col] + Ps[(1 * 2 + which) * BN + col] +
+                          Ps[(2 * 2 + which) * BN + col] + Ps[(3 * 2 + which) * BN + col];
+          prow[which * N + n0 + col] = s;
+        }
+      }
+    }
+    if (epi != DOSX_EPI_ROWLN_BWD && tid == 0)
+      prow[g.partial_ld - 1] = Ps[8 * BN] + Ps[8 * BN + 1] + Ps[8 * BN + 2] + Ps[8 * BN + 3];
+  }
+}
+
+template <int NTW, int WL>
+constexpr size_t gemm_smem_bytes() {
+  constexpr int BN = 128 * NTW;
+  constexpr int LDWT = (WL == 0) ? (BK + 4) : (BN + 4);
+  constexpr int WROWS = (WL == 0) ? BN : BK;
+  constexpr int STAGE = BM * LDA + WROWS * LDWT;
+  constexpr int CTILE = BM * (BN + 4);
+  constexpr int MAINF = STAGE > CTILE ? STAGE : CTILE;
+  return (size_t)(MAINF + 8 * BN + 4) * sizeof(float);
+}
+
+template <int NTW, int WL>
+int launch_gemm(const GemmLaunch& L, hipStream_t s) {
+  constexpr int BN = 128 * NTW;
+  dim3 grid(ceil_div(L.g.M, BM), ceil_div(L.g.N, BN));
+  constexpr size_t smem = gemm_smem_bytes<NTW, WL>();
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<NTW, WL>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_kernel<NTW, WL>), grid, dim3(256), smem, s, L);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int seg_vec_ok(const DosxSeg* segs, int nseg) {
+  for (int i = 0; i < nseg; ++i)
+    if ((segs[i].ld & 3) || (segs[i].width & 3) || !aligned16(segs[i].p)) return 0;
+  return 1;
+}
+
+int gemm_bn(int N, int epi) {
+  const bool full_row = (epi == DOSX_EPI_LN || epi == DOSX_EPI_PRELU_LN_BWD || epi == DOSX_EPI_ROWLN_BWD);
+  if (full_row) return N <= 128 ? 128 : (N <= 256 ? 256 : 512);
+  return 128;
+}
+
+}  // namespace
+
+extern "C" int dosx_gemm_partial_rows(int M, int N) {
+  // row-wise epilogues use one N tile (N <= 512); the element-wise PRELU_BWD epilogue tiles N by 128.
+  // Callers size their partial buffers with this upper bound for either case.
+  return ceil_div(M, BM) * ceil_div(N, 128);
+}
+
+extern "C" int dosx_gemm(const DosxGemm* gp, dosx_stream_t stream) {
+  DOSX_CHECK_ARG(gp != nullptr, "dosx_gemm: null descriptor");
+  const DosxGemm& g = *gp;
+  if (g.M <= 0 || g.N <= 0) return 0;
+  DOSX_CHECK_ARG(g.K > 0, "dosx_gemm: K=%d", g.K);
+  DOSX_CHECK_ARG(g.nseg >= 1 && g.nseg <= 3, "dosx_gemm: nseg=%d", g.nseg);
+  int ksum = 0;
+  for (int i = 0; i < g.nseg; ++i) {
+    DOSX_CHECK_ARG(g.a[i].p && g.a[i].width > 0 && g.a[i].map.d > 0, "dosx_gemm: bad segment %d", i);
+    ksum += g.a[i].width;
+  }
+  DOSX_CHECK_ARG(ksum == g.K, "dosx_gemm: segment widths sum to %d, K=%d", ksum, g.K);
+  DOSX_CHECK_ARG((g.N & 3) == 0 && (g.ldo & 3) == 0 && aligned16(g.out), "dosx_gemm: N/ldo/out must be 4-float aligned");
+  DOSX_CHECK_ARG(g.w && g.out, "dosx_gemm: null w/out");
+  const bool full_row = (g.epi == DOSX_EPI_LN || g.epi == DOSX_EPI_PRELU_LN_BWD || g.epi == DOSX_EPI_ROWLN_BWD);
+  DOSX_CHECK_ARG(!full_row || g.N <= 512, "dosx_gemm: row-wise epilogue needs N <= 512 (hidden <= 256), got %d", g.N);
+  DOSX_CHECK_ARG(!g.stats_out || g.N <= 128 * 4, "dosx_gemm: stats_out needs N <= 512");
+  DOSX_CHECK_ARG(g.out_map.d > 0, "dosx_gemm: out_map.d must be > 0");
+  if (g.res) DOSX_CHECK_ARG(g.res_map.d > 0 && (g.ldr & 3) == 0 && aligned16(g.res), "dosx_gemm: bad residual");
+  if (g.pro == DOSX_PRO_LN_PRELU || g.pro == DOSX_PRO_ROWLN)
+    DOSX_CHECK_ARG(g.pro_gamma && g.pro_beta, "dosx_gemm: prologue needs gamma/beta");
+  if (g.pro == DOSX_PRO_ROWLN) DOSX_CHECK_ARG(g.pro_stats, "dosx_gemm: ROWLN prologue needs stats");
+  if (g.pro == DOSX_PRO_PRELU || g.pro == DOSX_PRO_LN_PRELU) DOSX_CHECK_ARG(g.pro_alpha, "dosx_gemm: prologue needs alpha");
+  if (g.epi == DOSX_EPI_LN) DOSX_CHECK_ARG(g.aux_out, "dosx_gemm: EPI_LN needs aux_out (rstd)");
+  if (g.epi == DOSX_EPI_PRELU_LN_BWD)
+    DOSX_CHECK_ARG(g.aux && g.aux_stats && g.epi_gamma && g.epi_beta && g.epi_alpha && (g.ldaux & 3) == 0,
+                   "dosx_gemm: PRELU_LN_BWD needs aux/aux_stats/gamma/beta/alpha");
+  if (g.epi == DOSX_EPI_ROWLN_BWD)
+    DOSX_CHECK_ARG(g.aux && g.aux_stats && g.epi_gamma && (g.ldaux & 3) == 0, "dosx_gemm: ROWLN_BWD needs aux/aux_stats/gamma");
+  if (g.epi == DOSX_EPI_RELU_MASK) DOSX_CHECK_ARG(g.aux && (g.ldaux & 3) == 0, "dosx_gemm: RELU_MASK needs aux");
+  if (g.epi == DOSX_EPI_PRELU_BWD) DOSX_CHECK_ARG(g.aux && g.epi_alpha && (g.ldaux & 3) == 0, "dosx_gemm: PRELU_BWD needs aux/alpha");
+
+  GemmLaunch L;
+  L.g = g;
+  L.vecA = seg_vec_ok(g.a, g.nseg) && (g.K & 3) == 0;
+  if (g.pro == DOSX_PRO_LN_PRELU || g.pro == DOSX_PRO_ROWLN)
+    L.vecA = L.vecA && aligned16(g.pro_gamma) && aligned16(g.pro_beta);
+  L.vecW = ((g.ldw & 3) == 0) && aligned16(g.w) && (g.w_layout == 0 ? (g.K & 3) == 0 : (g.N & 3) == 0);
+  int bn = gemm_bn(g.N, g.epi);
+  if (g.stats_out && bn < g.N) bn = g.N <= 256 ? 256 : 512;
+  hipStream_t s = to_stream(stream);
+  if (g.w_layout == 0) {
+    if (bn == 128) return launch_gemm<1, 0>(L, s);
+    if (bn == 256) return launch_gemm<2, 0>(L, s);
+    return launch_gemm<4, 0>(L, s);
+  } else {
+    if (bn == 128) return launch_gemm<1, 1>(L, s);
+    if (bn == 256) return launch_gemm<2, 1>(L, s);
+    return launch_gemm<4, 1>(L, s);
+  }
+}
+
+// =============================================================================================
+// weight gradient: slab[z][n][k] = sum_{m in split z} dY[m][n] * A'[m][k]      (64 x 64 tile / WG)
+// =============================================================================================
+namespace {
+
+constexpr int WT = 64;        // tile edge (n and k)
+constexpr int LDT = WT + 4;   // 68
+
+struct WgradLaunch {
+  DosxWgrad g;
+  int vecA;
+  int vecY;
+};
+
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
+  const DosxWgrad& g = L.g;
+  __shared__ __align__(16) float Ys[BM * LDT];
+  __shared__ __align__(16) float Xs[BM * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int k0 = blockIdx.x * WT, n0 = blockIdx.y * WT, z = blockIdx.z;
+  const int M = g.M, N = g.N, K = g.K;
+  const int chunk = ((M + g.nsplit - 1) / g.nsplit + BM - 1) / BM * BM;
+  const int ms = z * chunk, me = min(M, ms + chunk);
+  const int wn = wave >> 1, wk = wave & 1;
+  const int r = tid >> 3, c4 = (tid & 7) * 4;   // staging: row r, cols c4 and c4+32
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float bsum = 0.f;
+  const bool do_bias = (g.slab_bias != nullptr) && (blockIdx.x == 0);
+
+  float4 y0, y1, x0, x1;
+  auto load = [&](int m) {
+    const int gm = m + r;
+    const bool ok = gm < me;
+    y0 = y1 = f4zero();
+    if (ok) {
+      const float* yp = g.dy.p + (size_t)dosx_map_row(g.dy.map, gm) * g.dy.ld;
+#pragma unroll
+      for (int hseg = 0; hseg < 2; ++hseg) {
+        const int n = n0 + c4 + 32 * hseg;
+        float4 v = f4zero();
+        if (n < N) {
+          if (L.vecY) v = ld4(yp + n);
+          else {
+            v.x = yp[n];
+            if (n + 1 < N) v.y = yp[n + 1];
+            if (n + 2 < N) v.z = yp[n + 2];
+            if (n + 3 < N) v.w = yp[n + 3];
+          }
+        }
+        if (hseg == 0) y0 = v; else y1 = v;
+      }
+    }
+    AState st;
+    a_state_init(st, g.a, g.nseg, g.pro, g.pro_stats, g.pro_alpha, gm, ok);
+    x0 = a_load4(st, g.pro, k0 + c4, K, L.vecA, g.pro_gamma, g.pro_beta);
+    x1 = a_load4(st, g.pro, k0 + c4 + 32, K, L.vecA, g.pro_gamma, g.pro_beta);
+  };
+
+  if (ms < me) load(ms);
+  for (int m = ms; m < me; m += BM) {
+    st4(&Ys[r * LDT + c4], y0);
+    st4(&Ys[r * LDT + c4 + 32], y1);
+    st4(&Xs[r * LDT + c4], x0);
+    st4(&Xs[r * LDT + c4 + 32], x1);
+    __syncthreads();
+    if (m + BM < me) load(m + BM);
+    if (do_bias && tid < WT) {
+#pragma unroll 8
+      for (int rr = 0; rr < BM; ++rr) bsum += Ys[rr * LDT + tid];
+    }
+#pragma unroll
+    for (int mm = 0; mm < BM; mm += 2) {
+      const float a = Ys[(mm + hh) * LDT + wn * 32 + l31];
+      const float b = Xs[(mm + hh) * LDT + wk * 32 + l31];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  float* slab = g.slab + (size_t)z * N * K;
+  const int kcol = k0 + wk * 32 + l31;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int n = n0 + wn * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+    if (n < N && kcol < K) slab[(size_t)n * K + kcol] = acc[i];
+  }
+  if (do_bias && tid < WT && n0 + tid < N) g.slab_bias[(size_t)z * N + n0 + tid] = bsum;
+}
+
+__global__ void reduce_partials_kernel(const DosxReduceJob* jobs) {
+  const DosxReduceJob j = jobs[blockIdx.y];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < j.count; i += gridDim.x * blockDim.x) {
+    float s = 0.f;
+    const float* p = j.src + i;
+    for (int k = 0; k < j.nsplit; ++k) s += p[(size_t)k * j.stride];
+    if (j.accumulate) s += j.dst[i];
+    j.dst[i] = s;
+  }
+}
+
+}  // namespace
+
+extern "C" int dosx_wgrad_splits(int M, int N, int K) {
+  if (M <= 0) return 1;
+  const int tiles = ceil_div(N, WT) * ceil_div(K, WT);
+  int s = ceil_div(512, tiles);
+  const int cap = ceil_div(M, 128);
+  if (s > cap) s = cap;
+  if (s > 16) s = 16;
+  if (s < 1) s = 1;
+  return s;
+}
+
+extern "C" int dosx_wgrad(const DosxWgrad* gp, dosx_stream_t stream) {
+  DOSX_CHECK_ARG(gp != nullptr, "dosx_wgrad: null descriptor");
+  const DosxWgrad& g = *gp;
+  DOSX_CHECK_ARG(g.N > 0 && g.K > 0 && g.nsplit >= 1, "dosx_wgrad: bad dims N=%d K=%d nsplit=%d", g.N, g.K, g.nsplit);
+  DOSX_CHECK_ARG(g.nseg >= 1 && g.nseg <= 3 && g.slab && g.dy.p, "dosx_wgrad: bad operands");
+  int ksum = 0;
+  for (int i = 0; i < g.nseg; ++i) {
+    DOSX_CHECK_ARG(g.a[i].p && g.a[i].width > 0 && g.a[i].map.d > 0, "dosx_wgrad: bad segment %d", i);
+    ksum += g.a[i].width;
+  }
+  DOSX_CHECK_ARG(ksum == g.K, "dosx_wgrad: segment widths sum to %d, K=%d", ksum, g.K);
+  DOSX_CHECK_ARG(g.dy.map.d > 0, "dosx_wgrad: dy.map.d must be > 0");
+  WgradLaunch L;
+  L.g = g;
+  L.vecA = seg_vec_ok(g.a, g.nseg) && (g.K & 3) == 0;
+  if (g.pro == DOSX_PRO_LN_PRELU || g.pro == DOSX_PRO_ROWLN)
+    L.vecA = L.vecA && aligned16(g.pro_gamma) && aligned16(g.pro_beta);
+  L.vecY = ((g.dy.ld & 3) == 0) && aligned16(g.dy.p) && (g.N & 3) == 0;
+  dim3 grid(ceil_div(g.K, WT), ceil_div(g.N, WT), g.nsplit);
+  hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, to_stream(stream), L);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_reduce_partials(const DosxReduceJob* jobs_dev, int n_jobs, int max_count, dosx_stream_t stream) {
+  if (n_jobs <= 0) return 0;
+  DOSX_CHECK_ARG(jobs_dev != nullptr && max_count > 0, "dosx_reduce_partials: bad args");
+  int gx = ceil_div(max_count, 256);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, n_jobs), dim3(256), 0, to_stream(stream), jobs_dev);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,514 @@
+// Graph-structured, HBM-bound kernels of the message-passing stack (gfx950).
+//
+// All of them are atomic-free: edges are stored sorted by destination, so the edge->node
+// aggregation (torch_scatter.scatter_mean/sum in the reference) is a contiguous CSR segment
+// reduction, and the gather-backward scatter-adds go through the per-source inverse index.
+// Rows are H floats; `lpr` = min(64, H/4) lanes own one row as float4, so a wave streams
+// 64/lpr rows per step with fully coalesced 16-B accesses.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float smooth_cutoff_f(float x) {
+  // e3nn gate_points_2101.smooth_cutoff: u = 2(x-1); (1 - cos(pi u))/2 ; 0 if u > 0 ; 1 if u < -1
+  const float u = 2.f * (x - 1.f);
+  float y = (1.f - cospif(u)) * 0.5f;
+  if (u > 0.f) y = 0.f;
+  if (u < -1.f) y = 1.f;
+  return y;
+}
+
+__global__ void edge_feat_kernel(const float* __restrict__ vec, float* __restrict__ out, int E, float inv_rmax) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const float x = vec[3 * (size_t)e], y = vec[3 * (size_t)e + 1], z = vec[3 * (size_t)e + 2];
+  const float len = sqrtf(x * x + y * y + z * z);
+  const float inv = 1.f / fmaxf(len, 1e-12f);
+  const float c = smooth_cutoff_f(len * inv_rmax);
+  const float s3 = 1.7320508075688772f * c;
+  st4(out + 4 * (size_t)e, make_float4(c, s3 * x * inv, s3 * y * inv, s3 * z * inv));
+}
+
+// Sub-row layout helper: lane -> (sub-row slot, float4 column)
+struct RowLanes {
+  int lpr;     // lanes per row
+  int rps;     // rows per wave step = 64 / lpr
+  int slot;    // which row of the step this lane serves
+  int c4;      // first column (floats) owned by this lane
+};
+__device__ __forceinline__ RowLanes row_lanes(int H, int lane) {
+  RowLanes r;
+  r.lpr = min(64, H >> 2);
+  r.rps = 64 / r.lpr;
+  r.slot = lane / r.lpr;
+  r.c4 = (lane % r.lpr) * 4;
+  return r;
+}
+// sum the per-slot partial vectors of a wave so that every lane holds the total for its column
+__device__ __forceinline__ float4 slots_sum(float4 v, int lpr) {
+  for (int o = lpr; o < 64; o <<= 1) {
+    v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64);
+    v.z += __shfl_xor(v.z, o, 64); v.w += __shfl_xor(v.w, o, 64);
+  }
+  return v;
+}
+
+// agg[n] = scale[n] * sum_{e in seg(n)} msg[e] ; e_out[e] = e_in[e] + msg[e].  One wave per node.
+__global__ __launch_bounds__(256) void segment_reduce_kernel(const float* __restrict__ msg,
+                                                             const int* __restrict__ rowptr,
+                                                             const float* __restrict__ scale,
+                                                             float* __restrict__ agg,
+                                                             const float* e_in, float* e_out, int N,
+                                                             int H) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const RowLanes rl = row_lanes(H, lane);
+  const int beg = rowptr[n], end = rowptr[n + 1];
+  for (int cb = 0; cb < H; cb += 256) {           // column blocks (H > 256 only loops)
+    const int c = cb + rl.c4;
+    float4 acc = f4zero();
+    if (c < H) {
+      int e = beg + rl.slot;
+      // 4 rows in flight per lane
+      for (; e + 3 * rl.rps < end; e += 4 * rl.rps) {
+        const size_t o0 = (size_t)e * H + c, o1 = o0 + (size_t)rl.rps * H, o2 = o1 + (size_t)rl.rps * H,
+                     o3 = o2 + (size_t)rl.rps * H;
+        const float4 m0 = ld4(msg + o0), m1 = ld4(msg + o1), m2 = ld4(msg + o2), m3 = ld4(msg + o3);
+        if (e_out) {
+          const float4 a0 = ld4(e_in + o0), a1 = ld4(e_in + o1), a2 = ld4(e_in + o2), a3 = ld4(e_in + o3);
+          st4(e_out + o0, f4add(a0, m0)); st4(e_out + o1, f4add(a1, m1));
+          st4(e_out + o2, f4add(a2, m2)); st4(e_out + o3, f4add(a3, m3));
+        }
+        acc = f4add(acc, f4add(f4add(m0, m1), f4add(m2, m3)));
+      }
+      for (; e < end; e += rl.rps) {
+        const size_t o0 = (size_t)e * H + c;
+        const float4 m0 = ld4(msg + o0);
+        if (e_out) st4(e_out + o0, f4add(ld4(e_in + o0), m0));
+        acc = f4add(acc, m0);
+      }
+    }
+    acc = slots_sum(acc, rl.lpr);
+    if (c < H && rl.slot == 0) {
+      const float s = scale ? scale[n] : 1.f;
+      st4(agg + (size_t)n * H + c, make_float4(acc.x * s, acc.y * s, acc.z * s, acc.w * s));
+    }
+  }
+}
+
+// dmsg[e] = de_new[e] + scale[dst[e]] * dagg[dst[e]]   (element-wise over E*H/4 float4)
+__global__ void edge_grad_combine_kernel(const float* __restrict__ de_new, const float* __restrict__ dagg,
+                                         int ld_dagg, const int* __restrict__ dst,
+                                         const float* __restrict__ scale, float* __restrict__ dmsg, int E,
+                                         int H) {
+  const int h4 = H >> 2;
+  const size_t total = (size_t)E * h4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int e = (int)(i / h4), c = (int)(i % h4) * 4;
+    const int d = dst[e];
+    const float s = scale ? scale[d] : 1.f;
+    float4 v = ld4(dagg + (size_t)d * ld_dagg + c);
+    v = make_float4(v.x * s, v.y * s, v.z * s, v.w * s);
+    if (de_new) v = f4add(v, ld4(de_new + (size_t)e * H + c));
+    st4(dmsg + (size_t)e * H + c, v);
+  }
+}
+
+// One wave per node: gather-backward (both gathers) + residuals; also the edge residual gradient.
+__global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict__ dcat,
+                                                         const float* __restrict__ dnode, int ld_dnode,
+                                                         const float* __restrict__ dx_res,
+                                                         const int* __restrict__ rowptr_dst,
+                                                         const int* __restrict__ rowptr_src,
+                                                         const int* __restrict__ perm_src,
+                                                         const float* __restrict__ de_new,
+                                                         float* __restrict__ dx, float* __restrict__ de_out,
+                                                         int N, int H) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const RowLanes rl = row_lanes(H, lane);
+  const size_t ldc = 3 * (size_t)H;
+  const int db = rowptr_dst[n], de = rowptr_dst[n + 1];
+  const int sb = rowptr_src[n], se = rowptr_src[n + 1];
+  for (int cb = 0; cb < H; cb += 256) {
+    const int c = cb + rl.c4;
+    float4 acc = f4zero();
+    if (c < H) {
+      for (int e = db + rl.slot; e < de; e += rl.rps) {
+        const float* row = dcat + (size_t)e * ldc;
+        acc = f4add(acc, ld4(row + H + c));
+        if (de_out) {
+          float4 v = ld4(row + 2 * H + c);
+          if (de_new) v = f4add(v, ld4(de_new + (size_t)e * H + c));
+          st4(de_out + (size_t)e * H + c, v);
+        }
+      }
+      for (int j = sb + rl.slot; j < se; j += rl.rps) {
+        const int e = perm_src[j];
+        acc = f4add(acc, ld4(dcat + (size_t)e * ldc + c));
+      }
+    }
+    acc = slots_sum(acc, rl.lpr);
+    if (c < H && rl.slot == 0) {
+      if (dx_res) acc = f4add(acc, ld4(dx_res + (size_t)n * H + c));
+      if (dnode) acc = f4add(acc, ld4(dnode + (size_t)n * ld_dnode + c));
+      st4(dx + (size_t)n * H + c, acc);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void graph_pool_kernel(const float* __restrict__ x, const int* __restrict__ ptr,
+                                                         float* __restrict__ out, int ld_out, int B, int H) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const RowLanes rl = row_lanes(H, lane);
+  const int beg = ptr[b], end = ptr[b + 1];
+  for (int cb = 0; cb < H; cb += 256) {
+    const int c = cb + rl.c4;
+    float4 acc = f4zero();
+    if (c < H)
+      for (int n = beg + rl.slot; n < end; n += rl.rps) acc = f4add(acc, ld4(x + (size_t)n * H + c));
+    acc = slots_sum(acc, rl.lpr);
+    if (c < H && rl.slot == 0) st4(out + (size_t)b * ld_out + c, acc);
+  }
+}
+
+__global__ void graph_pool_bwd_kernel(const float* __restrict__ dpool, int ld, const int* __restrict__ node_graph,
+                                      float* __restrict__ dx, int N, int H, int accumulate) {
+  const int h4 = H >> 2;
+  const size_t total = (size_t)N * h4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / h4), c = (int)(i % h4) * 4;
+    float4 v = ld4(dpool + (size_t)node_graph[n] * ld + c);
+    if (accumulate) v = f4add(v, ld4(dx + (size_t)n * H + c));
+    st4(dx + (size_t)n * H + c, v);
+  }
+}
+
+// wave per node: LayerNorm statistics of the node row, normalised row scattered to its dense slot
+__global__ __launch_bounds__(256) void dense_normalize_kernel(const float* __restrict__ x,
+                                                              const int* __restrict__ dense_row,
+                                                              float* __restrict__ kvhat,
+                                                              float* __restrict__ rstd_nodes, int N, int H) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const float* row = x + (size_t)n * H;
+  float s1 = 0.f;
+  for (int c = lane * 4; c < H; c += 256) {
+    const float4 v = ld4(row + c);
+    s1 += v.x + v.y + v.z + v.w;
+  }
+  const float mean = wave_sum(s1) / (float)H;
+  float s2 = 0.f;
+  for (int c = lane * 4; c < H; c += 256) {
+    const float4 v = ld4(row + c);
+    const float a = v.x - mean, b = v.y - mean, c2 = v.z - mean, d = v.w - mean;
+    s2 += a * a + b * b + c2 * c2 + d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(s2) / (float)H + DOSX_LN_EPS);
+  float* o = kvhat + (size_t)dense_row[n] * H;
+  for (int c = lane * 4; c < H; c += 256) {
+    const float4 v = ld4(row + c);
+    st4(o + c, make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd));
+  }
+  if (lane == 0) rstd_nodes[n] = rstd;
+}
+
+// generic "no-affine LN backward" for one row: dx = rstd * (g - mean(g) - xhat * mean(g*xhat))
+__device__ __forceinline__ void rownorm_bwd_row(const float* __restrict__ g, const float* __restrict__ xh,
+                                                float rstd, float* __restrict__ dx, int H, int lane,
+                                                int accumulate) {
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = lane * 4; c < H; c += 256) {
+    const float4 a = ld4(g + c), b = ld4(xh + c);
+    s1 += a.x + a.y + a.z + a.w;
+    s2 += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+  }
+  const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
+  for (int c = lane * 4; c < H; c += 256) {
+    const float4 a = ld4(g + c), b = ld4(xh + c);
+    float4 o = make_float4(rstd * (a.x - m1 - b.x * m2), rstd * (a.y - m1 - b.y * m2),
+                           rstd * (a.z - m1 - b.z * m2), rstd * (a.w - m1 - b.w * m2));
+    if (accumulate) o = f4add(o, ld4(dx + c));
+    st4(dx + c, o);
+  }
+}
+
+__global__ __launch_bounds__(256) void dense_normalize_bwd_kernel(const float* __restrict__ dkvhat,
+                                                                  const float* __restrict__ kvhat,
+                                                                  const float* __restrict__ rstd_nodes,
+                                                                  const int* __restrict__ dense_row,
+                                                                  float* __restrict__ dx, int N, int H,
+                                                                  int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const size_t d = (size_t)dense_row[n] * H;
+  rownorm_bwd_row(dkvhat + d, kvhat + d, rstd_nodes[n], dx + (size_t)n * H, H, lane, accumulate);
+}
+
+__global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ x, float* __restrict__ xhat,
+                                                      float* __restrict__ rstd_out, int M, int H) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= M) return;
+  const float* row = x + (size_t)r * H;
+  float s1 = 0.f;
+  for (int c = lane * 4; c < H; c += 256) {
+    const float4 v = ld4(row + c);
+    s1 += v.x + v.y + v.z + v.w;
+  }
+  const float mean = wave_sum(s1) / (float)H;
+  float s2 = 0.f;
+  for (int c = lane * 4; c < H; c += 256) {
+    const float4 v = ld4(row + c);
+    const float a = v.x - mean, b = v.y - mean, c2 = v.z - mean, d = v.w - mean;
+    s2 += a * a + b * b + c2 * c2 + d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(s2) / (float)H + DOSX_LN_EPS);
+  for (int c = lane * 4; c < H; c += 256) {
+    const float4 v = ld4(row + c);
+    st4(xhat + (size_t)r * H + c,
+        make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd));
+  }
+  if (lane == 0) rstd_out[r] = rstd;
+}
+
+__global__ __launch_bounds__(256) void rownorm_bwd_kernel(const float* __restrict__ dxhat,
+                                                          const float* __restrict__ xhat,
+                                                          const float* __restrict__ rstd, float* __restrict__ dx,
+                                                          int M, int H, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= M) return;
+  rownorm_bwd_row(dxhat + (size_t)r * H, xhat + (size_t)r * H, rstd[r], dx + (size_t)r * H, H, lane, accumulate);
+}
+
+__global__ void fill_kernel(float* p, float v, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+__global__ void embed_rows_kernel(const float* __restrict__ table, const int* __restrict__ idx,
+                                  float* __restrict__ out, int rows, int width) {
+  const size_t total = (size_t)rows * width;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / width), c = (int)(i % width);
+    out[i] = table[(size_t)idx[r] * width + c];
+  }
+}
+
+// one block per table row; threads own columns; rows scanned in order -> deterministic
+__global__ void embed_rows_bwd_kernel(const float* __restrict__ dout, int ld, const int* __restrict__ idx,
+                                      float* __restrict__ dtable, int rows, int width) {
+  const int t = blockIdx.x;
+  for (int c = threadIdx.x; c < width; c += blockDim.x) {
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r)
+      if (idx[r] == t) s += dout[(size_t)r * ld + c];
+    dtable[(size_t)t * width + c] = s;
+  }
+}
+
+// dst[i, 0:W] (+)= sum_j src[(i*stride_out + j*stride_red), 0:W]   (rows of ld_src / ld_dst floats)
+__global__ void reduce_rows_kernel(const float* __restrict__ src, int ld_src, float* dst, int ld_dst, int n_out,
+                                   int n_red, int stride_out, int stride_red, int W, int accumulate) {
+  const int w4 = W >> 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out * w4) return;
+  const int o = i / w4, c = (i % w4) * 4;
+  float4 acc = f4zero();
+  for (int j = 0; j < n_red; ++j)
+    acc = f4add(acc, ld4(src + ((size_t)o * stride_out + (size_t)j * stride_red) * ld_src + c));
+  if (accumulate) acc = f4add(acc, ld4(dst + (size_t)o * ld_dst + c));
+  st4(dst + (size_t)o * ld_dst + c, acc);
+}
+
+// out = dy * (y > 0 ? 1 : slope)    (LeakyReLU / ReLU backward from the saved OUTPUT)
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float slope, float* out,
+                               size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 d = ld4(dy + 4 * i), v = ld4(y + 4 * i);
+    st4(out + 4 * i, make_float4(v.x > 0.f ? d.x : slope * d.x, v.y > 0.f ? d.y : slope * d.y,
+                                 v.z > 0.f ? d.z : slope * d.z, v.w > 0.f ? d.w : slope * d.w));
+  }
+}
+
+inline int grid_1d(size_t total, int block) {
+  size_t g = (total + block - 1) / block;
+  if (g > 2048 * 4) g = 2048 * 4;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+#define CHECK_H(H) DOSX_CHECK_ARG((H) > 0 && ((H) & 3) == 0 && ((H) >= 256 ? ((H) % 256) == 0 : (256 % (H)) == 0), \
+                                  "%s: H=%d must be a power-of-two multiple of 4 (or a multiple of 256)", __func__, (H))
+
+extern "C" int dosx_edge_feat_sh1(const float* edge_vec, float* edge_attr, int E, float r_max, dosx_stream_t stream) {
+  if (E <= 0) return 0;
+  DOSX_CHECK_ARG(edge_vec && edge_attr && r_max > 0.f, "dosx_edge_feat_sh1: bad args");
+  hipLaunchKernelGGL(edge_feat_kernel, dim3(ceil_div(E, 256)), dim3(256), 0, to_stream(stream), edge_vec, edge_attr, E,
+                     1.f / r_max);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_segment_reduce(const float* msg, const int32_t* rowptr, const float* scale, float* agg,
+                                   const float* e_in, float* e_out, int N, int E, int H, dosx_stream_t stream) {
+  (void)E;
+  if (N <= 0) return 0;
+  CHECK_H(H);
+  DOSX_CHECK_ARG(msg && rowptr && agg && (!e_out || e_in), "dosx_segment_reduce: bad args");
+  hipLaunchKernelGGL(segment_reduce_kernel, dim3(ceil_div(N, 4)), dim3(256), 0, to_stream(stream), msg, rowptr, scale,
+                     agg, e_in, e_out, N, H);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_edge_grad_combine(const float* de_new, const float* dagg, int ld_dagg, const int32_t* dst,
+                                      const float* scale, float* dmsg, int E, int H, dosx_stream_t stream) {
+  if (E <= 0) return 0;
+  CHECK_H(H);
+  DOSX_CHECK_ARG(dagg && dst && dmsg && (ld_dagg & 3) == 0, "dosx_edge_grad_combine: bad args");
+  hipLaunchKernelGGL(edge_grad_combine_kernel, dim3(grid_1d((size_t)E * (H / 4), 256)), dim3(256), 0,
+                     to_stream(stream), de_new, dagg, ld_dagg, dst, scale, dmsg, E, H);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_gather_bwd(const float* dcat, const float* dnode, int ld_dnode, const float* dx_res,
+                               const int32_t* rowptr_dst, const int32_t* rowptr_src, const int32_t* perm_src,
+                               const float* de_new, float* dx, float* de_out, int N, int E, int H,
+                               dosx_stream_t stream) {
+  (void)E;
+  if (N <= 0) return 0;
+  CHECK_H(H);
+  DOSX_CHECK_ARG(dcat && rowptr_dst && rowptr_src && perm_src && dx && (ld_dnode & 3) == 0, "dosx_gather_bwd: bad args");
+  hipLaunchKernelGGL(gather_bwd_kernel, dim3(ceil_div(N, 4)), dim3(256), 0, to_stream(stream), dcat, dnode, ld_dnode,
+                     dx_res, rowptr_dst, rowptr_src, perm_src, de_new, dx, de_out, N, H);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_graph_pool(const float* x, const int32_t* graph_ptr, float* out, int ld_out, int B, int H,
+                               dosx_stream_t stream) {
+  if (B <= 0) return 0;
+  CHECK_H(H);
+  DOSX_CHECK_ARG(x && graph_ptr && out && (ld_out & 3) == 0, "dosx_graph_pool: bad args");
+  hipLaunchKernelGGL(graph_pool_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, to_stream(stream), x, graph_ptr, out, ld_out,
+                     B, H);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_graph_pool_bwd(const float* dpool, int ld_dpool, const int32_t* node_graph, float* dx, int N, int H,
+                                   int accumulate, dosx_stream_t stream) {
+  if (N <= 0) return 0;
+  CHECK_H(H);
+  DOSX_CHECK_ARG(dpool && node_graph && dx && (ld_dpool & 3) == 0, "dosx_graph_pool_bwd: bad args");
+  hipLaunchKernelGGL(graph_pool_bwd_kernel, dim3(grid_1d((size_t)N * (H / 4), 256)), dim3(256), 0, to_stream(stream),
+                     dpool, ld_dpool, node_graph, dx, N, H, accumulate);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_dense_normalize(const float* x, const int32_t* dense_row, float* kvhat, float* rstd_nodes, int N,
+                                    int H, int dense_rows, dosx_stream_t stream) {
+  CHECK_H(H);
+  DOSX_CHECK_ARG(kvhat && dense_rows >= 0, "dosx_dense_normalize: bad args");
+  if (dense_rows > 0) {
+    hipError_t e = hipMemsetAsync(kvhat, 0, (size_t)dense_rows * H * sizeof(float), to_stream(stream));
+    DOSX_CHECK_ARG(e == hipSuccess, "dosx_dense_normalize: memset failed: %s", hipGetErrorString(e));
+  }
+  if (N <= 0) return 0;
+  DOSX_CHECK_ARG(x && dense_row && rstd_nodes, "dosx_dense_normalize: bad args");
+  hipLaunchKernelGGL(dense_normalize_kernel, dim3(ceil_div(N, 4)), dim3(256), 0, to_stream(stream), x, dense_row, kvhat,
+                     rstd_nodes, N, H);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_dense_normalize_bwd(const float* dkvhat, const float* kvhat, const float* rstd_nodes,
+                                        const int32_t* dense_row, float* dx, int N, int H, int accumulate,
+                                        dosx_stream_t stream) {
+  if (N <= 0) return 0;
+  CHECK_H(H);
+  DOSX_CHECK_ARG(dkvhat && kvhat && rstd_nodes && dense_row && dx, "dosx_dense_normalize_bwd: bad args");
+  hipLaunchKernelGGL(dense_normalize_bwd_kernel, dim3(ceil_div(N, 4)), dim3(256), 0, to_stream(stream), dkvhat, kvhat,
+                     rstd_nodes, dense_row, dx, N, H, accumulate);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_rownorm(const float* x, float* xhat, float* rstd, int M, int H, dosx_stream_t stream) {
+  if (M <= 0) return 0;
+  CHECK_H(H);
+  DOSX_CHECK_ARG(x && xhat && rstd, "dosx_rownorm: bad args");
+  hipLaunchKernelGGL(rownorm_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, to_stream(stream), x, xhat, rstd, M, H);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_rownorm_bwd(const float* dxhat, const float* xhat, const float* rstd, float* dx, int M, int H,
+                                int accumulate, dosx_stream_t stream) {
+  if (M <= 0) return 0;
+  CHECK_H(H);
+  DOSX_CHECK_ARG(dxhat && xhat && rstd && dx, "dosx_rownorm_bwd: bad args");
+  hipLaunchKernelGGL(rownorm_bwd_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, to_stream(stream), dxhat, xhat, rstd, dx, M,
+                     H, accumulate);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_fill(float* p, float value, int64_t n, dosx_stream_t stream) {
+  if (n <= 0) return 0;
+  DOSX_CHECK_ARG(p, "dosx_fill: null");
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_1d((size_t)n, 256)), dim3(256), 0, to_stream(stream), p, value, (size_t)n);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_embed_rows(const float* table, const int32_t* idx, float* out, int rows, int width,
+                               dosx_stream_t stream) {
+  if (rows <= 0) return 0;
+  DOSX_CHECK_ARG(table && idx && out && width > 0, "dosx_embed_rows: bad args");
+  hipLaunchKernelGGL(embed_rows_kernel, dim3(grid_1d((size_t)rows * width, 256)), dim3(256), 0, to_stream(stream), table,
+                     idx, out, rows, width);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_embed_rows_bwd(const float* dout, int ld_dout, const int32_t* idx, float* dtable, int rows,
+                                   int table_rows, int width, dosx_stream_t stream) {
+  if (table_rows <= 0) return 0;
+  DOSX_CHECK_ARG(dout && idx && dtable && width > 0, "dosx_embed_rows_bwd: bad args");
+  hipLaunchKernelGGL(embed_rows_bwd_kernel, dim3(table_rows), dim3(128), 0, to_stream(stream), dout, ld_dout, idx, dtable,
+                     rows, width);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_reduce_rows(const float* src, int ld_src, float* dst, int ld_dst, int n_out, int n_red,
+                                int stride_out, int stride_red, int width, int accumulate, dosx_stream_t stream) {
+  if (n_out <= 0) return 0;
+  DOSX_CHECK_ARG(src && dst && (width & 3) == 0 && (ld_src & 3) == 0 && (ld_dst & 3) == 0 && width > 0,
+                 "dosx_reduce_rows: bad args");
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3(ceil_div(n_out * (width / 4), 256)), dim3(256), 0, to_stream(stream), src,
+                     ld_src, dst, ld_dst, n_out, n_red, stride_out, stride_red, width, accumulate);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_act_bwd(const float* dy, const float* y, float slope, float* out, int64_t n, dosx_stream_t stream) {
+  if (n <= 0) return 0;
+  DOSX_CHECK_ARG(dy && y && out && (n & 3) == 0, "dosx_act_bwd: bad args (n must be a multiple of 4)");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_1d((size_t)n / 4, 256)), dim3(256), 0, to_stream(stream), dy, y, slope, out,
+                     (size_t)n / 4);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}

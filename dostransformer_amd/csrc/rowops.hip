@@ -1,0 +1,408 @@
+// Row-wise kernels: LayerNorm (+backward), the fused final-LN + out_layer dot product, the
+// callers' losses and the flat AdamW step (gfx950).  One wave per row, float4 lanes.
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+// y = xhat*gamma + beta ; saves xhat and rstd
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ y,
+                                                        float* __restrict__ xhat, float* __restrict__ rstd_out,
+                                                        int M, int H) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= M) return;
+  const float* row = x + (size_t)r * H;
+  float s1 = 0.f;
+  for (int c = lane * 4; c < H; c += 256) {
+    const float4 v = ld4(row + c);
+    s1 += v.x + v.y + v.z + v.w;
+  }
+  const float mean = wave_sum(s1) / (float)H;
+  float s2 = 0.f;
+  for (int c = lane * 4; c < H; c += 256) {
+    const float4 v = ld4(row + c);
+    const float a = v.x - mean, b = v.y - mean, c2 = v.z - mean, d = v.w - mean;
+    s2 += a * a + b * b + c2 * c2 + d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(s2) / (float)H + DOSX_LN_EPS);
+  for (int c = lane * 4; c < H; c += 256) {
+    const float4 v = ld4(row + c), g = ld4(gamma + c), b = ld4(beta + c);
+    const float4 h = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
+    if (xhat) st4(xhat + (size_t)r * H + c, h);
+    st4(y + (size_t)r * H + c, make_float4(h.x * g.x + b.x, h.y * g.y + b.y, h.z * g.z + b.z, h.w * g.w + b.w));
+  }
+  if (lane == 0 && rstd_out) rstd_out[r] = rstd;
+}
+
+// Shared skeleton of the LN-backward row kernels.  NV = number of H-wide partial vectors this
+// kernel produces per workgroup (2: dgamma,dbeta ; 3: + dw), plus optional trailing scalar.
+// Workgroup = 4 waves x 8 rows = 32 rows; partial row layout [v0(H) | v1(H) | (v2(H)) | (scalar)].
+template <bool ROWDOT>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy,     // [M,H]   (!ROWDOT)
+                                                     const float* __restrict__ ddos,   // [Bq,S]  (ROWDOT)
+                                                     const float* __restrict__ xhat, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* __restrict__ w, float* __restrict__ dx,
+                                                     float* __restrict__ partials, int M, int H, int S, int Bq) {
+  extern __shared__ __align__(16) float sm[];   // [4][NV*H + 1]
+  constexpr int NV = ROWDOT ? 3 : 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pld = NV * H + (ROWDOT ? 1 : 0);
+  float* my = sm + (size_t)wave * (NV * H + 1);
+  for (int c = lane; c < NV * H + 1; c += 64) my[c] = 0.f;
+  float db = 0.f;
+  for (int i = 0; i < 8; ++i) {
+    const int r = blockIdx.x * 32 + wave * 8 + i;
+    if (r >= M) break;
+    const float rs = rstd[r];
+    float dyr = 0.f;
+    if (ROWDOT) {
+      dyr = ddos[(size_t)(r % Bq) * S + (r / Bq)];
+      db += dyr;
+    }
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane * 4; c < H; c += 256) {
+      const float4 xh = ld4(xhat + (size_t)r * H + c), g = ld4(gamma + c);
+      float4 d;
+      if (ROWDOT) {
+        const float4 ww = ld4(w + c), bt = ld4(beta + c);
+        d = make_float4(dyr * ww.x, dyr * ww.y, dyr * ww.z, dyr * ww.w);
+        my[2 * H + c + 0] += dyr * (xh.x * g.x + bt.x);
+        my[2 * H + c + 1] += dyr * (xh.y * g.y + bt.y);
+        my[2 * H + c + 2] += dyr * (xh.z * g.z + bt.z);
+        my[2 * H + c + 3] += dyr * (xh.w * g.w + bt.w);
+      } else {
+        d = ld4(dy + (size_t)r * H + c);
+      }
+      my[c + 0] += d.x * xh.x; my[c + 1] += d.y * xh.y; my[c + 2] += d.z * xh.z; my[c + 3] += d.w * xh.w;
+      my[H + c + 0] += d.x; my[H + c + 1] += d.y; my[H + c + 2] += d.z; my[H + c + 3] += d.w;
+      const float4 dh = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+      s1 += dh.x + dh.y + dh.z + dh.w;
+      s2 += dh.x * xh.x + dh.y * xh.y + dh.z * xh.z + dh.w * xh.w;
+    }
+    const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
+    for (int c = lane * 4; c < H; c += 256) {
+      const float4 xh = ld4(xhat + (size_t)r * H + c), g = ld4(gamma + c);
+      float4 d;
+      if (ROWDOT) {
+        const float4 ww = ld4(w + c);
+        d = make_float4(dyr * ww.x, dyr * ww.y, dyr * ww.z, dyr * ww.w);
+      } else {
+        d = ld4(dy + (size_t)r * H + c);
+      }
+      st4(dx + (size_t)r * H + c,
+          make_float4(rs * (d.x * g.x - m1 - xh.x * m2), rs * (d.y * g.y - m1 - xh.y * m2),
+                      rs * (d.z * g.z - m1 - xh.z * m2), rs * (d.w * g.w - m1 - xh.w * m2)));
+    }
+  }
+  if (ROWDOT && lane == 0) my[NV * H] = db;
+  __syncthreads();
+  float* prow = partials + (size_t)blockIdx.x * pld;
+  const int stride = NV * H + 1;
+  for (int c = threadIdx.x; c < pld; c += 256)
+    prow[c] = sm[c] + sm[stride + c] + sm[2 * stride + c] + sm[3 * stride + c];
+}
+
+// y[r] = (LN(x[r])*gamma+beta) . w + b   ->  dos[(r % Bq)*S + r / Bq]
+__global__ __launch_bounds__(256) void ln_rowdot_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float* __restrict__ xhat,
+                                                        float* __restrict__ rstd_out, float* __restrict__ dos, int S,
+                                                        int Bq, int H) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= S * Bq) return;
+  const float* row = x + (size_t)r * H;
+  float s1 = 0.f;
+  for (int c = lane * 4; c < H; c += 256) {
+    const float4 v = ld4(row + c);
+    s1 += v.x + v.y + v.z + v.w;
+  }
+  const float mean = wave_sum(s1) / (float)H;
+  float s2 = 0.f;
+  for (int c = lane * 4; c < H; c += 256) {
+    const float4 v = ld4(row + c);
+    const float a = v.x - mean, bb = v.y - mean, c2 = v.z - mean, d = v.w - mean;
+    s2 += a * a + bb * bb + c2 * c2 + d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(s2) / (float)H + DOSX_LN_EPS);
+  float dot = 0.f;
+  for (int c = lane * 4; c < H; c += 256) {
+    const float4 v = ld4(row + c), g = ld4(gamma + c), bt = ld4(beta + c), ww = ld4(w + c);
+    const float4 h = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
+    st4(xhat + (size_t)r * H + c, h);
+    dot += (h.x * g.x + bt.x) * ww.x + (h.y * g.y + bt.y) * ww.y + (h.z * g.z + bt.z) * ww.z + (h.w * g.w + bt.w) * ww.w;
+  }
+  dot = wave_sum(dot);
+  if (lane == 0) {
+    rstd_out[r] = rstd;
+    dos[(size_t)(r % Bq) * S + (r / Bq)] = dot + b[0];
+  }
+}
+
+// plain y[r] = x[r] . w + b  (x already activated)
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ b, float* __restrict__ dos, int S,
+                                                     int Bq, int H) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= S * Bq) return;
+  float dot = 0.f;
+  for (int c = lane * 4; c < H; c += 256) {
+    const float4 v = ld4(x + (size_t)r * H + c), ww = ld4(w + c);
+    dot += v.x * ww.x + v.y * ww.y + v.z * ww.z + v.w * ww.w;
+  }
+  dot = wave_sum(dot);
+  if (lane == 0) dos[(size_t)(r % Bq) * S + (r / Bq)] = dot + b[0];
+}
+
+// dx[r] = ddos * w ; partial rows [dw(H) | db]
+__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ ddos, const float* __restrict__ x,
+                                                         const float* __restrict__ w, float* __restrict__ dx,
+                                                         float* __restrict__ partials, int S, int Bq, int H) {
+  extern __shared__ __align__(16) float sm[];   // [4][H+1]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int M = S * Bq;
+  float* my = sm + (size_t)wave * (H + 1);
+  for (int c = lane; c < H + 1; c += 64) my[c] = 0.f;
+  float db = 0.f;
+  for (int i = 0; i < 8; ++i) {
+    const int r = blockIdx.x * 32 + wave * 8 + i;
+    if (r >= M) break;
+    const float dyr = ddos[(size_t)(r % Bq) * S + (r / Bq)];
+    db += dyr;
+    for (int c = lane * 4; c < H; c += 256) {
+      const float4 v = ld4(x + (size_t)r * H + c), ww = ld4(w + c);
+      my[c] += dyr * v.x; my[c + 1] += dyr * v.y; my[c + 2] += dyr * v.z; my[c + 3] += dyr * v.w;
+      st4(dx + (size_t)r * H + c, make_float4(dyr * ww.x, dyr * ww.y, dyr * ww.z, dyr * ww.w));
+    }
+  }
+  if (lane == 0) my[H] = db;
+  __syncthreads();
+  float* prow = partials + (size_t)blockIdx.x * (H + 1);
+  for (int c = threadIdx.x; c < H + 1; c += 256)
+    prow[c] = sm[c] + sm[(H + 1) + c] + sm[2 * (H + 1) + c] + sm[3 * (H + 1) + c];
+}
+
+// ---- losses -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void sse2_kernel(const float* __restrict__ pg, const float* __restrict__ ps,
+                                                    const float* __restrict__ y, float* __restrict__ sse, int count) {
+  __shared__ float red[2][16];
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < count; i += 1024) {
+    const float t = y[i], d0 = pg[i] - t, d1 = ps[i] - t;
+    a += d0 * d0;
+    b += d1 * d1;
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wave] = a; red[1][wave] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int i = 0; i < 16; ++i) { s0 += red[0][i]; s1 += red[1][i]; }
+    sse[0] = s0;
+    sse[1] = s1;
+  }
+}
+
+__global__ void loss_phonon_bwd_kernel(const float* __restrict__ pg, const float* __restrict__ ps,
+                                       const float* __restrict__ y, const float* __restrict__ sse, float beta,
+                                       float inv_count, float* __restrict__ dpg, float* __restrict__ dps,
+                                       float* __restrict__ loss, int count) {
+  const float r0 = sqrtf(sse[0] * inv_count), r1 = sqrtf(sse[1] * inv_count);
+  const float k0 = inv_count / r0, k1 = beta * inv_count / r1;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && loss) loss[0] = r0 + beta * r1;
+  if (i < count) {
+    const float t = y[i];
+    dpg[i] = (pg[i] - t) * k0;
+    dps[i] = (ps[i] - t) * k1;
+  }
+}
+
+// one wave per crystal
+__global__ __launch_bounds__(256) void loss_edos_kernel(const float* __restrict__ pg, const float* __restrict__ ps,
+                                                        const float* __restrict__ y_ft, float beta, int B, int S,
+                                                        float inv_bglobal, float* __restrict__ dpg,
+                                                        float* __restrict__ dps, float* __restrict__ loss_partial) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const size_t o = (size_t)b * S;
+  float a = 0.f, c = 0.f;
+  for (int s = lane; s < S; s += 64) {
+    const float t = fmaxf(y_ft[o + s], 0.f);   // torch.where(y < 0, 0, y)
+    const float d0 = t - pg[o + s], d1 = t - ps[o + s];
+    a += d0 * d0;
+    c += d1 * d1;
+  }
+  a = wave_sum(a);
+  c = wave_sum(c);
+  const float r0 = sqrtf(a / (float)S), r1 = sqrtf(c / (float)S);
+  const float k0 = inv_bglobal / ((float)S * r0), k1 = beta * inv_bglobal / ((float)S * r1);
+  for (int s = lane; s < S; s += 64) {
+    const float t = fmaxf(y_ft[o + s], 0.f);
+    dpg[o + s] = (pg[o + s] - t) * k0;
+    dps[o + s] = (ps[o + s] - t) * k1;
+  }
+  if (lane == 0) loss_partial[b] = (r0 + beta * r1) * inv_bglobal;
+}
+
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, size_t n, float decay, float beta1, float beta2, float eps,
+                             float step_size, float inv_bc2s, float gscale) {
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 pp = ld4(p + 4 * i), gg = ld4(g + 4 * i), mm = ld4(m + 4 * i), vv = ld4(v + 4 * i);
+    float* P = &pp.x; float* G = &gg.x; float* Mm = &mm.x; float* V = &vv.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gr = G[j] * gscale;
+      float pj = P[j] * decay;
+      const float mj = Mm[j] + (gr - Mm[j]) * (1.f - beta1);
+      const float vj = V[j] * beta2 + (1.f - beta2) * gr * gr;
+      const float denom = sqrtf(vj) * inv_bc2s + eps;
+      pj -= step_size * (mj / denom);
+      P[j] = pj; Mm[j] = mj; V[j] = vj;
+    }
+    st4(p + 4 * i, pp); st4(m + 4 * i, mm); st4(v + 4 * i, vv);
+  }
+  // tail (n not a multiple of 4)
+  const size_t t0 = n4 << 2;
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid < n - t0) {
+    const size_t i = t0 + tid;
+    const float gr = g[i] * gscale;
+    float pj = p[i] * decay;
+    const float mj = m[i] + (gr - m[i]) * (1.f - beta1);
+    const float vj = v[i] * beta2 + (1.f - beta2) * gr * gr;
+    pj -= step_size * (mj / (sqrtf(vj) * inv_bc2s + eps));
+    p[i] = pj; m[i] = mj; v[i] = vj;
+  }
+}
+
+}  // namespace
+
+#define CHECK_H4(H) DOSX_CHECK_ARG((H) > 0 && ((H) & 3) == 0, "%s: H=%d must be a multiple of 4", __func__, (H))
+
+extern "C" int dosx_layernorm(const float* x, const float* gamma, const float* beta, float* y, float* xhat, float* rstd,
+                              int M, int H, dosx_stream_t stream) {
+  if (M <= 0) return 0;
+  CHECK_H4(H);
+  DOSX_CHECK_ARG(x && gamma && beta && y, "dosx_layernorm: bad args");
+  hipLaunchKernelGGL(layernorm_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, to_stream(stream), x, gamma, beta, y, xhat, rstd,
+                     M, H);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dx,
+                                  float* partials, int M, int H, dosx_stream_t stream) {
+  if (M <= 0) return 0;
+  CHECK_H4(H);
+  DOSX_CHECK_ARG(dy && xhat && rstd && gamma && dx && partials, "dosx_layernorm_bwd: bad args");
+  const size_t smem = 4 * (size_t)(2 * H + 1) * sizeof(float);
+  hipLaunchKernelGGL((ln_bwd_kernel<false>), dim3(ceil_div(M, 32)), dim3(256), smem, to_stream(stream), dy, nullptr, xhat,
+                     rstd, gamma, nullptr, nullptr, dx, partials, M, H, 0, 1);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_ln_rowdot(const float* x, const float* gamma, const float* beta, const float* w, const float* b,
+                              float* xhat, float* rstd, float* dos, int S, int Bq, int H, dosx_stream_t stream) {
+  if (S * Bq <= 0) return 0;
+  CHECK_H4(H);
+  DOSX_CHECK_ARG(x && gamma && beta && w && b && xhat && rstd && dos, "dosx_ln_rowdot: bad args");
+  hipLaunchKernelGGL(ln_rowdot_kernel, dim3(ceil_div(S * Bq, 4)), dim3(256), 0, to_stream(stream), x, gamma, beta, w, b,
+                     xhat, rstd, dos, S, Bq, H);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_ln_rowdot_bwd(const float* ddos, const float* xhat, const float* rstd, const float* gamma,
+                                  const float* beta, const float* w, float* dx, float* partials, int S, int Bq, int H,
+                                  dosx_stream_t stream) {
+  const int M = S * Bq;
+  if (M <= 0) return 0;
+  CHECK_H4(H);
+  DOSX_CHECK_ARG(ddos && xhat && rstd && gamma && beta && w && dx && partials, "dosx_ln_rowdot_bwd: bad args");
+  const size_t smem = 4 * (size_t)(3 * H + 1) * sizeof(float);
+  hipLaunchKernelGGL((ln_bwd_kernel<true>), dim3(ceil_div(M, 32)), dim3(256), smem, to_stream(stream), nullptr, ddos, xhat,
+                     rstd, gamma, beta, w, dx, partials, M, H, S, Bq);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_rowdot(const float* x, const float* w, const float* b, float* dos, int S, int Bq, int H,
+                           dosx_stream_t stream) {
+  if (S * Bq <= 0) return 0;
+  CHECK_H4(H);
+  DOSX_CHECK_ARG(x && w && b && dos, "dosx_rowdot: bad args");
+  hipLaunchKernelGGL(rowdot_kernel, dim3(ceil_div(S * Bq, 4)), dim3(256), 0, to_stream(stream), x, w, b, dos, S, Bq, H);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_rowdot_bwd(const float* ddos, const float* x, const float* w, float* dx, float* partials, int S,
+                               int Bq, int H, dosx_stream_t stream) {
+  const int M = S * Bq;
+  if (M <= 0) return 0;
+  CHECK_H4(H);
+  DOSX_CHECK_ARG(ddos && x && w && dx && partials, "dosx_rowdot_bwd: bad args");
+  const size_t smem = 4 * (size_t)(H + 1) * sizeof(float);
+  hipLaunchKernelGGL(rowdot_bwd_kernel, dim3(ceil_div(M, 32)), dim3(256), smem, to_stream(stream), ddos, x, w, dx, partials,
+                     S, Bq, H);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_sse2(const float* pg, const float* ps, const float* y, float* sse, int count, dosx_stream_t stream) {
+  DOSX_CHECK_ARG(pg && ps && y && sse && count > 0, "dosx_sse2: bad args");
+  hipLaunchKernelGGL(sse2_kernel, dim3(1), dim3(1024), 0, to_stream(stream), pg, ps, y, sse, count);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_loss_phonon_bwd(const float* pg, const float* ps, const float* y, const float* sse, float beta,
+                                    double count_global, float* dpg, float* dps, float* loss, int count,
+                                    dosx_stream_t stream) {
+  DOSX_CHECK_ARG(pg && ps && y && sse && dpg && dps && count > 0 && count_global > 0, "dosx_loss_phonon_bwd: bad args");
+  hipLaunchKernelGGL(loss_phonon_bwd_kernel, dim3(ceil_div(count, 256)), dim3(256), 0, to_stream(stream), pg, ps, y, sse,
+                     beta, (float)(1.0 / count_global), dpg, dps, loss, count);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_loss_edos(const float* pg, const float* ps, const float* y_ft, float beta, int B, int S, int B_global,
+                              float* dpg, float* dps, float* loss_partial, dosx_stream_t stream) {
+  DOSX_CHECK_ARG(pg && ps && y_ft && dpg && dps && loss_partial && B > 0 && S > 0 && B_global > 0, "dosx_loss_edos: bad args");
+  hipLaunchKernelGGL(loss_edos_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, to_stream(stream), pg, ps, y_ft, beta, B, S,
+                     1.f / (float)B_global, dpg, dps, loss_partial);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                          float eps, float weight_decay, int step, float grad_scale, dosx_stream_t stream) {
+  if (n <= 0) return 0;
+  DOSX_CHECK_ARG(p && g && m && v && step >= 1, "dosx_adamw: bad args");
+  DOSX_CHECK_ARG(((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                   reinterpret_cast<uintptr_t>(v)) & 15) == 0, "dosx_adamw: buffers must be 16-byte aligned");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_bc2s = (float)(1.0 / sqrt(bc2));
+  const float decay = 1.f - lr * weight_decay;
+  size_t g1 = ((size_t)n / 4 + 255) / 256;
+  if (g1 > 4096) g1 = 4096;
+  if (g1 < 1) g1 = 1;
+  hipLaunchKernelGGL(adamw_kernel, dim3((int)g1), dim3(256), 0, to_stream(stream), p, g, m, v, (size_t)n, decay, beta1,
+                     beta2, eps, step_size, inv_bc2s, grad_scale);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}

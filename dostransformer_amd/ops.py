@@ -1,0 +1,321 @@
+"""Thin torch-tensor wrappers over the libdosx C ABI (one Python function per entry point).
+
+Tensors are only used as device-memory handles (``data_ptr()``) and every launch goes to
+``torch.cuda.current_stream()`` so the calls are stream-ordered with the rest of the program and
+capturable in a HIP graph.  No arithmetic happens in Python.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import BIG, Attn, Gemm, ReduceJob, RowMap, Seg, Wgrad
+
+PRO_NONE, PRO_PRELU, PRO_LN_PRELU, PRO_ROWLN = 0, 1, 2, 3
+EPI_BIAS_ACT, EPI_LN, EPI_PRELU_LN_BWD, EPI_RELU_MASK, EPI_ROWLN_BWD, EPI_PRELU_BWD = 0, 1, 2, 3, 4, 5
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk_f32(*ts):
+    for t in ts:
+        if t is not None:
+            if t.dtype != torch.float32 or not t.is_cuda:
+                raise TypeError(f"dosx ops need float32 CUDA tensors, got {t.dtype} on {t.device}")
+
+
+def ident() -> RowMap:
+    return RowMap(BIG, 0, 1, 0, None)
+
+
+def rowmap(d: int = BIG, m: int = 0, c: int = 1, off: int = 0, idx: Optional[torch.Tensor] = None) -> RowMap:
+    """row(r) = idx[t] if idx else t,  t = (r // d) * m + (r % d) * c + off."""
+    return RowMap(int(d), int(m), int(c), int(off), _p(idx))
+
+
+def seg(t: torch.Tensor, width: Optional[int] = None, col: int = 0, rmap: Optional[RowMap] = None) -> Seg:
+    """A K-segment: columns [col, col+width) of the 2-D row-major tensor ``t`` (rows via rmap)."""
+    assert t.dim() == 2 and t.stride(1) == 1, "segment must be 2-D with unit inner stride"
+    w = t.shape[1] - col if width is None else width
+    return Seg(t.data_ptr() + 4 * col, int(t.stride(0)), int(w), rmap if rmap is not None else ident())
+
+
+def _set_segs(dst, segs: Sequence[Seg]):
+    assert 1 <= len(segs) <= 3
+    for i, s in enumerate(segs):
+        dst[i] = s
+
+
+def gemm(M: int, N: int, segs: Sequence[Seg], w: torch.Tensor, out: torch.Tensor, *, w_layout: int = 0,
+         pro: int = PRO_NONE, pro_gamma=None, pro_beta=None, pro_alpha=None, pro_stats=None,
+         epi: int = EPI_BIAS_ACT, act: int = ACT_NONE, act_slope: float = 0.01, bias=None,
+         out_map: Optional[RowMap] = None, res=None, res_map: Optional[RowMap] = None,
+         stats_out=None, aux_out=None, aux=None, aux_stats=None, epi_gamma=None, epi_beta=None,
+         epi_alpha=None, partials=None, partial_ld: int = 0, keep: Optional[list] = None) -> None:
+    """out[M,N] = epilogue(prologue(A) @ B); see include/dosx.h:DosxGemm."""
+    g = Gemm()
+    g.M, g.N = int(M), int(N)
+    g.K = int(sum(s.width for s in segs))
+    g.nseg = len(segs)
+    _set_segs(g.a, segs)
+    g.pro = pro
+    g.pro_gamma, g.pro_beta, g.pro_alpha, g.pro_stats = _p(pro_gamma), _p(pro_beta), _p(pro_alpha), _p(pro_stats)
+    assert w.dim() == 2 and w.stride(1) == 1
+    g.w, g.ldw, g.w_layout = w.data_ptr(), int(w.stride(0)), int(w_layout)
+    g.epi, g.act, g.act_slope = epi, act, float(act_slope)
+    g.bias = _p(bias)
+    g.out, g.ldo = out.data_ptr(), int(out.stride(0))
+    g.out_map = out_map if out_map is not None else ident()
+    g.res = _p(res)
+    g.ldr = int(res.stride(0)) if res is not None else 0
+    g.res_map = res_map if res_map is not None else ident()
+    g.stats_out, g.aux_out = _p(stats_out), _p(aux_out)
+    g.aux = _p(aux)
+    g.ldaux = int(aux.stride(0)) if aux is not None else 0
+    g.aux_stats = _p(aux_stats)
+    g.epi_gamma, g.epi_beta, g.epi_alpha = _p(epi_gamma), _p(epi_beta), _p(epi_alpha)
+    g.partials, g.partial_ld = _p(partials), int(partial_ld)
+    lib = _lib.load()
+    _lib.check(lib.dosx_gemm(C.byref(g), _stream()), "dosx_gemm")
+
+
+def gemm_partial_rows(M: int, N: int) -> int:
+    return _lib.load().dosx_gemm_partial_rows(int(M), int(N))
+
+
+def wgrad_splits(M: int, N: int, K: int) -> int:
+    return _lib.load().dosx_wgrad_splits(int(M), int(N), int(K))
+
+
+def wgrad(M: int, N: int, dy: Seg, segs: Sequence[Seg], slab: torch.Tensor, slab_bias: Optional[torch.Tensor],
+          nsplit: int, *, pro: int = PRO_NONE, pro_gamma=None, pro_beta=None, pro_alpha=None, pro_stats=None) -> None:
+    g = Wgrad()
+    g.M, g.N = int(M), int(N)
+    g.K = int(sum(s.width for s in segs))
+    g.dy = dy
+    g.nseg = len(segs)
+    _set_segs(g.a, segs)
+    g.pro = pro
+    g.pro_gamma, g.pro_beta, g.pro_alpha, g.pro_stats = _p(pro_gamma), _p(pro_beta), _p(pro_alpha), _p(pro_stats)
+    g.slab, g.slab_bias, g.nsplit = slab.data_ptr(), _p(slab_bias), int(nsplit)
+    lib = _lib.load()
+    _lib.check(lib.dosx_wgrad(C.byref(g), _stream()), "dosx_wgrad")
+
+
+_JOB_DT = np.dtype([("src", np.uint64), ("dst", np.uint64), ("nsplit", np.int32), ("stride", np.int32),
+                    ("count", np.int32), ("accumulate", np.int32)])
+assert _JOB_DT.itemsize == C.sizeof(ReduceJob)
+
+
+class GradSink:
+    """Collects the partial-sum slabs produced during a backward pass and reduces all of them
+    into the parameter-gradient buffers with ONE deterministic kernel launch per 'wave'
+    (jobs that share a destination are serialised into successive waves)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.jobs: List[Tuple[int, int, int, int, int, int]] = []
+        self._keep: List[torch.Tensor] = []
+
+    def scratch(self, *shape) -> torch.Tensor:
+        t = torch.empty(shape, device=self.device, dtype=torch.float32)
+        self._keep.append(t)
+        return t
+
+    def add(self, src: torch.Tensor, src_off: int, dst: torch.Tensor, nsplit: int, stride: int, count: int,
+            dst_off: int = 0, accumulate: bool = False):
+        if count <= 0 or nsplit <= 0:
+            return
+        assert dst.is_contiguous() or dst.numel() == count
+        self.jobs.append((src.data_ptr() + 4 * src_off, dst.data_ptr() + 4 * dst_off, int(nsplit), int(stride),
+                          int(count), 1 if accumulate else 0))
+
+    def flush(self):
+        if not self.jobs:
+            return
+        # jobs that share a destination go to successive launches (later ones accumulate)
+        occ = {}
+        waves: List[List[tuple]] = []
+        for j in self.jobs:
+            k = occ.get(j[1], 0)
+            occ[j[1]] = k + 1
+            if k >= len(waves):
+                waves.append([])
+            waves[k].append(j if k == 0 else j[:5] + (1,))
+        lib = _lib.load()
+        for wv in waves:
+            arr = np.array(wv, dtype=_JOB_DT)
+            host = torch.from_numpy(arr.view(np.uint8)).pin_memory()
+            dev = host.to(self.device, non_blocking=True)
+            self._keep.extend([host, dev])
+            mx = int(arr["count"].max())
+            _lib.check(lib.dosx_reduce_partials(dev.data_ptr(), len(wv), mx, _stream()), "dosx_reduce_partials")
+        self.jobs = []
+
+    def release(self):
+        self._keep = []
+
+
+def edge_feat_sh1(edge_vec: torch.Tensor, r_max: float = 4.0) -> torch.Tensor:
+    _chk_f32(edge_vec)
+    e = edge_vec.shape[0]
+    out = torch.empty(e, 4, device=edge_vec.device, dtype=torch.float32)
+    lib = _lib.load()
+    _lib.check(lib.dosx_edge_feat_sh1(edge_vec.data_ptr(), out.data_ptr(), e, float(r_max), _stream()), "dosx_edge_feat_sh1")
+    return out
+
+
+def segment_reduce(msg, rowptr, scale, agg, e_in, e_out, N, E, H):
+    lib = _lib.load()
+    _lib.check(lib.dosx_segment_reduce(_p(msg), _p(rowptr), _p(scale), _p(agg), _p(e_in), _p(e_out), N, E, H, _stream()),
+               "dosx_segment_reduce")
+
+
+def edge_grad_combine(de_new, dagg, ld_dagg, dst, scale, dmsg, E, H):
+    lib = _lib.load()
+    _lib.check(lib.dosx_edge_grad_combine(_p(de_new), dagg, ld_dagg, _p(dst), _p(scale), _p(dmsg), E, H, _stream()),
+               "dosx_edge_grad_combine")
+
+
+def gather_bwd(dcat, dnode_ptr, ld_dnode, dx_res, rowptr_dst, rowptr_src, perm_src, de_new, dx, de_out, N, E, H):
+    lib = _lib.load()
+    _lib.check(lib.dosx_gather_bwd(_p(dcat), dnode_ptr, ld_dnode, _p(dx_res), _p(rowptr_dst), _p(rowptr_src),
+                                   _p(perm_src), _p(de_new), _p(dx), _p(de_out), N, E, H, _stream()), "dosx_gather_bwd")
+
+
+def graph_pool(x, graph_ptr, out_ptr, ld_out, B, H):
+    lib = _lib.load()
+    _lib.check(lib.dosx_graph_pool(_p(x), _p(graph_ptr), out_ptr, ld_out, B, H, _stream()), "dosx_graph_pool")
+
+
+def graph_pool_bwd(dpool_ptr, ld, node_graph, dx, N, H, accumulate):
+    lib = _lib.load()
+    _lib.check(lib.dosx_graph_pool_bwd(dpool_ptr, ld, _p(node_graph), _p(dx), N, H, int(accumulate), _stream()),
+               "dosx_graph_pool_bwd")
+
+
+def dense_normalize(x, dense_row, kvhat, rstd_nodes, N, H, dense_rows):
+    lib = _lib.load()
+    _lib.check(lib.dosx_dense_normalize(_p(x), _p(dense_row), _p(kvhat), _p(rstd_nodes), N, H, dense_rows, _stream()),
+               "dosx_dense_normalize")
+
+
+def dense_normalize_bwd(dkvhat, kvhat, rstd_nodes, dense_row, dx, N, H, accumulate):
+    lib = _lib.load()
+    _lib.check(lib.dosx_dense_normalize_bwd(_p(dkvhat), _p(kvhat), _p(rstd_nodes), _p(dense_row), _p(dx), N, H,
+                                            int(accumulate), _stream()), "dosx_dense_normalize_bwd")
+
+
+def rownorm(x, xhat, rstd, M, H):
+    lib = _lib.load()
+    _lib.check(lib.dosx_rownorm(_p(x), _p(xhat), _p(rstd), M, H, _stream()), "dosx_rownorm")
+
+
+def rownorm_bwd(dxhat, xhat, rstd, dx, M, H, accumulate):
+    lib = _lib.load()
+    _lib.check(lib.dosx_rownorm_bwd(_p(dxhat), _p(xhat), _p(rstd), _p(dx), M, H, int(accumulate), _stream()),
+               "dosx_rownorm_bwd")
+
+
+def layernorm(x, gamma, beta, y, xhat, rstd, M, H):
+    lib = _lib.load()
+    _lib.check(lib.dosx_layernorm(_p(x), _p(gamma), _p(beta), _p(y), _p(xhat), _p(rstd), M, H, _stream()), "dosx_layernorm")
+
+
+def layernorm_bwd(dy, xhat, rstd, gamma, dx, partials, M, H):
+    lib = _lib.load()
+    _lib.check(lib.dosx_layernorm_bwd(_p(dy), _p(xhat), _p(rstd), _p(gamma), _p(dx), _p(partials), M, H, _stream()),
+               "dosx_layernorm_bwd")
+
+
+def attention_fwd(a: Attn):
+    lib = _lib.load()
+    _lib.check(lib.dosx_attention_fwd(C.byref(a), _stream()), "dosx_attention_fwd")
+
+
+def attention_bwd(a: Attn):
+    lib = _lib.load()
+    _lib.check(lib.dosx_attention_bwd(C.byref(a), _stream()), "dosx_attention_bwd")
+
+
+def ln_rowdot(x, gamma, beta, w, b, xhat, rstd, dos, S, Bq, H):
+    lib = _lib.load()
+    _lib.check(lib.dosx_ln_rowdot(_p(x), _p(gamma), _p(beta), _p(w), _p(b), _p(xhat), _p(rstd), _p(dos), S, Bq, H, _stream()),
+               "dosx_ln_rowdot")
+
+
+def ln_rowdot_bwd(ddos, xhat, rstd, gamma, beta, w, dx, partials, S, Bq, H):
+    lib = _lib.load()
+    _lib.check(lib.dosx_ln_rowdot_bwd(_p(ddos), _p(xhat), _p(rstd), _p(gamma), _p(beta), _p(w), _p(dx), _p(partials), S, Bq,
+                                      H, _stream()), "dosx_ln_rowdot_bwd")
+
+
+def rowdot(x, w, b, dos, S, Bq, H):
+    lib = _lib.load()
+    _lib.check(lib.dosx_rowdot(_p(x), _p(w), _p(b), _p(dos), S, Bq, H, _stream()), "dosx_rowdot")
+
+
+def rowdot_bwd(ddos, x, w, dx, partials, S, Bq, H):
+    lib = _lib.load()
+    _lib.check(lib.dosx_rowdot_bwd(_p(ddos), _p(x), _p(w), _p(dx), _p(partials), S, Bq, H, _stream()), "dosx_rowdot_bwd")
+
+
+def sse2(pg, ps, y, sse, count):
+    lib = _lib.load()
+    _lib.check(lib.dosx_sse2(_p(pg), _p(ps), _p(y), _p(sse), count, _stream()), "dosx_sse2")
+
+
+def loss_phonon_bwd(pg, ps, y, sse, beta, count_global, dpg, dps, loss, count):
+    lib = _lib.load()
+    _lib.check(lib.dosx_loss_phonon_bwd(_p(pg), _p(ps), _p(y), _p(sse), float(beta), float(count_global), _p(dpg), _p(dps),
+                                        _p(loss), count, _stream()), "dosx_loss_phonon_bwd")
+
+
+def loss_edos(pg, ps, y_ft, beta, B, S, B_global, dpg, dps, loss_partial):
+    lib = _lib.load()
+    _lib.check(lib.dosx_loss_edos(_p(pg), _p(ps), _p(y_ft), float(beta), B, S, B_global, _p(dpg), _p(dps), _p(loss_partial),
+                                  _stream()), "dosx_loss_edos")
+
+
+def adamw(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    lib = _lib.load()
+    _lib.check(lib.dosx_adamw(_p(p), _p(g), _p(m), _p(v), int(n), float(lr), float(beta1), float(beta2), float(eps),
+                              float(weight_decay), int(step), float(grad_scale), _stream()), "dosx_adamw")
+
+
+def fill(t: torch.Tensor, value: float):
+    lib = _lib.load()
+    _lib.check(lib.dosx_fill(t.data_ptr(), float(value), t.numel(), _stream()), "dosx_fill")
+
+
+def embed_rows(table, idx, out, rows, width):
+    lib = _lib.load()
+    _lib.check(lib.dosx_embed_rows(_p(table), _p(idx), _p(out), rows, width, _stream()), "dosx_embed_rows")
+
+
+def embed_rows_bwd(dout_ptr, ld, idx, dtable, rows, table_rows, width):
+    lib = _lib.load()
+    _lib.check(lib.dosx_embed_rows_bwd(dout_ptr, ld, _p(idx), _p(dtable), rows, table_rows, width, _stream()),
+               "dosx_embed_rows_bwd")
+
+
+def reduce_rows(src_ptr, ld_src, dst_ptr, ld_dst, n_out, n_red, stride_out, stride_red, width, accumulate=False):
+    lib = _lib.load()
+    _lib.check(lib.dosx_reduce_rows(src_ptr, ld_src, dst_ptr, ld_dst, n_out, n_red, stride_out, stride_red, width,
+                                    int(accumulate), _stream()), "dosx_reduce_rows")
+
+
+def act_bwd(dy, y, slope, out):
+    lib = _lib.load()
+    _lib.check(lib.dosx_act_bwd(_p(dy), _p(y), float(slope), _p(out), dy.numel(), _stream()), "dosx_act_bwd")

@@ -1,0 +1,282 @@
+/* dosx.h — C ABI of libdosx.so: the MI355X (gfx950) hot path of DOSTransformer.
+ *
+ * The reference (HeewoongNoh/DOSTransformer) is pure Python and has NO FFI / plugin
+ * boundary of its own; its hot path is a chain of implicit PyTorch /
+ * torch_scatter / PyG kernels.  This header is the boundary the build introduces:
+ * every entry point replaces a group of those implicit launches, and the Python
+ * modules in dostransformer_amd/ (same class names / ctor signatures / state_dict
+ * keys as the reference's embedder_phDOS, embedder_eDOS and layers packages) bind
+ * them through ctypes (see INTEGRATION.md for the stub).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is DEVICE memory unless noted;
+ *    all floating point data is fp32 row-major, all index data int32;
+ *  - nothing is allocated, freed or retained by the library: the caller passes
+ *    outputs and scratch ("partials") buffers;
+ *  - every call is asynchronous on the given hipStream_t, re-entrant and
+ *    graph-capturable (no hidden synchronisation, no host<->device copies);
+ *  - return value 0 on success, negative on error; dosx_last_error() gives a
+ *    thread-local message.
+ */
+#ifndef DOSX_H
+#define DOSX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dosx_stream_t; /* hipStream_t */
+
+/* Row indirection used for gathered operands and remapped outputs:
+ *   t = (r / d) * m + (r % d) * c + off ;  row = idx ? idx[t] : t
+ * identity: d = 1<<30, m = 0, c = 1, off = 0.  r % B: d=B,m=0,c=1.  r / B: d=B,m=1,c=0. */
+typedef struct DosxRowMap {
+  int32_t d, m, c, off;
+  const int32_t* idx;
+} DosxRowMap;
+
+/* One K-segment of a (virtually concatenated, row-gathered) matrix operand.
+ * Replaces torch.cat([x[row], x[col], edge_attr], 1) (DOSTransformer_phonon.py:166,194). */
+typedef struct DosxSeg {
+  const float* p;
+  int32_t ld;    /* row stride in floats */
+  int32_t width; /* columns taken from this segment */
+  DosxRowMap map;
+} DosxSeg;
+
+/* Prologue applied to the A operand while it is staged into LDS. */
+enum {
+  DOSX_PRO_NONE = 0,
+  DOSX_PRO_PRELU = 1,    /* a = z >= 0 ? z : alpha*z            (nn.PReLU, DOSTransformer_phonon.py:129) */
+  DOSX_PRO_LN_PRELU = 2, /* a = prelu(xhat*gamma + beta)          (LayerNorm+PReLU of Edge/NodeModel, :193,204) */
+  DOSX_PRO_ROWLN = 3     /* a = (x-mean[r])*rstd[r]*gamma + beta  (pre-norm LN, layers/transformer.py:141-142) */
+};
+
+/* Epilogues of dosx_gemm (all but PLAIN/BIAS_ACT need the whole row in one tile: N <= 512). */
+enum {
+  DOSX_EPI_BIAS_ACT = 0,     /* out = act(acc + bias) [+ res]; act: 0 none, 1 relu, 2 leaky(slope)   */
+  DOSX_EPI_LN = 1,           /* out = xhat = LN_noaffine(acc + bias); aux_out = rstd[M]              */
+  DOSX_EPI_PRELU_LN_BWD = 2, /* acc = dL/d prelu(y), y = xhat*g+b  ->  out = dL/dz (pre-LN)          */
+  DOSX_EPI_RELU_MASK = 3,    /* out = acc * (aux > 0)                                                 */
+  DOSX_EPI_ROWLN_BWD = 4,    /* acc = dL/d LN(x) -> out = res + dL/dx ; x = aux, stats = aux_stats    */
+  DOSX_EPI_PRELU_BWD = 5     /* out = acc * (aux >= 0 ? 1 : alpha); partial dalpha                    */
+};
+
+/* C[M,N] = epilogue( prologue(A)[M,K] * B ),  fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * w_layout 0: B = W^T with W[N,K] row-major  (nn.Linear forward,  y = x W^T + b)
+ * w_layout 1: B = W   with W[K,N] row-major  (nn.Linear backward, dx = dy W)         */
+typedef struct DosxGemm {
+  int32_t M, N, K;
+  int32_t nseg;
+  DosxSeg a[3];
+  int32_t pro;
+  const float* pro_gamma;
+  const float* pro_beta;
+  const float* pro_alpha; /* device scalar */
+  const float* pro_stats; /* [M,2] mean,rstd (ROWLN) */
+  const float* w;
+  int32_t ldw;
+  int32_t w_layout;
+  int32_t epi;
+  int32_t act;
+  float act_slope;
+  const float* bias;
+  float* out;
+  int32_t ldo;
+  DosxRowMap out_map;
+  const float* res;
+  int32_t ldr;
+  DosxRowMap res_map;
+  float* stats_out;   /* optional [M,2]: mean, rstd of the final output rows (needs N <= tile) */
+  float* aux_out;     /* EPI_LN: rstd [M] */
+  const float* aux;   /* backward epilogues: xhat / h / x / z, [M, ldaux] */
+  int32_t ldaux;
+  const float* aux_stats; /* rstd [M] (PRELU_LN_BWD) or [M,2] mean,rstd (ROWLN_BWD) */
+  const float* epi_gamma;
+  const float* epi_beta;
+  const float* epi_alpha;
+  float* partials;    /* per-workgroup partial sums: row wg = [dgamma(N) | dbeta(N) | dalpha] */
+  int32_t partial_ld;
+} DosxGemm;
+
+/* number of workgroup rows dosx_gemm writes into `partials`: ceil(M/32) for the row-wise (full-row)
+ * epilogues, ceil(M/32)*ceil(N/128) for the element-wise PRELU_BWD epilogue. */
+int dosx_gemm_partial_rows(int M, int N);
+int dosx_gemm(const DosxGemm* g, dosx_stream_t stream);
+
+/* dW partial slabs: slab[s][N][K] = sum_{m in split s} dY[m][n] * prologue(A)[m][k]
+ * (nn.Linear weight gradient), optional bias partial slab_bias[s][N] = sum_m dY[m][n].
+ * `nsplit` must come from dosx_wgrad_splits(). */
+typedef struct DosxWgrad {
+  int32_t M, N, K;
+  DosxSeg dy;        /* width = N */
+  int32_t nseg;
+  DosxSeg a[3];
+  int32_t pro;
+  const float* pro_gamma;
+  const float* pro_beta;
+  const float* pro_alpha;
+  const float* pro_stats;
+  float* slab;       /* [nsplit, N, K] */
+  float* slab_bias;  /* [nsplit, N] or NULL */
+  int32_t nsplit;
+} DosxWgrad;
+int dosx_wgrad_splits(int M, int N, int K);
+int dosx_wgrad(const DosxWgrad* g, dosx_stream_t stream);
+
+/* Batched deterministic reduction of partial slabs: dst[i] (+)= sum_s src[s*stride + i]. */
+typedef struct DosxReduceJob {
+  const float* src;
+  float* dst;
+  int32_t nsplit;
+  int32_t stride;
+  int32_t count;
+  int32_t accumulate; /* 0: overwrite dst, 1: add to dst */
+} DosxReduceJob;
+/* jobs: DEVICE array of n_jobs entries; max_count = max over jobs of count (host value). */
+int dosx_reduce_partials(const DosxReduceJob* jobs_dev, int n_jobs, int max_count, dosx_stream_t stream);
+
+/* a1: edge_attr[E,4] = smooth_cutoff(|v|/r_max) * [1, sqrt3 * v/max(|v|,1e-12)]
+ * (DOSTransformer_phonon.py:74-77; e3nn semantics restated in oracle/dos_oracle.py). */
+int dosx_edge_feat_sh1(const float* edge_vec, float* edge_attr, int E, float r_max, dosx_stream_t stream);
+
+/* a5 + a6: CSR segment reduction over destination-sorted edges (replaces torch_scatter
+ * scatter_mean / scatter_sum by `col`, DOSTransformer_phonon.py:209 / DOSTransformer.py:187)
+ *   agg[n]   = scale[n] * sum_{e in [rowptr[n], rowptr[n+1])} msg[e]       (scale NULL -> 1)
+ *   e_out[e] = e_in[e] + msg[e]   (edge residual, DOSTransformer_phonon.py:84; skipped if e_out NULL) */
+int dosx_segment_reduce(const float* msg, const int32_t* rowptr, const float* scale, float* agg,
+                        const float* e_in, float* e_out, int N, int E, int H, dosx_stream_t stream);
+
+/* backward of the aggregation + residual:  dmsg[e] = (de_new ? de_new[e] : 0) + scale[dst[e]] * dagg[dst[e]]
+ * dagg has row stride ld_dagg (it is a column block of the node-MLP input gradient). */
+int dosx_edge_grad_combine(const float* de_new, const float* dagg, int ld_dagg, const int32_t* dst,
+                           const float* scale, float* dmsg, int E, int H, dosx_stream_t stream);
+
+/* backward of the two gathers x[row], x[col] (the scatter-adds of SURVEY.md §2.2) fused with
+ * the node / edge residual gradients, atomic-free:
+ *   dx[n]      = dx_res[n] + dnode[n, 0:H]
+ *              + sum_{e in dst-seg(n)} dcat[e, H:2H] + sum_{j in src-seg(n)} dcat[perm_src[j], 0:H]
+ *   de_out[e]  = (de_new ? de_new[e] : 0) + dcat[e, 2H:3H]          (skipped if de_out NULL) */
+int dosx_gather_bwd(const float* dcat, const float* dnode, int ld_dnode, const float* dx_res,
+                    const int32_t* rowptr_dst, const int32_t* rowptr_src, const int32_t* perm_src,
+                    const float* de_new, float* dx, float* de_out, int N, int E, int H,
+                    dosx_stream_t stream);
+
+/* a7: node->graph sum pooling over contiguous node ranges (scatter_sum(x, batch),
+ * DOSTransformer_phonon.py:180) and its backward (broadcast add). */
+int dosx_graph_pool(const float* x, const int32_t* graph_ptr, float* out, int ld_out, int B, int H,
+                    dosx_stream_t stream);
+int dosx_graph_pool_bwd(const float* dpool, int ld_dpool, const int32_t* node_graph, float* dx, int N, int H,
+                        int accumulate, dosx_stream_t stream);
+
+/* a8 (+ the LN statistics of layer_norms[0] on keys): to_dense_batch + row normalisation.
+ *   kvhat[dense_row[n]] = (x[n]-mean)*rstd ; rstd_nodes[n] ; all other rows of kvhat = 0
+ * (to_dense_batch DOSTransformer_phonon.py:86-87; padded rows stay exact zeros so that
+ *  LayerNorm gives beta on them).  kvhat must be zero-filled by the caller
+ *  (dosx_fill) or pass zero_rows = total dense rows to let the kernel do it. */
+int dosx_dense_normalize(const float* x, const int32_t* dense_row, float* kvhat, float* rstd_nodes,
+                         int N, int H, int dense_rows, dosx_stream_t stream);
+/* backward: dx[n] (+)= rstd[n] * (g - mean(g) - xhat*mean(g*xhat)),  g = dkvhat[dense_row[n]] */
+int dosx_dense_normalize_bwd(const float* dkvhat, const float* kvhat, const float* rstd_nodes,
+                             const int32_t* dense_row, float* dx, int N, int H, int accumulate,
+                             dosx_stream_t stream);
+
+/* Row LayerNorm without affine (key/value side of self attention) and with affine. */
+int dosx_rownorm(const float* x, float* xhat, float* rstd, int M, int H, dosx_stream_t stream);
+int dosx_rownorm_bwd(const float* dxhat, const float* xhat, const float* rstd, float* dx, int M, int H,
+                     int accumulate, dosx_stream_t stream);
+/* y = LN(x)*gamma+beta (layers/transformer.py:76-77); saves xhat, rstd. */
+int dosx_layernorm(const float* x, const float* gamma, const float* beta, float* y, float* xhat, float* rstd,
+                   int M, int H, dosx_stream_t stream);
+/* dx = LNbwd(dy); partials: ceil(M/32) rows of [dgamma(H) | dbeta(H)] */
+int dosx_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dx,
+                       float* partials, int M, int H, dosx_stream_t stream);
+
+/* a9 + the attention half of a10: one pre-norm attention block
+ *   x1 = x + softmax_fp32( LN0(x) K^T * H^-1/2 ) K ,  K = kvhat*gamma0 + beta0   (K == V)
+ * (layers/transformer.py:131-138, layers/multihead_attention.py:68-74: no projections, no
+ *  mask, no heads).  Query row (s, bq) is at x + (s*q_stride_s + bq*q_stride_b)*H; output
+ *  row (s,bq) at s*Bq + bq; key row (j, bk) at j*Bk + bk with bk = bq % Bk. */
+typedef struct DosxAttn {
+  int32_t Sq, Bq, Nk, Bk, H;
+  int32_t q_stride_s, q_stride_b;
+  const float* x;      /* queries / residual */
+  const float* kvhat;  /* [Nk*Bk, H] normalised keys (no affine) */
+  const float* gamma0;
+  const float* beta0;
+  float* out;          /* [Sq*Bq, H] */
+  float* probs;        /* [Bq, Sq, Nk] saved softmax */
+  float* qstats;       /* [Sq*Bq, 2] mean, rstd of LN0 on the query rows */
+  float* out_stats;    /* optional [Sq*Bq, 2] mean, rstd of the OUTPUT rows (for the following LN1) */
+  /* backward only */
+  const float* dout;   /* [Sq*Bq, H] */
+  float* dx;           /* [Sq*Bq, H] = dout + LN0bwd(dq) */
+  float* dscores;      /* [Bq, Sq, Nk] scratch: dS */
+  float* dkvhat;       /* [Nk*Bk, H] (+)= */
+  int32_t dkv_accumulate;
+  float* partials_q;   /* [Bq * ceil(Sq/32)] rows of [dgamma(H) | dbeta(H)] */
+  float* partials_kv;  /* [Bk * ceil(Nk/32)] rows of [dgamma(H) | dbeta(H)] */
+} DosxAttn;
+int dosx_attention_fwd(const DosxAttn* a, dosx_stream_t stream);
+int dosx_attention_bwd(const DosxAttn* a, dosx_stream_t stream);
+
+/* out_layer (nn.Linear(H,1), DOSTransformer_phonon.py:101,115) fused with the encoder's final
+ * LayerNorm (layers/transformer.py:76-77) and the squeeze/transposed store:
+ *   y[r] = (xhat[r]*gamma+beta) . w + b ;  dos[(r % Bq) , r / Bq] = y[r]   (dos is [Bq, S]) */
+int dosx_ln_rowdot(const float* x, const float* gamma, const float* beta, const float* w, const float* b,
+                   float* xhat, float* rstd, float* dos, int S, int Bq, int H, dosx_stream_t stream);
+/* ddos [Bq,S] -> dx [S*Bq,H]; partials: ceil(M/32) rows of [dgamma(H) | dbeta(H) | dw(H) | db] */
+int dosx_ln_rowdot_bwd(const float* ddos, const float* xhat, const float* rstd, const float* gamma,
+                       const float* beta, const float* w, float* dx, float* partials, int S, int Bq, int H,
+                       dosx_stream_t stream);
+/* plain y[r] = act(x[r]) . w + b for the GNN-only variants' last layer (graphnetwork_phonon.py:26,70) */
+int dosx_rowdot(const float* x, const float* w, const float* b, float* dos, int S, int Bq, int H,
+                dosx_stream_t stream);
+int dosx_rowdot_bwd(const float* ddos, const float* x, const float* w, float* dx, float* partials, int S,
+                    int Bq, int H, dosx_stream_t stream);
+
+/* a14: losses of the callers, forward + gradient in one pass.
+ * phonon (main_phDOS.py:109-114): loss = sqrt(mean_all (pg-y)^2) + beta*sqrt(mean_all (ps-y)^2)
+ *   two-phase so that data-parallel ranks can all-reduce the two SSE scalars in between:
+ *   dosx_sse2 writes sse[0..1]; dosx_loss_phonon_bwd consumes (possibly all-reduced) sse and
+ *   `count` = global number of elements.
+ * eDOS (main_eDOS.py:111-123): loss = mean_b rmse_b(global) + beta * mean_b rmse_b(system),
+ *   target clamped at 0; `B_global` = number of crystals in the un-sharded batch. */
+int dosx_sse2(const float* pg, const float* ps, const float* y, float* sse, int count, dosx_stream_t stream);
+int dosx_loss_phonon_bwd(const float* pg, const float* ps, const float* y, const float* sse, float beta,
+                         double count_global, float* dpg, float* dps, float* loss, int count,
+                         dosx_stream_t stream);
+int dosx_loss_edos(const float* pg, const float* ps, const float* y_ft, float beta, int B, int S, int B_global,
+                   float* dpg, float* dps, float* loss_partial, dosx_stream_t stream);
+
+/* torch.optim.AdamW step on a flat buffer (main_eDOS.py:93,127): decoupled weight decay.
+ * `step` is the 1-based step count. */
+int dosx_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+               float eps, float weight_decay, int step, float grad_scale, dosx_stream_t stream);
+
+/* misc */
+int dosx_fill(float* p, float value, int64_t n, dosx_stream_t stream);
+/* out[r] = table[idx[r]] rows (prompt_token[g.system], DOSTransformer_phonon.py:105) and its backward
+ * (deterministic: one workgroup per table row scans idx). */
+int dosx_embed_rows(const float* table, const int32_t* idx, float* out, int rows, int width, dosx_stream_t stream);
+int dosx_embed_rows_bwd(const float* dout, int ld_dout, const int32_t* idx, float* dtable, int rows,
+                        int table_rows, int width, dosx_stream_t stream);
+/* dst[i, 0:width] (+)= sum_{j < n_red} src[(i*stride_out + j*stride_red), 0:width]
+ * Row reductions of the [S,B,H] layout: over the batch (gradient of the energy-embedding broadcast,
+ * DOSTransformer_phonon.py:143: n_out=S, n_red=B, stride_out=B, stride_red=1) or over the energy bins
+ * (gradient of graph.expand(51,...), :91: n_out=B, n_red=S, stride_out=1, stride_red=B). */
+int dosx_reduce_rows(const float* src, int ld_src, float* dst, int ld_dst, int n_out, int n_red, int stride_out,
+                     int stride_red, int width, int accumulate, dosx_stream_t stream);
+/* out = dy * (y > 0 ? 1 : slope): backward of F.leaky_relu (DOSTransformer_phonon.py:95) from its output. */
+int dosx_act_bwd(const float* dy, const float* y, float slope, float* out, int64_t n, dosx_stream_t stream);
+
+const char* dosx_last_error(void);
+int dosx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DOSX_H */
