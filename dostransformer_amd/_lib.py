@@ -73,7 +73,7 @@ class ReduceJob(C.Structure):
 class Attn(C.Structure):
     _fields_ = [
         ("Sq", C.c_int32), ("Bq", C.c_int32), ("Nk", C.c_int32), ("Bk", C.c_int32), ("H", C.c_int32),
-        ("q_stride_s", C.c_int32), ("q_stride_b", C.c_int32),
+        ("q_stride_s", C.c_int32), ("q_stride_b", C.c_int32), ("flags", C.c_int32),
         ("x", C.c_void_p), ("kvhat", C.c_void_p), ("gamma0", C.c_void_p), ("beta0", C.c_void_p),
         ("out", C.c_void_p), ("probs", C.c_void_p), ("qstats", C.c_void_p), ("out_stats", C.c_void_p),
         ("dout", C.c_void_p), ("dx", C.c_void_p), ("dscores", C.c_void_p), ("dkvhat", C.c_void_p),
@@ -85,7 +85,7 @@ class Attn(C.Structure):
 # name -> argtypes  (restype is int unless listed in _RESTYPES)
 _P, _I, _F, _L, _D = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_double
 _SIGS = {
-    "dosx_gemm_partial_rows": [_I, _I],
+    "dosx_gemm_partial_rows": [_I, _I, _I],
     "dosx_gemm": [C.POINTER(Gemm), _P],
     "dosx_wgrad_splits": [_I, _I, _I],
     "dosx_wgrad": [C.POINTER(Wgrad), _P],
@@ -137,6 +137,9 @@ def load() -> C.CDLL:
             f"or `make -C dostransformer_amd/csrc` (needs hipcc, --offload-arch=gfx950). "
             f"dostransformer_amd has no CPU fallback.")
     try:
+        # torch bundles its own HIP runtime (torch/lib/libamdhip64.so); it must be the one already in the
+        # process when libdosx.so is resolved, otherwise two runtimes coexist and ours sees no device.
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
         raise DosxUnavailable(f"cannot load {LIB_PATH}: {e}") from e

@@ -1,0 +1,70 @@
+"""Shared implementation of the four drop-in model classes (phonon / eDOS x DOSTransformer /
+Graphnetwork).  The public modules under ``embedder_phDOS`` / ``embedder_eDOS`` only fix the
+constructor signatures and parameter creation order of their reference counterparts."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import functional as Fn
+from ._fused import FusedModel
+
+
+class DOSTransformerBase(FusedModel):
+    """forward(g) -> (dos_global [B,S], x [N,H], dos_system [B,S])   (`DOSTransformer_phonon.py:66-119`)."""
+    _cfg: Fn.ModelCfg
+
+    def _check_train_flags(self):
+        if self.training and getattr(self, "_attn_drop", 0.0) > 0.0:
+            raise NotImplementedError("attn_drop > 0 is not implemented in the fused MI355X path "
+                                      "(reference default 0.0, utils.py:40)")
+
+    def _program_fwd(self, P, g, m):
+        dos, xL, ctx = Fn.dostransformer_fwd(P, self._cfg, g, m)
+        B = m.num_graphs
+        return dos[:B], xL, dos[B:], (ctx, dos)
+
+    def _program_bwd(self, P, G, m, saved, grads, sink):
+        ctx, dos = saved
+        dg, dx, ds = grads
+        B = m.num_graphs
+        ddos = torch.zeros_like(dos)
+        if dg is not None:
+            ddos[:B].copy_(dg)
+        if ds is not None:
+            ddos[B:].copy_(ds)
+        Fn.dostransformer_bwd(P, G, self._cfg, m, ctx, ddos, None if dx is None else dx.float().contiguous(), sink)
+
+    def forward(self, g):
+        self._check_train_flags()
+        return self._run(g)
+
+
+class GraphnetworkBase(FusedModel):
+    _cfg: Fn.ModelCfg
+    _returns_x: bool
+
+    def _extra_dead(self, g) -> Tuple[str, ...]:
+        # Encoder picks node_encoder or node_encoder_prompt by input width
+        # (graphnetwork_phonon.py:150-153, graphnetwork.py:96-99); the other one is dead for this run.
+        expected = 118 if self._cfg.kind == "phonon" else 200
+        width = g.x.shape[1] if g is not None else expected
+        unused = "GN_encoder.node_encoder_prompt" if width == expected else "GN_encoder.node_encoder"
+        return tuple(f"{unused}.{s}" for s in ("0.weight", "0.bias", "1.weight", "2.weight", "2.bias"))
+
+    def _program_fwd(self, P, g, m):
+        dos, xL, ctx = Fn.graphnetwork_fwd(P, self._cfg, g, m)
+        return (dos, xL, ctx) if self._returns_x else (dos, ctx)
+
+    def _program_bwd(self, P, G, m, saved, grads, sink):
+        ddos = grads[0]
+        dx = grads[1] if self._returns_x else None
+        if ddos is None:
+            ddos = torch.zeros(m.num_graphs, self._cfg.S, device=P["embeddings.weight"].device)
+        Fn.graphnetwork_bwd(P, G, self._cfg, m, saved, ddos.float().contiguous(),
+                            None if dx is None else dx.float().contiguous(), sink)
+
+    def forward(self, g):
+        out = self._run(g)
+        return out if self._returns_x else out[0]

@@ -223,8 +223,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const DosxAttn a) {
     return s < Sq ? a.x + ((size_t)s * a.q_stride_s + (size_t)bq * a.q_stride_b) * H : nullptr;
   }, tid);
   __syncthreads();
-  ln_rows_inplace(Qs, g.LDH, H, a.gamma0, a.beta0, a.qstats, s0, Sq, a.Bq, bq, tid);
-  __syncthreads();
+  if (!(a.flags & DOSX_ATTN_RAW_Q)) {
+    ln_rows_inplace(Qs, g.LDH, H, a.gamma0, a.beta0, a.qstats, s0, Sq, a.Bq, bq, tid);
+    __syncthreads();
+  }
 
   f32x16 sacc[MAX_KT];
   qk_product(sacc, Qs, g.LDH, KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, tid);
@@ -266,7 +268,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const DosxAttn a) {
     float* orow = a.out + ((size_t)s * a.Bq + bq) * H;
     float s1 = 0.f;
     for (int c = lane * 4; c < H; c += 256) {
-      const float4 v = f4add(ld4(Qs + lr * g.LDH + c), ld4(xr + c));
+      float4 v = ld4(Qs + lr * g.LDH + c);
+      if (!(a.flags & DOSX_ATTN_NO_RESIDUAL)) v = f4add(v, ld4(xr + c));
       st4(orow + c, v);
       st4(Qs + lr * g.LDH + c, v);
       s1 += v.x + v.y + v.z + v.w;
@@ -343,12 +346,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const DosxAttn a) {
   __syncthreads();
 
   // LN0 backward on the query rows + residual;  partial dgamma0 / dbeta0 (query side)
+  const bool raw_q = (a.flags & DOSX_ATTN_RAW_Q) != 0, no_res = (a.flags & DOSX_ATTN_NO_RESIDUAL) != 0;
   for (int c = lane; c < 2 * g.HP; c += 64) Pp[wave * 2 * g.HP + c] = 0.f;
   for (int i = 0; i < 8; ++i) {
     const int lr = wave * 8 + i, s = s0 + lr;
     if (s >= Sq) break;
     const float* xr = a.x + ((size_t)s * a.q_stride_s + (size_t)bq * a.q_stride_b) * H;
     const size_t orow = ((size_t)s * a.Bq + bq);
+    if (raw_q) {
+      for (int c = lane * 4; c < H; c += 256) {
+        float4 d = ld4(Ds + lr * g.LDH + c);
+        if (!no_res) d = f4add(d, ld4(a.dout + orow * H + c));
+        st4(a.dx + orow * H + c, d);
+      }
+      continue;
+    }
     const float mean = a.qstats[2 * orow], rstd = a.qstats[2 * orow + 1];
     float s1 = 0.f, s2 = 0.f;
     for (int c = lane * 4; c < H; c += 256) {
@@ -365,7 +377,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const DosxAttn a) {
     const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
     for (int c = lane * 4; c < H; c += 256) {
       const float4 xv = ld4(xr + c), d = ld4(Ds + lr * g.LDH + c), gm = ld4(a.gamma0 + c);
-      const float4 go = ld4(a.dout + orow * H + c);
+      float4 go = f4zero();
+      if (!no_res) go = ld4(a.dout + orow * H + c);
       const float4 xh = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
       st4(a.dx + orow * H + c,
           make_float4(go.x + rstd * (d.x * gm.x - m1 - xh.x * m2), go.y + rstd * (d.y * gm.y - m1 - xh.y * m2),
@@ -427,7 +440,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const DosxAttn a) {
       // recompute LN0(x) for the query rows in place (rows beyond Sq are zero rows: their P/dS are 0)
       for (int i = 0; i < 8; ++i) {
         const int lr = wave * 8 + i, s = s0 + lr;
-        if (s >= Sq) break;
+        if (s >= Sq || (a.flags & DOSX_ATTN_RAW_Q)) break;
         const size_t orow = (size_t)s * a.Bq + bq;
         const float mean = a.qstats[2 * orow], rstd = a.qstats[2 * orow + 1];
         float* row = Qs + lr * g.LDH;
@@ -495,7 +508,8 @@ int check_attn(const DosxAttn& a, const char* who) {
   DOSX_CHECK_ARG(a.H > 0 && (a.H & 3) == 0 && a.H <= 32 * 4 * MAX_CT, "%s: H=%d unsupported (multiple of 4, <= 256)", who, a.H);
   DOSX_CHECK_ARG(a.Nk > 0 && a.Nk <= 320, "%s: Nk=%d unsupported (1..320 keys per crystal)", who, a.Nk);
   DOSX_CHECK_ARG(a.Sq > 0 && a.Bq > 0 && a.Bk > 0 && a.Bq % a.Bk == 0, "%s: bad Sq/Bq/Bk = %d/%d/%d", who, a.Sq, a.Bq, a.Bk);
-  DOSX_CHECK_ARG(a.x && a.kvhat && a.gamma0 && a.beta0 && a.probs && a.qstats, "%s: null operand", who);
+  DOSX_CHECK_ARG(a.x && a.kvhat && a.gamma0 && a.beta0 && a.probs, "%s: null operand", who);
+  DOSX_CHECK_ARG(a.qstats || (a.flags & DOSX_ATTN_RAW_Q), "%s: qstats required unless RAW_Q", who);
   return 0;
 }
 

@@ -475,10 +475,10 @@ int gemm_bn(int N, int epi) {
 
 }  // namespace
 
-extern "C" int dosx_gemm_partial_rows(int M, int N) {
-  // row-wise epilogues use one N tile (N <= 512); the element-wise PRELU_BWD epilogue tiles N by 128.
-  // Callers size their partial buffers with this upper bound for either case.
-  return ceil_div(M, BM) * ceil_div(N, 128);
+extern "C" int dosx_gemm_partial_rows(int M, int N, int epi) {
+  // row-wise epilogues run as one N tile (N <= 512); the element-wise PRELU_BWD epilogue tiles N by 128.
+  if (epi == DOSX_EPI_PRELU_BWD) return ceil_div(M, BM) * ceil_div(N, 128);
+  return ceil_div(M, BM);
 }
 
 extern "C" int dosx_gemm(const DosxGemm* gp, dosx_stream_t stream) {

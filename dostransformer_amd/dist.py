@@ -1,0 +1,80 @@
+"""Data parallelism over the GPUs of one node: one process per GPU, ``torch.distributed`` with the
+``nccl`` backend (= RCCL over xGMI on ROCm); ``gloo`` on CPU for the tests.
+
+Crystals are independent units (no edge crosses graphs), so the batch shards with NO data-path
+collective; the only exchanges per step are
+  1. phonon loss: all-reduce of the two SSE scalars before backward — the reference's loss is ONE
+     rmse over all B*51 elements (`main_phDOS.py:109-114`), which does not decompose over shards;
+  2. one all-reduce (sum) of the flat fp32 gradient buffer.
+Shards must be padded to the GLOBAL ``n_max``: the reference attends over zero-padded atoms, so
+``Nmax`` changes the numerics.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence, Tuple
+
+import torch
+import torch.distributed as td
+
+from .batch import CrystalBatch, collate
+
+
+def shard_bounds(n_edges: Sequence[int], world: int) -> List[Tuple[int, int]]:
+    """Contiguous shards of the crystal list, balanced by edge count (the dominant cost)."""
+    n = len(n_edges)
+    if world <= 0:
+        raise ValueError("world must be positive")
+    total = float(sum(n_edges))
+    bounds, start, acc = [], 0, 0.0
+    for r in range(world):
+        remaining_ranks = world - r
+        if r == world - 1:
+            end = n
+        else:
+            target = (total - acc) / remaining_ranks
+            end, s = start, 0.0
+            # leave at least one crystal for each remaining rank when possible
+            max_end = n - (remaining_ranks - 1) if n >= world else n
+            while end < max_end and (s + n_edges[end] / 2.0 <= target or end == start):
+                s += n_edges[end]
+                end += 1
+            acc += s
+        bounds.append((start, end))
+        start = end
+    return bounds
+
+
+def shard_batch(crystals: Sequence[Dict[str, object]], world: int, rank: int, sort_edges: bool = True) -> CrystalBatch:
+    """This rank's shard of a global batch, padded to the global ``n_max``."""
+    n_max = max(int(c["x"].shape[0]) for c in crystals)
+    lo, hi = shard_bounds([int(c["edge_index"].shape[1]) for c in crystals], world)[rank]
+    if hi <= lo:
+        raise ValueError(f"rank {rank} of {world} got an empty shard ({len(crystals)} crystals)")
+    return collate(crystals[lo:hi], sort_edges=sort_edges, n_max=n_max)
+
+
+class DataParallel:
+    """The two collectives of a data-parallel step (see module doc)."""
+
+    def __init__(self, group=None):
+        if not td.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.group = group
+        self.world = td.get_world_size(group)
+        self.rank = td.get_rank(group)
+
+    def all_reduce_sum_scalars(self, sse: torch.Tensor, local_count: int) -> int:
+        """In-place sum of the SSE pair over ranks; returns the global element count."""
+        buf = torch.cat([sse.double(), torch.tensor([float(local_count)], dtype=torch.float64, device=sse.device)])
+        td.all_reduce(buf, op=td.ReduceOp.SUM, group=self.group)
+        sse.copy_(buf[:2].to(sse.dtype))
+        return int(round(float(buf[2])))
+
+    def global_count(self, local: int) -> int:
+        t = torch.tensor([float(local)], dtype=torch.float64,
+                         device="cuda" if td.get_backend(self.group) == "nccl" else "cpu")
+        td.all_reduce(t, op=td.ReduceOp.SUM, group=self.group)
+        return int(round(float(t[0])))
+
+    def all_reduce_grads(self, flat_grad: torch.Tensor) -> None:
+        td.all_reduce(flat_grad, op=td.ReduceOp.SUM, group=self.group)

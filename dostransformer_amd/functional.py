@@ -1,0 +1,481 @@
+"""Forward / backward programs of the DOSTransformer hot path, expressed as sequences of libdosx
+kernel launches.  Python here only sequences launches and owns buffer lifetimes; every flop is in
+``csrc/*.hip``.  Parameters (``P``) and their gradient buffers (``G``) are dicts keyed exactly like
+the reference ``state_dict()``.
+
+Layout conventions: every ``[seq, batch, H]`` tensor of the reference is a row-major ``[seq*batch, H]``
+matrix with row ``r = s*batch + b``; the two prediction branches (global / system) share one batch
+of ``2B`` "crystals" (branch-major inside the batch axis: bq = branch*B + b).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+from ._lib import Attn, Seg
+from .batch import GraphMeta
+from .ops import (ACT_LEAKY, ACT_RELU, EPI_LN, EPI_PRELU_BWD, EPI_PRELU_LN_BWD, EPI_RELU_MASK, EPI_ROWLN_BWD,
+                  PRO_LN_PRELU, PRO_PRELU, PRO_ROWLN, GradSink, rowmap, seg)
+
+Params = Dict[str, torch.Tensor]
+
+
+def _empty(dev, *shape):
+    return torch.empty(shape, device=dev, dtype=torch.float32)
+
+
+def _rows32(m: int) -> int:
+    return (m + 31) // 32
+
+
+class SegList:
+    """K-segments of a gathered/concatenated operand + the tensors that keep their memory alive."""
+
+    def __init__(self, segs: Sequence[Seg], keep: Sequence[torch.Tensor]):
+        self.segs = list(segs)
+        self.keep = list(keep)
+        self.K = sum(s.width for s in segs)
+
+
+def _wgrad_linear(sink: GradSink, G: Params, wkey: str, bkey: Optional[str], M: int, N: int, dy: Seg,
+                  segs: Sequence[Seg], **pro) -> None:
+    """dW (and db) of y = A W^T + b as split slabs + reduce jobs."""
+    if wkey not in G:
+        return
+    K = sum(s.width for s in segs)
+    ns = ops.wgrad_splits(M, N, K)
+    slab = sink.scratch(ns, N, K)
+    slab_b = sink.scratch(ns, N) if bkey is not None else None
+    ops.wgrad(M, N, dy, segs, slab, slab_b, ns, **pro)
+    sink.add(slab, 0, G[wkey], ns, N * K, N * K)
+    if bkey is not None:
+        sink.add(slab_b, 0, G[bkey], ns, N, N)
+
+
+# ------------------------------------------------------------------------------------------------
+# Encoder MLP: Linear -> PReLU -> Linear          (DOSTransformer_phonon.py:129-130,141-142)
+# ------------------------------------------------------------------------------------------------
+def mlp_prelu_fwd(P: Params, key: str, a: SegList, M: int, H: int):
+    dev = P[key + ".0.weight"].device
+    z = _empty(dev, M, H)
+    ops.gemm(M, H, a.segs, P[key + ".0.weight"], z, bias=P[key + ".0.bias"])
+    y = _empty(dev, M, H)
+    ops.gemm(M, H, [seg(z)], P[key + ".2.weight"], y, pro=PRO_PRELU, pro_alpha=P[key + ".1.weight"],
+             bias=P[key + ".2.bias"])
+    return y, (a, z, M, H)
+
+
+def mlp_prelu_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: GradSink, dy_seg: Optional[Seg] = None):
+    a, z, M, H = ctx
+    dev = z.device
+    alpha = P[key + ".1.weight"]
+    dys = dy_seg if dy_seg is not None else seg(dy)
+    _wgrad_linear(sink, G, key + ".2.weight", key + ".2.bias", M, H, dys, [seg(z)], pro=PRO_PRELU, pro_alpha=alpha)
+    rows = ops.gemm_partial_rows(M, H, EPI_PRELU_BWD)
+    part = sink.scratch(rows, 1)
+    dz = _empty(dev, M, H)
+    ops.gemm(M, H, [dys], P[key + ".2.weight"], dz, w_layout=1, epi=EPI_PRELU_BWD, aux=z, epi_alpha=alpha,
+             partials=part, partial_ld=1)
+    sink.add(part, 0, G[key + ".1.weight"], rows, 1, 1)
+    _wgrad_linear(sink, G, key + ".0.weight", key + ".0.bias", M, H, seg(dz), a.segs)
+
+
+# ------------------------------------------------------------------------------------------------
+# Edge / Node MLP: Linear -> LayerNorm -> PReLU -> Linear     (DOSTransformer_phonon.py:193,204)
+# ------------------------------------------------------------------------------------------------
+def mlp_ln_fwd(P: Params, key: str, a: SegList, M: int, H: int, res: Optional[torch.Tensor] = None):
+    dev = P[key + ".0.weight"].device
+    xhat = _empty(dev, M, 2 * H)
+    rstd = _empty(dev, M)
+    ops.gemm(M, 2 * H, a.segs, P[key + ".0.weight"], xhat, bias=P[key + ".0.bias"], epi=EPI_LN, aux_out=rstd)
+    y = _empty(dev, M, H)
+    ops.gemm(M, H, [seg(xhat)], P[key + ".3.weight"], y, pro=PRO_LN_PRELU, pro_gamma=P[key + ".1.weight"],
+             pro_beta=P[key + ".1.bias"], pro_alpha=P[key + ".2.weight"], bias=P[key + ".3.bias"], res=res)
+    return y, (a, xhat, rstd, M, H)
+
+
+def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: GradSink) -> torch.Tensor:
+    """Returns dL/d(concatenated input) [M, K_in]."""
+    a, xhat, rstd, M, H = ctx
+    dev = xhat.device
+    gam, bet, alpha = P[key + ".1.weight"], P[key + ".1.bias"], P[key + ".2.weight"]
+    _wgrad_linear(sink, G, key + ".3.weight", key + ".3.bias", M, H, seg(dy), [seg(xhat)], pro=PRO_LN_PRELU,
+                  pro_gamma=gam, pro_beta=bet, pro_alpha=alpha)
+    rows = _rows32(M)
+    pld = 4 * H + 1
+    part = sink.scratch(rows, pld)
+    dz = _empty(dev, M, 2 * H)
+    ops.gemm(M, 2 * H, [seg(dy)], P[key + ".3.weight"], dz, w_layout=1, epi=EPI_PRELU_LN_BWD, aux=xhat,
+             aux_stats=rstd, epi_gamma=gam, epi_beta=bet, epi_alpha=alpha, partials=part, partial_ld=pld)
+    sink.add(part, 0, G[key + ".1.weight"], rows, pld, 2 * H)
+    sink.add(part, 2 * H, G[key + ".1.bias"], rows, pld, 2 * H)
+    sink.add(part, 4 * H, G[key + ".2.weight"], rows, pld, 1)
+    _wgrad_linear(sink, G, key + ".0.weight", key + ".0.bias", M, 2 * H, seg(dz), a.segs)
+    dcat = _empty(dev, M, a.K)
+    ops.gemm(M, a.K, [seg(dz)], P[key + ".0.weight"], dcat, w_layout=1)
+    return dcat
+
+
+# ------------------------------------------------------------------------------------------------
+# Message passing stack       (DOSTransformer_phonon.py:81-84,148-171 / DOSTransformer.py:56-59)
+# ------------------------------------------------------------------------------------------------
+def gnn_fwd(P: Params, m: GraphMeta, x: torch.Tensor, e: torch.Tensor, L: int, mean: bool, H: int):
+    N, E = m.num_nodes, m.num_edges
+    dev = x.device
+    scale = m.inv_deg if mean else None
+    ctxs = []
+    for l in range(L):
+        pre = f"stacked_processor.{l}"
+        a_e = SegList([seg(x, rmap=rowmap(idx=m.src)), seg(x, rmap=rowmap(idx=m.dst)), seg(e)], [x, e])
+        msg, cxe = mlp_ln_fwd(P, pre + ".edge_model.edge_mlp", a_e, E, H)
+        agg = _empty(dev, N, H)
+        last = l == L - 1                       # the last layer's edge update is dead
+        e_new = None if last else _empty(dev, E, H)
+        ops.segment_reduce(msg, m.rowptr_dst, scale, agg, e, e_new, N, E, H)
+        a_n = SegList([seg(x), seg(agg)], [x, agg])
+        x_new, cxn = mlp_ln_fwd(P, pre + ".node_model.node_mlp_2", a_n, N, H, res=x)
+        ctxs.append((cxe, cxn))
+        x, e = x_new, e_new
+    return x, ctxs
+
+
+def gnn_bwd(P: Params, G: Params, m: GraphMeta, ctxs, dx: torch.Tensor, sink: GradSink, L: int, mean: bool, H: int):
+    N, E = m.num_nodes, m.num_edges
+    dev = dx.device
+    scale = m.inv_deg if mean else None
+    de = None
+    for l in reversed(range(L)):
+        pre = f"stacked_processor.{l}"
+        cxe, cxn = ctxs[l]
+        dcat_n = mlp_ln_bwd(P, G, pre + ".node_model.node_mlp_2", cxn, dx, sink)          # [N, 2H]
+        dmsg = _empty(dev, E, H)
+        ops.edge_grad_combine(de, dcat_n.data_ptr() + 4 * H, 2 * H, m.dst, scale, dmsg, E, H)
+        dcat_e = mlp_ln_bwd(P, G, pre + ".edge_model.edge_mlp", cxe, dmsg, sink)          # [E, 3H]
+        dx_old = _empty(dev, N, H)
+        de_old = _empty(dev, E, H)
+        ops.gather_bwd(dcat_e, dcat_n.data_ptr(), 2 * H, dx, m.rowptr_dst, m.rowptr_src, m.perm_src, de, dx_old,
+                       de_old, N, E, H)
+        dx, de = dx_old, de_old
+    return dx, de
+
+
+# ------------------------------------------------------------------------------------------------
+# TransformerEncoder      (layers/transformer.py:46-79,120-157; layers/multihead_attention.py:49-76)
+# ------------------------------------------------------------------------------------------------
+def _attn_desc(Sq, Bq, Nk, Bk, H, qs, qb, x, kvhat, gam, bet) -> Attn:
+    a = Attn()
+    a.Sq, a.Bq, a.Nk, a.Bk, a.H = Sq, Bq, Nk, Bk, H
+    a.q_stride_s, a.q_stride_b, a.flags = qs, qb, 0
+    a.x, a.kvhat, a.gamma0, a.beta0 = x.data_ptr(), kvhat.data_ptr(), gam.data_ptr(), bet.data_ptr()
+    return a
+
+
+def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int, qb: int, kvhat: torch.Tensor,
+                Nk: int, Bk: int, H: int, T: int, final_ln: bool = True):
+    """x: query rows (row (s,bq) at (s*qs + bq*qb)); kvhat: [Nk*Bk, H] normalised keys (stale across layers)."""
+    dev = kvhat.device
+    rows = Sq * Bq
+    lay = []
+    for t in range(T):
+        lp = f"{pre}.layers.{t}"
+        g0, b0 = P[lp + ".layer_norms.0.weight"], P[lp + ".layer_norms.0.bias"]
+        x1 = _empty(dev, rows, H)
+        probs = _empty(dev, Bq, Sq, Nk)
+        qstats = _empty(dev, rows, 2)
+        st1 = _empty(dev, rows, 2)
+        a = _attn_desc(Sq, Bq, Nk, Bk, H, qs, qb, x, kvhat, g0, b0)
+        a.out, a.probs, a.qstats, a.out_stats = x1.data_ptr(), probs.data_ptr(), qstats.data_ptr(), st1.data_ptr()
+        ops.attention_fwd(a)
+        h = _empty(dev, rows, 4 * H)
+        ops.gemm(rows, 4 * H, [seg(x1)], P[lp + ".fc1.weight"], h, pro=PRO_ROWLN,
+                 pro_gamma=P[lp + ".layer_norms.1.weight"], pro_beta=P[lp + ".layer_norms.1.bias"], pro_stats=st1,
+                 bias=P[lp + ".fc1.bias"], act=ACT_RELU)
+        x2 = _empty(dev, rows, H)
+        ops.gemm(rows, H, [seg(h)], P[lp + ".fc2.weight"], x2, bias=P[lp + ".fc2.bias"], res=x1)
+        lay.append((x, qs, qb, x1, probs, qstats, st1, h))
+        x, qs, qb = x2, Bq, 1
+    fin = None
+    if final_ln:
+        y = _empty(dev, rows, H)
+        xhat = _empty(dev, rows, H)
+        rstd = _empty(dev, rows)
+        ops.layernorm(x, P[pre + ".layer_norm.weight"], P[pre + ".layer_norm.bias"], y, xhat, rstd, rows, H)
+        fin = (xhat, rstd)
+        x = y
+    return x, (lay, fin, Sq, Bq, Nk, Bk, H, T, kvhat)
+
+
+def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: torch.Tensor, dkvhat: torch.Tensor, sink: GradSink):
+    """dy: grad of the encoder output (after the final LN if there is one).  Accumulates into dkvhat.
+    Returns the gradient w.r.t. the (expanded [Sq*Bq, H]) query input."""
+    lay, fin, Sq, Bq, Nk, Bk, H, T, kvhat = ctx
+    dev = kvhat.device
+    rows = Sq * Bq
+    r32 = _rows32(rows)
+    dx = dy
+    if fin is not None:
+        xhat, rstd = fin
+        part = sink.scratch(r32, 2 * H)
+        dx = _empty(dev, rows, H)
+        ops.layernorm_bwd(dy, xhat, rstd, P[pre + ".layer_norm.weight"], dx, part, rows, H)
+        sink.add(part, 0, G[pre + ".layer_norm.weight"], r32, 2 * H, H)
+        sink.add(part, H, G[pre + ".layer_norm.bias"], r32, 2 * H, H)
+    nqt, nkt = (Sq + 31) // 32, (Nk + 31) // 32
+    for t in reversed(range(T)):
+        lp = f"{pre}.layers.{t}"
+        x_in, qs, qb, x1, probs, qstats, st1, h = lay[t]
+        g1, b1 = P[lp + ".layer_norms.1.weight"], P[lp + ".layer_norms.1.bias"]
+        g0, b0 = P[lp + ".layer_norms.0.weight"], P[lp + ".layer_norms.0.bias"]
+        # fc2
+        _wgrad_linear(sink, G, lp + ".fc2.weight", lp + ".fc2.bias", rows, H, seg(dx), [seg(h)])
+        dh = _empty(dev, rows, 4 * H)
+        ops.gemm(rows, 4 * H, [seg(dx)], P[lp + ".fc2.weight"], dh, w_layout=1, epi=EPI_RELU_MASK, aux=h)
+        # fc1 (+ LN1 backward + residual)
+        _wgrad_linear(sink, G, lp + ".fc1.weight", lp + ".fc1.bias", rows, 4 * H, seg(dh), [seg(x1)], pro=PRO_ROWLN,
+                      pro_gamma=g1, pro_beta=b1, pro_stats=st1)
+        part = sink.scratch(r32, 2 * H)
+        dx1 = _empty(dev, rows, H)
+        ops.gemm(rows, H, [seg(dh)], P[lp + ".fc1.weight"], dx1, w_layout=1, epi=EPI_ROWLN_BWD, aux=x1, aux_stats=st1,
+                 epi_gamma=g1, res=dx, partials=part, partial_ld=2 * H)
+        sink.add(part, 0, G[lp + ".layer_norms.1.weight"], r32, 2 * H, H)
+        sink.add(part, H, G[lp + ".layer_norms.1.bias"], r32, 2 * H, H)
+        # attention (+ LN0 backward on the query side + residual); key side accumulates into dkvhat
+        npart = Bq * nqt + Bk * nkt
+        part = sink.scratch(npart, 2 * H)
+        dxin = _empty(dev, rows, H)
+        dsc = _empty(dev, Bq, Sq, Nk)
+        a = _attn_desc(Sq, Bq, Nk, Bk, H, qs, qb, x_in, kvhat, g0, b0)
+        a.probs, a.qstats = probs.data_ptr(), qstats.data_ptr()
+        a.dout, a.dx, a.dscores, a.dkvhat, a.dkv_accumulate = dx1.data_ptr(), dxin.data_ptr(), dsc.data_ptr(), \
+            dkvhat.data_ptr(), 1
+        a.partials_q = part.data_ptr()
+        a.partials_kv = part.data_ptr() + 4 * Bq * nqt * 2 * H
+        ops.attention_bwd(a)
+        sink.add(part, 0, G[lp + ".layer_norms.0.weight"], npart, 2 * H, H)
+        sink.add(part, H, G[lp + ".layer_norms.0.bias"], npart, 2 * H, H)
+        dx = dxin
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------
+# Full models
+# ------------------------------------------------------------------------------------------------
+class ModelCfg:
+    def __init__(self, kind: str, n_layers: int, n_t: int, hidden: int, n_atom: int, n_bond: int, bins: int,
+                 mean: bool, prompt_key: str):
+        self.kind, self.L, self.T, self.H = kind, n_layers, n_t, hidden
+        self.Fa, self.Fb, self.S, self.mean, self.prompt_key = n_atom, n_bond, bins, mean, prompt_key
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
+
+
+def _edge_inputs(cfg: ModelCfg, g, m: GraphMeta):
+    """Edge features in the kernels' (destination-sorted) edge order."""
+    if cfg.kind == "phonon":
+        vec = _f32(g.edge_vec)
+        if m.edge_perm is not None:
+            vec = vec[m.edge_perm]
+        return ops.edge_feat_sh1(vec, 4.0)            # r_max = 4 (DOSTransformer_phonon.py:77)
+    ea = _f32(g.edge_attr)
+    if m.edge_perm is not None:
+        ea = ea[m.edge_perm]
+    return ea
+
+
+def gnn_trunk_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta, node_key: str = "GN_encoder.node_encoder"):
+    """Encoder + L processors (+ eDOS global encoder).  Returns x_L [N,H], u [B,H] or None, ctx."""
+    H, N, E, B = cfg.H, m.num_nodes, m.num_edges, m.num_graphs
+    xin = _f32(g.x)
+    ea = _edge_inputs(cfg, g, m)
+    x0, cn = mlp_prelu_fwd(P, node_key, SegList([seg(xin)], [xin]), N, H)
+    e0, ce = mlp_prelu_fwd(P, "GN_encoder.edge_encoder", SegList([seg(ea)], [ea]), E, H)
+    u, cu = None, None
+    if cfg.kind == "edos":
+        glob = _f32(g.glob).reshape(B, 2)
+        u, cu = mlp_prelu_fwd(P, "GN_encoder.global_encoder", SegList([seg(glob)], [glob]), B, H)
+    xL, cg = gnn_fwd(P, m, x0, e0, cfg.L, cfg.mean, H)
+    return xL, u, (cn, ce, cu, cg, node_key)
+
+
+def gnn_trunk_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, dxL: torch.Tensor, du_seg: Optional[Seg],
+                  sink: GradSink):
+    cn, ce, cu, cg, node_key = ctx
+    dx0, de0 = gnn_bwd(P, G, m, cg, dxL, sink, cfg.L, cfg.mean, cfg.H)
+    mlp_prelu_bwd(P, G, node_key, cn, dx0, sink)
+    mlp_prelu_bwd(P, G, "GN_encoder.edge_encoder", ce, de0, sink)
+    if cu is not None and du_seg is not None:
+        mlp_prelu_bwd(P, G, "GN_encoder.global_encoder", cu, None, sink, dy_seg=du_seg)
+
+
+def decoder_fwd(P: Params, cfg: ModelCfg, m: GraphMeta, xL: torch.Tensor, u: Optional[torch.Tensor]):
+    """GN_decoder: Linear on sum-pooled nodes (phonon) / on cat[u, pooled] (eDOS)."""
+    H, B = cfg.H, m.num_graphs
+    dev = xL.device
+    pooled = _empty(dev, B, H)
+    ops.graph_pool(xL, m.graph_ptr, pooled.data_ptr(), H, B, H)
+    segs = SegList([seg(pooled)], [pooled]) if u is None else SegList([seg(u), seg(pooled)], [u, pooled])
+    graph = _empty(dev, B, H)
+    ops.gemm(B, H, segs.segs, P["GN_decoder.mlp.0.weight"], graph, bias=P["GN_decoder.mlp.0.bias"])
+    return graph, segs
+
+
+def decoder_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, segs: SegList, dgraph: torch.Tensor, dxL: torch.Tensor,
+                sink: GradSink) -> Optional[Seg]:
+    """Adds the pooled-node gradient into dxL; returns the Seg of du (eDOS) or None."""
+    H, B, N = cfg.H, m.num_graphs, m.num_nodes
+    dev = dgraph.device
+    _wgrad_linear(sink, G, "GN_decoder.mlp.0.weight", "GN_decoder.mlp.0.bias", B, H, seg(dgraph), segs.segs)
+    K = segs.K
+    dcat = _empty(dev, B, K)
+    ops.gemm(B, K, [seg(dgraph)], P["GN_decoder.mlp.0.weight"], dcat, w_layout=1)
+    ops.graph_pool_bwd(dcat.data_ptr() + 4 * (K - H), K, m.node_graph, dxL, N, H, True)
+    sink._keep.append(dcat)
+    return seg(dcat, width=H, col=0) if K == 2 * H else None
+
+
+def dostransformer_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta):
+    """Forward of DOSTransformer_phonon / DOSTransformer (DOSTransformer_phonon.py:66-119,
+    DOSTransformer.py:45-93).  Returns (dos [2B,S] : rows [0,B) global, [B,2B) system; x_L; ctx)."""
+    H, S, T, B, N = cfg.H, cfg.S, cfg.T, m.num_graphs, m.num_nodes
+    nmax = m.n_max
+    dev = P["embeddings.weight"].device
+    xL, u, ctrunk = gnn_trunk_fwd(P, cfg, g, m)
+    # to_dense_batch + the (parameter-free part of the) key LayerNorm, shared by every cross attention
+    kvhat = _empty(dev, nmax * B, H)
+    rstd_n = _empty(dev, N)
+    ops.dense_normalize(xL, m.dense_row, kvhat, rstd_n, N, H, nmax * B)
+    emb = P["embeddings.weight"]
+    E1, c1 = encoder_fwd(P, "transformer", emb, S, B, 1, 0, kvhat, nmax, B, H, T)
+    graph, dec_segs = decoder_fwd(P, cfg, m, xL, u)
+    sysidx = g.system.to(torch.int32).contiguous()
+    hp = H // 2
+    prow = _empty(dev, B, hp)
+    ops.embed_rows(P[cfg.prompt_key], sysidx, prow, B, hp)
+    dosin = _empty(dev, S * 2 * B, H)
+    modB = rowmap(d=B, m=0, c=1)
+    a_g = SegList([seg(E1), seg(graph, rmap=modB)], [E1, graph])
+    a_s = SegList([seg(E1), seg(graph, rmap=modB), seg(prow, rmap=modB)], [E1, graph, prow])
+    ops.gemm(S * B, H, a_g.segs, P["fc.weight"], dosin, bias=P["fc.bias"], act=ACT_LEAKY, act_slope=0.01,
+             out_map=rowmap(d=B, m=2 * B, c=1, off=0))
+    ops.gemm(S * B, H, a_s.segs, P["fc_prompt.weight"], dosin, bias=P["fc_prompt.bias"], act=ACT_LEAKY,
+             act_slope=0.01, out_map=rowmap(d=B, m=2 * B, c=1, off=B))
+    kvs = _empty(dev, S * 2 * B, H)
+    rstd_s = _empty(dev, S * 2 * B)
+    ops.rownorm(dosin, kvs, rstd_s, S * 2 * B, H)
+    hs, c2 = encoder_fwd(P, "transformer_self", dosin, S, 2 * B, 2 * B, 1, kvs, S, 2 * B, H, T)
+    hsrc, c3 = encoder_fwd(P, "transformer_source", hs, S, 2 * B, 2 * B, 1, kvhat, nmax, B, H, T, final_ln=False)
+    xhat_f = _empty(dev, S * 2 * B, H)
+    rstd_f = _empty(dev, S * 2 * B)
+    dos = _empty(dev, 2 * B, S)
+    ops.ln_rowdot(hsrc, P["transformer_source.layer_norm.weight"], P["transformer_source.layer_norm.bias"],
+                  P["out_layer.weight"], P["out_layer.bias"], xhat_f, rstd_f, dos, S, 2 * B, H)
+    ctx = (ctrunk, kvhat, rstd_n, c1, dec_segs, sysidx, prow, dosin, a_g, a_s, kvs, rstd_s, c2, c3, xhat_f, rstd_f, xL)
+    return dos, xL, ctx
+
+
+def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, ddos: torch.Tensor,
+                       dx_ext: Optional[torch.Tensor], sink: GradSink) -> None:
+    """Backward; ddos [2B,S] (rows [0,B): d dos_global, [B,2B): d dos_system); dx_ext: optional
+    gradient w.r.t. the returned node embeddings.  Writes every live parameter gradient into G."""
+    (ctrunk, kvhat, rstd_n, c1, dec_segs, sysidx, prow, dosin, a_g, a_s, kvs, rstd_s, c2, c3, xhat_f, rstd_f, xL) = ctx
+    H, S, B, N = cfg.H, cfg.S, m.num_graphs, m.num_nodes
+    nmax = m.n_max
+    dev = ddos.device
+    rows2 = S * 2 * B
+    r32 = _rows32(rows2)
+    pld = 3 * H + 1
+    part = sink.scratch(r32, pld)
+    dx = _empty(dev, rows2, H)
+    gf, bf = P["transformer_source.layer_norm.weight"], P["transformer_source.layer_norm.bias"]
+    ops.ln_rowdot_bwd(ddos, xhat_f, rstd_f, gf, bf, P["out_layer.weight"], dx, part, S, 2 * B, H)
+    sink.add(part, 0, G["transformer_source.layer_norm.weight"], r32, pld, H)
+    sink.add(part, H, G["transformer_source.layer_norm.bias"], r32, pld, H)
+    sink.add(part, 2 * H, G["out_layer.weight"], r32, pld, H)
+    sink.add(part, 3 * H, G["out_layer.bias"], r32, pld, 1)
+    dkv = torch.zeros(nmax * B, H, device=dev, dtype=torch.float32)
+    dhs = encoder_bwd(P, G, "transformer_source", c3, dx, dkv, sink)
+    dkvs = torch.zeros(rows2, H, device=dev, dtype=torch.float32)
+    ddosin = encoder_bwd(P, G, "transformer_self", c2, dhs, dkvs, sink)
+    ops.rownorm_bwd(dkvs, kvs, rstd_s, ddosin, rows2, H, True)
+    dpre = _empty(dev, rows2, H)
+    ops.act_bwd(ddosin, dosin, 0.01, dpre)
+    map0, map1 = rowmap(d=B, m=2 * B, c=1, off=0), rowmap(d=B, m=2 * B, c=1, off=B)
+    _wgrad_linear(sink, G, "fc.weight", "fc.bias", S * B, H, seg(dpre, rmap=map0), a_g.segs)
+    _wgrad_linear(sink, G, "fc_prompt.weight", "fc_prompt.bias", S * B, H, seg(dpre, rmap=map1), a_s.segs)
+    Wfc, Wfp = P["fc.weight"], P["fc_prompt.weight"]
+    dE1 = _empty(dev, S * B, H)
+    ops.gemm(S * B, H, [seg(dpre, rmap=map0)], Wfc[:, :H], dE1, w_layout=1)
+    ops.gemm(S * B, H, [seg(dpre, rmap=map1)], Wfp[:, :H], dE1, w_layout=1, res=dE1)
+    # graph / prompt inputs are constant over the energy axis: reduce over s first, then a [2B,H] GEMM
+    R = _empty(dev, 2 * B, H)
+    ops.reduce_rows(dpre.data_ptr(), H, R.data_ptr(), H, 2 * B, S, 1, 2 * B, H)
+    dgraph = _empty(dev, B, H)
+    ops.gemm(B, H, [seg(R[:B])], Wfc[:, H:2 * H], dgraph, w_layout=1)
+    ops.gemm(B, H, [seg(R[B:])], Wfp[:, H:2 * H], dgraph, w_layout=1, res=dgraph)
+    hp = H // 2
+    dprow = _empty(dev, B, hp)
+    ops.gemm(B, hp, [seg(R[B:])], Wfp[:, 2 * H:], dprow, w_layout=1)
+    ops.embed_rows_bwd(dprow.data_ptr(), hp, sysidx, G[cfg.prompt_key], B, G[cfg.prompt_key].shape[0], hp)
+    # first encoder (queries = energy embeddings broadcast over the batch)
+    dX1 = encoder_bwd(P, G, "transformer", c1, dE1, dkv, sink)
+    ops.reduce_rows(dX1.data_ptr(), H, G["embeddings.weight"].data_ptr(), H, S, B, B, 1, H)
+    # node embeddings: dense keys + pooled decoder input (+ external grad on the returned x)
+    dxL = _empty(dev, N, H)
+    ops.dense_normalize_bwd(dkv, kvhat, rstd_n, m.dense_row, dxL, N, H, False)
+    du_seg = decoder_bwd(P, G, cfg, m, dec_segs, dgraph, dxL, sink)
+    if dx_ext is not None:
+        dxL.add_(dx_ext)
+    gnn_trunk_bwd(P, G, cfg, m, ctrunk, dxL, du_seg, sink)
+    sink.flush()
+
+
+# ---- GNN-only variants (graphnetwork_phonon.py:48-72, graphnetwork.py:26-43) -----------------------
+def graphnetwork_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta):
+    H, S, B = cfg.H, cfg.S, m.num_graphs
+    dev = P["embeddings.weight"].device
+    expected = 118 if cfg.kind == "phonon" else 200          # graphnetwork_phonon.py:150-153 / graphnetwork.py:96-99
+    node_key = "GN_encoder.node_encoder" if g.x.shape[1] == expected else "GN_encoder.node_encoder_prompt"
+    xL, u, ctrunk = gnn_trunk_fwd(P, cfg, g, m, node_key)
+    graph, dec_segs = decoder_fwd(P, cfg, m, xL, u)
+    emb = P["embeddings.weight"]
+    a = SegList([seg(emb, rmap=rowmap(d=B, m=1, c=0)), seg(graph, rmap=rowmap(d=B, m=0, c=1))], [emb, graph])
+    hid = _empty(dev, S * B, H)
+    ops.gemm(S * B, H, a.segs, P["out_layer.0.weight"], hid, bias=P["out_layer.0.bias"], act=ACT_LEAKY, act_slope=0.01)
+    dos = _empty(dev, B, S)
+    ops.rowdot(hid, P["out_layer.2.weight"], P["out_layer.2.bias"], dos, S, B, H)
+    return dos, xL, (ctrunk, dec_segs, a, hid, xL)
+
+
+def graphnetwork_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, ddos: torch.Tensor,
+                     dx_ext: Optional[torch.Tensor], sink: GradSink) -> None:
+    ctrunk, dec_segs, a, hid, xL = ctx
+    H, S, B, N = cfg.H, cfg.S, m.num_graphs, m.num_nodes
+    dev = ddos.device
+    rows = S * B
+    r32 = _rows32(rows)
+    part = sink.scratch(r32, H + 1)
+    dhid = _empty(dev, rows, H)
+    ops.rowdot_bwd(ddos, hid, P["out_layer.2.weight"], dhid, part, S, B, H)
+    sink.add(part, 0, G["out_layer.2.weight"], r32, H + 1, H)
+    sink.add(part, H, G["out_layer.2.bias"], r32, H + 1, 1)
+    dpre = _empty(dev, rows, H)
+    ops.act_bwd(dhid, hid, 0.01, dpre)
+    _wgrad_linear(sink, G, "out_layer.0.weight", "out_layer.0.bias", rows, H, seg(dpre), a.segs)
+    W0 = P["out_layer.0.weight"]
+    Rs = _empty(dev, S, H)
+    ops.reduce_rows(dpre.data_ptr(), H, Rs.data_ptr(), H, S, B, B, 1, H)          # sum over the batch
+    ops.gemm(S, H, [seg(Rs)], W0[:, :H], G["embeddings.weight"], w_layout=1)
+    Rb = _empty(dev, B, H)
+    ops.reduce_rows(dpre.data_ptr(), H, Rb.data_ptr(), H, B, S, 1, B, H)          # sum over the energy bins
+    dgraph = _empty(dev, B, H)
+    ops.gemm(B, H, [seg(Rb)], W0[:, H:], dgraph, w_layout=1)
+    dxL = torch.zeros(N, H, device=dev, dtype=torch.float32)
+    du_seg = decoder_bwd(P, G, cfg, m, dec_segs, dgraph, dxL, sink)
+    if dx_ext is not None:
+        dxL.add_(dx_ext)
+    gnn_trunk_bwd(P, G, cfg, m, ctrunk, dxL, du_seg, sink)
+    sink.flush()

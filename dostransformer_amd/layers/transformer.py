@@ -1,0 +1,144 @@
+"""Drop-in for the reference's ``layers/transformer.py`` on MI355X: pre-norm encoder whose layers
+re-use the ORIGINAL keys/values (`transformer.py:72-73`) and share ``layer_norms[0]`` between q, k
+and v (`:131-134`).  Forward/backward run as the libdosx encoder program (``functional.encoder_*``).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+
+from .. import functional as Fn
+from .. import ops
+from .multihead_attention import MultiheadAttention
+
+
+def Linear(in_features, out_features, bias=True):
+    m = nn.Linear(in_features, out_features, bias)
+    nn.init.xavier_uniform_(m.weight)
+    if bias:
+        nn.init.constant_(m.bias, 0.)
+    return m
+
+
+def LayerNorm(embedding_dim):
+    return nn.LayerNorm(embedding_dim)
+
+
+class TransformerEncoderLayer(nn.Module):
+    """Parameter layout of `transformer.py:98-118`; executed by the enclosing TransformerEncoder."""
+
+    def __init__(self, embed_dim, num_heads=4, attn_dropout=0.0, relu_dropout=0.0, res_dropout=0.0):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.self_attn = MultiheadAttention(embed_dim=embed_dim, num_heads=num_heads, attn_dropout=attn_dropout)
+        self.relu_dropout = relu_dropout
+        self.res_dropout = res_dropout
+        self.normalize_before = True
+        self.fc1 = Linear(embed_dim, 4 * embed_dim)
+        self.fc2 = Linear(4 * embed_dim, embed_dim)
+        self.layer_norms = nn.ModuleList([LayerNorm(embed_dim) for _ in range(2)])
+
+    def forward(self, x, x_k=None, x_v=None, mask=None):
+        enc = _single_layer_view(self)
+        return enc(x, x_k, x_v, mask, _skip_final_ln=True)
+
+
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kv, enc, names, skip_final, *params):
+        sq, b, h = x.shape
+        self_attn = kv is None
+        dev = x.device
+        P = {"enc." + n: p.detach() for n, p in zip(names, params)}
+        x2 = x.detach().contiguous().reshape(sq * b, h)
+        src = x2 if self_attn else kv.detach().contiguous().reshape(-1, h)
+        nk = sq if self_attn else kv.shape[0]
+        kvhat = torch.empty(nk * b, h, device=dev)
+        rstd = torch.empty(nk * b, device=dev)
+        ops.rownorm(src, kvhat, rstd, nk * b, h)
+        y, c = Fn.encoder_fwd(P, "enc", x2, sq, b, b, 1, kvhat, nk, b, h, len(enc.layers), final_ln=not skip_final)
+        ctx.c, ctx.P, ctx.names, ctx.params = c, P, names, params
+        ctx.kv = (kvhat, rstd, nk, self_attn)
+        ctx.dims = (sq, b, h)
+        return y.reshape(sq, b, h)
+
+    @staticmethod
+    def backward(ctx, dy):
+        sq, b, h = ctx.dims
+        kvhat, rstd, nk, self_attn = ctx.kv
+        dev = dy.device
+        G = {k: torch.zeros_like(v) for k, v in ctx.P.items() if ".self_attn." not in k}
+        sink = ops.GradSink(dev)
+        dkv = torch.zeros(nk * b, h, device=dev)
+        dx = Fn.encoder_bwd(ctx.P, G, "enc", ctx.c, dy.contiguous().reshape(sq * b, h).float(), dkv, sink)
+        sink.flush()
+        sink.release()
+        dkv_in = None
+        if self_attn:
+            ops.rownorm_bwd(dkv, kvhat, rstd, dx, sq * b, h, True)
+        else:
+            dkv_in = torch.empty(nk * b, h, device=dev)
+            ops.rownorm_bwd(dkv, kvhat, rstd, dkv_in, nk * b, h, False)
+            dkv_in = dkv_in.reshape(nk, b, h)
+        grads = tuple(G.get("enc." + n) for n in ctx.names)
+        return (dx.reshape(sq, b, h), dkv_in, None, None, None) + grads
+
+
+class TransformerEncoder(nn.Module):
+    """`transformer.py:8-44` constructor, `:46-79` forward contract ((seq, batch, dim) tensors)."""
+
+    def __init__(self, embed_dim, num_heads, layers, attn_dropout=0.0, relu_dropout=0.0, res_dropout=0.0,
+                 embed_dropout=0.0, attn_mask=False):
+        super().__init__()
+        self.dropout = embed_dropout
+        self.attn_dropout = attn_dropout
+        self.embed_dim = embed_dim
+        self.embed_scale = math.sqrt(embed_dim)
+        self.attn_mask = attn_mask
+        self.layers = nn.ModuleList([])
+        for _ in range(layers):
+            self.layers.append(TransformerEncoderLayer(embed_dim, num_heads=num_heads, attn_dropout=attn_dropout,
+                                                       relu_dropout=relu_dropout, res_dropout=res_dropout))
+        self.register_buffer('version', torch.Tensor([2]))
+        self.normalize = True
+        if self.normalize:
+            self.layer_norm = LayerNorm(embed_dim)
+
+    def _check_dropouts(self):
+        if self.training and any(p > 0.0 for p in (self.dropout, self.attn_dropout) +
+                                 tuple(x for l in self.layers for x in (l.relu_dropout, l.res_dropout))):
+            raise NotImplementedError("dropout > 0 is not implemented in the fused MI355X path "
+                                      "(all reference defaults are 0.0: transformer.py:22-23, utils.py:40)")
+
+    def forward(self, x_in, x_in_k=None, x_in_v=None, mask=None, _skip_final_ln=False):
+        if x_in_k is None or x_in_v is None:
+            # upstream leaves x_k unbound here and crashes (transformer.py:64-73); be explicit instead
+            raise ValueError("TransformerEncoder needs x_in_k and x_in_v (pass x_in for self attention)")
+        if x_in_k is not x_in_v:
+            raise NotImplementedError("fused path shares K and V (every reference call site does)")
+        if not x_in.is_cuda:
+            raise RuntimeError("TransformerEncoder runs only on an MI355X through libdosx (no CPU fallback)")
+        self._check_dropouts()
+        live = [(n, p) for n, p in self.named_parameters() if ".self_attn." not in n]
+        names = tuple(n for n, _ in live)
+        params = tuple(p for _, p in live)
+        kv = None if x_in_k is x_in else x_in_k.float()
+        y = _EncoderFn.apply(x_in.float(), kv, self, names, _skip_final_ln, *params)
+        return y.to(x_in.dtype)
+
+    def max_positions(self):
+        raise AttributeError("max_positions() is dead code upstream (embed_positions is never defined)")
+
+
+def _single_layer_view(layer: TransformerEncoderLayer) -> TransformerEncoder:
+    enc = TransformerEncoder.__new__(TransformerEncoder)
+    nn.Module.__init__(enc)
+    enc.dropout, enc.attn_dropout = 0.0, layer.self_attn.attn_dropout
+    enc.embed_dim = layer.embed_dim
+    enc.layers = nn.ModuleList([layer])
+    enc.normalize = False
+    enc.training = layer.training
+    return enc

@@ -90,8 +90,8 @@ def gemm(M: int, N: int, segs: Sequence[Seg], w: torch.Tensor, out: torch.Tensor
     _lib.check(lib.dosx_gemm(C.byref(g), _stream()), "dosx_gemm")
 
 
-def gemm_partial_rows(M: int, N: int) -> int:
-    return _lib.load().dosx_gemm_partial_rows(int(M), int(N))
+def gemm_partial_rows(M: int, N: int, epi: int) -> int:
+    return _lib.load().dosx_gemm_partial_rows(int(M), int(N), int(epi))
 
 
 def wgrad_splits(M: int, N: int, K: int) -> int:

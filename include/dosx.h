@@ -102,9 +102,9 @@ typedef struct DosxGemm {
   int32_t partial_ld;
 } DosxGemm;
 
-/* number of workgroup rows dosx_gemm writes into `partials`: ceil(M/32) for the row-wise (full-row)
- * epilogues, ceil(M/32)*ceil(N/128) for the element-wise PRELU_BWD epilogue. */
-int dosx_gemm_partial_rows(int M, int N);
+/* exact number of workgroup rows dosx_gemm writes into `partials` for this epilogue: ceil(M/32) for
+ * the row-wise epilogues, ceil(M/32)*ceil(N/128) for the element-wise PRELU_BWD epilogue. */
+int dosx_gemm_partial_rows(int M, int N, int epi);
 int dosx_gemm(const DosxGemm* g, dosx_stream_t stream);
 
 /* dW partial slabs: slab[s][N][K] = sum_{m in split s} dY[m][n] * prologue(A)[m][k]
@@ -200,9 +200,13 @@ int dosx_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, co
  * (layers/transformer.py:131-138, layers/multihead_attention.py:68-74: no projections, no
  *  mask, no heads).  Query row (s, bq) is at x + (s*q_stride_s + bq*q_stride_b)*H; output
  *  row (s,bq) at s*Bq + bq; key row (j, bk) at j*Bk + bk with bk = bq % Bk. */
+enum { DOSX_ATTN_RAW_Q = 1, DOSX_ATTN_NO_RESIDUAL = 2 };
 typedef struct DosxAttn {
   int32_t Sq, Bq, Nk, Bk, H;
   int32_t q_stride_s, q_stride_b;
+  int32_t flags;       /* DOSX_ATTN_RAW_Q: queries are used as given (no LN0, gamma0/beta0 still applied to
+                          kvhat); DOSX_ATTN_NO_RESIDUAL: out = softmax(..)K without "+ x".  Both set =
+                          the bare MultiheadAttention.forward (layers/multihead_attention.py:49-76). */
   const float* x;      /* queries / residual */
   const float* kvhat;  /* [Nk*Bk, H] normalised keys (no affine) */
   const float* gamma0;

@@ -1,0 +1,275 @@
+"""Model-level parity on a real MI355X: the drop-in modules (libdosx programs through the C ABI)
+against (a) the golden vectors generated from the reference and (b) the oracle evaluated live on the
+same seeded inputs.  Tolerance on the predicted DOS vectors: 1e-4 RMSE (BASELINE.json north_star)."""
+import pytest
+import torch
+
+from tests.util import batch_from, load, maxabs, rmse, sub
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+DOS_RMSE = 1e-4          # north_star tolerance on the predicted DOS vector
+
+
+def relerr(a, b):
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def test_g1_multihead_attention():
+    from dostransformer_amd.layers.multihead_attention import MultiheadAttention
+    z = load("g1_mha.npz")
+    mha = MultiheadAttention(16, 1).to(DEV)
+    q = torch.from_numpy(z["f32/q"]).to(DEV).requires_grad_(True)
+    kv = torch.from_numpy(z["f32/kv"]).to(DEV).requires_grad_(True)
+    out = mha(q, kv, kv)
+    assert maxabs(out.cpu(), z["f32/out"]) < 5e-6
+    # gradient against torch autograd of the same expression
+    w = torch.randn(out.shape, generator=torch.Generator().manual_seed(1)).to(DEV)
+    (out * w).sum().backward()
+    q2 = q.detach().double().requires_grad_(True)
+    kv2 = kv.detach().double().requires_grad_(True)
+    a = torch.softmax(torch.bmm(q2.transpose(0, 1), kv2.permute(1, 2, 0)) * 16 ** -0.5, -1)
+    (torch.bmm(a, kv2.transpose(0, 1)).transpose(0, 1) * w.double()).sum().backward()
+    assert relerr(q.grad, q2.grad) < 5e-5 and relerr(kv.grad, kv2.grad) < 5e-5
+    assert mha.in_proj_weight.grad is None and mha.out_proj.weight.grad is None
+    # the float64 fixture (fp32 softmax quirk) is met within fp32 rounding as well
+    assert maxabs(mha(torch.from_numpy(z["f64/q"]).to(DEV), *(torch.from_numpy(z["f64/kv"]).to(DEV),) * 2).cpu(),
+                  z["f64/out"]) < 1e-5
+    with pytest.raises(AssertionError):
+        mha(q, kv[:3], kv)
+
+
+@pytest.mark.parametrize("mode", ["cross", "self"])
+def test_g2_transformer_encoder(mode):
+    from dostransformer_amd.layers import TransformerEncoder
+    z = load("g2_encoder.npz")
+    enc = TransformerEncoder(embed_dim=16, num_heads=1, layers=2, attn_dropout=0.0)
+    enc.load_state_dict(sub(z, "p/"))
+    enc = enc.to(DEV)
+    x = torch.from_numpy(z[f"{mode}/x"]).to(DEV).requires_grad_(True)
+    if mode == "cross":
+        kv = torch.from_numpy(z["cross/kv"]).to(DEV).requires_grad_(True)
+        y = enc(x, kv, kv)
+    else:
+        y = enc(x, x, x)
+    assert maxabs(y.cpu(), z[f"{mode}/y"]) < 2e-5
+    (y * torch.from_numpy(z[f"{mode}/w"]).to(DEV)).sum().backward()
+    assert relerr(x.grad, z[f"{mode}/dx"]) < 1e-4
+    if mode == "cross":
+        assert relerr(kv.grad, z["cross/dkv"]) < 1e-4
+    dead = set(str(s) for s in z[f"{mode}/dead"])
+    for k, p in enc.named_parameters():
+        if k in dead:
+            assert p.grad is None, k
+        else:
+            assert relerr(p.grad, z[f"{mode}/g/{k}"]) < 2e-4, k
+    with pytest.raises(ValueError):
+        enc(x)
+
+
+def _load_model(model, z, prefix="p0/"):
+    sd = {k: v.float() if v.is_floating_point() else v for k, v in sub(z, prefix).items()}
+    model.load_state_dict(sd)
+    return model.to(DEV)
+
+
+def _check_full(z, model, kind, g, tol_grad=2e-3):
+    from dostransformer_amd.train import Trainer
+    model = _load_model(model, z)
+    gd = g.to(DEV, dtype=torch.float32)
+    dg, xn, ds = model(gd)
+    assert rmse(dg.cpu(), z["dos_global"]) < DOS_RMSE and rmse(ds.cpu(), z["dos_system"]) < DOS_RMSE
+    assert rmse(xn.cpu(), z["x_nodes"]) < DOS_RMSE
+    # the reference caller's loss expression on our outputs (main_phDOS.py:109-114 / main_eDOS.py:111-123)
+    if kind == "phonon":
+        y = gd.phdos
+        loss = torch.sqrt(torch.nn.functional.mse_loss(dg, y)) + torch.sqrt(torch.nn.functional.mse_loss(ds, y))
+    else:
+        y = torch.where(gd.y_ft < 0, torch.zeros_like(gd.y_ft), gd.y_ft).reshape(len(gd.mp_id), -1)
+        loss = torch.sqrt(((y - dg) ** 2).mean(1)).mean() + torch.sqrt(((y - ds) ** 2).mean(1)).mean()
+    assert abs(float(loss) - float(z["loss"])) < 1e-4
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-2)
+    opt.zero_grad()
+    loss.backward()
+    dead = set(str(s) for s in z["dead_params"])
+    worst = 0.0
+    for k, p in model.named_parameters():
+        if k in dead:
+            assert p.grad is None, k
+        else:
+            assert p.grad is not None, k
+            ref = torch.from_numpy(z["g/" + k])
+            e = float((p.grad.cpu().double() - ref.double()).abs().max() / (ref.abs().max() + 1e-7))
+            worst = max(worst, e)
+            assert e < tol_grad, (k, e)
+    # three optimizer steps exactly like the reference loop (torch.optim.AdamW on model.parameters())
+    opt.step()
+    p1 = sub(z, "p1/")
+    for k, v in model.state_dict().items():
+        if v.is_floating_point():
+            assert maxabs(v.cpu(), p1[k]) < 2e-6, ("p1", k)
+    for _ in range(2):
+        dg, _, ds = model(gd)
+        if kind == "phonon":
+            loss = torch.sqrt(torch.nn.functional.mse_loss(dg, y)) + torch.sqrt(torch.nn.functional.mse_loss(ds, y))
+        else:
+            loss = torch.sqrt(((y - dg) ** 2).mean(1)).mean() + torch.sqrt(((y - ds) ** 2).mean(1)).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    p3 = sub(z, "p3/")
+    for k, v in model.state_dict().items():
+        if v.is_floating_point():
+            assert maxabs(v.cpu(), p3[k]) < 5e-6, ("p3", k)
+    for k in dead:
+        assert torch.equal(model.state_dict()[k].cpu(), sub(z, "p0/")[k].float())
+    return worst
+
+
+def test_g5_phonon_full():
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    z = load("g5_phonon.npz")
+    _check_full(z, DOSTransformer_phonon(3, 1, 118, 4, 16, DEV, 0.0), "phonon", batch_from(z))
+
+
+def test_g6_edos_full():
+    from dostransformer_amd.embedder_eDOS.DOSTransformer import DOSTransformer
+    z = load("g6_edos.npz")
+    _check_full(z, DOSTransformer(3, 2, 200, 41, 2, 16, DEV, 0.0), "edos", batch_from(z))
+
+
+@pytest.mark.parametrize("kind", ["phonon", "edos"])
+def test_fused_trainer_matches_golden_trajectory(kind):
+    from dostransformer_amd.train import Trainer
+    if kind == "phonon":
+        from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+        z = load("g5_phonon.npz")
+        model = _load_model(DOSTransformer_phonon(3, 1, 118, 4, 16, DEV, 0.0), z)
+    else:
+        from dostransformer_amd.embedder_eDOS.DOSTransformer import DOSTransformer
+        z = load("g6_edos.npz")
+        model = _load_model(DOSTransformer(3, 2, 200, 41, 2, 16, DEV, 0.0), z)
+    g = batch_from(z).to(DEV, dtype=torch.float32)
+    tr = Trainer(model, lr=1e-4, beta=1.0)
+    loss = tr.step(g)
+    assert abs(float(loss) - float(z["loss"])) < 1e-4
+    p1 = sub(z, "p1/")
+    for k, v in model.state_dict().items():
+        if v.is_floating_point():
+            assert maxabs(v.cpu(), p1[k]) < 2e-6, ("p1", k)
+    tr.step(g)
+    tr.step(g)
+    p3 = sub(z, "p3/")
+    for k, v in model.state_dict().items():
+        if v.is_floating_point():
+            assert maxabs(v.cpu(), p3[k]) < 5e-6, ("p3", k)
+
+
+def test_g7_batch_composition():
+    from dostransformer_amd.batch import graph_meta
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    z = load("g7_batch_composition.npz")
+    model = _load_model(DOSTransformer_phonon(3, 1, 118, 4, 16, DEV, 0.0), z).eval()
+    a = batch_from(z, "alone/b/").to(DEV, dtype=torch.float32)
+    b = batch_from(z, "both/b/").to(DEV, dtype=torch.float32)
+    with torch.no_grad():
+        oa, ob = model(a), model(b)
+    assert rmse(oa[0].cpu(), z["alone/dos_global"]) < DOS_RMSE and rmse(oa[2].cpu(), z["alone/dos_system"]) < DOS_RMSE
+    assert rmse(ob[0].cpu(), z["both/dos_global"]) < DOS_RMSE and rmse(ob[2].cpu(), z["both/dos_system"]) < DOS_RMSE
+    assert maxabs(oa[0][0].cpu(), ob[0][0].cpu()) > 1e-3          # unmasked padding: batch mates matter
+    a2 = batch_from(z, "alone/b/").to(DEV, dtype=torch.float32)
+    graph_meta(a2, DEV, n_max=11)                                  # pad to the global Nmax -> same as batched
+    with torch.no_grad():
+        oa2 = model(a2)
+    assert maxabs(oa2[0][0].cpu(), ob[0][0].cpu()) < 1e-5
+
+
+def test_g8_graphnetworks():
+    from dostransformer_amd.embedder_eDOS.graphnetwork import Graphnetwork
+    from dostransformer_amd.embedder_phDOS.graphnetwork_phonon import Graphnetwork_phonon
+    z = load("g8_graphnetwork_phonon.npz")
+    model = _load_model(Graphnetwork_phonon(3, 118, 4, 16, 51, DEV), z)
+    dos = model(batch_from(z).to(DEV, dtype=torch.float32))
+    assert rmse(dos.cpu(), z["dos"]) < DOS_RMSE
+    (dos * torch.from_numpy(z["w"]).float().to(DEV)).sum().backward()
+    dead = set(str(s) for s in z["dead_params"])
+    for k, p in model.named_parameters():
+        if k in dead:
+            assert p.grad is None, k
+        else:
+            assert relerr(p.grad, z["g/" + k]) < 2e-3, k
+    z = load("g8_graphnetwork_edos.npz")
+    model = _load_model(Graphnetwork(3, 200, 41, 2, 16, 201, DEV), z)
+    dos, xn = model(batch_from(z).to(DEV, dtype=torch.float32))
+    assert rmse(dos.cpu(), z["dos"]) < DOS_RMSE and rmse(xn.cpu(), z["x_nodes"]) < DOS_RMSE
+    (dos * torch.from_numpy(z["w"]).to(DEV)).sum().backward()
+    dead = set(str(s) for s in z["dead_params"])
+    for k, p in model.named_parameters():
+        if k in dead:
+            assert p.grad is None, k
+        else:
+            assert relerr(p.grad, z["g/" + k]) < 2e-3, k
+
+
+@pytest.mark.parametrize("kind,H,T,B", [("phonon", 64, 1, 8), ("phonon", 128, 2, 16), ("edos", 64, 2, 6),
+                                         ("edos", 256, 2, 4)])
+def test_against_oracle_live(kind, H, T, B):
+    """BASELINE configs at oracle-feasible batch sizes: outputs, loss, every gradient and one AdamW
+    step against the oracle (fp64 for phonon like main_phDOS.py:15-16, fp32 for eDOS)."""
+    from oracle import dos_oracle as O
+    from dostransformer_amd import synth
+    from dostransformer_amd.train import Trainer
+    torch.manual_seed(0)
+    if kind == "phonon":
+        from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+        model = DOSTransformer_phonon(3, T, 118, 4, H, DEV, 0.0)
+        g_ref = synth.phonon_batch(B, seed=11, dtype=torch.float64)
+        g = synth.phonon_batch(B, seed=11, dtype=torch.float32)
+        ref_dt = torch.float64
+        fwd = O.dostransformer_phonon_forward
+    else:
+        from dostransformer_amd.embedder_eDOS.DOSTransformer import DOSTransformer
+        model = DOSTransformer(3, T, 200, 41, 2, H, DEV, 0.0)
+        g_ref = synth.edos_batch(B, seed=12, dtype=torch.float32)
+        g = synth.edos_batch(B, seed=12, dtype=torch.float32)
+        ref_dt = torch.float32
+        fwd = O.dostransformer_forward
+    params = {k: (v.detach().clone().to(ref_dt) if v.is_floating_point() else v.clone())
+              for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    g = g.to(DEV)
+    with torch.no_grad():
+        rg, rx, rs = fwd(params, g_ref, 3, T)
+    tr = Trainer(model, lr=1e-4, beta=1.0)
+    loss = tr.forward_backward(g)
+    dg, xn, ds = tr.last_outputs
+    assert rmse(dg.cpu(), rg) < DOS_RMSE and rmse(ds.cpu(), rs) < DOS_RMSE
+    assert rmse(xn.cpu(), rx) < DOS_RMSE * max(1.0, float(rx.abs().max()))
+    state = {}
+    ref_loss, grads = O.train_step(kind, params, state, g_ref, 3, T, lr=1e-4, beta=1.0)
+    assert abs(float(loss) - float(ref_loss)) < 2e-4
+    fp = model.flat_params()
+    tol = 3e-3 if kind == "phonon" else 2e-2      # eDOS reference itself is fp32 (cancellation in tiny grads)
+    for k, gr in grads.items():
+        if gr is None:
+            assert k not in fp.G, k
+        else:
+            e = float((fp.G[k].cpu().double() - gr.double()).abs().max() / (gr.abs().max() + 1e-6))
+            assert e < tol, (k, e)
+    tr.optimizer_step()
+    # Adam's first step moves every element by ~lr*sign(g): where |g| is at the noise floor of the fp32
+    # (GPU) vs fp64 (oracle) gradient the sign itself is ill-conditioned, so compare the update only
+    # where the gradient is resolved, and bound it by 2*lr everywhere.
+    for k, v in model.state_dict().items():
+        if not v.is_floating_point():
+            continue
+        d = (v.cpu().double() - params[k].double()).abs()
+        assert float(d.max()) <= 2.1e-4, k
+        gr = grads.get(k)
+        if gr is not None:
+            ok = gr.abs() >= 1e-2 * gr.abs().max()
+            assert float(d[ok].max()) < 5e-6, k
+        else:
+            assert float(d.max()) == 0.0, k

@@ -217,8 +217,8 @@ def test_gemm_prelu_ln_bwd_epilogue(M, H2):
     xhat = ((z - mu) / torch.sqrt(var + 1e-5)).detach().float().contiguous()
     rstd = (1 / torch.sqrt(var + 1e-5)).detach().float().reshape(-1).contiguous()
     dz = torch.empty(M, H2, device=DEV)
-    rows = o.gemm_partial_rows(M, H2)
-    part = torch.zeros(rows, 2 * H2 + 1, device=DEV)
+    rows = o.gemm_partial_rows(M, H2, o.EPI_PRELU_LN_BWD)
+    part = torch.full((rows, 2 * H2 + 1), float('nan'), device=DEV)
     o.gemm(M, H2, [o.seg(dy)], w3, dz, w_layout=1, epi=o.EPI_PRELU_LN_BWD, aux=xhat, aux_stats=rstd,
            epi_gamma=gam.detach().float(), epi_beta=bet.detach().float(), epi_alpha=alpha.detach().float(),
            partials=part, partial_ld=2 * H2 + 1)
@@ -243,8 +243,8 @@ def test_gemm_rowln_bwd_relu_mask_prelu_bwd():
     rs = 1 / torch.sqrt(x.detach().var(1, unbiased=False) + 1e-5)
     stats = torch.stack([mu, rs], 1).float().contiguous()
     dx = torch.empty(M, H, device=DEV)
-    rows = o.gemm_partial_rows(M, H)
-    part = torch.zeros(rows, 2 * H, device=DEV)
+    rows = o.gemm_partial_rows(M, H, o.EPI_ROWLN_BWD)
+    part = torch.full((rows, 2 * H), float('nan'), device=DEV)
     o.gemm(M, H, [o.seg(dh)], w1, dx, w_layout=1, epi=o.EPI_ROWLN_BWD, aux=x.detach().float(), aux_stats=stats,
            epi_gamma=gam.detach().float(), res=res, partials=part, partial_ld=2 * H)
     assert err(dx, x.grad + res.double()) < 5e-5
@@ -260,8 +260,8 @@ def test_gemm_rowln_bwd_relu_mask_prelu_bwd():
     # prelu bwd (N tiled by 128: two partial columns per row block)
     z = rnd(M, 4 * H, seed=10)
     alpha = torch.tensor([0.2], device=DEV)
-    rows = o.gemm_partial_rows(M, 4 * H)
-    part = torch.zeros(rows, 1, device=DEV)
+    rows = o.gemm_partial_rows(M, 4 * H, o.EPI_PRELU_BWD)
+    part = torch.full((rows, 1), float('nan'), device=DEV)
     o.gemm(M, 4 * H, [o.seg(dy)], w2, out, w_layout=1, epi=o.EPI_PRELU_BWD, aux=z, epi_alpha=alpha, partials=part,
            partial_ld=1)
     da = dy.double() @ w2.double()
