@@ -39,9 +39,11 @@ template <class RowPtr>
 __device__ __forceinline__ void load_rows(float* dst, int LDH, int HP, int H, RowPtr rowptr, int tid) {
   const int row = tid >> 3;
   const float* p = rowptr(row);
+  const bool ok = p != nullptr;
+  const float* q = ok ? p : rowptr(0);          // tile row 0 is always a valid row
   for (int c = (tid & 7) * 4; c < HP; c += 32) {
-    float4 v = f4zero();
-    if (p && c < H) v = ld4(p + c);
+    float4 v = ld4(q + (c < H ? c : 0));        // unconditional load, masked afterwards (no branch)
+    if (!(ok && c < H)) v = f4zero();
     st4(dst + row * LDH + c, v);
   }
 }
@@ -51,14 +53,12 @@ __device__ __forceinline__ void stage_k_chunk(float* Ks, const float* __restrict
                                               const float* __restrict__ beta, int Nk, int NKP, int Bk, int bk, int H,
                                               int kc, int tid) {
   const int kq = (tid & 7) * 4, k = kc + kq;
-  float4 g = f4zero(), b = f4zero();
-  if (k < H) { g = ld4(gamma + k); b = ld4(beta + k); }
+  const int kk = k < H ? k : 0;
+  const float4 g = ld4(gamma + kk), b = ld4(beta + kk);
   for (int j = tid >> 3; j < NKP; j += 32) {
-    float4 v = f4zero();
-    if (j < Nk && k < H) {
-      const float4 h = ld4(kvhat + ((size_t)j * Bk + bk) * H + k);
-      v = make_float4(h.x * g.x + b.x, h.y * g.y + b.y, h.z * g.z + b.z, h.w * g.w + b.w);
-    }
+    const float4 h = ld4(kvhat + ((size_t)min(j, Nk - 1) * Bk + bk) * H + kk);
+    float4 v = make_float4(h.x * g.x + b.x, h.y * g.y + b.y, h.z * g.z + b.z, h.w * g.w + b.w);
+    if (!(j < Nk && k < H)) v = f4zero();
     st4(Ks + j * LDK + kq, v);
   }
 }
@@ -68,12 +68,12 @@ __device__ __forceinline__ void stage_v_chunk(float* Vs, const float* __restrict
                                               const float* __restrict__ beta, int Nk, int Bk, int bk, int H, int HP,
                                               int LDH, int j0, int tid) {
   const int jj = tid >> 3, j = j0 + jj;
+  const float* row = kvhat + ((size_t)min(j, Nk - 1) * Bk + bk) * H;
   for (int c = (tid & 7) * 4; c < HP; c += 32) {
-    float4 v = f4zero();
-    if (j < Nk && c < H) {
-      const float4 h = ld4(kvhat + ((size_t)j * Bk + bk) * H + c), g = ld4(gamma + c), b = ld4(beta + c);
-      v = make_float4(h.x * g.x + b.x, h.y * g.y + b.y, h.z * g.z + b.z, h.w * g.w + b.w);
-    }
+    const int cc = c < H ? c : 0;
+    const float4 h = ld4(row + cc), g = ld4(gamma + cc), b = ld4(beta + cc);
+    float4 v = make_float4(h.x * g.x + b.x, h.y * g.y + b.y, h.z * g.z + b.z, h.w * g.w + b.w);
+    if (!(j < Nk && c < H)) v = f4zero();
     st4(Vs + jj * LDH + c, v);
   }
 }

@@ -8,6 +8,8 @@
 // chain) so results track an fp32 torch reference to rounding.  A is gathered / concatenated /
 // normalised on the fly while it is staged into LDS, so torch.cat([x[row], x[col], e]) and the
 // LayerNorm/PReLU between the two Linear layers of every MLP never exist in HBM.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -32,60 +34,64 @@ struct AState {
   bool ok;
 };
 
+// `gm` must be a VALID row (callers clamp it); `ok` says whether the row's data is used or zeroed.
+// Loads are issued unconditionally from valid addresses and masked afterwards: a branch around a
+// global load makes hipcc wait vmcnt(0) per load and serialises the L2 round trips.
 __device__ __forceinline__ void a_state_init(AState& st, const DosxSeg* segs, int nseg, int pro,
                                               const float* pro_stats, const float* pro_alpha, int gm,
                                               bool ok) {
   st.ok = ok;
-  st.rp[0] = st.rp[1] = st.rp[2] = nullptr;
-  if (ok) {
-#pragma unroll
-    for (int s = 0; s < 3; ++s)
-      if (s < nseg) st.rp[s] = segs[s].p + (size_t)dosx_map_row(segs[s].map, gm) * (size_t)segs[s].ld;
-  }
+  st.rp[0] = segs[0].p + (size_t)dosx_map_row(segs[0].map, gm) * (size_t)segs[0].ld;
+  st.rp[1] = st.rp[2] = st.rp[0];
+  if (nseg > 1) st.rp[1] = segs[1].p + (size_t)dosx_map_row(segs[1].map, gm) * (size_t)segs[1].ld;
+  if (nseg > 2) st.rp[2] = segs[2].p + (size_t)dosx_map_row(segs[2].map, gm) * (size_t)segs[2].ld;
   st.w0 = segs[0].width;
   st.w01 = nseg > 1 ? st.w0 + segs[1].width : 0x7fffffff;
   if (nseg == 1) st.w0 = 0x7fffffff;
   st.mean = 0.f;
   st.rstd = 0.f;
   st.alpha = 0.f;
-  if (pro == DOSX_PRO_ROWLN && ok) {
+  if (pro == DOSX_PRO_ROWLN) {
     st.mean = pro_stats[2 * (size_t)gm];
     st.rstd = pro_stats[2 * (size_t)gm + 1];
   }
   if (pro == DOSX_PRO_PRELU || pro == DOSX_PRO_LN_PRELU) st.alpha = *pro_alpha;
 }
 
-__device__ __forceinline__ float a_xform1(const AState& st, int pro, float v, int k, const float* gamma,
-                                          const float* beta) {
-  if (pro == DOSX_PRO_PRELU) return prelu_f(v, st.alpha);
-  if (pro == DOSX_PRO_LN_PRELU) return prelu_f(v * gamma[k] + beta[k], st.alpha);
-  if (pro == DOSX_PRO_ROWLN) return (v - st.mean) * st.rstd * gamma[k] + beta[k];
+template <int PRO>
+__device__ __forceinline__ float a_xform1(const AState& st, float v, int k, const float* gamma, const float* beta) {
+  if (PRO == DOSX_PRO_PRELU) return prelu_f(v, st.alpha);
+  if (PRO == DOSX_PRO_LN_PRELU) return prelu_f(v * gamma[k] + beta[k], st.alpha);
+  if (PRO == DOSX_PRO_ROWLN) return (v - st.mean) * st.rstd * gamma[k] + beta[k];
   return v;
 }
 
-__device__ __forceinline__ float4 a_load4(const AState& st, int pro, int k, int K, int vec, const float* gamma,
-                                          const float* beta) {
-  float4 v = f4zero();
-  if (!st.ok || k >= K) return v;
-  if (vec) {
-    const float* p;
-    if (k < st.w0) p = st.rp[0] + k;
-    else if (k < st.w01) p = st.rp[1] + (k - st.w0);
-    else p = st.rp[2] + (k - st.w01);
-    v = ld4(p);
-    if (pro == DOSX_PRO_PRELU) {
-      v.x = prelu_f(v.x, st.alpha); v.y = prelu_f(v.y, st.alpha);
-      v.z = prelu_f(v.z, st.alpha); v.w = prelu_f(v.w, st.alpha);
-    } else if (pro == DOSX_PRO_LN_PRELU) {
-      float4 g = ld4(gamma + k), b = ld4(beta + k);
-      v.x = prelu_f(v.x * g.x + b.x, st.alpha); v.y = prelu_f(v.y * g.y + b.y, st.alpha);
-      v.z = prelu_f(v.z * g.z + b.z, st.alpha); v.w = prelu_f(v.w * g.w + b.w, st.alpha);
-    } else if (pro == DOSX_PRO_ROWLN) {
-      float4 g = ld4(gamma + k), b = ld4(beta + k);
-      v.x = (v.x - st.mean) * st.rstd * g.x + b.x; v.y = (v.y - st.mean) * st.rstd * g.y + b.y;
-      v.z = (v.z - st.mean) * st.rstd * g.z + b.z; v.w = (v.w - st.mean) * st.rstd * g.w + b.w;
+// PRO and VEC are compile-time so that the staging code is straight-line.  Staging is split in two:
+// a_issue() only ISSUES the global loads (unconditionally, from clamped = always valid addresses);
+// a_finish() applies the prologue transform and the out-of-range mask and runs one k-chunk later,
+// right before the LDS store — so the loads stay in flight across the MFMA block of the current
+// chunk (a select placed right after a load makes hipcc wait for it before the MFMAs).
+struct ARaw {
+  float4 v, g, b;
+};
+
+template <int PRO, int VEC>
+__device__ __forceinline__ ARaw a_issue(const AState& st, int k, int K, const float* gamma, const float* beta) {
+  ARaw r;
+  r.v = f4zero(); r.g = f4zero(); r.b = f4zero();
+  if (VEC) {
+    const int kc = (k < K) ? k : 0;
+    const float* p0 = st.rp[0] + kc;
+    const float* p1 = st.rp[1] + (kc - st.w0);
+    const float* p2 = st.rp[2] + (kc - st.w01);
+    const float* p = (kc < st.w0) ? p0 : ((kc < st.w01) ? p1 : p2);
+    r.v = ld4(p);
+    if (PRO == DOSX_PRO_LN_PRELU || PRO == DOSX_PRO_ROWLN) {
+      r.g = ld4(gamma + kc);
+      r.b = ld4(beta + kc);
     }
   } else {
+    if (!st.ok || k >= K) return r;
     float t[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -95,11 +101,29 @@ __device__ __forceinline__ float4 a_load4(const AState& st, int pro, int k, int 
         if (kk < st.w0) x = st.rp[0][kk];
         else if (kk < st.w01) x = st.rp[1][kk - st.w0];
         else x = st.rp[2][kk - st.w01];
-        t[i] = a_xform1(st, pro, x, kk, gamma, beta);
+        t[i] = a_xform1<PRO>(st, x, kk, gamma, beta);
       }
     }
-    v = make_float4(t[0], t[1], t[2], t[3]);
+    r.v = make_float4(t[0], t[1], t[2], t[3]);
   }
+  return r;
+}
+
+template <int PRO, int VEC>
+__device__ __forceinline__ float4 a_finish(const AState& st, const ARaw& r, int k, int K) {
+  float4 v = r.v;
+  if (!VEC) return v;
+  if (PRO == DOSX_PRO_PRELU) {
+    v.x = prelu_f(v.x, st.alpha); v.y = prelu_f(v.y, st.alpha);
+    v.z = prelu_f(v.z, st.alpha); v.w = prelu_f(v.w, st.alpha);
+  } else if (PRO == DOSX_PRO_LN_PRELU) {
+    v.x = prelu_f(v.x * r.g.x + r.b.x, st.alpha); v.y = prelu_f(v.y * r.g.y + r.b.y, st.alpha);
+    v.z = prelu_f(v.z * r.g.z + r.b.z, st.alpha); v.w = prelu_f(v.w * r.g.w + r.b.w, st.alpha);
+  } else if (PRO == DOSX_PRO_ROWLN) {
+    v.x = (v.x - st.mean) * st.rstd * r.g.x + r.b.x; v.y = (v.y - st.mean) * st.rstd * r.g.y + r.b.y;
+    v.z = (v.z - st.mean) * st.rstd * r.g.z + r.b.z; v.w = (v.w - st.mean) * st.rstd * r.g.w + r.b.w;
+  }
+  if (!(st.ok && k < K)) v = f4zero();
   return v;
 }
 
@@ -107,7 +131,7 @@ __device__ __forceinline__ float4 a_load4(const AState& st, int pro, int k, int 
 // C = prologue(A) . B  with fused row-wise epilogues.   NTW = 32-wide MFMA tiles per wave,
 // BN = 128*NTW columns per workgroup.  WL: 0 = W[N,K] (k-contiguous), 1 = W[K,N] (n-contiguous).
 // ---------------------------------------------------------------------------------------------
-template <int NTW, int WL>
+template <int NTW, int WL, int PRO, int VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmLaunch L) {
   const DosxGemm& g = L.g;
   constexpr int BN = 128 * NTW;
@@ -133,7 +157,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmLaunch L) {
   // ---- staging setup ----
   const int arow = tid >> 3, akq = (tid & 7) * 4;
   AState ast;
-  a_state_init(ast, g.a, g.nseg, g.pro, g.pro_stats, g.pro_alpha, m0 + arow, (m0 + arow) < M);
+  a_state_init(ast, g.a, g.nseg, PRO, g.pro_stats, g.pro_alpha, min(m0 + arow, M - 1), (m0 + arow) < M);
 
   auto loadW = [&](int k0, float4(&wr)[NW4]) {
 #pragma unroll
@@ -141,42 +165,43 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmLaunch L) {
       float4 v = f4zero();
       if (WL == 0) {
         const int n = n0 + (tid >> 3) + 32 * i, k = k0 + (tid & 7) * 4;
-        if (n < N && k < K) {
+        if (VEC) {   // unconditional load from a clamped (valid) address; masked in storeW
+          v = ld4(g.w + (size_t)min(n, N - 1) * g.ldw + (k < K ? k : 0));
+        } else if (n < N && k < K) {
           const float* p = g.w + (size_t)n * g.ldw + k;
-          if (L.vecW) v = ld4(p);
-          else {
-            v.x = p[0];
-            if (k + 1 < K) v.y = p[1];
-            if (k + 2 < K) v.z = p[2];
-            if (k + 3 < K) v.w = p[3];
-          }
+          v.x = p[0];
+          if (k + 1 < K) v.y = p[1];
+          if (k + 2 < K) v.z = p[2];
+          if (k + 3 < K) v.w = p[3];
         }
       } else {
         const int lin = tid + 256 * i;
         const int r = lin / (BN / 4), c4 = (lin % (BN / 4)) * 4;
         const int k = k0 + r, n = n0 + c4;
-        if (k < K && n < N) {
+        if (VEC) {
+          v = ld4(g.w + (size_t)min(k, K - 1) * g.ldw + (n < N ? n : 0));
+        } else if (k < K && n < N) {
           const float* p = g.w + (size_t)k * g.ldw + n;
-          if (L.vecW) v = ld4(p);
-          else {
-            v.x = p[0];
-            if (n + 1 < N) v.y = p[1];
-            if (n + 2 < N) v.z = p[2];
-            if (n + 3 < N) v.w = p[3];
-          }
+          v.x = p[0];
+          if (n + 1 < N) v.y = p[1];
+          if (n + 2 < N) v.z = p[2];
+          if (n + 3 < N) v.w = p[3];
         }
       }
       wr[i] = v;
     }
   };
-  auto storeW = [&](const float4(&wr)[NW4]) {
+  auto storeW = [&](int k0, const float4(&wr)[NW4]) {
 #pragma unroll
     for (int i = 0; i < NW4; ++i) {
+      float4 v = wr[i];
       if (WL == 0) {
-        st4(&Ws[((tid >> 3) + 32 * i) * LDWT + (tid & 7) * 4], wr[i]);
+        if (VEC && !((n0 + (tid >> 3) + 32 * i) < N && (k0 + (tid & 7) * 4) < K)) v = f4zero();
+        st4(&Ws[((tid >> 3) + 32 * i) * LDWT + (tid & 7) * 4], v);
       } else {
         const int lin = tid + 256 * i;
-        st4(&Ws[(lin / (BN / 4)) * LDWT + (lin % (BN / 4)) * 4], wr[i]);
+        if (VEC && !((k0 + lin / (BN / 4)) < K && (n0 + (lin % (BN / 4)) * 4) < N)) v = f4zero();
+        st4(&Ws[(lin / (BN / 4)) * LDWT + (lin % (BN / 4)) * 4], v);
       }
     }
   };
@@ -187,42 +212,80 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmLaunch L) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  bool tile_on[NTW];
-#pragma unroll
-  for (int t = 0; t < NTW; ++t) tile_on[t] = (n0 + (wave * NTW + t) * 32) < N;
+  // wave-uniform: how many of this wave's 32-column tiles intersect [0, N)
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  int tiles_on = (N - n0 - wave_u * NTW * 32 + 31) / 32;
+  tiles_on = tiles_on < 0 ? 0 : (tiles_on > NTW ? NTW : tiles_on);
 
   const int nk = (K + BK - 1) / BK;
-  float4 areg = a_load4(ast, g.pro, akq, K, L.vecA, g.pro_gamma, g.pro_beta);
+  ARaw araw = a_issue<PRO, VEC>(ast, akq, K, g.pro_gamma, g.pro_beta);
   float4 wreg[NW4];
   loadW(0, wreg);
 
   for (int kt = 0; kt < nk; ++kt) {
-    st4(&As[arow * LDA + akq], areg);
-    storeW(wreg);
+    st4(&As[arow * LDA + akq], a_finish<PRO, VEC>(ast, araw, kt * BK + akq, K));
+    storeW(kt * BK, wreg);
     __syncthreads();
     if (kt + 1 < nk) {
-      areg = a_load4(ast, g.pro, (kt + 1) * BK + akq, K, L.vecA, g.pro_gamma, g.pro_beta);
+      araw = a_issue<PRO, VEC>(ast, (kt + 1) * BK + akq, K, g.pro_gamma, g.pro_beta);
       loadW((kt + 1) * BK, wreg);
     }
+    if (tiles_on == NTW) {
+      // fast path (every tile of this wave is inside N): straight-line, so hipcc can hoist the
+      // ds_reads of the whole chunk ahead of the MFMA chain
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 8) {
-      const float4 a = ld4(&As[l31 * LDA + kk + 4 * hh]);
-#pragma unroll
-      for (int t = 0; t < NTW; ++t) {
-        if (!tile_on[t]) continue;
-        const int col = (wave * NTW + t) * 32 + l31;
+      for (int kk = 0; kk < BK; kk += 8) {
+        const float4 a = ld4(&As[l31 * LDA + kk + 4 * hh]);
         if (WL == 0) {
-          const float4 b = ld4(&Ws[col * LDWT + kk + 4 * hh]);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+          float4 b[NTW];
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) b[t] = ld4(&Ws[((wave * NTW + t) * 32 + l31) * LDWT + kk + 4 * hh]);
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
         } else {
-          const float* bp = &Ws[(kk + 4 * hh) * LDWT + col];
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bp[0], acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bp[LDWT], acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bp[2 * LDWT], acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bp[3 * LDWT], acc[t], 0, 0, 0);
+          float b[NTW][4];
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) {
+            const float* bp = &Ws[(kk + 4 * hh) * LDWT + (wave * NTW + t) * 32 + l31];
+            b[t][0] = bp[0]; b[t][1] = bp[LDWT]; b[t][2] = bp[2 * LDWT]; b[t][3] = bp[3 * LDWT];
+          }
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t][0], acc[t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t][1], acc[t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t][2], acc[t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t][3], acc[t], 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 8) {
+        const float4 a = ld4(&As[l31 * LDA + kk + 4 * hh]);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+          if (t >= tiles_on) continue;
+          const int col = (wave * NTW + t) * 32 + l31;
+          if (WL == 0) {
+            const float4 b = ld4(&Ws[col * LDWT + kk + 4 * hh]);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+          } else {
+            const float* bp = &Ws[(kk + 4 * hh) * LDWT + col];
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bp[0], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bp[LDWT], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bp[2 * LDWT], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bp[3 * LDWT], acc[t], 0, 0, 0);
+          }
         }
       }
     }
@@ -443,20 +506,44 @@ constexpr size_t gemm_smem_bytes() {
   return (size_t)(MAINF + 8 * BN + 4) * sizeof(float);
 }
 
-template <int NTW, int WL>
+template <int NTW, int WL, int PRO, int VEC>
 int launch_gemm(const GemmLaunch& L, hipStream_t s) {
   constexpr int BN = 128 * NTW;
   dim3 grid(ceil_div(L.g.M, BM), ceil_div(L.g.N, BN));
   constexpr size_t smem = gemm_smem_bytes<NTW, WL>();
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<NTW, WL>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<NTW, WL, PRO, VEC>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<NTW, WL>), grid, dim3(256), smem, s, L);
+  hipLaunchKernelGGL((gemm_kernel<NTW, WL, PRO, VEC>), grid, dim3(256), smem, s, L);
   DOSX_LAUNCH_CHECK();
   return 0;
+}
+
+template <int NTW>
+int dispatch_gemm(const GemmLaunch& L, hipStream_t s) {
+  const int vec = L.vecA && L.vecW;
+  if (L.g.w_layout == 0) {
+    if (!vec) {
+      // generic (unaligned) staging exists for the un-transformed operand only: the raw
+      // 118 / 41 / 4 / 2 wide input features of the three encoders
+      if (L.g.pro != DOSX_PRO_NONE) { dosx_set_error("dosx_gemm: prologue %d needs 4-float aligned operands", L.g.pro); return -22; }
+      return launch_gemm<NTW, 0, DOSX_PRO_NONE, 0>(L, s);
+    }
+    switch (L.g.pro) {
+      case DOSX_PRO_NONE: return launch_gemm<NTW, 0, DOSX_PRO_NONE, 1>(L, s);
+      case DOSX_PRO_PRELU: return launch_gemm<NTW, 0, DOSX_PRO_PRELU, 1>(L, s);
+      case DOSX_PRO_LN_PRELU: return launch_gemm<NTW, 0, DOSX_PRO_LN_PRELU, 1>(L, s);
+      case DOSX_PRO_ROWLN: return launch_gemm<NTW, 0, DOSX_PRO_ROWLN, 1>(L, s);
+    }
+  } else {
+    if (L.g.pro != DOSX_PRO_NONE) { dosx_set_error("dosx_gemm: w_layout 1 supports no prologue"); return -22; }
+    return vec ? launch_gemm<NTW, 1, DOSX_PRO_NONE, 1>(L, s) : launch_gemm<NTW, 1, DOSX_PRO_NONE, 0>(L, s);
+  }
+  dosx_set_error("dosx_gemm: bad prologue %d", L.g.pro);
+  return -22;
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -467,9 +554,16 @@ int seg_vec_ok(const DosxSeg* segs, int nseg) {
   return 1;
 }
 
-int gemm_bn(int N, int epi) {
+int gemm_bn(int M, int N, int epi) {
   const bool full_row = (epi == DOSX_EPI_LN || epi == DOSX_EPI_PRELU_LN_BWD || epi == DOSX_EPI_ROWLN_BWD);
   if (full_row) return N <= 128 ? 128 : (N <= 256 ? 256 : 512);
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("DOSX_GEMM_BN");
+    forced = e ? atoi(e) : 0;
+  }
+  if (forced == 128 || forced == 256 || forced == 512) return N >= forced ? forced : 128;
+  (void)M;
   return 128;
 }
 
@@ -519,18 +613,12 @@ extern "C" int dosx_gemm(const DosxGemm* gp, dosx_stream_t stream) {
   if (g.pro == DOSX_PRO_LN_PRELU || g.pro == DOSX_PRO_ROWLN)
     L.vecA = L.vecA && aligned16(g.pro_gamma) && aligned16(g.pro_beta);
   L.vecW = ((g.ldw & 3) == 0) && aligned16(g.w) && (g.w_layout == 0 ? (g.K & 3) == 0 : (g.N & 3) == 0);
-  int bn = gemm_bn(g.N, g.epi);
+  int bn = gemm_bn(g.M, g.N, g.epi);
   if (g.stats_out && bn < g.N) bn = g.N <= 256 ? 256 : 512;
   hipStream_t s = to_stream(stream);
-  if (g.w_layout == 0) {
-    if (bn == 128) return launch_gemm<1, 0>(L, s);
-    if (bn == 256) return launch_gemm<2, 0>(L, s);
-    return launch_gemm<4, 0>(L, s);
-  } else {
-    if (bn == 128) return launch_gemm<1, 1>(L, s);
-    if (bn == 256) return launch_gemm<2, 1>(L, s);
-    return launch_gemm<4, 1>(L, s);
-  }
+  if (bn == 128) return dispatch_gemm<1>(L, s);
+  if (bn == 256) return dispatch_gemm<2>(L, s);
+  return dispatch_gemm<4>(L, s);
 }
 
 // =============================================================================================
@@ -547,6 +635,7 @@ struct WgradLaunch {
   int vecY;
 };
 
+template <int PRO, int VEC>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
   const DosxWgrad& g = L.g;
   __shared__ __align__(16) float Ys[BM * LDT];
@@ -565,43 +654,52 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
   float bsum = 0.f;
   const bool do_bias = (g.slab_bias != nullptr) && (blockIdx.x == 0);
 
-  float4 y0, y1, x0, x1;
-  auto load = [&](int m) {
-    const int gm = m + r;
-    const bool ok = gm < me;
+  // staging registers of the NEXT chunk: raw loads are issued before the MFMA block of the current
+  // chunk and finished (prologue transform + masks) right before their LDS store
+  float4 y0, y1;
+  ARaw xr0, xr1;
+  AState st;
+  bool row_ok = false;
+  auto issue = [&](int m) {
+    row_ok = (m + r) < me;
+    const int gm = min(m + r, me - 1);          // me > ms >= 0 here: always a valid row
     y0 = y1 = f4zero();
-    if (ok) {
-      const float* yp = g.dy.p + (size_t)dosx_map_row(g.dy.map, gm) * g.dy.ld;
+    const float* yp = g.dy.p + (size_t)dosx_map_row(g.dy.map, gm) * g.dy.ld;
 #pragma unroll
-      for (int hseg = 0; hseg < 2; ++hseg) {
-        const int n = n0 + c4 + 32 * hseg;
-        float4 v = f4zero();
-        if (n < N) {
-          if (L.vecY) v = ld4(yp + n);
-          else {
-            v.x = yp[n];
-            if (n + 1 < N) v.y = yp[n + 1];
-            if (n + 2 < N) v.z = yp[n + 2];
-            if (n + 3 < N) v.w = yp[n + 3];
-          }
-        }
-        if (hseg == 0) y0 = v; else y1 = v;
+    for (int hseg = 0; hseg < 2; ++hseg) {
+      const int n = n0 + c4 + 32 * hseg;
+      float4 v = f4zero();
+      if (VEC) {
+        v = ld4(yp + (n < N ? n : 0));
+      } else if (row_ok && n < N) {
+        v.x = yp[n];
+        if (n + 1 < N) v.y = yp[n + 1];
+        if (n + 2 < N) v.z = yp[n + 2];
+        if (n + 3 < N) v.w = yp[n + 3];
       }
+      if (hseg == 0) y0 = v; else y1 = v;
     }
-    AState st;
-    a_state_init(st, g.a, g.nseg, g.pro, g.pro_stats, g.pro_alpha, gm, ok);
-    x0 = a_load4(st, g.pro, k0 + c4, K, L.vecA, g.pro_gamma, g.pro_beta);
-    x1 = a_load4(st, g.pro, k0 + c4 + 32, K, L.vecA, g.pro_gamma, g.pro_beta);
+    a_state_init(st, g.a, g.nseg, PRO, g.pro_stats, g.pro_alpha, gm, row_ok);
+    xr0 = a_issue<PRO, VEC>(st, k0 + c4, K, g.pro_gamma, g.pro_beta);
+    xr1 = a_issue<PRO, VEC>(st, k0 + c4 + 32, K, g.pro_gamma, g.pro_beta);
+  };
+  auto store = [&]() {
+    float4 a0 = y0, a1 = y1;
+    if (VEC) {
+      if (!(row_ok && (n0 + c4) < N)) a0 = f4zero();
+      if (!(row_ok && (n0 + c4 + 32) < N)) a1 = f4zero();
+    }
+    st4(&Ys[r * LDT + c4], a0);
+    st4(&Ys[r * LDT + c4 + 32], a1);
+    st4(&Xs[r * LDT + c4], a_finish<PRO, VEC>(st, xr0, k0 + c4, K));
+    st4(&Xs[r * LDT + c4 + 32], a_finish<PRO, VEC>(st, xr1, k0 + c4 + 32, K));
   };
 
-  if (ms < me) load(ms);
+  if (ms < me) issue(ms);
   for (int m = ms; m < me; m += BM) {
-    st4(&Ys[r * LDT + c4], y0);
-    st4(&Ys[r * LDT + c4 + 32], y1);
-    st4(&Xs[r * LDT + c4], x0);
-    st4(&Xs[r * LDT + c4 + 32], x1);
+    store();
     __syncthreads();
-    if (m + BM < me) load(m + BM);
+    if (m + BM < me) issue(m + BM);
     if (do_bias && tid < WT) {
 #pragma unroll 8
       for (int rr = 0; rr < BM; ++rr) bsum += Ys[rr * LDT + tid];
@@ -668,7 +766,20 @@ extern "C" int dosx_wgrad(const DosxWgrad* gp, dosx_stream_t stream) {
     L.vecA = L.vecA && aligned16(g.pro_gamma) && aligned16(g.pro_beta);
   L.vecY = ((g.dy.ld & 3) == 0) && aligned16(g.dy.p) && (g.N & 3) == 0;
   dim3 grid(ceil_div(g.K, WT), ceil_div(g.N, WT), g.nsplit);
-  hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, to_stream(stream), L);
+  hipStream_t st = to_stream(stream);
+  const int vec = L.vecA && L.vecY;
+  if (!vec) {
+    DOSX_CHECK_ARG(g.pro == DOSX_PRO_NONE, "dosx_wgrad: prologue %d needs 4-float aligned operands", g.pro);
+    hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_NONE, 0>), grid, dim3(256), 0, st, L);
+  } else {
+    switch (g.pro) {
+      case DOSX_PRO_NONE: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_NONE, 1>), grid, dim3(256), 0, st, L); break;
+      case DOSX_PRO_PRELU: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_PRELU, 1>), grid, dim3(256), 0, st, L); break;
+      case DOSX_PRO_LN_PRELU: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_LN_PRELU, 1>), grid, dim3(256), 0, st, L); break;
+      case DOSX_PRO_ROWLN: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_ROWLN, 1>), grid, dim3(256), 0, st, L); break;
+      default: DOSX_CHECK_ARG(false, "dosx_wgrad: bad prologue %d", g.pro);
+    }
+  }
   DOSX_LAUNCH_CHECK();
   return 0;
 }
@@ -677,7 +788,7 @@ extern "C" int dosx_reduce_partials(const DosxReduceJob* jobs_dev, int n_jobs, i
   if (n_jobs <= 0) return 0;
   DOSX_CHECK_ARG(jobs_dev != nullptr && max_count > 0, "dosx_reduce_partials: bad args");
   int gx = ceil_div(max_count, 256);
-  if (gx > 64) gx = 64;
+  if (gx > 2048) gx = 2048;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, n_jobs), dim3(256), 0, to_stream(stream), jobs_dev);
   DOSX_LAUNCH_CHECK();
   return 0;

@@ -85,11 +85,15 @@ def mlp_prelu_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: G
 # ------------------------------------------------------------------------------------------------
 # Edge / Node MLP: Linear -> LayerNorm -> PReLU -> Linear     (DOSTransformer_phonon.py:193,204)
 # ------------------------------------------------------------------------------------------------
-def mlp_ln_fwd(P: Params, key: str, a: SegList, M: int, H: int, res: Optional[torch.Tensor] = None):
+def mlp_ln_fwd(P: Params, key: str, a: SegList, M: int, H: int, res: Optional[torch.Tensor] = None,
+               tag: Optional[str] = None):
     dev = P[key + ".0.weight"].device
     xhat = _empty(dev, M, 2 * H)
     rstd = _empty(dev, M)
+    ev = ops.KERNEL_TIMER.start() if tag else None
     ops.gemm(M, 2 * H, a.segs, P[key + ".0.weight"], xhat, bias=P[key + ".0.bias"], epi=EPI_LN, aux_out=rstd)
+    if ev is not None:
+        ops.KERNEL_TIMER.stop(ev, tag, "gemm_kernel<NT,LN-epilogue>", "mfma", 2.0 * M * a.K * 2 * H)
     y = _empty(dev, M, H)
     ops.gemm(M, H, [seg(xhat)], P[key + ".3.weight"], y, pro=PRO_LN_PRELU, pro_gamma=P[key + ".1.weight"],
              pro_beta=P[key + ".1.bias"], pro_alpha=P[key + ".2.weight"], bias=P[key + ".3.bias"], res=res)
@@ -129,11 +133,16 @@ def gnn_fwd(P: Params, m: GraphMeta, x: torch.Tensor, e: torch.Tensor, L: int, m
     for l in range(L):
         pre = f"stacked_processor.{l}"
         a_e = SegList([seg(x, rmap=rowmap(idx=m.src)), seg(x, rmap=rowmap(idx=m.dst)), seg(e)], [x, e])
-        msg, cxe = mlp_ln_fwd(P, pre + ".edge_model.edge_mlp", a_e, E, H)
+        msg, cxe = mlp_ln_fwd(P, pre + ".edge_model.edge_mlp", a_e, E, H, tag="edge_mlp_gemm1_fwd")
         agg = _empty(dev, N, H)
         last = l == L - 1                       # the last layer's edge update is dead
         e_new = None if last else _empty(dev, E, H)
+        ev = ops.KERNEL_TIMER.start()
         ops.segment_reduce(msg, m.rowptr_dst, scale, agg, e, e_new, N, E, H)
+        # algorithmic bytes: messages + CSR row pointers + aggregated output (+ the fused edge residual
+        # e_new = e + msg: one more read and one write of [E,H])
+        ops.KERNEL_TIMER.stop(ev, "scatter_add_fwd", "segment_reduce_kernel", "hbm",
+                              4.0 * (E * H + (N + 1) + N * H + (0 if last else 2 * E * H)))
         a_n = SegList([seg(x), seg(agg)], [x, agg])
         x_new, cxn = mlp_ln_fwd(P, pre + ".node_model.node_mlp_2", a_n, N, H, res=x)
         ctxs.append((cxe, cxn))
@@ -187,11 +196,16 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
         st1 = _empty(dev, rows, 2)
         a = _attn_desc(Sq, Bq, Nk, Bk, H, qs, qb, x, kvhat, g0, b0)
         a.out, a.probs, a.qstats, a.out_stats = x1.data_ptr(), probs.data_ptr(), qstats.data_ptr(), st1.data_ptr()
+        ev = ops.KERNEL_TIMER.start()
         ops.attention_fwd(a)
+        ops.KERNEL_TIMER.stop(ev, f"attention_fwd_{pre}", "attn_fwd_kernel", "mfma", 4.0 * Bq * Sq * Nk * H)
         h = _empty(dev, rows, 4 * H)
+        ev = ops.KERNEL_TIMER.start()
         ops.gemm(rows, 4 * H, [seg(x1)], P[lp + ".fc1.weight"], h, pro=PRO_ROWLN,
                  pro_gamma=P[lp + ".layer_norms.1.weight"], pro_beta=P[lp + ".layer_norms.1.bias"], pro_stats=st1,
                  bias=P[lp + ".fc1.bias"], act=ACT_RELU)
+        ops.KERNEL_TIMER.stop(ev, f"ffn_fc1_fwd_{pre}", "gemm_kernel<NT,rowLN-prologue,relu>", "mfma",
+                              2.0 * rows * H * 4 * H)
         x2 = _empty(dev, rows, H)
         ops.gemm(rows, H, [seg(h)], P[lp + ".fc2.weight"], x2, bias=P[lp + ".fc2.bias"], res=x1)
         lay.append((x, qs, qb, x1, probs, qstats, st1, h))

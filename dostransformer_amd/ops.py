@@ -20,6 +20,61 @@ EPI_BIAS_ACT, EPI_LN, EPI_PRELU_LN_BWD, EPI_RELU_MASK, EPI_ROWLN_BWD, EPI_PRELU_
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 
 
+class _KernelTimer:
+    """HIP-event timing of tagged launches (events are recorded on torch's current stream, the
+    stream every libdosx kernel is launched on).  Used by bench.py for the roofline figures."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []
+
+    def reset(self, enabled: bool):
+        self.enabled = enabled
+        self.records = []
+
+    def start(self):
+        if not self.enabled:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def stop(self, ev, tag: str, kernel: str, bound: str, work: float):
+        """work: algorithmic flops (bound == 'mfma') or bytes (bound == 'hbm') of this launch."""
+        if ev is None:
+            return
+        end = torch.cuda.Event(enable_timing=True)
+        end.record()
+        self.records.append((tag, kernel, bound, float(work), ev, end))
+
+    def roofline(self, hbm_peak_gbs: float, mfma_peak_tflops: float):
+        agg = {}
+        for tag, kernel, bound, work, s, e in self.records:
+            ms = s.elapsed_time(e)
+            a = agg.setdefault(tag, {"kernel": kernel, "bound": bound, "work": 0.0, "ms": 0.0, "n": 0})
+            a["work"] += work
+            a["ms"] += ms
+            a["n"] += 1
+        out = []
+        for tag, a in agg.items():
+            if a["ms"] <= 0:
+                continue
+            if a["bound"] == "mfma":
+                ach, peak, unit = a["work"] / (a["ms"] * 1e-3) / 1e12, mfma_peak_tflops, "TFLOP/s"
+            else:
+                ach, peak, unit = a["work"] / (a["ms"] * 1e-3) / 1e9, hbm_peak_gbs, "GB/s"
+            out.append({"site": tag, "kernel": a["kernel"], "bound": a["bound"], "achieved": round(ach, 3),
+                        "peak": peak, "unit": unit, "frac": round(ach / peak, 5), "traffic": None,
+                        "launches": a["n"], "avg_us": round(1e3 * a["ms"] / a["n"], 3),
+                        "work_per_launch": a["work"] / a["n"], "total_ms": round(a["ms"], 3)})
+        out.sort(key=lambda r: -r["total_ms"])
+        dom = dict(out[0]) if out else None
+        return {"dominant": dom, "all": out}
+
+
+KERNEL_TIMER = _KernelTimer()
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 

@@ -1,0 +1,124 @@
+"""CPU tests of the host-side logic: batch container / CSR metadata, drop-in module structure,
+flat-parameter storage, data-parallel sharding."""
+import numpy as np
+import pytest
+import torch
+
+from dostransformer_amd import synth
+from dostransformer_amd.batch import CrystalBatch, collate, graph_meta, split_crystals
+from dostransformer_amd.dist import shard_batch, shard_bounds
+
+
+def test_batch_mapping_and_attribute_protocol():
+    g = synth.phonon_batch(4, seed=1, dtype=torch.float64)
+    assert "batch" in g and "edge_index" in g and "pos" not in g          # DOSTransformer_phonon.py:48-56
+    assert g["edge_vec"] is g.edge_vec and g.x.shape[1] == 118 and g.phdos.shape == (4, 51)
+    assert g.system.shape == (4,) and g.system.dtype == torch.int64
+    e = synth.edos_batch(3, seed=2)
+    assert e.glob.shape == (6,) and e.y_ft.shape == (3 * 201,) and len(e.mp_id) == 3 and e.x.shape[1] == 200
+    counts = torch.bincount(e.batch)
+    ptr = torch.cumsum(counts, 0)
+    assert torch.all(e.x[ptr - 1] == 0)                                    # phantom all-zero node per crystal
+    assert not torch.isin(ptr - 1, e.edge_index.flatten()).any()           # ... and it is isolated
+    g.to("cpu")
+
+
+@pytest.mark.parametrize("sort_edges", [True, False])
+def test_csr_metadata(sort_edges):
+    g = synth.phonon_batch(5, seed=3, dtype=torch.float32, sort_edges=sort_edges)
+    m = graph_meta(g)
+    N, E, B = m.num_nodes, m.num_edges, m.num_graphs
+    src, dst = m.src.long(), m.dst.long()
+    assert torch.all(dst[1:] >= dst[:-1])
+    ei = g.edge_index if m.edge_perm is None else g.edge_index[:, m.edge_perm]
+    assert torch.equal(ei[0], src) and torch.equal(ei[1], dst)
+    rp = m.rowptr_dst.long()
+    for n in range(N):
+        assert torch.all(dst[rp[n]:rp[n + 1]] == n)
+    assert rp[-1] == E
+    rs = m.rowptr_src.long()
+    ps = m.perm_src.long()
+    for n in range(N):
+        assert torch.all(src[ps[rs[n]:rs[n + 1]]] == n)
+    assert sorted(ps.tolist()) == list(range(E))
+    gp = m.graph_ptr.long()
+    assert gp[-1] == N and m.n_max == int((gp[1:] - gp[:-1]).max())
+    pos = torch.arange(N) - gp[m.node_graph.long()]
+    assert torch.equal(m.dense_row.long(), pos * B + m.node_graph.long())
+    deg = torch.bincount(dst, minlength=N).clamp(min=1).float()
+    assert torch.allclose(m.inv_deg, 1.0 / deg)
+    with pytest.raises(ValueError):
+        collate(split_crystals(g), n_max=1)
+
+
+def test_foreign_batch_object_gets_metadata():
+    g = synth.edos_batch(3, seed=4, sort_edges=False)
+
+    class Foreign:            # e.g. a PyG Batch: attributes only
+        pass
+    f = Foreign()
+    for k in g.keys():
+        setattr(f, k, g[k])
+    m = graph_meta(f)
+    assert m.num_graphs == 3 and m.edge_perm is not None and m.num_edges == g.edge_index.shape[1]
+
+
+def test_split_collate_roundtrip():
+    g = synth.edos_batch(4, seed=5)
+    g2 = collate(split_crystals(g))
+    for k in ("x", "edge_index", "edge_attr", "glob", "y_ft", "system", "batch"):
+        assert torch.equal(g[k], g2[k]), k
+
+
+def test_shard_bounds_cover_and_balance():
+    for n, w in [(64, 8), (8, 8), (512, 8), (10, 3), (5, 2)]:
+        ne = np.random.RandomState(n).randint(40, 240, size=n).tolist()
+        b = shard_bounds(ne, w)
+        assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+        assert all(hi > lo for lo, hi in b)
+        loads = [sum(ne[lo:hi]) for lo, hi in b]
+        if n >= 8 * w:
+            assert max(loads) < 1.35 * sum(ne) / w
+    cs = synth.phonon_crystals(16, seed=6, dtype=torch.float32)
+    n_max = max(c["x"].shape[0] for c in cs)
+    shards = [shard_batch(cs, 4, r) for r in range(4)]
+    assert sum(s.num_graphs for s in shards) == 16 and all(s.meta.n_max == n_max for s in shards)
+
+
+def test_flat_params_layout_and_dead_parameters():
+    from dostransformer_amd._fused import FlatParams, is_dead_param
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    torch.manual_seed(0)
+    model = DOSTransformer_phonon(3, 2, 118, 4, 16, "cpu", 0.0)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    fp = FlatParams(model, torch.device("cpu"))
+    after = model.state_dict()
+    assert list(before) == list(after) and all(torch.equal(before[k], after[k]) for k in before)
+    dead = [n for n, _ in model.named_parameters() if is_dead_param(n)]
+    n_dead = sum(p.numel() for n, p in model.named_parameters() if is_dead_param(n))
+    assert "alpha" in dead and any("node_mlp_1" in d for d in dead) and any("in_proj_weight" in d for d in dead)
+    assert all(n not in fp.P for n in dead) and n_dead > 0
+    for n, p in model.named_parameters():
+        if n in fp.P:
+            assert p.data_ptr() == fp.P[n].data_ptr() and fp.G[n].shape == p.shape
+            assert (p.data_ptr() - fp.flat.data_ptr()) % 256 == 0
+    # in-place updates of the flat buffer are what the module sees (fused AdamW writes there)
+    fp.flat.add_(1.0)
+    assert torch.allclose(model.fc.weight, before["fc.weight"] + 1.0)
+    assert fp.intact(torch.device("cpu"))
+    model.double()
+    assert not fp.intact(torch.device("cpu"))            # .to()/.double() re-homes parameters -> re-flatten
+
+
+def test_drop_in_aliases():
+    import sys
+    import dostransformer_amd
+    dostransformer_amd.install_dropin()
+    from layers import TransformerEncoder                                   # reference: DOSTransformer.py:6
+    from embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon  # reference: main_phDOS.py:67
+    from embedder_eDOS.DOSTransformer import DOSTransformer                 # reference: main_eDOS.py:68
+    from embedder_eDOS.graphnetwork import Graphnetwork
+    from embedder_phDOS.graphnetwork_phonon import Graphnetwork_phonon
+    assert TransformerEncoder.__module__.startswith("dostransformer_amd")
+    for k in ("layers", "embedder_phDOS", "embedder_eDOS"):
+        sys.modules.pop(k, None)

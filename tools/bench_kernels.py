@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of the libdosx kernels at the shapes of the BASELINE configs (and at a
+roofline scale that leaves the 256 MiB Infinity Cache).  Prints one line per case:
+achieved TFLOP/s (fp32 MFMA peak 157.3) or GB/s (HBM peak 8000)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dostransformer_amd import ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def timeit(fn, iters=50, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) * 1e3 / iters     # us
+
+
+def gemm_case(name, M, N, K, wl=0, pro=0, epi=0, nseg=1, gather=False):
+    a = torch.randn(M, K // nseg, device=DEV)
+    segs = [ops.seg(a)] * nseg
+    if gather:
+        n_nodes = max(1, M // 20)
+        x = torch.randn(n_nodes, K // 3, device=DEV)
+        src = torch.randint(0, n_nodes, (M,), device=DEV, dtype=torch.int32)
+        dst = torch.sort(torch.randint(0, n_nodes, (M,), device=DEV, dtype=torch.int32))[0]
+        e = torch.randn(M, K // 3, device=DEV)
+        segs = [ops.seg(x, rmap=ops.rowmap(idx=src)), ops.seg(x, rmap=ops.rowmap(idx=dst)), ops.seg(e)]
+    w = torch.randn(N, K, device=DEV) if wl == 0 else torch.randn(K, N, device=DEV)
+    out = torch.empty(M, N, device=DEV)
+    kw = {}
+    if epi == ops.EPI_LN:
+        kw = dict(epi=ops.EPI_LN, aux_out=torch.empty(M, device=DEV), bias=torch.randn(N, device=DEV))
+    if pro == ops.PRO_LN_PRELU:
+        kw.update(pro=pro, pro_gamma=torch.randn(K, device=DEV), pro_beta=torch.randn(K, device=DEV),
+                  pro_alpha=torch.tensor([0.25], device=DEV))
+    if pro == ops.PRO_ROWLN:
+        kw.update(pro=pro, pro_gamma=torch.randn(K, device=DEV), pro_beta=torch.randn(K, device=DEV),
+                  pro_stats=torch.rand(M, 2, device=DEV))
+    us = timeit(lambda: ops.gemm(M, N, segs, w, out, w_layout=wl, **kw))
+    tf = 2.0 * M * N * K / us / 1e6
+    print(f"gemm  {name:34s} M={M:6d} N={N:4d} K={K:4d} wl={wl} pro={pro} epi={epi}: {us:8.1f} us  {tf:6.1f} TF/s  "
+          f"({100 * tf / 157.3:4.1f}% of fp32 MFMA peak)")
+
+
+def wgrad_case(name, M, N, K):
+    dy = torch.randn(M, N, device=DEV)
+    a = torch.randn(M, K, device=DEV)
+    ns = ops.wgrad_splits(M, N, K)
+    slab = torch.empty(ns, N, K, device=DEV)
+    sb = torch.empty(ns, N, device=DEV)
+    us = timeit(lambda: ops.wgrad(M, N, ops.seg(dy), [ops.seg(a)], slab, sb, ns))
+    tf = 2.0 * M * N * K / us / 1e6
+    print(f"wgrad {name:34s} M={M:6d} N={N:4d} K={K:4d} splits={ns:2d}: {us:8.1f} us  {tf:6.1f} TF/s  "
+          f"({100 * tf / 157.3:4.1f}%)")
+
+
+def segreduce_case(name, N, deg, H, residual=True):
+    E = N * deg
+    msg = torch.randn(E, H, device=DEV)
+    e_in = torch.randn(E, H, device=DEV) if residual else None
+    e_out = torch.empty(E, H, device=DEV) if residual else None
+    rowptr = (torch.arange(N + 1, device=DEV, dtype=torch.int32) * deg).contiguous()
+    agg = torch.empty(N, H, device=DEV)
+    us = timeit(lambda: ops.segment_reduce(msg, rowptr, None, agg, e_in, e_out, N, E, H))
+    by = 4.0 * (E * H + N + 1 + N * H + (2 * E * H if residual else 0))
+    print(f"scatter-add {name:28s} N={N:8d} E={E:9d} H={H} residual={int(residual)}: {us:9.1f} us  "
+          f"{by / us / 1e3:7.1f} GB/s ({100 * by / us / 1e3 / 8000:4.1f}% of 8 TB/s)  [{by / 1e6:.1f} MB]")
+
+
+def attn_case(name, Sq, Bq, Nk, Bk, H):
+    from dostransformer_amd._lib import Attn
+    x = torch.randn(Sq * Bq, H, device=DEV)
+    kv = torch.randn(Nk * Bk, H, device=DEV)
+    g, b = torch.randn(H, device=DEV), torch.randn(H, device=DEV)
+    out = torch.empty(Sq * Bq, H, device=DEV)
+    probs = torch.empty(Bq, Sq, Nk, device=DEV)
+    qs, os_ = torch.empty(Sq * Bq, 2, device=DEV), torch.empty(Sq * Bq, 2, device=DEV)
+    a = Attn()
+    a.Sq, a.Bq, a.Nk, a.Bk, a.H, a.q_stride_s, a.q_stride_b = Sq, Bq, Nk, Bk, H, Bq, 1
+    a.x, a.kvhat, a.gamma0, a.beta0 = x.data_ptr(), kv.data_ptr(), g.data_ptr(), b.data_ptr()
+    a.out, a.probs, a.qstats, a.out_stats = out.data_ptr(), probs.data_ptr(), qs.data_ptr(), os_.data_ptr()
+    us = timeit(lambda: ops.attention_fwd(a))
+    fl = 4.0 * Bq * Sq * Nk * H
+    dout = torch.randn(Sq * Bq, H, device=DEV)
+    dx = torch.empty(Sq * Bq, H, device=DEV)
+    dsc = torch.empty(Bq, Sq, Nk, device=DEV)
+    dkv = torch.zeros(Nk * Bk, H, device=DEV)
+    nqt, nkt = (Sq + 31) // 32, (Nk + 31) // 32
+    part = torch.empty(Bq * nqt + Bk * nkt, 2 * H, device=DEV)
+    a.dout, a.dx, a.dscores, a.dkvhat, a.dkv_accumulate = dout.data_ptr(), dx.data_ptr(), dsc.data_ptr(), dkv.data_ptr(), 1
+    a.partials_q, a.partials_kv = part.data_ptr(), part.data_ptr() + 4 * Bq * nqt * 2 * H
+    usb = timeit(lambda: ops.attention_bwd(a))
+    print(f"attn  {name:30s} Sq={Sq} Bq={Bq} Nk={Nk} H={H}: fwd {us:7.1f} us {fl / us / 1e6:6.2f} TF/s "
+          f"({100 * fl / us / 1e6 / 157.3:4.1f}%) | bwd(dq+dkv) {usb:7.1f} us {2.5 * fl / usb / 1e6:6.2f} TF/s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--what", default="all")
+    args = ap.parse_args()
+    w = args.what
+    H = 128
+    E, N, R1, R2 = 9000, 450, 51 * 64, 51 * 128
+    if w in ("all", "gemm"):
+        gemm_case("edge gemm1 (gather, LN epi)", E, 2 * H, 3 * H, epi=ops.EPI_LN, gather=True)
+        gemm_case("edge gemm1 (plain A, LN epi)", E, 2 * H, 3 * H, epi=ops.EPI_LN)
+        gemm_case("edge gemm2 (LN_PRELU pro)", E, H, 2 * H, pro=ops.PRO_LN_PRELU)
+        gemm_case("edge dgrad (dz->dcat)", E, 3 * H, 2 * H, wl=1)
+        gemm_case("edge dgrad2 (dy->da)", E, 2 * H, H, wl=1)
+        gemm_case("node gemm1", N, 2 * H, 2 * H, epi=ops.EPI_LN)
+        gemm_case("ffn fc1 (rowLN pro) 2B", R2, 4 * H, H, pro=ops.PRO_ROWLN)
+        gemm_case("ffn fc2 2B", R2, H, 4 * H)
+        gemm_case("ffn fc1 B", R1, 4 * H, H, pro=ops.PRO_ROWLN)
+        gemm_case("ffn dgrad fc2 (dy->dh)", R2, 4 * H, H, wl=1)
+        gemm_case("ffn dgrad fc1 (dh->dx)", R2, H, 4 * H, wl=1)
+        gemm_case("big  (roofline scale)", 262144, 512, 128, pro=0)
+        gemm_case("big2 (roofline scale)", 262144, 256, 384, epi=ops.EPI_LN)
+        gemm_case("eDOS edge gemm1 H256", 16000, 512, 768, epi=ops.EPI_LN)
+        gemm_case("eDOS fc1 H256 2B", 201 * 128, 1024, 256, pro=ops.PRO_ROWLN)
+    if w in ("all", "wgrad"):
+        wgrad_case("edge W1 (2H x 3H)", E, 2 * H, 3 * H)
+        wgrad_case("edge W2 (H x 2H)", E, H, 2 * H)
+        wgrad_case("fc1 (4H x H) 2B", R2, 4 * H, H)
+        wgrad_case("fc2 (H x 4H) 2B", R2, H, 4 * H)
+        wgrad_case("node W1", N, 2 * H, 2 * H)
+        wgrad_case("big", 262144, 512, 128)
+    if w in ("all", "scatter"):
+        segreduce_case("cfg2 batch", 450, 20, 128)
+        segreduce_case("cfg2 batch (last layer)", 450, 20, 128, residual=False)
+        segreduce_case("roofline scale 4Mi edges", 209715, 20, 128)
+        segreduce_case("roofline scale, no residual", 209715, 20, 128, residual=False)
+        segreduce_case("roofline scale H=256", 104857, 20, 256)
+    if w in ("all", "attn"):
+        attn_case("phonon cross (energies->atoms)", 51, 64, 12, 64, 128)
+        attn_case("phonon cross 2B", 51, 128, 12, 64, 128)
+        attn_case("phonon self 2B", 51, 128, 51, 128, 128)
+        attn_case("eDOS cross 2B", 201, 128, 41, 64, 256)
+        attn_case("eDOS self 2B", 201, 128, 201, 128, 256)
+        attn_case("roofline scale self", 201, 2048, 201, 2048, 256)
+
+
+if __name__ == "__main__":
+    main()
