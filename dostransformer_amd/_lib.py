@@ -10,7 +10,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdosx.so")
+LIB_PATH = os.environ.get("DOSX_LIB") or os.path.join(_HERE, "csrc", "libdosx.so")   # DOSX_LIB: diagnostic builds only
 
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int32)
@@ -89,7 +89,7 @@ _SIGS = {
     "dosx_gemm": [C.POINTER(Gemm), _P],
     "dosx_wgrad_splits": [_I, _I, _I],
     "dosx_wgrad": [C.POINTER(Wgrad), _P],
-    "dosx_reduce_partials": [_P, _I, _I, _P],
+    "dosx_reduce_partials": [C.POINTER(ReduceJob), _I, _P],
     "dosx_edge_feat_sh1": [_P, _P, _I, _F, _P],
     "dosx_segment_reduce": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "dosx_edge_grad_combine": [_P, _P, _I, _P, _P, _P, _I, _I, _P],

@@ -78,7 +78,25 @@ __device__ __forceinline__ void stage_v_chunk(float* Vs, const float* __restrict
   }
 }
 
+// Whole key set of one crystal into LDS: Ks[j][0..HP) = kvhat[(j*Bk+bk)]*gamma+beta (zero beyond Nk / H).
+// Used by the key-resident kernels: ONE global-load phase, then QK^T and PV both read this tile.
+__device__ __forceinline__ void stage_k_full(float* Ks, const float* __restrict__ kvhat, const float* __restrict__ gamma,
+                                             const float* __restrict__ beta, int Nk, int NKP, int Bk, int bk, int H, int HP,
+                                             int LDH, int tid) {
+  for (int c = (tid & 7) * 4; c < HP; c += 32) {
+    const int cc = c < H ? c : 0;
+    const float4 g = ld4(gamma + cc), b = ld4(beta + cc);
+    for (int j = tid >> 3; j < NKP; j += 32) {
+      const float4 h = ld4(kvhat + ((size_t)min(j, Nk - 1) * Bk + bk) * H + cc);
+      float4 v = make_float4(h.x * g.x + b.x, h.y * g.y + b.y, h.z * g.z + b.z, h.w * g.w + b.w);
+      if (!(j < Nk && c < H)) v = f4zero();
+      st4(Ks + j * LDH + c, v);
+    }
+  }
+}
+
 // S[32][NKP] (+)= A[32][H] . K^T : A tile resident in LDS (As, stride LDH), K streamed in k-chunks.
+template <bool KRES>
 __device__ __forceinline__ void qk_product(f32x16 (&acc)[MAX_KT], const float* As, int LDH, float* Ks,
                                            const float* kvhat, const float* gamma, const float* beta, int Nk, int NKP,
                                            int Bk, int bk, int H, int HP, int tid) {
@@ -89,8 +107,10 @@ __device__ __forceinline__ void qk_product(f32x16 (&acc)[MAX_KT], const float* A
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   for (int kc = 0; kc < HP; kc += KC) {
-    stage_k_chunk(Ks, kvhat, gamma, beta, Nk, NKP, Bk, bk, H, kc, tid);
-    __syncthreads();
+    if (!KRES) {
+      stage_k_chunk(Ks, kvhat, gamma, beta, Nk, NKP, Bk, bk, H, kc, tid);
+      __syncthreads();
+    }
 #pragma unroll
     for (int kk = 0; kk < KC; kk += 8) {
       const float4 a = ld4(As + l31 * LDH + kc + kk + 4 * hh);
@@ -98,14 +118,15 @@ __device__ __forceinline__ void qk_product(f32x16 (&acc)[MAX_KT], const float* A
       for (int t = 0; t < MAX_KT; ++t) {
         const int jt = wave + 4 * t;
         if (jt >= nkt) continue;
-        const float4 b = ld4(Ks + (jt * 32 + l31) * LDK + kk + 4 * hh);
+        const float4 b = KRES ? ld4(Ks + (jt * 32 + l31) * LDH + kc + kk + 4 * hh)
+                              : ld4(Ks + (jt * 32 + l31) * LDK + kk + 4 * hh);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
       }
     }
-    __syncthreads();
+    if (!KRES) __syncthreads();
   }
 }
 
@@ -127,6 +148,7 @@ __device__ __forceinline__ void store_scores(const f32x16 (&acc)[MAX_KT], float*
 }
 
 // O[32][HP] = P[32][NKP] . V : P resident in LDS (Ps, stride LDS_), V streamed in 32-key chunks.
+template <bool KRES>
 __device__ __forceinline__ void pv_product(f32x16 (&acc)[MAX_CT], const float* Ps, int LDS_, float* Vs,
                                            const float* kvhat, const float* gamma, const float* beta, int Nk, int NKP,
                                            int Bk, int bk, int H, int HP, int LDH, int tid) {
@@ -137,8 +159,10 @@ __device__ __forceinline__ void pv_product(f32x16 (&acc)[MAX_CT], const float* P
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   for (int j0 = 0; j0 < NKP; j0 += KC) {
-    stage_v_chunk(Vs, kvhat, gamma, beta, Nk, Bk, bk, H, HP, LDH, j0, tid);
-    __syncthreads();
+    if (!KRES) {
+      stage_v_chunk(Vs, kvhat, gamma, beta, Nk, Bk, bk, H, HP, LDH, j0, tid);
+      __syncthreads();
+    }
 #pragma unroll
     for (int kk = 0; kk < KC; kk += 8) {
       const float4 a = ld4(Ps + l31 * LDS_ + j0 + kk + 4 * hh);
@@ -146,14 +170,14 @@ __device__ __forceinline__ void pv_product(f32x16 (&acc)[MAX_CT], const float* P
       for (int t = 0; t < MAX_CT; ++t) {
         const int ct = wave + 4 * t;
         if (ct >= nct) continue;
-        const float* bp = Vs + (kk + 4 * hh) * LDH + ct * 32 + l31;
+        const float* bp = Vs + ((KRES ? j0 : 0) + kk + 4 * hh) * LDH + ct * 32 + l31;
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bp[0], acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bp[LDH], acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bp[2 * LDH], acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bp[3 * LDH], acc[t], 0, 0, 0);
       }
     }
-    __syncthreads();
+    if (!KRES) __syncthreads();
   }
 }
 
@@ -208,6 +232,7 @@ __device__ __forceinline__ void ln_rows_inplace(float* T, int LDH, int H, const 
 }
 
 // ================================== forward =====================================================
+template <bool KRES>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const DosxAttn a) {
   extern __shared__ __align__(16) float sm[];
   const Geo g = make_geo(a.H, a.Nk);
@@ -222,6 +247,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const DosxAttn a) {
     const int s = s0 + i;
     return s < Sq ? a.x + ((size_t)s * a.q_stride_s + (size_t)bq * a.q_stride_b) * H : nullptr;
   }, tid);
+  if (KRES) stage_k_full(KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, g.LDH, tid);
   __syncthreads();
   if (!(a.flags & DOSX_ATTN_RAW_Q)) {
     ln_rows_inplace(Qs, g.LDH, H, a.gamma0, a.beta0, a.qstats, s0, Sq, a.Bq, bq, tid);
@@ -229,7 +255,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const DosxAttn a) {
   }
 
   f32x16 sacc[MAX_KT];
-  qk_product(sacc, Qs, g.LDH, KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, tid);
+  qk_product<KRES>(sacc, Qs, g.LDH, KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, tid);
   store_scores(sacc, Ss, g.LDS_, g.NKP, rsqrtf((float)H), tid);
   __syncthreads();
 
@@ -256,7 +282,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const DosxAttn a) {
   __syncthreads();
 
   f32x16 oacc[MAX_CT];
-  pv_product(oacc, Ss, g.LDS_, KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, g.LDH, tid);
+  pv_product<KRES>(oacc, Ss, g.LDS_, KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, g.LDH, tid);
   store_out_tile(oacc, Qs, g.LDH, g.HP, tid);
   __syncthreads();
 
@@ -292,14 +318,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const DosxAttn a) {
 }
 
 // ================================== backward: dq / dx ============================================
+template <bool KRES>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const DosxAttn a) {
   extern __shared__ __align__(16) float sm[];
   const Geo g = make_geo(a.H, a.Nk);
   float* Ds = sm;                                   // [32][LDH]  dOut tile, later dq tile
   float* Ps = Ds + QT * g.LDH;                      // [32][LDS_] probabilities
   float* Ss = Ps + QT * g.LDS_;                     // [32][LDS_] dP -> dS
-  float* KV = Ss + QT * g.LDS_;                     // chunk staging
-  float* Pp = KV + max(g.NKP * LDK, KC * g.LDH);    // [4][2][HP] partial column sums
+  float* KV = Ss + QT * g.LDS_;                     // chunk staging, or the whole key tile (KRES)
+  float* Pp = KV + (KRES ? g.NKP * g.LDH : max(g.NKP * LDK, KC * g.LDH));    // [4][2][HP] partial column sums
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int s0 = blockIdx.x * QT, bq = blockIdx.y, bk = bq % a.Bk;
   const int H = a.H, Sq = a.Sq, Nk = a.Nk;
@@ -314,11 +341,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const DosxAttn a) {
     for (int j = lane; j < g.NKP; j += 64)
       Ps[i * g.LDS_ + j] = (s < Sq && j < Nk) ? a.probs[((size_t)bq * Sq + s) * Nk + j] : 0.f;
   }
+  if (KRES) stage_k_full(KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, g.LDH, tid);
   __syncthreads();
 
   // dP = dO . V^T
   f32x16 sacc[MAX_KT];
-  qk_product(sacc, Ds, g.LDH, KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, tid);
+  qk_product<KRES>(sacc, Ds, g.LDH, KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, tid);
   store_scores(sacc, Ss, g.LDS_, g.NKP, 1.f, tid);
   __syncthreads();
 
@@ -341,7 +369,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const DosxAttn a) {
 
   // dq_ln = dS . K
   f32x16 oacc[MAX_CT];
-  pv_product(oacc, Ss, g.LDS_, KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, g.LDH, tid);
+  pv_product<KRES>(oacc, Ss, g.LDS_, KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, g.LDH, tid);
   store_out_tile(oacc, Ds, g.LDH, g.HP, tid);
   __syncthreads();
 
@@ -409,6 +437,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const DosxAttn a) {
   const int j0 = blockIdx.x * 32, bk = blockIdx.y;
   const int H = a.H, Sq = a.Sq, Nk = a.Nk;
   const int nct = g.HP / 32;
+  const bool raw_q = (a.flags & DOSX_ATTN_RAW_Q) != 0;
+  constexpr int MAXC = 4 * MAX_CT;                  // column groups of 32 per row (H <= 256)
 
   f32x16 acc[MAX_CT];
 #pragma unroll
@@ -416,57 +446,88 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const DosxAttn a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  for (int bq = bk; bq < a.Bq; bq += a.Bk) {
-    for (int s0 = 0; s0 < Sq; s0 += QT) {
-      load_rows(dOs, g.LDH, g.HP, H, [&](int i) -> const float* {
-        const int s = s0 + i;
-        return s < Sq ? a.dout + ((size_t)s * a.Bq + bq) * H : nullptr;
-      }, tid);
-      load_rows(Qs, g.LDH, g.HP, H, [&](int i) -> const float* {
-        const int s = s0 + i;
-        return s < Sq ? a.x + ((size_t)s * a.q_stride_s + (size_t)bq * a.q_stride_b) * H : nullptr;
-      }, tid);
-      {
-        const int i = tid >> 3, s = s0 + i;
-        for (int jj = (tid & 7); jj < 32; jj += 8) {
-          const int j = j0 + jj;
-          const bool ok = (s < Sq) && (j < Nk);
-          const size_t o = ((size_t)bq * Sq + s) * Nk + j;
-          Pc[i * LDK + jj] = ok ? a.probs[o] : 0.f;
-          Sc[i * LDK + jj] = ok ? a.dscores[o] : 0.f;
-        }
-      }
-      __syncthreads();
-      // recompute LN0(x) for the query rows in place (rows beyond Sq are zero rows: their P/dS are 0)
-      for (int i = 0; i < 8; ++i) {
-        const int lr = wave * 8 + i, s = s0 + lr;
-        if (s >= Sq || (a.flags & DOSX_ATTN_RAW_Q)) break;
-        const size_t orow = (size_t)s * a.Bq + bq;
-        const float mean = a.qstats[2 * orow], rstd = a.qstats[2 * orow + 1];
-        float* row = Qs + lr * g.LDH;
-        for (int c = lane * 4; c < H; c += 256) {
-          const float4 v = ld4(row + c), gm = ld4(a.gamma0 + c), bt = ld4(a.beta0 + c);
-          st4(row + c, make_float4((v.x - mean) * rstd * gm.x + bt.x, (v.y - mean) * rstd * gm.y + bt.y,
-                                   (v.z - mean) * rstd * gm.z + bt.z, (v.w - mean) * rstd * gm.w + bt.w));
-        }
-      }
-      __syncthreads();
+  // staging registers of the NEXT (query batch entry, 32-query chunk): loads are issued one iteration
+  // ahead (before the MFMA block) from clamped addresses and masked / normalised when stored to LDS
+  const int ri = tid >> 3, cg = tid & 7;
+  float4 rdo[MAXC], rx[MAXC], gq[MAXC], bt[MAXC];
+  float rp[4], rs[4], rmean = 0.f, rrstd = 1.f;
+  bool rok = false;
 #pragma unroll
-      for (int mm = 0; mm < QT; mm += 2) {
-        const float pa = Pc[(mm + hh) * LDK + l31];
-        const float sa = Sc[(mm + hh) * LDK + l31];
+  for (int c = 0; c < MAXC; ++c) {
+    const int col = cg * 4 + 32 * c, cc = col < H ? col : 0;
+    gq[c] = ld4(a.gamma0 + cc);
+    bt[c] = ld4(a.beta0 + cc);
+  }
+  const int nchunks = (Sq + QT - 1) / QT, nit = (a.Bq / a.Bk) * nchunks;
+  auto issue = [&](int it) {
+    const int bq = bk + (it / nchunks) * a.Bk, s = (it % nchunks) * QT + ri;
+    rok = s < Sq;
+    const int sc = rok ? s : Sq - 1;
+    const float* dop = a.dout + ((size_t)sc * a.Bq + bq) * H;
+    const float* xp = a.x + ((size_t)sc * a.q_stride_s + (size_t)bq * a.q_stride_b) * H;
 #pragma unroll
-        for (int t = 0; t < MAX_CT; ++t) {
-          const int ct = wave + 4 * t;
-          if (ct >= nct) continue;
-          const float b1 = dOs[(mm + hh) * g.LDH + ct * 32 + l31];
-          const float b2 = Qs[(mm + hh) * g.LDH + ct * 32 + l31];
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa, b1, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa, b2, acc[t], 0, 0, 0);
-        }
+    for (int c = 0; c < MAXC; ++c) {
+      if (c < nct) {
+        const int col = cg * 4 + 32 * c, cc = col < H ? col : 0;
+        rdo[c] = ld4(dop + cc);
+        rx[c] = ld4(xp + cc);
       }
-      __syncthreads();
     }
+    const size_t prow = ((size_t)bq * Sq + sc) * Nk;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int jc = min(j0 + cg + 8 * jj, Nk - 1);
+      rp[jj] = a.probs[prow + jc];
+      rs[jj] = a.dscores[prow + jc];
+    }
+    if (!raw_q) {
+      rmean = a.qstats[2 * ((size_t)sc * a.Bq + bq)];
+      rrstd = a.qstats[2 * ((size_t)sc * a.Bq + bq) + 1];
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      if (c < nct) {
+        const int col = cg * 4 + 32 * c;
+        const bool valid = rok && col < H;
+        float4 d = rdo[c], q = rx[c];
+        if (!raw_q)
+          q = make_float4((q.x - rmean) * rrstd * gq[c].x + bt[c].x, (q.y - rmean) * rrstd * gq[c].y + bt[c].y,
+                          (q.z - rmean) * rrstd * gq[c].z + bt[c].z, (q.w - rmean) * rrstd * gq[c].w + bt[c].w);
+        if (!valid) { d = f4zero(); q = f4zero(); }
+        st4(dOs + ri * g.LDH + col, d);
+        st4(Qs + ri * g.LDH + col, q);
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const bool valid = rok && (j0 + cg + 8 * jj) < Nk;
+      Pc[ri * LDK + cg + 8 * jj] = valid ? rp[jj] : 0.f;
+      Sc[ri * LDK + cg + 8 * jj] = valid ? rs[jj] : 0.f;
+    }
+  };
+
+  issue(0);
+  for (int it = 0; it < nit; ++it) {
+    store();
+    __syncthreads();
+    if (it + 1 < nit) issue(it + 1);
+#pragma unroll
+    for (int mm = 0; mm < QT; mm += 2) {
+      const float pa = Pc[(mm + hh) * LDK + l31];
+      const float sa = Sc[(mm + hh) * LDK + l31];
+#pragma unroll
+      for (int t = 0; t < MAX_CT; ++t) {
+        const int ct = wave + 4 * t;
+        if (ct >= nct) continue;
+        const float b1 = dOs[(mm + hh) * g.LDH + ct * 32 + l31];
+        const float b2 = Qs[(mm + hh) * g.LDH + ct * 32 + l31];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa, b1, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa, b2, acc[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
   }
 
   store_out_tile(acc, Qs, g.LDH, g.HP, tid);
@@ -496,12 +557,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const DosxAttn a) {
   }
 }
 
-size_t fwd_smem(const Geo& g) {
-  return sizeof(float) * (size_t)(QT * g.LDH + QT * g.LDS_ + max(g.NKP * LDK, KC * g.LDH));
+size_t fwd_smem(const Geo& g, bool kres) {
+  return sizeof(float) * (size_t)(QT * g.LDH + QT * g.LDS_ + (kres ? g.NKP * g.LDH : max(g.NKP * LDK, KC * g.LDH)));
 }
-size_t dq_smem(const Geo& g) {
-  return sizeof(float) * (size_t)(QT * g.LDH + 2 * QT * g.LDS_ + max(g.NKP * LDK, KC * g.LDH) + 8 * g.HP);
+size_t dq_smem(const Geo& g, bool kres) {
+  return sizeof(float) *
+         (size_t)(QT * g.LDH + 2 * QT * g.LDS_ + (kres ? g.NKP * g.LDH : max(g.NKP * LDK, KC * g.LDH)) + 8 * g.HP);
 }
+constexpr size_t KRES_LDS_LIMIT = 144 * 1024;   // keep the whole key tile of a crystal in LDS when it fits
 size_t dkv_smem(const Geo& g) { return sizeof(float) * (size_t)(2 * QT * g.LDH + 2 * QT * LDK + 8 * g.HP); }
 
 int check_attn(const DosxAttn& a, const char* who) {
@@ -521,15 +584,20 @@ extern "C" int dosx_attention_fwd(const DosxAttn* ap, dosx_stream_t stream) {
   if (int rc = check_attn(a, "dosx_attention_fwd")) return rc;
   DOSX_CHECK_ARG(a.out, "dosx_attention_fwd: null out");
   const Geo g = make_geo(a.H, a.Nk);
-  const size_t smem = fwd_smem(g);
+  const bool kres = fwd_smem(g, true) <= KRES_LDS_LIMIT;
+  const size_t smem = fwd_smem(g, kres);
   DOSX_CHECK_ARG(smem <= 160 * 1024, "dosx_attention_fwd: LDS need %zu > 160 KiB", smem);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(ceil_div(a.Sq, QT), a.Bq), dim3(256), smem, to_stream(stream), a);
+  const dim3 grid(ceil_div(a.Sq, QT), a.Bq);
+  if (kres) hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, dim3(256), smem, to_stream(stream), a);
+  else hipLaunchKernelGGL((attn_fwd_kernel<false>), grid, dim3(256), smem, to_stream(stream), a);
   DOSX_LAUNCH_CHECK();
   return 0;
 }
@@ -540,17 +608,22 @@ extern "C" int dosx_attention_bwd(const DosxAttn* ap, dosx_stream_t stream) {
   if (int rc = check_attn(a, "dosx_attention_bwd")) return rc;
   DOSX_CHECK_ARG(a.dout && a.dx && a.dscores && a.dkvhat && a.partials_q && a.partials_kv, "dosx_attention_bwd: null operand");
   const Geo g = make_geo(a.H, a.Nk);
-  const size_t s1 = dq_smem(g), s2 = dkv_smem(g);
+  const bool kres = dq_smem(g, true) <= KRES_LDS_LIMIT;
+  const size_t s1 = dq_smem(g, kres), s2 = dkv_smem(g);
   DOSX_CHECK_ARG(s1 <= 160 * 1024 && s2 <= 160 * 1024, "dosx_attention_bwd: LDS need %zu/%zu > 160 KiB", s1, s2);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(ceil_div(a.Sq, QT), a.Bq), dim3(256), s1, to_stream(stream), a);
+  const dim3 grid(ceil_div(a.Sq, QT), a.Bq);
+  if (kres) hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, dim3(256), s1, to_stream(stream), a);
+  else hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), grid, dim3(256), s1, to_stream(stream), a);
   DOSX_LAUNCH_CHECK();
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(ceil_div(a.Nk, 32), a.Bk), dim3(256), s2, to_stream(stream), a);
   DOSX_LAUNCH_CHECK();

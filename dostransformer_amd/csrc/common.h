@@ -34,19 +34,43 @@ static inline hipStream_t to_stream(dosx_stream_t s) { return reinterpret_cast<h
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 __device__ __forceinline__ int dosx_map_row(const DosxRowMap& rm, int r) {
-  int t = (r / rm.d) * rm.m + (r % rm.d) * rm.c + rm.off;
+  int t;
+  if (rm.d >= (1 << 30)) t = r * rm.c + rm.off;     // no div/mod part (identity maps): skip the two integer divisions
+  else t = (r / rm.d) * rm.m + (r % rm.d) * rm.c + rm.off;
   return rm.idx ? rm.idx[t] : t;
 }
 
+// Wave64 all-reduce on the DPP path.  __shfl_xor() lowers to ds_bpermute_b32 (an LDS-pipe round
+// trip, ~100+ cycles per step, 6 dependent steps): measured 1.4-1.6k cycles per LayerNorm row in
+// the row-wise epilogues.  Here: 4 single-instruction DPP steps make every lane of a 16-lane row hold
+// its row total, then the 4 row totals are read with v_readlane and combined on uniform registers.
+//   quad_perm[1,0,3,2] = xor 1 ; quad_perm[2,3,0,1] = xor 2 ; row_half_mirror / row_mirror exchange
+//   the (already uniform) quads / halves of a row.
+#define DOSX_DPP_F(v, ctrl) \
+  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, false))
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += DOSX_DPP_F(v, 0xB1);    // quad_perm [1,0,3,2]
+  v += DOSX_DPP_F(v, 0x4E);    // quad_perm [2,3,0,1]
+  v += DOSX_DPP_F(v, 0x141);   // row_half_mirror
+  v += DOSX_DPP_F(v, 0x140);   // row_mirror
+  const int iv = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+  return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, DOSX_DPP_F(v, 0xB1));
+  v = fmaxf(v, DOSX_DPP_F(v, 0x4E));
+  v = fmaxf(v, DOSX_DPP_F(v, 0x141));
+  v = fmaxf(v, DOSX_DPP_F(v, 0x140));
+  const int iv = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }

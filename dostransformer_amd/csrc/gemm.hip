@@ -12,6 +12,19 @@
 
 #include "common.h"
 
+// Diagnostic build only (-DDOSX_STAMPS, never shipped): wave 0 of a few workgroups records
+// s_memtime at phase boundaries (see tools/stamp_gemm.py).
+#ifdef DOSX_STAMPS
+extern "C" { __device__ unsigned long long dosx_stamp_buf[64 * 64]; }
+#define STAMP(slot)                                                                              \
+  do {                                                                                           \
+    if ((threadIdx.x == 0) && (blockIdx.y == 0) && (blockIdx.x % 37 == 0) && (blockIdx.x / 37) < 64 && (slot) < 64) \
+      dosx_stamp_buf[(blockIdx.x / 37) * 64 + (slot)] = __builtin_amdgcn_s_memtime();            \
+  } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int BM = 32;
@@ -22,6 +35,8 @@ struct GemmLaunch {
   DosxGemm g;
   int vecA;
   int vecW;
+  int dma;   // W tile by LDS-DMA (needs K % 32 == 0: no k tail to zero-fill)
+  int rt;    // 32-row blocks per workgroup (1 or 2)
 };
 
 __device__ __forceinline__ float prelu_f(float v, float a) { return v >= 0.f ? v : a * v; }
@@ -131,33 +146,57 @@ __device__ __forceinline__ float4 a_finish(const AState& st, const ARaw& r, int 
 // C = prologue(A) . B  with fused row-wise epilogues.   NTW = 32-wide MFMA tiles per wave,
 // BN = 128*NTW columns per workgroup.  WL: 0 = W[N,K] (k-contiguous), 1 = W[K,N] (n-contiguous).
 // ---------------------------------------------------------------------------------------------
-template <int NTW, int WL, int PRO, int VEC>
+// DMA = 1: the W tile (the bulk of the staged bytes) goes global -> LDS directly
+// (__builtin_amdgcn_global_load_lds, 16 B per lane: no VGPR staging, no ds_write, no masks), double
+// buffered so the DMA of chunk k+1 flies under the MFMAs of chunk k.  The destination of one
+// wave-instruction is lane-linear (1 KiB), so the W[N,K] tile is stored with UNPADDED 128-B rows and
+// the 16-B chunk index XOR-swizzled with (row>>1)&7 on the SOURCE address (and on the fragment read)
+// to keep ds_read_b128 conflict-free; the W[K,N] tile is read with ds_read_b32 along n and needs none.
+// RT = 32-row blocks per workgroup (BM = 32*RT).  The per-CU global->LDS rate (~10-25 B/clk measured,
+// W comes from L2) - not the MFMA pipe - bounds a 32-row tile: every k-chunk re-streams the whole
+// [BN x 32] W slice for only 32 rows (18 B per MFMA-clk at BN=256).  RT = 2 halves the bytes per flop.
+template <int RT, int NTW, int WL, int PRO, int VEC, int EPI, int DMA>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmLaunch L) {
   const DosxGemm& g = L.g;
+  constexpr int BMR = BM * RT;
   constexpr int BN = 128 * NTW;
-  constexpr int LDWT = (WL == 0) ? (BK + 4) : (BN + 4);
+  constexpr int LDWT = DMA ? ((WL == 0) ? BK : BN) : ((WL == 0) ? (BK + 4) : (BN + 4));
   constexpr int WROWS = (WL == 0) ? BN : BK;
   constexpr int LDC = BN + 4;
-  constexpr int STAGE = BM * LDA + WROWS * LDWT;
+  constexpr int STAGE = BMR * LDA + WROWS * LDWT;     // floats of one staging buffer (A tile + W tile)
   constexpr int CTILE = BM * LDC;
-  constexpr int MAINF = STAGE > CTILE ? STAGE : CTILE;
+  constexpr int MAINF = DMA ? 2 * STAGE : (STAGE > CTILE ? STAGE : CTILE);
+  static_assert(!DMA || 2 * STAGE >= CTILE, "C tile must fit in the staging buffers");
   constexpr int CG = (BN + 255) / 256;   // float4 column groups per lane in the row-wise epilogue
   constexpr int NW4 = BN / 32;           // float4 W loads per thread per k-chunk
 
   extern __shared__ __align__(16) float smem[];
   float* As = smem;
-  float* Ws = smem + BM * LDA;
+  float* Ws = smem + BMR * LDA;
   float* Cs = smem;
-  float* Ps = smem + MAINF;              // [4][2][BN] + 4
+  float* Ps = smem + CTILE;              // [4][2][BN] + 4 (behind the C tile; staging memory is dead by then)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int m0 = blockIdx.x * BMR, n0 = blockIdx.y * BN;
   const int M = g.M, N = g.N, K = g.K;
 
+  STAMP(0);
   // ---- staging setup ----
   const int arow = tid >> 3, akq = (tid & 7) * 4;
-  AState ast;
-  a_state_init(ast, g.a, g.nseg, PRO, g.pro_stats, g.pro_alpha, min(m0 + arow, M - 1), (m0 + arow) < M);
+  AState ast[RT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r)
+    a_state_init(ast[r], g.a, g.nseg, PRO, g.pro_stats, g.pro_alpha, min(m0 + arow + 32 * r, M - 1),
+                 (m0 + arow + 32 * r) < M);
+  auto issueA = [&](ARaw(&ar)[RT], int k0) {
+#pragma unroll
+    for (int r = 0; r < RT; ++r) ar[r] = a_issue<PRO, VEC>(ast[r], k0 + akq, K, g.pro_gamma, g.pro_beta);
+  };
+  auto storeA = [&](float* Ad, const ARaw(&ar)[RT], int k0) {
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+      st4(&Ad[(arow + 32 * r) * LDA + akq], a_finish<PRO, VEC>(ast[r], ar[r], k0 + akq, K));
+  };
 
   auto loadW = [&](int k0, float4(&wr)[NW4]) {
 #pragma unroll
@@ -191,26 +230,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmLaunch L) {
       wr[i] = v;
     }
   };
-  auto storeW = [&](int k0, const float4(&wr)[NW4]) {
+  auto storeW = [&](float* Wd, int k0, const float4(&wr)[NW4], int i0, int i1) {
 #pragma unroll
     for (int i = 0; i < NW4; ++i) {
+      if (i < i0 || i >= i1) continue;
       float4 v = wr[i];
       if (WL == 0) {
         if (VEC && !((n0 + (tid >> 3) + 32 * i) < N && (k0 + (tid & 7) * 4) < K)) v = f4zero();
-        st4(&Ws[((tid >> 3) + 32 * i) * LDWT + (tid & 7) * 4], v);
+        st4(&Wd[((tid >> 3) + 32 * i) * LDWT + (tid & 7) * 4], v);
       } else {
         const int lin = tid + 256 * i;
         if (VEC && !((k0 + lin / (BN / 4)) < K && (n0 + (lin % (BN / 4)) * 4) < N)) v = f4zero();
-        st4(&Ws[(lin / (BN / 4)) * LDWT + (lin % (BN / 4)) * 4], v);
+        st4(&Wd[(lin / (BN / 4)) * LDWT + (lin % (BN / 4)) * 4], v);
       }
     }
   };
 
-  f32x16 acc[NTW];
+  f32x16 acc[RT][NTW];
 #pragma unroll
-  for (int t = 0; t < NTW; ++t)
+  for (int rr = 0; rr < RT; ++rr)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rr][t][r] = 0.f;
 
   // wave-uniform: how many of this wave's 32-column tiles intersect [0, N)
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -218,78 +260,198 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmLaunch L) {
   tiles_on = tiles_on < 0 ? 0 : (tiles_on > NTW ? NTW : tiles_on);
 
   const int nk = (K + BK - 1) / BK;
-  ARaw araw = a_issue<PRO, VEC>(ast, akq, K, g.pro_gamma, g.pro_beta);
-  float4 wreg[NW4];
-  loadW(0, wreg);
 
-  for (int kt = 0; kt < nk; ++kt) {
-    st4(&As[arow * LDA + akq], a_finish<PRO, VEC>(ast, araw, kt * BK + akq, K));
-    storeW(kt * BK, wreg);
-    __syncthreads();
-    if (kt + 1 < nk) {
-      araw = a_issue<PRO, VEC>(ast, (kt + 1) * BK + akq, K, g.pro_gamma, g.pro_beta);
-      loadW((kt + 1) * BK, wreg);
-    }
+  // One k-chunk of MFMAs from a staging buffer.  Pipelined variant: ALL fragment reads of the chunk are
+  // issued first, then `between()` (the LDS stores of the NEXT chunk into the other buffer), then the
+  // MFMA chain - so the stores drain through the LDS pipe underneath the matrix work.
+  // B-operand addressing (see the DMA note above)
+  auto wfrag4 = [&](const float* Wsb, int col, int kq /* k offset, multiple of 4 */) -> float4 {
+    if (DMA) return ld4(&Wsb[col * BK + ((((kq >> 2) ^ ((col >> 1) & 7))) << 2)]);
+    return ld4(&Wsb[col * LDWT + kq]);
+  };
+
+  // One k-chunk of MFMAs from a staging buffer.
+  auto compute = [&](const float* Asb, const float* Wsb) {
     if (tiles_on == NTW) {
-      // fast path (every tile of this wave is inside N): straight-line, so hipcc can hoist the
-      // ds_reads of the whole chunk ahead of the MFMA chain
+      // fast path (every tile of this wave is inside N): straight-line, so hipcc hoists the ds_reads
 #pragma unroll
       for (int kk = 0; kk < BK; kk += 8) {
-        const float4 a = ld4(&As[l31 * LDA + kk + 4 * hh]);
-        if (WL == 0) {
-          float4 b[NTW];
+        float4 a[RT];
 #pragma unroll
-          for (int t = 0; t < NTW; ++t) b[t] = ld4(&Ws[((wave * NTW + t) * 32 + l31) * LDWT + kk + 4 * hh]);
+        for (int r = 0; r < RT; ++r) a[r] = ld4(&Asb[(32 * r + l31) * LDA + kk + 4 * hh]);
+        float b[NTW][4];
 #pragma unroll
-          for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
-#pragma unroll
-          for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t].y, acc[t], 0, 0, 0);
-#pragma unroll
-          for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
-#pragma unroll
-          for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
-        } else {
-          float b[NTW][4];
-#pragma unroll
-          for (int t = 0; t < NTW; ++t) {
-            const float* bp = &Ws[(kk + 4 * hh) * LDWT + (wave * NTW + t) * 32 + l31];
+        for (int t = 0; t < NTW; ++t) {
+          if (WL == 0) {
+            const float4 v = wfrag4(Wsb, (wave * NTW + t) * 32 + l31, kk + 4 * hh);
+            b[t][0] = v.x; b[t][1] = v.y; b[t][2] = v.z; b[t][3] = v.w;
+          } else {
+            const float* bp = &Wsb[(kk + 4 * hh) * LDWT + (wave * NTW + t) * 32 + l31];
             b[t][0] = bp[0]; b[t][1] = bp[LDWT]; b[t][2] = bp[2 * LDWT]; b[t][3] = bp[3 * LDWT];
           }
-#pragma unroll
-          for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t][0], acc[t], 0, 0, 0);
-#pragma unroll
-          for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t][1], acc[t], 0, 0, 0);
-#pragma unroll
-          for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t][2], acc[t], 0, 0, 0);
-#pragma unroll
-          for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t][3], acc[t], 0, 0, 0);
         }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int r = 0; r < RT; ++r) {
+            const float av = c == 0 ? a[r].x : c == 1 ? a[r].y : c == 2 ? a[r].z : a[r].w;
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+              acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[t][c], acc[r][t], 0, 0, 0);
+          }
       }
     } else {
 #pragma unroll
       for (int kk = 0; kk < BK; kk += 8) {
-        const float4 a = ld4(&As[l31 * LDA + kk + 4 * hh]);
+        float4 a[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) a[r] = ld4(&Asb[(32 * r + l31) * LDA + kk + 4 * hh]);
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
           if (t >= tiles_on) continue;
           const int col = (wave * NTW + t) * 32 + l31;
+          float b[4];
           if (WL == 0) {
-            const float4 b = ld4(&Ws[col * LDWT + kk + 4 * hh]);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+            const float4 v = wfrag4(Wsb, col, kk + 4 * hh);
+            b[0] = v.x; b[1] = v.y; b[2] = v.z; b[3] = v.w;
           } else {
-            const float* bp = &Ws[(kk + 4 * hh) * LDWT + col];
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bp[0], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bp[LDWT], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bp[2 * LDWT], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bp[3 * LDWT], acc[t], 0, 0, 0);
+            const float* bp = &Wsb[(kk + 4 * hh) * LDWT + col];
+            b[0] = bp[0]; b[1] = bp[LDWT]; b[2] = bp[2 * LDWT]; b[3] = bp[3 * LDWT];
+          }
+#pragma unroll
+          for (int r = 0; r < RT; ++r) {
+            acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].x, b[0], acc[r][t], 0, 0, 0);
+            acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].y, b[1], acc[r][t], 0, 0, 0);
+            acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].z, b[2], acc[r][t], 0, 0, 0);
+            acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].w, b[3], acc[r][t], 0, 0, 0);
           }
         }
       }
     }
-    __syncthreads();
+  };
+
+  STAMP(1);
+  if constexpr (DMA) {
+    // W tile of chunk k0 -> LDS buffer Wd, asynchronously.  Thread/lane mapping is the register path's
+    // (row = tid/8 + 32 i, 16-B chunk = tid%8 | float4 index = tid + 256 i), which makes every
+    // wave-instruction's 64 x 16 B land contiguously at a wave-uniform LDS base.
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    auto dmaW = [&](float* Wd, int k0) {
+#pragma unroll
+      for (int i = 0; i < NW4; ++i) {
+        const float* src;
+        float* dst;
+        if (WL == 0) {
+          const int row = (tid >> 3) + 32 * i;                    // tile-local output column
+          const int c = (tid & 7) ^ ((row >> 1) & 7);             // swizzled source chunk
+          src = g.w + (size_t)min(n0 + row, N - 1) * g.ldw + k0 + c * 4;
+          dst = Wd + (8 * wave_s + 32 * i) * BK;
+        } else {
+          const int lin = tid + 256 * i;
+          const int r = lin / (BN / 4), c4 = (lin % (BN / 4)) * 4;
+          const int n = n0 + c4;
+          src = g.w + (size_t)min(k0 + r, K - 1) * g.ldw + (n < N ? n : 0);
+          dst = Wd + (64 * wave_s + 256 * i) * 4;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
+    };
+    ARaw araw[RT];
+    issueA(araw, 0);
+    dmaW(smem + BMR * LDA, 0);
+    storeA(smem, araw, 0);
+    __syncthreads();        // (emits vmcnt(0) while a DMA is in flight: the tile has landed)
+    for (int kt = 0; kt < nk; ++kt) {
+      float* Acur = smem + (kt & 1) * STAGE;
+      float* Anxt = smem + ((kt & 1) ^ 1) * STAGE;
+      if (kt + 1 < nk) {
+        issueA(araw, (kt + 1) * BK);
+        dmaW(Anxt + BMR * LDA, (kt + 1) * BK);
+      }
+      STAMP(3 + 3 * kt);
+      compute(Acur, Acur + BMR * LDA);
+      STAMP(4 + 3 * kt);
+      if (kt + 1 < nk) storeA(Anxt, araw, (kt + 1) * BK);
+      __syncthreads();
+    }
+  } else {
+    ARaw araw[RT];
+    issueA(araw, 0);
+    float4 wreg[NW4];
+    loadW(0, wreg);
+    for (int kt = 0; kt < nk; ++kt) {
+      storeA(As, araw, kt * BK);
+      storeW(Ws, kt * BK, wreg, 0, NW4);
+      STAMP(2 + 3 * kt);
+      __syncthreads();
+      STAMP(3 + 3 * kt);
+      if (kt + 1 < nk) {
+        issueA(araw, (kt + 1) * BK);
+        loadW((kt + 1) * BK, wreg);
+      }
+      compute(As, Ws);
+      STAMP(4 + 3 * kt);
+      __syncthreads();
+    }
+  }
+  STAMP(55);
+
+  // ---- epilogue operand prefetch -----------------------------------------------------------------
+  // Every global operand of the row-wise epilogue (bias / gamma / beta vectors, the rows of `aux` and
+  // `res`, the per-row statistics) is loaded HERE, unconditionally and from always-valid addresses
+  // (absent operands alias `out`, whose values are then ignored), before the accumulator round trip
+  // through LDS.  The row loop below then touches no global memory except its stores; a load inside
+  // that loop costs one exposed L2/HBM round trip per row (8 per wave).
+  const int ncols = min(BN, N - n0);
+  const float invN = 1.f / (float)N;
+  constexpr int epi = EPI;     // compile-time: only this epilogue's code exists in the kernel
+  const bool is_prelu_ln = (epi == DOSX_EPI_PRELU_LN_BWD), is_rowln = (epi == DOSX_EPI_ROWLN_BWD);
+  const bool aux_first = (epi != DOSX_EPI_BIAS_ACT && epi != DOSX_EPI_LN);
+  const float* dummy = g.out;
+  const float* p1 = aux_first ? (g.aux ? g.aux : dummy) : (g.res ? g.res : dummy);   // per-row operand 1
+  const int ld1 = aux_first ? (g.aux ? g.ldaux : 0) : (g.res ? g.ldr : 0);
+  const float* p2 = (is_rowln && g.res) ? g.res : dummy;                                // per-row operand 2
+  const int ld2 = (is_rowln && g.res) ? g.ldr : 0;
+  const float* statp = g.aux_stats ? g.aux_stats : dummy;
+  float4 pg[CG], pb[CG];   // column partial sums (dgamma, dbeta) over all row blocks of this workgroup
+  float pal = 0.f;         // dalpha partial
+#pragma unroll
+  for (int j = 0; j < CG; ++j) { pg[j] = f4zero(); pb[j] = f4zero(); }
+  float e_alpha = 0.f;
+  if (epi == DOSX_EPI_PRELU_LN_BWD || epi == DOSX_EPI_PRELU_BWD) e_alpha = *g.epi_alpha;
+  bool on[CG];
+  int gcol[CG];
+  float4 biasv[CG], gamv[CG], betv[CG];
+#pragma unroll
+  for (int j = 0; j < CG; ++j) {
+    const int c = lane * 4 + 256 * j;
+    on[j] = c < ncols;
+    gcol[j] = n0 + (on[j] ? c : 0);
+    biasv[j] = ld4((g.bias ? g.bias : dummy) + gcol[j]);
+    gamv[j] = ld4((g.epi_gamma ? g.epi_gamma : dummy) + gcol[j]);
+    betv[j] = ld4((g.epi_beta ? g.epi_beta : dummy) + gcol[j]);
+    if (!g.bias) biasv[j] = f4zero();
+  }
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {        // one 32-row block at a time through the LDS C tile
+  const int mb = m0 + 32 * rt;
+  float4 pv1[8][CG], pv2[8][CG];
+  float st0[8], st1[8];
+  size_t orow_[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int rc = min(mb + wave * 8 + i, M - 1);
+    const size_t r1 = (size_t)((!aux_first && g.res) ? dosx_map_row(g.res_map, rc) : rc) * ld1;
+    const size_t r2 = (size_t)((is_rowln && g.res) ? dosx_map_row(g.res_map, rc) : rc) * ld2;
+    orow_[i] = (size_t)(epi == DOSX_EPI_BIAS_ACT ? dosx_map_row(g.out_map, rc) : rc) * g.ldo;
+#pragma unroll
+    for (int j = 0; j < CG; ++j) {
+      pv1[i][j] = ld4(p1 + r1 + gcol[j]);
+      pv2[i][j] = ld4(p2 + r2 + gcol[j]);
+    }
+    st0[i] = statp[is_rowln ? 2 * (size_t)rc : (size_t)rc];
+    st1[i] = statp[is_rowln ? 2 * (size_t)rc + 1 : (size_t)rc];
   }
 
   // ---- accumulators -> LDS C tile (aliases the staging buffers; loop ended with a barrier) ----
@@ -299,42 +461,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmLaunch L) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-      Cs[row * LDC + col] = acc[t][r];
+      Cs[row * LDC + col] = acc[rt][t][r];
     }
   }
+  STAMP(56);
   __syncthreads();
+  STAMP(57);
 
   // ---- row-wise epilogue: wave w owns rows 8w..8w+7, lanes sweep the columns as float4 --------
-  const int ncols = min(BN, N - n0);
-  const float invN = 1.f / (float)N;
-  const int epi = g.epi;
-  float4 pg[CG], pb[CG];   // column partial sums (dgamma, dbeta)
-  float pal = 0.f;         // dalpha partial
 #pragma unroll
-  for (int j = 0; j < CG; ++j) { pg[j] = f4zero(); pb[j] = f4zero(); }
-  float e_alpha = 0.f;
-  if (epi == DOSX_EPI_PRELU_LN_BWD || epi == DOSX_EPI_PRELU_BWD) e_alpha = *g.epi_alpha;
-
   for (int i = 0; i < 8; ++i) {
-    const int lr = wave * 8 + i, r = m0 + lr;
-    if (r >= M) break;
+    const int lr = wave * 8 + i, r = mb + lr;
+    const bool rvalid = r < M;              // wave-uniform
     float4 v[CG];
-    bool on[CG];
 #pragma unroll
-    for (int j = 0; j < CG; ++j) {
-      const int c = lane * 4 + 256 * j;
-      on[j] = c < ncols;
-      v[j] = on[j] ? ld4(&Cs[lr * LDC + c]) : f4zero();
-    }
+    for (int j = 0; j < CG; ++j) v[j] = on[j] ? ld4(&Cs[lr * LDC + lane * 4 + 256 * j]) : f4zero();
+    float* const orow = g.out + orow_[i];
     if (epi == DOSX_EPI_BIAS_ACT) {
-      const size_t orow = (size_t)dosx_map_row(g.out_map, r) * g.ldo;
-      const size_t rrow = g.res ? (size_t)dosx_map_row(g.res_map, r) * g.ldr : 0;
       float s1 = 0.f;
 #pragma unroll
       for (int j = 0; j < CG; ++j) {
         if (!on[j]) continue;
-        const int c = n0 + lane * 4 + 256 * j;
-        if (g.bias) v[j] = f4add(v[j], ld4(g.bias + c));
+        v[j] = f4add(v[j], biasv[j]);
         if (g.act == 1) {
           v[j].x = fmaxf(v[j].x, 0.f); v[j].y = fmaxf(v[j].y, 0.f);
           v[j].z = fmaxf(v[j].z, 0.f); v[j].w = fmaxf(v[j].w, 0.f);
@@ -343,8 +491,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmLaunch L) {
           v[j].x = v[j].x >= 0.f ? v[j].x : sl * v[j].x; v[j].y = v[j].y >= 0.f ? v[j].y : sl * v[j].y;
           v[j].z = v[j].z >= 0.f ? v[j].z : sl * v[j].z; v[j].w = v[j].w >= 0.f ? v[j].w : sl * v[j].w;
         }
-        if (g.res) v[j] = f4add(v[j], ld4(g.res + rrow + c));
-        st4(g.out + orow + c, v[j]);
+        if (g.res) v[j] = f4add(v[j], pv1[i][j]);
+        if (rvalid) st4(orow + gcol[j], v[j]);
         s1 += v[j].x + v[j].y + v[j].z + v[j].w;
       }
       if (g.stats_out) {
@@ -357,7 +505,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmLaunch L) {
           s2 += a * a + b * b + c2 * c2 + d * d;
         }
         const float var = wave_sum(s2) * invN;
-        if (lane == 0) {
+        if (lane == 0 && rvalid) {
           g.stats_out[2 * (size_t)r] = mean;
           g.stats_out[2 * (size_t)r + 1] = rsqrtf(var + DOSX_LN_EPS);
         }
@@ -367,8 +515,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmLaunch L) {
 #pragma unroll
       for (int j = 0; j < CG; ++j) {
         if (!on[j]) continue;
-        const int c = n0 + lane * 4 + 256 * j;
-        if (g.bias) v[j] = f4add(v[j], ld4(g.bias + c));
+        v[j] = f4add(v[j], biasv[j]);
         s1 += v[j].x + v[j].y + v[j].z + v[j].w;
       }
       const float mean = wave_sum(s1) * invN;
@@ -380,56 +527,46 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmLaunch L) {
         s2 += v[j].x * v[j].x + v[j].y * v[j].y + v[j].z * v[j].z + v[j].w * v[j].w;
       }
       const float rstd = rsqrtf(wave_sum(s2) * invN + DOSX_LN_EPS);
-      const size_t orow = (size_t)r * g.ldo;
 #pragma unroll
       for (int j = 0; j < CG; ++j) {
-        if (!on[j]) continue;
-        const int c = n0 + lane * 4 + 256 * j;
-        st4(g.out + orow + c, make_float4(v[j].x * rstd, v[j].y * rstd, v[j].z * rstd, v[j].w * rstd));
+        if (!on[j] || !rvalid) continue;
+        st4(orow + gcol[j], make_float4(v[j].x * rstd, v[j].y * rstd, v[j].z * rstd, v[j].w * rstd));
       }
-      if (lane == 0) g.aux_out[r] = rstd;
+      if (lane == 0 && rvalid) g.aux_out[r] = rstd;
     } else if (epi == DOSX_EPI_RELU_MASK) {
-      const size_t orow = (size_t)r * g.ldo, arow_ = (size_t)r * g.ldaux;
 #pragma unroll
       for (int j = 0; j < CG; ++j) {
-        if (!on[j]) continue;
-        const int c = n0 + lane * 4 + 256 * j;
-        const float4 h = ld4(g.aux + arow_ + c);
-        st4(g.out + orow + c, make_float4(h.x > 0.f ? v[j].x : 0.f, h.y > 0.f ? v[j].y : 0.f,
-                                          h.z > 0.f ? v[j].z : 0.f, h.w > 0.f ? v[j].w : 0.f));
+        if (!on[j] || !rvalid) continue;
+        const float4 h = pv1[i][j];
+        st4(orow + gcol[j], make_float4(h.x > 0.f ? v[j].x : 0.f, h.y > 0.f ? v[j].y : 0.f,
+                                        h.z > 0.f ? v[j].z : 0.f, h.w > 0.f ? v[j].w : 0.f));
       }
     } else if (epi == DOSX_EPI_PRELU_BWD) {
-      const size_t orow = (size_t)r * g.ldo, arow_ = (size_t)r * g.ldaux;
 #pragma unroll
       for (int j = 0; j < CG; ++j) {
-        if (!on[j]) continue;
-        const int c = n0 + lane * 4 + 256 * j;
-        const float4 z = ld4(g.aux + arow_ + c);
+        if (!on[j] || !rvalid) continue;
+        const float4 z = pv1[i][j];
         float4 o;
         o.x = z.x >= 0.f ? v[j].x : e_alpha * v[j].x; if (z.x < 0.f) pal += v[j].x * z.x;
         o.y = z.y >= 0.f ? v[j].y : e_alpha * v[j].y; if (z.y < 0.f) pal += v[j].y * z.y;
         o.z = z.z >= 0.f ? v[j].z : e_alpha * v[j].z; if (z.z < 0.f) pal += v[j].z * z.z;
         o.w = z.w >= 0.f ? v[j].w : e_alpha * v[j].w; if (z.w < 0.f) pal += v[j].w * z.w;
-        st4(g.out + orow + c, o);
+        st4(orow + gcol[j], o);
       }
     } else {  // DOSX_EPI_PRELU_LN_BWD or DOSX_EPI_ROWLN_BWD : LayerNorm backward over the full row
-      const bool is_prelu = (epi == DOSX_EPI_PRELU_LN_BWD);
-      float mean = 0.f, rstd;
-      if (is_prelu) rstd = g.aux_stats[r];
-      else { mean = g.aux_stats[2 * (size_t)r]; rstd = g.aux_stats[2 * (size_t)r + 1]; }
-      const size_t arow_ = (size_t)r * g.ldaux;
+      const float mean = is_prelu_ln ? 0.f : st0[i];
+      const float rstd = is_prelu_ln ? st0[i] : st1[i];
       float4 xh[CG], dxh[CG];
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int j = 0; j < CG; ++j) {
         xh[j] = f4zero(); dxh[j] = f4zero();
-        if (!on[j]) continue;
-        const int c = n0 + lane * 4 + 256 * j;
-        float4 a = ld4(g.aux + arow_ + c);
-        const float4 gm = ld4(g.epi_gamma + c);
+        if (!on[j] || !rvalid) continue;
+        float4 a = pv1[i][j];
+        const float4 gm = gamv[j];
         float4 dy = v[j];
-        if (is_prelu) {
-          const float4 bt = ld4(g.epi_beta + c);
+        if (is_prelu_ln) {
+          const float4 bt = betv[j];
           const float y0 = a.x * gm.x + bt.x, y1 = a.y * gm.y + bt.y, y2 = a.z * gm.z + bt.z,
                       y3 = a.w * gm.w + bt.w;
           if (y0 < 0.f) { pal += dy.x * y0; dy.x *= e_alpha; }
@@ -448,20 +585,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmLaunch L) {
         s2 += dxh[j].x * a.x + dxh[j].y * a.y + dxh[j].z * a.z + dxh[j].w * a.w;
       }
       const float m1 = wave_sum(s1) * invN, m2 = wave_sum(s2) * invN;
-      const size_t orow = (size_t)r * g.ldo;
-      const size_t rrow = g.res ? (size_t)dosx_map_row(g.res_map, r) * g.ldr : 0;
 #pragma unroll
       for (int j = 0; j < CG; ++j) {
-        if (!on[j]) continue;
-        const int c = n0 + lane * 4 + 256 * j;
+        if (!on[j] || !rvalid) continue;
         float4 o = make_float4(rstd * (dxh[j].x - m1 - xh[j].x * m2), rstd * (dxh[j].y - m1 - xh[j].y * m2),
                                rstd * (dxh[j].z - m1 - xh[j].z * m2), rstd * (dxh[j].w - m1 - xh[j].w * m2));
-        if (g.res) o = f4add(o, ld4(g.res + rrow + c));
-        st4(g.out + orow + c, o);
+        if (is_rowln && g.res) o = f4add(o, pv2[i][j]);
+        st4(orow + gcol[j], o);
       }
     }
   }
 
+  if (rt + 1 < RT) __syncthreads();     // the C tile is rewritten by the next row block
+  }   // rt
+  STAMP(58);
   // ---- per-workgroup partial sums for the parameter gradients of the fused LN / PReLU ----------
   if (g.partials && (epi == DOSX_EPI_PRELU_LN_BWD || epi == DOSX_EPI_ROWLN_BWD || epi == DOSX_EPI_PRELU_BWD)) {
     float* prow = g.partials + (size_t)(blockIdx.x * gridDim.y + blockIdx.y) * g.partial_ld;
@@ -495,54 +632,87 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmLaunch L) {
   }
 }
 
-template <int NTW, int WL>
+template <int RT, int NTW, int WL, int DMA>
 constexpr size_t gemm_smem_bytes() {
   constexpr int BN = 128 * NTW;
-  constexpr int LDWT = (WL == 0) ? (BK + 4) : (BN + 4);
+  constexpr int LDWT = DMA ? ((WL == 0) ? BK : BN) : ((WL == 0) ? (BK + 4) : (BN + 4));
   constexpr int WROWS = (WL == 0) ? BN : BK;
-  constexpr int STAGE = BM * LDA + WROWS * LDWT;
+  constexpr int STAGE = BM * RT * LDA + WROWS * LDWT;
   constexpr int CTILE = BM * (BN + 4);
-  constexpr int MAINF = STAGE > CTILE ? STAGE : CTILE;
-  return (size_t)(MAINF + 8 * BN + 4) * sizeof(float);
+  constexpr int MAINF = DMA ? 2 * STAGE : (STAGE > CTILE ? STAGE : CTILE);
+  constexpr int EPIF = CTILE + 8 * BN + 4;
+  return (size_t)(MAINF > EPIF ? MAINF : EPIF) * sizeof(float);
 }
 
-template <int NTW, int WL, int PRO, int VEC>
-int launch_gemm(const GemmLaunch& L, hipStream_t s) {
+template <int RT, int NTW, int WL, int PRO, int VEC, int EPI, int DMA>
+int launch_gemm3(const GemmLaunch& L, hipStream_t s) {
   constexpr int BN = 128 * NTW;
-  dim3 grid(ceil_div(L.g.M, BM), ceil_div(L.g.N, BN));
-  constexpr size_t smem = gemm_smem_bytes<NTW, WL>();
+  dim3 grid(ceil_div(L.g.M, BM * RT), ceil_div(L.g.N, BN));
+  constexpr size_t smem = gemm_smem_bytes<RT, NTW, WL, DMA>();
+  static_assert(smem <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<NTW, WL, PRO, VEC>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<RT, NTW, WL, PRO, VEC, EPI, DMA>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<NTW, WL, PRO, VEC>), grid, dim3(256), smem, s, L);
+  hipLaunchKernelGGL((gemm_kernel<RT, NTW, WL, PRO, VEC, EPI, DMA>), grid, dim3(256), smem, s, L);
   DOSX_LAUNCH_CHECK();
   return 0;
 }
 
+template <int NTW, int WL, int PRO, int VEC, int EPI, int DMA>
+int launch_gemm2(const GemmLaunch& L, hipStream_t s) {
+  if (L.rt == 2) return launch_gemm3<2, NTW, WL, PRO, VEC, EPI, DMA>(L, s);
+  return launch_gemm3<1, NTW, WL, PRO, VEC, EPI, DMA>(L, s);
+}
+
+// The LDS-DMA staging variant is compiled only with -DDOSX_ENABLE_DMA (experiments): measured on
+// MI355X it loses to the register-staged path at every shape of this workload (2.78 vs 2.68 ms per
+// cfg2 step; 73 vs 97 TF/s at M=262144,N=256,K=384) because its two staging buffers halve the
+// number of co-resident workgroups, which is what actually hides the load latency here.
+template <int NTW, int WL, int PRO, int VEC, int EPI>
+int launch_gemm(const GemmLaunch& L, hipStream_t s) {
+#ifdef DOSX_ENABLE_DMA
+  if (VEC && L.dma) return launch_gemm2<NTW, WL, PRO, VEC, EPI, VEC ? 1 : 0>(L, s);
+#endif
+  return launch_gemm2<NTW, WL, PRO, VEC, EPI, 0>(L, s);
+}
+
+// Only the (layout, prologue, epilogue) combinations the forward / backward programs use exist.
 template <int NTW>
 int dispatch_gemm(const GemmLaunch& L, hipStream_t s) {
   const int vec = L.vecA && L.vecW;
-  if (L.g.w_layout == 0) {
-    if (!vec) {
-      // generic (unaligned) staging exists for the un-transformed operand only: the raw
-      // 118 / 41 / 4 / 2 wide input features of the three encoders
-      if (L.g.pro != DOSX_PRO_NONE) { dosx_set_error("dosx_gemm: prologue %d needs 4-float aligned operands", L.g.pro); return -22; }
-      return launch_gemm<NTW, 0, DOSX_PRO_NONE, 0>(L, s);
+  const int pro = L.g.pro, epi = L.g.epi;
+  if (!vec) {
+    // generic (unaligned) staging: the raw 118 / 41 / 4 / 2 wide input features of the three encoders
+    if (pro != DOSX_PRO_NONE || epi != DOSX_EPI_BIAS_ACT) {
+      dosx_set_error("dosx_gemm: prologue %d / epilogue %d need 4-float aligned operands", pro, epi);
+      return -22;
     }
-    switch (L.g.pro) {
-      case DOSX_PRO_NONE: return launch_gemm<NTW, 0, DOSX_PRO_NONE, 1>(L, s);
-      case DOSX_PRO_PRELU: return launch_gemm<NTW, 0, DOSX_PRO_PRELU, 1>(L, s);
-      case DOSX_PRO_LN_PRELU: return launch_gemm<NTW, 0, DOSX_PRO_LN_PRELU, 1>(L, s);
-      case DOSX_PRO_ROWLN: return launch_gemm<NTW, 0, DOSX_PRO_ROWLN, 1>(L, s);
-    }
-  } else {
-    if (L.g.pro != DOSX_PRO_NONE) { dosx_set_error("dosx_gemm: w_layout 1 supports no prologue"); return -22; }
-    return vec ? launch_gemm<NTW, 1, DOSX_PRO_NONE, 1>(L, s) : launch_gemm<NTW, 1, DOSX_PRO_NONE, 0>(L, s);
+    return L.g.w_layout == 0 ? launch_gemm<NTW, 0, DOSX_PRO_NONE, 0, DOSX_EPI_BIAS_ACT>(L, s)
+                             : launch_gemm<NTW, 1, DOSX_PRO_NONE, 0, DOSX_EPI_BIAS_ACT>(L, s);
   }
-  dosx_set_error("dosx_gemm: bad prologue %d", L.g.pro);
+  if (L.g.w_layout == 0) {
+    if (epi == DOSX_EPI_LN && pro == DOSX_PRO_NONE) return launch_gemm<NTW, 0, DOSX_PRO_NONE, 1, DOSX_EPI_LN>(L, s);
+    if (epi == DOSX_EPI_BIAS_ACT) {
+      switch (pro) {
+        case DOSX_PRO_NONE: return launch_gemm<NTW, 0, DOSX_PRO_NONE, 1, DOSX_EPI_BIAS_ACT>(L, s);
+        case DOSX_PRO_PRELU: return launch_gemm<NTW, 0, DOSX_PRO_PRELU, 1, DOSX_EPI_BIAS_ACT>(L, s);
+        case DOSX_PRO_LN_PRELU: return launch_gemm<NTW, 0, DOSX_PRO_LN_PRELU, 1, DOSX_EPI_BIAS_ACT>(L, s);
+        case DOSX_PRO_ROWLN: return launch_gemm<NTW, 0, DOSX_PRO_ROWLN, 1, DOSX_EPI_BIAS_ACT>(L, s);
+      }
+    }
+  } else if (pro == DOSX_PRO_NONE) {
+    switch (epi) {
+      case DOSX_EPI_BIAS_ACT: return launch_gemm<NTW, 1, DOSX_PRO_NONE, 1, DOSX_EPI_BIAS_ACT>(L, s);
+      case DOSX_EPI_PRELU_LN_BWD: return launch_gemm<NTW, 1, DOSX_PRO_NONE, 1, DOSX_EPI_PRELU_LN_BWD>(L, s);
+      case DOSX_EPI_RELU_MASK: return launch_gemm<NTW, 1, DOSX_PRO_NONE, 1, DOSX_EPI_RELU_MASK>(L, s);
+      case DOSX_EPI_ROWLN_BWD: return launch_gemm<NTW, 1, DOSX_PRO_NONE, 1, DOSX_EPI_ROWLN_BWD>(L, s);
+      case DOSX_EPI_PRELU_BWD: return launch_gemm<NTW, 1, DOSX_PRO_NONE, 1, DOSX_EPI_PRELU_BWD>(L, s);
+    }
+  }
+  dosx_set_error("dosx_gemm: unsupported combination w_layout=%d prologue=%d epilogue=%d", L.g.w_layout, pro, epi);
   return -22;
 }
 
@@ -569,10 +739,27 @@ int gemm_bn(int M, int N, int epi) {
 
 }  // namespace
 
+// 32-row blocks per workgroup.  64-row tiles halve the W bytes streamed per flop (the binding
+// resource, see gemm_kernel) but also halve the number of workgroups: use them when the grid still
+// fills the 256 CUs, or when the 32-row grid would run a nearly empty second round.
+inline int gemm_rt(int M, int N, int epi) {
+  if (M <= BM) return 1;
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("DOSX_GEMM_RT"); forced = e ? atoi(e) : 0; }
+  if (forced == 1 || forced == 2) return forced;
+  const int ntiles = ceil_div(N, gemm_bn(M, N, epi));
+  const int wg1 = ceil_div(M, BM) * ntiles, wg2 = ceil_div(M, 2 * BM) * ntiles;
+  if (wg2 >= 192) return 2;
+  if (wg1 > 256 && wg1 <= 400 && wg2 >= 128) return 2;
+  return 1;
+}
+
 extern "C" int dosx_gemm_partial_rows(int M, int N, int epi) {
-  // row-wise epilogues run as one N tile (N <= 512); the element-wise PRELU_BWD epilogue tiles N by 128.
-  if (epi == DOSX_EPI_PRELU_BWD) return ceil_div(M, BM) * ceil_div(N, 128);
-  return ceil_div(M, BM);
+  // one partial row per workgroup; row-wise epilogues run as one N tile (N <= 512), the
+  // element-wise PRELU_BWD epilogue tiles N by 128.
+  const int rows = ceil_div(M, BM * gemm_rt(M, N, epi));
+  if (epi == DOSX_EPI_PRELU_BWD) return rows * ceil_div(N, 128);
+  return rows;
 }
 
 extern "C" int dosx_gemm(const DosxGemm* gp, dosx_stream_t stream) {
@@ -613,6 +800,12 @@ extern "C" int dosx_gemm(const DosxGemm* gp, dosx_stream_t stream) {
   if (g.pro == DOSX_PRO_LN_PRELU || g.pro == DOSX_PRO_ROWLN)
     L.vecA = L.vecA && aligned16(g.pro_gamma) && aligned16(g.pro_beta);
   L.vecW = ((g.ldw & 3) == 0) && aligned16(g.w) && (g.w_layout == 0 ? (g.K & 3) == 0 : (g.N & 3) == 0);
+  {
+    static int dma_on = -1;
+    if (dma_on < 0) { const char* e = getenv("DOSX_GEMM_DMA"); dma_on = (e && e[0] == '1') ? 1 : 0; }
+    L.dma = (dma_on && L.vecA && L.vecW && (g.K % BK) == 0) ? 1 : 0;
+  }
+  L.rt = gemm_rt(g.M, g.N, g.epi);
   int bn = gemm_bn(g.M, g.N, g.epi);
   if (g.stats_out && bn < g.N) bn = g.N <= 256 ? 256 : 512;
   hipStream_t s = to_stream(stream);
@@ -723,14 +916,54 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
   if (do_bias && tid < WT && n0 + tid < N) g.slab_bias[(size_t)z * N + n0 + tid] = bsum;
 }
 
-__global__ void reduce_partials_kernel(const DosxReduceJob* jobs) {
-  const DosxReduceJob j = jobs[blockIdx.y];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < j.count; i += gridDim.x * blockDim.x) {
-    float s = 0.f;
-    const float* p = j.src + i;
-    for (int k = 0; k < j.nsplit; ++k) s += p[(size_t)k * j.stride];
-    if (j.accumulate) s += j.dst[i];
-    j.dst[i] = s;
+// Jobs travel as a kernel argument (no device-side table, no host->device copy, graph-capturable).
+// Blocks are mapped to (job, 1024-element slice) through the prefix array `first_block`.
+constexpr int RP_MAX_JOBS = 64;
+constexpr int RP_SLICE = 256;       // elements per block: 64 float4 lanes x 4 waves that split the slabs
+struct ReduceLaunch {
+  DosxReduceJob job[RP_MAX_JOBS];
+  int first_block[RP_MAX_JOBS + 1];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceLaunch L) {
+  __shared__ float4 red[4][64];
+  // binary search: largest j with first_block[j] <= blockIdx.x
+  int lo = 0, hi = L.n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (L.first_block[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const DosxReduceJob j = L.job[lo];
+  const int q = threadIdx.x & 63, sl = threadIdx.x >> 6;      // wave sl sums slabs sl, sl+4, sl+8, ...
+  const int i = ((int)blockIdx.x - L.first_block[lo]) * RP_SLICE + q * 4;
+  const bool vec = ((j.stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(j.src) & 15) == 0) && ((j.count & 3) == 0);
+  float4 s0 = f4zero(), s1 = f4zero();
+  if (i < j.count) {
+    if (vec) {
+      const float* p = j.src + i;
+      int k = sl;
+      for (; k + 4 < j.nsplit; k += 8) {       // two independent chains keep two loads in flight
+        s0 = f4add(s0, ld4(p + (size_t)k * j.stride));
+        s1 = f4add(s1, ld4(p + (size_t)(k + 4) * j.stride));
+      }
+      if (k < j.nsplit) s0 = f4add(s0, ld4(p + (size_t)k * j.stride));
+    } else {
+      const int e1 = (i + 1 < j.count) ? 1 : 0, e2 = (i + 2 < j.count) ? 2 : 0, e3 = (i + 3 < j.count) ? 3 : 0;
+      for (int k = sl; k < j.nsplit; k += 4) {
+        const float* p = j.src + (size_t)k * j.stride + i;
+        s0 = f4add(s0, make_float4(p[0], p[e1], p[e2], p[e3]));
+      }
+    }
+  }
+  red[sl][q] = f4add(s0, s1);
+  __syncthreads();
+  if (sl == 0 && i < j.count) {
+    float4 t = f4add(f4add(red[0][q], red[1][q]), f4add(red[2][q], red[3][q]));
+    float* d = j.dst + i;
+    const int n = min(4, j.count - i);
+    const float tv[4] = {t.x, t.y, t.z, t.w};
+    for (int e = 0; e < n; ++e) d[e] = tv[e] + (j.accumulate ? d[e] : 0.f);
   }
 }
 
@@ -784,12 +1017,29 @@ extern "C" int dosx_wgrad(const DosxWgrad* gp, dosx_stream_t stream) {
   return 0;
 }
 
-extern "C" int dosx_reduce_partials(const DosxReduceJob* jobs_dev, int n_jobs, int max_count, dosx_stream_t stream) {
+extern "C" int dosx_reduce_partials(const DosxReduceJob* jobs_host, int n_jobs, dosx_stream_t stream) {
   if (n_jobs <= 0) return 0;
-  DOSX_CHECK_ARG(jobs_dev != nullptr && max_count > 0, "dosx_reduce_partials: bad args");
-  int gx = ceil_div(max_count, 256);
-  if (gx > 2048) gx = 2048;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(gx, n_jobs), dim3(256), 0, to_stream(stream), jobs_dev);
-  DOSX_LAUNCH_CHECK();
+  DOSX_CHECK_ARG(jobs_host != nullptr, "dosx_reduce_partials: null job table");
+  for (int done = 0; done < n_jobs; done += RP_MAX_JOBS) {
+    ReduceLaunch L;
+    L.n = n_jobs - done < RP_MAX_JOBS ? n_jobs - done : RP_MAX_JOBS;
+    int blocks = 0;
+    for (int i = 0; i < L.n; ++i) {
+      const DosxReduceJob& j = jobs_host[done + i];
+      DOSX_CHECK_ARG(j.src && j.dst && j.count > 0 && j.nsplit > 0, "dosx_reduce_partials: bad job %d", done + i);
+      L.job[i] = j;
+      L.first_block[i] = blocks;
+      blocks += ceil_div(j.count, RP_SLICE);
+    }
+    L.first_block[L.n] = blocks;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(256), 0, to_stream(stream), L);
+    DOSX_LAUNCH_CHECK();
+  }
   return 0;
 }
+
+#ifdef DOSX_STAMPS
+extern "C" int dosx_debug_read_stamps(unsigned long long* host64x64) {
+  return (int)hipMemcpyFromSymbol(host64x64, HIP_SYMBOL(dosx_stamp_buf), sizeof(unsigned long long) * 64 * 64);
+}
+#endif

@@ -107,15 +107,15 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
     gam, bet, alpha = P[key + ".1.weight"], P[key + ".1.bias"], P[key + ".2.weight"]
     _wgrad_linear(sink, G, key + ".3.weight", key + ".3.bias", M, H, seg(dy), [seg(xhat)], pro=PRO_LN_PRELU,
                   pro_gamma=gam, pro_beta=bet, pro_alpha=alpha)
-    rows = _rows32(M)
-    pld = 4 * H + 1
+    rows = ops.gemm_partial_rows(M, 2 * H, EPI_PRELU_LN_BWD)
+    pld = 4 * H + 4          # [dgamma(2H) | dbeta(2H) | pad(3) | dalpha]; multiple of 4 -> vector reduce
     part = sink.scratch(rows, pld)
     dz = _empty(dev, M, 2 * H)
     ops.gemm(M, 2 * H, [seg(dy)], P[key + ".3.weight"], dz, w_layout=1, epi=EPI_PRELU_LN_BWD, aux=xhat,
              aux_stats=rstd, epi_gamma=gam, epi_beta=bet, epi_alpha=alpha, partials=part, partial_ld=pld)
     sink.add(part, 0, G[key + ".1.weight"], rows, pld, 2 * H)
     sink.add(part, 2 * H, G[key + ".1.bias"], rows, pld, 2 * H)
-    sink.add(part, 4 * H, G[key + ".2.weight"], rows, pld, 1)
+    sink.add(part, pld - 1, G[key + ".2.weight"], rows, pld, 1)
     _wgrad_linear(sink, G, key + ".0.weight", key + ".0.bias", M, 2 * H, seg(dz), a.segs)
     dcat = _empty(dev, M, a.K)
     ops.gemm(M, a.K, [seg(dz)], P[key + ".0.weight"], dcat, w_layout=1)
@@ -249,12 +249,13 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: torch.Tensor, dkvhat: t
         # fc1 (+ LN1 backward + residual)
         _wgrad_linear(sink, G, lp + ".fc1.weight", lp + ".fc1.bias", rows, 4 * H, seg(dh), [seg(x1)], pro=PRO_ROWLN,
                       pro_gamma=g1, pro_beta=b1, pro_stats=st1)
-        part = sink.scratch(r32, 2 * H)
+        rgp = ops.gemm_partial_rows(rows, H, EPI_ROWLN_BWD)
+        part = sink.scratch(rgp, 2 * H)
         dx1 = _empty(dev, rows, H)
         ops.gemm(rows, H, [seg(dh)], P[lp + ".fc1.weight"], dx1, w_layout=1, epi=EPI_ROWLN_BWD, aux=x1, aux_stats=st1,
                  epi_gamma=g1, res=dx, partials=part, partial_ld=2 * H)
-        sink.add(part, 0, G[lp + ".layer_norms.1.weight"], r32, 2 * H, H)
-        sink.add(part, H, G[lp + ".layer_norms.1.bias"], r32, 2 * H, H)
+        sink.add(part, 0, G[lp + ".layer_norms.1.weight"], rgp, 2 * H, H)
+        sink.add(part, H, G[lp + ".layer_norms.1.bias"], rgp, 2 * H, H)
         # attention (+ LN0 backward on the query side + residual); key side accumulates into dkvhat
         npart = Bq * nqt + Bk * nkt
         part = sink.scratch(npart, 2 * H)

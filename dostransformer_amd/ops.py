@@ -168,11 +168,6 @@ def wgrad(M: int, N: int, dy: Seg, segs: Sequence[Seg], slab: torch.Tensor, slab
     _lib.check(lib.dosx_wgrad(C.byref(g), _stream()), "dosx_wgrad")
 
 
-_JOB_DT = np.dtype([("src", np.uint64), ("dst", np.uint64), ("nsplit", np.int32), ("stride", np.int32),
-                    ("count", np.int32), ("accumulate", np.int32)])
-assert _JOB_DT.itemsize == C.sizeof(ReduceJob)
-
-
 class GradSink:
     """Collects the partial-sum slabs produced during a backward pass and reduces all of them
     into the parameter-gradient buffers with ONE deterministic kernel launch per 'wave'
@@ -210,12 +205,10 @@ class GradSink:
             waves[k].append(j if k == 0 else j[:5] + (1,))
         lib = _lib.load()
         for wv in waves:
-            arr = np.array(wv, dtype=_JOB_DT)
-            host = torch.from_numpy(arr.view(np.uint8)).pin_memory()
-            dev = host.to(self.device, non_blocking=True)
-            self._keep.extend([host, dev])
-            mx = int(arr["count"].max())
-            _lib.check(lib.dosx_reduce_partials(dev.data_ptr(), len(wv), mx, _stream()), "dosx_reduce_partials")
+            arr = (ReduceJob * len(wv))()
+            for i, j in enumerate(wv):
+                arr[i].src, arr[i].dst, arr[i].nsplit, arr[i].stride, arr[i].count, arr[i].accumulate = j
+            _lib.check(lib.dosx_reduce_partials(arr, len(wv), _stream()), "dosx_reduce_partials")
         self.jobs = []
 
     def release(self):

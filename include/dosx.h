@@ -136,8 +136,9 @@ typedef struct DosxReduceJob {
   int32_t count;
   int32_t accumulate; /* 0: overwrite dst, 1: add to dst */
 } DosxReduceJob;
-/* jobs: DEVICE array of n_jobs entries; max_count = max over jobs of count (host value). */
-int dosx_reduce_partials(const DosxReduceJob* jobs_dev, int n_jobs, int max_count, dosx_stream_t stream);
+/* jobs: HOST array of n_jobs entries (copied into kernel arguments, <= 64 jobs per launch: no device
+ * table, no host->device copy, safe under graph capture).  Jobs of one call must have distinct dst. */
+int dosx_reduce_partials(const DosxReduceJob* jobs_host, int n_jobs, dosx_stream_t stream);
 
 /* a1: edge_attr[E,4] = smooth_cutoff(|v|/r_max) * [1, sqrt3 * v/max(|v|,1e-12)]
  * (DOSTransformer_phonon.py:74-77; e3nn semantics restated in oracle/dos_oracle.py). */
