@@ -90,13 +90,23 @@ def cpu_baseline(kind, L, T, H, B, budget_s=15.0):
 
 
 def main():
+    # Exactly ONE line may reach stdout (the JSON record): libraries print there too (RCCL emits a
+    # version banner on fd 1), so fd 1 is pointed at stderr for the whole run and the record is
+    # written to the saved descriptor at the end.
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="phonon_h128_b64", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step from captured HIP graphs (exact ghost padding to (N,E) buckets); "
+                         "measured slower than eager launches while the step is GPU-bound (2.95 vs 2.72 ms)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed/RCCL even for one rank (exercises the data-parallel code path on a 1-GPU box)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -111,47 +121,63 @@ def main():
 
     import torch.distributed as td
     dp = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         td.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         from dostransformer_amd.dist import DataParallel
         dp = DataParallel()
 
     from dostransformer_amd import ops
+    from dostransformer_amd.batch import bucket_sizes, pad_batch
     from dostransformer_amd.dist import shard_batch
     from dostransformer_amd.train import Trainer
 
     kind, L, T, H, B = CONFIGS[args.config]
     model = build_model(kind, L, T, H, device).to(device)
-    trainer = Trainer(model, lr=1e-4, beta=1.0, dist=dp)
+    use_graph = args.graph
+    trainer = Trainer(model, lr=1e-4, beta=1.0, dist=dp, graph=use_graph)
 
-    # device-resident, pre-collated shards of N_DISTINCT_BATCHES global batches (global n_max per batch)
+    # device-resident, pre-collated shards of N_DISTINCT_BATCHES global batches (global n_max per batch);
+    # in graph mode each is padded (exactly: ghost nodes/edges) to its (N, E) shape bucket
     batches = []
     for k in range(N_DISTINCT_BATCHES):
         crystals = make_crystals(kind, B * world, seed=k, dtype=torch.float32)
-        batches.append(shard_batch(crystals, world, rank).to(device))
+        g = shard_batch(crystals, world, rank)
+        if use_graph:
+            g = pad_batch(g, *bucket_sizes(g.meta.num_nodes, g.meta.num_edges))
+        batches.append(g.to(device))
     n_global = B * world
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dp is not None:
             td.barrier()
 
-    for i in range(args.warmup):
+    for i in range(max(args.warmup, len(batches) if use_graph else 0)):     # graph mode: capture every bucket
         trainer.step(batches[i % len(batches)], n_global)
     sync()
-    # per-kernel HIP-event timing of the dominant kernel over the timed region (same stream as the launches)
-    ops.KERNEL_TIMER.reset(enabled=True)
+    # eager mode: per-kernel HIP-event timing over the timed region itself (same stream as the launches);
+    # graph mode: the timed region replays captured graphs (no per-kernel events possible), so the
+    # kernel timing comes from an instrumented eager pass of the same steps right after it.
+    ops.KERNEL_TIMER.reset(enabled=not use_graph)
     t0 = time.perf_counter()
     for i in range(args.steps):
         trainer.step(batches[i % len(batches)], n_global)
     torch.cuda.synchronize()
-    if world > 1:
+    if dp is not None:
         td.barrier()
     elapsed = time.perf_counter() - t0
     ops.KERNEL_TIMER.enabled = False
+    if use_graph:
+        trainer.graph = False
+        ops.KERNEL_TIMER.reset(enabled=True)
+        for i in range(min(args.steps, 24)):
+            trainer.step(batches[i % len(batches)], n_global)
+        torch.cuda.synchronize()
+        ops.KERNEL_TIMER.enabled = False
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
+    if dp is not None:
         td.all_reduce(t, op=td.ReduceOp.MAX)
     elapsed = float(t[0])
 
@@ -169,14 +195,18 @@ def main():
             "config": {"workload": f"{args.config}: {kind} DOSTransformer layers={L} transformer={T} hidden={H}, "
                                    f"{B} crystals/GPU (global batch {n_global}), full train step "
                                    f"(fwd+loss+bwd+AdamW), {N_DISTINCT_BATCHES} distinct pre-collated batches",
-                       "global_batch": n_global, "parallelism": f"dp{world}"},
+                       "global_batch": n_global, "parallelism": f"dp{world}",
+                       "launch": "hip-graph replay per (N,E) bucket, exact ghost padding" if use_graph else "eager",
+                       "kernel_timing": ("HIP events, instrumented eager pass after the timed region" if use_graph
+                                         else "HIP events inside the timed region")},
             "roofline": roof["dominant"],
             "kernels": roof["all"],
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kind, L, T, H, B, args.cpu_budget)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if dp is not None:
         td.destroy_process_group()
 
 

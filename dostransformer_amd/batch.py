@@ -280,3 +280,59 @@ def split_crystals(g: CrystalBatch) -> List[Dict[str, object]]:
             c["mp_id"] = g.mp_id[b]
         out.append(c)
     return out
+
+
+# --------------------------------------------------------------------------------------------------
+# Shape bucketing for HIP-graph replay: pad a (destination-sorted) batch with GHOST nodes / edges.
+# --------------------------------------------------------------------------------------------------
+def bucket_sizes(num_nodes: int, num_edges: int, node_step: int = 32, edge_step: int = 512):
+    """Padded (N, E) of the bucket a batch falls into; always leaves room for >= 1 ghost node."""
+    n_pad = (num_nodes + 1 + node_step - 1) // node_step * node_step
+    e_pad = (num_edges + edge_step - 1) // edge_step * edge_step
+    return n_pad, e_pad
+
+
+def pad_batch(g: CrystalBatch, n_pad: int, e_pad: int) -> CrystalBatch:
+    """Pad to fixed (N, E) so that every kernel launch of a training step has static geometry and the
+    step can be replayed from a captured HIP graph.
+
+    Ghost nodes carry zero features, belong to NO crystal (outside every ``graph_ptr`` range, their
+    ``node_graph`` / ``dense_row`` point at one spare zero row past the real ones) and ghost edges
+    are self loops on the first ghost node.  Nothing a real crystal computes reads a ghost row, and every
+    gradient reaching a ghost row is exactly zero, so outputs and parameter gradients are bitwise
+    those of the unpadded batch (tests/test_gpu_models.py::test_ghost_padding_is_exact)."""
+    m = g.meta
+    if m is None or m.edge_perm is not None:
+        raise ValueError("pad_batch needs a batch built by collate(sort_edges=True)")
+    N, E, B = m.num_nodes, m.num_edges, m.num_graphs
+    if n_pad < N + 1 or e_pad < E:
+        raise ValueError(f"bucket ({n_pad},{e_pad}) too small for N={N}, E={E} (+1 ghost node)")
+    dn, de = n_pad - N, e_pad - E
+    f = dict(g._fields)
+    dev = g.x.device
+
+    def padrows(t, n):
+        return torch.cat([t, t.new_zeros((n,) + tuple(t.shape[1:]))], 0) if n > 0 else t
+
+    f["x"] = padrows(g.x, dn)
+    f["batch"] = torch.cat([g.batch, torch.full((dn,), B, dtype=g.batch.dtype, device=dev)])
+    f["edge_index"] = torch.cat([g.edge_index, torch.full((2, de), N, dtype=g.edge_index.dtype, device=dev)], 1)
+    for k in _EDGE_FIELDS:
+        if k in f and isinstance(f[k], torch.Tensor):
+            f[k] = padrows(f[k], de)
+    i32 = lambda v, n: torch.full((n,), v, dtype=torch.int32, device=m.src.device)
+    deg_ghost = torch.ones(dn, dtype=torch.float32, device=m.inv_deg.device)
+    deg_ghost[0] = 1.0 / max(de, 1)
+    meta = GraphMeta(
+        num_nodes=n_pad, num_edges=e_pad, num_graphs=B, n_max=m.n_max,
+        src=torch.cat([m.src, i32(N, de)]), dst=torch.cat([m.dst, i32(N, de)]), edge_perm=None,
+        rowptr_dst=torch.cat([m.rowptr_dst, i32(e_pad, dn)]),
+        perm_src=torch.cat([m.perm_src, torch.arange(E, e_pad, dtype=torch.int32, device=m.perm_src.device)]),
+        rowptr_src=torch.cat([m.rowptr_src, i32(e_pad, dn)]),
+        graph_ptr=m.graph_ptr, node_graph=torch.cat([m.node_graph, i32(B, dn)]),
+        dense_row=torch.cat([m.dense_row, i32(m.n_max * B, dn)]),
+        inv_deg=torch.cat([m.inv_deg, deg_ghost]),
+    )
+    out = CrystalBatch(f, B, meta)
+    object.__setattr__(out, "real_nodes", N)
+    return out

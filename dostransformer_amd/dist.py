@@ -63,12 +63,10 @@ class DataParallel:
         self.world = td.get_world_size(group)
         self.rank = td.get_rank(group)
 
-    def all_reduce_sum_scalars(self, sse: torch.Tensor, local_count: int) -> int:
-        """In-place sum of the SSE pair over ranks; returns the global element count."""
-        buf = torch.cat([sse.double(), torch.tensor([float(local_count)], dtype=torch.float64, device=sse.device)])
-        td.all_reduce(buf, op=td.ReduceOp.SUM, group=self.group)
-        sse.copy_(buf[:2].to(sse.dtype))
-        return int(round(float(buf[2])))
+    def all_reduce_sse(self, sse: torch.Tensor) -> None:
+        """In-place sum over ranks of the phonon loss' two SSE scalars (no host synchronisation; the
+        global element count is static: crystals in the un-sharded batch x 51)."""
+        td.all_reduce(sse, op=td.ReduceOp.SUM, group=self.group)
 
     def global_count(self, local: int) -> int:
         t = torch.tensor([float(local)], dtype=torch.float64,

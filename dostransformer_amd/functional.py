@@ -40,15 +40,16 @@ class SegList:
 
 
 def _wgrad_linear(sink: GradSink, G: Params, wkey: str, bkey: Optional[str], M: int, N: int, dy: Seg,
-                  segs: Sequence[Seg], **pro) -> None:
-    """dW (and db) of y = A W^T + b as split slabs + reduce jobs."""
+                  segs: Sequence[Seg], keep=(), **pro) -> None:
+    """dW (and db) of y = A W^T + b as split slabs + reduce jobs (launched on the sink's side stream;
+    ``keep``: the tensor(s) behind ``dy`` that the caller may drop before the side stream has run)."""
     if wkey not in G:
         return
     K = sum(s.width for s in segs)
     ns = ops.wgrad_splits(M, N, K)
     slab = sink.scratch(ns, N, K)
     slab_b = sink.scratch(ns, N) if bkey is not None else None
-    ops.wgrad(M, N, dy, segs, slab, slab_b, ns, **pro)
+    sink.on_side(lambda: ops.wgrad(M, N, dy, segs, slab, slab_b, ns, **pro), keep)
     sink.add(slab, 0, G[wkey], ns, N * K, N * K)
     if bkey is not None:
         sink.add(slab_b, 0, G[bkey], ns, N, N)
@@ -72,14 +73,15 @@ def mlp_prelu_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: G
     dev = z.device
     alpha = P[key + ".1.weight"]
     dys = dy_seg if dy_seg is not None else seg(dy)
-    _wgrad_linear(sink, G, key + ".2.weight", key + ".2.bias", M, H, dys, [seg(z)], pro=PRO_PRELU, pro_alpha=alpha)
+    _wgrad_linear(sink, G, key + ".2.weight", key + ".2.bias", M, H, dys, [seg(z)], keep=(dy,) if dy is not None else (),
+                  pro=PRO_PRELU, pro_alpha=alpha)
     rows = ops.gemm_partial_rows(M, H, EPI_PRELU_BWD)
     part = sink.scratch(rows, 1)
     dz = _empty(dev, M, H)
     ops.gemm(M, H, [dys], P[key + ".2.weight"], dz, w_layout=1, epi=EPI_PRELU_BWD, aux=z, epi_alpha=alpha,
              partials=part, partial_ld=1)
     sink.add(part, 0, G[key + ".1.weight"], rows, 1, 1)
-    _wgrad_linear(sink, G, key + ".0.weight", key + ".0.bias", M, H, seg(dz), a.segs)
+    _wgrad_linear(sink, G, key + ".0.weight", key + ".0.bias", M, H, seg(dz), a.segs, keep=(dz,))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -105,7 +107,7 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
     a, xhat, rstd, M, H = ctx
     dev = xhat.device
     gam, bet, alpha = P[key + ".1.weight"], P[key + ".1.bias"], P[key + ".2.weight"]
-    _wgrad_linear(sink, G, key + ".3.weight", key + ".3.bias", M, H, seg(dy), [seg(xhat)], pro=PRO_LN_PRELU,
+    _wgrad_linear(sink, G, key + ".3.weight", key + ".3.bias", M, H, seg(dy), [seg(xhat)], keep=(dy,), pro=PRO_LN_PRELU,
                   pro_gamma=gam, pro_beta=bet, pro_alpha=alpha)
     rows = ops.gemm_partial_rows(M, 2 * H, EPI_PRELU_LN_BWD)
     pld = 4 * H + 4          # [dgamma(2H) | dbeta(2H) | pad(3) | dalpha]; multiple of 4 -> vector reduce
@@ -116,7 +118,7 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
     sink.add(part, 0, G[key + ".1.weight"], rows, pld, 2 * H)
     sink.add(part, 2 * H, G[key + ".1.bias"], rows, pld, 2 * H)
     sink.add(part, pld - 1, G[key + ".2.weight"], rows, pld, 1)
-    _wgrad_linear(sink, G, key + ".0.weight", key + ".0.bias", M, 2 * H, seg(dz), a.segs)
+    _wgrad_linear(sink, G, key + ".0.weight", key + ".0.bias", M, 2 * H, seg(dz), a.segs, keep=(dz,))
     dcat = _empty(dev, M, a.K)
     ops.gemm(M, a.K, [seg(dz)], P[key + ".0.weight"], dcat, w_layout=1)
     return dcat
@@ -243,12 +245,12 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: torch.Tensor, dkvhat: t
         g1, b1 = P[lp + ".layer_norms.1.weight"], P[lp + ".layer_norms.1.bias"]
         g0, b0 = P[lp + ".layer_norms.0.weight"], P[lp + ".layer_norms.0.bias"]
         # fc2
-        _wgrad_linear(sink, G, lp + ".fc2.weight", lp + ".fc2.bias", rows, H, seg(dx), [seg(h)])
+        _wgrad_linear(sink, G, lp + ".fc2.weight", lp + ".fc2.bias", rows, H, seg(dx), [seg(h)], keep=(dx,))
         dh = _empty(dev, rows, 4 * H)
         ops.gemm(rows, 4 * H, [seg(dx)], P[lp + ".fc2.weight"], dh, w_layout=1, epi=EPI_RELU_MASK, aux=h)
         # fc1 (+ LN1 backward + residual)
-        _wgrad_linear(sink, G, lp + ".fc1.weight", lp + ".fc1.bias", rows, 4 * H, seg(dh), [seg(x1)], pro=PRO_ROWLN,
-                      pro_gamma=g1, pro_beta=b1, pro_stats=st1)
+        _wgrad_linear(sink, G, lp + ".fc1.weight", lp + ".fc1.bias", rows, 4 * H, seg(dh), [seg(x1)], keep=(dh,),
+                      pro=PRO_ROWLN, pro_gamma=g1, pro_beta=b1, pro_stats=st1)
         rgp = ops.gemm_partial_rows(rows, H, EPI_ROWLN_BWD)
         part = sink.scratch(rgp, 2 * H)
         dx1 = _empty(dev, rows, H)
@@ -343,9 +345,9 @@ def decoder_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, segs: SegList
     """Adds the pooled-node gradient into dxL; returns the Seg of du (eDOS) or None."""
     H, B, N = cfg.H, m.num_graphs, m.num_nodes
     dev = dgraph.device
-    _wgrad_linear(sink, G, "GN_decoder.mlp.0.weight", "GN_decoder.mlp.0.bias", B, H, seg(dgraph), segs.segs)
+    _wgrad_linear(sink, G, "GN_decoder.mlp.0.weight", "GN_decoder.mlp.0.bias", B, H, seg(dgraph), segs.segs, keep=(dgraph,))
     K = segs.K
-    dcat = _empty(dev, B, K)
+    dcat = torch.zeros(B + 1, K, device=dev, dtype=torch.float32)     # row B: zero gradient for ghost nodes
     ops.gemm(B, K, [seg(dgraph)], P["GN_decoder.mlp.0.weight"], dcat, w_layout=1)
     ops.graph_pool_bwd(dcat.data_ptr() + 4 * (K - H), K, m.node_graph, dxL, N, H, True)
     sink._keep.append(dcat)
@@ -360,9 +362,9 @@ def dostransformer_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta):
     dev = P["embeddings.weight"].device
     xL, u, ctrunk = gnn_trunk_fwd(P, cfg, g, m)
     # to_dense_batch + the (parameter-free part of the) key LayerNorm, shared by every cross attention
-    kvhat = _empty(dev, nmax * B, H)
+    kvhat = _empty(dev, nmax * B + 1, H)          # + 1 spare row: the dense slot of ghost (padding) nodes
     rstd_n = _empty(dev, N)
-    ops.dense_normalize(xL, m.dense_row, kvhat, rstd_n, N, H, nmax * B)
+    ops.dense_normalize(xL, m.dense_row, kvhat, rstd_n, N, H, nmax * B + 1)
     emb = P["embeddings.weight"]
     E1, c1 = encoder_fwd(P, "transformer", emb, S, B, 1, 0, kvhat, nmax, B, H, T)
     graph, dec_segs = decoder_fwd(P, cfg, m, xL, u)
@@ -411,7 +413,7 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
     sink.add(part, H, G["transformer_source.layer_norm.bias"], r32, pld, H)
     sink.add(part, 2 * H, G["out_layer.weight"], r32, pld, H)
     sink.add(part, 3 * H, G["out_layer.bias"], r32, pld, 1)
-    dkv = torch.zeros(nmax * B, H, device=dev, dtype=torch.float32)
+    dkv = torch.zeros(nmax * B + 1, H, device=dev, dtype=torch.float32)     # spare row stays zero
     dhs = encoder_bwd(P, G, "transformer_source", c3, dx, dkv, sink)
     dkvs = torch.zeros(rows2, H, device=dev, dtype=torch.float32)
     ddosin = encoder_bwd(P, G, "transformer_self", c2, dhs, dkvs, sink)
@@ -419,8 +421,8 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
     dpre = _empty(dev, rows2, H)
     ops.act_bwd(ddosin, dosin, 0.01, dpre)
     map0, map1 = rowmap(d=B, m=2 * B, c=1, off=0), rowmap(d=B, m=2 * B, c=1, off=B)
-    _wgrad_linear(sink, G, "fc.weight", "fc.bias", S * B, H, seg(dpre, rmap=map0), a_g.segs)
-    _wgrad_linear(sink, G, "fc_prompt.weight", "fc_prompt.bias", S * B, H, seg(dpre, rmap=map1), a_s.segs)
+    _wgrad_linear(sink, G, "fc.weight", "fc.bias", S * B, H, seg(dpre, rmap=map0), a_g.segs, keep=(dpre,))
+    _wgrad_linear(sink, G, "fc_prompt.weight", "fc_prompt.bias", S * B, H, seg(dpre, rmap=map1), a_s.segs, keep=(dpre,))
     Wfc, Wfp = P["fc.weight"], P["fc_prompt.weight"]
     dE1 = _empty(dev, S * B, H)
     ops.gemm(S * B, H, [seg(dpre, rmap=map0)], Wfc[:, :H], dE1, w_layout=1)
@@ -479,7 +481,7 @@ def graphnetwork_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, ddo
     sink.add(part, H, G["out_layer.2.bias"], r32, H + 1, 1)
     dpre = _empty(dev, rows, H)
     ops.act_bwd(dhid, hid, 0.01, dpre)
-    _wgrad_linear(sink, G, "out_layer.0.weight", "out_layer.0.bias", rows, H, seg(dpre), a.segs)
+    _wgrad_linear(sink, G, "out_layer.0.weight", "out_layer.0.bias", rows, H, seg(dpre), a.segs, keep=(dpre,))
     W0 = P["out_layer.0.weight"]
     Rs = _empty(dev, S, H)
     ops.reduce_rows(dpre.data_ptr(), H, Rs.data_ptr(), H, S, B, B, 1, H)          # sum over the batch

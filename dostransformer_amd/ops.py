@@ -173,10 +173,44 @@ class GradSink:
     into the parameter-gradient buffers with ONE deterministic kernel launch per 'wave'
     (jobs that share a destination are serialised into successive waves)."""
 
+    # Weight-gradient (wgrad) and key/value-gradient kernels feed nothing but the final slab reduction,
+    # so they are launched on a SIDE stream and run concurrently with the dgrad chain on the main stream:
+    # at BASELINE sizes every kernel is one partial wave of workgroups, two streams simply fill more CUs.
+    use_side_stream = __import__("os").environ.get("DOSX_SIDE_STREAM", "0") == "1"     # measured: no gain (2.86 vs 2.73 ms/step), off by default
+    _side_streams: dict = {}
+
     def __init__(self, device):
         self.device = device
         self.jobs: List[Tuple[int, int, int, int, int, int]] = []
         self._keep: List[torch.Tensor] = []
+        self.main = torch.cuda.current_stream()
+        self.side = None
+        if GradSink.use_side_stream:
+            key = (str(device), torch.cuda.is_current_stream_capturing())
+            if key not in GradSink._side_streams:
+                GradSink._side_streams[key] = torch.cuda.Stream(device=device)
+            self.side = GradSink._side_streams[key]
+        self._forked = False
+
+    def on_side(self, fn, keep=()) -> None:
+        """Run ``fn`` (kernel launches) on the side stream, ordered after everything launched so far on
+        the main stream.  ``keep``: tensors the side work reads that the caller is about to drop."""
+        self._keep.extend(keep)
+        if self.side is None:
+            fn()
+            return
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        self.side.wait_event(ev)
+        with torch.cuda.stream(self.side):
+            fn()
+        self._forked = True
+
+    def join(self) -> None:
+        """Main stream waits for all side work issued so far."""
+        if self.side is not None and self._forked:
+            self.main.wait_stream(self.side)
+            self._forked = False
 
     def scratch(self, *shape) -> torch.Tensor:
         t = torch.empty(shape, device=self.device, dtype=torch.float32)
@@ -192,6 +226,7 @@ class GradSink:
                           int(count), 1 if accumulate else 0))
 
     def flush(self):
+        self.join()
         if not self.jobs:
             return
         # jobs that share a destination go to successive launches (later ones accumulate)

@@ -3,17 +3,47 @@ forward program -> loss kernel -> backward program -> (RCCL all-reduce) -> flat 
 
 No autograd graph, no per-parameter optimizer loop, no host synchronisation: the loss stays on the
 device (the reference prints it every step, `main_eDOS.py:129`; read ``.item()`` only when needed).
+
+``Trainer(graph=True)`` additionally replays the step from captured HIP graphs: batches are padded
+with ghost nodes / edges to a small set of (N, E) buckets (``batch.pad_batch`` — exact, not
+approximate), every launch of the forward / loss / backward programs for a bucket is captured once,
+and a step is then "copy the batch into the bucket's static buffers, replay, AdamW".  The ~160
+launches of a step cost the host ~20 us each when issued from Python; replay removes that.
 """
 from __future__ import annotations
 
-from typing import Optional
+from typing import Dict, Optional
 
 import torch
 
 from . import functional as Fn
 from . import ops
 from ._models import DOSTransformerBase
-from .batch import graph_meta
+from .batch import CrystalBatch, GraphMeta, bucket_sizes, graph_meta, pad_batch
+
+_META_TENSORS = ("src", "dst", "rowptr_dst", "perm_src", "rowptr_src", "graph_ptr", "node_graph", "dense_row", "inv_deg")
+
+
+class _Slot:
+    """Static buffers + captured graphs of one shape bucket."""
+
+    def __init__(self, g: CrystalBatch, kind: str):
+        m = g.meta
+        self.fields = ["x", "system"] + (["edge_vec", "phdos"] if kind == "phonon" else ["edge_attr", "glob", "y_ft"])
+        f = {k: g[k].clone() for k in self.fields}
+        f["edge_index"], f["batch"] = g.edge_index, g.batch         # never read by the kernels
+        meta = GraphMeta(num_nodes=m.num_nodes, num_edges=m.num_edges, num_graphs=m.num_graphs, n_max=m.n_max,
+                         edge_perm=None, **{k: getattr(m, k).clone() for k in _META_TENSORS})
+        self.g = CrystalBatch(f, g.num_graphs, meta)
+        self.graph_a = self.graph_b = None
+        self.keep = None
+
+    def load(self, g: CrystalBatch) -> None:
+        for k in self.fields:
+            self.g[k].copy_(g[k], non_blocking=True)
+        m, sm = g.meta, self.g.meta
+        for k in _META_TENSORS:
+            getattr(sm, k).copy_(getattr(m, k), non_blocking=True)
 
 
 class Trainer:
@@ -25,61 +55,137 @@ class Trainer:
     """
 
     def __init__(self, model: DOSTransformerBase, lr: float = 1e-4, beta: float = 1.0, weight_decay: float = 1e-2,
-                 betas=(0.9, 0.999), eps: float = 1e-8, dist=None):
+                 betas=(0.9, 0.999), eps: float = 1e-8, dist=None, graph: bool = False):
         if not isinstance(model, DOSTransformerBase):
             raise TypeError("Trainer drives DOSTransformer / DOSTransformer_phonon modules")
         self.model, self.lr, self.beta, self.wd, self.betas, self.eps = model, lr, beta, weight_decay, betas, eps
         self.dist = dist
+        self.graph = graph
         self.step_count = 0
         self._m = self._v = None
         self._fp = None
         self.kind = model._cfg.kind
         self.last_outputs = None
+        self._slots: Dict[tuple, _Slot] = {}
 
     def _state(self, fp):
         if self._fp is not fp:
             self._m = torch.zeros_like(fp.flat)
             self._v = torch.zeros_like(fp.flat)
             self._fp = fp
+            self._slots = {}
         return self._m, self._v
 
+    # ---- the step, split where the data-parallel collectives go --------------------------------
+    def _part_a(self, fp, g, m):
+        """forward program (+ the phonon SSE pair).  Returns the state part B needs."""
+        model, dev, cfg = self.model, fp.flat.device, self.model._cfg
+        B, S = m.num_graphs, cfg.S
+        dg, xL, ds, (ctx, dos) = model._program_fwd(fp.P, g, m)
+        st = {"ctx": ctx, "dos": dos, "out": (dg, xL, ds), "B": B, "S": S}
+        if self.kind == "phonon":
+            st["y"] = Fn._f32(g.phdos).reshape(B, S)
+            st["sse"] = torch.empty(2, device=dev, dtype=torch.float32)
+            ops.sse2(dos[:B], dos[B:], st["y"], st["sse"], B * S)
+        else:
+            st["y"] = Fn._f32(g.y_ft).reshape(-1)
+        return st
+
+    def _part_b(self, fp, m, st, n_global: int):
+        """loss gradient + backward program.  n_global: crystals in the un-sharded batch."""
+        dev, cfg = fp.flat.device, self.model._cfg
+        B, S, dos = st["B"], st["S"], st["dos"]
+        ddos = torch.empty_like(dos)
+        if self.kind == "phonon":
+            loss = torch.empty(1, device=dev, dtype=torch.float32)
+            ops.loss_phonon_bwd(dos[:B], dos[B:], st["y"], st["sse"], self.beta, float(n_global * S), ddos[:B],
+                                ddos[B:], loss, B * S)
+            loss = loss[0]
+        else:
+            lp = torch.empty(B, device=dev, dtype=torch.float32)
+            ops.loss_edos(dos[:B], dos[B:], st["y"], self.beta, B, S, n_global, ddos[:B], ddos[B:], lp)
+            loss = lp.sum()
+        sink = ops.GradSink(dev)
+        Fn.dostransformer_bwd(fp.P, fp.G, cfg, m, st["ctx"], ddos, None, sink)
+        sink.release()
+        return loss
+
+    def _n_global(self, B: int, n_global: Optional[int]) -> int:
+        if n_global is not None:
+            return int(n_global)
+        return self.dist.global_count(B) if self.dist is not None else B
+
+    # ---- eager path ------------------------------------------------------------------------------
     def forward_backward(self, g, n_global: Optional[int] = None) -> torch.Tensor:
         """Forward + loss + backward; leaves the gradients in the flat buffer.  Returns the loss
         (0-dim device tensor; for eDOS under data parallelism it is this rank's share)."""
         model = self.model
         dev = model._module_device()
         fp = model._ensure_flat(dev, g)
+        self._state(fp)
         m = graph_meta(g, dev)
-        cfg = model._cfg
-        B, S = m.num_graphs, cfg.S
+        ng = self._n_global(m.num_graphs, n_global)
         with torch.no_grad():
-            dg, xL, ds, (ctx, dos) = model._program_fwd(fp.P, g, m)
-            self.last_outputs = (dg, xL, ds)
-            ddos = torch.empty_like(dos)
-            if self.kind == "phonon":
-                y = Fn._f32(g.phdos).reshape(B, S)
-                sse = torch.empty(2, device=dev, dtype=torch.float32)
-                ops.sse2(dos[:B], dos[B:], y, sse, B * S)
-                count_global = float(B * S)
-                if self.dist is not None:
-                    count_global = float(self.dist.all_reduce_sum_scalars(sse, B * S))
-                loss = torch.empty(1, device=dev, dtype=torch.float32)
-                ops.loss_phonon_bwd(dos[:B], dos[B:], y, sse, self.beta, count_global, ddos[:B], ddos[B:], loss,
-                                    B * S)
-                loss = loss[0]
-            else:
-                y = Fn._f32(g.y_ft).reshape(-1)
-                bg = B if n_global is None else n_global
-                if self.dist is not None and n_global is None:
-                    bg = self.dist.global_count(B)
-                lp = torch.empty(B, device=dev, dtype=torch.float32)
-                ops.loss_edos(dos[:B], dos[B:], y, self.beta, B, S, bg, ddos[:B], ddos[B:], lp)
-                loss = lp.sum()
-            sink = ops.GradSink(dev)
-            Fn.dostransformer_bwd(fp.P, fp.G, cfg, m, ctx, ddos, None, sink)
-            sink.release()
-        return loss
+            st = self._part_a(fp, g, m)
+            self.last_outputs = st["out"]
+            if self.kind == "phonon" and self.dist is not None:
+                self.dist.all_reduce_sse(st["sse"])
+            return self._part_b(fp, m, st, ng)
 
+    # ---- graph path ------------------------------------------------------------------------------
+    def _capture(self, slot: _Slot, fp, ng: int) -> None:
+        timer_on = ops.KERNEL_TIMER.enabled
+        ops.KERNEL_TIMER.enabled = False
+        g, m = slot.g, slot.g.meta
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():          # eager warm-up (lazy kernel attributes etc.)
+            st = self._part_a(fp, g, m)
+            self._part_b(fp, m, st, ng)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        split = self.dist is not None and self.kind == "phonon"
+        with torch.no_grad():
+            slot.graph_a = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(slot.graph_a):
+                st = self._part_a(fp, g, m)
+                if not split:
+                    loss = self._part_b(fp, m, st, ng)
+            if split:
+                slot.graph_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(slot.graph_b, pool=slot.graph_a.pool()):
+                    loss = self._part_b(fp, m, st, ng)
+        slot.keep = (st, loss)            # keeps the graph-owned outputs from being recycled
+        slot.loss, slot.out, slot.sse = loss, st["out"], st.get("sse")
+        ops.KERNEL_TIMER.enabled = timer_on
+
+    def _graph_step(self, g: CrystalBatch, n_global: Optional[int]) -> torch.Tensor:
+        model = self.model
+        dev = model._module_device()
+        fp = model._ensure_flat(dev, g)
+        self._state(fp)
+        m = g.meta
+        if m is None or m.edge_perm is not None:
+            raise ValueError("graph mode needs batches from collate(sort_edges=True) (+ pad_batch)")
+        if getattr(g, "real_nodes", None) is None:               # not padded yet: pad on the fly
+            g = pad_batch(g, *bucket_sizes(m.num_nodes, m.num_edges))
+            m = g.meta
+        ng = self._n_global(m.num_graphs, n_global)
+        key = (m.num_nodes, m.num_edges, m.num_graphs, m.n_max, ng)
+        slot = self._slots.get(key)
+        if slot is None:
+            slot = _Slot(g, self.kind)
+            self._capture(slot, fp, ng)
+            self._slots[key] = slot
+        slot.load(g)
+        slot.graph_a.replay()
+        if slot.graph_b is not None:
+            self.dist.all_reduce_sse(slot.sse)
+            slot.graph_b.replay()
+        self.last_outputs = slot.out
+        return slot.loss
+
+    # ---- optimizer -------------------------------------------------------------------------------
     def optimizer_step(self) -> None:
         fp = self._fp if self._fp is not None else self.model.flat_params()
         m, v = self._state(fp)
@@ -90,8 +196,6 @@ class Trainer:
                   self.step_count, 1.0)
 
     def step(self, g, n_global: Optional[int] = None) -> torch.Tensor:
-        fp = self.model.flat_params(g)
-        self._state(fp)
-        loss = self.forward_backward(g, n_global)
+        loss = self._graph_step(g, n_global) if self.graph else self.forward_backward(g, n_global)
         self.optimizer_step()
         return loss
