@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="phonon_h128_b64", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--launch", choices=["replay", "eager", "graph"], default="replay",
+                    help="replay: re-issue a recorded launch list on static buffers (2 HIP streams); eager: marshal "
+                         "every launch from Python; graph: torch/HIP graph replay")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from captured HIP graphs (exact ghost padding to (N,E) buckets); "
                          "measured slower than eager launches while the step is GPU-bound (2.95 vs 2.72 ms)")
@@ -135,8 +138,9 @@ def main():
 
     kind, L, T, H, B = CONFIGS[args.config]
     model = build_model(kind, L, T, H, device).to(device)
-    use_graph = args.graph
-    trainer = Trainer(model, lr=1e-4, beta=1.0, dist=dp, graph=use_graph)
+    mode = "graph" if args.graph else args.launch
+    use_graph = mode in ("graph", "replay")          # both run on ghost-padded (N,E) shape buckets
+    trainer = Trainer(model, lr=1e-4, beta=1.0, dist=dp, graph=(mode == "graph"), replay=(mode == "replay"))
 
     # device-resident, pre-collated shards of N_DISTINCT_BATCHES global batches (global n_max per batch);
     # in graph mode each is padded (exactly: ghost nodes/edges) to its (N, E) shape bucket
@@ -170,7 +174,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ops.KERNEL_TIMER.enabled = False
     if use_graph:
-        trainer.graph = False
+        trainer.graph = trainer.replay = False
         ops.KERNEL_TIMER.reset(enabled=True)
         for i in range(min(args.steps, 24)):
             trainer.step(batches[i % len(batches)], n_global)
@@ -183,6 +187,15 @@ def main():
 
     if rank == 0:
         roof = ops.KERNEL_TIMER.roofline(HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS)
+        # HBM traffic per launch from the committed rocprofv3 PMC passes (cannot be collected in-process)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["sites"]
+        except Exception:
+            pmc = {}
+        if args.config == "phonon_h128_b64" and world == 1:
+            for rec in roof["all"] + ([roof["dominant"]] if roof["dominant"] else []):
+                if rec["site"] in pmc:
+                    rec["traffic"] = pmc[rec["site"]]["hbm_bytes_per_launch"]
         out = {
             "metric": "crystals/sec training throughput (Phonon DOS, hidden=128)" if kind == "phonon" else
                       "crystals/sec training throughput (Electron DOS)",
@@ -196,7 +209,9 @@ def main():
                                    f"{B} crystals/GPU (global batch {n_global}), full train step "
                                    f"(fwd+loss+bwd+AdamW), {N_DISTINCT_BATCHES} distinct pre-collated batches",
                        "global_batch": n_global, "parallelism": f"dp{world}",
-                       "launch": "hip-graph replay per (N,E) bucket, exact ghost padding" if use_graph else "eager",
+                       "launch": {"graph": "hip-graph replay per (N,E) bucket, exact ghost padding",
+                                  "replay": "recorded launch list per (N,E) bucket (exact ghost padding), 2 HIP streams",
+                                  "eager": "eager"}[mode],
                        "kernel_timing": ("HIP events, instrumented eager pass after the timed region" if use_graph
                                          else "HIP events inside the timed region")},
             "roofline": roof["dominant"],

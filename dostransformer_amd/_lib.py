@@ -111,6 +111,7 @@ _SIGS = {
     "dosx_sse2": [_P, _P, _P, _P, _I, _P],
     "dosx_loss_phonon_bwd": [_P, _P, _P, _P, _F, _D, _P, _P, _P, _I, _P],
     "dosx_loss_edos": [_P, _P, _P, _F, _I, _I, _I, _P, _P, _P, _P],
+    "dosx_sum": [_P, _I, _P, _P],
     "dosx_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
     "dosx_fill": [_P, _F, _L, _P],
     "dosx_embed_rows": [_P, _P, _P, _I, _I, _P],

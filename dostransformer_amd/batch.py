@@ -285,7 +285,7 @@ def split_crystals(g: CrystalBatch) -> List[Dict[str, object]]:
 # --------------------------------------------------------------------------------------------------
 # Shape bucketing for HIP-graph replay: pad a (destination-sorted) batch with GHOST nodes / edges.
 # --------------------------------------------------------------------------------------------------
-def bucket_sizes(num_nodes: int, num_edges: int, node_step: int = 32, edge_step: int = 512):
+def bucket_sizes(num_nodes: int, num_edges: int, node_step: int = 8, edge_step: int = 128):
     """Padded (N, E) of the bucket a batch falls into; always leaves room for >= 1 ghost node."""
     n_pad = (num_nodes + 1 + node_step - 1) // node_step * node_step
     e_pad = (num_edges + edge_step - 1) // edge_step * edge_step

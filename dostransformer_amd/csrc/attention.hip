@@ -622,10 +622,14 @@ extern "C" int dosx_attention_bwd(const DosxAttn* ap, dosx_stream_t stream) {
     attr_set = true;
   }
   const dim3 grid(ceil_div(a.Sq, QT), a.Bq);
-  if (kres) hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, dim3(256), s1, to_stream(stream), a);
-  else hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), grid, dim3(256), s1, to_stream(stream), a);
-  DOSX_LAUNCH_CHECK();
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(ceil_div(a.Nk, 32), a.Bk), dim3(256), s2, to_stream(stream), a);
-  DOSX_LAUNCH_CHECK();
+  if (!(a.flags & DOSX_ATTN_BWD_SKIP_DQ)) {
+    if (kres) hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, dim3(256), s1, to_stream(stream), a);
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), grid, dim3(256), s1, to_stream(stream), a);
+    DOSX_LAUNCH_CHECK();
+  }
+  if (!(a.flags & DOSX_ATTN_BWD_SKIP_DKV)) {
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(ceil_div(a.Nk, 32), a.Bk), dim3(256), s2, to_stream(stream), a);
+    DOSX_LAUNCH_CHECK();
+  }
   return 0;
 }

@@ -253,6 +253,17 @@ __global__ __launch_bounds__(256) void loss_edos_kernel(const float* __restrict_
   if (lane == 0) loss_partial[b] = (r0 + beta * r1) * inv_bglobal;
 }
 
+// dst[0] = sum(src[0..n))  (one block; deterministic order)
+__global__ __launch_bounds__(256) void sum_kernel(const float* __restrict__ src, int n, float* __restrict__ dst) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += src[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) dst[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, size_t n, float decay, float beta1, float beta2, float eps,
                              float step_size, float inv_bc2s, float gscale) {
@@ -383,6 +394,13 @@ extern "C" int dosx_loss_edos(const float* pg, const float* ps, const float* y_f
   DOSX_CHECK_ARG(pg && ps && y_ft && dpg && dps && loss_partial && B > 0 && S > 0 && B_global > 0, "dosx_loss_edos: bad args");
   hipLaunchKernelGGL(loss_edos_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, to_stream(stream), pg, ps, y_ft, beta, B, S,
                      1.f / (float)B_global, dpg, dps, loss_partial);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_sum(const float* src, int n, float* dst, dosx_stream_t stream) {
+  DOSX_CHECK_ARG(src && dst && n > 0, "dosx_sum: bad args");
+  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, to_stream(stream), src, n, dst);
   DOSX_LAUNCH_CHECK();
   return 0;
 }

@@ -23,7 +23,7 @@ Params = Dict[str, torch.Tensor]
 
 
 def _empty(dev, *shape):
-    return torch.empty(shape, device=dev, dtype=torch.float32)
+    return ops.alloc(dev, *shape)
 
 
 def _rows32(m: int) -> int:
@@ -269,7 +269,17 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: torch.Tensor, dkvhat: t
             dkvhat.data_ptr(), 1
         a.partials_q = part.data_ptr()
         a.partials_kv = part.data_ptr() + 4 * Bq * nqt * 2 * H
+        # dq (feeds the next layer's backward) on the main stream; dk+dv (feeds only the key-gradient
+        # consumers at the very end) on the side stream, in layer order so dkvhat accumulates in order
+        a.flags = 8          # DOSX_ATTN_BWD_SKIP_DKV
         ops.attention_bwd(a)
+        a2 = _attn_desc(Sq, Bq, Nk, Bk, H, qs, qb, x_in, kvhat, g0, b0)
+        a2.probs, a2.qstats = probs.data_ptr(), qstats.data_ptr()
+        a2.dout, a2.dx, a2.dscores, a2.dkvhat, a2.dkv_accumulate = dx1.data_ptr(), dxin.data_ptr(), dsc.data_ptr(), \
+            dkvhat.data_ptr(), 1
+        a2.partials_q, a2.partials_kv = a.partials_q, a.partials_kv
+        a2.flags = 4         # DOSX_ATTN_BWD_SKIP_DQ
+        sink.on_side(lambda a2=a2: ops.attention_bwd(a2), (dx1, dsc, dxin))
         sink.add(part, 0, G[lp + ".layer_norms.0.weight"], npart, 2 * H, H)
         sink.add(part, H, G[lp + ".layer_norms.0.bias"], npart, 2 * H, H)
         dx = dxin
@@ -347,7 +357,7 @@ def decoder_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, segs: SegList
     dev = dgraph.device
     _wgrad_linear(sink, G, "GN_decoder.mlp.0.weight", "GN_decoder.mlp.0.bias", B, H, seg(dgraph), segs.segs, keep=(dgraph,))
     K = segs.K
-    dcat = torch.zeros(B + 1, K, device=dev, dtype=torch.float32)     # row B: zero gradient for ghost nodes
+    dcat = ops.zeros(dev, B + 1, K)     # row B: zero gradient for ghost nodes
     ops.gemm(B, K, [seg(dgraph)], P["GN_decoder.mlp.0.weight"], dcat, w_layout=1)
     ops.graph_pool_bwd(dcat.data_ptr() + 4 * (K - H), K, m.node_graph, dxL, N, H, True)
     sink._keep.append(dcat)
@@ -368,7 +378,7 @@ def dostransformer_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta):
     emb = P["embeddings.weight"]
     E1, c1 = encoder_fwd(P, "transformer", emb, S, B, 1, 0, kvhat, nmax, B, H, T)
     graph, dec_segs = decoder_fwd(P, cfg, m, xL, u)
-    sysidx = g.system.to(torch.int32).contiguous()
+    sysidx = g.system if g.system.dtype == torch.int32 else g.system.to(torch.int32).contiguous()
     hp = H // 2
     prow = _empty(dev, B, hp)
     ops.embed_rows(P[cfg.prompt_key], sysidx, prow, B, hp)
@@ -413,10 +423,11 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
     sink.add(part, H, G["transformer_source.layer_norm.bias"], r32, pld, H)
     sink.add(part, 2 * H, G["out_layer.weight"], r32, pld, H)
     sink.add(part, 3 * H, G["out_layer.bias"], r32, pld, 1)
-    dkv = torch.zeros(nmax * B + 1, H, device=dev, dtype=torch.float32)     # spare row stays zero
+    dkv = ops.zeros(dev, nmax * B + 1, H)     # spare row stays zero
     dhs = encoder_bwd(P, G, "transformer_source", c3, dx, dkv, sink)
-    dkvs = torch.zeros(rows2, H, device=dev, dtype=torch.float32)
+    dkvs = ops.zeros(dev, rows2, H)
     ddosin = encoder_bwd(P, G, "transformer_self", c2, dhs, dkvs, sink)
+    sink.join()          # dkvs is produced on the side stream
     ops.rownorm_bwd(dkvs, kvs, rstd_s, ddosin, rows2, H, True)
     dpre = _empty(dev, rows2, H)
     ops.act_bwd(ddosin, dosin, 0.01, dpre)
@@ -442,6 +453,7 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
     ops.reduce_rows(dX1.data_ptr(), H, G["embeddings.weight"].data_ptr(), H, S, B, B, 1, H)
     # node embeddings: dense keys + pooled decoder input (+ external grad on the returned x)
     dxL = _empty(dev, N, H)
+    sink.join()          # dkv (dense keys) is produced on the side stream
     ops.dense_normalize_bwd(dkv, kvhat, rstd_n, m.dense_row, dxL, N, H, False)
     du_seg = decoder_bwd(P, G, cfg, m, dec_segs, dgraph, dxL, sink)
     if dx_ext is not None:
@@ -490,7 +502,7 @@ def graphnetwork_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, ddo
     ops.reduce_rows(dpre.data_ptr(), H, Rb.data_ptr(), H, B, S, 1, B, H)          # sum over the energy bins
     dgraph = _empty(dev, B, H)
     ops.gemm(B, H, [seg(Rb)], W0[:, H:], dgraph, w_layout=1)
-    dxL = torch.zeros(N, H, device=dev, dtype=torch.float32)
+    dxL = ops.zeros(dev, N, H)
     du_seg = decoder_bwd(P, G, cfg, m, dec_segs, dgraph, dxL, sink)
     if dx_ext is not None:
         dxL.add_(dx_ext)

@@ -74,7 +74,7 @@ class _EncoderFn(torch.autograd.Function):
         sink = ops.GradSink(dev)
         dkv = torch.zeros(nk * b, h, device=dev)
         dx = Fn.encoder_bwd(ctx.P, G, "enc", ctx.c, dy.contiguous().reshape(sq * b, h).float(), dkv, sink)
-        sink.flush()
+        sink.flush()         # (joins the side stream: dkv is complete)
         sink.release()
         dkv_in = None
         if self_attn:

@@ -75,6 +75,70 @@ class _KernelTimer:
 KERNEL_TIMER = _KernelTimer()
 
 
+class _Recorder:
+    """Launch recorder: while active, every libdosx call (function pointer + fully marshalled ctypes
+    arguments, stream handle included) and every stream fork/join is appended to ``prog`` and every
+    tensor allocated through :func:`alloc` is kept alive, so the exact same launch sequence can be
+    re-issued later on the same buffers by :class:`Program` with no Python marshalling, no allocation
+    and no autograd — the host-side analogue of a captured graph, but it keeps real HIP streams (the
+    side stream of GradSink runs concurrently with the main one on replay)."""
+
+    def __init__(self):
+        self.active = False
+        self.prog = []
+        self.keep = []
+
+    def begin(self):
+        if self.active:
+            raise RuntimeError("recorder already active")
+        self.active, self.prog, self.keep = True, [], []
+
+    def end(self) -> "Program":
+        p = Program(self.prog, self.keep)
+        self.active, self.prog, self.keep = False, [], []
+        return p
+
+
+class Program:
+    def __init__(self, prog, keep):
+        self.prog, self.keep = prog, keep
+
+    def run(self) -> None:
+        for fn, args in self.prog:
+            rc = fn(*args)
+            if rc:
+                _lib.check(rc, getattr(fn, "__name__", "dosx call"))
+
+    def __len__(self):
+        return len(self.prog)
+
+
+RECORDER = _Recorder()
+
+
+def _call(name: str, *args) -> None:
+    fn = getattr(_lib.load(), name)
+    rc = fn(*args)
+    if rc:
+        _lib.check(rc, name)
+    if RECORDER.active:
+        RECORDER.prog.append((fn, args))
+
+
+def alloc(device, *shape) -> torch.Tensor:
+    """Uninitialised fp32 device buffer (kept alive for the recorded program while recording)."""
+    t = torch.empty(shape, device=device, dtype=torch.float32)
+    if RECORDER.active:
+        RECORDER.keep.append(t)
+    return t
+
+
+def zeros(device, *shape) -> torch.Tensor:
+    t = alloc(device, *shape)
+    fill(t, 0.0)
+    return t
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -141,8 +205,7 @@ def gemm(M: int, N: int, segs: Sequence[Seg], w: torch.Tensor, out: torch.Tensor
     g.aux_stats = _p(aux_stats)
     g.epi_gamma, g.epi_beta, g.epi_alpha = _p(epi_gamma), _p(epi_beta), _p(epi_alpha)
     g.partials, g.partial_ld = _p(partials), int(partial_ld)
-    lib = _lib.load()
-    _lib.check(lib.dosx_gemm(C.byref(g), _stream()), "dosx_gemm")
+    _call("dosx_gemm", C.byref(g), _stream())
 
 
 def gemm_partial_rows(M: int, N: int, epi: int) -> int:
@@ -164,8 +227,7 @@ def wgrad(M: int, N: int, dy: Seg, segs: Sequence[Seg], slab: torch.Tensor, slab
     g.pro = pro
     g.pro_gamma, g.pro_beta, g.pro_alpha, g.pro_stats = _p(pro_gamma), _p(pro_beta), _p(pro_alpha), _p(pro_stats)
     g.slab, g.slab_bias, g.nsplit = slab.data_ptr(), _p(slab_bias), int(nsplit)
-    lib = _lib.load()
-    _lib.check(lib.dosx_wgrad(C.byref(g), _stream()), "dosx_wgrad")
+    _call("dosx_wgrad", C.byref(g), _stream())
 
 
 class GradSink:
@@ -202,6 +264,9 @@ class GradSink:
         ev = torch.cuda.Event()
         ev.record(self.main)
         self.side.wait_event(ev)
+        if RECORDER.active:
+            RECORDER.prog.append((ev.record, (self.main,)))
+            RECORDER.prog.append((self.side.wait_event, (ev,)))
         with torch.cuda.stream(self.side):
             fn()
         self._forked = True
@@ -210,10 +275,12 @@ class GradSink:
         """Main stream waits for all side work issued so far."""
         if self.side is not None and self._forked:
             self.main.wait_stream(self.side)
+            if RECORDER.active:
+                RECORDER.prog.append((self.main.wait_stream, (self.side,)))
             self._forked = False
 
     def scratch(self, *shape) -> torch.Tensor:
-        t = torch.empty(shape, device=self.device, dtype=torch.float32)
+        t = alloc(self.device, *shape)
         self._keep.append(t)
         return t
 
@@ -238,12 +305,11 @@ class GradSink:
             if k >= len(waves):
                 waves.append([])
             waves[k].append(j if k == 0 else j[:5] + (1,))
-        lib = _lib.load()
         for wv in waves:
             arr = (ReduceJob * len(wv))()
             for i, j in enumerate(wv):
                 arr[i].src, arr[i].dst, arr[i].nsplit, arr[i].stride, arr[i].count, arr[i].accumulate = j
-            _lib.check(lib.dosx_reduce_partials(arr, len(wv), _stream()), "dosx_reduce_partials")
+            _call("dosx_reduce_partials", arr, len(wv), _stream())
         self.jobs = []
 
     def release(self):
@@ -253,152 +319,121 @@ class GradSink:
 def edge_feat_sh1(edge_vec: torch.Tensor, r_max: float = 4.0) -> torch.Tensor:
     _chk_f32(edge_vec)
     e = edge_vec.shape[0]
-    out = torch.empty(e, 4, device=edge_vec.device, dtype=torch.float32)
-    lib = _lib.load()
-    _lib.check(lib.dosx_edge_feat_sh1(edge_vec.data_ptr(), out.data_ptr(), e, float(r_max), _stream()), "dosx_edge_feat_sh1")
+    out = alloc(edge_vec.device, e, 4)
+    _call("dosx_edge_feat_sh1", edge_vec.data_ptr(), out.data_ptr(), e, float(r_max), _stream())
     return out
 
 
 def segment_reduce(msg, rowptr, scale, agg, e_in, e_out, N, E, H):
-    lib = _lib.load()
-    _lib.check(lib.dosx_segment_reduce(_p(msg), _p(rowptr), _p(scale), _p(agg), _p(e_in), _p(e_out), N, E, H, _stream()),
-               "dosx_segment_reduce")
+    _call("dosx_segment_reduce", _p(msg), _p(rowptr), _p(scale), _p(agg), _p(e_in), _p(e_out), N, E, H, _stream())
 
 
 def edge_grad_combine(de_new, dagg, ld_dagg, dst, scale, dmsg, E, H):
-    lib = _lib.load()
-    _lib.check(lib.dosx_edge_grad_combine(_p(de_new), dagg, ld_dagg, _p(dst), _p(scale), _p(dmsg), E, H, _stream()),
-               "dosx_edge_grad_combine")
+    _call("dosx_edge_grad_combine", _p(de_new), dagg, ld_dagg, _p(dst), _p(scale), _p(dmsg), E, H, _stream())
 
 
 def gather_bwd(dcat, dnode_ptr, ld_dnode, dx_res, rowptr_dst, rowptr_src, perm_src, de_new, dx, de_out, N, E, H):
-    lib = _lib.load()
-    _lib.check(lib.dosx_gather_bwd(_p(dcat), dnode_ptr, ld_dnode, _p(dx_res), _p(rowptr_dst), _p(rowptr_src),
-                                   _p(perm_src), _p(de_new), _p(dx), _p(de_out), N, E, H, _stream()), "dosx_gather_bwd")
+    _call("dosx_gather_bwd", _p(dcat), dnode_ptr, ld_dnode, _p(dx_res), _p(rowptr_dst), _p(rowptr_src),
+                                   _p(perm_src), _p(de_new), _p(dx), _p(de_out), N, E, H, _stream())
 
 
 def graph_pool(x, graph_ptr, out_ptr, ld_out, B, H):
-    lib = _lib.load()
-    _lib.check(lib.dosx_graph_pool(_p(x), _p(graph_ptr), out_ptr, ld_out, B, H, _stream()), "dosx_graph_pool")
+    _call("dosx_graph_pool", _p(x), _p(graph_ptr), out_ptr, ld_out, B, H, _stream())
 
 
 def graph_pool_bwd(dpool_ptr, ld, node_graph, dx, N, H, accumulate):
-    lib = _lib.load()
-    _lib.check(lib.dosx_graph_pool_bwd(dpool_ptr, ld, _p(node_graph), _p(dx), N, H, int(accumulate), _stream()),
-               "dosx_graph_pool_bwd")
+    _call("dosx_graph_pool_bwd", dpool_ptr, ld, _p(node_graph), _p(dx), N, H, int(accumulate), _stream())
 
 
 def dense_normalize(x, dense_row, kvhat, rstd_nodes, N, H, dense_rows):
-    lib = _lib.load()
-    _lib.check(lib.dosx_dense_normalize(_p(x), _p(dense_row), _p(kvhat), _p(rstd_nodes), N, H, dense_rows, _stream()),
-               "dosx_dense_normalize")
+    _call("dosx_dense_normalize", _p(x), _p(dense_row), _p(kvhat), _p(rstd_nodes), N, H, dense_rows, _stream())
 
 
 def dense_normalize_bwd(dkvhat, kvhat, rstd_nodes, dense_row, dx, N, H, accumulate):
-    lib = _lib.load()
-    _lib.check(lib.dosx_dense_normalize_bwd(_p(dkvhat), _p(kvhat), _p(rstd_nodes), _p(dense_row), _p(dx), N, H,
-                                            int(accumulate), _stream()), "dosx_dense_normalize_bwd")
+    _call("dosx_dense_normalize_bwd", _p(dkvhat), _p(kvhat), _p(rstd_nodes), _p(dense_row), _p(dx), N, H,
+                                            int(accumulate), _stream())
 
 
 def rownorm(x, xhat, rstd, M, H):
-    lib = _lib.load()
-    _lib.check(lib.dosx_rownorm(_p(x), _p(xhat), _p(rstd), M, H, _stream()), "dosx_rownorm")
+    _call("dosx_rownorm", _p(x), _p(xhat), _p(rstd), M, H, _stream())
 
 
 def rownorm_bwd(dxhat, xhat, rstd, dx, M, H, accumulate):
-    lib = _lib.load()
-    _lib.check(lib.dosx_rownorm_bwd(_p(dxhat), _p(xhat), _p(rstd), _p(dx), M, H, int(accumulate), _stream()),
-               "dosx_rownorm_bwd")
+    _call("dosx_rownorm_bwd", _p(dxhat), _p(xhat), _p(rstd), _p(dx), M, H, int(accumulate), _stream())
 
 
 def layernorm(x, gamma, beta, y, xhat, rstd, M, H):
-    lib = _lib.load()
-    _lib.check(lib.dosx_layernorm(_p(x), _p(gamma), _p(beta), _p(y), _p(xhat), _p(rstd), M, H, _stream()), "dosx_layernorm")
+    _call("dosx_layernorm", _p(x), _p(gamma), _p(beta), _p(y), _p(xhat), _p(rstd), M, H, _stream())
 
 
 def layernorm_bwd(dy, xhat, rstd, gamma, dx, partials, M, H):
-    lib = _lib.load()
-    _lib.check(lib.dosx_layernorm_bwd(_p(dy), _p(xhat), _p(rstd), _p(gamma), _p(dx), _p(partials), M, H, _stream()),
-               "dosx_layernorm_bwd")
+    _call("dosx_layernorm_bwd", _p(dy), _p(xhat), _p(rstd), _p(gamma), _p(dx), _p(partials), M, H, _stream())
 
 
 def attention_fwd(a: Attn):
-    lib = _lib.load()
-    _lib.check(lib.dosx_attention_fwd(C.byref(a), _stream()), "dosx_attention_fwd")
+    _call("dosx_attention_fwd", C.byref(a), _stream())
 
 
 def attention_bwd(a: Attn):
-    lib = _lib.load()
-    _lib.check(lib.dosx_attention_bwd(C.byref(a), _stream()), "dosx_attention_bwd")
+    _call("dosx_attention_bwd", C.byref(a), _stream())
 
 
 def ln_rowdot(x, gamma, beta, w, b, xhat, rstd, dos, S, Bq, H):
-    lib = _lib.load()
-    _lib.check(lib.dosx_ln_rowdot(_p(x), _p(gamma), _p(beta), _p(w), _p(b), _p(xhat), _p(rstd), _p(dos), S, Bq, H, _stream()),
-               "dosx_ln_rowdot")
+    _call("dosx_ln_rowdot", _p(x), _p(gamma), _p(beta), _p(w), _p(b), _p(xhat), _p(rstd), _p(dos), S, Bq, H, _stream())
 
 
 def ln_rowdot_bwd(ddos, xhat, rstd, gamma, beta, w, dx, partials, S, Bq, H):
-    lib = _lib.load()
-    _lib.check(lib.dosx_ln_rowdot_bwd(_p(ddos), _p(xhat), _p(rstd), _p(gamma), _p(beta), _p(w), _p(dx), _p(partials), S, Bq,
-                                      H, _stream()), "dosx_ln_rowdot_bwd")
+    _call("dosx_ln_rowdot_bwd", _p(ddos), _p(xhat), _p(rstd), _p(gamma), _p(beta), _p(w), _p(dx), _p(partials), S, Bq,
+                                      H, _stream())
 
 
 def rowdot(x, w, b, dos, S, Bq, H):
-    lib = _lib.load()
-    _lib.check(lib.dosx_rowdot(_p(x), _p(w), _p(b), _p(dos), S, Bq, H, _stream()), "dosx_rowdot")
+    _call("dosx_rowdot", _p(x), _p(w), _p(b), _p(dos), S, Bq, H, _stream())
 
 
 def rowdot_bwd(ddos, x, w, dx, partials, S, Bq, H):
-    lib = _lib.load()
-    _lib.check(lib.dosx_rowdot_bwd(_p(ddos), _p(x), _p(w), _p(dx), _p(partials), S, Bq, H, _stream()), "dosx_rowdot_bwd")
+    _call("dosx_rowdot_bwd", _p(ddos), _p(x), _p(w), _p(dx), _p(partials), S, Bq, H, _stream())
 
 
 def sse2(pg, ps, y, sse, count):
-    lib = _lib.load()
-    _lib.check(lib.dosx_sse2(_p(pg), _p(ps), _p(y), _p(sse), count, _stream()), "dosx_sse2")
+    _call("dosx_sse2", _p(pg), _p(ps), _p(y), _p(sse), count, _stream())
 
 
 def loss_phonon_bwd(pg, ps, y, sse, beta, count_global, dpg, dps, loss, count):
-    lib = _lib.load()
-    _lib.check(lib.dosx_loss_phonon_bwd(_p(pg), _p(ps), _p(y), _p(sse), float(beta), float(count_global), _p(dpg), _p(dps),
-                                        _p(loss), count, _stream()), "dosx_loss_phonon_bwd")
+    _call("dosx_loss_phonon_bwd", _p(pg), _p(ps), _p(y), _p(sse), float(beta), float(count_global), _p(dpg), _p(dps),
+                                        _p(loss), count, _stream())
 
 
 def loss_edos(pg, ps, y_ft, beta, B, S, B_global, dpg, dps, loss_partial):
-    lib = _lib.load()
-    _lib.check(lib.dosx_loss_edos(_p(pg), _p(ps), _p(y_ft), float(beta), B, S, B_global, _p(dpg), _p(dps), _p(loss_partial),
-                                  _stream()), "dosx_loss_edos")
+    _call("dosx_loss_edos", _p(pg), _p(ps), _p(y_ft), float(beta), B, S, B_global, _p(dpg), _p(dps), _p(loss_partial),
+                                  _stream())
+
+
+def sum_to(src, n, dst):
+    _call("dosx_sum", _p(src), int(n), _p(dst), _stream())
 
 
 def adamw(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
-    lib = _lib.load()
-    _lib.check(lib.dosx_adamw(_p(p), _p(g), _p(m), _p(v), int(n), float(lr), float(beta1), float(beta2), float(eps),
-                              float(weight_decay), int(step), float(grad_scale), _stream()), "dosx_adamw")
+    _call("dosx_adamw", _p(p), _p(g), _p(m), _p(v), int(n), float(lr), float(beta1), float(beta2), float(eps),
+                              float(weight_decay), int(step), float(grad_scale), _stream())
 
 
 def fill(t: torch.Tensor, value: float):
-    lib = _lib.load()
-    _lib.check(lib.dosx_fill(t.data_ptr(), float(value), t.numel(), _stream()), "dosx_fill")
+    _call("dosx_fill", t.data_ptr(), float(value), t.numel(), _stream())
 
 
 def embed_rows(table, idx, out, rows, width):
-    lib = _lib.load()
-    _lib.check(lib.dosx_embed_rows(_p(table), _p(idx), _p(out), rows, width, _stream()), "dosx_embed_rows")
+    _call("dosx_embed_rows", _p(table), _p(idx), _p(out), rows, width, _stream())
 
 
 def embed_rows_bwd(dout_ptr, ld, idx, dtable, rows, table_rows, width):
-    lib = _lib.load()
-    _lib.check(lib.dosx_embed_rows_bwd(dout_ptr, ld, _p(idx), _p(dtable), rows, table_rows, width, _stream()),
-               "dosx_embed_rows_bwd")
+    _call("dosx_embed_rows_bwd", dout_ptr, ld, _p(idx), _p(dtable), rows, table_rows, width, _stream())
 
 
 def reduce_rows(src_ptr, ld_src, dst_ptr, ld_dst, n_out, n_red, stride_out, stride_red, width, accumulate=False):
-    lib = _lib.load()
-    _lib.check(lib.dosx_reduce_rows(src_ptr, ld_src, dst_ptr, ld_dst, n_out, n_red, stride_out, stride_red, width,
-                                    int(accumulate), _stream()), "dosx_reduce_rows")
+    _call("dosx_reduce_rows", src_ptr, ld_src, dst_ptr, ld_dst, n_out, n_red, stride_out, stride_red, width,
+                                    int(accumulate), _stream())
 
 
 def act_bwd(dy, y, slope, out):
-    lib = _lib.load()
-    _lib.check(lib.dosx_act_bwd(_p(dy), _p(y), float(slope), _p(out), dy.numel(), _stream()), "dosx_act_bwd")
+    _call("dosx_act_bwd", _p(dy), _p(y), float(slope), _p(out), dy.numel(), _stream())

@@ -4,7 +4,12 @@ forward program -> loss kernel -> backward program -> (RCCL all-reduce) -> flat 
 No autograd graph, no per-parameter optimizer loop, no host synchronisation: the loss stays on the
 device (the reference prints it every step, `main_eDOS.py:129`; read ``.item()`` only when needed).
 
-``Trainer(graph=True)`` additionally replays the step from captured HIP graphs: batches are padded
+``Trainer(replay=True)`` re-issues a RECORDED launch sequence (``ops.Program``): the first step on a shape
+bucket runs normally while every libdosx call is recorded with its marshalled arguments on static
+buffers; later steps copy the batch into the bucket's input buffers and replay the list — no Python
+marshalling, no allocator, two real HIP streams (weight-gradient kernels overlap the dgrad chain).
+
+``Trainer(graph=True)`` instead replays the step from captured HIP graphs: batches are padded
 with ghost nodes / edges to a small set of (N, E) buckets (``batch.pad_batch`` — exact, not
 approximate), every launch of the forward / loss / backward programs for a bucket is captured once,
 and a step is then "copy the batch into the bucket's static buffers, replay, AdamW".  The ~160
@@ -31,11 +36,13 @@ class _Slot:
         m = g.meta
         self.fields = ["x", "system"] + (["edge_vec", "phdos"] if kind == "phonon" else ["edge_attr", "glob", "y_ft"])
         f = {k: g[k].clone() for k in self.fields}
+        f["system"] = f["system"].to(torch.int32)                   # what the kernels index with
         f["edge_index"], f["batch"] = g.edge_index, g.batch         # never read by the kernels
         meta = GraphMeta(num_nodes=m.num_nodes, num_edges=m.num_edges, num_graphs=m.num_graphs, n_max=m.n_max,
                          edge_perm=None, **{k: getattr(m, k).clone() for k in _META_TENSORS})
         self.g = CrystalBatch(f, g.num_graphs, meta)
         self.graph_a = self.graph_b = None
+        self.prog_a = self.prog_b = None
         self.keep = None
 
     def load(self, g: CrystalBatch) -> None:
@@ -55,12 +62,13 @@ class Trainer:
     """
 
     def __init__(self, model: DOSTransformerBase, lr: float = 1e-4, beta: float = 1.0, weight_decay: float = 1e-2,
-                 betas=(0.9, 0.999), eps: float = 1e-8, dist=None, graph: bool = False):
+                 betas=(0.9, 0.999), eps: float = 1e-8, dist=None, graph: bool = False, replay: bool = False):
         if not isinstance(model, DOSTransformerBase):
             raise TypeError("Trainer drives DOSTransformer / DOSTransformer_phonon modules")
         self.model, self.lr, self.beta, self.wd, self.betas, self.eps = model, lr, beta, weight_decay, betas, eps
         self.dist = dist
         self.graph = graph
+        self.replay = replay
         self.step_count = 0
         self._m = self._v = None
         self._fp = None
@@ -85,7 +93,7 @@ class Trainer:
         st = {"ctx": ctx, "dos": dos, "out": (dg, xL, ds), "B": B, "S": S}
         if self.kind == "phonon":
             st["y"] = Fn._f32(g.phdos).reshape(B, S)
-            st["sse"] = torch.empty(2, device=dev, dtype=torch.float32)
+            st["sse"] = Fn._empty(dev, 2)
             ops.sse2(dos[:B], dos[B:], st["y"], st["sse"], B * S)
         else:
             st["y"] = Fn._f32(g.y_ft).reshape(-1)
@@ -95,16 +103,17 @@ class Trainer:
         """loss gradient + backward program.  n_global: crystals in the un-sharded batch."""
         dev, cfg = fp.flat.device, self.model._cfg
         B, S, dos = st["B"], st["S"], st["dos"]
-        ddos = torch.empty_like(dos)
+        ddos = Fn._empty(dev, *dos.shape)
         if self.kind == "phonon":
-            loss = torch.empty(1, device=dev, dtype=torch.float32)
+            loss = Fn._empty(dev, 1)
             ops.loss_phonon_bwd(dos[:B], dos[B:], st["y"], st["sse"], self.beta, float(n_global * S), ddos[:B],
                                 ddos[B:], loss, B * S)
             loss = loss[0]
         else:
-            lp = torch.empty(B, device=dev, dtype=torch.float32)
+            lp = Fn._empty(dev, B + 1)
             ops.loss_edos(dos[:B], dos[B:], st["y"], self.beta, B, S, n_global, ddos[:B], ddos[B:], lp)
-            loss = lp.sum()
+            ops.sum_to(lp, B, lp[B:])
+            loss = lp[B]
         sink = ops.GradSink(dev)
         Fn.dostransformer_bwd(fp.P, fp.G, cfg, m, st["ctx"], ddos, None, sink)
         sink.release()
@@ -159,6 +168,35 @@ class Trainer:
         slot.loss, slot.out, slot.sse = loss, st["out"], st.get("sse")
         ops.KERNEL_TIMER.enabled = timer_on
 
+    def _record(self, slot: _Slot, fp, ng: int) -> None:
+        """Run the step once on the slot's static buffers while recording every launch."""
+        timer_on = ops.KERNEL_TIMER.enabled
+        ops.KERNEL_TIMER.enabled = False
+        side_before = ops.GradSink.use_side_stream
+        ops.GradSink.use_side_stream = True          # replay is cheap enough on the host to feed two streams
+        g, m = slot.g, slot.g.meta
+        split = self.dist is not None and self.kind == "phonon"
+        try:
+            with torch.no_grad():
+                ops.RECORDER.begin()
+                st = self._part_a(fp, g, m)
+                if split:
+                    slot.prog_a = ops.RECORDER.end()
+                    self.dist.all_reduce_sse(st["sse"])
+                    ops.RECORDER.begin()
+                loss = self._part_b(fp, m, st, ng)
+                if split:
+                    slot.prog_b = ops.RECORDER.end()
+                else:
+                    slot.prog_a = ops.RECORDER.end()
+        finally:
+            if ops.RECORDER.active:
+                ops.RECORDER.end()
+            ops.GradSink.use_side_stream = side_before
+            ops.KERNEL_TIMER.enabled = timer_on
+        slot.keep = (st, loss)
+        slot.loss, slot.out, slot.sse = loss, st["out"], st.get("sse")
+
     def _graph_step(self, g: CrystalBatch, n_global: Optional[int]) -> torch.Tensor:
         model = self.model
         dev = model._module_device()
@@ -175,13 +213,23 @@ class Trainer:
         slot = self._slots.get(key)
         if slot is None:
             slot = _Slot(g, self.kind)
-            self._capture(slot, fp, ng)
             self._slots[key] = slot
+            if self.replay:
+                self._record(slot, fp, ng)       # this IS the step for this batch (run + record)
+                self.last_outputs = slot.out
+                return slot.loss
+            self._capture(slot, fp, ng)
         slot.load(g)
-        slot.graph_a.replay()
-        if slot.graph_b is not None:
-            self.dist.all_reduce_sse(slot.sse)
-            slot.graph_b.replay()
+        if self.replay:
+            slot.prog_a.run()
+            if slot.prog_b is not None:
+                self.dist.all_reduce_sse(slot.sse)
+                slot.prog_b.run()
+        else:
+            slot.graph_a.replay()
+            if slot.graph_b is not None:
+                self.dist.all_reduce_sse(slot.sse)
+                slot.graph_b.replay()
         self.last_outputs = slot.out
         return slot.loss
 
@@ -196,6 +244,6 @@ class Trainer:
                   self.step_count, 1.0)
 
     def step(self, g, n_global: Optional[int] = None) -> torch.Tensor:
-        loss = self._graph_step(g, n_global) if self.graph else self.forward_backward(g, n_global)
+        loss = self._graph_step(g, n_global) if (self.graph or self.replay) else self.forward_backward(g, n_global)
         self.optimizer_step()
         return loss

@@ -201,7 +201,9 @@ int dosx_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, co
  * (layers/transformer.py:131-138, layers/multihead_attention.py:68-74: no projections, no
  *  mask, no heads).  Query row (s, bq) is at x + (s*q_stride_s + bq*q_stride_b)*H; output
  *  row (s,bq) at s*Bq + bq; key row (j, bk) at j*Bk + bk with bk = bq % Bk. */
-enum { DOSX_ATTN_RAW_Q = 1, DOSX_ATTN_NO_RESIDUAL = 2 };
+/* BWD_SKIP_*: dosx_attention_bwd launches two kernels (dq: needs dout,P -> dx,dS ; dkv: needs dS -> dkvhat);
+ * a caller may issue them separately (e.g. dkv on a second stream: only the final key-gradient consumers need it). */
+enum { DOSX_ATTN_RAW_Q = 1, DOSX_ATTN_NO_RESIDUAL = 2, DOSX_ATTN_BWD_SKIP_DQ = 4, DOSX_ATTN_BWD_SKIP_DKV = 8 };
 typedef struct DosxAttn {
   int32_t Sq, Bq, Nk, Bk, H;
   int32_t q_stride_s, q_stride_b;
@@ -256,6 +258,10 @@ int dosx_loss_phonon_bwd(const float* pg, const float* ps, const float* y, const
                          dosx_stream_t stream);
 int dosx_loss_edos(const float* pg, const float* ps, const float* y_ft, float beta, int B, int S, int B_global,
                    float* dpg, float* dps, float* loss_partial, dosx_stream_t stream);
+
+/* dst[0] = sum_i src[i]: the mean over crystals of the eDOS loss (main_eDOS.py:117,121) from the
+ * per-crystal shares written by dosx_loss_edos. */
+int dosx_sum(const float* src, int n, float* dst, dosx_stream_t stream);
 
 /* torch.optim.AdamW step on a flat buffer (main_eDOS.py:93,127): decoupled weight decay.
  * `step` is the 1-based step count. */

@@ -306,9 +306,11 @@ def test_ghost_padding_is_exact(kind):
     assert float((g0 - g1).abs().max()) <= 1e-6 * float(g0.abs().max())      # slab split points move, math does not
 
 
+@pytest.mark.parametrize("mode", ["graph", "replay"])
 @pytest.mark.parametrize("kind", ["phonon", "edos"])
-def test_graph_replay_matches_eager(kind):
-    """Trainer(graph=True): captured HIP graphs per shape bucket reproduce the eager trajectory."""
+def test_graph_replay_matches_eager(kind, mode):
+    """Trainer(graph=True) / Trainer(replay=True): captured HIP graphs / recorded launch lists per shape
+    bucket reproduce the eager trajectory."""
     import copy
     from dostransformer_amd import synth
     from dostransformer_amd.train import Trainer
@@ -326,7 +328,7 @@ def test_graph_replay_matches_eager(kind):
     m_g = mk()
     m_g.load_state_dict(copy.deepcopy(m_e.state_dict()))
     m_g = m_g.to(DEV)
-    te, tg = Trainer(m_e, lr=1e-3), Trainer(m_g, lr=1e-3, graph=True)
+    te, tg = Trainer(m_e, lr=1e-3), Trainer(m_g, lr=1e-3, graph=(mode == "graph"), replay=(mode == "replay"))
     for i in range(7):                      # revisits buckets -> replays, not only captures
         le = te.step(batches[i % 3])
         lg = tg.step(batches[i % 3])
