@@ -12,6 +12,8 @@
 
 #include "common.h"
 
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+
 // Diagnostic build only (-DDOSX_STAMPS, never shipped): wave 0 of a few workgroups records
 // s_memtime at phase boundaries (see tools/stamp_gemm.py).
 #ifdef DOSX_STAMPS
@@ -21,8 +23,19 @@ extern "C" { __device__ unsigned long long dosx_stamp_buf[64 * 64]; }
     if ((threadIdx.x == 0) && (blockIdx.y == 0) && (blockIdx.x % 37 == 0) && (blockIdx.x / 37) < 64 && (slot) < 64) \
       dosx_stamp_buf[(blockIdx.x / 37) * 64 + (slot)] = __builtin_amdgcn_s_memtime();            \
   } while (0)
+// staging wave 0 (thread 256) of workgroup 0 -> row 32 of the stamp buffer
+#define STAMP_S(slot)                                                                            \
+  do {                                                                                           \
+    if ((threadIdx.x == 256) && (blockIdx.y == 0) && (blockIdx.x == 0) && (slot) < 64)           \
+      dosx_stamp_buf[32 * 64 + (slot)] = __builtin_amdgcn_s_memtime();                           \
+  } while (0)
 #else
 #define STAMP(slot) do { } while (0)
+#define STAMP_S(slot) do { } while (0)
+#endif
+
+#ifndef DOSX_PRIO_VARIANT
+#define DOSX_PRIO_VARIANT 1
 #endif
 
 namespace {
@@ -30,12 +43,12 @@ namespace {
 constexpr int BM = 32;
 constexpr int BK = 32;
 constexpr int LDA = BK + 4;  // 36 floats: 16-B aligned rows, conflict-free ds_read_b128
+constexpr int GEMM_KMAX = 1024;   // largest K of a GEMM with a LayerNorm prologue (its gamma/beta live in LDS)
 
 struct GemmLaunch {
   DosxGemm g;
   int vecA;
   int vecW;
-  int dma;   // W tile by LDS-DMA (needs K % 32 == 0: no k tail to zero-fill)
   int rt;    // 32-row blocks per workgroup (1 or 2)
 };
 
@@ -87,13 +100,13 @@ __device__ __forceinline__ float a_xform1(const AState& st, float v, int k, cons
 // right before the LDS store — so the loads stay in flight across the MFMA block of the current
 // chunk (a select placed right after a load makes hipcc wait for it before the MFMAs).
 struct ARaw {
-  float4 v, g, b;
+  float4 v;
 };
 
 template <int PRO, int VEC>
 __device__ __forceinline__ ARaw a_issue(const AState& st, int k, int K, const float* gamma, const float* beta) {
   ARaw r;
-  r.v = f4zero(); r.g = f4zero(); r.b = f4zero();
+  r.v = f4zero();
   if (VEC) {
     const int kc = (k < K) ? k : 0;
     const float* p0 = st.rp[0] + kc;
@@ -101,10 +114,6 @@ __device__ __forceinline__ ARaw a_issue(const AState& st, int k, int K, const fl
     const float* p2 = st.rp[2] + (kc - st.w01);
     const float* p = (kc < st.w0) ? p0 : ((kc < st.w01) ? p1 : p2);
     r.v = ld4(p);
-    if (PRO == DOSX_PRO_LN_PRELU || PRO == DOSX_PRO_ROWLN) {
-      r.g = ld4(gamma + kc);
-      r.b = ld4(beta + kc);
-    }
   } else {
     if (!st.ok || k >= K) return r;
     float t[4] = {0.f, 0.f, 0.f, 0.f};
@@ -124,156 +133,304 @@ __device__ __forceinline__ ARaw a_issue(const AState& st, int k, int K, const fl
   return r;
 }
 
-template <int PRO, int VEC>
-__device__ __forceinline__ float4 a_finish(const AState& st, const ARaw& r, int k, int K) {
+// g / b: the 4 gamma / beta values of the prologue LayerNorm at columns k..k+3 (ignored otherwise).
+// MASK = 0: no zero-fill (the caller knows k < K; rows beyond M are clamped duplicates whose results are
+// never stored).  Every VALU instruction of a staging wave has to squeeze in between the matrix wave's
+// back-to-back MFMAs on the same SIMD (measured: ~30 clk per VALU op), so the interior path has none.
+template <int PRO, int VEC, int MASK = 1>
+__device__ __forceinline__ float4 a_finish(const AState& st, const ARaw& r, int k, int K, float4 g, float4 b) {
   float4 v = r.v;
   if (!VEC) return v;
   if (PRO == DOSX_PRO_PRELU) {
     v.x = prelu_f(v.x, st.alpha); v.y = prelu_f(v.y, st.alpha);
     v.z = prelu_f(v.z, st.alpha); v.w = prelu_f(v.w, st.alpha);
   } else if (PRO == DOSX_PRO_LN_PRELU) {
-    v.x = prelu_f(v.x * r.g.x + r.b.x, st.alpha); v.y = prelu_f(v.y * r.g.y + r.b.y, st.alpha);
-    v.z = prelu_f(v.z * r.g.z + r.b.z, st.alpha); v.w = prelu_f(v.w * r.g.w + r.b.w, st.alpha);
+    v.x = prelu_f(v.x * g.x + b.x, st.alpha); v.y = prelu_f(v.y * g.y + b.y, st.alpha);
+    v.z = prelu_f(v.z * g.z + b.z, st.alpha); v.w = prelu_f(v.w * g.w + b.w, st.alpha);
   } else if (PRO == DOSX_PRO_ROWLN) {
-    v.x = (v.x - st.mean) * st.rstd * r.g.x + r.b.x; v.y = (v.y - st.mean) * st.rstd * r.g.y + r.b.y;
-    v.z = (v.z - st.mean) * st.rstd * r.g.z + r.b.z; v.w = (v.w - st.mean) * st.rstd * r.g.w + r.b.w;
+    v.x = (v.x - st.mean) * st.rstd * g.x + b.x; v.y = (v.y - st.mean) * st.rstd * g.y + b.y;
+    v.z = (v.z - st.mean) * st.rstd * g.z + b.z; v.w = (v.w - st.mean) * st.rstd * g.w + b.w;
   }
-  if (!(st.ok && k < K)) v = f4zero();
+  if (MASK && !(st.ok && k < K)) v = f4zero();
   return v;
 }
 
 // ---------------------------------------------------------------------------------------------
 // C = prologue(A) . B  with fused row-wise epilogues.   NTW = 32-wide MFMA tiles per wave,
 // BN = 128*NTW columns per workgroup.  WL: 0 = W[N,K] (k-contiguous), 1 = W[K,N] (n-contiguous).
+// RT = 32-row blocks per workgroup (BM = 32*RT): RT = 2 halves the W bytes streamed per flop.
+//
+// WAVE SPECIALISATION.  A workgroup is 8 waves = 2 per SIMD: waves 0-3 ("matrix waves") only read MFMA
+// fragments from LDS and issue v_mfma; waves 4-7 ("staging waves") only move the next k-chunk
+// global -> registers -> (prologue transform) -> LDS.  Two LDS stage buffers, ONE barrier per chunk.
+// Measured with s_memtime stamps on the previous 4-wave kernel (every wave staged, then multiplied):
+// at this workload's sizes (<= 1-2 workgroups per CU) 30-60 % of every k-chunk was the exposed
+// global-load wait + ds_write phase, because one wave per SIMD cannot overlap its own staging with its
+// own MFMAs.  With a staging wave next to each matrix wave the matrix pipe only stalls on the barrier.
+// The epilogue uses all 8 waves (4 rows each per 32-row block).
 // ---------------------------------------------------------------------------------------------
-// DMA = 1: the W tile (the bulk of the staged bytes) goes global -> LDS directly
-// (__builtin_amdgcn_global_load_lds, 16 B per lane: no VGPR staging, no ds_write, no masks), double
-// buffered so the DMA of chunk k+1 flies under the MFMAs of chunk k.  The destination of one
-// wave-instruction is lane-linear (1 KiB), so the W[N,K] tile is stored with UNPADDED 128-B rows and
-// the 16-B chunk index XOR-swizzled with (row>>1)&7 on the SOURCE address (and on the fragment read)
-// to keep ds_read_b128 conflict-free; the W[K,N] tile is read with ds_read_b32 along n and needs none.
-// RT = 32-row blocks per workgroup (BM = 32*RT).  The per-CU global->LDS rate (~10-25 B/clk measured,
-// W comes from L2) - not the MFMA pipe - bounds a 32-row tile: every k-chunk re-streams the whole
-// [BN x 32] W slice for only 32 rows (18 B per MFMA-clk at BN=256).  RT = 2 halves the bytes per flop.
-template <int RT, int NTW, int WL, int PRO, int VEC, int EPI, int DMA>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmLaunch L) {
+template <int RT, int NTW, int WL, int PRO, int VEC, int EPI>
+__global__ __launch_bounds__(512) void gemm_kernel(const GemmLaunch L) {
   const DosxGemm& g = L.g;
   constexpr int BMR = BM * RT;
   constexpr int BN = 128 * NTW;
-  constexpr int LDWT = DMA ? ((WL == 0) ? BK : BN) : ((WL == 0) ? (BK + 4) : (BN + 4));
+  constexpr int LDWT = (WL == 0) ? (BK + 4) : (BN + 4);
   constexpr int WROWS = (WL == 0) ? BN : BK;
   constexpr int LDC = BN + 4;
   constexpr int STAGE = BMR * LDA + WROWS * LDWT;     // floats of one staging buffer (A tile + W tile)
   constexpr int CTILE = BM * LDC;
-  constexpr int MAINF = DMA ? 2 * STAGE : (STAGE > CTILE ? STAGE : CTILE);
-  static_assert(!DMA || 2 * STAGE >= CTILE, "C tile must fit in the staging buffers");
   constexpr int CG = (BN + 255) / 256;   // float4 column groups per lane in the row-wise epilogue
-  constexpr int NW4 = BN / 32;           // float4 W loads per thread per k-chunk
+  constexpr int NW4 = BN / 32;           // float4 W loads per staging thread per k-chunk
+  constexpr int ER = 4;                  // epilogue rows per wave per 32-row block (8 waves)
+  constexpr bool PROLN = VEC && (PRO == DOSX_PRO_LN_PRELU || PRO == DOSX_PRO_ROWLN);
 
   extern __shared__ __align__(16) float smem[];
-  float* As = smem;
-  float* Ws = smem + BMR * LDA;
   float* Cs = smem;
-  float* Ps = smem + CTILE;              // [4][2][BN] + 4 (behind the C tile; staging memory is dead by then)
+  float* Ps = smem + CTILE;              // [8][2][BN] + 8 (behind the C tile; staging memory is dead by then)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int m0 = blockIdx.x * BMR, n0 = blockIdx.y * BN;
   const int M = g.M, N = g.N, K = g.K;
-
-  STAMP(0);
-  // ---- staging setup ----
-  const int arow = tid >> 3, akq = (tid & 7) * 4;
-  AState ast[RT];
-#pragma unroll
-  for (int r = 0; r < RT; ++r)
-    a_state_init(ast[r], g.a, g.nseg, PRO, g.pro_stats, g.pro_alpha, min(m0 + arow + 32 * r, M - 1),
-                 (m0 + arow + 32 * r) < M);
-  auto issueA = [&](ARaw(&ar)[RT], int k0) {
-#pragma unroll
-    for (int r = 0; r < RT; ++r) ar[r] = a_issue<PRO, VEC>(ast[r], k0 + akq, K, g.pro_gamma, g.pro_beta);
-  };
-  auto storeA = [&](float* Ad, const ARaw(&ar)[RT], int k0) {
-#pragma unroll
-    for (int r = 0; r < RT; ++r)
-      st4(&Ad[(arow + 32 * r) * LDA + akq], a_finish<PRO, VEC>(ast[r], ar[r], k0 + akq, K));
-  };
-
-  auto loadW = [&](int k0, float4(&wr)[NW4]) {
-#pragma unroll
-    for (int i = 0; i < NW4; ++i) {
-      float4 v = f4zero();
-      if (WL == 0) {
-        const int n = n0 + (tid >> 3) + 32 * i, k = k0 + (tid & 7) * 4;
-        if (VEC) {   // unconditional load from a clamped (valid) address; masked in storeW
-          v = ld4(g.w + (size_t)min(n, N - 1) * g.ldw + (k < K ? k : 0));
-        } else if (n < N && k < K) {
-          const float* p = g.w + (size_t)n * g.ldw + k;
-          v.x = p[0];
-          if (k + 1 < K) v.y = p[1];
-          if (k + 2 < K) v.z = p[2];
-          if (k + 3 < K) v.w = p[3];
-        }
-      } else {
-        const int lin = tid + 256 * i;
-        const int r = lin / (BN / 4), c4 = (lin % (BN / 4)) * 4;
-        const int k = k0 + r, n = n0 + c4;
-        if (VEC) {
-          v = ld4(g.w + (size_t)min(k, K - 1) * g.ldw + (n < N ? n : 0));
-        } else if (k < K && n < N) {
-          const float* p = g.w + (size_t)k * g.ldw + n;
-          v.x = p[0];
-          if (n + 1 < N) v.y = p[1];
-          if (n + 2 < N) v.z = p[2];
-          if (n + 3 < N) v.w = p[3];
-        }
-      }
-      wr[i] = v;
-    }
-  };
-  auto storeW = [&](float* Wd, int k0, const float4(&wr)[NW4], int i0, int i1) {
-#pragma unroll
-    for (int i = 0; i < NW4; ++i) {
-      if (i < i0 || i >= i1) continue;
-      float4 v = wr[i];
-      if (WL == 0) {
-        if (VEC && !((n0 + (tid >> 3) + 32 * i) < N && (k0 + (tid & 7) * 4) < K)) v = f4zero();
-        st4(&Wd[((tid >> 3) + 32 * i) * LDWT + (tid & 7) * 4], v);
-      } else {
-        const int lin = tid + 256 * i;
-        if (VEC && !((k0 + lin / (BN / 4)) < K && (n0 + (lin % (BN / 4)) * 4) < N)) v = f4zero();
-        st4(&Wd[(lin / (BN / 4)) * LDWT + (lin % (BN / 4)) * 4], v);
-      }
-    }
-  };
-
-  f32x16 acc[RT][NTW];
-#pragma unroll
-  for (int rr = 0; rr < RT; ++rr)
-#pragma unroll
-    for (int t = 0; t < NTW; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[rr][t][r] = 0.f;
-
-  // wave-uniform: how many of this wave's 32-column tiles intersect [0, N)
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  int tiles_on = (N - n0 - wave_u * NTW * 32 + 31) / 32;
-  tiles_on = tiles_on < 0 ? 0 : (tiles_on > NTW ? NTW : tiles_on);
-
   const int nk = (K + BK - 1) / BK;
 
-  // One k-chunk of MFMAs from a staging buffer.  Pipelined variant: ALL fragment reads of the chunk are
-  // issued first, then `between()` (the LDS stores of the NEXT chunk into the other buffer), then the
-  // MFMA chain - so the stores drain through the LDS pipe underneath the matrix work.
-  // B-operand addressing (see the DMA note above)
-  auto wfrag4 = [&](const float* Wsb, int col, int kq /* k offset, multiple of 4 */) -> float4 {
-    if (DMA) return ld4(&Wsb[col * BK + ((((kq >> 2) ^ ((col >> 1) & 7))) << 2)]);
-    return ld4(&Wsb[col * LDWT + kq]);
-  };
+  f32x16 acc[RT][NTW];
 
-  // One k-chunk of MFMAs from a staging buffer.
-  auto compute = [&](const float* Asb, const float* Wsb) {
-    if (tiles_on == NTW) {
-      // fast path (every tile of this wave is inside N): straight-line, so hipcc hoists the ds_reads
+  STAMP(0);
+  if (wave_u >= 4) {
+    // =============================== staging waves ===============================================
+    const int st = tid - 256;                      // 0..255
+    const int arow = st >> 3, akq = (st & 7) * 4;
+    AState ast[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+      a_state_init(ast[r], g.a, g.nseg, PRO, g.pro_stats, g.pro_alpha, min(m0 + arow + 32 * r, M - 1),
+                   (m0 + arow + 32 * r) < M);
+    auto issueA = [&](ARaw(&ar)[RT], int k0) {
+#pragma unroll
+      for (int r = 0; r < RT; ++r) ar[r] = a_issue<PRO, VEC>(ast[r], k0 + akq, K, g.pro_gamma, g.pro_beta);
+    };
+    const float* Gs = smem + 2 * STAGE;            // [KMAX] gamma, [KMAX] beta of the prologue LayerNorm
+    const float* Bs = Gs + GEMM_KMAX;
+    auto storeA = [&](float* Ad, const ARaw(&ar)[RT], int k0) {
+      const int k = k0 + akq;
+      float4 gv = f4zero(), bv = f4zero();
+      if constexpr (PROLN) {                         // (K % 4 == 0 here: k < K means k+3 < K)
+        gv = ld4(Gs + (k < K ? k : 0));
+        bv = ld4(Bs + (k < K ? k : 0));
+      }
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+        st4(&Ad[(arow + 32 * r) * LDA + akq], a_finish<PRO, VEC, 1>(ast[r], ar[r], k, K, gv, bv));
+    };
+    auto loadW = [&](int k0, float4(&wr)[NW4]) {
+#pragma unroll
+      for (int i = 0; i < NW4; ++i) {
+        float4 v = f4zero();
+        if (WL == 0) {
+          const int n = n0 + (st >> 3) + 32 * i, k = k0 + (st & 7) * 4;
+          if (VEC) {   // unconditional load from a clamped (valid) address; masked in storeW
+            v = ld4(g.w + (size_t)min(n, N - 1) * g.ldw + (k < K ? k : 0));
+          } else if (n < N && k < K) {
+            const float* p = g.w + (size_t)n * g.ldw + k;
+            v.x = p[0];
+            if (k + 1 < K) v.y = p[1];
+            if (k + 2 < K) v.z = p[2];
+            if (k + 3 < K) v.w = p[3];
+          }
+        } else {
+          const int lin = st + 256 * i;
+          const int r = lin / (BN / 4), c4 = (lin % (BN / 4)) * 4;
+          const int k = k0 + r, n = n0 + c4;
+          if (VEC) {
+            v = ld4(g.w + (size_t)min(k, K - 1) * g.ldw + (n < N ? n : 0));
+          } else if (k < K && n < N) {
+            const float* p = g.w + (size_t)k * g.ldw + n;
+            v.x = p[0];
+            if (n + 1 < N) v.y = p[1];
+            if (n + 2 < N) v.z = p[2];
+            if (n + 3 < N) v.w = p[3];
+          }
+        }
+        wr[i] = v;
+      }
+    };
+    auto storeW = [&](float* Wd, int k0, const float4(&wr)[NW4]) {
+#pragma unroll
+      for (int i = 0; i < NW4; ++i) {
+        float4 v = wr[i];
+        if (WL == 0) {
+          if (VEC && !((n0 + (st >> 3) + 32 * i) < N && (k0 + (st & 7) * 4) < K)) v = f4zero();
+          st4(&Wd[((st >> 3) + 32 * i) * LDWT + (st & 7) * 4], v);
+        } else {
+          const int lin = st + 256 * i;
+          if (VEC && !((k0 + lin / (BN / 4)) < K && (n0 + (lin % (BN / 4)) * 4) < N)) v = f4zero();
+          st4(&Wd[(lin / (BN / 4)) * LDWT + (lin % (BN / 4)) * 4], v);
+        }
+      }
+    };
+
+    // Register pipeline, two chunks deep: chunk c travels in register set c & 1 and is stored to LDS
+    // buffer c & 1 one iteration before the matrix waves read it, so every global load has two chunk
+    // periods to land.  `issue(set_a, set_w, k0)` starts the loads of a chunk, `store(buf, set_a,
+    // set_w, k0)` finishes it (prologue transform, LDS store).
+    ARaw ar0[RT], ar1[RT];
+    float4 wr0[NW4], wr1[NW4];
+    auto pipeline = [&](auto&& issue, auto&& store) {
+      STAMP_S(0);
+      issue(ar0, wr0, 0);
+      if (nk > 1) issue(ar1, wr1, BK);
+      if constexpr (PROLN) {
+        float* Gw = smem + 2 * STAGE;
+        for (int k = st * 4; k < K; k += 1024) {
+          st4(Gw + k, ld4(g.pro_gamma + k));
+          st4(Gw + GEMM_KMAX + k, ld4(g.pro_beta + k));
+        }
+        __syncthreads();                                 // gamma / beta visible to every staging wave
+      }
+      store(smem, ar0, wr0, 0);
+      if (nk > 2) issue(ar0, wr0, 2 * BK);
+      STAMP_S(1);
+      __syncthreads();                                   // chunk 0 is visible
+      for (int kt = 0; kt < nk; kt += 2) {
+        STAMP_S(2 + 3 * kt);
+        if (kt + 1 < nk) {                               // chunk kt+1: set 1 -> buffer 1 (last read a barrier ago)
+          store(smem + STAGE, ar1, wr1, (kt + 1) * BK);
+          STAMP_S(3 + 3 * kt);
+          if (kt + 3 < nk) issue(ar1, wr1, (kt + 3) * BK);
+        }
+        STAMP_S(4 + 3 * kt);
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        STAMP_S(5 + 3 * kt);
+        if (kt + 2 < nk) {                               // chunk kt+2: set 0 -> buffer 0
+          store(smem, ar0, wr0, (kt + 2) * BK);
+          STAMP_S(6 + 3 * kt);
+          if (kt + 4 < nk) issue(ar0, wr0, (kt + 4) * BK);
+        }
+        STAMP_S(7 + 3 * kt);
+        __syncthreads();
+      }
+    };
+
+    // ---- interior fast path: buffer addressing, no per-chunk vector ALU ---------------------------
+    // Every VALU instruction of a staging wave has to squeeze in between the back-to-back MFMAs of the
+    // matrix wave on the same SIMD (measured ~30 clk per VALU op, stamps in DESIGN.md).  So the per-lane
+    // byte offsets of every load slot are computed ONCE; a chunk advances a scalar offset only
+    // (buffer_load_dwordx4 v, voffset, rsrc, soffset) and its stores are plain ds_write_b128.
+    // Needs: aligned operands, K % 32 == 0, segment widths % 32 == 0 (a chunk never straddles two
+    // segments), lane offsets < 2^31 (checked per wave; a wave that fails uses the pointer path, both
+    // produce the same LDS image).
+    bool fast = VEC && (K % BK) == 0;
+    uint32_t voffA[RT][3], voffW[NW4];
+    if (VEC) {
+      const int w0 = g.a[0].width, w1 = g.nseg > 1 ? g.a[1].width : 0;
+      if (g.nseg > 1 && ((w0 | w1) & (BK - 1))) fast = false;
+      bool fits = true;
+#pragma unroll
+      for (int r = 0; r < RT; ++r) {
+        const int gm = min(m0 + arow + 32 * r, M - 1);
+#pragma unroll
+        for (int sgi = 0; sgi < 3; ++sgi) {
+          voffA[r][sgi] = 0;
+          if (sgi < g.nseg) {
+            const size_t off = ((size_t)dosx_map_row(g.a[sgi].map, gm) * (size_t)g.a[sgi].ld + akq) * 4;
+            fits = fits && off < 0x7fffffffu;
+            voffA[r][sgi] = (uint32_t)off;
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NW4; ++i) {
+        size_t off;
+        if (WL == 0) {
+          off = ((size_t)min(n0 + (st >> 3) + 32 * i, N - 1) * g.ldw + (st & 7) * 4) * 4;
+        } else {
+          const int lin = st + 256 * i, c4 = (lin % (BN / 4)) * 4;
+          off = ((size_t)(lin / (BN / 4)) * g.ldw + ((n0 + c4) < N ? (n0 + c4) : 0)) * 4;
+        }
+        fits = fits && off < 0x7fffffffu;
+        voffW[i] = (uint32_t)off;
+      }
+      if (WL == 1 && (size_t)K * g.ldw * 4 >= 0x7fffffffu) fits = false;
+      fast = fast && __all(fits);
+    }
+    if (DOSX_PRIO_VARIANT == 1) __builtin_amdgcn_s_setprio(3);
+    if (fast) {
+      const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)g.w, 0, 0x7fffffff, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc((void*)g.a[0].p, 0, 0x7fffffff, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rA1 =
+          __builtin_amdgcn_make_buffer_rsrc((void*)g.a[g.nseg > 1 ? 1 : 0].p, 0, 0x7fffffff, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rA2 =
+          __builtin_amdgcn_make_buffer_rsrc((void*)g.a[g.nseg > 2 ? 2 : 0].p, 0, 0x7fffffff, 0x00020000);
+      const int e0 = g.nseg > 1 ? g.a[0].width : 0x7fffffff;                       // end of segment 0
+      const int e1 = g.nseg > 2 ? e0 + g.a[1].width : 0x7fffffff;                  // end of segment 1
+      auto issue = [&](ARaw(&ar)[RT], float4(&wr)[NW4], int k0) {
+        const int k0u = __builtin_amdgcn_readfirstlane(k0);
+        const int sgi = k0u < e0 ? 0 : (k0u < e1 ? 1 : 2);                          // wave-uniform
+        const int soffA = (k0u - (sgi == 0 ? 0 : (sgi == 1 ? e0 : e1))) * 4;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+          v4i32 v;
+          if (sgi == 0) v = __builtin_amdgcn_raw_buffer_load_b128(rA0, voffA[r][0], soffA, 0);
+          else if (sgi == 1) v = __builtin_amdgcn_raw_buffer_load_b128(rA1, voffA[r][1], soffA, 0);
+          else v = __builtin_amdgcn_raw_buffer_load_b128(rA2, voffA[r][2], soffA, 0);
+          ar[r].v = __builtin_bit_cast(float4, v);
+        }
+        const int soffW = (WL == 0) ? k0u * 4 : k0u * g.ldw * 4;
+#pragma unroll
+        for (int i = 0; i < NW4; ++i)
+          wr[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rW, voffW[i], soffW, 0));
+      };
+      auto store = [&](float* buf, const ARaw(&ar)[RT], const float4(&wr)[NW4], int k0) {
+        const int k = k0 + akq;
+        float4 gv = f4zero(), bv = f4zero();
+        if constexpr (PROLN) {
+          gv = ld4(Gs + k);
+          bv = ld4(Bs + k);
+        }
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+          st4(&buf[(arow + 32 * r) * LDA + akq], a_finish<PRO, VEC, 0>(ast[r], ar[r], k, K, gv, bv));
+        float* Wd = buf + BMR * LDA;
+#pragma unroll
+        for (int i = 0; i < NW4; ++i) {
+          if (WL == 0) st4(&Wd[((st >> 3) + 32 * i) * LDWT + (st & 7) * 4], wr[i]);
+          else st4(&Wd[((st + 256 * i) / (BN / 4)) * LDWT + ((st + 256 * i) % (BN / 4)) * 4], wr[i]);
+        }
+      };
+      pipeline(issue, store);
+    } else {
+      auto issue = [&](ARaw(&ar)[RT], float4(&wr)[NW4], int k0) {
+        issueA(ar, k0);
+        loadW(k0, wr);
+      };
+      auto store = [&](float* buf, const ARaw(&ar)[RT], const float4(&wr)[NW4], int k0) {
+        storeA(buf, ar, k0);
+        storeW(buf + BMR * LDA, k0, wr);
+      };
+      pipeline(issue, store);
+    }
+  } else {
+    // =============================== matrix waves ================================================
+#pragma unroll
+    for (int rr = 0; rr < RT; ++rr)
+#pragma unroll
+      for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rr][t][r] = 0.f;
+    if (DOSX_PRIO_VARIANT == 2) __builtin_amdgcn_s_setprio(2);
+    if constexpr (PROLN) __syncthreads();
+    __syncthreads();
+    STAMP(1);
+    // One k-chunk of MFMAs.  Straight-line and unconditional: W rows / columns beyond N are zero-filled
+    // in LDS, so a ragged last column block just multiplies zeros.  (A wave-uniform "skip my
+    // out-of-range tiles" branch here made hipcc keep the accumulators in VGPRs across the k-loop and
+    // copy them to/from AGPRs around the MFMA block: 2 x 16*RT*NTW moves per chunk.)
+    for (int kt = 0; kt < nk; ++kt) {
+      const float* Asb = smem + (kt & 1) * STAGE;
+      const float* Wsb = Asb + BMR * LDA;
+      STAMP(3 + 3 * kt);
 #pragma unroll
       for (int kk = 0; kk < BK; kk += 8) {
         float4 a[RT];
@@ -283,7 +440,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmLaunch L) {
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
           if (WL == 0) {
-            const float4 v = wfrag4(Wsb, (wave * NTW + t) * 32 + l31, kk + 4 * hh);
+            const float4 v = ld4(&Wsb[((wave * NTW + t) * 32 + l31) * LDWT + kk + 4 * hh]);
             b[t][0] = v.x; b[t][1] = v.y; b[t][2] = v.z; b[t][3] = v.w;
           } else {
             const float* bp = &Wsb[(kk + 4 * hh) * LDWT + (wave * NTW + t) * 32 + l31];
@@ -300,120 +457,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmLaunch L) {
               acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[t][c], acc[r][t], 0, 0, 0);
           }
       }
-    } else {
-#pragma unroll
-      for (int kk = 0; kk < BK; kk += 8) {
-        float4 a[RT];
-#pragma unroll
-        for (int r = 0; r < RT; ++r) a[r] = ld4(&Asb[(32 * r + l31) * LDA + kk + 4 * hh]);
-#pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-          if (t >= tiles_on) continue;
-          const int col = (wave * NTW + t) * 32 + l31;
-          float b[4];
-          if (WL == 0) {
-            const float4 v = wfrag4(Wsb, col, kk + 4 * hh);
-            b[0] = v.x; b[1] = v.y; b[2] = v.z; b[3] = v.w;
-          } else {
-            const float* bp = &Wsb[(kk + 4 * hh) * LDWT + col];
-            b[0] = bp[0]; b[1] = bp[LDWT]; b[2] = bp[2 * LDWT]; b[3] = bp[3 * LDWT];
-          }
-#pragma unroll
-          for (int r = 0; r < RT; ++r) {
-            acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].x, b[0], acc[r][t], 0, 0, 0);
-            acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].y, b[1], acc[r][t], 0, 0, 0);
-            acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].z, b[2], acc[r][t], 0, 0, 0);
-            acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r].w, b[3], acc[r][t], 0, 0, 0);
-          }
-        }
-      }
-    }
-  };
-
-  STAMP(1);
-  if constexpr (DMA) {
-    // W tile of chunk k0 -> LDS buffer Wd, asynchronously.  Thread/lane mapping is the register path's
-    // (row = tid/8 + 32 i, 16-B chunk = tid%8 | float4 index = tid + 256 i), which makes every
-    // wave-instruction's 64 x 16 B land contiguously at a wave-uniform LDS base.
-    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-    auto dmaW = [&](float* Wd, int k0) {
-#pragma unroll
-      for (int i = 0; i < NW4; ++i) {
-        const float* src;
-        float* dst;
-        if (WL == 0) {
-          const int row = (tid >> 3) + 32 * i;                    // tile-local output column
-          const int c = (tid & 7) ^ ((row >> 1) & 7);             // swizzled source chunk
-          src = g.w + (size_t)min(n0 + row, N - 1) * g.ldw + k0 + c * 4;
-          dst = Wd + (8 * wave_s + 32 * i) * BK;
-        } else {
-          const int lin = tid + 256 * i;
-          const int r = lin / (BN / 4), c4 = (lin % (BN / 4)) * 4;
-          const int n = n0 + c4;
-          src = g.w + (size_t)min(k0 + r, K - 1) * g.ldw + (n < N ? n : 0);
-          dst = Wd + (64 * wave_s + 256 * i) * 4;
-        }
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-      }
-    };
-    ARaw araw[RT];
-    issueA(araw, 0);
-    dmaW(smem + BMR * LDA, 0);
-    storeA(smem, araw, 0);
-    __syncthreads();        // (emits vmcnt(0) while a DMA is in flight: the tile has landed)
-    for (int kt = 0; kt < nk; ++kt) {
-      float* Acur = smem + (kt & 1) * STAGE;
-      float* Anxt = smem + ((kt & 1) ^ 1) * STAGE;
-      if (kt + 1 < nk) {
-        issueA(araw, (kt + 1) * BK);
-        dmaW(Anxt + BMR * LDA, (kt + 1) * BK);
-      }
-      STAMP(3 + 3 * kt);
-      compute(Acur, Acur + BMR * LDA);
-      STAMP(4 + 3 * kt);
-      if (kt + 1 < nk) storeA(Anxt, araw, (kt + 1) * BK);
-      __syncthreads();
-    }
-  } else {
-    ARaw araw[RT];
-    issueA(araw, 0);
-    float4 wreg[NW4];
-    loadW(0, wreg);
-    for (int kt = 0; kt < nk; ++kt) {
-      storeA(As, araw, kt * BK);
-      storeW(Ws, kt * BK, wreg, 0, NW4);
-      STAMP(2 + 3 * kt);
-      __syncthreads();
-      STAMP(3 + 3 * kt);
-      if (kt + 1 < nk) {
-        issueA(araw, (kt + 1) * BK);
-        loadW((kt + 1) * BK, wreg);
-      }
-      compute(As, Ws);
       STAMP(4 + 3 * kt);
       __syncthreads();
     }
   }
+  __builtin_amdgcn_s_setprio(0);
   STAMP(55);
 
-  // ---- epilogue operand prefetch -----------------------------------------------------------------
+  // ---- epilogue operand prefetch (all 8 waves; wave w owns rows 4w..4w+3 of each 32-row block) -----
   // Every global operand of the row-wise epilogue (bias / gamma / beta vectors, the rows of `aux` and
-  // `res`, the per-row statistics) is loaded HERE, unconditionally and from always-valid addresses
-  // (absent operands alias `out`, whose values are then ignored), before the accumulator round trip
-  // through LDS.  The row loop below then touches no global memory except its stores; a load inside
-  // that loop costs one exposed L2/HBM round trip per row (8 per wave).
+  // `res`, the per-row statistics) is loaded HERE from always-valid (clamped) addresses, before the
+  // accumulator round trip through LDS.  The row loop below then touches no global memory except its
+  // stores; a load inside that loop costs one exposed L2/HBM round trip per row.
   const int ncols = min(BN, N - n0);
   const float invN = 1.f / (float)N;
   constexpr int epi = EPI;     // compile-time: only this epilogue's code exists in the kernel
-  const bool is_prelu_ln = (epi == DOSX_EPI_PRELU_LN_BWD), is_rowln = (epi == DOSX_EPI_ROWLN_BWD);
-  const bool aux_first = (epi != DOSX_EPI_BIAS_ACT && epi != DOSX_EPI_LN);
-  const float* dummy = g.out;
-  const float* p1 = aux_first ? (g.aux ? g.aux : dummy) : (g.res ? g.res : dummy);   // per-row operand 1
-  const int ld1 = aux_first ? (g.aux ? g.ldaux : 0) : (g.res ? g.ldr : 0);
-  const float* p2 = (is_rowln && g.res) ? g.res : dummy;                                // per-row operand 2
-  const int ld2 = (is_rowln && g.res) ? g.ldr : 0;
-  const float* statp = g.aux_stats ? g.aux_stats : dummy;
+  constexpr bool is_prelu_ln = (epi == DOSX_EPI_PRELU_LN_BWD), is_rowln = (epi == DOSX_EPI_ROWLN_BWD);
+  constexpr bool aux_first = (epi != DOSX_EPI_BIAS_ACT && epi != DOSX_EPI_LN);   // operand 1 is `aux`
+  constexpr bool use_stats = is_prelu_ln || is_rowln;
+  const bool has1 = aux_first ? (g.aux != nullptr) : (g.res != nullptr && epi == DOSX_EPI_BIAS_ACT);
+  const bool has2 = is_rowln && g.res != nullptr;
+  const float* p1 = aux_first ? g.aux : g.res;
+  const int ld1 = aux_first ? g.ldaux : g.ldr;
   float4 pg[CG], pb[CG];   // column partial sums (dgamma, dbeta) over all row blocks of this workgroup
   float pal = 0.f;         // dalpha partial
 #pragma unroll
@@ -428,50 +493,74 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmLaunch L) {
     const int c = lane * 4 + 256 * j;
     on[j] = c < ncols;
     gcol[j] = n0 + (on[j] ? c : 0);
-    biasv[j] = ld4((g.bias ? g.bias : dummy) + gcol[j]);
-    gamv[j] = ld4((g.epi_gamma ? g.epi_gamma : dummy) + gcol[j]);
-    betv[j] = ld4((g.epi_beta ? g.epi_beta : dummy) + gcol[j]);
-    if (!g.bias) biasv[j] = f4zero();
+    biasv[j] = f4zero(); gamv[j] = f4zero(); betv[j] = f4zero();
+    if (g.bias) biasv[j] = ld4(g.bias + gcol[j]);
+    if (use_stats) {
+      gamv[j] = ld4(g.epi_gamma + gcol[j]);
+      if (is_prelu_ln) betv[j] = ld4(g.epi_beta + gcol[j]);
+    }
   }
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {        // one 32-row block at a time through the LDS C tile
   const int mb = m0 + 32 * rt;
-  float4 pv1[8][CG], pv2[8][CG];
-  float st0[8], st1[8];
-  size_t orow_[8];
+  float4 pv1[ER][CG], pv2[ER][CG];
+  float st0[ER], st1[ER];
+  size_t orow_[ER];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int rc = min(mb + wave * 8 + i, M - 1);
-    const size_t r1 = (size_t)((!aux_first && g.res) ? dosx_map_row(g.res_map, rc) : rc) * ld1;
-    const size_t r2 = (size_t)((is_rowln && g.res) ? dosx_map_row(g.res_map, rc) : rc) * ld2;
+  for (int i = 0; i < ER; ++i) {
+    const int rc = min(mb + wave * ER + i, M - 1);
     orow_[i] = (size_t)(epi == DOSX_EPI_BIAS_ACT ? dosx_map_row(g.out_map, rc) : rc) * g.ldo;
+    st0[i] = 0.f; st1[i] = 0.f;
 #pragma unroll
-    for (int j = 0; j < CG; ++j) {
-      pv1[i][j] = ld4(p1 + r1 + gcol[j]);
-      pv2[i][j] = ld4(p2 + r2 + gcol[j]);
+    for (int j = 0; j < CG; ++j) { pv1[i][j] = f4zero(); pv2[i][j] = f4zero(); }
+  }
+  if (has1) {          // wave-uniform, outside every loop: the loads of all rows are issued back to back
+#pragma unroll
+    for (int i = 0; i < ER; ++i) {
+      const int rc = min(mb + wave * ER + i, M - 1);
+      const size_t r1 = (size_t)(aux_first ? rc : dosx_map_row(g.res_map, rc)) * ld1;
+#pragma unroll
+      for (int j = 0; j < CG; ++j) pv1[i][j] = ld4(p1 + r1 + gcol[j]);
     }
-    st0[i] = statp[is_rowln ? 2 * (size_t)rc : (size_t)rc];
-    st1[i] = statp[is_rowln ? 2 * (size_t)rc + 1 : (size_t)rc];
+  }
+  if (has2) {
+#pragma unroll
+    for (int i = 0; i < ER; ++i) {
+      const int rc = min(mb + wave * ER + i, M - 1);
+      const size_t r2 = (size_t)dosx_map_row(g.res_map, rc) * g.ldr;
+#pragma unroll
+      for (int j = 0; j < CG; ++j) pv2[i][j] = ld4(g.res + r2 + gcol[j]);
+    }
+  }
+  if (use_stats) {
+#pragma unroll
+    for (int i = 0; i < ER; ++i) {
+      const int rc = min(mb + wave * ER + i, M - 1);
+      st0[i] = g.aux_stats[is_rowln ? 2 * (size_t)rc : (size_t)rc];
+      st1[i] = g.aux_stats[is_rowln ? 2 * (size_t)rc + 1 : (size_t)rc];
+    }
   }
 
-  // ---- accumulators -> LDS C tile (aliases the staging buffers; loop ended with a barrier) ----
+  // ---- accumulators -> LDS C tile (aliases the staging buffers; the k-loop ended with a barrier) ----
+  if (wave_u < 4) {
 #pragma unroll
-  for (int t = 0; t < NTW; ++t) {
-    const int col = (wave * NTW + t) * 32 + l31;
+    for (int t = 0; t < NTW; ++t) {
+      const int col = (wave * NTW + t) * 32 + l31;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-      Cs[row * LDC + col] = acc[rt][t][r];
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        Cs[row * LDC + col] = acc[rt][t][r];
+      }
     }
   }
   STAMP(56);
   __syncthreads();
   STAMP(57);
 
-  // ---- row-wise epilogue: wave w owns rows 8w..8w+7, lanes sweep the columns as float4 --------
+  // ---- row-wise epilogue: lanes sweep the columns as float4 ------------------------------------
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int lr = wave * 8 + i, r = mb + lr;
+  for (int i = 0; i < ER; ++i) {
+    const int lr = wave * ER + i, r = mb + lr;
     const bool rvalid = r < M;              // wave-uniform
     float4 v[CG];
 #pragma unroll
@@ -491,7 +580,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmLaunch L) {
           v[j].x = v[j].x >= 0.f ? v[j].x : sl * v[j].x; v[j].y = v[j].y >= 0.f ? v[j].y : sl * v[j].y;
           v[j].z = v[j].z >= 0.f ? v[j].z : sl * v[j].z; v[j].w = v[j].w >= 0.f ? v[j].w : sl * v[j].w;
         }
-        if (g.res) v[j] = f4add(v[j], pv1[i][j]);
+        v[j] = f4add(v[j], pv1[i][j]);       // residual (zeros when absent)
         if (rvalid) st4(orow + gcol[j], v[j]);
         s1 += v[j].x + v[j].y + v[j].z + v[j].w;
       }
@@ -590,7 +679,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmLaunch L) {
         if (!on[j] || !rvalid) continue;
         float4 o = make_float4(rstd * (dxh[j].x - m1 - xh[j].x * m2), rstd * (dxh[j].y - m1 - xh[j].y * m2),
                                rstd * (dxh[j].z - m1 - xh[j].z * m2), rstd * (dxh[j].w - m1 - xh[j].w * m2));
-        if (is_rowln && g.res) o = f4add(o, pv2[i][j]);
+        if (is_rowln) o = f4add(o, pv2[i][j]);
         st4(orow + gcol[j], o);
       }
     }
@@ -602,6 +691,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmLaunch L) {
   // ---- per-workgroup partial sums for the parameter gradients of the fused LN / PReLU ----------
   if (g.partials && (epi == DOSX_EPI_PRELU_LN_BWD || epi == DOSX_EPI_ROWLN_BWD || epi == DOSX_EPI_PRELU_BWD)) {
     float* prow = g.partials + (size_t)(blockIdx.x * gridDim.y + blockIdx.y) * g.partial_ld;
+    __syncthreads();                    // (the C tile rows of other waves are still being read above)
     if (epi != DOSX_EPI_PRELU_BWD) {
 #pragma unroll
       for (int j = 0; j < CG; ++j) {
@@ -614,69 +704,68 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmLaunch L) {
     }
     if (epi != DOSX_EPI_ROWLN_BWD) {
       const float s = wave_sum(pal);
-      if (lane == 0) Ps[8 * BN + wave] = s;
+      if (lane == 0) Ps[16 * BN + wave] = s;
     }
     __syncthreads();
     if (epi != DOSX_EPI_PRELU_BWD) {
-      for (int c = tid; c < 2 * BN; c += 256) {
+      for (int c = tid; c < 2 * BN; c += 512) {
         const int which = c / BN, col = c % BN;
         if (col < ncols) {
-          const float s = Ps[(0 * 2 + which) * BN + col] + Ps[(1 * 2 + which) * BN + col] +
-                          Ps[(2 * 2 + which) * BN + col] + Ps[(3 * 2 + which) * BN + col];
+          float s = 0.f;
+#pragma unroll
+          for (int w = 0; w < 8; ++w) s += Ps[(w * 2 + which) * BN + col];
           prow[which * N + n0 + col] = s;
         }
       }
     }
-    if (epi != DOSX_EPI_ROWLN_BWD && tid == 0)
-      prow[g.partial_ld - 1] = Ps[8 * BN] + Ps[8 * BN + 1] + Ps[8 * BN + 2] + Ps[8 * BN + 3];
+    if (epi != DOSX_EPI_ROWLN_BWD && tid == 0) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) s += Ps[16 * BN + w];
+      prow[g.partial_ld - 1] = s;
+    }
   }
 }
 
-template <int RT, int NTW, int WL, int DMA>
+template <int RT, int NTW, int WL, int PROLN>
 constexpr size_t gemm_smem_bytes() {
   constexpr int BN = 128 * NTW;
-  constexpr int LDWT = DMA ? ((WL == 0) ? BK : BN) : ((WL == 0) ? (BK + 4) : (BN + 4));
+  constexpr int LDWT = (WL == 0) ? (BK + 4) : (BN + 4);
   constexpr int WROWS = (WL == 0) ? BN : BK;
   constexpr int STAGE = BM * RT * LDA + WROWS * LDWT;
   constexpr int CTILE = BM * (BN + 4);
-  constexpr int MAINF = DMA ? 2 * STAGE : (STAGE > CTILE ? STAGE : CTILE);
-  constexpr int EPIF = CTILE + 8 * BN + 4;
+  constexpr int MAINF = 2 * STAGE + (PROLN ? 2 * GEMM_KMAX : 0);
+  constexpr int EPIF = CTILE + 16 * BN + 8;
   return (size_t)(MAINF > EPIF ? MAINF : EPIF) * sizeof(float);
 }
 
-template <int RT, int NTW, int WL, int PRO, int VEC, int EPI, int DMA>
+template <int RT, int NTW, int WL, int PRO, int VEC, int EPI>
 int launch_gemm3(const GemmLaunch& L, hipStream_t s) {
   constexpr int BN = 128 * NTW;
   dim3 grid(ceil_div(L.g.M, BM * RT), ceil_div(L.g.N, BN));
-  constexpr size_t smem = gemm_smem_bytes<RT, NTW, WL, DMA>();
-  static_assert(smem <= 160 * 1024, "LDS budget");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<RT, NTW, WL, PRO, VEC, EPI, DMA>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
+  constexpr size_t smem = gemm_smem_bytes<RT, NTW, WL, (VEC && (PRO == DOSX_PRO_LN_PRELU || PRO == DOSX_PRO_ROWLN)) ? 1 : 0>();
+  if constexpr (smem > 160 * 1024) {     // (512-column tile + LayerNorm prologue: no caller has this shape)
+    dosx_set_error("dosx_gemm: tile %dx%d with prologue %d exceeds the 160 KB LDS", BM * RT, BN, PRO);
+    return -22;
+  } else {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<RT, NTW, WL, PRO, VEC, EPI>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel<RT, NTW, WL, PRO, VEC, EPI>), grid, dim3(512), smem, s, L);
+    DOSX_LAUNCH_CHECK();
+    return 0;
   }
-  hipLaunchKernelGGL((gemm_kernel<RT, NTW, WL, PRO, VEC, EPI, DMA>), grid, dim3(256), smem, s, L);
-  DOSX_LAUNCH_CHECK();
-  return 0;
 }
 
-template <int NTW, int WL, int PRO, int VEC, int EPI, int DMA>
-int launch_gemm2(const GemmLaunch& L, hipStream_t s) {
-  if (L.rt == 2) return launch_gemm3<2, NTW, WL, PRO, VEC, EPI, DMA>(L, s);
-  return launch_gemm3<1, NTW, WL, PRO, VEC, EPI, DMA>(L, s);
-}
-
-// The LDS-DMA staging variant is compiled only with -DDOSX_ENABLE_DMA (experiments): measured on
-// MI355X it loses to the register-staged path at every shape of this workload (2.78 vs 2.68 ms per
-// cfg2 step; 73 vs 97 TF/s at M=262144,N=256,K=384) because its two staging buffers halve the
-// number of co-resident workgroups, which is what actually hides the load latency here.
 template <int NTW, int WL, int PRO, int VEC, int EPI>
 int launch_gemm(const GemmLaunch& L, hipStream_t s) {
-#ifdef DOSX_ENABLE_DMA
-  if (VEC && L.dma) return launch_gemm2<NTW, WL, PRO, VEC, EPI, VEC ? 1 : 0>(L, s);
-#endif
-  return launch_gemm2<NTW, WL, PRO, VEC, EPI, 0>(L, s);
+  if constexpr (NTW < 4) {              // (two 64-row stage buffers of a 512-column tile exceed the LDS)
+    if (L.rt == 2) return launch_gemm3<2, NTW, WL, PRO, VEC, EPI>(L, s);
+  }
+  return launch_gemm3<1, NTW, WL, PRO, VEC, EPI>(L, s);
 }
 
 // Only the (layout, prologue, epilogue) combinations the forward / backward programs use exist.
@@ -747,6 +836,7 @@ inline int gemm_rt(int M, int N, int epi) {
   static int forced = -1;
   if (forced < 0) { const char* e = getenv("DOSX_GEMM_RT"); forced = e ? atoi(e) : 0; }
   if (forced == 1 || forced == 2) return forced;
+  if (gemm_bn(M, N, epi) == 512) return 1;
   const int ntiles = ceil_div(N, gemm_bn(M, N, epi));
   const int wg1 = ceil_div(M, BM) * ntiles, wg2 = ceil_div(M, 2 * BM) * ntiles;
   if (wg2 >= 192) return 2;
@@ -784,6 +874,8 @@ extern "C" int dosx_gemm(const DosxGemm* gp, dosx_stream_t stream) {
   if (g.pro == DOSX_PRO_LN_PRELU || g.pro == DOSX_PRO_ROWLN)
     DOSX_CHECK_ARG(g.pro_gamma && g.pro_beta, "dosx_gemm: prologue needs gamma/beta");
   if (g.pro == DOSX_PRO_ROWLN) DOSX_CHECK_ARG(g.pro_stats, "dosx_gemm: ROWLN prologue needs stats");
+  if (g.pro == DOSX_PRO_LN_PRELU || g.pro == DOSX_PRO_ROWLN)
+    DOSX_CHECK_ARG(g.K <= GEMM_KMAX, "dosx_gemm: LayerNorm prologue needs K <= %d, got %d", GEMM_KMAX, g.K);
   if (g.pro == DOSX_PRO_PRELU || g.pro == DOSX_PRO_LN_PRELU) DOSX_CHECK_ARG(g.pro_alpha, "dosx_gemm: prologue needs alpha");
   if (g.epi == DOSX_EPI_LN) DOSX_CHECK_ARG(g.aux_out, "dosx_gemm: EPI_LN needs aux_out (rstd)");
   if (g.epi == DOSX_EPI_PRELU_LN_BWD)
@@ -800,14 +892,10 @@ extern "C" int dosx_gemm(const DosxGemm* gp, dosx_stream_t stream) {
   if (g.pro == DOSX_PRO_LN_PRELU || g.pro == DOSX_PRO_ROWLN)
     L.vecA = L.vecA && aligned16(g.pro_gamma) && aligned16(g.pro_beta);
   L.vecW = ((g.ldw & 3) == 0) && aligned16(g.w) && (g.w_layout == 0 ? (g.K & 3) == 0 : (g.N & 3) == 0);
-  {
-    static int dma_on = -1;
-    if (dma_on < 0) { const char* e = getenv("DOSX_GEMM_DMA"); dma_on = (e && e[0] == '1') ? 1 : 0; }
-    L.dma = (dma_on && L.vecA && L.vecW && (g.K % BK) == 0) ? 1 : 0;
-  }
   L.rt = gemm_rt(g.M, g.N, g.epi);
   int bn = gemm_bn(g.M, g.N, g.epi);
   if (g.stats_out && bn < g.N) bn = g.N <= 256 ? 256 : 512;
+  if (bn == 512) L.rt = 1;
   hipStream_t s = to_stream(stream);
   if (bn == 128) return dispatch_gemm<1>(L, s);
   if (bn == 256) return dispatch_gemm<2>(L, s);
@@ -853,6 +941,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
   ARaw xr0, xr1;
   AState st;
   bool row_ok = false;
+  // this thread always stages the same two 4-column groups: their gamma / beta live in registers
+  float4 gq0 = f4zero(), gq1 = f4zero(), bq0 = f4zero(), bq1 = f4zero();
+  if (VEC && (PRO == DOSX_PRO_LN_PRELU || PRO == DOSX_PRO_ROWLN)) {
+    const int ka = (k0 + c4) < K ? (k0 + c4) : 0, kb = (k0 + c4 + 32) < K ? (k0 + c4 + 32) : 0;
+    gq0 = ld4(g.pro_gamma + ka); bq0 = ld4(g.pro_beta + ka);
+    gq1 = ld4(g.pro_gamma + kb); bq1 = ld4(g.pro_beta + kb);
+  }
   auto issue = [&](int m) {
     row_ok = (m + r) < me;
     const int gm = min(m + r, me - 1);          // me > ms >= 0 here: always a valid row
@@ -884,8 +979,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
     }
     st4(&Ys[r * LDT + c4], a0);
     st4(&Ys[r * LDT + c4 + 32], a1);
-    st4(&Xs[r * LDT + c4], a_finish<PRO, VEC>(st, xr0, k0 + c4, K));
-    st4(&Xs[r * LDT + c4 + 32], a_finish<PRO, VEC>(st, xr1, k0 + c4 + 32, K));
+    st4(&Xs[r * LDT + c4], a_finish<PRO, VEC>(st, xr0, k0 + c4, K, gq0, bq0));
+    st4(&Xs[r * LDT + c4 + 32], a_finish<PRO, VEC>(st, xr1, k0 + c4 + 32, K, gq1, bq1));
   };
 
   if (ms < me) issue(ms);
