@@ -95,54 +95,97 @@ __device__ __forceinline__ void stage_k_full(float* Ks, const float* __restrict_
   }
 }
 
-// S[32][NKP] (+)= A[32][H] . K^T : A tile resident in LDS (As, stride LDH), K streamed in k-chunks.
+// How the QK^T-shaped products are split over the 4 waves.  With >= 3 key tiles every wave owns whole
+// 32-key tiles (jt = wave + 4t) and the full feature range.  With 1 or 2 key tiles (the 12-atom /
+// 51-bin cases of the phonon configs) that would leave 3 or 2 waves idle for 16 serial MFMA steps, so
+// the FEATURE range is split instead: ks = 4 (or 2) partial score tiles, summed when the scores are read.
+struct QkSplit {
+  int ks;       // partial tiles
+  int kpart;    // this wave's partial
+  int jt0;      // this wave's first key tile
+  int jstep;    // key-tile stride (4 when ks == 1: tiles wave, wave+4, ...; else no second tile)
+};
+__host__ __device__ inline int qk_ks(int NKP, int HP, bool kres) {
+  if (!kres) return 1;
+  const int nkt = NKP / 32;
+  if (nkt == 1 && HP % 32 == 0) return 4;
+  if (nkt == 2 && HP % 16 == 0) return 2;
+  return 1;
+}
+__device__ __forceinline__ QkSplit make_split(int NKP, int HP, bool kres, int wave) {
+  QkSplit q;
+  q.ks = qk_ks(NKP, HP, kres);
+  q.kpart = q.ks == 4 ? wave : (q.ks == 2 ? (wave >> 1) : 0);
+  q.jt0 = q.ks == 4 ? 0 : (q.ks == 2 ? (wave & 1) : wave);
+  q.jstep = q.ks == 1 ? 4 : 1024;
+  return q;
+}
+
+// S[32][NKP] (+)= A[32][H] . K^T : A tile resident in LDS (As, stride LDH), K streamed in k-chunks
+// (or resident: KRES).  Partial products of wave-split `q` stay in acc; store_scores() writes them to
+// the partial tile q.kpart.
 template <bool KRES>
 __device__ __forceinline__ void qk_product(f32x16 (&acc)[MAX_KT], const float* As, int LDH, float* Ks,
                                            const float* kvhat, const float* gamma, const float* beta, int Nk, int NKP,
-                                           int Bk, int bk, int H, int HP, int tid) {
-  const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+                                           int Bk, int bk, int H, int HP, int tid, const QkSplit q) {
+  const int lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int nkt = NKP / 32;
 #pragma unroll
   for (int t = 0; t < MAX_KT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  for (int kc = 0; kc < HP; kc += KC) {
-    if (!KRES) {
-      stage_k_chunk(Ks, kvhat, gamma, beta, Nk, NKP, Bk, bk, H, kc, tid);
-      __syncthreads();
-    }
-#pragma unroll
-    for (int kk = 0; kk < KC; kk += 8) {
-      const float4 a = ld4(As + l31 * LDH + kc + kk + 4 * hh);
+  const int kbeg = q.kpart * (HP / q.ks), kend = kbeg + HP / q.ks;
+  if (KRES) {
+    for (int k = kbeg; k < kend; k += 8) {
+      const float4 a = ld4(As + l31 * LDH + k + 4 * hh);
 #pragma unroll
       for (int t = 0; t < MAX_KT; ++t) {
-        const int jt = wave + 4 * t;
+        const int jt = q.jt0 + q.jstep * t;
         if (jt >= nkt) continue;
-        const float4 b = KRES ? ld4(Ks + (jt * 32 + l31) * LDH + kc + kk + 4 * hh)
-                              : ld4(Ks + (jt * 32 + l31) * LDK + kk + 4 * hh);
+        const float4 b = ld4(Ks + (jt * 32 + l31) * LDH + k + 4 * hh);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
       }
     }
-    if (!KRES) __syncthreads();
+    return;
+  }
+  for (int kc = 0; kc < HP; kc += KC) {
+    stage_k_chunk(Ks, kvhat, gamma, beta, Nk, NKP, Bk, bk, H, kc, tid);
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < KC; kk += 8) {
+      const float4 a = ld4(As + l31 * LDH + kc + kk + 4 * hh);
+#pragma unroll
+      for (int t = 0; t < MAX_KT; ++t) {
+        const int jt = q.jt0 + q.jstep * t;
+        if (jt >= nkt) continue;
+        const float4 b = ld4(Ks + (jt * 32 + l31) * LDK + kk + 4 * hh);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
   }
 }
 
-// store the QK^T accumulators (times scale) into Ss[32][LDS_]
-__device__ __forceinline__ void store_scores(const f32x16 (&acc)[MAX_KT], float* Ss, int LDS_, int NKP, float scale,
-                                             int tid) {
-  const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+// store the (partial) QK^T accumulators into partial tile q.kpart of Ss ([ks][32][LDS_])
+__device__ __forceinline__ void store_scores(const f32x16 (&acc)[MAX_KT], float* Ss, int LDS_, int NKP, int tid,
+                                             const QkSplit q) {
+  const int lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int nkt = NKP / 32;
+  float* Sp = Ss + q.kpart * QT * LDS_;
 #pragma unroll
   for (int t = 0; t < MAX_KT; ++t) {
-    const int jt = wave + 4 * t;
+    const int jt = q.jt0 + q.jstep * t;
     if (jt >= nkt) continue;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-      Ss[row * LDS_ + jt * 32 + l31] = acc[t][r] * scale;
+      Sp[row * LDS_ + jt * 32 + l31] = acc[t][r];
     }
   }
 }
@@ -196,87 +239,128 @@ __device__ __forceinline__ void store_out_tile(const f32x16 (&acc)[MAX_CT], floa
   }
 }
 
-// In-place LayerNorm (affine) of the 32 rows of an LDS tile; wave w owns rows 8w..8w+7.
-// Writes (mean, rstd) to stats[(row)] when the row is valid.
-__device__ __forceinline__ void ln_rows_inplace(float* T, int LDH, int H, const float* __restrict__ gamma,
-                                                const float* __restrict__ beta, float* stats_out, int s0, int Sq,
-                                                int Bq, int bq, int tid) {
-  const int lane = tid & 63, wave = tid >> 6;
-  for (int i = 0; i < 8; ++i) {
-    const int lr = wave * 8 + i;
-    float* row = T + lr * LDH;
-    float s1 = 0.f;
-    for (int c = lane * 4; c < H; c += 256) {
-      const float4 v = ld4(row + c);
-      s1 += v.x + v.y + v.z + v.w;
-    }
-    const float mean = wave_sum(s1) / (float)H;
-    float s2 = 0.f;
-    for (int c = lane * 4; c < H; c += 256) {
-      const float4 v = ld4(row + c);
-      const float a = v.x - mean, b = v.y - mean, c2 = v.z - mean, d = v.w - mean;
-      s2 += a * a + b * b + c2 * c2 + d * d;
-    }
-    const float rstd = rsqrtf(wave_sum(s2) / (float)H + DOSX_LN_EPS);
-    for (int c = lane * 4; c < H; c += 256) {
-      const float4 v = ld4(row + c), g = ld4(gamma + c), b = ld4(beta + c);
-      st4(row + c, make_float4((v.x - mean) * rstd * g.x + b.x, (v.y - mean) * rstd * g.y + b.y,
-                               (v.z - mean) * rstd * g.z + b.z, (v.w - mean) * rstd * g.w + b.w));
-    }
-    const int s = s0 + lr;
-    if (stats_out && lane == 0 && s < Sq) {
-      stats_out[2 * ((size_t)s * Bq + bq)] = mean;
-      stats_out[2 * ((size_t)s * Bq + bq) + 1] = rstd;
-    }
-  }
-}
+constexpr int RW = 8;      // query rows per wave in the row phases (32-row tile / 4 waves)
+constexpr int MAXJ = 5;    // keys per lane in the softmax phases (Nk <= 320)
 
 // ================================== forward =====================================================
+// Row phases (LayerNorm of the queries, softmax, residual + statistics) keep a wave's 8 rows in
+// REGISTERS (lane l owns columns 4l..4l+3, H <= 256) and run the 8 reductions as independent chains:
+// a row-at-a-time loop through LDS cost ~8 exposed latency chains per phase and a global round trip
+// per row for the residual (the raw query rows are simply kept from the first load).
 template <bool KRES>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const DosxAttn a) {
   extern __shared__ __align__(16) float sm[];
   const Geo g = make_geo(a.H, a.Nk);
-  float* Qs = sm;                                   // [32][LDH]   (later: output tile)
-  float* Ss = Qs + QT * g.LDH;                      // [32][LDS_]
-  float* KV = Ss + QT * g.LDS_;                     // max(NKP*36, 32*LDH)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const QkSplit q = make_split(g.NKP, g.HP, KRES, wave);
+  float* Qs = sm;                                   // [32][LDH]   (later: output tile)
+  float* Ss = Qs + QT * g.LDH;                      // [ks][32][LDS_] partial scores; tile 0 becomes P
+  float* KV = Ss + q.ks * QT * g.LDS_;              // max(NKP*36, 32*LDH) or the whole key tile
   const int s0 = blockIdx.x * QT, bq = blockIdx.y, bk = bq % a.Bk;
   const int H = a.H, Sq = a.Sq, Nk = a.Nk;
+  const bool raw_q = (a.flags & DOSX_ATTN_RAW_Q) != 0;
+  const int c0 = lane * 4;
+  const bool con = c0 < H;                          // this lane owns 4 real columns
+  const float invH = 1.f / (float)H;
 
-  load_rows(Qs, g.LDH, g.HP, H, [&](int i) -> const float* {
-    const int s = s0 + i;
-    return s < Sq ? a.x + ((size_t)s * a.q_stride_s + (size_t)bq * a.q_stride_b) * H : nullptr;
-  }, tid);
-  if (KRES) stage_k_full(KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, g.LDH, tid);
-  __syncthreads();
-  if (!(a.flags & DOSX_ATTN_RAW_Q)) {
-    ln_rows_inplace(Qs, g.LDH, H, a.gamma0, a.beta0, a.qstats, s0, Sq, a.Bq, bq, tid);
-    __syncthreads();
+  // ---- query rows: global -> registers (kept for the residual) -> LayerNorm -> LDS ----
+  float4 xr[RW];
+#pragma unroll
+  for (int i = 0; i < RW; ++i) {
+    const int s = min(s0 + wave * RW + i, Sq - 1);
+    xr[i] = ld4(a.x + ((size_t)s * a.q_stride_s + (size_t)bq * a.q_stride_b) * H + (con ? c0 : 0));
   }
+  const float4 g0 = ld4(a.gamma0 + (con ? c0 : 0)), b0 = ld4(a.beta0 + (con ? c0 : 0));
+  if (KRES) stage_k_full(KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, g.LDH, tid);
+  {
+    float mean[RW], rstd[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const float4 v = xr[i];
+      mean[i] = con ? (v.x + v.y) + (v.z + v.w) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < RW; ++i) mean[i] = wave_sum(mean[i]) * invH;
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const float4 v = xr[i];
+      const float p0 = v.x - mean[i], p1 = v.y - mean[i], p2 = v.z - mean[i], p3 = v.w - mean[i];
+      rstd[i] = con ? (p0 * p0 + p1 * p1) + (p2 * p2 + p3 * p3) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < RW; ++i) rstd[i] = rsqrtf(wave_sum(rstd[i]) * invH + DOSX_LN_EPS);
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const int lr = wave * RW + i, s = s0 + lr;
+      const float4 v = xr[i];
+      float4 o = v;
+      if (!raw_q)
+        o = make_float4((v.x - mean[i]) * rstd[i] * g0.x + b0.x, (v.y - mean[i]) * rstd[i] * g0.y + b0.y,
+                        (v.z - mean[i]) * rstd[i] * g0.z + b0.z, (v.w - mean[i]) * rstd[i] * g0.w + b0.w);
+      if (!(con && s < Sq)) o = f4zero();
+      if (c0 < g.HP) st4(Qs + lr * g.LDH + c0, o);
+      if (!raw_q && a.qstats && lane == 0 && s < Sq) {
+        a.qstats[2 * ((size_t)s * a.Bq + bq)] = mean[i];
+        a.qstats[2 * ((size_t)s * a.Bq + bq) + 1] = rstd[i];
+      }
+    }
+  }
+  __syncthreads();
 
   f32x16 sacc[MAX_KT];
-  qk_product<KRES>(sacc, Qs, g.LDH, KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, tid);
-  store_scores(sacc, Ss, g.LDS_, g.NKP, rsqrtf((float)H), tid);
+  qk_product<KRES>(sacc, Qs, g.LDH, KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, tid, q);
+  store_scores(sacc, Ss, g.LDS_, g.NKP, tid, q);
   __syncthreads();
 
-  // exact fp32 softmax over the Nk keys (padded atoms included, like the reference)
-  for (int i = 0; i < 8; ++i) {
-    const int lr = wave * 8 + i, s = s0 + lr;
-    float* row = Ss + lr * g.LDS_;
-    float mx = -INFINITY;
-    for (int j = lane; j < Nk; j += 64) mx = fmaxf(mx, row[j]);
-    mx = wave_max(mx);
-    float sum = 0.f;
-    for (int j = lane; j < Nk; j += 64) {
-      const float e = expf(row[j] - mx);
-      row[j] = e;
-      sum += e;
+  // ---- exact fp32 softmax over the Nk keys (padded atoms included, like the reference) ----
+  {
+    const float scale = rsqrtf((float)H);
+    const int pstride = QT * g.LDS_;
+    float v[RW][MAXJ], mx[RW], sum[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const float* row = Ss + (wave * RW + i) * g.LDS_;
+      mx[i] = -INFINITY;
+#pragma unroll
+      for (int jj = 0; jj < MAXJ; ++jj) {
+        const int j = lane + 64 * jj;
+        float t = -INFINITY;
+        if (j < Nk) {
+          t = row[j];
+          if (q.ks > 1) t += row[pstride + j];
+          if (q.ks > 2) t += row[2 * pstride + j] + row[3 * pstride + j];
+          t *= scale;
+        }
+        v[i][jj] = t;
+        mx[i] = fmaxf(mx[i], t);
+      }
     }
-    const float inv = 1.f / wave_sum(sum);
-    for (int j = lane; j < g.NKP; j += 64) {
-      const float p = j < Nk ? row[j] * inv : 0.f;
-      row[j] = p;
-      if (j < Nk && s < Sq) a.probs[((size_t)bq * Sq + s) * Nk + j] = p;
+#pragma unroll
+    for (int i = 0; i < RW; ++i) mx[i] = wave_max(mx[i]);
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      sum[i] = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < MAXJ; ++jj) {
+        const float e = (lane + 64 * jj) < Nk ? expf(v[i][jj] - mx[i]) : 0.f;
+        v[i][jj] = e;
+        sum[i] += e;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RW; ++i) sum[i] = 1.f / wave_sum(sum[i]);
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const int lr = wave * RW + i, s = s0 + lr;
+      float* row = Ss + lr * g.LDS_;
+#pragma unroll
+      for (int jj = 0; jj < MAXJ; ++jj) {
+        const int j = lane + 64 * jj;
+        if (j >= g.NKP) continue;
+        const float pr = v[i][jj] * sum[i];           // 0 beyond Nk
+        row[j] = pr;
+        if (j < Nk && s < Sq) a.probs[((size_t)bq * Sq + s) * Nk + j] = pr;
+      }
     }
   }
   __syncthreads();
@@ -286,32 +370,37 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const DosxAttn a) {
   store_out_tile(oacc, Qs, g.LDH, g.HP, tid);
   __syncthreads();
 
-  // epilogue: residual add, optional statistics of the output rows (feeds the following LN1)
-  for (int i = 0; i < 8; ++i) {
-    const int lr = wave * 8 + i, s = s0 + lr;
-    if (s >= Sq) break;
-    const float* xr = a.x + ((size_t)s * a.q_stride_s + (size_t)bq * a.q_stride_b) * H;
-    float* orow = a.out + ((size_t)s * a.Bq + bq) * H;
-    float s1 = 0.f;
-    for (int c = lane * 4; c < H; c += 256) {
-      float4 v = ld4(Qs + lr * g.LDH + c);
-      if (!(a.flags & DOSX_ATTN_NO_RESIDUAL)) v = f4add(v, ld4(xr + c));
-      st4(orow + c, v);
-      st4(Qs + lr * g.LDH + c, v);
-      s1 += v.x + v.y + v.z + v.w;
+  // ---- epilogue: residual add from the kept query rows, statistics of the output rows (feeds LN1) ----
+  {
+    const bool no_res = (a.flags & DOSX_ATTN_NO_RESIDUAL) != 0;
+    float4 o[RW];
+    float mean[RW], var[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const int lr = wave * RW + i, s = s0 + lr;
+      float4 v = con ? ld4(Qs + lr * g.LDH + c0) : f4zero();
+      if (!no_res) v = f4add(v, xr[i]);
+      o[i] = v;
+      if (con && s < Sq) st4(a.out + ((size_t)s * a.Bq + bq) * H + c0, v);
+      mean[i] = con ? (v.x + v.y) + (v.z + v.w) : 0.f;
     }
     if (a.out_stats) {
-      const float mean = wave_sum(s1) / (float)H;
-      float s2 = 0.f;
-      for (int c = lane * 4; c < H; c += 256) {
-        const float4 v = ld4(Qs + lr * g.LDH + c);
-        const float p = v.x - mean, q = v.y - mean, r2 = v.z - mean, t = v.w - mean;
-        s2 += p * p + q * q + r2 * r2 + t * t;
+#pragma unroll
+      for (int i = 0; i < RW; ++i) mean[i] = wave_sum(mean[i]) * invH;
+#pragma unroll
+      for (int i = 0; i < RW; ++i) {
+        const float p0 = o[i].x - mean[i], p1 = o[i].y - mean[i], p2 = o[i].z - mean[i], p3 = o[i].w - mean[i];
+        var[i] = con ? (p0 * p0 + p1 * p1) + (p2 * p2 + p3 * p3) : 0.f;
       }
-      const float rstd = rsqrtf(wave_sum(s2) / (float)H + DOSX_LN_EPS);
-      if (lane == 0) {
-        a.out_stats[2 * ((size_t)s * a.Bq + bq)] = mean;
-        a.out_stats[2 * ((size_t)s * a.Bq + bq) + 1] = rstd;
+#pragma unroll
+      for (int i = 0; i < RW; ++i) var[i] = wave_sum(var[i]) * invH;
+#pragma unroll
+      for (int i = 0; i < RW; ++i) {
+        const int s = s0 + wave * RW + i;
+        if (lane == 0 && s < Sq) {
+          a.out_stats[2 * ((size_t)s * a.Bq + bq)] = mean[i];
+          a.out_stats[2 * ((size_t)s * a.Bq + bq) + 1] = rsqrtf(var[i] + DOSX_LN_EPS);
+        }
       }
     }
   }
@@ -322,47 +411,89 @@ template <bool KRES>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const DosxAttn a) {
   extern __shared__ __align__(16) float sm[];
   const Geo g = make_geo(a.H, a.Nk);
-  float* Ds = sm;                                   // [32][LDH]  dOut tile, later dq tile
-  float* Ps = Ds + QT * g.LDH;                      // [32][LDS_] probabilities
-  float* Ss = Ps + QT * g.LDS_;                     // [32][LDS_] dP -> dS
-  float* KV = Ss + QT * g.LDS_;                     // chunk staging, or the whole key tile (KRES)
-  float* Pp = KV + (KRES ? g.NKP * g.LDH : max(g.NKP * LDK, KC * g.LDH));    // [4][2][HP] partial column sums
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const QkSplit q = make_split(g.NKP, g.HP, KRES, wave);
+  float* Ds = sm;                                   // [32][LDH]  dOut tile, later dq tile
+  float* Ss = Ds + QT * g.LDH;                      // [ks][32][LDS_] partial dP; tile 0 becomes dS
+  float* KV = Ss + q.ks * QT * g.LDS_;              // chunk staging, or the whole key tile (KRES)
+  float* Pp = KV + (KRES ? g.NKP * g.LDH : max(g.NKP * LDK, KC * g.LDH));    // [4][2][HP] partial column sums
   const int s0 = blockIdx.x * QT, bq = blockIdx.y, bk = bq % a.Bk;
   const int H = a.H, Sq = a.Sq, Nk = a.Nk;
+  const bool raw_q = (a.flags & DOSX_ATTN_RAW_Q) != 0, no_res = (a.flags & DOSX_ATTN_NO_RESIDUAL) != 0;
+  const int c0 = lane * 4;
+  const bool con = c0 < H;
+  const float invH = 1.f / (float)H;
 
-  load_rows(Ds, g.LDH, g.HP, H, [&](int i) -> const float* {
-    const int s = s0 + i;
-    return s < Sq ? a.dout + ((size_t)s * a.Bq + bq) * H : nullptr;
-  }, tid);
-  // probabilities tile (zero padded)
-  for (int i = wave; i < QT; i += 4) {
-    const int s = s0 + i;
-    for (int j = lane; j < g.NKP; j += 64)
-      Ps[i * g.LDS_ + j] = (s < Sq && j < Nk) ? a.probs[((size_t)bq * Sq + s) * Nk + j] : 0.f;
+  // ---- this wave's 8 rows of dOut (kept for the residual) and of x, their statistics, their P row ----
+  float4 go[RW], xr[RW];
+  float mean[RW], rstd[RW], pr[RW][MAXJ];
+#pragma unroll
+  for (int i = 0; i < RW; ++i) {
+    const int s = min(s0 + wave * RW + i, Sq - 1);
+    const size_t orow = (size_t)s * a.Bq + bq;
+    go[i] = ld4(a.dout + orow * H + (con ? c0 : 0));
+    xr[i] = ld4(a.x + ((size_t)s * a.q_stride_s + (size_t)bq * a.q_stride_b) * H + (con ? c0 : 0));
+    mean[i] = raw_q ? 0.f : a.qstats[2 * orow];
+    rstd[i] = raw_q ? 1.f : a.qstats[2 * orow + 1];
+#pragma unroll
+    for (int jj = 0; jj < MAXJ; ++jj) {
+      const int j = lane + 64 * jj;
+      pr[i][jj] = a.probs[((size_t)bq * Sq + s) * Nk + (j < Nk ? j : 0)];
+    }
   }
+  const float4 g0 = ld4(a.gamma0 + (con ? c0 : 0));
   if (KRES) stage_k_full(KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, g.LDH, tid);
+#pragma unroll
+  for (int i = 0; i < RW; ++i) {
+    const int lr = wave * RW + i;
+    float4 d = go[i];
+    if (!(con && (s0 + lr) < Sq)) d = f4zero();
+    if (c0 < g.HP) st4(Ds + lr * g.LDH + c0, d);
+  }
   __syncthreads();
 
   // dP = dO . V^T
   f32x16 sacc[MAX_KT];
-  qk_product<KRES>(sacc, Ds, g.LDH, KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, tid);
-  store_scores(sacc, Ss, g.LDS_, g.NKP, 1.f, tid);
+  qk_product<KRES>(sacc, Ds, g.LDH, KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, tid, q);
+  store_scores(sacc, Ss, g.LDS_, g.NKP, tid, q);
   __syncthreads();
 
   // dS = P * (dP - rowsum(P*dP)) * scale
-  const float scale = rsqrtf((float)H);
-  for (int i = 0; i < 8; ++i) {
-    const int lr = wave * 8 + i, s = s0 + lr;
-    float* drow = Ss + lr * g.LDS_;
-    const float* prow = Ps + lr * g.LDS_;
-    float dot = 0.f;
-    for (int j = lane; j < Nk; j += 64) dot += prow[j] * drow[j];
-    dot = wave_sum(dot);
-    for (int j = lane; j < g.NKP; j += 64) {
-      const float ds = j < Nk ? prow[j] * (drow[j] - dot) * scale : 0.f;
-      drow[j] = ds;
-      if (j < Nk && s < Sq) a.dscores[((size_t)bq * Sq + s) * Nk + j] = ds;
+  {
+    const float scale = rsqrtf((float)H);
+    const int pstride = QT * g.LDS_;
+    float dp[RW][MAXJ], dot[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const float* row = Ss + (wave * RW + i) * g.LDS_;
+      dot[i] = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < MAXJ; ++jj) {
+        const int j = lane + 64 * jj;
+        float t = 0.f;
+        if (j < Nk) {
+          t = row[j];
+          if (q.ks > 1) t += row[pstride + j];
+          if (q.ks > 2) t += row[2 * pstride + j] + row[3 * pstride + j];
+          dot[i] += pr[i][jj] * t;
+        }
+        dp[i][jj] = t;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RW; ++i) dot[i] = wave_sum(dot[i]);
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const int lr = wave * RW + i, s = s0 + lr;
+      float* row = Ss + lr * g.LDS_;
+#pragma unroll
+      for (int jj = 0; jj < MAXJ; ++jj) {
+        const int j = lane + 64 * jj;
+        if (j >= g.NKP) continue;
+        const float ds = (j < Nk && s < Sq) ? pr[i][jj] * (dp[i][jj] - dot[i]) * scale : 0.f;
+        row[j] = ds;
+        if (j < Nk && s < Sq) a.dscores[((size_t)bq * Sq + s) * Nk + j] = ds;
+      }
     }
   }
   __syncthreads();
@@ -374,43 +505,45 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const DosxAttn a) {
   __syncthreads();
 
   // LN0 backward on the query rows + residual;  partial dgamma0 / dbeta0 (query side)
-  const bool raw_q = (a.flags & DOSX_ATTN_RAW_Q) != 0, no_res = (a.flags & DOSX_ATTN_NO_RESIDUAL) != 0;
-  for (int c = lane; c < 2 * g.HP; c += 64) Pp[wave * 2 * g.HP + c] = 0.f;
-  for (int i = 0; i < 8; ++i) {
-    const int lr = wave * 8 + i, s = s0 + lr;
-    if (s >= Sq) break;
-    const float* xr = a.x + ((size_t)s * a.q_stride_s + (size_t)bq * a.q_stride_b) * H;
-    const size_t orow = ((size_t)s * a.Bq + bq);
-    if (raw_q) {
-      for (int c = lane * 4; c < H; c += 256) {
-        float4 d = ld4(Ds + lr * g.LDH + c);
-        if (!no_res) d = f4add(d, ld4(a.dout + orow * H + c));
-        st4(a.dx + orow * H + c, d);
-      }
-      continue;
+  {
+    float4 pg = f4zero(), pb = f4zero();
+    float4 d[RW], xh[RW];
+    float s1[RW], s2[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const int lr = wave * RW + i;
+      const bool rv = con && (s0 + lr) < Sq;
+      d[i] = rv ? ld4(Ds + lr * g.LDH + c0) : f4zero();
+      const float4 xv = xr[i];
+      xh[i] = make_float4((xv.x - mean[i]) * rstd[i], (xv.y - mean[i]) * rstd[i], (xv.z - mean[i]) * rstd[i],
+                          (xv.w - mean[i]) * rstd[i]);
+      if (!rv) xh[i] = f4zero();
+      pg.x += d[i].x * xh[i].x; pg.y += d[i].y * xh[i].y; pg.z += d[i].z * xh[i].z; pg.w += d[i].w * xh[i].w;
+      pb = f4add(pb, d[i]);
+      const float4 dh = make_float4(d[i].x * g0.x, d[i].y * g0.y, d[i].z * g0.z, d[i].w * g0.w);
+      s1[i] = (dh.x + dh.y) + (dh.z + dh.w);
+      s2[i] = (dh.x * xh[i].x + dh.y * xh[i].y) + (dh.z * xh[i].z + dh.w * xh[i].w);
     }
-    const float mean = a.qstats[2 * orow], rstd = a.qstats[2 * orow + 1];
-    float s1 = 0.f, s2 = 0.f;
-    for (int c = lane * 4; c < H; c += 256) {
-      const float4 xv = ld4(xr + c), d = ld4(Ds + lr * g.LDH + c), gm = ld4(a.gamma0 + c);
-      const float4 xh = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
-      float* pgm = Pp + wave * 2 * g.HP + c;
-      pgm[0] += d.x * xh.x; pgm[1] += d.y * xh.y; pgm[2] += d.z * xh.z; pgm[3] += d.w * xh.w;
-      float* pbt = pgm + g.HP;
-      pbt[0] += d.x; pbt[1] += d.y; pbt[2] += d.z; pbt[3] += d.w;
-      const float4 dh = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
-      s1 += dh.x + dh.y + dh.z + dh.w;
-      s2 += dh.x * xh.x + dh.y * xh.y + dh.z * xh.z + dh.w * xh.w;
+    if (!raw_q) {
+#pragma unroll
+      for (int i = 0; i < RW; ++i) { s1[i] = wave_sum(s1[i]) * invH; s2[i] = wave_sum(s2[i]) * invH; }
     }
-    const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
-    for (int c = lane * 4; c < H; c += 256) {
-      const float4 xv = ld4(xr + c), d = ld4(Ds + lr * g.LDH + c), gm = ld4(a.gamma0 + c);
-      float4 go = f4zero();
-      if (!no_res) go = ld4(a.dout + orow * H + c);
-      const float4 xh = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
-      st4(a.dx + orow * H + c,
-          make_float4(go.x + rstd * (d.x * gm.x - m1 - xh.x * m2), go.y + rstd * (d.y * gm.y - m1 - xh.y * m2),
-                      go.z + rstd * (d.z * gm.z - m1 - xh.z * m2), go.w + rstd * (d.w * gm.w - m1 - xh.w * m2)));
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+      const int s = s0 + wave * RW + i;
+      if (!(con && s < Sq)) continue;
+      float4 o;
+      if (raw_q) o = d[i];
+      else
+        o = make_float4(rstd[i] * (d[i].x * g0.x - s1[i] - xh[i].x * s2[i]), rstd[i] * (d[i].y * g0.y - s1[i] - xh[i].y * s2[i]),
+                        rstd[i] * (d[i].z * g0.z - s1[i] - xh[i].z * s2[i]), rstd[i] * (d[i].w * g0.w - s1[i] - xh[i].w * s2[i]));
+      if (!no_res) o = f4add(o, go[i]);
+      st4(a.dx + ((size_t)s * a.Bq + bq) * H + c0, o);
+    }
+    if (raw_q) { pg = f4zero(); pb = f4zero(); }
+    if (c0 < g.HP) {
+      st4(Pp + wave * 2 * g.HP + c0, pg);
+      st4(Pp + wave * 2 * g.HP + g.HP + c0, pb);
     }
   }
   __syncthreads();
@@ -558,11 +691,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const DosxAttn a) {
 }
 
 size_t fwd_smem(const Geo& g, bool kres) {
-  return sizeof(float) * (size_t)(QT * g.LDH + QT * g.LDS_ + (kres ? g.NKP * g.LDH : max(g.NKP * LDK, KC * g.LDH)));
+  return sizeof(float) * (size_t)(QT * g.LDH + qk_ks(g.NKP, g.HP, kres) * QT * g.LDS_ +
+                                  (kres ? g.NKP * g.LDH : max(g.NKP * LDK, KC * g.LDH)));
 }
 size_t dq_smem(const Geo& g, bool kres) {
-  return sizeof(float) *
-         (size_t)(QT * g.LDH + 2 * QT * g.LDS_ + (kres ? g.NKP * g.LDH : max(g.NKP * LDK, KC * g.LDH)) + 8 * g.HP);
+  return sizeof(float) * (size_t)(QT * g.LDH + qk_ks(g.NKP, g.HP, kres) * QT * g.LDS_ +
+                                  (kres ? g.NKP * g.LDH : max(g.NKP * LDK, KC * g.LDH)) + 8 * g.HP);
 }
 constexpr size_t KRES_LDS_LIMIT = 144 * 1024;   // keep the whole key tile of a crystal in LDS when it fits
 size_t dkv_smem(const Geo& g) { return sizeof(float) * (size_t)(2 * QT * g.LDH + 2 * QT * LDK + 8 * g.HP); }

@@ -916,99 +916,212 @@ struct WgradLaunch {
   int vecY;
 };
 
-template <int PRO, int VEC>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradLaunch L) {
+// Wave-specialised like gemm_kernel: waves 0-3 multiply (one 32x32 sub-tile each), waves 4-7 stage the
+// next 32-row chunk of dY and A' (two LDS stage buffers, one barrier per chunk, loads two chunks deep).
+// FAST = 1: every row map on the path is affine (optionally followed by an index gather on A) and the
+// tile lies inside one K-segment, so all lane offsets are fixed and a chunk advances scalar offsets
+// only (buffer loads; rows beyond M read as zero through the buffer bounds: no masks, no vector ALU
+// beyond the prologue transform).  FAST = 0: generic pointer path (any map, ragged everything).
+template <int PRO, int VEC, int FAST>
+__global__ __launch_bounds__(512) void wgrad_kernel(const WgradLaunch L) {
   const DosxWgrad& g = L.g;
-  __shared__ __align__(16) float Ys[BM * LDT];
-  __shared__ __align__(16) float Xs[BM * LDT];
+  constexpr int STG = 2 * BM * LDT;                       // floats of one stage buffer: Ys | Xs
+  __shared__ __align__(16) float Sm[2 * STG];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int k0 = blockIdx.x * WT, n0 = blockIdx.y * WT, z = blockIdx.z;
   const int M = g.M, N = g.N, K = g.K;
   const int chunk = ((M + g.nsplit - 1) / g.nsplit + BM - 1) / BM * BM;
   const int ms = z * chunk, me = min(M, ms + chunk);
-  const int wn = wave >> 1, wk = wave & 1;
-  const int r = tid >> 3, c4 = (tid & 7) * 4;   // staging: row r, cols c4 and c4+32
+  const int nch = ms < me ? (me - ms + BM - 1) / BM : 0;
+  const bool do_bias = (g.slab_bias != nullptr) && (blockIdx.x == 0);
 
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  float bsum = 0.f;
-  const bool do_bias = (g.slab_bias != nullptr) && (blockIdx.x == 0);
+  float4 bs0 = f4zero(), bs1 = f4zero();                 // staging lanes: column sums of their dY values
 
-  // staging registers of the NEXT chunk: raw loads are issued before the MFMA block of the current
-  // chunk and finished (prologue transform + masks) right before their LDS store
-  float4 y0, y1;
-  ARaw xr0, xr1;
-  AState st;
-  bool row_ok = false;
-  // this thread always stages the same two 4-column groups: their gamma / beta live in registers
-  float4 gq0 = f4zero(), gq1 = f4zero(), bq0 = f4zero(), bq1 = f4zero();
-  if (VEC && (PRO == DOSX_PRO_LN_PRELU || PRO == DOSX_PRO_ROWLN)) {
-    const int ka = (k0 + c4) < K ? (k0 + c4) : 0, kb = (k0 + c4 + 32) < K ? (k0 + c4 + 32) : 0;
-    gq0 = ld4(g.pro_gamma + ka); bq0 = ld4(g.pro_beta + ka);
-    gq1 = ld4(g.pro_gamma + kb); bq1 = ld4(g.pro_beta + kb);
-  }
-  auto issue = [&](int m) {
-    row_ok = (m + r) < me;
-    const int gm = min(m + r, me - 1);          // me > ms >= 0 here: always a valid row
-    y0 = y1 = f4zero();
-    const float* yp = g.dy.p + (size_t)dosx_map_row(g.dy.map, gm) * g.dy.ld;
-#pragma unroll
-    for (int hseg = 0; hseg < 2; ++hseg) {
-      const int n = n0 + c4 + 32 * hseg;
-      float4 v = f4zero();
-      if (VEC) {
-        v = ld4(yp + (n < N ? n : 0));
-      } else if (row_ok && n < N) {
-        v.x = yp[n];
-        if (n + 1 < N) v.y = yp[n + 1];
-        if (n + 2 < N) v.z = yp[n + 2];
-        if (n + 3 < N) v.w = yp[n + 3];
+  if (wave_u >= 4) {
+    // =============================== staging waves ===============================================
+    const int st = tid - 256;
+    const int r = st >> 3, c4 = (st & 7) * 4;             // row r of the chunk, columns c4 and c4 + 32
+    float4 gq0 = f4zero(), gq1 = f4zero(), bq0 = f4zero(), bq1 = f4zero();
+    if (VEC && (PRO == DOSX_PRO_LN_PRELU || PRO == DOSX_PRO_ROWLN)) {
+      const int ka = (k0 + c4) < K ? (k0 + c4) : 0, kb = (k0 + c4 + 32) < K ? (k0 + c4 + 32) : 0;
+      gq0 = ld4(g.pro_gamma + ka); bq0 = ld4(g.pro_beta + ka);
+      gq1 = ld4(g.pro_gamma + kb); bq1 = ld4(g.pro_beta + kb);
+    }
+    struct Set {
+      float4 y0, y1;
+      ARaw x0, x1;
+      AState st;        // generic path: row pointers / statistics of this lane's row
+      bool row_ok;
+      int idx;          // fast path: gathered row index of this lane's row, fetched two chunks ahead
+      float mean, rstd;
+    };
+    Set s0, s1;
+    auto pipeline = [&](auto&& issue, auto&& store) {
+      if (nch > 0) issue(s0, ms);
+      if (nch > 1) issue(s1, ms + BM);
+      if (nch > 0) store(Sm, s0);
+      if (nch > 2) issue(s0, ms + 2 * BM);
+      __syncthreads();
+      for (int c = 0; c < nch; c += 2) {
+        if (c + 1 < nch) {
+          store(Sm + STG, s1);
+          if (c + 3 < nch) issue(s1, ms + (c + 3) * BM);
+        }
+        __syncthreads();
+        if (c + 1 >= nch) break;
+        if (c + 2 < nch) {
+          store(Sm, s0);
+          if (c + 4 < nch) issue(s0, ms + (c + 4) * BM);
+        }
+        __syncthreads();
       }
-      if (hseg == 0) y0 = v; else y1 = v;
+    };
+    if constexpr (FAST) {
+      // the K-segment this tile lives in (host guarantees it does not straddle two)
+      int sgi = 0, kbase = 0;
+      if (g.nseg > 1 && k0 >= g.a[0].width) { sgi = 1; kbase = g.a[0].width; }
+      if (g.nseg > 2 && k0 >= g.a[0].width + g.a[1].width) { sgi = 2; kbase = g.a[0].width + g.a[1].width; }
+      const DosxSeg sa = g.a[sgi];
+      const int kw = sa.width - (k0 - kbase);                         // columns of this tile inside K
+      const int cy = g.dy.map.c, oy = g.dy.map.off, ca = sa.map.c, oa = sa.map.off;
+      const bool gather = sa.map.idx != nullptr;
+      // bounds: rows >= M read as zero (dY) -> they add nothing to the sums; no masks anywhere
+      const uint32_t ybytes = (uint32_t)(((size_t)(M - 1) * cy + oy + 1) * (size_t)g.dy.ld * 4);
+      const uint32_t abytes = gather ? 0x7fffffffu : (uint32_t)(((size_t)(M - 1) * ca + oa + 1) * (size_t)sa.ld * 4);
+      const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)g.dy.p, 0, ybytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)sa.p, 0, abytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rI = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(gather ? sa.map.idx : (const int*)g.dy.p), 0, (uint32_t)(((size_t)(M - 1) * ca + oa + 1) * 4), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(PRO == DOSX_PRO_ROWLN ? g.pro_stats : g.dy.p), 0, (uint32_t)((size_t)M * 8), 0x00020000);
+      const int ny0 = (n0 + c4) < N ? (n0 + c4) : 0, ny1 = (n0 + c4 + 32) < N ? (n0 + c4 + 32) : 0;
+      const int kx0 = c4 < kw ? c4 : 0, kx1 = (c4 + 32) < kw ? (c4 + 32) : 0;
+      const uint32_t vY0 = (uint32_t)((((size_t)(ms + r) * cy + oy) * g.dy.ld + ny0) * 4);
+      const uint32_t vY1 = (uint32_t)((((size_t)(ms + r) * cy + oy) * g.dy.ld + ny1) * 4);
+      const uint32_t colA0 = (uint32_t)((k0 - kbase + kx0) * 4), colA1 = (uint32_t)((k0 - kbase + kx1) * 4);
+      const uint32_t vA0 = (uint32_t)(((size_t)(ms + r) * ca + oa) * sa.ld * 4) + colA0;   // (!gather)
+      const uint32_t vA1 = (uint32_t)(((size_t)(ms + r) * ca + oa) * sa.ld * 4) + colA1;
+      const uint32_t vI = (uint32_t)(((size_t)(ms + r) * ca + oa) * 4);
+      const uint32_t vS = (uint32_t)((ms + r) * 8);
+      const int stepY = BM * cy * g.dy.ld * 4, stepA = BM * ca * sa.ld * 4, stepI = BM * ca * 4;
+      const float alpha = (PRO == DOSX_PRO_PRELU || PRO == DOSX_PRO_LN_PRELU) ? *g.pro_alpha : 0.f;
+      auto load_idx = [&](Set& q, int m) {
+        const int cidx = __builtin_amdgcn_readfirstlane((m - ms) / BM);
+        q.idx = __builtin_amdgcn_raw_buffer_load_b32(rI, vI, cidx * stepI, 0);
+      };
+      if (gather) {
+        if (nch > 0) load_idx(s0, ms);
+        if (nch > 1) load_idx(s1, ms + BM);
+      }
+      auto issue = [&](Set& q, int m) {
+        const int cidx = __builtin_amdgcn_readfirstlane((m - ms) / BM);
+        q.y0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rY, vY0, cidx * stepY, 0));
+        q.y1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rY, vY1, cidx * stepY, 0));
+        if (gather) {
+          const uint32_t rowb = (uint32_t)q.idx * (uint32_t)(sa.ld * 4);
+          q.x0.v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rA, rowb + colA0, 0, 0));
+          q.x1.v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rA, rowb + colA1, 0, 0));
+          if (m + 2 * BM < me) load_idx(q, m + 2 * BM);
+        } else {
+          q.x0.v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rA, vA0, cidx * stepA, 0));
+          q.x1.v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rA, vA1, cidx * stepA, 0));
+        }
+        if (PRO == DOSX_PRO_ROWLN) {
+          q.mean = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, vS, cidx * (BM * 8), 0));
+          q.rstd = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, vS + 4, cidx * (BM * 8), 0));
+        }
+      };
+      auto store = [&](float* buf, Set& q) {
+        AState t;
+        t.ok = true; t.mean = q.mean; t.rstd = q.rstd; t.alpha = alpha;
+        st4(&buf[r * LDT + c4], q.y0);
+        st4(&buf[r * LDT + c4 + 32], q.y1);
+        st4(&buf[BM * LDT + r * LDT + c4], a_finish<PRO, VEC, 0>(t, q.x0, 0, K, gq0, bq0));
+        st4(&buf[BM * LDT + r * LDT + c4 + 32], a_finish<PRO, VEC, 0>(t, q.x1, 0, K, gq1, bq1));
+        if (do_bias) { bs0 = f4add(bs0, q.y0); bs1 = f4add(bs1, q.y1); }
+      };
+      s0.mean = s0.rstd = s1.mean = s1.rstd = 0.f;
+      pipeline(issue, store);
+    } else {
+      auto issue = [&](Set& q, int m) {
+        q.row_ok = (m + r) < me;
+        const int gm = min(m + r, me - 1);          // me > ms >= 0 here: always a valid row
+        q.y0 = q.y1 = f4zero();
+        const float* yp = g.dy.p + (size_t)dosx_map_row(g.dy.map, gm) * g.dy.ld;
+#pragma unroll
+        for (int hseg = 0; hseg < 2; ++hseg) {
+          const int n = n0 + c4 + 32 * hseg;
+          float4 v = f4zero();
+          if (VEC) {
+            v = ld4(yp + (n < N ? n : 0));
+          } else if (q.row_ok && n < N) {
+            v.x = yp[n];
+            if (n + 1 < N) v.y = yp[n + 1];
+            if (n + 2 < N) v.z = yp[n + 2];
+            if (n + 3 < N) v.w = yp[n + 3];
+          }
+          if (hseg == 0) q.y0 = v; else q.y1 = v;
+        }
+        a_state_init(q.st, g.a, g.nseg, PRO, g.pro_stats, g.pro_alpha, gm, q.row_ok);
+        q.x0 = a_issue<PRO, VEC>(q.st, k0 + c4, K, g.pro_gamma, g.pro_beta);
+        q.x1 = a_issue<PRO, VEC>(q.st, k0 + c4 + 32, K, g.pro_gamma, g.pro_beta);
+      };
+      auto store = [&](float* buf, Set& q) {
+        float4 a0 = q.y0, a1 = q.y1;
+        if (VEC) {
+          if (!(q.row_ok && (n0 + c4) < N)) a0 = f4zero();
+          if (!(q.row_ok && (n0 + c4 + 32) < N)) a1 = f4zero();
+        }
+        st4(&buf[r * LDT + c4], a0);
+        st4(&buf[r * LDT + c4 + 32], a1);
+        st4(&buf[BM * LDT + r * LDT + c4], a_finish<PRO, VEC, 1>(q.st, q.x0, k0 + c4, K, gq0, bq0));
+        st4(&buf[BM * LDT + r * LDT + c4 + 32], a_finish<PRO, VEC, 1>(q.st, q.x1, k0 + c4 + 32, K, gq1, bq1));
+        if (do_bias) { bs0 = f4add(bs0, a0); bs1 = f4add(bs1, a1); }
+      };
+      pipeline(issue, store);
     }
-    a_state_init(st, g.a, g.nseg, PRO, g.pro_stats, g.pro_alpha, gm, row_ok);
-    xr0 = a_issue<PRO, VEC>(st, k0 + c4, K, g.pro_gamma, g.pro_beta);
-    xr1 = a_issue<PRO, VEC>(st, k0 + c4 + 32, K, g.pro_gamma, g.pro_beta);
-  };
-  auto store = [&]() {
-    float4 a0 = y0, a1 = y1;
-    if (VEC) {
-      if (!(row_ok && (n0 + c4) < N)) a0 = f4zero();
-      if (!(row_ok && (n0 + c4 + 32) < N)) a1 = f4zero();
-    }
-    st4(&Ys[r * LDT + c4], a0);
-    st4(&Ys[r * LDT + c4 + 32], a1);
-    st4(&Xs[r * LDT + c4], a_finish<PRO, VEC>(st, xr0, k0 + c4, K, gq0, bq0));
-    st4(&Xs[r * LDT + c4 + 32], a_finish<PRO, VEC>(st, xr1, k0 + c4 + 32, K, gq1, bq1));
-  };
-
-  if (ms < me) issue(ms);
-  for (int m = ms; m < me; m += BM) {
-    store();
+  } else {
+    // =============================== matrix waves ================================================
+    const int wn = wave >> 1, wk = wave & 1;
     __syncthreads();
-    if (m + BM < me) issue(m + BM);
-    if (do_bias && tid < WT) {
+    for (int c = 0; c < nch; ++c) {
+      const float* Ys = Sm + (c & 1) * STG;
+      const float* Xs = Ys + BM * LDT;
+#pragma unroll
+      for (int mm = 0; mm < BM; mm += 2) {
+        const float a = Ys[(mm + hh) * LDT + wn * 32 + l31];
+        const float b = Xs[(mm + hh) * LDT + wk * 32 + l31];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      }
+      __syncthreads();
+    }
+    float* slab = g.slab + (size_t)z * N * K;
+    const int kcol = k0 + wk * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int n = n0 + wn * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+      if (n < N && kcol < K) slab[(size_t)n * K + kcol] = acc[i];
+    }
+  }
+  if (do_bias) {          // workgroup-uniform: column sums of the staged dY rows -> slab_bias[z][n0 .. n0+63]
+    float* Br = Sm;       // [32][LDT]   (the stage buffers are dead: the loop ended with a barrier)
+    if (wave_u >= 4) {
+      const int st = tid - 256, r = st >> 3, c4 = (st & 7) * 4;
+      st4(&Br[r * LDT + c4], bs0);
+      st4(&Br[r * LDT + c4 + 32], bs1);
+    }
+    __syncthreads();
+    if (tid < WT && n0 + tid < N) {
+      float sum = 0.f;
 #pragma unroll 8
-      for (int rr = 0; rr < BM; ++rr) bsum += Ys[rr * LDT + tid];
+      for (int rr = 0; rr < BM; ++rr) sum += Br[rr * LDT + tid];
+      g.slab_bias[(size_t)z * N + n0 + tid] = sum;
     }
-#pragma unroll
-    for (int mm = 0; mm < BM; mm += 2) {
-      const float a = Ys[(mm + hh) * LDT + wn * 32 + l31];
-      const float b = Xs[(mm + hh) * LDT + wk * 32 + l31];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-    }
-    __syncthreads();
   }
-
-  float* slab = g.slab + (size_t)z * N * K;
-  const int kcol = k0 + wk * 32 + l31;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int n = n0 + wn * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-    if (n < N && kcol < K) slab[(size_t)n * K + kcol] = acc[i];
-  }
-  if (do_bias && tid < WT && n0 + tid < N) g.slab_bias[(size_t)z * N + n0 + tid] = bsum;
 }
 
 // Jobs travel as a kernel argument (no device-side table, no host->device copy, graph-capturable).
@@ -1096,15 +1209,33 @@ extern "C" int dosx_wgrad(const DosxWgrad* gp, dosx_stream_t stream) {
   dim3 grid(ceil_div(g.K, WT), ceil_div(g.N, WT), g.nsplit);
   hipStream_t st = to_stream(stream);
   const int vec = L.vecA && L.vecY;
+  // fast (buffer-addressed) staging: affine row maps (+ optional gather on A), K tiles inside one segment,
+  // every byte offset below 2^31
+  auto affine = [](const DosxRowMap& m) { return m.d >= (1 << 30) && m.c >= 1 && m.off >= 0; };
+  bool fast = vec && g.M > 0 && affine(g.dy.map) && g.dy.map.idx == nullptr &&
+              ((size_t)g.M * g.dy.map.c + g.dy.map.off) * (size_t)g.dy.ld * 4 < 0x7fffffffull;
+  for (int i = 0; fast && i < g.nseg; ++i) {
+    const DosxSeg& sg = g.a[i];
+    fast = affine(sg.map) && (g.nseg == 1 || (sg.width % WT) == 0) && (size_t)sg.ld * 4 < 0x7fffffffull &&
+           ((size_t)g.M * sg.map.c + sg.map.off) * (size_t)(sg.map.idx ? 4 : (size_t)sg.ld * 4) < 0x7fffffffull;
+  }
   if (!vec) {
     DOSX_CHECK_ARG(g.pro == DOSX_PRO_NONE, "dosx_wgrad: prologue %d needs 4-float aligned operands", g.pro);
-    hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_NONE, 0>), grid, dim3(256), 0, st, L);
+    hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_NONE, 0, 0>), grid, dim3(512), 0, st, L);
+  } else if (fast) {
+    switch (g.pro) {
+      case DOSX_PRO_NONE: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_NONE, 1, 1>), grid, dim3(512), 0, st, L); break;
+      case DOSX_PRO_PRELU: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_PRELU, 1, 1>), grid, dim3(512), 0, st, L); break;
+      case DOSX_PRO_LN_PRELU: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_LN_PRELU, 1, 1>), grid, dim3(512), 0, st, L); break;
+      case DOSX_PRO_ROWLN: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_ROWLN, 1, 1>), grid, dim3(512), 0, st, L); break;
+      default: DOSX_CHECK_ARG(false, "dosx_wgrad: bad prologue %d", g.pro);
+    }
   } else {
     switch (g.pro) {
-      case DOSX_PRO_NONE: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_NONE, 1>), grid, dim3(256), 0, st, L); break;
-      case DOSX_PRO_PRELU: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_PRELU, 1>), grid, dim3(256), 0, st, L); break;
-      case DOSX_PRO_LN_PRELU: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_LN_PRELU, 1>), grid, dim3(256), 0, st, L); break;
-      case DOSX_PRO_ROWLN: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_ROWLN, 1>), grid, dim3(256), 0, st, L); break;
+      case DOSX_PRO_NONE: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_NONE, 1, 0>), grid, dim3(512), 0, st, L); break;
+      case DOSX_PRO_PRELU: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_PRELU, 1, 0>), grid, dim3(512), 0, st, L); break;
+      case DOSX_PRO_LN_PRELU: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_LN_PRELU, 1, 0>), grid, dim3(512), 0, st, L); break;
+      case DOSX_PRO_ROWLN: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_ROWLN, 1, 0>), grid, dim3(512), 0, st, L); break;
       default: DOSX_CHECK_ARG(false, "dosx_wgrad: bad prologue %d", g.pro);
     }
   }

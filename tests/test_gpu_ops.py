@@ -200,6 +200,39 @@ def test_wgrad_prologues_and_gather():
     assert err(slab.sum(0), dy.double().T @ act) < TOL
 
 
+@pytest.mark.parametrize("M,N,K", [(15, 64, 16), (40, 64, 16), (100, 128, 32), (6528, 512, 128), (33, 16, 64)])
+def test_wgrad_rowln_prologue(M, N, K):
+    """dW of fc1 with the pre-FFN LayerNorm recomputed from saved (mean, rstd) (transformer.py:141-143)."""
+    o = ops()
+    dy, x, gam, bet = rnd(M, N, seed=1), rnd(M, K, seed=2), rnd(K, seed=3), rnd(K, seed=4)
+    mu = x.mean(1, keepdim=True)
+    rstd = 1 / torch.sqrt(x.var(1, unbiased=False, keepdim=True) + 1e-5)
+    stats = torch.cat([mu, rstd], 1).contiguous()
+    ns = o.wgrad_splits(M, N, K)
+    slab = torch.empty(ns, N, K, device=DEV)
+    slab_b = torch.empty(ns, N, device=DEV)
+    o.wgrad(M, N, o.seg(dy), [o.seg(x)], slab, slab_b, ns, pro=o.PRO_ROWLN, pro_gamma=gam, pro_beta=bet, pro_stats=stats)
+    ref = dy.double().T @ (((x - mu) * rstd) * gam + bet).double()
+    assert err(slab.sum(0), ref) < TOL
+    assert err(slab_b.sum(0), dy.double().sum(0)) < TOL
+
+
+def test_wgrad_gather_fast_path():
+    """cat[x[row], x[col], e] with 64-wide segments: every K tile lies inside one segment (buffer-addressed staging)."""
+    o = ops()
+    n, e, h = 40, 1000, 64
+    x, ea = rnd(n, h, seed=1), rnd(e, h, seed=2)
+    src = torch.randint(0, n, (e,), generator=torch.Generator().manual_seed(3)).to(torch.int32).to(DEV)
+    dst = torch.randint(0, n, (e,), generator=torch.Generator().manual_seed(4)).to(torch.int32).to(DEV)
+    dz = rnd(e, 2 * h, seed=5)
+    segs = [o.seg(x, rmap=o.rowmap(idx=src)), o.seg(x, rmap=o.rowmap(idx=dst)), o.seg(ea)]
+    ns = o.wgrad_splits(e, 2 * h, 3 * h)
+    slab = torch.empty(ns, 2 * h, 3 * h, device=DEV)
+    o.wgrad(e, 2 * h, o.seg(dz), segs, slab, None, ns)
+    cat = torch.cat([x[src.long()], x[dst.long()], ea], 1).double()
+    assert err(slab.sum(0), dz.double().T @ cat) < TOL
+
+
 @pytest.mark.parametrize("M,H2", [(100, 256), (45, 512), (33, 32)])
 def test_gemm_prelu_ln_bwd_epilogue(M, H2):
     o = ops()
