@@ -9,6 +9,18 @@
 // softmax is exact (no online rescaling).  QK^T and PV run on v_mfma_f32_32x32x2_f32.
 #include "common.h"
 
+// Diagnostic build only (-DDOSX_STAMPS): wave 0 of workgroup (0,0) records s_memtime at phase boundaries.
+#ifdef DOSX_STAMPS
+extern "C" { __device__ unsigned long long dosx_attn_stamp_buf[64]; }
+#define ASTAMP(slot)                                                                     \
+  do {                                                                                   \
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0)                          \
+      dosx_attn_stamp_buf[(slot)] = __builtin_amdgcn_s_memtime();                        \
+  } while (0)
+#else
+#define ASTAMP(slot) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int QT = 32;           // query rows per workgroup
@@ -83,12 +95,28 @@ __device__ __forceinline__ void stage_v_chunk(float* Vs, const float* __restrict
 __device__ __forceinline__ void stage_k_full(float* Ks, const float* __restrict__ kvhat, const float* __restrict__ gamma,
                                              const float* __restrict__ beta, int Nk, int NKP, int Bk, int bk, int H, int HP,
                                              int LDH, int tid) {
-  for (int c = (tid & 7) * 4; c < HP; c += 32) {
-    const int cc = c < H ? c : 0;
-    const float4 g = ld4(gamma + cc), b = ld4(beta + cc);
-    for (int j = tid >> 3; j < NKP; j += 32) {
-      const float4 h = ld4(kvhat + ((size_t)min(j, Nk - 1) * Bk + bk) * H + cc);
-      float4 v = make_float4(h.x * g.x + b.x, h.y * g.y + b.y, h.z * g.z + b.z, h.w * g.w + b.w);
+  // items: (32-key block jb, 32-column block cb); this thread owns key jb*32 + tid/8, columns cb*32 + (tid%8)*4.
+  // Loads are issued in batches of 8 before any is used (a load-use-store loop exposes one global round
+  // trip per item: ~0.7 us each, 4..8 of them in front of the first MFMA).
+  const int ncb = HP / 32, nit = (NKP / 32) * ncb;
+  const int jr = tid >> 3, cq = (tid & 7) * 4;
+  for (int i0 = 0; i0 < nit; i0 += 8) {
+    float4 h[8], gq[8], bq[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int it = min(i0 + u, nit - 1);
+      const int j = (it / ncb) * 32 + jr, c = (it % ncb) * 32 + cq, cc = c < H ? c : 0;
+      h[u] = ld4(kvhat + ((size_t)min(j, Nk - 1) * Bk + bk) * H + cc);
+      gq[u] = ld4(gamma + cc);
+      bq[u] = ld4(beta + cc);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int it = i0 + u;
+      if (it >= nit) break;
+      const int j = (it / ncb) * 32 + jr, c = (it % ncb) * 32 + cq;
+      float4 v = make_float4(h[u].x * gq[u].x + bq[u].x, h[u].y * gq[u].y + bq[u].y, h[u].z * gq[u].z + bq[u].z,
+                             h[u].w * gq[u].w + bq[u].w);
       if (!(j < Nk && c < H)) v = f4zero();
       st4(Ks + j * LDH + c, v);
     }
@@ -239,19 +267,25 @@ __device__ __forceinline__ void store_out_tile(const f32x16 (&acc)[MAX_CT], floa
   }
 }
 
-constexpr int RW = 8;      // query rows per wave in the row phases (32-row tile / 4 waves)
-constexpr int MAXJ = 5;    // keys per lane in the softmax phases (Nk <= 320)
+// ---- row phases --------------------------------------------------------------------------------
+// LayerNorm of the queries, softmax, residual + statistics, dS and the LayerNorm backward all work on
+// whole rows.  Layout: a wave owns 8 rows of the 32-row tile and processes them in 2 passes of 4 rows,
+// one QUARTER WAVE (16 lanes = one DPP row) per row: lane q of a row owns columns 4q + 64k (k < KCB)
+// and keys q + 16 jj (jj < NJ).  A reduction is then 4 DPP instructions for 4 rows at once
+// (row16_sum); the first version gave each row a full wave and paid a 64-lane reduction (DPP +
+// v_readlane) per row: 16 of them per phase were ~5k clk of the 33k-clk forward kernel (stamps).
+constexpr int RP = 2;      // passes (4 rows each) per wave
+constexpr int KCB = 4;     // 64-column blocks per row (H <= 256)
+
+__device__ __forceinline__ int row_of(int wave, int p, int lane) { return wave * 8 + p * 4 + (lane >> 4); }
 
 // ================================== forward =====================================================
-// Row phases (LayerNorm of the queries, softmax, residual + statistics) keep a wave's 8 rows in
-// REGISTERS (lane l owns columns 4l..4l+3, H <= 256) and run the 8 reductions as independent chains:
-// a row-at-a-time loop through LDS cost ~8 exposed latency chains per phase and a global round trip
-// per row for the residual (the raw query rows are simply kept from the first load).
-template <bool KRES>
+// NJ = ceil(Nk / 16): keys per lane in the softmax (compile time: 1 / 4 / 20 cover Nk <= 16 / 64 / 320).
+template <bool KRES, int NJ>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const DosxAttn a) {
   extern __shared__ __align__(16) float sm[];
   const Geo g = make_geo(a.H, a.Nk);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q16 = lane & 15;
   const QkSplit q = make_split(g.NKP, g.HP, KRES, wave);
   float* Qs = sm;                                   // [32][LDH]   (later: output tile)
   float* Ss = Qs + QT * g.LDH;                      // [ks][32][LDS_] partial scores; tile 0 becomes P
@@ -259,71 +293,95 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const DosxAttn a) {
   const int s0 = blockIdx.x * QT, bq = blockIdx.y, bk = bq % a.Bk;
   const int H = a.H, Sq = a.Sq, Nk = a.Nk;
   const bool raw_q = (a.flags & DOSX_ATTN_RAW_Q) != 0;
-  const int c0 = lane * 4;
-  const bool con = c0 < H;                          // this lane owns 4 real columns
   const float invH = 1.f / (float)H;
+  ASTAMP(0);
 
   // ---- query rows: global -> registers (kept for the residual) -> LayerNorm -> LDS ----
-  float4 xr[RW];
+  float4 xr[RP][KCB], g0[KCB], b0[KCB];
 #pragma unroll
-  for (int i = 0; i < RW; ++i) {
-    const int s = min(s0 + wave * RW + i, Sq - 1);
-    xr[i] = ld4(a.x + ((size_t)s * a.q_stride_s + (size_t)bq * a.q_stride_b) * H + (con ? c0 : 0));
+  for (int k = 0; k < KCB; ++k) {
+    const int c = q16 * 4 + 64 * k, cc = c < H ? c : 0;
+    g0[k] = ld4(a.gamma0 + cc);
+    b0[k] = ld4(a.beta0 + cc);
+#pragma unroll
+    for (int p = 0; p < RP; ++p) {
+      const int s = min(s0 + row_of(wave, p, lane), Sq - 1);
+      xr[p][k] = ld4(a.x + ((size_t)s * a.q_stride_s + (size_t)bq * a.q_stride_b) * H + cc);
+    }
   }
-  const float4 g0 = ld4(a.gamma0 + (con ? c0 : 0)), b0 = ld4(a.beta0 + (con ? c0 : 0));
   if (KRES) stage_k_full(KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, g.LDH, tid);
+  ASTAMP(1);
   {
-    float mean[RW], rstd[RW];
+    float mean[RP], rstd[RP];
 #pragma unroll
-    for (int i = 0; i < RW; ++i) {
-      const float4 v = xr[i];
-      mean[i] = con ? (v.x + v.y) + (v.z + v.w) : 0.f;
+    for (int p = 0; p < RP; ++p) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < KCB; ++k)
+        if (q16 * 4 + 64 * k < H) t += (xr[p][k].x + xr[p][k].y) + (xr[p][k].z + xr[p][k].w);
+      mean[p] = t;
     }
 #pragma unroll
-    for (int i = 0; i < RW; ++i) mean[i] = wave_sum(mean[i]) * invH;
+    for (int p = 0; p < RP; ++p) mean[p] = row16_sum(mean[p]) * invH;
 #pragma unroll
-    for (int i = 0; i < RW; ++i) {
-      const float4 v = xr[i];
-      const float p0 = v.x - mean[i], p1 = v.y - mean[i], p2 = v.z - mean[i], p3 = v.w - mean[i];
-      rstd[i] = con ? (p0 * p0 + p1 * p1) + (p2 * p2 + p3 * p3) : 0.f;
+    for (int p = 0; p < RP; ++p) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < KCB; ++k) {
+        if (q16 * 4 + 64 * k < H) {
+          const float p0 = xr[p][k].x - mean[p], p1 = xr[p][k].y - mean[p], p2 = xr[p][k].z - mean[p],
+                      p3 = xr[p][k].w - mean[p];
+          t += (p0 * p0 + p1 * p1) + (p2 * p2 + p3 * p3);
+        }
+      }
+      rstd[p] = t;
     }
 #pragma unroll
-    for (int i = 0; i < RW; ++i) rstd[i] = rsqrtf(wave_sum(rstd[i]) * invH + DOSX_LN_EPS);
+    for (int p = 0; p < RP; ++p) rstd[p] = rsqrtf(row16_sum(rstd[p]) * invH + DOSX_LN_EPS);
 #pragma unroll
-    for (int i = 0; i < RW; ++i) {
-      const int lr = wave * RW + i, s = s0 + lr;
-      const float4 v = xr[i];
-      float4 o = v;
-      if (!raw_q)
-        o = make_float4((v.x - mean[i]) * rstd[i] * g0.x + b0.x, (v.y - mean[i]) * rstd[i] * g0.y + b0.y,
-                        (v.z - mean[i]) * rstd[i] * g0.z + b0.z, (v.w - mean[i]) * rstd[i] * g0.w + b0.w);
-      if (!(con && s < Sq)) o = f4zero();
-      if (c0 < g.HP) st4(Qs + lr * g.LDH + c0, o);
-      if (!raw_q && a.qstats && lane == 0 && s < Sq) {
-        a.qstats[2 * ((size_t)s * a.Bq + bq)] = mean[i];
-        a.qstats[2 * ((size_t)s * a.Bq + bq) + 1] = rstd[i];
+    for (int p = 0; p < RP; ++p) {
+      const int lr = row_of(wave, p, lane), s = s0 + lr;
+#pragma unroll
+      for (int k = 0; k < KCB; ++k) {
+        const int c = q16 * 4 + 64 * k;
+        if (c >= g.HP) continue;
+        const float4 v = xr[p][k];
+        float4 o = v;
+        if (!raw_q)
+          o = make_float4((v.x - mean[p]) * rstd[p] * g0[k].x + b0[k].x, (v.y - mean[p]) * rstd[p] * g0[k].y + b0[k].y,
+                          (v.z - mean[p]) * rstd[p] * g0[k].z + b0[k].z, (v.w - mean[p]) * rstd[p] * g0[k].w + b0[k].w);
+        if (!(c < H && s < Sq)) o = f4zero();
+        st4(Qs + lr * g.LDH + c, o);
+      }
+      if (!raw_q && a.qstats && q16 == 0 && s < Sq) {
+        a.qstats[2 * ((size_t)s * a.Bq + bq)] = mean[p];
+        a.qstats[2 * ((size_t)s * a.Bq + bq) + 1] = rstd[p];
       }
     }
   }
+  ASTAMP(2);
   __syncthreads();
+  ASTAMP(3);
 
   f32x16 sacc[MAX_KT];
   qk_product<KRES>(sacc, Qs, g.LDH, KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, tid, q);
   store_scores(sacc, Ss, g.LDS_, g.NKP, tid, q);
+  ASTAMP(4);
   __syncthreads();
+  ASTAMP(5);
 
   // ---- exact fp32 softmax over the Nk keys (padded atoms included, like the reference) ----
   {
     const float scale = rsqrtf((float)H);
     const int pstride = QT * g.LDS_;
-    float v[RW][MAXJ], mx[RW], sum[RW];
+    float v[RP][NJ], mx[RP], sum[RP];
 #pragma unroll
-    for (int i = 0; i < RW; ++i) {
-      const float* row = Ss + (wave * RW + i) * g.LDS_;
-      mx[i] = -INFINITY;
+    for (int p = 0; p < RP; ++p) {
+      const float* row = Ss + row_of(wave, p, lane) * g.LDS_;
+      mx[p] = -INFINITY;
 #pragma unroll
-      for (int jj = 0; jj < MAXJ; ++jj) {
-        const int j = lane + 64 * jj;
+      for (int jj = 0; jj < NJ; ++jj) {
+        const int j = q16 + 16 * jj;
         float t = -INFINITY;
         if (j < Nk) {
           t = row[j];
@@ -331,124 +389,157 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const DosxAttn a) {
           if (q.ks > 2) t += row[2 * pstride + j] + row[3 * pstride + j];
           t *= scale;
         }
-        v[i][jj] = t;
-        mx[i] = fmaxf(mx[i], t);
+        v[p][jj] = t;
+        mx[p] = fmaxf(mx[p], t);
       }
     }
 #pragma unroll
-    for (int i = 0; i < RW; ++i) mx[i] = wave_max(mx[i]);
+    for (int p = 0; p < RP; ++p) mx[p] = row16_max(mx[p]);
 #pragma unroll
-    for (int i = 0; i < RW; ++i) {
-      sum[i] = 0.f;
+    for (int p = 0; p < RP; ++p) {
+      sum[p] = 0.f;
 #pragma unroll
-      for (int jj = 0; jj < MAXJ; ++jj) {
-        const float e = (lane + 64 * jj) < Nk ? expf(v[i][jj] - mx[i]) : 0.f;
-        v[i][jj] = e;
-        sum[i] += e;
+      for (int jj = 0; jj < NJ; ++jj) {
+        const float e = (q16 + 16 * jj) < Nk ? expf(v[p][jj] - mx[p]) : 0.f;
+        v[p][jj] = e;
+        sum[p] += e;
       }
     }
 #pragma unroll
-    for (int i = 0; i < RW; ++i) sum[i] = 1.f / wave_sum(sum[i]);
+    for (int p = 0; p < RP; ++p) sum[p] = 1.f / row16_sum(sum[p]);
 #pragma unroll
-    for (int i = 0; i < RW; ++i) {
-      const int lr = wave * RW + i, s = s0 + lr;
+    for (int p = 0; p < RP; ++p) {
+      const int lr = row_of(wave, p, lane), s = s0 + lr;
       float* row = Ss + lr * g.LDS_;
 #pragma unroll
-      for (int jj = 0; jj < MAXJ; ++jj) {
-        const int j = lane + 64 * jj;
+      for (int jj = 0; jj < NJ; ++jj) {
+        const int j = q16 + 16 * jj;
         if (j >= g.NKP) continue;
-        const float pr = v[i][jj] * sum[i];           // 0 beyond Nk
+        const float pr = v[p][jj] * sum[p];           // 0 beyond Nk
         row[j] = pr;
         if (j < Nk && s < Sq) a.probs[((size_t)bq * Sq + s) * Nk + j] = pr;
       }
+      if (NJ * 16 < g.NKP) {                          // (NJ*16 >= Nk always; zero the rest of the padded tile)
+        for (int j = NJ * 16 + q16; j < g.NKP; j += 16) row[j] = 0.f;
+      }
     }
   }
+  ASTAMP(6);
   __syncthreads();
+  ASTAMP(7);
 
   f32x16 oacc[MAX_CT];
   pv_product<KRES>(oacc, Ss, g.LDS_, KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, g.LDH, tid);
   store_out_tile(oacc, Qs, g.LDH, g.HP, tid);
+  ASTAMP(8);
   __syncthreads();
+  ASTAMP(9);
 
   // ---- epilogue: residual add from the kept query rows, statistics of the output rows (feeds LN1) ----
   {
     const bool no_res = (a.flags & DOSX_ATTN_NO_RESIDUAL) != 0;
-    float4 o[RW];
-    float mean[RW], var[RW];
+    float4 o[RP][KCB];
+    float mean[RP], var[RP];
 #pragma unroll
-    for (int i = 0; i < RW; ++i) {
-      const int lr = wave * RW + i, s = s0 + lr;
-      float4 v = con ? ld4(Qs + lr * g.LDH + c0) : f4zero();
-      if (!no_res) v = f4add(v, xr[i]);
-      o[i] = v;
-      if (con && s < Sq) st4(a.out + ((size_t)s * a.Bq + bq) * H + c0, v);
-      mean[i] = con ? (v.x + v.y) + (v.z + v.w) : 0.f;
+    for (int p = 0; p < RP; ++p) {
+      const int lr = row_of(wave, p, lane), s = s0 + lr;
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < KCB; ++k) {
+        const int c = q16 * 4 + 64 * k;
+        float4 v = f4zero();
+        if (c < H) {
+          v = ld4(Qs + lr * g.LDH + c);
+          if (!no_res) v = f4add(v, xr[p][k]);
+          if (s < Sq) st4(a.out + ((size_t)s * a.Bq + bq) * H + c, v);
+          t += (v.x + v.y) + (v.z + v.w);
+        }
+        o[p][k] = v;
+      }
+      mean[p] = t;
     }
     if (a.out_stats) {
 #pragma unroll
-      for (int i = 0; i < RW; ++i) mean[i] = wave_sum(mean[i]) * invH;
+      for (int p = 0; p < RP; ++p) mean[p] = row16_sum(mean[p]) * invH;
 #pragma unroll
-      for (int i = 0; i < RW; ++i) {
-        const float p0 = o[i].x - mean[i], p1 = o[i].y - mean[i], p2 = o[i].z - mean[i], p3 = o[i].w - mean[i];
-        var[i] = con ? (p0 * p0 + p1 * p1) + (p2 * p2 + p3 * p3) : 0.f;
+      for (int p = 0; p < RP; ++p) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < KCB; ++k) {
+          if (q16 * 4 + 64 * k < H) {
+            const float p0 = o[p][k].x - mean[p], p1 = o[p][k].y - mean[p], p2 = o[p][k].z - mean[p],
+                        p3 = o[p][k].w - mean[p];
+            t += (p0 * p0 + p1 * p1) + (p2 * p2 + p3 * p3);
+          }
+        }
+        var[p] = t;
       }
 #pragma unroll
-      for (int i = 0; i < RW; ++i) var[i] = wave_sum(var[i]) * invH;
+      for (int p = 0; p < RP; ++p) var[p] = row16_sum(var[p]) * invH;
 #pragma unroll
-      for (int i = 0; i < RW; ++i) {
-        const int s = s0 + wave * RW + i;
-        if (lane == 0 && s < Sq) {
-          a.out_stats[2 * ((size_t)s * a.Bq + bq)] = mean[i];
-          a.out_stats[2 * ((size_t)s * a.Bq + bq) + 1] = rsqrtf(var[i] + DOSX_LN_EPS);
+      for (int p = 0; p < RP; ++p) {
+        const int s = s0 + row_of(wave, p, lane);
+        if (q16 == 0 && s < Sq) {
+          a.out_stats[2 * ((size_t)s * a.Bq + bq)] = mean[p];
+          a.out_stats[2 * ((size_t)s * a.Bq + bq) + 1] = rsqrtf(var[p] + DOSX_LN_EPS);
         }
       }
     }
   }
+  ASTAMP(10);
 }
 
 // ================================== backward: dq / dx ============================================
-template <bool KRES>
+template <bool KRES, int NJ>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const DosxAttn a) {
   extern __shared__ __align__(16) float sm[];
   const Geo g = make_geo(a.H, a.Nk);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q16 = lane & 15;
   const QkSplit q = make_split(g.NKP, g.HP, KRES, wave);
   float* Ds = sm;                                   // [32][LDH]  dOut tile, later dq tile
   float* Ss = Ds + QT * g.LDH;                      // [ks][32][LDS_] partial dP; tile 0 becomes dS
   float* KV = Ss + q.ks * QT * g.LDS_;              // chunk staging, or the whole key tile (KRES)
-  float* Pp = KV + (KRES ? g.NKP * g.LDH : max(g.NKP * LDK, KC * g.LDH));    // [4][2][HP] partial column sums
+  float* Pp = KV + (KRES ? g.NKP * g.LDH : max(g.NKP * LDK, KC * g.LDH));    // [16][2][HP] partial column sums
   const int s0 = blockIdx.x * QT, bq = blockIdx.y, bk = bq % a.Bk;
   const int H = a.H, Sq = a.Sq, Nk = a.Nk;
   const bool raw_q = (a.flags & DOSX_ATTN_RAW_Q) != 0, no_res = (a.flags & DOSX_ATTN_NO_RESIDUAL) != 0;
-  const int c0 = lane * 4;
-  const bool con = c0 < H;
   const float invH = 1.f / (float)H;
 
-  // ---- this wave's 8 rows of dOut (kept for the residual) and of x, their statistics, their P row ----
-  float4 go[RW], xr[RW];
-  float mean[RW], rstd[RW], pr[RW][MAXJ];
+  // ---- this wave's rows of dOut (kept for the residual) and of x, their statistics, their P row ----
+  float4 go[RP][KCB], xr[RP][KCB], g0[KCB];
+  float mean[RP], rstd[RP], pr[RP][NJ];
 #pragma unroll
-  for (int i = 0; i < RW; ++i) {
-    const int s = min(s0 + wave * RW + i, Sq - 1);
+  for (int p = 0; p < RP; ++p) {
+    const int s = min(s0 + row_of(wave, p, lane), Sq - 1);
     const size_t orow = (size_t)s * a.Bq + bq;
-    go[i] = ld4(a.dout + orow * H + (con ? c0 : 0));
-    xr[i] = ld4(a.x + ((size_t)s * a.q_stride_s + (size_t)bq * a.q_stride_b) * H + (con ? c0 : 0));
-    mean[i] = raw_q ? 0.f : a.qstats[2 * orow];
-    rstd[i] = raw_q ? 1.f : a.qstats[2 * orow + 1];
 #pragma unroll
-    for (int jj = 0; jj < MAXJ; ++jj) {
-      const int j = lane + 64 * jj;
-      pr[i][jj] = a.probs[((size_t)bq * Sq + s) * Nk + (j < Nk ? j : 0)];
+    for (int k = 0; k < KCB; ++k) {
+      const int c = q16 * 4 + 64 * k, cc = c < H ? c : 0;
+      go[p][k] = ld4(a.dout + orow * H + cc);
+      xr[p][k] = ld4(a.x + ((size_t)s * a.q_stride_s + (size_t)bq * a.q_stride_b) * H + cc);
+    }
+    mean[p] = raw_q ? 0.f : a.qstats[2 * orow];
+    rstd[p] = raw_q ? 1.f : a.qstats[2 * orow + 1];
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+      const int j = q16 + 16 * jj;
+      pr[p][jj] = a.probs[((size_t)bq * Sq + s) * Nk + (j < Nk ? j : 0)];
     }
   }
-  const float4 g0 = ld4(a.gamma0 + (con ? c0 : 0));
+#pragma unroll
+  for (int k = 0; k < KCB; ++k) g0[k] = ld4(a.gamma0 + ((q16 * 4 + 64 * k) < H ? (q16 * 4 + 64 * k) : 0));
   if (KRES) stage_k_full(KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, g.LDH, tid);
 #pragma unroll
-  for (int i = 0; i < RW; ++i) {
-    const int lr = wave * RW + i;
-    float4 d = go[i];
-    if (!(con && (s0 + lr) < Sq)) d = f4zero();
-    if (c0 < g.HP) st4(Ds + lr * g.LDH + c0, d);
+  for (int p = 0; p < RP; ++p) {
+    const int lr = row_of(wave, p, lane);
+#pragma unroll
+    for (int k = 0; k < KCB; ++k) {
+      const int c = q16 * 4 + 64 * k;
+      if (c >= g.HP) continue;
+      float4 d = go[p][k];
+      if (!(c < H && (s0 + lr) < Sq)) d = f4zero();
+      st4(Ds + lr * g.LDH + c, d);
+    }
   }
   __syncthreads();
 
@@ -462,37 +553,40 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const DosxAttn a) {
   {
     const float scale = rsqrtf((float)H);
     const int pstride = QT * g.LDS_;
-    float dp[RW][MAXJ], dot[RW];
+    float dp[RP][NJ], dot[RP];
 #pragma unroll
-    for (int i = 0; i < RW; ++i) {
-      const float* row = Ss + (wave * RW + i) * g.LDS_;
-      dot[i] = 0.f;
+    for (int p = 0; p < RP; ++p) {
+      const float* row = Ss + row_of(wave, p, lane) * g.LDS_;
+      dot[p] = 0.f;
 #pragma unroll
-      for (int jj = 0; jj < MAXJ; ++jj) {
-        const int j = lane + 64 * jj;
+      for (int jj = 0; jj < NJ; ++jj) {
+        const int j = q16 + 16 * jj;
         float t = 0.f;
         if (j < Nk) {
           t = row[j];
           if (q.ks > 1) t += row[pstride + j];
           if (q.ks > 2) t += row[2 * pstride + j] + row[3 * pstride + j];
-          dot[i] += pr[i][jj] * t;
+          dot[p] += pr[p][jj] * t;
         }
-        dp[i][jj] = t;
+        dp[p][jj] = t;
       }
     }
 #pragma unroll
-    for (int i = 0; i < RW; ++i) dot[i] = wave_sum(dot[i]);
+    for (int p = 0; p < RP; ++p) dot[p] = row16_sum(dot[p]);
 #pragma unroll
-    for (int i = 0; i < RW; ++i) {
-      const int lr = wave * RW + i, s = s0 + lr;
+    for (int p = 0; p < RP; ++p) {
+      const int lr = row_of(wave, p, lane), s = s0 + lr;
       float* row = Ss + lr * g.LDS_;
 #pragma unroll
-      for (int jj = 0; jj < MAXJ; ++jj) {
-        const int j = lane + 64 * jj;
+      for (int jj = 0; jj < NJ; ++jj) {
+        const int j = q16 + 16 * jj;
         if (j >= g.NKP) continue;
-        const float ds = (j < Nk && s < Sq) ? pr[i][jj] * (dp[i][jj] - dot[i]) * scale : 0.f;
+        const float ds = (j < Nk && s < Sq) ? pr[p][jj] * (dp[p][jj] - dot[p]) * scale : 0.f;
         row[j] = ds;
         if (j < Nk && s < Sq) a.dscores[((size_t)bq * Sq + s) * Nk + j] = ds;
+      }
+      if (NJ * 16 < g.NKP) {
+        for (int j = NJ * 16 + q16; j < g.NKP; j += 16) row[j] = 0.f;
       }
     }
   }
@@ -506,44 +600,61 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const DosxAttn a) {
 
   // LN0 backward on the query rows + residual;  partial dgamma0 / dbeta0 (query side)
   {
-    float4 pg = f4zero(), pb = f4zero();
-    float4 d[RW], xh[RW];
-    float s1[RW], s2[RW];
+    float4 pg[KCB], pb[KCB], d[RP][KCB], xh[RP][KCB];
+    float s1[RP], s2[RP];
 #pragma unroll
-    for (int i = 0; i < RW; ++i) {
-      const int lr = wave * RW + i;
-      const bool rv = con && (s0 + lr) < Sq;
-      d[i] = rv ? ld4(Ds + lr * g.LDH + c0) : f4zero();
-      const float4 xv = xr[i];
-      xh[i] = make_float4((xv.x - mean[i]) * rstd[i], (xv.y - mean[i]) * rstd[i], (xv.z - mean[i]) * rstd[i],
-                          (xv.w - mean[i]) * rstd[i]);
-      if (!rv) xh[i] = f4zero();
-      pg.x += d[i].x * xh[i].x; pg.y += d[i].y * xh[i].y; pg.z += d[i].z * xh[i].z; pg.w += d[i].w * xh[i].w;
-      pb = f4add(pb, d[i]);
-      const float4 dh = make_float4(d[i].x * g0.x, d[i].y * g0.y, d[i].z * g0.z, d[i].w * g0.w);
-      s1[i] = (dh.x + dh.y) + (dh.z + dh.w);
-      s2[i] = (dh.x * xh[i].x + dh.y * xh[i].y) + (dh.z * xh[i].z + dh.w * xh[i].w);
+    for (int k = 0; k < KCB; ++k) { pg[k] = f4zero(); pb[k] = f4zero(); }
+#pragma unroll
+    for (int p = 0; p < RP; ++p) {
+      const int lr = row_of(wave, p, lane);
+      s1[p] = 0.f; s2[p] = 0.f;
+#pragma unroll
+      for (int k = 0; k < KCB; ++k) {
+        const int c = q16 * 4 + 64 * k;
+        const bool rv = c < H && (s0 + lr) < Sq;
+        const float4 dd = rv ? ld4(Ds + lr * g.LDH + c) : f4zero();
+        const float4 xv = xr[p][k];
+        float4 h = make_float4((xv.x - mean[p]) * rstd[p], (xv.y - mean[p]) * rstd[p], (xv.z - mean[p]) * rstd[p],
+                               (xv.w - mean[p]) * rstd[p]);
+        if (!rv) h = f4zero();
+        d[p][k] = dd; xh[p][k] = h;
+        pg[k].x += dd.x * h.x; pg[k].y += dd.y * h.y; pg[k].z += dd.z * h.z; pg[k].w += dd.w * h.w;
+        pb[k] = f4add(pb[k], dd);
+        const float4 dh = make_float4(dd.x * g0[k].x, dd.y * g0[k].y, dd.z * g0[k].z, dd.w * g0[k].w);
+        s1[p] += (dh.x + dh.y) + (dh.z + dh.w);
+        s2[p] += (dh.x * h.x + dh.y * h.y) + (dh.z * h.z + dh.w * h.w);
+      }
     }
     if (!raw_q) {
 #pragma unroll
-      for (int i = 0; i < RW; ++i) { s1[i] = wave_sum(s1[i]) * invH; s2[i] = wave_sum(s2[i]) * invH; }
+      for (int p = 0; p < RP; ++p) { s1[p] = row16_sum(s1[p]) * invH; s2[p] = row16_sum(s2[p]) * invH; }
     }
 #pragma unroll
-    for (int i = 0; i < RW; ++i) {
-      const int s = s0 + wave * RW + i;
-      if (!(con && s < Sq)) continue;
-      float4 o;
-      if (raw_q) o = d[i];
-      else
-        o = make_float4(rstd[i] * (d[i].x * g0.x - s1[i] - xh[i].x * s2[i]), rstd[i] * (d[i].y * g0.y - s1[i] - xh[i].y * s2[i]),
-                        rstd[i] * (d[i].z * g0.z - s1[i] - xh[i].z * s2[i]), rstd[i] * (d[i].w * g0.w - s1[i] - xh[i].w * s2[i]));
-      if (!no_res) o = f4add(o, go[i]);
-      st4(a.dx + ((size_t)s * a.Bq + bq) * H + c0, o);
+    for (int p = 0; p < RP; ++p) {
+      const int s = s0 + row_of(wave, p, lane);
+#pragma unroll
+      for (int k = 0; k < KCB; ++k) {
+        const int c = q16 * 4 + 64 * k;
+        if (!(c < H && s < Sq)) continue;
+        const float4 dd = d[p][k], h = xh[p][k];
+        float4 o;
+        if (raw_q) o = dd;
+        else
+          o = make_float4(rstd[p] * (dd.x * g0[k].x - s1[p] - h.x * s2[p]), rstd[p] * (dd.y * g0[k].y - s1[p] - h.y * s2[p]),
+                          rstd[p] * (dd.z * g0[k].z - s1[p] - h.z * s2[p]), rstd[p] * (dd.w * g0[k].w - s1[p] - h.w * s2[p]));
+        if (!no_res) o = f4add(o, go[p][k]);
+        st4(a.dx + ((size_t)s * a.Bq + bq) * H + c, o);
+      }
     }
-    if (raw_q) { pg = f4zero(); pb = f4zero(); }
-    if (c0 < g.HP) {
-      st4(Pp + wave * 2 * g.HP + c0, pg);
-      st4(Pp + wave * 2 * g.HP + g.HP + c0, pb);
+    // column partial sums: one slot per quarter wave (16 slots), summed in a fixed order below
+    const int slot = wave * 4 + (lane >> 4);
+#pragma unroll
+    for (int k = 0; k < KCB; ++k) {
+      const int c = q16 * 4 + 64 * k;
+      if (c >= g.HP) continue;
+      if (raw_q) { pg[k] = f4zero(); pb[k] = f4zero(); }
+      st4(Pp + slot * 2 * g.HP + c, pg[k]);
+      st4(Pp + slot * 2 * g.HP + g.HP + c, pb[k]);
     }
   }
   __syncthreads();
@@ -551,7 +662,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const DosxAttn a) {
   for (int c = tid; c < 2 * H; c += 256) {
     const int which = c / H, col = c % H;
     const int o = which * g.HP + col;
-    prow[c] = Pp[o] + Pp[2 * g.HP + o] + Pp[4 * g.HP + o] + Pp[6 * g.HP + o];
+    float t = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl) t += Pp[sl * 2 * g.HP + o];
+    prow[c] = t;
   }
 }
 
@@ -696,7 +810,7 @@ size_t fwd_smem(const Geo& g, bool kres) {
 }
 size_t dq_smem(const Geo& g, bool kres) {
   return sizeof(float) * (size_t)(QT * g.LDH + qk_ks(g.NKP, g.HP, kres) * QT * g.LDS_ +
-                                  (kres ? g.NKP * g.LDH : max(g.NKP * LDK, KC * g.LDH)) + 8 * g.HP);
+                                  (kres ? g.NKP * g.LDH : max(g.NKP * LDK, KC * g.LDH)) + 32 * g.HP);
 }
 constexpr size_t KRES_LDS_LIMIT = 144 * 1024;   // keep the whole key tile of a crystal in LDS when it fits
 size_t dkv_smem(const Geo& g) { return sizeof(float) * (size_t)(2 * QT * g.LDH + 2 * QT * LDK + 8 * g.HP); }
@@ -721,17 +835,21 @@ extern "C" int dosx_attention_fwd(const DosxAttn* ap, dosx_stream_t stream) {
   const bool kres = fwd_smem(g, true) <= KRES_LDS_LIMIT;
   const size_t smem = fwd_smem(g, kres);
   DOSX_CHECK_ARG(smem <= 160 * 1024, "dosx_attention_fwd: LDS need %zu > 160 KiB", smem);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
   const dim3 grid(ceil_div(a.Sq, QT), a.Bq);
-  if (kres) hipLaunchKernelGGL((attn_fwd_kernel<true>), grid, dim3(256), smem, to_stream(stream), a);
-  else hipLaunchKernelGGL((attn_fwd_kernel<false>), grid, dim3(256), smem, to_stream(stream), a);
+  const int nj = a.Nk <= 16 ? 1 : (a.Nk <= 64 ? 4 : 20);
+#define DOSX_FWD(KR, NJ_)                                                                                   \
+  do {                                                                                                      \
+    static bool attr_set = false;                                                                           \
+    if (!attr_set) {                                                                                        \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<KR, NJ_>),                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
+      attr_set = true;                                                                                      \
+    }                                                                                                       \
+    hipLaunchKernelGGL((attn_fwd_kernel<KR, NJ_>), grid, dim3(256), smem, to_stream(stream), a);            \
+  } while (0)
+  if (kres) { if (nj == 1) DOSX_FWD(true, 1); else if (nj == 4) DOSX_FWD(true, 4); else DOSX_FWD(true, 20); }
+  else { if (nj == 1) DOSX_FWD(false, 1); else if (nj == 4) DOSX_FWD(false, 4); else DOSX_FWD(false, 20); }
+#undef DOSX_FWD
   DOSX_LAUNCH_CHECK();
   return 0;
 }
@@ -747,18 +865,26 @@ extern "C" int dosx_attention_bwd(const DosxAttn* ap, dosx_stream_t stream) {
   DOSX_CHECK_ARG(s1 <= 160 * 1024 && s2 <= 160 * 1024, "dosx_attention_bwd: LDS need %zu/%zu > 160 KiB", s1, s2);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   const dim3 grid(ceil_div(a.Sq, QT), a.Bq);
   if (!(a.flags & DOSX_ATTN_BWD_SKIP_DQ)) {
-    if (kres) hipLaunchKernelGGL((attn_bwd_dq_kernel<true>), grid, dim3(256), s1, to_stream(stream), a);
-    else hipLaunchKernelGGL((attn_bwd_dq_kernel<false>), grid, dim3(256), s1, to_stream(stream), a);
+    const int nj = a.Nk <= 16 ? 1 : (a.Nk <= 64 ? 4 : 20);
+#define DOSX_DQ(KR, NJ_)                                                                                    \
+  do {                                                                                                      \
+    static bool attr_dq = false;                                                                            \
+    if (!attr_dq) {                                                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<KR, NJ_>),                \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
+      attr_dq = true;                                                                                       \
+    }                                                                                                       \
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<KR, NJ_>), grid, dim3(256), s1, to_stream(stream), a);           \
+  } while (0)
+    if (kres) { if (nj == 1) DOSX_DQ(true, 1); else if (nj == 4) DOSX_DQ(true, 4); else DOSX_DQ(true, 20); }
+    else { if (nj == 1) DOSX_DQ(false, 1); else if (nj == 4) DOSX_DQ(false, 4); else DOSX_DQ(false, 20); }
+#undef DOSX_DQ
     DOSX_LAUNCH_CHECK();
   }
   if (!(a.flags & DOSX_ATTN_BWD_SKIP_DKV)) {
@@ -767,3 +893,9 @@ extern "C" int dosx_attention_bwd(const DosxAttn* ap, dosx_stream_t stream) {
   }
   return 0;
 }
+
+#ifdef DOSX_STAMPS
+extern "C" int dosx_debug_read_attn_stamps(unsigned long long* host64) {
+  return (int)hipMemcpyFromSymbol(host64, HIP_SYMBOL(dosx_attn_stamp_buf), sizeof(unsigned long long) * 64);
+}
+#endif

@@ -73,6 +73,24 @@ __device__ __forceinline__ float wave_max(float v) {
   return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
+// Sum / max over each 16-lane DPP row (quarter wave): 4 single-instruction steps, the result lands in
+// all 16 lanes, no cross-row step and no v_readlane.  The row phases of attention.hip give every query
+// row one quarter wave, so a wave reduces 4 rows per instruction sequence.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += DOSX_DPP_F(v, 0xB1);
+  v += DOSX_DPP_F(v, 0x4E);
+  v += DOSX_DPP_F(v, 0x141);
+  v += DOSX_DPP_F(v, 0x140);
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, DOSX_DPP_F(v, 0xB1));
+  v = fmaxf(v, DOSX_DPP_F(v, 0x4E));
+  v = fmaxf(v, DOSX_DPP_F(v, 0x141));
+  v = fmaxf(v, DOSX_DPP_F(v, 0x140));
+  return v;
+}
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
