@@ -169,8 +169,10 @@ __device__ __forceinline__ float4 a_finish(const AState& st, const ARaw& r, int 
 // own MFMAs.  With a staging wave next to each matrix wave the matrix pipe only stalls on the barrier.
 // The epilogue uses all 8 waves (4 rows each per 32-row block).
 // ---------------------------------------------------------------------------------------------
+// (128-column tiles with a light epilogue are held to 128 VGPRs = 4 waves per SIMD: two workgroups per CU)
 template <int RT, int NTW, int WL, int PRO, int VEC, int EPI>
-__global__ __launch_bounds__(512) void gemm_kernel(const GemmLaunch L) {
+__global__ __launch_bounds__(512, (NTW == 1 && (EPI == DOSX_EPI_BIAS_ACT || EPI == DOSX_EPI_LN || EPI == DOSX_EPI_RELU_MASK)) ? 4 : 2)
+void gemm_kernel(const GemmLaunch L) {
   const DosxGemm& g = L.g;
   constexpr int BMR = BM * RT;
   constexpr int BN = 128 * NTW;
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmLaunch L) {
 
   extern __shared__ __align__(16) float smem[];
   float* Cs = smem;
-  float* Ps = smem + CTILE;              // [8][2][BN] + 8 (behind the C tile; staging memory is dead by then)
+  float* Ps = smem + RT * CTILE;         // [8][2][BN] + 8 (behind the C tiles; staging memory is dead by then)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -197,6 +199,93 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmLaunch L) {
   f32x16 acc[RT][NTW];
 
   STAMP(0);
+  // ---- epilogue operand prefetch (all 8 waves; wave w owns rows 4w..4w+3 of each 32-row block) -----
+  // Every global operand of the row-wise epilogue (bias / gamma / beta vectors, the rows of `aux` and
+  // `res`, the per-row statistics) is loaded HERE, at kernel start, from always-valid (clamped)
+  // addresses: the loads fly under the whole k-loop and the row loop at the end touches no global
+  // memory except its stores (a load inside that loop costs one exposed L2/HBM round trip per row;
+  // issued after the k-loop they still cost one round trip per kernel: ~1.2k clk of a 30k-clk kernel).
+  const int ncols = min(BN, N - n0);
+  const float invN = 1.f / (float)N;
+  constexpr int epi = EPI;     // compile-time: only this epilogue's code exists in the kernel
+  constexpr bool is_prelu_ln = (epi == DOSX_EPI_PRELU_LN_BWD), is_rowln = (epi == DOSX_EPI_ROWLN_BWD);
+  constexpr bool aux_first = (epi != DOSX_EPI_BIAS_ACT && epi != DOSX_EPI_LN);   // operand 1 is `aux`
+  constexpr bool use_stats = is_prelu_ln || is_rowln;
+  const bool has1 = aux_first ? (g.aux != nullptr) : (g.res != nullptr && epi == DOSX_EPI_BIAS_ACT);
+  const bool has2 = is_rowln && g.res != nullptr;
+  const float* p1 = aux_first ? g.aux : g.res;
+  const int ld1 = aux_first ? g.ldaux : g.ldr;
+  float4 pg[CG], pb[CG];   // column partial sums (dgamma, dbeta) over all row blocks of this workgroup
+  float pal = 0.f;         // dalpha partial
+#pragma unroll
+  for (int j = 0; j < CG; ++j) { pg[j] = f4zero(); pb[j] = f4zero(); }
+  float e_alpha = 0.f;
+  if (epi == DOSX_EPI_PRELU_LN_BWD || epi == DOSX_EPI_PRELU_BWD) e_alpha = *g.epi_alpha;
+  bool on[CG];
+  int gcol[CG];
+  float4 biasv[CG], gamv[CG], betv[CG];
+#pragma unroll
+  for (int j = 0; j < CG; ++j) {
+    const int c = lane * 4 + 256 * j;
+    on[j] = c < ncols;
+    gcol[j] = n0 + (on[j] ? c : 0);
+    biasv[j] = f4zero(); gamv[j] = f4zero(); betv[j] = f4zero();
+    if (g.bias) biasv[j] = ld4(g.bias + gcol[j]);
+    if (use_stats) {
+      gamv[j] = ld4(g.epi_gamma + gcol[j]);
+      if (is_prelu_ln) betv[j] = ld4(g.epi_beta + gcol[j]);
+    }
+  }
+  float4 pv1[RT][ER][CG], pv2[RT][ER][CG];
+  float st0[RT][ER], st1[RT][ER];
+  size_t orow_[RT][ER];
+  // The per-row operands are hoisted above the k-loop only for the backward epilogues (they always have
+  // them).  The plain bias/activation epilogue keeps its registers for occupancy instead: at <= 128
+  // VGPRs two 8-wave workgroups share a CU, which matters more for its (larger) grids; its optional
+  // residual rows are fetched after the k-loop.
+  constexpr bool HOIST = (epi != DOSX_EPI_BIAS_ACT);
+  auto prefetch_rows = [&]() {
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int mb = m0 + 32 * rt;
+#pragma unroll
+    for (int i = 0; i < ER; ++i) {
+      const int rc = min(mb + wave * ER + i, M - 1);
+      orow_[rt][i] = (size_t)(epi == DOSX_EPI_BIAS_ACT ? dosx_map_row(g.out_map, rc) : rc) * g.ldo;
+      st0[rt][i] = 0.f; st1[rt][i] = 0.f;
+#pragma unroll
+      for (int j = 0; j < CG; ++j) { pv1[rt][i][j] = f4zero(); pv2[rt][i][j] = f4zero(); }
+    }
+    if (has1) {          // wave-uniform, outside every loop: the loads of all rows are issued back to back
+#pragma unroll
+      for (int i = 0; i < ER; ++i) {
+        const int rc = min(mb + wave * ER + i, M - 1);
+        const size_t r1 = (size_t)(aux_first ? rc : dosx_map_row(g.res_map, rc)) * ld1;
+#pragma unroll
+        for (int j = 0; j < CG; ++j) pv1[rt][i][j] = ld4(p1 + r1 + gcol[j]);
+      }
+    }
+    if (has2) {
+#pragma unroll
+      for (int i = 0; i < ER; ++i) {
+        const int rc = min(mb + wave * ER + i, M - 1);
+        const size_t r2 = (size_t)dosx_map_row(g.res_map, rc) * g.ldr;
+#pragma unroll
+        for (int j = 0; j < CG; ++j) pv2[rt][i][j] = ld4(g.res + r2 + gcol[j]);
+      }
+    }
+    if (use_stats) {
+#pragma unroll
+      for (int i = 0; i < ER; ++i) {
+        const int rc = min(mb + wave * ER + i, M - 1);
+        st0[rt][i] = g.aux_stats[is_rowln ? 2 * (size_t)rc : (size_t)rc];
+        st1[rt][i] = g.aux_stats[is_rowln ? 2 * (size_t)rc + 1 : (size_t)rc];
+      }
+    }
+  }
+  };
+  if constexpr (HOIST) prefetch_rows();
+
   if (wave_u >= 4) {
     // =============================== staging waves ===============================================
     const int st = tid - 256;                      // 0..255
@@ -464,99 +553,28 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmLaunch L) {
   __builtin_amdgcn_s_setprio(0);
   STAMP(55);
 
-  // ---- epilogue operand prefetch (all 8 waves; wave w owns rows 4w..4w+3 of each 32-row block) -----
-  // Every global operand of the row-wise epilogue (bias / gamma / beta vectors, the rows of `aux` and
-  // `res`, the per-row statistics) is loaded HERE from always-valid (clamped) addresses, before the
-  // accumulator round trip through LDS.  The row loop below then touches no global memory except its
-  // stores; a load inside that loop costs one exposed L2/HBM round trip per row.
-  const int ncols = min(BN, N - n0);
-  const float invN = 1.f / (float)N;
-  constexpr int epi = EPI;     // compile-time: only this epilogue's code exists in the kernel
-  constexpr bool is_prelu_ln = (epi == DOSX_EPI_PRELU_LN_BWD), is_rowln = (epi == DOSX_EPI_ROWLN_BWD);
-  constexpr bool aux_first = (epi != DOSX_EPI_BIAS_ACT && epi != DOSX_EPI_LN);   // operand 1 is `aux`
-  constexpr bool use_stats = is_prelu_ln || is_rowln;
-  const bool has1 = aux_first ? (g.aux != nullptr) : (g.res != nullptr && epi == DOSX_EPI_BIAS_ACT);
-  const bool has2 = is_rowln && g.res != nullptr;
-  const float* p1 = aux_first ? g.aux : g.res;
-  const int ld1 = aux_first ? g.ldaux : g.ldr;
-  float4 pg[CG], pb[CG];   // column partial sums (dgamma, dbeta) over all row blocks of this workgroup
-  float pal = 0.f;         // dalpha partial
-#pragma unroll
-  for (int j = 0; j < CG; ++j) { pg[j] = f4zero(); pb[j] = f4zero(); }
-  float e_alpha = 0.f;
-  if (epi == DOSX_EPI_PRELU_LN_BWD || epi == DOSX_EPI_PRELU_BWD) e_alpha = *g.epi_alpha;
-  bool on[CG];
-  int gcol[CG];
-  float4 biasv[CG], gamv[CG], betv[CG];
-#pragma unroll
-  for (int j = 0; j < CG; ++j) {
-    const int c = lane * 4 + 256 * j;
-    on[j] = c < ncols;
-    gcol[j] = n0 + (on[j] ? c : 0);
-    biasv[j] = f4zero(); gamv[j] = f4zero(); betv[j] = f4zero();
-    if (g.bias) biasv[j] = ld4(g.bias + gcol[j]);
-    if (use_stats) {
-      gamv[j] = ld4(g.epi_gamma + gcol[j]);
-      if (is_prelu_ln) betv[j] = ld4(g.epi_beta + gcol[j]);
-    }
-  }
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {        // one 32-row block at a time through the LDS C tile
-  const int mb = m0 + 32 * rt;
-  float4 pv1[ER][CG], pv2[ER][CG];
-  float st0[ER], st1[ER];
-  size_t orow_[ER];
-#pragma unroll
-  for (int i = 0; i < ER; ++i) {
-    const int rc = min(mb + wave * ER + i, M - 1);
-    orow_[i] = (size_t)(epi == DOSX_EPI_BIAS_ACT ? dosx_map_row(g.out_map, rc) : rc) * g.ldo;
-    st0[i] = 0.f; st1[i] = 0.f;
-#pragma unroll
-    for (int j = 0; j < CG; ++j) { pv1[i][j] = f4zero(); pv2[i][j] = f4zero(); }
-  }
-  if (has1) {          // wave-uniform, outside every loop: the loads of all rows are issued back to back
-#pragma unroll
-    for (int i = 0; i < ER; ++i) {
-      const int rc = min(mb + wave * ER + i, M - 1);
-      const size_t r1 = (size_t)(aux_first ? rc : dosx_map_row(g.res_map, rc)) * ld1;
-#pragma unroll
-      for (int j = 0; j < CG; ++j) pv1[i][j] = ld4(p1 + r1 + gcol[j]);
-    }
-  }
-  if (has2) {
-#pragma unroll
-    for (int i = 0; i < ER; ++i) {
-      const int rc = min(mb + wave * ER + i, M - 1);
-      const size_t r2 = (size_t)dosx_map_row(g.res_map, rc) * g.ldr;
-#pragma unroll
-      for (int j = 0; j < CG; ++j) pv2[i][j] = ld4(g.res + r2 + gcol[j]);
-    }
-  }
-  if (use_stats) {
-#pragma unroll
-    for (int i = 0; i < ER; ++i) {
-      const int rc = min(mb + wave * ER + i, M - 1);
-      st0[i] = g.aux_stats[is_rowln ? 2 * (size_t)rc : (size_t)rc];
-      st1[i] = g.aux_stats[is_rowln ? 2 * (size_t)rc + 1 : (size_t)rc];
-    }
-  }
-
-  // ---- accumulators -> LDS C tile (aliases the staging buffers; the k-loop ended with a barrier) ----
+  if constexpr (!HOIST) prefetch_rows();
+  // ---- accumulators -> LDS C tiles (alias the staging buffers; the k-loop ended with a barrier) ----
   if (wave_u < 4) {
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-      const int col = (wave * NTW + t) * 32 + l31;
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-        Cs[row * LDC + col] = acc[rt][t][r];
+      for (int t = 0; t < NTW; ++t) {
+        const int col = (wave * NTW + t) * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+          Cs[rt * CTILE + row * LDC + col] = acc[rt][t][r];
+        }
       }
-    }
   }
   STAMP(56);
   __syncthreads();
   STAMP(57);
 
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+  const int mb = m0 + 32 * rt;
   // ---- row-wise epilogue: lanes sweep the columns as float4 ------------------------------------
 #pragma unroll
   for (int i = 0; i < ER; ++i) {
@@ -564,8 +582,8 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmLaunch L) {
     const bool rvalid = r < M;              // wave-uniform
     float4 v[CG];
 #pragma unroll
-    for (int j = 0; j < CG; ++j) v[j] = on[j] ? ld4(&Cs[lr * LDC + lane * 4 + 256 * j]) : f4zero();
-    float* const orow = g.out + orow_[i];
+    for (int j = 0; j < CG; ++j) v[j] = on[j] ? ld4(&Cs[rt * CTILE + lr * LDC + lane * 4 + 256 * j]) : f4zero();
+    float* const orow = g.out + orow_[rt][i];
     if (epi == DOSX_EPI_BIAS_ACT) {
       float s1 = 0.f;
 #pragma unroll
@@ -580,7 +598,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmLaunch L) {
           v[j].x = v[j].x >= 0.f ? v[j].x : sl * v[j].x; v[j].y = v[j].y >= 0.f ? v[j].y : sl * v[j].y;
           v[j].z = v[j].z >= 0.f ? v[j].z : sl * v[j].z; v[j].w = v[j].w >= 0.f ? v[j].w : sl * v[j].w;
         }
-        v[j] = f4add(v[j], pv1[i][j]);       // residual (zeros when absent)
+        v[j] = f4add(v[j], pv1[rt][i][j]);   // residual (zeros when absent)
         if (rvalid) st4(orow + gcol[j], v[j]);
         s1 += v[j].x + v[j].y + v[j].z + v[j].w;
       }
@@ -626,7 +644,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmLaunch L) {
 #pragma unroll
       for (int j = 0; j < CG; ++j) {
         if (!on[j] || !rvalid) continue;
-        const float4 h = pv1[i][j];
+        const float4 h = pv1[rt][i][j];
         st4(orow + gcol[j], make_float4(h.x > 0.f ? v[j].x : 0.f, h.y > 0.f ? v[j].y : 0.f,
                                         h.z > 0.f ? v[j].z : 0.f, h.w > 0.f ? v[j].w : 0.f));
       }
@@ -634,7 +652,7 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmLaunch L) {
 #pragma unroll
       for (int j = 0; j < CG; ++j) {
         if (!on[j] || !rvalid) continue;
-        const float4 z = pv1[i][j];
+        const float4 z = pv1[rt][i][j];
         float4 o;
         o.x = z.x >= 0.f ? v[j].x : e_alpha * v[j].x; if (z.x < 0.f) pal += v[j].x * z.x;
         o.y = z.y >= 0.f ? v[j].y : e_alpha * v[j].y; if (z.y < 0.f) pal += v[j].y * z.y;
@@ -643,15 +661,15 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmLaunch L) {
         st4(orow + gcol[j], o);
       }
     } else {  // DOSX_EPI_PRELU_LN_BWD or DOSX_EPI_ROWLN_BWD : LayerNorm backward over the full row
-      const float mean = is_prelu_ln ? 0.f : st0[i];
-      const float rstd = is_prelu_ln ? st0[i] : st1[i];
+      const float mean = is_prelu_ln ? 0.f : st0[rt][i];
+      const float rstd = is_prelu_ln ? st0[rt][i] : st1[rt][i];
       float4 xh[CG], dxh[CG];
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int j = 0; j < CG; ++j) {
         xh[j] = f4zero(); dxh[j] = f4zero();
         if (!on[j] || !rvalid) continue;
-        float4 a = pv1[i][j];
+        float4 a = pv1[rt][i][j];
         const float4 gm = gamv[j];
         float4 dy = v[j];
         if (is_prelu_ln) {
@@ -679,13 +697,12 @@ __global__ __launch_bounds__(512) void gemm_kernel(const GemmLaunch L) {
         if (!on[j] || !rvalid) continue;
         float4 o = make_float4(rstd * (dxh[j].x - m1 - xh[j].x * m2), rstd * (dxh[j].y - m1 - xh[j].y * m2),
                                rstd * (dxh[j].z - m1 - xh[j].z * m2), rstd * (dxh[j].w - m1 - xh[j].w * m2));
-        if (is_rowln) o = f4add(o, pv2[i][j]);
+        if (is_rowln) o = f4add(o, pv2[rt][i][j]);
         st4(orow + gcol[j], o);
       }
     }
   }
 
-  if (rt + 1 < RT) __syncthreads();     // the C tile is rewritten by the next row block
   }   // rt
   STAMP(58);
   // ---- per-workgroup partial sums for the parameter gradients of the fused LN / PReLU ----------
@@ -735,7 +752,7 @@ constexpr size_t gemm_smem_bytes() {
   constexpr int STAGE = BM * RT * LDA + WROWS * LDWT;
   constexpr int CTILE = BM * (BN + 4);
   constexpr int MAINF = 2 * STAGE + (PROLN ? 2 * GEMM_KMAX : 0);
-  constexpr int EPIF = CTILE + 16 * BN + 8;
+  constexpr int EPIF = RT * CTILE + 16 * BN + 8;
   return (size_t)(MAINF > EPIF ? MAINF : EPIF) * sizeof(float);
 }
 
