@@ -44,6 +44,9 @@ __host__ __device__ inline Geo make_geo(int H, int Nk) {
   return g;
 }
 
+// floats of one streamed-chunk buffer: a K chunk is [NKP][36], a V chunk is [32][LDH]
+__host__ __device__ inline int chunk_buf_floats(int NKP, int LDH) { return NKP * LDK > KC * LDH ? NKP * LDK : KC * LDH; }
+
 // Load 32 rows x H (float4) of a row-strided matrix into LDS [32][LDH], zero padded.
 // row pointer for tile row i: base + rowoff(i) (nullptr -> zeros).  Optional affine LN on load:
 //   v = (v - mean)*rstd*gamma + beta   (stats == nullptr: plain copy)
@@ -60,31 +63,60 @@ __device__ __forceinline__ void load_rows(float* dst, int LDH, int HP, int H, Ro
   }
 }
 
+// Streamed (non-resident) key tiles.  A chunk is fetched into registers one chunk ahead (the loads fly
+// under the MFMAs of the current chunk) and written, with the key affine applied, into the OTHER of two
+// LDS chunk buffers: one barrier per chunk.
+constexpr int MAXKR = 10;   // 32-key row blocks per crystal (Nk <= 320)
+constexpr int MAXVC = 8;    // 32-column blocks per row (H <= 256)
+
 // K chunk for the NT products: Ks[j][0..31] = kvhat[(j*Bk+bk)][kc..kc+31]*gamma+beta, j < Nk else 0
-__device__ __forceinline__ void stage_k_chunk(float* Ks, const float* __restrict__ kvhat, const float* __restrict__ gamma,
-                                              const float* __restrict__ beta, int Nk, int NKP, int Bk, int bk, int H,
-                                              int kc, int tid) {
+struct KChunk { float4 h[MAXKR], g, b; };
+__device__ __forceinline__ void k_chunk_load(KChunk& r, const float* __restrict__ kvhat, const float* __restrict__ gamma,
+                                             const float* __restrict__ beta, int Nk, int NKP, int Bk, int bk, int H,
+                                             int kc, int tid) {
+  const int k = kc + (tid & 7) * 4, kk = k < H ? k : 0;
+  r.g = ld4(gamma + kk);
+  r.b = ld4(beta + kk);
+#pragma unroll
+  for (int i = 0; i < MAXKR; ++i) {
+    const int j = (tid >> 3) + 32 * i;
+    if (j < NKP) r.h[i] = ld4(kvhat + ((size_t)min(j, Nk - 1) * Bk + bk) * H + kk);
+  }
+}
+__device__ __forceinline__ void k_chunk_store(float* Ks, const KChunk& r, int Nk, int NKP, int H, int kc, int tid) {
   const int kq = (tid & 7) * 4, k = kc + kq;
-  const int kk = k < H ? k : 0;
-  const float4 g = ld4(gamma + kk), b = ld4(beta + kk);
-  for (int j = tid >> 3; j < NKP; j += 32) {
-    const float4 h = ld4(kvhat + ((size_t)min(j, Nk - 1) * Bk + bk) * H + kk);
-    float4 v = make_float4(h.x * g.x + b.x, h.y * g.y + b.y, h.z * g.z + b.z, h.w * g.w + b.w);
+#pragma unroll
+  for (int i = 0; i < MAXKR; ++i) {
+    const int j = (tid >> 3) + 32 * i;
+    if (j >= NKP) break;
+    const float4 h = r.h[i];
+    float4 v = make_float4(h.x * r.g.x + r.b.x, h.y * r.g.y + r.b.y, h.z * r.g.z + r.b.z, h.w * r.g.w + r.b.w);
     if (!(j < Nk && k < H)) v = f4zero();
     st4(Ks + j * LDK + kq, v);
   }
 }
 
 // V chunk for the NN products: Vs[jj][0..HP) = K rows j0..j0+31 (affine), zero beyond Nk / H
-__device__ __forceinline__ void stage_v_chunk(float* Vs, const float* __restrict__ kvhat, const float* __restrict__ gamma,
-                                              const float* __restrict__ beta, int Nk, int Bk, int bk, int H, int HP,
-                                              int LDH, int j0, int tid) {
-  const int jj = tid >> 3, j = j0 + jj;
+struct VChunk { float4 h[MAXVC]; };
+__device__ __forceinline__ void v_chunk_load(VChunk& r, const float* __restrict__ kvhat, int Nk, int Bk, int bk, int H,
+                                             int HP, int j0, int tid) {
+  const int j = j0 + (tid >> 3);
   const float* row = kvhat + ((size_t)min(j, Nk - 1) * Bk + bk) * H;
-  for (int c = (tid & 7) * 4; c < HP; c += 32) {
-    const int cc = c < H ? c : 0;
-    const float4 h = ld4(row + cc), g = ld4(gamma + cc), b = ld4(beta + cc);
-    float4 v = make_float4(h.x * g.x + b.x, h.y * g.y + b.y, h.z * g.z + b.z, h.w * g.w + b.w);
+#pragma unroll
+  for (int i = 0; i < MAXVC; ++i) {
+    const int c = (tid & 7) * 4 + 32 * i;
+    if (c < HP) r.h[i] = ld4(row + (c < H ? c : 0));
+  }
+}
+__device__ __forceinline__ void v_chunk_store(float* Vs, const VChunk& r, const float4 (&g)[MAXVC], const float4 (&b)[MAXVC],
+                                              int Nk, int H, int HP, int LDH, int j0, int tid) {
+  const int jj = tid >> 3, j = j0 + jj;
+#pragma unroll
+  for (int i = 0; i < MAXVC; ++i) {
+    const int c = (tid & 7) * 4 + 32 * i;
+    if (c >= HP) break;
+    const float4 h = r.h[i];
+    float4 v = make_float4(h.x * g[i].x + b[i].x, h.y * g[i].y + b[i].y, h.z * g[i].z + b[i].z, h.w * g[i].w + b[i].w);
     if (!(j < Nk && c < H)) v = f4zero();
     st4(Vs + jj * LDH + c, v);
   }
@@ -164,24 +196,52 @@ __device__ __forceinline__ void qk_product(f32x16 (&acc)[MAX_KT], const float* A
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   const int kbeg = q.kpart * (HP / q.ks), kend = kbeg + HP / q.ks;
   if (KRES) {
+    // software-pipelined: the fragments of step k+8 are read from LDS while the MFMAs of step k run
+    // (the loop bounds are run-time values, hipcc does not pipeline it by itself: ~200 clk of exposed
+    // ds_read latency per 8-12 MFMAs otherwise)
+    const float* ap = As + l31 * LDH + 4 * hh;
+    const float* bp[MAX_KT];
+    bool on[MAX_KT];
+#pragma unroll
+    for (int t = 0; t < MAX_KT; ++t) {
+      const int jt = q.jt0 + q.jstep * t;
+      on[t] = jt < nkt;
+      bp[t] = Ks + ((on[t] ? jt : 0) * 32 + l31) * LDH + 4 * hh;
+    }
+    float4 an = ld4(ap + kbeg), bn[MAX_KT];
+#pragma unroll
+    for (int t = 0; t < MAX_KT; ++t) bn[t] = on[t] ? ld4(bp[t] + kbeg) : f4zero();
     for (int k = kbeg; k < kend; k += 8) {
-      const float4 a = ld4(As + l31 * LDH + k + 4 * hh);
+      const float4 a = an;
+      float4 b[MAX_KT];
+#pragma unroll
+      for (int t = 0; t < MAX_KT; ++t) b[t] = bn[t];
+      const int kn = (k + 8 < kend) ? k + 8 : k;
+      an = ld4(ap + kn);
+#pragma unroll
+      for (int t = 0; t < MAX_KT; ++t)
+        if (on[t]) bn[t] = ld4(bp[t] + kn);
 #pragma unroll
       for (int t = 0; t < MAX_KT; ++t) {
-        const int jt = q.jt0 + q.jstep * t;
-        if (jt >= nkt) continue;
-        const float4 b = ld4(Ks + (jt * 32 + l31) * LDH + k + 4 * hh);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+        if (!on[t]) continue;
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t].y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
       }
     }
     return;
   }
-  for (int kc = 0; kc < HP; kc += KC) {
-    stage_k_chunk(Ks, kvhat, gamma, beta, Nk, NKP, Bk, bk, H, kc, tid);
-    __syncthreads();
+  // streamed K: two chunk buffers (Ks, Ks + CHB), register prefetch one chunk ahead, one barrier per chunk
+  const int CHB = chunk_buf_floats(NKP, LDH);
+  KChunk kr;
+  k_chunk_load(kr, kvhat, gamma, beta, Nk, NKP, Bk, bk, H, 0, tid);
+  k_chunk_store(Ks, kr, Nk, NKP, H, 0, tid);
+  __syncthreads();
+  for (int kc = 0, ib = 0; kc < HP; kc += KC, ib ^= 1) {
+    const float* Kc = Ks + ib * CHB;
+    const bool more = kc + KC < HP;
+    if (more) k_chunk_load(kr, kvhat, gamma, beta, Nk, NKP, Bk, bk, H, kc + KC, tid);
 #pragma unroll
     for (int kk = 0; kk < KC; kk += 8) {
       const float4 a = ld4(As + l31 * LDH + kc + kk + 4 * hh);
@@ -189,13 +249,14 @@ __device__ __forceinline__ void qk_product(f32x16 (&acc)[MAX_KT], const float* A
       for (int t = 0; t < MAX_KT; ++t) {
         const int jt = q.jt0 + q.jstep * t;
         if (jt >= nkt) continue;
-        const float4 b = ld4(Ks + (jt * 32 + l31) * LDK + kk + 4 * hh);
+        const float4 b = ld4(Kc + (jt * 32 + l31) * LDK + kk + 4 * hh);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
       }
     }
+    if (more) k_chunk_store(Ks + (ib ^ 1) * CHB, kr, Nk, NKP, H, kc + KC, tid);
     __syncthreads();
   }
 }
@@ -229,11 +290,65 @@ __device__ __forceinline__ void pv_product(f32x16 (&acc)[MAX_CT], const float* P
   for (int t = 0; t < MAX_CT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  for (int j0 = 0; j0 < NKP; j0 += KC) {
-    if (!KRES) {
-      stage_v_chunk(Vs, kvhat, gamma, beta, Nk, Bk, bk, H, HP, LDH, j0, tid);
-      __syncthreads();
+  if (KRES) {
+    // resident V (= K) tile: software-pipelined like qk_product
+    const float* ap = Ps + l31 * LDS_ + 4 * hh;
+    const float* vp[MAX_CT];
+    bool on[MAX_CT];
+#pragma unroll
+    for (int t = 0; t < MAX_CT; ++t) {
+      const int ct = wave + 4 * t;
+      on[t] = ct < nct;
+      vp[t] = Vs + (4 * hh) * LDH + (on[t] ? ct : 0) * 32 + l31;
     }
+    float4 an = ld4(ap);
+    float bn[MAX_CT][4];
+#pragma unroll
+    for (int t = 0; t < MAX_CT; ++t)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) bn[t][c] = on[t] ? vp[t][c * LDH] : 0.f;
+    for (int j = 0; j < NKP; j += 8) {
+      const float4 a = an;
+      float b[MAX_CT][4];
+#pragma unroll
+      for (int t = 0; t < MAX_CT; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) b[t][c] = bn[t][c];
+      const int jn = (j + 8 < NKP) ? j + 8 : j;
+      an = ld4(ap + jn);
+#pragma unroll
+      for (int t = 0; t < MAX_CT; ++t)
+        if (on[t]) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) bn[t][c] = vp[t][(jn + c) * LDH];
+        }
+#pragma unroll
+      for (int t = 0; t < MAX_CT; ++t) {
+        if (!on[t]) continue;
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t][0], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t][1], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t][2], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t][3], acc[t], 0, 0, 0);
+      }
+    }
+    return;
+  }
+  const int CHB = chunk_buf_floats(NKP, LDH);
+  float4 gq[MAXVC], bq[MAXVC];
+#pragma unroll
+  for (int i = 0; i < MAXVC; ++i) {
+    const int c = (tid & 7) * 4 + 32 * i, cc = c < H ? c : 0;
+    gq[i] = ld4(gamma + cc);
+    bq[i] = ld4(beta + cc);
+  }
+  VChunk vr;
+  v_chunk_load(vr, kvhat, Nk, Bk, bk, H, HP, 0, tid);
+  v_chunk_store(Vs, vr, gq, bq, Nk, H, HP, LDH, 0, tid);
+  __syncthreads();
+  for (int j0 = 0, ib = 0; j0 < NKP; j0 += KC, ib ^= 1) {
+    const float* Vc = Vs + ib * CHB;
+    const bool more = j0 + KC < NKP;
+    if (more) v_chunk_load(vr, kvhat, Nk, Bk, bk, H, HP, j0 + KC, tid);
 #pragma unroll
     for (int kk = 0; kk < KC; kk += 8) {
       const float4 a = ld4(Ps + l31 * LDS_ + j0 + kk + 4 * hh);
@@ -241,14 +356,15 @@ __device__ __forceinline__ void pv_product(f32x16 (&acc)[MAX_CT], const float* P
       for (int t = 0; t < MAX_CT; ++t) {
         const int ct = wave + 4 * t;
         if (ct >= nct) continue;
-        const float* bp = Vs + ((KRES ? j0 : 0) + kk + 4 * hh) * LDH + ct * 32 + l31;
+        const float* bp = Vc + (kk + 4 * hh) * LDH + ct * 32 + l31;
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bp[0], acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bp[LDH], acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bp[2 * LDH], acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bp[3 * LDH], acc[t], 0, 0, 0);
       }
     }
-    if (!KRES) __syncthreads();
+    if (more) v_chunk_store(Vs + (ib ^ 1) * CHB, vr, gq, bq, Nk, H, HP, LDH, j0 + KC, tid);
+    __syncthreads();
   }
 }
 
@@ -499,7 +615,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const DosxAttn a) {
   float* Ds = sm;                                   // [32][LDH]  dOut tile, later dq tile
   float* Ss = Ds + QT * g.LDH;                      // [ks][32][LDS_] partial dP; tile 0 becomes dS
   float* KV = Ss + q.ks * QT * g.LDS_;              // chunk staging, or the whole key tile (KRES)
-  float* Pp = KV + (KRES ? g.NKP * g.LDH : max(g.NKP * LDK, KC * g.LDH));    // [16][2][HP] partial column sums
+  // [16][2][HP] partial column sums: behind the resident key tile, or (streamed keys) ON the chunk buffers,
+  // which are dead after the dS.K product
+  float* Pp = KRES ? KV + g.NKP * g.LDH : KV;
   const int s0 = blockIdx.x * QT, bq = blockIdx.y, bk = bq % a.Bk;
   const int H = a.H, Sq = a.Sq, Nk = a.Nk;
   const bool raw_q = (a.flags & DOSX_ATTN_RAW_Q) != 0, no_res = (a.flags & DOSX_ATTN_NO_RESIDUAL) != 0;
@@ -806,11 +924,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const DosxAttn a) {
 
 size_t fwd_smem(const Geo& g, bool kres) {
   return sizeof(float) * (size_t)(QT * g.LDH + qk_ks(g.NKP, g.HP, kres) * QT * g.LDS_ +
-                                  (kres ? g.NKP * g.LDH : max(g.NKP * LDK, KC * g.LDH)));
+                                  (kres ? g.NKP * g.LDH : 2 * chunk_buf_floats(g.NKP, g.LDH)));
 }
 size_t dq_smem(const Geo& g, bool kres) {
-  return sizeof(float) * (size_t)(QT * g.LDH + qk_ks(g.NKP, g.HP, kres) * QT * g.LDS_ +
-                                  (kres ? g.NKP * g.LDH : max(g.NKP * LDK, KC * g.LDH)) + 32 * g.HP);
+  const size_t kv = kres ? (size_t)g.NKP * g.LDH + 32 * g.HP : (size_t)max(2 * chunk_buf_floats(g.NKP, g.LDH), 32 * g.HP);
+  return sizeof(float) * ((size_t)QT * g.LDH + (size_t)qk_ks(g.NKP, g.HP, kres) * QT * g.LDS_ + kv);
 }
 constexpr size_t KRES_LDS_LIMIT = 144 * 1024;   // keep the whole key tile of a crystal in LDS when it fits
 size_t dkv_smem(const Geo& g) { return sizeof(float) * (size_t)(2 * QT * g.LDH + 2 * QT * LDK + 8 * g.HP); }
@@ -836,7 +954,7 @@ extern "C" int dosx_attention_fwd(const DosxAttn* ap, dosx_stream_t stream) {
   const size_t smem = fwd_smem(g, kres);
   DOSX_CHECK_ARG(smem <= 160 * 1024, "dosx_attention_fwd: LDS need %zu > 160 KiB", smem);
   const dim3 grid(ceil_div(a.Sq, QT), a.Bq);
-  const int nj = a.Nk <= 16 ? 1 : (a.Nk <= 64 ? 4 : 20);
+  const int nj = a.Nk <= 16 ? 1 : (a.Nk <= 64 ? 4 : (a.Nk <= 208 ? 13 : 20));
 #define DOSX_FWD(KR, NJ_)                                                                                   \
   do {                                                                                                      \
     static bool attr_set = false;                                                                           \
@@ -847,8 +965,8 @@ extern "C" int dosx_attention_fwd(const DosxAttn* ap, dosx_stream_t stream) {
     }                                                                                                       \
     hipLaunchKernelGGL((attn_fwd_kernel<KR, NJ_>), grid, dim3(256), smem, to_stream(stream), a);            \
   } while (0)
-  if (kres) { if (nj == 1) DOSX_FWD(true, 1); else if (nj == 4) DOSX_FWD(true, 4); else DOSX_FWD(true, 20); }
-  else { if (nj == 1) DOSX_FWD(false, 1); else if (nj == 4) DOSX_FWD(false, 4); else DOSX_FWD(false, 20); }
+  if (kres) { if (nj == 1) DOSX_FWD(true, 1); else if (nj == 4) DOSX_FWD(true, 4); else if (nj == 13) DOSX_FWD(true, 13); else DOSX_FWD(true, 20); }
+  else { if (nj == 1) DOSX_FWD(false, 1); else if (nj == 4) DOSX_FWD(false, 4); else if (nj == 13) DOSX_FWD(false, 13); else DOSX_FWD(false, 20); }
 #undef DOSX_FWD
   DOSX_LAUNCH_CHECK();
   return 0;
@@ -871,7 +989,7 @@ extern "C" int dosx_attention_bwd(const DosxAttn* ap, dosx_stream_t stream) {
   }
   const dim3 grid(ceil_div(a.Sq, QT), a.Bq);
   if (!(a.flags & DOSX_ATTN_BWD_SKIP_DQ)) {
-    const int nj = a.Nk <= 16 ? 1 : (a.Nk <= 64 ? 4 : 20);
+    const int nj = a.Nk <= 16 ? 1 : (a.Nk <= 64 ? 4 : (a.Nk <= 208 ? 13 : 20));
 #define DOSX_DQ(KR, NJ_)                                                                                    \
   do {                                                                                                      \
     static bool attr_dq = false;                                                                            \
@@ -882,8 +1000,8 @@ extern "C" int dosx_attention_bwd(const DosxAttn* ap, dosx_stream_t stream) {
     }                                                                                                       \
     hipLaunchKernelGGL((attn_bwd_dq_kernel<KR, NJ_>), grid, dim3(256), s1, to_stream(stream), a);           \
   } while (0)
-    if (kres) { if (nj == 1) DOSX_DQ(true, 1); else if (nj == 4) DOSX_DQ(true, 4); else DOSX_DQ(true, 20); }
-    else { if (nj == 1) DOSX_DQ(false, 1); else if (nj == 4) DOSX_DQ(false, 4); else DOSX_DQ(false, 20); }
+    if (kres) { if (nj == 1) DOSX_DQ(true, 1); else if (nj == 4) DOSX_DQ(true, 4); else if (nj == 13) DOSX_DQ(true, 13); else DOSX_DQ(true, 20); }
+    else { if (nj == 1) DOSX_DQ(false, 1); else if (nj == 4) DOSX_DQ(false, 4); else if (nj == 13) DOSX_DQ(false, 13); else DOSX_DQ(false, 20); }
 #undef DOSX_DQ
     DOSX_LAUNCH_CHECK();
   }
