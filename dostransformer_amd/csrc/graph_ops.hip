@@ -136,18 +136,42 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict
     const int c = cb + rl.c4;
     float4 acc = f4zero();
     if (c < H) {
-      for (int e = db + rl.slot; e < de; e += rl.rps) {
-        const float* row = dcat + (size_t)e * ldc;
-        acc = f4add(acc, ld4(row + H + c));
-        if (de_out) {
-          float4 v = ld4(row + 2 * H + c);
-          if (de_new) v = f4add(v, ld4(de_new + (size_t)e * H + c));
-          st4(de_out + (size_t)e * H + c, v);
+      // 4 edges in flight per lane slot (the one-edge loop was a chain of ~20 dependent L2 round trips per
+      // node: 14.7 us); indices beyond the segment are clamped and their contribution masked
+      for (int e0 = db + rl.slot; e0 < de; e0 += 4 * rl.rps) {
+        float4 v1[4], v2[4], v3[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = min(e0 + u * rl.rps, de - 1);
+          const float* row = dcat + (size_t)e * ldc;
+          v1[u] = ld4(row + H + c);
+          if (de_out) {
+            v2[u] = ld4(row + 2 * H + c);
+            if (de_new) v3[u] = ld4(de_new + (size_t)e * H + c);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = e0 + u * rl.rps;
+          if (e >= de) break;
+          acc = f4add(acc, v1[u]);
+          if (de_out) {
+            float4 v = v2[u];
+            if (de_new) v = f4add(v, v3[u]);
+            st4(de_out + (size_t)e * H + c, v);
+          }
         }
       }
-      for (int j = sb + rl.slot; j < se; j += rl.rps) {
-        const int e = perm_src[j];
-        acc = f4add(acc, ld4(dcat + (size_t)e * ldc + c));
+      for (int j0 = sb + rl.slot; j0 < se; j0 += 4 * rl.rps) {
+        int ei[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ei[u] = perm_src[min(j0 + u * rl.rps, se - 1)];
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = ld4(dcat + (size_t)ei[u] * ldc + c);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (j0 + u * rl.rps < se) acc = f4add(acc, v[u]);
       }
     }
     acc = slots_sum(acc, rl.lpr);
@@ -320,9 +344,20 @@ __global__ void reduce_rows_kernel(const float* __restrict__ src, int ld_src, fl
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_out * w4) return;
   const int o = i / w4, c = (i % w4) * 4;
+  // 8 independent loads in flight per lane (a one-load-per-iteration loop is a chain of n_red exposed
+  // L2 round trips: 15-18 us for the 64..128-row sums of the heads' backward); fixed summation order
   float4 acc = f4zero();
-  for (int j = 0; j < n_red; ++j)
-    acc = f4add(acc, ld4(src + ((size_t)o * stride_out + (size_t)j * stride_red) * ld_src + c));
+  const float* base = src + (size_t)o * stride_out * ld_src + c;
+  const size_t step = (size_t)stride_red * ld_src;
+  int j = 0;
+  for (; j + 8 <= n_red; j += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = ld4(base + (size_t)(j + u) * step);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = f4add(acc, v[u]);
+  }
+  for (; j < n_red; ++j) acc = f4add(acc, ld4(base + (size_t)j * step));
   if (accumulate) acc = f4add(acc, ld4(dst + (size_t)o * ld_dst + c));
   st4(dst + (size_t)o * ld_dst + c, acc);
 }

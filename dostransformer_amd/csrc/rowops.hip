@@ -37,9 +37,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   if (lane == 0 && rstd_out) rstd_out[r] = rstd;
 }
 
-// Shared skeleton of the LN-backward row kernels.  NV = number of H-wide partial vectors this
-// kernel produces per workgroup (2: dgamma,dbeta ; 3: + dw), plus optional trailing scalar.
-// Workgroup = 4 waves x 8 rows = 32 rows; partial row layout [v0(H) | v1(H) | (v2(H)) | (scalar)].
+// LN-backward row kernels.  NV = number of H-wide partial vectors per workgroup (2: dgamma,dbeta ; 3: + dw),
+// plus an optional trailing scalar (db).  Workgroup = 4 waves x 8 rows = 32 rows; partial row layout
+// [v0(H) | v1(H) | (v2(H)) | (scalar)].  One QUARTER WAVE per row, 2 passes of 4 rows per wave, everything in
+// registers: a reduction over 4 rows is 4 DPP instructions (row16_sum), and the column partial sums are
+// register accumulators written once (the first version walked its 8 rows one after the other with in-loop
+// global loads, two 64-lane reductions and LDS read-modify-writes per row: 12-15 us at 3-6k rows).
 template <bool ROWDOT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy,     // [M,H]   (!ROWDOT)
                                                      const float* __restrict__ ddos,   // [Bq,S]  (ROWDOT)
@@ -47,63 +50,103 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      const float* __restrict__ w, float* __restrict__ dx,
                                                      float* __restrict__ partials, int M, int H, int S, int Bq) {
-  extern __shared__ __align__(16) float sm[];   // [4][NV*H + 1]
+  extern __shared__ __align__(16) float sm[];   // [16 slots][NV*H] + [16]
   constexpr int NV = ROWDOT ? 3 : 2;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int KB = 4;                          // 64-column blocks per row (H <= 256)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q16 = lane & 15;
   const int pld = NV * H + (ROWDOT ? 1 : 0);
-  float* my = sm + (size_t)wave * (NV * H + 1);
-  for (int c = lane; c < NV * H + 1; c += 64) my[c] = 0.f;
+  const float invH = 1.f / (float)H;
+  float4 g[KB], bt[KB], ww[KB], pg[KB], pb[KB], pw[KB];
+#pragma unroll
+  for (int k = 0; k < KB; ++k) {
+    const int c = q16 * 4 + 64 * k, cc = c < H ? c : 0;
+    g[k] = ld4(gamma + cc);
+    bt[k] = ROWDOT ? ld4(beta + cc) : f4zero();
+    ww[k] = ROWDOT ? ld4(w + cc) : f4zero();
+    pg[k] = f4zero(); pb[k] = f4zero(); pw[k] = f4zero();
+  }
+  float4 xh[2][KB], d[2][KB];
+  float rs[2], dyr[2], s1[2], s2[2];
   float db = 0.f;
-  for (int i = 0; i < 8; ++i) {
-    const int r = blockIdx.x * 32 + wave * 8 + i;
-    if (r >= M) break;
-    const float rs = rstd[r];
-    float dyr = 0.f;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int r = blockIdx.x * 32 + wave * 8 + p * 4 + (lane >> 4);
+    const bool rv = r < M;
+    const int rc = rv ? r : M - 1;
+    rs[p] = rstd[rc];
+    dyr[p] = 0.f;
     if (ROWDOT) {
-      dyr = ddos[(size_t)(r % Bq) * S + (r / Bq)];
-      db += dyr;
+      dyr[p] = rv ? ddos[(size_t)(rc % Bq) * S + (rc / Bq)] : 0.f;
+      if (q16 == 0) db += dyr[p];
     }
-    float s1 = 0.f, s2 = 0.f;
-    for (int c = lane * 4; c < H; c += 256) {
-      const float4 xh = ld4(xhat + (size_t)r * H + c), g = ld4(gamma + c);
-      float4 d;
-      if (ROWDOT) {
-        const float4 ww = ld4(w + c), bt = ld4(beta + c);
-        d = make_float4(dyr * ww.x, dyr * ww.y, dyr * ww.z, dyr * ww.w);
-        my[2 * H + c + 0] += dyr * (xh.x * g.x + bt.x);
-        my[2 * H + c + 1] += dyr * (xh.y * g.y + bt.y);
-        my[2 * H + c + 2] += dyr * (xh.z * g.z + bt.z);
-        my[2 * H + c + 3] += dyr * (xh.w * g.w + bt.w);
-      } else {
-        d = ld4(dy + (size_t)r * H + c);
-      }
-      my[c + 0] += d.x * xh.x; my[c + 1] += d.y * xh.y; my[c + 2] += d.z * xh.z; my[c + 3] += d.w * xh.w;
-      my[H + c + 0] += d.x; my[H + c + 1] += d.y; my[H + c + 2] += d.z; my[H + c + 3] += d.w;
-      const float4 dh = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
-      s1 += dh.x + dh.y + dh.z + dh.w;
-      s2 += dh.x * xh.x + dh.y * xh.y + dh.z * xh.z + dh.w * xh.w;
-    }
-    const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
-    for (int c = lane * 4; c < H; c += 256) {
-      const float4 xh = ld4(xhat + (size_t)r * H + c), g = ld4(gamma + c);
-      float4 d;
-      if (ROWDOT) {
-        const float4 ww = ld4(w + c);
-        d = make_float4(dyr * ww.x, dyr * ww.y, dyr * ww.z, dyr * ww.w);
-      } else {
-        d = ld4(dy + (size_t)r * H + c);
-      }
-      st4(dx + (size_t)r * H + c,
-          make_float4(rs * (d.x * g.x - m1 - xh.x * m2), rs * (d.y * g.y - m1 - xh.y * m2),
-                      rs * (d.z * g.z - m1 - xh.z * m2), rs * (d.w * g.w - m1 - xh.w * m2)));
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const int c = q16 * 4 + 64 * k, cc = c < H ? c : 0;
+      xh[p][k] = ld4(xhat + (size_t)rc * H + cc);
+      if (ROWDOT) d[p][k] = make_float4(dyr[p] * ww[k].x, dyr[p] * ww[k].y, dyr[p] * ww[k].z, dyr[p] * ww[k].w);
+      else d[p][k] = ld4(dy + (size_t)rc * H + cc);
+      if (!(rv && c < H)) { d[p][k] = f4zero(); xh[p][k] = f4zero(); }
     }
   }
-  if (ROWDOT && lane == 0) my[NV * H] = db;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    s1[p] = 0.f; s2[p] = 0.f;
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const float4 dd = d[p][k], h = xh[p][k];
+      if (ROWDOT) {
+        pw[k].x += dyr[p] * (h.x * g[k].x + bt[k].x); pw[k].y += dyr[p] * (h.y * g[k].y + bt[k].y);
+        pw[k].z += dyr[p] * (h.z * g[k].z + bt[k].z); pw[k].w += dyr[p] * (h.w * g[k].w + bt[k].w);
+      }
+      pg[k].x += dd.x * h.x; pg[k].y += dd.y * h.y; pg[k].z += dd.z * h.z; pg[k].w += dd.w * h.w;
+      pb[k] = f4add(pb[k], dd);
+      const float4 dh = make_float4(dd.x * g[k].x, dd.y * g[k].y, dd.z * g[k].z, dd.w * g[k].w);
+      s1[p] += (dh.x + dh.y) + (dh.z + dh.w);
+      s2[p] += (dh.x * h.x + dh.y * h.y) + (dh.z * h.z + dh.w * h.w);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) { s1[p] = row16_sum(s1[p]) * invH; s2[p] = row16_sum(s2[p]) * invH; }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int r = blockIdx.x * 32 + wave * 8 + p * 4 + (lane >> 4);
+    if (r >= M) continue;
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const int c = q16 * 4 + 64 * k;
+      if (c >= H) continue;
+      const float4 dd = d[p][k], h = xh[p][k];
+      st4(dx + (size_t)r * H + c,
+          make_float4(rs[p] * (dd.x * g[k].x - s1[p] - h.x * s2[p]), rs[p] * (dd.y * g[k].y - s1[p] - h.y * s2[p]),
+                      rs[p] * (dd.z * g[k].z - s1[p] - h.z * s2[p]), rs[p] * (dd.w * g[k].w - s1[p] - h.w * s2[p])));
+    }
+  }
+  // column partial sums: one slot per quarter wave (16), summed in a fixed order
+  const int slot = wave * 4 + (lane >> 4);
+  float* my = sm + (size_t)slot * (NV * H);
+#pragma unroll
+  for (int k = 0; k < KB; ++k) {
+    const int c = q16 * 4 + 64 * k;
+    if (c >= H) continue;
+    st4(my + c, pg[k]);
+    st4(my + H + c, pb[k]);
+    if (ROWDOT) st4(my + 2 * H + c, pw[k]);
+  }
+  if (ROWDOT && q16 == 0) sm[16 * NV * H + slot] = db;
   __syncthreads();
   float* prow = partials + (size_t)blockIdx.x * pld;
-  const int stride = NV * H + 1;
-  for (int c = threadIdx.x; c < pld; c += 256)
-    prow[c] = sm[c] + sm[stride + c] + sm[2 * stride + c] + sm[3 * stride + c];
+  for (int c = threadIdx.x; c < NV * H; c += 256) {
+    float t = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl) t += sm[sl * NV * H + c];
+    prow[c] = t;
+  }
+  if (ROWDOT && threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl) t += sm[16 * NV * H + sl];
+    prow[NV * H] = t;
+  }
 }
 
 // y[r] = (LN(x[r])*gamma+beta) . w + b   ->  dos[(r % Bq)*S + r / Bq]
@@ -317,7 +360,8 @@ extern "C" int dosx_layernorm_bwd(const float* dy, const float* xhat, const floa
   if (M <= 0) return 0;
   CHECK_H4(H);
   DOSX_CHECK_ARG(dy && xhat && rstd && gamma && dx && partials, "dosx_layernorm_bwd: bad args");
-  const size_t smem = 4 * (size_t)(2 * H + 1) * sizeof(float);
+  DOSX_CHECK_ARG(H <= 256, "dosx_layernorm_bwd: H=%d > 256", H);
+  const size_t smem = (16 * (size_t)(2 * H) + 16) * sizeof(float);
   hipLaunchKernelGGL((ln_bwd_kernel<false>), dim3(ceil_div(M, 32)), dim3(256), smem, to_stream(stream), dy, nullptr, xhat,
                      rstd, gamma, nullptr, nullptr, dx, partials, M, H, 0, 1);
   DOSX_LAUNCH_CHECK();
@@ -342,7 +386,8 @@ extern "C" int dosx_ln_rowdot_bwd(const float* ddos, const float* xhat, const fl
   if (M <= 0) return 0;
   CHECK_H4(H);
   DOSX_CHECK_ARG(ddos && xhat && rstd && gamma && beta && w && dx && partials, "dosx_ln_rowdot_bwd: bad args");
-  const size_t smem = 4 * (size_t)(3 * H + 1) * sizeof(float);
+  DOSX_CHECK_ARG(H <= 256, "dosx_ln_rowdot_bwd: H=%d > 256", H);
+  const size_t smem = (16 * (size_t)(3 * H) + 16) * sizeof(float);
   hipLaunchKernelGGL((ln_bwd_kernel<true>), dim3(ceil_div(M, 32)), dim3(256), smem, to_stream(stream), nullptr, ddos, xhat,
                      rstd, gamma, beta, w, dx, partials, M, H, S, Bq);
   DOSX_LAUNCH_CHECK();
