@@ -20,18 +20,31 @@ typedef int v4i32 __attribute__((ext_vector_type(4)));
 extern "C" { __device__ unsigned long long dosx_stamp_buf[64 * 64]; }
 #define STAMP(slot)                                                                              \
   do {                                                                                           \
-    if ((threadIdx.x == 0) && (blockIdx.y == 0) && (blockIdx.x % 37 == 0) && (blockIdx.x / 37) < 64 && (slot) < 64) \
+    if ((threadIdx.x == 0) && (blockIdx.x % 37 == 0) && (blockIdx.x / 37) < 64 && (slot) < 64)   \
       dosx_stamp_buf[(blockIdx.x / 37) * 64 + (slot)] = __builtin_amdgcn_s_memtime();            \
   } while (0)
 // staging wave 0 (thread 256) of workgroup 0 -> row 32 of the stamp buffer
 #define STAMP_S(slot)                                                                            \
   do {                                                                                           \
-    if ((threadIdx.x == 256) && (blockIdx.y == 0) && (blockIdx.x == 0) && (slot) < 64)           \
+    if ((threadIdx.x == 256) && (blockIdx.x == 0) && (slot) < 64)                                \
+      dosx_stamp_buf[32 * 64 + (slot)] = __builtin_amdgcn_s_memtime();                           \
+  } while (0)
+// wgrad_kernel: workgroup (0,0,0), matrix wave 0 -> row 0, staging wave 0 -> row 32
+#define WSTAMP(slot)                                                                             \
+  do {                                                                                           \
+    if (threadIdx.x == 0 && blockIdx.x == 0 && (slot) < 64)                                      \
+      dosx_stamp_buf[(slot)] = __builtin_amdgcn_s_memtime();                                     \
+  } while (0)
+#define WSTAMP_S(slot)                                                                           \
+  do {                                                                                           \
+    if (threadIdx.x == 256 && blockIdx.x == 0 && (slot) < 64)                                    \
       dosx_stamp_buf[32 * 64 + (slot)] = __builtin_amdgcn_s_memtime();                           \
   } while (0)
 #else
 #define STAMP(slot) do { } while (0)
 #define STAMP_S(slot) do { } while (0)
+#define WSTAMP(slot) do { } while (0)
+#define WSTAMP_S(slot) do { } while (0)
 #endif
 
 #ifndef DOSX_PRIO_VARIANT
@@ -192,7 +205,18 @@ void gemm_kernel(const GemmLaunch L) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int m0 = blockIdx.x * BMR, n0 = blockIdx.y * BN;
+  // 1-D grid.  Workgroups go to the 8 XCDs round-robin by linear id: within a group of 8 consecutive row
+  // blocks the column blocks are enumerated next, so all column blocks of one row block run on the same XCD
+  // (id % 8 == row block % 8) and its A rows cross the fabric once, not once per column block.
+  const int gx = (g.M + BMR - 1) / BMR, gy = (g.N + BN - 1) / BN;
+  int bx, by;
+  {
+    const int lin = blockIdx.x, grp = lin / (8 * gy), rem = lin % (8 * gy);
+    const int rows_in_grp = min(8, gx - grp * 8);          // last group may be short
+    bx = grp * 8 + rem % rows_in_grp;
+    by = rem / rows_in_grp;
+  }
+  const int m0 = bx * BMR, n0 = by * BN;
   const int M = g.M, N = g.N, K = g.K;
   const int nk = (K + BK - 1) / BK;
 
@@ -707,7 +731,7 @@ void gemm_kernel(const GemmLaunch L) {
   STAMP(58);
   // ---- per-workgroup partial sums for the parameter gradients of the fused LN / PReLU ----------
   if (g.partials && (epi == DOSX_EPI_PRELU_LN_BWD || epi == DOSX_EPI_ROWLN_BWD || epi == DOSX_EPI_PRELU_BWD)) {
-    float* prow = g.partials + (size_t)(blockIdx.x * gridDim.y + blockIdx.y) * g.partial_ld;
+    float* prow = g.partials + (size_t)(bx * gy + by) * g.partial_ld;
     __syncthreads();                    // (the C tile rows of other waves are still being read above)
     if (epi != DOSX_EPI_PRELU_BWD) {
 #pragma unroll
@@ -759,7 +783,7 @@ constexpr size_t gemm_smem_bytes() {
 template <int RT, int NTW, int WL, int PRO, int VEC, int EPI>
 int launch_gemm3(const GemmLaunch& L, hipStream_t s) {
   constexpr int BN = 128 * NTW;
-  dim3 grid(ceil_div(L.g.M, BM * RT), ceil_div(L.g.N, BN));
+  dim3 grid(ceil_div(L.g.M, BM * RT) * ceil_div(L.g.N, BN));
   constexpr size_t smem = gemm_smem_bytes<RT, NTW, WL, (VEC && (PRO == DOSX_PRO_LN_PRELU || PRO == DOSX_PRO_ROWLN)) ? 1 : 0>();
   if constexpr (smem > 160 * 1024) {     // (512-column tile + LayerNorm prologue: no caller has this shape)
     dosx_set_error("dosx_gemm: tile %dx%d with prologue %d exceeds the 160 KB LDS", BM * RT, BN, PRO);
@@ -946,17 +970,24 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradLaunch L) {
   __shared__ __align__(16) float Sm[2 * STG];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int k0 = blockIdx.x * WT, n0 = blockIdx.y * WT, z = blockIdx.z;
+  // 1-D grid, the M-split index varies fastest: workgroups are dealt to the 8 XCDs round-robin by linear id,
+  // so (with 8 | nsplit) all the (n, k) tiles of one M-split land on the SAME XCD and share its L2: every
+  // dY / A row of the split crosses the fabric once instead of once per tile that uses it
+  const int ntk = (g.K + WT - 1) / WT;
+  const int z = blockIdx.x % g.nsplit, tile = blockIdx.x / g.nsplit;
+  const int bx = tile % ntk, by = tile / ntk;
+  const int k0 = bx * WT, n0 = by * WT;
   const int M = g.M, N = g.N, K = g.K;
   const int chunk = ((M + g.nsplit - 1) / g.nsplit + BM - 1) / BM * BM;
   const int ms = z * chunk, me = min(M, ms + chunk);
   const int nch = ms < me ? (me - ms + BM - 1) / BM : 0;
-  const bool do_bias = (g.slab_bias != nullptr) && (blockIdx.x == 0);
+  const bool do_bias = (g.slab_bias != nullptr) && (bx == 0);
 
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   float4 bs0 = f4zero(), bs1 = f4zero();                 // staging lanes: column sums of their dY values
+  WSTAMP(0);
 
   if (wave_u >= 4) {
     // =============================== staging waves ===============================================
@@ -978,22 +1009,30 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradLaunch L) {
     };
     Set s0, s1;
     auto pipeline = [&](auto&& issue, auto&& store) {
+      WSTAMP_S(0);
       if (nch > 0) issue(s0, ms);
       if (nch > 1) issue(s1, ms + BM);
       if (nch > 0) store(Sm, s0);
       if (nch > 2) issue(s0, ms + 2 * BM);
+      WSTAMP_S(1);
       __syncthreads();
       for (int c = 0; c < nch; c += 2) {
+        WSTAMP_S(2 + 3 * c);
         if (c + 1 < nch) {
           store(Sm + STG, s1);
+          WSTAMP_S(3 + 3 * c);
           if (c + 3 < nch) issue(s1, ms + (c + 3) * BM);
         }
+        WSTAMP_S(4 + 3 * c);
         __syncthreads();
         if (c + 1 >= nch) break;
+        WSTAMP_S(5 + 3 * c);
         if (c + 2 < nch) {
           store(Sm, s0);
+          WSTAMP_S(6 + 3 * c);
           if (c + 4 < nch) issue(s0, ms + (c + 4) * BM);
         }
+        WSTAMP_S(7 + 3 * c);
         __syncthreads();
       }
     };
@@ -1105,17 +1144,21 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradLaunch L) {
     // =============================== matrix waves ================================================
     const int wn = wave >> 1, wk = wave & 1;
     __syncthreads();
+    WSTAMP(1);
     for (int c = 0; c < nch; ++c) {
       const float* Ys = Sm + (c & 1) * STG;
       const float* Xs = Ys + BM * LDT;
+      WSTAMP(2 + 2 * c);
 #pragma unroll
       for (int mm = 0; mm < BM; mm += 2) {
         const float a = Ys[(mm + hh) * LDT + wn * 32 + l31];
         const float b = Xs[(mm + hh) * LDT + wk * 32 + l31];
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
       }
+      WSTAMP(3 + 2 * c);
       __syncthreads();
     }
+    WSTAMP(60);
     float* slab = g.slab + (size_t)z * N * K;
     const int kcol = k0 + wk * 32 + l31;
 #pragma unroll
@@ -1168,7 +1211,13 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceLaunch
     if (vec) {
       const float* p = j.src + i;
       int k = sl;
-      for (; k + 4 < j.nsplit; k += 8) {       // two independent chains keep two loads in flight
+      for (; k + 12 < j.nsplit; k += 16) {     // four loads in flight per lane (16 slabs: one batch per wave)
+        const float4 v0 = ld4(p + (size_t)k * j.stride), v1 = ld4(p + (size_t)(k + 4) * j.stride);
+        const float4 v2 = ld4(p + (size_t)(k + 8) * j.stride), v3 = ld4(p + (size_t)(k + 12) * j.stride);
+        s0 = f4add(s0, f4add(v0, v2));
+        s1 = f4add(s1, f4add(v1, v3));
+      }
+      for (; k + 4 < j.nsplit; k += 8) {
         s0 = f4add(s0, ld4(p + (size_t)k * j.stride));
         s1 = f4add(s1, ld4(p + (size_t)(k + 4) * j.stride));
       }
@@ -1223,7 +1272,7 @@ extern "C" int dosx_wgrad(const DosxWgrad* gp, dosx_stream_t stream) {
   if (g.pro == DOSX_PRO_LN_PRELU || g.pro == DOSX_PRO_ROWLN)
     L.vecA = L.vecA && aligned16(g.pro_gamma) && aligned16(g.pro_beta);
   L.vecY = ((g.dy.ld & 3) == 0) && aligned16(g.dy.p) && (g.N & 3) == 0;
-  dim3 grid(ceil_div(g.K, WT), ceil_div(g.N, WT), g.nsplit);
+  dim3 grid(ceil_div(g.K, WT) * ceil_div(g.N, WT) * g.nsplit);
   hipStream_t st = to_stream(stream);
   const int vec = L.vecA && L.vecY;
   // fast (buffer-addressed) staging: affine row maps (+ optional gather on A), K tiles inside one segment,
