@@ -64,7 +64,7 @@ def cpu_baseline(kind, L, T, H, B, budget_s=15.0):
     state = {}
     # pick the thread count the oracle runs fastest with on this box (the reference pins 2,
     # main_phDOS.py:12; all cores of a big host oversubscribe these small ops badly)
-    best_t, best = 2, None
+    best_t, best, t2 = 2, None, None
     for nt in (2, 8, 16, 32):
         if nt > (os.cpu_count() or 1):
             break
@@ -73,6 +73,8 @@ def cpu_baseline(kind, L, T, H, B, budget_s=15.0):
         t0 = time.perf_counter()
         O.train_step(kind, params, state, g, L, T)
         el = time.perf_counter() - t0
+        if nt == 2:
+            t2 = el                                        # the reference's own setting (torch.set_num_threads(2))
         if best is None or el < best:
             best_t, best = nt, el
     torch.set_num_threads(best_t)
@@ -84,9 +86,19 @@ def cpu_baseline(kind, L, T, H, B, budget_s=15.0):
         el = time.perf_counter() - t0
         if el > budget_s or n >= 200:
             break
+    cpu_model = "unknown CPU"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {"value": round(B * n / el, 2), "unit": "crystals/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n} full train steps (fwd+loss+bwd+AdamW) of one batch of {B} crystals, "
-                      f"{'fp64' if dt == torch.float64 else 'fp32'}, {el:.1f}s, ms/step {1e3 * el / n:.1f}"}
+                      f"{'fp64' if dt == torch.float64 else 'fp32'}, {el:.1f}s, ms/step {1e3 * el / n:.1f}; "
+                      f"host: {cpu_model}, {os.cpu_count()} logical CPUs, fastest of 2/8/16/32 threads; with the "
+                      f"reference's own 2 threads: {B / t2:.1f} crystals/s"}
 
 
 def main():
@@ -127,7 +139,10 @@ def main():
     if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        td.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        # (no device_id=: the eager communicator it creates costs every later kernel launch of this process
+        #  ~3 us on this stack: 2.42 vs 1.92 ms/step measured with tools/dist_overhead.py; the device is
+        #  already selected with torch.cuda.set_device above)
+        td.init_process_group("nccl", rank=rank, world_size=world)
         from dostransformer_amd.dist import DataParallel
         dp = DataParallel()
 
