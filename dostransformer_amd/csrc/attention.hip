@@ -4,9 +4,12 @@
 //
 // (layers/transformer.py:131-138 + layers/multihead_attention.py:68-74: no q/k/v/out projection,
 //  no mask, no head split; zero-padded atoms are real keys with value beta0 — SURVEY.md §0.2-0.3.)
-// One workgroup (4 waves) owns a 32-query tile of one crystal; the whole key set of a crystal
-// (Nk <= 320: atoms <= Nmax, or the 51/201 energy bins for self attention) lives in LDS, so the
-// softmax is exact (no online rescaling).  QK^T and PV run on v_mfma_f32_32x32x2_f32.
+// One workgroup owns a 32-query tile of one crystal; the key set of the crystal (Nk <= 320: atoms <= Nmax,
+// or the 51/201 energy bins for self attention) is streamed twice through LDS in 32-wide chunks by four
+// staging waves while four matrix waves run the row phases and the MFMAs; the whole score row of a
+// query lives in LDS, so the softmax is exact (no online rescaling).
+#include <stdlib.h>
+
 #include "common.h"
 
 // Diagnostic build only (-DDOSX_STAMPS): wave 0 of workgroup (0,0) records s_memtime at phase boundaries.
@@ -47,327 +50,6 @@ __host__ __device__ inline Geo make_geo(int H, int Nk) {
 // floats of one streamed-chunk buffer: a K chunk is [NKP][36], a V chunk is [32][LDH]
 __host__ __device__ inline int chunk_buf_floats(int NKP, int LDH) { return NKP * LDK > KC * LDH ? NKP * LDK : KC * LDH; }
 
-// Load 32 rows x H (float4) of a row-strided matrix into LDS [32][LDH], zero padded.
-// row pointer for tile row i: base + rowoff(i) (nullptr -> zeros).  Optional affine LN on load:
-//   v = (v - mean)*rstd*gamma + beta   (stats == nullptr: plain copy)
-template <class RowPtr>
-__device__ __forceinline__ void load_rows(float* dst, int LDH, int HP, int H, RowPtr rowptr, int tid) {
-  const int row = tid >> 3;
-  const float* p = rowptr(row);
-  const bool ok = p != nullptr;
-  const float* q = ok ? p : rowptr(0);          // tile row 0 is always a valid row
-  for (int c = (tid & 7) * 4; c < HP; c += 32) {
-    float4 v = ld4(q + (c < H ? c : 0));        // unconditional load, masked afterwards (no branch)
-    if (!(ok && c < H)) v = f4zero();
-    st4(dst + row * LDH + c, v);
-  }
-}
-
-// Streamed (non-resident) key tiles.  A chunk is fetched into registers one chunk ahead (the loads fly
-// under the MFMAs of the current chunk) and written, with the key affine applied, into the OTHER of two
-// LDS chunk buffers: one barrier per chunk.
-constexpr int MAXKR = 10;   // 32-key row blocks per crystal (Nk <= 320)
-constexpr int MAXVC = 8;    // 32-column blocks per row (H <= 256)
-
-// K chunk for the NT products: Ks[j][0..31] = kvhat[(j*Bk+bk)][kc..kc+31]*gamma+beta, j < Nk else 0
-struct KChunk { float4 h[MAXKR], g, b; };
-__device__ __forceinline__ void k_chunk_load(KChunk& r, const float* __restrict__ kvhat, const float* __restrict__ gamma,
-                                             const float* __restrict__ beta, int Nk, int NKP, int Bk, int bk, int H,
-                                             int kc, int tid) {
-  const int k = kc + (tid & 7) * 4, kk = k < H ? k : 0;
-  r.g = ld4(gamma + kk);
-  r.b = ld4(beta + kk);
-#pragma unroll
-  for (int i = 0; i < MAXKR; ++i) {
-    const int j = (tid >> 3) + 32 * i;
-    if (j < NKP) r.h[i] = ld4(kvhat + ((size_t)min(j, Nk - 1) * Bk + bk) * H + kk);
-  }
-}
-__device__ __forceinline__ void k_chunk_store(float* Ks, const KChunk& r, int Nk, int NKP, int H, int kc, int tid) {
-  const int kq = (tid & 7) * 4, k = kc + kq;
-#pragma unroll
-  for (int i = 0; i < MAXKR; ++i) {
-    const int j = (tid >> 3) + 32 * i;
-    if (j >= NKP) break;
-    const float4 h = r.h[i];
-    float4 v = make_float4(h.x * r.g.x + r.b.x, h.y * r.g.y + r.b.y, h.z * r.g.z + r.b.z, h.w * r.g.w + r.b.w);
-    if (!(j < Nk && k < H)) v = f4zero();
-    st4(Ks + j * LDK + kq, v);
-  }
-}
-
-// V chunk for the NN products: Vs[jj][0..HP) = K rows j0..j0+31 (affine), zero beyond Nk / H
-struct VChunk { float4 h[MAXVC]; };
-__device__ __forceinline__ void v_chunk_load(VChunk& r, const float* __restrict__ kvhat, int Nk, int Bk, int bk, int H,
-                                             int HP, int j0, int tid) {
-  const int j = j0 + (tid >> 3);
-  const float* row = kvhat + ((size_t)min(j, Nk - 1) * Bk + bk) * H;
-#pragma unroll
-  for (int i = 0; i < MAXVC; ++i) {
-    const int c = (tid & 7) * 4 + 32 * i;
-    if (c < HP) r.h[i] = ld4(row + (c < H ? c : 0));
-  }
-}
-__device__ __forceinline__ void v_chunk_store(float* Vs, const VChunk& r, const float4 (&g)[MAXVC], const float4 (&b)[MAXVC],
-                                              int Nk, int H, int HP, int LDH, int j0, int tid) {
-  const int jj = tid >> 3, j = j0 + jj;
-#pragma unroll
-  for (int i = 0; i < MAXVC; ++i) {
-    const int c = (tid & 7) * 4 + 32 * i;
-    if (c >= HP) break;
-    const float4 h = r.h[i];
-    float4 v = make_float4(h.x * g[i].x + b[i].x, h.y * g[i].y + b[i].y, h.z * g[i].z + b[i].z, h.w * g[i].w + b[i].w);
-    if (!(j < Nk && c < H)) v = f4zero();
-    st4(Vs + jj * LDH + c, v);
-  }
-}
-
-// Whole key set of one crystal into LDS: Ks[j][0..HP) = kvhat[(j*Bk+bk)]*gamma+beta (zero beyond Nk / H).
-// Used by the key-resident kernels: ONE global-load phase, then QK^T and PV both read this tile.
-__device__ __forceinline__ void stage_k_full(float* Ks, const float* __restrict__ kvhat, const float* __restrict__ gamma,
-                                             const float* __restrict__ beta, int Nk, int NKP, int Bk, int bk, int H, int HP,
-                                             int LDH, int tid) {
-  // items: (32-key block jb, 32-column block cb); this thread owns key jb*32 + tid/8, columns cb*32 + (tid%8)*4.
-  // Loads are issued in batches of 8 before any is used (a load-use-store loop exposes one global round
-  // trip per item: ~0.7 us each, 4..8 of them in front of the first MFMA).
-  const int ncb = HP / 32, nit = (NKP / 32) * ncb;
-  const int jr = tid >> 3, cq = (tid & 7) * 4;
-  for (int i0 = 0; i0 < nit; i0 += 8) {
-    float4 h[8], gq[8], bq[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int it = min(i0 + u, nit - 1);
-      const int j = (it / ncb) * 32 + jr, c = (it % ncb) * 32 + cq, cc = c < H ? c : 0;
-      h[u] = ld4(kvhat + ((size_t)min(j, Nk - 1) * Bk + bk) * H + cc);
-      gq[u] = ld4(gamma + cc);
-      bq[u] = ld4(beta + cc);
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int it = i0 + u;
-      if (it >= nit) break;
-      const int j = (it / ncb) * 32 + jr, c = (it % ncb) * 32 + cq;
-      float4 v = make_float4(h[u].x * gq[u].x + bq[u].x, h[u].y * gq[u].y + bq[u].y, h[u].z * gq[u].z + bq[u].z,
-                             h[u].w * gq[u].w + bq[u].w);
-      if (!(j < Nk && c < H)) v = f4zero();
-      st4(Ks + j * LDH + c, v);
-    }
-  }
-}
-
-// How the QK^T-shaped products are split over the 4 waves.  With >= 3 key tiles every wave owns whole
-// 32-key tiles (jt = wave + 4t) and the full feature range.  With 1 or 2 key tiles (the 12-atom /
-// 51-bin cases of the phonon configs) that would leave 3 or 2 waves idle for 16 serial MFMA steps, so
-// the FEATURE range is split instead: ks = 4 (or 2) partial score tiles, summed when the scores are read.
-struct QkSplit {
-  int ks;       // partial tiles
-  int kpart;    // this wave's partial
-  int jt0;      // this wave's first key tile
-  int jstep;    // key-tile stride (4 when ks == 1: tiles wave, wave+4, ...; else no second tile)
-};
-__host__ __device__ inline int qk_ks(int NKP, int HP, bool kres) {
-  if (!kres) return 1;
-  const int nkt = NKP / 32;
-  if (nkt == 1 && HP % 32 == 0) return 4;
-  if (nkt == 2 && HP % 16 == 0) return 2;
-  return 1;
-}
-__device__ __forceinline__ QkSplit make_split(int NKP, int HP, bool kres, int wave) {
-  QkSplit q;
-  q.ks = qk_ks(NKP, HP, kres);
-  q.kpart = q.ks == 4 ? wave : (q.ks == 2 ? (wave >> 1) : 0);
-  q.jt0 = q.ks == 4 ? 0 : (q.ks == 2 ? (wave & 1) : wave);
-  q.jstep = q.ks == 1 ? 4 : 1024;
-  return q;
-}
-
-// S[32][NKP] (+)= A[32][H] . K^T : A tile resident in LDS (As, stride LDH), K streamed in k-chunks
-// (or resident: KRES).  Partial products of wave-split `q` stay in acc; store_scores() writes them to
-// the partial tile q.kpart.
-template <bool KRES>
-__device__ __forceinline__ void qk_product(f32x16 (&acc)[MAX_KT], const float* As, int LDH, float* Ks,
-                                           const float* kvhat, const float* gamma, const float* beta, int Nk, int NKP,
-                                           int Bk, int bk, int H, int HP, int tid, const QkSplit q) {
-  const int lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
-  const int nkt = NKP / 32;
-#pragma unroll
-  for (int t = 0; t < MAX_KT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  const int kbeg = q.kpart * (HP / q.ks), kend = kbeg + HP / q.ks;
-  if (KRES) {
-    // software-pipelined: the fragments of step k+8 are read from LDS while the MFMAs of step k run
-    // (the loop bounds are run-time values, hipcc does not pipeline it by itself: ~200 clk of exposed
-    // ds_read latency per 8-12 MFMAs otherwise)
-    const float* ap = As + l31 * LDH + 4 * hh;
-    const float* bp[MAX_KT];
-    bool on[MAX_KT];
-#pragma unroll
-    for (int t = 0; t < MAX_KT; ++t) {
-      const int jt = q.jt0 + q.jstep * t;
-      on[t] = jt < nkt;
-      bp[t] = Ks + ((on[t] ? jt : 0) * 32 + l31) * LDH + 4 * hh;
-    }
-    float4 an = ld4(ap + kbeg), bn[MAX_KT];
-#pragma unroll
-    for (int t = 0; t < MAX_KT; ++t) bn[t] = on[t] ? ld4(bp[t] + kbeg) : f4zero();
-    for (int k = kbeg; k < kend; k += 8) {
-      const float4 a = an;
-      float4 b[MAX_KT];
-#pragma unroll
-      for (int t = 0; t < MAX_KT; ++t) b[t] = bn[t];
-      const int kn = (k + 8 < kend) ? k + 8 : k;
-      an = ld4(ap + kn);
-#pragma unroll
-      for (int t = 0; t < MAX_KT; ++t)
-        if (on[t]) bn[t] = ld4(bp[t] + kn);
-#pragma unroll
-      for (int t = 0; t < MAX_KT; ++t) {
-        if (!on[t]) continue;
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t].y, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
-      }
-    }
-    return;
-  }
-  // streamed K: two chunk buffers (Ks, Ks + CHB), register prefetch one chunk ahead, one barrier per chunk
-  const int CHB = chunk_buf_floats(NKP, LDH);
-  KChunk kr;
-  k_chunk_load(kr, kvhat, gamma, beta, Nk, NKP, Bk, bk, H, 0, tid);
-  k_chunk_store(Ks, kr, Nk, NKP, H, 0, tid);
-  __syncthreads();
-  for (int kc = 0, ib = 0; kc < HP; kc += KC, ib ^= 1) {
-    const float* Kc = Ks + ib * CHB;
-    const bool more = kc + KC < HP;
-    if (more) k_chunk_load(kr, kvhat, gamma, beta, Nk, NKP, Bk, bk, H, kc + KC, tid);
-#pragma unroll
-    for (int kk = 0; kk < KC; kk += 8) {
-      const float4 a = ld4(As + l31 * LDH + kc + kk + 4 * hh);
-#pragma unroll
-      for (int t = 0; t < MAX_KT; ++t) {
-        const int jt = q.jt0 + q.jstep * t;
-        if (jt >= nkt) continue;
-        const float4 b = ld4(Kc + (jt * 32 + l31) * LDK + kk + 4 * hh);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
-      }
-    }
-    if (more) k_chunk_store(Ks + (ib ^ 1) * CHB, kr, Nk, NKP, H, kc + KC, tid);
-    __syncthreads();
-  }
-}
-
-// store the (partial) QK^T accumulators into partial tile q.kpart of Ss ([ks][32][LDS_])
-__device__ __forceinline__ void store_scores(const f32x16 (&acc)[MAX_KT], float* Ss, int LDS_, int NKP, int tid,
-                                             const QkSplit q) {
-  const int lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
-  const int nkt = NKP / 32;
-  float* Sp = Ss + q.kpart * QT * LDS_;
-#pragma unroll
-  for (int t = 0; t < MAX_KT; ++t) {
-    const int jt = q.jt0 + q.jstep * t;
-    if (jt >= nkt) continue;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-      Sp[row * LDS_ + jt * 32 + l31] = acc[t][r];
-    }
-  }
-}
-
-// O[32][HP] = P[32][NKP] . V : P resident in LDS (Ps, stride LDS_), V streamed in 32-key chunks.
-template <bool KRES>
-__device__ __forceinline__ void pv_product(f32x16 (&acc)[MAX_CT], const float* Ps, int LDS_, float* Vs,
-                                           const float* kvhat, const float* gamma, const float* beta, int Nk, int NKP,
-                                           int Bk, int bk, int H, int HP, int LDH, int tid) {
-  const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-  const int nct = HP / 32;
-#pragma unroll
-  for (int t = 0; t < MAX_CT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  if (KRES) {
-    // resident V (= K) tile: software-pipelined like qk_product
-    const float* ap = Ps + l31 * LDS_ + 4 * hh;
-    const float* vp[MAX_CT];
-    bool on[MAX_CT];
-#pragma unroll
-    for (int t = 0; t < MAX_CT; ++t) {
-      const int ct = wave + 4 * t;
-      on[t] = ct < nct;
-      vp[t] = Vs + (4 * hh) * LDH + (on[t] ? ct : 0) * 32 + l31;
-    }
-    float4 an = ld4(ap);
-    float bn[MAX_CT][4];
-#pragma unroll
-    for (int t = 0; t < MAX_CT; ++t)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) bn[t][c] = on[t] ? vp[t][c * LDH] : 0.f;
-    for (int j = 0; j < NKP; j += 8) {
-      const float4 a = an;
-      float b[MAX_CT][4];
-#pragma unroll
-      for (int t = 0; t < MAX_CT; ++t)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) b[t][c] = bn[t][c];
-      const int jn = (j + 8 < NKP) ? j + 8 : j;
-      an = ld4(ap + jn);
-#pragma unroll
-      for (int t = 0; t < MAX_CT; ++t)
-        if (on[t]) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) bn[t][c] = vp[t][(jn + c) * LDH];
-        }
-#pragma unroll
-      for (int t = 0; t < MAX_CT; ++t) {
-        if (!on[t]) continue;
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t][0], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t][1], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t][2], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t][3], acc[t], 0, 0, 0);
-      }
-    }
-    return;
-  }
-  const int CHB = chunk_buf_floats(NKP, LDH);
-  float4 gq[MAXVC], bq[MAXVC];
-#pragma unroll
-  for (int i = 0; i < MAXVC; ++i) {
-    const int c = (tid & 7) * 4 + 32 * i, cc = c < H ? c : 0;
-    gq[i] = ld4(gamma + cc);
-    bq[i] = ld4(beta + cc);
-  }
-  VChunk vr;
-  v_chunk_load(vr, kvhat, Nk, Bk, bk, H, HP, 0, tid);
-  v_chunk_store(Vs, vr, gq, bq, Nk, H, HP, LDH, 0, tid);
-  __syncthreads();
-  for (int j0 = 0, ib = 0; j0 < NKP; j0 += KC, ib ^= 1) {
-    const float* Vc = Vs + ib * CHB;
-    const bool more = j0 + KC < NKP;
-    if (more) v_chunk_load(vr, kvhat, Nk, Bk, bk, H, HP, j0 + KC, tid);
-#pragma unroll
-    for (int kk = 0; kk < KC; kk += 8) {
-      const float4 a = ld4(Ps + l31 * LDS_ + j0 + kk + 4 * hh);
-#pragma unroll
-      for (int t = 0; t < MAX_CT; ++t) {
-        const int ct = wave + 4 * t;
-        if (ct >= nct) continue;
-        const float* bp = Vc + (kk + 4 * hh) * LDH + ct * 32 + l31;
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bp[0], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bp[LDH], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bp[2 * LDH], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bp[3 * LDH], acc[t], 0, 0, 0);
-      }
-    }
-    if (more) v_chunk_store(Vs + (ib ^ 1) * CHB, vr, gq, bq, Nk, H, HP, LDH, j0 + KC, tid);
-    __syncthreads();
-  }
-}
-
 __device__ __forceinline__ void store_out_tile(const f32x16 (&acc)[MAX_CT], float* Os, int LDH, int HP, int tid) {
   const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
   const int nct = HP / 32;
@@ -395,24 +77,207 @@ constexpr int KCB = 4;     // 64-column blocks per row (H <= 256)
 
 __device__ __forceinline__ int row_of(int wave, int p, int lane) { return wave * 8 + p * 4 + (lane >> 4); }
 
-// ================================== forward =====================================================
-// NJ = ceil(Nk / 16): keys per lane in the softmax (compile time: 1 / 4 / 20 cover Nk <= 16 / 64 / 320).
-template <bool KRES, int NJ>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const DosxAttn a) {
+// ================================== streamed keys: wave-specialised kernels ========================
+// When the key set of a crystal does not fit the LDS next to the query tile (eDOS: 201 bins x 256 features),
+// the keys are STREAMED twice (once for Q.K^T, once for P.V) in 32-wide chunks.  Same recipe as gemm_kernel:
+// 8 waves = 4 matrix waves (row phases + MFMA) + 4 staging waves that only move the next chunk
+// global -> registers -> LDS (two chunk buffers, one barrier per chunk, loads two chunks deep).
+// The staging path carries NO arithmetic: the key affine is folded out of the products,
+//     (x̂q γ+β) . (k̂ γ+β)  =  ((x̂q γ+β) ∘ γ) . k̂  + const(q)        (the constant cancels in the softmax)
+//     P . (k̂ γ+β)          =  (P . k̂) ∘ γ + β                        (rows of P sum to 1)
+//     dO . (k̂ γ+β)^T       =  (dO ∘ γ) . k̂^T + const(q)               (cancels in dS = P ∘ (dP - Σ P dP))
+//     dS . (k̂ γ+β)         =  (dS . k̂) ∘ γ                           (rows of dS sum to 0)
+// so both operands are the raw normalised keys k̂ (`kvhat`), fetched with buffer loads whose bounds return
+// zeros for the rows beyond Nk.  (Exact in real arithmetic; fp32 rounding differs from the resident-key
+// kernels at the 1e-7 level, tests/test_gpu_ops.py::test_attention_fwd_bwd covers both.)
+constexpr int SKR = 10;    // 32-key row blocks per crystal (Nk <= 320): float4 per staging lane per K chunk
+constexpr int SVC = 8;     // 32-column blocks per row (H <= 256):      float4 per staging lane per V chunk
+
+struct StreamGeo {
+  int nkc;     // K chunks  = HP / 32 (feature chunks of the Q.K^T-shaped product)
+  int nvc;     // V chunks  = NKP / 32 (key chunks of the P.V-shaped product)
+  int CHB;     // floats of one chunk buffer
+};
+
+// The staging waves' whole job.  `sync()` is the workgroup barrier; the matrix waves execute the mirror-image
+// sequence in stream_matrix_*().  Barrier schedule:  [K prologue] B | nkc x (B) | [V prologue] B | B | nvc x (B)
+__device__ __forceinline__ void stream_stage(const DosxAttn& a, const Geo& g, const StreamGeo& sg, float* CH, int bk, int st) {
+  const int H = a.H, Nk = a.Nk;
+  const __amdgpu_buffer_rsrc_t rK =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.kvhat, 0, (uint32_t)((size_t)Nk * a.Bk * H * 4), 0x00020000);
+  const int jr = st >> 3, q4 = (st & 7) * 4;
+  // ---- K chunks: Ks[j][0..31] = kvhat[j*Bk+bk][32c .. 32c+31], j = jr + 32 i
+  {
+    const int nrb = g.NKP / 32;
+    uint32_t voff[SKR];
+#pragma unroll
+    for (int i = 0; i < SKR; ++i) voff[i] = (uint32_t)((((size_t)(jr + 32 * i) * a.Bk + bk) * H + q4) * 4);
+    float4 r0[SKR], r1[SKR];
+    auto issue = [&](float4(&r)[SKR], int c) {
+      const int so = __builtin_amdgcn_readfirstlane(c) * (KC * 4);
+#pragma unroll
+      for (int i = 0; i < SKR; ++i)
+        if (i < nrb) r[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rK, voff[i], so, 0));
+    };
+    auto store = [&](float* buf, const float4(&r)[SKR]) {
+#pragma unroll
+      for (int i = 0; i < SKR; ++i)
+        if (i < nrb) st4(buf + (jr + 32 * i) * LDK + q4, r[i]);
+    };
+    issue(r0, 0);
+    if (sg.nkc > 1) issue(r1, 1);
+    store(CH, r0);
+    if (sg.nkc > 2) issue(r0, 2);
+    __syncthreads();
+    for (int c = 0; c < sg.nkc; c += 2) {
+      if (c + 1 < sg.nkc) {
+        store(CH + sg.CHB, r1);
+        if (c + 3 < sg.nkc) issue(r1, c + 3);
+      }
+      __syncthreads();
+      if (c + 1 >= sg.nkc) break;
+      if (c + 2 < sg.nkc) {
+        store(CH, r0);
+        if (c + 4 < sg.nkc) issue(r0, c + 4);
+      }
+      __syncthreads();
+    }
+  }
+  // ---- V chunks: Vs[jj][0..HP) = kvhat[(32c+jj)*Bk+bk][0..HP)   (both chunk buffers are free again)
+  {
+    const int ncb = g.HP / 32;
+    uint32_t voff[SVC];
+#pragma unroll
+    for (int i = 0; i < SVC; ++i) {
+      const int c = q4 + 32 * i;
+      voff[i] = (uint32_t)((((size_t)jr * a.Bk + bk) * H + (c < H ? c : 0)) * 4);
+    }
+    const int step = KC * a.Bk * H * 4;                    // bytes between consecutive 32-key chunks
+    float4 r0[SVC], r1[SVC];
+    auto issue = [&](float4(&r)[SVC], int c) {
+      const int so = __builtin_amdgcn_readfirstlane(c) * step;
+#pragma unroll
+      for (int i = 0; i < SVC; ++i)
+        if (i < ncb) r[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rK, voff[i], so, 0));
+    };
+    auto store = [&](float* buf, const float4(&r)[SVC]) {
+#pragma unroll
+      for (int i = 0; i < SVC; ++i)
+        if (i < ncb) st4(buf + jr * g.LDH + q4 + 32 * i, r[i]);
+    };
+    issue(r0, 0);
+    if (sg.nvc > 1) issue(r1, 1);
+    store(CH, r0);
+    if (sg.nvc > 2) issue(r0, 2);
+    __syncthreads();            // (matrix waves: scores stored)
+    __syncthreads();            // (matrix waves: softmax / dS done)
+    for (int c = 0; c < sg.nvc; c += 2) {
+      if (c + 1 < sg.nvc) {
+        store(CH + sg.CHB, r1);
+        if (c + 3 < sg.nvc) issue(r1, c + 3);
+      }
+      __syncthreads();
+      if (c + 1 >= sg.nvc) break;
+      if (c + 2 < sg.nvc) {
+        store(CH, r0);
+        if (c + 4 < sg.nvc) issue(r0, c + 4);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// matrix waves: S[32][NKP] = A[32][HP] . kvhat^T, one barrier per streamed feature chunk
+__device__ __forceinline__ void stream_qk(f32x16 (&acc)[MAX_KT], const float* As, int LDH, const float* CH, const StreamGeo& sg,
+                                          int NKP, int tid) {
+  const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int nkt = NKP / 32;
+#pragma unroll
+  for (int t = 0; t < MAX_KT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  for (int c = 0; c < sg.nkc; ++c) {
+    const float* Kc = CH + (c & 1) * sg.CHB;
+#pragma unroll
+    for (int kk = 0; kk < KC; kk += 8) {
+      const float4 av = ld4(As + l31 * LDH + c * KC + kk + 4 * hh);
+#pragma unroll
+      for (int t = 0; t < MAX_KT; ++t) {
+        const int jt = wave + 4 * t;
+        if (jt >= nkt) continue;
+        const float4 b = ld4(Kc + (jt * 32 + l31) * LDK + kk + 4 * hh);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b.x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b.y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b.z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b.w, acc[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// matrix waves: O[32][HP] = P[32][NKP] . kvhat, one barrier per streamed key chunk
+__device__ __forceinline__ void stream_pv(f32x16 (&acc)[MAX_CT], const float* Ps, int LDS_, const float* CH, const StreamGeo& sg,
+                                          int HP, int LDH, int tid) {
+  const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int nct = HP / 32;
+#pragma unroll
+  for (int t = 0; t < MAX_CT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  for (int c = 0; c < sg.nvc; ++c) {
+    const float* Vc = CH + (c & 1) * sg.CHB;
+#pragma unroll
+    for (int kk = 0; kk < KC; kk += 8) {
+      const float4 av = ld4(Ps + l31 * LDS_ + c * KC + kk + 4 * hh);
+#pragma unroll
+      for (int t = 0; t < MAX_CT; ++t) {
+        const int ct = wave + 4 * t;
+        if (ct >= nct) continue;
+        const float* bp = Vc + (kk + 4 * hh) * LDH + ct * 32 + l31;
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bp[0], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bp[LDH], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bp[2 * LDH], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bp[3 * LDH], acc[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ void store_scores1(const f32x16 (&acc)[MAX_KT], float* Ss, int LDS_, int NKP, int tid) {
+  const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int nkt = NKP / 32;
+#pragma unroll
+  for (int t = 0; t < MAX_KT; ++t) {
+    const int jt = wave + 4 * t;
+    if (jt >= nkt) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Ss[((r & 3) + 8 * (r >> 2) + 4 * hh) * LDS_ + jt * 32 + l31] = acc[t][r];
+  }
+}
+
+template <int NJ>
+__global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const DosxAttn a) {
   extern __shared__ __align__(16) float sm[];
   const Geo g = make_geo(a.H, a.Nk);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q16 = lane & 15;
-  const QkSplit q = make_split(g.NKP, g.HP, KRES, wave);
+  StreamGeo sg;
+  sg.nkc = g.HP / 32; sg.nvc = g.NKP / 32; sg.CHB = chunk_buf_floats(g.NKP, g.LDH);
   float* Qs = sm;                                   // [32][LDH]   (later: output tile)
-  float* Ss = Qs + QT * g.LDH;                      // [ks][32][LDS_] partial scores; tile 0 becomes P
-  float* KV = Ss + q.ks * QT * g.LDS_;              // max(NKP*36, 32*LDH) or the whole key tile
+  float* Ss = Qs + QT * g.LDH;                      // [32][LDS_]  scores -> P
+  float* CH = Ss + QT * g.LDS_;                     // two chunk buffers
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q16 = lane & 15;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int s0 = blockIdx.x * QT, bq = blockIdx.y, bk = bq % a.Bk;
+  if (wave_u >= 4) {
+    stream_stage(a, g, sg, CH, bk, tid - 256);
+    return;                                         // (the epilogue barrier below counts live waves only)
+  }
   const int H = a.H, Sq = a.Sq, Nk = a.Nk;
   const bool raw_q = (a.flags & DOSX_ATTN_RAW_Q) != 0;
   const float invH = 1.f / (float)H;
-  ASTAMP(0);
 
-  // ---- query rows: global -> registers (kept for the residual) -> LayerNorm -> LDS ----
+  // ---- query rows: global -> registers (kept for the residual) -> LayerNorm -> (x gamma) -> LDS ----
   float4 xr[RP][KCB], g0[KCB], b0[KCB];
 #pragma unroll
   for (int k = 0; k < KCB; ++k) {
@@ -425,8 +290,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const DosxAttn a) {
       xr[p][k] = ld4(a.x + ((size_t)s * a.q_stride_s + (size_t)bq * a.q_stride_b) * H + cc);
     }
   }
-  if (KRES) stage_k_full(KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, g.LDH, tid);
-  ASTAMP(1);
   {
     float mean[RP], rstd[RP];
 #pragma unroll
@@ -466,6 +329,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const DosxAttn a) {
         if (!raw_q)
           o = make_float4((v.x - mean[p]) * rstd[p] * g0[k].x + b0[k].x, (v.y - mean[p]) * rstd[p] * g0[k].y + b0[k].y,
                           (v.z - mean[p]) * rstd[p] * g0[k].z + b0[k].z, (v.w - mean[p]) * rstd[p] * g0[k].w + b0[k].w);
+        o = make_float4(o.x * g0[k].x, o.y * g0[k].y, o.z * g0[k].z, o.w * g0[k].w);      // key gamma folded into Q
         if (!(c < H && s < Sq)) o = f4zero();
         st4(Qs + lr * g.LDH + c, o);
       }
@@ -475,21 +339,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const DosxAttn a) {
       }
     }
   }
-  ASTAMP(2);
   __syncthreads();
-  ASTAMP(3);
 
   f32x16 sacc[MAX_KT];
-  qk_product<KRES>(sacc, Qs, g.LDH, KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, tid, q);
-  store_scores(sacc, Ss, g.LDS_, g.NKP, tid, q);
-  ASTAMP(4);
+  stream_qk(sacc, Qs, g.LDH, CH, sg, g.NKP, tid);
+  store_scores1(sacc, Ss, g.LDS_, g.NKP, tid);
   __syncthreads();
-  ASTAMP(5);
 
   // ---- exact fp32 softmax over the Nk keys (padded atoms included, like the reference) ----
   {
     const float scale = rsqrtf((float)H);
-    const int pstride = QT * g.LDS_;
     float v[RP][NJ], mx[RP], sum[RP];
 #pragma unroll
     for (int p = 0; p < RP; ++p) {
@@ -498,13 +357,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const DosxAttn a) {
 #pragma unroll
       for (int jj = 0; jj < NJ; ++jj) {
         const int j = q16 + 16 * jj;
-        float t = -INFINITY;
-        if (j < Nk) {
-          t = row[j];
-          if (q.ks > 1) t += row[pstride + j];
-          if (q.ks > 2) t += row[2 * pstride + j] + row[3 * pstride + j];
-          t *= scale;
-        }
+        const float t = j < Nk ? row[j] * scale : -INFINITY;
         v[p][jj] = t;
         mx[p] = fmaxf(mx[p], t);
       }
@@ -535,23 +388,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const DosxAttn a) {
         row[j] = pr;
         if (j < Nk && s < Sq) a.probs[((size_t)bq * Sq + s) * Nk + j] = pr;
       }
-      if (NJ * 16 < g.NKP) {                          // (NJ*16 >= Nk always; zero the rest of the padded tile)
+      if (NJ * 16 < g.NKP) {
         for (int j = NJ * 16 + q16; j < g.NKP; j += 16) row[j] = 0.f;
       }
     }
   }
-  ASTAMP(6);
   __syncthreads();
-  ASTAMP(7);
 
   f32x16 oacc[MAX_CT];
-  pv_product<KRES>(oacc, Ss, g.LDS_, KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, g.LDH, tid);
+  stream_pv(oacc, Ss, g.LDS_, CH, sg, g.HP, g.LDH, tid);
   store_out_tile(oacc, Qs, g.LDH, g.HP, tid);
-  ASTAMP(8);
-  __syncthreads();
-  ASTAMP(9);
+  __syncthreads();                                  // (matrix waves only: the staging waves have exited)
 
-  // ---- epilogue: residual add from the kept query rows, statistics of the output rows (feeds LN1) ----
+  // ---- epilogue: (P.k̂) gamma + beta + residual, statistics of the output rows (feeds LN1) ----
   {
     const bool no_res = (a.flags & DOSX_ATTN_NO_RESIDUAL) != 0;
     float4 o[RP][KCB];
@@ -565,7 +414,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const DosxAttn a) {
         const int c = q16 * 4 + 64 * k;
         float4 v = f4zero();
         if (c < H) {
-          v = ld4(Qs + lr * g.LDH + c);
+          const float4 r = ld4(Qs + lr * g.LDH + c);
+          v = make_float4(r.x * g0[k].x + b0[k].x, r.y * g0[k].y + b0[k].y, r.z * g0[k].z + b0[k].z, r.w * g0[k].w + b0[k].w);
           if (!no_res) v = f4add(v, xr[p][k]);
           if (s < Sq) st4(a.out + ((size_t)s * a.Bq + bq) * H + c, v);
           t += (v.x + v.y) + (v.z + v.w);
@@ -602,30 +452,33 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const DosxAttn a) {
       }
     }
   }
-  ASTAMP(10);
 }
 
-// ================================== backward: dq / dx ============================================
-template <bool KRES, int NJ>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const DosxAttn a) {
+template <int NJ>
+__global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(const DosxAttn a) {
   extern __shared__ __align__(16) float sm[];
   const Geo g = make_geo(a.H, a.Nk);
+  StreamGeo sg;
+  sg.nkc = g.HP / 32; sg.nvc = g.NKP / 32; sg.CHB = chunk_buf_floats(g.NKP, g.LDH);
+  float* Ds = sm;                                   // [32][LDH]  dOut*gamma tile, later dS.k̂ tile
+  float* Ss = Ds + QT * g.LDH;                      // [32][LDS_] dP -> dS
+  float* CH = Ss + QT * g.LDS_;                     // two chunk buffers; later [16][2][HP] column partial sums
+  float* Pp = CH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q16 = lane & 15;
-  const QkSplit q = make_split(g.NKP, g.HP, KRES, wave);
-  float* Ds = sm;                                   // [32][LDH]  dOut tile, later dq tile
-  float* Ss = Ds + QT * g.LDH;                      // [ks][32][LDS_] partial dP; tile 0 becomes dS
-  float* KV = Ss + q.ks * QT * g.LDS_;              // chunk staging, or the whole key tile (KRES)
-  // [16][2][HP] partial column sums: behind the resident key tile, or (streamed keys) ON the chunk buffers,
-  // which are dead after the dS.K product
-  float* Pp = KRES ? KV + g.NKP * g.LDH : KV;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int s0 = blockIdx.x * QT, bq = blockIdx.y, bk = bq % a.Bk;
+  if (wave_u >= 4) {
+    stream_stage(a, g, sg, CH, bk, tid - 256);
+    return;
+  }
   const int H = a.H, Sq = a.Sq, Nk = a.Nk;
   const bool raw_q = (a.flags & DOSX_ATTN_RAW_Q) != 0, no_res = (a.flags & DOSX_ATTN_NO_RESIDUAL) != 0;
   const float invH = 1.f / (float)H;
 
-  // ---- this wave's rows of dOut (kept for the residual) and of x, their statistics, their P row ----
   float4 go[RP][KCB], xr[RP][KCB], g0[KCB];
   float mean[RP], rstd[RP], pr[RP][NJ];
+#pragma unroll
+  for (int k = 0; k < KCB; ++k) g0[k] = ld4(a.gamma0 + ((q16 * 4 + 64 * k) < H ? (q16 * 4 + 64 * k) : 0));
 #pragma unroll
   for (int p = 0; p < RP; ++p) {
     const int s = min(s0 + row_of(wave, p, lane), Sq - 1);
@@ -645,32 +498,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const DosxAttn a) {
     }
   }
 #pragma unroll
-  for (int k = 0; k < KCB; ++k) g0[k] = ld4(a.gamma0 + ((q16 * 4 + 64 * k) < H ? (q16 * 4 + 64 * k) : 0));
-  if (KRES) stage_k_full(KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, g.LDH, tid);
-#pragma unroll
   for (int p = 0; p < RP; ++p) {
     const int lr = row_of(wave, p, lane);
 #pragma unroll
     for (int k = 0; k < KCB; ++k) {
       const int c = q16 * 4 + 64 * k;
       if (c >= g.HP) continue;
-      float4 d = go[p][k];
+      float4 d = make_float4(go[p][k].x * g0[k].x, go[p][k].y * g0[k].y, go[p][k].z * g0[k].z, go[p][k].w * g0[k].w);
       if (!(c < H && (s0 + lr) < Sq)) d = f4zero();
       st4(Ds + lr * g.LDH + c, d);
     }
   }
   __syncthreads();
 
-  // dP = dO . V^T
+  // dP (up to a row constant) = (dO gamma) . k̂^T
   f32x16 sacc[MAX_KT];
-  qk_product<KRES>(sacc, Ds, g.LDH, KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, tid, q);
-  store_scores(sacc, Ss, g.LDS_, g.NKP, tid, q);
+  stream_qk(sacc, Ds, g.LDH, CH, sg, g.NKP, tid);
+  store_scores1(sacc, Ss, g.LDS_, g.NKP, tid);
   __syncthreads();
 
   // dS = P * (dP - rowsum(P*dP)) * scale
   {
     const float scale = rsqrtf((float)H);
-    const int pstride = QT * g.LDS_;
     float dp[RP][NJ], dot[RP];
 #pragma unroll
     for (int p = 0; p < RP; ++p) {
@@ -679,13 +528,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const DosxAttn a) {
 #pragma unroll
       for (int jj = 0; jj < NJ; ++jj) {
         const int j = q16 + 16 * jj;
-        float t = 0.f;
-        if (j < Nk) {
-          t = row[j];
-          if (q.ks > 1) t += row[pstride + j];
-          if (q.ks > 2) t += row[2 * pstride + j] + row[3 * pstride + j];
-          dot[p] += pr[p][jj] * t;
-        }
+        const float t = j < Nk ? row[j] : 0.f;
+        if (j < Nk) dot[p] += pr[p][jj] * t;
         dp[p][jj] = t;
       }
     }
@@ -710,13 +554,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const DosxAttn a) {
   }
   __syncthreads();
 
-  // dq_ln = dS . K
   f32x16 oacc[MAX_CT];
-  pv_product<KRES>(oacc, Ss, g.LDS_, KV, a.kvhat, a.gamma0, a.beta0, Nk, g.NKP, a.Bk, bk, H, g.HP, g.LDH, tid);
+  stream_pv(oacc, Ss, g.LDS_, CH, sg, g.HP, g.LDH, tid);
   store_out_tile(oacc, Ds, g.LDH, g.HP, tid);
-  __syncthreads();
+  __syncthreads();                                  // (matrix waves only from here on)
 
-  // LN0 backward on the query rows + residual;  partial dgamma0 / dbeta0 (query side)
+  // dq_ln = (dS.k̂) gamma ; LN0 backward on the query rows + residual; partial dgamma0 / dbeta0 (query side)
   {
     float4 pg[KCB], pb[KCB], d[RP][KCB], xh[RP][KCB];
     float s1[RP], s2[RP];
@@ -730,7 +573,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const DosxAttn a) {
       for (int k = 0; k < KCB; ++k) {
         const int c = q16 * 4 + 64 * k;
         const bool rv = c < H && (s0 + lr) < Sq;
-        const float4 dd = rv ? ld4(Ds + lr * g.LDH + c) : f4zero();
+        float4 dd = rv ? ld4(Ds + lr * g.LDH + c) : f4zero();
+        dd = make_float4(dd.x * g0[k].x, dd.y * g0[k].y, dd.z * g0[k].z, dd.w * g0[k].w);
         const float4 xv = xr[p][k];
         float4 h = make_float4((xv.x - mean[p]) * rstd[p], (xv.y - mean[p]) * rstd[p], (xv.z - mean[p]) * rstd[p],
                                (xv.w - mean[p]) * rstd[p]);
@@ -764,7 +608,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const DosxAttn a) {
         st4(a.dx + ((size_t)s * a.Bq + bq) * H + c, o);
       }
     }
-    // column partial sums: one slot per quarter wave (16 slots), summed in a fixed order below
     const int slot = wave * 4 + (lane >> 4);
 #pragma unroll
     for (int k = 0; k < KCB; ++k) {
@@ -922,15 +765,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const DosxAttn a) {
   }
 }
 
-size_t fwd_smem(const Geo& g, bool kres) {
-  return sizeof(float) * (size_t)(QT * g.LDH + qk_ks(g.NKP, g.HP, kres) * QT * g.LDS_ +
-                                  (kres ? g.NKP * g.LDH : 2 * chunk_buf_floats(g.NKP, g.LDH)));
+size_t fwd_smem(const Geo& g) {
+  return sizeof(float) * (size_t)(QT * g.LDH + QT * g.LDS_ + 2 * chunk_buf_floats(g.NKP, g.LDH));
 }
-size_t dq_smem(const Geo& g, bool kres) {
-  const size_t kv = kres ? (size_t)g.NKP * g.LDH + 32 * g.HP : (size_t)max(2 * chunk_buf_floats(g.NKP, g.LDH), 32 * g.HP);
-  return sizeof(float) * ((size_t)QT * g.LDH + (size_t)qk_ks(g.NKP, g.HP, kres) * QT * g.LDS_ + kv);
+size_t dq_smem(const Geo& g) {    // (the [16][2][HP] column partial sums reuse the chunk buffers)
+  return sizeof(float) * ((size_t)QT * g.LDH + (size_t)QT * g.LDS_ + (size_t)max(2 * chunk_buf_floats(g.NKP, g.LDH), 32 * g.HP));
 }
-constexpr size_t KRES_LDS_LIMIT = 144 * 1024;   // keep the whole key tile of a crystal in LDS when it fits
 size_t dkv_smem(const Geo& g) { return sizeof(float) * (size_t)(2 * QT * g.LDH + 2 * QT * LDK + 8 * g.HP); }
 
 int check_attn(const DosxAttn& a, const char* who) {
@@ -950,24 +790,22 @@ extern "C" int dosx_attention_fwd(const DosxAttn* ap, dosx_stream_t stream) {
   if (int rc = check_attn(a, "dosx_attention_fwd")) return rc;
   DOSX_CHECK_ARG(a.out, "dosx_attention_fwd: null out");
   const Geo g = make_geo(a.H, a.Nk);
-  const bool kres = fwd_smem(g, true) <= KRES_LDS_LIMIT;
-  const size_t smem = fwd_smem(g, kres);
+  const size_t smem = fwd_smem(g);
   DOSX_CHECK_ARG(smem <= 160 * 1024, "dosx_attention_fwd: LDS need %zu > 160 KiB", smem);
   const dim3 grid(ceil_div(a.Sq, QT), a.Bq);
   const int nj = a.Nk <= 16 ? 1 : (a.Nk <= 64 ? 4 : (a.Nk <= 208 ? 13 : 20));
-#define DOSX_FWD(KR, NJ_)                                                                                   \
+#define DOSX_FWDS(NJ_)                                                                                      \
   do {                                                                                                      \
     static bool attr_set = false;                                                                           \
     if (!attr_set) {                                                                                        \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<KR, NJ_>),                   \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_stream_kernel<NJ_>),                \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
       attr_set = true;                                                                                      \
     }                                                                                                       \
-    hipLaunchKernelGGL((attn_fwd_kernel<KR, NJ_>), grid, dim3(256), smem, to_stream(stream), a);            \
+    hipLaunchKernelGGL((attn_fwd_stream_kernel<NJ_>), grid, dim3(512), smem, to_stream(stream), a);         \
   } while (0)
-  if (kres) { if (nj == 1) DOSX_FWD(true, 1); else if (nj == 4) DOSX_FWD(true, 4); else if (nj == 13) DOSX_FWD(true, 13); else DOSX_FWD(true, 20); }
-  else { if (nj == 1) DOSX_FWD(false, 1); else if (nj == 4) DOSX_FWD(false, 4); else if (nj == 13) DOSX_FWD(false, 13); else DOSX_FWD(false, 20); }
-#undef DOSX_FWD
+  if (nj == 1) DOSX_FWDS(1); else if (nj == 4) DOSX_FWDS(4); else if (nj == 13) DOSX_FWDS(13); else DOSX_FWDS(20);
+#undef DOSX_FWDS
   DOSX_LAUNCH_CHECK();
   return 0;
 }
@@ -978,8 +816,7 @@ extern "C" int dosx_attention_bwd(const DosxAttn* ap, dosx_stream_t stream) {
   if (int rc = check_attn(a, "dosx_attention_bwd")) return rc;
   DOSX_CHECK_ARG(a.dout && a.dx && a.dscores && a.dkvhat && a.partials_q && a.partials_kv, "dosx_attention_bwd: null operand");
   const Geo g = make_geo(a.H, a.Nk);
-  const bool kres = dq_smem(g, true) <= KRES_LDS_LIMIT;
-  const size_t s1 = dq_smem(g, kres), s2 = dkv_smem(g);
+  const size_t s1 = dq_smem(g), s2 = dkv_smem(g);
   DOSX_CHECK_ARG(s1 <= 160 * 1024 && s2 <= 160 * 1024, "dosx_attention_bwd: LDS need %zu/%zu > 160 KiB", s1, s2);
   static bool attr_set = false;
   if (!attr_set) {
@@ -990,19 +827,18 @@ extern "C" int dosx_attention_bwd(const DosxAttn* ap, dosx_stream_t stream) {
   const dim3 grid(ceil_div(a.Sq, QT), a.Bq);
   if (!(a.flags & DOSX_ATTN_BWD_SKIP_DQ)) {
     const int nj = a.Nk <= 16 ? 1 : (a.Nk <= 64 ? 4 : (a.Nk <= 208 ? 13 : 20));
-#define DOSX_DQ(KR, NJ_)                                                                                    \
+#define DOSX_DQS(NJ_)                                                                                       \
   do {                                                                                                      \
     static bool attr_dq = false;                                                                            \
     if (!attr_dq) {                                                                                         \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<KR, NJ_>),                \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_stream_kernel<NJ_>),             \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
       attr_dq = true;                                                                                       \
     }                                                                                                       \
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<KR, NJ_>), grid, dim3(256), s1, to_stream(stream), a);           \
+    hipLaunchKernelGGL((attn_bwd_dq_stream_kernel<NJ_>), grid, dim3(512), s1, to_stream(stream), a);        \
   } while (0)
-    if (kres) { if (nj == 1) DOSX_DQ(true, 1); else if (nj == 4) DOSX_DQ(true, 4); else if (nj == 13) DOSX_DQ(true, 13); else DOSX_DQ(true, 20); }
-    else { if (nj == 1) DOSX_DQ(false, 1); else if (nj == 4) DOSX_DQ(false, 4); else if (nj == 13) DOSX_DQ(false, 13); else DOSX_DQ(false, 20); }
-#undef DOSX_DQ
+    if (nj == 1) DOSX_DQS(1); else if (nj == 4) DOSX_DQS(4); else if (nj == 13) DOSX_DQS(13); else DOSX_DQS(20);
+#undef DOSX_DQS
     DOSX_LAUNCH_CHECK();
   }
   if (!(a.flags & DOSX_ATTN_BWD_SKIP_DKV)) {
