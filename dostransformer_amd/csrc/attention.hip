@@ -631,137 +631,247 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(const DosxAttn 
 }
 
 // ================================== backward: dk + dv ============================================
-// One workgroup per (32-key tile, crystal): dkv_ln[keys,H] = sum_q P^T dO + dS^T LN0(x) over every
-// query row of every query batch entry that maps to this crystal (bq = bk + i*Bk).
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const DosxAttn a) {
+// One workgroup per (KG x 32-key group, crystal):  dK[keys,H] = sum_q P^T dO + dS^T LN0(x)  over every query
+// row of every query batch entry that maps to this crystal (bq = bk + i*Bk); then dkvhat += dK * gamma0 and the
+// key-side partial sums of dgamma0 / dbeta0.  Wave-specialised like the other kernels: 4 staging waves stream
+// 16-query chunks (dO rows, the query rows with LayerNorm + affine applied, the P and dS columns of this key
+// group) into two LDS stage buffers, 4 matrix waves accumulate; KG = 2 key tiles per workgroup halve the
+// number of times every dO / x row is re-read.  All 8 waves run the row epilogue.
+constexpr int DQC = 16;    // queries per streamed chunk
+
+template <int KG>
+__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const DosxAttn a) {
   extern __shared__ __align__(16) float sm[];
   const Geo g = make_geo(a.H, a.Nk);
-  float* dOs = sm;                                  // [32 q][LDH]
-  float* Qs = dOs + QT * g.LDH;                     // [32 q][LDH]  (later: result tile)
-  float* Pc = Qs + QT * g.LDH;                      // [32 q][36]   P   chunk (cols = keys of this tile)
-  float* Sc = Pc + QT * LDK;                        // [32 q][36]   dS  chunk
-  float* Pp = Sc + QT * LDK;                        // [4][2][HP]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-  const int j0 = blockIdx.x * 32, bk = blockIdx.y;
+  constexpr int LDP = 32 * KG + 4;
+  const int STG = 2 * DQC * g.LDH + 2 * DQC * LDP;        // floats of one stage buffer: dOs | Qs | Pc | Sc
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5, q16 = lane & 15;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int j0 = blockIdx.x * 32 * KG, bk = blockIdx.y;
   const int H = a.H, Sq = a.Sq, Nk = a.Nk;
   const int nct = g.HP / 32;
   const bool raw_q = (a.flags & DOSX_ATTN_RAW_Q) != 0;
-  constexpr int MAXC = 4 * MAX_CT;                  // column groups of 32 per row (H <= 256)
+  const int nchunks = (Sq + DQC - 1) / DQC, nit = (a.Bq / a.Bk) * nchunks;
 
-  f32x16 acc[MAX_CT];
+  // epilogue operands, fetched up front by every wave: this wave's 4*KG key rows (quarter wave per row)
+  float4 kh[KG][KCB], dk0[KG][KCB], g0[KCB];
 #pragma unroll
-  for (int t = 0; t < MAX_CT; ++t)
+  for (int k = 0; k < KCB; ++k) g0[k] = ld4(a.gamma0 + ((q16 * 4 + 64 * k) < H ? (q16 * 4 + 64 * k) : 0));
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-  // staging registers of the NEXT (query batch entry, 32-query chunk): loads are issued one iteration
-  // ahead (before the MFMA block) from clamped addresses and masked / normalised when stored to LDS
-  const int ri = tid >> 3, cg = tid & 7;
-  float4 rdo[MAXC], rx[MAXC], gq[MAXC], bt[MAXC];
-  float rp[4], rs[4], rmean = 0.f, rrstd = 1.f;
-  bool rok = false;
+  for (int p = 0; p < KG; ++p) {
+    const int j = min(j0 + wave * 4 * KG + p * 4 + (lane >> 4), Nk - 1);
+    const size_t krow = ((size_t)j * a.Bk + bk) * H;
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c) {
-    const int col = cg * 4 + 32 * c, cc = col < H ? col : 0;
-    gq[c] = ld4(a.gamma0 + cc);
-    bt[c] = ld4(a.beta0 + cc);
+    for (int k = 0; k < KCB; ++k) {
+      const int c = q16 * 4 + 64 * k, cc = c < H ? c : 0;
+      kh[p][k] = ld4(a.kvhat + krow + cc);
+      dk0[p][k] = a.dkv_accumulate ? ld4(a.dkvhat + krow + cc) : f4zero();
+    }
   }
-  const int nchunks = (Sq + QT - 1) / QT, nit = (a.Bq / a.Bk) * nchunks;
-  auto issue = [&](int it) {
-    const int bq = bk + (it / nchunks) * a.Bk, s = (it % nchunks) * QT + ri;
-    rok = s < Sq;
-    const int sc = rok ? s : Sq - 1;
-    const float* dop = a.dout + ((size_t)sc * a.Bq + bq) * H;
-    const float* xp = a.x + ((size_t)sc * a.q_stride_s + (size_t)bq * a.q_stride_b) * H;
-#pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-      if (c < nct) {
-        const int col = cg * 4 + 32 * c, cc = col < H ? col : 0;
-        rdo[c] = ld4(dop + cc);
-        rx[c] = ld4(xp + cc);
-      }
-    }
-    const size_t prow = ((size_t)bq * Sq + sc) * Nk;
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int jc = min(j0 + cg + 8 * jj, Nk - 1);
-      rp[jj] = a.probs[prow + jc];
-      rs[jj] = a.dscores[prow + jc];
-    }
-    if (!raw_q) {
-      rmean = a.qstats[2 * ((size_t)sc * a.Bq + bq)];
-      rrstd = a.qstats[2 * ((size_t)sc * a.Bq + bq) + 1];
-    }
-  };
-  auto store = [&]() {
-#pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-      if (c < nct) {
-        const int col = cg * 4 + 32 * c;
-        const bool valid = rok && col < H;
-        float4 d = rdo[c], q = rx[c];
-        if (!raw_q)
-          q = make_float4((q.x - rmean) * rrstd * gq[c].x + bt[c].x, (q.y - rmean) * rrstd * gq[c].y + bt[c].y,
-                          (q.z - rmean) * rrstd * gq[c].z + bt[c].z, (q.w - rmean) * rrstd * gq[c].w + bt[c].w);
-        if (!valid) { d = f4zero(); q = f4zero(); }
-        st4(dOs + ri * g.LDH + col, d);
-        st4(Qs + ri * g.LDH + col, q);
-      }
-    }
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const bool valid = rok && (j0 + cg + 8 * jj) < Nk;
-      Pc[ri * LDK + cg + 8 * jj] = valid ? rp[jj] : 0.f;
-      Sc[ri * LDK + cg + 8 * jj] = valid ? rs[jj] : 0.f;
-    }
-  };
 
-  issue(0);
-  for (int it = 0; it < nit; ++it) {
-    store();
-    __syncthreads();
-    if (it + 1 < nit) issue(it + 1);
+  f32x16 acc[KG][MAX_CT];
+  if (wave_u >= 4) {
+    // =============================== staging waves ===============================================
+    const int st = tid - 256, row = st >> 4, cq = (st & 15) * 4;
+    const uint32_t xrows = (uint32_t)((size_t)(Sq - 1) * a.q_stride_s + (size_t)(a.Bq - 1) * a.q_stride_b + 1);
+    const __amdgpu_buffer_rsrc_t rO =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.dout, 0, (uint32_t)((size_t)Sq * a.Bq * H * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, xrows * (uint32_t)(H * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rP =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.probs, 0, (uint32_t)((size_t)a.Bq * Sq * Nk * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rS =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.dscores, 0, (uint32_t)((size_t)a.Bq * Sq * Nk * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(raw_q ? (const float*)a.dout : a.qstats), 0, (uint32_t)((size_t)Sq * a.Bq * 8), 0x00020000);
+    uint32_t vO[KCB], vX[KCB], vP[2 * KG];
+    float4 gq[KCB], bq4[KCB];
 #pragma unroll
-    for (int mm = 0; mm < QT; mm += 2) {
-      const float pa = Pc[(mm + hh) * LDK + l31];
-      const float sa = Sc[(mm + hh) * LDK + l31];
+    for (int k = 0; k < KCB; ++k) {
+      const int c = cq + 64 * k, cc = c < H ? c : 0;
+      vO[k] = (uint32_t)(((size_t)row * a.Bq * H + cc) * 4);
+      vX[k] = (uint32_t)(((size_t)row * a.q_stride_s * H + cc) * 4);
+      gq[k] = ld4(a.gamma0 + cc);
+      bq4[k] = ld4(a.beta0 + cc);
+    }
+#pragma unroll
+    for (int u = 0; u < 2 * KG; ++u) vP[u] = (uint32_t)(((size_t)row * Nk + min(j0 + (st & 15) + 16 * u, Nk - 1)) * 4);
+    const uint32_t vT = (uint32_t)((size_t)row * a.Bq * 8);
+    struct Set {
+      float4 d[KCB], x[KCB];
+      float pp[2 * KG], ss[2 * KG], mean, rstd;
+      bool rok;
+    };
+    Set s0, s1;
+    auto issue = [&](Set& q, int it) {
+      const int itu = __builtin_amdgcn_readfirstlane(it);
+      const int bq = bk + (itu / nchunks) * a.Bk, sb = (itu % nchunks) * DQC;
+      q.rok = (sb + row) < Sq;
+      const int soO = (sb * a.Bq + bq) * H * 4;
+      const int soX = (int)(((size_t)sb * a.q_stride_s + (size_t)bq * a.q_stride_b) * H * 4);
+      const int soP = (bq * Sq + sb) * Nk * 4;
+      const int soT = (sb * a.Bq + bq) * 8;
+#pragma unroll
+      for (int k = 0; k < KCB; ++k) {
+        if (k < (g.HP + 63) / 64) {
+          q.d[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rO, vO[k], soO, 0));
+          q.x[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rX, vX[k], soX, 0));
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2 * KG; ++u) {
+        q.pp[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rP, vP[u], soP, 0));
+        q.ss[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, vP[u], soP, 0));
+      }
+      q.mean = 0.f; q.rstd = 1.f;
+      if (!raw_q) {
+        q.mean = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rT, vT, soT, 0));
+        q.rstd = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rT, vT + 4, soT, 0));
+      }
+    };
+    auto store = [&](float* buf, const Set& q) {
+      float* dOs = buf;
+      float* Qs = buf + DQC * g.LDH;
+      float* Pc = Qs + DQC * g.LDH;
+      float* Sc = Pc + DQC * LDP;
+#pragma unroll
+      for (int k = 0; k < KCB; ++k) {
+        const int c = cq + 64 * k;
+        if (c >= g.HP) continue;
+        float4 d = q.d[k], x = q.x[k];
+        if (!raw_q)
+          x = make_float4((x.x - q.mean) * q.rstd * gq[k].x + bq4[k].x, (x.y - q.mean) * q.rstd * gq[k].y + bq4[k].y,
+                          (x.z - q.mean) * q.rstd * gq[k].z + bq4[k].z, (x.w - q.mean) * q.rstd * gq[k].w + bq4[k].w);
+        if (!(q.rok && c < H)) { d = f4zero(); x = f4zero(); }
+        st4(dOs + row * g.LDH + c, d);
+        st4(Qs + row * g.LDH + c, x);
+      }
+#pragma unroll
+      for (int u = 0; u < 2 * KG; ++u) {
+        const int jl = (st & 15) + 16 * u;
+        const bool ok = q.rok && (j0 + jl) < Nk;
+        Pc[row * LDP + jl] = ok ? q.pp[u] : 0.f;
+        Sc[row * LDP + jl] = ok ? q.ss[u] : 0.f;
+      }
+    };
+    if (nit > 0) issue(s0, 0);
+    if (nit > 1) issue(s1, 1);
+    if (nit > 0) store(sm, s0);
+    if (nit > 2) issue(s0, 2);
+    __syncthreads();
+    for (int c = 0; c < nit; c += 2) {
+      if (c + 1 < nit) {
+        store(sm + STG, s1);
+        if (c + 3 < nit) issue(s1, c + 3);
+      }
+      __syncthreads();
+      if (c + 1 >= nit) break;
+      if (c + 2 < nit) {
+        store(sm, s0);
+        if (c + 4 < nit) issue(s0, c + 4);
+      }
+      __syncthreads();
+    }
+  } else {
+    // =============================== matrix waves ================================================
+#pragma unroll
+    for (int kt = 0; kt < KG; ++kt)
+#pragma unroll
+      for (int t = 0; t < MAX_CT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[kt][t][r] = 0.f;
+    __syncthreads();
+    for (int c = 0; c < nit; ++c) {
+      const float* dOs = sm + (c & 1) * STG;
+      const float* Qs = dOs + DQC * g.LDH;
+      const float* Pc = Qs + DQC * g.LDH;
+      const float* Sc = Pc + DQC * LDP;
+#pragma unroll
+      for (int mm = 0; mm < DQC; mm += 2) {
+        float pa[KG], sa[KG];
+#pragma unroll
+        for (int kt = 0; kt < KG; ++kt) {
+          pa[kt] = Pc[(mm + hh) * LDP + kt * 32 + l31];
+          sa[kt] = Sc[(mm + hh) * LDP + kt * 32 + l31];
+        }
+#pragma unroll
+        for (int t = 0; t < MAX_CT; ++t) {
+          const int ct = wave + 4 * t;
+          if (ct >= nct) continue;
+          const float b1 = dOs[(mm + hh) * g.LDH + ct * 32 + l31];
+          const float b2 = Qs[(mm + hh) * g.LDH + ct * 32 + l31];
+#pragma unroll
+          for (int kt = 0; kt < KG; ++kt) {
+            acc[kt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kt], b1, acc[kt][t], 0, 0, 0);
+            acc[kt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[kt], b2, acc[kt][t], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- result tile R[32*KG][LDH] (aliases the stage buffers) + 32 partial-sum slots behind it ----
+  float* R = sm;
+  float* Pp = sm + 32 * KG * g.LDH;                  // [32 slots][2][HP]
+  if (wave_u < 4) {
+#pragma unroll
+    for (int kt = 0; kt < KG; ++kt)
 #pragma unroll
       for (int t = 0; t < MAX_CT; ++t) {
         const int ct = wave + 4 * t;
         if (ct >= nct) continue;
-        const float b1 = dOs[(mm + hh) * g.LDH + ct * 32 + l31];
-        const float b2 = Qs[(mm + hh) * g.LDH + ct * 32 + l31];
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa, b1, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa, b2, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          R[(kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * g.LDH + ct * 32 + l31] = acc[kt][t][r];
+      }
+  }
+  __syncthreads();
+  {
+    float4 pg[KCB], pb[KCB];
+#pragma unroll
+    for (int k = 0; k < KCB; ++k) { pg[k] = f4zero(); pb[k] = f4zero(); }
+#pragma unroll
+    for (int p = 0; p < KG; ++p) {
+      const int lr = wave * 4 * KG + p * 4 + (lane >> 4), j = j0 + lr;
+      if (j >= Nk) continue;
+      const size_t krow = ((size_t)j * a.Bk + bk) * H;
+#pragma unroll
+      for (int k = 0; k < KCB; ++k) {
+        const int c = q16 * 4 + 64 * k;
+        if (c >= H) continue;
+        const float4 d = ld4(R + lr * g.LDH + c), xh = kh[p][k];
+        pg[k].x += d.x * xh.x; pg[k].y += d.y * xh.y; pg[k].z += d.z * xh.z; pg[k].w += d.w * xh.w;
+        pb[k] = f4add(pb[k], d);
+        st4(a.dkvhat + krow + c, make_float4(d.x * g0[k].x + dk0[p][k].x, d.y * g0[k].y + dk0[p][k].y,
+                                             d.z * g0[k].z + dk0[p][k].z, d.w * g0[k].w + dk0[p][k].w));
       }
     }
-    __syncthreads();
-  }
-
-  store_out_tile(acc, Qs, g.LDH, g.HP, tid);
-  for (int c = lane; c < 2 * g.HP; c += 64) Pp[wave * 2 * g.HP + c] = 0.f;
-  __syncthreads();
-  for (int i = 0; i < 8; ++i) {
-    const int lr = wave * 8 + i, j = j0 + lr;
-    if (j >= Nk) break;
-    const size_t krow = ((size_t)j * a.Bk + bk) * H;
-    for (int c = lane * 4; c < H; c += 256) {
-      const float4 d = ld4(Qs + lr * g.LDH + c), xh = ld4(a.kvhat + krow + c), gm = ld4(a.gamma0 + c);
-      float* pgm = Pp + wave * 2 * g.HP + c;
-      pgm[0] += d.x * xh.x; pgm[1] += d.y * xh.y; pgm[2] += d.z * xh.z; pgm[3] += d.w * xh.w;
-      float* pbt = pgm + g.HP;
-      pbt[0] += d.x; pbt[1] += d.y; pbt[2] += d.z; pbt[3] += d.w;
-      float4 o = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
-      if (a.dkv_accumulate) o = f4add(o, ld4(a.dkvhat + krow + c));
-      st4(a.dkvhat + krow + c, o);
+    const int slot = wave * 4 + (lane >> 4);
+#pragma unroll
+    for (int k = 0; k < KCB; ++k) {
+      const int c = q16 * 4 + 64 * k;
+      if (c >= g.HP) continue;
+      st4(Pp + slot * 2 * g.HP + c, pg[k]);
+      st4(Pp + slot * 2 * g.HP + g.HP + c, pb[k]);
     }
   }
   __syncthreads();
-  float* prow = a.partials_kv + ((size_t)bk * gridDim.x + blockIdx.x) * 2 * H;
-  for (int c = tid; c < 2 * H; c += 256) {
-    const int which = c / H, col = c % H;
-    const int o = which * g.HP + col;
-    prow[c] = Pp[o] + Pp[2 * g.HP + o] + Pp[4 * g.HP + o] + Pp[6 * g.HP + o];
+  // partial rows are indexed by 32-key tile (the caller sizes them so): this group's sums go to its first tile,
+  // its other tiles get zeros
+  const int nkt = (Nk + 31) / 32;
+  for (int kt = 0; kt < KG; ++kt) {
+    const int tile = blockIdx.x * KG + kt;
+    if (tile >= nkt) break;
+    float* prow = a.partials_kv + ((size_t)bk * nkt + tile) * 2 * H;
+    for (int c = tid; c < 2 * H; c += 512) {
+      float t = 0.f;
+      if (kt == 0) {
+        const int o = (c / H) * g.HP + (c % H);
+#pragma unroll
+        for (int sl = 0; sl < 32; ++sl) t += Pp[sl * 2 * g.HP + o];
+      }
+      prow[c] = t;
+    }
   }
 }
 
@@ -771,7 +881,11 @@ size_t fwd_smem(const Geo& g) {
 size_t dq_smem(const Geo& g) {    // (the [16][2][HP] column partial sums reuse the chunk buffers)
   return sizeof(float) * ((size_t)QT * g.LDH + (size_t)QT * g.LDS_ + (size_t)max(2 * chunk_buf_floats(g.NKP, g.LDH), 32 * g.HP));
 }
-size_t dkv_smem(const Geo& g) { return sizeof(float) * (size_t)(2 * QT * g.LDH + 2 * QT * LDK + 8 * g.HP); }
+size_t dkv_smem(const Geo& g, int kg) {
+  const size_t stage = 2 * (size_t)(2 * DQC * g.LDH + 2 * DQC * (32 * kg + 4));
+  const size_t epi = (size_t)32 * kg * g.LDH + 32 * 2 * g.HP;
+  return sizeof(float) * (stage > epi ? stage : epi);
+}
 
 int check_attn(const DosxAttn& a, const char* who) {
   DOSX_CHECK_ARG(a.H > 0 && (a.H & 3) == 0 && a.H <= 32 * 4 * MAX_CT, "%s: H=%d unsupported (multiple of 4, <= 256)", who, a.H);
@@ -816,11 +930,14 @@ extern "C" int dosx_attention_bwd(const DosxAttn* ap, dosx_stream_t stream) {
   if (int rc = check_attn(a, "dosx_attention_bwd")) return rc;
   DOSX_CHECK_ARG(a.dout && a.dx && a.dscores && a.dkvhat && a.partials_q && a.partials_kv, "dosx_attention_bwd: null operand");
   const Geo g = make_geo(a.H, a.Nk);
-  const size_t s1 = dq_smem(g), s2 = dkv_smem(g);
+  const int kg = a.Nk > 32 ? 2 : 1;
+  const size_t s1 = dq_smem(g), s2 = dkv_smem(g, kg);
   DOSX_CHECK_ARG(s1 <= 160 * 1024 && s2 <= 160 * 1024, "dosx_attention_bwd: LDS need %zu/%zu > 160 KiB", s1, s2);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
@@ -842,7 +959,8 @@ extern "C" int dosx_attention_bwd(const DosxAttn* ap, dosx_stream_t stream) {
     DOSX_LAUNCH_CHECK();
   }
   if (!(a.flags & DOSX_ATTN_BWD_SKIP_DKV)) {
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(ceil_div(a.Nk, 32), a.Bk), dim3(256), s2, to_stream(stream), a);
+    if (kg == 2) hipLaunchKernelGGL((attn_bwd_dkv_kernel<2>), dim3(ceil_div(a.Nk, 64), a.Bk), dim3(512), s2, to_stream(stream), a);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<1>), dim3(ceil_div(a.Nk, 32), a.Bk), dim3(512), s2, to_stream(stream), a);
     DOSX_LAUNCH_CHECK();
   }
   return 0;
