@@ -532,6 +532,9 @@ void gemm_kernel(const GemmLaunch L) {
       for (int t = 0; t < NTW; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[rr][t][r] = 0.f;
+    f32x16 accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
     if (DOSX_PRIO_VARIANT == 2) __builtin_amdgcn_s_setprio(2);
     if constexpr (PROLN) __syncthreads();
     __syncthreads();
@@ -560,18 +563,31 @@ void gemm_kernel(const GemmLaunch L) {
             b[t][0] = bp[0]; b[t][1] = bp[LDWT]; b[t][2] = bp[2 * LDWT]; b[t][3] = bp[3 * LDWT];
           }
         }
+        if constexpr (RT * NTW == 1) {
+          // a single tile per wave: alternate two accumulators, or the 16 MFMAs of a chunk form one dependent
+          // chain and issue every ~87 clk instead of every 64
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].x, b[0][0], acc[0][0], 0, 0, 0);
+          accb = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].y, b[0][1], accb, 0, 0, 0);
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].z, b[0][2], acc[0][0], 0, 0, 0);
+          accb = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0].w, b[0][3], accb, 0, 0, 0);
+        } else {
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+          for (int c = 0; c < 4; ++c)
 #pragma unroll
-          for (int r = 0; r < RT; ++r) {
-            const float av = c == 0 ? a[r].x : c == 1 ? a[r].y : c == 2 ? a[r].z : a[r].w;
+            for (int r = 0; r < RT; ++r) {
+              const float av = c == 0 ? a[r].x : c == 1 ? a[r].y : c == 2 ? a[r].z : a[r].w;
 #pragma unroll
-            for (int t = 0; t < NTW; ++t)
-              acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[t][c], acc[r][t], 0, 0, 0);
-          }
+              for (int t = 0; t < NTW; ++t)
+                acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[t][c], acc[r][t], 0, 0, 0);
+            }
+        }
       }
       STAMP(4 + 3 * kt);
       __syncthreads();
+    }
+    if constexpr (RT * NTW == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][0][r] += accb[r];
     }
   }
   __builtin_amdgcn_s_setprio(0);
@@ -1065,27 +1081,24 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradLaunch L) {
       const uint32_t vS = (uint32_t)((ms + r) * 8);
       const int stepY = BM * cy * g.dy.ld * 4, stepA = BM * ca * sa.ld * 4, stepI = BM * ca * 4;
       const float alpha = (PRO == DOSX_PRO_PRELU || PRO == DOSX_PRO_LN_PRELU) ? *g.pro_alpha : 0.f;
+      // (every load below is unconditional: a load inside a run-time branch makes hipcc place s_waitcnt vmcnt(0)
+      //  at the join, i.e. right behind the issue - measured 900-1850 clk per chunk in the staging waves)
       auto load_idx = [&](Set& q, int m) {
         const int cidx = __builtin_amdgcn_readfirstlane((m - ms) / BM);
-        q.idx = __builtin_amdgcn_raw_buffer_load_b32(rI, vI, cidx * stepI, 0);
+        q.idx = __builtin_amdgcn_raw_buffer_load_b32(rI, vI, cidx * stepI, 0);      // (!gather: dummy, unused)
       };
-      if (gather) {
-        if (nch > 0) load_idx(s0, ms);
-        if (nch > 1) load_idx(s1, ms + BM);
-      }
+      if (nch > 0) load_idx(s0, ms);
+      if (nch > 1) load_idx(s1, ms + BM);
       auto issue = [&](Set& q, int m) {
         const int cidx = __builtin_amdgcn_readfirstlane((m - ms) / BM);
         q.y0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rY, vY0, cidx * stepY, 0));
         q.y1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rY, vY1, cidx * stepY, 0));
-        if (gather) {
-          const uint32_t rowb = (uint32_t)q.idx * (uint32_t)(sa.ld * 4);
-          q.x0.v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rA, rowb + colA0, 0, 0));
-          q.x1.v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rA, rowb + colA1, 0, 0));
-          if (m + 2 * BM < me) load_idx(q, m + 2 * BM);
-        } else {
-          q.x0.v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rA, vA0, cidx * stepA, 0));
-          q.x1.v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rA, vA1, cidx * stepA, 0));
-        }
+        const uint32_t rowb = (uint32_t)q.idx * (uint32_t)(sa.ld * 4);
+        const uint32_t o0 = gather ? rowb + colA0 : vA0, o1 = gather ? rowb + colA1 : vA1;
+        const int soA = gather ? 0 : cidx * stepA;
+        q.x0.v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rA, o0, soA, 0));
+        q.x1.v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rA, o1, soA, 0));
+        load_idx(q, m + 2 * BM);                    // rows beyond M read index 0 through the buffer bounds
         if (PRO == DOSX_PRO_ROWLN) {
           q.mean = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, vS, cidx * (BM * 8), 0));
           q.rstd = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, vS + 4, cidx * (BM * 8), 0));
@@ -1143,22 +1156,37 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradLaunch L) {
   } else {
     // =============================== matrix waves ================================================
     const int wn = wave >> 1, wk = wave & 1;
+    f32x16 acc2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
     __syncthreads();
     WSTAMP(1);
     for (int c = 0; c < nch; ++c) {
       const float* Ys = Sm + (c & 1) * STG;
       const float* Xs = Ys + BM * LDT;
       WSTAMP(2 + 2 * c);
+      // all 32 fragment reads of the chunk are issued before the first MFMA (they return in order, the MFMAs
+      // then wait on a falling lgkmcnt): reading pair i+1 only after MFMA i was issued exposed ~64 clk of LDS
+      // latency per pair (1400 instead of 1024 clk per chunk)
+      float av[BM / 2], bv[BM / 2];
 #pragma unroll
-      for (int mm = 0; mm < BM; mm += 2) {
-        const float a = Ys[(mm + hh) * LDT + wn * 32 + l31];
-        const float b = Xs[(mm + hh) * LDT + wk * 32 + l31];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      for (int i = 0; i < BM / 2; ++i) {
+        av[i] = Ys[(2 * i + hh) * LDT + wn * 32 + l31];
+        bv[i] = Xs[(2 * i + hh) * LDT + wk * 32 + l31];
+      }
+      // two accumulators (even / odd row pairs): 16 MFMAs chained through ONE accumulator issue every ~87 clk
+      // instead of every 64 (dependent-issue latency of the 16-pass instruction)
+#pragma unroll
+      for (int i = 0; i < BM / 2; i += 2) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i + 1], bv[i + 1], acc2, 0, 0, 0);
       }
       WSTAMP(3 + 2 * c);
       __syncthreads();
     }
     WSTAMP(60);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] += acc2[i];
     float* slab = g.slab + (size_t)z * N * K;
     const int kcol = k0 + wk * 32 + l31;
 #pragma unroll
