@@ -1,0 +1,26 @@
+"""Checkpoint I/O (the reference has none).  The model part is a plain ``state_dict`` in the
+reference's key layout, so weights move both ways between this build and upstream-trained
+models; the optimizer part is ``Trainer.state_dict()`` (AdamW moments keyed by parameter name)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+
+def save(path: str, model: torch.nn.Module, trainer=None, extra: Optional[dict] = None) -> None:
+    ckpt = {"format": "dostransformer_amd/1",
+            "model": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+            "optimizer": trainer.state_dict() if trainer is not None else None,
+            "extra": extra or {}}
+    torch.save(ckpt, path)
+
+
+def load(path: str, model: torch.nn.Module, trainer=None, strict: bool = True) -> dict:
+    """Loads a checkpoint written by :func:`save`, or a bare reference ``state_dict`` file."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    sd = ckpt["model"] if isinstance(ckpt, dict) and "model" in ckpt else ckpt
+    model.load_state_dict(sd, strict=strict)
+    if trainer is not None and isinstance(ckpt, dict) and ckpt.get("optimizer") is not None:
+        trainer.load_state_dict(ckpt["optimizer"])
+    return ckpt.get("extra", {}) if isinstance(ckpt, dict) else {}

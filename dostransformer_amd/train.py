@@ -243,6 +243,34 @@ class Trainer:
         ops.adamw(fp.flat, fp.grad, m, v, fp.total, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
                   self.step_count, 1.0)
 
+    # ---- checkpoint / resume (absent upstream) ------------------------------------
+    def state_dict(self) -> dict:
+        """Optimizer state keyed by the reference's parameter names, in ``torch.optim.AdamW`` vocabulary
+        (``exp_avg`` / ``exp_avg_sq`` / ``step``); together with ``model.state_dict()`` (reference key
+        layout) this is a complete resume point."""
+        fp = self._fp if self._fp is not None else self.model.flat_params()
+        m, v = self._state(fp)
+        views = lambda buf: {n: buf[o:o + fp.P[n].numel()].view(fp.P[n].shape).detach().cpu().clone()
+                             for n, o in zip(fp.names, fp.offsets)}
+        return {"step": self.step_count, "exp_avg": views(m), "exp_avg_sq": views(v),
+                "hyper": {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "beta": self.beta}}
+
+    def load_state_dict(self, sd: dict) -> None:
+        fp = self._fp if self._fp is not None else self.model.flat_params()
+        m, v = self._state(fp)
+        missing = [n for n in fp.names if n not in sd["exp_avg"] or n not in sd["exp_avg_sq"]]
+        if missing:
+            raise KeyError(f"optimizer state lacks {missing[:3]}{'...' if len(missing) > 3 else ''}")
+        with torch.no_grad():
+            for n, o in zip(fp.names, fp.offsets):
+                k = fp.P[n].numel()
+                m[o:o + k].copy_(sd["exp_avg"][n].reshape(-1).to(m.device, torch.float32))
+                v[o:o + k].copy_(sd["exp_avg_sq"][n].reshape(-1).to(v.device, torch.float32))
+        self.step_count = int(sd["step"])
+        h = sd.get("hyper", {})
+        self.lr, self.eps, self.wd = h.get("lr", self.lr), h.get("eps", self.eps), h.get("weight_decay", self.wd)
+        self.betas, self.beta = tuple(h.get("betas", self.betas)), h.get("beta", self.beta)
+
     def step(self, g, n_global: Optional[int] = None) -> torch.Tensor:
         loss = self._graph_step(g, n_global) if (self.graph or self.replay) else self.forward_backward(g, n_global)
         self.optimizer_step()

@@ -323,3 +323,49 @@ def train_step(kind: str, params: Params, state: Dict[str, dict], g, n_layers: i
     grads = dict(zip(names, gr))
     adamw_step(params, grads, state, lr)
     return loss.detach(), grads
+
+
+# ---------------------------------------------------------------------------------------------------
+# Evaluation loops: `utils.py:61-143`
+# ---------------------------------------------------------------------------------------------------
+def r2(y_true: torch.Tensor, y_pred: torch.Tensor) -> float:
+    """`utils.py:20-23`: sklearn `r2_score(y_true.flatten(), y_pred.flatten(), 'variance_weighted')`; on the
+    flattened (single-output) arrays that is 1 - SS_res / SS_tot."""
+    t, p = y_true.double().flatten(), y_pred.double().flatten()
+    return float(1.0 - ((t - p) ** 2).sum() / ((t - t.mean()) ** 2).sum())
+
+
+def _batch_metrics(y: torch.Tensor, pred: torch.Tensor):
+    mse = ((y - pred) ** 2).mean(dim=1)
+    return float(torch.sqrt(mse).mean()), float(mse.mean()), float((pred - y).abs().mean()), r2(y, pred)
+
+
+def eval_phonon(p: Params, loader, n_layers: int, n_t: int):
+    """`utils.py:117-143` (`test_phonon`): per-batch RMSE / MSE / MAE / R^2 of `preds_system`, averaged over batches."""
+    acc = [0.0, 0.0, 0.0, 0.0]
+    with torch.no_grad():
+        for g in loader:
+            dg, _, ds = dostransformer_phonon_forward(p, g, n_layers, n_t)
+            y = g.phdos.reshape(dg.shape[0], -1)
+            for i, v in enumerate(_batch_metrics(y, ds)):
+                acc[i] += v
+    return tuple(a / len(loader) for a in acc)
+
+
+def eval_edos(p: Params, loader, n_layers: int, n_t: int):
+    """`utils.py:61-112` (`test`): target and prediction clamped at 0 (`:76-78`), metrics as above, plus the
+    concatenated (mp_id, preds, y, sum-pooled node embeddings) of `:90-110`."""
+    acc = [0.0, 0.0, 0.0, 0.0]
+    ids, preds, ys, embs = [], [], [], []
+    with torch.no_grad():
+        for g in loader:
+            _, x_nodes, ds = dostransformer_forward(p, g, n_layers, n_t)
+            y = torch.clamp(g.y_ft, min=0.0).reshape(len(g.mp_id), -1)
+            ds = torch.clamp(ds, min=0.0)
+            for i, v in enumerate(_batch_metrics(y, ds)):
+                acc[i] += v
+            ids += list(g.mp_id)
+            preds.append(ds)
+            ys.append(y)
+            embs.append(scatter_sum(x_nodes, g.batch, len(g.mp_id)))
+    return tuple(a / len(loader) for a in acc), (ids, torch.cat(preds), torch.cat(ys), torch.cat(embs))

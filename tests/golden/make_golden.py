@@ -331,10 +331,64 @@ def main():
     out["dead_params"] = np.array(dead)
     np.savez_compressed(os.path.join(HERE, "g8_graphnetwork_edos.npz"), **out)
 
+    make_g9(DOSTransformer_phonon, DOSTransformer, dev)
+
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 
 
+def make_g9(DOSTransformer_phonon, DOSTransformer, dev):
+    """G9: the reference's own evaluation loops (utils.py:61-143: `test`, `test_phonon`, `r2`) over two batches each.
+    utils.py imports ase / torch_geometric.data at module level only for the dataset builders; those names get
+    empty stand-ins (never called on this path)."""
+    for name, attrs in (("ase", ("Atoms", "Atom")), ("ase.neighborlist", ("neighbor_list",)),
+                        ("torch_geometric.data", ("Data",))):
+        m = sys.modules.get(name) or types.ModuleType(name)
+        for a in attrs:
+            setattr(m, a, None)
+        sys.modules[name] = m
+    sys.modules["torch_geometric"].data = sys.modules["torch_geometric.data"]
+    import utils as ref_utils
+
+    out = {}
+    crit = torch.nn.L1Loss()                         # main_eDOS.py:98 / main_phDOS.py:97
+    # phonon, fp64 like main_phDOS.py:15-16
+    torch.set_default_dtype(torch.float64)
+    loader = [synth.phonon_batch(3, seed=91, dtype=torch.float64, sort_edges=False, n_atoms=[2, 6, 4]),
+              synth.phonon_batch(2, seed=92, dtype=torch.float64, sort_edges=False, n_atoms=[5, 3])]
+    for i, g in enumerate(loader):
+        pack_batch(out, g, f"ph/b{i}/")
+    torch.manual_seed(0)
+    model = DOSTransformer_phonon(3, 1, 118, 4, 16, dev, 0.0)
+    pack_sd(out, model.state_dict(), "ph/p0/")
+    rmse, mse, mae, r2v = ref_utils.test_phonon(model, loader, crit, ref_utils.r2, dev)
+    out["ph/metrics"] = np.array([float(rmse), float(mse), float(mae), float(r2v)])
+    torch.set_default_dtype(torch.float32)
+    # eDOS, fp32; targets with negative entries so the clamp-at-zero of utils.py:76-78 matters
+    loader = [synth.edos_batch(3, seed=93, dtype=torch.float32, sort_edges=False, n_atoms=[2, 7, 4]),
+              synth.edos_batch(2, seed=94, dtype=torch.float32, sort_edges=False, n_atoms=[3, 5])]
+    for g in loader:
+        g["y_ft"] = g.y_ft - 0.3
+    for i, g in enumerate(loader):
+        pack_batch(out, g, f"e/b{i}/")
+        out[f"e/b{i}/mp_id"] = np.array(g.mp_id)
+    torch.manual_seed(0)
+    model = DOSTransformer(3, 2, 200, 41, 2, 16, dev, 0.0)
+    pack_sd(out, model.state_dict(), "e/p0/")
+    rmse, mse, mae, r2v, preds_y = ref_utils.test(model, loader, crit, ref_utils.r2, dev)
+    out["e/metrics"] = np.array([float(rmse), float(mse), float(mae), float(r2v)])
+    mp_id, preds, y, emb = preds_y[0]
+    out["e/mp_id"], out["e/preds"], out["e/y"], out["e/embeddings"] = np.array(mp_id), preds, y, emb
+    np.savez_compressed(os.path.join(HERE, "g9_eval.npz"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-g9":     # (does not touch the other fixtures)
+        install_standins()
+        sys.path.insert(0, REF)
+        from embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon as _P
+        from embedder_eDOS.DOSTransformer import DOSTransformer as _E
+        make_g9(_P, _E, torch.device("cpu"))
+    else:
+        main()

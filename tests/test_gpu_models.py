@@ -1,6 +1,7 @@
 """Model-level parity on a real MI355X: the drop-in modules (libdosx programs through the C ABI)
 against (a) the golden vectors generated from the reference and (b) the oracle evaluated live on the
 same seeded inputs.  Tolerance on the predicted DOS vectors: 1e-4 RMSE (BASELINE.json north_star)."""
+import numpy as np
 import pytest
 import torch
 
@@ -337,3 +338,52 @@ def test_graph_replay_matches_eager(kind, mode):
     for (k, a), (_, b) in zip(m_e.state_dict().items(), m_g.state_dict().items()):
         if a.is_floating_point():
             assert float((a - b).abs().max()) < 2e-5, k
+
+
+def test_g9_eval_loops_match_reference():
+    """`dostransformer_amd.evaluate.test / test_phonon` against the reference's own utils.test / test_phonon."""
+    from dostransformer_amd import evaluate
+    from dostransformer_amd.embedder_eDOS.DOSTransformer import DOSTransformer
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    z = load("g9_eval.npz")
+    model = DOSTransformer_phonon(3, 1, 118, 4, 16, DEV, 0.0)
+    sd = {k: (v.float() if v.is_floating_point() else v) for k, v in sub(z, "ph/p0/").items()}
+    model.load_state_dict(sd)
+    model = model.to(DEV)
+    loader = [batch_from(z, "ph/b0/").to(DEV, dtype=torch.float32), batch_from(z, "ph/b1/").to(DEV, dtype=torch.float32)]
+    m = evaluate.test_phonon(model, loader, torch.nn.L1Loss(), evaluate.r2, DEV)
+    assert np.allclose(m, z["ph/metrics"], rtol=2e-5, atol=2e-6), (m, z["ph/metrics"])
+    assert not model.training                      # utils.py:118: model.eval()
+    model = DOSTransformer(3, 2, 200, 41, 2, 16, DEV, 0.0)
+    model.load_state_dict(sub(z, "e/p0/"))
+    model = model.to(DEV)
+    loader = [batch_from(z, "e/b0/").to(DEV), batch_from(z, "e/b1/").to(DEV)]
+    rmse_, mse_, mae_, r2_, preds_y = evaluate.test(model, loader, torch.nn.L1Loss(), evaluate.r2, DEV)
+    assert np.allclose([rmse_, mse_, mae_, r2_], z["e/metrics"], rtol=5e-5, atol=5e-6)
+    ids, preds, y, emb = preds_y[0]
+    assert ids == [str(s) for s in z["e/mp_id"]]
+    assert maxabs(preds, z["e/preds"]) < 2e-5 and maxabs(y, z["e/y"]) == 0.0 and maxabs(emb, z["e/embeddings"]) < 2e-4
+
+
+def test_checkpoint_resume_is_exact(tmp_path):
+    """2 steps + save + load into a fresh model/trainer + 1 step == 3 uninterrupted steps (bitwise)."""
+    from dostransformer_amd import checkpoint, synth
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    from dostransformer_amd.train import Trainer
+    g = synth.phonon_batch(4, seed=3, dtype=torch.float32).to(DEV)
+    torch.manual_seed(0)
+    a = DOSTransformer_phonon(3, 1, 118, 4, 16, DEV, 0.0).to(DEV)
+    ta = Trainer(a, lr=1e-3)
+    for _ in range(2):
+        ta.step(g)
+    path = str(tmp_path / "ck.pt")
+    checkpoint.save(path, a, ta, extra={"epoch": 7})
+    ta.step(g)
+    torch.manual_seed(123)                               # different init: everything must come from the file
+    b = DOSTransformer_phonon(3, 1, 118, 4, 16, DEV, 0.0).to(DEV)
+    tb = Trainer(b, lr=5e-2)
+    assert checkpoint.load(path, b, tb) == {"epoch": 7}
+    assert tb.step_count == 2 and tb.lr == 1e-3
+    tb.step(g)
+    for (k, va), (_, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(va.cpu(), vb.cpu()), k

@@ -163,3 +163,16 @@ def test_g8_graphnetworks():
             assert v.grad is None
         else:
             assert maxabs(v.grad, z["g/" + k]) < 5e-4, k
+
+
+def test_g9_eval_loops():
+    """utils.py:61-143 (`test`, `test_phonon`, `r2`) run by the reference itself over two batches each."""
+    z = load("g9_eval.npz")
+    loader = [batch_from(z, "ph/b0/"), batch_from(z, "ph/b1/")]
+    m = O.eval_phonon(sub(z, "ph/p0/"), loader, 3, 1)
+    assert np.allclose(m, z["ph/metrics"], rtol=1e-9, atol=1e-11)
+    loader = [batch_from(z, "e/b0/"), batch_from(z, "e/b1/")]
+    m, (ids, preds, y, emb) = O.eval_edos(sub(z, "e/p0/"), loader, 3, 2)
+    assert np.allclose(m, z["e/metrics"], rtol=2e-5, atol=1e-6)
+    assert ids == [str(s) for s in z["e/mp_id"]]
+    assert maxabs(preds, z["e/preds"]) < 1e-5 and maxabs(y, z["e/y"]) == 0.0 and maxabs(emb, z["e/embeddings"]) < 1e-4
