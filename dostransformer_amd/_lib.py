@@ -113,6 +113,8 @@ _SIGS = {
     "dosx_loss_edos": [_P, _P, _P, _F, _I, _I, _I, _P, _P, _P, _P],
     "dosx_sum": [_P, _I, _P, _P],
     "dosx_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
+    "dosx_csr_workspace_bytes": [_I, C.POINTER(C.c_size_t)],
+    "dosx_csr_build": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P],
     "dosx_fill": [_P, _F, _L, _P],
     "dosx_embed_rows": [_P, _P, _P, _I, _I, _P],
     "dosx_embed_rows_bwd": [_P, _I, _P, _P, _I, _I, _I, _P],

@@ -224,6 +224,19 @@ def graph_meta(g, device=None, n_max: Optional[int] = None) -> GraphMeta:
     arrays — the same host round trip the reference pays in ``to_dense_batch``.
     """
     m = getattr(g, _META_KEY, None) if not isinstance(g, CrystalBatch) else g.meta
+    if (m is None or (n_max is not None and m.n_max != n_max)) and torch.is_tensor(g.edge_index) and g.edge_index.is_cuda:
+        # foreign batch already on the GPU (the reference's loop: `batch.to(device)` then `model(batch)`,
+        # main_eDOS.py:106-109): derive everything on the device; the only host read is the 4-byte n_max, and not
+        # even that when the caller supplies it (the reference syncs on it inside to_dense_batch)
+        m = graph_meta_device(g, n_max)
+        try:
+            if isinstance(g, CrystalBatch):
+                object.__setattr__(g, _META_KEY, m)
+            else:
+                setattr(g, _META_KEY, m)
+        except Exception:
+            pass
+        return m
     if m is None or (n_max is not None and m.n_max != n_max):
         ei = g.edge_index.detach().cpu().numpy()
         bv = g.batch.detach().cpu().numpy()
@@ -248,6 +261,31 @@ def graph_meta(g, device=None, n_max: Optional[int] = None) -> GraphMeta:
         except Exception:
             pass
     return m
+
+
+def graph_meta_device(g, n_max: Optional[int] = None, num_graphs: Optional[int] = None) -> GraphMeta:
+    """GraphMeta of a device-resident batch built by ``dosx_csr_build``: stable destination sort,
+    CSR pointers, dense slots — no host round trip apart from the optional read of ``n_max``."""
+    from . import ops
+    ei = g.edge_index.to(torch.int64)
+    bv = g.batch.to(torch.int64)
+    if num_graphs is None:
+        if isinstance(g, CrystalBatch):
+            num_graphs = g.num_graphs
+        elif hasattr(g, "system") and torch.is_tensor(g.system) and g.system.dim() > 0:
+            num_graphs = int(g.system.shape[0])
+        elif hasattr(g, "num_graphs"):
+            num_graphs = int(g.num_graphs)
+        else:
+            num_graphs = int(bv[-1]) + 1 if bv.numel() else 0          # (host sync; PyG batches carry num_graphs)
+    r = ops.csr_build(ei, bv, num_graphs)
+    true_max = None
+    if n_max is None:
+        n_max = true_max = int(r["n_max"].item())
+    return GraphMeta(num_nodes=int(bv.shape[0]), num_edges=int(ei.shape[1]), num_graphs=int(num_graphs), n_max=int(n_max),
+                     src=r["src"], dst=r["dst"], edge_perm=r["edge_perm"], rowptr_dst=r["rowptr_dst"],
+                     perm_src=r["perm_src"], rowptr_src=r["rowptr_src"], graph_ptr=r["graph_ptr"],
+                     node_graph=r["node_graph"], dense_row=r["dense_row"], inv_deg=r["inv_deg"])
 
 
 def split_crystals(g: CrystalBatch) -> List[Dict[str, object]]:

@@ -1,0 +1,152 @@
+// Device-side graph metadata ("CSR build") for a batch that arrives as PyG-style index tensors
+// (counterpart of what torch_geometric's collate + to_dense_batch + torch_scatter derive on the
+// fly: `DOSTransformer_phonon.py:48-56,86,209`).  Everything the kernels of this library index with is derived
+// from `edge_index [2,E]` (int64, any order) and `batch [N]` (int64, non-decreasing) ON THE DEVICE, stream-ordered,
+// with no host round trip:
+//     edges stably sorted by destination (so every aggregation is a contiguous, atomic-free, bit-reproducible
+//     segment sum), the permutation that sort applied, CSR row pointers by destination and by source, the
+//     source-sorted inverse index for the gather backward, per-graph node ranges, the dense (pos, graph) slot of
+//     every node, 1/in-degree, and the largest crystal (device scalar).
+// The two stable sorts are rocPRIM LSD radix sorts (a plain library primitive); the rest are the small kernels below.
+#include <string.h>
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "common.h"
+
+namespace {
+
+__global__ void csr_keys_kernel(const long long* __restrict__ edge_index, int E, int* __restrict__ kdst, int* __restrict__ iota) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  kdst[e] = (int)edge_index[(size_t)E + e];
+  iota[e] = e;
+}
+
+// after the sort by destination: src in the new order, the 64-bit permutation for the caller's edge tensors
+__global__ void csr_permute_kernel(const long long* __restrict__ edge_index, const int* __restrict__ perm, int E,
+                                   int* __restrict__ src, long long* __restrict__ edge_perm, int* __restrict__ iota) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int p = perm[e];
+  src[e] = (int)edge_index[p];
+  if (edge_perm) edge_perm[e] = p;
+  iota[e] = e;
+}
+
+__device__ __forceinline__ int lower_bound_i32(const int* __restrict__ a, int n, int key) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+__device__ __forceinline__ int lower_bound_i64(const long long* __restrict__ a, int n, long long key) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// row pointers from the sorted key arrays (binary search per node: no atomics, no scan)
+__global__ void csr_rowptr_kernel(const int* __restrict__ dst_sorted, const int* __restrict__ src_sorted, int E, int N,
+                                  int* __restrict__ rowptr_dst, int* __restrict__ rowptr_src) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n > N) return;
+  rowptr_dst[n] = lower_bound_i32(dst_sorted, E, n);
+  rowptr_src[n] = lower_bound_i32(src_sorted, E, n);
+}
+
+__global__ void csr_graph_ptr_kernel(const long long* __restrict__ batch, int N, int B, int* __restrict__ graph_ptr) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > B) return;
+  graph_ptr[b] = lower_bound_i64(batch, N, (long long)b);
+}
+
+__global__ void csr_nodes_kernel(const long long* __restrict__ batch, const int* __restrict__ graph_ptr,
+                                 const int* __restrict__ rowptr_dst, int N, int B, int* __restrict__ node_graph,
+                                 int* __restrict__ dense_row, float* __restrict__ inv_deg) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int b = (int)batch[n];
+  node_graph[n] = b;
+  dense_row[n] = (n - graph_ptr[b]) * B + b;
+  const int deg = rowptr_dst[n + 1] - rowptr_dst[n];
+  inv_deg[n] = 1.f / (float)(deg > 1 ? deg : 1);
+}
+
+__global__ void csr_nmax_kernel(const int* __restrict__ graph_ptr, int B, int* __restrict__ n_max) {
+  __shared__ int red[256];
+  int m = 0;
+  for (int b = threadIdx.x; b < B; b += 256) m = max(m, graph_ptr[b + 1] - graph_ptr[b]);
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = max(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) n_max[0] = red[0];
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t sort_temp_bytes(int E) {
+  size_t bytes = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const int*)nullptr, (int*)nullptr, (const int*)nullptr, (int*)nullptr,
+                                  (size_t)(E > 0 ? E : 1), 0, 32, (hipStream_t)0);
+  return bytes;
+}
+
+}  // namespace
+
+extern "C" int dosx_csr_workspace_bytes(int E, size_t* bytes) {
+  DOSX_CHECK_ARG(bytes != nullptr && E >= 0, "dosx_csr_workspace_bytes: bad args");
+  // [kdst | iota | keys_out] (3 x E int32) + the radix sort's own temporary storage
+  *bytes = 3 * align256((size_t)(E > 0 ? E : 1) * 4) + align256(sort_temp_bytes(E));
+  return 0;
+}
+
+extern "C" int dosx_csr_build(const long long* edge_index, const long long* batch, int N, int E, int B, int* src, int* dst,
+                              long long* edge_perm, int* rowptr_dst, int* perm_src, int* rowptr_src, int* graph_ptr,
+                              int* node_graph, int* dense_row, float* inv_deg, int* n_max, void* workspace, size_t ws_bytes,
+                              dosx_stream_t stream) {
+  DOSX_CHECK_ARG(N >= 0 && E >= 0 && B >= 0, "dosx_csr_build: bad sizes N=%d E=%d B=%d", N, E, B);
+  DOSX_CHECK_ARG(src && dst && rowptr_dst && perm_src && rowptr_src && graph_ptr && node_graph && dense_row && inv_deg,
+                 "dosx_csr_build: null output");
+  DOSX_CHECK_ARG((E == 0 || edge_index) && (N == 0 || batch), "dosx_csr_build: null input");
+  size_t need = 0;
+  dosx_csr_workspace_bytes(E, &need);
+  DOSX_CHECK_ARG(workspace && ws_bytes >= need, "dosx_csr_build: workspace %zu < %zu bytes", ws_bytes, need);
+  hipStream_t s = to_stream(stream);
+  char* w = static_cast<char*>(workspace);
+  const size_t seg = align256((size_t)(E > 0 ? E : 1) * 4);
+  int* kdst = reinterpret_cast<int*>(w);
+  int* iota = reinterpret_cast<int*>(w + seg);
+  int* keys_out = reinterpret_cast<int*>(w + 2 * seg);
+  void* tmp = w + 3 * seg;
+  size_t tmp_bytes = ws_bytes - 3 * seg;
+  if (E > 0) {
+    const int g = ceil_div(E, 256);
+    hipLaunchKernelGGL(csr_keys_kernel, dim3(g), dim3(256), 0, s, edge_index, E, kdst, iota);
+    // stable sort by destination: dst <- sorted keys, perm_src (scratch) <- original position of every sorted edge
+    hipError_t e1 = rocprim::radix_sort_pairs(tmp, tmp_bytes, kdst, dst, iota, perm_src, (size_t)E, 0, 32, s);
+    DOSX_CHECK_ARG(e1 == hipSuccess, "dosx_csr_build: radix sort failed: %s", hipGetErrorString(e1));
+    hipLaunchKernelGGL(csr_permute_kernel, dim3(g), dim3(256), 0, s, edge_index, perm_src, E, src, edge_perm, iota);
+    // stable sort of the dst-ordered edge ids by source: perm_src = ids (dst-sorted numbering) ordered by src
+    hipError_t e2 = rocprim::radix_sort_pairs(tmp, tmp_bytes, src, keys_out, iota, perm_src, (size_t)E, 0, 32, s);
+    DOSX_CHECK_ARG(e2 == hipSuccess, "dosx_csr_build: radix sort failed: %s", hipGetErrorString(e2));
+  }
+  hipLaunchKernelGGL(csr_rowptr_kernel, dim3(ceil_div(N + 1, 256)), dim3(256), 0, s, dst, keys_out, E, N, rowptr_dst, rowptr_src);
+  hipLaunchKernelGGL(csr_graph_ptr_kernel, dim3(ceil_div(B + 1, 256)), dim3(256), 0, s, batch, N, B, graph_ptr);
+  if (N > 0)
+    hipLaunchKernelGGL(csr_nodes_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, s, batch, graph_ptr, rowptr_dst, N, B, node_graph,
+                       dense_row, inv_deg);
+  if (n_max) hipLaunchKernelGGL(csr_nmax_kernel, dim3(1), dim3(256), 0, s, graph_ptr, B, n_max);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}

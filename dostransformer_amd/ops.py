@@ -437,3 +437,25 @@ def reduce_rows(src_ptr, ld_src, dst_ptr, ld_dst, n_out, n_red, stride_out, stri
 
 def act_bwd(dy, y, slope, out):
     _call("dosx_act_bwd", _p(dy), _p(y), float(slope), _p(out), dy.numel(), _stream())
+
+
+def csr_build(edge_index: torch.Tensor, batch: torch.Tensor, num_graphs: int, want_perm: bool = True):
+    """Graph metadata from PyG-style index tensors ON THE DEVICE (include/dosx.h: dosx_csr_build); returns a dict of
+    int32 device tensors (+ ``inv_deg`` fp32, ``edge_perm`` int64 or None, ``n_max`` 1-element device tensor)."""
+    assert edge_index.is_cuda and batch.is_cuda and edge_index.dtype == torch.int64 and batch.dtype == torch.int64
+    ei = edge_index.contiguous()
+    bv = batch.contiguous()
+    dev, E, N, B = ei.device, int(ei.shape[1]), int(bv.shape[0]), int(num_graphs)
+    i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)
+    out = {"src": i32(E), "dst": i32(E), "rowptr_dst": i32(N + 1), "perm_src": i32(E), "rowptr_src": i32(N + 1),
+           "graph_ptr": i32(B + 1), "node_graph": i32(N), "dense_row": i32(N),
+           "inv_deg": torch.empty(N, dtype=torch.float32, device=dev), "n_max": i32(1),
+           "edge_perm": torch.empty(E, dtype=torch.int64, device=dev) if want_perm else None}
+    nbytes = C.c_size_t(0)
+    _lib.check(_lib.load().dosx_csr_workspace_bytes(E, C.byref(nbytes)), "dosx_csr_workspace_bytes")
+    ws = torch.empty(int(nbytes.value), dtype=torch.uint8, device=dev)
+    _call("dosx_csr_build", ei.data_ptr(), bv.data_ptr(), N, E, B, out["src"].data_ptr(), out["dst"].data_ptr(),
+          _p(out["edge_perm"]), out["rowptr_dst"].data_ptr(), out["perm_src"].data_ptr(), out["rowptr_src"].data_ptr(),
+          out["graph_ptr"].data_ptr(), out["node_graph"].data_ptr(), out["dense_row"].data_ptr(), out["inv_deg"].data_ptr(),
+          out["n_max"].data_ptr(), ws.data_ptr(), C.c_size_t(ws.numel()), _stream())
+    return out

@@ -268,6 +268,22 @@ int dosx_sum(const float* src, int n, float* dst, dosx_stream_t stream);
 int dosx_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                float eps, float weight_decay, int step, float grad_scale, dosx_stream_t stream);
 
+/* Graph metadata ("CSR build") on the device, stream-ordered, no host round trip — counterpart of what PyG's
+ * collate / to_dense_batch / torch_scatter derive per call from `edge_index` and `batch`
+ * (DOSTransformer_phonon.py:48-56,86,209).
+ *   edge_index [2,E] int64 (any order), batch [N] int64 non-decreasing, B graphs.
+ *   dst/src [E]      : the edges STABLY sorted by destination (aggregation = contiguous segment sum);
+ *   edge_perm [E]    : int64, position of sorted edge e in the caller's edge arrays (may be NULL);
+ *   rowptr_dst/src [N+1], perm_src [E] : CSR by destination / by source (ids in the sorted numbering);
+ *   graph_ptr [B+1], node_graph [N], dense_row [N] = pos*B + graph, inv_deg [N] = 1/max(in-degree,1);
+ *   n_max [1]        : device scalar, atoms of the largest crystal (may be NULL).
+ * workspace: dosx_csr_workspace_bytes(E) bytes of device scratch owned by the caller. */
+int dosx_csr_workspace_bytes(int E, size_t* bytes);
+int dosx_csr_build(const long long* edge_index, const long long* batch, int N, int E, int B, int32_t* src, int32_t* dst,
+                   long long* edge_perm, int32_t* rowptr_dst, int32_t* perm_src, int32_t* rowptr_src,
+                   int32_t* graph_ptr, int32_t* node_graph, int32_t* dense_row, float* inv_deg, int32_t* n_max,
+                   void* workspace, size_t ws_bytes, dosx_stream_t stream);
+
 /* misc */
 int dosx_fill(float* p, float value, int64_t n, dosx_stream_t stream);
 /* out[r] = table[idx[r]] rows (prompt_token[g.system], DOSTransformer_phonon.py:105) and its backward

@@ -387,3 +387,24 @@ def test_checkpoint_resume_is_exact(tmp_path):
     tb.step(g)
     for (k, va), (_, vb) in zip(a.state_dict().items(), b.state_dict().items()):
         assert torch.equal(va.cpu(), vb.cpu()), k
+
+
+def test_foreign_device_batch_uses_device_csr():
+    """A PyG-style batch that is already on the GPU (unsorted edges, no metadata) goes through dosx_csr_build and
+    gives the same outputs as the host-collated, destination-sorted batch."""
+    from dostransformer_amd import synth
+    from dostransformer_amd.batch import CrystalBatch
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    torch.manual_seed(0)
+    model = DOSTransformer_phonon(3, 1, 118, 4, 16, DEV, 0.0).to(DEV)
+    g = synth.phonon_batch(5, seed=11, dtype=torch.float32, sort_edges=False)
+    perm = torch.randperm(g.edge_index.shape[1], generator=torch.Generator().manual_seed(5))
+    foreign = CrystalBatch({"x": g.x.to(DEV), "edge_index": g.edge_index[:, perm].to(DEV), "edge_vec": g.edge_vec[perm].to(DEV),
+                            "batch": g.batch.to(DEV), "system": g.system.to(DEV), "phdos": g.phdos.to(DEV)}, 5, meta=None)
+    ref = synth.phonon_batch(5, seed=11, dtype=torch.float32).to(DEV)
+    with torch.no_grad():
+        a = model(foreign)
+        b = model(ref)
+    assert foreign.meta is not None and foreign.meta.src.is_cuda and foreign.meta.edge_perm is not None
+    for u, v in zip(a, b):
+        assert maxabs(u.cpu(), v.cpu()) < 2e-6

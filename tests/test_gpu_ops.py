@@ -550,3 +550,24 @@ def test_losses_adamw_misc():
     oo = torch.empty(100, 32, device=DEV)
     o.act_bwd(dyv, yv, 0.01, oo)
     assert err(oo, torch.where(yv > 0, dyv, 0.01 * dyv)) < 1e-7
+
+
+@pytest.mark.parametrize("B,seed", [(1, 0), (7, 1), (64, 2)])
+def test_csr_build_matches_host(B, seed):
+    """dosx_csr_build (device) == batch._build_meta_host (numpy) on shuffled, PyG-style index tensors."""
+    import numpy as np
+    from dostransformer_amd import synth
+    from dostransformer_amd.batch import _build_meta_host
+    o = ops()
+    g = synth.phonon_batch(B, seed=seed, dtype=torch.float32, sort_edges=False)
+    ei = g.edge_index.clone()
+    perm = torch.randperm(ei.shape[1], generator=torch.Generator().manual_seed(seed))
+    ei = ei[:, perm]                                         # arbitrary edge order
+    ref = _build_meta_host(ei.numpy(), g.batch.numpy(), B, None, presorted=False)
+    r = o.csr_build(ei.to(DEV), g.batch.to(DEV), B)
+    torch.cuda.synchronize()
+    for k in ("src", "dst", "rowptr_dst", "perm_src", "rowptr_src", "graph_ptr", "node_graph", "dense_row"):
+        assert torch.equal(r[k].cpu(), getattr(ref, k)), k
+    assert torch.equal(r["edge_perm"].cpu(), ref.edge_perm)
+    assert torch.equal(r["inv_deg"].cpu(), ref.inv_deg)
+    assert int(r["n_max"].item()) == ref.n_max

@@ -106,6 +106,16 @@ def attn_case(name, Sq, Bq, Nk, Bk, H):
           f"({100 * fl / us / 1e6 / 157.3:4.1f}%) | bwd(dq+dkv) {usb:7.1f} us {2.5 * fl / usb / 1e6:6.2f} TF/s")
 
 
+def csr_case(name, B, kind="phonon"):
+    from dostransformer_amd import synth
+    g = synth.phonon_batch(B, seed=0, dtype=torch.float32, sort_edges=False) if kind == "phonon" else \
+        synth.edos_batch(B, seed=0, dtype=torch.float32, sort_edges=False)
+    ei, bv = g.edge_index.to(DEV), g.batch.to(DEV)
+    us = timeit(lambda: ops.csr_build(ei, bv, B), iters=20)
+    print(f"csr   {name:30s} B={B} N={bv.shape[0]} E={ei.shape[1]}: {us:7.1f} us per build (2 stable radix sorts + 5 kernels, "
+          f"no host round trip)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="all")
@@ -113,6 +123,10 @@ def main():
     w = args.what
     H = 128
     E, N, R1, R2 = 9000, 450, 51 * 64, 51 * 128
+    if w in ("all", "csr"):
+        csr_case("cfg2 batch", 64)
+        csr_case("cfg3 batch (eDOS)", 64, "edos")
+        csr_case("512 crystals", 512)
     if w in ("all", "gemm"):
         gemm_case("edge gemm1 (gather, LN epi)", E, 2 * H, 3 * H, epi=ops.EPI_LN, gather=True)
         gemm_case("edge gemm1 (plain A, LN epi)", E, 2 * H, 3 * H, epi=ops.EPI_LN)
