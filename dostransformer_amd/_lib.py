@@ -82,6 +82,19 @@ class Attn(C.Structure):
     ]
 
 
+class Ffn(C.Structure):
+    _fields_ = [
+        ("M", C.c_int32), ("H", C.c_int32),
+        ("x", C.c_void_p), ("ldx", C.c_int32),
+        ("stats", C.c_void_p),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("w1", C.c_void_p), ("b1", C.c_void_p),
+        ("w2", C.c_void_p), ("b2", C.c_void_p),
+        ("h", C.c_void_p), ("ldh", C.c_int32),
+        ("out", C.c_void_p), ("ldo", C.c_int32),
+    ]
+
+
 # name -> argtypes  (restype is int unless listed in _RESTYPES)
 _P, _I, _F, _L, _D = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_double
 _SIGS = {
@@ -113,6 +126,8 @@ _SIGS = {
     "dosx_loss_edos": [_P, _P, _P, _F, _I, _I, _I, _P, _P, _P, _P],
     "dosx_sum": [_P, _I, _P, _P],
     "dosx_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
+    "dosx_ffn_supported": [_I],
+    "dosx_ffn_fwd": [C.POINTER(Ffn), _P],
     "dosx_csr_workspace_bytes": [_I, C.POINTER(C.c_size_t)],
     "dosx_csr_build": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P],
     "dosx_fill": [_P, _F, _L, _P],

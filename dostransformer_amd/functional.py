@@ -202,14 +202,21 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
         ops.attention_fwd(a)
         ops.KERNEL_TIMER.stop(ev, f"attention_fwd_{pre}", "attn_fwd_kernel", "mfma", 4.0 * Bq * Sq * Nk * H)
         h = _empty(dev, rows, 4 * H)
-        ev = ops.KERNEL_TIMER.start()
-        ops.gemm(rows, 4 * H, [seg(x1)], P[lp + ".fc1.weight"], h, pro=PRO_ROWLN,
-                 pro_gamma=P[lp + ".layer_norms.1.weight"], pro_beta=P[lp + ".layer_norms.1.bias"], pro_stats=st1,
-                 bias=P[lp + ".fc1.bias"], act=ACT_RELU)
-        ops.KERNEL_TIMER.stop(ev, f"ffn_fc1_fwd_{pre}", "gemm_kernel<NT,rowLN-prologue,relu>", "mfma",
-                              2.0 * rows * H * 4 * H)
         x2 = _empty(dev, rows, H)
-        ops.gemm(rows, H, [seg(h)], P[lp + ".fc2.weight"], x2, bias=P[lp + ".fc2.bias"], res=x1)
+        if ops.ffn_supported(H):
+            # both GEMMs of the feed-forward half in one launch (the 32 x 4H intermediate tile stays in LDS)
+            ev = ops.KERNEL_TIMER.start()
+            ops.ffn_fwd(rows, H, x1, st1, P[lp + ".layer_norms.1.weight"], P[lp + ".layer_norms.1.bias"],
+                        P[lp + ".fc1.weight"], P[lp + ".fc1.bias"], P[lp + ".fc2.weight"], P[lp + ".fc2.bias"], h, x2)
+            ops.KERNEL_TIMER.stop(ev, f"ffn_fwd_{pre}", "ffn_fwd_kernel (fc1+relu+fc2 fused)", "mfma", 4.0 * rows * H * 4 * H)
+        else:
+            ev = ops.KERNEL_TIMER.start()
+            ops.gemm(rows, 4 * H, [seg(x1)], P[lp + ".fc1.weight"], h, pro=PRO_ROWLN,
+                     pro_gamma=P[lp + ".layer_norms.1.weight"], pro_beta=P[lp + ".layer_norms.1.bias"], pro_stats=st1,
+                     bias=P[lp + ".fc1.bias"], act=ACT_RELU)
+            ops.KERNEL_TIMER.stop(ev, f"ffn_fc1_fwd_{pre}", "gemm_kernel<NT,rowLN-prologue,relu>", "mfma",
+                                  2.0 * rows * H * 4 * H)
+            ops.gemm(rows, H, [seg(h)], P[lp + ".fc2.weight"], x2, bias=P[lp + ".fc2.bias"], res=x1)
         lay.append((x, qs, qb, x1, probs, qstats, st1, h))
         x, qs, qb = x2, Bq, 1
     fin = None

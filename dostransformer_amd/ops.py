@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import BIG, Attn, Gemm, ReduceJob, RowMap, Seg, Wgrad
+from ._lib import Ffn, BIG, Attn, Gemm, ReduceJob, RowMap, Seg, Wgrad
 
 PRO_NONE, PRO_PRELU, PRO_LN_PRELU, PRO_ROWLN = 0, 1, 2, 3
 EPI_BIAS_ACT, EPI_LN, EPI_PRELU_LN_BWD, EPI_RELU_MASK, EPI_ROWLN_BWD, EPI_PRELU_BWD = 0, 1, 2, 3, 4, 5
@@ -206,6 +206,24 @@ def gemm(M: int, N: int, segs: Sequence[Seg], w: torch.Tensor, out: torch.Tensor
     g.epi_gamma, g.epi_beta, g.epi_alpha = _p(epi_gamma), _p(epi_beta), _p(epi_alpha)
     g.partials, g.partial_ld = _p(partials), int(partial_ld)
     _call("dosx_gemm", C.byref(g), _stream())
+
+
+def ffn_supported(H: int) -> bool:
+    return bool(_lib.load().dosx_ffn_supported(int(H)))
+
+
+def ffn_fwd(M: int, H: int, x: torch.Tensor, stats: torch.Tensor, gamma, beta, w1, b1, w2, b2, h: torch.Tensor,
+            out: torch.Tensor) -> None:
+    """out = x + fc2(relu(fc1(LN1(x)))), h = relu(fc1(LN1(x))) in one launch (include/dosx.h: DosxFfn)."""
+    a = Ffn()
+    a.M, a.H = int(M), int(H)
+    a.x, a.ldx = x.data_ptr(), int(x.stride(0))
+    a.stats = stats.data_ptr()
+    a.gamma, a.beta = gamma.data_ptr(), beta.data_ptr()
+    a.w1, a.b1, a.w2, a.b2 = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
+    a.h, a.ldh = h.data_ptr(), int(h.stride(0))
+    a.out, a.ldo = out.data_ptr(), int(out.stride(0))
+    _call("dosx_ffn_fwd", C.byref(a), _stream())
 
 
 def gemm_partial_rows(M: int, N: int, epi: int) -> int:

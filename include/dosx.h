@@ -268,6 +268,25 @@ int dosx_sum(const float* src, int n, float* dst, dosx_stream_t stream);
 int dosx_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                float eps, float weight_decay, int step, float grad_scale, dosx_stream_t stream);
 
+/* Fused feed-forward half of the encoder layer (layers/transformer.py:141-148), forward:
+ *     h   = relu( LN1(x) . W1^T + b1 )      [M,4H]   (written out: the backward needs it)
+ *     out = x + h . W2^T + b2               [M,H]
+ * LN1(x) = (x - mean)*rstd*gamma + beta with the per-row (mean, rstd) pairs in `stats` (produced by the attention
+ * kernel's epilogue).  One launch instead of two GEMMs; dosx_ffn_supported(H) says whether this H has the fused kernel
+ * (H % 32 == 0, H <= 128), otherwise the caller issues the two dosx_gemm calls. */
+typedef struct DosxFfn {
+  int32_t M, H;
+  const float* x; int32_t ldx;
+  const float* stats;
+  const float* gamma; const float* beta;
+  const float* w1; const float* b1;       /* fc1.weight [4H,H], fc1.bias [4H] */
+  const float* w2; const float* b2;       /* fc2.weight [H,4H], fc2.bias [H]  */
+  float* h; int32_t ldh;
+  float* out; int32_t ldo;
+} DosxFfn;
+int dosx_ffn_supported(int H);
+int dosx_ffn_fwd(const DosxFfn* a, dosx_stream_t stream);
+
 /* Graph metadata ("CSR build") on the device, stream-ordered, no host round trip — counterpart of what PyG's
  * collate / to_dense_batch / torch_scatter derive per call from `edge_index` and `batch`
  * (DOSTransformer_phonon.py:48-56,86,209).

@@ -571,3 +571,25 @@ def test_csr_build_matches_host(B, seed):
     assert torch.equal(r["edge_perm"].cpu(), ref.edge_perm)
     assert torch.equal(r["inv_deg"].cpu(), ref.inv_deg)
     assert int(r["n_max"].item()) == ref.n_max
+
+
+@pytest.mark.parametrize("M,H", [(33, 32), (100, 64), (3264, 128), (6528, 128), (1, 128)])
+def test_ffn_fused_forward(M, H):
+    """dosx_ffn_fwd == the two GEMMs of layers/transformer.py:141-148 (pre-norm FFN with residual)."""
+    o = ops()
+    assert o.ffn_supported(H)
+    x = rnd(M, H, seed=1)
+    g, b = rnd(H, seed=2), rnd(H, seed=3)
+    w1, b1 = rnd(4 * H, H, seed=4, scale=0.2), rnd(4 * H, seed=5)
+    w2, b2 = rnd(H, 4 * H, seed=6, scale=0.2), rnd(H, seed=7)
+    mu = x.mean(1, keepdim=True)
+    rstd = 1 / torch.sqrt(x.var(1, unbiased=False, keepdim=True) + 1e-5)
+    stats = torch.cat([mu, rstd], 1).contiguous()
+    h = torch.empty(M, 4 * H, device=DEV)
+    out = torch.empty(M, H, device=DEV)
+    o.ffn_fwd(M, H, x, stats, g, b, w1, b1, w2, b2, h, out)
+    xd = x.double()
+    ln = F.layer_norm(xd, (H,), g.double(), b.double(), 1e-5)
+    href = torch.relu(ln @ w1.double().T + b1.double())
+    assert err(h, href) < TOL
+    assert err(out, xd + href @ w2.double().T + b2.double()) < TOL

@@ -106,6 +106,22 @@ def attn_case(name, Sq, Bq, Nk, Bk, H):
           f"({100 * fl / us / 1e6 / 157.3:4.1f}%) | bwd(dq+dkv) {usb:7.1f} us {2.5 * fl / usb / 1e6:6.2f} TF/s")
 
 
+def ffn_case(name, M, H):
+    x = torch.randn(M, H, device=DEV); stats = torch.rand(M, 2, device=DEV)
+    g, b = torch.randn(H, device=DEV), torch.randn(H, device=DEV)
+    w1, b1 = torch.randn(4 * H, H, device=DEV), torch.randn(4 * H, device=DEV)
+    w2, b2 = torch.randn(H, 4 * H, device=DEV), torch.randn(H, device=DEV)
+    h = torch.empty(M, 4 * H, device=DEV); out = torch.empty(M, H, device=DEV)
+    us = timeit(lambda: ops.ffn_fwd(M, H, x, stats, g, b, w1, b1, w2, b2, h, out))
+    def two():
+        ops.gemm(M, 4 * H, [ops.seg(x)], w1, h, pro=ops.PRO_ROWLN, pro_gamma=g, pro_beta=b, pro_stats=stats, bias=b1, act=1)
+        ops.gemm(M, H, [ops.seg(h)], w2, out, bias=b2, res=x)
+    us2 = timeit(two)
+    fl = 16.0 * M * H * H
+    print(f"ffn   {name:30s} M={M} H={H}: fused {us:6.1f} us {fl / us / 1e6:6.1f} TF/s ({100 * fl / us / 1e6 / 157.3:4.1f}%) | "
+          f"two GEMMs {us2:6.1f} us")
+
+
 def csr_case(name, B, kind="phonon"):
     from dostransformer_amd import synth
     g = synth.phonon_batch(B, seed=0, dtype=torch.float32, sort_edges=False) if kind == "phonon" else \
@@ -123,6 +139,10 @@ def main():
     w = args.what
     H = 128
     E, N, R1, R2 = 9000, 450, 51 * 64, 51 * 128
+    if w in ("all", "ffn"):
+        ffn_case("FFN fwd 2B", R2, H)
+        ffn_case("FFN fwd B", R1, H)
+        ffn_case("FFN fwd roofline scale", 262144, H)
     if w in ("all", "csr"):
         csr_case("cfg2 batch", 64)
         csr_case("cfg3 batch (eDOS)", 64, "edos")
