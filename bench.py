@@ -194,9 +194,9 @@ def main():
         for i in range(min(args.steps, 24)):
             # An eager step is host-bound (~17 us of Python per launch): without a head start the GPU
             # would idle between a site's start event and its kernel and the bracket would time the host.
-            # A ~10 ms device-side spin lets the host enqueue the whole step first, so every bracket times
+            # A ~4 ms device-side spin lets the host enqueue the whole step first, so every bracket times
             # back-to-back GPU execution (a bracket then adds ~1 us to a kernel: tools/event_overhead.py).
-            torch.cuda._sleep(int(2.0e7))
+            torch.cuda._sleep(int(1.0e7))
             trainer.step(batches[i % len(batches)], n_global)
             torch.cuda.synchronize()
         ops.KERNEL_TIMER.enabled = False

@@ -13,10 +13,10 @@ from collections import defaultdict
 # bench.py roofline site -> substring that identifies the kernel symbol (template arguments included)
 SITES = {
     "edge_mlp_gemm1_fwd": "gemm_kernel<2, 2, 0, 0, 1, 1>",
-    "ffn_fc1_fwd_transformer_self": "gemm_kernel<2, 1, 0, 3, 1, 0>",
+    "ffn_fwd_transformer_self": "ffn_fwd_kernel",
     "scatter_add_fwd": "segment_reduce_kernel",
-    "attention_fwd_transformer_self": "attn_fwd_kernel<true, 4>",
-    "attention_fwd_transformer": "attn_fwd_kernel<true, 1>",
+    "attention_fwd_transformer_self": "attn_fwd_stream_kernel<4>",
+    "attention_fwd_transformer": "attn_fwd_stream_kernel<1>",
 }
 
 
