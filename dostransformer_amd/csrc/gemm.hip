@@ -4,9 +4,9 @@
 //   dosx_wgrad  : slab[s][N,K] = dY[ms:me]^T . prologue(A)[ms:me]  (nn.Linear wgrad, split over M)
 //   dosx_reduce_partials : deterministic sum of the split slabs
 //
-// One workgroup = 4 waves (one per SIMD); v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma
-// chain) so results track an fp32 torch reference to rounding.  A is gathered / concatenated /
-// normalised on the fly while it is staged into LDS, so torch.cat([x[row], x[col], e]) and the
+// One workgroup = 8 waves: 4 matrix waves (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma chain, so results
+// track an fp32 torch reference to rounding) + 4 staging waves (global -> registers -> LDS).  A is gathered /
+// concatenated / normalised on the fly while it is staged, so torch.cat([x[row], x[col], e]) and the
 // LayerNorm/PReLU between the two Linear layers of every MLP never exist in HBM.
 #include <stdlib.h>
 
@@ -45,10 +45,6 @@ extern "C" { __device__ unsigned long long dosx_stamp_buf[64 * 64]; }
 #define STAMP_S(slot) do { } while (0)
 #define WSTAMP(slot) do { } while (0)
 #define WSTAMP_S(slot) do { } while (0)
-#endif
-
-#ifndef DOSX_PRIO_VARIANT
-#define DOSX_PRIO_VARIANT 1
 #endif
 
 namespace {
@@ -468,7 +464,6 @@ void gemm_kernel(const GemmLaunch L) {
       if (WL == 1 && (size_t)K * g.ldw * 4 >= 0x7fffffffu) fits = false;
       fast = fast && __all(fits);
     }
-    if (DOSX_PRIO_VARIANT == 1) __builtin_amdgcn_s_setprio(3);
     if (fast) {
       const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)g.w, 0, 0x7fffffff, 0x00020000);
       const __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc((void*)g.a[0].p, 0, 0x7fffffff, 0x00020000);
@@ -535,7 +530,6 @@ void gemm_kernel(const GemmLaunch L) {
     f32x16 accb;
 #pragma unroll
     for (int r = 0; r < 16; ++r) accb[r] = 0.f;
-    if (DOSX_PRIO_VARIANT == 2) __builtin_amdgcn_s_setprio(2);
     if constexpr (PROLN) __syncthreads();
     __syncthreads();
     STAMP(1);
@@ -590,7 +584,6 @@ void gemm_kernel(const GemmLaunch L) {
       for (int r = 0; r < 16; ++r) acc[0][0][r] += accb[r];
     }
   }
-  __builtin_amdgcn_s_setprio(0);
   STAMP(55);
 
   if constexpr (!HOIST) prefetch_rows();
