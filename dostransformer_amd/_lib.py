@@ -95,6 +95,10 @@ class Ffn(C.Structure):
     ]
 
 
+class Call(C.Structure):
+    _fields_ = [("fn", C.c_void_p), ("kind", C.c_int32), ("nint", C.c_int32), ("iarg", C.c_int64 * 19), ("farg", C.c_double * 6)]
+
+
 # name -> argtypes  (restype is int unless listed in _RESTYPES)
 _P, _I, _F, _L, _D = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_double
 _SIGS = {
@@ -130,6 +134,7 @@ _SIGS = {
     "dosx_ffn_fwd": [C.POINTER(Ffn), _P],
     "dosx_csr_workspace_bytes": [_I, C.POINTER(C.c_size_t)],
     "dosx_csr_build": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P],
+    "dosx_replay": [C.POINTER(Call), _I, C.POINTER(C.c_int)],
     "dosx_fill": [_P, _F, _L, _P],
     "dosx_embed_rows": [_P, _P, _P, _I, _I, _P],
     "dosx_embed_rows_bwd": [_P, _I, _P, _P, _I, _I, _I, _P],

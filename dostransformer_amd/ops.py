@@ -100,10 +100,83 @@ class _Recorder:
 
 
 class Program:
+    """A recorded launch list.  ``run()`` re-issues it through ``dosx_replay`` (one ctypes call; the loop over the
+    entries runs in C, csrc/replay.cpp).  Entries are libdosx calls and the stream fork / join operations of
+    :class:`GradSink`, which are lowered to hipEventRecord / hipStreamWaitEvent on the raw handles."""
+
     def __init__(self, prog, keep):
         self.prog, self.keep = prog, keep
+        self._calls = None
+        self._n = 0
+        self._events = []
+
+    # ---- lowering ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _hip():
+        lib = getattr(Program, "_hiplib", None)
+        if lib is None:
+            import os
+            lib = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+            Program._hiplib = lib
+        return lib
+
+    def _compile(self):
+        hip = self._hip()
+        ev_record = C.cast(hip.hipEventRecord, C.c_void_p).value
+        st_wait = C.cast(hip.hipStreamWaitEvent, C.c_void_p).value
+        out = []
+
+        def emit(fnptr, ints, flts=(), kind=0):
+            c = _lib.Call()
+            c.fn, c.kind, c.nint = fnptr, kind, len(ints)
+            assert len(ints) <= 19 and len(flts) <= 6
+            for i, v in enumerate(ints):
+                c.iarg[i] = int(v) if v is not None else 0
+            for i, v in enumerate(flts):
+                c.farg[i] = float(v)
+            out.append(c)
+
+        for fn, args in self.prog:
+            owner = getattr(fn, "__self__", None)
+            if isinstance(owner, torch.cuda.Event) and fn.__name__ == "record":          # ev.record(stream)
+                emit(ev_record, [owner.cuda_event, args[0].cuda_stream])
+            elif isinstance(owner, torch.cuda.Stream) and fn.__name__ == "wait_event":    # stream.wait_event(ev)
+                emit(st_wait, [owner.cuda_stream, args[0].cuda_event, 0])
+            elif isinstance(owner, torch.cuda.Stream) and fn.__name__ == "wait_stream":   # main.wait_stream(side)
+                ev = torch.cuda.Event()
+                ev.record(args[0])                                                       # creates the hip event
+                self._events.append(ev)
+                emit(ev_record, [ev.cuda_event, args[0].cuda_stream])
+                emit(st_wait, [owner.cuda_stream, ev.cuda_event, 0])
+            else:                                                                         # a libdosx entry point
+                ints, flts, sig = [], [], ""
+                for a, t in zip(args, fn.argtypes):
+                    if t is C.c_float or t is C.c_double:
+                        flts.append(a.value if hasattr(a, "value") else a)
+                        sig += "f" if t is C.c_float else "d"
+                    elif hasattr(a, "_obj"):                                              # byref(descriptor)
+                        ints.append(C.addressof(a._obj))
+                    elif isinstance(a, C.Array) or isinstance(a, C.Structure):
+                        ints.append(C.addressof(a))
+                    else:
+                        ints.append(a.value if hasattr(a, "value") else a)
+                kind = {"": 0, "f": 1, "fd": 2, "ffffff": 3}.get(sig)
+                if kind is None:
+                    raise RuntimeError(f"no replay signature class for {getattr(fn, '__name__', fn)}: floats '{sig}'")
+                emit(C.cast(fn, C.c_void_p).value, ints, flts, kind)
+        self._n = len(out)
+        self._calls = (_lib.Call * self._n)(*out)
 
     def run(self) -> None:
+        if self._calls is None:
+            self._compile()
+        failed = C.c_int(-1)
+        rc = _lib.load().dosx_replay(self._calls, self._n, C.byref(failed))
+        if rc:
+            _lib.check(rc, f"replayed call #{failed.value}")
+
+    def run_python(self) -> None:
+        """Reference implementation of run(): the same list issued entry by entry from Python."""
         for fn, args in self.prog:
             rc = fn(*args)
             if rc:

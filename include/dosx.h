@@ -303,6 +303,21 @@ int dosx_csr_build(const long long* edge_index, const long long* batch, int N, i
                    int32_t* graph_ptr, int32_t* node_graph, int32_t* dense_row, float* inv_deg, int32_t* n_max,
                    void* workspace, size_t ws_bytes, dosx_stream_t stream);
 
+/* Replay of a recorded launch list (the host side of train.Trainer(replay=True), see csrc/replay.cpp): `n` calls are
+ * issued in order; a call = function pointer + its integer-class arguments in order (pointers, ints, by-pointer
+ * descriptors; at most 19) + its floating-point arguments in order; `kind` names the floating-point signature
+ * class.  Besides this library's own entry points the list may hold hipEventRecord / hipStreamWaitEvent (stream
+ * fork/join).  Returns the first non-zero return code (index in *failed_index) or 0.  x86-64 System V hosts only. */
+enum { DOSX_CALL_INTS = 0, DOSX_CALL_F1 = 1, DOSX_CALL_F1D1 = 2, DOSX_CALL_F6 = 3 };
+typedef struct DosxCall {
+  void* fn;
+  int32_t kind;
+  int32_t nint;
+  int64_t iarg[19];
+  double farg[6];
+} DosxCall;
+int dosx_replay(const DosxCall* calls, int n, int* failed_index);
+
 /* misc */
 int dosx_fill(float* p, float value, int64_t n, dosx_stream_t stream);
 /* out[r] = table[idx[r]] rows (prompt_token[g.system], DOSTransformer_phonon.py:105) and its backward

@@ -39,19 +39,21 @@ def test_ctypes_structs_match_c_layout(tmp_path):
     probe.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "dosx.h"\n'
         'int main(void){\n'
-        ' printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(DosxRowMap), sizeof(DosxSeg), sizeof(DosxGemm), sizeof(DosxWgrad),'
-        ' sizeof(DosxReduceJob), sizeof(DosxAttn));\n'
-        ' printf("%zu %zu %zu %zu %zu %zu\\n", offsetof(DosxGemm, w), offsetof(DosxGemm, out_map), offsetof(DosxGemm, partials),'
-        ' offsetof(DosxWgrad, slab), offsetof(DosxAttn, x), offsetof(DosxAttn, partials_kv));\n return 0; }\n')
+        ' printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(DosxRowMap), sizeof(DosxSeg), sizeof(DosxGemm), sizeof(DosxWgrad),'
+        ' sizeof(DosxReduceJob), sizeof(DosxAttn), sizeof(DosxFfn), sizeof(DosxCall));\n'
+        ' printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", offsetof(DosxGemm, w), offsetof(DosxGemm, out_map), offsetof(DosxGemm, partials),'
+        ' offsetof(DosxWgrad, slab), offsetof(DosxAttn, x), offsetof(DosxAttn, partials_kv), offsetof(DosxFfn, out),'
+        ' offsetof(DosxCall, iarg), offsetof(DosxCall, farg));\n return 0; }\n')
     exe = tmp_path / "probe"
     subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(probe), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
-    sizes = [int(x) for x in out[:6]]
-    offs = [int(x) for x in out[6:]]
+    sizes = [int(x) for x in out[:8]]
+    offs = [int(x) for x in out[8:]]
     assert sizes == [C.sizeof(_lib.RowMap), C.sizeof(_lib.Seg), C.sizeof(_lib.Gemm), C.sizeof(_lib.Wgrad),
-                     C.sizeof(_lib.ReduceJob), C.sizeof(_lib.Attn)]
+                     C.sizeof(_lib.ReduceJob), C.sizeof(_lib.Attn), C.sizeof(_lib.Ffn), C.sizeof(_lib.Call)]
     assert offs == [_lib.Gemm.w.offset, _lib.Gemm.out_map.offset, _lib.Gemm.partials.offset, _lib.Wgrad.slab.offset,
-                    _lib.Attn.x.offset, _lib.Attn.partials_kv.offset]
+                    _lib.Attn.x.offset, _lib.Attn.partials_kv.offset, _lib.Ffn.out.offset, _lib.Call.iarg.offset,
+                    _lib.Call.farg.offset]
 
 
 def test_argument_validation_needs_no_gpu():
