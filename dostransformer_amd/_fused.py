@@ -31,21 +31,32 @@ def is_dead_param(name: str) -> bool:
     return _DEAD.search(name) is not None
 
 
+_LATE = ("GN_encoder.", "stacked_processor.", "GN_decoder.")
+
+
+def is_late_param(name: str) -> bool:
+    """Parameters of the GNN trunk: their gradients are complete only at the very end of the backward pass.  All
+    others (transformer stacks, heads, embeddings) are final once the backward reaches the GNN, so their slice of
+    the flat gradient buffer can be all-reduced while the GNN backward still runs (dist / train.Trainer)."""
+    return name.startswith(_LATE)
+
+
 class FlatParams:
     """Flat fp32 parameter + gradient storage for the live parameters of a module."""
 
     def __init__(self, module: nn.Module, device: torch.device, extra_dead=()):
-        names, params = [], []
-        for n, p in module.named_parameters():
-            if is_dead_param(n) or n in extra_dead:
-                continue
-            names.append(n)
-            params.append(p)
-        offs, tot = [], 0
-        for p in params:
+        live = [(n, p) for n, p in module.named_parameters() if not (is_dead_param(n) or n in extra_dead)]
+        # layout: [ late bucket (GNN trunk) | early bucket (everything else) ], each in module order
+        ordered = [x for x in live if is_late_param(x[0])] + [x for x in live if not is_late_param(x[0])]
+        names, params = [n for n, _ in ordered], [p for _, p in ordered]
+        offs, tot, n_late = [], 0, 0
+        for n, p in ordered:
             offs.append(tot)
             tot += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+            if is_late_param(n):
+                n_late = tot
         self.names, self.offsets, self.total = names, offs, tot
+        self.n_late = n_late          # floats: flat[:n_late] is the late bucket, flat[n_late:] the early one
         self.flat = torch.zeros(tot, device=device, dtype=torch.float32)
         self.grad = torch.zeros(tot, device=device, dtype=torch.float32)
         self.P: Dict[str, torch.Tensor] = {}

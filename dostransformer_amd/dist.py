@@ -76,3 +76,8 @@ class DataParallel:
 
     def all_reduce_grads(self, flat_grad: torch.Tensor) -> None:
         td.all_reduce(flat_grad, op=td.ReduceOp.SUM, group=self.group)
+
+    def all_reduce_grads_async(self, flat_grad: torch.Tensor):
+        """Start the sum of a (contiguous slice of the) flat gradient buffer; ordered after the work already queued on
+        the CURRENT stream.  Returns the handle; ``.wait()`` makes the then-current stream wait for the result."""
+        return td.all_reduce(flat_grad, op=td.ReduceOp.SUM, group=self.group, async_op=True)

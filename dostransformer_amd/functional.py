@@ -412,7 +412,7 @@ def dostransformer_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta):
 
 
 def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, ddos: torch.Tensor,
-                       dx_ext: Optional[torch.Tensor], sink: GradSink) -> None:
+                       dx_ext: Optional[torch.Tensor], sink: GradSink, mid_hook=None) -> None:
     """Backward; ddos [2B,S] (rows [0,B): d dos_global, [B,2B): d dos_system); dx_ext: optional
     gradient w.r.t. the returned node embeddings.  Writes every live parameter gradient into G."""
     (ctrunk, kvhat, rstd_n, c1, dec_segs, sysidx, prow, dosin, a_g, a_s, kvs, rstd_s, c2, c3, xhat_f, rstd_f, xL) = ctx
@@ -458,6 +458,11 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
     # first encoder (queries = energy embeddings broadcast over the batch)
     dX1 = encoder_bwd(P, G, "transformer", c1, dE1, dkv, sink)
     ops.reduce_rows(dX1.data_ptr(), H, G["embeddings.weight"].data_ptr(), H, S, B, B, 1, H)
+    # Every gradient of the transformer stacks, the heads and the embeddings is complete (or queued on the side
+    # stream) here; what follows only touches the GNN trunk's parameters.  mid_hook: data-parallel training reduces
+    # and all-reduces that early bucket now, underneath the GNN backward (train.Trainer).
+    if mid_hook is not None:
+        mid_hook(sink)
     # node embeddings: dense keys + pooled decoder input (+ external grad on the returned x)
     dxL = _empty(dev, N, H)
     sink.join()          # dkv (dense keys) is produced on the side stream

@@ -345,6 +345,11 @@ class GradSink:
             self.side = GradSink._side_streams[key]
         self._forked = False
 
+    @staticmethod
+    def side_stream(device):
+        """The (process-wide) side stream used by recorded programs on ``device`` (None before the first recording)."""
+        return GradSink._side_streams.get((str(device), False))
+
     def on_side(self, fn, keep=()) -> None:
         """Run ``fn`` (kernel launches) on the side stream, ordered after everything launched so far on
         the main stream.  ``keep``: tensors the side work reads that the caller is about to drop."""
@@ -383,14 +388,26 @@ class GradSink:
         self.jobs.append((src.data_ptr() + 4 * src_off, dst.data_ptr() + 4 * dst_off, int(nsplit), int(stride),
                           int(count), 1 if accumulate else 0))
 
+    def flush_on_side(self):
+        """Reduce the jobs collected so far WITHOUT joining: the reduction is queued on the side stream behind the
+        weight-gradient kernels it depends on (and behind everything the main stream has issued up to here), so the
+        main stream runs on.  Used for the early gradient bucket of data-parallel training."""
+        jobs, self.jobs = self.jobs, []
+        self.on_side(lambda: self._reduce(jobs))
+
     def flush(self):
         self.join()
-        if not self.jobs:
+        jobs, self.jobs = self.jobs, []
+        self._reduce(jobs)
+
+    def _reduce(self, jobs):
+        self_jobs = jobs
+        if not self_jobs:
             return
         # jobs that share a destination go to successive launches (later ones accumulate)
         occ = {}
         waves: List[List[tuple]] = []
-        for j in self.jobs:
+        for j in self_jobs:
             k = occ.get(j[1], 0)
             occ[j[1]] = k + 1
             if k >= len(waves):
@@ -401,7 +418,6 @@ class GradSink:
             for i, j in enumerate(wv):
                 arr[i].src, arr[i].dst, arr[i].nsplit, arr[i].stride, arr[i].count, arr[i].accumulate = j
             _call("dosx_reduce_partials", arr, len(wv), _stream())
-        self.jobs = []
 
     def release(self):
         self._keep = []

@@ -43,6 +43,7 @@ class _Slot:
         self.g = CrystalBatch(f, g.num_graphs, meta)
         self.graph_a = self.graph_b = None
         self.prog_a = self.prog_b = None
+        self.plan = []
         self.keep = None
 
     def load(self, g: CrystalBatch) -> None:
@@ -69,6 +70,10 @@ class Trainer:
         self.dist = dist
         self.graph = graph
         self.replay = replay
+        self.bucketed = dist is not None and not graph       # early-bucket overlap (eager and replay modes)
+        self._early_work = None
+        self._early_side = None
+        self._rec_parts = []
         self.step_count = 0
         self._m = self._v = None
         self._fp = None
@@ -115,9 +120,33 @@ class Trainer:
             ops.sum_to(lp, B, lp[B:])
             loss = lp[B]
         sink = ops.GradSink(dev)
-        Fn.dostransformer_bwd(fp.P, fp.G, cfg, m, st["ctx"], ddos, None, sink)
+        Fn.dostransformer_bwd(fp.P, fp.G, cfg, m, st["ctx"], ddos, None, sink, mid_hook=self._mid_hook(fp))
         sink.release()
         return loss
+
+    # ---- data parallel: early gradient bucket ------------------------------------------------------
+    def _mid_hook(self, fp):
+        """Backward reaches the GNN trunk: reduce the early bucket's slabs on the side stream and start its
+        all-reduce there, underneath the GNN backward (xGMI traffic overlaps compute; only the GNN bucket's
+        all-reduce stays exposed at the end of the step)."""
+        if self.dist is None or not self.bucketed or fp.n_late <= 0 or fp.n_late >= fp.total:
+            return None
+
+        def hook(sink):
+            sink.flush_on_side()
+            rec = ops.RECORDER.active
+            if rec:                                   # the collective is not a libdosx call: split the recording
+                self._rec_parts.append(ops.RECORDER.end())
+            self._start_early(fp, sink.side)
+            if rec:
+                ops.RECORDER.begin()
+        return hook
+
+    def _start_early(self, fp, side) -> None:
+        stream = side if side is not None else torch.cuda.current_stream()
+        with torch.cuda.stream(stream):
+            self._early_work = self.dist.all_reduce_grads_async(fp.grad[fp.n_late:])
+        self._early_side = side
 
     def _n_global(self, B: int, n_global: Optional[int]) -> int:
         if n_global is not None:
@@ -178,17 +207,26 @@ class Trainer:
         split = self.dist is not None and self.kind == "phonon"
         try:
             with torch.no_grad():
+                # the plan of a replayed step: recorded programs separated by the collectives (which are not
+                # libdosx calls): [fwd] (sse) [bwd up to the GNN] (early bucket all-reduce) [GNN bwd]
+                plan = []
+                self._rec_parts = []
                 ops.RECORDER.begin()
                 st = self._part_a(fp, g, m)
                 if split:
-                    slot.prog_a = ops.RECORDER.end()
+                    plan.append(("prog", ops.RECORDER.end()))
+                    plan.append(("sse", None))
                     self.dist.all_reduce_sse(st["sse"])
                     ops.RECORDER.begin()
                 loss = self._part_b(fp, m, st, ng)
-                if split:
-                    slot.prog_b = ops.RECORDER.end()
-                else:
-                    slot.prog_a = ops.RECORDER.end()
+                last = ops.RECORDER.end()
+                for part in self._rec_parts:          # (_mid_hook closed these while recording)
+                    plan.append(("prog", part))
+                    plan.append(("early", None))
+                plan.append(("prog", last))
+                self._rec_parts = []
+                slot.plan = plan
+                slot.prog_a = plan[0][1]
         finally:
             if ops.RECORDER.active:
                 ops.RECORDER.end()
@@ -221,10 +259,13 @@ class Trainer:
             self._capture(slot, fp, ng)
         slot.load(g)
         if self.replay:
-            slot.prog_a.run()
-            if slot.prog_b is not None:
-                self.dist.all_reduce_sse(slot.sse)
-                slot.prog_b.run()
+            for kind, prog in slot.plan:
+                if kind == "prog":
+                    prog.run()
+                elif kind == "sse":
+                    self.dist.all_reduce_sse(slot.sse)
+                else:
+                    self._start_early(fp, ops.GradSink.side_stream(fp.flat.device))
         else:
             slot.graph_a.replay()
             if slot.graph_b is not None:
@@ -238,7 +279,12 @@ class Trainer:
         fp = self._fp if self._fp is not None else self.model.flat_params()
         m, v = self._state(fp)
         if self.dist is not None:
-            self.dist.all_reduce_grads(fp.grad)
+            if self._early_work is not None:          # early bucket already in flight: only the GNN bucket is exposed
+                self.dist.all_reduce_grads(fp.grad[:fp.n_late])
+                self._early_work.wait()
+                self._early_work = None
+            else:
+                self.dist.all_reduce_grads(fp.grad)
         self.step_count += 1
         ops.adamw(fp.flat, fp.grad, m, v, fp.total, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
                   self.step_count, 1.0)

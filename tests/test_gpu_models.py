@@ -408,3 +408,43 @@ def test_foreign_device_batch_uses_device_csr():
     assert foreign.meta is not None and foreign.meta.src.is_cuda and foreign.meta.edge_perm is not None
     for u, v in zip(a, b):
         assert maxabs(u.cpu(), v.cpu()) < 2e-6
+
+
+@pytest.mark.parametrize("mode", ["eager", "replay"])
+def test_data_parallel_buckets_match_single_process(mode):
+    """World-size-1 RCCL group: the bucketed data-parallel step (early bucket all-reduced under the GNN backward,
+    GNN bucket at the end) must leave exactly the parameters of the plain step."""
+    import os
+    import torch.distributed as td
+    from dostransformer_amd import synth
+    from dostransformer_amd.batch import bucket_sizes, pad_batch
+    from dostransformer_amd.dist import DataParallel
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    from dostransformer_amd.train import Trainer
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29543")
+    created = not td.is_initialized()
+    if created:
+        td.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        gs = []
+        for k in range(2):
+            g = synth.phonon_batch(6, seed=20 + k, dtype=torch.float32)
+            gs.append(pad_batch(g, *bucket_sizes(g.meta.num_nodes, g.meta.num_edges)).to(DEV))
+        out = []
+        for dist in (None, DataParallel()):
+            torch.manual_seed(0)
+            model = DOSTransformer_phonon(3, 1, 118, 4, 32, DEV, 0.0).to(DEV)
+            tr = Trainer(model, lr=1e-3, dist=dist, replay=(mode == "replay"))
+            for i in range(4):
+                tr.step(gs[i % 2], 6)
+            torch.cuda.synchronize()
+            out.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+            if dist is not None:
+                fp = model.flat_params()
+                assert 0 < fp.n_late < fp.total and tr._early_work is None
+        for k in out[0]:
+            assert torch.equal(out[0][k], out[1][k]), k
+    finally:
+        if created:
+            td.destroy_process_group()

@@ -122,3 +122,19 @@ def test_drop_in_aliases():
     assert TransformerEncoder.__module__.startswith("dostransformer_amd")
     for k in ("layers", "embedder_phDOS", "embedder_eDOS"):
         sys.modules.pop(k, None)
+
+
+def test_flat_params_bucket_layout():
+    """[late = GNN trunk | early = the rest], both aligned, every live parameter exactly once."""
+    import torch
+    from dostransformer_amd._fused import FlatParams, is_dead_param, is_late_param
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    model = DOSTransformer_phonon(3, 1, 118, 4, 16, "cpu", 0.0)
+    fp = FlatParams(model, torch.device("cpu"))
+    live = [n for n, _ in model.named_parameters() if not is_dead_param(n)]
+    assert sorted(fp.names) == sorted(live)
+    flags = [is_late_param(n) for n in fp.names]
+    assert flags == sorted(flags, reverse=True) and any(flags) and not all(flags)      # late block first
+    for n, o in zip(fp.names, fp.offsets):
+        assert (o < fp.n_late) == is_late_param(n) and o % 64 == 0
+    assert fp.n_late % 64 == 0 and 0 < fp.n_late < fp.total
