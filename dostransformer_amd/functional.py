@@ -461,11 +461,11 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
     # Every gradient of the transformer stacks, the heads and the embeddings is complete (or queued on the side
     # stream) here; what follows only touches the GNN trunk's parameters.  mid_hook: data-parallel training reduces
     # and all-reduces that early bucket now, underneath the GNN backward (train.Trainer).
-    if mid_hook is not None:
-        mid_hook(sink)
+    sink.join()          # dkv (dense keys) is produced on the side stream
+    if mid_hook is not None:          # (after the join: the early bucket's reduction must not sit between the main
+        mid_hook(sink)                #  stream and the dk/dv kernels it is waiting for)
     # node embeddings: dense keys + pooled decoder input (+ external grad on the returned x)
     dxL = _empty(dev, N, H)
-    sink.join()          # dkv (dense keys) is produced on the side stream
     ops.dense_normalize_bwd(dkv, kvhat, rstd_n, m.dense_row, dxL, N, H, False)
     du_seg = decoder_bwd(P, G, cfg, m, dec_segs, dgraph, dxL, sink)
     if dx_ext is not None:

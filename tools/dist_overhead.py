@@ -24,8 +24,9 @@ class Neither(DataParallel):
     def all_reduce_grads(self, flat_grad): pass
     def all_reduce_sse(self, sse): pass
 
-def run(name, dp):
+def run(name, dp, bucketed=True):
     tr = Trainer(model, replay=True, dist=dp)
+    tr.bucketed = tr.bucketed and bucketed
     for i in range(16): tr.step(gs[i % 8], 64)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     n = 200
@@ -37,3 +38,6 @@ run("dist: both all-reduces", DataParallel())
 run("dist: no grad all-reduce", NoGrad())
 run("dist: no SSE all-reduce", NoSse())
 run("dist: split programs only", Neither())
+run("dist: one bucket (no overlap)", DataParallel(), bucketed=False)
+run("dist: two buckets", DataParallel())
+run("no dist", None)
