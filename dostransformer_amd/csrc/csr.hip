@@ -150,3 +150,88 @@ extern "C" int dosx_csr_build(const long long* edge_index, const long long* batc
   DOSX_LAUNCH_CHECK();
   return 0;
 }
+
+// =============================================================================================================
+// Collate on the device ("cache per-crystal CSR, collate by offset-add on GPU").
+// The whole dataset is resident: per crystal its edges are already sorted by destination and its local CSR is cached
+// (loader.DeviceDataset).  A batch = the selected crystals' segments copied next to each other with the node / edge
+// offsets of the batch added: because node ids of crystal b are all smaller than those of crystal b+1, the
+// concatenation IS the batch's destination-sorted edge list, its CSR and its source-sorted inverse index.
+// =============================================================================================================
+namespace {
+
+__device__ __forceinline__ int seg_of(const int* __restrict__ ptr, int B, int i) {     // largest b with ptr[b] <= i
+  int lo = 0, hi = B;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (ptr[mid] <= i) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ void collate_nodes_kernel(const int* __restrict__ sel, const int* __restrict__ node_ptr_all,
+                                     const int* __restrict__ out_node_ptr, const int* __restrict__ out_edge_ptr, int B, int N, int E,
+                                     const int* __restrict__ rowptr_dst_all, const int* __restrict__ rowptr_src_all,
+                                     const float* __restrict__ inv_deg_all, long long* __restrict__ batch,
+                                     int* __restrict__ node_graph, int* __restrict__ dense_row, float* __restrict__ inv_deg,
+                                     int* __restrict__ rowptr_dst, int* __restrict__ rowptr_src, int* __restrict__ node_row) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n > N) return;
+  if (n == N) {
+    rowptr_dst[N] = E;
+    rowptr_src[N] = E;
+    return;
+  }
+  const int b = seg_of(out_node_ptr, B, n), c = sel[b];
+  const int l = n - out_node_ptr[b], s = node_ptr_all[c] + l;
+  batch[n] = b;
+  node_graph[n] = b;
+  dense_row[n] = l * B + b;
+  inv_deg[n] = inv_deg_all[s];
+  rowptr_dst[n] = rowptr_dst_all[s + c] + out_edge_ptr[b];       // the cached row pointers hold n_c + 1 entries per crystal
+  rowptr_src[n] = rowptr_src_all[s + c] + out_edge_ptr[b];
+  node_row[n] = s;
+}
+
+__global__ void collate_edges_kernel(const int* __restrict__ sel, const int* __restrict__ edge_ptr_all,
+                                     const int* __restrict__ out_node_ptr, const int* __restrict__ out_edge_ptr, int B, int E,
+                                     const int* __restrict__ src_all, const int* __restrict__ dst_all,
+                                     const int* __restrict__ perm_src_all, int* __restrict__ src, int* __restrict__ dst,
+                                     int* __restrict__ perm_src, long long* __restrict__ edge_index, int* __restrict__ edge_row) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int b = seg_of(out_edge_ptr, B, e), c = sel[b];
+  const int l = e - out_edge_ptr[b], s = edge_ptr_all[c] + l;
+  const int no = out_node_ptr[b];
+  const int sv = src_all[s] + no, dv = dst_all[s] + no;
+  src[e] = sv;
+  dst[e] = dv;
+  perm_src[e] = perm_src_all[s] + out_edge_ptr[b];
+  edge_index[e] = sv;
+  edge_index[(size_t)E + e] = dv;
+  edge_row[e] = s;
+}
+
+}  // namespace
+
+extern "C" int dosx_collate(const int* sel, const int* node_ptr_all, const int* edge_ptr_all, const int* out_node_ptr,
+                            const int* out_edge_ptr, int B, int N, int E, const int* src_all, const int* dst_all,
+                            const int* perm_src_all, const int* rowptr_dst_all, const int* rowptr_src_all,
+                            const float* inv_deg_all, long long* batch, long long* edge_index, int* src, int* dst, int* perm_src,
+                            int* rowptr_dst, int* rowptr_src, int* node_graph, int* dense_row, float* inv_deg, int* node_row,
+                            int* edge_row, dosx_stream_t stream) {
+  DOSX_CHECK_ARG(B > 0 && N >= 0 && E >= 0, "dosx_collate: bad sizes B=%d N=%d E=%d", B, N, E);
+  DOSX_CHECK_ARG(sel && node_ptr_all && edge_ptr_all && out_node_ptr && out_edge_ptr, "dosx_collate: null index input");
+  DOSX_CHECK_ARG(batch && src && dst && perm_src && rowptr_dst && rowptr_src && node_graph && dense_row && inv_deg && node_row &&
+                     (E == 0 || (edge_index && edge_row)),
+                 "dosx_collate: null output");
+  hipStream_t s = to_stream(stream);
+  hipLaunchKernelGGL(collate_nodes_kernel, dim3(ceil_div(N + 1, 256)), dim3(256), 0, s, sel, node_ptr_all, out_node_ptr, out_edge_ptr,
+                     B, N, E, rowptr_dst_all, rowptr_src_all, inv_deg_all, batch, node_graph, dense_row, inv_deg, rowptr_dst,
+                     rowptr_src, node_row);
+  if (E > 0)
+    hipLaunchKernelGGL(collate_edges_kernel, dim3(ceil_div(E, 256)), dim3(256), 0, s, sel, edge_ptr_all, out_node_ptr, out_edge_ptr, B,
+                       E, src_all, dst_all, perm_src_all, src, dst, perm_src, edge_index, edge_row);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}

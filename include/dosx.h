@@ -303,6 +303,19 @@ int dosx_csr_build(const long long* edge_index, const long long* batch, int N, i
                    int32_t* graph_ptr, int32_t* node_graph, int32_t* dense_row, float* inv_deg, int32_t* n_max,
                    void* workspace, size_t ws_bytes, dosx_stream_t stream);
 
+/* Collate on the device: the dataset is resident with per-crystal destination-sorted edges and cached
+ * local CSR (`*_all` arrays, crystal c owns nodes [node_ptr_all[c], node_ptr_all[c+1]) and edges likewise; its cached
+ * row pointers have n_c + 1 entries starting at node_ptr_all[c] + c).  `sel [B]` picks the crystals of the batch,
+ * `out_node_ptr / out_edge_ptr [B+1]` are the batch's prefix sums (N, E = their last entries).  Outputs: everything
+ * dosx_csr_build would give for the concatenated batch (already destination-sorted), plus `batch` / `edge_index` in
+ * the reference's int64 schema and `node_row [N]`, `edge_row [E]` = source rows for gathering the feature tensors. */
+int dosx_collate(const int32_t* sel, const int32_t* node_ptr_all, const int32_t* edge_ptr_all, const int32_t* out_node_ptr,
+                 const int32_t* out_edge_ptr, int B, int N, int E, const int32_t* src_all, const int32_t* dst_all,
+                 const int32_t* perm_src_all, const int32_t* rowptr_dst_all, const int32_t* rowptr_src_all,
+                 const float* inv_deg_all, long long* batch, long long* edge_index, int32_t* src, int32_t* dst,
+                 int32_t* perm_src, int32_t* rowptr_dst, int32_t* rowptr_src, int32_t* node_graph, int32_t* dense_row,
+                 float* inv_deg, int32_t* node_row, int32_t* edge_row, dosx_stream_t stream);
+
 /* Replay of a recorded launch list (the host side of train.Trainer(replay=True), see csrc/replay.cpp): `n` calls are
  * issued in order; a call = function pointer + its integer-class arguments in order (pointers, ints, by-pointer
  * descriptors; at most 19) + its floating-point arguments in order; `kind` names the floating-point signature

@@ -448,3 +448,27 @@ def test_data_parallel_buckets_match_single_process(mode):
     finally:
         if created:
             td.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["phonon", "edos"])
+def test_device_collate_matches_host(kind):
+    """loader.DeviceDataset.collate (dosx_collate + row gathers, all on the GPU) == batch.collate on the host."""
+    from dostransformer_amd import synth
+    from dostransformer_amd.batch import collate
+    from dostransformer_amd.loader import DeviceDataset
+    cs = synth.phonon_crystals(12, seed=31, dtype=torch.float32) if kind == "phonon" else synth.edos_crystals(12, seed=32, dtype=torch.float32)
+    ds = DeviceDataset(cs, DEV)
+    for sel in ([3, 0, 7], [11], list(range(12)), [5, 5, 2]):
+        d = ds.collate(sel)
+        h = collate([cs[i] for i in sel])
+        torch.cuda.synchronize()
+        for k in h.keys():
+            if isinstance(h[k], torch.Tensor):
+                assert torch.equal(d[k].cpu(), h[k]), k
+            else:
+                assert d[k] == h[k], k
+        assert (d.meta.num_nodes, d.meta.num_edges, d.meta.num_graphs, d.meta.n_max) == \
+               (h.meta.num_nodes, h.meta.num_edges, h.meta.num_graphs, h.meta.n_max)
+        for k in ("src", "dst", "rowptr_dst", "perm_src", "rowptr_src", "graph_ptr", "node_graph", "dense_row", "inv_deg"):
+            assert torch.equal(getattr(d.meta, k).cpu(), getattr(h.meta, k)), k
+        assert d.meta.edge_perm is None

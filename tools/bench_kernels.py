@@ -132,6 +132,33 @@ def csr_case(name, B, kind="phonon"):
           f"no host round trip)")
 
 
+def collate_case(name, B, kind="phonon"):
+    import time
+    from dostransformer_amd import synth
+    from dostransformer_amd.batch import collate
+    from dostransformer_amd.loader import DeviceDataset
+    cs = synth.phonon_crystals(4 * B, seed=0, dtype=torch.float32) if kind == "phonon" else synth.edos_crystals(4 * B, seed=0, dtype=torch.float32)
+    ds = DeviceDataset(cs, DEV)
+    sel = list(range(B, 2 * B))
+    for _ in range(3):
+        ds.collate(sel)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 50
+    for _ in range(n):
+        ds.collate(sel)
+    t_host = (time.perf_counter() - t0) / n
+    torch.cuda.synchronize()
+    t_dev = (time.perf_counter() - t0) / n
+    t0 = time.perf_counter()
+    for _ in range(10):
+        collate([cs[i] for i in sel]).to(DEV)
+    torch.cuda.synchronize()
+    t_ref = (time.perf_counter() - t0) / 10
+    print(f"coll  {name:30s} B={B}: device collate {t_dev * 1e6:7.1f} us per batch (host part {t_host * 1e6:6.1f} us) | host collate + "
+          f"H2D {t_ref * 1e6:8.1f} us")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="all")
@@ -143,6 +170,9 @@ def main():
         ffn_case("FFN fwd 2B", R2, H)
         ffn_case("FFN fwd B", R1, H)
         ffn_case("FFN fwd roofline scale", 262144, H)
+    if w in ("all", "collate"):
+        collate_case("phonon 64 crystals", 64)
+        collate_case("eDOS 64 crystals", 64, "edos")
     if w in ("all", "csr"):
         csr_case("cfg2 batch", 64)
         csr_case("cfg3 batch (eDOS)", 64, "edos")
