@@ -476,7 +476,7 @@ void gemm_kernel(const GemmLaunch L) {
       auto issue = [&](ARaw(&ar)[RT], float4(&wr)[NW4], int k0) {
         const int k0u = __builtin_amdgcn_readfirstlane(k0);
         const int sgi = k0u < e0 ? 0 : (k0u < e1 ? 1 : 2);                          // wave-uniform
-        const int soffA = (k0u - (sgi == 0 ? 0 : (sgi == 1 ? e0 : e1))) * 4;
+        const int soffA = __builtin_amdgcn_readfirstlane((k0u - (sgi == 0 ? 0 : (sgi == 1 ? e0 : e1))) * 4);
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
           v4i32 v;
@@ -485,7 +485,7 @@ void gemm_kernel(const GemmLaunch L) {
           else v = __builtin_amdgcn_raw_buffer_load_b128(rA2, voffA[r][2], soffA, 0);
           ar[r].v = __builtin_bit_cast(float4, v);
         }
-        const int soffW = (WL == 0) ? k0u * 4 : k0u * g.ldw * 4;
+        const int soffW = __builtin_amdgcn_readfirstlane((WL == 0) ? k0u * 4 : k0u * g.ldw * 4);   // (keeps it in an SGPR: no waterfall loop)
 #pragma unroll
         for (int i = 0; i < NW4; ++i)
           wr[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rW, voffW[i], soffW, 0));
