@@ -32,9 +32,11 @@ _META_TENSORS = ("src", "dst", "rowptr_dst", "perm_src", "rowptr_src", "graph_pt
 class _Slot:
     """Static buffers + captured graphs of one shape bucket."""
 
-    def __init__(self, g: CrystalBatch, kind: str):
+    def __init__(self, g: CrystalBatch, kind: str, targets: bool = True):
         m = g.meta
-        self.fields = ["x", "system"] + (["edge_vec", "phdos"] if kind == "phonon" else ["edge_attr", "glob", "y_ft"])
+        self.fields = ["x", "system"] + (["edge_vec"] if kind == "phonon" else ["edge_attr", "glob"])
+        if targets:
+            self.fields.append("phdos" if kind == "phonon" else "y_ft")
         f = {k: g[k].clone() for k in self.fields}
         f["system"] = f["system"].to(torch.int32)                   # what the kernels index with
         f["edge_index"], f["batch"] = g.edge_index, g.batch         # never read by the kernels

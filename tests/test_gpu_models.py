@@ -215,7 +215,9 @@ def test_g8_graphnetworks():
 
 
 @pytest.mark.parametrize("kind,H,T,B", [("phonon", 64, 1, 8), ("phonon", 128, 2, 16), ("edos", 64, 2, 6),
-                                         ("edos", 256, 2, 4)])
+                                         ("edos", 256, 2, 4),
+                                         # BASELINE.json configs[1], [2] and the per-GPU shard of [4] at FULL size
+                                         ("phonon", 128, 2, 64), ("edos", 256, 2, 64), ("edos", 256, 4, 32)])
 def test_against_oracle_live(kind, H, T, B):
     """BASELINE configs at oracle-feasible batch sizes: outputs, loss, every gradient and one AdamW
     step against the oracle (fp64 for phonon like main_phDOS.py:15-16, fp32 for eDOS)."""
@@ -472,3 +474,47 @@ def test_device_collate_matches_host(kind):
         for k in ("src", "dst", "rowptr_dst", "perm_src", "rowptr_src", "graph_ptr", "node_graph", "dense_row", "inv_deg"):
             assert torch.equal(getattr(d.meta, k).cpu(), getattr(h.meta, k)), k
         assert d.meta.edge_perm is None
+
+
+@pytest.mark.parametrize("kind", ["phonon", "edos"])
+def test_predictor_replay_is_bitwise_eager(kind):
+    """predict.Predictor (recorded forward program per shape bucket, ghost padded) == model(batch) under no_grad,
+    for single crystals and batches, on first use of a bucket (record) and on revisits (replay)."""
+    from dostransformer_amd import synth
+    from dostransformer_amd.batch import collate
+    from dostransformer_amd.predict import Predictor
+    torch.manual_seed(0)
+    if kind == "phonon":
+        from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+        model = DOSTransformer_phonon(3, 2, 118, 4, 64, DEV, 0.0).to(DEV)
+        cs = synth.phonon_crystals(10, seed=61, dtype=torch.float32)
+    else:
+        from dostransformer_amd.embedder_eDOS.DOSTransformer import DOSTransformer
+        model = DOSTransformer(3, 1, 200, 41, 2, 64, DEV, 0.0).to(DEV)
+        cs = synth.edos_crystals(10, seed=62, dtype=torch.float32)
+    model.eval()
+    pred = Predictor(model)
+    sels = [[0], [1], [0], [2, 3, 4], [9], [2, 3, 4], [1], list(range(10)), [4, 3, 2]]
+    for sel in sels:
+        g = collate([cs[i] for i in sel]).to(DEV)
+        with torch.no_grad():
+            ref = [t.clone() for t in model(g)]
+        out = pred(g)
+        torch.cuda.synchronize()
+        for a, b in zip(ref, out):
+            assert a.shape == b.shape and torch.equal(a, b), sel
+    assert 1 <= len(pred._slots) < len(sels)          # buckets were revisited, i.e. replays happened
+
+
+def test_eval_loop_accepts_predictor():
+    from dostransformer_amd import evaluate, synth
+    from dostransformer_amd.batch import collate
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    from dostransformer_amd.predict import Predictor
+    torch.manual_seed(0)
+    model = DOSTransformer_phonon(3, 2, 118, 4, 64, DEV, 0.0).to(DEV)
+    cs = synth.phonon_crystals(12, seed=63, dtype=torch.float32)
+    loader = [collate(cs[i:i + 4]).to(DEV) for i in (0, 4, 8, 0)]
+    a = evaluate.test_phonon(model, loader)
+    b = evaluate.test_phonon(Predictor(model), loader)
+    assert a == b
