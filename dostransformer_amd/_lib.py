@@ -135,6 +135,8 @@ _SIGS = {
     "dosx_csr_workspace_bytes": [_I, C.POINTER(C.c_size_t)],
     "dosx_csr_build": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P],
     "dosx_collate": [_P] * 5 + [_I] * 3 + [_P] * 18 + [_P],
+    "dosx_neighbor_count": [_P, _P, _P, _P, _I, _L, _D, _I, _I, _P, _P],
+    "dosx_neighbor_fill": [_P, _P, _P, _P, _I, _L, _D, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "dosx_replay": [C.POINTER(Call), _I, C.POINTER(C.c_int)],
     "dosx_fill": [_P, _F, _L, _P],
     "dosx_embed_rows": [_P, _P, _P, _I, _I, _P],

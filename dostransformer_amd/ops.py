@@ -566,3 +566,39 @@ def csr_build(edge_index: torch.Tensor, batch: torch.Tensor, num_graphs: int, wa
           out["graph_ptr"].data_ptr(), out["node_graph"].data_ptr(), out["dense_row"].data_ptr(), out["inv_deg"].data_ptr(),
           out["n_max"].data_ptr(), ws.data_ptr(), C.c_size_t(ws.numel()), _stream())
     return out
+
+
+def neighbor_list(pos: torch.Tensor, cell: torch.Tensor, atom_ptr: torch.Tensor, cutoff: float,
+                  self_interaction: bool = True, pbc=(True, True, True)):
+    """Periodic neighbour list of C crystals in one go (include/dosx.h: dosx_neighbor_count / _fill; the job ASE's
+    ``neighbor_list("ijS", ...)`` does in `utils.py:267`).  ``pos [N,3]`` fp64, ``cell [C,3,3]`` fp64 (rows = lattice
+    vectors), ``atom_ptr [C+1]`` int32, all on the GPU.  Returns a dict of device tensors: ``crystal``, ``src``,
+    ``dst`` (crystal-local atom indices), ``shift [E,3]`` int32, ``edge_vec [E,3]`` fp64, ``edge_ptr [C+1]`` int64."""
+    assert pos.is_cuda and pos.dtype == torch.float64 and cell.dtype == torch.float64 and atom_ptr.dtype == torch.int32
+    pos, cell, atom_ptr = pos.contiguous(), cell.contiguous(), atom_ptr.contiguous()
+    dev, Cn = pos.device, int(cell.shape[0])
+    assert cell.shape == (Cn, 3, 3) and atom_ptr.shape == (Cn + 1,)
+    n = (atom_ptr[1:] - atom_ptr[:-1]).to(torch.int64)
+    pair_ptr = torch.zeros(Cn + 1, dtype=torch.int64, device=dev)
+    pair_ptr[1:] = torch.cumsum(n * n, 0)
+    n_pairs = int(pair_ptr[-1])                      # featurisation runs once per dataset: a host read is fine here
+    mask = sum(1 << k for k in range(3) if pbc[k])
+    count = torch.empty(max(n_pairs, 1), dtype=torch.int32, device=dev)
+    _call("dosx_neighbor_count", pos.data_ptr(), cell.data_ptr(), atom_ptr.data_ptr(), pair_ptr.data_ptr(), Cn,
+          n_pairs, C.c_double(cutoff), int(self_interaction), mask, count.data_ptr(), _stream())
+    incl = torch.cumsum(count[:n_pairs].to(torch.int64), 0)
+    off = incl - count[:n_pairs]
+    E = int(incl[-1]) if n_pairs else 0
+    i32 = lambda *s: torch.empty(*s, dtype=torch.int32, device=dev)
+    out = {"crystal": i32(E), "src": i32(E), "dst": i32(E), "shift": i32(E, 3),
+           "edge_vec": torch.empty(E, 3, dtype=torch.float64, device=dev)}
+    if E:
+        _call("dosx_neighbor_fill", pos.data_ptr(), cell.data_ptr(), atom_ptr.data_ptr(), pair_ptr.data_ptr(), Cn,
+              n_pairs, C.c_double(cutoff), int(self_interaction), mask, off.data_ptr(), out["crystal"].data_ptr(),
+              out["src"].data_ptr(), out["dst"].data_ptr(), out["shift"].data_ptr(), out["edge_vec"].data_ptr(), _stream())
+    edge_ptr = torch.zeros(Cn + 1, dtype=torch.int64, device=dev)
+    if n_pairs:
+        ends = pair_ptr[1:] - 1                      # last pair of every crystal (crystals have >= 1 atom)
+        edge_ptr[1:] = incl[ends]
+    out["edge_ptr"] = edge_ptr
+    return out

@@ -316,6 +316,22 @@ int dosx_collate(const int32_t* sel, const int32_t* node_ptr_all, const int32_t*
                  int32_t* perm_src, int32_t* rowptr_dst, int32_t* rowptr_src, int32_t* node_graph, int32_t* dense_row,
                  float* inv_deg, int32_t* node_row, int32_t* edge_row, dosx_stream_t stream);
 
+/* Periodic neighbour list of C crystals at once (replaces ASE's `neighbor_list("ijS", a, cutoff=r_max,
+ * self_interaction=True)` + the edge_vec arithmetic of `utils.py:267-273` in build_data).  `pos [N][3]` Cartesian,
+ * `cell [C][3][3]` lattice vectors as rows, crystal c owns atoms [atom_ptr[c], atom_ptr[c+1]) and the ordered atom
+ * pairs [pair_ptr[c], pair_ptr[c+1]) (pair_ptr = prefix sums of n_c^2, n_pairs = its last entry).  An edge is a triple
+ * (i, j, S) with |pos[j]-pos[i]+S·cell| < cutoff; (i, i, 0) only if `self_interaction`; bit k of `pbc_mask` = axis k is
+ * periodic.  Two passes: `_count` writes the number of edges of every pair, the caller turns it into exclusive offsets
+ * `pair_off` (E = their total), `_fill` writes per edge: crystal, src = i and dst = j (crystal-local), shift [E][3],
+ * edge_vec [E][3] = pos[dst]-pos[src]+shift·cell.  Order: crystal, i, j, shift (lexicographic) — deterministic. */
+int dosx_neighbor_count(const double* pos, const double* cell, const int32_t* atom_ptr, const long long* pair_ptr, int C,
+                        long long n_pairs, double cutoff, int self_interaction, int pbc_mask, int32_t* pair_count,
+                        dosx_stream_t stream);
+int dosx_neighbor_fill(const double* pos, const double* cell, const int32_t* atom_ptr, const long long* pair_ptr, int C,
+                       long long n_pairs, double cutoff, int self_interaction, int pbc_mask, const long long* pair_off,
+                       int32_t* crystal, int32_t* src, int32_t* dst, int32_t* shift, double* edge_vec,
+                       dosx_stream_t stream);
+
 /* Replay of a recorded launch list (the host side of train.Trainer(replay=True), see csrc/replay.cpp): `n` calls are
  * issued in order; a call = function pointer + its integer-class arguments in order (pointers, ints, by-pointer
  * descriptors; at most 19) + its floating-point arguments in order; `kind` names the floating-point signature

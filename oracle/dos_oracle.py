@@ -369,3 +369,38 @@ def eval_edos(p: Params, loader, n_layers: int, n_t: int):
             ys.append(y)
             embs.append(scatter_sum(x_nodes, g.batch, len(g.mp_id)))
     return tuple(a / len(loader) for a in acc), (ids, torch.cat(preds), torch.cat(ys), torch.cat(embs))
+
+
+# ---------------------------------------------------------------------------------------------------
+# §8f-3 phonon featurisation: periodic neighbour list (`utils.py:267` calls ASE's neighbor_list("ijS", a, cutoff,
+# self_interaction=True); ASE is not in the reference tree and has no pinned version -> PARITY UNPINNED for this
+# function: it restates ASE's documented contract — all (i, j, S) with |pos[j]-pos[i]+S@cell| < cutoff, the (i,i,0)
+# pair only with self_interaction — by brute force, and is pinned only by the crystallographic known answers in
+# tests/test_oracle_golden.py (coordination shells of sc / fcc / bcc / hcp lattices).
+def neighbor_list_bruteforce(pos, cell, cutoff, self_interaction=True):
+    """numpy, one crystal.  Returns (i, j, S [E,3] int, D [E,3]) sorted by (i, j, S); D is summed in the order of
+    `utils.py:271-273`: (pos[j]-pos[i]) + ((S0*a0 + S1*a1) + S2*a2)."""
+    import numpy as np
+    pos = np.asarray(pos, np.float64).reshape(-1, 3)
+    cell = np.asarray(cell, np.float64).reshape(3, 3)
+    n = pos.shape[0]
+    inv = np.linalg.inv(cell)
+    frac = pos @ inv
+    spread = np.ceil(np.abs(frac[:, None, :] - frac[None, :, :]).max(axis=(0, 1))).astype(int) if n else np.zeros(3, int)
+    reach = np.ceil(cutoff * np.linalg.norm(inv, axis=0)).astype(int) + spread + 1     # generous, not minimal
+    ax = [np.arange(-r, r + 1) for r in reach]
+    S = np.stack(np.meshgrid(*ax, indexing="ij"), -1).reshape(-1, 3)                   # lexicographic
+    sh = (S[:, 0:1] * cell[0][None, :] + S[:, 1:2] * cell[1][None, :]) + S[:, 2:3] * cell[2][None, :]
+    ii, jj, ss, dd = [], [], [], []
+    for i in range(n):
+        for j in range(n):
+            d = (pos[j] - pos[i])[None, :] + sh
+            r2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+            keep = r2 < cutoff * cutoff
+            if i == j and not self_interaction:
+                keep &= ~((S == 0).all(axis=1))
+            k = np.nonzero(keep)[0]
+            ii.append(np.full(k.shape, i)); jj.append(np.full(k.shape, j)); ss.append(S[k]); dd.append(d[k])
+    if not ii:
+        return np.zeros(0, int), np.zeros(0, int), np.zeros((0, 3), int), np.zeros((0, 3))
+    return np.concatenate(ii), np.concatenate(jj), np.concatenate(ss), np.concatenate(dd)

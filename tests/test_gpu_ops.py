@@ -2,6 +2,7 @@
 torch float64 reference of the same op, on seeded inputs.  Needs a real MI355X."""
 import math
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -593,3 +594,78 @@ def test_ffn_fused_forward(M, H):
     href = torch.relu(ln @ w1.double().T + b1.double())
     assert err(h, href) < TOL
     assert err(out, xd + href @ w2.double().T + b2.double()) < TOL
+
+
+# ---- §8f-3 periodic neighbour list (dosx_neighbor_count / _fill) --------------------------------------------------
+def _random_crystals(seed, sizes):
+    rng = np.random.default_rng(seed)
+    pos, cells = [], []
+    for n in sizes:
+        cell = np.diag(rng.uniform(2.5, 6.0, 3)) + rng.uniform(-1.2, 1.2, (3, 3))       # triclinic, well conditioned
+        frac = rng.uniform(-1.5, 2.5, (n, 3))                                           # NOT wrapped into the cell
+        pos.append(frac @ cell)
+        cells.append(cell)
+    return pos, cells
+
+
+@pytest.mark.parametrize("cutoff,si", [(3.0, True), (5.0, True), (4.0, False)])
+def test_neighbor_list_matches_oracle(cutoff, si):
+    """Same edges, same order (crystal, i, j, shift), bit-identical edge_vec as the brute-force restatement."""
+    from oracle.dos_oracle import neighbor_list_bruteforce
+    sizes = [1, 2, 12, 5, 30, 1, 7]
+    pos, cells = _random_crystals(7, sizes)
+    ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    out = ops().neighbor_list(torch.from_numpy(np.concatenate(pos)).to(DEV), torch.from_numpy(np.stack(cells)).to(DEV),
+                            torch.from_numpy(ptr).to(DEV), cutoff, self_interaction=si)
+    eptr = out["edge_ptr"].cpu().numpy()
+    assert eptr[-1] == out["src"].numel() > 0
+    for c, (p, cell) in enumerate(zip(pos, cells)):
+        i, j, S, D = neighbor_list_bruteforce(p, cell, cutoff, si)
+        a, b = eptr[c], eptr[c + 1]
+        assert b - a == len(i), c
+        assert (out["crystal"][a:b].cpu().numpy() == c).all()
+        assert (out["src"][a:b].cpu().numpy() == i).all() and (out["dst"][a:b].cpu().numpy() == j).all()
+        assert (out["shift"][a:b].cpu().numpy() == S).all()
+        assert np.array_equal(out["edge_vec"][a:b].cpu().numpy(), D)
+
+
+def test_neighbor_list_known_answers_and_slab():
+    """fcc coordination shells (12, 6, 24) straight from the kernel; a non-periodic axis only keeps shift 0 there."""
+    fcc = np.array([[0, 0, 0], [0, .5, .5], [.5, 0, .5], [.5, .5, 0]], float)
+    cell = np.eye(3)[None]
+    ptr = torch.tensor([0, 4], dtype=torch.int32, device=DEV)
+    for rc, expect in [(0.71, 12), (1.01, 18), (1.23, 42)]:
+        out = ops().neighbor_list(torch.from_numpy(fcc).to(DEV), torch.from_numpy(cell).to(DEV), ptr, rc, self_interaction=False)
+        assert (np.bincount(out["src"].cpu().numpy(), minlength=4) == expect).all()
+    slab = ops().neighbor_list(torch.from_numpy(fcc).to(DEV), torch.from_numpy(cell).to(DEV), ptr, 1.01,
+                             self_interaction=False, pbc=(True, True, False))
+    assert int(slab["shift"][:, 2].abs().max()) == 0 and 0 < slab["src"].numel() < 4 * 18
+
+
+def test_build_data_all_feeds_the_model():
+    """structures -> featurize.build_data_all -> collate -> model: schema of `utils.py:291-301`, x = mass one-hot."""
+    from dostransformer_amd import featurize
+    from dostransformer_amd.batch import collate
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    from oracle.dos_oracle import neighbor_list_bruteforce
+    rng = np.random.default_rng(3)
+    pos, cells = _random_crystals(11, [2, 5, 3])
+    entries = [{"symbols": [featurize.SYMBOLS[k] for k in rng.integers(0, 90, p.shape[0])], "positions": p, "cell": c,
+                "phdos": rng.uniform(0, 1, 51), "crystal_system": cs, "mp_id": f"mp-{k}"}
+               for k, (p, c, cs) in enumerate(zip(pos, cells, ["Cubic", "Monoclinic", "Triclinic"]))]
+    data = featurize.build_data_all(entries, r_max=4.0, device=DEV, dtype=torch.float32)
+    assert [int(d["system"]) for d in data] == [0, 5, 6]
+    for d, e in zip(data, entries):
+        i, j, S, D = neighbor_list_bruteforce(e["positions"], e["cell"], 4.0, True)
+        assert d["edge_index"].shape == (2, len(i)) and np.array_equal(d["edge_index"].numpy(), np.stack([i, j]))
+        assert np.allclose(d["edge_vec"].numpy(), D, atol=1e-6)
+        z = [featurize.SYMBOLS.index(s) for s in e["symbols"]]
+        assert d["x"].shape == (len(z), 118) and (d["x"] != 0).sum() == len(z)
+        assert np.allclose(d["x"][range(len(z)), z].numpy(), [featurize.ATOMIC_MASSES[k] for k in z], rtol=1e-6)
+        assert d["phdos"].shape == (1, 51)
+    torch.manual_seed(0)
+    model = DOSTransformer_phonon(2, 1, 118, 4, 32, DEV, 0.0).to(DEV)
+    g = collate(data).to(DEV)
+    with torch.no_grad():
+        dg, x, ds = model(g)
+    assert dg.shape == (3, 51) and torch.isfinite(dg).all() and torch.isfinite(ds).all()

@@ -176,3 +176,41 @@ def test_g9_eval_loops():
     assert np.allclose(m, z["e/metrics"], rtol=2e-5, atol=1e-6)
     assert ids == [str(s) for s in z["e/mp_id"]]
     assert maxabs(preds, z["e/preds"]) < 1e-5 and maxabs(y, z["e/y"]) == 0.0 and maxabs(emb, z["e/embeddings"]) < 1e-4
+
+
+# ---- §8f-3: the brute-force periodic neighbour list is pinned by crystallographic known answers --------------------
+def _nl(pos, cell, rc, si=False):
+    from oracle.dos_oracle import neighbor_list_bruteforce
+    return neighbor_list_bruteforce(np.asarray(pos, float), np.asarray(cell, float), rc, si)
+
+
+@pytest.mark.parametrize("name,pos,shells", [
+    ("sc", [[0, 0, 0]], [(1.01, 6), (1.42, 18), (1.74, 26), (2.01, 32)]),
+    ("fcc", [[0, 0, 0], [0, .5, .5], [.5, 0, .5], [.5, .5, 0]], [(0.71, 12), (1.01, 18), (1.23, 42)]),
+    ("bcc", [[0, 0, 0], [.5, .5, .5]], [(0.87, 8), (1.01, 14), (1.42, 26)]),
+])
+def test_neighbor_oracle_coordination_shells(name, pos, shells):
+    for rc, expect in shells:
+        i, j, S, D = _nl(pos, np.eye(3), rc)
+        assert (np.bincount(i, minlength=len(pos)) == expect).all(), (name, rc)
+        assert (np.linalg.norm(D, axis=1) < rc).all() and (np.linalg.norm(D, axis=1) > 0).all()
+
+
+def test_neighbor_oracle_hcp_and_symmetries():
+    a, c = 1.0, np.sqrt(8.0 / 3.0)                       # ideal hcp: 12 nearest neighbours at distance a
+    cell = np.array([[a, 0, 0], [-a / 2, a * np.sqrt(3) / 2, 0], [0, 0, c]])
+    frac = np.array([[1 / 3, 2 / 3, 0.25], [2 / 3, 1 / 3, 0.75]])
+    pos = frac @ cell
+    i, j, S, D = _nl(pos, cell, 1.01)
+    assert (np.bincount(i) == 12).all()
+    # self_interaction adds exactly the n zero-length (i, i, 0) pairs
+    i2, j2, S2, D2 = _nl(pos, cell, 1.01, si=True)
+    assert len(i2) == len(i) + 2 and ((np.abs(D2).sum(1) == 0).sum() == 2)
+    # (i, j, S) is an edge  <=>  (j, i, -S) is one
+    fwd = set(zip(i.tolist(), j.tolist(), map(tuple, S.tolist())))
+    assert fwd == {(b, a_, tuple(-np.array(s))) for a_, b, s in fwd}
+    # translating an atom by a lattice vector changes shifts, not the set of difference vectors
+    pos_u = pos.copy(); pos_u[1] += 2 * cell[0] - 3 * cell[2]
+    i3, j3, S3, D3 = _nl(pos_u, cell, 1.01)
+    key = lambda ii, jj, DD: sorted((int(p), int(q), *np.round(d, 9)) for p, q, d in zip(ii, jj, DD))
+    assert key(i, j, D) == key(i3, j3, D3)

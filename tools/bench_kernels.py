@@ -159,6 +159,36 @@ def collate_case(name, B, kind="phonon"):
           f"H2D {t_ref * 1e6:8.1f} us")
 
 
+def neighbor_case(name, C, r_max):
+    """A phonon-dataset-sized featurisation (the reference's set is ~1.5k crystals, r_max 4, `main_phDOS.py:21`)."""
+    import time
+    import numpy as np
+    rng = np.random.default_rng(0)
+    sizes = rng.integers(2, 13, C)
+    pos, cells = [], []
+    for n in sizes:
+        cell = np.diag(rng.uniform(3.0, 7.0, 3)) + rng.uniform(-1.0, 1.0, (3, 3))
+        pos.append(rng.uniform(0, 1, (n, 3)) @ cell)
+        cells.append(cell)
+    ptr = torch.from_numpy(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)).to(DEV)
+    P, L = torch.from_numpy(np.concatenate(pos)).to(DEV), torch.from_numpy(np.stack(cells)).to(DEV)
+    for _ in range(2):
+        out = ops.neighbor_list(P, L, ptr, r_max)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        out = ops.neighbor_list(P, L, ptr, r_max)
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / 5
+    from oracle.dos_oracle import neighbor_list_bruteforce
+    t0 = time.perf_counter()
+    for c in range(20):
+        neighbor_list_bruteforce(pos[c], cells[c], r_max, True)
+    t_cpu = (time.perf_counter() - t0) / 20 * C
+    print(f"nlist {name:30s} C={C} atoms={int(sizes.sum())} edges={out['src'].numel()} r_max={r_max}: {t * 1e3:7.2f} ms for the whole "
+          f"set (count + scan + fill, incl. 2 host reads) | numpy brute force ~{t_cpu * 1e3:8.0f} ms (extrapolated from 20)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="all")
@@ -170,6 +200,9 @@ def main():
         ffn_case("FFN fwd 2B", R2, H)
         ffn_case("FFN fwd B", R1, H)
         ffn_case("FFN fwd roofline scale", 262144, H)
+    if w in ("all", "neighbors"):
+        neighbor_case("phonon-set sized", 1500, 4.0)
+        neighbor_case("phonon-set sized", 1500, 6.0)
     if w in ("all", "collate"):
         collate_case("phonon 64 crystals", 64)
         collate_case("eDOS 64 crystals", 64, "edos")
