@@ -100,3 +100,23 @@ def phonon_crystals(batch_size: int, seed: int, dtype=torch.float64):
 def edos_crystals(batch_size: int, seed: int, dtype=torch.float32):
     gen = torch.Generator().manual_seed(seed)
     return [edos_crystal(gen, dtype=dtype, idx=i) for i in range(batch_size)]
+
+
+def phonon_structures(count: int, seed: int):
+    """Synthetic *structures* (what `utils.py:178-196` load_data yields per row, before build_data): random triclinic
+    cells of 2-12 atoms with a smooth random target DOS.  Input of ``featurize.build_data_all``."""
+    import numpy as np
+    from .featurize import CRYSTAL_SYSTEMS, SYMBOLS
+    rng = np.random.default_rng(seed)
+    systems = list(CRYSTAL_SYSTEMS) + ["Triclinic"]
+    out = []
+    for k in range(count):
+        n = int(rng.integers(2, 13))
+        cell = np.diag(rng.uniform(3.0, 6.5, 3)) + rng.uniform(-0.8, 0.8, (3, 3))
+        grid = np.linspace(0.0, 1.0, PH_BINS)
+        dos = sum(a * np.exp(-((grid - c) / w) ** 2) for a, c, w in
+                  zip(rng.uniform(0.2, 1.0, 3), rng.uniform(0.1, 0.9, 3), rng.uniform(0.05, 0.2, 3)))
+        out.append({"symbols": [SYMBOLS[z] for z in rng.integers(0, 83, n)], "positions": rng.uniform(0, 1, (n, 3)) @ cell,
+                    "cell": cell, "phdos": dos / dos.max(), "crystal_system": systems[int(rng.integers(0, 7))],
+                    "mp_id": f"synth-{k}"})
+    return out
