@@ -179,20 +179,27 @@ __device__ __forceinline__ float4 a_finish(const AState& st, const ARaw& r, int 
 // The epilogue uses all 8 waves (4 rows each per 32-row block).
 // ---------------------------------------------------------------------------------------------
 // (128-column tiles with a light epilogue are held to 128 VGPRs = 4 waves per SIMD: two workgroups per CU)
-template <int RT, int NTW, int WL, int PRO, int VEC, int EPI>
+template <int RTP, int NTW, int WL, int PRO, int VEC, int EPI>
 __global__ __launch_bounds__(512, (NTW == 1 && (EPI == DOSX_EPI_BIAS_ACT || EPI == DOSX_EPI_LN || EPI == DOSX_EPI_RELU_MASK)) ? 4 : 2)
 void gemm_kernel(const GemmLaunch L) {
   const DosxGemm& g = L.g;
-  constexpr int BMR = BM * RT;
+  // RTP = 0: HALF tile.  The workgroup owns 16 rows and multiplies with the 16x16x4 MFMA (same flop rate, half the
+  // rows per instruction): kernels with M of a few hundred rows get twice the workgroups, each with half the MFMA
+  // time per k-chunk.  Staging, LDS layout and register sets are those of RT = 1 (the staging waves still fill a
+  // 32-row A tile; its upper 16 rows are the next workgroup's rows, loaded from valid addresses and never read).
+  constexpr bool HALF = (RTP == 0);
+  constexpr int RT = HALF ? 1 : RTP;
+  constexpr int BMR = HALF ? 16 : BM * RT;  // rows of C this workgroup owns
+  constexpr int BMS = BM * RT;              // rows of the staged A tile
   constexpr int BN = 128 * NTW;
   constexpr int LDWT = (WL == 0) ? (BK + 4) : (BN + 4);
   constexpr int WROWS = (WL == 0) ? BN : BK;
   constexpr int LDC = BN + 4;
-  constexpr int STAGE = BMR * LDA + WROWS * LDWT;     // floats of one staging buffer (A tile + W tile)
+  constexpr int STAGE = BMS * LDA + WROWS * LDWT;     // floats of one staging buffer (A tile + W tile)
   constexpr int CTILE = BM * LDC;
   constexpr int CG = (BN + 255) / 256;   // float4 column groups per lane in the row-wise epilogue
   constexpr int NW4 = BN / 32;           // float4 W loads per staging thread per k-chunk
-  constexpr int ER = 4;                  // epilogue rows per wave per 32-row block (8 waves)
+  constexpr int ER = HALF ? 2 : 4;       // epilogue rows per wave per row block (8 waves)
   constexpr bool PROLN = VEC && (PRO == DOSX_PRO_LN_PRELU || PRO == DOSX_PRO_ROWLN);
 
   extern __shared__ __align__(16) float smem[];
@@ -217,6 +224,7 @@ void gemm_kernel(const GemmLaunch L) {
   const int nk = (K + BK - 1) / BK;
 
   f32x16 acc[RT][NTW];
+  f32x4 acch[2 * NTW];      // HALF: 16x16 accumulators of this wave's 2*NTW column tiles
 
   STAMP(0);
   // ---- epilogue operand prefetch (all 8 waves; wave w owns rows 4w..4w+3 of each 32-row block) -----
@@ -500,7 +508,7 @@ void gemm_kernel(const GemmLaunch L) {
 #pragma unroll
         for (int r = 0; r < RT; ++r)
           st4(&buf[(arow + 32 * r) * LDA + akq], a_finish<PRO, VEC, 0>(ast[r], ar[r], k, K, gv, bv));
-        float* Wd = buf + BMR * LDA;
+        float* Wd = buf + BMS * LDA;
 #pragma unroll
         for (int i = 0; i < NW4; ++i) {
           if (WL == 0) st4(&Wd[((st >> 3) + 32 * i) * LDWT + (st & 7) * 4], wr[i]);
@@ -515,7 +523,7 @@ void gemm_kernel(const GemmLaunch L) {
       };
       auto store = [&](float* buf, const ARaw(&ar)[RT], const float4(&wr)[NW4], int k0) {
         storeA(buf, ar, k0);
-        storeW(buf + BMR * LDA, k0, wr);
+        storeW(buf + BMS * LDA, k0, wr);
       };
       pipeline(issue, store);
     }
@@ -530,16 +538,50 @@ void gemm_kernel(const GemmLaunch L) {
     f32x16 accb;
 #pragma unroll
     for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2 * NTW; ++t) acch[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (PROLN) __syncthreads();
     __syncthreads();
     STAMP(1);
+    if constexpr (HALF) {
+      // 16x16x4 MFMA: lane l holds A[row l&15][k = 4*(l>>4) + j] and B[k][col l&15] for the j-th of the 4 MFMAs
+      // of a float4; one float4 per lane covers 16 k values, a 32-wide chunk is two such steps.
+      const int l15 = lane & 15, g4 = lane >> 4;
+      for (int kt = 0; kt < nk; ++kt) {
+        const float* Asb = smem + (kt & 1) * STAGE;
+        const float* Wsb = Asb + BMS * LDA;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 16) {
+          const float4 a = ld4(&Asb[l15 * LDA + kk + 4 * g4]);
+          float b[2 * NTW][4];
+#pragma unroll
+          for (int t = 0; t < 2 * NTW; ++t) {
+            if (WL == 0) {
+              const float4 v = ld4(&Wsb[((wave * 2 * NTW + t) * 16 + l15) * LDWT + kk + 4 * g4]);
+              b[t][0] = v.x; b[t][1] = v.y; b[t][2] = v.z; b[t][3] = v.w;
+            } else {
+              const float* bp = &Wsb[(kk + 4 * g4) * LDWT + (wave * 2 * NTW + t) * 16 + l15];
+              b[t][0] = bp[0]; b[t][1] = bp[LDWT]; b[t][2] = bp[2 * LDWT]; b[t][3] = bp[3 * LDWT];
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float av = c == 0 ? a.x : c == 1 ? a.y : c == 2 ? a.z : a.w;
+#pragma unroll
+            for (int t = 0; t < 2 * NTW; ++t)
+              acch[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[t][c], acch[t], 0, 0, 0);
+          }
+        }
+        __syncthreads();
+      }
+    } else {
     // One k-chunk of MFMAs.  Straight-line and unconditional: W rows / columns beyond N are zero-filled
     // in LDS, so a ragged last column block just multiplies zeros.  (A wave-uniform "skip my
     // out-of-range tiles" branch here made hipcc keep the accumulators in VGPRs across the k-loop and
     // copy them to/from AGPRs around the MFMA block: 2 x 16*RT*NTW moves per chunk.)
     for (int kt = 0; kt < nk; ++kt) {
       const float* Asb = smem + (kt & 1) * STAGE;
-      const float* Wsb = Asb + BMR * LDA;
+      const float* Wsb = Asb + BMS * LDA;
       STAMP(3 + 3 * kt);
 #pragma unroll
       for (int kk = 0; kk < BK; kk += 8) {
@@ -583,12 +625,22 @@ void gemm_kernel(const GemmLaunch L) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[0][0][r] += accb[r];
     }
+    }   // !HALF
   }
   STAMP(55);
 
   if constexpr (!HOIST) prefetch_rows();
   // ---- accumulators -> LDS C tiles (alias the staging buffers; the k-loop ended with a barrier) ----
-  if (wave_u < 4) {
+  if constexpr (HALF) {
+    if (wave_u < 4) {                 // 16x16 C fragment: col = lane & 15, row = 4 * (lane >> 4) + reg
+#pragma unroll
+      for (int t = 0; t < 2 * NTW; ++t) {
+        const int col = (wave * 2 * NTW + t) * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cs[(4 * (lane >> 4) + r) * LDC + col] = acch[t][r];
+      }
+    }
+  } else if (wave_u < 4) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -777,8 +829,9 @@ void gemm_kernel(const GemmLaunch L) {
   }
 }
 
-template <int RT, int NTW, int WL, int PROLN>
+template <int RTP, int NTW, int WL, int PROLN>
 constexpr size_t gemm_smem_bytes() {
+  constexpr int RT = RTP == 0 ? 1 : RTP;
   constexpr int BN = 128 * NTW;
   constexpr int LDWT = (WL == 0) ? (BK + 4) : (BN + 4);
   constexpr int WROWS = (WL == 0) ? BN : BK;
@@ -792,7 +845,7 @@ constexpr size_t gemm_smem_bytes() {
 template <int RT, int NTW, int WL, int PRO, int VEC, int EPI>
 int launch_gemm3(const GemmLaunch& L, hipStream_t s) {
   constexpr int BN = 128 * NTW;
-  dim3 grid(ceil_div(L.g.M, BM * RT) * ceil_div(L.g.N, BN));
+  dim3 grid(ceil_div(L.g.M, RT == 0 ? 16 : BM * RT) * ceil_div(L.g.N, BN));
   constexpr size_t smem = gemm_smem_bytes<RT, NTW, WL, (VEC && (PRO == DOSX_PRO_LN_PRELU || PRO == DOSX_PRO_ROWLN)) ? 1 : 0>();
   if constexpr (smem > 160 * 1024) {     // (512-column tile + LayerNorm prologue: no caller has this shape)
     dosx_set_error("dosx_gemm: tile %dx%d with prologue %d exceeds the 160 KB LDS", BM * RT, BN, PRO);
@@ -815,6 +868,7 @@ int launch_gemm(const GemmLaunch& L, hipStream_t s) {
   if constexpr (NTW < 4) {              // (two 64-row stage buffers of a 512-column tile exceed the LDS)
     if (L.rt == 2) return launch_gemm3<2, NTW, WL, PRO, VEC, EPI>(L, s);
   }
+  if (L.rt == 0) return launch_gemm3<0, NTW, WL, PRO, VEC, EPI>(L, s);
   return launch_gemm3<1, NTW, WL, PRO, VEC, EPI>(L, s);
 }
 
@@ -882,22 +936,36 @@ int gemm_bn(int M, int N, int epi) {
 // resource, see gemm_kernel) but also halve the number of workgroups: use them when the grid still
 // fills the 256 CUs, or when the 32-row grid would run a nearly empty second round.
 inline int gemm_rt(int M, int N, int epi) {
-  if (M <= BM) return 1;
-  static int forced = -1;
-  if (forced < 0) { const char* e = getenv("DOSX_GEMM_RT"); forced = e ? atoi(e) : 0; }
-  if (forced == 1 || forced == 2) return forced;
-  if (gemm_bn(M, N, epi) == 512) return 1;
+  static int forced = -2, half_max = -1;
+  if (forced == -2) {
+    const char* e = getenv("DOSX_GEMM_RT");
+    forced = e ? atoi(e) : -1;
+    const char* h = getenv("DOSX_GEMM_HALF_MAX");
+    half_max = h ? atoi(h) : 128;
+  }
+  if (M <= 16) return 0;
+  if (forced >= 0 && forced <= 2 && !(forced == 2 && gemm_bn(M, N, epi) == 512)) return M <= BM && forced == 2 ? 1 : forced;
   const int ntiles = ceil_div(N, gemm_bn(M, N, epi));
   const int wg1 = ceil_div(M, BM) * ntiles, wg2 = ceil_div(M, 2 * BM) * ntiles;
+  // HALF (16-row) tiles: a kernel this small is one partial round of workgroups whichever way it is cut, so its
+  // duration is one workgroup's latency - halve that
+  if (wg1 <= half_max) return 0;
+  if (M <= BM) return 1;
+  if (gemm_bn(M, N, epi) == 512) return 1;
   if (wg2 >= 192) return 2;
   if (wg1 > 256 && wg1 <= 400 && wg2 >= 128) return 2;
   return 1;
 }
 
+inline int gemm_rows_per_wg(int M, int N, int epi) {
+  const int rt = gemm_rt(M, N, epi);
+  return rt == 0 ? 16 : BM * rt;
+}
+
 extern "C" int dosx_gemm_partial_rows(int M, int N, int epi) {
   // one partial row per workgroup; row-wise epilogues run as one N tile (N <= 512), the
   // element-wise PRELU_BWD epilogue tiles N by 128.
-  const int rows = ceil_div(M, BM * gemm_rt(M, N, epi));
+  const int rows = ceil_div(M, gemm_rows_per_wg(M, N, epi));
   if (epi == DOSX_EPI_PRELU_BWD) return rows * ceil_div(N, 128);
   return rows;
 }
@@ -945,7 +1013,7 @@ extern "C" int dosx_gemm(const DosxGemm* gp, dosx_stream_t stream) {
   L.rt = gemm_rt(g.M, g.N, g.epi);
   int bn = gemm_bn(g.M, g.N, g.epi);
   if (g.stats_out && bn < g.N) bn = g.N <= 256 ? 256 : 512;
-  if (bn == 512) L.rt = 1;
+  if (bn == 512 && L.rt == 2) L.rt = 1;
   hipStream_t s = to_stream(stream);
   if (bn == 128) return dispatch_gemm<1>(L, s);
   if (bn == 256) return dispatch_gemm<2>(L, s);

@@ -90,7 +90,9 @@ def test_gemm_gather_concat_act_residual_remap():
     assert err(got[:, B:], ref) < TOL and float(got[:, :B].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("M,H2,K", [(100, 256, 384), (37, 512, 768), (64, 128, 192), (9, 32, 48), (300, 16, 24)])
+# small M runs the 16-row (HALF) tiles, 4500 the 32-row and 9000 the 64-row ones (gemm_rt in csrc/gemm.hip)
+@pytest.mark.parametrize("M,H2,K", [(100, 256, 384), (37, 512, 768), (64, 128, 192), (9, 32, 48), (300, 16, 24),
+                                    (4500, 256, 384), (9000, 256, 384)])
 def test_gemm_ln_epilogue_and_ln_prelu_prologue(M, H2, K):
     o = ops()
     a = rnd(M, K, seed=1)
@@ -117,9 +119,10 @@ def test_gemm_ln_epilogue_and_ln_prelu_prologue(M, H2, K):
     assert err(y, act @ w3.double().T + b3.double() + res.double()) < TOL
 
 
-def test_gemm_rowln_prologue_and_stats_out():
+@pytest.mark.parametrize("M", [200, 3264, 6528])
+def test_gemm_rowln_prologue_and_stats_out(M):
     o = ops()
-    M, H = 200, 128
+    H = 128
     x = rnd(M, H, seed=1)
     w1 = rnd(4 * H, H, seed=2, scale=0.1)
     b1 = rnd(4 * H, seed=3)
@@ -234,7 +237,7 @@ def test_wgrad_gather_fast_path():
     assert err(slab.sum(0), dz.double().T @ cat) < TOL
 
 
-@pytest.mark.parametrize("M,H2", [(100, 256), (45, 512), (33, 32)])
+@pytest.mark.parametrize("M,H2", [(100, 256), (45, 512), (33, 32), (4500, 256), (9000, 256)])
 def test_gemm_prelu_ln_bwd_epilogue(M, H2):
     o = ops()
     H = H2 // 2
@@ -263,9 +266,10 @@ def test_gemm_prelu_ln_bwd_epilogue(M, H2):
     assert abs(float(ps[2 * H2]) - float(alpha.grad)) < 5e-5 * (1 + abs(float(alpha.grad)))
 
 
-def test_gemm_rowln_bwd_relu_mask_prelu_bwd():
+@pytest.mark.parametrize("M", [150, 5000, 13000])
+def test_gemm_rowln_bwd_relu_mask_prelu_bwd(M):
     o = ops()
-    M, H = 150, 64
+    H = 64
     x = rnd(M, H, seed=1).double().requires_grad_(True)
     gam = rnd(H, seed=2).double().requires_grad_(True)
     bet = rnd(H, seed=3).double().requires_grad_(True)
