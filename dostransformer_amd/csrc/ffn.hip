@@ -9,6 +9,8 @@
 // by column block) and then of fc2 through two LDS stage buffers, one barrier per chunk, loads two chunks deep;
 // they also copy the finished h tile to HBM while the matrix waves are already in fc2.
 // Needs H % 32 == 0 and H <= 128 (tile: 32 x 516 floats); larger H uses the two-GEMM path.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef int v4i32 __attribute__((ext_vector_type(4)));
@@ -19,27 +21,33 @@ constexpr int FBK = 32;          // k-chunk
 constexpr int FLDW = FBK + 4;    // 36: padded rows of a staged weight chunk
 constexpr int FBN = 128;         // columns per chunk / per column block
 
+// HALF: the workgroup owns 16 rows and multiplies with the 16x16x4 MFMA (two 16-column tiles per wave instead of one
+// 32-column tile): twice the workgroups, half the MFMA time each, and two of them fit the LDS of one CU.
+template <bool HALF>
 __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
   extern __shared__ __align__(16) float sm[];
+  constexpr int R = HALF ? 16 : 32;                // rows per workgroup
+  constexpr int ER = R / 8;                        // epilogue rows per wave
   const int H = a.H, H4 = 4 * a.H, M = a.M;
   const int LDX = H + 4, LDT = H4 + 4;
-  float* Xs = sm;                                  // [32][LDX]  LN1(x) tile (A operand of fc1)
-  float* T = Xs + 32 * LDX;                        // [32][LDT]  relu(fc1) tile (A operand of fc2)
-  float* ST = T + 32 * LDT;                        // 2 stage buffers [128][36]; later the C tile [32][H+4]
+  float* Xs = sm;                                  // [R][LDX]  LN1(x) tile (A operand of fc1)
+  float* T = Xs + R * LDX;                         // [R][LDT]  relu(fc1) tile (A operand of fc2)
+  float* ST = T + R * LDT;                         // 2 stage buffers [128][36]; later the C tile [R][H+4]
   constexpr int STG = FBN * FLDW;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int l15 = lane & 15, g4 = lane >> 4;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int m0 = blockIdx.x * 32;
+  const int m0 = blockIdx.x * R;
   const int nk1 = H / FBK, nb1 = H4 / FBN, n1 = nb1 * nk1, n2 = H4 / FBK, nch = n1 + n2;
 
   // epilogue operands of this wave's 4 rows, fetched at kernel start (all 8 waves)
   const int c0 = lane * 4;
   const bool con = c0 < H;
-  float4 xres[4], bias2 = f4zero();
+  float4 xres[ER], bias2 = f4zero();
   if (con) bias2 = ld4(a.b2 + c0);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = min(m0 + wave * 4 + i, M - 1);
+  for (int i = 0; i < ER; ++i) {
+    const int r = min(m0 + wave * ER + i, M - 1);
     xres[i] = ld4(a.x + (size_t)r * a.ldx + (con ? c0 : 0));
   }
 
@@ -70,7 +78,7 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
     };
     auto copy_h = [&]() {        // the finished relu(fc1) tile -> HBM (rows m0.., H4 columns), float4 per lane
       const int per_row = H4 / 4;
-      for (int i = st; i < 32 * per_row; i += 256) {
+      for (int i = st; i < R * per_row; i += 256) {
         const int r = i / per_row, c = (i % per_row) * 4;
         if (m0 + r < M) st4(a.h + (size_t)(m0 + r) * a.ldh + c, ld4(T + r * LDT + c));
       }
@@ -100,15 +108,74 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
     {   // LN1(x) tile -> Xs  (row r = tid/8, 4-float groups tid%8 + 8 i)
       const int r = tid >> 3, rr = min(m0 + r, M - 1);
       const float mean = a.stats[2 * (size_t)rr], rstd = a.stats[2 * (size_t)rr + 1];
-      for (int c = (tid & 7) * 4; c < H; c += 32) {
+      for (int c = (tid & 7) * 4; c < H && r < R; c += 32) {
         const float4 v = ld4(a.x + (size_t)rr * a.ldx + c), g = ld4(a.gamma + c), b = ld4(a.beta + c);
         st4(Xs + r * LDX + c, make_float4((v.x - mean) * rstd * g.x + b.x, (v.y - mean) * rstd * g.y + b.y,
                                           (v.z - mean) * rstd * g.z + b.z, (v.w - mean) * rstd * g.w + b.w));
       }
     }
     __syncthreads();
-    f32x16 acc;
     int c = 0;
+    if constexpr (HALF) {
+      f32x4 acc0, acc1;
+      // ---- fc1: nb1 column blocks of 128 (this wave: two 16-column tiles), each nk1 chunks ----
+      for (int cb = 0; cb < nb1; ++cb) {
+        acc0 = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = acc0;
+        for (int kc = 0; kc < nk1; ++kc, ++c) {
+          const float* Ws = ST + (c & 1) * STG;
+#pragma unroll
+          for (int kk = 0; kk < FBK; kk += 16) {
+            const float4 av = ld4(Xs + l15 * LDX + kc * FBK + kk + 4 * g4);
+            const float4 b0 = ld4(Ws + (wave * 32 + l15) * FLDW + kk + 4 * g4);
+            const float4 b1 = ld4(Ws + (wave * 32 + 16 + l15) * FLDW + kk + 4 * g4);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b0.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b1.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b0.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b1.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b0.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b1.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b0.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b1.w, acc1, 0, 0, 0);
+          }
+          __syncthreads();
+        }
+        const int col = cb * FBN + wave * 32 + l15;
+        const float b1a = a.b1[col], b1b = a.b1[col + 16];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          T[(4 * g4 + r) * LDT + col] = fmaxf(acc0[r] + b1a, 0.f);
+          T[(4 * g4 + r) * LDT + col + 16] = fmaxf(acc1[r] + b1b, 0.f);
+        }
+      }
+      __syncthreads();                             // T complete (the staging waves copy it out from here on)
+      acc0 = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = acc0;
+      for (int kc = 0; kc < n2; ++kc, ++c) {
+        const float* Ws = ST + (c & 1) * STG;
+#pragma unroll
+        for (int kk = 0; kk < FBK; kk += 16) {
+          const float4 av = ld4(T + l15 * LDT + kc * FBK + kk + 4 * g4);
+          const float4 b0 = ld4(Ws + (wave * 32 + l15) * FLDW + kk + 4 * g4);
+          const float4 b1 = ld4(Ws + (wave * 32 + 16 + l15) * FLDW + kk + 4 * g4);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b0.x, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b1.x, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b0.y, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b1.y, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b0.z, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b1.z, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b0.w, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b1.w, acc1, 0, 0, 0);
+        }
+        __syncthreads();
+      }
+      float* Cs = ST;                              // C tile (the stage buffers are dead: the last chunk ended with a barrier)
+      const int col = wave * 32 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        Cs[(4 * g4 + r) * (FBN + 4) + col] = acc0[r];
+        Cs[(4 * g4 + r) * (FBN + 4) + col + 16] = acc1[r];
+      }
+    } else {
+    f32x16 acc;
     // ---- fc1: nb1 column blocks of 128, each nk1 chunks ----
     for (int cb = 0; cb < nb1; ++cb) {
 #pragma unroll
@@ -153,14 +220,15 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
     const int col = wave * 32 + l31;
 #pragma unroll
     for (int r = 0; r < 16; ++r) Cs[((r & 3) + 8 * (r >> 2) + 4 * hh) * (FBN + 4) + col] = acc[r];
+    }   // !HALF
   }
   __syncthreads();
-  // ---- row epilogue (8 waves x 4 rows): out = C + b2 + x ----
+  // ---- row epilogue (8 waves x ER rows): out = C + b2 + x ----
   {
     const float* Cs = ST;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int lr = wave * 4 + i, r = m0 + lr;
+    for (int i = 0; i < ER; ++i) {
+      const int lr = wave * ER + i, r = m0 + lr;
       if (!(con && r < M)) continue;
       const float4 v = ld4(Cs + lr * (FBN + 4) + c0);
       st4(a.out + (size_t)r * a.ldo + c0, make_float4(v.x + bias2.x + xres[i].x, v.y + bias2.y + xres[i].y,
@@ -183,13 +251,19 @@ extern "C" int dosx_ffn_fwd(const DosxFfn* ap, dosx_stream_t stream) {
   const long long span = (const char*)a.w1 > (const char*)a.w2 ? (const char*)a.w1 - (const char*)a.w2 : (const char*)a.w2 - (const char*)a.w1;
   DOSX_CHECK_ARG(span + (long long)16 * a.H * a.H < 0x7fffffffLL, "dosx_ffn_fwd: fc1 / fc2 weights more than 2 GiB apart");
   const int H = a.H, H4 = 4 * H;
-  const size_t smem = sizeof(float) * ((size_t)32 * (H + 4) + (size_t)32 * (H4 + 4) + 2 * (size_t)FBN * FLDW);
+  static int half_max = -1;
+  if (half_max < 0) { const char* e = getenv("DOSX_FFN_HALF_MAX"); half_max = e ? atoi(e) : 128; }
+  const bool half = ceil_div(a.M, 32) <= half_max;       // 16-row workgroups while the 32-row grid is one partial round
+  const int R = half ? 16 : 32;
+  const size_t smem = sizeof(float) * ((size_t)R * (H + 4) + (size_t)R * (H4 + 4) + 2 * (size_t)FBN * FLDW);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(ffn_fwd_kernel, dim3(ceil_div(a.M, 32)), dim3(512), smem, to_stream(stream), a);
+  if (half) hipLaunchKernelGGL(ffn_fwd_kernel<true>, dim3(ceil_div(a.M, 16)), dim3(512), smem, to_stream(stream), a);
+  else hipLaunchKernelGGL(ffn_fwd_kernel<false>, dim3(ceil_div(a.M, 32)), dim3(512), smem, to_stream(stream), a);
   DOSX_LAUNCH_CHECK();
   return 0;
 }
