@@ -329,7 +329,9 @@ class GradSink:
     # Weight-gradient (wgrad) and key/value-gradient kernels feed nothing but the final slab reduction,
     # so they are launched on a SIDE stream and run concurrently with the dgrad chain on the main stream:
     # at BASELINE sizes every kernel is one partial wave of workgroups, two streams simply fill more CUs.
-    use_side_stream = __import__("os").environ.get("DOSX_SIDE_STREAM", "0") == "1"     # measured: no gain (2.86 vs 2.73 ms/step), off by default
+    # Off for eagerly issued steps (the host cannot feed two streams from Python: no gain), switched on by
+    # train.Trainer while it records a replayed step (1.80 vs 1.88 ms serialised).
+    use_side_stream = __import__("os").environ.get("DOSX_SIDE_STREAM", "0") == "1"
     _side_streams: dict = {}
 
     def __init__(self, device):
