@@ -187,9 +187,12 @@ void gemm_kernel(const GemmLaunch L) {
   // rows per instruction): kernels with M of a few hundred rows get twice the workgroups, each with half the MFMA
   // time per k-chunk.  Staging, LDS layout and register sets are those of RT = 1 (the staging waves still fill a
   // 32-row A tile; its upper 16 rows are the next workgroup's rows, loaded from valid addresses and never read).
-  constexpr bool HALF = (RTP == 0);
-  constexpr int RT = HALF ? 1 : RTP;
-  constexpr int BMR = HALF ? 16 : BM * RT;  // rows of C this workgroup owns
+  constexpr bool HALF = (RTP == 0 || RTP == 3);
+  constexpr int HT = RTP == 3 ? 3 : 1;      // 16-row sub-tiles of a HALF-family workgroup (RTP = 3: 48 rows, for row
+                                            // counts where 32 rows per CU are too few and 64 leave CUs idle: M = 9000)
+  constexpr int RT = HALF ? (HT + 1) / 2 : RTP;   // 32-row blocks of the staged A tile / register sets of the staging waves
+  constexpr int RTE = HALF ? 1 : RT;        // row blocks of the epilogue (the HALF family runs it as one block)
+  constexpr int BMR = HALF ? 16 * HT : BM * RT;  // rows of C this workgroup owns
   constexpr int BMS = BM * RT;              // rows of the staged A tile
   constexpr int BN = 128 * NTW;
   constexpr int LDWT = (WL == 0) ? (BK + 4) : (BN + 4);
@@ -199,7 +202,7 @@ void gemm_kernel(const GemmLaunch L) {
   constexpr int CTILE = BM * LDC;
   constexpr int CG = (BN + 255) / 256;   // float4 column groups per lane in the row-wise epilogue
   constexpr int NW4 = BN / 32;           // float4 W loads per staging thread per k-chunk
-  constexpr int ER = HALF ? 2 : 4;       // epilogue rows per wave per row block (8 waves)
+  constexpr int ER = HALF ? 2 * HT : 4;  // epilogue rows per wave per row block (8 waves)
   constexpr bool PROLN = VEC && (PRO == DOSX_PRO_LN_PRELU || PRO == DOSX_PRO_ROWLN);
 
   extern __shared__ __align__(16) float smem[];
@@ -224,7 +227,7 @@ void gemm_kernel(const GemmLaunch L) {
   const int nk = (K + BK - 1) / BK;
 
   f32x16 acc[RT][NTW];
-  f32x4 acch[2 * NTW];      // HALF: 16x16 accumulators of this wave's 2*NTW column tiles
+  f32x4 acch[HT][2 * NTW];  // HALF: 16x16 accumulators of this wave's HT x 2*NTW tiles
 
   STAMP(0);
   // ---- epilogue operand prefetch (all 8 waves; wave w owns rows 4w..4w+3 of each 32-row block) -----
@@ -264,9 +267,9 @@ void gemm_kernel(const GemmLaunch L) {
       if (is_prelu_ln) betv[j] = ld4(g.epi_beta + gcol[j]);
     }
   }
-  float4 pv1[RT][ER][CG], pv2[RT][ER][CG];
-  float st0[RT][ER], st1[RT][ER];
-  size_t orow_[RT][ER];
+  float4 pv1[RTE][ER][CG], pv2[RTE][ER][CG];
+  float st0[RTE][ER], st1[RTE][ER];
+  size_t orow_[RTE][ER];
   // The per-row operands are hoisted above the k-loop only for the backward epilogues (they always have
   // them).  The plain bias/activation epilogue keeps its registers for occupancy instead: at <= 128
   // VGPRs two 8-wave workgroups share a CU, which matters more for its (larger) grids; its optional
@@ -274,7 +277,7 @@ void gemm_kernel(const GemmLaunch L) {
   constexpr bool HOIST = (epi != DOSX_EPI_BIAS_ACT);
   auto prefetch_rows = [&]() {
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
+  for (int rt = 0; rt < RTE; ++rt) {
     const int mb = m0 + 32 * rt;
 #pragma unroll
     for (int i = 0; i < ER; ++i) {
@@ -539,7 +542,9 @@ void gemm_kernel(const GemmLaunch L) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) accb[r] = 0.f;
 #pragma unroll
-    for (int t = 0; t < 2 * NTW; ++t) acch[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < HT; ++h)
+#pragma unroll
+      for (int t = 0; t < 2 * NTW; ++t) acch[h][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (PROLN) __syncthreads();
     __syncthreads();
     STAMP(1);
@@ -552,7 +557,9 @@ void gemm_kernel(const GemmLaunch L) {
         const float* Wsb = Asb + BMS * LDA;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
-          const float4 a = ld4(&Asb[l15 * LDA + kk + 4 * g4]);
+          float4 a[HT];
+#pragma unroll
+          for (int h = 0; h < HT; ++h) a[h] = ld4(&Asb[(16 * h + l15) * LDA + kk + 4 * g4]);
           float b[2 * NTW][4];
 #pragma unroll
           for (int t = 0; t < 2 * NTW; ++t) {
@@ -565,12 +572,14 @@ void gemm_kernel(const GemmLaunch L) {
             }
           }
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float av = c == 0 ? a.x : c == 1 ? a.y : c == 2 ? a.z : a.w;
+          for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int t = 0; t < 2 * NTW; ++t)
-              acch[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[t][c], acch[t], 0, 0, 0);
-          }
+            for (int h = 0; h < HT; ++h) {
+              const float av = c == 0 ? a[h].x : c == 1 ? a[h].y : c == 2 ? a[h].z : a[h].w;
+#pragma unroll
+              for (int t = 0; t < 2 * NTW; ++t)
+                acch[h][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[t][c], acch[h][t], 0, 0, 0);
+            }
         }
         __syncthreads();
       }
@@ -634,11 +643,13 @@ void gemm_kernel(const GemmLaunch L) {
   if constexpr (HALF) {
     if (wave_u < 4) {                 // 16x16 C fragment: col = lane & 15, row = 4 * (lane >> 4) + reg
 #pragma unroll
-      for (int t = 0; t < 2 * NTW; ++t) {
-        const int col = (wave * 2 * NTW + t) * 16 + (lane & 15);
+      for (int h = 0; h < HT; ++h)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Cs[(4 * (lane >> 4) + r) * LDC + col] = acch[t][r];
-      }
+        for (int t = 0; t < 2 * NTW; ++t) {
+          const int col = (wave * 2 * NTW + t) * 16 + (lane & 15);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Cs[(16 * h + 4 * (lane >> 4) + r) * LDC + col] = acch[h][t][r];
+        }
     }
   } else if (wave_u < 4) {
 #pragma unroll
@@ -658,7 +669,7 @@ void gemm_kernel(const GemmLaunch L) {
   STAMP(57);
 
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
+  for (int rt = 0; rt < RTE; ++rt) {
   const int mb = m0 + 32 * rt;
   // ---- row-wise epilogue: lanes sweep the columns as float4 ------------------------------------
 #pragma unroll
@@ -831,7 +842,7 @@ void gemm_kernel(const GemmLaunch L) {
 
 template <int RTP, int NTW, int WL, int PROLN>
 constexpr size_t gemm_smem_bytes() {
-  constexpr int RT = RTP == 0 ? 1 : RTP;
+  constexpr int RT = RTP == 0 ? 1 : (RTP == 3 ? 2 : RTP);
   constexpr int BN = 128 * NTW;
   constexpr int LDWT = (WL == 0) ? (BK + 4) : (BN + 4);
   constexpr int WROWS = (WL == 0) ? BN : BK;
@@ -845,7 +856,7 @@ constexpr size_t gemm_smem_bytes() {
 template <int RT, int NTW, int WL, int PRO, int VEC, int EPI>
 int launch_gemm3(const GemmLaunch& L, hipStream_t s) {
   constexpr int BN = 128 * NTW;
-  dim3 grid(ceil_div(L.g.M, RT == 0 ? 16 : BM * RT) * ceil_div(L.g.N, BN));
+  dim3 grid(ceil_div(L.g.M, RT == 0 ? 16 : (RT == 3 ? 48 : BM * RT)) * ceil_div(L.g.N, BN));
   constexpr size_t smem = gemm_smem_bytes<RT, NTW, WL, (VEC && (PRO == DOSX_PRO_LN_PRELU || PRO == DOSX_PRO_ROWLN)) ? 1 : 0>();
   if constexpr (smem > 160 * 1024) {     // (512-column tile + LayerNorm prologue: no caller has this shape)
     dosx_set_error("dosx_gemm: tile %dx%d with prologue %d exceeds the 160 KB LDS", BM * RT, BN, PRO);
@@ -867,6 +878,7 @@ template <int NTW, int WL, int PRO, int VEC, int EPI>
 int launch_gemm(const GemmLaunch& L, hipStream_t s) {
   if constexpr (NTW < 4) {              // (two 64-row stage buffers of a 512-column tile exceed the LDS)
     if (L.rt == 2) return launch_gemm3<2, NTW, WL, PRO, VEC, EPI>(L, s);
+    if (L.rt == 3) return launch_gemm3<3, NTW, WL, PRO, VEC, EPI>(L, s);
   }
   if (L.rt == 0) return launch_gemm3<0, NTW, WL, PRO, VEC, EPI>(L, s);
   return launch_gemm3<1, NTW, WL, PRO, VEC, EPI>(L, s);
@@ -936,15 +948,17 @@ int gemm_bn(int M, int N, int epi) {
 // resource, see gemm_kernel) but also halve the number of workgroups: use them when the grid still
 // fills the 256 CUs, or when the 32-row grid would run a nearly empty second round.
 inline int gemm_rt(int M, int N, int epi) {
-  static int forced = -2, half_max = -1;
+  static int forced = -2, half_max = -1, ht3 = 1;
   if (forced == -2) {
     const char* e = getenv("DOSX_GEMM_RT");
     forced = e ? atoi(e) : -1;
     const char* h = getenv("DOSX_GEMM_HALF_MAX");
     half_max = h ? atoi(h) : 128;
+    const char* t = getenv("DOSX_GEMM_HT3");
+    ht3 = t ? atoi(t) : 1;
   }
   if (M <= 16) return 0;
-  if (forced >= 0 && forced <= 2 && !(forced == 2 && gemm_bn(M, N, epi) == 512)) return M <= BM && forced == 2 ? 1 : forced;
+  if (forced >= 0 && forced <= 3 && !(forced >= 2 && gemm_bn(M, N, epi) == 512)) return M <= BM && forced >= 2 ? 1 : forced;
   const int ntiles = ceil_div(N, gemm_bn(M, N, epi));
   const int wg1 = ceil_div(M, BM) * ntiles, wg2 = ceil_div(M, 2 * BM) * ntiles;
   // HALF (16-row) tiles: a kernel this small is one partial round of workgroups whichever way it is cut, so its
@@ -952,6 +966,9 @@ inline int gemm_rt(int M, int N, int epi) {
   if (wg1 <= half_max) return 0;
   if (M <= BM) return 1;
   if (gemm_bn(M, N, epi) == 512) return 1;
+  // one column tile, more 32-row blocks than CUs: 48-row workgroups (three 16-row sub-tiles) if those fit one round -
+  // the busiest CU then holds 48 rows instead of 64 (M = 9000: 188 workgroups instead of 282 / 141)
+  if (ht3 && ntiles == 1 && wg1 > 256 && ceil_div(M, 48) <= 256) return 3;
   if (wg2 >= 192) return 2;
   if (wg1 > 256 && wg1 <= 400 && wg2 >= 128) return 2;
   return 1;
@@ -959,7 +976,7 @@ inline int gemm_rt(int M, int N, int epi) {
 
 inline int gemm_rows_per_wg(int M, int N, int epi) {
   const int rt = gemm_rt(M, N, epi);
-  return rt == 0 ? 16 : BM * rt;
+  return rt == 0 ? 16 : (rt == 3 ? 48 : BM * rt);
 }
 
 extern "C" int dosx_gemm_partial_rows(int M, int N, int epi) {
@@ -1013,7 +1030,7 @@ extern "C" int dosx_gemm(const DosxGemm* gp, dosx_stream_t stream) {
   L.rt = gemm_rt(g.M, g.N, g.epi);
   int bn = gemm_bn(g.M, g.N, g.epi);
   if (g.stats_out && bn < g.N) bn = g.N <= 256 ? 256 : 512;
-  if (bn == 512 && L.rt == 2) L.rt = 1;
+  if (bn == 512 && L.rt >= 2) L.rt = 1;
   hipStream_t s = to_stream(stream);
   if (bn == 128) return dispatch_gemm<1>(L, s);
   if (bn == 256) return dispatch_gemm<2>(L, s);
