@@ -82,6 +82,21 @@ class Attn(C.Structure):
     ]
 
 
+class FfnBwd(C.Structure):
+    _fields_ = [
+        ("M", C.c_int32), ("H", C.c_int32),
+        ("dy", C.c_void_p), ("lddy", C.c_int32),
+        ("h", C.c_void_p), ("ldh", C.c_int32),
+        ("x", C.c_void_p), ("ldx", C.c_int32),
+        ("stats", C.c_void_p),
+        ("gamma", C.c_void_p),
+        ("w1", C.c_void_p), ("w2", C.c_void_p),
+        ("dh", C.c_void_p), ("lddh", C.c_int32),
+        ("dx", C.c_void_p), ("lddx", C.c_int32),
+        ("partials", C.c_void_p), ("partial_ld", C.c_int32),
+    ]
+
+
 class Ffn(C.Structure):
     _fields_ = [
         ("M", C.c_int32), ("H", C.c_int32),
@@ -132,6 +147,8 @@ _SIGS = {
     "dosx_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
     "dosx_ffn_supported": [_I],
     "dosx_ffn_fwd": [C.POINTER(Ffn), _P],
+    "dosx_ffn_bwd_partial_rows": [_I],
+    "dosx_ffn_bwd": [C.POINTER(FfnBwd), _P],
     "dosx_csr_workspace_bytes": [_I, C.POINTER(C.c_size_t)],
     "dosx_csr_build": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P],
     "dosx_collate": [_P] * 5 + [_I] * 3 + [_P] * 18 + [_P],

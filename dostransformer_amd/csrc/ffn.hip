@@ -237,6 +237,259 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Backward of the same half layer, one launch:
+//     dh  = (dy . W2) o [h > 0]                              [M,4H]   (written out: the fc1 weight gradient needs it)
+//     dx  = dy + LN1_bwd( dh . W1 )                          [M,H]
+//     partials[wg] = [ sum_rows dyl*xhat | sum_rows dyl ]    (dgamma | dbeta of LN1; dyl = dh . W1)
+// Same structure as the forward: the R x 4H tile of dh stays in LDS as the A operand of the second GEMM.  Both weight
+// matrices are read as stored (k-major: W2 [H][4H], W1 [4H][H]), so a staged chunk is 32 k-rows x 128 columns.
+constexpr int BLDW = FBN + 4;    // 132: padded rows of a k-major weight chunk
+
+template <bool HALF>
+__global__ __launch_bounds__(512) void ffn_bwd_kernel(const DosxFfnBwd a) {
+  extern __shared__ __align__(16) float sm[];
+  constexpr int R = HALF ? 16 : 32;
+  constexpr int ER = R / 8;
+  constexpr int NV = HALF ? 8 : 16;                // C elements per lane per 128-column block
+  const int H = a.H, H4 = 4 * a.H, M = a.M;
+  const int LDX = H + 4, LDT = H4 + 4;
+  float* Ys = sm;                                  // [R][LDX]  dy tile (A operand of the fc2 dgrad)
+  float* T = Ys + R * LDX;                         // [R][LDT]  dh tile (A operand of the fc1 dgrad)
+  float* ST = T + R * LDT;                         // 2 stage buffers [32][132]; later C tile [R][132] + Ps [8][2][128]
+  constexpr int STG = FBK * BLDW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int l15 = lane & 15, g4 = lane >> 4;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int m0 = blockIdx.x * R;
+  const int nk1 = H / FBK, nb1 = H4 / FBN, n1 = nb1 * nk1, n2 = H4 / FBK, nch = n1 + n2;
+
+  // epilogue operands of this wave's ER rows, fetched at kernel start (all 8 waves)
+  const int c0 = lane * 4;
+  const bool con = c0 < H;
+  float4 dyr[ER], xr[ER], gam = f4zero();
+  float mean[ER], rstd[ER];
+  if (con) gam = ld4(a.gamma + c0);
+#pragma unroll
+  for (int i = 0; i < ER; ++i) {
+    const int r = min(m0 + wave * ER + i, M - 1);
+    dyr[i] = ld4(a.dy + (size_t)r * a.lddy + (con ? c0 : 0));
+    xr[i] = ld4(a.x + (size_t)r * a.ldx + (con ? c0 : 0));
+    mean[i] = a.stats[2 * (size_t)r];
+    rstd[i] = a.stats[2 * (size_t)r + 1];
+  }
+
+  if (wave_u >= 4) {
+    // =============================== staging waves ===============================================
+    const int st = tid - 256;
+    const float* wlo = a.w1 < a.w2 ? a.w1 : a.w2;
+    const uint32_t d1 = (uint32_t)((const char*)a.w1 - (const char*)wlo), d2 = (uint32_t)((const char*)a.w2 - (const char*)wlo);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)wlo, 0, 0x7fffffff, 0x00020000);
+    uint32_t v1[4], v2[4], lds[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int lin = st + 256 * i, r = lin >> 5, c4 = (lin & 31) * 4;
+      v1[i] = d2 + (uint32_t)((r * H4 + c4) * 4);                         // phase 1: W2 rows k, columns cb*128 + c4
+      v2[i] = d1 + (uint32_t)((r * H + min(c4, H - 4)) * 4);              // phase 2: W1 rows k, columns c4 (< H, clamped)
+      lds[i] = (uint32_t)(r * BLDW + c4);
+    }
+    float4 r0[4], r1[4];
+    auto issue = [&](float4(&r)[4], int c) {
+      const int cu = __builtin_amdgcn_readfirstlane(c);
+      const bool p1 = cu < n1;
+      const int so = p1 ? ((cu % nk1) * FBK * H4 + (cu / nk1) * FBN) * 4 : (cu - n1) * FBK * H * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        r[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rW, p1 ? v1[i] : v2[i], so, 0));
+    };
+    auto store = [&](float* buf, const float4(&r)[4]) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) st4(buf + lds[i], r[i]);
+    };
+    auto copy_dh = [&]() {       // the finished dh tile -> HBM
+      const int per_row = H4 / 4;
+      for (int i = st; i < R * per_row; i += 256) {
+        const int r = i / per_row, c = (i % per_row) * 4;
+        if (m0 + r < M) st4(a.dh + (size_t)(m0 + r) * a.lddh + c, ld4(T + r * LDT + c));
+      }
+    };
+    issue(r0, 0);
+    issue(r1, 1);
+    store(ST, r0);
+    issue(r0, 2);
+    __syncthreads();                               // (matrix waves: Ys written) chunk 0 visible
+    for (int c = 0; c < nch; c += 2) {
+      if (c + 1 < nch) {
+        store(ST + STG, r1);
+        if (c + 3 < nch) issue(r1, c + 3);
+      }
+      __syncthreads();
+      if (c + 1 == n1) { __syncthreads(); copy_dh(); }
+      if (c + 1 >= nch) break;
+      if (c + 2 < nch) {
+        store(ST, r0);
+        if (c + 4 < nch) issue(r0, c + 4);
+      }
+      __syncthreads();
+      if (c + 2 == n1) { __syncthreads(); copy_dh(); }
+    }
+  } else {
+    // =============================== matrix waves ================================================
+    {   // dy tile -> Ys
+      const int r = tid >> 3, rr = min(m0 + r, M - 1);
+      for (int c = (tid & 7) * 4; c < H && r < R; c += 32) st4(Ys + r * LDX + c, ld4(a.dy + (size_t)rr * a.lddy + c));
+    }
+    __syncthreads();
+    int c = 0;
+    // C-fragment coordinates of this lane inside a 128-column block: rows crow(v), columns ccol(v)
+    auto crow = [&](int v) { return HALF ? 4 * g4 + (v & 3) : (v & 3) + 8 * (v >> 2) + 4 * hh; };
+    auto ccol = [&](int v) { return HALF ? wave * 32 + l15 + 16 * (v >> 2) : wave * 32 + l31; };
+    float acc[NV];
+    // ---- phase 1: dh tile, nb1 column blocks of 128, each nk1 chunks ----
+    for (int cb = 0; cb < nb1; ++cb) {
+      float hv[NV];                                // relu mask operand, in flight under the k-loop of the block
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+        hv[v] = a.h[(size_t)min(m0 + crow(v), M - 1) * a.ldh + cb * FBN + ccol(v)];
+      if constexpr (HALF) {
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        for (int kc = 0; kc < nk1; ++kc, ++c) {
+          const float* Ws = ST + (c & 1) * STG;
+#pragma unroll
+          for (int kk = 0; kk < FBK; kk += 16) {
+            const float4 av = ld4(Ys + l15 * LDX + kc * FBK + kk + 4 * g4);
+            const float* bp = Ws + (kk + 4 * g4) * BLDW + wave * 32 + l15;
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bp[0], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bp[16], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bp[BLDW], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bp[BLDW + 16], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bp[2 * BLDW], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bp[2 * BLDW + 16], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bp[3 * BLDW], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bp[3 * BLDW + 16], a1, 0, 0, 0);
+          }
+          __syncthreads();
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { acc[v] = a0[v]; acc[4 + v] = a1[v]; }
+      } else {
+        f32x16 a0;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) a0[v] = 0.f;
+        for (int kc = 0; kc < nk1; ++kc, ++c) {
+          const float* Ws = ST + (c & 1) * STG;
+#pragma unroll
+          for (int kk = 0; kk < FBK; kk += 8) {
+            const float4 av = ld4(Ys + l31 * LDX + kc * FBK + kk + 4 * hh);
+            const float* bp = Ws + (kk + 4 * hh) * BLDW + wave * 32 + l31;
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bp[0], a0, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bp[BLDW], a0, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bp[2 * BLDW], a0, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bp[3 * BLDW], a0, 0, 0, 0);
+          }
+          __syncthreads();
+        }
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] = a0[v];
+      }
+#pragma unroll
+      for (int v = 0; v < NV; ++v) T[crow(v) * LDT + cb * FBN + ccol(v)] = hv[v] > 0.f ? acc[v] : 0.f;
+    }
+    __syncthreads();                               // T complete (the staging waves copy it out from here on)
+    // ---- phase 2: dyl = dh . W1, one 128-column block, n2 chunks, A operand = T ----
+    if constexpr (HALF) {
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+      for (int kc = 0; kc < n2; ++kc, ++c) {
+        const float* Ws = ST + (c & 1) * STG;
+#pragma unroll
+        for (int kk = 0; kk < FBK; kk += 16) {
+          const float4 av = ld4(T + l15 * LDT + kc * FBK + kk + 4 * g4);
+          const float* bp = Ws + (kk + 4 * g4) * BLDW + wave * 32 + l15;
+          a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bp[0], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bp[16], a1, 0, 0, 0);
+          a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bp[BLDW], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bp[BLDW + 16], a1, 0, 0, 0);
+          a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bp[2 * BLDW], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bp[2 * BLDW + 16], a1, 0, 0, 0);
+          a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bp[3 * BLDW], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bp[3 * BLDW + 16], a1, 0, 0, 0);
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) { acc[v] = a0[v]; acc[4 + v] = a1[v]; }
+    } else {
+      f32x16 a0;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) a0[v] = 0.f;
+      for (int kc = 0; kc < n2; ++kc, ++c) {
+        const float* Ws = ST + (c & 1) * STG;
+#pragma unroll
+        for (int kk = 0; kk < FBK; kk += 8) {
+          const float4 av = ld4(T + l31 * LDT + kc * FBK + kk + 4 * hh);
+          const float* bp = Ws + (kk + 4 * hh) * BLDW + wave * 32 + l31;
+          a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bp[0], a0, 0, 0, 0);
+          a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bp[BLDW], a0, 0, 0, 0);
+          a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bp[2 * BLDW], a0, 0, 0, 0);
+          a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bp[3 * BLDW], a0, 0, 0, 0);
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[v] = a0[v];
+    }
+    float* Cs = ST;                                // C tile (the stage buffers are dead: the last chunk ended with a barrier)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) Cs[crow(v) * BLDW + ccol(v)] = acc[v];
+  }
+  __syncthreads();
+  // ---- row epilogue (8 waves x ER rows): LayerNorm backward over the row + residual; column sums for dgamma / dbeta ----
+  float4 pg = f4zero(), pb = f4zero();
+  {
+    const float* Cs = ST;
+    const float invH = 1.f / (float)H;
+#pragma unroll
+    for (int i = 0; i < ER; ++i) {
+      const int lr = wave * ER + i, r = m0 + lr;
+      const bool ok = con && r < M;                // (r < M is wave-uniform)
+      float4 xh = f4zero(), dxh = f4zero();
+      float s1 = 0.f, s2 = 0.f;
+      if (ok) {
+        const float4 dyl = ld4(Cs + lr * BLDW + c0);
+        xh = make_float4((xr[i].x - mean[i]) * rstd[i], (xr[i].y - mean[i]) * rstd[i], (xr[i].z - mean[i]) * rstd[i],
+                         (xr[i].w - mean[i]) * rstd[i]);
+        pg.x += dyl.x * xh.x; pg.y += dyl.y * xh.y; pg.z += dyl.z * xh.z; pg.w += dyl.w * xh.w;
+        pb = f4add(pb, dyl);
+        dxh = make_float4(dyl.x * gam.x, dyl.y * gam.y, dyl.z * gam.z, dyl.w * gam.w);
+        s1 = dxh.x + dxh.y + dxh.z + dxh.w;
+        s2 = dxh.x * xh.x + dxh.y * xh.y + dxh.z * xh.z + dxh.w * xh.w;
+      }
+      const float m1 = wave_sum(s1) * invH, m2 = wave_sum(s2) * invH;
+      if (ok)
+        st4(a.dx + (size_t)r * a.lddx + c0,
+            make_float4(rstd[i] * (dxh.x - m1 - xh.x * m2) + dyr[i].x, rstd[i] * (dxh.y - m1 - xh.y * m2) + dyr[i].y,
+                        rstd[i] * (dxh.z - m1 - xh.z * m2) + dyr[i].z, rstd[i] * (dxh.w - m1 - xh.w * m2) + dyr[i].w));
+    }
+  }
+  {
+    float* Ps = ST + STG;                          // [8][2][128], behind the C tile
+    if (con) {
+      st4(Ps + (wave * 2 + 0) * FBN + c0, pg);
+      st4(Ps + (wave * 2 + 1) * FBN + c0, pb);
+    }
+    __syncthreads();
+    float* prow = a.partials + (size_t)blockIdx.x * a.partial_ld;
+    for (int c = tid; c < 2 * H; c += 512) {
+      const int which = c / H, col = c % H;
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) s += Ps[(w * 2 + which) * FBN + col];
+      prow[which * H + col] = s;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int dosx_ffn_supported(int H) { return (H % 32) == 0 && H >= 32 && H <= 128; }
@@ -264,6 +517,41 @@ extern "C" int dosx_ffn_fwd(const DosxFfn* ap, dosx_stream_t stream) {
   }
   if (half) hipLaunchKernelGGL(ffn_fwd_kernel<true>, dim3(ceil_div(a.M, 16)), dim3(512), smem, to_stream(stream), a);
   else hipLaunchKernelGGL(ffn_fwd_kernel<false>, dim3(ceil_div(a.M, 32)), dim3(512), smem, to_stream(stream), a);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+static int ffn_bwd_half(int M) {
+  static int half_max = -1;
+  if (half_max < 0) { const char* e = getenv("DOSX_FFN_HALF_MAX"); half_max = e ? atoi(e) : 128; }
+  return ceil_div(M, 32) <= half_max;
+}
+
+extern "C" int dosx_ffn_bwd_partial_rows(int M) { return M <= 0 ? 0 : ceil_div(M, ffn_bwd_half(M) ? 16 : 32); }
+
+extern "C" int dosx_ffn_bwd(const DosxFfnBwd* ap, dosx_stream_t stream) {
+  DOSX_CHECK_ARG(ap != nullptr, "dosx_ffn_bwd: null descriptor");
+  const DosxFfnBwd& a = *ap;
+  if (a.M <= 0) return 0;
+  DOSX_CHECK_ARG(dosx_ffn_supported(a.H), "dosx_ffn_bwd: H=%d unsupported (multiple of 32, <= 128)", a.H);
+  DOSX_CHECK_ARG(a.dy && a.h && a.x && a.stats && a.gamma && a.w1 && a.w2 && a.dh && a.dx && a.partials, "dosx_ffn_bwd: null operand");
+  DOSX_CHECK_ARG((a.lddy & 3) == 0 && (a.ldh & 3) == 0 && (a.ldx & 3) == 0 && (a.lddh & 3) == 0 && (a.lddx & 3) == 0,
+                 "dosx_ffn_bwd: leading dimensions must be multiples of 4");
+  DOSX_CHECK_ARG(a.partial_ld >= 2 * a.H, "dosx_ffn_bwd: partial_ld %d < 2H", a.partial_ld);
+  const long long span = (const char*)a.w1 > (const char*)a.w2 ? (const char*)a.w1 - (const char*)a.w2 : (const char*)a.w2 - (const char*)a.w1;
+  DOSX_CHECK_ARG(span + (long long)16 * a.H * a.H < 0x7fffffffLL, "dosx_ffn_bwd: fc1 / fc2 weights more than 2 GiB apart");
+  const int H = a.H, H4 = 4 * H;
+  const bool half = ffn_bwd_half(a.M);
+  const int R = half ? 16 : 32;
+  const size_t smem = sizeof(float) * ((size_t)R * (H + 4) + (size_t)R * (H4 + 4) + 2 * (size_t)FBK * (FBN + 4));
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  if (half) hipLaunchKernelGGL(ffn_bwd_kernel<true>, dim3(ceil_div(a.M, 16)), dim3(512), smem, to_stream(stream), a);
+  else hipLaunchKernelGGL(ffn_bwd_kernel<false>, dim3(ceil_div(a.M, 32)), dim3(512), smem, to_stream(stream), a);
   DOSX_LAUNCH_CHECK();
   return 0;
 }

@@ -230,6 +230,9 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
     return x, (lay, fin, Sq, Bq, Nk, Bk, H, T, kvhat)
 
 
+_FUSED_FFN_BWD = __import__("os").environ.get("DOSX_FUSED_FFN_BWD", "1") == "1"
+
+
 def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: torch.Tensor, dkvhat: torch.Tensor, sink: GradSink):
     """dy: grad of the encoder output (after the final LN if there is one).  Accumulates into dkvhat.
     Returns the gradient w.r.t. the (expanded [Sq*Bq, H]) query input."""
@@ -254,15 +257,22 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: torch.Tensor, dkvhat: t
         # fc2
         _wgrad_linear(sink, G, lp + ".fc2.weight", lp + ".fc2.bias", rows, H, seg(dx), [seg(h)], keep=(dx,))
         dh = _empty(dev, rows, 4 * H)
-        ops.gemm(rows, 4 * H, [seg(dx)], P[lp + ".fc2.weight"], dh, w_layout=1, epi=EPI_RELU_MASK, aux=h)
+        dx1 = _empty(dev, rows, H)
+        fused = ops.ffn_supported(H) and _FUSED_FFN_BWD
+        if fused:           # both dgrad GEMMs + ReLU mask + LN1 backward + residual in one launch (csrc/ffn.hip)
+            rgp = ops.ffn_bwd_partial_rows(rows)
+            part = sink.scratch(rgp, 2 * H)
+            ops.ffn_bwd(rows, H, dx, h, x1, st1, g1, P[lp + ".fc1.weight"], P[lp + ".fc2.weight"], dh, dx1, part)
+        else:
+            ops.gemm(rows, 4 * H, [seg(dx)], P[lp + ".fc2.weight"], dh, w_layout=1, epi=EPI_RELU_MASK, aux=h)
         # fc1 (+ LN1 backward + residual)
         _wgrad_linear(sink, G, lp + ".fc1.weight", lp + ".fc1.bias", rows, 4 * H, seg(dh), [seg(x1)], keep=(dh,),
                       pro=PRO_ROWLN, pro_gamma=g1, pro_beta=b1, pro_stats=st1)
-        rgp = ops.gemm_partial_rows(rows, H, EPI_ROWLN_BWD)
-        part = sink.scratch(rgp, 2 * H)
-        dx1 = _empty(dev, rows, H)
-        ops.gemm(rows, H, [seg(dh)], P[lp + ".fc1.weight"], dx1, w_layout=1, epi=EPI_ROWLN_BWD, aux=x1, aux_stats=st1,
-                 epi_gamma=g1, res=dx, partials=part, partial_ld=2 * H)
+        if not fused:
+            rgp = ops.gemm_partial_rows(rows, H, EPI_ROWLN_BWD)
+            part = sink.scratch(rgp, 2 * H)
+            ops.gemm(rows, H, [seg(dh)], P[lp + ".fc1.weight"], dx1, w_layout=1, epi=EPI_ROWLN_BWD, aux=x1, aux_stats=st1,
+                     epi_gamma=g1, res=dx, partials=part, partial_ld=2 * H)
         sink.add(part, 0, G[lp + ".layer_norms.1.weight"], rgp, 2 * H, H)
         sink.add(part, H, G[lp + ".layer_norms.1.bias"], rgp, 2 * H, H)
         # attention (+ LN0 backward on the query side + residual); key side accumulates into dkvhat

@@ -299,6 +299,27 @@ def ffn_fwd(M: int, H: int, x: torch.Tensor, stats: torch.Tensor, gamma, beta, w
     _call("dosx_ffn_fwd", C.byref(a), _stream())
 
 
+def ffn_bwd_partial_rows(M: int) -> int:
+    return _lib.load().dosx_ffn_bwd_partial_rows(int(M))
+
+
+def ffn_bwd(M: int, H: int, dy: torch.Tensor, h: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, gamma, w1, w2,
+            dh: torch.Tensor, dx: torch.Tensor, partials: torch.Tensor) -> None:
+    """dh = (dy W2) o [h>0], dx = dy + LN1_bwd(dh W1), LN1 dgamma|dbeta partial rows — one launch
+    (include/dosx.h: DosxFfnBwd)."""
+    a = _lib.FfnBwd()
+    a.M, a.H = int(M), int(H)
+    a.dy, a.lddy = dy.data_ptr(), int(dy.stride(0))
+    a.h, a.ldh = h.data_ptr(), int(h.stride(0))
+    a.x, a.ldx = x.data_ptr(), int(x.stride(0))
+    a.stats, a.gamma = stats.data_ptr(), gamma.data_ptr()
+    a.w1, a.w2 = w1.data_ptr(), w2.data_ptr()
+    a.dh, a.lddh = dh.data_ptr(), int(dh.stride(0))
+    a.dx, a.lddx = dx.data_ptr(), int(dx.stride(0))
+    a.partials, a.partial_ld = partials.data_ptr(), int(partials.stride(0))
+    _call("dosx_ffn_bwd", C.byref(a), _stream())
+
+
 def gemm_partial_rows(M: int, N: int, epi: int) -> int:
     return _lib.load().dosx_gemm_partial_rows(int(M), int(N), int(epi))
 

@@ -287,6 +287,27 @@ typedef struct DosxFfn {
 int dosx_ffn_supported(int H);
 int dosx_ffn_fwd(const DosxFfn* a, dosx_stream_t stream);
 
+/* Backward of the same half layer in one launch (what autograd derives from layers/transformer.py:141-148):
+ *     dh = (dy . W2) o [h > 0]            [M,4H]  (written out: the fc1 weight gradient reads it)
+ *     dx = dy + LN1_bwd(dh . W1)          [M,H]   (dy also flows through the residual connection)
+ *     partials[r] = [ dgamma | dbeta ] of LN1 summed over the rows of workgroup r (dosx_ffn_bwd_partial_rows(M) rows,
+ *                   reduced by dosx_reduce_partials like every other slab)
+ * Same H support as the forward (dosx_ffn_supported).  The weight / bias gradients of fc1 and fc2 stay dosx_wgrad calls. */
+typedef struct DosxFfnBwd {
+  int32_t M, H;
+  const float* dy; int32_t lddy;
+  const float* h; int32_t ldh;            /* relu(fc1(LN1 x)) saved by the forward */
+  const float* x; int32_t ldx;            /* input of the half layer (pre-LN1) */
+  const float* stats;                     /* (mean, rstd) per row of x */
+  const float* gamma;                     /* LN1 weight */
+  const float* w1; const float* w2;       /* fc1.weight [4H,H], fc2.weight [H,4H] */
+  float* dh; int32_t lddh;
+  float* dx; int32_t lddx;
+  float* partials; int32_t partial_ld;
+} DosxFfnBwd;
+int dosx_ffn_bwd_partial_rows(int M);
+int dosx_ffn_bwd(const DosxFfnBwd* a, dosx_stream_t stream);
+
 /* Graph metadata ("CSR build") on the device, stream-ordered, no host round trip — counterpart of what PyG's
  * collate / to_dense_batch / torch_scatter derive per call from `edge_index` and `batch`
  * (DOSTransformer_phonon.py:48-56,86,209).

@@ -600,6 +600,37 @@ def test_ffn_fused_forward(M, H):
     assert err(out, xd + href @ w2.double().T + b2.double()) < TOL
 
 
+@pytest.mark.parametrize("M,H", [(33, 32), (100, 64), (3264, 128), (6528, 128), (1, 128), (50, 96)])
+def test_ffn_fused_backward(M, H):
+    """dosx_ffn_bwd == autograd of the pre-norm FFN half layer: dh (masked), dx (incl. the residual path), LN1 dgamma/dbeta."""
+    o = ops()
+    x = rnd(M, H, seed=1).double().requires_grad_(True)
+    g = rnd(H, seed=2).double().requires_grad_(True)
+    b = rnd(H, seed=3).double().requires_grad_(True)
+    w1, b1 = rnd(4 * H, H, seed=4, scale=0.2), rnd(4 * H, seed=5)
+    w2, b2 = rnd(H, 4 * H, seed=6, scale=0.2), rnd(H, seed=7)
+    dy = rnd(M, H, seed=8)
+    ln = F.layer_norm(x, (H,), g, b, 1e-5)
+    pre = ln @ w1.double().T + b1.double()
+    pre.retain_grad()
+    href = torch.relu(pre)
+    out = x + href @ w2.double().T + b2.double()
+    out.backward(dy.double())
+    xf = x.detach().float()
+    mu = xf.mean(1, keepdim=True)
+    rstd = 1 / torch.sqrt(xf.var(1, unbiased=False, keepdim=True) + 1e-5)
+    stats = torch.cat([mu, rstd], 1).contiguous()
+    rows = o.ffn_bwd_partial_rows(M)
+    dh = torch.empty(M, 4 * H, device=DEV)
+    dx = torch.empty(M, H, device=DEV)
+    part = torch.full((rows, 2 * H), float("nan"), device=DEV)
+    o.ffn_bwd(M, H, dy, href.detach().float().contiguous(), xf, stats, g.detach().float(), w1, w2, dh, dx, part)
+    assert err(dh, pre.grad) < TOL
+    assert err(dx, x.grad) < 5e-5
+    ps = part.double().sum(0)
+    assert err(ps[:H], g.grad) < 5e-5 and err(ps[H:], b.grad) < 5e-5
+
+
 # ---- §8f-3 periodic neighbour list (dosx_neighbor_count / _fill) --------------------------------------------------
 def _random_crystals(seed, sizes):
     rng = np.random.default_rng(seed)

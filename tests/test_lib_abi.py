@@ -66,7 +66,10 @@ def test_argument_validation_needs_no_gpu():
     assert b"K=0" in lib.dosx_last_error()
     assert lib.dosx_gemm(None, None) != 0
     assert lib.dosx_wgrad_splits(9000, 256, 384) >= 1
-    assert lib.dosx_gemm_partial_rows(100, 256, 2) == 4 and lib.dosx_gemm_partial_rows(100, 256, 5) == 8
+    # one partial row per workgroup: 16-row tiles for small grids, 48-row tiles for M = 9000 (gemm_rt in csrc/gemm.hip)
+    assert lib.dosx_gemm_partial_rows(100, 256, 2) == 7 and lib.dosx_gemm_partial_rows(100, 256, 5) == 14
+    assert lib.dosx_gemm_partial_rows(9000, 256, 2) == 188 and lib.dosx_gemm_partial_rows(13056, 128, 4) == 204
+    assert lib.dosx_ffn_bwd_partial_rows(3264) == 204 and lib.dosx_ffn_bwd_partial_rows(6528) == 204
 
 
 def test_product_path_fails_loudly_without_gpu():
