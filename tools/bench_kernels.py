@@ -122,6 +122,25 @@ def ffn_case(name, M, H):
           f"two GEMMs {us2:6.1f} us")
 
 
+def ffn_bwd_case(name, M, H):
+    x = torch.randn(M, H, device=DEV); stats = torch.rand(M, 2, device=DEV)
+    g = torch.randn(H, device=DEV)
+    w1, w2 = torch.randn(4 * H, H, device=DEV), torch.randn(H, 4 * H, device=DEV)
+    h = torch.randn(M, 4 * H, device=DEV); dy = torch.randn(M, H, device=DEV)
+    dh = torch.empty(M, 4 * H, device=DEV); dx = torch.empty(M, H, device=DEV)
+    part = torch.empty(ops.ffn_bwd_partial_rows(M), 2 * H, device=DEV)
+    us = timeit(lambda: ops.ffn_bwd(M, H, dy, h, x, stats, g, w1, w2, dh, dx, part))
+    part2 = torch.empty(ops.gemm_partial_rows(M, H, ops.EPI_ROWLN_BWD), 2 * H, device=DEV)
+    def two():
+        ops.gemm(M, 4 * H, [ops.seg(dy)], w2, dh, w_layout=1, epi=ops.EPI_RELU_MASK, aux=h)
+        ops.gemm(M, H, [ops.seg(dh)], w1, dx, w_layout=1, epi=ops.EPI_ROWLN_BWD, aux=x, aux_stats=stats, epi_gamma=g, res=dy,
+                 partials=part2, partial_ld=2 * H)
+    us2 = timeit(two)
+    fl = 16.0 * M * H * H
+    print(f"ffnb  {name:30s} M={M} H={H}: fused {us:6.1f} us {fl / us / 1e6:6.1f} TF/s ({100 * fl / us / 1e6 / 157.3:4.1f}%) | "
+          f"two GEMMs {us2:6.1f} us")
+
+
 def csr_case(name, B, kind="phonon"):
     from dostransformer_amd import synth
     g = synth.phonon_batch(B, seed=0, dtype=torch.float32, sort_edges=False) if kind == "phonon" else \
@@ -200,6 +219,9 @@ def main():
         ffn_case("FFN fwd 2B", R2, H)
         ffn_case("FFN fwd B", R1, H)
         ffn_case("FFN fwd roofline scale", 262144, H)
+        ffn_bwd_case("FFN bwd 2B", R2, H)
+        ffn_bwd_case("FFN bwd B", R1, H)
+        ffn_bwd_case("FFN bwd roofline scale", 262144, H)
     if w in ("all", "neighbors"):
         neighbor_case("phonon-set sized", 1500, 4.0)
         neighbor_case("phonon-set sized", 1500, 6.0)
