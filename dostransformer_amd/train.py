@@ -26,6 +26,7 @@ from . import ops
 from ._models import DOSTransformerBase
 from .batch import CrystalBatch, GraphMeta, bucket_sizes, graph_meta, pad_batch
 
+_EARLY_REDUCE = __import__("os").environ.get("DOSX_EARLY_REDUCE", "1") == "1"
 _META_TENSORS = ("src", "dst", "rowptr_dst", "perm_src", "rowptr_src", "graph_ptr", "node_graph", "dense_row", "inv_deg")
 
 
@@ -131,6 +132,8 @@ class Trainer:
         """Backward reaches the GNN trunk: reduce the early bucket's slabs on the side stream and start its
         all-reduce there, underneath the GNN backward (xGMI traffic overlaps compute; only the GNN bucket's
         all-reduce stays exposed at the end of the step)."""
+        if self.dist is None and self.replay and _EARLY_REDUCE:
+            return lambda sink: sink.flush_on_side()      # single GPU: just take the early slab reduction off the tail
         if self.dist is None or not self.bucketed or fp.n_late <= 0 or fp.n_late >= fp.total:
             return None
 
