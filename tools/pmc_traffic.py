@@ -12,8 +12,8 @@ from collections import defaultdict
 
 # bench.py roofline site -> substring that identifies the kernel symbol (template arguments included)
 SITES = {
-    "edge_mlp_gemm1_fwd": "gemm_kernel<2, 2, 0, 0, 1, 1>",
-    "ffn_fwd_transformer_self": "ffn_fwd_kernel",
+    "edge_mlp_gemm1_fwd": "gemm_kernel<3, 2, 0, 0, 1, 1>",     # 48-row tiles, LN epilogue (M ~ 9000, N 256, K 384)
+    "ffn_fwd_transformer_self": "ffn_fwd_kernel<false>",
     "scatter_add_fwd": "segment_reduce_kernel",
     "attention_fwd_transformer_self": "attn_fwd_stream_kernel<4>",
     "attention_fwd_transformer": "attn_fwd_stream_kernel<1>",
