@@ -233,8 +233,11 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
 _FUSED_FFN_BWD = __import__("os").environ.get("DOSX_FUSED_FFN_BWD", "1") == "1"
 
 
-def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: torch.Tensor, dkvhat: torch.Tensor, sink: GradSink):
-    """dy: grad of the encoder output (after the final LN if there is one).  Accumulates into dkvhat.
+def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: torch.Tensor, dkvhat: torch.Tensor, sink: GradSink,
+                dkv_fresh: bool = False):
+    """dy: grad of the encoder output (after the final LN if there is one).  Accumulates into dkvhat
+    (``dkv_fresh``: dkvhat is uninitialised and every row of it is a key row — the first layer processed
+    overwrites it, which saves the zero fill).
     Returns the gradient w.r.t. the (expanded [Sq*Bq, H]) query input."""
     lay, fin, Sq, Bq, Nk, Bk, H, T, kvhat = ctx
     dev = kvhat.device
@@ -282,8 +285,9 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: torch.Tensor, dkvhat: t
         dsc = _empty(dev, Bq, Sq, Nk)
         a = _attn_desc(Sq, Bq, Nk, Bk, H, qs, qb, x_in, kvhat, g0, b0)
         a.probs, a.qstats = probs.data_ptr(), qstats.data_ptr()
+        acc = 0 if (dkv_fresh and t == T - 1) else 1
         a.dout, a.dx, a.dscores, a.dkvhat, a.dkv_accumulate = dx1.data_ptr(), dxin.data_ptr(), dsc.data_ptr(), \
-            dkvhat.data_ptr(), 1
+            dkvhat.data_ptr(), acc
         a.partials_q = part.data_ptr()
         a.partials_kv = part.data_ptr() + 4 * Bq * nqt * 2 * H
         # dq (feeds the next layer's backward) on the main stream; dk+dv (feeds only the key-gradient
@@ -293,7 +297,7 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: torch.Tensor, dkvhat: t
         a2 = _attn_desc(Sq, Bq, Nk, Bk, H, qs, qb, x_in, kvhat, g0, b0)
         a2.probs, a2.qstats = probs.data_ptr(), qstats.data_ptr()
         a2.dout, a2.dx, a2.dscores, a2.dkvhat, a2.dkv_accumulate = dx1.data_ptr(), dxin.data_ptr(), dsc.data_ptr(), \
-            dkvhat.data_ptr(), 1
+            dkvhat.data_ptr(), acc
         a2.partials_q, a2.partials_kv = a.partials_q, a.partials_kv
         a2.flags = 4         # DOSX_ATTN_BWD_SKIP_DQ
         sink.on_side(lambda a2=a2: ops.attention_bwd(a2), (dx1, dsc, dxin))
@@ -442,8 +446,8 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
     sink.add(part, 3 * H, G["out_layer.bias"], r32, pld, 1)
     dkv = ops.zeros(dev, nmax * B + 1, H)     # spare row stays zero
     dhs = encoder_bwd(P, G, "transformer_source", c3, dx, dkv, sink)
-    dkvs = ops.zeros(dev, rows2, H)
-    ddosin = encoder_bwd(P, G, "transformer_self", c2, dhs, dkvs, sink)
+    dkvs = _empty(dev, rows2, H)              # self-attention: every row is a key row, the first layer overwrites
+    ddosin = encoder_bwd(P, G, "transformer_self", c2, dhs, dkvs, sink, dkv_fresh=True)
     sink.join()          # dkvs is produced on the side stream
     ops.rownorm_bwd(dkvs, kvs, rstd_s, ddosin, rows2, H, True)
     dpre = _empty(dev, rows2, H)
