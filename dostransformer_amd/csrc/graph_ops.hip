@@ -331,7 +331,18 @@ __global__ void embed_rows_bwd_kernel(const float* __restrict__ dout, int ld, co
   const int t = blockIdx.x;
   for (int c = threadIdx.x; c < width; c += blockDim.x) {
     float s = 0.f;
-    for (int r = 0; r < rows; ++r)
+    int r = 0;
+    // unconditional loads, 8 in flight (a load under `if (idx[r] == t)` made this a chain of `rows` exposed round
+    // trips: 9 us for 64 rows); same summation order
+    for (; r + 8 <= rows; r += 8) {
+      float v[8];
+      int k[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { k[u] = idx[r + u]; v[u] = dout[(size_t)(r + u) * ld + c]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (k[u] == t) s += v[u];
+    }
+    for (; r < rows; ++r)
       if (idx[r] == t) s += dout[(size_t)r * ld + c];
     dtable[(size_t)t * width + c] = s;
   }
