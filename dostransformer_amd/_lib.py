@@ -107,6 +107,8 @@ class Ffn(C.Structure):
         ("w2", C.c_void_p), ("b2", C.c_void_p),
         ("h", C.c_void_p), ("ldh", C.c_int32),
         ("out", C.c_void_p), ("ldo", C.c_int32),
+        ("fin_gamma", C.c_void_p), ("fin_beta", C.c_void_p),
+        ("fin_xhat", C.c_void_p), ("fin_rstd", C.c_void_p),
     ]
 
 

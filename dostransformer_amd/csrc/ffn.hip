@@ -223,16 +223,37 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
     }   // !HALF
   }
   __syncthreads();
-  // ---- row epilogue (8 waves x ER rows): out = C + b2 + x ----
+  // ---- row epilogue (8 waves x ER rows): out = C + b2 + x, optionally followed by the encoder's final LayerNorm ----
   {
     const float* Cs = ST;
+    const bool fin = a.fin_gamma != nullptr;
+    float4 fg = f4zero(), fb = f4zero();
+    if (fin && con) { fg = ld4(a.fin_gamma + c0); fb = ld4(a.fin_beta + c0); }
+    const float invH = 1.f / (float)H;
 #pragma unroll
     for (int i = 0; i < ER; ++i) {
       const int lr = wave * ER + i, r = m0 + lr;
-      if (!(con && r < M)) continue;
-      const float4 v = ld4(Cs + lr * (FBN + 4) + c0);
-      st4(a.out + (size_t)r * a.ldo + c0, make_float4(v.x + bias2.x + xres[i].x, v.y + bias2.y + xres[i].y,
-                                                       v.z + bias2.z + xres[i].z, v.w + bias2.w + xres[i].w));
+      const bool ok = con && r < M;                // (r < M is wave-uniform)
+      float4 o = f4zero();
+      if (ok) {
+        const float4 v = ld4(Cs + lr * (FBN + 4) + c0);
+        o = make_float4(v.x + bias2.x + xres[i].x, v.y + bias2.y + xres[i].y, v.z + bias2.z + xres[i].z,
+                        v.w + bias2.w + xres[i].w);
+      }
+      if (!fin) {
+        if (ok) st4(a.out + (size_t)r * a.ldo + c0, o);
+        continue;
+      }
+      const float mean = wave_sum(o.x + o.y + o.z + o.w) * invH;        // lanes beyond H / rows beyond M hold zeros
+      const float4 d = ok ? make_float4(o.x - mean, o.y - mean, o.z - mean, o.w - mean) : f4zero();
+      const float rstd = rsqrtf(wave_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w) * invH + DOSX_LN_EPS);
+      if (ok) {
+        const float4 xh = make_float4(d.x * rstd, d.y * rstd, d.z * rstd, d.w * rstd);
+        st4(a.fin_xhat + (size_t)r * H + c0, xh);
+        st4(a.out + (size_t)r * a.ldo + c0,
+            make_float4(xh.x * fg.x + fb.x, xh.y * fg.y + fb.y, xh.z * fg.z + fb.z, xh.w * fg.w + fb.w));
+        if (lane == 0) a.fin_rstd[r] = rstd;
+      }
     }
   }
 }
@@ -501,6 +522,7 @@ extern "C" int dosx_ffn_fwd(const DosxFfn* ap, dosx_stream_t stream) {
   DOSX_CHECK_ARG(dosx_ffn_supported(a.H), "dosx_ffn_fwd: H=%d unsupported (multiple of 32, <= 128)", a.H);
   DOSX_CHECK_ARG(a.x && a.stats && a.gamma && a.beta && a.w1 && a.b1 && a.w2 && a.b2 && a.h && a.out, "dosx_ffn_fwd: null operand");
   DOSX_CHECK_ARG((a.ldx & 3) == 0 && (a.ldh & 3) == 0 && (a.ldo & 3) == 0, "dosx_ffn_fwd: leading dimensions must be multiples of 4");
+  if (a.fin_gamma) DOSX_CHECK_ARG(a.fin_beta && a.fin_xhat && a.fin_rstd, "dosx_ffn_fwd: final LayerNorm needs beta / xhat / rstd");
   const long long span = (const char*)a.w1 > (const char*)a.w2 ? (const char*)a.w1 - (const char*)a.w2 : (const char*)a.w2 - (const char*)a.w1;
   DOSX_CHECK_ARG(span + (long long)16 * a.H * a.H < 0x7fffffffLL, "dosx_ffn_fwd: fc1 / fc2 weights more than 2 GiB apart");
   const int H = a.H, H4 = 4 * H;

@@ -189,6 +189,7 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
     dev = kvhat.device
     rows = Sq * Bq
     lay = []
+    fin_fused = None
     for t in range(T):
         lp = f"{pre}.layers.{t}"
         g0, b0 = P[lp + ".layer_norms.0.weight"], P[lp + ".layer_norms.0.bias"]
@@ -204,10 +205,16 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
         h = _empty(dev, rows, 4 * H)
         x2 = _empty(dev, rows, H)
         if ops.ffn_supported(H):
-            # both GEMMs of the feed-forward half in one launch (the 32 x 4H intermediate tile stays in LDS)
+            # both GEMMs of the feed-forward half in one launch (the 32 x 4H intermediate tile stays in LDS); the last
+            # layer also applies the encoder's final LayerNorm in its row epilogue
+            fin_args = None
+            if final_ln and t == T - 1:
+                fin_fused = (_empty(dev, rows, H), _empty(dev, rows))
+                fin_args = (P[pre + ".layer_norm.weight"], P[pre + ".layer_norm.bias"]) + fin_fused
             ev = ops.KERNEL_TIMER.start()
             ops.ffn_fwd(rows, H, x1, st1, P[lp + ".layer_norms.1.weight"], P[lp + ".layer_norms.1.bias"],
-                        P[lp + ".fc1.weight"], P[lp + ".fc1.bias"], P[lp + ".fc2.weight"], P[lp + ".fc2.bias"], h, x2)
+                        P[lp + ".fc1.weight"], P[lp + ".fc1.bias"], P[lp + ".fc2.weight"], P[lp + ".fc2.bias"], h, x2,
+                        fin=fin_args)
             ops.KERNEL_TIMER.stop(ev, f"ffn_fwd_{pre}", "ffn_fwd_kernel (fc1+relu+fc2 fused)", "mfma", 4.0 * rows * H * 4 * H)
         else:
             ev = ops.KERNEL_TIMER.start()
@@ -220,7 +227,9 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
         lay.append((x, qs, qb, x1, probs, qstats, st1, h))
         x, qs, qb = x2, Bq, 1
     fin = None
-    if final_ln:
+    if final_ln and fin_fused is not None:
+        fin = fin_fused                  # x already is the normalised output
+    elif final_ln:
         y = _empty(dev, rows, H)
         xhat = _empty(dev, rows, H)
         rstd = _empty(dev, rows)

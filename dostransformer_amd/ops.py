@@ -286,8 +286,9 @@ def ffn_supported(H: int) -> bool:
 
 
 def ffn_fwd(M: int, H: int, x: torch.Tensor, stats: torch.Tensor, gamma, beta, w1, b1, w2, b2, h: torch.Tensor,
-            out: torch.Tensor) -> None:
-    """out = x + fc2(relu(fc1(LN1(x)))), h = relu(fc1(LN1(x))) in one launch (include/dosx.h: DosxFfn)."""
+            out: torch.Tensor, fin=None) -> None:
+    """out = x + fc2(relu(fc1(LN1(x)))), h = relu(fc1(LN1(x))) in one launch (include/dosx.h: DosxFfn).
+    ``fin = (gamma, beta, xhat, rstd)``: also apply the encoder's final LayerNorm (out = LN(...), xhat / rstd saved)."""
     a = Ffn()
     a.M, a.H = int(M), int(H)
     a.x, a.ldx = x.data_ptr(), int(x.stride(0))
@@ -296,6 +297,8 @@ def ffn_fwd(M: int, H: int, x: torch.Tensor, stats: torch.Tensor, gamma, beta, w
     a.w1, a.b1, a.w2, a.b2 = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
     a.h, a.ldh = h.data_ptr(), int(h.stride(0))
     a.out, a.ldo = out.data_ptr(), int(out.stride(0))
+    if fin is not None:
+        a.fin_gamma, a.fin_beta, a.fin_xhat, a.fin_rstd = (t.data_ptr() for t in fin)
     _call("dosx_ffn_fwd", C.byref(a), _stream())
 
 

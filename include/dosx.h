@@ -283,6 +283,11 @@ typedef struct DosxFfn {
   const float* w2; const float* b2;       /* fc2.weight [H,4H], fc2.bias [H]  */
   float* h; int32_t ldh;
   float* out; int32_t ldo;
+  /* optional: the encoder's final LayerNorm (layers/transformer.py:76-77) applied to the result of the LAST layer in
+   * the same launch: with fin_gamma != NULL, `out` receives LN(x + ffn)*gamma + beta, fin_xhat [M,H] (row stride H) the
+   * normalised rows and fin_rstd [M] their 1/sigma (what dosx_layernorm would have produced from the un-normalised sum) */
+  const float* fin_gamma; const float* fin_beta;
+  float* fin_xhat; float* fin_rstd;
 } DosxFfn;
 int dosx_ffn_supported(int H);
 int dosx_ffn_fwd(const DosxFfn* a, dosx_stream_t stream);

@@ -597,7 +597,16 @@ def test_ffn_fused_forward(M, H):
     ln = F.layer_norm(xd, (H,), g.double(), b.double(), 1e-5)
     href = torch.relu(ln @ w1.double().T + b1.double())
     assert err(h, href) < TOL
-    assert err(out, xd + href @ w2.double().T + b2.double()) < TOL
+    ref = xd + href @ w2.double().T + b2.double()
+    assert err(out, ref) < TOL
+    # same launch with the encoder's final LayerNorm fused into the row epilogue
+    fg, fb = rnd(H, seed=8), rnd(H, seed=9)
+    xhat, rstd_o, y = torch.empty(M, H, device=DEV), torch.empty(M, device=DEV), torch.empty(M, H, device=DEV)
+    o.ffn_fwd(M, H, x, stats, g, b, w1, b1, w2, b2, h, y, fin=(fg, fb, xhat, rstd_o))
+    mu2 = ref.mean(1, keepdim=True)
+    rs2 = 1 / torch.sqrt(ref.var(1, unbiased=False, keepdim=True) + 1e-5)
+    assert err(xhat, (ref - mu2) * rs2) < 5e-5 and err(rstd_o, rs2[:, 0]) < 5e-5
+    assert err(y, (ref - mu2) * rs2 * fg.double() + fb.double()) < 5e-5
 
 
 @pytest.mark.parametrize("M,H", [(33, 32), (100, 64), (3264, 128), (6528, 128), (1, 128), (50, 96)])
