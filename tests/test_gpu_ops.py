@@ -34,7 +34,11 @@ def prelu(x, a):
 
 
 @pytest.mark.parametrize("M,N,K", [(100, 128, 64), (33, 256, 384), (257, 512, 128), (64, 64, 118), (5, 16, 41),
-                                    (1000, 512, 100), (77, 32, 4)])
+                                    (1000, 512, 100), (77, 32, 4),
+                                    # 48-row tiles (8192 < M <= 12288, one column tile): aligned, ragged, unaligned K
+                                    (9000, 128, 256), (10001, 96, 41), (12288, 128, 118), (8193, 256, 64),
+                                    # 32- and 64-row tiles with ragged edges
+                                    (5000, 100, 64), (20011, 128, 96)])
 @pytest.mark.parametrize("wl", [0, 1])
 def test_gemm_plain(M, N, K, wl):
     o = ops()
