@@ -312,6 +312,35 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const float* __restric
   rownorm_bwd_row(dxhat + (size_t)r * H, xhat + (size_t)r * H, rstd[r], dx + (size_t)r * H, H, lane, accumulate);
 }
 
+// out = (dx_in + rownorm_bwd(dxhat, xhat, rstd)) * act'(y): key-side LN backward + the LeakyReLU backward behind it
+__global__ __launch_bounds__(256) void rownorm_bwd_act_kernel(const float* __restrict__ dxhat,
+                                                              const float* __restrict__ xhat,
+                                                              const float* __restrict__ rstd,
+                                                              const float* __restrict__ dx_in,
+                                                              const float* __restrict__ y, float slope,
+                                                              float* __restrict__ out, int M, int H) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= M) return;
+  const size_t o = (size_t)r * H;
+  const float* g = dxhat + o;
+  const float* xh = xhat + o;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = lane * 4; c < H; c += 256) {
+    const float4 a = ld4(g + c), b = ld4(xh + c);
+    s1 += a.x + a.y + a.z + a.w;
+    s2 += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+  }
+  const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H, rs = rstd[r];
+  for (int c = lane * 4; c < H; c += 256) {
+    const float4 a = ld4(g + c), b = ld4(xh + c), d = ld4(dx_in + o + c), v = ld4(y + o + c);
+    const float4 t = make_float4(d.x + rs * (a.x - m1 - b.x * m2), d.y + rs * (a.y - m1 - b.y * m2),
+                                 d.z + rs * (a.z - m1 - b.z * m2), d.w + rs * (a.w - m1 - b.w * m2));
+    st4(out + o + c, make_float4(v.x > 0.f ? t.x : slope * t.x, v.y > 0.f ? t.y : slope * t.y,
+                                 v.z > 0.f ? t.z : slope * t.z, v.w > 0.f ? t.w : slope * t.w));
+  }
+}
+
 __global__ void fill_kernel(float* p, float v, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -468,8 +497,9 @@ extern "C" int dosx_dense_normalize(const float* x, const int32_t* dense_row, fl
   CHECK_H(H);
   DOSX_CHECK_ARG(kvhat && dense_rows >= 0, "dosx_dense_normalize: bad args");
   if (dense_rows > 0) {
-    hipError_t e = hipMemsetAsync(kvhat, 0, (size_t)dense_rows * H * sizeof(float), to_stream(stream));
-    DOSX_CHECK_ARG(e == hipSuccess, "dosx_dense_normalize: memset failed: %s", hipGetErrorString(e));
+    const size_t n = (size_t)dense_rows * H;      // (own fill kernel: 2.5 us where the runtime's memset kernel takes 5.5)
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_1d(n, 256)), dim3(256), 0, to_stream(stream), kvhat, 0.f, n);
+    DOSX_LAUNCH_CHECK();
   }
   if (N <= 0) return 0;
   DOSX_CHECK_ARG(x && dense_row && rstd_nodes, "dosx_dense_normalize: bad args");
@@ -496,6 +526,17 @@ extern "C" int dosx_rownorm(const float* x, float* xhat, float* rstd, int M, int
   CHECK_H(H);
   DOSX_CHECK_ARG(x && xhat && rstd, "dosx_rownorm: bad args");
   hipLaunchKernelGGL(rownorm_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, to_stream(stream), x, xhat, rstd, M, H);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_rownorm_bwd_act(const float* dxhat, const float* xhat, const float* rstd, const float* dx_in,
+                                    const float* y, float slope, float* out, int M, int H, dosx_stream_t stream) {
+  if (M <= 0) return 0;
+  CHECK_H(H);
+  DOSX_CHECK_ARG(dxhat && xhat && rstd && dx_in && y && out, "dosx_rownorm_bwd_act: bad args");
+  hipLaunchKernelGGL(rownorm_bwd_act_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, to_stream(stream), dxhat, xhat, rstd,
+                     dx_in, y, slope, out, M, H);
   DOSX_LAUNCH_CHECK();
   return 0;
 }

@@ -458,9 +458,8 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
     dkvs = _empty(dev, rows2, H)              # self-attention: every row is a key row, the first layer overwrites
     ddosin = encoder_bwd(P, G, "transformer_self", c2, dhs, dkvs, sink, dkv_fresh=True)
     sink.join()          # dkvs is produced on the side stream
-    ops.rownorm_bwd(dkvs, kvs, rstd_s, ddosin, rows2, H, True)
-    dpre = _empty(dev, rows2, H)
-    ops.act_bwd(ddosin, dosin, 0.01, dpre)
+    dpre = _empty(dev, rows2, H)         # key-side LN backward + the LeakyReLU backward behind it, one launch
+    ops.rownorm_bwd_act(dkvs, kvs, rstd_s, ddosin, dosin, 0.01, dpre, rows2, H)
     map0, map1 = rowmap(d=B, m=2 * B, c=1, off=0), rowmap(d=B, m=2 * B, c=1, off=B)
     _wgrad_linear(sink, G, "fc.weight", "fc.bias", S * B, H, seg(dpre, rmap=map0), a_g.segs, keep=(dpre,))
     _wgrad_linear(sink, G, "fc_prompt.weight", "fc_prompt.bias", S * B, H, seg(dpre, rmap=map1), a_s.segs, keep=(dpre,))

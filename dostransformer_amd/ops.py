@@ -495,6 +495,11 @@ def rownorm_bwd(dxhat, xhat, rstd, dx, M, H, accumulate):
     _call("dosx_rownorm_bwd", _p(dxhat), _p(xhat), _p(rstd), _p(dx), M, H, int(accumulate), _stream())
 
 
+def rownorm_bwd_act(dxhat, xhat, rstd, dx_in, y, slope, out, M, H):
+    """out = (dx_in + rownorm_bwd(dxhat, xhat, rstd)) * (y > 0 ? 1 : slope)   (include/dosx.h: dosx_rownorm_bwd_act)."""
+    _call("dosx_rownorm_bwd_act", _p(dxhat), _p(xhat), _p(rstd), _p(dx_in), _p(y), float(slope), _p(out), M, H, _stream())
+
+
 def layernorm(x, gamma, beta, y, xhat, rstd, M, H):
     _call("dosx_layernorm", _p(x), _p(gamma), _p(beta), _p(y), _p(xhat), _p(rstd), M, H, _stream())
 

@@ -189,6 +189,11 @@ int dosx_dense_normalize_bwd(const float* dkvhat, const float* kvhat, const floa
 int dosx_rownorm(const float* x, float* xhat, float* rstd, int M, int H, dosx_stream_t stream);
 int dosx_rownorm_bwd(const float* dxhat, const float* xhat, const float* rstd, float* dx, int M, int H,
                      int accumulate, dosx_stream_t stream);
+/* The same followed by the backward of the (Leaky)ReLU that produced the normalised rows' input y
+ * (DOSTransformer_phonon.py:103,106 `F.leaky_relu(self.fc(...))` feeding the self-attention keys):
+ *     out = (dx_in + rownorm_bwd(dxhat, xhat, rstd)) * (y > 0 ? 1 : slope)         one launch instead of two */
+int dosx_rownorm_bwd_act(const float* dxhat, const float* xhat, const float* rstd, const float* dx_in, const float* y,
+                         float slope, float* out, int M, int H, dosx_stream_t stream);
 /* y = LN(x)*gamma+beta (layers/transformer.py:76-77); saves xhat, rstd. */
 int dosx_layernorm(const float* x, const float* gamma, const float* beta, float* y, float* xhat, float* rstd,
                    int M, int H, dosx_stream_t stream);

@@ -582,6 +582,23 @@ def test_csr_build_matches_host(B, seed):
     assert int(r["n_max"].item()) == ref.n_max
 
 
+@pytest.mark.parametrize("M,H", [(7, 16), (100, 128), (3000, 256)])
+def test_rownorm_bwd_act(M, H):
+    """dosx_rownorm_bwd_act == autograd of  xhat = LN_noaffine(leaky_relu(pre))  plus an extra gradient on leaky_relu(pre)."""
+    o = ops()
+    pre = rnd(M, H, seed=1).double().requires_grad_(True)
+    y = F.leaky_relu(pre, 0.01)
+    xhat = F.layer_norm(y, (H,), None, None, 1e-5)
+    dxhat, dy_extra = rnd(M, H, seed=2), rnd(M, H, seed=3)
+    (xhat * dxhat.double()).sum().backward(retain_graph=True)
+    y.backward(dy_extra.double())
+    yf = y.detach().float()
+    rstd = (1 / torch.sqrt(yf.double().var(1, unbiased=False) + 1e-5)).float()
+    out = torch.empty(M, H, device=DEV)
+    o.rownorm_bwd_act(dxhat, xhat.detach().float().contiguous(), rstd, dy_extra, yf, 0.01, out, M, H)
+    assert err(out, pre.grad) < 5e-5
+
+
 @pytest.mark.parametrize("M,H", [(33, 32), (100, 64), (3264, 128), (6528, 128), (1, 128)])
 def test_ffn_fused_forward(M, H):
     """dosx_ffn_fwd == the two GEMMs of layers/transformer.py:141-148 (pre-norm FFN with residual)."""
