@@ -123,6 +123,7 @@ _SIGS = {
     "dosx_gemm": [C.POINTER(Gemm), _P],
     "dosx_wgrad_splits": [_I, _I, _I],
     "dosx_wgrad": [C.POINTER(Wgrad), _P],
+    "dosx_wgrad_grouped": [C.POINTER(Wgrad), _I, _P],
     "dosx_reduce_partials": [C.POINTER(ReduceJob), _I, _P],
     "dosx_edge_feat_sh1": [_P, _P, _I, _F, _P],
     "dosx_segment_reduce": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],

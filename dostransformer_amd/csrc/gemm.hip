@@ -1049,6 +1049,7 @@ struct WgradLaunch {
   DosxWgrad g;
   int vecA;
   int vecY;
+  int variant;     // grouped launches: 0..3 = fast vectorised path with prologue NONE / PRELU / LN_PRELU / ROWLN, -1 = not groupable
 };
 
 // Wave-specialised like gemm_kernel: waves 0-3 multiply (one 32x32 sub-tile each), waves 4-7 stage the
@@ -1057,18 +1058,19 @@ struct WgradLaunch {
 // tile lies inside one K-segment, so all lane offsets are fixed and a chunk advances scalar offsets
 // only (buffer loads; rows beyond M read as zero through the buffer bounds: no masks, no vector ALU
 // beyond the prologue transform).  FAST = 0: generic pointer path (any map, ragged everything).
+constexpr int WSTG = 2 * BM * LDT;                        // floats of one stage buffer: Ys | Xs
+
 template <int PRO, int VEC, int FAST>
-__global__ __launch_bounds__(512) void wgrad_kernel(const WgradLaunch L) {
+__device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, float* __restrict__ Sm) {
   const DosxWgrad& g = L.g;
-  constexpr int STG = 2 * BM * LDT;                       // floats of one stage buffer: Ys | Xs
-  __shared__ __align__(16) float Sm[2 * STG];
+  constexpr int STG = WSTG;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   // 1-D grid, the M-split index varies fastest: workgroups are dealt to the 8 XCDs round-robin by linear id,
   // so (with 8 | nsplit) all the (n, k) tiles of one M-split land on the SAME XCD and share its L2: every
   // dY / A row of the split crosses the fabric once instead of once per tile that uses it
   const int ntk = (g.K + WT - 1) / WT;
-  const int z = blockIdx.x % g.nsplit, tile = blockIdx.x / g.nsplit;
+  const int z = bid % g.nsplit, tile = bid / g.nsplit;
   const int bx = tile % ntk, by = tile / ntk;
   const int k0 = bx * WT, n0 = by * WT;
   const int M = g.M, N = g.N, K = g.K;
@@ -1290,6 +1292,41 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradLaunch L) {
   }
 }
 
+template <int PRO, int VEC, int FAST>
+__global__ __launch_bounds__(512) void wgrad_kernel(const WgradLaunch L) {
+  __shared__ __align__(16) float Sm[2 * WSTG];
+  wgrad_body<PRO, VEC, FAST>(L, (int)blockIdx.x, Sm);
+}
+
+// Grouped launch: ONE grid over several weight-gradient jobs (the jobs travel as a kernel argument like the slab
+// reduction's).  Interleaved one by one with the dgrad chain, each job is a kernel of 256-384 workgroups that shares the
+// matrix pipes with whatever the main stream runs; issued together they are one saturating grid with no tails.
+constexpr int WG_MAX_JOBS = 12;
+struct WgradGroup {
+  WgradLaunch job[WG_MAX_JOBS];
+  int first_block[WG_MAX_JOBS + 1];
+  int n;
+};
+static_assert(sizeof(WgradGroup) <= 4000, "WgradGroup must fit the kernel argument segment");
+
+__global__ __launch_bounds__(512) void wgrad_grouped_kernel(const WgradGroup G) {
+  __shared__ __align__(16) float Sm[2 * WSTG];
+  int lo = 0, hi = G.n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (G.first_block[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const WgradLaunch& L = G.job[lo];
+  const int bid = (int)blockIdx.x - G.first_block[lo];
+  switch (L.variant) {             // workgroup-uniform
+    case 0: wgrad_body<DOSX_PRO_NONE, 1, 1>(L, bid, Sm); break;
+    case 1: wgrad_body<DOSX_PRO_PRELU, 1, 1>(L, bid, Sm); break;
+    case 2: wgrad_body<DOSX_PRO_LN_PRELU, 1, 1>(L, bid, Sm); break;
+    case 3: wgrad_body<DOSX_PRO_ROWLN, 1, 1>(L, bid, Sm); break;
+    default: break;
+  }
+}
+
 // Jobs travel as a kernel argument (no device-side table, no host->device copy, graph-capturable).
 // Blocks are mapped to (job, 1024-element slice) through the prefix array `first_block`.
 constexpr int RP_MAX_JOBS = 64;
@@ -1360,9 +1397,10 @@ extern "C" int dosx_wgrad_splits(int M, int N, int K) {
   return s;
 }
 
-extern "C" int dosx_wgrad(const DosxWgrad* gp, dosx_stream_t stream) {
-  DOSX_CHECK_ARG(gp != nullptr, "dosx_wgrad: null descriptor");
-  const DosxWgrad& g = *gp;
+namespace {
+
+// validation + launch parameters of one job; `fast` / `vec` select the kernel variant
+int wgrad_prepare(const DosxWgrad& g, WgradLaunch& L, int& vec, bool& fast, int& blocks) {
   DOSX_CHECK_ARG(g.N > 0 && g.K > 0 && g.nsplit >= 1, "dosx_wgrad: bad dims N=%d K=%d nsplit=%d", g.N, g.K, g.nsplit);
   DOSX_CHECK_ARG(g.nseg >= 1 && g.nseg <= 3 && g.slab && g.dy.p, "dosx_wgrad: bad operands");
   int ksum = 0;
@@ -1372,47 +1410,96 @@ extern "C" int dosx_wgrad(const DosxWgrad* gp, dosx_stream_t stream) {
   }
   DOSX_CHECK_ARG(ksum == g.K, "dosx_wgrad: segment widths sum to %d, K=%d", ksum, g.K);
   DOSX_CHECK_ARG(g.dy.map.d > 0, "dosx_wgrad: dy.map.d must be > 0");
-  WgradLaunch L;
   L.g = g;
   L.vecA = seg_vec_ok(g.a, g.nseg) && (g.K & 3) == 0;
   if (g.pro == DOSX_PRO_LN_PRELU || g.pro == DOSX_PRO_ROWLN)
     L.vecA = L.vecA && aligned16(g.pro_gamma) && aligned16(g.pro_beta);
   L.vecY = ((g.dy.ld & 3) == 0) && aligned16(g.dy.p) && (g.N & 3) == 0;
-  dim3 grid(ceil_div(g.K, WT) * ceil_div(g.N, WT) * g.nsplit);
-  hipStream_t st = to_stream(stream);
-  const int vec = L.vecA && L.vecY;
+  blocks = ceil_div(g.K, WT) * ceil_div(g.N, WT) * g.nsplit;
+  vec = L.vecA && L.vecY;
   // fast (buffer-addressed) staging: affine row maps (+ optional gather on A), K tiles inside one segment,
   // every byte offset below 2^31
   auto affine = [](const DosxRowMap& m) { return m.d >= (1 << 30) && m.c >= 1 && m.off >= 0; };
-  bool fast = vec && g.M > 0 && affine(g.dy.map) && g.dy.map.idx == nullptr &&
-              ((size_t)g.M * g.dy.map.c + g.dy.map.off) * (size_t)g.dy.ld * 4 < 0x7fffffffull;
+  fast = vec && g.M > 0 && affine(g.dy.map) && g.dy.map.idx == nullptr &&
+         ((size_t)g.M * g.dy.map.c + g.dy.map.off) * (size_t)g.dy.ld * 4 < 0x7fffffffull;
   for (int i = 0; fast && i < g.nseg; ++i) {
     const DosxSeg& sg = g.a[i];
     fast = affine(sg.map) && (g.nseg == 1 || (sg.width % WT) == 0) && (size_t)sg.ld * 4 < 0x7fffffffull &&
            ((size_t)g.M * sg.map.c + sg.map.off) * (size_t)(sg.map.idx ? 4 : (size_t)sg.ld * 4) < 0x7fffffffull;
   }
+  if (!vec) DOSX_CHECK_ARG(g.pro == DOSX_PRO_NONE, "dosx_wgrad: prologue %d needs 4-float aligned operands", g.pro);
+  DOSX_CHECK_ARG(g.pro >= DOSX_PRO_NONE && g.pro <= DOSX_PRO_ROWLN, "dosx_wgrad: bad prologue %d", g.pro);
+  L.variant = (vec && fast) ? (g.pro == DOSX_PRO_NONE ? 0 : g.pro == DOSX_PRO_PRELU ? 1 : g.pro == DOSX_PRO_LN_PRELU ? 2 : 3) : -1;
+  return 0;
+}
+
+int wgrad_launch_one(const WgradLaunch& L, int vec, bool fast, int blocks, hipStream_t st) {
+  const DosxWgrad& g = L.g;
+  dim3 grid(blocks);
   if (!vec) {
-    DOSX_CHECK_ARG(g.pro == DOSX_PRO_NONE, "dosx_wgrad: prologue %d needs 4-float aligned operands", g.pro);
     hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_NONE, 0, 0>), grid, dim3(512), 0, st, L);
   } else if (fast) {
     switch (g.pro) {
       case DOSX_PRO_NONE: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_NONE, 1, 1>), grid, dim3(512), 0, st, L); break;
       case DOSX_PRO_PRELU: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_PRELU, 1, 1>), grid, dim3(512), 0, st, L); break;
       case DOSX_PRO_LN_PRELU: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_LN_PRELU, 1, 1>), grid, dim3(512), 0, st, L); break;
-      case DOSX_PRO_ROWLN: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_ROWLN, 1, 1>), grid, dim3(512), 0, st, L); break;
-      default: DOSX_CHECK_ARG(false, "dosx_wgrad: bad prologue %d", g.pro);
+      default: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_ROWLN, 1, 1>), grid, dim3(512), 0, st, L); break;
     }
   } else {
     switch (g.pro) {
       case DOSX_PRO_NONE: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_NONE, 1, 0>), grid, dim3(512), 0, st, L); break;
       case DOSX_PRO_PRELU: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_PRELU, 1, 0>), grid, dim3(512), 0, st, L); break;
       case DOSX_PRO_LN_PRELU: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_LN_PRELU, 1, 0>), grid, dim3(512), 0, st, L); break;
-      case DOSX_PRO_ROWLN: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_ROWLN, 1, 0>), grid, dim3(512), 0, st, L); break;
-      default: DOSX_CHECK_ARG(false, "dosx_wgrad: bad prologue %d", g.pro);
+      default: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_ROWLN, 1, 0>), grid, dim3(512), 0, st, L); break;
     }
   }
   DOSX_LAUNCH_CHECK();
   return 0;
+}
+
+}  // namespace
+
+extern "C" int dosx_wgrad(const DosxWgrad* gp, dosx_stream_t stream) {
+  DOSX_CHECK_ARG(gp != nullptr, "dosx_wgrad: null descriptor");
+  WgradLaunch L;
+  int vec = 0, blocks = 0;
+  bool fast = false;
+  if (int rc = wgrad_prepare(*gp, L, vec, fast, blocks)) return rc;
+  return wgrad_launch_one(L, vec, fast, blocks, to_stream(stream));
+}
+
+extern "C" int dosx_wgrad_grouped(const DosxWgrad* jobs, int n_jobs, dosx_stream_t stream) {
+  if (n_jobs <= 0) return 0;
+  DOSX_CHECK_ARG(jobs != nullptr, "dosx_wgrad_grouped: null job table");
+  hipStream_t st = to_stream(stream);
+  WgradGroup G;
+  G.n = 0;
+  int blocks_total = 0;
+  auto flush = [&]() -> int {
+    if (G.n == 0) return 0;
+    G.first_block[G.n] = blocks_total;
+    hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(blocks_total), dim3(512), 0, st, G);
+    DOSX_LAUNCH_CHECK();
+    G.n = 0;
+    blocks_total = 0;
+    return 0;
+  };
+  for (int i = 0; i < n_jobs; ++i) {
+    WgradLaunch L;
+    int vec = 0, blocks = 0;
+    bool fast = false;
+    if (int rc = wgrad_prepare(jobs[i], L, vec, fast, blocks)) return rc;
+    if (L.variant < 0) {                      // (unaligned / non-affine operands: its own launch, as dosx_wgrad would)
+      if (int rc = wgrad_launch_one(L, vec, fast, blocks, st)) return rc;
+      continue;
+    }
+    G.job[G.n] = L;
+    G.first_block[G.n] = blocks_total;
+    blocks_total += blocks;
+    if (++G.n == WG_MAX_JOBS)
+      if (int rc = flush()) return rc;
+  }
+  return flush();
 }
 
 extern "C" int dosx_reduce_partials(const DosxReduceJob* jobs_host, int n_jobs, dosx_stream_t stream) {

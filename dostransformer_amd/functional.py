@@ -49,7 +49,11 @@ def _wgrad_linear(sink: GradSink, G: Params, wkey: str, bkey: Optional[str], M: 
     ns = ops.wgrad_splits(M, N, K)
     slab = sink.scratch(ns, N, K)
     slab_b = sink.scratch(ns, N) if bkey is not None else None
-    sink.on_side(lambda: ops.wgrad(M, N, dy, segs, slab, slab_b, ns, **pro), keep)
+    if GradSink.group_wgrad:
+        sink.defer_wgrad(ops.wgrad_desc(M, N, dy, segs, slab, slab_b, ns, **pro),
+                         tuple(keep) + tuple(t for t in pro.values() if isinstance(t, torch.Tensor)))
+    else:
+        sink.on_side(lambda: ops.wgrad(M, N, dy, segs, slab, slab_b, ns, **pro), keep)
     sink.add(slab, 0, G[wkey], ns, N * K, N * K)
     if bkey is not None:
         sink.add(slab_b, 0, G[bkey], ns, N, N)

@@ -331,8 +331,8 @@ def wgrad_splits(M: int, N: int, K: int) -> int:
     return _lib.load().dosx_wgrad_splits(int(M), int(N), int(K))
 
 
-def wgrad(M: int, N: int, dy: Seg, segs: Sequence[Seg], slab: torch.Tensor, slab_bias: Optional[torch.Tensor],
-          nsplit: int, *, pro: int = PRO_NONE, pro_gamma=None, pro_beta=None, pro_alpha=None, pro_stats=None) -> None:
+def wgrad_desc(M: int, N: int, dy: Seg, segs: Sequence[Seg], slab: torch.Tensor, slab_bias: Optional[torch.Tensor],
+               nsplit: int, *, pro: int = PRO_NONE, pro_gamma=None, pro_beta=None, pro_alpha=None, pro_stats=None) -> Wgrad:
     g = Wgrad()
     g.M, g.N = int(M), int(N)
     g.K = int(sum(s.width for s in segs))
@@ -342,7 +342,21 @@ def wgrad(M: int, N: int, dy: Seg, segs: Sequence[Seg], slab: torch.Tensor, slab
     g.pro = pro
     g.pro_gamma, g.pro_beta, g.pro_alpha, g.pro_stats = _p(pro_gamma), _p(pro_beta), _p(pro_alpha), _p(pro_stats)
     g.slab, g.slab_bias, g.nsplit = slab.data_ptr(), _p(slab_bias), int(nsplit)
+    return g
+
+
+def wgrad(M: int, N: int, dy: Seg, segs: Sequence[Seg], slab: torch.Tensor, slab_bias: Optional[torch.Tensor],
+          nsplit: int, **pro) -> None:
+    g = wgrad_desc(M, N, dy, segs, slab, slab_bias, nsplit, **pro)
     _call("dosx_wgrad", C.byref(g), _stream())
+
+
+def wgrad_grouped(descs: Sequence[Wgrad]) -> None:
+    """All the jobs in as few launches as possible (include/dosx.h: dosx_wgrad_grouped)."""
+    if not descs:
+        return
+    arr = (Wgrad * len(descs))(*descs)
+    _call("dosx_wgrad_grouped", arr, len(descs), _stream())
 
 
 class GradSink:
@@ -375,6 +389,22 @@ class GradSink:
     def side_stream(device):
         """The (process-wide) side stream used by recorded programs on ``device`` (None before the first recording)."""
         return GradSink._side_streams.get((str(device), False))
+
+    # Weight-gradient jobs can be collected and issued as ONE grouped launch at the next flush instead of one kernel
+    # each on the side stream (DESIGN.md 3.1: interleaved they cost the dgrad chain ~0.45 ms per step of interference).
+    group_wgrad = __import__("os").environ.get("DOSX_GROUP_WGRAD", "0") == "1"
+
+    def defer_wgrad(self, desc, keep=()) -> None:
+        self._keep.extend(keep)
+        if not hasattr(self, "_wjobs"):
+            self._wjobs = []
+        self._wjobs.append(desc)
+
+    def run_grouped(self) -> None:
+        jobs = getattr(self, "_wjobs", [])
+        if jobs:
+            self._wjobs = []
+            wgrad_grouped(jobs)
 
     def on_side(self, fn, keep=()) -> None:
         """Run ``fn`` (kernel launches) on the side stream, ordered after everything launched so far on
@@ -418,10 +448,12 @@ class GradSink:
         """Reduce the jobs collected so far WITHOUT joining: the reduction is queued on the side stream behind the
         weight-gradient kernels it depends on (and behind everything the main stream has issued up to here), so the
         main stream runs on.  Used for the early gradient bucket of data-parallel training."""
+        self.run_grouped()
         jobs, self.jobs = self.jobs, []
         self.on_side(lambda: self._reduce(jobs))
 
     def flush(self):
+        self.run_grouped()
         self.join()
         jobs, self.jobs = self.jobs, []
         self._reduce(jobs)

@@ -126,6 +126,9 @@ typedef struct DosxWgrad {
 } DosxWgrad;
 int dosx_wgrad_splits(int M, int N, int K);
 int dosx_wgrad(const DosxWgrad* g, dosx_stream_t stream);
+/* The same for `n_jobs` independent jobs in as few launches as possible (one grid over up to 12 jobs at a time; jobs
+ * with unaligned or non-affine operands get their own launch).  Results are identical to n_jobs dosx_wgrad calls. */
+int dosx_wgrad_grouped(const DosxWgrad* jobs, int n_jobs, dosx_stream_t stream);
 
 /* Batched deterministic reduction of partial slabs: dst[i] (+)= sum_s src[s*stride + i]. */
 typedef struct DosxReduceJob {
