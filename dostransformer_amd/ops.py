@@ -359,6 +359,9 @@ def wgrad_grouped(descs: Sequence[Wgrad]) -> None:
     _call("dosx_wgrad_grouped", arr, len(descs), _stream())
 
 
+_LPT = __import__("os").environ.get("DOSX_WGRAD_LPT", "1") == "1"
+
+
 class GradSink:
     """Collects the partial-sum slabs produced during a backward pass and reduces all of them
     into the parameter-gradient buffers with ONE deterministic kernel launch per 'wave'
@@ -392,7 +395,7 @@ class GradSink:
 
     # Weight-gradient jobs can be collected and issued as ONE grouped launch at the next flush instead of one kernel
     # each on the side stream (interleaved they cost the dgrad chain ~0.45 ms per step of interference).
-    group_wgrad = __import__("os").environ.get("DOSX_GROUP_WGRAD", "0") == "1"
+    group_wgrad = __import__("os").environ.get("DOSX_GROUP_WGRAD", "1") == "1"
 
     def defer_wgrad(self, desc, keep=()) -> None:
         self._keep.extend(keep)
@@ -404,6 +407,8 @@ class GradSink:
         jobs = getattr(self, "_wjobs", [])
         if jobs:
             self._wjobs = []
+            if _LPT:      # biggest jobs first: the tail of the grid is then made of the small ones
+                jobs = sorted(jobs, key=lambda g: -(g.M * g.N * g.K))
             wgrad_grouped(jobs)
 
     def on_side(self, fn, keep=()) -> None:

@@ -582,6 +582,47 @@ def test_csr_build_matches_host(B, seed):
     assert int(r["n_max"].item()) == ref.n_max
 
 
+def test_wgrad_grouped_is_bitwise_the_single_launches():
+    """dosx_wgrad_grouped over a mixed job list (all four fast prologues, a gather, an unaligned job that falls back to
+    its own launch, more than 12 jobs so that two grouped launches happen) == the same jobs through dosx_wgrad."""
+    o = ops()
+    jobs, outs = [], []
+
+    def add(M, N, K, seed, **kw):
+        dy, a = rnd(M, N, seed=seed), rnd(M, K, seed=seed + 1)
+        ns = o.wgrad_splits(M, N, K)
+        pair = []
+        for _ in range(2):
+            pair.append((torch.full((ns, N, K), float("nan"), device=DEV), torch.full((ns, N), float("nan"), device=DEV)))
+        segs = kw.pop("segs", None) or [o.seg(a)]
+        keep = (dy, a, segs)
+        jobs.append((M, N, dy, segs, pair, ns, kw, keep))
+
+    H = 64
+    add(900, 128, 64, 1)
+    add(3000, 256, 128, 3, pro=o.PRO_PRELU, pro_alpha=torch.tensor([0.25], device=DEV))
+    add(1000, 64, 128, 5, pro=o.PRO_LN_PRELU, pro_gamma=rnd(128, seed=50), pro_beta=rnd(128, seed=51),
+        pro_alpha=torch.tensor([0.1], device=DEV))
+    add(2000, 256, 64, 7, pro=o.PRO_ROWLN, pro_gamma=rnd(64, seed=52), pro_beta=rnd(64, seed=53),
+        pro_stats=torch.rand(2000, 2, device=DEV))
+    add(333, 64, 118, 9)                                   # K % 4 != 0: not groupable, own launch
+    x = rnd(50, H, seed=60)
+    idx = torch.randint(0, 50, (1200,), device=DEV, dtype=torch.int32)
+    e = rnd(1200, H, seed=61)
+    add(1200, 128, 2 * H, 11, segs=[o.seg(x, rmap=o.rowmap(idx=idx)), o.seg(e)])
+    for k in range(9):
+        add(500 + 100 * k, 64, 64, 20 + 2 * k)
+    descs = []
+    for M, N, dy, segs, pair, ns, kw, _ in jobs:
+        o.wgrad(M, N, o.seg(dy), segs, pair[0][0], pair[0][1], ns, **kw)
+        descs.append(o.wgrad_desc(M, N, o.seg(dy), segs, pair[1][0], pair[1][1], ns, **kw))
+    o.wgrad_grouped(descs)
+    torch.cuda.synchronize()
+    for k, (M, N, dy, segs, pair, ns, kw, _) in enumerate(jobs):
+        assert torch.equal(pair[0][0], pair[1][0]) and torch.equal(pair[0][1], pair[1][1]), k
+        assert not torch.isnan(pair[1][0]).any()
+
+
 @pytest.mark.parametrize("M,H", [(7, 16), (100, 128), (3000, 256)])
 def test_rownorm_bwd_act(M, H):
     """dosx_rownorm_bwd_act == autograd of  xhat = LN_noaffine(leaky_relu(pre))  plus an extra gradient on leaky_relu(pre)."""
