@@ -199,6 +199,13 @@ void gemm_kernel(const GemmLaunch L) {
   constexpr int WROWS = (WL == 0) ? BN : BK;
   constexpr int LDC = BN + 4;
   constexpr int STAGE = BMS * LDA + WROWS * LDWT;     // floats of one staging buffer (A tile + W tile)
+  // TB: three stage buffers instead of two (256-column HALF-family tiles: they run one workgroup per CU anyway).  The
+  // staging waves then run TWO chunks ahead, so at the barrier that ends chunk c the data of chunk c+1 is already
+  // visible and the matrix waves fetch its first fragments underneath the last MFMAs of chunk c - without that, every
+  // chunk starts with ~1000 clk of exposed ds_read latency behind the barrier (stamps: 4100 clk per chunk for 3072 clk
+  // of MFMAs, also with the global loads removed).
+  constexpr bool TB = HALF && NTW == 2;
+  constexpr int NB = TB ? 3 : 2;
   constexpr int CTILE = BM * LDC;
   constexpr int CG = (BN + 255) / 256;   // float4 column groups per lane in the row-wise epilogue
   constexpr int NW4 = BN / 32;           // float4 W loads per staging thread per k-chunk
@@ -330,7 +337,7 @@ void gemm_kernel(const GemmLaunch L) {
 #pragma unroll
       for (int r = 0; r < RT; ++r) ar[r] = a_issue<PRO, VEC>(ast[r], k0 + akq, K, g.pro_gamma, g.pro_beta);
     };
-    const float* Gs = smem + 2 * STAGE;            // [KMAX] gamma, [KMAX] beta of the prologue LayerNorm
+    const float* Gs = smem + NB * STAGE;            // [KMAX] gamma, [KMAX] beta of the prologue LayerNorm
     const float* Bs = Gs + GEMM_KMAX;
     auto storeA = [&](float* Ad, const ARaw(&ar)[RT], int k0) {
       const int k = k0 + akq;
@@ -401,7 +408,7 @@ void gemm_kernel(const GemmLaunch L) {
       issue(ar0, wr0, 0);
       if (nk > 1) issue(ar1, wr1, BK);
       if constexpr (PROLN) {
-        float* Gw = smem + 2 * STAGE;
+        float* Gw = smem + NB * STAGE;
         for (int k = st * 4; k < K; k += 1024) {
           st4(Gw + k, ld4(g.pro_gamma + k));
           st4(Gw + GEMM_KMAX + k, ld4(g.pro_beta + k));
@@ -410,6 +417,30 @@ void gemm_kernel(const GemmLaunch L) {
       }
       store(smem, ar0, wr0, 0);
       if (nk > 2) issue(ar0, wr0, 2 * BK);
+      if constexpr (TB) {
+        // chunk c travels in register set c & 1 and is stored to buffer c % 3 TWO iterations before it is read
+        if (nk > 1) {
+          store(smem + STAGE, ar1, wr1, BK);
+          if (nk > 3) issue(ar1, wr1, 3 * BK);
+        }
+        __syncthreads();                                 // chunks 0 and 1 are visible
+        int b2 = 2;                                      // buffer of chunk kt + 2
+        for (int kt = 0; kt < nk; kt += 2) {
+          if (kt + 2 < nk) {                             // buffer (kt+2) % 3 was last read in iteration kt - 1
+            store(smem + b2 * STAGE, ar0, wr0, (kt + 2) * BK);
+            if (kt + 4 < nk) issue(ar0, wr0, (kt + 4) * BK);
+          }
+          b2 = b2 == 2 ? 0 : b2 + 1;
+          __syncthreads();
+          if (kt + 1 >= nk) break;
+          if (kt + 3 < nk) {
+            store(smem + b2 * STAGE, ar1, wr1, (kt + 3) * BK);
+            if (kt + 5 < nk) issue(ar1, wr1, (kt + 5) * BK);
+          }
+          b2 = b2 == 2 ? 0 : b2 + 1;
+          __syncthreads();
+        }
+      } else {
       STAMP_S(1);
       __syncthreads();                                   // chunk 0 is visible
       for (int kt = 0; kt < nk; kt += 2) {
@@ -430,6 +461,7 @@ void gemm_kernel(const GemmLaunch L) {
         }
         STAMP_S(7 + 3 * kt);
         __syncthreads();
+      }
       }
     };
 
@@ -552,36 +584,57 @@ void gemm_kernel(const GemmLaunch L) {
       // 16x16x4 MFMA: lane l holds A[row l&15][k = 4*(l>>4) + j] and B[k][col l&15] for the j-th of the 4 MFMAs
       // of a float4; one float4 per lane covers 16 k values, a 32-wide chunk is two such steps.
       const int l15 = lane & 15, g4 = lane >> 4;
-      for (int kt = 0; kt < nk; ++kt) {
-        const float* Asb = smem + (kt & 1) * STAGE;
+      struct Frag { float4 a[HT]; float b[2 * NTW][4]; };
+      auto fetch = [&](Frag& f, const float* Asb, int kk) {
         const float* Wsb = Asb + BMS * LDA;
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 16) {
-          float4 a[HT];
+        for (int h = 0; h < HT; ++h) f.a[h] = ld4(&Asb[(16 * h + l15) * LDA + kk + 4 * g4]);
 #pragma unroll
-          for (int h = 0; h < HT; ++h) a[h] = ld4(&Asb[(16 * h + l15) * LDA + kk + 4 * g4]);
-          float b[2 * NTW][4];
-#pragma unroll
-          for (int t = 0; t < 2 * NTW; ++t) {
-            if (WL == 0) {
-              const float4 v = ld4(&Wsb[((wave * 2 * NTW + t) * 16 + l15) * LDWT + kk + 4 * g4]);
-              b[t][0] = v.x; b[t][1] = v.y; b[t][2] = v.z; b[t][3] = v.w;
-            } else {
-              const float* bp = &Wsb[(kk + 4 * g4) * LDWT + (wave * 2 * NTW + t) * 16 + l15];
-              b[t][0] = bp[0]; b[t][1] = bp[LDWT]; b[t][2] = bp[2 * LDWT]; b[t][3] = bp[3 * LDWT];
-            }
+        for (int t = 0; t < 2 * NTW; ++t) {
+          if (WL == 0) {
+            const float4 v = ld4(&Wsb[((wave * 2 * NTW + t) * 16 + l15) * LDWT + kk + 4 * g4]);
+            f.b[t][0] = v.x; f.b[t][1] = v.y; f.b[t][2] = v.z; f.b[t][3] = v.w;
+          } else {
+            const float* bp = &Wsb[(kk + 4 * g4) * LDWT + (wave * 2 * NTW + t) * 16 + l15];
+            f.b[t][0] = bp[0]; f.b[t][1] = bp[LDWT]; f.b[t][2] = bp[2 * LDWT]; f.b[t][3] = bp[3 * LDWT];
           }
-#pragma unroll
-          for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int h = 0; h < HT; ++h) {
-              const float av = c == 0 ? a[h].x : c == 1 ? a[h].y : c == 2 ? a[h].z : a[h].w;
-#pragma unroll
-              for (int t = 0; t < 2 * NTW; ++t)
-                acch[h][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[t][c], acch[h][t], 0, 0, 0);
-            }
         }
-        __syncthreads();
+      };
+      auto mma = [&](const Frag& f) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int h = 0; h < HT; ++h) {
+            const float av = c == 0 ? f.a[h].x : c == 1 ? f.a[h].y : c == 2 ? f.a[h].z : f.a[h].w;
+#pragma unroll
+            for (int t = 0; t < 2 * NTW; ++t)
+              acch[h][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, f.b[t][c], acch[h][t], 0, 0, 0);
+          }
+      };
+      if constexpr (TB) {
+        Frag f0, f1;
+        int cur = 0;
+        fetch(f0, smem, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+          const float* Asb = smem + cur * STAGE;
+          cur = cur == 2 ? 0 : cur + 1;
+          fetch(f1, Asb, 16);
+          mma(f0);
+          fetch(f0, smem + cur * STAGE, 0);      // chunk kt+1: stored before the previous barrier (stale after the last chunk, unused)
+          mma(f1);
+          __syncthreads();
+        }
+      } else {
+        for (int kt = 0; kt < nk; ++kt) {
+          const float* Asb = smem + (kt & 1) * STAGE;
+          Frag f;
+#pragma unroll
+          for (int kk = 0; kk < BK; kk += 16) {
+            fetch(f, Asb, kk);
+            mma(f);
+          }
+          __syncthreads();
+        }
       }
     } else {
     // One k-chunk of MFMAs.  Straight-line and unconditional: W rows / columns beyond N are zero-filled
@@ -848,7 +901,8 @@ constexpr size_t gemm_smem_bytes() {
   constexpr int WROWS = (WL == 0) ? BN : BK;
   constexpr int STAGE = BM * RT * LDA + WROWS * LDWT;
   constexpr int CTILE = BM * (BN + 4);
-  constexpr int MAINF = 2 * STAGE + (PROLN ? 2 * GEMM_KMAX : 0);
+  constexpr int NB = ((RTP == 0 || RTP == 3) && NTW == 2) ? 3 : 2;      // (TB in gemm_kernel)
+  constexpr int MAINF = NB * STAGE + (PROLN ? 2 * GEMM_KMAX : 0);
   constexpr int EPIF = RT * CTILE + 16 * BN + 8;
   return (size_t)(MAINF > EPIF ? MAINF : EPIF) * sizeof(float);
 }
