@@ -262,6 +262,16 @@ void gemm_kernel(const GemmLaunch L) {
   bool on[CG];
   int gcol[CG];
   float4 biasv[CG], gamv[CG], betv[CG];
+  // LN epilogue: quarter-wave layout (16 lanes per row, KQ float4 per lane at columns 4*q16 + 64*k)
+  constexpr int KQ = BN / 64;
+  float4 biasq[KQ];
+  if constexpr (EPI == DOSX_EPI_LN && NTW <= 2) {
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) {
+      const int c = (lane & 15) * 4 + 64 * k;
+      biasq[k] = (g.bias && c < ncols) ? ld4(g.bias + n0 + c) : f4zero();
+    }
+  }
 #pragma unroll
   for (int j = 0; j < CG; ++j) {
     const int c = lane * 4 + 256 * j;
@@ -721,6 +731,51 @@ void gemm_kernel(const GemmLaunch L) {
   __syncthreads();
   STAMP(57);
 
+  if constexpr (epi == DOSX_EPI_LN && NTW <= 2) {          // (512-column tiles keep the full-wave version: 8 float4 per lane cost more than they save)
+    // ---- LayerNorm epilogue, one QUARTER wave per row: four rows of a wave are reduced at once with 4-step DPP
+    // sums (a 64-lane sum per row - DPP + 4 v_readlane + scalar adds, twice per row, rows one after the other - took
+    // ~830 clk per row: 5000 clk of a 54000-clk kernel at 6 rows per wave)
+    const int q16 = lane & 15, qd = lane >> 4;
+#pragma unroll
+    for (int rt = 0; rt < RTE; ++rt)
+#pragma unroll
+      for (int p = 0; p < (ER + 3) / 4; ++p) {
+        const int li = 4 * p + qd;                       // this quarter's row among the wave's ER rows
+        const int lr = wave * ER + (li < ER ? li : 0);
+        const int r = m0 + 32 * rt + lr;
+        const bool rv = li < ER && r < M;
+        float4 v[KQ];
+        float s1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) {
+          const int c = q16 * 4 + 64 * k;
+          v[k] = f4zero();
+          if (c < ncols) {
+            v[k] = f4add(ld4(&Cs[rt * CTILE + lr * LDC + c]), biasq[k]);
+            s1 += v[k].x + v[k].y + v[k].z + v[k].w;
+          }
+        }
+        const float mean = row16_sum(s1) * invN;
+        float s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < KQ; ++k) {
+          if (q16 * 4 + 64 * k < ncols) {
+            v[k].x -= mean; v[k].y -= mean; v[k].z -= mean; v[k].w -= mean;
+            s2 += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w;
+          }
+        }
+        const float rstd = rsqrtf(row16_sum(s2) * invN + DOSX_LN_EPS);
+        if (rv) {
+          float* const orow = g.out + (size_t)r * g.ldo + n0;
+#pragma unroll
+          for (int k = 0; k < KQ; ++k) {
+            const int c = q16 * 4 + 64 * k;
+            if (c < ncols) st4(orow + c, make_float4(v[k].x * rstd, v[k].y * rstd, v[k].z * rstd, v[k].w * rstd));
+          }
+          if (q16 == 0) g.aux_out[r] = rstd;
+        }
+      }
+  } else {
 #pragma unroll
   for (int rt = 0; rt < RTE; ++rt) {
   const int mb = m0 + 32 * rt;
@@ -853,6 +908,7 @@ void gemm_kernel(const GemmLaunch L) {
   }
 
   }   // rt
+  }   // epilogues other than LN
   STAMP(58);
   // ---- per-workgroup partial sums for the parameter gradients of the fused LN / PReLU ----------
   if (g.partials && (epi == DOSX_EPI_PRELU_LN_BWD || epi == DOSX_EPI_ROWLN_BWD || epi == DOSX_EPI_PRELU_BWD)) {
