@@ -15,6 +15,18 @@
 
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 
+#ifdef DOSX_STAMPS
+__device__ unsigned long long dosx_ffn_stamp_buf[64];
+extern "C" int dosx_debug_read_ffn_stamps(unsigned long long* host64) {
+  return (int)hipMemcpyFromSymbol(host64, HIP_SYMBOL(dosx_ffn_stamp_buf), sizeof(unsigned long long) * 64);
+}
+#define FSTAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x == 0) dosx_ffn_stamp_buf[(slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define FSTAMP_S(slot) do { if (threadIdx.x == 256 && blockIdx.x == 0) dosx_ffn_stamp_buf[32 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FSTAMP(slot) do { } while (0)
+#define FSTAMP_S(slot) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int FBK = 32;          // k-chunk
@@ -38,6 +50,7 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
   const int l15 = lane & 15, g4 = lane >> 4;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int m0 = blockIdx.x * R;
+  FSTAMP(0);
   const int nk1 = H / FBK, nb1 = H4 / FBN, n1 = nb1 * nk1, n2 = H4 / FBK, nch = n1 + n2;
 
   // epilogue operands of this wave's 4 rows, fetched at kernel start (all 8 waves)
@@ -115,6 +128,7 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
       }
     }
     __syncthreads();
+    FSTAMP(1);
     int c = 0;
     if constexpr (HALF) {
       f32x4 acc0, acc1;
@@ -198,7 +212,9 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * hh) * LDT + col] = fmaxf(acc[r] + b1, 0.f);
     }
+    FSTAMP(2);
     __syncthreads();                               // T complete (the staging waves copy it out from here on)
+    FSTAMP(3);
     // ---- fc2: one 128-column block, n2 chunks, A operand = T ----
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -215,6 +231,7 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
       }
       __syncthreads();
     }
+    FSTAMP(4);
     // C tile (the stage buffers are dead: the last chunk ended with a barrier)
     float* Cs = ST;
     const int col = wave * 32 + l31;
@@ -223,6 +240,7 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
     }   // !HALF
   }
   __syncthreads();
+  FSTAMP(5);
   // ---- row epilogue (8 waves x ER rows): out = C + b2 + x, optionally followed by the encoder's final LayerNorm ----
   {
     const float* Cs = ST;
@@ -256,6 +274,7 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
       }
     }
   }
+  FSTAMP(6);
 }
 
 
