@@ -29,15 +29,16 @@ extern "C" int dosx_debug_read_ffn_stamps(unsigned long long* host64) {
 
 namespace {
 
-constexpr int FBK = 32;          // k-chunk
-constexpr int FLDW = FBK + 4;    // 36: padded rows of a staged weight chunk
+// k-chunk width KB (32, or 64 when H % 64 == 0: half as many barriers - a 32-wide chunk is only 16 MFMAs = 1024 clk
+// per wave and each barrier costs ~450 clk of ds_read round trip and skew, tools/stamp_ffn.py) is a template argument
 constexpr int FBN = 128;         // columns per chunk / per column block
 
 // HALF: the workgroup owns 16 rows and multiplies with the 16x16x4 MFMA (two 16-column tiles per wave instead of one
 // 32-column tile): twice the workgroups, half the MFMA time each, and two of them fit the LDS of one CU.
-template <bool HALF>
+template <bool HALF, int KB>
 __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
   extern __shared__ __align__(16) float sm[];
+  constexpr int FBK = KB, FLDW = KB + 4;           // chunk width, padded row of a staged weight chunk
   constexpr int R = HALF ? 16 : 32;                // rows per workgroup
   constexpr int ER = R / 8;                        // epilogue rows per wave
   const int H = a.H, H4 = 4 * a.H, M = a.M;
@@ -66,28 +67,29 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
 
   if (wave_u >= 4) {
     // =============================== staging waves ===============================================
-    const int st = tid - 256, jr = st >> 3, kq = (st & 7) * 4;
+    constexpr int TPR = FBK / 4, RPP = 256 / TPR, NP = FBN / RPP;      // threads per chunk row, rows per pass, passes
+    const int st = tid - 256, jr = st / TPR, kq = (st % TPR) * 4;
     const float* wlo = a.w1 < a.w2 ? a.w1 : a.w2;
     const uint32_t d1 = (uint32_t)((const char*)a.w1 - (const char*)wlo), d2 = (uint32_t)((const char*)a.w2 - (const char*)wlo);
     const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)wlo, 0, 0x7fffffff, 0x00020000);
-    uint32_t v1[4], v2[4];
+    uint32_t v1[NP], v2[NP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      v1[i] = d1 + (uint32_t)(((jr + 32 * i) * H + kq) * 4);                       // fc1 rows: (cb*128 + j), j = jr + 32 i
-      v2[i] = d2 + (uint32_t)((min(jr + 32 * i, H - 1) * H4 + kq) * 4);            // fc2 rows: j < H (clamped)
+    for (int i = 0; i < NP; ++i) {
+      v1[i] = d1 + (uint32_t)(((jr + RPP * i) * H + kq) * 4);                      // fc1 rows: (cb*128 + j), j = jr + RPP i
+      v2[i] = d2 + (uint32_t)((min(jr + RPP * i, H - 1) * H4 + kq) * 4);           // fc2 rows: j < H (clamped)
     }
-    float4 r0[4], r1[4];
-    auto issue = [&](float4(&r)[4], int c) {
+    float4 r0[NP], r1[NP];
+    auto issue = [&](float4(&r)[NP], int c) {
       const int cu = __builtin_amdgcn_readfirstlane(c);
       const bool p1 = cu < n1;
       const int so = p1 ? ((cu / nk1) * FBN * H + (cu % nk1) * FBK) * 4 : (cu - n1) * FBK * 4;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NP; ++i)
         r[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rW, p1 ? v1[i] : v2[i], so, 0));
     };
-    auto store = [&](float* buf, const float4(&r)[4]) {
+    auto store = [&](float* buf, const float4(&r)[NP]) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) st4(buf + (jr + 32 * i) * FLDW + kq, r[i]);
+      for (int i = 0; i < NP; ++i) st4(buf + (jr + RPP * i) * FLDW + kq, r[i]);
     };
     auto copy_h = [&]() {        // the finished relu(fc1) tile -> HBM (rows m0.., H4 columns), float4 per lane
       const int per_row = H4 / 4;
@@ -287,9 +289,10 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
 // matrices are read as stored (k-major: W2 [H][4H], W1 [4H][H]), so a staged chunk is 32 k-rows x 128 columns.
 constexpr int BLDW = FBN + 4;    // 132: padded rows of a k-major weight chunk
 
-template <bool HALF>
+template <bool HALF, int KB>
 __global__ __launch_bounds__(512) void ffn_bwd_kernel(const DosxFfnBwd a) {
   extern __shared__ __align__(16) float sm[];
+  constexpr int FBK = KB;
   constexpr int R = HALF ? 16 : 32;
   constexpr int ER = R / 8;
   constexpr int NV = HALF ? 8 : 16;                // C elements per lane per 128-column block
@@ -326,26 +329,27 @@ __global__ __launch_bounds__(512) void ffn_bwd_kernel(const DosxFfnBwd a) {
     const float* wlo = a.w1 < a.w2 ? a.w1 : a.w2;
     const uint32_t d1 = (uint32_t)((const char*)a.w1 - (const char*)wlo), d2 = (uint32_t)((const char*)a.w2 - (const char*)wlo);
     const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)wlo, 0, 0x7fffffff, 0x00020000);
-    uint32_t v1[4], v2[4], lds[4];
+    constexpr int NP = FBK * 32 / 256;             // float4 per staging thread per chunk
+    uint32_t v1[NP], v2[NP], lds[NP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NP; ++i) {
       const int lin = st + 256 * i, r = lin >> 5, c4 = (lin & 31) * 4;
       v1[i] = d2 + (uint32_t)((r * H4 + c4) * 4);                         // phase 1: W2 rows k, columns cb*128 + c4
       v2[i] = d1 + (uint32_t)((r * H + min(c4, H - 4)) * 4);              // phase 2: W1 rows k, columns c4 (< H, clamped)
       lds[i] = (uint32_t)(r * BLDW + c4);
     }
-    float4 r0[4], r1[4];
-    auto issue = [&](float4(&r)[4], int c) {
+    float4 r0[NP], r1[NP];
+    auto issue = [&](float4(&r)[NP], int c) {
       const int cu = __builtin_amdgcn_readfirstlane(c);
       const bool p1 = cu < n1;
       const int so = p1 ? ((cu % nk1) * FBK * H4 + (cu / nk1) * FBN) * 4 : (cu - n1) * FBK * H * 4;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NP; ++i)
         r[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rW, p1 ? v1[i] : v2[i], so, 0));
     };
-    auto store = [&](float* buf, const float4(&r)[4]) {
+    auto store = [&](float* buf, const float4(&r)[NP]) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) st4(buf + lds[i], r[i]);
+      for (int i = 0; i < NP; ++i) st4(buf + lds[i], r[i]);
     };
     auto copy_dh = [&]() {       // the finished dh tile -> HBM
       const int per_row = H4 / 4;
@@ -532,6 +536,13 @@ __global__ __launch_bounds__(512) void ffn_bwd_kernel(const DosxFfnBwd a) {
 
 }  // namespace
 
+static int ffn_chunk(int H) {
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("DOSX_FFN_KB"); forced = e ? atoi(e) : 0; }
+  if (forced == 32) return 32;
+  return (H % 64) == 0 ? 64 : 32;
+}
+
 extern "C" int dosx_ffn_supported(int H) { return (H % 32) == 0 && H >= 32 && H <= 128; }
 
 extern "C" int dosx_ffn_fwd(const DosxFfn* ap, dosx_stream_t stream) {
@@ -549,15 +560,21 @@ extern "C" int dosx_ffn_fwd(const DosxFfn* ap, dosx_stream_t stream) {
   if (half_max < 0) { const char* e = getenv("DOSX_FFN_HALF_MAX"); half_max = e ? atoi(e) : 128; }
   const bool half = ceil_div(a.M, 32) <= half_max;       // 16-row workgroups while the 32-row grid is one partial round
   const int R = half ? 16 : 32;
-  const size_t smem = sizeof(float) * ((size_t)R * (H + 4) + (size_t)R * (H4 + 4) + 2 * (size_t)FBN * FLDW);
+  const int kb = ffn_chunk(H);
+  const size_t smem = sizeof(float) * ((size_t)R * (H + 4) + (size_t)R * (H4 + 4) + 2 * (size_t)FBN * (kb + 4));
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fwd_kernel<false, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fwd_kernel<true, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fwd_kernel<false, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fwd_kernel<true, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  if (half) hipLaunchKernelGGL(ffn_fwd_kernel<true>, dim3(ceil_div(a.M, 16)), dim3(512), smem, to_stream(stream), a);
-  else hipLaunchKernelGGL(ffn_fwd_kernel<false>, dim3(ceil_div(a.M, 32)), dim3(512), smem, to_stream(stream), a);
+  const dim3 grid(ceil_div(a.M, R));
+  if (half && kb == 64) hipLaunchKernelGGL((ffn_fwd_kernel<true, 64>), grid, dim3(512), smem, to_stream(stream), a);
+  else if (half) hipLaunchKernelGGL((ffn_fwd_kernel<true, 32>), grid, dim3(512), smem, to_stream(stream), a);
+  else if (kb == 64) hipLaunchKernelGGL((ffn_fwd_kernel<false, 64>), grid, dim3(512), smem, to_stream(stream), a);
+  else hipLaunchKernelGGL((ffn_fwd_kernel<false, 32>), grid, dim3(512), smem, to_stream(stream), a);
   DOSX_LAUNCH_CHECK();
   return 0;
 }
@@ -584,15 +601,21 @@ extern "C" int dosx_ffn_bwd(const DosxFfnBwd* ap, dosx_stream_t stream) {
   const int H = a.H, H4 = 4 * H;
   const bool half = ffn_bwd_half(a.M);
   const int R = half ? 16 : 32;
-  const size_t smem = sizeof(float) * ((size_t)R * (H + 4) + (size_t)R * (H4 + 4) + 2 * (size_t)FBK * (FBN + 4));
+  const int kb = ffn_chunk(H);
+  const size_t smem = sizeof(float) * ((size_t)R * (H + 4) + (size_t)R * (H4 + 4) + 2 * (size_t)kb * (FBN + 4));
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_bwd_kernel<false, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_bwd_kernel<true, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_bwd_kernel<false, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_bwd_kernel<true, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  if (half) hipLaunchKernelGGL(ffn_bwd_kernel<true>, dim3(ceil_div(a.M, 16)), dim3(512), smem, to_stream(stream), a);
-  else hipLaunchKernelGGL(ffn_bwd_kernel<false>, dim3(ceil_div(a.M, 32)), dim3(512), smem, to_stream(stream), a);
+  const dim3 grid(ceil_div(a.M, R));
+  if (half && kb == 64) hipLaunchKernelGGL((ffn_bwd_kernel<true, 64>), grid, dim3(512), smem, to_stream(stream), a);
+  else if (half) hipLaunchKernelGGL((ffn_bwd_kernel<true, 32>), grid, dim3(512), smem, to_stream(stream), a);
+  else if (kb == 64) hipLaunchKernelGGL((ffn_bwd_kernel<false, 64>), grid, dim3(512), smem, to_stream(stream), a);
+  else hipLaunchKernelGGL((ffn_bwd_kernel<false, 32>), grid, dim3(512), smem, to_stream(stream), a);
   DOSX_LAUNCH_CHECK();
   return 0;
 }
