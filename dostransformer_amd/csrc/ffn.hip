@@ -79,13 +79,20 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
       v2[i] = d2 + (uint32_t)((min(jr + RPP * i, H - 1) * H4 + kq) * 4);           // fc2 rows: j < H (clamped)
     }
     float4 r0[NP], r1[NP];
+    // chunks are issued strictly in order 0, 1, 2, ...: the scalar offset of the next one is carried along (cu / nk1
+    // and cu % nk1 by a run-time nk1 are ~40 emulated-division instructions, and every vector-ALU instruction of a
+    // staging wave waits ~30 clk for an issue slot between the matrix wave's MFMAs: `issue` took up to 2200 clk)
+    int nxt_c = 0, nxt_kc = 0, nxt_so1 = 0;
     auto issue = [&](float4(&r)[NP], int c) {
-      const int cu = __builtin_amdgcn_readfirstlane(c);
+      (void)c;
+      const int cu = __builtin_amdgcn_readfirstlane(nxt_c);
       const bool p1 = cu < n1;
-      const int so = p1 ? ((cu / nk1) * FBN * H + (cu % nk1) * FBK) * 4 : (cu - n1) * FBK * 4;
+      const int so = __builtin_amdgcn_readfirstlane(p1 ? nxt_so1 : (cu - n1) * FBK * 4);
 #pragma unroll
       for (int i = 0; i < NP; ++i)
         r[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rW, p1 ? v1[i] : v2[i], so, 0));
+      ++nxt_c;
+      if (++nxt_kc == nk1) { nxt_kc = 0; nxt_so1 += (FBN * H - (nk1 - 1) * FBK) * 4; } else nxt_so1 += FBK * 4;
     };
     auto store = [&](float* buf, const float4(&r)[NP]) {
 #pragma unroll
@@ -120,6 +127,15 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
     }
   } else {
     // =============================== matrix waves ================================================
+    // fc1 bias of this lane's columns in every 128-column block, fetched up front: loaded at the end of a block it
+    // cost one exposed global round trip (~1600 clk) per block - 4 per kernel (stamps, tools/stamp_ffn.py)
+    float b1r[4][2];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const int col = min(cb, nb1 - 1) * FBN + wave * 32 + (HALF ? l15 : l31);
+      b1r[cb][0] = a.b1[col];
+      b1r[cb][1] = HALF ? a.b1[col + 16] : 0.f;
+    }
     {   // LN1(x) tile -> Xs  (row r = tid/8, 4-float groups tid%8 + 8 i)
       const int r = tid >> 3, rr = min(m0 + r, M - 1);
       const float mean = a.stats[2 * (size_t)rr], rstd = a.stats[2 * (size_t)rr + 1];
@@ -156,7 +172,8 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
           __syncthreads();
         }
         const int col = cb * FBN + wave * 32 + l15;
-        const float b1a = a.b1[col], b1b = a.b1[col + 16];
+        const float b1a = cb == 0 ? b1r[0][0] : cb == 1 ? b1r[1][0] : cb == 2 ? b1r[2][0] : b1r[3][0];
+        const float b1b = cb == 0 ? b1r[0][1] : cb == 1 ? b1r[1][1] : cb == 2 ? b1r[2][1] : b1r[3][1];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           T[(4 * g4 + r) * LDT + col] = fmaxf(acc0[r] + b1a, 0.f);
@@ -210,7 +227,7 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
         __syncthreads();
       }
       const int col = cb * FBN + wave * 32 + l31;
-      const float b1 = a.b1[col];
+      const float b1 = cb == 0 ? b1r[0][0] : cb == 1 ? b1r[1][0] : cb == 2 ? b1r[2][0] : b1r[3][0];
 #pragma unroll
       for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * hh) * LDT + col] = fmaxf(acc[r] + b1, 0.f);
     }
@@ -339,13 +356,19 @@ __global__ __launch_bounds__(512) void ffn_bwd_kernel(const DosxFfnBwd a) {
       lds[i] = (uint32_t)(r * BLDW + c4);
     }
     float4 r0[NP], r1[NP];
+    // (chunks are issued strictly in order: the scalar offset is carried along instead of dividing by a run-time nk1,
+    //  see ffn_fwd_kernel)
+    int nxt_c = 0, nxt_kc = 0, nxt_so1 = 0;
     auto issue = [&](float4(&r)[NP], int c) {
-      const int cu = __builtin_amdgcn_readfirstlane(c);
+      (void)c;
+      const int cu = __builtin_amdgcn_readfirstlane(nxt_c);
       const bool p1 = cu < n1;
-      const int so = p1 ? ((cu % nk1) * FBK * H4 + (cu / nk1) * FBN) * 4 : (cu - n1) * FBK * H * 4;
+      const int so = __builtin_amdgcn_readfirstlane(p1 ? nxt_so1 : (cu - n1) * FBK * H * 4);
 #pragma unroll
       for (int i = 0; i < NP; ++i)
         r[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rW, p1 ? v1[i] : v2[i], so, 0));
+      ++nxt_c;
+      if (++nxt_kc == nk1) { nxt_kc = 0; nxt_so1 += (FBN - (nk1 - 1) * FBK * H4) * 4; } else nxt_so1 += FBK * H4 * 4;
     };
     auto store = [&](float* buf, const float4(&r)[NP]) {
 #pragma unroll
