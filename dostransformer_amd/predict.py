@@ -23,10 +23,11 @@ from .train import _Slot
 
 
 class Predictor:
-    def __init__(self, model: DOSTransformerBase):
+    def __init__(self, model: DOSTransformerBase, bucket=(8, 128)):
         if not isinstance(model, DOSTransformerBase):
             raise TypeError("Predictor drives DOSTransformer / DOSTransformer_phonon modules")
         self.model = model
+        self.bucket = tuple(bucket)
         self.kind = model._cfg.kind
         self._fp = None
         self._slots: Dict[tuple, _Slot] = {}
@@ -66,7 +67,7 @@ class Predictor:
         n_real = getattr(g, "real_nodes", None)
         if n_real is None:
             n_real = m.num_nodes
-            g = pad_batch(g, *bucket_sizes(m.num_nodes, m.num_edges))
+            g = pad_batch(g, *bucket_sizes(m.num_nodes, m.num_edges, *self.bucket))
             m = g.meta
         key = (m.num_nodes, m.num_edges, m.num_graphs, m.n_max)
         slot = self._slots.get(key)

@@ -66,13 +66,17 @@ class Trainer:
     """
 
     def __init__(self, model: DOSTransformerBase, lr: float = 1e-4, beta: float = 1.0, weight_decay: float = 1e-2,
-                 betas=(0.9, 0.999), eps: float = 1e-8, dist=None, graph: bool = False, replay: bool = False):
+                 betas=(0.9, 0.999), eps: float = 1e-8, dist=None, graph: bool = False, replay: bool = False,
+                 bucket=(8, 128)):
         if not isinstance(model, DOSTransformerBase):
             raise TypeError("Trainer drives DOSTransformer / DOSTransformer_phonon modules")
         self.model, self.lr, self.beta, self.wd, self.betas, self.eps = model, lr, beta, weight_decay, betas, eps
         self.dist = dist
         self.graph = graph
         self.replay = replay
+        # (node, edge) granularity of the shape buckets unpadded batches are ghost-padded to in graph / replay mode: a
+        # coarser grid means fewer distinct launch lists to record when batches are reshuffled every epoch
+        self.bucket = tuple(bucket)
         self.bucketed = dist is not None and not graph       # early-bucket overlap (eager and replay modes)
         self._early_work = None
         self._early_side = None
@@ -249,7 +253,7 @@ class Trainer:
         if m is None or m.edge_perm is not None:
             raise ValueError("graph mode needs batches from collate(sort_edges=True) (+ pad_batch)")
         if getattr(g, "real_nodes", None) is None:               # not padded yet: pad on the fly
-            g = pad_batch(g, *bucket_sizes(m.num_nodes, m.num_edges))
+            g = pad_batch(g, *bucket_sizes(m.num_nodes, m.num_edges, *self.bucket))
             m = g.meta
         ng = self._n_global(m.num_graphs, n_global)
         key = (m.num_nodes, m.num_edges, m.num_graphs, m.n_max, ng)

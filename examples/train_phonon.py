@@ -54,8 +54,10 @@ def main(argv=None):
     ds = {k: DeviceDataset([crystals[i] for i in idx], dev) for k, idx in split.items()}
 
     model = DOSTransformer_phonon(args.layers, args.transformer, 118, 4, args.hidden, dev, 0.0).to(dev)
-    trainer = Trainer(model, lr=args.lr, beta=args.beta, replay=True)
-    predictor = Predictor(model)
+    # coarse shape buckets: reshuffled batches then fall into a few dozen (N, E, n_max) buckets that are all recorded
+    # within the first epoch (ghost padding is exact; it costs a few per cent of extra rows)
+    trainer = Trainer(model, lr=args.lr, beta=args.beta, replay=True, bucket=(32, 1024))
+    predictor = Predictor(model, bucket=(32, 1024))
     best, history = float("inf"), []
     for epoch in range(args.epochs):
         model.train()
