@@ -144,6 +144,7 @@ class CrystalBatch:
         m = self.meta
         if m is not None:
             object.__setattr__(self, _META_KEY, m.to(device))
+        object.__setattr__(self, "_dosx_padded", None)      # (predict.Predictor's cached ghost-padded copy is stale now)
         return self
 
     def clone(self) -> "CrystalBatch":

@@ -67,7 +67,14 @@ class Predictor:
         n_real = getattr(g, "real_nodes", None)
         if n_real is None:
             n_real = m.num_nodes
-            g = pad_batch(g, *bucket_sizes(m.num_nodes, m.num_edges, *self.bucket))
+            cached = getattr(g, "_dosx_padded", None)          # evaluation loops revisit the same batch objects:
+            if cached is None or cached[0] != self.bucket:     # pad (≈20 small torch ops) only once per batch
+                cached = (self.bucket, pad_batch(g, *bucket_sizes(m.num_nodes, m.num_edges, *self.bucket)))
+                try:
+                    object.__setattr__(g, "_dosx_padded", cached)
+                except (AttributeError, TypeError):
+                    pass
+            g = cached[1]
             m = g.meta
         key = (m.num_nodes, m.num_edges, m.num_graphs, m.n_max)
         slot = self._slots.get(key)
