@@ -86,6 +86,23 @@ def cpu_baseline(kind, L, T, H, B, budget_s=15.0):
         el = time.perf_counter() - t0
         if el > budget_s or n >= 200:
             break
+    # the same step in fp32 on the same threads (phonon only: the reference runs it in fp64, main_phDOS.py:15-16, the
+    # GPU path computes in fp32 — so the like-for-like arithmetic comparison is this figure, not the fp64 one)
+    f32_note = ""
+    if dt == torch.float64:
+        p32 = {k: (v.float() if v.is_floating_point() else v) for k, v in params.items()}
+        g32 = collate(make_crystals(kind, B, 1000, torch.float32))
+        s32 = {}
+        O.train_step(kind, p32, s32, g32, L, T)
+        t0 = time.perf_counter()
+        n32 = 0
+        while True:
+            O.train_step(kind, p32, s32, g32, L, T)
+            n32 += 1
+            e32 = time.perf_counter() - t0
+            if e32 > max(2.0, budget_s / 4) or n32 >= 100:
+                break
+        f32_note = f"; same port in fp32 on the same threads: {B * n32 / e32:.1f} crystals/s ({1e3 * e32 / n32:.1f} ms/step)"
     cpu_model = "unknown CPU"
     try:
         for line in open("/proc/cpuinfo"):
@@ -98,7 +115,49 @@ def cpu_baseline(kind, L, T, H, B, budget_s=15.0):
             "sample": f"{n} full train steps (fwd+loss+bwd+AdamW) of one batch of {B} crystals, "
                       f"{'fp64' if dt == torch.float64 else 'fp32'}, {el:.1f}s, ms/step {1e3 * el / n:.1f}; "
                       f"host: {cpu_model}, {os.cpu_count()} logical CPUs, fastest of 2/8/16/32 threads; with the "
-                      f"reference's own 2 threads: {B / t2:.1f} crystals/s"}
+                      f"reference's own 2 threads: {B / t2:.1f} crystals/s" + f32_note}
+
+
+def algorithmic_flops(kind, L, T, H, N, E, B, n_max):
+    """Forward flops of one batch by SURVEY.md §8d's formula (REAL nodes / edges, no ghost padding); a training step
+    is 3x this (forward + two backward products per forward product)."""
+    S = 51 if kind == "phonon" else 201
+    Fa, Fb = (118, 4) if kind == "phonon" else (200, 41)
+    f = 2.0 * N * (Fa * H + H * H) + 2.0 * E * (Fb * H + H * H)
+    if kind == "edos":
+        f += 2.0 * B * (2 * H + H * H)
+    f += L * (16.0 * E * H * H + 12.0 * N * H * H)
+    f += (2.0 if kind == "phonon" else 4.0) * B * H * H
+    f += 5.0 * T * 16 * S * B * H * H + 3.0 * T * 4 * B * S * n_max * H + 2.0 * T * 4 * B * S * S * H
+    f += 9.0 * S * B * H * H + 4.0 * S * B * H
+    return f
+
+
+def load_traffic():
+    """HBM bytes per kernel launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.py).  The file records the
+    hash of the sources it was measured on; a file measured on different sources is REFUSED (traffic stays null)."""
+    import glob
+    from dostransformer_amd._lib import source_hash
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return {}, "no profiles/r*_pmc_traffic.json"
+    try:
+        rec = json.load(open(files[-1]))
+    except Exception as e:  # pragma: no cover
+        return {}, f"{os.path.basename(files[-1])}: {e}"
+    if rec.get("source_hash") != source_hash():
+        return {}, f"{os.path.basename(files[-1])} was measured on other sources (hash {rec.get('source_hash')}, now {source_hash()}): refused"
+    return rec.get("kernels", {}), f"{os.path.basename(files[-1])} (git {rec.get('git_head', '?')[:12]})"
+
+
+def traffic_of(kernels, key):
+    """launch-weighted mean bytes per launch over the profiled symbols that contain `key`"""
+    tot = n = 0
+    for sym, r in kernels.items():
+        if key in sym:
+            tot += r["hbm_bytes_per_launch"] * r["launches"]
+            n += r["launches"]
+    return int(tot / n) if n else None
 
 
 def main():
@@ -116,10 +175,18 @@ def main():
     ap.add_argument("--launch", choices=["replay", "eager", "graph"], default="replay",
                     help="replay: re-issue a recorded launch list on static buffers (2 HIP streams); eager: marshal "
                          "every launch from Python; graph: torch/HIP graph replay")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the step from captured HIP graphs (exact ghost padding to (N,E) buckets); "
-                         "measured slower than eager launches while the step is GPU-bound (2.95 vs 2.72 ms)")
+    ap.add_argument("--graph", action="store_true", help="same as --launch graph")
+    ap.add_argument("--shuffle", action="store_true",
+                    help="steady-state epoch mode: every step collates a FRESH random batch from a device-resident pool "
+                         "(loader.DeviceDataset), pads it to its shape bucket and trains on it; reports the slot hit rate")
+    ap.add_argument("--pool", type=int, default=1536, help="--shuffle: crystals in the device-resident pool per GPU")
+    ap.add_argument("--bucket", type=int, nargs=2, default=None, metavar=("NODES", "EDGES"),
+                    help="shape-bucket granularity (default 8 128; --shuffle: 64 1280)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl = RCCL over xGMI (production); gloo = host-staged sums, only for running the N > 1 code path "
+                         "on a box with fewer GPUs than ranks (together with --share-gpu; no scaling meaning)")
+    ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (test harness; see --dist-backend)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed/RCCL even for one rank (exercises the data-parallel code path on a 1-GPU box)")
     args = ap.parse_args()
@@ -131,7 +198,7 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    device = torch.device(f"cuda:{local_rank}")
+    device = torch.device("cuda:0" if args.share_gpu else f"cuda:{local_rank}")
     torch.cuda.set_device(device)
 
     import torch.distributed as td
@@ -142,101 +209,151 @@ def main():
         # (no device_id=: the eager communicator it creates costs every later kernel launch of this process
         #  ~3 us on this stack: 2.42 vs 1.92 ms/step measured with tools/dist_overhead.py; the device is
         #  already selected with torch.cuda.set_device above)
-        td.init_process_group("nccl", rank=rank, world_size=world)
+        td.init_process_group(args.dist_backend, rank=rank, world_size=world)
         from dostransformer_amd.dist import DataParallel
         dp = DataParallel()
 
+    import numpy as np
     from dostransformer_amd import ops
     from dostransformer_amd.batch import bucket_sizes, pad_batch
     from dostransformer_amd.dist import shard_batch
+    from dostransformer_amd.loader import DeviceDataset
     from dostransformer_amd.train import Trainer
 
     kind, L, T, H, B = CONFIGS[args.config]
     model = build_model(kind, L, T, H, device).to(device)
     mode = "graph" if args.graph else args.launch
     use_graph = mode in ("graph", "replay")          # both run on ghost-padded (N,E) shape buckets
-    trainer = Trainer(model, lr=1e-4, beta=1.0, dist=dp, graph=(mode == "graph"), replay=(mode == "replay"))
-
-    # device-resident, pre-collated shards of N_DISTINCT_BATCHES global batches (global n_max per batch);
-    # in graph mode each is padded (exactly: ghost nodes/edges) to its (N, E) shape bucket
-    batches = []
-    for k in range(N_DISTINCT_BATCHES):
-        crystals = make_crystals(kind, B * world, seed=k, dtype=torch.float32)
-        g = shard_batch(crystals, world, rank)
-        if use_graph:
-            g = pad_batch(g, *bucket_sizes(g.meta.num_nodes, g.meta.num_edges))
-        batches.append(g.to(device))
+    bucket = tuple(args.bucket) if args.bucket else ((64, 1280) if args.shuffle else (8, 128))
+    trainer = Trainer(model, lr=1e-4, beta=1.0, dist=dp, graph=(mode == "graph"), replay=(mode == "replay"), bucket=bucket)
     n_global = B * world
+
+    real_dims = []          # (N, E, n_max) of the un-padded batches: the algorithmic-flop count uses real rows only
+    if args.shuffle:
+        # Every rank holds its own pool (data-parallel shards of a shuffled epoch are disjoint anyway); the global
+        # n_max is fixed to the pool-wide maximum so that ranks need no exchange to agree on it.
+        pool = make_crystals(kind, args.pool, seed=12345 + rank, dtype=torch.float32)
+        ds = DeviceDataset(pool, device)
+        pool_nmax = int(max(c["x"].shape[0] for c in pool))
+        rng = np.random.default_rng(777 + rank)
+        order = {"perm": rng.permutation(len(ds)), "pos": 0}
+
+        def next_batch():
+            if order["pos"] + B > len(ds):            # next epoch: reshuffle
+                order["perm"], order["pos"] = rng.permutation(len(ds)), 0
+            idx = order["perm"][order["pos"]:order["pos"] + B]
+            order["pos"] += B
+            g = ds.collate(idx, n_max=pool_nmax)
+            real_dims.append((g.meta.num_nodes, g.meta.num_edges, g.meta.n_max))
+            return g
+    else:
+        # device-resident, pre-collated shards of N_DISTINCT_BATCHES global batches (global n_max per batch);
+        # in graph / replay mode each is padded (exactly: ghost nodes/edges) to its (N, E) shape bucket
+        batches = []
+        for k in range(N_DISTINCT_BATCHES):
+            crystals = make_crystals(kind, B * world, seed=k, dtype=torch.float32)
+            g = shard_batch(crystals, world, rank)
+            real_dims.append((g.meta.num_nodes, g.meta.num_edges, g.meta.n_max))
+            if use_graph:
+                g = pad_batch(g, *bucket_sizes(g.meta.num_nodes, g.meta.num_edges, *bucket))
+            batches.append(g.to(device))
+        it = {"i": 0}
+
+        def next_batch():
+            g = batches[it["i"] % len(batches)]
+            it["i"] += 1
+            return g
 
     def sync():
         torch.cuda.synchronize()
         if dp is not None:
             td.barrier()
 
-    for i in range(max(args.warmup, len(batches) if use_graph else 0)):     # graph mode: capture every bucket
-        trainer.step(batches[i % len(batches)], n_global)
+    n_warm = max(args.warmup, N_DISTINCT_BATCHES if (use_graph and not args.shuffle) else 0)   # record every fixed bucket
+    for i in range(n_warm):
+        trainer.step(next_batch(), n_global)
     sync()
     # eager mode: per-kernel HIP-event timing over the timed region itself (same stream as the launches);
-    # graph mode: the timed region replays captured graphs (no per-kernel events possible), so the
+    # graph / replay mode: the timed region re-issues recorded launches (no per-kernel events possible), so the
     # kernel timing comes from an instrumented eager pass of the same steps right after it.
     ops.KERNEL_TIMER.reset(enabled=not use_graph)
+    hits0, miss0 = trainer.slot_hits, trainer.slot_misses
+    if args.shuffle:
+        real_dims.clear()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        trainer.step(batches[i % len(batches)], n_global)
+        trainer.step(next_batch(), n_global)
     torch.cuda.synchronize()
     if dp is not None:
         td.barrier()
     elapsed = time.perf_counter() - t0
     ops.KERNEL_TIMER.enabled = False
+    hits, misses = trainer.slot_hits - hits0, trainer.slot_misses - miss0
+    n_slots = len(trainer._slots)
+    n_inst = 0
     if use_graph:
         trainer.graph = trainer.replay = False
         ops.KERNEL_TIMER.reset(enabled=True)
-        for i in range(min(args.steps, 24)):
+        n_inst = min(args.steps, 24)
+        for i in range(n_inst):
             # An eager step is host-bound (~17 us of Python per launch): without a head start the GPU
             # would idle between a site's start event and its kernel and the bracket would time the host.
-            # A ~4 ms device-side spin lets the host enqueue the whole step first, so every bracket times
+            # A device-side spin lets the host enqueue the whole step first, so every bracket times
             # back-to-back GPU execution (a bracket then adds ~1 us to a kernel: tools/event_overhead.py).
-            torch.cuda._sleep(int(1.0e7))
-            trainer.step(batches[i % len(batches)], n_global)
+            g = next_batch()
+            torch.cuda._sleep(int(1.5e7))
+            trainer.step(g, n_global)
             torch.cuda.synchronize()
         ops.KERNEL_TIMER.enabled = False
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    else:
+        n_inst = args.steps
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.dist_backend == "nccl" else "cpu")
     if dp is not None:
         td.all_reduce(t, op=td.ReduceOp.MAX)
     elapsed = float(t[0])
 
     if rank == 0:
         roof = ops.KERNEL_TIMER.roofline(HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS)
-        # HBM traffic per launch from the committed rocprofv3 PMC passes (cannot be collected in-process)
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["sites"]
-        except Exception:
-            pmc = {}
-        if args.config == "phonon_h128_b64" and world == 1:
-            for rec in roof["all"] + ([roof["dominant"]] if roof["dominant"] else []):
-                if rec["site"] in pmc:
-                    rec["traffic"] = pmc[rec["site"]]["hbm_bytes_per_launch"]
+        kernels, traffic_src = load_traffic() if (args.config == "phonon_h128_b64" and world == 1 and not args.shuffle) \
+            else ({}, "traffic is profiled for the default configuration only")
+        for rec in roof["all"] + ([roof["dominant"]] if roof["dominant"] else []):
+            rec["traffic"] = traffic_of(kernels, rec["kernel"])
+            rec["us_per_step"] = round(1e3 * rec["total_ms"] / max(n_inst, 1), 2)
+        ms_step = 1e3 * elapsed / args.steps
+        dims = real_dims if args.shuffle else [real_dims[i % len(real_dims)] for i in range(args.steps)]
+        flops_step = 3.0 * sum(algorithmic_flops(kind, L, T, H, n, e, B, nm) for n, e, nm in dims) / max(len(dims), 1)
         out = {
             "metric": "crystals/sec training throughput (Phonon DOS, hidden=128)" if kind == "phonon" else
                       "crystals/sec training throughput (Electron DOS)",
             "value": round(n_global * args.steps / elapsed, 2),
             "unit": "crystals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {kind} DOSTransformer layers={L} transformer={T} hidden={H}, "
-                                   f"{B} crystals/GPU (global batch {n_global}), full train step "
-                                   f"(fwd+loss+bwd+AdamW), {N_DISTINCT_BATCHES} distinct pre-collated batches",
+                                   f"{B} crystals/GPU (global batch {n_global}), full train step (fwd+loss+bwd+AdamW), " +
+                                   (f"a fresh random batch every step from a device-resident pool of {args.pool} crystals "
+                                    f"(on-GPU collate + ghost padding inside the timed region)" if args.shuffle else
+                                    f"{N_DISTINCT_BATCHES} distinct pre-collated batches"),
                        "global_batch": n_global, "parallelism": f"dp{world}",
                        "launch": {"graph": "hip-graph replay per (N,E) bucket, exact ghost padding",
                                   "replay": "recorded launch list per (N,E) bucket (exact ghost padding), 2 HIP streams",
                                   "eager": "eager"}[mode],
-                       "kernel_timing": ("HIP events, instrumented eager pass after the timed region" if use_graph
-                                         else "HIP events inside the timed region")},
+                       "bucket": list(bucket),
+                       "kernel_timing": ("HIP events around every libdosx launch, instrumented eager pass after the timed region"
+                                         if use_graph else "HIP events around every libdosx launch inside the timed region")},
+            # whole-step figure: algorithmic flops of a train step (SURVEY.md §8d formula on the real, un-padded rows,
+            # x3 for fwd+bwd) / measured step time / fp32 MFMA dense peak
+            "step_frac": round(flops_step / (ms_step * 1e-3) / (MFMA_F32_PEAK_TFLOPS * 1e12), 4),
+            "step_gflop": round(flops_step / 1e9, 2),
             "roofline": roof["dominant"],
+            "traffic_source": traffic_src,
             "kernels": roof["all"],
         }
+        if use_graph:
+            out["slots"] = {"hits": hits, "misses": misses, "hit_rate": round(hits / max(hits + misses, 1), 4),
+                            "live": n_slots, "max": trainer.max_slots}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kind, L, T, H, B, args.cpu_budget)
         sys.stdout.flush()

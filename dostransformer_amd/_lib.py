@@ -112,8 +112,13 @@ class Ffn(C.Structure):
     ]
 
 
+class CopyJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("dwords", C.c_int64)]
+
+
 class Call(C.Structure):
-    _fields_ = [("fn", C.c_void_p), ("kind", C.c_int32), ("nint", C.c_int32), ("iarg", C.c_int64 * 19), ("farg", C.c_double * 6)]
+    _fields_ = [("op", C.c_int32), ("nint", C.c_int32), ("nflt", C.c_int32), ("reserved", C.c_int32),
+                ("iarg", C.c_int64 * 19), ("farg", C.c_double * 6)]
 
 
 # name -> argtypes  (restype is int unless listed in _RESTYPES)
@@ -121,6 +126,7 @@ _P, _I, _F, _L, _D = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_double
 _SIGS = {
     "dosx_gemm_partial_rows": [_I, _I, _I],
     "dosx_gemm": [C.POINTER(Gemm), _P],
+    "dosx_gemm_kernel_name": [C.POINTER(Gemm), C.c_char_p, _I],
     "dosx_wgrad_splits": [_I, _I, _I],
     "dosx_wgrad": [C.POINTER(Wgrad), _P],
     "dosx_wgrad_grouped": [C.POINTER(Wgrad), _I, _P],
@@ -158,7 +164,9 @@ _SIGS = {
     "dosx_collate": [_P] * 5 + [_I] * 3 + [_P] * 18 + [_P],
     "dosx_neighbor_count": [_P, _P, _P, _P, _I, _L, _D, _I, _I, _P, _P],
     "dosx_neighbor_fill": [_P, _P, _P, _P, _I, _L, _D, _I, _I, _P, _P, _P, _P, _P, _P, _P],
+    "dosx_replay_op": [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "dosx_replay": [C.POINTER(Call), _I, C.POINTER(C.c_int)],
+    "dosx_copy_many": [C.POINTER(CopyJob), _I, _P],
     "dosx_fill": [_P, _F, _L, _P],
     "dosx_embed_rows": [_P, _P, _P, _I, _I, _P],
     "dosx_embed_rows_bwd": [_P, _I, _P, _P, _I, _I, _I, _P],
@@ -196,6 +204,23 @@ def load() -> C.CDLL:
         fn.restype = _RESTYPES.get(name, C.c_int)
     _lib = lib
     return lib
+
+
+def source_hash() -> str:
+    """sha256 (first 16 hex digits) over the sources that decide which kernels a step launches and what they do: csrc/,
+    include/dosx.h and the launch-sequencing Python.  profiles/r*_pmc_traffic.json carries the hash it was measured on;
+    bench.py refuses the file when it differs (the box has no .git, so a content hash stands in for the commit)."""
+    import glob
+    import hashlib
+    root = os.path.dirname(_HERE)
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) +
+                   glob.glob(os.path.join(_HERE, "csrc", "*.cpp")))
+    files += [os.path.join(root, "include", "dosx.h")] + [os.path.join(_HERE, f) for f in ("functional.py", "ops.py", "train.py")]
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.relpath(f, root).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def check(rc: int, what: str) -> None:

@@ -103,6 +103,8 @@ class CrystalBatch:
         object.__setattr__(self, "_fields", dict(fields))
         object.__setattr__(self, "num_graphs", int(num_graphs))
         object.__setattr__(self, _META_KEY, meta)
+        object.__setattr__(self, "n_global", None)         # crystals in the un-sharded batch (set by dist.shard_batch)
+        object.__setattr__(self, "_dosx_padded", None)     # predict.Predictor's cached ghost-padded copy
 
     # --- mapping protocol (`'batch' in data`, `data['edge_index']`) ---
     def __contains__(self, key):
@@ -113,6 +115,7 @@ class CrystalBatch:
 
     def __setitem__(self, key, value):
         self._fields[key] = value
+        object.__setattr__(self, "_dosx_padded", None)     # (contents changed: the cached padded copy is stale)
 
     def keys(self):
         return self._fields.keys()
@@ -125,10 +128,11 @@ class CrystalBatch:
         raise AttributeError(name)
 
     def __setattr__(self, name, value):
-        if name in ("num_graphs", _META_KEY):
+        if name in ("num_graphs", _META_KEY, "n_global"):
             object.__setattr__(self, name, value)
         else:
             self._fields[name] = value
+        object.__setattr__(self, "_dosx_padded", None)     # (contents / metadata changed: cached padded copy is stale)
 
     @property
     def meta(self) -> Optional[GraphMeta]:
@@ -136,21 +140,30 @@ class CrystalBatch:
 
     def to(self, device, dtype: Optional[torch.dtype] = None) -> "CrystalBatch":
         """In-place move like PyG's ``batch.to(device)`` (`main_eDOS.py:106`); returns self."""
+        moved = False
         for k, v in list(self._fields.items()):
             if isinstance(v, torch.Tensor):
-                if dtype is not None and v.is_floating_point():
-                    v = v.to(dtype)
-                self._fields[k] = v.to(device)
+                w = v
+                if dtype is not None and w.is_floating_point():
+                    w = w.to(dtype)
+                w = w.to(device)
+                if w is not v:
+                    self._fields[k] = w
+                    moved = True
         m = self.meta
-        if m is not None:
+        if m is not None and m.src.device != torch.empty(0, device=device).device:
             object.__setattr__(self, _META_KEY, m.to(device))
-        object.__setattr__(self, "_dosx_padded", None)      # (predict.Predictor's cached ghost-padded copy is stale now)
+            moved = True
+        if moved:           # (evaluation loops call .to(device) on every visit: keep Predictor's padded copy when nothing moved)
+            object.__setattr__(self, "_dosx_padded", None)
         return self
 
     def clone(self) -> "CrystalBatch":
         f = {k: (v.clone() if isinstance(v, torch.Tensor) else list(v) if isinstance(v, list) else v)
              for k, v in self._fields.items()}
-        return CrystalBatch(f, self.num_graphs, self.meta)
+        out = CrystalBatch(f, self.num_graphs, self.meta)
+        object.__setattr__(out, "n_global", self.n_global)
+        return out
 
     def __repr__(self):
         parts = []
@@ -374,4 +387,5 @@ def pad_batch(g: CrystalBatch, n_pad: int, e_pad: int) -> CrystalBatch:
     )
     out = CrystalBatch(f, B, meta)
     object.__setattr__(out, "real_nodes", N)
+    object.__setattr__(out, "n_global", g.n_global)
     return out

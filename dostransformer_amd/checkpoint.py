@@ -16,9 +16,13 @@ def save(path: str, model: torch.nn.Module, trainer=None, extra: Optional[dict] 
     torch.save(ckpt, path)
 
 
-def load(path: str, model: torch.nn.Module, trainer=None, strict: bool = True) -> dict:
-    """Loads a checkpoint written by :func:`save`, or a bare reference ``state_dict`` file."""
-    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+def load(path: str, model: torch.nn.Module, trainer=None, strict: bool = True, trust_pickle: bool = False) -> dict:
+    """Loads a checkpoint written by :func:`save`, or a bare reference ``state_dict`` file.
+
+    The format holds only tensors, str, int, float, tuple and dict, so files are read with ``weights_only=True``
+    (no arbitrary unpickling: upstream-trained ``state_dict`` files are third-party input).  ``trust_pickle=True`` is
+    the explicit opt-in for a legacy file that really needs the full unpickler."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=not trust_pickle)
     sd = ckpt["model"] if isinstance(ckpt, dict) and "model" in ckpt else ckpt
     model.load_state_dict(sd, strict=strict)
     if trainer is not None and isinstance(ckpt, dict) and ckpt.get("optimizer") is not None:

@@ -1089,6 +1089,32 @@ inline int gemm_rows_per_wg(int M, int N, int epi) {
   return rt == 0 ? 16 : (rt == 3 ? 48 : BM * rt);
 }
 
+// tile / vector-path selection of one GEMM: fills L, returns the column tile (128 / 256 / 512)
+static int gemm_plan(const DosxGemm& g, GemmLaunch& L) {
+  L.g = g;
+  L.vecA = seg_vec_ok(g.a, g.nseg) && (g.K & 3) == 0;
+  if (g.pro == DOSX_PRO_LN_PRELU || g.pro == DOSX_PRO_ROWLN)
+    L.vecA = L.vecA && aligned16(g.pro_gamma) && aligned16(g.pro_beta);
+  L.vecW = ((g.ldw & 3) == 0) && aligned16(g.w) && (g.w_layout == 0 ? (g.K & 3) == 0 : (g.N & 3) == 0);
+  L.rt = gemm_rt(g.M, g.N, g.epi);
+  int bn = gemm_bn(g.M, g.N, g.epi);
+  if (g.stats_out && bn < g.N) bn = g.N <= 256 ? 256 : 512;
+  if (bn == 512 && L.rt >= 2) L.rt = 1;
+  return bn;
+}
+
+// The device symbol dosx_gemm would launch for this descriptor, as rocprofv3 prints it ("gemm_kernel<RT, NTW, WL, PRO,
+// VEC, EPI>"): lets a profiler-side tool (bench.py's roofline, tools/pmc_traffic.py) tie a call site to its kernel.
+extern "C" int dosx_gemm_kernel_name(const DosxGemm* gp, char* buf, int n) {
+  DOSX_CHECK_ARG(gp && buf && n > 0, "dosx_gemm_kernel_name: bad args");
+  GemmLaunch L;
+  const int bn = gemm_plan(*gp, L);
+  const int vec = L.vecA && L.vecW;
+  snprintf(buf, (size_t)n, "gemm_kernel<%d, %d, %d, %d, %d, %d>", L.rt, bn / 128, gp->w_layout, vec ? gp->pro : 0, vec,
+           vec ? gp->epi : 0);
+  return 0;
+}
+
 extern "C" int dosx_gemm_partial_rows(int M, int N, int epi) {
   // one partial row per workgroup; row-wise epilogues run as one N tile (N <= 512), the
   // element-wise PRELU_BWD epilogue tiles N by 128.
@@ -1132,15 +1158,7 @@ extern "C" int dosx_gemm(const DosxGemm* gp, dosx_stream_t stream) {
   if (g.epi == DOSX_EPI_PRELU_BWD) DOSX_CHECK_ARG(g.aux && g.epi_alpha && (g.ldaux & 3) == 0, "dosx_gemm: PRELU_BWD needs aux/alpha");
 
   GemmLaunch L;
-  L.g = g;
-  L.vecA = seg_vec_ok(g.a, g.nseg) && (g.K & 3) == 0;
-  if (g.pro == DOSX_PRO_LN_PRELU || g.pro == DOSX_PRO_ROWLN)
-    L.vecA = L.vecA && aligned16(g.pro_gamma) && aligned16(g.pro_beta);
-  L.vecW = ((g.ldw & 3) == 0) && aligned16(g.w) && (g.w_layout == 0 ? (g.K & 3) == 0 : (g.N & 3) == 0);
-  L.rt = gemm_rt(g.M, g.N, g.epi);
-  int bn = gemm_bn(g.M, g.N, g.epi);
-  if (g.stats_out && bn < g.N) bn = g.N <= 256 ? 256 : 512;
-  if (bn == 512 && L.rt >= 2) L.rt = 1;
+  const int bn = gemm_plan(g, L);
   hipStream_t s = to_stream(stream);
   if (bn == 128) return dispatch_gemm<1>(L, s);
   if (bn == 256) return dispatch_gemm<2>(L, s);

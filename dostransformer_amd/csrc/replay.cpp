@@ -1,49 +1,84 @@
 // Host-side replay of a recorded launch list (include/dosx.h: dosx_replay).
 //
-// A training step on a fixed shape bucket is the same ~220 library calls every time.  `Trainer(replay=True)` records
-// them once (function pointer + marshalled arguments on static buffers, stream fork/join events included) and later
-// re-issues the list; doing that from Python costs ~6.6 us per entry in ctypes (1.5 ms per step, 80 % of the GPU time
-// of the step).  This loop does it in C: ~0.3 us per entry on top of the launch itself.
+// A training step on a fixed shape bucket is the same ~200 library calls every time.  `Trainer(replay=True)` records
+// them once (entry point + marshalled arguments on static buffers, stream fork/join events included) and later
+// re-issues the list; doing that from Python costs ~6.6 us per entry in ctypes (1.5 ms per step, as much as the GPU
+// time of the step).  This loop does it in C: ~0.3 us per entry on top of the launch itself.
 //
-// Calling convention (x86-64 System V, the only host this library targets): integer-class arguments (pointers,
-// int32/int64/size_t, by-pointer descriptors) travel in rdi, rsi, rdx, rcx, r8, r9 and then on the stack in order;
-// float / double arguments travel in xmm0.. independently of the integer ones.  So a recorded call is its integer
-// arguments in order plus its floating-point arguments in order, and the callee is invoked through a function-pointer
-// type with MAXI integer parameters followed by the floating-point ones: surplus integer arguments are ignored by the
-// callee (caller-cleaned stack).  `kind` selects the floating-point signature class.
+// Every entry names its callee by an OP index (dosx_replay_op("dosx_gemm") ...) and carries its integer-class
+// arguments (pointers, integers, by-pointer descriptors) and its floating-point arguments, each in declaration order.
+// The callee is reached through a TYPED thunk generated from include/dosx.h (tools/gen_replay_thunks.py ->
+// replay_thunks.inc): an ordinary C call with every argument cast to its declared parameter type, so nothing depends
+// on how a particular ABI passes surplus or mismatched arguments.
+#include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "../../include/dosx.h"
 
 void dosx_set_error(const char* fmt, ...);
 
-#define I19 int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, \
-            int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t
-#define A19(c) c.iarg[0], c.iarg[1], c.iarg[2], c.iarg[3], c.iarg[4], c.iarg[5], c.iarg[6], c.iarg[7], c.iarg[8], c.iarg[9], \
-               c.iarg[10], c.iarg[11], c.iarg[12], c.iarg[13], c.iarg[14], c.iarg[15], c.iarg[16], c.iarg[17], c.iarg[18]
+namespace {
+
+struct DosxThunk {
+  const char* name;
+  int (*call)(const DosxCall&);
+  int nint, nflt;
+};
+
+// stream fork / join of the recorded program (GradSink): plain HIP runtime calls on raw handles
+int thunk_hipEventRecord(const DosxCall& c) {
+  return (int)hipEventRecord((hipEvent_t)(uintptr_t)c.iarg[0], (hipStream_t)(uintptr_t)c.iarg[1]);
+}
+int thunk_hipStreamWaitEvent(const DosxCall& c) {
+  return (int)hipStreamWaitEvent((hipStream_t)(uintptr_t)c.iarg[0], (hipEvent_t)(uintptr_t)c.iarg[1], (unsigned)c.iarg[2]);
+}
+
+#include "replay_thunks.inc"
+
+constexpr int kNumThunks = (int)(sizeof(kThunks) / sizeof(kThunks[0]));
+const DosxThunk kHipThunks[] = {
+    {"hipEventRecord", thunk_hipEventRecord, 2, 0},
+    {"hipStreamWaitEvent", thunk_hipStreamWaitEvent, 3, 0},
+};
+constexpr int kNumHip = 2;
+
+inline const DosxThunk* thunk_of(int op) {
+  if (op >= 0 && op < kNumThunks) return &kThunks[op];
+  if (op >= DOSX_OP_HIP_BASE && op < DOSX_OP_HIP_BASE + kNumHip) return &kHipThunks[op - DOSX_OP_HIP_BASE];
+  return nullptr;
+}
+
+}  // namespace
+
+extern "C" int dosx_replay_op(const char* name, int* n_int, int* n_float) {
+  if (!name) return -1;
+  for (int i = 0; i < kNumThunks + kNumHip; ++i) {
+    const int op = i < kNumThunks ? i : DOSX_OP_HIP_BASE + (i - kNumThunks);
+    const DosxThunk* t = thunk_of(op);
+    if (strcmp(t->name, name) == 0) {
+      if (n_int) *n_int = t->nint;
+      if (n_float) *n_float = t->nflt;
+      return op;
+    }
+  }
+  return -1;
+}
 
 extern "C" int dosx_replay(const DosxCall* calls, int n, int* failed_index) {
   for (int i = 0; i < n; ++i) {
     const DosxCall& c = calls[i];
+    const DosxThunk* t = thunk_of(c.op);
     int rc;
-    switch (c.kind) {
-      case DOSX_CALL_INTS:
-        rc = reinterpret_cast<int (*)(I19)>(c.fn)(A19(c));
-        break;
-      case DOSX_CALL_F1:
-        rc = reinterpret_cast<int (*)(I19, float)>(c.fn)(A19(c), (float)c.farg[0]);
-        break;
-      case DOSX_CALL_F1D1:
-        rc = reinterpret_cast<int (*)(I19, float, double)>(c.fn)(A19(c), (float)c.farg[0], c.farg[1]);
-        break;
-      case DOSX_CALL_F6:
-        rc = reinterpret_cast<int (*)(I19, float, float, float, float, float, float)>(c.fn)(
-            A19(c), (float)c.farg[0], (float)c.farg[1], (float)c.farg[2], (float)c.farg[3], (float)c.farg[4], (float)c.farg[5]);
-        break;
-      default:
-        dosx_set_error("dosx_replay: entry %d has unknown kind %d", i, c.kind);
-        if (failed_index) *failed_index = i;
-        return -22;
+    if (!t) {
+      dosx_set_error("dosx_replay: entry %d has unknown op %d", i, c.op);
+      rc = -22;
+    } else if (c.nint != t->nint || c.nflt != t->nflt) {
+      dosx_set_error("dosx_replay: entry %d (%s) carries %d+%d arguments, the entry point takes %d+%d", i, t->name, c.nint,
+                     c.nflt, t->nint, t->nflt);
+      rc = -22;
+    } else {
+      rc = t->call(c);
     }
     if (rc != 0) {
       if (failed_index) *failed_index = i;

@@ -50,11 +50,29 @@ def shard_batch(crystals: Sequence[Dict[str, object]], world: int, rank: int, so
     lo, hi = shard_bounds([int(c["edge_index"].shape[1]) for c in crystals], world)[rank]
     if hi <= lo:
         raise ValueError(f"rank {rank} of {world} got an empty shard ({len(crystals)} crystals)")
-    return collate(crystals[lo:hi], sort_edges=sort_edges, n_max=n_max)
+    g = collate(crystals[lo:hi], sort_edges=sort_edges, n_max=n_max)
+    g.n_global = len(crystals)          # train.Trainer reads it instead of running a count collective every step
+    return g
+
+
+class _Done:
+    """Handle of a host-staged collective: the sum is done, its copy back to the device is queued on ``stream``."""
+
+    def __init__(self, stream=None):
+        self.stream = stream
+
+    def wait(self):
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        return True
 
 
 class DataParallel:
-    """The two collectives of a data-parallel step (see module doc)."""
+    """The two collectives of a data-parallel step (see module doc).
+
+    Production backend is ``nccl`` (= RCCL over xGMI): collectives run on device buffers, stream-ordered.  With a
+    ``gloo`` group (the CPU tests, and the 2-ranks-on-one-GPU harness of tests/test_dp_gpu.py — RCCL refuses two ranks
+    on one device) device tensors are staged through the host: same sums, synchronous."""
 
     def __init__(self, group=None):
         if not td.is_initialized():
@@ -62,22 +80,35 @@ class DataParallel:
         self.group = group
         self.world = td.get_world_size(group)
         self.rank = td.get_rank(group)
+        self.staged = td.get_backend(group) != "nccl"
+
+    def _sum(self, t: torch.Tensor) -> None:
+        if self.staged and t.is_cuda:
+            h = t.detach().cpu()                   # (synchronises with the stream that produced t)
+            td.all_reduce(h, op=td.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+        else:
+            td.all_reduce(t, op=td.ReduceOp.SUM, group=self.group)
 
     def all_reduce_sse(self, sse: torch.Tensor) -> None:
         """In-place sum over ranks of the phonon loss' two SSE scalars (no host synchronisation; the
         global element count is static: crystals in the un-sharded batch x 51)."""
-        td.all_reduce(sse, op=td.ReduceOp.SUM, group=self.group)
+        self._sum(sse)
 
     def global_count(self, local: int) -> int:
-        t = torch.tensor([float(local)], dtype=torch.float64,
-                         device="cuda" if td.get_backend(self.group) == "nccl" else "cpu")
+        """Sum of a per-rank count.  Blocking + host read: callers that know the global batch size pass it instead
+        (``dist.shard_batch`` records it on the batch, ``Trainer.step(g, n_global)``)."""
+        t = torch.tensor([float(local)], dtype=torch.float64, device="cpu" if self.staged else "cuda")
         td.all_reduce(t, op=td.ReduceOp.SUM, group=self.group)
         return int(round(float(t[0])))
 
     def all_reduce_grads(self, flat_grad: torch.Tensor) -> None:
-        td.all_reduce(flat_grad, op=td.ReduceOp.SUM, group=self.group)
+        self._sum(flat_grad)
 
     def all_reduce_grads_async(self, flat_grad: torch.Tensor):
         """Start the sum of a (contiguous slice of the) flat gradient buffer; ordered after the work already queued on
         the CURRENT stream.  Returns the handle; ``.wait()`` makes the then-current stream wait for the result."""
+        if self.staged and flat_grad.is_cuda:
+            self._sum(flat_grad)
+            return _Done(torch.cuda.current_stream())
         return td.all_reduce(flat_grad, op=td.ReduceOp.SUM, group=self.group, async_op=True)

@@ -91,15 +91,11 @@ def mlp_prelu_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: G
 # ------------------------------------------------------------------------------------------------
 # Edge / Node MLP: Linear -> LayerNorm -> PReLU -> Linear     (DOSTransformer_phonon.py:193,204)
 # ------------------------------------------------------------------------------------------------
-def mlp_ln_fwd(P: Params, key: str, a: SegList, M: int, H: int, res: Optional[torch.Tensor] = None,
-               tag: Optional[str] = None):
+def mlp_ln_fwd(P: Params, key: str, a: SegList, M: int, H: int, res: Optional[torch.Tensor] = None):
     dev = P[key + ".0.weight"].device
     xhat = _empty(dev, M, 2 * H)
     rstd = _empty(dev, M)
-    ev = ops.KERNEL_TIMER.start() if tag else None
     ops.gemm(M, 2 * H, a.segs, P[key + ".0.weight"], xhat, bias=P[key + ".0.bias"], epi=EPI_LN, aux_out=rstd)
-    if ev is not None:
-        ops.KERNEL_TIMER.stop(ev, tag, "gemm_kernel<NT,LN-epilogue>", "mfma", 2.0 * M * a.K * 2 * H)
     y = _empty(dev, M, H)
     ops.gemm(M, H, [seg(xhat)], P[key + ".3.weight"], y, pro=PRO_LN_PRELU, pro_gamma=P[key + ".1.weight"],
              pro_beta=P[key + ".1.bias"], pro_alpha=P[key + ".2.weight"], bias=P[key + ".3.bias"], res=res)
@@ -139,16 +135,11 @@ def gnn_fwd(P: Params, m: GraphMeta, x: torch.Tensor, e: torch.Tensor, L: int, m
     for l in range(L):
         pre = f"stacked_processor.{l}"
         a_e = SegList([seg(x, rmap=rowmap(idx=m.src)), seg(x, rmap=rowmap(idx=m.dst)), seg(e)], [x, e])
-        msg, cxe = mlp_ln_fwd(P, pre + ".edge_model.edge_mlp", a_e, E, H, tag="edge_mlp_gemm1_fwd")
+        msg, cxe = mlp_ln_fwd(P, pre + ".edge_model.edge_mlp", a_e, E, H)
         agg = _empty(dev, N, H)
         last = l == L - 1                       # the last layer's edge update is dead
         e_new = None if last else _empty(dev, E, H)
-        ev = ops.KERNEL_TIMER.start()
         ops.segment_reduce(msg, m.rowptr_dst, scale, agg, e, e_new, N, E, H)
-        # algorithmic bytes: messages + CSR row pointers + aggregated output (+ the fused edge residual
-        # e_new = e + msg: one more read and one write of [E,H])
-        ops.KERNEL_TIMER.stop(ev, "scatter_add_fwd", "segment_reduce_kernel", "hbm",
-                              4.0 * (E * H + (N + 1) + N * H + (0 if last else 2 * E * H)))
         a_n = SegList([seg(x), seg(agg)], [x, agg])
         x_new, cxn = mlp_ln_fwd(P, pre + ".node_model.node_mlp_2", a_n, N, H, res=x)
         ctxs.append((cxe, cxn))
@@ -203,9 +194,7 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
         st1 = _empty(dev, rows, 2)
         a = _attn_desc(Sq, Bq, Nk, Bk, H, qs, qb, x, kvhat, g0, b0)
         a.out, a.probs, a.qstats, a.out_stats = x1.data_ptr(), probs.data_ptr(), qstats.data_ptr(), st1.data_ptr()
-        ev = ops.KERNEL_TIMER.start()
         ops.attention_fwd(a)
-        ops.KERNEL_TIMER.stop(ev, f"attention_fwd_{pre}", "attn_fwd_kernel", "mfma", 4.0 * Bq * Sq * Nk * H)
         h = _empty(dev, rows, 4 * H)
         x2 = _empty(dev, rows, H)
         if ops.ffn_supported(H):
@@ -215,18 +204,13 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
             if final_ln and t == T - 1:
                 fin_fused = (_empty(dev, rows, H), _empty(dev, rows))
                 fin_args = (P[pre + ".layer_norm.weight"], P[pre + ".layer_norm.bias"]) + fin_fused
-            ev = ops.KERNEL_TIMER.start()
             ops.ffn_fwd(rows, H, x1, st1, P[lp + ".layer_norms.1.weight"], P[lp + ".layer_norms.1.bias"],
                         P[lp + ".fc1.weight"], P[lp + ".fc1.bias"], P[lp + ".fc2.weight"], P[lp + ".fc2.bias"], h, x2,
                         fin=fin_args)
-            ops.KERNEL_TIMER.stop(ev, f"ffn_fwd_{pre}", "ffn_fwd_kernel (fc1+relu+fc2 fused)", "mfma", 4.0 * rows * H * 4 * H)
         else:
-            ev = ops.KERNEL_TIMER.start()
             ops.gemm(rows, 4 * H, [seg(x1)], P[lp + ".fc1.weight"], h, pro=PRO_ROWLN,
                      pro_gamma=P[lp + ".layer_norms.1.weight"], pro_beta=P[lp + ".layer_norms.1.bias"], pro_stats=st1,
                      bias=P[lp + ".fc1.bias"], act=ACT_RELU)
-            ops.KERNEL_TIMER.stop(ev, f"ffn_fc1_fwd_{pre}", "gemm_kernel<NT,rowLN-prologue,relu>", "mfma",
-                                  2.0 * rows * H * 4 * H)
             ops.gemm(rows, H, [seg(h)], P[lp + ".fc2.weight"], x2, bias=P[lp + ".fc2.bias"], res=x1)
         lay.append((x, qs, qb, x1, probs, qstats, st1, h))
         x, qs, qb = x2, Bq, 1
@@ -331,7 +315,21 @@ class ModelCfg:
 
 
 def _f32(t: torch.Tensor) -> torch.Tensor:
-    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
+    if t.dtype == torch.float32 and t.is_contiguous():
+        return t
+    if ops.RECORDER.active:
+        # a torch cast is not a libdosx call: it would run once while recording and never again on replay, so the
+        # replayed kernels would keep reading the first batch's converted copy (train._Slot stores fp32 for this reason)
+        raise RuntimeError(f"recorded programs need float32 contiguous inputs, got {t.dtype} (contiguous={t.is_contiguous()})")
+    return t.to(torch.float32).contiguous()
+
+
+def _i32(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype == torch.int32 and t.is_contiguous():
+        return t
+    if ops.RECORDER.active:
+        raise RuntimeError(f"recorded programs need int32 contiguous indices, got {t.dtype}")
+    return t.to(torch.int32).contiguous()
 
 
 def _edge_inputs(cfg: ModelCfg, g, m: GraphMeta):
@@ -412,7 +410,7 @@ def dostransformer_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta):
     emb = P["embeddings.weight"]
     E1, c1 = encoder_fwd(P, "transformer", emb, S, B, 1, 0, kvhat, nmax, B, H, T)
     graph, dec_segs = decoder_fwd(P, cfg, m, xL, u)
-    sysidx = g.system if g.system.dtype == torch.int32 else g.system.to(torch.int32).contiguous()
+    sysidx = _i32(g.system)
     hp = H // 2
     prow = _empty(dev, B, hp)
     ops.embed_rows(P[cfg.prompt_key], sysidx, prow, B, hp)

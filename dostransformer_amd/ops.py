@@ -21,8 +21,11 @@ ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 
 
 class _KernelTimer:
-    """HIP-event timing of tagged launches (events are recorded on torch's current stream, the
-    stream every libdosx kernel is launched on).  Used by bench.py for the roofline figures."""
+    """HIP-event timing of EVERY libdosx launch (events are recorded on torch's current stream, the stream the call
+    is issued on — under ``torch.cuda.stream(side)`` that is the side stream).  Each wrapper below hands ``_call`` a
+    work record ``(site, kernel, bound, work)``: ``site`` names the launch family + shape, ``kernel`` the device symbol
+    (what rocprofv3 lists), ``bound`` 'mfma' | 'hbm' and ``work`` the ALGORITHMIC flops / bytes of the launch.  bench.py
+    turns the records into the ``roofline`` object: the dominant site is the one with the largest total time."""
 
     def __init__(self):
         self.enabled = False
@@ -111,25 +114,27 @@ class Program:
         self._events = []
 
     # ---- lowering ------------------------------------------------------------------------------------------
-    @staticmethod
-    def _hip():
-        lib = getattr(Program, "_hiplib", None)
-        if lib is None:
-            import os
-            lib = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
-            Program._hiplib = lib
-        return lib
-
     def _compile(self):
-        hip = self._hip()
-        ev_record = C.cast(hip.hipEventRecord, C.c_void_p).value
-        st_wait = C.cast(hip.hipStreamWaitEvent, C.c_void_p).value
+        lib = _lib.load()
+        ops_by_name = {}
+
+        def op_of(name):
+            if name not in ops_by_name:
+                ni, nf = C.c_int(0), C.c_int(0)
+                op = lib.dosx_replay_op(name.encode(), C.byref(ni), C.byref(nf))
+                if op < 0:
+                    raise RuntimeError(f"{name} is not a replayable entry point")
+                ops_by_name[name] = (op, ni.value, nf.value)
+            return ops_by_name[name]
+
         out = []
 
-        def emit(fnptr, ints, flts=(), kind=0):
+        def emit(name, ints, flts=()):
+            op, ni, nf = op_of(name)
+            if (ni, nf) != (len(ints), len(flts)):
+                raise RuntimeError(f"{name}: recorded {len(ints)}+{len(flts)} arguments, the entry point takes {ni}+{nf}")
             c = _lib.Call()
-            c.fn, c.kind, c.nint = fnptr, kind, len(ints)
-            assert len(ints) <= 19 and len(flts) <= 6
+            c.op, c.nint, c.nflt = op, len(ints), len(flts)
             for i, v in enumerate(ints):
                 c.iarg[i] = int(v) if v is not None else 0
             for i, v in enumerate(flts):
@@ -139,31 +144,27 @@ class Program:
         for fn, args in self.prog:
             owner = getattr(fn, "__self__", None)
             if isinstance(owner, torch.cuda.Event) and fn.__name__ == "record":          # ev.record(stream)
-                emit(ev_record, [owner.cuda_event, args[0].cuda_stream])
+                emit("hipEventRecord", [owner.cuda_event, args[0].cuda_stream])
             elif isinstance(owner, torch.cuda.Stream) and fn.__name__ == "wait_event":    # stream.wait_event(ev)
-                emit(st_wait, [owner.cuda_stream, args[0].cuda_event, 0])
+                emit("hipStreamWaitEvent", [owner.cuda_stream, args[0].cuda_event, 0])
             elif isinstance(owner, torch.cuda.Stream) and fn.__name__ == "wait_stream":   # main.wait_stream(side)
                 ev = torch.cuda.Event()
                 ev.record(args[0])                                                       # creates the hip event
                 self._events.append(ev)
-                emit(ev_record, [ev.cuda_event, args[0].cuda_stream])
-                emit(st_wait, [owner.cuda_stream, ev.cuda_event, 0])
+                emit("hipEventRecord", [ev.cuda_event, args[0].cuda_stream])
+                emit("hipStreamWaitEvent", [owner.cuda_stream, ev.cuda_event, 0])
             else:                                                                         # a libdosx entry point
-                ints, flts, sig = [], [], ""
+                ints, flts = [], []
                 for a, t in zip(args, fn.argtypes):
                     if t is C.c_float or t is C.c_double:
                         flts.append(a.value if hasattr(a, "value") else a)
-                        sig += "f" if t is C.c_float else "d"
                     elif hasattr(a, "_obj"):                                              # byref(descriptor)
                         ints.append(C.addressof(a._obj))
                     elif isinstance(a, C.Array) or isinstance(a, C.Structure):
                         ints.append(C.addressof(a))
                     else:
                         ints.append(a.value if hasattr(a, "value") else a)
-                kind = {"": 0, "f": 1, "fd": 2, "ffffff": 3}.get(sig)
-                if kind is None:
-                    raise RuntimeError(f"no replay signature class for {getattr(fn, '__name__', fn)}: floats '{sig}'")
-                emit(C.cast(fn, C.c_void_p).value, ints, flts, kind)
+                emit(fn.__name__, ints, flts)
         self._n = len(out)
         self._calls = (_lib.Call * self._n)(*out)
 
@@ -189,11 +190,17 @@ class Program:
 RECORDER = _Recorder()
 
 
-def _call(name: str, *args) -> None:
+def _call(name: str, *args, w=None) -> None:
+    """Issue one libdosx entry point.  ``w``: callable returning the work record ``(site, kernel, bound, work)`` of this
+    launch, evaluated only when the kernel timer is on (bench.py's instrumented pass)."""
     fn = getattr(_lib.load(), name)
+    ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
     rc = fn(*args)
     if rc:
         _lib.check(rc, name)
+    if ev is not None:
+        site, kernel, bound, work = w() if w is not None else (name[5:], name[5:] + "_kernel", "hbm", 0.0)
+        KERNEL_TIMER.stop(ev, site, kernel, bound, work)
     if RECORDER.active:
         RECORDER.prog.append((fn, args))
 
@@ -278,7 +285,14 @@ def gemm(M: int, N: int, segs: Sequence[Seg], w: torch.Tensor, out: torch.Tensor
     g.aux_stats = _p(aux_stats)
     g.epi_gamma, g.epi_beta, g.epi_alpha = _p(epi_gamma), _p(epi_beta), _p(epi_alpha)
     g.partials, g.partial_ld = _p(partials), int(partial_ld)
-    _call("dosx_gemm", C.byref(g), _stream())
+    _call("dosx_gemm", C.byref(g), _stream(), w=lambda: _gemm_work(g))
+
+
+def _gemm_work(g: Gemm):
+    buf = C.create_string_buffer(96)
+    _lib.load().dosx_gemm_kernel_name(C.byref(g), buf, 96)
+    sym = buf.value.decode()
+    return (f"gemm[M{g.M},N{g.N},K{g.K},{sym[11:]}]", sym, "mfma", 2.0 * g.M * g.N * g.K)
 
 
 def ffn_supported(H: int) -> bool:
@@ -299,7 +313,8 @@ def ffn_fwd(M: int, H: int, x: torch.Tensor, stats: torch.Tensor, gamma, beta, w
     a.out, a.ldo = out.data_ptr(), int(out.stride(0))
     if fin is not None:
         a.fin_gamma, a.fin_beta, a.fin_xhat, a.fin_rstd = (t.data_ptr() for t in fin)
-    _call("dosx_ffn_fwd", C.byref(a), _stream())
+    _call("dosx_ffn_fwd", C.byref(a), _stream(),
+          w=lambda: (f"ffn_fwd[M{M},H{H}]", "ffn_fwd_kernel", "mfma", 16.0 * M * H * H))
 
 
 def ffn_bwd_partial_rows(M: int) -> int:
@@ -320,7 +335,8 @@ def ffn_bwd(M: int, H: int, dy: torch.Tensor, h: torch.Tensor, x: torch.Tensor, 
     a.dh, a.lddh = dh.data_ptr(), int(dh.stride(0))
     a.dx, a.lddx = dx.data_ptr(), int(dx.stride(0))
     a.partials, a.partial_ld = partials.data_ptr(), int(partials.stride(0))
-    _call("dosx_ffn_bwd", C.byref(a), _stream())
+    _call("dosx_ffn_bwd", C.byref(a), _stream(),
+          w=lambda: (f"ffn_bwd[M{M},H{H}]", "ffn_bwd_kernel", "mfma", 16.0 * M * H * H))
 
 
 def gemm_partial_rows(M: int, N: int, epi: int) -> int:
@@ -348,7 +364,8 @@ def wgrad_desc(M: int, N: int, dy: Seg, segs: Sequence[Seg], slab: torch.Tensor,
 def wgrad(M: int, N: int, dy: Seg, segs: Sequence[Seg], slab: torch.Tensor, slab_bias: Optional[torch.Tensor],
           nsplit: int, **pro) -> None:
     g = wgrad_desc(M, N, dy, segs, slab, slab_bias, nsplit, **pro)
-    _call("dosx_wgrad", C.byref(g), _stream())
+    _call("dosx_wgrad", C.byref(g), _stream(),
+          w=lambda: (f"wgrad[M{g.M},N{g.N},K{g.K}]", "wgrad_kernel", "mfma", 2.0 * g.M * g.N * g.K))
 
 
 def wgrad_grouped(descs: Sequence[Wgrad]) -> None:
@@ -356,7 +373,8 @@ def wgrad_grouped(descs: Sequence[Wgrad]) -> None:
     if not descs:
         return
     arr = (Wgrad * len(descs))(*descs)
-    _call("dosx_wgrad_grouped", arr, len(descs), _stream())
+    _call("dosx_wgrad_grouped", arr, len(descs), _stream(),
+          w=lambda: ("wgrad_grouped", "wgrad_grouped_kernel", "mfma", sum(2.0 * d.M * d.N * d.K for d in descs)))
 
 
 _LPT = __import__("os").environ.get("DOSX_WGRAD_LPT", "1") == "1"
@@ -480,7 +498,9 @@ class GradSink:
             arr = (ReduceJob * len(wv))()
             for i, j in enumerate(wv):
                 arr[i].src, arr[i].dst, arr[i].nsplit, arr[i].stride, arr[i].count, arr[i].accumulate = j
-            _call("dosx_reduce_partials", arr, len(wv), _stream())
+            _call("dosx_reduce_partials", arr, len(wv), _stream(),
+                  w=lambda wv=wv: ("reduce_partials", "reduce_partials_kernel", "hbm",
+                                   sum(4.0 * (j[2] + 1 + j[5]) * j[4] for j in wv)))
 
     def release(self):
         self._keep = []
@@ -490,76 +510,107 @@ def edge_feat_sh1(edge_vec: torch.Tensor, r_max: float = 4.0) -> torch.Tensor:
     _chk_f32(edge_vec)
     e = edge_vec.shape[0]
     out = alloc(edge_vec.device, e, 4)
-    _call("dosx_edge_feat_sh1", edge_vec.data_ptr(), out.data_ptr(), e, float(r_max), _stream())
+    _call("dosx_edge_feat_sh1", edge_vec.data_ptr(), out.data_ptr(), e, float(r_max), _stream(),
+          w=lambda: ("edge_feat_sh1", "edge_feat_kernel", "hbm", 28.0 * e))
     return out
 
 
 def segment_reduce(msg, rowptr, scale, agg, e_in, e_out, N, E, H):
-    _call("dosx_segment_reduce", _p(msg), _p(rowptr), _p(scale), _p(agg), _p(e_in), _p(e_out), N, E, H, _stream())
+    # algorithmic bytes: messages + CSR row pointers + aggregated output (+ the fused edge residual e_out = e_in + msg:
+    # one more read and one write of [E,H])
+    _call("dosx_segment_reduce", _p(msg), _p(rowptr), _p(scale), _p(agg), _p(e_in), _p(e_out), N, E, H, _stream(),
+          w=lambda: (f"scatter_add_fwd[N{N},E{E},H{H}{',res' if e_out is not None else ''}]", "segment_reduce_kernel", "hbm",
+                     4.0 * (E * H + (N + 1) + N * H + (2 * E * H if e_out is not None else 0))))
 
 
 def edge_grad_combine(de_new, dagg, ld_dagg, dst, scale, dmsg, E, H):
-    _call("dosx_edge_grad_combine", _p(de_new), dagg, ld_dagg, _p(dst), _p(scale), _p(dmsg), E, H, _stream())
+    _call("dosx_edge_grad_combine", _p(de_new), dagg, ld_dagg, _p(dst), _p(scale), _p(dmsg), E, H, _stream(),
+          w=lambda: (f"edge_grad_combine[E{E},H{H}]", "edge_grad_combine_kernel", "hbm",
+                     4.0 * (E * H * (3 if de_new is not None else 2) + E)))
 
 
 def gather_bwd(dcat, dnode_ptr, ld_dnode, dx_res, rowptr_dst, rowptr_src, perm_src, de_new, dx, de_out, N, E, H):
+    # algorithmic bytes: dcat [E,3H] read once (+ de_new read, de_out written), 3 index arrays, 3 node-row streams
     _call("dosx_gather_bwd", _p(dcat), dnode_ptr, ld_dnode, _p(dx_res), _p(rowptr_dst), _p(rowptr_src),
-                                   _p(perm_src), _p(de_new), _p(dx), _p(de_out), N, E, H, _stream())
+          _p(perm_src), _p(de_new), _p(dx), _p(de_out), N, E, H, _stream(),
+          w=lambda: (f"gather_bwd[N{N},E{E},H{H}]", "gather_bwd_kernel", "hbm",
+                     4.0 * (E * H * ((3 if de_out is not None else 2) + (1 if de_new is not None else 0)
+                                     + (1 if de_out is not None else 0)) + E + 2 * (N + 1) + 3 * N * H)))
 
 
 def graph_pool(x, graph_ptr, out_ptr, ld_out, B, H):
-    _call("dosx_graph_pool", _p(x), _p(graph_ptr), out_ptr, ld_out, B, H, _stream())
+    _call("dosx_graph_pool", _p(x), _p(graph_ptr), out_ptr, ld_out, B, H, _stream(),
+          w=lambda: ("graph_pool", "graph_pool_kernel", "hbm", 4.0 * (x.shape[0] * H + B * H)))
 
 
 def graph_pool_bwd(dpool_ptr, ld, node_graph, dx, N, H, accumulate):
-    _call("dosx_graph_pool_bwd", dpool_ptr, ld, _p(node_graph), _p(dx), N, H, int(accumulate), _stream())
+    _call("dosx_graph_pool_bwd", dpool_ptr, ld, _p(node_graph), _p(dx), N, H, int(accumulate), _stream(),
+          w=lambda: ("graph_pool_bwd", "graph_pool_bwd_kernel", "hbm", 4.0 * N * H * (3 if accumulate else 2)))
 
 
 def dense_normalize(x, dense_row, kvhat, rstd_nodes, N, H, dense_rows):
-    _call("dosx_dense_normalize", _p(x), _p(dense_row), _p(kvhat), _p(rstd_nodes), N, H, dense_rows, _stream())
+    _call("dosx_dense_normalize", _p(x), _p(dense_row), _p(kvhat), _p(rstd_nodes), N, H, dense_rows, _stream(),
+          w=lambda: ("dense_normalize", "dense_normalize_kernel", "hbm", 4.0 * (N * H + dense_rows * H + N * H)))
 
 
 def dense_normalize_bwd(dkvhat, kvhat, rstd_nodes, dense_row, dx, N, H, accumulate):
     _call("dosx_dense_normalize_bwd", _p(dkvhat), _p(kvhat), _p(rstd_nodes), _p(dense_row), _p(dx), N, H,
-                                            int(accumulate), _stream())
+          int(accumulate), _stream(),
+          w=lambda: ("dense_normalize_bwd", "dense_normalize_bwd_kernel", "hbm", 4.0 * N * H * 3))
 
 
 def rownorm(x, xhat, rstd, M, H):
-    _call("dosx_rownorm", _p(x), _p(xhat), _p(rstd), M, H, _stream())
+    _call("dosx_rownorm", _p(x), _p(xhat), _p(rstd), M, H, _stream(),
+          w=lambda: ("rownorm", "rownorm_kernel", "hbm", 8.0 * M * H))
 
 
 def rownorm_bwd(dxhat, xhat, rstd, dx, M, H, accumulate):
-    _call("dosx_rownorm_bwd", _p(dxhat), _p(xhat), _p(rstd), _p(dx), M, H, int(accumulate), _stream())
+    _call("dosx_rownorm_bwd", _p(dxhat), _p(xhat), _p(rstd), _p(dx), M, H, int(accumulate), _stream(),
+          w=lambda: ("rownorm_bwd", "rownorm_bwd_kernel", "hbm", 12.0 * M * H))
 
 
 def rownorm_bwd_act(dxhat, xhat, rstd, dx_in, y, slope, out, M, H):
     """out = (dx_in + rownorm_bwd(dxhat, xhat, rstd)) * (y > 0 ? 1 : slope)   (include/dosx.h: dosx_rownorm_bwd_act)."""
-    _call("dosx_rownorm_bwd_act", _p(dxhat), _p(xhat), _p(rstd), _p(dx_in), _p(y), float(slope), _p(out), M, H, _stream())
+    _call("dosx_rownorm_bwd_act", _p(dxhat), _p(xhat), _p(rstd), _p(dx_in), _p(y), float(slope), _p(out), M, H, _stream(),
+          w=lambda: ("rownorm_bwd_act", "rownorm_bwd_act_kernel", "hbm", 20.0 * M * H))
 
 
 def layernorm(x, gamma, beta, y, xhat, rstd, M, H):
-    _call("dosx_layernorm", _p(x), _p(gamma), _p(beta), _p(y), _p(xhat), _p(rstd), M, H, _stream())
+    _call("dosx_layernorm", _p(x), _p(gamma), _p(beta), _p(y), _p(xhat), _p(rstd), M, H, _stream(),
+          w=lambda: ("layernorm", "ln_fwd_kernel", "hbm", 12.0 * M * H))
 
 
 def layernorm_bwd(dy, xhat, rstd, gamma, dx, partials, M, H):
-    _call("dosx_layernorm_bwd", _p(dy), _p(xhat), _p(rstd), _p(gamma), _p(dx), _p(partials), M, H, _stream())
+    _call("dosx_layernorm_bwd", _p(dy), _p(xhat), _p(rstd), _p(gamma), _p(dx), _p(partials), M, H, _stream(),
+          w=lambda: ("layernorm_bwd", "ln_bwd_kernel", "hbm", 12.0 * M * H))
+
+
+def _attn_shape(a: Attn) -> str:
+    return f"Sq{a.Sq},Bq{a.Bq},Nk{a.Nk},Bk{a.Bk},H{a.H}"
 
 
 def attention_fwd(a: Attn):
-    _call("dosx_attention_fwd", C.byref(a), _stream())
+    # algorithmic flops: Q.K^T and P.V, 2*Sq*Nk*H each per query batch entry
+    _call("dosx_attention_fwd", C.byref(a), _stream(),
+          w=lambda: (f"attention_fwd[{_attn_shape(a)}]", "attn_fwd", "mfma", 4.0 * a.Bq * a.Sq * a.Nk * a.H))
 
 
 def attention_bwd(a: Attn):
-    _call("dosx_attention_bwd", C.byref(a), _stream())
+    # dP = dO.K^T and dQ = dS.K (dq half), dK = dS^T.Q and dV = P^T.dO (dkv half): 4*Bq*Sq*Nk*H flops each half
+    halves = (0 if a.flags & 4 else 1) + (0 if a.flags & 8 else 1)
+    name = "attention_bwd" + ("_dkv" if (a.flags & 4) else ("_dq" if (a.flags & 8) else ""))
+    _call("dosx_attention_bwd", C.byref(a), _stream(),
+          w=lambda: (f"{name}[{_attn_shape(a)}]", "attn_bwd", "mfma", 4.0 * halves * a.Bq * a.Sq * a.Nk * a.H))
 
 
 def ln_rowdot(x, gamma, beta, w, b, xhat, rstd, dos, S, Bq, H):
-    _call("dosx_ln_rowdot", _p(x), _p(gamma), _p(beta), _p(w), _p(b), _p(xhat), _p(rstd), _p(dos), S, Bq, H, _stream())
+    _call("dosx_ln_rowdot", _p(x), _p(gamma), _p(beta), _p(w), _p(b), _p(xhat), _p(rstd), _p(dos), S, Bq, H, _stream(),
+          w=lambda: ("ln_rowdot", "ln_rowdot_kernel", "hbm", 8.0 * S * Bq * H))
 
 
 def ln_rowdot_bwd(ddos, xhat, rstd, gamma, beta, w, dx, partials, S, Bq, H):
     _call("dosx_ln_rowdot_bwd", _p(ddos), _p(xhat), _p(rstd), _p(gamma), _p(beta), _p(w), _p(dx), _p(partials), S, Bq,
-                                      H, _stream())
+          H, _stream(), w=lambda: ("ln_rowdot_bwd", "ln_bwd_kernel", "hbm", 8.0 * S * Bq * H))
 
 
 def rowdot(x, w, b, dos, S, Bq, H):
@@ -590,11 +641,28 @@ def sum_to(src, n, dst):
 
 def adamw(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     _call("dosx_adamw", _p(p), _p(g), _p(m), _p(v), int(n), float(lr), float(beta1), float(beta2), float(eps),
-                              float(weight_decay), int(step), float(grad_scale), _stream())
+          float(weight_decay), int(step), float(grad_scale), _stream(),
+          w=lambda: ("adamw", "adamw_kernel", "hbm", 28.0 * n))
+
+
+def copy_many(pairs) -> None:
+    """dst.copy_(src) for every (dst, src) pair of same-sized 4-byte-element contiguous device tensors, in one launch."""
+    jobs = []
+    for dst, src in pairs:
+        assert dst.is_contiguous() and src.is_contiguous() and dst.element_size() == 4 and src.dtype == dst.dtype \
+            and dst.numel() == src.numel() and src.device == dst.device, "copy_many: mismatched pair"
+        if dst.numel():
+            jobs.append((src.data_ptr(), dst.data_ptr(), dst.numel()))
+    if not jobs:
+        return
+    arr = (_lib.CopyJob * len(jobs))(*jobs)
+    _call("dosx_copy_many", arr, len(jobs), _stream(),
+          w=lambda: ("copy_many", "copy_many_kernel", "hbm", 8.0 * sum(j[2] for j in jobs)))
 
 
 def fill(t: torch.Tensor, value: float):
-    _call("dosx_fill", t.data_ptr(), float(value), t.numel(), _stream())
+    _call("dosx_fill", t.data_ptr(), float(value), t.numel(), _stream(),
+          w=lambda: ("fill", "fill_kernel", "hbm", 4.0 * t.numel()))
 
 
 def embed_rows(table, idx, out, rows, width):
@@ -607,11 +675,13 @@ def embed_rows_bwd(dout_ptr, ld, idx, dtable, rows, table_rows, width):
 
 def reduce_rows(src_ptr, ld_src, dst_ptr, ld_dst, n_out, n_red, stride_out, stride_red, width, accumulate=False):
     _call("dosx_reduce_rows", src_ptr, ld_src, dst_ptr, ld_dst, n_out, n_red, stride_out, stride_red, width,
-                                    int(accumulate), _stream())
+          int(accumulate), _stream(),
+          w=lambda: ("reduce_rows", "reduce_rows_kernel", "hbm", 4.0 * width * n_out * (n_red + 1)))
 
 
 def act_bwd(dy, y, slope, out):
-    _call("dosx_act_bwd", _p(dy), _p(y), float(slope), _p(out), dy.numel(), _stream())
+    _call("dosx_act_bwd", _p(dy), _p(y), float(slope), _p(out), dy.numel(), _stream(),
+          w=lambda: ("act_bwd", "act_bwd_kernel", "hbm", 12.0 * dy.numel()))
 
 
 def csr_build(edge_index: torch.Tensor, batch: torch.Tensor, num_graphs: int, want_perm: bool = True):

@@ -17,6 +17,7 @@ launches of a step cost the host ~20 us each when issued from Python; replay rem
 """
 from __future__ import annotations
 
+from collections import OrderedDict
 from typing import Dict, Optional
 
 import torch
@@ -38,7 +39,11 @@ class _Slot:
         self.fields = ["x", "system"] + (["edge_vec"] if kind == "phonon" else ["edge_attr", "glob"])
         if targets:
             self.fields.append("phdos" if kind == "phonon" else "y_ft")
-        f = {k: g[k].clone() for k in self.fields}
+        # Static buffers hold exactly what the kernels read: fp32 contiguous features, int32 indices.  load() then
+        # converts while it copies (the phonon pipeline is fp64 upstream, main_phDOS.py:15-16) and the recorded
+        # program never needs a cast of its own — a torch cast inside the recording would not be replayed.
+        f = {k: (g[k].to(torch.float32).contiguous().clone() if g[k].is_floating_point() else g[k].clone())
+             for k in self.fields}
         f["system"] = f["system"].to(torch.int32)                   # what the kernels index with
         f["edge_index"], f["batch"] = g.edge_index, g.batch         # never read by the kernels
         meta = GraphMeta(num_nodes=m.num_nodes, num_edges=m.num_edges, num_graphs=m.num_graphs, n_max=m.n_max,
@@ -50,11 +55,18 @@ class _Slot:
         self.keep = None
 
     def load(self, g: CrystalBatch) -> None:
-        for k in self.fields:
-            self.g[k].copy_(g[k], non_blocking=True)
+        """Copy a batch of this bucket's shape into the static buffers: ONE launch for everything that is already in
+        the kernels' format (fp32 / int32, contiguous, on the device); fields that need a dtype conversion (fp64
+        phonon data, int64 ``system``) or come from elsewhere go through ``Tensor.copy_``."""
+        pairs = []
         m, sm = g.meta, self.g.meta
-        for k in _META_TENSORS:
-            getattr(sm, k).copy_(getattr(m, k), non_blocking=True)
+        items = [(self.g[k], g[k]) for k in self.fields] + [(getattr(sm, k), getattr(m, k)) for k in _META_TENSORS]
+        for dst, src in items:
+            if src.dtype == dst.dtype and src.device == dst.device and src.is_contiguous() and src.shape == dst.shape:
+                pairs.append((dst, src))
+            else:
+                dst.copy_(src.reshape(dst.shape) if src.numel() == dst.numel() else src, non_blocking=True)
+        ops.copy_many(pairs)
 
 
 class Trainer:
@@ -67,7 +79,7 @@ class Trainer:
 
     def __init__(self, model: DOSTransformerBase, lr: float = 1e-4, beta: float = 1.0, weight_decay: float = 1e-2,
                  betas=(0.9, 0.999), eps: float = 1e-8, dist=None, graph: bool = False, replay: bool = False,
-                 bucket=(8, 128)):
+                 bucket=(8, 128), max_slots: int = 32):
         if not isinstance(model, DOSTransformerBase):
             raise TypeError("Trainer drives DOSTransformer / DOSTransformer_phonon modules")
         self.model, self.lr, self.beta, self.wd, self.betas, self.eps = model, lr, beta, weight_decay, betas, eps
@@ -86,14 +98,33 @@ class Trainer:
         self._fp = None
         self.kind = model._cfg.kind
         self.last_outputs = None
-        self._slots: Dict[tuple, _Slot] = {}
+        # shape buckets seen so far -> static buffers + recorded program, least recently used first; bounded: with
+        # per-epoch shuffling new (N, E) buckets keep appearing, each holding a step's worth of activations
+        self._slots: "OrderedDict[tuple, _Slot]" = OrderedDict()
+        self.max_slots = int(max_slots)
+        self.slot_hits = self.slot_misses = 0
 
     def _state(self, fp):
+        """AdamW moments laid out like ``fp``.  When the parameters are re-homed (module moved to another device after
+        ``load_state_dict``, a different dead-parameter set, ...) the moments follow BY NAME instead of being reset:
+        ``step_count`` keeps counting, so zeroed moments would silently corrupt the bias correction."""
         if self._fp is not fp:
-            self._m = torch.zeros_like(fp.flat)
-            self._v = torch.zeros_like(fp.flat)
-            self._fp = fp
-            self._slots = {}
+            m, v = torch.zeros_like(fp.flat), torch.zeros_like(fp.flat)
+            old = self._fp
+            if old is not None and self._m is not None:
+                old_off = dict(zip(old.names, old.offsets))
+                with torch.no_grad():
+                    for n, o in zip(fp.names, fp.offsets):
+                        oo = old_off.get(n)
+                        if oo is None:
+                            continue
+                        k = fp.P[n].numel()
+                        if old.P[n].numel() != k:
+                            raise RuntimeError(f"parameter {n} changed size under a running optimizer")
+                        m[o:o + k].copy_(self._m[oo:oo + k])
+                        v[o:o + k].copy_(self._v[oo:oo + k])
+            self._m, self._v, self._fp = m, v, fp
+            self._slots = OrderedDict()
         return self._m, self._v
 
     # ---- the step, split where the data-parallel collectives go --------------------------------
@@ -157,9 +188,14 @@ class Trainer:
             self._early_work = self.dist.all_reduce_grads_async(fp.grad[fp.n_late:])
         self._early_side = side
 
-    def _n_global(self, B: int, n_global: Optional[int]) -> int:
+    def _n_global(self, B: int, n_global: Optional[int], g=None) -> int:
+        """Crystals in the un-sharded batch: the caller's value, else what the sharder recorded on the batch
+        (``dist.shard_batch``), else — last resort, a blocking collective + host read — the sum over ranks."""
         if n_global is not None:
             return int(n_global)
+        ng = getattr(g, "n_global", None) if g is not None else None
+        if ng is not None:
+            return int(ng)
         return self.dist.global_count(B) if self.dist is not None else B
 
     # ---- eager path ------------------------------------------------------------------------------
@@ -171,7 +207,7 @@ class Trainer:
         fp = model._ensure_flat(dev, g)
         self._state(fp)
         m = graph_meta(g, dev)
-        ng = self._n_global(m.num_graphs, n_global)
+        ng = self._n_global(m.num_graphs, n_global, g)
         with torch.no_grad():
             st = self._part_a(fp, g, m)
             self.last_outputs = st["out"]
@@ -255,10 +291,13 @@ class Trainer:
         if getattr(g, "real_nodes", None) is None:               # not padded yet: pad on the fly
             g = pad_batch(g, *bucket_sizes(m.num_nodes, m.num_edges, *self.bucket))
             m = g.meta
-        ng = self._n_global(m.num_graphs, n_global)
+        ng = self._n_global(m.num_graphs, n_global, g)
         key = (m.num_nodes, m.num_edges, m.num_graphs, m.n_max, ng)
         slot = self._slots.get(key)
         if slot is None:
+            self.slot_misses += 1
+            while len(self._slots) >= self.max_slots:          # evict the least recently used bucket
+                self._slots.popitem(last=False)
             slot = _Slot(g, self.kind)
             self._slots[key] = slot
             if self.replay:
@@ -266,6 +305,9 @@ class Trainer:
                 self.last_outputs = slot.out
                 return slot.loss
             self._capture(slot, fp, ng)
+        else:
+            self.slot_hits += 1
+            self._slots.move_to_end(key)
         slot.load(g)
         if self.replay:
             for kind, prog in slot.plan:

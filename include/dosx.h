@@ -106,6 +106,9 @@ typedef struct DosxGemm {
  * the row-wise epilogues, ceil(M/32)*ceil(N/128) for the element-wise PRELU_BWD epilogue. */
 int dosx_gemm_partial_rows(int M, int N, int epi);
 int dosx_gemm(const DosxGemm* g, dosx_stream_t stream);
+/* diagnostic: the device symbol dosx_gemm launches for this descriptor, as a profiler prints it
+ * ("gemm_kernel<RT, NTW, WL, PRO, VEC, EPI>"), written to the HOST buffer buf[n]. */
+int dosx_gemm_kernel_name(const DosxGemm* g, char* buf, int n);
 
 /* dW partial slabs: slab[s][N][K] = sum_{m in split s} dY[m][n] * prologue(A)[m][k]
  * (nn.Linear weight gradient), optional bias partial slab_bias[s][N] = sum_m dY[m][n].
@@ -367,21 +370,34 @@ int dosx_neighbor_fill(const double* pos, const double* cell, const int32_t* ato
                        dosx_stream_t stream);
 
 /* Replay of a recorded launch list (the host side of train.Trainer(replay=True), see csrc/replay.cpp): `n` calls are
- * issued in order; a call = function pointer + its integer-class arguments in order (pointers, ints, by-pointer
- * descriptors; at most 19) + its floating-point arguments in order; `kind` names the floating-point signature
- * class.  Besides this library's own entry points the list may hold hipEventRecord / hipStreamWaitEvent (stream
- * fork/join).  Returns the first non-zero return code (index in *failed_index) or 0.  x86-64 System V hosts only. */
-enum { DOSX_CALL_INTS = 0, DOSX_CALL_F1 = 1, DOSX_CALL_F1D1 = 2, DOSX_CALL_F6 = 3 };
+ * issued in order.  A call names its callee by `op` (from dosx_replay_op: every `int dosx_*` entry point of this header,
+ * plus "hipEventRecord" / "hipStreamWaitEvent" for stream fork/join) and carries the callee's integer-class arguments in
+ * declaration order (pointers, integers, by-pointer descriptors; at most 19) and its float/double arguments in
+ * declaration order (at most 6).  Each op is dispatched through a typed thunk generated from this header, i.e. an
+ * ordinary C call.  Returns the first non-zero return code (its index in *failed_index) or 0. */
+enum { DOSX_OP_HIP_BASE = 1000 };
 typedef struct DosxCall {
-  void* fn;
-  int32_t kind;
+  int32_t op;
   int32_t nint;
+  int32_t nflt;
+  int32_t reserved;
   int64_t iarg[19];
   double farg[6];
 } DosxCall;
+/* op index of an entry point by name (-1 if unknown); optionally its integer-class / floating-point argument counts */
+int dosx_replay_op(const char* name, int* n_int, int* n_float);
 int dosx_replay(const DosxCall* calls, int n, int* failed_index);
 
 /* misc */
+/* Batched device-to-device copy in ONE launch: dst[0:dwords] = src[0:dwords] (32-bit words, 4-byte aligned, any mix of
+ * fp32 / int32 buffers).  jobs: HOST array, copied into kernel arguments (no device table, graph-capturable).
+ * train._Slot.load moves a batch's fields and CSR arrays into the static buffers of its shape bucket with it. */
+typedef struct DosxCopyJob {
+  const void* src;
+  void* dst;
+  int64_t dwords;
+} DosxCopyJob;
+int dosx_copy_many(const DosxCopyJob* jobs_host, int n_jobs, dosx_stream_t stream);
 int dosx_fill(float* p, float value, int64_t n, dosx_stream_t stream);
 /* out[r] = table[idx[r]] rows (prompt_token[g.system], DOSTransformer_phonon.py:105) and its backward
  * (deterministic: one workgroup per table row scans idx). */

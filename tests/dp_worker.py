@@ -1,0 +1,72 @@
+"""Worker of tests/test_dp_gpu.py: ONE rank of a 2-rank data-parallel run that shares cuda:0 with its peer.
+
+RCCL refuses two ranks on one device, so the group is gloo and `dist.DataParallel` stages its sums through the host;
+everything else — `shard_batch`, the SSE pre-reduce, the early-bucket hook, the split recording of replayed steps, the
+bucket logic of `optimizer_step` — is the production code path with world_size 2.
+
+usage: dp_worker.py <rank> <world> <port> <outdir>        (started as a fresh interpreter, never forked from a GPU process)"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CASES = [("phonon", "eager"), ("phonon", "replay"), ("edos", "eager"), ("edos", "replay")]
+STEPS = 3
+B_GLOBAL = 10
+
+
+def make_model(kind, dev):
+    torch.manual_seed(0)
+    if kind == "phonon":
+        from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+        return DOSTransformer_phonon(3, 2, 118, 4, 32, dev, 0.0).to(dev)
+    from dostransformer_amd.embedder_eDOS.DOSTransformer import DOSTransformer
+    return DOSTransformer(3, 1, 200, 41, 2, 32, dev, 0.0).to(dev)
+
+
+def make_crystals(kind, step):
+    from dostransformer_amd import synth
+    return synth.phonon_crystals(B_GLOBAL, 300 + step, torch.float32) if kind == "phonon" else \
+        synth.edos_crystals(B_GLOBAL, 400 + step, torch.float32)
+
+
+def main():
+    rank, world, port, outdir = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    import torch.distributed as td
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    from dostransformer_amd.dist import DataParallel, shard_batch
+    from dostransformer_amd.train import Trainer
+    dev = "cuda:0"
+    out = {}
+    for kind, mode in CASES:
+        model = make_model(kind, dev)
+        tr = Trainer(model, lr=1e-3, beta=1.0, dist=DataParallel(), replay=(mode == "replay"))
+        losses = []
+        # steps 0 and 2 use the SAME crystals (same bucket: step 2 is a true replay in replay mode), step 1 others
+        for step in (0, 1, 0)[:STEPS]:
+            g = shard_batch(make_crystals(kind, step), world, rank).to(dev)
+            n_global = None if step == 1 else B_GLOBAL          # step 1: take it from the batch (shard_batch records it)
+            losses.append(float(tr.step(g, n_global)))
+            if step == 0 and len(losses) == 1:
+                torch.cuda.synchronize()
+                out[f"{kind}/{mode}/grad0"] = model.flat_params().grad.detach().cpu().numpy().copy()
+        torch.cuda.synchronize()
+        fp = model.flat_params()
+        assert 0 < fp.n_late < fp.total and tr._early_work is None
+        out[f"{kind}/{mode}/loss"] = np.array(losses)
+        for k, v in model.state_dict().items():
+            if v.is_floating_point():
+                out[f"{kind}/{mode}/p/{k}"] = v.detach().cpu().numpy()
+        td.barrier()
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)
+    td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -138,3 +138,73 @@ def test_flat_params_bucket_layout():
     for n, o in zip(fp.names, fp.offsets):
         assert (o < fp.n_late) == is_late_param(n) and o % 64 == 0
     assert fp.n_late % 64 == 0 and 0 < fp.n_late < fp.total
+
+
+def test_checkpoint_is_read_without_unpickling_objects(tmp_path):
+    """checkpoint.load uses weights_only=True: a file carrying an arbitrary pickled object is refused unless
+    the caller opts in; our own format (tensors / str / int / float / tuple / dict) round-trips."""
+    from dostransformer_amd import checkpoint
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    torch.manual_seed(0)
+    m = DOSTransformer_phonon(3, 1, 118, 4, 16, "cpu", 0.0)
+    p = str(tmp_path / "a.pt")
+    checkpoint.save(p, m, extra={"epoch": 3, "note": "x"})
+    m2 = DOSTransformer_phonon(3, 1, 118, 4, 16, "cpu", 0.0)
+    assert checkpoint.load(p, m2) == {"epoch": 3, "note": "x"}
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+
+    class Evil:
+        def __reduce__(self):
+            return (print, ("pwned",))
+    bad = str(tmp_path / "bad.pt")
+    torch.save({"model": m.state_dict(), "extra": {"x": Evil()}}, bad)
+    with pytest.raises(Exception):
+        checkpoint.load(bad, m2)
+
+
+def test_padded_copy_cache_is_invalidated_by_assignment():
+    g = synth.phonon_batch(2, seed=5, dtype=torch.float32)
+    object.__setattr__(g, "_dosx_padded", ("bucket", "copy"))
+    g.to("cpu")
+    assert g._dosx_padded is not None                      # nothing moved
+    g.x = g.x * 2
+    assert g._dosx_padded is None
+    object.__setattr__(g, "_dosx_padded", ("bucket", "copy"))
+    g["edge_vec"] = g.edge_vec + 1
+    assert g._dosx_padded is None
+    object.__setattr__(g, "_dosx_padded", ("bucket", "copy"))
+    g.to("cpu", torch.float64)
+    assert g._dosx_padded is None and g.x.dtype == torch.float64
+
+
+def test_shard_batch_records_the_global_batch_size():
+    from dostransformer_amd.batch import bucket_sizes, pad_batch
+    cs = synth.phonon_crystals(7, seed=4, dtype=torch.float32)
+    g = shard_batch(cs, 2, 1)
+    assert g.n_global == 7
+    gp = pad_batch(g, *bucket_sizes(g.meta.num_nodes, g.meta.num_edges))
+    assert gp.n_global == 7 and gp.clone().n_global == 7
+    assert collate(cs).n_global is None
+
+
+def test_optimizer_moments_follow_rehomed_parameters():
+    """Trainer._state carries m / v BY NAME when the flat parameter buffer is rebuilt (CPU-only: pure bookkeeping)."""
+    from dostransformer_amd._fused import FlatParams
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    from dostransformer_amd.train import Trainer
+    torch.manual_seed(0)
+    m = DOSTransformer_phonon(3, 1, 118, 4, 16, "cpu", 0.0)
+    tr = Trainer(m)
+    fp = m.flat_params()
+    mm, vv = tr._state(fp)
+    mm.copy_(torch.arange(mm.numel(), dtype=torch.float32))
+    vv.fill_(2.0)
+    tr.step_count = 5
+    want = {n: mm[o:o + fp.P[n].numel()].clone() for n, o in zip(fp.names, fp.offsets)}
+    fp2 = FlatParams(m, torch.device("cpu"), extra_dead=("fc.bias",))       # a different layout (one parameter less)
+    m2, v2 = tr._state(fp2)
+    assert tr.step_count == 5 and m2.numel() == fp2.total
+    for n, o in zip(fp2.names, fp2.offsets):
+        assert torch.equal(m2[o:o + fp2.P[n].numel()], want[n]), n
+        assert float(v2[o:o + fp2.P[n].numel()].min()) == 2.0

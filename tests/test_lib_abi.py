@@ -95,3 +95,59 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py") and f != "smoke.py":       # smoke.py is __graft_entry__.smoke()'s body (checker allowed)
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), (dp, f)
+
+
+def test_replay_thunks_cover_the_header_and_are_typed():
+    """dosx_replay dispatches through thunks GENERATED from include/dosx.h (tools/gen_replay_thunks.py): every `int
+    dosx_*` entry point that fits a DosxCall has an op, with the argument-class counts of its prototype; the committed
+    replay_thunks.inc is what the generator produces from the committed header."""
+    from dostransformer_amd import _lib
+    lib = _lib.load()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_replay_thunks as gen
+    protos = list(gen.prototypes(open(HEADER).read()))
+    assert len(protos) >= 40
+    seen = set()
+    for name, params in protos:
+        ni = sum(1 for t in params if t not in gen.FLOAT_TYPES)
+        nf = len(params) - ni
+        a, b = C.c_int(-1), C.c_int(-1)
+        op = lib.dosx_replay_op(name.encode(), C.byref(a), C.byref(b))
+        if ni > 19 or nf > 6:
+            assert op == -1, name                       # does not fit a DosxCall: not replayable
+            continue
+        assert op >= 0 and (a.value, b.value) == (ni, nf), (name, op, a.value, b.value, ni, nf)
+        assert op not in seen
+        seen.add(op)
+    for name, n in (("hipEventRecord", 2), ("hipStreamWaitEvent", 3)):
+        a = C.c_int(-1)
+        assert lib.dosx_replay_op(name.encode(), C.byref(a), None) >= 1000 and a.value == n
+    assert lib.dosx_replay_op(b"no_such_entry", None, None) == -1
+    # a call whose argument counts do not match its entry point is rejected before anything is launched
+    c = _lib.Call()
+    c.op, c.nint, c.nflt = lib.dosx_replay_op(b"dosx_fill", None, None), 2, 1
+    failed = C.c_int(-1)
+    assert lib.dosx_replay((_lib.Call * 1)(c), 1, C.byref(failed)) != 0 and failed.value == 0
+    assert b"dosx_fill" in lib.dosx_last_error()
+    out = os.path.join(ROOT, "dostransformer_amd", "csrc", "replay_thunks.inc")
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        sys.argv, argv = ["gen", HEADER, os.path.join(d, "t.inc")], sys.argv
+        try:
+            gen.main()
+        finally:
+            sys.argv = argv
+        assert open(os.path.join(d, "t.inc")).read() == open(out).read()
+
+
+def test_gemm_kernel_name_matches_the_tile_choice():
+    from dostransformer_amd import _lib
+    lib = _lib.load()
+    g = _lib.Gemm()
+    g.M, g.N, g.K, g.nseg = 9000, 256, 384, 1
+    g.w_layout, g.pro, g.epi = 0, 0, 1
+    g.a[0].ld, g.a[0].width = 384, 384
+    g.ldw = 384
+    buf = C.create_string_buffer(96)
+    assert lib.dosx_gemm_kernel_name(C.byref(g), buf, 96) == 0
+    assert buf.value == b"gemm_kernel<3, 2, 0, 0, 1, 1>"       # 48-row tiles, 256 columns, LN epilogue (edge GEMM1 at cfg2)
