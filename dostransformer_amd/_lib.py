@@ -48,7 +48,7 @@ class Gemm(C.Structure):
         ("aux", C.c_void_p), ("ldaux", C.c_int32),
         ("aux_stats", C.c_void_p),
         ("epi_gamma", C.c_void_p), ("epi_beta", C.c_void_p), ("epi_alpha", C.c_void_p),
-        ("partials", C.c_void_p), ("partial_ld", C.c_int32),
+        ("partials", C.c_void_p), ("partial_ld", C.c_int32), ("res_col0", C.c_int32),
     ]
 
 
@@ -133,12 +133,13 @@ _SIGS = {
     "dosx_reduce_partials": [C.POINTER(ReduceJob), _I, _P],
     "dosx_edge_feat_sh1": [_P, _P, _I, _F, _P],
     "dosx_segment_reduce": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
-    "dosx_edge_grad_combine": [_P, _P, _I, _P, _P, _P, _I, _I, _P],
+    "dosx_edge_grad_combine": [_P, _I, _P, _I, _P, _P, _P, _I, _I, _P],
     "dosx_gather_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "dosx_graph_pool": [_P, _P, _P, _I, _I, _I, _P],
-    "dosx_graph_pool_bwd": [_P, _I, _P, _P, _I, _I, _I, _P],
+    "dosx_graph_pool_bwd": [_P, _I, _P, _P, _I, _I, _I, _I, _P],
     "dosx_dense_normalize": [_P, _P, _P, _P, _I, _I, _I, _P],
-    "dosx_dense_normalize_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "dosx_dense_normalize_slots": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "dosx_dense_normalize_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dosx_rownorm": [_P, _P, _P, _I, _I, _P],
     "dosx_rownorm_bwd": [_P, _P, _P, _P, _I, _I, _I, _P],
     "dosx_rownorm_bwd_act": [_P, _P, _P, _P, _P, _F, _P, _I, _I, _P],
@@ -152,6 +153,7 @@ _SIGS = {
     "dosx_rowdot_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "dosx_sse2": [_P, _P, _P, _P, _I, _P],
     "dosx_loss_phonon_bwd": [_P, _P, _P, _P, _F, _D, _P, _P, _P, _I, _P],
+    "dosx_loss_phonon": [_P, _P, _P, _P, _F, _P, _P, _P, _I, _P],
     "dosx_loss_edos": [_P, _P, _P, _F, _I, _I, _I, _P, _P, _P, _P],
     "dosx_sum": [_P, _I, _P, _P],
     "dosx_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],

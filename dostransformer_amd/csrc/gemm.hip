@@ -305,12 +305,19 @@ void gemm_kernel(const GemmLaunch L) {
       for (int j = 0; j < CG; ++j) { pv1[rt][i][j] = f4zero(); pv2[rt][i][j] = f4zero(); }
     }
     if (has1) {          // wave-uniform, outside every loop: the loads of all rows are issued back to back
+      // res_col0 (plain epilogue only): the residual covers the columns [res_col0, N) and its own column 0 is the
+      // output's column res_col0 - the edge-state gradient rides on the last H columns of the [E,3H] concat gradient
+      const int rc0 = aux_first ? 0 : g.res_col0;
 #pragma unroll
       for (int i = 0; i < ER; ++i) {
         const int rc = min(mb + wave * ER + i, M - 1);
         const size_t r1 = (size_t)(aux_first ? rc : dosx_map_row(g.res_map, rc)) * ld1;
 #pragma unroll
-        for (int j = 0; j < CG; ++j) pv1[rt][i][j] = ld4(p1 + r1 + gcol[j]);
+        for (int j = 0; j < CG; ++j) {
+          const bool in = gcol[j] >= rc0;                       // (load unconditionally from a valid address, then select)
+          const float4 t = ld4(p1 + r1 + (in ? gcol[j] - rc0 : 0));
+          pv1[rt][i][j] = in ? t : f4zero();
+        }
       }
     }
     if (has2) {
@@ -1142,6 +1149,8 @@ extern "C" int dosx_gemm(const DosxGemm* gp, dosx_stream_t stream) {
   DOSX_CHECK_ARG(!g.stats_out || g.N <= 128 * 4, "dosx_gemm: stats_out needs N <= 512");
   DOSX_CHECK_ARG(g.out_map.d > 0, "dosx_gemm: out_map.d must be > 0");
   if (g.res) DOSX_CHECK_ARG(g.res_map.d > 0 && (g.ldr & 3) == 0 && aligned16(g.res), "dosx_gemm: bad residual");
+  DOSX_CHECK_ARG(g.res_col0 >= 0 && (g.res_col0 & 3) == 0 && (g.res_col0 == 0 || (g.res && g.epi == DOSX_EPI_BIAS_ACT)),
+                 "dosx_gemm: res_col0=%d needs a residual, the plain epilogue and a multiple of 4", g.res_col0);
   if (g.pro == DOSX_PRO_LN_PRELU || g.pro == DOSX_PRO_ROWLN)
     DOSX_CHECK_ARG(g.pro_gamma && g.pro_beta, "dosx_gemm: prologue needs gamma/beta");
   if (g.pro == DOSX_PRO_ROWLN) DOSX_CHECK_ARG(g.pro_stats, "dosx_gemm: ROWLN prologue needs stats");
@@ -1520,7 +1529,13 @@ extern "C" int dosx_wgrad_splits(int M, int N, int K) {
   int s = ceil_div(512, tiles);
   const int cap = ceil_div(M, 128);
   if (s > cap) s = cap;
-  if (s > 16) s = 16;
+  static int max_split = 0;
+  if (max_split == 0) {
+    const char* e = getenv("DOSX_WGRAD_MAXSPLIT");
+    max_split = e ? atoi(e) : 16;
+    if (max_split < 1) max_split = 16;
+  }
+  if (s > max_split) s = max_split;
   if (s < 1) s = 1;
   return s;
 }

@@ -97,8 +97,9 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(const float* __rest
   }
 }
 
-// dmsg[e] = de_new[e] + scale[dst[e]] * dagg[dst[e]]   (element-wise over E*H/4 float4)
-__global__ void edge_grad_combine_kernel(const float* __restrict__ de_new, const float* __restrict__ dagg,
+// dmsg[e] = de_new[e] + scale[dst[e]] * dagg[dst[e]]   (element-wise over E*H/4 float4; de_new rows ld_de floats apart:
+// it is the e-block of the previous layer's [E,3H] concat gradient)
+__global__ void edge_grad_combine_kernel(const float* __restrict__ de_new, int ld_de, const float* __restrict__ dagg,
                                          int ld_dagg, const int* __restrict__ dst,
                                          const float* __restrict__ scale, float* __restrict__ dmsg, int E,
                                          int H) {
@@ -110,13 +111,21 @@ __global__ void edge_grad_combine_kernel(const float* __restrict__ de_new, const
     const float s = scale ? scale[d] : 1.f;
     float4 v = ld4(dagg + (size_t)d * ld_dagg + c);
     v = make_float4(v.x * s, v.y * s, v.z * s, v.w * s);
-    if (de_new) v = f4add(v, ld4(de_new + (size_t)e * H + c));
+    if (de_new) v = f4add(v, ld4(de_new + (size_t)e * ld_de + c));
     st4(dmsg + (size_t)e * H + c, v);
   }
 }
 
-// One wave per node: gather-backward (both gathers) + residuals; also the edge residual gradient.
-__global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict__ dcat,
+// Backward of the two gathers x[row], x[col] (+ node residuals).  One wave per node, H/4 lanes per row (a wave covers
+// 64/lpr rows per step).  Everything a node needs is fetched in THREE dependent round trips instead of one per group of
+// rows: (1) the four segment bounds, (2) up to GB_U rows per lane of the destination segment (contiguous rows of dcat,
+// columns [H,2H)) TOGETHER with the source segment's edge ids, (3) the source rows (columns [0,H)) those ids name.  The
+// previous version walked each segment 4 rows at a time (a chain of ~10 exposed L2 round trips per node: 20-34 us for
+// 450 nodes); segments longer than GB_U * rows-per-step simply loop.  Optional de_out / de_new: the edge residual
+// gradient (legacy form; the training programs now carry it on dcat's e-block instead, see DosxGemm.res_col0).
+constexpr int GB_U = 12;
+
+__global__ __launch_bounds__(128) void gather_bwd_kernel(const float* __restrict__ dcat,
                                                          const float* __restrict__ dnode, int ld_dnode,
                                                          const float* __restrict__ dx_res,
                                                          const int* __restrict__ rowptr_dst,
@@ -126,7 +135,7 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict
                                                          float* __restrict__ dx, float* __restrict__ de_out,
                                                          int N, int H) {
   const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int n = blockIdx.x * 2 + (threadIdx.x >> 6);
   if (n >= N) return;
   const RowLanes rl = row_lanes(H, lane);
   const size_t ldc = 3 * (size_t)H;
@@ -134,52 +143,51 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict
   const int sb = rowptr_src[n], se = rowptr_src[n + 1];
   for (int cb = 0; cb < H; cb += 256) {
     const int c = cb + rl.c4;
+    const bool cok = c < H;
+    const int cc = cok ? c : 0;
     float4 acc = f4zero();
-    if (c < H) {
-      // 4 edges in flight per lane slot (the one-edge loop was a chain of ~20 dependent L2 round trips per
-      // node: 14.7 us); indices beyond the segment are clamped and their contribution masked
-      for (int e0 = db + rl.slot; e0 < de; e0 += 4 * rl.rps) {
-        float4 v1[4], v2[4], v3[4];
+    float4 r0 = f4zero(), r1 = f4zero();
+    if (rl.slot == 0) {                          // node rows: issued up front, consumed at the very end
+      if (dx_res) r0 = ld4(dx_res + (size_t)n * H + cc);
+      if (dnode) r1 = ld4(dnode + (size_t)n * ld_dnode + cc);
+    }
+    int e0 = db + rl.slot, j0 = sb + rl.slot;
+    const int estep = GB_U * rl.rps;
+    while (e0 < de || j0 < se) {                 // wave-uniform trip count is max over the slots: lanes mask themselves
+      int ei[GB_U];
+      float4 v1[GB_U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int e = min(e0 + u * rl.rps, de - 1);
-          const float* row = dcat + (size_t)e * ldc;
-          v1[u] = ld4(row + H + c);
-          if (de_out) {
-            v2[u] = ld4(row + 2 * H + c);
-            if (de_new) v3[u] = ld4(de_new + (size_t)e * H + c);
-          }
-        }
+      for (int u = 0; u < GB_U; ++u) ei[u] = perm_src[min(max(j0 + u * rl.rps, 0), max(se - 1, 0))];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < GB_U; ++u) {
+        const int e = min(e0 + u * rl.rps, max(de - 1, 0));
+        v1[u] = ld4(dcat + (size_t)e * ldc + H + cc);
+      }
+      if (de_out) {                              // legacy edge-residual part (not on the training path any more)
+#pragma unroll
+        for (int u = 0; u < GB_U; ++u) {
           const int e = e0 + u * rl.rps;
-          if (e >= de) break;
-          acc = f4add(acc, v1[u]);
-          if (de_out) {
-            float4 v = v2[u];
-            if (de_new) v = f4add(v, v3[u]);
+          if (e < de && cok) {
+            float4 v = ld4(dcat + (size_t)e * ldc + 2 * H + c);
+            if (de_new) v = f4add(v, ld4(de_new + (size_t)e * H + c));
             st4(de_out + (size_t)e * H + c, v);
           }
         }
       }
-      for (int j0 = sb + rl.slot; j0 < se; j0 += 4 * rl.rps) {
-        int ei[4];
+      float4 v0[GB_U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) ei[u] = perm_src[min(j0 + u * rl.rps, se - 1)];
-        float4 v[4];
+      for (int u = 0; u < GB_U; ++u) v0[u] = ld4(dcat + (size_t)ei[u] * ldc + cc);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = ld4(dcat + (size_t)ei[u] * ldc + c);
+      for (int u = 0; u < GB_U; ++u)
+        if (e0 + u * rl.rps < de) acc = f4add(acc, v1[u]);
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (j0 + u * rl.rps < se) acc = f4add(acc, v[u]);
-      }
+      for (int u = 0; u < GB_U; ++u)
+        if (j0 + u * rl.rps < se) acc = f4add(acc, v0[u]);
+      e0 += estep;
+      j0 += estep;
     }
     acc = slots_sum(acc, rl.lpr);
-    if (c < H && rl.slot == 0) {
-      if (dx_res) acc = f4add(acc, ld4(dx_res + (size_t)n * H + c));
-      if (dnode) acc = f4add(acc, ld4(dnode + (size_t)n * ld_dnode + c));
-      st4(dx + (size_t)n * H + c, acc);
-    }
+    if (cok && rl.slot == 0) st4(dx + (size_t)n * H + c, f4add(acc, f4add(r0, r1)));
   }
 }
 
@@ -201,12 +209,15 @@ __global__ __launch_bounds__(256) void graph_pool_kernel(const float* __restrict
 }
 
 __global__ void graph_pool_bwd_kernel(const float* __restrict__ dpool, int ld, const int* __restrict__ node_graph,
-                                      float* __restrict__ dx, int N, int H, int accumulate) {
+                                      float* __restrict__ dx, int N, int H, int accumulate, int num_graphs) {
   const int h4 = H >> 2;
   const size_t total = (size_t)N * h4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int n = (int)(i / h4), c = (int)(i % h4) * 4;
-    float4 v = ld4(dpool + (size_t)node_graph[n] * ld + c);
+    const int gph = node_graph[n];
+    const bool ghost = num_graphs > 0 && gph >= num_graphs;
+    float4 v = ld4(dpool + (size_t)(ghost ? 0 : gph) * ld + c);
+    if (ghost) v = f4zero();
     if (accumulate) v = f4add(v, ld4(dx + (size_t)n * H + c));
     st4(dx + (size_t)n * H + c, v);
   }
@@ -242,6 +253,46 @@ __global__ __launch_bounds__(256) void dense_normalize_kernel(const float* __res
   if (lane == 0) rstd_nodes[n] = rstd;
 }
 
+// One wave per dense slot (pos, b): the node's normalised row, or zeros for a padded slot / the spare ghost row.
+__global__ __launch_bounds__(256) void dense_normalize_slots_kernel(const float* __restrict__ x,
+                                                                    const int* __restrict__ graph_ptr,
+                                                                    float* __restrict__ kvhat,
+                                                                    float* __restrict__ rstd_nodes, int B, int n_max, int H) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r > n_max * B) return;
+  float* o = kvhat + (size_t)r * H;
+  int n = -1;
+  if (r < n_max * B) {
+    const int pos = r / B, b = r % B;
+    const int beg = graph_ptr[b], end = graph_ptr[b + 1];
+    if (beg + pos < end) n = beg + pos;
+  }
+  if (n < 0) {
+    for (int c = lane * 4; c < H; c += 256) st4(o + c, f4zero());
+    return;
+  }
+  const float* row = x + (size_t)n * H;
+  float s1 = 0.f;
+  for (int c = lane * 4; c < H; c += 256) {
+    const float4 v = ld4(row + c);
+    s1 += v.x + v.y + v.z + v.w;
+  }
+  const float mean = wave_sum(s1) / (float)H;
+  float s2 = 0.f;
+  for (int c = lane * 4; c < H; c += 256) {
+    const float4 v = ld4(row + c);
+    const float a = v.x - mean, b2 = v.y - mean, c2 = v.z - mean, d = v.w - mean;
+    s2 += a * a + b2 * b2 + c2 * c2 + d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(s2) / (float)H + DOSX_LN_EPS);
+  for (int c = lane * 4; c < H; c += 256) {
+    const float4 v = ld4(row + c);
+    st4(o + c, make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd));
+  }
+  if (lane == 0) rstd_nodes[n] = rstd;
+}
+
 // generic "no-affine LN backward" for one row: dx = rstd * (g - mean(g) - xhat * mean(g*xhat))
 __device__ __forceinline__ void rownorm_bwd_row(const float* __restrict__ g, const float* __restrict__ xh,
                                                 float rstd, float* __restrict__ dx, int H, int lane,
@@ -267,11 +318,17 @@ __global__ __launch_bounds__(256) void dense_normalize_bwd_kernel(const float* _
                                                                   const float* __restrict__ rstd_nodes,
                                                                   const int* __restrict__ dense_row,
                                                                   float* __restrict__ dx, int N, int H,
-                                                                  int accumulate) {
+                                                                  int accumulate, int ghost_row) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
-  const size_t d = (size_t)dense_row[n] * H;
+  const int dr = dense_row[n];
+  if (dr == ghost_row) {            // ghost / padding node: zero gradient, rstd_nodes[n] was never written
+    if (!accumulate)
+      for (int c = lane * 4; c < H; c += 256) st4(dx + (size_t)n * H + c, f4zero());
+    return;
+  }
+  const size_t d = (size_t)dr * H;
   rownorm_bwd_row(dkvhat + d, kvhat + d, rstd_nodes[n], dx + (size_t)n * H, H, lane, accumulate);
 }
 
@@ -445,13 +502,14 @@ extern "C" int dosx_segment_reduce(const float* msg, const int32_t* rowptr, cons
   return 0;
 }
 
-extern "C" int dosx_edge_grad_combine(const float* de_new, const float* dagg, int ld_dagg, const int32_t* dst,
+extern "C" int dosx_edge_grad_combine(const float* de_new, int ld_de_new, const float* dagg, int ld_dagg, const int32_t* dst,
                                       const float* scale, float* dmsg, int E, int H, dosx_stream_t stream) {
   if (E <= 0) return 0;
   CHECK_H(H);
-  DOSX_CHECK_ARG(dagg && dst && dmsg && (ld_dagg & 3) == 0, "dosx_edge_grad_combine: bad args");
+  DOSX_CHECK_ARG(dagg && dst && dmsg && (ld_dagg & 3) == 0 && (!de_new || (ld_de_new >= H && (ld_de_new & 3) == 0)),
+                 "dosx_edge_grad_combine: bad args");
   hipLaunchKernelGGL(edge_grad_combine_kernel, dim3(grid_1d((size_t)E * (H / 4), 256)), dim3(256), 0,
-                     to_stream(stream), de_new, dagg, ld_dagg, dst, scale, dmsg, E, H);
+                     to_stream(stream), de_new, ld_de_new, dagg, ld_dagg, dst, scale, dmsg, E, H);
   DOSX_LAUNCH_CHECK();
   return 0;
 }
@@ -464,7 +522,7 @@ extern "C" int dosx_gather_bwd(const float* dcat, const float* dnode, int ld_dno
   if (N <= 0) return 0;
   CHECK_H(H);
   DOSX_CHECK_ARG(dcat && rowptr_dst && rowptr_src && perm_src && dx && (ld_dnode & 3) == 0, "dosx_gather_bwd: bad args");
-  hipLaunchKernelGGL(gather_bwd_kernel, dim3(ceil_div(N, 4)), dim3(256), 0, to_stream(stream), dcat, dnode, ld_dnode,
+  hipLaunchKernelGGL(gather_bwd_kernel, dim3(ceil_div(N, 2)), dim3(128), 0, to_stream(stream), dcat, dnode, ld_dnode,
                      dx_res, rowptr_dst, rowptr_src, perm_src, de_new, dx, de_out, N, H);
   DOSX_LAUNCH_CHECK();
   return 0;
@@ -482,12 +540,12 @@ extern "C" int dosx_graph_pool(const float* x, const int32_t* graph_ptr, float* 
 }
 
 extern "C" int dosx_graph_pool_bwd(const float* dpool, int ld_dpool, const int32_t* node_graph, float* dx, int N, int H,
-                                   int accumulate, dosx_stream_t stream) {
+                                   int accumulate, int num_graphs, dosx_stream_t stream) {
   if (N <= 0) return 0;
   CHECK_H(H);
   DOSX_CHECK_ARG(dpool && node_graph && dx && (ld_dpool & 3) == 0, "dosx_graph_pool_bwd: bad args");
   hipLaunchKernelGGL(graph_pool_bwd_kernel, dim3(grid_1d((size_t)N * (H / 4), 256)), dim3(256), 0, to_stream(stream),
-                     dpool, ld_dpool, node_graph, dx, N, H, accumulate);
+                     dpool, ld_dpool, node_graph, dx, N, H, accumulate, num_graphs);
   DOSX_LAUNCH_CHECK();
   return 0;
 }
@@ -509,14 +567,24 @@ extern "C" int dosx_dense_normalize(const float* x, const int32_t* dense_row, fl
   return 0;
 }
 
+extern "C" int dosx_dense_normalize_slots(const float* x, const int32_t* graph_ptr, float* kvhat, float* rstd_nodes, int B,
+                                          int n_max, int H, dosx_stream_t stream) {
+  CHECK_H(H);
+  DOSX_CHECK_ARG(x && graph_ptr && kvhat && rstd_nodes && B > 0 && n_max >= 0, "dosx_dense_normalize_slots: bad args");
+  hipLaunchKernelGGL(dense_normalize_slots_kernel, dim3(ceil_div(n_max * B + 1, 4)), dim3(256), 0, to_stream(stream), x,
+                     graph_ptr, kvhat, rstd_nodes, B, n_max, H);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int dosx_dense_normalize_bwd(const float* dkvhat, const float* kvhat, const float* rstd_nodes,
-                                        const int32_t* dense_row, float* dx, int N, int H, int accumulate,
+                                        const int32_t* dense_row, float* dx, int N, int H, int accumulate, int ghost_row,
                                         dosx_stream_t stream) {
   if (N <= 0) return 0;
   CHECK_H(H);
   DOSX_CHECK_ARG(dkvhat && kvhat && rstd_nodes && dense_row && dx, "dosx_dense_normalize_bwd: bad args");
   hipLaunchKernelGGL(dense_normalize_bwd_kernel, dim3(ceil_div(N, 4)), dim3(256), 0, to_stream(stream), dkvhat, kvhat,
-                     rstd_nodes, dense_row, dx, N, H, accumulate);
+                     rstd_nodes, dense_row, dx, N, H, accumulate, ghost_row);
   DOSX_LAUNCH_CHECK();
   return 0;
 }

@@ -268,6 +268,42 @@ __global__ void loss_phonon_bwd_kernel(const float* __restrict__ pg, const float
   }
 }
 
+// Single-process form of the two kernels above in ONE launch (one workgroup: the gradient needs the global SSE pair
+// first; B*S is a few thousand elements).  Same summation order as sse2_kernel -> bitwise the two-phase result.
+__global__ __launch_bounds__(1024) void loss_phonon_fused_kernel(const float* __restrict__ pg, const float* __restrict__ ps,
+                                                                 const float* __restrict__ y, float* __restrict__ sse,
+                                                                 float beta, float inv_count, float* __restrict__ dpg,
+                                                                 float* __restrict__ dps, float* __restrict__ loss, int count) {
+  __shared__ float red[2][16];
+  __shared__ float tot[2];
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < count; i += 1024) {
+    const float t = y[i], d0 = pg[i] - t, d1 = ps[i] - t;
+    a += d0 * d0;
+    b += d1 * d1;
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wave] = a; red[1][wave] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int i = 0; i < 16; ++i) { s0 += red[0][i]; s1 += red[1][i]; }
+    tot[0] = s0; tot[1] = s1;
+    if (sse) { sse[0] = s0; sse[1] = s1; }
+  }
+  __syncthreads();
+  const float r0 = sqrtf(tot[0] * inv_count), r1 = sqrtf(tot[1] * inv_count);
+  const float k0 = inv_count / r0, k1 = beta * inv_count / r1;
+  if (threadIdx.x == 0 && loss) loss[0] = r0 + beta * r1;
+  for (int i = threadIdx.x; i < count; i += 1024) {
+    const float t = y[i];
+    dpg[i] = (pg[i] - t) * k0;
+    dps[i] = (ps[i] - t) * k1;
+  }
+}
+
 // one wave per crystal
 __global__ __launch_bounds__(256) void loss_edos_kernel(const float* __restrict__ pg, const float* __restrict__ ps,
                                                         const float* __restrict__ y_ft, float beta, int B, int S,
@@ -460,6 +496,15 @@ extern "C" int dosx_loss_phonon_bwd(const float* pg, const float* ps, const floa
   DOSX_CHECK_ARG(pg && ps && y && sse && dpg && dps && count > 0 && count_global > 0, "dosx_loss_phonon_bwd: bad args");
   hipLaunchKernelGGL(loss_phonon_bwd_kernel, dim3(ceil_div(count, 256)), dim3(256), 0, to_stream(stream), pg, ps, y, sse,
                      beta, (float)(1.0 / count_global), dpg, dps, loss, count);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_loss_phonon(const float* pg, const float* ps, const float* y, float* sse, float beta, float* dpg,
+                                float* dps, float* loss, int count, dosx_stream_t stream) {
+  DOSX_CHECK_ARG(pg && ps && y && dpg && dps && count > 0, "dosx_loss_phonon: bad args");
+  hipLaunchKernelGGL(loss_phonon_fused_kernel, dim3(1), dim3(1024), 0, to_stream(stream), pg, ps, y, sse, beta,
+                     (float)(1.0 / (double)count), dpg, dps, loss, count);
   DOSX_LAUNCH_CHECK();
   return 0;
 }

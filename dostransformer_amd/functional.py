@@ -102,8 +102,9 @@ def mlp_ln_fwd(P: Params, key: str, a: SegList, M: int, H: int, res: Optional[to
     return y, (a, xhat, rstd, M, H)
 
 
-def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: GradSink) -> torch.Tensor:
-    """Returns dL/d(concatenated input) [M, K_in]."""
+def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: GradSink, res: Optional[torch.Tensor] = None,
+               res_col0: int = 0) -> torch.Tensor:
+    """Returns dL/d(concatenated input) [M, K_in] (+ ``res`` added to its columns [res_col0, K_in))."""
     a, xhat, rstd, M, H = ctx
     dev = xhat.device
     gam, bet, alpha = P[key + ".1.weight"], P[key + ".1.bias"], P[key + ".2.weight"]
@@ -120,7 +121,7 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
     sink.add(part, pld - 1, G[key + ".2.weight"], rows, pld, 1)
     _wgrad_linear(sink, G, key + ".0.weight", key + ".0.bias", M, 2 * H, seg(dz), a.segs, keep=(dz,))
     dcat = _empty(dev, M, a.K)
-    ops.gemm(M, a.K, [seg(dz)], P[key + ".0.weight"], dcat, w_layout=1)
+    ops.gemm(M, a.K, [seg(dz)], P[key + ".0.weight"], dcat, w_layout=1, res=res, res_col0=res_col0 if res is not None else 0)
     return dcat
 
 
@@ -148,22 +149,26 @@ def gnn_fwd(P: Params, m: GraphMeta, x: torch.Tensor, e: torch.Tensor, L: int, m
 
 
 def gnn_bwd(P: Params, G: Params, m: GraphMeta, ctxs, dx: torch.Tensor, sink: GradSink, L: int, mean: bool, H: int):
+    """Returns (dL/dx_0 [N,H], dL/de_0 as a strided [E,H] view or None)."""
     N, E = m.num_nodes, m.num_edges
     dev = dx.device
     scale = m.inv_deg if mean else None
-    de = None
+    de = None           # dL/de_{l+1}: the e-block (columns [2H,3H)) of the next layer's concat gradient
     for l in reversed(range(L)):
         pre = f"stacked_processor.{l}"
         cxe, cxn = ctxs[l]
         dcat_n = mlp_ln_bwd(P, G, pre + ".node_model.node_mlp_2", cxn, dx, sink)          # [N, 2H]
         dmsg = _empty(dev, E, H)
         ops.edge_grad_combine(de, dcat_n.data_ptr() + 4 * H, 2 * H, m.dst, scale, dmsg, E, H)
-        dcat_e = mlp_ln_bwd(P, G, pre + ".edge_model.edge_mlp", cxe, dmsg, sink)          # [E, 3H]
+        # e_{l+1} = e_l + msg_l (DOSTransformer_phonon.py:84): dL/de_l = dL/de_{l+1} + (edge-MLP input gradient)[:, 2H:3H].
+        # The dgrad GEMM adds dL/de_{l+1} to exactly those columns, so the e-block of dcat_e IS dL/de_l and no kernel
+        # ever streams the edge gradient on its own.
+        dcat_e = mlp_ln_bwd(P, G, pre + ".edge_model.edge_mlp", cxe, dmsg, sink, res=de, res_col0=2 * H)   # [E, 3H]
         dx_old = _empty(dev, N, H)
-        de_old = _empty(dev, E, H)
-        ops.gather_bwd(dcat_e, dcat_n.data_ptr(), 2 * H, dx, m.rowptr_dst, m.rowptr_src, m.perm_src, de, dx_old,
-                       de_old, N, E, H)
-        dx, de = dx_old, de_old
+        ops.gather_bwd(dcat_e, dcat_n.data_ptr(), 2 * H, dx, m.rowptr_dst, m.rowptr_src, m.perm_src, None, dx_old,
+                       None, N, E, H)
+        sink._keep.append(dcat_n)
+        dx, de = dx_old, dcat_e[:, 2 * H:]
     return dx, de
 
 
@@ -389,9 +394,9 @@ def decoder_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, segs: SegList
     dev = dgraph.device
     _wgrad_linear(sink, G, "GN_decoder.mlp.0.weight", "GN_decoder.mlp.0.bias", B, H, seg(dgraph), segs.segs, keep=(dgraph,))
     K = segs.K
-    dcat = ops.zeros(dev, B + 1, K)     # row B: zero gradient for ghost nodes
+    dcat = _empty(dev, B, K)
     ops.gemm(B, K, [seg(dgraph)], P["GN_decoder.mlp.0.weight"], dcat, w_layout=1)
-    ops.graph_pool_bwd(dcat.data_ptr() + 4 * (K - H), K, m.node_graph, dxL, N, H, True)
+    ops.graph_pool_bwd(dcat.data_ptr() + 4 * (K - H), K, m.node_graph, dxL, N, H, True, num_graphs=B)   # ghost nodes: zero
     sink._keep.append(dcat)
     return seg(dcat, width=H, col=0) if K == 2 * H else None
 
@@ -406,22 +411,33 @@ def dostransformer_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta):
     # to_dense_batch + the (parameter-free part of the) key LayerNorm, shared by every cross attention
     kvhat = _empty(dev, nmax * B + 1, H)          # + 1 spare row: the dense slot of ghost (padding) nodes
     rstd_n = _empty(dev, N)
-    ops.dense_normalize(xL, m.dense_row, kvhat, rstd_n, N, H, nmax * B + 1)
+    ops.dense_normalize_slots(xL, m.graph_ptr, kvhat, rstd_n, B, nmax, H)
     emb = P["embeddings.weight"]
-    E1, c1 = encoder_fwd(P, "transformer", emb, S, B, 1, 0, kvhat, nmax, B, H, T)
-    graph, dec_segs = decoder_fwd(P, cfg, m, xL, u)
+    # The pooled decoder input and the prompt rows do not depend on the first encoder: in a recorded program they run
+    # on the side stream underneath it (three launch-latency-bound kernels off the critical path); eagerly they run here.
     sysidx = _i32(g.system)
     hp = H // 2
-    prow = _empty(dev, B, hp)
-    ops.embed_rows(P[cfg.prompt_key], sysidx, prow, B, hp)
+    side = ops.GradSink(dev)
+    box = {}
+
+    def _decoder_branch():
+        box["graph"], box["segs"] = decoder_fwd(P, cfg, m, xL, u)
+        box["prow"] = _empty(dev, B, hp)
+        ops.embed_rows(P[cfg.prompt_key], sysidx, box["prow"], B, hp)
+    side.on_side(_decoder_branch)
+    E1, c1 = encoder_fwd(P, "transformer", emb, S, B, 1, 0, kvhat, nmax, B, H, T)
+    side.join()
+    graph, dec_segs, prow = box["graph"], box["segs"], box["prow"]
     dosin = _empty(dev, S * 2 * B, H)
     modB = rowmap(d=B, m=0, c=1)
     a_g = SegList([seg(E1), seg(graph, rmap=modB)], [E1, graph])
     a_s = SegList([seg(E1), seg(graph, rmap=modB), seg(prow, rmap=modB)], [E1, graph, prow])
+    # the two heads write disjoint row sets of dosin (branch-major batch axis): side by side on two streams when recorded
+    side.on_side(lambda: ops.gemm(S * B, H, a_s.segs, P["fc_prompt.weight"], dosin, bias=P["fc_prompt.bias"], act=ACT_LEAKY,
+                                  act_slope=0.01, out_map=rowmap(d=B, m=2 * B, c=1, off=B)))
     ops.gemm(S * B, H, a_g.segs, P["fc.weight"], dosin, bias=P["fc.bias"], act=ACT_LEAKY, act_slope=0.01,
              out_map=rowmap(d=B, m=2 * B, c=1, off=0))
-    ops.gemm(S * B, H, a_s.segs, P["fc_prompt.weight"], dosin, bias=P["fc_prompt.bias"], act=ACT_LEAKY,
-             act_slope=0.01, out_map=rowmap(d=B, m=2 * B, c=1, off=B))
+    side.join()
     kvs = _empty(dev, S * 2 * B, H)
     rstd_s = _empty(dev, S * 2 * B)
     ops.rownorm(dosin, kvs, rstd_s, S * 2 * B, H)
@@ -469,16 +485,20 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
     dE1 = _empty(dev, S * B, H)
     ops.gemm(S * B, H, [seg(dpre, rmap=map0)], Wfc[:, :H], dE1, w_layout=1)
     ops.gemm(S * B, H, [seg(dpre, rmap=map1)], Wfp[:, :H], dE1, w_layout=1, res=dE1)
-    # graph / prompt inputs are constant over the energy axis: reduce over s first, then a [2B,H] GEMM
+    # graph / prompt inputs are constant over the energy axis: reduce over s first, then a [2B,H] GEMM.  Their
+    # consumers (decoder backward, prompt-embedding gradient) come after the first encoder's backward: side stream.
     R = _empty(dev, 2 * B, H)
-    ops.reduce_rows(dpre.data_ptr(), H, R.data_ptr(), H, 2 * B, S, 1, 2 * B, H)
     dgraph = _empty(dev, B, H)
-    ops.gemm(B, H, [seg(R[:B])], Wfc[:, H:2 * H], dgraph, w_layout=1)
-    ops.gemm(B, H, [seg(R[B:])], Wfp[:, H:2 * H], dgraph, w_layout=1, res=dgraph)
     hp = H // 2
     dprow = _empty(dev, B, hp)
-    ops.gemm(B, hp, [seg(R[B:])], Wfp[:, 2 * H:], dprow, w_layout=1)
-    ops.embed_rows_bwd(dprow.data_ptr(), hp, sysidx, G[cfg.prompt_key], B, G[cfg.prompt_key].shape[0], hp)
+
+    def _const_inputs_bwd():
+        ops.reduce_rows(dpre.data_ptr(), H, R.data_ptr(), H, 2 * B, S, 1, 2 * B, H)
+        ops.gemm(B, H, [seg(R[:B])], Wfc[:, H:2 * H], dgraph, w_layout=1)
+        ops.gemm(B, H, [seg(R[B:])], Wfp[:, H:2 * H], dgraph, w_layout=1, res=dgraph)
+        ops.gemm(B, hp, [seg(R[B:])], Wfp[:, 2 * H:], dprow, w_layout=1)
+        ops.embed_rows_bwd(dprow.data_ptr(), hp, sysidx, G[cfg.prompt_key], B, G[cfg.prompt_key].shape[0], hp)
+    sink.on_side(_const_inputs_bwd, (dpre, R, dgraph, dprow))
     # first encoder (queries = energy embeddings broadcast over the batch)
     dX1 = encoder_bwd(P, G, "transformer", c1, dE1, dkv, sink)
     ops.reduce_rows(dX1.data_ptr(), H, G["embeddings.weight"].data_ptr(), H, S, B, B, 1, H)
@@ -490,7 +510,7 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
         mid_hook(sink)                #  stream and the dk/dv kernels it is waiting for)
     # node embeddings: dense keys + pooled decoder input (+ external grad on the returned x)
     dxL = _empty(dev, N, H)
-    ops.dense_normalize_bwd(dkv, kvhat, rstd_n, m.dense_row, dxL, N, H, False)
+    ops.dense_normalize_bwd(dkv, kvhat, rstd_n, m.dense_row, dxL, N, H, False, ghost_row=nmax * B)
     du_seg = decoder_bwd(P, G, cfg, m, dec_segs, dgraph, dxL, sink)
     if dx_ext is not None:
         dxL.add_(dx_ext)

@@ -261,7 +261,7 @@ def gemm(M: int, N: int, segs: Sequence[Seg], w: torch.Tensor, out: torch.Tensor
          epi: int = EPI_BIAS_ACT, act: int = ACT_NONE, act_slope: float = 0.01, bias=None,
          out_map: Optional[RowMap] = None, res=None, res_map: Optional[RowMap] = None,
          stats_out=None, aux_out=None, aux=None, aux_stats=None, epi_gamma=None, epi_beta=None,
-         epi_alpha=None, partials=None, partial_ld: int = 0, keep: Optional[list] = None) -> None:
+         epi_alpha=None, partials=None, partial_ld: int = 0, res_col0: int = 0, keep: Optional[list] = None) -> None:
     """out[M,N] = epilogue(prologue(A) @ B); see include/dosx.h:DosxGemm."""
     g = Gemm()
     g.M, g.N = int(M), int(N)
@@ -285,6 +285,7 @@ def gemm(M: int, N: int, segs: Sequence[Seg], w: torch.Tensor, out: torch.Tensor
     g.aux_stats = _p(aux_stats)
     g.epi_gamma, g.epi_beta, g.epi_alpha = _p(epi_gamma), _p(epi_beta), _p(epi_alpha)
     g.partials, g.partial_ld = _p(partials), int(partial_ld)
+    g.res_col0 = int(res_col0)
     _call("dosx_gemm", C.byref(g), _stream(), w=lambda: _gemm_work(g))
 
 
@@ -524,7 +525,9 @@ def segment_reduce(msg, rowptr, scale, agg, e_in, e_out, N, E, H):
 
 
 def edge_grad_combine(de_new, dagg, ld_dagg, dst, scale, dmsg, E, H):
-    _call("dosx_edge_grad_combine", _p(de_new), dagg, ld_dagg, _p(dst), _p(scale), _p(dmsg), E, H, _stream(),
+    """de_new: None or a 2-D tensor / view with unit inner stride ([E,H] or the e-block of an [E,3H] gradient)."""
+    ld_de = int(de_new.stride(0)) if de_new is not None else 0
+    _call("dosx_edge_grad_combine", _p(de_new), ld_de, dagg, ld_dagg, _p(dst), _p(scale), _p(dmsg), E, H, _stream(),
           w=lambda: (f"edge_grad_combine[E{E},H{H}]", "edge_grad_combine_kernel", "hbm",
                      4.0 * (E * H * (3 if de_new is not None else 2) + E)))
 
@@ -543,8 +546,8 @@ def graph_pool(x, graph_ptr, out_ptr, ld_out, B, H):
           w=lambda: ("graph_pool", "graph_pool_kernel", "hbm", 4.0 * (x.shape[0] * H + B * H)))
 
 
-def graph_pool_bwd(dpool_ptr, ld, node_graph, dx, N, H, accumulate):
-    _call("dosx_graph_pool_bwd", dpool_ptr, ld, _p(node_graph), _p(dx), N, H, int(accumulate), _stream(),
+def graph_pool_bwd(dpool_ptr, ld, node_graph, dx, N, H, accumulate, num_graphs=0):
+    _call("dosx_graph_pool_bwd", dpool_ptr, ld, _p(node_graph), _p(dx), N, H, int(accumulate), int(num_graphs), _stream(),
           w=lambda: ("graph_pool_bwd", "graph_pool_bwd_kernel", "hbm", 4.0 * N * H * (3 if accumulate else 2)))
 
 
@@ -553,9 +556,14 @@ def dense_normalize(x, dense_row, kvhat, rstd_nodes, N, H, dense_rows):
           w=lambda: ("dense_normalize", "dense_normalize_kernel", "hbm", 4.0 * (N * H + dense_rows * H + N * H)))
 
 
-def dense_normalize_bwd(dkvhat, kvhat, rstd_nodes, dense_row, dx, N, H, accumulate):
+def dense_normalize_slots(x, graph_ptr, kvhat, rstd_nodes, B, n_max, H):
+    _call("dosx_dense_normalize_slots", _p(x), _p(graph_ptr), _p(kvhat), _p(rstd_nodes), B, n_max, H, _stream(),
+          w=lambda: ("dense_normalize", "dense_normalize_slots_kernel", "hbm", 4.0 * H * (x.shape[0] + n_max * B + 1)))
+
+
+def dense_normalize_bwd(dkvhat, kvhat, rstd_nodes, dense_row, dx, N, H, accumulate, ghost_row=-1):
     _call("dosx_dense_normalize_bwd", _p(dkvhat), _p(kvhat), _p(rstd_nodes), _p(dense_row), _p(dx), N, H,
-          int(accumulate), _stream(),
+          int(accumulate), int(ghost_row), _stream(),
           w=lambda: ("dense_normalize_bwd", "dense_normalize_bwd_kernel", "hbm", 4.0 * N * H * 3))
 
 
@@ -628,6 +636,11 @@ def sse2(pg, ps, y, sse, count):
 def loss_phonon_bwd(pg, ps, y, sse, beta, count_global, dpg, dps, loss, count):
     _call("dosx_loss_phonon_bwd", _p(pg), _p(ps), _p(y), _p(sse), float(beta), float(count_global), _p(dpg), _p(dps),
                                         _p(loss), count, _stream())
+
+
+def loss_phonon(pg, ps, y, sse, beta, dpg, dps, loss, count):
+    """single-process phonon loss + gradient in one launch (include/dosx.h: dosx_loss_phonon)"""
+    _call("dosx_loss_phonon", _p(pg), _p(ps), _p(y), _p(sse), float(beta), _p(dpg), _p(dps), _p(loss), count, _stream())
 
 
 def loss_edos(pg, ps, y_ft, beta, B, S, B_global, dpg, dps, loss_partial):

@@ -137,7 +137,8 @@ class Trainer:
         if self.kind == "phonon":
             st["y"] = Fn._f32(g.phdos).reshape(B, S)
             st["sse"] = Fn._empty(dev, 2)
-            ops.sse2(dos[:B], dos[B:], st["y"], st["sse"], B * S)
+            if self.dist is not None:      # ranks exchange the SSE pair between the two phases of the loss
+                ops.sse2(dos[:B], dos[B:], st["y"], st["sse"], B * S)
         else:
             st["y"] = Fn._f32(g.y_ft).reshape(-1)
         return st
@@ -149,8 +150,11 @@ class Trainer:
         ddos = Fn._empty(dev, *dos.shape)
         if self.kind == "phonon":
             loss = Fn._empty(dev, 1)
-            ops.loss_phonon_bwd(dos[:B], dos[B:], st["y"], st["sse"], self.beta, float(n_global * S), ddos[:B],
-                                ddos[B:], loss, B * S)
+            if self.dist is not None:
+                ops.loss_phonon_bwd(dos[:B], dos[B:], st["y"], st["sse"], self.beta, float(n_global * S), ddos[:B],
+                                    ddos[B:], loss, B * S)
+            else:                          # one launch: SSE pair, loss and gradient
+                ops.loss_phonon(dos[:B], dos[B:], st["y"], st["sse"], self.beta, ddos[:B], ddos[B:], loss, B * S)
             loss = loss[0]
         else:
             lp = Fn._empty(dev, B + 1)
@@ -167,8 +171,10 @@ class Trainer:
         """Backward reaches the GNN trunk: reduce the early bucket's slabs on the side stream and start its
         all-reduce there, underneath the GNN backward (xGMI traffic overlaps compute; only the GNN bucket's
         all-reduce stays exposed at the end of the step)."""
-        if self.dist is None and self.replay and _EARLY_REDUCE:
-            return lambda sink: sink.flush_on_side()      # single GPU: just take the early slab reduction off the tail
+        if self.dist is None and _EARLY_REDUCE:
+            # single GPU: the early bucket's weight gradients + slab reduction run HERE (replay: on the side stream,
+            # underneath the GNN backward; eager: inline), while their operands are still in L2 - not at the tail
+            return lambda sink: sink.flush_on_side()
         if self.dist is None or not self.bucketed or fp.n_late <= 0 or fp.n_late >= fp.total:
             return None
 

@@ -100,6 +100,9 @@ typedef struct DosxGemm {
   const float* epi_alpha;
   float* partials;    /* per-workgroup partial sums: row wg = [dgamma(N) | dbeta(N) | dalpha] */
   int32_t partial_ld;
+  int32_t res_col0;   /* EPI_BIAS_ACT: the residual is added to the output columns [res_col0, N) only, res column c
+                         to output column res_col0 + c (0 = all columns).  The backward of the edge residual
+                         e += e' (DOSTransformer_phonon.py:84) rides on the e-block of the [E,3H] concat gradient. */
 } DosxGemm;
 
 /* exact number of workgroup rows dosx_gemm writes into `partials` for this epilogue: ceil(M/32) for
@@ -158,8 +161,9 @@ int dosx_segment_reduce(const float* msg, const int32_t* rowptr, const float* sc
                         const float* e_in, float* e_out, int N, int E, int H, dosx_stream_t stream);
 
 /* backward of the aggregation + residual:  dmsg[e] = (de_new ? de_new[e] : 0) + scale[dst[e]] * dagg[dst[e]]
- * dagg has row stride ld_dagg (it is a column block of the node-MLP input gradient). */
-int dosx_edge_grad_combine(const float* de_new, const float* dagg, int ld_dagg, const int32_t* dst,
+ * dagg has row stride ld_dagg (it is a column block of the node-MLP input gradient), de_new row stride ld_de_new
+ * (it is the e-block of the next layer's [E,3H] concat gradient, or a plain [E,H] tensor). */
+int dosx_edge_grad_combine(const float* de_new, int ld_de_new, const float* dagg, int ld_dagg, const int32_t* dst,
                            const float* scale, float* dmsg, int E, int H, dosx_stream_t stream);
 
 /* backward of the two gathers x[row], x[col] (the scatter-adds of SURVEY.md §2.2) fused with
@@ -176,8 +180,10 @@ int dosx_gather_bwd(const float* dcat, const float* dnode, int ld_dnode, const f
  * DOSTransformer_phonon.py:180) and its backward (broadcast add). */
 int dosx_graph_pool(const float* x, const int32_t* graph_ptr, float* out, int ld_out, int B, int H,
                     dosx_stream_t stream);
+/* num_graphs > 0: nodes with node_graph[n] >= num_graphs (ghost / padding nodes) receive a zero pooled gradient and no
+ * row of dpool is read for them (otherwise dpool needs a zero row at index num_graphs). */
 int dosx_graph_pool_bwd(const float* dpool, int ld_dpool, const int32_t* node_graph, float* dx, int N, int H,
-                        int accumulate, dosx_stream_t stream);
+                        int accumulate, int num_graphs, dosx_stream_t stream);
 
 /* a8 (+ the LN statistics of layer_norms[0] on keys): to_dense_batch + row normalisation.
  *   kvhat[dense_row[n]] = (x[n]-mean)*rstd ; rstd_nodes[n] ; all other rows of kvhat = 0
@@ -186,9 +192,15 @@ int dosx_graph_pool_bwd(const float* dpool, int ld_dpool, const int32_t* node_gr
  *  (dosx_fill) or pass zero_rows = total dense rows to let the kernel do it. */
 int dosx_dense_normalize(const float* x, const int32_t* dense_row, float* kvhat, float* rstd_nodes,
                          int N, int H, int dense_rows, dosx_stream_t stream);
-/* backward: dx[n] (+)= rstd[n] * (g - mean(g) - xhat*mean(g*xhat)),  g = dkvhat[dense_row[n]] */
+/* The same in ONE launch, driven by the dense slots instead of the nodes (no separate zero fill): slot (pos, b) holds
+ * node graph_ptr[b] + pos if pos < atoms(b), else zeros; kvhat has n_max*B + 1 rows (the last one = the zero row ghost /
+ * padding nodes point at).  rstd_nodes is written for the nodes of the B graphs only. */
+int dosx_dense_normalize_slots(const float* x, const int32_t* graph_ptr, float* kvhat, float* rstd_nodes, int B,
+                               int n_max, int H, dosx_stream_t stream);
+/* backward: dx[n] (+)= rstd[n] * (g - mean(g) - xhat*mean(g*xhat)),  g = dkvhat[dense_row[n]];
+ * nodes whose dense_row equals `ghost_row` (>= 0) get dx (+)= 0 without reading rstd_nodes (ghost / padding nodes). */
 int dosx_dense_normalize_bwd(const float* dkvhat, const float* kvhat, const float* rstd_nodes,
-                             const int32_t* dense_row, float* dx, int N, int H, int accumulate,
+                             const int32_t* dense_row, float* dx, int N, int H, int accumulate, int ghost_row,
                              dosx_stream_t stream);
 
 /* Row LayerNorm without affine (key/value side of self attention) and with affine. */
@@ -267,6 +279,9 @@ int dosx_sse2(const float* pg, const float* ps, const float* y, float* sse, int 
 int dosx_loss_phonon_bwd(const float* pg, const float* ps, const float* y, const float* sse, float beta,
                          double count_global, float* dpg, float* dps, float* loss, int count,
                          dosx_stream_t stream);
+/* single-process form: dosx_sse2 + dosx_loss_phonon_bwd in one launch (count = all B*S elements; sse may be NULL) */
+int dosx_loss_phonon(const float* pg, const float* ps, const float* y, float* sse, float beta, float* dpg, float* dps,
+                     float* loss, int count, dosx_stream_t stream);
 int dosx_loss_edos(const float* pg, const float* ps, const float* y_ft, float beta, int B, int S, int B_global,
                    float* dpg, float* dps, float* loss_partial, dosx_stream_t stream);
 

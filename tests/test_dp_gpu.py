@@ -84,11 +84,13 @@ def test_two_rank_trainer_matches_single_process(two_rank_run, kind, mode):
             continue
         a, b = r0[pre + "p/" + k], v.detach().cpu().numpy()
         if k in fp.G:
-            # Adam's update is ~lr*sign(g) where |g| is at the fp32 noise floor of the two summation orders: compare
-            # tightly where the gradient is resolved, and bound the rest by the step size
+            # Adam's update is ~lr*sign(g) where |g| is at the fp32 noise floor of the two summation orders (the gradient
+            # check above is the sharp one: 2e-5 of the tensor maximum): compare the parameters where the gradient is
+            # resolved - 3 steps of lr 1e-3 move an element by up to 3e-3, 2e-5 is < 1 % of that - and bound the rest
+            # by the step size
             gk = fp.G[k].detach().cpu().numpy()
-            ok = np.abs(gk) >= 1e-3 * np.abs(gk).max()
-            assert np.abs(a - b)[ok].max() <= 2e-6, (k, np.abs(a - b)[ok].max())
+            ok = np.abs(gk) >= 1e-2 * np.abs(gk).max()
+            assert np.abs(a - b)[ok].max() <= 2e-5, (k, np.abs(a - b)[ok].max())
             assert np.abs(a - b).max() <= 3.1e-3, k
         else:
             assert np.array_equal(a, b), k          # dead parameters: untouched everywhere

@@ -214,6 +214,12 @@ def test_g8_graphnetworks():
             assert relerr(p.grad, z["g/" + k]) < 2e-3, k
 
 
+# per-tensor gradient tolerance (max abs error / max abs of the tensor) = 10 x the error observed on MI355X (round 2,
+# printed by the test); phonon: fp32 kernels against the fp64 oracle, eDOS: against the fp32 oracle (torch CPU)
+GRAD_TOL = {("phonon", 64, 1, 8): 3e-3, ("phonon", 128, 2, 16): 3e-3, ("edos", 64, 2, 6): 2e-2, ("edos", 256, 2, 4): 2e-2,
+            ("phonon", 128, 2, 64): 3e-3, ("edos", 256, 2, 64): 2e-2, ("edos", 256, 4, 32): 2e-2}
+
+
 @pytest.mark.parametrize("kind,H,T,B", [("phonon", 64, 1, 8), ("phonon", 128, 2, 16), ("edos", 64, 2, 6),
                                          ("edos", 256, 2, 4),
                                          # BASELINE.json configs[1], [2] and the per-GPU shard of [4] at FULL size
@@ -254,13 +260,16 @@ def test_against_oracle_live(kind, H, T, B):
     ref_loss, grads = O.train_step(kind, params, state, g_ref, 3, T, lr=1e-4, beta=1.0)
     assert abs(float(loss) - float(ref_loss)) < 2e-4
     fp = model.flat_params()
-    tol = 3e-3 if kind == "phonon" else 2e-2      # eDOS reference itself is fp32 (cancellation in tiny grads)
+    tol = GRAD_TOL[(kind, H, T, B)]
+    worst = (0.0, None)
     for k, gr in grads.items():
         if gr is None:
             assert k not in fp.G, k
         else:
             e = float((fp.G[k].cpu().double() - gr.double()).abs().max() / (gr.abs().max() + 1e-6))
-            assert e < tol, (k, e)
+            worst = max(worst, (e, k))
+    print(f"oracle-live {kind} H{H} T{T} B{B}: worst per-tensor gradient error (relative to the tensor max) {worst[0]:.3e} at {worst[1]}")
+    assert worst[0] < tol, worst
     tr.optimizer_step()
     # Adam's first step moves every element by ~lr*sign(g): where |g| is at the noise floor of the fp32
     # (GPU) vs fp64 (oracle) gradient the sign itself is ill-conditioned, so compare the update only
@@ -312,10 +321,13 @@ def test_ghost_padding_is_exact(kind):
 @pytest.mark.parametrize("mode", ["graph", "replay"])
 @pytest.mark.parametrize("kind", ["phonon", "edos"])
 def test_graph_replay_matches_eager(kind, mode):
-    """Trainer(graph=True) / Trainer(replay=True): captured HIP graphs / recorded launch lists per shape
-    bucket reproduce the eager trajectory."""
+    """Trainer(graph=True) / Trainer(replay=True): captured HIP graphs / recorded launch lists per shape bucket (two
+    streams in replay mode) reproduce the eager trajectory on the same ghost-padded batches BITWISE (no atomics anywhere,
+    fixed summation orders), and the eager trajectory on the un-padded batches up to the noise Adam makes of the moved
+    slab split points (padding changes M of the weight-gradient kernels, i.e. fp32 summation order at the 1e-7 level)."""
     import copy
     from dostransformer_amd import synth
+    from dostransformer_amd.batch import bucket_sizes, pad_batch
     from dostransformer_amd.train import Trainer
     torch.manual_seed(0)
     if kind == "phonon":
@@ -326,20 +338,26 @@ def test_graph_replay_matches_eager(kind, mode):
         from dostransformer_amd.embedder_eDOS.DOSTransformer import DOSTransformer
         mk = lambda: DOSTransformer(3, 1, 200, 41, 2, 64, DEV, 0.0)
         batches = [synth.edos_batch(4, seed=50 + k, dtype=torch.float32).to(DEV) for k in range(3)]
+    padded = [pad_batch(b, *bucket_sizes(b.meta.num_nodes, b.meta.num_edges)) for b in batches]
     torch.manual_seed(1)
     m_e = mk().to(DEV)
-    m_g = mk()
+    m_p, m_g = mk(), mk()
+    m_p.load_state_dict(copy.deepcopy(m_e.state_dict()))
     m_g.load_state_dict(copy.deepcopy(m_e.state_dict()))
-    m_g = m_g.to(DEV)
-    te, tg = Trainer(m_e, lr=1e-3), Trainer(m_g, lr=1e-3, graph=(mode == "graph"), replay=(mode == "replay"))
+    m_p, m_g = m_p.to(DEV), m_g.to(DEV)
+    te, tp = Trainer(m_e, lr=1e-3), Trainer(m_p, lr=1e-3)
+    tg = Trainer(m_g, lr=1e-3, graph=(mode == "graph"), replay=(mode == "replay"))
     for i in range(7):                      # revisits buckets -> replays, not only captures
         le = te.step(batches[i % 3])
-        lg = tg.step(batches[i % 3])
+        lp = tp.step(padded[i % 3])
+        lg = tg.step(batches[i % 3])        # pads on the fly
+        assert float(lp) == float(lg), i
         assert abs(float(le) - float(lg)) < 1e-5 * max(1.0, abs(float(le)))
-    assert len(tg._slots) >= 1
-    for (k, a), (_, b) in zip(m_e.state_dict().items(), m_g.state_dict().items()):
+    assert len(tg._slots) == 3 and tg.slot_hits == 4
+    for (k, a), (_, b), (_, c) in zip(m_e.state_dict().items(), m_p.state_dict().items(), m_g.state_dict().items()):
         if a.is_floating_point():
-            assert float((a - b).abs().max()) < 2e-5, k
+            assert torch.equal(b, c), k
+            assert float((a - c).abs().max()) < 7e-3, k          # 7 steps of lr 1e-3 bound any element's drift
 
 
 def test_g9_eval_loops_match_reference():
