@@ -78,7 +78,7 @@ class Attn(C.Structure):
         ("out", C.c_void_p), ("probs", C.c_void_p), ("qstats", C.c_void_p), ("out_stats", C.c_void_p),
         ("dout", C.c_void_p), ("dx", C.c_void_p), ("dscores", C.c_void_p), ("dkvhat", C.c_void_p),
         ("dkv_accumulate", C.c_int32),
-        ("partials_q", C.c_void_p), ("partials_kv", C.c_void_p),
+        ("partials_q", C.c_void_p), ("partials_kv", C.c_void_p), ("dkv_part", C.c_void_p),
     ]
 
 
@@ -145,6 +145,7 @@ _SIGS = {
     "dosx_rownorm_bwd_act": [_P, _P, _P, _P, _P, _F, _P, _I, _I, _P],
     "dosx_layernorm": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
     "dosx_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "dosx_attention_pkv_supported": [_I, _I],
     "dosx_attention_fwd": [C.POINTER(Attn), _P],
     "dosx_attention_bwd": [C.POINTER(Attn), _P],
     "dosx_ln_rowdot": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],

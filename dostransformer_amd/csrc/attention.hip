@@ -454,7 +454,13 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const DosxAttn a) 
   }
 }
 
-template <int NJ>
+// PKV: the kernel ALSO produces this tile's share of dK + dV ("partial key gradient"), while P, dS, dO and the
+// normalised query rows are in LDS anyway:    part[bq][tile][j][:] = sum_{q in tile} P[q,j] dO[q,:] + dS[q,j] Q[q,:]
+// (Q = LN0(x) gamma0 + beta0).  A small reduction kernel (attn_dkv_reduce_kernel) sums the 2-4 partials of every key row
+// and applies the key-side chain rule.  That replaces attn_bwd_dkv_kernel for NKP <= 64 (cfg2: cross attention over
+// <= 12 atoms, self attention over 51 bins): that kernel re-streamed every dO / x row and the dS round trip through HBM
+// behind one barrier per 16 queries - 27 us per launch for 0.08 GF - where this costs 32-64 MFMAs per wave.
+template <int NJ, bool PKV>
 __global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(const DosxAttn a) {
   extern __shared__ __align__(16) float sm[];
   const Geo g = make_geo(a.H, a.Nk);
@@ -464,6 +470,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(const DosxAttn 
   float* Ss = Ds + QT * g.LDH;                      // [32][LDS_] dP -> dS
   float* CH = Ss + QT * g.LDS_;                     // two chunk buffers; later [16][2][HP] column partial sums
   float* Pp = CH;
+  float* Ps2 = CH + max(2 * sg.CHB, 32 * g.HP);     // PKV: [32][LDS_] P tile
+  float* dOr = Ps2 + QT * g.LDS_;                   // PKV: [32][LDH] raw dO rows
+  float* Ql = Ds;                                   // PKV: [32][LDH] LN0(x) gamma0 + beta0 - takes over Ds once dP is done
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q16 = lane & 15;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int s0 = blockIdx.x * QT, bq = blockIdx.y, bk = bq % a.Bk;
@@ -504,9 +513,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(const DosxAttn 
     for (int k = 0; k < KCB; ++k) {
       const int c = q16 * 4 + 64 * k;
       if (c >= g.HP) continue;
+      const bool rv = c < H && (s0 + lr) < Sq;
       float4 d = make_float4(go[p][k].x * g0[k].x, go[p][k].y * g0[k].y, go[p][k].z * g0[k].z, go[p][k].w * g0[k].w);
-      if (!(c < H && (s0 + lr) < Sq)) d = f4zero();
+      if (!rv) d = f4zero();
       st4(Ds + lr * g.LDH + c, d);
+      if constexpr (PKV) st4(dOr + lr * g.LDH + c, rv ? go[p][k] : f4zero());
     }
   }
   __syncthreads();
@@ -517,6 +528,25 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(const DosxAttn 
   store_scores1(sacc, Ss, g.LDS_, g.NKP, tid);
   __syncthreads();
 
+  if constexpr (PKV) {          // every matrix wave is past its last read of Ds (= dO gamma): the rows become Q
+#pragma unroll
+    for (int p = 0; p < RP; ++p) {
+      const int lr = row_of(wave, p, lane);
+#pragma unroll
+      for (int k = 0; k < KCB; ++k) {
+        const int c = q16 * 4 + 64 * k;
+        if (c >= g.HP) continue;
+        const bool rv = c < H && (s0 + lr) < Sq;
+        const float4 b0 = ld4(a.beta0 + (c < H ? c : 0));
+        const float4 xv = xr[p][k];
+        float4 q = xv;
+        if (!raw_q)
+          q = make_float4((xv.x - mean[p]) * rstd[p] * g0[k].x + b0.x, (xv.y - mean[p]) * rstd[p] * g0[k].y + b0.y,
+                          (xv.z - mean[p]) * rstd[p] * g0[k].z + b0.z, (xv.w - mean[p]) * rstd[p] * g0[k].w + b0.w);
+        st4(Ql + lr * g.LDH + c, rv ? q : f4zero());
+      }
+    }
+  }
   // dS = P * (dP - rowsum(P*dP)) * scale
   {
     const float scale = rsqrtf((float)H);
@@ -545,14 +575,66 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(const DosxAttn 
         if (j >= g.NKP) continue;
         const float ds = (j < Nk && s < Sq) ? pr[p][jj] * (dp[p][jj] - dot[p]) * scale : 0.f;
         row[j] = ds;
-        if (j < Nk && s < Sq) a.dscores[((size_t)bq * Sq + s) * Nk + j] = ds;
+        if constexpr (PKV) Ps2[lr * g.LDS_ + j] = (j < Nk && s < Sq) ? pr[p][jj] : 0.f;
+        else if (j < Nk && s < Sq) a.dscores[((size_t)bq * Sq + s) * Nk + j] = ds;
       }
       if (NJ * 16 < g.NKP) {
-        for (int j = NJ * 16 + q16; j < g.NKP; j += 16) row[j] = 0.f;
+        for (int j = NJ * 16 + q16; j < g.NKP; j += 16) {
+          row[j] = 0.f;
+          if constexpr (PKV) Ps2[lr * g.LDS_ + j] = 0.f;
+        }
       }
     }
   }
   __syncthreads();
+
+  if constexpr (PKV) {
+    // ---- this tile's share of dK + dV: [NKP keys] x [32 queries] . [32 queries] x [HP] (matrix waves; the staging
+    // waves are streaming the k̂ chunks of the next product meanwhile) ----
+    constexpr int NKT = NJ == 1 ? 1 : 2;            // 32-key tiles (NJ = 1: Nk <= 16; NJ = 4: Nk <= 64)
+    const int l31 = lane & 31, hh = lane >> 5, nct = g.HP / 32;
+    f32x16 dacc[NKT][MAX_CT], dacc2[NKT][MAX_CT];     // P^T dO and dS^T Q in separate chains (a dependent MFMA chain
+#pragma unroll                                       //  issues every ~87 clk instead of every 64)
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int t = 0; t < MAX_CT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dacc[kt][t][r] = 0.f; dacc2[kt][t][r] = 0.f; }
+#pragma unroll 4
+    for (int mm = 0; mm < QT; mm += 2) {
+      float pa[NKT], sa[NKT];
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {            // (NKT = 2 with NKP = 32: the second tile reads past the row, into the
+        pa[kt] = Ps2[(mm + hh) * g.LDS_ + kt * 32 + l31];   //  next row / buffer - in bounds of the LDS, rows j >= Nk are
+        sa[kt] = Ss[(mm + hh) * g.LDS_ + kt * 32 + l31];    //  never stored)
+      }
+#pragma unroll
+      for (int t = 0; t < MAX_CT; ++t) {
+        const int ct = wave + 4 * t;
+        if (ct >= nct) continue;
+        const float b1 = dOr[(mm + hh) * g.LDH + ct * 32 + l31];
+        const float b2 = Ql[(mm + hh) * g.LDH + ct * 32 + l31];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+          dacc[kt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kt], b1, dacc[kt][t], 0, 0, 0);
+          dacc2[kt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[kt], b2, dacc2[kt][t], 0, 0, 0);
+        }
+      }
+    }
+    float* part = a.dkv_part + ((size_t)bq * gridDim.x + blockIdx.x) * (size_t)Nk * H;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int t = 0; t < MAX_CT; ++t) {
+        const int ct = wave + 4 * t, col = ct * 32 + l31;
+        if (ct >= nct) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (j < Nk && col < H) part[(size_t)j * H + col] = dacc[kt][t][r] + dacc2[kt][t][r];
+        }
+      }
+  }
 
   f32x16 oacc[MAX_CT];
   stream_pv(oacc, Ss, g.LDS_, CH, sg, g.HP, g.LDH, tid);
@@ -875,11 +957,89 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const DosxAttn a) {
   }
 }
 
+// Sum of the partial key gradients of one crystal + the key-side chain rule (see attn_bwd_dq_stream_kernel<.., PKV>):
+//   d[j]       = sum_{i < Bq/Bk} sum_{tile} part[bk + i*Bk][tile][j][:]          (fixed order: deterministic)
+//   dkvhat[j] (+)= d[j] * gamma0 ;  partial dgamma0 += d[j] * k̂[j] ;  partial dbeta0 += d[j]
+// One workgroup per crystal, one quarter wave per key row (16 rows per pass).
+__global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(const DosxAttn a, int nqt) {
+  __shared__ float Pp[16][2 * 256];                 // per quarter-wave slot: [dgamma | dbeta] (H <= 256)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q16 = lane & 15, slot = wave * 4 + (lane >> 4);
+  const int bk = blockIdx.x, H = a.H, Nk = a.Nk, rep = a.Bq / a.Bk;
+  float4 g0[KCB], pg[KCB], pb[KCB];
+#pragma unroll
+  for (int k = 0; k < KCB; ++k) {
+    g0[k] = ld4(a.gamma0 + ((q16 * 4 + 64 * k) < H ? (q16 * 4 + 64 * k) : 0));
+    pg[k] = f4zero(); pb[k] = f4zero();
+  }
+  for (int j0 = 0; j0 < Nk; j0 += 16) {
+    const int j = j0 + slot;
+    const bool jv = j < Nk;
+    const int jc = jv ? j : 0;
+    const size_t krow = ((size_t)jc * a.Bk + bk) * H;
+    float4 d[KCB], kh[KCB], d0[KCB];
+#pragma unroll
+    for (int k = 0; k < KCB; ++k) {
+      const int c = q16 * 4 + 64 * k, cc = c < H ? c : 0;
+      d[k] = f4zero();
+      kh[k] = ld4(a.kvhat + krow + cc);
+      d0[k] = a.dkv_accumulate ? ld4(a.dkvhat + krow + cc) : f4zero();
+    }
+    for (int i = 0; i < rep; ++i)
+      for (int t = 0; t < nqt; ++t) {
+        const float* p = a.dkv_part + (((size_t)(bk + i * a.Bk) * nqt + t) * Nk + jc) * H;
+#pragma unroll
+        for (int k = 0; k < KCB; ++k) {
+          const int c = q16 * 4 + 64 * k;
+          if (c < H) d[k] = f4add(d[k], ld4(p + c));
+        }
+      }
+    if (jv) {
+#pragma unroll
+      for (int k = 0; k < KCB; ++k) {
+        const int c = q16 * 4 + 64 * k;
+        if (c >= H) continue;
+        pg[k].x += d[k].x * kh[k].x; pg[k].y += d[k].y * kh[k].y; pg[k].z += d[k].z * kh[k].z; pg[k].w += d[k].w * kh[k].w;
+        pb[k] = f4add(pb[k], d[k]);
+        st4(a.dkvhat + krow + c, make_float4(d[k].x * g0[k].x + d0[k].x, d[k].y * g0[k].y + d0[k].y,
+                                             d[k].z * g0[k].z + d0[k].z, d[k].w * g0[k].w + d0[k].w));
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < KCB; ++k) {
+    const int c = q16 * 4 + 64 * k;
+    if (c >= H) continue;
+    st4(&Pp[slot][c], pg[k]);
+    st4(&Pp[slot][256 + c], pb[k]);
+  }
+  __syncthreads();
+  // partial rows are indexed by 32-key tile (the caller sizes them so): the sums go to the crystal's first tile, the
+  // other tiles get zeros
+  const int nkt = (Nk + 31) / 32;
+  for (int kt = 0; kt < nkt; ++kt) {
+    float* prow = a.partials_kv + ((size_t)bk * nkt + kt) * 2 * H;
+    for (int c = tid; c < 2 * H; c += 256) {
+      float t = 0.f;
+      if (kt == 0) {
+        const int o = (c / H) * 256 + (c % H);
+#pragma unroll
+        for (int sl = 0; sl < 16; ++sl) t += Pp[sl][o];
+      }
+      prow[c] = t;
+    }
+  }
+}
+
 size_t fwd_smem(const Geo& g) {
   return sizeof(float) * (size_t)(QT * g.LDH + QT * g.LDS_ + 2 * chunk_buf_floats(g.NKP, g.LDH));
 }
-size_t dq_smem(const Geo& g) {    // (the [16][2][HP] column partial sums reuse the chunk buffers)
-  return sizeof(float) * ((size_t)QT * g.LDH + (size_t)QT * g.LDS_ + (size_t)max(2 * chunk_buf_floats(g.NKP, g.LDH), 32 * g.HP));
+size_t dq_smem(const Geo& g, bool pkv = false) {    // (the [16][2][HP] column partial sums reuse the chunk buffers)
+  size_t fl = (size_t)QT * g.LDH + (size_t)QT * g.LDS_ + (size_t)max(2 * chunk_buf_floats(g.NKP, g.LDH), 32 * g.HP);
+  if (pkv) fl += (size_t)QT * g.LDS_ + (size_t)QT * g.LDH + 64;      // P tile, raw dO rows (the query rows take over Ds)
+  return sizeof(float) * fl;
+}
+inline bool pkv_ok(const DosxAttn& a) {
+  return a.dkv_part != nullptr && a.Nk <= 64 && dq_smem(make_geo(a.H, a.Nk), true) <= 160 * 1024;
 }
 size_t dkv_smem(const Geo& g, int kg) {
   const size_t stage = 2 * (size_t)(2 * DQC * g.LDH + 2 * DQC * (32 * kg + 4));
@@ -897,6 +1057,10 @@ int check_attn(const DosxAttn& a, const char* who) {
 }
 
 }  // namespace
+
+extern "C" int dosx_attention_pkv_supported(int Nk, int H) {
+  return Nk > 0 && Nk <= 64 && H > 0 && H <= 256 && dq_smem(make_geo(H, Nk), true) <= 160 * 1024;
+}
 
 extern "C" int dosx_attention_fwd(const DosxAttn* ap, dosx_stream_t stream) {
   DOSX_CHECK_ARG(ap, "dosx_attention_fwd: null");
@@ -928,10 +1092,12 @@ extern "C" int dosx_attention_bwd(const DosxAttn* ap, dosx_stream_t stream) {
   DOSX_CHECK_ARG(ap, "dosx_attention_bwd: null");
   const DosxAttn& a = *ap;
   if (int rc = check_attn(a, "dosx_attention_bwd")) return rc;
-  DOSX_CHECK_ARG(a.dout && a.dx && a.dscores && a.dkvhat && a.partials_q && a.partials_kv, "dosx_attention_bwd: null operand");
+  DOSX_CHECK_ARG(a.dout && a.dx && (a.dscores || pkv_ok(a)) && a.dkvhat && a.partials_q && a.partials_kv,
+                 "dosx_attention_bwd: null operand");
   const Geo g = make_geo(a.H, a.Nk);
   const int kg = a.Nk > 32 ? 2 : 1;
-  const size_t s1 = dq_smem(g), s2 = dkv_smem(g, kg);
+  const bool pkv = pkv_ok(a);
+  const size_t s1 = dq_smem(g, pkv), s2 = dkv_smem(g, kg);
   DOSX_CHECK_ARG(s1 <= 160 * 1024 && s2 <= 160 * 1024, "dosx_attention_bwd: LDS need %zu/%zu > 160 KiB", s1, s2);
   static bool attr_set = false;
   if (!attr_set) {
@@ -944,21 +1110,26 @@ extern "C" int dosx_attention_bwd(const DosxAttn* ap, dosx_stream_t stream) {
   const dim3 grid(ceil_div(a.Sq, QT), a.Bq);
   if (!(a.flags & DOSX_ATTN_BWD_SKIP_DQ)) {
     const int nj = a.Nk <= 16 ? 1 : (a.Nk <= 64 ? 4 : (a.Nk <= 208 ? 13 : 20));
-#define DOSX_DQS(NJ_)                                                                                       \
+#define DOSX_DQS(NJ_, PKV_)                                                                                 \
   do {                                                                                                      \
     static bool attr_dq = false;                                                                            \
     if (!attr_dq) {                                                                                         \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_stream_kernel<NJ_>),             \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_stream_kernel<NJ_, PKV_>),       \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
       attr_dq = true;                                                                                       \
     }                                                                                                       \
-    hipLaunchKernelGGL((attn_bwd_dq_stream_kernel<NJ_>), grid, dim3(512), s1, to_stream(stream), a);        \
+    hipLaunchKernelGGL((attn_bwd_dq_stream_kernel<NJ_, PKV_>), grid, dim3(512), s1, to_stream(stream), a);  \
   } while (0)
-    if (nj == 1) DOSX_DQS(1); else if (nj == 4) DOSX_DQS(4); else if (nj == 13) DOSX_DQS(13); else DOSX_DQS(20);
+    if (pkv) { if (nj == 1) DOSX_DQS(1, true); else DOSX_DQS(4, true); }
+    else if (nj == 1) DOSX_DQS(1, false); else if (nj == 4) DOSX_DQS(4, false); else if (nj == 13) DOSX_DQS(13, false);
+    else DOSX_DQS(20, false);
 #undef DOSX_DQS
     DOSX_LAUNCH_CHECK();
   }
-  if (!(a.flags & DOSX_ATTN_BWD_SKIP_DKV)) {
+  if (!(a.flags & DOSX_ATTN_BWD_SKIP_DKV) && pkv) {
+    hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3(a.Bk), dim3(256), 0, to_stream(stream), a, ceil_div(a.Sq, QT));
+    DOSX_LAUNCH_CHECK();
+  } else if (!(a.flags & DOSX_ATTN_BWD_SKIP_DKV)) {
     if (kg == 2) hipLaunchKernelGGL((attn_bwd_dkv_kernel<2>), dim3(ceil_div(a.Nk, 64), a.Bk), dim3(512), s2, to_stream(stream), a);
     else hipLaunchKernelGGL((attn_bwd_dkv_kernel<1>), dim3(ceil_div(a.Nk, 32), a.Bk), dim3(512), s2, to_stream(stream), a);
     DOSX_LAUNCH_CHECK();

@@ -15,6 +15,7 @@ import torch
 
 from . import ops
 from ._lib import Attn, Seg
+from ._lib import load as _lib_load
 from .batch import GraphMeta
 from .ops import (ACT_LEAKY, ACT_RELU, EPI_LN, EPI_PRELU_BWD, EPI_PRELU_LN_BWD, EPI_RELU_MASK, EPI_ROWLN_BWD,
                   PRO_LN_PRELU, PRO_PRELU, PRO_ROWLN, GradSink, rowmap, seg)
@@ -284,25 +285,29 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: torch.Tensor, dkvhat: t
         npart = Bq * nqt + Bk * nkt
         part = sink.scratch(npart, 2 * H)
         dxin = _empty(dev, rows, H)
-        dsc = _empty(dev, Bq, Sq, Nk)
-        a = _attn_desc(Sq, Bq, Nk, Bk, H, qs, qb, x_in, kvhat, g0, b0)
-        a.probs, a.qstats = probs.data_ptr(), qstats.data_ptr()
+        # Nk <= 64 (atoms of a crystal, the 51 phonon bins): the dq kernel leaves every query tile's share of dK + dV in
+        # `kvp` and the dk+dv half is a small reduction over those partials; larger key sets (201 eDOS bins) stream the
+        # dS round trip through `dsc` into the dkv kernel
+        small = bool(_lib_load().dosx_attention_pkv_supported(int(Nk), int(H)))
+        dsc = None if small else _empty(dev, Bq, Sq, Nk)
+        kvp = sink.scratch(Bq * nqt * Nk, H) if small else None
         acc = 0 if (dkv_fresh and t == T - 1) else 1
-        a.dout, a.dx, a.dscores, a.dkvhat, a.dkv_accumulate = dx1.data_ptr(), dxin.data_ptr(), dsc.data_ptr(), \
-            dkvhat.data_ptr(), acc
-        a.partials_q = part.data_ptr()
-        a.partials_kv = part.data_ptr() + 4 * Bq * nqt * 2 * H
+
+        def desc(flags):
+            a = _attn_desc(Sq, Bq, Nk, Bk, H, qs, qb, x_in, kvhat, g0, b0)
+            a.probs, a.qstats = probs.data_ptr(), qstats.data_ptr()
+            a.dout, a.dx, a.dkvhat, a.dkv_accumulate = dx1.data_ptr(), dxin.data_ptr(), dkvhat.data_ptr(), acc
+            a.dscores = dsc.data_ptr() if dsc is not None else None
+            a.dkv_part = kvp.data_ptr() if kvp is not None else None
+            a.partials_q = part.data_ptr()
+            a.partials_kv = part.data_ptr() + 4 * Bq * nqt * 2 * H
+            a.flags = flags
+            return a
         # dq (feeds the next layer's backward) on the main stream; dk+dv (feeds only the key-gradient
         # consumers at the very end) on the side stream, in layer order so dkvhat accumulates in order
-        a.flags = 8          # DOSX_ATTN_BWD_SKIP_DKV
-        ops.attention_bwd(a)
-        a2 = _attn_desc(Sq, Bq, Nk, Bk, H, qs, qb, x_in, kvhat, g0, b0)
-        a2.probs, a2.qstats = probs.data_ptr(), qstats.data_ptr()
-        a2.dout, a2.dx, a2.dscores, a2.dkvhat, a2.dkv_accumulate = dx1.data_ptr(), dxin.data_ptr(), dsc.data_ptr(), \
-            dkvhat.data_ptr(), acc
-        a2.partials_q, a2.partials_kv = a.partials_q, a.partials_kv
-        a2.flags = 4         # DOSX_ATTN_BWD_SKIP_DQ
-        sink.on_side(lambda a2=a2: ops.attention_bwd(a2), (dx1, dsc, dxin))
+        ops.attention_bwd(desc(8))          # DOSX_ATTN_BWD_SKIP_DKV
+        a2 = desc(4)                        # DOSX_ATTN_BWD_SKIP_DQ
+        sink.on_side(lambda a2=a2: ops.attention_bwd(a2), (dx1, dxin) + ((dsc,) if dsc is not None else ()))
         sink.add(part, 0, G[lp + ".layer_norms.0.weight"], npart, 2 * H, H)
         sink.add(part, H, G[lp + ".layer_norms.0.bias"], npart, 2 * H, H)
         dx = dxin

@@ -249,7 +249,13 @@ typedef struct DosxAttn {
   int32_t dkv_accumulate;
   float* partials_q;   /* [Bq * ceil(Sq/32)] rows of [dgamma(H) | dbeta(H)] */
   float* partials_kv;  /* [Bk * ceil(Nk/32)] rows of [dgamma(H) | dbeta(H)] */
+  float* dkv_part;     /* optional scratch [Bq * ceil(Sq/32), Nk, H]: with it (and Nk <= 64) the dq kernel also leaves each
+                          query tile's share of dK + dV there and the dkv half is a small reduction over those partials
+                          (no dscores round trip: dscores may then be NULL); without it the streamed dkv kernel runs */
 } DosxAttn;
+/* 1 if dosx_attention_bwd takes the partial-dKV path for this key count / width when dkv_part is given (else it needs
+ * dscores and runs the streamed dkv kernel) */
+int dosx_attention_pkv_supported(int Nk, int H);
 int dosx_attention_fwd(const DosxAttn* a, dosx_stream_t stream);
 int dosx_attention_bwd(const DosxAttn* a, dosx_stream_t stream);
 

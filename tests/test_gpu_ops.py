@@ -451,7 +451,13 @@ def _attn_ref(x, kvhat, gam, bet, Sq, Bq, Nk, Bk, H, qs, qb):
                                                    (201, 2, 41, 2, 256, False), (70, 3, 70, 3, 128, False),
                                                    (51, 5, 7, 5, 128, True), (201, 2, 201, 2, 256, False),
                                                    (7, 3, 5, 3, 16, False)])
-def test_attention_fwd_bwd(Sq, Bq, Nk, Bk, H, bcast):
+@pytest.mark.parametrize("pkv", [False, True])
+def test_attention_fwd_bwd(Sq, Bq, Nk, Bk, H, bcast, pkv):
+    """pkv: the dq kernel also produces the per-tile dK + dV partials and a reduction kernel finishes the key gradient
+    (Nk <= 64; DosxAttn.dkv_part) instead of the streamed dkv kernel behind the dscores round trip."""
+    from dostransformer_amd import _lib
+    if pkv and not _lib.load().dosx_attention_pkv_supported(Nk, H):
+        pytest.skip("partial-dKV path covers Nk <= 64")
     o = ops()
     from dostransformer_amd._lib import Attn
     qs, qb = (1, 0) if bcast else (Bq, 1)
@@ -488,7 +494,13 @@ def test_attention_fwd_bwd(Sq, Bq, Nk, Bk, H, bcast):
     a.dout, a.dx, a.dscores, a.dkvhat, a.dkv_accumulate = dout.data_ptr(), dx.data_ptr(), dsc.data_ptr(), dkv.data_ptr(), 1
     a.partials_q = part.data_ptr()
     a.partials_kv = part.data_ptr() + 4 * Bq * nqt * 2 * H
+    if pkv:
+        kvp = torch.full((Bq * nqt * Nk, H), float("nan"), device=DEV)
+        a.dkv_part, a.dscores = kvp.data_ptr(), None
+        dkv += 0.5                           # accumulate flag: the reduction adds onto what is there
     o.attention_bwd(a)
+    if pkv:
+        dkv -= 0.5
     ps = part.double().sum(0)
     if bcast:
         dxr = dx.double().reshape(Sq, Bq, H).sum(1)
