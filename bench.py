@@ -238,14 +238,20 @@ def main():
         rng = np.random.default_rng(777 + rank)
         order = {"perm": rng.permutation(len(ds)), "pos": 0}
 
-        def next_batch():
+        def next_indices():
             if order["pos"] + B > len(ds):            # next epoch: reshuffle
                 order["perm"], order["pos"] = rng.permutation(len(ds)), 0
             idx = order["perm"][order["pos"]:order["pos"] + B]
             order["pos"] += B
-            g = ds.collate(idx, n_max=pool_nmax)
-            real_dims.append((g.meta.num_nodes, g.meta.num_edges, g.meta.n_max))
-            return g
+            real_dims.append((int(ds.n_nodes[idx].sum()), int(ds.n_edges[idx].sum()), pool_nmax))
+            return idx
+
+        def next_batch():                             # (instrumented eager pass only)
+            return ds.collate(next_indices(), n_max=pool_nmax)
+
+        def do_step():
+            # collate straight into the bucket's static buffers (dosx_collate_padded) + replay
+            return trainer.step_dataset(ds, next_indices(), n_global, n_max=pool_nmax)
     else:
         # device-resident, pre-collated shards of N_DISTINCT_BATCHES global batches (global n_max per batch);
         # in graph / replay mode each is padded (exactly: ghost nodes/edges) to its (N, E) shape bucket
@@ -264,6 +270,9 @@ def main():
             it["i"] += 1
             return g
 
+        def do_step():
+            return trainer.step(next_batch(), n_global)
+
     def sync():
         torch.cuda.synchronize()
         if dp is not None:
@@ -271,7 +280,7 @@ def main():
 
     n_warm = max(args.warmup, N_DISTINCT_BATCHES if (use_graph and not args.shuffle) else 0)   # record every fixed bucket
     for i in range(n_warm):
-        trainer.step(next_batch(), n_global)
+        do_step()
     sync()
     # eager mode: per-kernel HIP-event timing over the timed region itself (same stream as the launches);
     # graph / replay mode: the timed region re-issues recorded launches (no per-kernel events possible), so the
@@ -282,7 +291,7 @@ def main():
         real_dims.clear()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        trainer.step(next_batch(), n_global)
+        do_step()
     torch.cuda.synchronize()
     if dp is not None:
         td.barrier()
@@ -334,7 +343,7 @@ def main():
             "config": {"workload": f"{args.config}: {kind} DOSTransformer layers={L} transformer={T} hidden={H}, "
                                    f"{B} crystals/GPU (global batch {n_global}), full train step (fwd+loss+bwd+AdamW), " +
                                    (f"a fresh random batch every step from a device-resident pool of {args.pool} crystals "
-                                    f"(on-GPU collate + ghost padding inside the timed region)" if args.shuffle else
+                                    f"(collated on the GPU straight into the shape bucket's static buffers, inside the timed region)" if args.shuffle else
                                     f"{N_DISTINCT_BATCHES} distinct pre-collated batches"),
                        "global_batch": n_global, "parallelism": f"dp{world}",
                        "launch": {"graph": "hip-graph replay per (N,E) bucket, exact ghost padding",

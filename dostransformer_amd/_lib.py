@@ -116,6 +116,15 @@ class CopyJob(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("dwords", C.c_int64)]
 
 
+class Collate(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("B", "N", "E", "N_pad", "E_pad", "n_max", "Fa", "Fe", "S", "n_glob")] + \
+               [(k, C.c_void_p) for k in ("sel", "out_node_ptr", "out_edge_ptr", "node_ptr_all", "edge_ptr_all", "src_all", "dst_all",
+                                          "perm_src_all", "rowptr_dst_all", "rowptr_src_all", "inv_deg_all", "x_all",
+                                          "edge_feat_all", "target_all", "glob_all", "system_all", "x", "edge_feat", "target",
+                                          "glob", "system", "src", "dst", "perm_src", "rowptr_dst", "rowptr_src", "graph_ptr",
+                                          "node_graph", "dense_row", "inv_deg", "node_row", "edge_row")]
+
+
 class Call(C.Structure):
     _fields_ = [("op", C.c_int32), ("nint", C.c_int32), ("nflt", C.c_int32), ("reserved", C.c_int32),
                 ("iarg", C.c_int64 * 19), ("farg", C.c_double * 6)]
@@ -165,6 +174,7 @@ _SIGS = {
     "dosx_csr_workspace_bytes": [_I, C.POINTER(C.c_size_t)],
     "dosx_csr_build": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P],
     "dosx_collate": [_P] * 5 + [_I] * 3 + [_P] * 18 + [_P],
+    "dosx_collate_padded": [C.POINTER(Collate), _P],
     "dosx_neighbor_count": [_P, _P, _P, _P, _I, _L, _D, _I, _I, _P, _P],
     "dosx_neighbor_fill": [_P, _P, _P, _P, _I, _L, _D, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "dosx_replay_op": [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)],

@@ -528,25 +528,6 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(const DosxAttn 
   store_scores1(sacc, Ss, g.LDS_, g.NKP, tid);
   __syncthreads();
 
-  if constexpr (PKV) {          // every matrix wave is past its last read of Ds (= dO gamma): the rows become Q
-#pragma unroll
-    for (int p = 0; p < RP; ++p) {
-      const int lr = row_of(wave, p, lane);
-#pragma unroll
-      for (int k = 0; k < KCB; ++k) {
-        const int c = q16 * 4 + 64 * k;
-        if (c >= g.HP) continue;
-        const bool rv = c < H && (s0 + lr) < Sq;
-        const float4 b0 = ld4(a.beta0 + (c < H ? c : 0));
-        const float4 xv = xr[p][k];
-        float4 q = xv;
-        if (!raw_q)
-          q = make_float4((xv.x - mean[p]) * rstd[p] * g0[k].x + b0.x, (xv.y - mean[p]) * rstd[p] * g0[k].y + b0.y,
-                          (xv.z - mean[p]) * rstd[p] * g0[k].z + b0.z, (xv.w - mean[p]) * rstd[p] * g0[k].w + b0.w);
-        st4(Ql + lr * g.LDH + c, rv ? q : f4zero());
-      }
-    }
-  }
   // dS = P * (dP - rowsum(P*dP)) * scale
   {
     const float scale = rsqrtf((float)H);
@@ -587,54 +568,6 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(const DosxAttn 
     }
   }
   __syncthreads();
-
-  if constexpr (PKV) {
-    // ---- this tile's share of dK + dV: [NKP keys] x [32 queries] . [32 queries] x [HP] (matrix waves; the staging
-    // waves are streaming the k̂ chunks of the next product meanwhile) ----
-    constexpr int NKT = NJ == 1 ? 1 : 2;            // 32-key tiles (NJ = 1: Nk <= 16; NJ = 4: Nk <= 64)
-    const int l31 = lane & 31, hh = lane >> 5, nct = g.HP / 32;
-    f32x16 dacc[NKT][MAX_CT], dacc2[NKT][MAX_CT];     // P^T dO and dS^T Q in separate chains (a dependent MFMA chain
-#pragma unroll                                       //  issues every ~87 clk instead of every 64)
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int t = 0; t < MAX_CT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { dacc[kt][t][r] = 0.f; dacc2[kt][t][r] = 0.f; }
-#pragma unroll 4
-    for (int mm = 0; mm < QT; mm += 2) {
-      float pa[NKT], sa[NKT];
-#pragma unroll
-      for (int kt = 0; kt < NKT; ++kt) {            // (NKT = 2 with NKP = 32: the second tile reads past the row, into the
-        pa[kt] = Ps2[(mm + hh) * g.LDS_ + kt * 32 + l31];   //  next row / buffer - in bounds of the LDS, rows j >= Nk are
-        sa[kt] = Ss[(mm + hh) * g.LDS_ + kt * 32 + l31];    //  never stored)
-      }
-#pragma unroll
-      for (int t = 0; t < MAX_CT; ++t) {
-        const int ct = wave + 4 * t;
-        if (ct >= nct) continue;
-        const float b1 = dOr[(mm + hh) * g.LDH + ct * 32 + l31];
-        const float b2 = Ql[(mm + hh) * g.LDH + ct * 32 + l31];
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-          dacc[kt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kt], b1, dacc[kt][t], 0, 0, 0);
-          dacc2[kt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[kt], b2, dacc2[kt][t], 0, 0, 0);
-        }
-      }
-    }
-    float* part = a.dkv_part + ((size_t)bq * gridDim.x + blockIdx.x) * (size_t)Nk * H;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int t = 0; t < MAX_CT; ++t) {
-        const int ct = wave + 4 * t, col = ct * 32 + l31;
-        if (ct >= nct) continue;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int j = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          if (j < Nk && col < H) part[(size_t)j * H + col] = dacc[kt][t][r] + dacc2[kt][t][r];
-        }
-      }
-  }
 
   f32x16 oacc[MAX_CT];
   stream_pv(oacc, Ss, g.LDS_, CH, sg, g.HP, g.LDH, tid);
@@ -710,6 +643,76 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(const DosxAttn 
     for (int sl = 0; sl < 16; ++sl) t += Pp[sl * 2 * g.HP + o];
     prow[c] = t;
   }
+
+  if constexpr (PKV) {          // dq is done and stored; each quarter wave is past its last read of its own Ds rows
+                                // (the dS.k̂ tile): they become Q = LN0(x) gamma0 + beta0 for the key-gradient product
+#pragma unroll
+    for (int p = 0; p < RP; ++p) {
+      const int lr = row_of(wave, p, lane);
+#pragma unroll
+      for (int k = 0; k < KCB; ++k) {
+        const int c = q16 * 4 + 64 * k;
+        if (c >= g.HP) continue;
+        const bool rv = c < H && (s0 + lr) < Sq;
+        const float4 b0 = ld4(a.beta0 + (c < H ? c : 0));
+        const float4 xv = xr[p][k];
+        float4 q = xv;
+        if (!raw_q)
+          q = make_float4((xv.x - mean[p]) * rstd[p] * g0[k].x + b0.x, (xv.y - mean[p]) * rstd[p] * g0[k].y + b0.y,
+                          (xv.z - mean[p]) * rstd[p] * g0[k].z + b0.z, (xv.w - mean[p]) * rstd[p] * g0[k].w + b0.w);
+        st4(Ql + lr * g.LDH + c, rv ? q : f4zero());
+      }
+    }
+  }
+  if constexpr (PKV) __syncthreads();
+  if constexpr (PKV) {
+    // ---- this tile's share of dK + dV: [NKP keys] x [32 queries] . [32 queries] x [HP].  LAST in the kernel: placed
+    // before the dS.k̂ product its global stores sat in front of that loop's barriers (s_waitcnt vmcnt(0)) ----
+    constexpr int NKT = NJ == 1 ? 1 : 2;            // 32-key tiles (NJ = 1: Nk <= 16; NJ = 4: Nk <= 64)
+    const int l31 = lane & 31, hh = lane >> 5, nct = g.HP / 32;
+    f32x16 dacc[NKT][MAX_CT], dacc2[NKT][MAX_CT];     // P^T dO and dS^T Q in separate chains (a dependent MFMA chain
+#pragma unroll                                       //  issues every ~87 clk instead of every 64)
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int t = 0; t < MAX_CT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dacc[kt][t][r] = 0.f; dacc2[kt][t][r] = 0.f; }
+#pragma unroll
+    for (int mm = 0; mm < QT; mm += 2) {          // fully unrolled: the fragment reads of later steps issue under the MFMAs
+      float pa[NKT], sa[NKT];
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {            // (NKT = 2 with NKP = 32: the second tile reads past the row, into the
+        pa[kt] = Ps2[(mm + hh) * g.LDS_ + kt * 32 + l31];   //  next row / buffer - in bounds of the LDS, rows j >= Nk are
+        sa[kt] = Ss[(mm + hh) * g.LDS_ + kt * 32 + l31];    //  never stored)
+      }
+#pragma unroll
+      for (int t = 0; t < MAX_CT; ++t) {
+        const int ct = wave + 4 * t;
+        if (ct >= nct) continue;
+        const float b1 = dOr[(mm + hh) * g.LDH + ct * 32 + l31];
+        const float b2 = Ql[(mm + hh) * g.LDH + ct * 32 + l31];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+          dacc[kt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kt], b1, dacc[kt][t], 0, 0, 0);
+          dacc2[kt][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[kt], b2, dacc2[kt][t], 0, 0, 0);
+        }
+      }
+    }
+    float* part = a.dkv_part + ((size_t)bq * gridDim.x + blockIdx.x) * (size_t)Nk * H;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int t = 0; t < MAX_CT; ++t) {
+        const int ct = wave + 4 * t, col = ct * 32 + l31;
+        if (ct >= nct) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (j < Nk && col < H) part[(size_t)j * H + col] = dacc[kt][t][r] + dacc2[kt][t][r];
+        }
+      }
+  }
+
 }
 
 // ================================== backward: dk + dv ============================================

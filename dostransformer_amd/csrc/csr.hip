@@ -235,3 +235,110 @@ extern "C" int dosx_collate(const int* sel, const int* node_ptr_all, const int* 
   DOSX_LAUNCH_CHECK();
   return 0;
 }
+
+
+// =============================================================================================================
+// Collate STRAIGHT INTO the static buffers of a shape bucket (train.Trainer.step_dataset): what dosx_collate + the row
+// gathers + batch.pad_batch + the slot copy did in ~40 launches, in three.  Real nodes / edges as in dosx_collate; the
+// ghost tail reproduces batch.pad_batch exactly: ghost nodes carry zero features, belong to no crystal (node_graph = B,
+// dense slot = the spare row n_max*B), ghost edges are self loops on the first ghost node with zero features.
+// =============================================================================================================
+namespace {
+
+__global__ void collate_pad_nodes_kernel(const DosxCollate d) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n > d.N_pad) return;
+  if (n <= d.B) d.graph_ptr[n] = d.out_node_ptr[n];     // (B <= N < N_pad: these threads exist)
+  if (n >= d.N) {                                        // ghost tail (+ the closing row-pointer entries)
+    const int rp = n == d.N ? d.E : d.E_pad;
+    d.rowptr_dst[n] = rp;
+    d.rowptr_src[n] = rp;
+    if (n < d.N_pad) {
+      d.node_graph[n] = d.B;
+      d.dense_row[n] = d.n_max * d.B;
+      d.inv_deg[n] = n == d.N ? 1.f / (float)max(d.E_pad - d.E, 1) : 1.f;
+      d.node_row[n] = -1;
+    }
+    return;
+  }
+  const int b = seg_of(d.out_node_ptr, d.B, n), c = d.sel[b];
+  const int l = n - d.out_node_ptr[b], s = d.node_ptr_all[c] + l;
+  d.node_graph[n] = b;
+  d.dense_row[n] = l * d.B + b;
+  d.inv_deg[n] = d.inv_deg_all[s];
+  d.rowptr_dst[n] = d.rowptr_dst_all[s + c] + d.out_edge_ptr[b];
+  d.rowptr_src[n] = d.rowptr_src_all[s + c] + d.out_edge_ptr[b];
+  d.node_row[n] = s;
+}
+
+__global__ void collate_pad_edges_kernel(const DosxCollate d) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= d.E_pad) return;
+  if (e >= d.E) {
+    d.src[e] = d.N;
+    d.dst[e] = d.N;
+    d.perm_src[e] = e;
+    d.edge_row[e] = -1;
+    return;
+  }
+  const int b = seg_of(d.out_edge_ptr, d.B, e), c = d.sel[b];
+  const int l = e - d.out_edge_ptr[b], s = d.edge_ptr_all[c] + l;
+  const int no = d.out_node_ptr[b];
+  d.src[e] = d.src_all[s] + no;
+  d.dst[e] = d.dst_all[s] + no;
+  d.perm_src[e] = d.perm_src_all[s] + d.out_edge_ptr[b];
+  d.edge_row[e] = s;
+}
+
+// feature rows: x [N_pad,Fa], edge features [E_pad,Fe], per-crystal targets [B,S] / globals [B,n_glob] / system [B]
+__global__ void collate_pad_gather_kernel(const DosxCollate d) {
+  const size_t nx = (size_t)d.N_pad * d.Fa, ne = (size_t)d.E_pad * d.Fe, nt = (size_t)d.B * d.S, ng = (size_t)d.B * d.n_glob;
+  const size_t total = nx + ne + nt + ng + d.B;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    if (i < nx) {
+      const int n = (int)(i / d.Fa), c = (int)(i % d.Fa), r = d.node_row[n];
+      d.x[i] = r >= 0 ? d.x_all[(size_t)r * d.Fa + c] : 0.f;
+    } else if (i < nx + ne) {
+      const size_t k = i - nx;
+      const int e = (int)(k / d.Fe), c = (int)(k % d.Fe), r = d.edge_row[e];
+      d.edge_feat[k] = r >= 0 ? d.edge_feat_all[(size_t)r * d.Fe + c] : 0.f;
+    } else if (i < nx + ne + nt) {
+      const size_t k = i - nx - ne;
+      d.target[k] = d.target_all[(size_t)d.sel[k / d.S] * d.S + k % d.S];
+    } else if (i < nx + ne + nt + ng) {
+      const size_t k = i - nx - ne - nt;
+      d.glob[k] = d.glob_all[(size_t)d.sel[k / d.n_glob] * d.n_glob + k % d.n_glob];
+    } else {
+      const int b = (int)(i - nx - ne - nt - ng);
+      d.system[b] = d.system_all[d.sel[b]];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int dosx_collate_padded(const DosxCollate* dp, dosx_stream_t stream) {
+  DOSX_CHECK_ARG(dp != nullptr, "dosx_collate_padded: null descriptor");
+  const DosxCollate& d = *dp;
+  DOSX_CHECK_ARG(d.B > 0 && d.N >= d.B && d.E >= 0 && d.N_pad > d.N && d.E_pad >= d.E && d.n_max > 0,
+                 "dosx_collate_padded: bad sizes B=%d N=%d E=%d N_pad=%d E_pad=%d n_max=%d (needs >= 1 ghost node)", d.B, d.N, d.E,
+                 d.N_pad, d.E_pad, d.n_max);
+  DOSX_CHECK_ARG(d.Fa > 0 && d.Fe > 0 && d.S >= 0 && d.n_glob >= 0, "dosx_collate_padded: bad widths");
+  DOSX_CHECK_ARG(d.sel && d.out_node_ptr && d.out_edge_ptr && d.node_ptr_all && d.edge_ptr_all && d.src_all && d.dst_all &&
+                     d.perm_src_all && d.rowptr_dst_all && d.rowptr_src_all && d.inv_deg_all && d.x_all && d.edge_feat_all &&
+                     d.system_all && (d.S == 0 || d.target_all) && (d.n_glob == 0 || d.glob_all),
+                 "dosx_collate_padded: null input");
+  DOSX_CHECK_ARG(d.x && d.edge_feat && d.system && (d.S == 0 || d.target) && (d.n_glob == 0 || d.glob) && d.src && d.dst &&
+                     d.perm_src && d.rowptr_dst && d.rowptr_src && d.graph_ptr && d.node_graph && d.dense_row && d.inv_deg &&
+                     d.node_row && d.edge_row,
+                 "dosx_collate_padded: null output");
+  hipStream_t s = to_stream(stream);
+  hipLaunchKernelGGL(collate_pad_nodes_kernel, dim3(ceil_div(d.N_pad + 1, 256)), dim3(256), 0, s, d);
+  if (d.E_pad > 0) hipLaunchKernelGGL(collate_pad_edges_kernel, dim3(ceil_div(d.E_pad, 256)), dim3(256), 0, s, d);
+  const size_t total = (size_t)d.N_pad * d.Fa + (size_t)d.E_pad * d.Fe + (size_t)d.B * (d.S + d.n_glob + 1);
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(collate_pad_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, s, d);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}

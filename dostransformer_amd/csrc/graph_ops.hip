@@ -53,47 +53,47 @@ __device__ __forceinline__ float4 slots_sum(float4 v, int lpr) {
   return v;
 }
 
-// agg[n] = scale[n] * sum_{e in seg(n)} msg[e] ; e_out[e] = e_in[e] + msg[e].  One wave per node.
-__global__ __launch_bounds__(256) void segment_reduce_kernel(const float* __restrict__ msg,
+// agg[n] = scale[n] * sum_{e in seg(n)} msg[e] ; e_out[e] = e_in[e] + msg[e].  One wave per node, two nodes per
+// workgroup; every lane slot keeps up to SR_U rows of the segment in flight at once (msg and e_in), so a node of <= SR_U *
+// rows-per-step edges (24 at H = 128) costs two dependent round trips (segment bounds, rows) instead of one per group of 4.
+constexpr int SR_U = 12;
+
+__global__ __launch_bounds__(128) void segment_reduce_kernel(const float* __restrict__ msg,
                                                              const int* __restrict__ rowptr,
                                                              const float* __restrict__ scale,
                                                              float* __restrict__ agg,
                                                              const float* e_in, float* e_out, int N,
                                                              int H) {
   const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int n = blockIdx.x * 2 + (threadIdx.x >> 6);
   if (n >= N) return;
   const RowLanes rl = row_lanes(H, lane);
   const int beg = rowptr[n], end = rowptr[n + 1];
+  const float sc = scale ? scale[n] : 1.f;
   for (int cb = 0; cb < H; cb += 256) {           // column blocks (H > 256 only loops)
     const int c = cb + rl.c4;
+    const bool cok = c < H;
+    const int cc = cok ? c : 0;
     float4 acc = f4zero();
-    if (c < H) {
-      int e = beg + rl.slot;
-      // 4 rows in flight per lane
-      for (; e + 3 * rl.rps < end; e += 4 * rl.rps) {
-        const size_t o0 = (size_t)e * H + c, o1 = o0 + (size_t)rl.rps * H, o2 = o1 + (size_t)rl.rps * H,
-                     o3 = o2 + (size_t)rl.rps * H;
-        const float4 m0 = ld4(msg + o0), m1 = ld4(msg + o1), m2 = ld4(msg + o2), m3 = ld4(msg + o3);
-        if (e_out) {
-          const float4 a0 = ld4(e_in + o0), a1 = ld4(e_in + o1), a2 = ld4(e_in + o2), a3 = ld4(e_in + o3);
-          st4(e_out + o0, f4add(a0, m0)); st4(e_out + o1, f4add(a1, m1));
-          st4(e_out + o2, f4add(a2, m2)); st4(e_out + o3, f4add(a3, m3));
-        }
-        acc = f4add(acc, f4add(f4add(m0, m1), f4add(m2, m3)));
+    for (int e0 = beg + rl.slot; e0 < end; e0 += SR_U * rl.rps) {
+      float4 m[SR_U], a[SR_U];
+#pragma unroll
+      for (int u = 0; u < SR_U; ++u) {
+        const size_t o = (size_t)min(e0 + u * rl.rps, end - 1) * H + cc;
+        m[u] = ld4(msg + o);
+        if (e_out) a[u] = ld4(e_in + o);
       }
-      for (; e < end; e += rl.rps) {
-        const size_t o0 = (size_t)e * H + c;
-        const float4 m0 = ld4(msg + o0);
-        if (e_out) st4(e_out + o0, f4add(ld4(e_in + o0), m0));
-        acc = f4add(acc, m0);
+#pragma unroll
+      for (int u = 0; u < SR_U; ++u) {
+        const int e = e0 + u * rl.rps;
+        if (e < end) {
+          acc = f4add(acc, m[u]);
+          if (e_out && cok) st4(e_out + (size_t)e * H + c, f4add(a[u], m[u]));
+        }
       }
     }
     acc = slots_sum(acc, rl.lpr);
-    if (c < H && rl.slot == 0) {
-      const float s = scale ? scale[n] : 1.f;
-      st4(agg + (size_t)n * H + c, make_float4(acc.x * s, acc.y * s, acc.z * s, acc.w * s));
-    }
+    if (cok && rl.slot == 0) st4(agg + (size_t)n * H + c, make_float4(acc.x * sc, acc.y * sc, acc.z * sc, acc.w * sc));
   }
 }
 
@@ -496,7 +496,7 @@ extern "C" int dosx_segment_reduce(const float* msg, const int32_t* rowptr, cons
   if (N <= 0) return 0;
   CHECK_H(H);
   DOSX_CHECK_ARG(msg && rowptr && agg && (!e_out || e_in), "dosx_segment_reduce: bad args");
-  hipLaunchKernelGGL(segment_reduce_kernel, dim3(ceil_div(N, 4)), dim3(256), 0, to_stream(stream), msg, rowptr, scale,
+  hipLaunchKernelGGL(segment_reduce_kernel, dim3(ceil_div(N, 2)), dim3(128), 0, to_stream(stream), msg, rowptr, scale,
                      agg, e_in, e_out, N, H);
   DOSX_LAUNCH_CHECK();
   return 0;

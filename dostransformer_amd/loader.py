@@ -106,6 +106,68 @@ class DeviceDataset:
         meta = GraphMeta(num_nodes=N, num_edges=E, num_graphs=B, n_max=int(n_max), edge_perm=None, graph_ptr=onp, **m)
         return CrystalBatch(fields, B, meta)
 
+    # ---- collate straight into a shape bucket's static buffers (train.Trainer.step_dataset) -------------------------
+    def _f32_tables(self):
+        """fp32 / int32 device copies of the feature tables in the kernels' format (built once, on first use)."""
+        t = getattr(self, "_tables32", None)
+        if t is None:
+            ek = "edge_vec" if "edge_vec" in self._edge else "edge_attr"
+            tk = "phdos" if "phdos" in self._graph else "y_ft"
+            t = {"x": self._x.to(torch.float32).contiguous(), "edge": self._edge[ek].to(torch.float32).contiguous(),
+                 "edge_key": ek, "target": self._graph[tk].to(torch.float32).contiguous(), "target_key": tk,
+                 "glob": self._graph["glob"].to(torch.float32).contiguous() if "glob" in self._graph else None,
+                 "system": self._graph["system"].to(torch.int32).contiguous()}
+            self._tables32 = t
+        return t
+
+    def bucket_dims(self, indices, n_max: Optional[int] = None):
+        """(idx, N, E, n_max) of a selection, from host-side counts only."""
+        idx = np.asarray(list(indices), np.int64)
+        nn = self.n_nodes[idx]
+        true_max = int(nn.max())
+        if n_max is None:
+            n_max = true_max
+        elif n_max < true_max:
+            raise ValueError(f"n_max={n_max} smaller than the largest crystal ({true_max} atoms)")
+        return idx, int(nn.sum()), int(self.n_edges[idx].sum()), int(n_max)
+
+    def collate_into(self, g: CrystalBatch, idx: np.ndarray, scratch: Dict[str, torch.Tensor]) -> None:
+        """Write the batch of crystals ``idx`` into the STATIC ghost-padded buffers of ``g`` (a bucket of
+        ``train.Trainer``): one small host->device copy (selection + prefix sums) and one ``dosx_collate_padded`` call
+        (3 launches).  The result is what ``pad_batch(self.collate(idx), N_pad, E_pad)`` holds in the fields the kernels read
+        (tests/test_gpu_round2.py::test_collate_into_matches_pad_batch)."""
+        from ._lib import Collate
+        import ctypes as C
+        t = self._f32_tables()
+        m = g.meta
+        B = int(idx.shape[0])
+        nn, ne = self.n_nodes[idx], self.n_edges[idx]
+        out_np = np.concatenate([[0], np.cumsum(nn)]).astype(np.int32)
+        out_ep = np.concatenate([[0], np.cumsum(ne)]).astype(np.int32)
+        small = scratch["small"]
+        host = torch.from_numpy(np.concatenate([idx.astype(np.int32), out_np, out_ep]))
+        small[:3 * B + 2].copy_(host, non_blocking=True)
+        d = Collate()
+        d.B, d.N, d.E, d.N_pad, d.E_pad, d.n_max = B, int(out_np[-1]), int(out_ep[-1]), m.num_nodes, m.num_edges, m.n_max
+        d.Fa, d.Fe, d.S = int(t["x"].shape[1]), int(t["edge"].shape[1]), int(t["target"].shape[1])
+        d.n_glob = int(t["glob"].shape[1]) if t["glob"] is not None else 0
+        base = small.data_ptr()
+        d.sel, d.out_node_ptr, d.out_edge_ptr = base, base + 4 * B, base + 4 * (2 * B + 1)
+        d.node_ptr_all, d.edge_ptr_all = self._node_ptr.data_ptr(), self._edge_ptr.data_ptr()
+        d.src_all, d.dst_all, d.perm_src_all = self._src.data_ptr(), self._dst.data_ptr(), self._perm.data_ptr()
+        d.rowptr_dst_all, d.rowptr_src_all, d.inv_deg_all = self._rpd.data_ptr(), self._rps.data_ptr(), self._invd.data_ptr()
+        d.x_all, d.edge_feat_all, d.target_all = t["x"].data_ptr(), t["edge"].data_ptr(), t["target"].data_ptr()
+        d.glob_all = t["glob"].data_ptr() if t["glob"] is not None else None
+        d.system_all = t["system"].data_ptr()
+        d.x, d.edge_feat, d.target = g.x.data_ptr(), g[t["edge_key"]].data_ptr(), g[t["target_key"]].data_ptr()
+        d.glob = g.glob.data_ptr() if t["glob"] is not None else None
+        d.system = g.system.data_ptr()
+        for k in ("src", "dst", "perm_src", "rowptr_dst", "rowptr_src", "graph_ptr", "node_graph", "dense_row", "inv_deg"):
+            setattr(d, k, getattr(m, k).data_ptr())
+        d.node_row, d.edge_row = scratch["node_row"].data_ptr(), scratch["edge_row"].data_ptr()
+        ops._call("dosx_collate_padded", C.byref(d), ops._stream(),
+                  w=lambda: ("collate_padded", "collate_pad", "hbm", 8.0 * (d.N_pad * d.Fa + d.E_pad * d.Fe)))
+
     def batches(self, batch_size: int, shuffle: bool = False, seed: int = 0, drop_last: bool = False) -> Iterator[CrystalBatch]:
         """One epoch of device-collated batches (the loop body of `main_eDOS.py:104`)."""
         order = np.arange(self.num_crystals)

@@ -53,6 +53,31 @@ class _Slot:
         self.prog_a = self.prog_b = None
         self.plan = []
         self.keep = None
+        self.scratch = None
+
+    @classmethod
+    def empty(cls, kind: str, device, B: int, n_pad: int, e_pad: int, n_max: int, Fa: int, Fe: int, S: int) -> "_Slot":
+        """Uninitialised static buffers of a bucket, to be filled by ``DeviceDataset.collate_into`` (no source batch)."""
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
+        i32 = lambda *s: torch.empty(*s, dtype=torch.int32, device=device)
+        f = {"x": f32(n_pad, Fa), "system": i32(B), "edge_index": None, "batch": None}
+        if kind == "phonon":
+            f["edge_vec"], f["phdos"] = f32(e_pad, Fe), f32(B, S)
+        else:
+            f["edge_attr"], f["glob"], f["y_ft"] = f32(e_pad, Fe), f32(2 * B), f32(B * S)
+        meta = GraphMeta(num_nodes=n_pad, num_edges=e_pad, num_graphs=B, n_max=n_max, edge_perm=None,
+                         src=i32(e_pad), dst=i32(e_pad), rowptr_dst=i32(n_pad + 1), perm_src=i32(e_pad),
+                         rowptr_src=i32(n_pad + 1), graph_ptr=i32(B + 1), node_graph=i32(n_pad), dense_row=i32(n_pad),
+                         inv_deg=f32(n_pad))
+        self = cls.__new__(cls)
+        self.fields = [k for k in f if k not in ("edge_index", "batch")]
+        self.g = CrystalBatch(f, B, meta)
+        self.graph_a = self.graph_b = None
+        self.prog_a = self.prog_b = None
+        self.plan = []
+        self.keep = None
+        self.scratch = {"small": i32(3 * B + 2), "node_row": i32(n_pad), "edge_row": i32(e_pad)}
+        return self
 
     def load(self, g: CrystalBatch) -> None:
         """Copy a batch of this bucket's shape into the static buffers: ONE launch for everything that is already in
@@ -286,35 +311,26 @@ class Trainer:
         slot.keep = (st, loss)
         slot.loss, slot.out, slot.sse = loss, st["out"], st.get("sse")
 
-    def _graph_step(self, g: CrystalBatch, n_global: Optional[int]) -> torch.Tensor:
-        model = self.model
-        dev = model._module_device()
-        fp = model._ensure_flat(dev, g)
-        self._state(fp)
-        m = g.meta
-        if m is None or m.edge_perm is not None:
-            raise ValueError("graph mode needs batches from collate(sort_edges=True) (+ pad_batch)")
-        if getattr(g, "real_nodes", None) is None:               # not padded yet: pad on the fly
-            g = pad_batch(g, *bucket_sizes(m.num_nodes, m.num_edges, *self.bucket))
-            m = g.meta
-        ng = self._n_global(m.num_graphs, n_global, g)
-        key = (m.num_nodes, m.num_edges, m.num_graphs, m.n_max, ng)
+    def _lookup(self, key):
+        """(slot or None) of a bucket key, with the LRU / hit-rate bookkeeping."""
         slot = self._slots.get(key)
         if slot is None:
             self.slot_misses += 1
             while len(self._slots) >= self.max_slots:          # evict the least recently used bucket
                 self._slots.popitem(last=False)
-            slot = _Slot(g, self.kind)
-            self._slots[key] = slot
-            if self.replay:
-                self._record(slot, fp, ng)       # this IS the step for this batch (run + record)
-                self.last_outputs = slot.out
-                return slot.loss
-            self._capture(slot, fp, ng)
         else:
             self.slot_hits += 1
             self._slots.move_to_end(key)
-        slot.load(g)
+        return slot
+
+    def _run_slot(self, slot: _Slot, fp, ng: int, fresh: bool) -> torch.Tensor:
+        """The step on a bucket whose static buffers hold the batch: record / capture on first use, replay afterwards."""
+        if fresh and self.replay:
+            self._record(slot, fp, ng)       # this IS the step for this batch (run + record)
+            self.last_outputs = slot.out
+            return slot.loss
+        if fresh:
+            self._capture(slot, fp, ng)
         if self.replay:
             for kind, prog in slot.plan:
                 if kind == "prog":
@@ -330,6 +346,62 @@ class Trainer:
                 slot.graph_b.replay()
         self.last_outputs = slot.out
         return slot.loss
+
+    def _graph_step(self, g: CrystalBatch, n_global: Optional[int]) -> torch.Tensor:
+        model = self.model
+        dev = model._module_device()
+        fp = model._ensure_flat(dev, g)
+        self._state(fp)
+        m = g.meta
+        if m is None or m.edge_perm is not None:
+            raise ValueError("graph mode needs batches from collate(sort_edges=True) (+ pad_batch)")
+        if getattr(g, "real_nodes", None) is None:               # not padded yet: pad on the fly
+            g = pad_batch(g, *bucket_sizes(m.num_nodes, m.num_edges, *self.bucket))
+            m = g.meta
+        ng = self._n_global(m.num_graphs, n_global, g)
+        key = (m.num_nodes, m.num_edges, m.num_graphs, m.n_max, ng)
+        slot = self._lookup(key)
+        fresh = slot is None
+        if fresh:
+            slot = _Slot(g, self.kind)
+            self._slots[key] = slot
+            if not self.replay:
+                pass                          # (capture runs on the slot's own copy of this batch, then replays it)
+        else:
+            slot.load(g)
+        return self._run_slot(slot, fp, ng, fresh)
+
+    def step_dataset(self, ds, indices, n_global: Optional[int] = None, n_max: Optional[int] = None) -> torch.Tensor:
+        """One training step on the crystals ``indices`` of a device-resident ``loader.DeviceDataset``: the batch is
+        collated by ``dosx_collate_padded`` STRAIGHT INTO the static buffers of its shape bucket (ghost padding
+        included) and the bucket's recorded program is replayed — no intermediate batch object, no padding ops, no
+        slot copy.  Same numbers as ``step(ds.collate(indices))`` (the counterpart of the loop body `main_phDOS.py:104-118`
+        with a shuffling DataLoader)."""
+        if not (self.replay or self.graph):
+            return self.step(ds.collate(indices, n_max=n_max), n_global)
+        model = self.model
+        dev = model._module_device()
+        fp = model._ensure_flat(dev, None)
+        self._state(fp)
+        idx, N, E, n_max = ds.bucket_dims(indices, n_max)
+        B = int(idx.shape[0])
+        n_pad, e_pad = bucket_sizes(N, E, *self.bucket)
+        ng = int(n_global) if n_global is not None else (self.dist.global_count(B) if self.dist is not None else B)
+        key = (n_pad, e_pad, B, n_max, ng)
+        slot = self._lookup(key)
+        fresh = slot is None
+        if fresh:
+            t = ds._f32_tables()
+            slot = _Slot.empty(self.kind, dev, B, n_pad, e_pad, n_max, int(t["x"].shape[1]), int(t["edge"].shape[1]),
+                               int(t["target"].shape[1]))
+            self._slots[key] = slot
+        elif getattr(slot, "scratch", None) is None:               # bucket first filled from a batch object
+            i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)
+            slot.scratch = {"small": i32(3 * B + 2), "node_row": i32(n_pad), "edge_row": i32(e_pad)}
+        ds.collate_into(slot.g, idx, slot.scratch)
+        loss = self._run_slot(slot, fp, ng, fresh)
+        self.optimizer_step()
+        return loss
 
     # ---- optimizer -------------------------------------------------------------------------------
     def optimizer_step(self) -> None:

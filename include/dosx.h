@@ -374,6 +374,49 @@ int dosx_collate(const int32_t* sel, const int32_t* node_ptr_all, const int32_t*
                  int32_t* perm_src, int32_t* rowptr_dst, int32_t* rowptr_src, int32_t* node_graph, int32_t* dense_row,
                  float* inv_deg, int32_t* node_row, int32_t* edge_row, dosx_stream_t stream);
 
+/* Collate straight into the STATIC buffers of a shape bucket, ghost padding included (train.Trainer.step_dataset): the
+ * selected crystals' segments + feature rows as dosx_collate / the row gathers would give them, followed by the ghost tail
+ * batch.pad_batch appends (ghost nodes: zero features, node_graph = B, dense slot n_max*B; ghost edges: self loops on the
+ * first ghost node, zero features; rowptr[N] = E, rowptr[N+1..N_pad] = E_pad).  All pointers device memory; feature data
+ * fp32.  target: [B,S] rows (phdos / y_ft), glob: [B,n_glob] (n_glob = 0: none), system: int32 [B].
+ * node_row / edge_row: scratch [N_pad] / [E_pad].  Needs N_pad > N (at least one ghost node). */
+typedef struct DosxCollate {
+  int32_t B, N, E, N_pad, E_pad, n_max, Fa, Fe, S, n_glob;
+  const int32_t* sel;
+  const int32_t* out_node_ptr;
+  const int32_t* out_edge_ptr;
+  const int32_t* node_ptr_all;
+  const int32_t* edge_ptr_all;
+  const int32_t* src_all;
+  const int32_t* dst_all;
+  const int32_t* perm_src_all;
+  const int32_t* rowptr_dst_all;
+  const int32_t* rowptr_src_all;
+  const float* inv_deg_all;
+  const float* x_all;
+  const float* edge_feat_all;
+  const float* target_all;
+  const float* glob_all;
+  const int32_t* system_all;
+  float* x;
+  float* edge_feat;
+  float* target;
+  float* glob;
+  int32_t* system;
+  int32_t* src;
+  int32_t* dst;
+  int32_t* perm_src;
+  int32_t* rowptr_dst;
+  int32_t* rowptr_src;
+  int32_t* graph_ptr;
+  int32_t* node_graph;
+  int32_t* dense_row;
+  float* inv_deg;
+  int32_t* node_row;
+  int32_t* edge_row;
+} DosxCollate;
+int dosx_collate_padded(const DosxCollate* d, dosx_stream_t stream);
+
 /* Periodic neighbour list of C crystals at once (replaces ASE's `neighbor_list("ijS", a, cutoff=r_max,
  * self_interaction=True)` + the edge_vec arithmetic of `utils.py:267-273` in build_data).  `pos [N][3]` Cartesian,
  * `cell [C][3][3]` lattice vectors as rows, crystal c owns atoms [atom_ptr[c], atom_ptr[c+1]) and the ordered atom

@@ -168,3 +168,68 @@ def test_fp32_training_trajectory_tracks_fp64_oracle(H, T, B, steps, every):
     assert hip_loss < 1e-4, hip_loss
     assert early < 1e-4, early
     assert hip_dos < 3.0 * cpu_dos + 2e-5, (hip_dos, cpu_dos)
+
+
+@pytest.mark.parametrize("kind", ["phonon", "edos"])
+def test_collate_into_matches_pad_batch(kind):
+    """loader.DeviceDataset.collate_into (dosx_collate_padded: selection + feature gathers + ghost tail straight into a
+    bucket's static buffers) == pad_batch(collate(...)) on every field and index array the kernels read, bit for bit."""
+    from dostransformer_amd import synth
+    from dostransformer_amd.batch import bucket_sizes, collate, pad_batch
+    from dostransformer_amd.loader import DeviceDataset
+    from dostransformer_amd.train import _Slot, _META_TENSORS
+    cs = synth.phonon_crystals(14, seed=41, dtype=torch.float32) if kind == "phonon" else synth.edos_crystals(14, seed=42, dtype=torch.float32)
+    ds = DeviceDataset(cs, DEV)
+    for sel in ([3, 0, 7], [11], list(range(14)), [5, 5, 2, 13]):
+        idx, N, E, n_max = ds.bucket_dims(sel, n_max=45)
+        n_pad, e_pad = bucket_sizes(N, E, 16, 256)
+        t = ds._f32_tables()
+        slot = _Slot.empty(kind, DEV, len(sel), n_pad, e_pad, n_max, t["x"].shape[1], t["edge"].shape[1], t["target"].shape[1])
+        for v in list(slot.g._fields.values()) + [getattr(slot.g.meta, k) for k in _META_TENSORS]:
+            if torch.is_tensor(v):
+                v.fill_(77)                                  # stale contents of a previous batch must all be overwritten
+        ds.collate_into(slot.g, idx, slot.scratch)
+        ref = pad_batch(collate([cs[i] for i in sel], n_max=45), n_pad, e_pad)
+        torch.cuda.synchronize()
+        for k in slot.fields:
+            a, b = slot.g[k].cpu(), ref[k]
+            assert torch.equal(a.reshape(-1), b.to(a.dtype).reshape(-1)), (k, sel)
+        for k in _META_TENSORS:
+            assert torch.equal(getattr(slot.g.meta, k).cpu(), getattr(ref.meta, k)), (k, sel)
+        assert (slot.g.meta.num_nodes, slot.g.meta.num_edges, slot.g.meta.n_max) == (ref.meta.num_nodes, ref.meta.num_edges, 45)
+
+
+@pytest.mark.parametrize("kind", ["phonon", "edos"])
+def test_step_dataset_is_the_step_on_the_collated_batch(kind):
+    """Trainer.step_dataset(ds, indices) (collate into the bucket + replay) leaves bitwise the parameters of
+    Trainer.step(pad_batch(ds.collate(indices))) — over shuffled epochs that revisit buckets."""
+    from dostransformer_amd import synth
+    from dostransformer_amd.loader import DeviceDataset
+    from dostransformer_amd.train import Trainer
+    if kind == "phonon":
+        mk = lambda: _phonon(32, 1)
+        cs = synth.phonon_crystals(24, seed=43, dtype=torch.float32)
+    else:
+        from dostransformer_amd.embedder_eDOS.DOSTransformer import DOSTransformer
+        mk = lambda: DOSTransformer(3, 1, 200, 41, 2, 32, DEV, 0.0)
+        cs = synth.edos_crystals(24, seed=44, dtype=torch.float32)
+    ds = DeviceDataset(cs, DEV)
+    nmax = max(int(c["x"].shape[0]) for c in cs)
+    torch.manual_seed(5)
+    m_a = mk().to(DEV)
+    m_b = mk()
+    m_b.load_state_dict(copy.deepcopy(m_a.state_dict()))
+    m_b = m_b.to(DEV)
+    ta = Trainer(m_a, lr=1e-3, replay=True, bucket=(64, 1024))
+    tb = Trainer(m_b, lr=1e-3, replay=True, bucket=(64, 1024))
+    rng = np.random.default_rng(0)
+    for epoch in range(3):
+        order = rng.permutation(24)
+        for i in range(0, 24, 6):
+            sel = order[i:i + 6]
+            la = ta.step_dataset(ds, sel, n_max=nmax)
+            lb = tb.step(ds.collate(sel, n_max=nmax))
+            assert float(la) == float(lb), (epoch, i)
+    assert ta.slot_hits > 0 and len(ta._slots) < 12
+    for (k, a), (_, b) in zip(m_a.state_dict().items(), m_b.state_dict().items()):
+        assert torch.equal(a, b), k
