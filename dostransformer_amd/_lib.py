@@ -78,7 +78,7 @@ class Attn(C.Structure):
         ("out", C.c_void_p), ("probs", C.c_void_p), ("qstats", C.c_void_p), ("out_stats", C.c_void_p),
         ("dout", C.c_void_p), ("dx", C.c_void_p), ("dscores", C.c_void_p), ("dkvhat", C.c_void_p),
         ("dkv_accumulate", C.c_int32),
-        ("partials_q", C.c_void_p), ("partials_kv", C.c_void_p), ("dkv_part", C.c_void_p),
+        ("partials_q", C.c_void_p), ("partials_kv", C.c_void_p), ("drop_mask", C.c_void_p), ("dkv_part", C.c_void_p),
     ]
 
 
@@ -179,6 +179,7 @@ _SIGS = {
     "dosx_neighbor_fill": [_P, _P, _P, _P, _I, _L, _D, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "dosx_replay_op": [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "dosx_replay": [C.POINTER(Call), _I, C.POINTER(C.c_int)],
+    "dosx_dropout_mask": [_P, _L, _F, _P, _L, _P],
     "dosx_copy_many": [C.POINTER(CopyJob), _I, _P],
     "dosx_fill": [_P, _F, _L, _P],
     "dosx_embed_rows": [_P, _P, _P, _I, _I, _P],

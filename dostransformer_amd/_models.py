@@ -11,17 +11,35 @@ from . import functional as Fn
 from ._fused import FusedModel
 
 
+def dos_device(P):
+    return P["embeddings.weight"].device
+
+
 class DOSTransformerBase(FusedModel):
     """forward(g) -> (dos_global [B,S], x [N,H], dos_system [B,S])   (`DOSTransformer_phonon.py:66-119`)."""
     _cfg: Fn.ModelCfg
 
     def _check_train_flags(self):
-        if self.training and getattr(self, "_attn_drop", 0.0) > 0.0:
-            raise NotImplementedError("attn_drop > 0 is not implemented in the fused MI355X path "
-                                      "(reference default 0.0, utils.py:40)")
+        pass          # (kept for callers of round 1: attention dropout is implemented now)
 
-    def _program_fwd(self, P, g, m):
-        dos, xL, ctx = Fn.dostransformer_fwd(P, self._cfg, g, m)
+    # ---- attention dropout (`utils.py:40` --attn_drop -> TransformerEncoder(attn_dropout=...), multihead_attention.py:70)
+    def _dropout(self, device, bump: bool):
+        """None in eval mode / p = 0, else (p, seed_dev).  The seed lives in a device scalar so that a recorded program
+        draws fresh masks on every replay; it starts from torch's RNG (follows torch.manual_seed) and is bumped once per
+        forward pass (``bump``: the autograd path; train.Trainer bumps it itself, outside the recorded program)."""
+        p = float(getattr(self, "_attn_drop", 0.0) or 0.0)
+        if not self.training or p <= 0.0:
+            return None
+        seed = getattr(self, "_drop_seed", None)
+        if seed is None or seed.device != device:
+            seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(device)
+            object.__setattr__(self, "_drop_seed", seed)
+        elif bump:
+            seed.add_(1)
+        return p, seed
+
+    def _program_fwd(self, P, g, m, bump_seed: bool = True):
+        dos, xL, ctx = Fn.dostransformer_fwd(P, self._cfg, g, m, drop=self._dropout(dos_device(P), bump_seed))
         B = m.num_graphs
         return dos[:B], xL, dos[B:], (ctx, dos)
 

@@ -346,6 +346,9 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const DosxAttn a) 
   store_scores1(sacc, Ss, g.LDS_, g.NKP, tid);
   __syncthreads();
 
+  float psum[RP];
+#pragma unroll
+  for (int p = 0; p < RP; ++p) psum[p] = 1.f;
   // ---- exact fp32 softmax over the Nk keys (padded atoms included, like the reference) ----
   {
     const float scale = rsqrtf((float)H);
@@ -376,21 +379,43 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const DosxAttn a) 
     }
 #pragma unroll
     for (int p = 0; p < RP; ++p) sum[p] = 1.f / row16_sum(sum[p]);
+    // attention dropout (multihead_attention.py:70: F.dropout on the softmax output): the saved probabilities stay the
+    // un-dropped P (the backward needs them), the P.V product takes P' = P o M, M in {0, 1/(1-p)} read from drop_mask
+    float mk[RP][NJ];
+#pragma unroll
+    for (int p = 0; p < RP; ++p)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) mk[p][jj] = 1.f;
+    if (a.drop_mask) {
+#pragma unroll
+      for (int p = 0; p < RP; ++p) {
+        const int s = min(s0 + row_of(wave, p, lane), Sq - 1);
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+          const int j = q16 + 16 * jj;
+          mk[p][jj] = a.drop_mask[((size_t)bq * Sq + s) * Nk + (j < Nk ? j : 0)];
+        }
+      }
+    }
 #pragma unroll
     for (int p = 0; p < RP; ++p) {
       const int lr = row_of(wave, p, lane), s = s0 + lr;
       float* row = Ss + lr * g.LDS_;
+      float t = 0.f;
 #pragma unroll
       for (int jj = 0; jj < NJ; ++jj) {
         const int j = q16 + 16 * jj;
         if (j >= g.NKP) continue;
         const float pr = v[p][jj] * sum[p];           // 0 beyond Nk
-        row[j] = pr;
+        const float prm = pr * mk[p][jj];
+        row[j] = prm;
+        t += prm;
         if (j < Nk && s < Sq) a.probs[((size_t)bq * Sq + s) * Nk + j] = pr;
       }
       if (NJ * 16 < g.NKP) {
         for (int j = NJ * 16 + q16; j < g.NKP; j += 16) row[j] = 0.f;
       }
+      if (a.drop_mask) psum[p] = row16_sum(t);        // rows of P' no longer sum to 1: P'.(k̂ gamma + beta) = (P'.k̂) gamma + beta sum(P')
     }
   }
   __syncthreads();
@@ -415,7 +440,8 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const DosxAttn a) 
         float4 v = f4zero();
         if (c < H) {
           const float4 r = ld4(Qs + lr * g.LDH + c);
-          v = make_float4(r.x * g0[k].x + b0[k].x, r.y * g0[k].y + b0[k].y, r.z * g0[k].z + b0[k].z, r.w * g0[k].w + b0[k].w);
+          v = make_float4(r.x * g0[k].x + b0[k].x * psum[p], r.y * g0[k].y + b0[k].y * psum[p],
+                          r.z * g0[k].z + b0[k].z * psum[p], r.w * g0[k].w + b0[k].w * psum[p]);
           if (!no_res) v = f4add(v, xr[p][k]);
           if (s < Sq) st4(a.out + ((size_t)s * a.Bq + bq) * H + c, v);
           t += (v.x + v.y) + (v.z + v.w);
@@ -506,6 +532,36 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(const DosxAttn 
       pr[p][jj] = a.probs[((size_t)bq * Sq + s) * Nk + (j < Nk ? j : 0)];
     }
   }
+  // attention dropout: dP = M o dP' with dP' = dO.V^T.  Without a mask the row constant dO.beta0 of dP' cancels in
+  // dS = P o (dP - sum P dP) and is never formed; with a mask it does not (sum_j P_j M_j != 1): cq = dO . beta0
+  float mk[RP][NJ], cq[RP];
+#pragma unroll
+  for (int p = 0; p < RP; ++p) {
+    cq[p] = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) mk[p][jj] = 1.f;
+  }
+  if (a.drop_mask) {
+#pragma unroll
+    for (int p = 0; p < RP; ++p) {
+      const int s = min(s0 + row_of(wave, p, lane), Sq - 1);
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) {
+        const int j = q16 + 16 * jj;
+        mk[p][jj] = a.drop_mask[((size_t)bq * Sq + s) * Nk + (j < Nk ? j : 0)];
+      }
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < KCB; ++k) {
+        const int c = q16 * 4 + 64 * k;
+        if (c < H) {
+          const float4 b0 = ld4(a.beta0 + c);
+          t += (go[p][k].x * b0.x + go[p][k].y * b0.y) + (go[p][k].z * b0.z + go[p][k].w * b0.w);
+        }
+      }
+      cq[p] = row16_sum(t);
+    }
+  }
 #pragma unroll
   for (int p = 0; p < RP; ++p) {
     const int lr = row_of(wave, p, lane);
@@ -539,7 +595,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(const DosxAttn 
 #pragma unroll
       for (int jj = 0; jj < NJ; ++jj) {
         const int j = q16 + 16 * jj;
-        const float t = j < Nk ? row[j] : 0.f;
+        float t = j < Nk ? row[j] : 0.f;
+        if (a.drop_mask) t = (t + cq[p]) * mk[p][jj];
         if (j < Nk) dot[p] += pr[p][jj] * t;
         dp[p][jj] = t;
       }
@@ -556,7 +613,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(const DosxAttn 
         if (j >= g.NKP) continue;
         const float ds = (j < Nk && s < Sq) ? pr[p][jj] * (dp[p][jj] - dot[p]) * scale : 0.f;
         row[j] = ds;
-        if constexpr (PKV) Ps2[lr * g.LDS_ + j] = (j < Nk && s < Sq) ? pr[p][jj] : 0.f;
+        if constexpr (PKV) Ps2[lr * g.LDS_ + j] = (j < Nk && s < Sq) ? pr[p][jj] * mk[p][jj] : 0.f;   // dV takes P' = P o M
         else if (j < Nk && s < Sq) a.dscores[((size_t)bq * Sq + s) * Nk + j] = ds;
       }
       if (NJ * 16 < g.NKP) {
@@ -766,6 +823,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const DosxAttn a) {
         __builtin_amdgcn_make_buffer_rsrc((void*)a.probs, 0, (uint32_t)((size_t)a.Bq * Sq * Nk * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rS =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.dscores, 0, (uint32_t)((size_t)a.Bq * Sq * Nk * 4), 0x00020000);
+    const bool has_mask = a.drop_mask != nullptr;       // attention dropout: dV = (P o M)^T dO
+    const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(has_mask ? a.drop_mask : a.probs), 0, (uint32_t)((size_t)a.Bq * Sq * Nk * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(raw_q ? (const float*)a.dout : a.qstats), 0, (uint32_t)((size_t)Sq * a.Bq * 8), 0x00020000);
     uint32_t vO[KCB], vX[KCB], vP[2 * KG];
@@ -783,7 +843,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const DosxAttn a) {
     const uint32_t vT = (uint32_t)((size_t)row * a.Bq * 8);
     struct Set {
       float4 d[KCB], x[KCB];
-      float pp[2 * KG], ss[2 * KG], mean, rstd;
+      float pp[2 * KG], ss[2 * KG], mm[2 * KG], mean, rstd;
       bool rok;
     };
     Set s0, s1;
@@ -806,6 +866,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const DosxAttn a) {
       for (int u = 0; u < 2 * KG; ++u) {
         q.pp[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rP, vP[u], soP, 0));
         q.ss[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, vP[u], soP, 0));
+        q.mm[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rM, vP[u], soP, 0));
       }
       q.mean = 0.f; q.rstd = 1.f;
       if (!raw_q) {
@@ -834,7 +895,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const DosxAttn a) {
       for (int u = 0; u < 2 * KG; ++u) {
         const int jl = (st & 15) + 16 * u;
         const bool ok = q.rok && (j0 + jl) < Nk;
-        Pc[row * LDP + jl] = ok ? q.pp[u] : 0.f;
+        Pc[row * LDP + jl] = ok ? (has_mask ? q.pp[u] * q.mm[u] : q.pp[u]) : 0.f;
         Sc[row * LDP + jl] = ok ? q.ss[u] : 0.f;
       }
     };

@@ -376,6 +376,34 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   }
 }
 
+// Philox4x32-10 (Salmon et al., SC'11): counter-based, so element i's draw depends only on (seed, stream_id, i)
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ mask, long long n, float p, float keep_scale,
+                                                           const unsigned long long* __restrict__ seed_dev,
+                                                           unsigned long long stream_id) {
+  const unsigned long long seed = *seed_dev;
+  const long long nblk = (n + 3) / 4;
+  for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < nblk; b += (long long)gridDim.x * blockDim.x) {
+    uint32_t c[4] = {(uint32_t)b, (uint32_t)((unsigned long long)b >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long long i = 4 * b + e;
+      if (i < n) mask[i] = ((float)(c[e] >> 8) * (1.f / 16777216.f) >= p) ? keep_scale : 0.f;
+    }
+  }
+}
+
 // Batched device-to-device copy: the jobs travel as a kernel argument (like the slab reduction's); blocks are mapped to
 // (job, 4 KiB slice) through the prefix array.  One launch moves every field + index array of a batch into its shape
 // bucket's static buffers (train._Slot.load: 12 hipMemcpyAsync of ~4.3 us each before).
@@ -569,5 +597,17 @@ extern "C" int dosx_copy_many(const DosxCopyJob* jobs_host, int n_jobs, dosx_str
       DOSX_LAUNCH_CHECK();
     }
   }
+  return 0;
+}
+
+extern "C" int dosx_dropout_mask(float* mask, int64_t n, float p, const unsigned long long* seed_dev, long long stream_id,
+                                 dosx_stream_t stream) {
+  if (n <= 0) return 0;
+  DOSX_CHECK_ARG(mask && seed_dev && p >= 0.f && p < 1.f, "dosx_dropout_mask: bad args (0 <= p < 1)");
+  long long blocks = ((n + 3) / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, to_stream(stream), mask, (long long)n, p,
+                     1.f / (1.f - p), seed_dev, (unsigned long long)stream_id);
+  DOSX_LAUNCH_CHECK();
   return 0;
 }

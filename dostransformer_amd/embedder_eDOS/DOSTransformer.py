@@ -16,7 +16,7 @@ class DOSTransformer(DOSTransformerBase):
         self.promt_token = nn.Embedding(7, n_hidden // 2)
         self.GN_encoder = Encoder(n_atom_feats, n_bond_feats, n_hidden, n_global_feats=n_glob_feats)
         self.stacked_processor = nn.ModuleList(
-            [Processor(EdgeModel(n_hidden), NodeModel(n_hidden)) for _ in range(layers)])
+            [Processor(EdgeModel(n_hidden), NodeModel(n_hidden, aggr="sum")) for _ in range(layers)])
         for name in ("transformer", "transformer_self", "transformer_source"):
             setattr(self, name, TransformerEncoder(embed_dim=n_hidden, num_heads=1, layers=t_layers,
                                                    attn_dropout=attn_drop))

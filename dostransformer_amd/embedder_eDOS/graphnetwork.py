@@ -16,7 +16,7 @@ class Graphnetwork(GraphnetworkBase):
         self.GN_encoder = Encoder(n_atom_feats, n_bond_feats, n_hidden, n_global_feats=n_glob_feats,
                                   prompt_branch=True)
         self.stacked_processor = nn.ModuleList(
-            [Processor(EdgeModel(n_hidden), NodeModel(n_hidden)) for _ in range(layers)])
+            [Processor(EdgeModel(n_hidden), NodeModel(n_hidden, aggr="sum")) for _ in range(layers)])
         self.GN_decoder = Decoder(n_hidden * 2, n_hidden)
         self.device = device
         self.out_layer = nn.Sequential(nn.Linear(n_hidden * 2, n_hidden), nn.LeakyReLU(), nn.Linear(n_hidden, 1))

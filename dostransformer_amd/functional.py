@@ -184,9 +184,14 @@ def _attn_desc(Sq, Bq, Nk, Bk, H, qs, qb, x, kvhat, gam, bet) -> Attn:
     return a
 
 
+DROP_MASK_LOG: Optional[list] = None      # tests: set to a list to receive (prefix, layer, mask tensor) of every drawn mask
+
+
 def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int, qb: int, kvhat: torch.Tensor,
-                Nk: int, Bk: int, H: int, T: int, final_ln: bool = True):
-    """x: query rows (row (s,bq) at (s*qs + bq*qb)); kvhat: [Nk*Bk, H] normalised keys (stale across layers)."""
+                Nk: int, Bk: int, H: int, T: int, final_ln: bool = True, drop=None):
+    """x: query rows (row (s,bq) at (s*qs + bq*qb)); kvhat: [Nk*Bk, H] normalised keys (stale across layers).
+    drop: None or (p, seed_dev, stream_base): attention dropout in training mode (multihead_attention.py:70) - every
+    layer draws its own [Bq,Sq,Nk] multiplier mask (ops.dropout_mask) that the backward re-uses."""
     dev = kvhat.device
     rows = Sq * Bq
     lay = []
@@ -200,6 +205,13 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
         st1 = _empty(dev, rows, 2)
         a = _attn_desc(Sq, Bq, Nk, Bk, H, qs, qb, x, kvhat, g0, b0)
         a.out, a.probs, a.qstats, a.out_stats = x1.data_ptr(), probs.data_ptr(), qstats.data_ptr(), st1.data_ptr()
+        mask = None
+        if drop is not None and drop[0] > 0.0:
+            mask = _empty(dev, Bq, Sq, Nk)
+            ops.dropout_mask(mask, drop[0], drop[1], drop[2] + t)
+            a.drop_mask = mask.data_ptr()
+            if DROP_MASK_LOG is not None:
+                DROP_MASK_LOG.append((pre, t, mask))
         ops.attention_fwd(a)
         h = _empty(dev, rows, 4 * H)
         x2 = _empty(dev, rows, H)
@@ -218,7 +230,7 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
                      pro_gamma=P[lp + ".layer_norms.1.weight"], pro_beta=P[lp + ".layer_norms.1.bias"], pro_stats=st1,
                      bias=P[lp + ".fc1.bias"], act=ACT_RELU)
             ops.gemm(rows, H, [seg(h)], P[lp + ".fc2.weight"], x2, bias=P[lp + ".fc2.bias"], res=x1)
-        lay.append((x, qs, qb, x1, probs, qstats, st1, h))
+        lay.append((x, qs, qb, x1, probs, qstats, st1, h, mask))
         x, qs, qb = x2, Bq, 1
     fin = None
     if final_ln and fin_fused is not None:
@@ -257,7 +269,7 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: torch.Tensor, dkvhat: t
     nqt, nkt = (Sq + 31) // 32, (Nk + 31) // 32
     for t in reversed(range(T)):
         lp = f"{pre}.layers.{t}"
-        x_in, qs, qb, x1, probs, qstats, st1, h = lay[t]
+        x_in, qs, qb, x1, probs, qstats, st1, h, mask = lay[t]
         g1, b1 = P[lp + ".layer_norms.1.weight"], P[lp + ".layer_norms.1.bias"]
         g0, b0 = P[lp + ".layer_norms.0.weight"], P[lp + ".layer_norms.0.bias"]
         # fc2
@@ -299,6 +311,7 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: torch.Tensor, dkvhat: t
             a.dout, a.dx, a.dkvhat, a.dkv_accumulate = dx1.data_ptr(), dxin.data_ptr(), dkvhat.data_ptr(), acc
             a.dscores = dsc.data_ptr() if dsc is not None else None
             a.dkv_part = kvp.data_ptr() if kvp is not None else None
+            a.drop_mask = mask.data_ptr() if mask is not None else None
             a.partials_q = part.data_ptr()
             a.partials_kv = part.data_ptr() + 4 * Bq * nqt * 2 * H
             a.flags = flags
@@ -307,7 +320,7 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: torch.Tensor, dkvhat: t
         # consumers at the very end) on the side stream, in layer order so dkvhat accumulates in order
         ops.attention_bwd(desc(8))          # DOSX_ATTN_BWD_SKIP_DKV
         a2 = desc(4)                        # DOSX_ATTN_BWD_SKIP_DQ
-        sink.on_side(lambda a2=a2: ops.attention_bwd(a2), (dx1, dxin) + ((dsc,) if dsc is not None else ()))
+        sink.on_side(lambda a2=a2: ops.attention_bwd(a2), (dx1, dxin) + tuple(t_ for t_ in (dsc, mask) if t_ is not None))
         sink.add(part, 0, G[lp + ".layer_norms.0.weight"], npart, 2 * H, H)
         sink.add(part, H, G[lp + ".layer_norms.0.bias"], npart, 2 * H, H)
         dx = dxin
@@ -406,9 +419,11 @@ def decoder_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, segs: SegList
     return seg(dcat, width=H, col=0) if K == 2 * H else None
 
 
-def dostransformer_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta):
+def dostransformer_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta, drop=None):
     """Forward of DOSTransformer_phonon / DOSTransformer (DOSTransformer_phonon.py:66-119,
-    DOSTransformer.py:45-93).  Returns (dos [2B,S] : rows [0,B) global, [B,2B) system; x_L; ctx)."""
+    DOSTransformer.py:45-93).  Returns (dos [2B,S] : rows [0,B) global, [B,2B) system; x_L; ctx).
+    drop: None (eval mode / attn_drop 0) or (p, seed_dev): attention dropout of the three encoders."""
+    dr = (lambda base: None) if drop is None else (lambda base: (drop[0], drop[1], base))
     H, S, T, B, N = cfg.H, cfg.S, cfg.T, m.num_graphs, m.num_nodes
     nmax = m.n_max
     dev = P["embeddings.weight"].device
@@ -430,7 +445,7 @@ def dostransformer_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta):
         box["prow"] = _empty(dev, B, hp)
         ops.embed_rows(P[cfg.prompt_key], sysidx, box["prow"], B, hp)
     side.on_side(_decoder_branch)
-    E1, c1 = encoder_fwd(P, "transformer", emb, S, B, 1, 0, kvhat, nmax, B, H, T)
+    E1, c1 = encoder_fwd(P, "transformer", emb, S, B, 1, 0, kvhat, nmax, B, H, T, drop=dr(0))
     side.join()
     graph, dec_segs, prow = box["graph"], box["segs"], box["prow"]
     dosin = _empty(dev, S * 2 * B, H)
@@ -446,8 +461,8 @@ def dostransformer_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta):
     kvs = _empty(dev, S * 2 * B, H)
     rstd_s = _empty(dev, S * 2 * B)
     ops.rownorm(dosin, kvs, rstd_s, S * 2 * B, H)
-    hs, c2 = encoder_fwd(P, "transformer_self", dosin, S, 2 * B, 2 * B, 1, kvs, S, 2 * B, H, T)
-    hsrc, c3 = encoder_fwd(P, "transformer_source", hs, S, 2 * B, 2 * B, 1, kvhat, nmax, B, H, T, final_ln=False)
+    hs, c2 = encoder_fwd(P, "transformer_self", dosin, S, 2 * B, 2 * B, 1, kvs, S, 2 * B, H, T, drop=dr(64))
+    hsrc, c3 = encoder_fwd(P, "transformer_source", hs, S, 2 * B, 2 * B, 1, kvhat, nmax, B, H, T, final_ln=False, drop=dr(128))
     xhat_f = _empty(dev, S * 2 * B, H)
     rstd_f = _empty(dev, S * 2 * B)
     dos = _empty(dev, 2 * B, S)

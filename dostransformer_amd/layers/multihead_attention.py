@@ -19,7 +19,7 @@ RAW_Q, NO_RESIDUAL = 1, 2
 
 class _BareAttention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, kv):
+    def forward(ctx, q, kv, mask=None):
         sq, b, h = q.shape
         nk = kv.shape[0]
         dev = q.device
@@ -34,7 +34,9 @@ class _BareAttention(torch.autograd.Function):
         a.q_stride_s, a.q_stride_b, a.flags = b, 1, RAW_Q | NO_RESIDUAL
         a.x, a.kvhat, a.gamma0, a.beta0 = q2.data_ptr(), kv2.data_ptr(), ones.data_ptr(), zeros.data_ptr()
         a.out, a.probs = out.data_ptr(), probs.data_ptr()
+        a.drop_mask = mask.data_ptr() if mask is not None else None
         ops.attention_fwd(a)
+        ctx.mask = mask
         ctx.save_for_backward(q2, kv2, probs, ones, zeros)
         ctx.dims = (sq, b, nk, h)
         return out.reshape(sq, b, h)
@@ -59,8 +61,9 @@ class _BareAttention(torch.autograd.Function):
             dkv.data_ptr(), 1
         a.partials_q = part.data_ptr()
         a.partials_kv = part.data_ptr() + 4 * b * nqt * 2 * h
+        a.drop_mask = ctx.mask.data_ptr() if ctx.mask is not None else None
         ops.attention_bwd(a)
-        return dq.reshape(sq, b, h), dkv.reshape(nk, b, h)
+        return dq.reshape(sq, b, h), dkv.reshape(nk, b, h), None
 
 
 class MultiheadAttention(nn.Module):
@@ -102,11 +105,19 @@ class MultiheadAttention(nn.Module):
         assert embed_dim == self.embed_dim
         assert list(query.size()) == [tgt_len, bsz, embed_dim]
         assert key.size() == value.size()
-        if self.training and self.attn_dropout > 0.0:
-            raise NotImplementedError("attention dropout > 0 is not implemented in the fused MI355X path "
-                                      "(the reference default is 0.0, utils.py:40)")
         if key is not value and not (key.data_ptr() == value.data_ptr() and key.stride() == value.stride()):
             raise NotImplementedError("the fused kernel shares K and V (every reference call site passes the "
                                       "same tensor, DOSTransformer_phonon.py:88,97,99)")
-        out = _BareAttention.apply(query.float(), key.float())
+        mask = None
+        if self.training and self.attn_dropout > 0.0:          # F.dropout(attn_weights, p, training) (`:70`)
+            seed = getattr(self, "_drop_seed", None)
+            if seed is None or seed.device != query.device:
+                seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(query.device)
+                object.__setattr__(self, "_drop_seed", seed)
+            else:
+                seed.add_(1)
+            mask = torch.empty(bsz, tgt_len, key.shape[0], device=query.device, dtype=torch.float32)
+            ops.dropout_mask(mask, float(self.attn_dropout), seed, 0)
+            self.last_drop_mask = mask
+        out = _BareAttention.apply(query.float(), key.float(), mask)
         return out.to(query.dtype)

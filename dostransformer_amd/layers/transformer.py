@@ -59,7 +59,8 @@ class _EncoderFn(torch.autograd.Function):
         kvhat = torch.empty(nk * b, h, device=dev)
         rstd = torch.empty(nk * b, device=dev)
         ops.rownorm(src, kvhat, rstd, nk * b, h)
-        y, c = Fn.encoder_fwd(P, "enc", x2, sq, b, b, 1, kvhat, nk, b, h, len(enc.layers), final_ln=not skip_final)
+        y, c = Fn.encoder_fwd(P, "enc", x2, sq, b, b, 1, kvhat, nk, b, h, len(enc.layers), final_ln=not skip_final,
+                              drop=enc._dropout(dev))
         ctx.c, ctx.P, ctx.names, ctx.params = c, P, names, params
         ctx.kv = (kvhat, rstd, nk, self_attn)
         ctx.dims = (sq, b, h)
@@ -108,10 +109,29 @@ class TransformerEncoder(nn.Module):
             self.layer_norm = LayerNorm(embed_dim)
 
     def _check_dropouts(self):
-        if self.training and any(p > 0.0 for p in (self.dropout, self.attn_dropout) +
+        """attn_dropout (the only one a reference call site sets: DOSTransformer*.py:27-38 via --attn_drop) is implemented
+        in the attention kernels.  relu / res dropout sit inside the fused FFN / residual epilogues and embed dropout
+        draws DIFFERENT masks for keys and values (transformer.py:61-68), i.e. K != V, which the K == V kernels cannot
+        express: those three raise instead of being silently ignored."""
+        if self.training and any(p > 0.0 for p in (self.dropout,) +
                                  tuple(x for l in self.layers for x in (l.relu_dropout, l.res_dropout))):
-            raise NotImplementedError("dropout > 0 is not implemented in the fused MI355X path "
-                                      "(all reference defaults are 0.0: transformer.py:22-23, utils.py:40)")
+            raise NotImplementedError("relu / res / embed dropout > 0 is not implemented in the fused MI355X path "
+                                      "(no reference call site sets them: DOSTransformer_phonon.py:27-38; defaults "
+                                      "transformer.py:22-23); attn_dropout is supported")
+
+    def _dropout(self, device):
+        """None (eval / p = 0) or (p, seed_dev, stream_base) for Fn.encoder_fwd; the seed starts from torch's RNG and is
+        bumped once per forward call."""
+        p = float(self.attn_dropout or 0.0)
+        if not self.training or p <= 0.0:
+            return None
+        seed = getattr(self, "_drop_seed", None)
+        if seed is None or seed.device != device:
+            seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(device)
+            object.__setattr__(self, "_drop_seed", seed)
+        else:
+            seed.add_(1)
+        return p, seed, 0
 
     def forward(self, x_in, x_in_k=None, x_in_v=None, mask=None, _skip_final_ln=False):
         if x_in_k is None or x_in_v is None:

@@ -658,6 +658,13 @@ def adamw(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1
           w=lambda: ("adamw", "adamw_kernel", "hbm", 28.0 * n))
 
 
+def dropout_mask(mask: torch.Tensor, p: float, seed_dev: torch.Tensor, stream_id: int) -> None:
+    """mask <- {0, 1/(1-p)} multipliers (include/dosx.h: dosx_dropout_mask); seed_dev: 1-element int64 device tensor."""
+    assert mask.dtype == torch.float32 and mask.is_contiguous() and seed_dev.dtype == torch.int64 and seed_dev.is_cuda
+    _call("dosx_dropout_mask", mask.data_ptr(), mask.numel(), float(p), seed_dev.data_ptr(), int(stream_id), _stream(),
+          w=lambda: ("dropout_mask", "dropout_mask_kernel", "hbm", 4.0 * mask.numel()))
+
+
 def copy_many(pairs) -> None:
     """dst.copy_(src) for every (dst, src) pair of same-sized 4-byte-element contiguous device tensors, in one launch."""
     jobs = []

@@ -54,7 +54,9 @@ class Predictor:
 
     def __call__(self, g: CrystalBatch):
         model = self.model
-        model._check_train_flags()
+        if model.training and getattr(model, "_attn_drop", 0.0) > 0.0:
+            raise RuntimeError("Predictor replays an inference program: call model.eval() first (attention dropout is "
+                               "active in training mode)")
         dev = model._module_device()
         if dev.type != "cuda":
             raise RuntimeError("Predictor runs only on an MI355X through libdosx (no CPU fallback)")

@@ -157,7 +157,7 @@ class Trainer:
         """forward program (+ the phonon SSE pair).  Returns the state part B needs."""
         model, dev, cfg = self.model, fp.flat.device, self.model._cfg
         B, S = m.num_graphs, cfg.S
-        dg, xL, ds, (ctx, dos) = model._program_fwd(fp.P, g, m)
+        dg, xL, ds, (ctx, dos) = model._program_fwd(fp.P, g, m, bump_seed=False)     # (step() bumps the dropout seed)
         st = {"ctx": ctx, "dos": dos, "out": (dg, xL, ds), "B": B, "S": S}
         if self.kind == "phonon":
             st["y"] = Fn._f32(g.phdos).reshape(B, S)
@@ -399,6 +399,7 @@ class Trainer:
             i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)
             slot.scratch = {"small": i32(3 * B + 2), "node_row": i32(n_pad), "edge_row": i32(e_pad)}
         ds.collate_into(slot.g, idx, slot.scratch)
+        self._bump_dropout_seed()
         loss = self._run_slot(slot, fp, ng, fresh)
         self.optimizer_step()
         return loss
@@ -446,7 +447,15 @@ class Trainer:
         self.lr, self.eps, self.wd = h.get("lr", self.lr), h.get("eps", self.eps), h.get("weight_decay", self.wd)
         self.betas, self.beta = tuple(h.get("betas", self.betas)), h.get("beta", self.beta)
 
+    def _bump_dropout_seed(self) -> None:
+        """Attention dropout draws its masks from a device-resident seed inside the (possibly recorded) program; one bump
+        per step, issued here so that it is never part of a recording."""
+        seed = getattr(self.model, "_drop_seed", None)
+        if seed is not None and self.model.training and getattr(self.model, "_attn_drop", 0.0) > 0.0:
+            seed.add_(1)
+
     def step(self, g, n_global: Optional[int] = None) -> torch.Tensor:
+        self._bump_dropout_seed()
         loss = self._graph_step(g, n_global) if (self.graph or self.replay) else self.forward_backward(g, n_global)
         self.optimizer_step()
         return loss

@@ -249,6 +249,9 @@ typedef struct DosxAttn {
   int32_t dkv_accumulate;
   float* partials_q;   /* [Bq * ceil(Sq/32)] rows of [dgamma(H) | dbeta(H)] */
   float* partials_kv;  /* [Bk * ceil(Nk/32)] rows of [dgamma(H) | dbeta(H)] */
+  const float* drop_mask; /* optional [Bq, Sq, Nk]: attention dropout (F.dropout on the softmax output,
+                          layers/multihead_attention.py:70) as an explicit multiplier M in {0, 1/(1-p)} (dosx_dropout_mask);
+                          `probs` stays the un-dropped softmax.  NULL = no dropout (eval mode / p = 0) */
   float* dkv_part;     /* optional scratch [Bq * ceil(Sq/32), Nk, H]: with it (and Nk <= 64) the dq kernel also leaves each
                           query tile's share of dK + dV there and the dkv half is a small reduction over those partials
                           (no dscores round trip: dscores may then be NULL); without it the streamed dkv kernel runs */
@@ -453,6 +456,12 @@ int dosx_replay_op(const char* name, int* n_int, int* n_float);
 int dosx_replay(const DosxCall* calls, int n, int* failed_index);
 
 /* misc */
+/* Dropout multiplier: mask[i] = u_i >= p ? 1/(1-p) : 0 with u_i uniform in [0,1) from Philox4x32-10 (counter = (i/4, stream_id),
+ * key = *seed_dev, word i%4 of the block; the top 24 bits make u).  The seed is read FROM DEVICE MEMORY so a recorded /
+ * graph-captured program draws fresh masks on every replay: the caller bumps *seed_dev between steps.  stream_id
+ * separates the masks of different layers / sites drawn under one seed. */
+int dosx_dropout_mask(float* mask, int64_t n, float p, const unsigned long long* seed_dev, long long stream_id,
+                      dosx_stream_t stream);
 /* Batched device-to-device copy in ONE launch: dst[0:dwords] = src[0:dwords] (32-bit words, 4-byte aligned, any mix of
  * fp32 / int32 buffers).  jobs: HOST array, copied into kernel arguments (no device table, graph-capturable).
  * train._Slot.load moves a batch's fields and CSR arrays into the static buffers of its shape bucket with it. */

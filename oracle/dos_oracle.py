@@ -140,32 +140,37 @@ def gnn_stack(p: Params, x, edge_index, e, n_layers: int, mean: bool):
 # a9-a11: attention / transformer encoder       layers/multihead_attention.py:49-76,
 #                                               layers/transformer.py:46-79,120-157
 # --------------------------------------------------------------------------------------
-def multihead_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+def multihead_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, drop_mask=None) -> torch.Tensor:
     """(seq,batch,dim) in/out. No projections, no mask, no head split; softmax in fp32
-    (`multihead_attention.py:68-74`); scaling = embed_dim**-0.5 (`:20`)."""
+    (`multihead_attention.py:68-74`); scaling = embed_dim**-0.5 (`:20`).
+    drop_mask [batch, tgt, src]: `F.dropout(attn_weights, p, training)` (`:70`) with the Bernoulli draw made explicit - the
+    multiplier M in {0, 1/(1-p)} (None = eval mode / p = 0)."""
     dim = q.shape[2]
     w = torch.bmm(q.transpose(0, 1), k.transpose(0, 1).transpose(1, 2)) * (dim ** -0.5)
     w = F.softmax(w.float(), dim=-1).type_as(w)
+    if drop_mask is not None:
+        w = w * drop_mask.to(w.dtype)
     return torch.bmm(w, v.transpose(0, 1)).transpose(0, 1)
 
 
-def encoder_layer(p: Params, prefix: str, x, x_k, x_v):
+def encoder_layer(p: Params, prefix: str, x, x_k, x_v, drop_mask=None):
     """Pre-norm block; layer_norms.0 is shared by q, k and v (`transformer.py:131-134`)."""
     r = x
     q = _layer_norm(p, prefix + ".layer_norms.0", x)
     k = _layer_norm(p, prefix + ".layer_norms.0", x_k)
     v = _layer_norm(p, prefix + ".layer_norms.0", x_v)
-    x = r + multihead_attention(q, k, v)
+    x = r + multihead_attention(q, k, v, drop_mask)
     r = x
     y = _layer_norm(p, prefix + ".layer_norms.1", x)
     y = _linear(p, prefix + ".fc2", F.relu(_linear(p, prefix + ".fc1", y)))
     return r + y
 
 
-def transformer_encoder(p: Params, prefix: str, x, x_k, x_v, n_layers: int):
-    """x_k / x_v are NOT updated between layers (`transformer.py:72-73`)."""
+def transformer_encoder(p: Params, prefix: str, x, x_k, x_v, n_layers: int, drop_masks=None):
+    """x_k / x_v are NOT updated between layers (`transformer.py:72-73`).  drop_masks: one attention-dropout multiplier
+    per layer (training mode with attn_dropout > 0), see multihead_attention."""
     for t in range(n_layers):
-        x = encoder_layer(p, f"{prefix}.layers.{t}", x, x_k, x_v)
+        x = encoder_layer(p, f"{prefix}.layers.{t}", x, x_k, x_v, None if drop_masks is None else drop_masks[t])
     return _layer_norm(p, prefix + ".layer_norm", x)
 
 
@@ -180,22 +185,26 @@ def _batch_info(g) -> Tuple[int, int]:
     return nb, n_max
 
 
-def _heads(p: Params, energies, graph, x_dense, prompt_rows, n_t: int):
+def _heads(p: Params, energies, graph, x_dense, prompt_rows, n_t: int, drop_masks=None):
     """Shared tail of both DOSTransformer variants (`DOSTransformer_phonon.py:93-117`,
-    `DOSTransformer.py:68-91`): global branch, then prompt ('system') branch."""
+    `DOSTransformer.py:68-91`): global branch, then prompt ('system') branch.
+    drop_masks (training mode, attn_drop > 0): {"transformer_self" / "transformer_source": [per layer [2B, S, Nk]]} with
+    the global branch's draws in rows [0,B) and the system branch's in [B,2B)."""
     outs = []
+    nb = energies.shape[1]
+    dm = lambda key, branch: None if drop_masks is None else [m[branch * nb:(branch + 1) * nb] for m in drop_masks[key]]
     for branch in (0, 1):
         if branch == 0:
             h = F.leaky_relu(_linear(p, "fc", torch.cat([energies, graph], 2)))
         else:
             h = F.leaky_relu(_linear(p, "fc_prompt", torch.cat([energies, graph, prompt_rows], 2)))
-        h = transformer_encoder(p, "transformer_self", h, h, h, n_t)
-        h = transformer_encoder(p, "transformer_source", h, x_dense, x_dense, n_t)
+        h = transformer_encoder(p, "transformer_self", h, h, h, n_t, dm("transformer_self", branch))
+        h = transformer_encoder(p, "transformer_source", h, x_dense, x_dense, n_t, dm("transformer_source", branch))
         outs.append(_linear(p, "out_layer", h).squeeze(2).T)
     return outs[0], outs[1]
 
 
-def dostransformer_phonon_forward(p: Params, g, n_layers: int, n_t: int):
+def dostransformer_phonon_forward(p: Params, g, n_layers: int, n_t: int, drop_masks=None):
     """`embedder_phDOS/DOSTransformer_phonon.py:66-119` -> (dos_global [B,51], x [N,H], dos_system [B,51])."""
     nb, n_max = _batch_info(g)
     s = p["embeddings.weight"].shape[0]
@@ -206,15 +215,16 @@ def dostransformer_phonon_forward(p: Params, g, n_layers: int, n_t: int):
     energies = energies[:, None, :].expand(s, nb, energies.shape[1])   # :143
     x, e = gnn_stack(p, x, g.edge_index, e, n_layers, mean=True)       # :81-84
     x_dense = to_dense_batch(x, g.batch, nb, n_max).transpose(0, 1)    # :86-87
-    energies = transformer_encoder(p, "transformer", energies, x_dense, x_dense, n_t)   # :88
+    energies = transformer_encoder(p, "transformer", energies, x_dense, x_dense, n_t,
+                                   None if drop_masks is None else drop_masks["transformer"])   # :88
     graph = _linear(p, "GN_decoder.mlp.0", scatter_sum(x, g.batch, nb))               # :90, :180-181
     graph = graph[None].expand(s, nb, graph.shape[1])                  # :91
     prompt_rows = p["prompt_token.weight"][g.system][None].expand(s, nb, -1)            # :105
-    dos_global, dos_system = _heads(p, energies, graph, x_dense, prompt_rows, n_t)
+    dos_global, dos_system = _heads(p, energies, graph, x_dense, prompt_rows, n_t, drop_masks)
     return dos_global, x, dos_system
 
 
-def dostransformer_forward(p: Params, g, n_layers: int, n_t: int):
+def dostransformer_forward(p: Params, g, n_layers: int, n_t: int, drop_masks=None):
     """`embedder_eDOS/DOSTransformer.py:45-93` (note the upstream spelling ``promt_token``)."""
     nb, n_max = _batch_info(g)
     s = p["embeddings.weight"].shape[0]
@@ -225,11 +235,12 @@ def dostransformer_forward(p: Params, g, n_layers: int, n_t: int):
     u = _mlp_prelu(p, "GN_encoder.global_encoder", g.glob.reshape(-1, 2))   # :119-120
     x, e = gnn_stack(p, x, g.edge_index, e, n_layers, mean=False)      # :56-59, sum aggregation :187
     x_dense = to_dense_batch(x, g.batch, nb, n_max).transpose(0, 1)    # :61-62
-    energies = transformer_encoder(p, "transformer", energies, x_dense, x_dense, n_t)   # :63
+    energies = transformer_encoder(p, "transformer", energies, x_dense, x_dense, n_t,
+                                   None if drop_masks is None else drop_masks["transformer"])   # :63
     graph = _linear(p, "GN_decoder.mlp.0", torch.cat([u, scatter_sum(x, g.batch, nb)], 1))  # :158-159
     graph = graph[None].expand(s, nb, graph.shape[1])                  # :65 (.repeat)
     prompt_rows = p["promt_token.weight"][g.system][None].expand(s, nb, -1)             # :79
-    dos_global, dos_system = _heads(p, energies, graph, x_dense, prompt_rows, n_t)
+    dos_global, dos_system = _heads(p, energies, graph, x_dense, prompt_rows, n_t, drop_masks)
     return dos_global, x, dos_system
 
 

@@ -434,8 +434,9 @@ def test_layernorm_rowdot():
     assert err(dx, x.grad) < 5e-5 and err(ps[:H], gam.grad) < 5e-5 and err(ps[H:], bet.grad) < 5e-5
 
 
-def _attn_ref(x, kvhat, gam, bet, Sq, Bq, Nk, Bk, H, qs, qb):
-    """float64 torch reference of the attention block (same math as oracle.encoder_layer's first half)."""
+def _attn_ref(x, kvhat, gam, bet, Sq, Bq, Nk, Bk, H, qs, qb, mask=None):
+    """float64 torch reference of the attention block (same math as oracle.encoder_layer's first half); mask: the
+    attention-dropout multiplier applied to the softmax output (multihead_attention.py:70)."""
     rows = (torch.arange(Sq, device=DEV)[:, None] * qs + torch.arange(Bq, device=DEV)[None, :] * qb).reshape(-1)
     xq = x[rows].reshape(Sq, Bq, H)
     q = F.layer_norm(xq, (H,), gam, bet, 1e-5)
@@ -443,7 +444,8 @@ def _attn_ref(x, kvhat, gam, bet, Sq, Bq, Nk, Bk, H, qs, qb):
     k = k[:, torch.arange(Bq, device=DEV) % Bk]
     w = torch.bmm(q.transpose(0, 1), k.permute(1, 2, 0)) * H ** -0.5
     p = torch.softmax(w, -1)
-    out = xq + torch.bmm(p, k.transpose(0, 1)).transpose(0, 1)
+    pd = p if mask is None else p * mask
+    out = xq + torch.bmm(pd, k.transpose(0, 1)).transpose(0, 1)
     return out.reshape(Sq * Bq, H), p
 
 
@@ -451,8 +453,9 @@ def _attn_ref(x, kvhat, gam, bet, Sq, Bq, Nk, Bk, H, qs, qb):
                                                    (201, 2, 41, 2, 256, False), (70, 3, 70, 3, 128, False),
                                                    (51, 5, 7, 5, 128, True), (201, 2, 201, 2, 256, False),
                                                    (7, 3, 5, 3, 16, False)])
+@pytest.mark.parametrize("drop", [0.0, 0.35])
 @pytest.mark.parametrize("pkv", [False, True])
-def test_attention_fwd_bwd(Sq, Bq, Nk, Bk, H, bcast, pkv):
+def test_attention_fwd_bwd(Sq, Bq, Nk, Bk, H, bcast, pkv, drop):
     """pkv: the dq kernel also produces the per-tile dK + dV partials and a reduction kernel finishes the key gradient
     (Nk <= 64; DosxAttn.dkv_part) instead of the streamed dkv kernel behind the dscores round trip."""
     from dostransformer_amd import _lib
@@ -468,7 +471,10 @@ def test_attention_fwd_bwd(Sq, Bq, Nk, Bk, H, bcast, pkv):
     kv = kv.double().requires_grad_(True)
     gam = rnd(H, seed=3).double().requires_grad_(True)
     bet = (0.3 * rnd(H, seed=4)).double().requires_grad_(True)
-    ref, pref = _attn_ref(x, kv, gam, bet, Sq, Bq, Nk, Bk, H, qs, qb)
+    mask = None
+    if drop > 0:          # an arbitrary Bernoulli multiplier: the kernels take the mask as an operand
+        mask = (torch.rand(Bq, Sq, Nk, generator=torch.Generator().manual_seed(9)) >= drop).float().to(DEV) / (1 - drop)
+    ref, pref = _attn_ref(x, kv, gam, bet, Sq, Bq, Nk, Bk, H, qs, qb, None if mask is None else mask.double())
     dout = rnd(Sq * Bq, H, seed=5)
     ref.backward(dout.double())
     f = lambda t: t.detach().float().contiguous()
@@ -481,6 +487,7 @@ def test_attention_fwd_bwd(Sq, Bq, Nk, Bk, H, bcast, pkv):
     ostats = torch.empty(Sq * Bq, 2, device=DEV)
     a.x, a.kvhat, a.gamma0, a.beta0 = xf.data_ptr(), kvf.data_ptr(), gf.data_ptr(), bf.data_ptr()
     a.out, a.probs, a.qstats, a.out_stats = out.data_ptr(), probs.data_ptr(), qstats.data_ptr(), ostats.data_ptr()
+    a.drop_mask = mask.data_ptr() if mask is not None else None
     o.attention_fwd(a)
     assert err(out, ref) < 3e-5
     assert err(probs, pref) < 3e-5

@@ -233,3 +233,243 @@ def test_step_dataset_is_the_step_on_the_collated_batch(kind):
     assert ta.slot_hits > 0 and len(ta._slots) < 12
     for (k, a), (_, b) in zip(m_a.state_dict().items(), m_b.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+# ---- attention dropout (VERDICT r1 missing #1; reference: multihead_attention.py:70, --attn_drop utils.py:40) -----------
+def _philox_mask_numpy(n, p, seed, stream_id):
+    """numpy restatement of dosx_dropout_mask: Philox4x32-10, counter (i/4, stream_id), key = seed, word i%4."""
+    nblk = (n + 3) // 4
+    b = np.arange(nblk, dtype=np.uint64)
+    c = [(b & np.uint64(0xFFFFFFFF)).astype(np.uint64), (b >> np.uint64(32)).astype(np.uint64),
+         np.full(nblk, stream_id & 0xFFFFFFFF, np.uint64), np.full(nblk, (stream_id >> 32) & 0xFFFFFFFF, np.uint64)]
+    k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    M0, M1, W0, W1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & MASK, p1 >> np.uint64(32), p1 & MASK
+        c = [hi1 ^ c[1] ^ k0, lo1, hi0 ^ c[3] ^ k1, lo0]
+        k0, k1 = (k0 + W0) & MASK, (k1 + W1) & MASK
+    words = np.stack(c, 1).reshape(-1)[:n]
+    u = (words >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    return np.where(u >= np.float32(p), np.float32(1.0 / (1.0 - p)), np.float32(0.0)).astype(np.float32)
+
+
+def test_dropout_mask_kernel():
+    from dostransformer_amd import ops
+    n, p = 100003, 0.3
+    seed = torch.tensor([0x1234567 + (5 << 40)], dtype=torch.int64, device=DEV)
+    m = torch.empty(n, device=DEV)
+    ops.dropout_mask(m, p, seed, 7)
+    ref = _philox_mask_numpy(n, p, int(seed.item()), 7)
+    assert np.array_equal(m.cpu().numpy(), ref)
+    keep = float((m > 0).float().mean())
+    assert abs(keep - (1 - p)) < 4 * (p * (1 - p) / n) ** 0.5 + 1e-3          # keep rate
+    assert abs(float(m.mean()) - 1.0) < 0.01                                    # unbiased multiplier
+    m2 = torch.empty(n, device=DEV)
+    ops.dropout_mask(m2, p, seed, 7)
+    assert torch.equal(m, m2)                                                   # same (seed, stream) -> same mask
+    ops.dropout_mask(m2, p, seed, 8)
+    assert not torch.equal(m, m2)                                               # another stream id -> another mask
+    seed.add_(1)
+    ops.dropout_mask(m2, p, seed, 7)
+    assert not torch.equal(m, m2)                                               # bumped seed -> another mask
+    z = torch.empty(1000, device=DEV)
+    ops.dropout_mask(z, 0.0, seed, 0)
+    assert bool((z == 1).all())
+
+
+@pytest.mark.parametrize("mode", ["cross", "self"])
+def test_transformer_encoder_attention_dropout_matches_oracle(mode):
+    """TransformerEncoder(attn_dropout=0.3) in training mode: outputs and gradients equal the oracle's with the SAME
+    Bernoulli draws (the masks the kernels used, captured per layer); eval mode ignores dropout; p = 0 is untouched."""
+    from oracle import dos_oracle as O
+    from dostransformer_amd import functional as Fn
+    from dostransformer_amd.layers import TransformerEncoder
+    torch.manual_seed(0)
+    Hh, S, Bq, Nk, T = 32, 51, 5, 9, 2
+    enc = TransformerEncoder(embed_dim=Hh, num_heads=1, layers=T, attn_dropout=0.3).to(DEV)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(S, Bq, Hh, generator=gen).to(DEV).requires_grad_(True)
+    kv = torch.randn(Nk, Bq, Hh, generator=gen).to(DEV).requires_grad_(True)
+    w = torch.randn(S, Bq, Hh, generator=gen).to(DEV)
+    Fn.DROP_MASK_LOG = []
+    try:
+        enc.train()
+        y = enc(x, kv, kv) if mode == "cross" else enc(x, x, x)
+        masks = [m.clone() for _, _, m in Fn.DROP_MASK_LOG]
+    finally:
+        Fn.DROP_MASK_LOG = None
+    assert len(masks) == T and all(0.5 < float((m > 0).float().mean()) < 0.9 for m in masks)
+    (y * w).sum().backward()
+    p64 = {"e." + k: v.detach().double().cpu() for k, v in enc.state_dict().items() if v.is_floating_point()}
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    kv64 = kv.detach().double().cpu().requires_grad_(True)
+    m64 = [m.double().cpu() for m in masks]
+    yr = O.transformer_encoder(p64, "e", x64, kv64 if mode == "cross" else x64, kv64 if mode == "cross" else x64, T, m64)
+    (yr * w.double().cpu()).sum().backward()
+    assert float((y.detach().cpu().double() - yr.detach()).abs().max()) < 2e-5
+    assert float((x.grad.cpu().double() - x64.grad).abs().max() / x64.grad.abs().max()) < 1e-4
+    if mode == "cross":
+        assert float((kv.grad.cpu().double() - kv64.grad).abs().max() / kv64.grad.abs().max()) < 1e-4
+    # a second training forward draws different masks; eval mode is deterministic and equals the p = 0 oracle
+    y2 = enc(x, kv, kv) if mode == "cross" else enc(x, x, x)
+    assert not torch.equal(y.detach(), y2.detach())
+    enc.eval()
+    with torch.no_grad():
+        ye = enc(x, kv, kv) if mode == "cross" else enc(x, x, x)
+        y0 = O.transformer_encoder(p64, "e", x64, kv64 if mode == "cross" else x64, kv64 if mode == "cross" else x64, T)
+    assert float((ye.cpu().double() - y0.detach()).abs().max()) < 2e-5
+
+
+def test_model_attention_dropout_train_step_matches_oracle():
+    """DOSTransformer_phonon(attn_drop=0.25): one training step through Trainer == the oracle with the same masks (loss and
+    every gradient); replayed steps draw fresh masks each time (the seed lives on the device, outside the recording)."""
+    from oracle import dos_oracle as O
+    from dostransformer_amd import functional as Fn, synth
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    from dostransformer_amd.train import Trainer
+    torch.manual_seed(0)
+    model = DOSTransformer_phonon(3, 2, 118, 4, 32, DEV, 0.25)
+    p64 = {k: (v.detach().clone().double() if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
+    model = model.to(DEV).train()
+    g64 = synth.phonon_batch(5, seed=21, dtype=torch.float64)
+    g = synth.phonon_batch(5, seed=21, dtype=torch.float32).to(DEV)
+    tr = Trainer(model, lr=1e-4)
+    Fn.DROP_MASK_LOG = []
+    try:
+        loss = tr.forward_backward(g)
+        log = list(Fn.DROP_MASK_LOG)
+    finally:
+        Fn.DROP_MASK_LOG = None
+    masks = {}
+    for pre, t, m in log:
+        masks.setdefault(pre, []).append(m.double().cpu())
+    assert sorted(masks) == ["transformer", "transformer_self", "transformer_source"] and all(len(v) == 2 for v in masks.values())
+    for k in p64:
+        if p64[k].is_floating_point():
+            p64[k].requires_grad_(True)
+    dg, _, dsys = O.dostransformer_phonon_forward(p64, g64, 3, 2, drop_masks=masks)
+    ref = O.loss_phonon(dg, dsys, g64.phdos, 1.0)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 2e-5
+    fp = model.flat_params()
+    for k, v in p64.items():
+        if k in fp.G:
+            e = float((fp.G[k].cpu().double() - v.grad).abs().max() / (v.grad.abs().max() + 1e-9))
+            assert e < 3e-3, (k, e)
+    # replay: every step must see a new mask (same batch, lr = 0 -> identical weights; the loss changes only through dropout)
+    tr2 = Trainer(model, lr=0.0, weight_decay=0.0, replay=True)
+    losses = [float(tr2.step(g)) for _ in range(4)]
+    assert len(set(losses)) == 4, losses
+    model.eval()
+    with torch.no_grad():
+        a = model(g)[0].clone()
+        b = model(g)[0].clone()
+    assert torch.equal(a, b)
+
+
+# ---- callable GNN blocks (VERDICT r1 missing #4): fixtures G3 / G4 through the HIP path ---------------------------------
+@pytest.mark.parametrize("name", ["mean", "sum"])
+def test_g3_processor_block_through_hip(name):
+    """One Processor layer called ON ITS OWN with the upstream signature (`DOSTransformer_phonon.py:148-171`): isolated
+    node, duplicate edges, unsorted edge_index; outputs, input gradients, parameter gradients, node_mlp_1 untouched."""
+    from dostransformer_amd._blocks import EdgeModel, NodeModel, Processor
+    from tests.util import load, maxabs, sub
+    z = load("g3_processor.npz")
+    proc = Processor(EdgeModel(8), NodeModel(8, aggr=name))
+    proc.load_state_dict(sub(z, f"{name}/p/"))
+    proc = proc.to(DEV)
+    x = torch.from_numpy(z["x"]).to(DEV).requires_grad_(True)
+    e = torch.from_numpy(z["e"]).to(DEV).requires_grad_(True)
+    ei = torch.from_numpy(z["edge_index"]).to(DEV)
+    ox, oe = proc(x, ei, e)
+    assert maxabs(ox.cpu(), z[f"{name}/ox"]) < 5e-6 and maxabs(oe.cpu(), z[f"{name}/oe"]) < 5e-6
+    ((ox * torch.from_numpy(z[f"{name}/wx"]).to(DEV)).sum() + (oe * torch.from_numpy(z[f"{name}/we"]).to(DEV)).sum()).backward()
+    assert maxabs(x.grad.cpu(), z[f"{name}/dx"]) < 2e-5 and maxabs(e.grad.cpu(), z[f"{name}/de"]) < 2e-5
+    dead = set(str(s) for s in z[f"{name}/dead"])
+    for k, v in proc.named_parameters():
+        if k in dead:
+            assert v.grad is None, k
+        else:
+            assert maxabs(v.grad.cpu(), z[f"{name}/g/{k}"]) < 5e-5, k
+    # the separate EdgeModel / NodeModel calls compose to the same result
+    with torch.no_grad():
+        e2 = proc.edge_model(x[ei[0]], x[ei[1]], e)
+        x2 = proc.node_model(x, ei, e2)
+    assert maxabs(e2.cpu(), oe.detach().cpu()) < 2e-6 and maxabs(x2.cpu(), ox.detach().cpu()) < 2e-6
+
+
+def test_g4_edge_features_through_hip():
+    from dostransformer_amd import ops
+    from tests.util import load, maxabs
+    z = load("g4_edge_features.npz")
+    out = ops.edge_feat_sh1(torch.from_numpy(z["edge_vec"]).float().to(DEV), 4.0)
+    assert maxabs(out.cpu(), z["edge_attr"]) < 2e-6
+    assert out[0].cpu().tolist() == [1.0, 0.0, 0.0, 0.0]                 # zero-length self edge, bit exact
+
+
+@pytest.mark.parametrize("kind", ["phonon", "edos"])
+def test_encoder_decoder_blocks_match_oracle(kind):
+    """Encoder / Decoder called on their own (`DOSTransformer_phonon.py:126-145,174-183`, `DOSTransformer.py:100-122,151-161`)."""
+    from oracle import dos_oracle as O
+    from dostransformer_amd import synth
+    from dostransformer_amd._blocks import Decoder, Encoder
+    torch.manual_seed(0)
+    H = 32
+    if kind == "phonon":
+        enc, dec = Encoder(118, 4, H), Decoder(H, H)
+        g = synth.phonon_batch(4, seed=7, dtype=torch.float32)
+        ea = O.edge_features_sh1(g.edge_vec)
+    else:
+        enc, dec = Encoder(200, 41, H, n_global_feats=2), Decoder(2 * H, H)
+        g = synth.edos_batch(3, seed=8, dtype=torch.float32)
+        ea = g.edge_attr
+    pe = {"GN_encoder." + k: v.detach().clone() for k, v in enc.state_dict().items()}
+    pd = {"GN_decoder." + k: v.detach().clone() for k, v in dec.state_dict().items()}
+    enc, dec = enc.to(DEV), dec.to(DEV)
+    energies = torch.randn(51, H).to(DEV)
+    args = (g.x.to(DEV), ea.to(DEV)) + ((g.glob.to(DEV),) if kind == "edos" else ()) + (g.batch.to(DEV), energies)
+    outs = enc(*args)
+    x_ref = O._mlp_prelu(pe, "GN_encoder.node_encoder", g.x)
+    e_ref = O._mlp_prelu(pe, "GN_encoder.edge_encoder", ea)
+    assert float((outs[0].cpu() - x_ref).abs().max()) < 2e-5 and float((outs[1].cpu() - e_ref).abs().max()) < 2e-5
+    assert outs[-1].shape == (51, g.num_graphs, H) and torch.equal(outs[-1][:, 0], energies)
+    xs = outs[0]
+    if kind == "edos":
+        u_ref = O._mlp_prelu(pe, "GN_encoder.global_encoder", g.glob.reshape(-1, 2))
+        assert float((outs[2].cpu() - u_ref).abs().max()) < 2e-5
+        y = dec(xs, outs[2], g.batch.to(DEV))
+        y_ref = O._linear(pd, "GN_decoder.mlp.0", torch.cat([u_ref, O.scatter_sum(x_ref, g.batch, g.num_graphs)], 1))
+    else:
+        y = dec(xs, g.batch.to(DEV))
+        y_ref = O._linear(pd, "GN_decoder.mlp.0", O.scatter_sum(x_ref, g.batch, g.num_graphs))
+    assert float((y.cpu() - y_ref).abs().max()) < 5e-5
+    y.sum().backward()
+    assert enc.node_encoder[0].weight.grad is not None and dec.mlp[0].weight.grad is not None
+
+
+def test_graphnetwork_prompt_branch():
+    """Graphnetwork_phonon with 118 + H/2 wide node features takes `node_encoder_prompt` (`graphnetwork_phonon.py:150-153`);
+    the plain `node_encoder` then stays without a gradient."""
+    from oracle import dos_oracle as O
+    from dostransformer_amd import synth
+    from dostransformer_amd.embedder_phDOS.graphnetwork_phonon import Graphnetwork_phonon
+    torch.manual_seed(0)
+    H = 32
+    model = Graphnetwork_phonon(3, 118, 4, H, 51, DEV)
+    p = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    g = synth.phonon_batch(4, seed=9, dtype=torch.float32)
+    g.x = torch.cat([g.x, torch.randn(g.x.shape[0], H // 2, generator=torch.Generator().manual_seed(1))], 1)
+    ref = O.graphnetwork_phonon_forward(p, g, 3)
+    gg = g.clone().to(DEV)
+    out = model(gg)
+    assert rmse(out.detach().cpu(), ref) < 1e-4
+    out.sum().backward()
+    assert model.GN_encoder.node_encoder_prompt[0].weight.grad is not None
+    assert model.GN_encoder.node_encoder[0].weight.grad is None
+    pr = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in p.items()}
+    O.graphnetwork_phonon_forward(pr, g, 3).sum().backward()
+    w = "GN_encoder.node_encoder_prompt.0.weight"
+    gr = dict(model.named_parameters())[w].grad.cpu()
+    assert float((gr - pr[w].grad).abs().max() / pr[w].grad.abs().max()) < 1e-3
