@@ -102,8 +102,15 @@ def attn_case(name, Sq, Bq, Nk, Bk, H):
     a.dout, a.dx, a.dscores, a.dkvhat, a.dkv_accumulate = dout.data_ptr(), dx.data_ptr(), dsc.data_ptr(), dkv.data_ptr(), 1
     a.partials_q, a.partials_kv = part.data_ptr(), part.data_ptr() + 4 * Bq * nqt * 2 * H
     usb = timeit(lambda: ops.attention_bwd(a))
+    note = ""
+    from dostransformer_amd import _lib
+    if _lib.load().dosx_attention_pkv_supported(Nk, H):      # the path the training programs take for Nk <= 64
+        kvp = torch.empty(Bq * nqt * Nk, H, device=DEV)
+        a.dkv_part = kvp.data_ptr()
+        usp = timeit(lambda: ops.attention_bwd(a))
+        note = f" | bwd(dq + in-kernel dK/dV partials + reduce) {usp:7.1f} us {2.5 * fl / usp / 1e6:6.2f} TF/s"
     print(f"attn  {name:30s} Sq={Sq} Bq={Bq} Nk={Nk} H={H}: fwd {us:7.1f} us {fl / us / 1e6:6.2f} TF/s "
-          f"({100 * fl / us / 1e6 / 157.3:4.1f}%) | bwd(dq+dkv) {usb:7.1f} us {2.5 * fl / usb / 1e6:6.2f} TF/s")
+          f"({100 * fl / us / 1e6 / 157.3:4.1f}%) | bwd(dq+streamed dkv) {usb:7.1f} us {2.5 * fl / usb / 1e6:6.2f} TF/s" + note)
 
 
 def ffn_case(name, M, H):

@@ -1,23 +1,22 @@
 #!/usr/bin/env python3
-"""Aggregate two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs of the same command) into
-HBM bytes per launch for the kernels behind bench.py's roofline sites.
+"""Aggregate two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs of the same command) into HBM bytes per
+launch of EVERY kernel symbol, tagged with the hash of the sources they were measured on.
 
   bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
-(on gfx950 FETCH_SIZE under-reports a wide coalesced read stream by 2x: MI355X_MICROARCH.md, HBM / rocprofv3
-section; both counters are in KiB.)  Usage: pmc_traffic.py <fetch_counter_collection.csv> <write_...csv> <out.json>"""
+(on gfx950 FETCH_SIZE under-reports a wide coalesced read stream by 2x: MI355X_MICROARCH.md, HBM / rocprofv3 section; both
+counters are in KiB.)  bench.py looks a roofline site's kernel symbol up in this file and REFUSES the file when its
+`source_hash` is not the hash of the sources it is running (dostransformer_amd._lib.source_hash), so a stale file can
+never be reported as `roofline.traffic`.
+
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [git_head]"""
 import csv
 import json
+import os
 import sys
 from collections import defaultdict
 
-# bench.py roofline site -> substring that identifies the kernel symbol (template arguments included)
-SITES = {
-    "edge_mlp_gemm1_fwd": "gemm_kernel<3, 2, 0, 0, 1, 1>",     # 48-row tiles, LN epilogue (M ~ 9000, N 256, K 384)
-    "ffn_fwd_transformer_self": "ffn_fwd_kernel<false>",
-    "scatter_add_fwd": "segment_reduce_kernel",
-    "attention_fwd_transformer_self": "attn_fwd_stream_kernel<4>",
-    "attention_fwd_transformer": "attn_fwd_stream_kernel<1>",
-}
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 def per_kernel(path, counter):
@@ -30,20 +29,38 @@ def per_kernel(path, counter):
     return {k: tot[k] / n[k] for k in tot}, n
 
 
-fetch, nf = per_kernel(sys.argv[1], "FETCH_SIZE")
-write, nw = per_kernel(sys.argv[2], "WRITE_SIZE")
-out = {"_note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps 20 "
-                "--warmup 3 --no-cpu-baseline --launch eager` (phonon_h128_b64), averaged per launch of the named "
-                "kernel symbol; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction, "
-                "MI355X_MICROARCH.md HBM section). Kernel-symbol granularity: all launches of that symbol.",
-       "sites": {}}
-for site, key in SITES.items():
-    ks = [k for k in fetch if key in k]
-    if not ks:
-        continue
-    k = ks[0]
-    f, w = fetch[k], write.get(k, 0.0)
-    out["sites"][site] = {"kernel": key, "launches_profiled": nf[k], "FETCH_SIZE_KB": round(f, 1), "WRITE_SIZE_KB": round(w, 1),
-                          "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
-json.dump(out, open(sys.argv[3], "w"), indent=1)
-print(json.dumps(out["sites"], indent=1))
+def short(sym):
+    """'void (anonymous namespace)::gemm_kernel<3, 2, 0, 0, 1, 1>((anonymous namespace)::GemmLaunch)' -> 'gemm_kernel<3, 2, 0, 0, 1, 1>'"""
+    s = sym.replace("(anonymous namespace)::", "").replace("void ", "")
+    depth = 0
+    for i, ch in enumerate(s):          # cut the argument list: first '(' outside template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            return s[:i].strip()
+    return s.strip()
+
+
+def main():
+    from dostransformer_amd._lib import source_hash
+    fetch, nf = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write, nw = per_kernel(sys.argv[2], "WRITE_SIZE")
+    out = {"_note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps 20 "
+                    "--warmup 3 --no-cpu-baseline --launch eager` (phonon_h128_b64), averaged per launch of each kernel "
+                    "symbol; hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction, "
+                    "MI355X_MICROARCH.md HBM section).",
+           "source_hash": source_hash(),
+           "git_head": sys.argv[4] if len(sys.argv) > 4 else "unknown",
+           "kernels": {}}
+    for k in sorted(fetch, key=lambda k: -fetch[k] * nf[k]):
+        f, w = fetch[k], write.get(k, 0.0)
+        out["kernels"][short(k)] = {"launches": nf[k], "FETCH_SIZE_KB": round(f, 1), "WRITE_SIZE_KB": round(w, 1),
+                                    "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    print(f"{len(out['kernels'])} kernel symbols, source_hash {out['source_hash']}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,24 +1,19 @@
 #!/bin/bash
-# The measurement job behind profiles/<round>_*: run on the GPU box (gpurun -- 'bash tools/profile_round.sh r01'),
+# The measurement job behind profiles/<round>_*: run on the GPU box
+#     gpurun -- 'bash tools/profile_round.sh r02 <git head>'
 # then copy gpurun_out/prof_<round>/summary/* into profiles/.  rocprofv3 passes are separate (kernel trace | one PMC
 # counter each), the program comes directly after `--`, outputs are CSV.
 set -u
-R=${1:-r01}
+R=${1:-r02}
+HEAD=${2:-unknown}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$R
 S=$OUT/summary
 mkdir -p "$S"
 export TMPDIR=/tmp
 cd "$ROOT"
-timeout 300 python3 bench.py > "$S/${R}_bench_phonon_h128_b64.json" 2> "$OUT/bench_phonon.err" < /dev/null
-timeout 400 python3 bench.py --config edos_h256_b64 > "$S/${R}_bench_edos_h256_b64.json" 2> "$OUT/bench_edos.err" < /dev/null
-timeout 600 python3 tools/bench_kernels.py > "$S/${R}_kernel_microbench.log" 2> "$OUT/microbench.err" < /dev/null
-timeout 200 python3 tools/predict_latency.py 2> /dev/null | grep "^predict" >> "$S/${R}_kernel_microbench.log"
+# PMC passes FIRST: the traffic file must exist (with this tree's source hash) when the bench lines below are produced
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o st -- \
-  python3 "$ROOT/bench.py" --steps 100 --warmup 20 --no-cpu-baseline > "$OUT/trace.log" 2>&1 < /dev/null
-f=$(find "$OUT/trace" -name "*kernel_stats.csv" | head -1)
-[ -n "$f" ] && cp "$f" "$S/${R}_bench_phonon_h128_b64_kernel_stats.csv"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_$c" -o pmc -- \
     python3 "$ROOT/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --launch eager > "$OUT/pmc_$c.log" 2>&1 < /dev/null
@@ -26,8 +21,24 @@ done
 ff=$(find "$OUT/pmc_FETCH_SIZE" -name "*counter_collection.csv" | head -1)
 fw=$(find "$OUT/pmc_WRITE_SIZE" -name "*counter_collection.csv" | head -1)
 if [ -n "$ff" ] && [ -n "$fw" ]; then
-  python3 "$ROOT/tools/pmc_traffic.py" "$ff" "$fw" "$S/${R}_pmc_traffic.json" > "$OUT/pmc_traffic.log" 2>&1
+  python3 "$ROOT/tools/pmc_traffic.py" "$ff" "$fw" "$S/${R}_pmc_traffic.json" "$HEAD" > "$OUT/pmc_traffic.log" 2>&1
+  cp "$S/${R}_pmc_traffic.json" "$ROOT/profiles/${R}_pmc_traffic.json"       # bench.py below reads it from profiles/
   python3 "$ROOT/tools/pmc_summary.py" "$ff" FETCH_SIZE "$S/${R}_pmc_fetch_size_summary.csv"
   python3 "$ROOT/tools/pmc_summary.py" "$fw" WRITE_SIZE "$S/${R}_pmc_write_size_summary.csv"
 fi
+cd "$ROOT"
+timeout 400 python3 bench.py > "$S/${R}_bench_phonon_h128_b64.json" 2> "$OUT/bench_phonon.err" < /dev/null
+timeout 400 python3 bench.py --shuffle --no-cpu-baseline > "$S/${R}_bench_phonon_h128_b64_shuffle.json" 2> "$OUT/bench_shuffle.err" < /dev/null
+timeout 500 python3 bench.py --config edos_h256_b64 > "$S/${R}_bench_edos_h256_b64.json" 2> "$OUT/bench_edos.err" < /dev/null
+timeout 600 python3 tools/bench_kernels.py > "$S/${R}_kernel_microbench.log" 2> "$OUT/microbench.err" < /dev/null
+timeout 200 python3 tools/predict_latency.py 2> /dev/null | grep "^predict" >> "$S/${R}_kernel_microbench.log"
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o st -- \
+  python3 "$ROOT/bench.py" --steps 100 --warmup 20 --no-cpu-baseline > "$OUT/trace.log" 2>&1 < /dev/null
+f=$(find "$OUT/trace" -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && cp "$f" "$S/${R}_bench_phonon_h128_b64_kernel_stats.csv"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_edos" -o st -- \
+  python3 "$ROOT/bench.py" --config edos_h256_b64 --steps 40 --warmup 10 --no-cpu-baseline > "$OUT/trace_edos.log" 2>&1 < /dev/null
+f=$(find "$OUT/trace_edos" -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && cp "$f" "$S/${R}_bench_edos_h256_b64_kernel_stats.csv"
 ls -la "$S"
