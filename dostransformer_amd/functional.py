@@ -294,13 +294,13 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: torch.Tensor, dkvhat: t
         sink.add(part, 0, G[lp + ".layer_norms.1.weight"], rgp, 2 * H, H)
         sink.add(part, H, G[lp + ".layer_norms.1.bias"], rgp, 2 * H, H)
         # attention (+ LN0 backward on the query side + residual); key side accumulates into dkvhat
-        npart = Bq * nqt + Bk * nkt
-        part = sink.scratch(npart, 2 * H)
-        dxin = _empty(dev, rows, H)
         # Nk <= 64 (atoms of a crystal, the 51 phonon bins): the dq kernel leaves every query tile's share of dK + dV in
         # `kvp` and the dk+dv half is a small reduction over those partials; larger key sets (201 eDOS bins) stream the
         # dS round trip through `dsc` into the dkv kernel
         small = bool(_lib_load().dosx_attention_pkv_supported(int(Nk), int(H)))
+        npart = Bq * nqt + Bk * ((Nk + 15) // 16 if small else nkt)        # key-side partial rows: per 16 / 32 keys
+        part = sink.scratch(npart, 2 * H)
+        dxin = _empty(dev, rows, H)
         dsc = None if small else _empty(dev, Bq, Sq, Nk)
         kvp = sink.scratch(Bq * nqt * Nk, H) if small else None
         acc = 0 if (dkv_fresh and t == T - 1) else 1

@@ -248,7 +248,7 @@ typedef struct DosxAttn {
   float* dkvhat;       /* [Nk*Bk, H] (+)= */
   int32_t dkv_accumulate;
   float* partials_q;   /* [Bq * ceil(Sq/32)] rows of [dgamma(H) | dbeta(H)] */
-  float* partials_kv;  /* [Bk * ceil(Nk/32)] rows of [dgamma(H) | dbeta(H)] */
+  float* partials_kv;  /* [Bk * ceil(Nk/32)] rows of [dgamma(H) | dbeta(H)]; [Bk * ceil(Nk/16)] rows on the dkv_part path */
   const float* drop_mask; /* optional [Bq, Sq, Nk]: attention dropout (F.dropout on the softmax output,
                           layers/multihead_attention.py:70) as an explicit multiplier M in {0, 1/(1-p)} (dosx_dropout_mask);
                           `probs` stays the un-dropped softmax.  NULL = no dropout (eval mode / p = 0) */

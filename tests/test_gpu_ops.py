@@ -496,7 +496,7 @@ def test_attention_fwd_bwd(Sq, Bq, Nk, Bk, H, bcast, pkv, drop):
     dx = torch.empty(Sq * Bq, H, device=DEV)
     dsc = torch.empty(Bq, Sq, Nk, device=DEV)
     dkv = torch.zeros(Nk * Bk, H, device=DEV)
-    nqt, nkt = (Sq + 31) // 32, (Nk + 31) // 32
+    nqt, nkt = (Sq + 31) // 32, ((Nk + 15) // 16 if pkv else (Nk + 31) // 32)
     part = torch.empty(Bq * nqt + Bk * nkt, 2 * H, device=DEV)
     a.dout, a.dx, a.dscores, a.dkvhat, a.dkv_accumulate = dout.data_ptr(), dx.data_ptr(), dsc.data_ptr(), dkv.data_ptr(), 1
     a.partials_q = part.data_ptr()

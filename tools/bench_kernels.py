@@ -98,7 +98,7 @@ def attn_case(name, Sq, Bq, Nk, Bk, H):
     dsc = torch.empty(Bq, Sq, Nk, device=DEV)
     dkv = torch.zeros(Nk * Bk, H, device=DEV)
     nqt, nkt = (Sq + 31) // 32, (Nk + 31) // 32
-    part = torch.empty(Bq * nqt + Bk * nkt, 2 * H, device=DEV)
+    part = torch.empty(Bq * nqt + Bk * max(nkt, (Nk + 15) // 16), 2 * H, device=DEV)
     a.dout, a.dx, a.dscores, a.dkvhat, a.dkv_accumulate = dout.data_ptr(), dx.data_ptr(), dsc.data_ptr(), dkv.data_ptr(), 1
     a.partials_q, a.partials_kv = part.data_ptr(), part.data_ptr() + 4 * Bq * nqt * 2 * H
     usb = timeit(lambda: ops.attention_bwd(a))
