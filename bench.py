@@ -300,7 +300,19 @@ def main():
     hits, misses = trainer.slot_hits - hits0, trainer.slot_misses - miss0
     n_slots = len(trainer._slots)
     n_inst = 0
-    if use_graph:
+    if mode == "replay":
+        # per-launch durations INSIDE the replayed two-stream step: the recorded programs are re-issued through
+        # dosx_replay_timed (a HIP event pair around every entry, on the stream it launches on); the few launches outside
+        # the recordings (slot copy, AdamW) are bracketed by ops._call
+        trainer.kernel_timer = ops.KERNEL_TIMER
+        ops.KERNEL_TIMER.reset(enabled=True)
+        n_inst = min(args.steps, 24)
+        for i in range(n_inst):
+            do_step()
+            torch.cuda.synchronize()
+        ops.KERNEL_TIMER.enabled = False
+        trainer.kernel_timer = None
+    elif use_graph:
         trainer.graph = trainer.replay = False
         ops.KERNEL_TIMER.reset(enabled=True)
         n_inst = min(args.steps, 24)
@@ -350,8 +362,10 @@ def main():
                                   "replay": "recorded launch list per (N,E) bucket (exact ghost padding), 2 HIP streams",
                                   "eager": "eager"}[mode],
                        "bucket": list(bucket),
-                       "kernel_timing": ("HIP events around every libdosx launch, instrumented eager pass after the timed region"
-                                         if use_graph else "HIP events around every libdosx launch inside the timed region")},
+                       "kernel_timing": {"replay": "HIP event pair around every launch of the REPLAYED step (dosx_replay_timed, each "
+                                                   "on the stream it launches on), 24 steps right after the timed region",
+                                         "graph": "HIP events around every libdosx launch, instrumented eager pass after the timed region",
+                                         "eager": "HIP events around every libdosx launch inside the timed region"}[mode]},
             # whole-step figure: algorithmic flops of a train step (SURVEY.md §8d formula on the real, un-padded rows,
             # x3 for fwd+bwd) / measured step time / fp32 MFMA dense peak
             "step_frac": round(flops_step / (ms_step * 1e-3) / (MFMA_F32_PEAK_TFLOPS * 1e12), 4),

@@ -179,6 +179,7 @@ _SIGS = {
     "dosx_neighbor_fill": [_P, _P, _P, _P, _I, _L, _D, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "dosx_replay_op": [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "dosx_replay": [C.POINTER(Call), _I, C.POINTER(C.c_int)],
+    "dosx_replay_timed": [C.POINTER(Call), _I, C.POINTER(C.c_float), C.POINTER(C.c_int)],
     "dosx_dropout_mask": [_P, _L, _F, _P, _L, _P],
     "dosx_copy_many": [C.POINTER(CopyJob), _I, _P],
     "dosx_fill": [_P, _F, _L, _P],

@@ -12,6 +12,7 @@
 // on how a particular ABI passes surplus or mismatched arguments.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/dosx.h"
@@ -63,6 +64,45 @@ extern "C" int dosx_replay_op(const char* name, int* n_int, int* n_float) {
     }
   }
   return -1;
+}
+
+// Diagnostic twin of dosx_replay: the same list, with a HIP event pair around every libdosx entry on the stream that entry
+// launches on (its last integer-class argument, by the convention of this header), so the duration of every launch is
+// measured INSIDE the replayed two-stream step - the configuration bench.py times - rather than in a separate eager
+// pass.  Synchronises the device at the end (it is a measurement call, not a product path); ms_out[i] = elapsed time of
+// entry i in milliseconds (0 for the stream fork / join entries).
+extern "C" int dosx_replay_timed(const DosxCall* calls, int n, float* ms_out, int* failed_index) {
+  if (n <= 0) return 0;
+  hipEvent_t* ev = (hipEvent_t*)malloc(sizeof(hipEvent_t) * 2 * (size_t)n);
+  if (!ev) { dosx_set_error("dosx_replay_timed: out of host memory"); return -12; }
+  int made = 0, rc = 0;
+  for (; made < 2 * n; ++made)
+    if (hipEventCreate(&ev[made]) != hipSuccess) { rc = -5; dosx_set_error("dosx_replay_timed: hipEventCreate failed"); break; }
+  for (int i = 0; rc == 0 && i < n; ++i) {
+    const DosxCall& c = calls[i];
+    const DosxThunk* t = thunk_of(c.op);
+    if (!t || c.nint != t->nint || c.nflt != t->nflt) {
+      dosx_set_error("dosx_replay_timed: entry %d is malformed (op %d)", i, c.op);
+      rc = -22;
+    } else {
+      const bool timed = c.op < DOSX_OP_HIP_BASE && c.nint > 0;
+      hipStream_t st = timed ? (hipStream_t)(uintptr_t)c.iarg[c.nint - 1] : nullptr;
+      if (timed) (void)hipEventRecord(ev[2 * i], st);
+      rc = t->call(c);
+      if (timed) (void)hipEventRecord(ev[2 * i + 1], st);
+    }
+    if (rc != 0 && failed_index) *failed_index = i;
+  }
+  (void)hipDeviceSynchronize();
+  for (int i = 0; i < n; ++i) {
+    float ms = 0.f;
+    if (rc == 0 && ms_out && calls[i].op < DOSX_OP_HIP_BASE && calls[i].nint > 0)
+      if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) != hipSuccess) ms = 0.f;
+    if (ms_out) ms_out[i] = ms;
+  }
+  for (int i = 0; i < made; ++i) (void)hipEventDestroy(ev[i]);
+  free(ev);
+  return rc;
 }
 
 extern "C" int dosx_replay(const DosxCall* calls, int n, int* failed_index) {

@@ -50,10 +50,14 @@ class _KernelTimer:
         end.record()
         self.records.append((tag, kernel, bound, float(work), ev, end))
 
+    def add_ms(self, tag: str, kernel: str, bound: str, work: float, ms: float):
+        """a launch whose duration was measured elsewhere (Program.run_timed)"""
+        self.records.append((tag, kernel, bound, float(work), None, float(ms)))
+
     def roofline(self, hbm_peak_gbs: float, mfma_peak_tflops: float):
         agg = {}
         for tag, kernel, bound, work, s, e in self.records:
-            ms = s.elapsed_time(e)
+            ms = e if s is None else s.elapsed_time(e)
             a = agg.setdefault(tag, {"kernel": kernel, "bound": bound, "work": 0.0, "ms": 0.0, "n": 0})
             a["work"] += work
             a["ms"] += ms
@@ -90,15 +94,16 @@ class _Recorder:
         self.active = False
         self.prog = []
         self.keep = []
+        self.work = {}
 
     def begin(self):
         if self.active:
             raise RuntimeError("recorder already active")
-        self.active, self.prog, self.keep = True, [], []
+        self.active, self.prog, self.keep, self.work = True, [], [], {}
 
     def end(self) -> "Program":
-        p = Program(self.prog, self.keep)
-        self.active, self.prog, self.keep = False, [], []
+        p = Program(self.prog, self.keep, self.work)
+        self.active, self.prog, self.keep, self.work = False, [], [], {}
         return p
 
 
@@ -107,9 +112,11 @@ class Program:
     entries runs in C, csrc/replay.cpp).  Entries are libdosx calls and the stream fork / join operations of
     :class:`GradSink`, which are lowered to hipEventRecord / hipStreamWaitEvent on the raw handles."""
 
-    def __init__(self, prog, keep):
+    def __init__(self, prog, keep, work=None):
         self.prog, self.keep = prog, keep
+        self.work = work or {}            # index in prog -> (site, kernel, bound, work) of that launch
         self._calls = None
+        self._entry_of = []               # lowered call index -> index in prog
         self._n = 0
         self._events = []
 
@@ -128,8 +135,11 @@ class Program:
             return ops_by_name[name]
 
         out = []
+        entry_of = self._entry_of = []
+        cur = [0]
 
         def emit(name, ints, flts=()):
+            entry_of.append(cur[0])
             op, ni, nf = op_of(name)
             if (ni, nf) != (len(ints), len(flts)):
                 raise RuntimeError(f"{name}: recorded {len(ints)}+{len(flts)} arguments, the entry point takes {ni}+{nf}")
@@ -141,7 +151,8 @@ class Program:
                 c.farg[i] = float(v)
             out.append(c)
 
-        for fn, args in self.prog:
+        for pi, (fn, args) in enumerate(self.prog):
+            cur[0] = pi
             owner = getattr(fn, "__self__", None)
             if isinstance(owner, torch.cuda.Event) and fn.__name__ == "record":          # ev.record(stream)
                 emit("hipEventRecord", [owner.cuda_event, args[0].cuda_stream])
@@ -176,6 +187,21 @@ class Program:
         if rc:
             _lib.check(rc, f"replayed call #{failed.value}")
 
+    def run_timed(self, timer: "_KernelTimer") -> None:
+        """run() with a HIP event pair around every entry (dosx_replay_timed): the per-launch durations of the REPLAYED
+        step, streams and all, appended to ``timer`` under the work records captured while recording."""
+        if self._calls is None:
+            self._compile()
+        ms = (C.c_float * self._n)()
+        failed = C.c_int(-1)
+        rc = _lib.load().dosx_replay_timed(self._calls, self._n, ms, C.byref(failed))
+        if rc:
+            _lib.check(rc, f"replayed call #{failed.value}")
+        for ci in range(self._n):
+            w = self.work.get(self._entry_of[ci])
+            if w is not None:
+                timer.add_ms(w[0], w[1], w[2], w[3], float(ms[ci]))
+
     def run_python(self) -> None:
         """Reference implementation of run(): the same list issued entry by entry from Python."""
         for fn, args in self.prog:
@@ -202,6 +228,8 @@ def _call(name: str, *args, w=None) -> None:
         site, kernel, bound, work = w() if w is not None else (name[5:], name[5:] + "_kernel", "hbm", 0.0)
         KERNEL_TIMER.stop(ev, site, kernel, bound, work)
     if RECORDER.active:
+        if w is not None:
+            RECORDER.work[len(RECORDER.prog)] = w()
         RECORDER.prog.append((fn, args))
 
 

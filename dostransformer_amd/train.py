@@ -128,6 +128,7 @@ class Trainer:
         self._slots: "OrderedDict[tuple, _Slot]" = OrderedDict()
         self.max_slots = int(max_slots)
         self.slot_hits = self.slot_misses = 0
+        self.kernel_timer = None          # ops._KernelTimer: replayed programs then run through dosx_replay_timed
 
     def _state(self, fp):
         """AdamW moments laid out like ``fp``.  When the parameters are re-homed (module moved to another device after
@@ -334,7 +335,10 @@ class Trainer:
         if self.replay:
             for kind, prog in slot.plan:
                 if kind == "prog":
-                    prog.run()
+                    if self.kernel_timer is not None:      # bench.py: event pair around every replayed launch
+                        prog.run_timed(self.kernel_timer)
+                    else:
+                        prog.run()
                 elif kind == "sse":
                     self.dist.all_reduce_sse(slot.sse)
                 else:

@@ -454,6 +454,10 @@ typedef struct DosxCall {
 /* op index of an entry point by name (-1 if unknown); optionally its integer-class / floating-point argument counts */
 int dosx_replay_op(const char* name, int* n_int, int* n_float);
 int dosx_replay(const DosxCall* calls, int n, int* failed_index);
+/* Measurement twin: replays the list with a HIP event pair around every library entry, recorded on the stream that entry
+ * launches on; ms_out[n] (HOST array) receives the elapsed milliseconds of every entry.  Ends with a device
+ * synchronisation - diagnostic use only (bench.py's per-kernel roofline figures). */
+int dosx_replay_timed(const DosxCall* calls, int n, float* ms_out, int* failed_index);
 
 /* misc */
 /* Dropout multiplier: mask[i] = u_i >= p ? 1/(1-p) : 0 with u_i uniform in [0,1) from Philox4x32-10 (counter = (i/4, stream_id),
