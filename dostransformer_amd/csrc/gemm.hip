@@ -1241,30 +1241,40 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, 
       float mean, rstd;
     };
     Set s0, s1;
+    // THREE stage buffers, the staging waves TWO chunks ahead of the matrix waves (chunk c+2 is stored while chunk c is
+    // multiplied): at the barrier that ends chunk c the data of chunk c+1 has been visible for a whole chunk, so the matrix
+    // waves fetch its fragments UNDER the MFMAs of chunk c.  With two buffers every chunk started with ~450 clk of exposed
+    // ds_read issue + latency behind the barrier (stamps, round 2: 1500 clk per chunk in the matrix waves for 1024 clk of
+    // MFMAs; chunk period 1900-2100 clk).  Chunk c travels in register set c & 1 and LDS buffer c % 3.
+    // Every `issue` is UNCONDITIONAL (chunks past the end of the split read valid / bounds-zeroed rows that are never
+    // stored): a conditionally issued batch of loads makes the number of loads in flight path-dependent, and hipcc then
+    // protects every later use with s_waitcnt vmcnt(0) - i.e. each store waited for the loads issued ONE chunk ago as well
+    // and the two-chunk-deep pipeline ran one deep: chunk period = memory latency (1900-2100 clk, stamps of round 2).
     auto pipeline = [&](auto&& issue, auto&& store) {
       WSTAMP_S(0);
-      if (nch > 0) issue(s0, ms);
-      if (nch > 1) issue(s1, ms + BM);
+      issue(s0, ms);
+      issue(s1, ms + BM);
       if (nch > 0) store(Sm, s0);
-      if (nch > 2) issue(s0, ms + 2 * BM);
+      issue(s0, ms + 2 * BM);
+      if (nch > 1) store(Sm + STG, s1);
+      issue(s1, ms + 3 * BM);
       WSTAMP_S(1);
-      __syncthreads();
+      __syncthreads();                                    // chunks 0 and 1 are visible
+      int b2 = 2;                                         // buffer of chunk c + 2
       for (int c = 0; c < nch; c += 2) {
         WSTAMP_S(2 + 3 * c);
-        if (c + 1 < nch) {
-          store(Sm + STG, s1);
-          WSTAMP_S(3 + 3 * c);
-          if (c + 3 < nch) issue(s1, ms + (c + 3) * BM);
-        }
+        if (c + 2 < nch) store(Sm + b2 * STG, s0);        // buffer (c+2) % 3 was last read during iteration c - 1
+        WSTAMP_S(3 + 3 * c);
+        issue(s0, ms + (c + 4) * BM);
+        b2 = b2 == 2 ? 0 : b2 + 1;
         WSTAMP_S(4 + 3 * c);
         __syncthreads();
         if (c + 1 >= nch) break;
         WSTAMP_S(5 + 3 * c);
-        if (c + 2 < nch) {
-          store(Sm, s0);
-          WSTAMP_S(6 + 3 * c);
-          if (c + 4 < nch) issue(s0, ms + (c + 4) * BM);
-        }
+        if (c + 3 < nch) store(Sm + b2 * STG, s1);
+        WSTAMP_S(6 + 3 * c);
+        issue(s1, ms + (c + 5) * BM);
+        b2 = b2 == 2 ? 0 : b2 + 1;
         WSTAMP_S(7 + 3 * c);
         __syncthreads();
       }
@@ -1304,8 +1314,8 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, 
         const int cidx = __builtin_amdgcn_readfirstlane((m - ms) / BM);
         q.idx = __builtin_amdgcn_raw_buffer_load_b32(rI, vI, cidx * stepI, 0);      // (!gather: dummy, unused)
       };
-      if (nch > 0) load_idx(s0, ms);
-      if (nch > 1) load_idx(s1, ms + BM);
+      load_idx(s0, ms);
+      load_idx(s1, ms + BM);
       auto issue = [&](Set& q, int m) {
         const int cidx = __builtin_amdgcn_readfirstlane((m - ms) / BM);
         q.y0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rY, vY0, cidx * stepY, 0));
@@ -1335,7 +1345,7 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, 
     } else {
       auto issue = [&](Set& q, int m) {
         q.row_ok = (m + r) < me;
-        const int gm = min(m + r, me - 1);          // me > ms >= 0 here: always a valid row
+        const int gm = max(min(m + r, M - 1), 0);   // always a valid row (chunks past the split are loaded, never stored)
         q.y0 = q.y1 = f4zero();
         const float* yp = g.dy.p + (size_t)dosx_map_row(g.dy.map, gm) * g.dy.ld;
 #pragma unroll
@@ -1378,26 +1388,41 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, 
     for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
     __syncthreads();
     WSTAMP(1);
-    for (int c = 0; c < nch; ++c) {
-      const float* Ys = Sm + (c & 1) * STG;
+    // Fragments travel in HALF chunks (16 rows = 8 MFMA steps): the reads of the next half are issued right before the 8
+    // MFMAs of the current one, so every LDS round trip hides under 512 clk of matrix work - across the barrier too: the
+    // first half of chunk c+1 is fetched under the second half of chunk c (its buffer has been complete since the previous
+    // barrier).  Two half-fragment sets = 32 registers (the full-chunk version of round 1 held 32 as well, the
+    // full-chunk double buffer 64 -> 135 VGPRs, one workgroup per CU: slower).
+    struct Frag { float a[BM / 4], b[BM / 4]; };
+    auto fetch = [&](Frag& f, int buf, int half) {
+      const float* Ys = Sm + buf * STG;
       const float* Xs = Ys + BM * LDT;
+#pragma unroll
+      for (int i = 0; i < BM / 4; ++i) {
+        f.a[i] = Ys[(BM / 2 * half + 2 * i + hh) * LDT + wn * 32 + l31];
+        f.b[i] = Xs[(BM / 2 * half + 2 * i + hh) * LDT + wk * 32 + l31];
+      }
+    };
+    // two accumulators (even / odd row pairs): MFMAs chained through ONE accumulator issue every ~87 clk
+    // instead of every 64 (dependent-issue latency of the 16-pass instruction)
+    auto mma = [&](const Frag& f) {
+#pragma unroll
+      for (int i = 0; i < BM / 4; i += 2) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i], f.b[i], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i + 1], f.b[i + 1], acc2, 0, 0, 0);
+      }
+    };
+    Frag f0, f1;
+    int cur = 0;                                            // buffer of chunk c
+    if (nch > 0) fetch(f0, 0, 0);
+    for (int c = 0; c < nch; ++c) {
       WSTAMP(2 + 2 * c);
-      // all 32 fragment reads of the chunk are issued before the first MFMA (they return in order, the MFMAs
-      // then wait on a falling lgkmcnt): reading pair i+1 only after MFMA i was issued exposed ~64 clk of LDS
-      // latency per pair (1400 instead of 1024 clk per chunk)
-      float av[BM / 2], bv[BM / 2];
-#pragma unroll
-      for (int i = 0; i < BM / 2; ++i) {
-        av[i] = Ys[(2 * i + hh) * LDT + wn * 32 + l31];
-        bv[i] = Xs[(2 * i + hh) * LDT + wk * 32 + l31];
-      }
-      // two accumulators (even / odd row pairs): 16 MFMAs chained through ONE accumulator issue every ~87 clk
-      // instead of every 64 (dependent-issue latency of the 16-pass instruction)
-#pragma unroll
-      for (int i = 0; i < BM / 2; i += 2) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i + 1], bv[i + 1], acc2, 0, 0, 0);
-      }
+      const int nxt = cur == 2 ? 0 : cur + 1;
+      fetch(f1, cur, 1);
+      mma(f0);
+      if (c + 1 < nch) fetch(f0, nxt, 0);
+      mma(f1);
+      cur = nxt;
       WSTAMP(3 + 2 * c);
       __syncthreads();
     }
@@ -1431,7 +1456,7 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, 
 
 template <int PRO, int VEC, int FAST>
 __global__ __launch_bounds__(512) void wgrad_kernel(const WgradLaunch L) {
-  __shared__ __align__(16) float Sm[2 * WSTG];
+  __shared__ __align__(16) float Sm[3 * WSTG];
   wgrad_body<PRO, VEC, FAST>(L, (int)blockIdx.x, Sm);
 }
 
@@ -1447,7 +1472,7 @@ struct WgradGroup {
 static_assert(sizeof(WgradGroup) <= 4000, "WgradGroup must fit the kernel argument segment");
 
 __global__ __launch_bounds__(512) void wgrad_grouped_kernel(const WgradGroup G) {
-  __shared__ __align__(16) float Sm[2 * WSTG];
+  __shared__ __align__(16) float Sm[3 * WSTG];
   int lo = 0, hi = G.n - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
