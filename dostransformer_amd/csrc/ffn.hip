@@ -7,7 +7,7 @@
 // two GEMMs at this workload's sizes are ~12 us together; the fixed part of a launch is ~5 us).  Same wave
 // specialisation as gemm_kernel: waves 0-3 multiply, waves 4-7 stream the 128x32 weight chunks of fc1 (column block
 // by column block) and then of fc2 through two LDS stage buffers, one barrier per chunk, loads two chunks deep;
-// they also copy the finished h tile to HBM while the matrix waves are already in fc2.
+// the matrix waves write h to HBM straight from the accumulators (round 1: the staging waves copied the finished tile out in one burst).
 // Needs H % 32 == 0 and H <= 128 (tile: 32 x 516 floats); larger H uses the two-GEMM path.
 #include <stdlib.h>
 
@@ -98,13 +98,6 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
 #pragma unroll
       for (int i = 0; i < NP; ++i) st4(buf + (jr + RPP * i) * FLDW + kq, r[i]);
     };
-    auto copy_h = [&]() {        // the finished relu(fc1) tile -> HBM (rows m0.., H4 columns), float4 per lane
-      const int per_row = H4 / 4;
-      for (int i = st; i < R * per_row; i += 256) {
-        const int r = i / per_row, c = (i % per_row) * 4;
-        if (m0 + r < M) st4(a.h + (size_t)(m0 + r) * a.ldh + c, ld4(T + r * LDT + c));
-      }
-    };
     issue(r0, 0);
     issue(r1, 1);
     store(ST, r0);
@@ -116,14 +109,14 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
         if (c + 3 < nch) issue(r1, c + 3);
       }
       __syncthreads();
-      if (c + 1 == n1) { __syncthreads(); copy_h(); }        // phase boundary: T complete behind this extra barrier
+      if (c + 1 == n1) __syncthreads();                      // phase boundary: T complete behind this extra barrier
       if (c + 1 >= nch) break;
       if (c + 2 < nch) {
         store(ST, r0);
         if (c + 4 < nch) issue(r0, c + 4);
       }
       __syncthreads();
-      if (c + 2 == n1) { __syncthreads(); copy_h(); }
+      if (c + 2 == n1) __syncthreads();
     }
   } else {
     // =============================== matrix waves ================================================
@@ -176,8 +169,13 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
         const float b1b = cb == 0 ? b1r[0][1] : cb == 1 ? b1r[1][1] : cb == 2 ? b1r[2][1] : b1r[3][1];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          T[(4 * g4 + r) * LDT + col] = fmaxf(acc0[r] + b1a, 0.f);
-          T[(4 * g4 + r) * LDT + col + 16] = fmaxf(acc1[r] + b1b, 0.f);
+          const float h0 = fmaxf(acc0[r] + b1a, 0.f), h1 = fmaxf(acc1[r] + b1b, 0.f);
+          T[(4 * g4 + r) * LDT + col] = h0;
+          T[(4 * g4 + r) * LDT + col + 16] = h1;
+          if (m0 + 4 * g4 + r < M) {               // h -> HBM straight from the accumulators (64-byte row segments)
+            a.h[(size_t)(m0 + 4 * g4 + r) * a.ldh + col] = h0;
+            a.h[(size_t)(m0 + 4 * g4 + r) * a.ldh + col + 16] = h1;
+          }
         }
       }
       __syncthreads();                             // T complete (the staging waves copy it out from here on)
@@ -229,7 +227,15 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
       const int col = cb * FBN + wave * 32 + l31;
       const float b1 = cb == 0 ? b1r[0][0] : cb == 1 ? b1r[1][0] : cb == 2 ? b1r[2][0] : b1r[3][0];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * hh) * LDT + col] = fmaxf(acc[r] + b1, 0.f);
+      for (int r = 0; r < 16; ++r) {
+        // h goes to the LDS tile (A operand of fc2) AND straight to HBM from the accumulators (one 128-byte row segment
+        // per half wave): the staging waves used to copy the finished 64 KB tile out in one burst at the phase boundary
+        // and fell a tile behind with the fc2 weight chunks - 3.2 of 26.2 us at M = 6528
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const float hvv = fmaxf(acc[r] + b1, 0.f);
+        T[row * LDT + col] = hvv;
+        if (m0 + row < M) a.h[(size_t)(m0 + row) * a.ldh + col] = hvv;
+      }
     }
     FSTAMP(2);
     __syncthreads();                               // T complete (the staging waves copy it out from here on)
@@ -374,13 +380,6 @@ __global__ __launch_bounds__(512) void ffn_bwd_kernel(const DosxFfnBwd a) {
 #pragma unroll
       for (int i = 0; i < NP; ++i) st4(buf + lds[i], r[i]);
     };
-    auto copy_dh = [&]() {       // the finished dh tile -> HBM
-      const int per_row = H4 / 4;
-      for (int i = st; i < R * per_row; i += 256) {
-        const int r = i / per_row, c = (i % per_row) * 4;
-        if (m0 + r < M) st4(a.dh + (size_t)(m0 + r) * a.lddh + c, ld4(T + r * LDT + c));
-      }
-    };
     issue(r0, 0);
     issue(r1, 1);
     store(ST, r0);
@@ -392,14 +391,14 @@ __global__ __launch_bounds__(512) void ffn_bwd_kernel(const DosxFfnBwd a) {
         if (c + 3 < nch) issue(r1, c + 3);
       }
       __syncthreads();
-      if (c + 1 == n1) { __syncthreads(); copy_dh(); }
+      if (c + 1 == n1) __syncthreads();
       if (c + 1 >= nch) break;
       if (c + 2 < nch) {
         store(ST, r0);
         if (c + 4 < nch) issue(r0, c + 4);
       }
       __syncthreads();
-      if (c + 2 == n1) { __syncthreads(); copy_dh(); }
+      if (c + 2 == n1) __syncthreads();
     }
   } else {
     // =============================== matrix waves ================================================
@@ -461,7 +460,11 @@ __global__ __launch_bounds__(512) void ffn_bwd_kernel(const DosxFfnBwd a) {
         for (int v = 0; v < 16; ++v) acc[v] = a0[v];
       }
 #pragma unroll
-      for (int v = 0; v < NV; ++v) T[crow(v) * LDT + cb * FBN + ccol(v)] = hv[v] > 0.f ? acc[v] : 0.f;
+      for (int v = 0; v < NV; ++v) {
+        const float d = hv[v] > 0.f ? acc[v] : 0.f;
+        T[crow(v) * LDT + cb * FBN + ccol(v)] = d;
+        if (m0 + crow(v) < M) a.dh[(size_t)(m0 + crow(v)) * a.lddh + cb * FBN + ccol(v)] = d;     // (see ffn_fwd_kernel)
+      }
     }
     __syncthreads();                               // T complete (the staging waves copy it out from here on)
     // ---- phase 2: dyl = dh . W1, one 128-column block, n2 chunks, A operand = T ----
