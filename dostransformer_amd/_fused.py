@@ -152,6 +152,14 @@ class FusedModel(nn.Module):
         fp = self._ensure_flat(dev, g)
         m = graph_meta(g, dev)
         if torch.is_grad_enabled():
-            return _ModelFn.apply(fp.anchor, self, g, m)
-        out = self._program_fwd(fp.P, g, m)
-        return out[:-1]
+            out = _ModelFn.apply(fp.anchor, self, g, m)
+        else:
+            out = self._program_fwd(fp.P, g, m)[:-1]
+        # The kernels compute in fp32.  A float64 batch (the phonon reference sets the default dtype to float64,
+        # main_phDOS.py:15-16) gets float64 outputs back, like upstream: the caller's MSELoss against its float64 target
+        # then back-propagates a float64 gradient, which this (autograd-aware) cast turns into the fp32 one the backward
+        # program takes.
+        dt = g.x.dtype if torch.is_tensor(getattr(g, "x", None)) else torch.float32
+        if dt.is_floating_point and dt != torch.float32:
+            out = tuple(t.to(dt) for t in out)
+        return out

@@ -491,8 +491,10 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
     sink.add(part, H, G["transformer_source.layer_norm.bias"], r32, pld, H)
     sink.add(part, 2 * H, G["out_layer.weight"], r32, pld, H)
     sink.add(part, 3 * H, G["out_layer.bias"], r32, pld, 1)
-    dkv = ops.zeros(dev, nmax * B + 1, H)     # spare row stays zero
-    dhs = encoder_bwd(P, G, "transformer_source", c3, dx, dkv, sink)
+    # key gradient of the two cross attentions (dense [nmax*B (+1 spare), H] layout): the first layer processed overwrites
+    # every key row, so no zero fill; the spare row (dense slot of ghost nodes) is never read (dense_normalize_bwd's ghost_row)
+    dkv = _empty(dev, nmax * B + 1, H)
+    dhs = encoder_bwd(P, G, "transformer_source", c3, dx, dkv, sink, dkv_fresh=True)
     dkvs = _empty(dev, rows2, H)              # self-attention: every row is a key row, the first layer overwrites
     ddosin = encoder_bwd(P, G, "transformer_self", c2, dhs, dkvs, sink, dkv_fresh=True)
     sink.join()          # dkvs is produced on the side stream

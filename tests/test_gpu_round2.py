@@ -473,3 +473,61 @@ def test_graphnetwork_prompt_branch():
     w = "GN_encoder.node_encoder_prompt.0.weight"
     gr = dict(model.named_parameters())[w].grad.cpu()
     assert float((gr - pr[w].grad).abs().max() / pr[w].grad.abs().max()) < 1e-3
+
+
+def test_reference_style_loop_with_fp64_batches_and_torch_adamw():
+    """The reference's own phonon loop (`main_phDOS.py:15-16,101-118`): default dtype float64, `model(batch)` through autograd,
+    `MSELoss` against the float64 target, `loss.backward()`, `torch.optim.AdamW.step()` - with the drop-in module.  Outputs
+    are fp32 (the kernels' arithmetic), torch promotes them against the fp64 target; three steps track the oracle."""
+    from oracle import dos_oracle as O
+    from dostransformer_amd import synth
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    torch.manual_seed(0)
+    model = DOSTransformer_phonon(3, 1, 118, 4, 32, DEV, 0.0)
+    p64 = {k: (v.detach().clone().double() if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-2)
+    crit = torch.nn.MSELoss()
+    state = {}
+    for step in range(3):
+        g64 = synth.phonon_batch(4, seed=700 + step, dtype=torch.float64)
+        batch = g64.clone().to(DEV)                                     # float64 fields on the GPU, like upstream
+        assert batch.x.dtype == torch.float64
+        model.train()
+        pg, xn, ps = model(batch)
+        loss = torch.sqrt(crit(pg, batch.phdos)).mean() + 1.0 * torch.sqrt(crit(ps, batch.phdos)).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        ref, _ = O.train_step("phonon", p64, state, g64, 3, 1, lr=1e-4, beta=1.0)
+        assert abs(float(loss) - float(ref)) < 5e-5, (step, float(loss), float(ref))
+    for k, v in model.state_dict().items():
+        if v.is_floating_point():
+            assert float((v.cpu().double() - p64[k]).abs().max()) < 3.1e-4, k
+    assert model.alpha.grad is None
+
+
+@pytest.mark.parametrize("kind", ["phonon", "edos"])
+def test_training_step_is_bitwise_reproducible(kind):
+    """No atomics, fixed summation orders, two streams joined by events: the same step on the same inputs gives the same
+    bits - gradients and updated parameters - run after run (replay mode, i.e. with the side stream active)."""
+    from dostransformer_amd import synth
+    from dostransformer_amd.train import Trainer
+    if kind == "phonon":
+        mk = lambda: _phonon(64, 2)
+        g = synth.phonon_batch(16, seed=77, dtype=torch.float32).to(DEV)
+    else:
+        from dostransformer_amd.embedder_eDOS.DOSTransformer import DOSTransformer
+        mk = lambda: DOSTransformer(3, 2, 200, 41, 2, 64, DEV, 0.0)
+        g = synth.edos_batch(8, seed=78, dtype=torch.float32).to(DEV)
+    runs = []
+    for _ in range(3):
+        torch.manual_seed(4)
+        m = mk().to(DEV)
+        tr = Trainer(m, lr=1e-3, replay=True)
+        for _ in range(3):
+            tr.step(g)
+        torch.cuda.synchronize()
+        runs.append((m.flat_params().grad.clone(), m.flat_params().flat.clone()))
+    for gr, fl in runs[1:]:
+        assert torch.equal(gr, runs[0][0]) and torch.equal(fl, runs[0][1])
