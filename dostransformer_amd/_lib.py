@@ -141,6 +141,7 @@ _SIGS = {
     "dosx_wgrad_grouped": [C.POINTER(Wgrad), _I, _P],
     "dosx_reduce_partials": [C.POINTER(ReduceJob), _I, _P],
     "dosx_edge_feat_sh1": [_P, _P, _I, _F, _P],
+    "dosx_edge_embed_sh1": [_P, _P, _P, _P, _P, _I, _I, _F, _P],
     "dosx_segment_reduce": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "dosx_edge_grad_combine": [_P, _I, _P, _I, _P, _P, _P, _I, _I, _P],
     "dosx_gather_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],

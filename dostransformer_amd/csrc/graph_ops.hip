@@ -29,6 +29,38 @@ __global__ void edge_feat_kernel(const float* __restrict__ vec, float* __restric
   st4(out + 4 * (size_t)e, make_float4(c, s3 * x * inv, s3 * y * inv, s3 * z * inv));
 }
 
+// Phonon edge embedding, first layer: edge_attr = SH(l<=1)(v) * smooth_cutoff(|v|/r_max)  (DOSTransformer_phonon.py:74-77)
+// AND z = edge_attr . W0^T + b0 (the K = 4 Linear of GN_encoder.edge_encoder, :129,142) in one pass: a K = 4 "GEMM" is 4
+// fma per output - as a dosx_gemm it was a 9.6 us launch behind a 4.4 us feature kernel.  Same k-ordered fma chain as the
+// MFMA path (k = 0..3, then + bias).  One thread per (edge, 4 output columns).
+__global__ void edge_embed_kernel(const float* __restrict__ vec, const float* __restrict__ w0, const float* __restrict__ b0,
+                                  float* __restrict__ attr, float* __restrict__ z, int E, int H, float inv_rmax) {
+  const int h4 = H >> 2;
+  const size_t total = (size_t)E * h4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int e = (int)(i / h4), c = (int)(i % h4) * 4;
+    const float x = vec[3 * (size_t)e], y = vec[3 * (size_t)e + 1], zz = vec[3 * (size_t)e + 2];
+    const float len = sqrtf(x * x + y * y + zz * zz);
+    const float inv = 1.f / fmaxf(len, 1e-12f);
+    const float cut = smooth_cutoff_f(len * inv_rmax);
+    const float s3 = 1.7320508075688772f * cut;
+    const float4 f = make_float4(cut, s3 * x * inv, s3 * y * inv, s3 * zz * inv);
+    if (c == 0) st4(attr + 4 * (size_t)e, f);
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 w = ld4(w0 + (size_t)(c + j) * 4);
+      float t = f.x * w.x;
+      t = fmaf(f.y, w.y, t);
+      t = fmaf(f.z, w.z, t);
+      t = fmaf(f.w, w.w, t);
+      o[j] = t;
+    }
+    const float4 b = ld4(b0 + c);
+    st4(z + (size_t)e * H + c, make_float4(o[0] + b.x, o[1] + b.y, o[2] + b.z, o[3] + b.w));
+  }
+}
+
 // Sub-row layout helper: lane -> (sub-row slot, float4 column)
 struct RowLanes {
   int lpr;     // lanes per row
@@ -486,6 +518,16 @@ extern "C" int dosx_edge_feat_sh1(const float* edge_vec, float* edge_attr, int E
   DOSX_CHECK_ARG(edge_vec && edge_attr && r_max > 0.f, "dosx_edge_feat_sh1: bad args");
   hipLaunchKernelGGL(edge_feat_kernel, dim3(ceil_div(E, 256)), dim3(256), 0, to_stream(stream), edge_vec, edge_attr, E,
                      1.f / r_max);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_edge_embed_sh1(const float* edge_vec, const float* w0, const float* b0, float* edge_attr, float* z, int E,
+                                   int H, float r_max, dosx_stream_t stream) {
+  if (E <= 0) return 0;
+  DOSX_CHECK_ARG(edge_vec && w0 && b0 && edge_attr && z && r_max > 0.f && H > 0 && (H & 3) == 0, "dosx_edge_embed_sh1: bad args");
+  hipLaunchKernelGGL(edge_embed_kernel, dim3(grid_1d((size_t)E * (H / 4), 256)), dim3(256), 0, to_stream(stream), edge_vec,
+                     w0, b0, edge_attr, z, E, H, 1.f / r_max);
   DOSX_LAUNCH_CHECK();
   return 0;
 }

@@ -63,10 +63,12 @@ def _wgrad_linear(sink: GradSink, G: Params, wkey: str, bkey: Optional[str], M: 
 # ------------------------------------------------------------------------------------------------
 # Encoder MLP: Linear -> PReLU -> Linear          (DOSTransformer_phonon.py:129-130,141-142)
 # ------------------------------------------------------------------------------------------------
-def mlp_prelu_fwd(P: Params, key: str, a: SegList, M: int, H: int):
+def mlp_prelu_fwd(P: Params, key: str, a: SegList, M: int, H: int, z: Optional[torch.Tensor] = None):
+    """z: the first Linear's output if the caller already has it (phonon edge encoder: ops.edge_embed_sh1)."""
     dev = P[key + ".0.weight"].device
-    z = _empty(dev, M, H)
-    ops.gemm(M, H, a.segs, P[key + ".0.weight"], z, bias=P[key + ".0.bias"])
+    if z is None:
+        z = _empty(dev, M, H)
+        ops.gemm(M, H, a.segs, P[key + ".0.weight"], z, bias=P[key + ".0.bias"])
     y = _empty(dev, M, H)
     ops.gemm(M, H, [seg(z)], P[key + ".2.weight"], y, pro=PRO_PRELU, pro_alpha=P[key + ".1.weight"],
              bias=P[key + ".2.bias"])
@@ -372,9 +374,17 @@ def gnn_trunk_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta, node_key: str = "GN
     """Encoder + L processors (+ eDOS global encoder).  Returns x_L [N,H], u [B,H] or None, ctx."""
     H, N, E, B = cfg.H, m.num_nodes, m.num_edges, m.num_graphs
     xin = _f32(g.x)
-    ea = _edge_inputs(cfg, g, m)
     x0, cn = mlp_prelu_fwd(P, node_key, SegList([seg(xin)], [xin]), N, H)
-    e0, ce = mlp_prelu_fwd(P, "GN_encoder.edge_encoder", SegList([seg(ea)], [ea]), E, H)
+    if cfg.kind == "phonon" and P["GN_encoder.edge_encoder.0.weight"].shape[1] == 4:
+        # SH(l<=1) * cutoff features (r_max = 4, DOSTransformer_phonon.py:77) and the K = 4 Linear on them in one launch
+        vec = _f32(g.edge_vec)
+        if m.edge_perm is not None:
+            vec = vec[m.edge_perm]
+        ea, z0 = ops.edge_embed_sh1(vec, P["GN_encoder.edge_encoder.0.weight"], P["GN_encoder.edge_encoder.0.bias"], 4.0)
+        e0, ce = mlp_prelu_fwd(P, "GN_encoder.edge_encoder", SegList([seg(ea)], [ea]), E, H, z=z0)
+    else:
+        ea = _edge_inputs(cfg, g, m)
+        e0, ce = mlp_prelu_fwd(P, "GN_encoder.edge_encoder", SegList([seg(ea)], [ea]), E, H)
     u, cu = None, None
     if cfg.kind == "edos":
         glob = _f32(g.glob).reshape(B, 2)

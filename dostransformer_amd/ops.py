@@ -544,6 +544,17 @@ def edge_feat_sh1(edge_vec: torch.Tensor, r_max: float = 4.0) -> torch.Tensor:
     return out
 
 
+def edge_embed_sh1(edge_vec: torch.Tensor, w0: torch.Tensor, b0: torch.Tensor, r_max: float = 4.0):
+    """(edge_attr [E,4], z [E,H]) = SH(l<=1)*cutoff features and the first (K = 4) Linear of the edge encoder on them."""
+    _chk_f32(edge_vec, w0, b0)
+    e, H = edge_vec.shape[0], w0.shape[0]
+    assert w0.shape[1] == 4 and w0.is_contiguous()
+    attr, z = alloc(edge_vec.device, e, 4), alloc(edge_vec.device, e, H)
+    _call("dosx_edge_embed_sh1", edge_vec.data_ptr(), w0.data_ptr(), b0.data_ptr(), attr.data_ptr(), z.data_ptr(), e, H,
+          float(r_max), _stream(), w=lambda: ("edge_embed_sh1", "edge_embed_kernel", "hbm", 4.0 * e * (3 + 4 + H)))
+    return attr, z
+
+
 def segment_reduce(msg, rowptr, scale, agg, e_in, e_out, N, E, H):
     # algorithmic bytes: messages + CSR row pointers + aggregated output (+ the fused edge residual e_out = e_in + msg:
     # one more read and one write of [E,H])

@@ -152,6 +152,10 @@ int dosx_reduce_partials(const DosxReduceJob* jobs_host, int n_jobs, dosx_stream
 /* a1: edge_attr[E,4] = smooth_cutoff(|v|/r_max) * [1, sqrt3 * v/max(|v|,1e-12)]
  * (DOSTransformer_phonon.py:74-77; e3nn semantics restated in oracle/dos_oracle.py). */
 int dosx_edge_feat_sh1(const float* edge_vec, float* edge_attr, int E, float r_max, dosx_stream_t stream);
+/* the same + the first Linear of GN_encoder.edge_encoder on it (DOSTransformer_phonon.py:129,142; K = 4) in one launch:
+ *   edge_attr[E,4] as above ;  z[E,H] = edge_attr . w0^T + b0     (w0 [H,4] row-major, b0 [H]) */
+int dosx_edge_embed_sh1(const float* edge_vec, const float* w0, const float* b0, float* edge_attr, float* z, int E, int H,
+                        float r_max, dosx_stream_t stream);
 
 /* a5 + a6: CSR segment reduction over destination-sorted edges (replaces torch_scatter
  * scatter_mean / scatter_sum by `col`, DOSTransformer_phonon.py:209 / DOSTransformer.py:187)

@@ -531,3 +531,22 @@ def test_training_step_is_bitwise_reproducible(kind):
         runs.append((m.flat_params().grad.clone(), m.flat_params().flat.clone()))
     for gr, fl in runs[1:]:
         assert torch.equal(gr, runs[0][0]) and torch.equal(fl, runs[0][1])
+
+
+def test_edge_embed_matches_feature_kernel_plus_gemm():
+    """dosx_edge_embed_sh1 == dosx_edge_feat_sh1 followed by the K = 4 dosx_gemm (bitwise features, rounding-level z)."""
+    from dostransformer_amd import ops
+    from tests.util import load
+    vec = torch.cat([torch.from_numpy(load("g4_edge_features.npz")["edge_vec"]).float(),
+                     (torch.rand(5000, 3, generator=torch.Generator().manual_seed(2)) * 2 - 1) * 2.5]).to(DEV)
+    H = 128
+    w0 = torch.randn(H, 4, generator=torch.Generator().manual_seed(3)).to(DEV)
+    b0 = torch.randn(H, generator=torch.Generator().manual_seed(4)).to(DEV)
+    attr, z = ops.edge_embed_sh1(vec, w0, b0, 4.0)
+    ref_attr = ops.edge_feat_sh1(vec, 4.0)
+    assert torch.equal(attr, ref_attr)
+    ref_z = torch.empty(vec.shape[0], H, device=DEV)
+    ops.gemm(vec.shape[0], H, [ops.seg(ref_attr)], w0, ref_z, bias=b0)
+    assert float((z - ref_z).abs().max()) < 1e-6 * float(ref_z.abs().max())
+    z64 = ref_attr.double() @ w0.double().T + b0.double()
+    assert float((z.double() - z64).abs().max()) < 2e-6 * float(z64.abs().max())
