@@ -48,7 +48,9 @@ class Gemm(C.Structure):
         ("aux", C.c_void_p), ("ldaux", C.c_int32),
         ("aux_stats", C.c_void_p),
         ("epi_gamma", C.c_void_p), ("epi_beta", C.c_void_p), ("epi_alpha", C.c_void_p),
-        ("partials", C.c_void_p), ("partial_ld", C.c_int32), ("res_col0", C.c_int32),
+        ("partials", C.c_void_p), ("partial_ld", C.c_int32),
+        ("seg_tile", C.c_void_p), ("seg_ntiles", C.c_int32), ("seg_rowptr", C.c_void_p), ("seg_scale", C.c_void_p),
+        ("seg_agg", C.c_void_p), ("res_col0", C.c_int32),
     ]
 
 
@@ -122,7 +124,9 @@ class Collate(C.Structure):
                                           "perm_src_all", "rowptr_dst_all", "rowptr_src_all", "inv_deg_all", "x_all",
                                           "edge_feat_all", "target_all", "glob_all", "system_all", "x", "edge_feat", "target",
                                           "glob", "system", "src", "dst", "perm_src", "rowptr_dst", "rowptr_src", "graph_ptr",
-                                          "node_graph", "dense_row", "inv_deg", "node_row", "edge_row")]
+                                          "node_graph", "dense_row", "inv_deg", "node_row", "edge_row")] + \
+               [("T", C.c_int32), ("tile_rows", C.c_int32)] + \
+               [(k, C.c_void_p) for k in ("out_tile_ptr", "tile_off_all", "tile_e_all", "tile_n_all", "seg_tile")]
 
 
 class Call(C.Structure):

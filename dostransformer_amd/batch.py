@@ -49,12 +49,43 @@ class GraphMeta:
     node_graph: torch.Tensor   # [N] int32
     dense_row: torch.Tensor    # [N] int32: row of node n in the [Nmax*B] dense layout = pos*B + graph
     inv_deg: torch.Tensor      # [N] float32: 1/max(in-degree,1)  (scatter_mean divisor)
+    # [2, T+1] int32 or None: node-aligned row tiles of the message GEMM (DosxGemm EPI_SEGSUM): tile t owns the edges
+    # [seg_tile[0,t], seg_tile[0,t+1]) (<= SEG_TILE_ROWS) = the whole destination segments of the nodes
+    # [seg_tile[1,t], seg_tile[1,t+1]).  None: some node has more incoming edges than a tile holds, or the metadata came
+    # from a builder that does not produce tiles (the layers then run the stand-alone segment reduction).
+    seg_tile: Optional[torch.Tensor] = None
 
     def to(self, device) -> "GraphMeta":
         kw = {}
         for k, v in self.__dict__.items():
             kw[k] = v.to(device) if isinstance(v, torch.Tensor) else v
         return GraphMeta(**kw)
+
+
+SEG_TILE_ROWS = 48            # rows of a node-aligned tile = BMR of gemm_kernel<3, ...> (three 16-row MFMA sub-tiles)
+
+
+def seg_tile_bound(n_pad: int, e_pad: int, num_graphs: int) -> int:
+    """Number of tile slots T of a shape bucket (the message GEMM's grid): any two consecutive greedy tiles hold more than
+    SEG_TILE_ROWS rows together, crystal-aligned tilings add at most one tile per crystal, + the ghost / node-only tiles."""
+    return (2 * e_pad + SEG_TILE_ROWS - 1) // SEG_TILE_ROWS + num_graphs + 2
+
+
+def seg_tiles_host(rowptr: np.ndarray, rows: int = SEG_TILE_ROWS) -> Optional[np.ndarray]:
+    """Greedy node-aligned tiling of destination-sorted edges: [2, T+1] boundaries (edges, nodes), or None if a node has
+    more than ``rows`` incoming edges."""
+    n = int(rowptr.shape[0]) - 1
+    if n > 0 and int(np.max(rowptr[1:] - rowptr[:-1])) > rows:
+        return None
+    eb, nb, k = [0], [0], 0
+    while k < n:
+        lim = rowptr[k] + rows
+        j = int(np.searchsorted(rowptr, lim, side="right")) - 1          # largest j with rowptr[j] <= rowptr[k] + rows
+        j = min(max(j, k + 1), n)
+        eb.append(int(rowptr[j]))
+        nb.append(j)
+        k = j
+    return np.stack([np.asarray(eb, np.int32), np.asarray(nb, np.int32)])
 
 
 def _build_meta_host(edge_index: np.ndarray, batch: np.ndarray, num_graphs: int,
@@ -93,6 +124,7 @@ def _build_meta_host(edge_index: np.ndarray, batch: np.ndarray, num_graphs: int,
         rowptr_dst=i32(rowptr_dst), perm_src=i32(perm_src), rowptr_src=i32(rowptr_src),
         graph_ptr=i32(graph_ptr), node_graph=i32(batch), dense_row=i32(dense_row),
         inv_deg=torch.from_numpy((1.0 / np.maximum(deg_in, 1)).astype(np.float32)),
+        seg_tile=(lambda t: None if t is None else torch.from_numpy(t))(seg_tiles_host(rowptr_dst)),
     )
 
 
@@ -344,6 +376,24 @@ def bucket_sizes(num_nodes: int, num_edges: int, node_step: int = 8, edge_step: 
     return n_pad, e_pad
 
 
+def pad_seg_tiles(t: Optional[torch.Tensor], N: int, E: int, n_pad: int, e_pad: int, B: int) -> Optional[torch.Tensor]:
+    """Tile table of a ghost-padded batch, [2, T+1] with T = seg_tile_bound(...) slots: the real tiles, then the ghost edges
+    in SEG_TILE_ROWS-row tiles (the first of them also owns every ghost node - their aggregate is a finite don't-care),
+    then empty slots.  Mirrors what dosx_collate_padded writes on the device."""
+    if t is None:
+        return None
+    T = seg_tile_bound(n_pad, e_pad, B)
+    real = int(t.shape[1]) - 1
+    ng = max(1, (e_pad - E + SEG_TILE_ROWS - 1) // SEG_TILE_ROWS)
+    if real + ng > T:
+        return None
+    k = torch.arange(T + 1 - real, dtype=torch.int64, device=t.device)
+    eb = torch.clamp(E + k * SEG_TILE_ROWS, max=e_pad)
+    nb = torch.where(k == 0, torch.full_like(k, N), torch.full_like(k, n_pad))
+    tail = torch.stack([eb, nb]).to(torch.int32)
+    return torch.cat([t[:, :real], tail], 1).contiguous()
+
+
 def pad_batch(g: CrystalBatch, n_pad: int, e_pad: int) -> CrystalBatch:
     """Pad to fixed (N, E) so that every kernel launch of a training step has static geometry and the
     step can be replayed from a captured HIP graph.
@@ -384,6 +434,7 @@ def pad_batch(g: CrystalBatch, n_pad: int, e_pad: int) -> CrystalBatch:
         graph_ptr=m.graph_ptr, node_graph=torch.cat([m.node_graph, i32(B, dn)]),
         dense_row=torch.cat([m.dense_row, i32(m.n_max * B, dn)]),
         inv_deg=torch.cat([m.inv_deg, deg_ghost]),
+        seg_tile=pad_seg_tiles(m.seg_tile, N, E, n_pad, e_pad, B),
     )
     out = CrystalBatch(f, B, meta)
     object.__setattr__(out, "real_nodes", N)

@@ -290,6 +290,26 @@ __global__ void collate_pad_edges_kernel(const DosxCollate d) {
   d.edge_row[e] = s;
 }
 
+// node-aligned row tiles of the message GEMM (DosxGemm EPI_SEGSUM): the selected crystals' precomputed local tilings with
+// the batch offsets added, then the ghost tiles (batch.pad_seg_tiles is the host twin of this kernel)
+__global__ void collate_pad_tiles_kernel(const DosxCollate d) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > d.T) return;
+  const int real = d.out_tile_ptr[d.B];
+  int eb, nb;
+  if (t < real) {
+    const int b = seg_of(d.out_tile_ptr, d.B, t), c = d.sel[b], l = t - d.out_tile_ptr[b];
+    eb = d.out_edge_ptr[b] + d.tile_e_all[d.tile_off_all[c] + l];
+    nb = d.out_node_ptr[b] + d.tile_n_all[d.tile_off_all[c] + l];
+  } else {
+    const int k = t - real;
+    eb = min(d.E + k * d.tile_rows, d.E_pad);
+    nb = k == 0 ? d.N : d.N_pad;
+  }
+  d.seg_tile[t] = eb;
+  d.seg_tile[d.T + 1 + t] = nb;
+}
+
 // feature rows: x [N_pad,Fa], edge features [E_pad,Fe], per-crystal targets [B,S] / globals [B,n_glob] / system [B]
 __global__ void collate_pad_gather_kernel(const DosxCollate d) {
   const size_t nx = (size_t)d.N_pad * d.Fa, ne = (size_t)d.E_pad * d.Fe, nt = (size_t)d.B * d.S, ng = (size_t)d.B * d.n_glob;
@@ -335,6 +355,11 @@ extern "C" int dosx_collate_padded(const DosxCollate* dp, dosx_stream_t stream) 
   hipStream_t s = to_stream(stream);
   hipLaunchKernelGGL(collate_pad_nodes_kernel, dim3(ceil_div(d.N_pad + 1, 256)), dim3(256), 0, s, d);
   if (d.E_pad > 0) hipLaunchKernelGGL(collate_pad_edges_kernel, dim3(ceil_div(d.E_pad, 256)), dim3(256), 0, s, d);
+  if (d.seg_tile) {
+    DOSX_CHECK_ARG(d.T > 0 && d.tile_rows > 0 && d.out_tile_ptr && d.tile_off_all && d.tile_e_all && d.tile_n_all,
+                   "dosx_collate_padded: seg_tile needs T, tile_rows and the per-crystal tile tables");
+    hipLaunchKernelGGL(collate_pad_tiles_kernel, dim3(ceil_div(d.T + 1, 256)), dim3(256), 0, s, d);
+  }
   const size_t total = (size_t)d.N_pad * d.Fa + (size_t)d.E_pad * d.Fe + (size_t)d.B * (d.S + d.n_glob + 1);
   size_t blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;

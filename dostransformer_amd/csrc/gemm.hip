@@ -229,8 +229,26 @@ void gemm_kernel(const GemmLaunch L) {
     bx = grp * 8 + rem % rows_in_grp;
     by = rem / rows_in_grp;
   }
-  const int m0 = bx * BMR, n0 = by * BN;
-  const int M = g.M, N = g.N, K = g.K;
+  // EPI_SEGSUM: the row tiles are NODE-ALIGNED and of variable height (<= BMR): workgroup t owns the rows
+  // [seg_tile[t], seg_tile[t+1]) = the whole destination segments of the nodes [seg_tile[T+1+t], seg_tile[T+2+t]).
+  // Every bound below that says M means "end of this workgroup's rows".
+  int m0_ = bx * BMR, mend_ = g.M, nlo_ = 0, nhi_ = 0;
+  if constexpr (EPI == DOSX_EPI_SEGSUM) {
+    bx = (int)blockIdx.x;
+    by = 0;
+    m0_ = g.seg_tile[bx];
+    mend_ = g.seg_tile[bx + 1];
+    nlo_ = g.seg_tile[g.seg_ntiles + 1 + bx];
+    nhi_ = g.seg_tile[g.seg_ntiles + 2 + bx];
+    if (m0_ >= mend_) {                                   // no rows: at most nodes without a row of their own (ghost /
+      const int w4 = g.N >> 2;                            // padding nodes behind the last real tile): aggregate = 0
+      for (int i = (int)threadIdx.x; i < (nhi_ - nlo_) * w4; i += 512)
+        st4(g.seg_agg + (size_t)(nlo_ + i / w4) * g.N + (i % w4) * 4, f4zero());
+      return;
+    }
+  }
+  const int m0 = m0_, n0 = by * BN;
+  const int M = mend_, N = g.N, K = g.K;
   const int nk = (K + BK - 1) / BK;
 
   f32x16 acc[RT][NTW];
@@ -247,9 +265,10 @@ void gemm_kernel(const GemmLaunch L) {
   const float invN = 1.f / (float)N;
   constexpr int epi = EPI;     // compile-time: only this epilogue's code exists in the kernel
   constexpr bool is_prelu_ln = (epi == DOSX_EPI_PRELU_LN_BWD), is_rowln = (epi == DOSX_EPI_ROWLN_BWD);
-  constexpr bool aux_first = (epi != DOSX_EPI_BIAS_ACT && epi != DOSX_EPI_LN);   // operand 1 is `aux`
+  constexpr bool aux_first = (epi != DOSX_EPI_BIAS_ACT && epi != DOSX_EPI_LN && epi != DOSX_EPI_SEGSUM);   // operand 1 is `aux`
   constexpr bool use_stats = is_prelu_ln || is_rowln;
-  const bool has1 = aux_first ? (g.aux != nullptr) : (g.res != nullptr && epi == DOSX_EPI_BIAS_ACT);
+  const bool has1 = aux_first ? (g.aux != nullptr)
+                              : (g.res != nullptr && (epi == DOSX_EPI_BIAS_ACT || (epi == DOSX_EPI_SEGSUM && g.out != nullptr)));
   const bool has2 = is_rowln && g.res != nullptr;
   const float* p1 = aux_first ? g.aux : g.res;
   const int ld1 = aux_first ? g.ldaux : g.ldr;
@@ -851,6 +870,16 @@ void gemm_kernel(const GemmLaunch L) {
         st4(orow + gcol[j], make_float4(v[j].x * rstd, v[j].y * rstd, v[j].z * rstd, v[j].w * rstd));
       }
       if (lane == 0 && rvalid) g.aux_out[r] = rstd;
+    } else if (epi == DOSX_EPI_SEGSUM) {
+      // edge residual e' = e + msg (DOSTransformer_phonon.py:84); msg itself (acc + bias) never goes to HBM: its only other
+      // consumer is the segment sum below, which reads it from the LDS tile
+      if (g.out != nullptr) {
+#pragma unroll
+        for (int j = 0; j < CG; ++j) {
+          if (!on[j] || !rvalid) continue;
+          st4(orow + gcol[j], f4add(f4add(v[j], biasv[j]), pv1[rt][i][j]));
+        }
+      }
     } else if (epi == DOSX_EPI_RELU_MASK) {
 #pragma unroll
       for (int j = 0; j < CG; ++j) {
@@ -916,6 +945,23 @@ void gemm_kernel(const GemmLaunch L) {
 
   }   // rt
   }   // epilogues other than LN
+  if constexpr (epi == DOSX_EPI_SEGSUM) {
+    // ---- segment sums: agg[n] = scale[n] * sum_{e in seg(n)} (acc[e] + bias)  (scatter_mean / scatter_sum by `col`,
+    // DOSTransformer_phonon.py:209 / DOSTransformer.py:187), one wave per node, rows in order (the summation order of the
+    // stand-alone segment_reduce kernel's row loop, so the tiling never changes a bit).  Rows of a node outside this tile
+    // can only be ghost rows of the first padding node: clipped.
+    for (int n = nlo_ + wave; n < nhi_; n += 8) {
+      const int rb = max(g.seg_rowptr[n], m0) - m0, re = min(g.seg_rowptr[n + 1], M) - m0;
+      const float sc = g.seg_scale ? g.seg_scale[n] : 1.f;
+#pragma unroll
+      for (int j = 0; j < CG; ++j) {
+        if (!on[j]) continue;
+        float4 t = f4zero();
+        for (int r = rb; r < re; ++r) t = f4add(t, f4add(ld4(&Cs[r * LDC + lane * 4 + 256 * j]), biasv[j]));
+        st4(g.seg_agg + (size_t)n * N + gcol[j], make_float4(t.x * sc, t.y * sc, t.z * sc, t.w * sc));
+      }
+    }
+  }
   STAMP(58);
   // ---- per-workgroup partial sums for the parameter gradients of the fused LN / PReLU ----------
   if (g.partials && (epi == DOSX_EPI_PRELU_LN_BWD || epi == DOSX_EPI_ROWLN_BWD || epi == DOSX_EPI_PRELU_BWD)) {
@@ -974,6 +1020,7 @@ template <int RT, int NTW, int WL, int PRO, int VEC, int EPI>
 int launch_gemm3(const GemmLaunch& L, hipStream_t s) {
   constexpr int BN = 128 * NTW;
   dim3 grid(ceil_div(L.g.M, RT == 0 ? 16 : (RT == 3 ? 48 : BM * RT)) * ceil_div(L.g.N, BN));
+  if (EPI == DOSX_EPI_SEGSUM) grid = dim3(L.g.seg_ntiles);          // one workgroup per node-aligned row tile
   constexpr size_t smem = gemm_smem_bytes<RT, NTW, WL, (VEC && (PRO == DOSX_PRO_LN_PRELU || PRO == DOSX_PRO_ROWLN)) ? 1 : 0>();
   if constexpr (smem > 160 * 1024) {     // (512-column tile + LayerNorm prologue: no caller has this shape)
     dosx_set_error("dosx_gemm: tile %dx%d with prologue %d exceeds the 160 KB LDS", BM * RT, BN, PRO);
@@ -1016,6 +1063,13 @@ int dispatch_gemm(const GemmLaunch& L, hipStream_t s) {
                              : launch_gemm<NTW, 1, DOSX_PRO_NONE, 0, DOSX_EPI_BIAS_ACT>(L, s);
   }
   if (L.g.w_layout == 0) {
+    if (epi == DOSX_EPI_SEGSUM) {
+      if constexpr (NTW <= 2) {
+        if (pro == DOSX_PRO_LN_PRELU) return launch_gemm3<3, NTW, 0, DOSX_PRO_LN_PRELU, 1, DOSX_EPI_SEGSUM>(L, s);
+      }
+      dosx_set_error("dosx_gemm: EPI_SEGSUM exists for the LN_PRELU prologue and N <= 256 only");
+      return -22;
+    }
     if (epi == DOSX_EPI_LN && pro == DOSX_PRO_NONE) return launch_gemm<NTW, 0, DOSX_PRO_NONE, 1, DOSX_EPI_LN>(L, s);
     if (epi == DOSX_EPI_BIAS_ACT) {
       switch (pro) {
@@ -1107,6 +1161,10 @@ static int gemm_plan(const DosxGemm& g, GemmLaunch& L) {
   int bn = gemm_bn(g.M, g.N, g.epi);
   if (g.stats_out && bn < g.N) bn = g.N <= 256 ? 256 : 512;
   if (bn == 512 && L.rt >= 2) L.rt = 1;
+  if (g.epi == DOSX_EPI_SEGSUM) {          // node-aligned 48-row tiles, one column tile
+    L.rt = 3;
+    bn = g.N <= 128 ? 128 : 256;
+  }
   return bn;
 }
 
@@ -1143,7 +1201,7 @@ extern "C" int dosx_gemm(const DosxGemm* gp, dosx_stream_t stream) {
   }
   DOSX_CHECK_ARG(ksum == g.K, "dosx_gemm: segment widths sum to %d, K=%d", ksum, g.K);
   DOSX_CHECK_ARG((g.N & 3) == 0 && (g.ldo & 3) == 0 && aligned16(g.out), "dosx_gemm: N/ldo/out must be 4-float aligned");
-  DOSX_CHECK_ARG(g.w && g.out, "dosx_gemm: null w/out");
+  DOSX_CHECK_ARG(g.w && (g.out || g.epi == DOSX_EPI_SEGSUM), "dosx_gemm: null w/out");
   const bool full_row = (g.epi == DOSX_EPI_LN || g.epi == DOSX_EPI_PRELU_LN_BWD || g.epi == DOSX_EPI_ROWLN_BWD);
   DOSX_CHECK_ARG(!full_row || g.N <= 512, "dosx_gemm: row-wise epilogue needs N <= 512 (hidden <= 256), got %d", g.N);
   DOSX_CHECK_ARG(!g.stats_out || g.N <= 128 * 4, "dosx_gemm: stats_out needs N <= 512");
@@ -1165,6 +1223,10 @@ extern "C" int dosx_gemm(const DosxGemm* gp, dosx_stream_t stream) {
     DOSX_CHECK_ARG(g.aux && g.aux_stats && g.epi_gamma && (g.ldaux & 3) == 0, "dosx_gemm: ROWLN_BWD needs aux/aux_stats/gamma");
   if (g.epi == DOSX_EPI_RELU_MASK) DOSX_CHECK_ARG(g.aux && (g.ldaux & 3) == 0, "dosx_gemm: RELU_MASK needs aux");
   if (g.epi == DOSX_EPI_PRELU_BWD) DOSX_CHECK_ARG(g.aux && g.epi_alpha && (g.ldaux & 3) == 0, "dosx_gemm: PRELU_BWD needs aux/alpha");
+  if (g.epi == DOSX_EPI_SEGSUM)
+    DOSX_CHECK_ARG(g.seg_tile && g.seg_ntiles > 0 && g.seg_rowptr && g.seg_agg && g.N <= 256 && (!g.out || g.res) &&
+                       g.out_map.d >= (1 << 30) && g.out_map.idx == nullptr && g.out_map.c == 1 && g.out_map.off == 0,
+                   "dosx_gemm: EPI_SEGSUM needs seg_tile / seg_rowptr / seg_agg, N <= 256, an identity out_map and res with out");
 
   GemmLaunch L;
   const int bn = gemm_plan(g, L);

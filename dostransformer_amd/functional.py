@@ -17,7 +17,7 @@ from . import ops
 from ._lib import Attn, Seg
 from ._lib import load as _lib_load
 from .batch import GraphMeta
-from .ops import (ACT_LEAKY, ACT_RELU, EPI_LN, EPI_PRELU_BWD, EPI_PRELU_LN_BWD, EPI_RELU_MASK, EPI_ROWLN_BWD,
+from .ops import (ACT_LEAKY, ACT_RELU, EPI_LN, EPI_PRELU_BWD, EPI_PRELU_LN_BWD, EPI_RELU_MASK, EPI_ROWLN_BWD, EPI_SEGSUM,
                   PRO_LN_PRELU, PRO_PRELU, PRO_ROWLN, GradSink, rowmap, seg)
 
 Params = Dict[str, torch.Tensor]
@@ -94,11 +94,21 @@ def mlp_prelu_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: G
 # ------------------------------------------------------------------------------------------------
 # Edge / Node MLP: Linear -> LayerNorm -> PReLU -> Linear     (DOSTransformer_phonon.py:193,204)
 # ------------------------------------------------------------------------------------------------
-def mlp_ln_fwd(P: Params, key: str, a: SegList, M: int, H: int, res: Optional[torch.Tensor] = None):
+def mlp_ln_fwd(P: Params, key: str, a: SegList, M: int, H: int, res: Optional[torch.Tensor] = None, segsum=None):
+    """segsum = (seg_tile, rowptr, scale, agg, e_in, e_out): the second Linear aggregates its rows per destination node in
+    its epilogue (DosxGemm EPI_SEGSUM): agg = scale * segment sums of the output, e_out = e_in + output (None: skipped);
+    the output itself (the messages) is not written and None is returned for it."""
     dev = P[key + ".0.weight"].device
     xhat = _empty(dev, M, 2 * H)
     rstd = _empty(dev, M)
     ops.gemm(M, 2 * H, a.segs, P[key + ".0.weight"], xhat, bias=P[key + ".0.bias"], epi=EPI_LN, aux_out=rstd)
+    if segsum is not None:
+        tile, rowptr, scale, agg, e_in, e_out = segsum
+        ops.gemm(M, H, [seg(xhat)], P[key + ".3.weight"], e_out, pro=PRO_LN_PRELU, pro_gamma=P[key + ".1.weight"],
+                 pro_beta=P[key + ".1.bias"], pro_alpha=P[key + ".2.weight"], bias=P[key + ".3.bias"],
+                 res=e_in if e_out is not None else None, epi=EPI_SEGSUM, seg_tile=tile, seg_rowptr=rowptr, seg_scale=scale,
+                 seg_agg=agg)
+        return None, (a, xhat, rstd, M, H)
     y = _empty(dev, M, H)
     ops.gemm(M, H, [seg(xhat)], P[key + ".3.weight"], y, pro=PRO_LN_PRELU, pro_gamma=P[key + ".1.weight"],
              pro_beta=P[key + ".1.bias"], pro_alpha=P[key + ".2.weight"], bias=P[key + ".3.bias"], res=res)
@@ -139,11 +149,16 @@ def gnn_fwd(P: Params, m: GraphMeta, x: torch.Tensor, e: torch.Tensor, L: int, m
     for l in range(L):
         pre = f"stacked_processor.{l}"
         a_e = SegList([seg(x, rmap=rowmap(idx=m.src)), seg(x, rmap=rowmap(idx=m.dst)), seg(e)], [x, e])
-        msg, cxe = mlp_ln_fwd(P, pre + ".edge_model.edge_mlp", a_e, E, H)
         agg = _empty(dev, N, H)
         last = l == L - 1                       # the last layer's edge update is dead
         e_new = None if last else _empty(dev, E, H)
-        ops.segment_reduce(msg, m.rowptr_dst, scale, agg, e, e_new, N, E, H)
+        if m.seg_tile is not None and H <= 256:
+            # scatter_mean / scatter_sum + the edge residual inside the message GEMM's epilogue (node-aligned row tiles):
+            # the messages never reach HBM and the layer is 4 launches instead of 5
+            _, cxe = mlp_ln_fwd(P, pre + ".edge_model.edge_mlp", a_e, E, H, segsum=(m.seg_tile, m.rowptr_dst, scale, agg, e, e_new))
+        else:
+            msg, cxe = mlp_ln_fwd(P, pre + ".edge_model.edge_mlp", a_e, E, H)
+            ops.segment_reduce(msg, m.rowptr_dst, scale, agg, e, e_new, N, E, H)
         a_n = SegList([seg(x), seg(agg)], [x, agg])
         x_new, cxn = mlp_ln_fwd(P, pre + ".node_model.node_mlp_2", a_n, N, H, res=x)
         ctxs.append((cxe, cxn))

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .batch import CrystalBatch, GraphMeta, _EDGE_FIELDS
+from .batch import SEG_TILE_ROWS, CrystalBatch, GraphMeta, _EDGE_FIELDS, seg_tile_bound, seg_tiles_host
 
 
 class DeviceDataset:
@@ -31,6 +31,7 @@ class DeviceDataset:
         self.node_ptr = np.concatenate([[0], np.cumsum(n_nodes)]).astype(np.int64)
         self.edge_ptr = np.concatenate([[0], np.cumsum(n_edges)]).astype(np.int64)
         srcs, dsts, perms, rpd, rps, invd, edge_feats = [], [], [], [], [], [], {k: [] for k in _EDGE_FIELDS}
+        tiles_e, tiles_n, tile_cnt = [], [], []            # per-crystal node-aligned row tiles (message GEMM, EPI_SEGSUM)
         for c in crystals:
             ei = c["edge_index"].numpy().astype(np.int64)
             n = int(c["x"].shape[0])
@@ -41,6 +42,12 @@ class DeviceDataset:
             srcs.append(s); dsts.append(d)
             perms.append(np.argsort(s, kind="stable"))
             rpd.append(np.concatenate([[0], np.cumsum(deg_in)]))
+            if tiles_e is not None:
+                tl = seg_tiles_host(rpd[-1])
+                if tl is None:                               # a node with more incoming edges than a tile holds
+                    tiles_e = tiles_n = None
+                else:
+                    tiles_e.append(tl[0][:-1]); tiles_n.append(tl[1][:-1]); tile_cnt.append(tl.shape[1] - 1)
             rps.append(np.concatenate([[0], np.cumsum(deg_out)]))
             invd.append((1.0 / np.maximum(deg_in, 1)).astype(np.float32))
             for k in _EDGE_FIELDS:
@@ -50,6 +57,11 @@ class DeviceDataset:
         self._src, self._dst, self._perm = i32(srcs), i32(dsts), i32(perms)
         self._rpd, self._rps = i32(rpd), i32(rps)
         self._invd = torch.from_numpy(np.concatenate(invd)).to(self.device)
+        self.tile_cnt = None
+        if tiles_e is not None:
+            self.tile_cnt = np.asarray(tile_cnt, np.int64)
+            self._tile_e, self._tile_n = i32(tiles_e), i32(tiles_n)
+            self._tile_off = torch.from_numpy(np.concatenate([[0], np.cumsum(self.tile_cnt)]).astype(np.int32)).to(self.device)
         self._node_ptr = torch.from_numpy(self.node_ptr.astype(np.int32)).to(self.device)
         self._edge_ptr = torch.from_numpy(self.edge_ptr.astype(np.int32)).to(self.device)
         f = lambda t: (t.to(dtype) if dtype is not None and t.is_floating_point() else t).to(self.device)
@@ -145,8 +157,14 @@ class DeviceDataset:
         out_np = np.concatenate([[0], np.cumsum(nn)]).astype(np.int32)
         out_ep = np.concatenate([[0], np.cumsum(ne)]).astype(np.int32)
         small = scratch["small"]
-        host = torch.from_numpy(np.concatenate([idx.astype(np.int32), out_np, out_ep]))
-        small[:3 * B + 2].copy_(host, non_blocking=True)
+        parts = [idx.astype(np.int32), out_np, out_ep]
+        tiled = m.seg_tile is not None
+        if tiled:
+            if self.tile_cnt is None:
+                raise ValueError("this bucket was set up for tiled message GEMMs but the dataset has no tile tables")
+            parts.append(np.concatenate([[0], np.cumsum(self.tile_cnt[idx])]).astype(np.int32))
+        host = torch.from_numpy(np.concatenate(parts))
+        small[:host.numel()].copy_(host, non_blocking=True)
         d = Collate()
         d.B, d.N, d.E, d.N_pad, d.E_pad, d.n_max = B, int(out_np[-1]), int(out_ep[-1]), m.num_nodes, m.num_edges, m.n_max
         d.Fa, d.Fe, d.S = int(t["x"].shape[1]), int(t["edge"].shape[1]), int(t["target"].shape[1])
@@ -165,6 +183,13 @@ class DeviceDataset:
         for k in ("src", "dst", "perm_src", "rowptr_dst", "rowptr_src", "graph_ptr", "node_graph", "dense_row", "inv_deg"):
             setattr(d, k, getattr(m, k).data_ptr())
         d.node_row, d.edge_row = scratch["node_row"].data_ptr(), scratch["edge_row"].data_ptr()
+        if tiled:
+            d.T, d.tile_rows = int(m.seg_tile.shape[1]) - 1, SEG_TILE_ROWS
+            if int(parts[3][-1]) + max(1, -(-(d.E_pad - d.E) // SEG_TILE_ROWS)) > d.T:
+                raise ValueError("tile table of the bucket is too small for this batch")
+            d.out_tile_ptr = base + 4 * (3 * B + 2)
+            d.tile_off_all, d.tile_e_all, d.tile_n_all = self._tile_off.data_ptr(), self._tile_e.data_ptr(), self._tile_n.data_ptr()
+            d.seg_tile = m.seg_tile.data_ptr()
         ops._call("dosx_collate_padded", C.byref(d), ops._stream(),
                   w=lambda: ("collate_padded", "collate_pad", "hbm", 8.0 * (d.N_pad * d.Fa + d.E_pad * d.Fe)))
 

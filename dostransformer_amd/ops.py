@@ -16,7 +16,7 @@ from . import _lib
 from ._lib import Ffn, BIG, Attn, Gemm, ReduceJob, RowMap, Seg, Wgrad
 
 PRO_NONE, PRO_PRELU, PRO_LN_PRELU, PRO_ROWLN = 0, 1, 2, 3
-EPI_BIAS_ACT, EPI_LN, EPI_PRELU_LN_BWD, EPI_RELU_MASK, EPI_ROWLN_BWD, EPI_PRELU_BWD = 0, 1, 2, 3, 4, 5
+EPI_BIAS_ACT, EPI_LN, EPI_PRELU_LN_BWD, EPI_RELU_MASK, EPI_ROWLN_BWD, EPI_PRELU_BWD, EPI_SEGSUM = 0, 1, 2, 3, 4, 5, 6
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 
 
@@ -289,7 +289,8 @@ def gemm(M: int, N: int, segs: Sequence[Seg], w: torch.Tensor, out: torch.Tensor
          epi: int = EPI_BIAS_ACT, act: int = ACT_NONE, act_slope: float = 0.01, bias=None,
          out_map: Optional[RowMap] = None, res=None, res_map: Optional[RowMap] = None,
          stats_out=None, aux_out=None, aux=None, aux_stats=None, epi_gamma=None, epi_beta=None,
-         epi_alpha=None, partials=None, partial_ld: int = 0, res_col0: int = 0, keep: Optional[list] = None) -> None:
+         epi_alpha=None, partials=None, partial_ld: int = 0, res_col0: int = 0, seg_tile=None, seg_rowptr=None,
+         seg_scale=None, seg_agg=None, keep: Optional[list] = None) -> None:
     """out[M,N] = epilogue(prologue(A) @ B); see include/dosx.h:DosxGemm."""
     g = Gemm()
     g.M, g.N = int(M), int(N)
@@ -302,7 +303,7 @@ def gemm(M: int, N: int, segs: Sequence[Seg], w: torch.Tensor, out: torch.Tensor
     g.w, g.ldw, g.w_layout = w.data_ptr(), int(w.stride(0)), int(w_layout)
     g.epi, g.act, g.act_slope = epi, act, float(act_slope)
     g.bias = _p(bias)
-    g.out, g.ldo = out.data_ptr(), int(out.stride(0))
+    g.out, g.ldo = (out.data_ptr(), int(out.stride(0))) if out is not None else (None, int(N))
     g.out_map = out_map if out_map is not None else ident()
     g.res = _p(res)
     g.ldr = int(res.stride(0)) if res is not None else 0
@@ -314,6 +315,9 @@ def gemm(M: int, N: int, segs: Sequence[Seg], w: torch.Tensor, out: torch.Tensor
     g.epi_gamma, g.epi_beta, g.epi_alpha = _p(epi_gamma), _p(epi_beta), _p(epi_alpha)
     g.partials, g.partial_ld = _p(partials), int(partial_ld)
     g.res_col0 = int(res_col0)
+    if seg_tile is not None:            # EPI_SEGSUM: [2, T+1] node-aligned tile table
+        g.seg_tile, g.seg_ntiles = seg_tile.data_ptr(), int(seg_tile.shape[1]) - 1
+        g.seg_rowptr, g.seg_scale, g.seg_agg = _p(seg_rowptr), _p(seg_scale), _p(seg_agg)
     _call("dosx_gemm", C.byref(g), _stream(), w=lambda: _gemm_work(g))
 
 

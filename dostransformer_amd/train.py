@@ -25,7 +25,7 @@ import torch
 from . import functional as Fn
 from . import ops
 from ._models import DOSTransformerBase
-from .batch import CrystalBatch, GraphMeta, bucket_sizes, graph_meta, pad_batch
+from .batch import CrystalBatch, GraphMeta, bucket_sizes, graph_meta, pad_batch, seg_tile_bound
 
 _EARLY_REDUCE = __import__("os").environ.get("DOSX_EARLY_REDUCE", "1") == "1"
 _META_TENSORS = ("src", "dst", "rowptr_dst", "perm_src", "rowptr_src", "graph_ptr", "node_graph", "dense_row", "inv_deg")
@@ -47,7 +47,8 @@ class _Slot:
         f["system"] = f["system"].to(torch.int32)                   # what the kernels index with
         f["edge_index"], f["batch"] = g.edge_index, g.batch         # never read by the kernels
         meta = GraphMeta(num_nodes=m.num_nodes, num_edges=m.num_edges, num_graphs=m.num_graphs, n_max=m.n_max,
-                         edge_perm=None, **{k: getattr(m, k).clone() for k in _META_TENSORS})
+                         edge_perm=None, seg_tile=None if m.seg_tile is None else m.seg_tile.clone(),
+                         **{k: getattr(m, k).clone() for k in _META_TENSORS})
         self.g = CrystalBatch(f, g.num_graphs, meta)
         self.graph_a = self.graph_b = None
         self.prog_a = self.prog_b = None
@@ -56,7 +57,8 @@ class _Slot:
         self.scratch = None
 
     @classmethod
-    def empty(cls, kind: str, device, B: int, n_pad: int, e_pad: int, n_max: int, Fa: int, Fe: int, S: int) -> "_Slot":
+    def empty(cls, kind: str, device, B: int, n_pad: int, e_pad: int, n_max: int, Fa: int, Fe: int, S: int,
+              tiled: bool = False) -> "_Slot":
         """Uninitialised static buffers of a bucket, to be filled by ``DeviceDataset.collate_into`` (no source batch)."""
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
         i32 = lambda *s: torch.empty(*s, dtype=torch.int32, device=device)
@@ -68,7 +70,8 @@ class _Slot:
         meta = GraphMeta(num_nodes=n_pad, num_edges=e_pad, num_graphs=B, n_max=n_max, edge_perm=None,
                          src=i32(e_pad), dst=i32(e_pad), rowptr_dst=i32(n_pad + 1), perm_src=i32(e_pad),
                          rowptr_src=i32(n_pad + 1), graph_ptr=i32(B + 1), node_graph=i32(n_pad), dense_row=i32(n_pad),
-                         inv_deg=f32(n_pad))
+                         inv_deg=f32(n_pad),
+                         seg_tile=i32(2, seg_tile_bound(n_pad, e_pad, B) + 1) if tiled else None)
         self = cls.__new__(cls)
         self.fields = [k for k in f if k not in ("edge_index", "batch")]
         self.g = CrystalBatch(f, B, meta)
@@ -76,7 +79,7 @@ class _Slot:
         self.prog_a = self.prog_b = None
         self.plan = []
         self.keep = None
-        self.scratch = {"small": i32(3 * B + 2), "node_row": i32(n_pad), "edge_row": i32(e_pad)}
+        self.scratch = {"small": i32(4 * B + 3), "node_row": i32(n_pad), "edge_row": i32(e_pad)}
         return self
 
     def load(self, g: CrystalBatch) -> None:
@@ -86,6 +89,10 @@ class _Slot:
         pairs = []
         m, sm = g.meta, self.g.meta
         items = [(self.g[k], g[k]) for k in self.fields] + [(getattr(sm, k), getattr(m, k)) for k in _META_TENSORS]
+        if sm.seg_tile is not None:
+            if m.seg_tile is None or m.seg_tile.shape != sm.seg_tile.shape:
+                raise ValueError("batch without (matching) message-GEMM tile table loaded into a bucket recorded with one")
+            items.append((sm.seg_tile, m.seg_tile))
         for dst, src in items:
             if src.dtype == dst.dtype and src.device == dst.device and src.is_contiguous() and src.shape == dst.shape:
                 pairs.append((dst, src))
@@ -363,7 +370,7 @@ class Trainer:
             g = pad_batch(g, *bucket_sizes(m.num_nodes, m.num_edges, *self.bucket))
             m = g.meta
         ng = self._n_global(m.num_graphs, n_global, g)
-        key = (m.num_nodes, m.num_edges, m.num_graphs, m.n_max, ng)
+        key = (m.num_nodes, m.num_edges, m.num_graphs, m.n_max, ng, m.seg_tile is not None)
         slot = self._lookup(key)
         fresh = slot is None
         if fresh:
@@ -391,17 +398,18 @@ class Trainer:
         B = int(idx.shape[0])
         n_pad, e_pad = bucket_sizes(N, E, *self.bucket)
         ng = int(n_global) if n_global is not None else (self.dist.global_count(B) if self.dist is not None else B)
-        key = (n_pad, e_pad, B, n_max, ng)
+        tiled = ds.tile_cnt is not None
+        key = (n_pad, e_pad, B, n_max, ng, tiled)
         slot = self._lookup(key)
         fresh = slot is None
         if fresh:
             t = ds._f32_tables()
             slot = _Slot.empty(self.kind, dev, B, n_pad, e_pad, n_max, int(t["x"].shape[1]), int(t["edge"].shape[1]),
-                               int(t["target"].shape[1]))
+                               int(t["target"].shape[1]), tiled=tiled)
             self._slots[key] = slot
         elif getattr(slot, "scratch", None) is None:               # bucket first filled from a batch object
             i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)
-            slot.scratch = {"small": i32(3 * B + 2), "node_row": i32(n_pad), "edge_row": i32(e_pad)}
+            slot.scratch = {"small": i32(4 * B + 3), "node_row": i32(n_pad), "edge_row": i32(e_pad)}
         ds.collate_into(slot.g, idx, slot.scratch)
         self._bump_dropout_seed()
         loss = self._run_slot(slot, fp, ng, fresh)

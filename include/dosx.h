@@ -62,7 +62,12 @@ enum {
   DOSX_EPI_PRELU_LN_BWD = 2, /* acc = dL/d prelu(y), y = xhat*g+b  ->  out = dL/dz (pre-LN)          */
   DOSX_EPI_RELU_MASK = 3,    /* out = acc * (aux > 0)                                                 */
   DOSX_EPI_ROWLN_BWD = 4,    /* acc = dL/d LN(x) -> out = res + dL/dx ; x = aux, stats = aux_stats    */
-  DOSX_EPI_PRELU_BWD = 5     /* out = acc * (aux >= 0 ? 1 : alpha); partial dalpha                    */
+  DOSX_EPI_PRELU_BWD = 5,    /* out = acc * (aux >= 0 ? 1 : alpha); partial dalpha                    */
+  DOSX_EPI_SEGSUM = 6        /* message GEMM of a GNN layer with the aggregation in its epilogue (a5 + a6):
+                                msg = acc + bias stays in LDS;  seg_agg[n] = seg_scale[n] * sum_{e in seg(n)} msg[e];
+                                out = msg + res (the edge residual e' = e + msg) unless out is NULL.  Row tiles are
+                                node-aligned: workgroup t owns rows [seg_tile[t], seg_tile[t+1]) (<= 48) = the whole
+                                destination segments of the nodes [seg_tile[T+1+t], seg_tile[T+2+t]), T = seg_ntiles    */
 };
 
 /* C[M,N] = epilogue( prologue(A)[M,K] * B ),  fp32 MFMA (v_mfma_f32_32x32x2_f32).
@@ -100,6 +105,12 @@ typedef struct DosxGemm {
   const float* epi_alpha;
   float* partials;    /* per-workgroup partial sums: row wg = [dgamma(N) | dbeta(N) | dalpha] */
   int32_t partial_ld;
+  /* EPI_SEGSUM only */
+  const int32_t* seg_tile;   /* [2][seg_ntiles + 1]: row (edge) boundaries, then node boundaries, of the node-aligned tiles */
+  int32_t seg_ntiles;
+  const int32_t* seg_rowptr; /* [nodes + 1] CSR by destination */
+  const float* seg_scale;    /* [nodes] 1/max(in-degree,1) for scatter_mean, NULL for scatter_sum */
+  float* seg_agg;            /* [nodes, N] */
   int32_t res_col0;   /* EPI_BIAS_ACT: the residual is added to the output columns [res_col0, N) only, res column c
                          to output column res_col0 + c (0 = all columns).  The backward of the edge residual
                          e += e' (DOSTransformer_phonon.py:84) rides on the e-block of the [E,3H] concat gradient. */
@@ -421,6 +432,16 @@ typedef struct DosxCollate {
   float* inv_deg;
   int32_t* node_row;
   int32_t* edge_row;
+  /* optional: node-aligned row tiles of the message GEMM (DosxGemm EPI_SEGSUM), seg_tile [2][T+1] (NULL = skip).  Crystal c
+   * owns the tiles [tile_off_all[c], tile_off_all[c+1]) of tile_e_all / tile_n_all (crystal-local START edge / node of each
+   * tile); out_tile_ptr [B+1] = prefix sums of the selected crystals' tile counts; ghost edges follow in tile_rows-row
+   * tiles, the first of which owns every ghost node; the remaining slots are empty. */
+  int32_t T, tile_rows;
+  const int32_t* out_tile_ptr;
+  const int32_t* tile_off_all;
+  const int32_t* tile_e_all;
+  const int32_t* tile_n_all;
+  int32_t* seg_tile;
 } DosxCollate;
 int dosx_collate_padded(const DosxCollate* d, dosx_stream_t stream);
 

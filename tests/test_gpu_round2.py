@@ -184,7 +184,8 @@ def test_collate_into_matches_pad_batch(kind):
         idx, N, E, n_max = ds.bucket_dims(sel, n_max=45)
         n_pad, e_pad = bucket_sizes(N, E, 16, 256)
         t = ds._f32_tables()
-        slot = _Slot.empty(kind, DEV, len(sel), n_pad, e_pad, n_max, t["x"].shape[1], t["edge"].shape[1], t["target"].shape[1])
+        slot = _Slot.empty(kind, DEV, len(sel), n_pad, e_pad, n_max, t["x"].shape[1], t["edge"].shape[1], t["target"].shape[1],
+                           tiled=True)
         for v in list(slot.g._fields.values()) + [getattr(slot.g.meta, k) for k in _META_TENSORS]:
             if torch.is_tensor(v):
                 v.fill_(77)                                  # stale contents of a previous batch must all be overwritten
@@ -197,6 +198,18 @@ def test_collate_into_matches_pad_batch(kind):
         for k in _META_TENSORS:
             assert torch.equal(getattr(slot.g.meta, k).cpu(), getattr(ref.meta, k)), (k, sel)
         assert (slot.g.meta.num_nodes, slot.g.meta.num_edges, slot.g.meta.n_max) == (ref.meta.num_nodes, ref.meta.num_edges, 45)
+        # node-aligned row tiles of the message GEMM: the device tiling is crystal-aligned, the host one greedy over the whole
+        # batch - different tables, both valid: monotone, <= 48 rows, tile edges = CSR pointers of its node range, full cover
+        from dostransformer_amd.batch import SEG_TILE_ROWS
+        for tt, nreal in ((slot.g.meta.seg_tile.cpu().numpy(), N), (ref.meta.seg_tile.numpy(), N)):
+            eb, nb = tt[0], tt[1]
+            rp = ref.meta.rowptr_dst.numpy()
+            assert eb[0] == 0 and nb[0] == 0 and eb[-1] == e_pad and nb[-1] == n_pad
+            assert (np.diff(eb) >= 0).all() and (np.diff(nb) >= 0).all() and np.diff(eb).max() <= SEG_TILE_ROWS
+            real = int(np.searchsorted(nb, nreal, side="left"))           # first boundary that reaches the real node count
+            assert nb[real] == nreal and eb[real] == E
+            assert (eb[:real + 1] == rp[nb[:real + 1]]).all()
+        assert slot.g.meta.seg_tile.shape == ref.meta.seg_tile.shape
 
 
 @pytest.mark.parametrize("kind", ["phonon", "edos"])
@@ -204,6 +217,7 @@ def test_step_dataset_is_the_step_on_the_collated_batch(kind):
     """Trainer.step_dataset(ds, indices) (collate into the bucket + replay) leaves bitwise the parameters of
     Trainer.step(pad_batch(ds.collate(indices))) — over shuffled epochs that revisit buckets."""
     from dostransformer_amd import synth
+    from dostransformer_amd.batch import collate
     from dostransformer_amd.loader import DeviceDataset
     from dostransformer_amd.train import Trainer
     if kind == "phonon":
@@ -228,7 +242,7 @@ def test_step_dataset_is_the_step_on_the_collated_batch(kind):
         for i in range(0, 24, 6):
             sel = order[i:i + 6]
             la = ta.step_dataset(ds, sel, n_max=nmax)
-            lb = tb.step(ds.collate(sel, n_max=nmax))
+            lb = tb.step(collate([cs[j] for j in sel], n_max=nmax).to(DEV))       # host collate: greedy tiles, same bits
             assert float(la) == float(lb), (epoch, i)
     assert ta.slot_hits > 0 and len(ta._slots) < 12
     for (k, a), (_, b) in zip(m_a.state_dict().items(), m_b.state_dict().items()):
@@ -550,3 +564,41 @@ def test_edge_embed_matches_feature_kernel_plus_gemm():
     assert float((z - ref_z).abs().max()) < 1e-6 * float(ref_z.abs().max())
     z64 = ref_attr.double() @ w0.double().T + b0.double()
     assert float((z.double() - z64).abs().max()) < 2e-6 * float(z64.abs().max())
+
+
+@pytest.mark.parametrize("H,mean", [(128, True), (64, False), (256, False), (16, True)])
+def test_message_gemm_with_segment_sum_epilogue(H, mean):
+    """DosxGemm EPI_SEGSUM (second Linear of the edge MLP + scatter_mean / scatter_sum by destination + edge residual in one
+    launch, node-aligned row tiles) == the same GEMM followed by dosx_segment_reduce; also on a ghost-padded batch and with
+    the residual output switched off (last layer)."""
+    from dostransformer_amd import functional as Fn, ops, synth
+    from dostransformer_amd.batch import bucket_sizes, pad_batch
+    g = synth.phonon_batch(9, seed=5, dtype=torch.float32)
+    for padded in (False, True):
+        b = pad_batch(g, *bucket_sizes(g.meta.num_nodes, g.meta.num_edges, 16, 256)) if padded else g
+        m = b.meta.to(DEV)
+        N, E = m.num_nodes, m.num_edges
+        gen = torch.Generator().manual_seed(1)
+        P = {"k.0.weight": torch.randn(2 * H, 3 * H, generator=gen) * 0.1, "k.0.bias": torch.randn(2 * H, generator=gen),
+             "k.1.weight": torch.randn(2 * H, generator=gen), "k.1.bias": torch.randn(2 * H, generator=gen),
+             "k.2.weight": torch.tensor([0.25]), "k.3.weight": torch.randn(H, 2 * H, generator=gen) * 0.1,
+             "k.3.bias": torch.randn(H, generator=gen)}
+        P = {k: v.to(DEV) for k, v in P.items()}
+        x = torch.randn(N, H, generator=gen).to(DEV)
+        e = torch.randn(E, H, generator=gen).to(DEV)
+        a = Fn.SegList([ops.seg(x, rmap=ops.rowmap(idx=m.src)), ops.seg(x, rmap=ops.rowmap(idx=m.dst)), ops.seg(e)], [x, e])
+        scale = m.inv_deg if mean else None
+        msg, _ = Fn.mlp_ln_fwd(P, "k", a, E, H)
+        agg0, e0 = torch.empty(N, H, device=DEV), torch.empty(E, H, device=DEV)
+        ops.segment_reduce(msg, m.rowptr_dst, scale, agg0, e, e0, N, E, H)
+        for with_res in (True, False):
+            agg1 = torch.full((N, H), float("nan"), device=DEV)
+            e1 = torch.full((E, H), float("nan"), device=DEV) if with_res else None
+            out, _ = Fn.mlp_ln_fwd(P, "k", a, E, H, segsum=(m.seg_tile, m.rowptr_dst, scale, agg1, e, e1))
+            torch.cuda.synchronize()
+            assert out is None
+            nr = getattr(b, "real_nodes", N)
+            assert bool(torch.isfinite(agg1).all())                    # ghost rows included: finite don't-cares
+            assert float((agg1[:nr] - agg0[:nr]).abs().max()) <= 2e-6 * float(agg0[:nr].abs().max())
+            if with_res:
+                assert torch.equal(e1, e0)                             # same fma chain + the same two adds per element
