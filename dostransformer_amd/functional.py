@@ -166,6 +166,9 @@ def gnn_fwd(P: Params, m: GraphMeta, x: torch.Tensor, e: torch.Tensor, L: int, m
     return x, ctxs
 
 
+_SPLIT_LATE_FLUSH = int(__import__("os").environ.get("DOSX_SPLIT_LATE_FLUSH", "1"))
+
+
 def gnn_bwd(P: Params, G: Params, m: GraphMeta, ctxs, dx: torch.Tensor, sink: GradSink, L: int, mean: bool, H: int):
     """Returns (dL/dx_0 [N,H], dL/de_0 as a strided [E,H] view or None)."""
     N, E = m.num_nodes, m.num_edges
@@ -187,6 +190,10 @@ def gnn_bwd(P: Params, G: Params, m: GraphMeta, ctxs, dx: torch.Tensor, sink: Gr
                        None, N, E, H)
         sink._keep.append(dcat_n)
         dx, de = dx_old, dcat_e[:, 2 * H:]
+        if sink.side is not None and ((_SPLIT_LATE_FLUSH == 1 and l == 1) or (_SPLIT_LATE_FLUSH == 2 and l >= 1)):
+            # the weight gradients of the layers finished so far go to the side stream NOW, underneath the first layer's
+            # backward, instead of all of them at the tail of the step where nothing else is left to overlap with
+            sink.flush_on_side()
     return dx, de
 
 
