@@ -527,8 +527,12 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
     # every key row, so no zero fill; the spare row (dense slot of ghost nodes) is never read (dense_normalize_bwd's ghost_row)
     dkv = _empty(dev, nmax * B + 1, H)
     dhs = encoder_bwd(P, G, "transformer_source", c3, dx, dkv, sink, dkv_fresh=True)
+    if sink.wside is not None:
+        sink.flush_on_side()                  # (weight-gradient stream: this encoder's jobs run under the next one's backward)
     dkvs = _empty(dev, rows2, H)              # self-attention: every row is a key row, the first layer overwrites
     ddosin = encoder_bwd(P, G, "transformer_self", c2, dhs, dkvs, sink, dkv_fresh=True)
+    if sink.wside is not None:
+        sink.flush_on_side()
     sink.join()          # dkvs is produced on the side stream
     dpre = _empty(dev, rows2, H)         # key-side LN backward + the LeakyReLU backward behind it, one launch
     ops.rownorm_bwd_act(dkvs, kvs, rstd_s, ddosin, dosin, 0.01, dpre, rows2, H)

@@ -424,6 +424,11 @@ class GradSink:
     # Off for eagerly issued steps (the host cannot feed two streams from Python: no gain), switched on by
     # train.Trainer while it records a replayed step (1.80 vs 1.88 ms serialised).
     use_side_stream = __import__("os").environ.get("DOSX_SIDE_STREAM", "0") == "1"
+    # ... and the grouped weight-gradient launches + slab reductions on a THIRD stream of their own, flushed after every
+    # encoder stack / GNN layer pair: queued on the side stream they sat in front of the key-gradient reductions the main
+    # stream joins on, on their own stream they fill the CUs the latency-bound dgrad chain leaves idle (cfg2: 1.443 ->
+    # 1.412 ms; round 1 had measured a third stream for the dk/dv CHAIN as a loss: that chain is on the critical path)
+    use_wgrad_stream = __import__("os").environ.get("DOSX_WGRAD_STREAM", "1") == "1"
     _side_streams: dict = {}
 
     def __init__(self, device):
@@ -432,17 +437,29 @@ class GradSink:
         self._keep: List[torch.Tensor] = []
         self.main = torch.cuda.current_stream()
         self.side = None
+        self.wside = None
         if GradSink.use_side_stream:
             key = (str(device), torch.cuda.is_current_stream_capturing())
             if key not in GradSink._side_streams:
                 GradSink._side_streams[key] = torch.cuda.Stream(device=device)
             self.side = GradSink._side_streams[key]
+            if GradSink.use_wgrad_stream:          # a third stream for the grouped weight gradients + slab reductions
+                k2 = key + ("w",)
+                if k2 not in GradSink._side_streams:
+                    GradSink._side_streams[k2] = torch.cuda.Stream(device=device)
+                self.wside = GradSink._side_streams[k2]
         self._forked = False
+        self._wforked = False
 
     @staticmethod
     def side_stream(device):
         """The (process-wide) side stream used by recorded programs on ``device`` (None before the first recording)."""
         return GradSink._side_streams.get((str(device), False))
+
+    @staticmethod
+    def grad_stream(device):
+        """The stream the gradient reductions of recorded programs run on (weight-gradient stream, else the side stream)."""
+        return GradSink._side_streams.get((str(device), False, "w")) or GradSink._side_streams.get((str(device), False))
 
     # Weight-gradient jobs can be collected and issued as ONE grouped launch at the next flush instead of one kernel
     # each on the side stream (DESIGN.md 3.1: interleaved they cost the dgrad chain ~0.45 ms per step of interference).
@@ -504,6 +521,22 @@ class GradSink:
         """Reduce the jobs collected so far WITHOUT joining: the reduction is queued on the side stream behind the
         weight-gradient kernels it depends on (and behind everything the main stream has issued up to here), so the
         main stream runs on.  Used for the early gradient bucket of data-parallel training."""
+        if self.wside is not None:
+            # own stream: ordered after everything issued so far on the main AND the side stream (the slabs of the
+            # attention key gradients are produced there), never in front of the kernels the main stream joins on
+            jobs, self.jobs = self.jobs, []
+            for src in ([self.main, self.side] if self._forked else [self.main]):
+                ev = torch.cuda.Event()
+                ev.record(src)
+                self.wside.wait_event(ev)
+                if RECORDER.active:
+                    RECORDER.prog.append((ev.record, (src,)))
+                    RECORDER.prog.append((self.wside.wait_event, (ev,)))
+            with torch.cuda.stream(self.wside):
+                self.run_grouped()
+                self._reduce(jobs)
+            self._wforked = True
+            return
         self.run_grouped()
         jobs, self.jobs = self.jobs, []
         self.on_side(lambda: self._reduce(jobs))
@@ -511,6 +544,11 @@ class GradSink:
     def flush(self):
         self.run_grouped()
         self.join()
+        if self.wside is not None and self._wforked:
+            self.main.wait_stream(self.wside)
+            if RECORDER.active:
+                RECORDER.prog.append((self.main.wait_stream, (self.wside,)))
+            self._wforked = False
         jobs, self.jobs = self.jobs, []
         self._reduce(jobs)
 

@@ -216,7 +216,7 @@ class Trainer:
             rec = ops.RECORDER.active
             if rec:                                   # the collective is not a libdosx call: split the recording
                 self._rec_parts.append(ops.RECORDER.end())
-            self._start_early(fp, sink.side)
+            self._start_early(fp, sink.wside if sink.wside is not None else sink.side)
             if rec:
                 ops.RECORDER.begin()
         return hook
@@ -349,7 +349,7 @@ class Trainer:
                 elif kind == "sse":
                     self.dist.all_reduce_sse(slot.sse)
                 else:
-                    self._start_early(fp, ops.GradSink.side_stream(fp.flat.device))
+                    self._start_early(fp, ops.GradSink.grad_stream(fp.flat.device))
         else:
             slot.graph_a.replay()
             if slot.graph_b is not None:
