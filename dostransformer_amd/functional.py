@@ -273,7 +273,7 @@ _FUSED_FFN_BWD = __import__("os").environ.get("DOSX_FUSED_FFN_BWD", "1") == "1"
 
 
 def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: torch.Tensor, dkvhat: torch.Tensor, sink: GradSink,
-                dkv_fresh: bool = False):
+                dkv_fresh: bool = False, kv_needed_next: bool = False):
     """dy: grad of the encoder output (after the final LN if there is one).  Accumulates into dkvhat
     (``dkv_fresh``: dkvhat is uninitialised and every row of it is a key row — the first layer processed
     overwrites it, which saves the zero fill).
@@ -344,7 +344,15 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: torch.Tensor, dkvhat: t
         # consumers at the very end) on the side stream, in layer order so dkvhat accumulates in order
         ops.attention_bwd(desc(8))          # DOSX_ATTN_BWD_SKIP_DKV
         a2 = desc(4)                        # DOSX_ATTN_BWD_SKIP_DQ
-        sink.on_side(lambda a2=a2: ops.attention_bwd(a2), (dx1, dxin) + tuple(t_ for t_ in (dsc, mask) if t_ is not None))
+        if kv_needed_next and t == 0:
+            # the caller consumes dkvhat right after this call: the LAST key-gradient kernel runs on the main stream (behind
+            # a join that is already satisfied - the earlier layers' reductions finished long ago) instead of bouncing
+            # main -> side -> main through two cross-queue events
+            sink.join()
+            ops.attention_bwd(a2)
+            sink._keep.extend(t_ for t_ in (dsc, mask) if t_ is not None)
+        else:
+            sink.on_side(lambda a2=a2: ops.attention_bwd(a2), (dx1, dxin) + tuple(t_ for t_ in (dsc, mask) if t_ is not None))
         sink.add(part, 0, G[lp + ".layer_norms.0.weight"], npart, 2 * H, H)
         sink.add(part, H, G[lp + ".layer_norms.0.bias"], npart, 2 * H, H)
         dx = dxin
@@ -530,7 +538,7 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
     if sink.wside is not None:
         sink.flush_on_side()                  # (weight-gradient stream: this encoder's jobs run under the next one's backward)
     dkvs = _empty(dev, rows2, H)              # self-attention: every row is a key row, the first layer overwrites
-    ddosin = encoder_bwd(P, G, "transformer_self", c2, dhs, dkvs, sink, dkv_fresh=True)
+    ddosin = encoder_bwd(P, G, "transformer_self", c2, dhs, dkvs, sink, dkv_fresh=True, kv_needed_next=True)
     if sink.wside is not None:
         sink.flush_on_side()
     sink.join()          # dkvs is produced on the side stream
@@ -558,12 +566,13 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
         ops.embed_rows_bwd(dprow.data_ptr(), hp, sysidx, G[cfg.prompt_key], B, G[cfg.prompt_key].shape[0], hp)
     sink.on_side(_const_inputs_bwd, (dpre, R, dgraph, dprow))
     # first encoder (queries = energy embeddings broadcast over the batch)
-    dX1 = encoder_bwd(P, G, "transformer", c1, dE1, dkv, sink)
-    ops.reduce_rows(dX1.data_ptr(), H, G["embeddings.weight"].data_ptr(), H, S, B, B, 1, H)
+    dX1 = encoder_bwd(P, G, "transformer", c1, dE1, dkv, sink, kv_needed_next=True)
     # Every gradient of the transformer stacks, the heads and the embeddings is complete (or queued on the side
     # stream) here; what follows only touches the GNN trunk's parameters.  mid_hook: data-parallel training reduces
     # and all-reduces that early bucket now, underneath the GNN backward (train.Trainer).
-    sink.join()          # dkv (dense keys) is produced on the side stream
+    sink.join()          # dkv (dense keys): the earlier layers' key-gradient kernels ran on the side stream
+    # gradient of the energy embeddings (sum over the batch): nobody waits for it - side stream, under the GNN backward
+    sink.on_side(lambda: ops.reduce_rows(dX1.data_ptr(), H, G["embeddings.weight"].data_ptr(), H, S, B, B, 1, H), (dX1,))
     if mid_hook is not None:          # (after the join: the early bucket's reduction must not sit between the main
         mid_hook(sink)                #  stream and the dk/dv kernels it is waiting for)
     # node embeddings: dense keys + pooled decoder input (+ external grad on the returned x)
