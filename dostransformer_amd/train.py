@@ -82,13 +82,27 @@ class _Slot:
         self.scratch = {"small": i32(4 * B + 3), "node_row": i32(n_pad), "edge_row": i32(e_pad)}
         return self
 
+    def _as_slot_dtype(self, g: CrystalBatch, k: str) -> torch.Tensor:
+        """Field k of a batch in the dtype the bucket stores.  The int64 -> int32 copy of `system` (the reference's crystal-
+        system index, [B]) is cached on the batch object: batches are revisited every epoch, and a cast per visit is one
+        more kernel in front of every step."""
+        t = g[k]
+        if k != "system" or t.dtype == torch.int32 or not isinstance(g, CrystalBatch):
+            return t
+        c = getattr(g, "_system32", None)
+        if c is None or c[0] is not t:
+            c = (t, t.to(torch.int32))
+            object.__setattr__(g, "_system32", c)
+        return c[1]
+
     def load(self, g: CrystalBatch) -> None:
         """Copy a batch of this bucket's shape into the static buffers: ONE launch for everything that is already in
         the kernels' format (fp32 / int32, contiguous, on the device); fields that need a dtype conversion (fp64
         phonon data, int64 ``system``) or come from elsewhere go through ``Tensor.copy_``."""
         pairs = []
         m, sm = g.meta, self.g.meta
-        items = [(self.g[k], g[k]) for k in self.fields] + [(getattr(sm, k), getattr(m, k)) for k in _META_TENSORS]
+        items = [(self.g[k], self._as_slot_dtype(g, k)) for k in self.fields] + \
+                [(getattr(sm, k), getattr(m, k)) for k in _META_TENSORS]
         if sm.seg_tile is not None:
             if m.seg_tile is None or m.seg_tile.shape != sm.seg_tile.shape:
                 raise ValueError("batch without (matching) message-GEMM tile table loaded into a bucket recorded with one")
