@@ -185,6 +185,8 @@ def gnn_bwd(P: Params, G: Params, m: GraphMeta, ctxs, dx: torch.Tensor, sink: Gr
         # The dgrad GEMM adds dL/de_{l+1} to exactly those columns, so the e-block of dcat_e IS dL/de_l and no kernel
         # ever streams the edge gradient on its own.
         dcat_e = mlp_ln_bwd(P, G, pre + ".edge_model.edge_mlp", cxe, dmsg, sink, res=de, res_col0=2 * H)   # [E, 3H]
+        if l == 0 and sink.wside is not None:
+            sink.flush_on_side()     # layer 0's weight gradients start now, under the gather backward and the encoders' backward
         dx_old = _empty(dev, N, H)
         ops.gather_bwd(dcat_e, dcat_n.data_ptr(), 2 * H, dx, m.rowptr_dst, m.rowptr_src, m.perm_src, None, dx_old,
                        None, N, E, H)
@@ -419,6 +421,7 @@ def gnn_trunk_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta, node_key: str = "GN
     if cfg.kind == "edos":
         glob = _f32(g.glob).reshape(B, 2)
         u, cu = mlp_prelu_fwd(P, "GN_encoder.global_encoder", SegList([seg(glob)], [glob]), B, H)
+
     xL, cg = gnn_fwd(P, m, x0, e0, cfg.L, cfg.mean, H)
     return xL, u, (cn, ce, cu, cg, node_key)
 
