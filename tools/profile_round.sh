@@ -16,7 +16,7 @@ cd "$ROOT"
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_$c" -o pmc -- \
-    python3 "$ROOT/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --launch eager > "$OUT/pmc_$c.log" 2>&1 < /dev/null
+    python3 "$ROOT/bench.py" --steps 20 --warmup 10 --no-cpu-baseline > "$OUT/pmc_$c.log" 2>&1 < /dev/null
 done
 ff=$(find "$OUT/pmc_FETCH_SIZE" -name "*counter_collection.csv" | head -1)
 fw=$(find "$OUT/pmc_WRITE_SIZE" -name "*counter_collection.csv" | head -1)
