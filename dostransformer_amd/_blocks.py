@@ -179,7 +179,7 @@ class NodeModel(nn.Module):
                 ee = ee[m.edge_perm].contiguous()
             agg = ops.alloc(xx.device, N, H)
             ops.segment_reduce(ee, m.rowptr_dst, m.inv_deg if mean else None, agg, None, None, N, m.num_edges, H)
-            y, c = Fn.mlp_ln_fwd(P, "node_mlp_2", Fn.SegList([seg(xx), seg(agg)], [xx, agg]), N, H)
+            y, c = Fn.mlp_ln_fwd(P, "node_mlp_2", Fn.SegList([seg(xx), seg(agg)], [xx, agg], plain=(xx, agg)), N, H)
             return [y], c
 
         def bwd(P, G, c, grads, sink):
@@ -226,7 +226,7 @@ class Processor(nn.Module):
             msg, cxe = Fn.mlp_ln_fwd(P, "edge_model.edge_mlp", a_e, E, H)
             agg = ops.alloc(xx.device, N, H)
             ops.segment_reduce(msg, m.rowptr_dst, scale, agg, None, None, N, E, H)
-            xn, cxn = Fn.mlp_ln_fwd(P, "node_model.node_mlp_2", Fn.SegList([seg(xx), seg(agg)], [xx, agg]), N, H)
+            xn, cxn = Fn.mlp_ln_fwd(P, "node_model.node_mlp_2", Fn.SegList([seg(xx), seg(agg)], [xx, agg], plain=(xx, agg)), N, H)
             e_out = msg
             if m.edge_perm is not None:                      # back to the caller's edge order
                 e_out = torch.empty_like(msg)

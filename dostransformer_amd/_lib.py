@@ -114,6 +114,34 @@ class Ffn(C.Structure):
     ]
 
 
+class MlpLn(C.Structure):
+    _fields_ = [
+        ("M", C.c_int32), ("K", C.c_int32), ("NH", C.c_int32), ("NO", C.c_int32), ("k0", C.c_int32),
+        ("a0", C.c_void_p), ("lda0", C.c_int32),
+        ("a1", C.c_void_p), ("lda1", C.c_int32),
+        ("w1", C.c_void_p), ("b1", C.c_void_p),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("alpha", C.c_void_p),
+        ("w2", C.c_void_p), ("b2", C.c_void_p),
+        ("res", C.c_void_p), ("ldres", C.c_int32),
+        ("xhat", C.c_void_p), ("rstd", C.c_void_p),
+        ("out", C.c_void_p), ("ldo", C.c_int32),
+    ]
+
+
+class MlpLnBwd(C.Structure):
+    _fields_ = [
+        ("M", C.c_int32), ("K", C.c_int32), ("NH", C.c_int32), ("NO", C.c_int32),
+        ("dy", C.c_void_p), ("lddy", C.c_int32),
+        ("xhat", C.c_void_p), ("rstd", C.c_void_p),
+        ("w1", C.c_void_p), ("w2", C.c_void_p),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p), ("alpha", C.c_void_p),
+        ("dz", C.c_void_p),
+        ("dcat", C.c_void_p), ("lddcat", C.c_int32),
+        ("partials", C.c_void_p), ("partial_ld", C.c_int32),
+    ]
+
+
 class CopyJob(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("dwords", C.c_int64)]
 
@@ -176,6 +204,10 @@ _SIGS = {
     "dosx_ffn_fwd": [C.POINTER(Ffn), _P],
     "dosx_ffn_bwd_partial_rows": [_I],
     "dosx_ffn_bwd": [C.POINTER(FfnBwd), _P],
+    "dosx_mlp_ln_supported": [_I, _I, _I],
+    "dosx_mlp_ln_fwd": [C.POINTER(MlpLn), _P],
+    "dosx_mlp_ln_bwd_partial_rows": [_I],
+    "dosx_mlp_ln_bwd": [C.POINTER(MlpLnBwd), _P],
     "dosx_csr_workspace_bytes": [_I, C.POINTER(C.c_size_t)],
     "dosx_csr_build": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P],
     "dosx_collate": [_P] * 5 + [_I] * 3 + [_P] * 18 + [_P],

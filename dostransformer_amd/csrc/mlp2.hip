@@ -1,0 +1,452 @@
+// Linear -> LayerNorm -> PReLU -> Linear (+ residual) in ONE launch for small row counts: the NodeModel MLP of a
+// message-passing layer (DOSTransformer_phonon.py:200-212 / DOSTransformer.py:178-190: node_mlp_2 on cat[x, agg]).
+//
+//     z    = [a0 | a1] . W1^T + b1                 [M,NH]
+//     xhat = LN_noaffine(z), rstd                  (saved: the backward and the weight gradients read them)
+//     out  = prelu(xhat*gamma + beta) . W2^T + b2 (+ res)          [M,NO]
+//
+// A batch has a few hundred nodes (cfg2: 450), so each of the two dosx_gemm launches this replaces was one partial
+// round of 16-row workgroups whose duration is the fixed part of a launch (~9.7 us each + the gap between them); here a
+// workgroup keeps its 16 x NH intermediate tile in LDS between the two products and all 8 waves multiply (16x16x4 MFMA),
+// each pulling the weight fragments of its own columns straight from L2 (see mlp_ln_fwd_kernel).
+// The backward kernel is the mirror image: da = dy . W2 -> PReLU / LayerNorm backward on the LDS tile (dz written out for
+// the W1 weight gradient, dgamma | dbeta | dalpha partial sums per workgroup) -> dcat = dz . W1.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int MR = 16;           // rows per workgroup
+constexpr int NCG = 2;           // float4 column groups per lane in the row phases (NH <= 512)
+constexpr int WQ = 64;           // k extent of one weight chunk
+constexpr int WLD_NK = WQ + 4;   // padded row of an [n][k] chunk in LDS
+constexpr int WLD_KN = 32 + 4;   // padded row of a [k][n] chunk in LDS
+constexpr int WP_FLOATS = 32 * WLD_NK > WQ * WLD_KN ? 32 * WLD_NK : WQ * WLD_KN;     // one wave's private chunk buffer
+
+// At 16 rows per workgroup a weight element is used by exactly ONE wave (the one that owns its output column), so the
+// weights need no workgroup-wide staging: every wave streams the chunks of its own NC columns global -> registers
+// (coalesced: whole 256-byte / 128-byte row pieces) -> its PRIVATE LDS buffer -> MFMA fragments.  LDS operations of one
+// wave execute in order, so the hand-over needs no s_barrier, only a compiler fence (wave_barrier); loads run one chunk
+// ahead in registers.  All 8 waves multiply; the only workgroup barriers are the three phase boundaries.
+//   version 1 (ffn.hip's recipe: 4 staging + 4 matrix waves, one barrier per chunk): 14 us forward at M = 424;
+//   version 2 (B fragments straight from global memory, 16 cache lines per load instruction): 17 us;
+//   the two dosx_gemm launches this kernel replaces: 9.7 + 9.6 us + the gap between them.
+
+// acc[t] += As[16][kdim] . W[col_base + 16 t + (0..15)][0..kdim)^T,  W row-major [n][ldw]  (nn.Linear weight)
+template <int NC>
+__device__ __forceinline__ void wave_gemm_nk(f32x4 (&acc)[NC / 16], const float* w, int ldw, int col_base, int kdim,
+                                             const float* As, int lda, float* Wp, int lane) {
+  constexpr int NR = NC / 4;                       // float4 per lane per chunk (4 rows of 16 lanes per instruction)
+  const int l15 = lane & 15, g4 = lane >> 4;
+  const float* src = w + (size_t)(col_base + g4) * ldw + l15 * 4;
+  float4 r0[NR], r1[NR];
+  auto issue = [&](float4(&r)[NR], int q) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) r[i] = ld4(src + (size_t)(4 * i) * ldw + q * WQ);
+  };
+  auto store = [&](const float4(&r)[NR]) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) st4(Wp + (g4 + 4 * i) * WLD_NK + l15 * 4, r[i]);
+  };
+  auto mma = [&](int q) {
+#pragma unroll
+    for (int kk = 0; kk < WQ; kk += 16) {
+      const float4 av = ld4(As + l15 * lda + q * WQ + kk + 4 * g4);
+#pragma unroll
+      for (int t = 0; t < NC / 16; ++t) {
+        const float4 b = ld4(Wp + (16 * t + l15) * WLD_NK + kk + 4 * g4);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b.x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b.y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b.z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b.w, acc[t], 0, 0, 0);
+      }
+    }
+  };
+  const int nq = kdim / WQ;
+  issue(r0, 0);
+  for (int q = 0; q < nq; q += 2) {
+    if (q + 1 < nq) issue(r1, q + 1);
+    store(r0);
+    __builtin_amdgcn_wave_barrier();
+    mma(q);
+    __builtin_amdgcn_wave_barrier();
+    if (q + 1 >= nq) break;
+    if (q + 2 < nq) issue(r0, q + 2);
+    store(r1);
+    __builtin_amdgcn_wave_barrier();
+    mma(q + 1);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// acc[t] += As[16][kdim] . W[0..kdim)[col_base + 16 t + (0..15)],  W row-major [k][ldw]  (a stored weight read as its
+// transpose: the dgrad products).  32 columns per wave.
+__device__ __forceinline__ void wave_gemm_kn(f32x4 (&acc)[2], const float* w, int ldw, int col_base, int kdim, const float* As,
+                                             int lda, float* Wp, int lane) {
+  constexpr int NR = 8;                            // 8 k rows of 8 lanes per instruction, 64 rows per chunk
+  const int l15 = lane & 15, g4 = lane >> 4, kr = lane >> 3, n4 = (lane & 7) * 4;
+  const float* src = w + (size_t)kr * ldw + col_base + n4;
+  float4 r0[NR], r1[NR];
+  auto issue = [&](float4(&r)[NR], int q) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) r[i] = ld4(src + (size_t)(q * WQ + 8 * i) * ldw);
+  };
+  auto store = [&](const float4(&r)[NR]) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) st4(Wp + (kr + 8 * i) * WLD_KN + n4, r[i]);
+  };
+  auto mma = [&](int q) {
+#pragma unroll
+    for (int kk = 0; kk < WQ; kk += 16) {
+      const float4 av = ld4(As + l15 * lda + q * WQ + kk + 4 * g4);
+      const float* bp = Wp + (kk + 4 * g4) * WLD_KN + l15;
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bp[0], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bp[16], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bp[WLD_KN], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bp[WLD_KN + 16], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bp[2 * WLD_KN], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bp[2 * WLD_KN + 16], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bp[3 * WLD_KN], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bp[3 * WLD_KN + 16], acc[1], 0, 0, 0);
+    }
+  };
+  const int nq = kdim / WQ;
+  issue(r0, 0);
+  for (int q = 0; q < nq; q += 2) {
+    if (q + 1 < nq) issue(r1, q + 1);
+    store(r0);
+    __builtin_amdgcn_wave_barrier();
+    mma(q);
+    __builtin_amdgcn_wave_barrier();
+    if (q + 1 >= nq) break;
+    if (q + 2 < nq) issue(r0, q + 2);
+    store(r1);
+    __builtin_amdgcn_wave_barrier();
+    mma(q + 1);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+__global__ __launch_bounds__(512) void mlp_ln_fwd_kernel(const DosxMlpLn a) {
+  extern __shared__ __align__(16) float sm[];
+  const int K = a.K, NH = a.NH, NO = a.NO, M = a.M;
+  const int LDX = K + 4, LDT = NH + 4, LDC = NO + 4;
+  float* Xs = sm;                                  // [16][LDX]  input tile (A operand of the first product); later the C tile
+  float* T = Xs + MR * LDX;                        // [16][LDT]  z -> prelu(LN(z)) (A operand of the second product)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+  float* Wp = T + MR * LDT + wave * WP_FLOATS;     // this wave's private weight-chunk buffer
+  const int m0 = blockIdx.x * MR;
+
+  // epilogue operands of this wave's 2 rows, fetched at kernel start
+  const int c0 = lane * 4;
+  const bool con = c0 < NO;
+  float4 rres[2], bias2 = f4zero();
+  if (con) bias2 = ld4(a.b2 + c0);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = min(m0 + wave * 2 + i, M - 1);
+    rres[i] = f4zero();
+    if (a.res) rres[i] = ld4(a.res + (size_t)r * a.ldres + (con ? c0 : 0));
+  }
+  // operands of the row phase (rows 2*wave, 2*wave+1; columns lane*4 + 256 j)
+  float4 gam[NCG], bet[NCG];
+  bool on[NCG];
+#pragma unroll
+  for (int j = 0; j < NCG; ++j) {
+    const int c = lane * 4 + 256 * j;
+    on[j] = c < NH;
+    gam[j] = ld4(a.gamma + (on[j] ? c : 0));
+    bet[j] = ld4(a.beta + (on[j] ? c : 0));
+  }
+  const float alpha = *a.alpha;
+  {   // [a0 | a1] tile -> Xs   (row r = tid/32, 4-float groups tid%32 + 32 i)
+    const int r = tid >> 5, rr = min(m0 + r, M - 1);
+    for (int c = (tid & 31) * 4; c < K; c += 128) {
+      const float* p = c < a.k0 ? a.a0 + (size_t)rr * a.lda0 + c : a.a1 + (size_t)rr * a.lda1 + (c - a.k0);
+      st4(Xs + r * LDX + c, ld4(p));
+    }
+  }
+  __syncthreads();                                         // Xs visible
+  // ---- first product: 256-column blocks (this wave: columns wave*32 .. +31 of the block = two 16-column tiles) ----
+  for (int blk = 0; blk * 256 < NH; ++blk) {
+    const int cb = blk * 256 + wave * 32;
+    const bool cok = cb < NH;                              // (wave-uniform: NH is a multiple of 128)
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const float b1a = a.b1[(cok ? cb : 0) + l15], b1b = a.b1[(cok ? cb : 0) + l15 + 16];
+    wave_gemm_nk<32>(acc, a.w1, K, cok ? cb : 0, K, Xs, LDX, Wp, lane);
+    if (cok) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        T[(4 * g4 + r) * LDT + cb + l15] = acc[0][r] + b1a;
+        T[(4 * g4 + r) * LDT + cb + l15 + 16] = acc[1][r] + b1b;
+      }
+    }
+  }
+  __syncthreads();                                         // z tile complete
+  // ---- row phase: LayerNorm statistics (two-pass, like torch) -> xhat, rstd out; prelu(xhat*gamma+beta) -> T ----
+  {
+    const float invN = 1.f / (float)NH;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int lr = wave * 2 + i, r = m0 + lr;
+      float4 z[NCG];
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < NCG; ++j) {
+        z[j] = f4zero();
+        if (on[j]) {
+          z[j] = ld4(T + lr * LDT + lane * 4 + 256 * j);
+          s += (z[j].x + z[j].y) + (z[j].z + z[j].w);
+        }
+      }
+      const float mean = wave_sum(s) * invN;
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < NCG; ++j) {
+        if (on[j]) {
+          z[j] = make_float4(z[j].x - mean, z[j].y - mean, z[j].z - mean, z[j].w - mean);
+          q += (z[j].x * z[j].x + z[j].y * z[j].y) + (z[j].z * z[j].z + z[j].w * z[j].w);
+        }
+      }
+      const float rstd = rsqrtf(wave_sum(q) * invN + DOSX_LN_EPS);
+#pragma unroll
+      for (int j = 0; j < NCG; ++j) {
+        if (!on[j]) continue;
+        const float4 xh = make_float4(z[j].x * rstd, z[j].y * rstd, z[j].z * rstd, z[j].w * rstd);
+        if (r < M) st4(a.xhat + (size_t)r * NH + lane * 4 + 256 * j, xh);
+        float4 y = make_float4(xh.x * gam[j].x + bet[j].x, xh.y * gam[j].y + bet[j].y, xh.z * gam[j].z + bet[j].z,
+                               xh.w * gam[j].w + bet[j].w);
+        y.x = y.x >= 0.f ? y.x : alpha * y.x; y.y = y.y >= 0.f ? y.y : alpha * y.y;
+        y.z = y.z >= 0.f ? y.z : alpha * y.z; y.w = y.w >= 0.f ? y.w : alpha * y.w;
+        st4(T + lr * LDT + lane * 4 + 256 * j, y);
+      }
+      if (lane == 0 && r < M) a.rstd[r] = rstd;
+    }
+  }
+  __syncthreads();                                         // activated tile complete
+  // ---- second product: 128-column blocks (this wave: one 16-column tile), A operand = T; C tile -> Xs ----
+  float* Cs = Xs;
+  for (int blk = 0; blk * 128 < NO; ++blk) {
+    const int oc = blk * 128 + wave * 16;
+    const bool ook = oc < NO;
+    f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+    wave_gemm_nk<16>(acc, a.w2, NH, ook ? oc : 0, NH, T, LDT, Wp, lane);
+    if (ook) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cs[(4 * g4 + r) * LDC + oc + l15] = acc[0][r];
+    }
+  }
+  __syncthreads();
+  // ---- row epilogue (8 waves x 2 rows): out = C + b2 (+ res) ----
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int lr = wave * 2 + i, r = m0 + lr;
+    if (con && r < M) {
+      const float4 v = ld4(Cs + lr * LDC + c0);
+      st4(a.out + (size_t)r * a.ldo + c0, make_float4(v.x + bias2.x + rres[i].x, v.y + bias2.y + rres[i].y,
+                                                       v.z + bias2.z + rres[i].z, v.w + bias2.w + rres[i].w));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Backward:  da = dy . W2 ;  dy' = da o prelu'(xhat*gamma+beta) ;  dz = LN_bwd(dy' * gamma)  (written out) ;
+//            dcat = dz . W1 ;  partials[wg] = [ sum dy'*xhat (NH) | sum dy' (NH) | pad | sum_{y<0} da*y ]
+// Both weight matrices are read as stored (k-major for these products: W2 [NO][NH], W1 [NH][K]).
+__global__ __launch_bounds__(512) void mlp_ln_bwd_kernel(const DosxMlpLnBwd a) {
+  extern __shared__ __align__(16) float sm[];
+  const int K = a.K, NH = a.NH, NO = a.NO, M = a.M;
+  const int LDY = NO + 4, LDT = NH + 4;
+  float* Ys = sm;                                  // [16][LDY]  dy tile
+  float* T = Ys + MR * LDY;                        // [16][LDT]  da -> dz
+  float* Ps = T + MR * LDT;                        // [8][2][NH] column sums of the 8 waves + 8 dalpha terms
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+  float* Wp = Ps + 16 * NH + 8 + wave * WP_FLOATS; // this wave's private weight-chunk buffer
+  const int m0 = blockIdx.x * MR;
+
+  // operands of the row phase (rows 2*wave, 2*wave+1; columns lane*4 + 256 j), in flight under the first product
+  float4 gam[NCG], bet[NCG], xh[2][NCG];
+  float rs[2];
+  bool on[NCG];
+#pragma unroll
+  for (int j = 0; j < NCG; ++j) {
+    const int c = lane * 4 + 256 * j;
+    on[j] = c < NH;
+    gam[j] = ld4(a.gamma + (on[j] ? c : 0));
+    bet[j] = ld4(a.beta + (on[j] ? c : 0));
+  }
+  const float alpha = *a.alpha;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = min(m0 + wave * 2 + i, M - 1);
+    rs[i] = a.rstd[r];
+#pragma unroll
+    for (int j = 0; j < NCG; ++j) xh[i][j] = ld4(a.xhat + (size_t)r * NH + (on[j] ? lane * 4 + 256 * j : 0));
+  }
+  {   // dy tile -> Ys
+    const int r = tid >> 5, rr = min(m0 + r, M - 1);
+    for (int c = (tid & 31) * 4; c < NO; c += 128) st4(Ys + r * LDY + c, ld4(a.dy + (size_t)rr * a.lddy + c));
+  }
+  __syncthreads();                                         // Ys visible
+  // ---- first product: da tile, 256-column blocks (this wave: two 16-column tiles), k over NO ----
+  for (int blk = 0; blk * 256 < NH; ++blk) {
+    const int cb = blk * 256 + wave * 32;
+    const bool cok = cb < NH;
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    wave_gemm_kn(acc, a.w2, NH, cok ? cb : 0, NO, Ys, LDY, Wp, lane);
+    if (cok) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        T[(4 * g4 + r) * LDT + cb + l15] = acc[0][r];
+        T[(4 * g4 + r) * LDT + cb + l15 + 16] = acc[1][r];
+      }
+    }
+  }
+  __syncthreads();                                         // da tile complete
+  // ---- row phase: PReLU backward, LayerNorm backward over the row; column sums for dgamma / dbeta / dalpha ----
+  {
+    const float invN = 1.f / (float)NH;
+    float4 pg[NCG], pb[NCG];
+    float pal = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCG; ++j) { pg[j] = f4zero(); pb[j] = f4zero(); }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int lr = wave * 2 + i, r = m0 + lr;
+      const bool rvalid = r < M;                   // (wave-uniform)
+      float4 dxh[NCG];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < NCG; ++j) {
+        dxh[j] = f4zero();
+        if (!on[j] || !rvalid) continue;
+        float4 dy = ld4(T + lr * LDT + lane * 4 + 256 * j);
+        const float4 x = xh[i][j], gm = gam[j], bt = bet[j];
+        const float y0 = x.x * gm.x + bt.x, y1 = x.y * gm.y + bt.y, y2 = x.z * gm.z + bt.z, y3 = x.w * gm.w + bt.w;
+        if (y0 < 0.f) { pal += dy.x * y0; dy.x *= alpha; }
+        if (y1 < 0.f) { pal += dy.y * y1; dy.y *= alpha; }
+        if (y2 < 0.f) { pal += dy.z * y2; dy.z *= alpha; }
+        if (y3 < 0.f) { pal += dy.w * y3; dy.w *= alpha; }
+        pg[j].x += dy.x * x.x; pg[j].y += dy.y * x.y; pg[j].z += dy.z * x.z; pg[j].w += dy.w * x.w;
+        pb[j] = f4add(pb[j], dy);
+        dxh[j] = make_float4(dy.x * gm.x, dy.y * gm.y, dy.z * gm.z, dy.w * gm.w);
+        s1 += dxh[j].x + dxh[j].y + dxh[j].z + dxh[j].w;
+        s2 += dxh[j].x * x.x + dxh[j].y * x.y + dxh[j].z * x.z + dxh[j].w * x.w;
+      }
+      const float m1 = wave_sum(s1) * invN, m2 = wave_sum(s2) * invN;
+#pragma unroll
+      for (int j = 0; j < NCG; ++j) {
+        if (!on[j]) continue;
+        float4 o = f4zero();                       // rows beyond M feed zeros to the second product
+        if (rvalid) {
+          const float4 x = xh[i][j];
+          o = make_float4(rs[i] * (dxh[j].x - m1 - x.x * m2), rs[i] * (dxh[j].y - m1 - x.y * m2),
+                          rs[i] * (dxh[j].z - m1 - x.z * m2), rs[i] * (dxh[j].w - m1 - x.w * m2));
+          st4(a.dz + (size_t)r * NH + lane * 4 + 256 * j, o);
+        }
+        st4(T + lr * LDT + lane * 4 + 256 * j, o);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NCG; ++j) {
+      if (!on[j]) continue;
+      st4(Ps + (wave * 2 + 0) * NH + lane * 4 + 256 * j, pg[j]);
+      st4(Ps + (wave * 2 + 1) * NH + lane * 4 + 256 * j, pb[j]);
+    }
+    const float sal = wave_sum(pal);
+    if (lane == 0) Ps[16 * NH + wave] = sal;
+  }
+  __syncthreads();                                         // dz tile + column sums complete
+  {
+    float* prow = a.partials + (size_t)blockIdx.x * a.partial_ld;
+    for (int cc = tid; cc < 2 * NH; cc += 512) {
+      const int which = cc >= NH ? 1 : 0, col = cc - which * NH;
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) s += Ps[(w * 2 + which) * NH + col];
+      prow[which * NH + col] = s;
+    }
+    if (tid == 0) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) s += Ps[16 * NH + w];
+      prow[a.partial_ld - 1] = s;
+    }
+  }
+  // ---- second product: dcat = dz . W1, 256-column blocks (two 16-column tiles per wave), k over NH; C straight to HBM ----
+  for (int blk = 0; blk * 256 < K; ++blk) {
+    const int cb = blk * 256 + wave * 32;
+    const bool cok = cb < K;
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    wave_gemm_kn(acc, a.w1, K, cok ? cb : 0, NH, T, LDT, Wp, lane);
+    if (cok) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + 4 * g4 + r;
+        if (row < M) {
+          a.dcat[(size_t)row * a.lddcat + cb + l15] = acc[0][r];
+          a.dcat[(size_t)row * a.lddcat + cb + l15 + 16] = acc[1][r];
+        }
+      }
+    }
+  }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int dosx_mlp_ln_supported(int K, int NH, int NO) {
+  return K % 128 == 0 && K >= 128 && K <= 512 && NH % 128 == 0 && NH >= 128 && NH <= 512 && NO % 64 == 0 && NO >= 64 &&
+         NO <= 256 && (NO <= 128 || NO % 128 == 0) && NO <= K;
+}
+
+extern "C" int dosx_mlp_ln_fwd(const DosxMlpLn* ap, dosx_stream_t stream) {
+  DOSX_CHECK_ARG(ap != nullptr, "dosx_mlp_ln_fwd: null descriptor");
+  const DosxMlpLn& a = *ap;
+  if (a.M <= 0) return 0;
+  DOSX_CHECK_ARG(dosx_mlp_ln_supported(a.K, a.NH, a.NO), "dosx_mlp_ln_fwd: K=%d NH=%d NO=%d unsupported", a.K, a.NH, a.NO);
+  DOSX_CHECK_ARG(a.a0 && a.w1 && a.b1 && a.gamma && a.beta && a.alpha && a.w2 && a.b2 && a.xhat && a.rstd && a.out,
+                 "dosx_mlp_ln_fwd: null operand");
+  DOSX_CHECK_ARG(a.k0 > 0 && a.k0 <= a.K && (a.k0 & 3) == 0 && (a.k0 == a.K || a.a1), "dosx_mlp_ln_fwd: bad input split k0=%d", a.k0);
+  DOSX_CHECK_ARG((a.lda0 & 3) == 0 && (a.lda1 & 3) == 0 && (a.ldo & 3) == 0 && (a.ldres & 3) == 0 && aligned16(a.a0) &&
+                 aligned16(a.a1) && aligned16(a.out) && aligned16(a.res) && aligned16(a.xhat),
+                 "dosx_mlp_ln_fwd: operands must be 16-byte aligned with leading dimensions that are multiples of 4");
+  const long long span = (const char*)a.w1 > (const char*)a.w2 ? (const char*)a.w1 - (const char*)a.w2 : (const char*)a.w2 - (const char*)a.w1;
+  DOSX_CHECK_ARG(span + (long long)4 * a.NH * (a.K + a.NO) < 0x7fffffffLL, "dosx_mlp_ln_fwd: the two weight matrices are more than 2 GiB apart");
+  const size_t smem = sizeof(float) * ((size_t)MR * (a.K + 4) + (size_t)MR * (a.NH + 4) + 8 * (size_t)WP_FLOATS);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_ln_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(mlp_ln_fwd_kernel, dim3(ceil_div(a.M, MR)), dim3(512), smem, to_stream(stream), a);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_mlp_ln_bwd_partial_rows(int M) { return M <= 0 ? 0 : ceil_div(M, MR); }
+
+extern "C" int dosx_mlp_ln_bwd(const DosxMlpLnBwd* ap, dosx_stream_t stream) {
+  DOSX_CHECK_ARG(ap != nullptr, "dosx_mlp_ln_bwd: null descriptor");
+  const DosxMlpLnBwd& a = *ap;
+  if (a.M <= 0) return 0;
+  DOSX_CHECK_ARG(dosx_mlp_ln_supported(a.K, a.NH, a.NO), "dosx_mlp_ln_bwd: K=%d NH=%d NO=%d unsupported", a.K, a.NH, a.NO);
+  DOSX_CHECK_ARG(a.dy && a.xhat && a.rstd && a.w1 && a.w2 && a.gamma && a.beta && a.alpha && a.dz && a.dcat && a.partials,
+                 "dosx_mlp_ln_bwd: null operand");
+  DOSX_CHECK_ARG((a.lddy & 3) == 0 && aligned16(a.dy) && aligned16(a.xhat) && aligned16(a.dz),
+                 "dosx_mlp_ln_bwd: operands must be 16-byte aligned with leading dimensions that are multiples of 4");
+  DOSX_CHECK_ARG(a.partial_ld >= 2 * a.NH + 1, "dosx_mlp_ln_bwd: partial_ld %d < 2*NH+1", a.partial_ld);
+  const long long span = (const char*)a.w1 > (const char*)a.w2 ? (const char*)a.w1 - (const char*)a.w2 : (const char*)a.w2 - (const char*)a.w1;
+  DOSX_CHECK_ARG(span + (long long)4 * a.NH * (a.K + a.NO) < 0x7fffffffLL, "dosx_mlp_ln_bwd: the two weight matrices are more than 2 GiB apart");
+  const size_t smem = sizeof(float) * ((size_t)MR * (a.NO + 4) + (size_t)MR * (a.NH + 4) + 16 * (size_t)a.NH + 8 + 8 * (size_t)WP_FLOATS);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_ln_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(mlp_ln_bwd_kernel, dim3(ceil_div(a.M, MR)), dim3(512), smem, to_stream(stream), a);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}

@@ -34,10 +34,11 @@ def _rows32(m: int) -> int:
 class SegList:
     """K-segments of a gathered/concatenated operand + the tensors that keep their memory alive."""
 
-    def __init__(self, segs: Sequence[Seg], keep: Sequence[torch.Tensor]):
+    def __init__(self, segs: Sequence[Seg], keep: Sequence[torch.Tensor], plain: Optional[Sequence[torch.Tensor]] = None):
         self.segs = list(segs)
         self.keep = list(keep)
         self.K = sum(s.width for s in segs)
+        self.plain = plain          # the segments as whole row-major tensors, when that is all they are (no row maps)
 
 
 def _wgrad_linear(sink: GradSink, G: Params, wkey: str, bkey: Optional[str], M: int, N: int, dy: Seg,
@@ -94,6 +95,10 @@ def mlp_prelu_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: G
 # ------------------------------------------------------------------------------------------------
 # Edge / Node MLP: Linear -> LayerNorm -> PReLU -> Linear     (DOSTransformer_phonon.py:193,204)
 # ------------------------------------------------------------------------------------------------
+def _mlp_ln_fused(a: SegList, M: int, H: int) -> bool:
+    return a.plain is not None and len(a.plain) <= 2 and ops.mlp_ln_supported(M, a.K, 2 * H, H)
+
+
 def mlp_ln_fwd(P: Params, key: str, a: SegList, M: int, H: int, res: Optional[torch.Tensor] = None, segsum=None):
     """segsum = (seg_tile, rowptr, scale, agg, e_in, e_out): the second Linear aggregates its rows per destination node in
     its epilogue (DosxGemm EPI_SEGSUM): agg = scale * segment sums of the output, e_out = e_in + output (None: skipped);
@@ -101,6 +106,13 @@ def mlp_ln_fwd(P: Params, key: str, a: SegList, M: int, H: int, res: Optional[to
     dev = P[key + ".0.weight"].device
     xhat = _empty(dev, M, 2 * H)
     rstd = _empty(dev, M)
+    if segsum is None and _mlp_ln_fused(a, M, H):
+        # a few hundred rows (the NodeModel: one row per atom): both Linear layers in ONE launch, the intermediate in LDS
+        y = _empty(dev, M, H)
+        ops.mlp_ln_fwd(M, a.plain[0], a.plain[1] if len(a.plain) > 1 else None, P[key + ".0.weight"], P[key + ".0.bias"],
+                       P[key + ".1.weight"], P[key + ".1.bias"], P[key + ".2.weight"], P[key + ".3.weight"],
+                       P[key + ".3.bias"], res, xhat, rstd, y)
+        return y, (a, xhat, rstd, M, H)
     ops.gemm(M, 2 * H, a.segs, P[key + ".0.weight"], xhat, bias=P[key + ".0.bias"], epi=EPI_LN, aux_out=rstd)
     if segsum is not None:
         tile, rowptr, scale, agg, e_in, e_out = segsum
@@ -123,18 +135,23 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
     gam, bet, alpha = P[key + ".1.weight"], P[key + ".1.bias"], P[key + ".2.weight"]
     _wgrad_linear(sink, G, key + ".3.weight", key + ".3.bias", M, H, seg(dy), [seg(xhat)], keep=(dy,), pro=PRO_LN_PRELU,
                   pro_gamma=gam, pro_beta=bet, pro_alpha=alpha)
-    rows = ops.gemm_partial_rows(M, 2 * H, EPI_PRELU_LN_BWD)
+    fused = res is None and _mlp_ln_fused(a, M, H) and dy.stride(1) == 1
+    rows = ops.mlp_ln_bwd_partial_rows(M) if fused else ops.gemm_partial_rows(M, 2 * H, EPI_PRELU_LN_BWD)
     pld = 4 * H + 4          # [dgamma(2H) | dbeta(2H) | pad(3) | dalpha]; multiple of 4 -> vector reduce
     part = sink.scratch(rows, pld)
     dz = _empty(dev, M, 2 * H)
-    ops.gemm(M, 2 * H, [seg(dy)], P[key + ".3.weight"], dz, w_layout=1, epi=EPI_PRELU_LN_BWD, aux=xhat,
-             aux_stats=rstd, epi_gamma=gam, epi_beta=bet, epi_alpha=alpha, partials=part, partial_ld=pld)
+    dcat = _empty(dev, M, a.K)
+    if fused:
+        ops.mlp_ln_bwd(M, dy, xhat, rstd, P[key + ".0.weight"], P[key + ".3.weight"], gam, bet, alpha, dz, dcat, part)
+    else:
+        ops.gemm(M, 2 * H, [seg(dy)], P[key + ".3.weight"], dz, w_layout=1, epi=EPI_PRELU_LN_BWD, aux=xhat,
+                 aux_stats=rstd, epi_gamma=gam, epi_beta=bet, epi_alpha=alpha, partials=part, partial_ld=pld)
     sink.add(part, 0, G[key + ".1.weight"], rows, pld, 2 * H)
     sink.add(part, 2 * H, G[key + ".1.bias"], rows, pld, 2 * H)
     sink.add(part, pld - 1, G[key + ".2.weight"], rows, pld, 1)
     _wgrad_linear(sink, G, key + ".0.weight", key + ".0.bias", M, 2 * H, seg(dz), a.segs, keep=(dz,))
-    dcat = _empty(dev, M, a.K)
-    ops.gemm(M, a.K, [seg(dz)], P[key + ".0.weight"], dcat, w_layout=1, res=res, res_col0=res_col0 if res is not None else 0)
+    if not fused:
+        ops.gemm(M, a.K, [seg(dz)], P[key + ".0.weight"], dcat, w_layout=1, res=res, res_col0=res_col0 if res is not None else 0)
     return dcat
 
 
@@ -159,7 +176,7 @@ def gnn_fwd(P: Params, m: GraphMeta, x: torch.Tensor, e: torch.Tensor, L: int, m
         else:
             msg, cxe = mlp_ln_fwd(P, pre + ".edge_model.edge_mlp", a_e, E, H)
             ops.segment_reduce(msg, m.rowptr_dst, scale, agg, e, e_new, N, E, H)
-        a_n = SegList([seg(x), seg(agg)], [x, agg])
+        a_n = SegList([seg(x), seg(agg)], [x, agg], plain=(x, agg))
         x_new, cxn = mlp_ln_fwd(P, pre + ".node_model.node_mlp_2", a_n, N, H, res=x)
         ctxs.append((cxe, cxn))
         x, e = x_new, e_new

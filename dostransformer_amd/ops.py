@@ -372,6 +372,58 @@ def ffn_bwd(M: int, H: int, dy: torch.Tensor, h: torch.Tensor, x: torch.Tensor, 
           w=lambda: (f"ffn_bwd[M{M},H{H}]", "ffn_bwd_kernel", "mfma", 16.0 * M * H * H))
 
 
+MLP_LN_MAX_ROWS = int(__import__("os").environ.get("DOSX_MLP_LN_MAX_ROWS", "4096"))
+MLP_LN_MAX_KN = int(__import__("os").environ.get("DOSX_MLP_LN_MAX_KN", str(256 * 256)))
+
+
+def mlp_ln_supported(M: int, K: int, NH: int, NO: int) -> bool:
+    """Whether the one-launch Linear-LN-PReLU-Linear kernel (include/dosx.h: DosxMlpLn) takes this block: its 16-row
+    workgroups are the better cut while they are at most one round of the 256 CUs (M <= 4096 rows) and one workgroup's
+    serial share of the weights is small (hidden <= 128: 13.7 + 14.5 us fwd + bwd against 2 x 2 launches of ~9.7 us at
+    450 rows; at hidden 256 / 1554 rows the backward measured 42.9 against 33.9 us - tools/bench_kernels.py --what nmlp)."""
+    return 0 < M <= MLP_LN_MAX_ROWS and K * NH <= MLP_LN_MAX_KN and bool(_lib.load().dosx_mlp_ln_supported(int(K), int(NH), int(NO)))
+
+
+def mlp_ln_fwd(M: int, a0: torch.Tensor, a1: Optional[torch.Tensor], w1, b1, gamma, beta, alpha, w2, b2,
+               res: Optional[torch.Tensor], xhat: torch.Tensor, rstd: torch.Tensor, out: torch.Tensor) -> None:
+    """out = prelu(LN([a0|a1] W1^T + b1)) W2^T + b2 (+ res); xhat / rstd saved (include/dosx.h: DosxMlpLn)."""
+    d = _lib.MlpLn()
+    k0 = int(a0.shape[1])
+    d.M, d.K, d.NH, d.NO, d.k0 = int(M), k0 + (int(a1.shape[1]) if a1 is not None else 0), int(w1.shape[0]), int(w2.shape[0]), k0
+    d.a0, d.lda0 = a0.data_ptr(), int(a0.stride(0))
+    if a1 is not None:
+        d.a1, d.lda1 = a1.data_ptr(), int(a1.stride(0))
+    d.w1, d.b1, d.gamma, d.beta, d.alpha = w1.data_ptr(), b1.data_ptr(), gamma.data_ptr(), beta.data_ptr(), alpha.data_ptr()
+    d.w2, d.b2 = w2.data_ptr(), b2.data_ptr()
+    if res is not None:
+        d.res, d.ldres = res.data_ptr(), int(res.stride(0))
+    d.xhat, d.rstd = xhat.data_ptr(), rstd.data_ptr()
+    d.out, d.ldo = out.data_ptr(), int(out.stride(0))
+    _call("dosx_mlp_ln_fwd", C.byref(d), _stream(),
+          w=lambda: (f"mlp_ln_fwd[M{d.M},K{d.K},NH{d.NH},NO{d.NO}]", "mlp_ln_fwd_kernel", "mfma", 2.0 * d.M * d.NH * (d.K + d.NO)))
+
+
+def mlp_ln_bwd_partial_rows(M: int) -> int:
+    return _lib.load().dosx_mlp_ln_bwd_partial_rows(int(M))
+
+
+def mlp_ln_bwd(M: int, dy: torch.Tensor, xhat: torch.Tensor, rstd: torch.Tensor, w1, w2, gamma, beta, alpha, dz: torch.Tensor,
+               dcat: torch.Tensor, partials: torch.Tensor) -> None:
+    """dz = LN/PReLU backward of (dy W2), dcat = dz W1, [dgamma | dbeta | .. | dalpha] partial rows - one launch
+    (include/dosx.h: DosxMlpLnBwd)."""
+    d = _lib.MlpLnBwd()
+    d.M, d.K, d.NH, d.NO = int(M), int(w1.shape[1]), int(w1.shape[0]), int(w2.shape[0])
+    d.dy, d.lddy = dy.data_ptr(), int(dy.stride(0))
+    d.xhat, d.rstd = xhat.data_ptr(), rstd.data_ptr()
+    d.w1, d.w2 = w1.data_ptr(), w2.data_ptr()
+    d.gamma, d.beta, d.alpha = gamma.data_ptr(), beta.data_ptr(), alpha.data_ptr()
+    d.dz = dz.data_ptr()
+    d.dcat, d.lddcat = dcat.data_ptr(), int(dcat.stride(0))
+    d.partials, d.partial_ld = partials.data_ptr(), int(partials.stride(0))
+    _call("dosx_mlp_ln_bwd", C.byref(d), _stream(),
+          w=lambda: (f"mlp_ln_bwd[M{d.M},K{d.K},NH{d.NH},NO{d.NO}]", "mlp_ln_bwd_kernel", "mfma", 2.0 * d.M * d.NH * (d.K + d.NO)))
+
+
 def gemm_partial_rows(M: int, N: int, epi: int) -> int:
     return _lib.load().dosx_gemm_partial_rows(int(M), int(N), int(epi))
 

@@ -363,6 +363,48 @@ typedef struct DosxFfnBwd {
 int dosx_ffn_bwd_partial_rows(int M);
 int dosx_ffn_bwd(const DosxFfnBwd* a, dosx_stream_t stream);
 
+/* Linear -> LayerNorm -> PReLU -> Linear (+ residual) in ONE launch for small row counts: the NodeModel MLP of a GNN layer
+ * (DOSTransformer_phonon.py:200-212 `node_mlp_2(cat[x, agg])`, DOSTransformer.py:178-190).
+ *     z    = [a0 | a1] . W1^T + b1                  [M,NH]     (a0: k0 columns, a1: K - k0 columns, plain row-major)
+ *     xhat = (z - mean) * rstd   (eps 1e-5)         written out with rstd: the backward and dosx_wgrad read them
+ *     out  = prelu(xhat*gamma + beta) . W2^T + b2 (+ res)      [M,NO]
+ * What two dosx_gemm calls (EPI_LN, then PRO_LN_PRELU) compute, for the shapes dosx_mlp_ln_supported accepts
+ * (K, NH multiples of 128 up to 512; NO a multiple of 64 up to 256, NO <= K); 16 rows per workgroup, so meant for
+ * M of a few thousand rows at most - the caller keeps the two-GEMM path for long inputs. */
+typedef struct DosxMlpLn {
+  int32_t M, K, NH, NO, k0;
+  const float* a0; int32_t lda0;
+  const float* a1; int32_t lda1;          /* may be NULL when k0 == K */
+  const float* w1; const float* b1;       /* [NH,K], [NH]  (nn.Linear layout) */
+  const float* gamma; const float* beta;  /* LayerNorm(NH) */
+  const float* alpha;                     /* PReLU (1 parameter) */
+  const float* w2; const float* b2;       /* [NO,NH], [NO] */
+  const float* res; int32_t ldres;        /* optional residual added to the output (NULL: none) */
+  float* xhat; float* rstd;               /* [M,NH] (row stride NH), [M] */
+  float* out; int32_t ldo;
+} DosxMlpLn;
+int dosx_mlp_ln_supported(int K, int NH, int NO);
+int dosx_mlp_ln_fwd(const DosxMlpLn* a, dosx_stream_t stream);
+
+/* Backward of the same block in one launch:
+ *     da = dy . W2 ; dy' = da o prelu'(xhat*gamma+beta) ; dz = LayerNorm_bwd(dy' o gamma)  [M,NH] (written: the W1 weight
+ *     gradient reads it) ; dcat = dz . W1  [M,K]
+ *     partials[r] = [ dgamma (NH) | dbeta (NH) | pad | dalpha ] summed over the rows of workgroup r — the layout of
+ *     DOSX_EPI_PRELU_LN_BWD (dalpha in column partial_ld - 1), dosx_mlp_ln_bwd_partial_rows(M) rows.
+ * The weight / bias gradients of the two Linear layers stay dosx_wgrad calls. */
+typedef struct DosxMlpLnBwd {
+  int32_t M, K, NH, NO;
+  const float* dy; int32_t lddy;
+  const float* xhat; const float* rstd;   /* saved by the forward */
+  const float* w1; const float* w2;
+  const float* gamma; const float* beta; const float* alpha;
+  float* dz;                              /* [M,NH], row stride NH */
+  float* dcat; int32_t lddcat;            /* [M,K] */
+  float* partials; int32_t partial_ld;
+} DosxMlpLnBwd;
+int dosx_mlp_ln_bwd_partial_rows(int M);
+int dosx_mlp_ln_bwd(const DosxMlpLnBwd* a, dosx_stream_t stream);
+
 /* Graph metadata ("CSR build") on the device, stream-ordered, no host round trip — counterpart of what PyG's
  * collate / to_dense_batch / torch_scatter derive per call from `edge_index` and `batch`
  * (DOSTransformer_phonon.py:48-56,86,209).

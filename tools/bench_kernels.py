@@ -215,6 +215,31 @@ def neighbor_case(name, C, r_max):
           f"set (count + scan + fill, incl. 2 host reads) | numpy brute force ~{t_cpu * 1e3:8.0f} ms (extrapolated from 20)")
 
 
+def node_mlp_case(name, M, H):
+    """NodeModel MLP: the one-launch kernel (csrc/mlp2.hip) against the two dosx_gemm launches it replaces, fwd and bwd."""
+    x, agg = torch.randn(M, H, device=DEV), torch.randn(M, H, device=DEV)
+    w1, b1 = torch.randn(2 * H, 2 * H, device=DEV) / 16, torch.randn(2 * H, device=DEV)
+    g, b, al = torch.randn(2 * H, device=DEV), torch.randn(2 * H, device=DEV), torch.full((1,), 0.25, device=DEV)
+    w2, b2 = torch.randn(H, 2 * H, device=DEV) / 16, torch.randn(H, device=DEV)
+    xhat, rstd, out = torch.empty(M, 2 * H, device=DEV), torch.empty(M, device=DEV), torch.empty(M, H, device=DEV)
+    us = timeit(lambda: ops.mlp_ln_fwd(M, x, agg, w1, b1, g, b, al, w2, b2, x, xhat, rstd, out))
+    def two():
+        ops.gemm(M, 2 * H, [ops.seg(x), ops.seg(agg)], w1, xhat, bias=b1, epi=ops.EPI_LN, aux_out=rstd)
+        ops.gemm(M, H, [ops.seg(xhat)], w2, out, pro=ops.PRO_LN_PRELU, pro_gamma=g, pro_beta=b, pro_alpha=al, bias=b2, res=x)
+    us2 = timeit(two)
+    dy, dz, dcat = torch.randn(M, H, device=DEV), torch.empty(M, 2 * H, device=DEV), torch.empty(M, 2 * H, device=DEV)
+    pld = 4 * H + 4
+    part = torch.empty(ops.mlp_ln_bwd_partial_rows(M), pld, device=DEV)
+    usb = timeit(lambda: ops.mlp_ln_bwd(M, dy, xhat, rstd, w1, w2, g, b, al, dz, dcat, part))
+    part2 = torch.empty(ops.gemm_partial_rows(M, 2 * H, ops.EPI_PRELU_LN_BWD), pld, device=DEV)
+    def twob():
+        ops.gemm(M, 2 * H, [ops.seg(dy)], w2, dz, w_layout=1, epi=ops.EPI_PRELU_LN_BWD, aux=xhat, aux_stats=rstd, epi_gamma=g,
+                 epi_beta=b, epi_alpha=al, partials=part2, partial_ld=pld)
+        ops.gemm(M, 2 * H, [ops.seg(dz)], w1, dcat, w_layout=1)
+    usb2 = timeit(twob)
+    print(f"nmlp  {name:30s} M={M} H={H}: fwd fused {us:6.1f} us | two GEMMs {us2:6.1f} us || bwd fused {usb:6.1f} us | two GEMMs {usb2:6.1f} us")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="all")
@@ -229,6 +254,11 @@ def main():
         ffn_bwd_case("FFN bwd 2B", R2, H)
         ffn_bwd_case("FFN bwd B", R1, H)
         ffn_bwd_case("FFN bwd roofline scale", 262144, H)
+    if w in ("all", "nmlp"):
+        node_mlp_case("cfg2 nodes", N, H)
+        node_mlp_case("one crystal", 7, H)
+        node_mlp_case("cfg3 nodes (eDOS)", 1554, 256)
+        node_mlp_case("4096 rows", 4096, H)
     if w in ("all", "neighbors"):
         neighbor_case("phonon-set sized", 1500, 4.0)
         neighbor_case("phonon-set sized", 1500, 6.0)
