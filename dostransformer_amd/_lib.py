@@ -96,6 +96,8 @@ class FfnBwd(C.Structure):
         ("dh", C.c_void_p), ("lddh", C.c_int32),
         ("dx", C.c_void_p), ("lddx", C.c_int32),
         ("partials", C.c_void_p), ("partial_ld", C.c_int32),
+        ("fin_gamma", C.c_void_p), ("fin_xhat", C.c_void_p), ("fin_rstd", C.c_void_p),
+        ("fin_dy", C.c_void_p),
     ]
 
 

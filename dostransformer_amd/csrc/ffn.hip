@@ -345,6 +345,43 @@ __global__ __launch_bounds__(512) void ffn_bwd_kernel(const DosxFfnBwd a) {
     mean[i] = a.stats[2 * (size_t)r];
     rstd[i] = a.stats[2 * (size_t)r + 1];
   }
+  // The encoder's FINAL LayerNorm (layers/transformer.py:76-77) sits right behind the last layer's feed-forward half: with
+  // fin_gamma set, `dy` is the gradient w.r.t. that LayerNorm's output and its backward runs here, on the rows each wave
+  // holds for the epilogue anyway (one wave per row) - no stand-alone ln_bwd launch in front of this kernel.  The result
+  // goes to fin_dy (the fc2 weight gradient reads it) and straight into the LDS tile of the first product.
+  const bool fin = a.fin_gamma != nullptr;
+  float4 pgf = f4zero(), pbf = f4zero();
+  if (fin) {
+    float4 gf = f4zero();
+    if (con) gf = ld4(a.fin_gamma + c0);
+    const float invH = 1.f / (float)a.H;
+#pragma unroll
+    for (int i = 0; i < ER; ++i) {
+      const int lr = wave * ER + i, r = m0 + lr, rc = min(r, M - 1);
+      const bool ok = con && r < M;
+      const float4 fx = ld4(a.fin_xhat + (size_t)rc * a.H + (con ? c0 : 0));
+      const float frs = a.fin_rstd[rc];
+      float4 d = dyr[i], dh = f4zero();
+      float s1 = 0.f, s2 = 0.f;
+      if (con) {
+        if (ok) {
+          pgf.x += d.x * fx.x; pgf.y += d.y * fx.y; pgf.z += d.z * fx.z; pgf.w += d.w * fx.w;
+          pbf = f4add(pbf, d);
+        }
+        dh = make_float4(d.x * gf.x, d.y * gf.y, d.z * gf.z, d.w * gf.w);
+        s1 = (dh.x + dh.y) + (dh.z + dh.w);
+        s2 = (dh.x * fx.x + dh.y * fx.y) + (dh.z * fx.z + dh.w * fx.w);
+      }
+      const float m1 = wave_sum(s1) * invH, m2 = wave_sum(s2) * invH;
+      d = make_float4(frs * (dh.x - m1 - fx.x * m2), frs * (dh.y - m1 - fx.y * m2), frs * (dh.z - m1 - fx.z * m2),
+                      frs * (dh.w - m1 - fx.w * m2));
+      dyr[i] = d;
+      if (con) {
+        st4(sm + lr * (a.H + 4) + c0, d);                    // Ys[lr][c0]
+        if (ok) st4(a.fin_dy + (size_t)r * a.lddy + c0, d);
+      }
+    }
+  }
 
   if (wave_u >= 4) {
     // =============================== staging waves ===============================================
@@ -402,7 +439,7 @@ __global__ __launch_bounds__(512) void ffn_bwd_kernel(const DosxFfnBwd a) {
     }
   } else {
     // =============================== matrix waves ================================================
-    {   // dy tile -> Ys
+    if (!fin) {   // dy tile -> Ys
       const int r = tid >> 3, rr = min(m0 + r, M - 1);
       for (int c = (tid & 7) * 4; c < H && r < R; c += 32) st4(Ys + r * LDX + c, ld4(a.dy + (size_t)rr * a.lddy + c));
     }
@@ -543,18 +580,23 @@ __global__ __launch_bounds__(512) void ffn_bwd_kernel(const DosxFfnBwd a) {
     }
   }
   {
-    float* Ps = ST + STG;                          // [8][2][128], behind the C tile
+    float* Ps = ST + STG;                          // [8][2 or 4][128], behind the C tile
+    const int npv = fin ? 4 : 2;                   // dgamma | dbeta of LN1 (| dgamma | dbeta of the final LayerNorm)
     if (con) {
-      st4(Ps + (wave * 2 + 0) * FBN + c0, pg);
-      st4(Ps + (wave * 2 + 1) * FBN + c0, pb);
+      st4(Ps + (wave * npv + 0) * FBN + c0, pg);
+      st4(Ps + (wave * npv + 1) * FBN + c0, pb);
+      if (fin) {
+        st4(Ps + (wave * npv + 2) * FBN + c0, pgf);
+        st4(Ps + (wave * npv + 3) * FBN + c0, pbf);
+      }
     }
     __syncthreads();
     float* prow = a.partials + (size_t)blockIdx.x * a.partial_ld;
-    for (int c = tid; c < 2 * H; c += 512) {
+    for (int c = tid; c < npv * H; c += 512) {
       const int which = c / H, col = c % H;
       float s = 0.f;
 #pragma unroll
-      for (int w = 0; w < 8; ++w) s += Ps[(w * 2 + which) * FBN + col];
+      for (int w = 0; w < 8; ++w) s += Ps[(w * npv + which) * FBN + col];
       prow[which * H + col] = s;
     }
   }
@@ -621,7 +663,8 @@ extern "C" int dosx_ffn_bwd(const DosxFfnBwd* ap, dosx_stream_t stream) {
   DOSX_CHECK_ARG(a.dy && a.h && a.x && a.stats && a.gamma && a.w1 && a.w2 && a.dh && a.dx && a.partials, "dosx_ffn_bwd: null operand");
   DOSX_CHECK_ARG((a.lddy & 3) == 0 && (a.ldh & 3) == 0 && (a.ldx & 3) == 0 && (a.lddh & 3) == 0 && (a.lddx & 3) == 0,
                  "dosx_ffn_bwd: leading dimensions must be multiples of 4");
-  DOSX_CHECK_ARG(a.partial_ld >= 2 * a.H, "dosx_ffn_bwd: partial_ld %d < 2H", a.partial_ld);
+  DOSX_CHECK_ARG(a.partial_ld >= (a.fin_gamma ? 4 : 2) * a.H, "dosx_ffn_bwd: partial_ld %d < %dH", a.partial_ld, a.fin_gamma ? 4 : 2);
+  if (a.fin_gamma) DOSX_CHECK_ARG(a.fin_xhat && a.fin_rstd && a.fin_dy, "dosx_ffn_bwd: final LayerNorm backward needs xhat / rstd / fin_dy");
   const long long span = (const char*)a.w1 > (const char*)a.w2 ? (const char*)a.w1 - (const char*)a.w2 : (const char*)a.w2 - (const char*)a.w1;
   DOSX_CHECK_ARG(span + (long long)16 * a.H * a.H < 0x7fffffffLL, "dosx_ffn_bwd: fc1 / fc2 weights more than 2 GiB apart");
   const int H = a.H, H4 = 4 * H;

@@ -289,6 +289,7 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
 
 
 _FUSED_FFN_BWD = __import__("os").environ.get("DOSX_FUSED_FFN_BWD", "1") == "1"
+_FUSED_FIN_BWD = __import__("os").environ.get("DOSX_FUSED_FIN_BWD", "1") == "1"
 
 
 def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: torch.Tensor, dkvhat: torch.Tensor, sink: GradSink,
@@ -302,7 +303,12 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: torch.Tensor, dkvhat: t
     rows = Sq * Bq
     r32 = _rows32(rows)
     dx = dy
-    if fin is not None:
+    fused = ops.ffn_supported(H) and _FUSED_FFN_BWD
+    fin_fused = None        # the final LayerNorm's backward rides in the last layer's ffn_bwd launch (csrc/ffn.hip)
+    if fin is not None and fused and _FUSED_FIN_BWD and T > 0 and dy.stride(1) == 1:
+        dx = _empty(dev, rows, H)
+        fin_fused = (P[pre + ".layer_norm.weight"], fin[0], fin[1], dx)
+    elif fin is not None:
         xhat, rstd = fin
         part = sink.scratch(r32, 2 * H)
         dx = _empty(dev, rows, H)
@@ -319,11 +325,17 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: torch.Tensor, dkvhat: t
         _wgrad_linear(sink, G, lp + ".fc2.weight", lp + ".fc2.bias", rows, H, seg(dx), [seg(h)], keep=(dx,))
         dh = _empty(dev, rows, 4 * H)
         dx1 = _empty(dev, rows, H)
-        fused = ops.ffn_supported(H) and _FUSED_FFN_BWD
+        pld = 2 * H
         if fused:           # both dgrad GEMMs + ReLU mask + LN1 backward + residual in one launch (csrc/ffn.hip)
             rgp = ops.ffn_bwd_partial_rows(rows)
-            part = sink.scratch(rgp, 2 * H)
-            ops.ffn_bwd(rows, H, dx, h, x1, st1, g1, P[lp + ".fc1.weight"], P[lp + ".fc2.weight"], dh, dx1, part)
+            with_fin = fin_fused is not None and t == T - 1
+            pld = 4 * H if with_fin else 2 * H
+            part = sink.scratch(rgp, pld)
+            ops.ffn_bwd(rows, H, dy if with_fin else dx, h, x1, st1, g1, P[lp + ".fc1.weight"], P[lp + ".fc2.weight"], dh, dx1,
+                        part, fin=fin_fused if with_fin else None)
+            if with_fin:
+                sink.add(part, 2 * H, G[pre + ".layer_norm.weight"], rgp, pld, H)
+                sink.add(part, 3 * H, G[pre + ".layer_norm.bias"], rgp, pld, H)
         else:
             ops.gemm(rows, 4 * H, [seg(dx)], P[lp + ".fc2.weight"], dh, w_layout=1, epi=EPI_RELU_MASK, aux=h)
         # fc1 (+ LN1 backward + residual)
@@ -334,8 +346,8 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: torch.Tensor, dkvhat: t
             part = sink.scratch(rgp, 2 * H)
             ops.gemm(rows, H, [seg(dh)], P[lp + ".fc1.weight"], dx1, w_layout=1, epi=EPI_ROWLN_BWD, aux=x1, aux_stats=st1,
                      epi_gamma=g1, res=dx, partials=part, partial_ld=2 * H)
-        sink.add(part, 0, G[lp + ".layer_norms.1.weight"], rgp, 2 * H, H)
-        sink.add(part, H, G[lp + ".layer_norms.1.bias"], rgp, 2 * H, H)
+        sink.add(part, 0, G[lp + ".layer_norms.1.weight"], rgp, pld, H)
+        sink.add(part, H, G[lp + ".layer_norms.1.bias"], rgp, pld, H)
         # attention (+ LN0 backward on the query side + residual); key side accumulates into dkvhat
         # Nk <= 64 (atoms of a crystal, the 51 phonon bins): the dq kernel leaves every query tile's share of dK + dV in
         # `kvp` and the dk+dv half is a small reduction over those partials; larger key sets (201 eDOS bins) stream the

@@ -355,10 +355,15 @@ def ffn_bwd_partial_rows(M: int) -> int:
 
 
 def ffn_bwd(M: int, H: int, dy: torch.Tensor, h: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, gamma, w1, w2,
-            dh: torch.Tensor, dx: torch.Tensor, partials: torch.Tensor) -> None:
+            dh: torch.Tensor, dx: torch.Tensor, partials: torch.Tensor, fin=None) -> None:
     """dh = (dy W2) o [h>0], dx = dy + LN1_bwd(dh W1), LN1 dgamma|dbeta partial rows — one launch
-    (include/dosx.h: DosxFfnBwd)."""
+    (include/dosx.h: DosxFfnBwd).  ``fin = (gamma, xhat, rstd, dy_out)``: ``dy`` is the gradient behind the encoder's
+    final LayerNorm, whose backward runs first in the same launch (dy_out receives the result, the partial rows two more
+    column groups)."""
     a = _lib.FfnBwd()
+    if fin is not None:
+        a.fin_gamma, a.fin_xhat, a.fin_rstd, a.fin_dy = (t.data_ptr() for t in fin)
+        assert fin[3].stride(0) == dy.stride(0)
     a.M, a.H = int(M), int(H)
     a.dy, a.lddy = dy.data_ptr(), int(dy.stride(0))
     a.h, a.ldh = h.data_ptr(), int(h.stride(0))

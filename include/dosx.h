@@ -359,6 +359,13 @@ typedef struct DosxFfnBwd {
   float* dh; int32_t lddh;
   float* dx; int32_t lddx;
   float* partials; int32_t partial_ld;
+  /* optional: the backward of the encoder's final LayerNorm (layers/transformer.py:76-77) in front of the LAST layer's
+   * half, same launch.  With fin_gamma != NULL, `dy` is the gradient w.r.t. that LayerNorm's OUTPUT; the kernel computes
+   * dy' = LN_bwd(dy) from fin_xhat [M,H] (row stride H) / fin_rstd [M] (what the forward's fin_* outputs hold), writes
+   * it to fin_dy [M,H] (row stride lddy: the fc2 weight gradient reads it), continues with dy', and appends
+   * [ dgamma | dbeta ] of that LayerNorm to every partial row (columns [2H,4H): partial_ld >= 4H). */
+  const float* fin_gamma; const float* fin_xhat; const float* fin_rstd;
+  float* fin_dy;
 } DosxFfnBwd;
 int dosx_ffn_bwd_partial_rows(int M);
 int dosx_ffn_bwd(const DosxFfnBwd* a, dosx_stream_t stream);

@@ -602,3 +602,44 @@ def test_message_gemm_with_segment_sum_epilogue(H, mean):
             assert float((agg1[:nr] - agg0[:nr]).abs().max()) <= 2e-6 * float(agg0[:nr].abs().max())
             if with_res:
                 assert torch.equal(e1, e0)                             # same fma chain + the same two adds per element
+
+
+@pytest.mark.parametrize("H,S,B", [(128, 51, 8), (64, 51, 3), (128, 7, 1)])
+@pytest.mark.parametrize("mode", ["cross", "self"])
+def test_final_layernorm_backward_inside_ffn_bwd(H, S, B, mode, monkeypatch):
+    """The encoder's final LayerNorm backward (layers/transformer.py:76-77) fused into the last layer's ffn_bwd launch
+    against the stand-alone dosx_layernorm_bwd launch it replaces and against torch autograd on the same module math."""
+    from dostransformer_amd import functional as Fn
+    from dostransformer_amd.layers import TransformerEncoder
+    torch.manual_seed(3)
+    enc = TransformerEncoder(embed_dim=H, num_heads=1, layers=2, attn_dropout=0.0).to(DEV)
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if "layer_norm" in n:
+                p.add_(0.2 * torch.randn_like(p))
+    gen = torch.Generator().manual_seed(11)
+    x0 = torch.randn(S, B, H, generator=gen).to(DEV)
+    kv0 = torch.randn(9, B, H, generator=gen).to(DEV)
+    w = torch.randn(S, B, H, generator=gen).to(DEV)
+
+    def run(fused):
+        monkeypatch.setattr(Fn, "_FUSED_FIN_BWD", fused)
+        enc.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_(True)
+        kv = kv0.clone().requires_grad_(True)
+        y = enc(x, kv, kv) if mode == "cross" else enc(x, x, x)
+        (y * w).sum().backward()
+        torch.cuda.synchronize()
+        g = {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}
+        return y.detach().clone(), x.grad.clone(), (kv.grad.clone() if mode == "cross" else None), g
+
+    y1, dx1, dkv1, g1 = run(True)
+    y0, dx0, dkv0, g0 = run(False)
+    sc = lambda t: float(t.abs().max()) + 1e-30
+    assert torch.equal(y1, y0)
+    assert float((dx1 - dx0).abs().max()) <= 2e-6 * sc(dx0)
+    if dkv0 is not None:
+        assert float((dkv1 - dkv0).abs().max()) <= 2e-6 * sc(dkv0)
+    assert set(g1) == set(g0) and "layer_norm.weight" in g1
+    for k in g0:
+        assert float((g1[k] - g0[k]).abs().max()) <= 5e-6 * sc(g0[k]), k

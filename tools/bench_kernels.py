@@ -42,6 +42,12 @@ def gemm_case(name, M, N, K, wl=0, pro=0, epi=0, nseg=1, gather=False):
     kw = {}
     if epi == ops.EPI_LN:
         kw = dict(epi=ops.EPI_LN, aux_out=torch.empty(M, device=DEV), bias=torch.randn(N, device=DEV))
+    if epi == ops.EPI_PRELU_LN_BWD:
+        rows = ops.gemm_partial_rows(M, N, epi)
+        kw = dict(epi=epi, aux=torch.randn(M, N, device=DEV), aux_stats=torch.rand(M, device=DEV) + 0.5,
+                  epi_gamma=torch.randn(N, device=DEV), epi_beta=torch.randn(N, device=DEV),
+                  epi_alpha=torch.tensor([0.25], device=DEV), partials=torch.empty(rows, 2 * N + 4, device=DEV),
+                  partial_ld=2 * N + 4)
     if pro == ops.PRO_LN_PRELU:
         kw.update(pro=pro, pro_gamma=torch.randn(K, device=DEV), pro_beta=torch.randn(K, device=DEV),
                   pro_alpha=torch.tensor([0.25], device=DEV))
@@ -285,6 +291,8 @@ def main():
         gemm_case("big2 (roofline scale)", 262144, 256, 384, epi=ops.EPI_LN)
         gemm_case("eDOS edge gemm1 H256", 16000, 512, 768, epi=ops.EPI_LN)
         gemm_case("eDOS fc1 H256 2B", 201 * 128, 1024, 256, pro=ops.PRO_ROWLN)
+        gemm_case("eDOS edge da (PRELU_LN_BWD epi)", 17880, 512, 256, wl=1, epi=ops.EPI_PRELU_LN_BWD)
+        gemm_case("cfg2 edge da (PRELU_LN_BWD epi)", 9000, 256, 128, wl=1, epi=ops.EPI_PRELU_LN_BWD)
     if w in ("all", "wgrad"):
         wgrad_case("edge W1 (2H x 3H)", E, 2 * H, 3 * H)
         wgrad_case("edge W2 (H x 2H)", E, H, 2 * H)
