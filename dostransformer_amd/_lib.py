@@ -98,6 +98,8 @@ class FfnBwd(C.Structure):
         ("partials", C.c_void_p), ("partial_ld", C.c_int32),
         ("fin_gamma", C.c_void_p), ("fin_xhat", C.c_void_p), ("fin_rstd", C.c_void_p),
         ("fin_dy", C.c_void_p),
+        ("fin_ddos", C.c_void_p), ("fin_w", C.c_void_p), ("fin_beta", C.c_void_p),
+        ("fin_S", C.c_int32), ("fin_Bq", C.c_int32),
     ]
 
 

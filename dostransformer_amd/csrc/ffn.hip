@@ -340,7 +340,8 @@ __global__ __launch_bounds__(512) void ffn_bwd_kernel(const DosxFfnBwd a) {
 #pragma unroll
   for (int i = 0; i < ER; ++i) {
     const int r = min(m0 + wave * ER + i, M - 1);
-    dyr[i] = ld4(a.dy + (size_t)r * a.lddy + (con ? c0 : 0));
+    dyr[i] = f4zero();
+    if (a.dy) dyr[i] = ld4(a.dy + (size_t)r * a.lddy + (con ? c0 : 0));
     xr[i] = ld4(a.x + (size_t)r * a.ldx + (con ? c0 : 0));
     mean[i] = a.stats[2 * (size_t)r];
     rstd[i] = a.stats[2 * (size_t)r + 1];
@@ -350,10 +351,13 @@ __global__ __launch_bounds__(512) void ffn_bwd_kernel(const DosxFfnBwd a) {
   // holds for the epilogue anyway (one wave per row) - no stand-alone ln_bwd launch in front of this kernel.  The result
   // goes to fin_dy (the fc2 weight gradient reads it) and straight into the LDS tile of the first product.
   const bool fin = a.fin_gamma != nullptr;
-  float4 pgf = f4zero(), pbf = f4zero();
+  const bool fdot = fin && a.fin_ddos != nullptr;   // ... and in front of it the H -> 1 output layer (dy rows = ddos[r] * w)
+  float4 pgf = f4zero(), pbf = f4zero(), pwf = f4zero();
+  float pdb = 0.f;
   if (fin) {
-    float4 gf = f4zero();
+    float4 gf = f4zero(), bf = f4zero(), wf = f4zero();
     if (con) gf = ld4(a.fin_gamma + c0);
+    if (fdot && con) { bf = ld4(a.fin_beta + c0); wf = ld4(a.fin_w + c0); }
     const float invH = 1.f / (float)a.H;
 #pragma unroll
     for (int i = 0; i < ER; ++i) {
@@ -362,6 +366,16 @@ __global__ __launch_bounds__(512) void ffn_bwd_kernel(const DosxFfnBwd a) {
       const float4 fx = ld4(a.fin_xhat + (size_t)rc * a.H + (con ? c0 : 0));
       const float frs = a.fin_rstd[rc];
       float4 d = dyr[i], dh = f4zero();
+      if (fdot) {
+        // row r = s * Bq + bq of the [S, Bq] row space; ddos is [Bq, S]
+        const float dd = a.fin_ddos[(size_t)(rc % a.fin_Bq) * a.fin_S + (rc / a.fin_Bq)];
+        d = make_float4(dd * wf.x, dd * wf.y, dd * wf.z, dd * wf.w);
+        if (ok) {
+          pwf.x += dd * (fx.x * gf.x + bf.x); pwf.y += dd * (fx.y * gf.y + bf.y);
+          pwf.z += dd * (fx.z * gf.z + bf.z); pwf.w += dd * (fx.w * gf.w + bf.w);
+        }
+        if (lane == 0 && r < M) pdb += dd;
+      }
       float s1 = 0.f, s2 = 0.f;
       if (con) {
         if (ok) {
@@ -580,8 +594,10 @@ __global__ __launch_bounds__(512) void ffn_bwd_kernel(const DosxFfnBwd a) {
     }
   }
   {
-    float* Ps = ST + STG;                          // [8][2 or 4][128], behind the C tile
-    const int npv = fin ? 4 : 2;                   // dgamma | dbeta of LN1 (| dgamma | dbeta of the final LayerNorm)
+    // column sums of the 8 waves: [8][npv][128] (+ 8 scalars) in the dh tile's LDS (dead since the second product)
+    float* Ps = T;
+    const int npv = fdot ? 5 : (fin ? 4 : 2);      // dgamma | dbeta of LN1 (| dgamma | dbeta of the final LayerNorm (| dw))
+    if (fin) __syncthreads();                      // (4-5 groups can reach past T into the C tile other waves still read)
     if (con) {
       st4(Ps + (wave * npv + 0) * FBN + c0, pg);
       st4(Ps + (wave * npv + 1) * FBN + c0, pb);
@@ -589,7 +605,9 @@ __global__ __launch_bounds__(512) void ffn_bwd_kernel(const DosxFfnBwd a) {
         st4(Ps + (wave * npv + 2) * FBN + c0, pgf);
         st4(Ps + (wave * npv + 3) * FBN + c0, pbf);
       }
+      if (fdot) st4(Ps + (wave * npv + 4) * FBN + c0, pwf);
     }
+    if (fdot && lane == 0) Ps[8 * 5 * FBN + wave] = pdb;
     __syncthreads();
     float* prow = a.partials + (size_t)blockIdx.x * a.partial_ld;
     for (int c = tid; c < npv * H; c += 512) {
@@ -598,6 +616,12 @@ __global__ __launch_bounds__(512) void ffn_bwd_kernel(const DosxFfnBwd a) {
 #pragma unroll
       for (int w = 0; w < 8; ++w) s += Ps[(w * npv + which) * FBN + col];
       prow[which * H + col] = s;
+    }
+    if (fdot && tid == 0) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) s += Ps[8 * 5 * FBN + w];
+      prow[5 * H] = s;
     }
   }
 }
@@ -660,11 +684,14 @@ extern "C" int dosx_ffn_bwd(const DosxFfnBwd* ap, dosx_stream_t stream) {
   const DosxFfnBwd& a = *ap;
   if (a.M <= 0) return 0;
   DOSX_CHECK_ARG(dosx_ffn_supported(a.H), "dosx_ffn_bwd: H=%d unsupported (multiple of 32, <= 128)", a.H);
-  DOSX_CHECK_ARG(a.dy && a.h && a.x && a.stats && a.gamma && a.w1 && a.w2 && a.dh && a.dx && a.partials, "dosx_ffn_bwd: null operand");
+  DOSX_CHECK_ARG((a.dy || a.fin_ddos) && a.h && a.x && a.stats && a.gamma && a.w1 && a.w2 && a.dh && a.dx && a.partials, "dosx_ffn_bwd: null operand");
   DOSX_CHECK_ARG((a.lddy & 3) == 0 && (a.ldh & 3) == 0 && (a.ldx & 3) == 0 && (a.lddh & 3) == 0 && (a.lddx & 3) == 0,
                  "dosx_ffn_bwd: leading dimensions must be multiples of 4");
-  DOSX_CHECK_ARG(a.partial_ld >= (a.fin_gamma ? 4 : 2) * a.H, "dosx_ffn_bwd: partial_ld %d < %dH", a.partial_ld, a.fin_gamma ? 4 : 2);
+  const int npv = a.fin_gamma ? (a.fin_ddos ? 5 : 4) : 2;
+  DOSX_CHECK_ARG(a.partial_ld >= npv * a.H + (a.fin_ddos ? 1 : 0), "dosx_ffn_bwd: partial_ld %d too small for %d column groups", a.partial_ld, npv);
   if (a.fin_gamma) DOSX_CHECK_ARG(a.fin_xhat && a.fin_rstd && a.fin_dy, "dosx_ffn_bwd: final LayerNorm backward needs xhat / rstd / fin_dy");
+  if (a.fin_ddos) DOSX_CHECK_ARG(a.fin_gamma && a.fin_beta && a.fin_w && a.fin_S > 0 && a.fin_Bq > 0 && a.fin_S * a.fin_Bq == a.M,
+                                 "dosx_ffn_bwd: output-layer backward needs gamma / beta / w and S * Bq == M");
   const long long span = (const char*)a.w1 > (const char*)a.w2 ? (const char*)a.w1 - (const char*)a.w2 : (const char*)a.w2 - (const char*)a.w1;
   DOSX_CHECK_ARG(span + (long long)16 * a.H * a.H < 0x7fffffffLL, "dosx_ffn_bwd: fc1 / fc2 weights more than 2 GiB apart");
   const int H = a.H, H4 = 4 * H;

@@ -292,11 +292,19 @@ _FUSED_FFN_BWD = __import__("os").environ.get("DOSX_FUSED_FFN_BWD", "1") == "1"
 _FUSED_FIN_BWD = __import__("os").environ.get("DOSX_FUSED_FIN_BWD", "1") == "1"
 
 
-def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: torch.Tensor, dkvhat: torch.Tensor, sink: GradSink,
-                dkv_fresh: bool = False, kv_needed_next: bool = False):
+def head_fused_bwd(H: int, T: int) -> bool:
+    """Whether encoder_bwd(head=...) runs the output layer + final LayerNorm backward inside its first ffn_bwd launch."""
+    return bool(ops.ffn_supported(H) and _FUSED_FFN_BWD and _FUSED_FIN_BWD and T > 0)
+
+
+def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: Optional[torch.Tensor], dkvhat: torch.Tensor, sink: GradSink,
+                dkv_fresh: bool = False, kv_needed_next: bool = False, head=None):
     """dy: grad of the encoder output (after the final LN if there is one).  Accumulates into dkvhat
     (``dkv_fresh``: dkvhat is uninitialised and every row of it is a key row — the first layer processed
     overwrites it, which saves the zero fill).
+    ``head = (gamma, beta, xhat, rstd, ddos [Bq,S], w, (G keys: ln weight, ln bias, out weight, out bias))`` with dy None
+    (only when head_fused_bwd(H, T)): the encoder's output went through LN -> H->1 output layer (ops.ln_rowdot) and ddos is
+    the gradient of that layer's output; their backward runs inside the last layer's ffn_bwd launch.
     Returns the gradient w.r.t. the (expanded [Sq*Bq, H]) query input."""
     lay, fin, Sq, Bq, Nk, Bk, H, T, kvhat = ctx
     dev = kvhat.device
@@ -305,7 +313,13 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: torch.Tensor, dkvhat: t
     dx = dy
     fused = ops.ffn_supported(H) and _FUSED_FFN_BWD
     fin_fused = None        # the final LayerNorm's backward rides in the last layer's ffn_bwd launch (csrc/ffn.hip)
-    if fin is not None and fused and _FUSED_FIN_BWD and T > 0 and dy.stride(1) == 1:
+    fin_keys = (pre + ".layer_norm.weight", pre + ".layer_norm.bias")
+    if head is not None:
+        assert dy is None and fin is None and head_fused_bwd(H, T)
+        hg, hb, hx, hr, hd, hw, fin_keys = head
+        dx = _empty(dev, rows, H)
+        fin_fused = (hg, hx, hr, dx, hd, hw, hb, Sq, Bq)
+    elif fin is not None and fused and _FUSED_FIN_BWD and T > 0 and dy.stride(1) == 1:
         dx = _empty(dev, rows, H)
         fin_fused = (P[pre + ".layer_norm.weight"], fin[0], fin[1], dx)
     elif fin is not None:
@@ -329,13 +343,16 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: torch.Tensor, dkvhat: t
         if fused:           # both dgrad GEMMs + ReLU mask + LN1 backward + residual in one launch (csrc/ffn.hip)
             rgp = ops.ffn_bwd_partial_rows(rows)
             with_fin = fin_fused is not None and t == T - 1
-            pld = 4 * H if with_fin else 2 * H
+            pld = (5 * H + 4 if head is not None else 4 * H) if with_fin else 2 * H
             part = sink.scratch(rgp, pld)
             ops.ffn_bwd(rows, H, dy if with_fin else dx, h, x1, st1, g1, P[lp + ".fc1.weight"], P[lp + ".fc2.weight"], dh, dx1,
                         part, fin=fin_fused if with_fin else None)
             if with_fin:
-                sink.add(part, 2 * H, G[pre + ".layer_norm.weight"], rgp, pld, H)
-                sink.add(part, 3 * H, G[pre + ".layer_norm.bias"], rgp, pld, H)
+                sink.add(part, 2 * H, G[fin_keys[0]], rgp, pld, H)
+                sink.add(part, 3 * H, G[fin_keys[1]], rgp, pld, H)
+                if head is not None:
+                    sink.add(part, 4 * H, G[fin_keys[2]], rgp, pld, H)
+                    sink.add(part, 5 * H, G[fin_keys[3]], rgp, pld, 1)
         else:
             ops.gemm(rows, 4 * H, [seg(dx)], P[lp + ".fc2.weight"], dh, w_layout=1, epi=EPI_RELU_MASK, aux=h)
         # fc1 (+ LN1 backward + residual)
@@ -554,19 +571,26 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
     dev = ddos.device
     rows2 = S * 2 * B
     r32 = _rows32(rows2)
-    pld = 3 * H + 1
-    part = sink.scratch(r32, pld)
-    dx = _empty(dev, rows2, H)
     gf, bf = P["transformer_source.layer_norm.weight"], P["transformer_source.layer_norm.bias"]
-    ops.ln_rowdot_bwd(ddos, xhat_f, rstd_f, gf, bf, P["out_layer.weight"], dx, part, S, 2 * B, H)
-    sink.add(part, 0, G["transformer_source.layer_norm.weight"], r32, pld, H)
-    sink.add(part, H, G["transformer_source.layer_norm.bias"], r32, pld, H)
-    sink.add(part, 2 * H, G["out_layer.weight"], r32, pld, H)
-    sink.add(part, 3 * H, G["out_layer.bias"], r32, pld, 1)
+    head = None
+    if head_fused_bwd(H, cfg.T) and ddos.is_contiguous():
+        # output layer + final LayerNorm backward inside the source encoder's first ffn_bwd launch
+        dx = None
+        head = (gf, bf, xhat_f, rstd_f, ddos, P["out_layer.weight"],
+                ("transformer_source.layer_norm.weight", "transformer_source.layer_norm.bias", "out_layer.weight", "out_layer.bias"))
+    else:
+        pld = 3 * H + 1
+        part = sink.scratch(r32, pld)
+        dx = _empty(dev, rows2, H)
+        ops.ln_rowdot_bwd(ddos, xhat_f, rstd_f, gf, bf, P["out_layer.weight"], dx, part, S, 2 * B, H)
+        sink.add(part, 0, G["transformer_source.layer_norm.weight"], r32, pld, H)
+        sink.add(part, H, G["transformer_source.layer_norm.bias"], r32, pld, H)
+        sink.add(part, 2 * H, G["out_layer.weight"], r32, pld, H)
+        sink.add(part, 3 * H, G["out_layer.bias"], r32, pld, 1)
     # key gradient of the two cross attentions (dense [nmax*B (+1 spare), H] layout): the first layer processed overwrites
     # every key row, so no zero fill; the spare row (dense slot of ghost nodes) is never read (dense_normalize_bwd's ghost_row)
     dkv = _empty(dev, nmax * B + 1, H)
-    dhs = encoder_bwd(P, G, "transformer_source", c3, dx, dkv, sink, dkv_fresh=True)
+    dhs = encoder_bwd(P, G, "transformer_source", c3, dx, dkv, sink, dkv_fresh=True, head=head)
     if sink.wside is not None:
         sink.flush_on_side()                  # (weight-gradient stream: this encoder's jobs run under the next one's backward)
     dkvs = _empty(dev, rows2, H)              # self-attention: every row is a key row, the first layer overwrites

@@ -362,10 +362,14 @@ def ffn_bwd(M: int, H: int, dy: torch.Tensor, h: torch.Tensor, x: torch.Tensor, 
     column groups)."""
     a = _lib.FfnBwd()
     if fin is not None:
-        a.fin_gamma, a.fin_xhat, a.fin_rstd, a.fin_dy = (t.data_ptr() for t in fin)
-        assert fin[3].stride(0) == dy.stride(0)
+        a.fin_gamma, a.fin_xhat, a.fin_rstd, a.fin_dy = (t.data_ptr() for t in fin[:4])
+        if len(fin) > 4:          # (.., ddos [Bq,S], w, beta, S, Bq): the H -> 1 output layer in front of that LayerNorm
+            a.fin_ddos, a.fin_w, a.fin_beta, a.fin_S, a.fin_Bq = fin[4].data_ptr(), fin[5].data_ptr(), fin[6].data_ptr(), int(fin[7]), int(fin[8])
     a.M, a.H = int(M), int(H)
-    a.dy, a.lddy = dy.data_ptr(), int(dy.stride(0))
+    if dy is not None:
+        a.dy, a.lddy = dy.data_ptr(), int(dy.stride(0))
+    else:
+        a.lddy = int(fin[3].stride(0))
     a.h, a.ldh = h.data_ptr(), int(h.stride(0))
     a.x, a.ldx = x.data_ptr(), int(x.stride(0))
     a.stats, a.gamma = stats.data_ptr(), gamma.data_ptr()

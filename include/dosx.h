@@ -366,6 +366,12 @@ typedef struct DosxFfnBwd {
    * [ dgamma | dbeta ] of that LayerNorm to every partial row (columns [2H,4H): partial_ld >= 4H). */
   const float* fin_gamma; const float* fin_xhat; const float* fin_rstd;
   float* fin_dy;
+  /* ... and, in front of that LayerNorm, the H -> 1 output layer of the model head (DOSTransformer_phonon.py:116-117
+   * `out_layer(LN(h))`): with fin_ddos != NULL (then `dy` may be NULL) the rows are  dy[r] = ddos[r % Bq][r / Bq] * w  for
+   * the [S, Bq] row space of the encoder and ddos [Bq, S]; the partial rows get [ dw (H) | db ] behind the LayerNorm's two
+   * groups (columns [4H, 5H] : partial_ld >= 5H + 1).  What dosx_ln_rowdot_bwd computes as a launch of its own. */
+  const float* fin_ddos; const float* fin_w; const float* fin_beta;
+  int32_t fin_S, fin_Bq;
 } DosxFfnBwd;
 int dosx_ffn_bwd_partial_rows(int M);
 int dosx_ffn_bwd(const DosxFfnBwd* a, dosx_stream_t stream);
