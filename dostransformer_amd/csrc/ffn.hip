@@ -354,7 +354,8 @@ __global__ __launch_bounds__(512) void ffn_bwd_kernel(const DosxFfnBwd a) {
   const bool fdot = fin && a.fin_ddos != nullptr;   // ... and in front of it the H -> 1 output layer (dy rows = ddos[r] * w)
   float4 pgf = f4zero(), pbf = f4zero(), pwf = f4zero();
   float pdb = 0.f;
-  if (fin) {
+  auto fin_rows = [&]() {
+  {
     float4 gf = f4zero(), bf = f4zero(), wf = f4zero();
     if (con) gf = ld4(a.fin_gamma + c0);
     if (fdot && con) { bf = ld4(a.fin_beta + c0); wf = ld4(a.fin_w + c0); }
@@ -396,6 +397,7 @@ __global__ __launch_bounds__(512) void ffn_bwd_kernel(const DosxFfnBwd a) {
       }
     }
   }
+  };
 
   if (wave_u >= 4) {
     // =============================== staging waves ===============================================
@@ -433,6 +435,7 @@ __global__ __launch_bounds__(512) void ffn_bwd_kernel(const DosxFfnBwd a) {
     };
     issue(r0, 0);
     issue(r1, 1);
+    if (fin) fin_rows();                           // (this wave's rows of the final-LayerNorm backward, weight loads in flight)
     store(ST, r0);
     issue(r0, 2);
     __syncthreads();                               // (matrix waves: Ys written) chunk 0 visible
@@ -453,6 +456,7 @@ __global__ __launch_bounds__(512) void ffn_bwd_kernel(const DosxFfnBwd a) {
     }
   } else {
     // =============================== matrix waves ================================================
+    if (fin) fin_rows();
     if (!fin) {   // dy tile -> Ys
       const int r = tid >> 3, rr = min(m0 + r, M - 1);
       for (int c = (tid & 7) * 4; c < H && r < R; c += 32) st4(Ys + r * LDX + c, ld4(a.dy + (size_t)rr * a.lddy + c));
