@@ -603,8 +603,8 @@ class GradSink:
         self.on_side(lambda: self._reduce(jobs))
 
     def flush(self):
+        self.join()              # (first: deferred weight-gradient jobs may read tensors produced on the side stream)
         self.run_grouped()
-        self.join()
         if self.wside is not None and self._wforked:
             self.main.wait_stream(self.wside)
             if RECORDER.active:

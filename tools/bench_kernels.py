@@ -48,6 +48,10 @@ def gemm_case(name, M, N, K, wl=0, pro=0, epi=0, nseg=1, gather=False):
                   epi_gamma=torch.randn(N, device=DEV), epi_beta=torch.randn(N, device=DEV),
                   epi_alpha=torch.tensor([0.25], device=DEV), partials=torch.empty(rows, 2 * N + 4, device=DEV),
                   partial_ld=2 * N + 4)
+    if epi == ops.EPI_PRELU_BWD:
+        rows = ops.gemm_partial_rows(M, N, epi)
+        kw = dict(epi=epi, aux=torch.randn(M, N, device=DEV), epi_alpha=torch.tensor([0.25], device=DEV),
+                  partials=torch.empty(rows, 4, device=DEV), partial_ld=4)
     if pro == ops.PRO_LN_PRELU:
         kw.update(pro=pro, pro_gamma=torch.randn(K, device=DEV), pro_beta=torch.randn(K, device=DEV),
                   pro_alpha=torch.tensor([0.25], device=DEV))
@@ -293,6 +297,8 @@ def main():
         gemm_case("eDOS fc1 H256 2B", 201 * 128, 1024, 256, pro=ops.PRO_ROWLN)
         gemm_case("eDOS edge da (PRELU_LN_BWD epi)", 17880, 512, 256, wl=1, epi=ops.EPI_PRELU_LN_BWD)
         gemm_case("cfg2 edge da (PRELU_LN_BWD epi)", 9000, 256, 128, wl=1, epi=ops.EPI_PRELU_LN_BWD)
+        gemm_case("node encoder dz (PRELU_BWD epi)", 424, 128, 128, wl=1, epi=ops.EPI_PRELU_BWD)
+        gemm_case("edge encoder dz (PRELU_BWD epi)", 9344, 128, 128, wl=1, epi=ops.EPI_PRELU_BWD)
     if w in ("all", "wgrad"):
         wgrad_case("edge W1 (2H x 3H)", E, 2 * H, 3 * H)
         wgrad_case("edge W2 (H x 2H)", E, H, 2 * H)
