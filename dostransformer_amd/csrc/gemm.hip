@@ -1547,6 +1547,7 @@ __global__ __launch_bounds__(512) void wgrad_grouped_kernel(const WgradGroup G) 
     case 1: wgrad_body<DOSX_PRO_PRELU, 1, 1>(L, bid, Sm); break;
     case 2: wgrad_body<DOSX_PRO_LN_PRELU, 1, 1>(L, bid, Sm); break;
     case 3: wgrad_body<DOSX_PRO_ROWLN, 1, 1>(L, bid, Sm); break;
+    case 4: wgrad_body<DOSX_PRO_NONE, 0, 0>(L, bid, Sm); break;      // unaligned operands (K = 118 atom features)
     default: break;
   }
 }
@@ -1659,7 +1660,8 @@ int wgrad_prepare(const DosxWgrad& g, WgradLaunch& L, int& vec, bool& fast, int&
   }
   if (!vec) DOSX_CHECK_ARG(g.pro == DOSX_PRO_NONE, "dosx_wgrad: prologue %d needs 4-float aligned operands", g.pro);
   DOSX_CHECK_ARG(g.pro >= DOSX_PRO_NONE && g.pro <= DOSX_PRO_ROWLN, "dosx_wgrad: bad prologue %d", g.pro);
-  L.variant = (vec && fast) ? (g.pro == DOSX_PRO_NONE ? 0 : g.pro == DOSX_PRO_PRELU ? 1 : g.pro == DOSX_PRO_LN_PRELU ? 2 : 3) : -1;
+  L.variant = (vec && fast) ? (g.pro == DOSX_PRO_NONE ? 0 : g.pro == DOSX_PRO_PRELU ? 1 : g.pro == DOSX_PRO_LN_PRELU ? 2 : 3)
+                            : (!vec ? 4 : -1);
   return 0;
 }
 
