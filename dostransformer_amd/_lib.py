@@ -115,6 +115,8 @@ class Ffn(C.Structure):
         ("out", C.c_void_p), ("ldo", C.c_int32),
         ("fin_gamma", C.c_void_p), ("fin_beta", C.c_void_p),
         ("fin_xhat", C.c_void_p), ("fin_rstd", C.c_void_p),
+        ("fin_w", C.c_void_p), ("fin_b", C.c_void_p), ("fin_dos", C.c_void_p),
+        ("fin_S", C.c_int32), ("fin_Bq", C.c_int32),
     ]
 
 

@@ -270,8 +270,11 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
   {
     const float* Cs = ST;
     const bool fin = a.fin_gamma != nullptr;
-    float4 fg = f4zero(), fb = f4zero();
+    const bool fdot = fin && a.fin_dos != nullptr;       // + the H -> 1 output layer on the normalised rows (model head)
+    float4 fg = f4zero(), fb = f4zero(), fw = f4zero();
     if (fin && con) { fg = ld4(a.fin_gamma + c0); fb = ld4(a.fin_beta + c0); }
+    if (fdot && con) fw = ld4(a.fin_w + c0);
+    const float fbias = fdot ? a.fin_b[0] : 0.f;
     const float invH = 1.f / (float)H;
 #pragma unroll
     for (int i = 0; i < ER; ++i) {
@@ -290,12 +293,18 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
       const float mean = wave_sum(o.x + o.y + o.z + o.w) * invH;        // lanes beyond H / rows beyond M hold zeros
       const float4 d = ok ? make_float4(o.x - mean, o.y - mean, o.z - mean, o.w - mean) : f4zero();
       const float rstd = rsqrtf(wave_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w) * invH + DOSX_LN_EPS);
+      float dot = 0.f;
       if (ok) {
         const float4 xh = make_float4(d.x * rstd, d.y * rstd, d.z * rstd, d.w * rstd);
+        const float4 y = make_float4(xh.x * fg.x + fb.x, xh.y * fg.y + fb.y, xh.z * fg.z + fb.z, xh.w * fg.w + fb.w);
         st4(a.fin_xhat + (size_t)r * H + c0, xh);
-        st4(a.out + (size_t)r * a.ldo + c0,
-            make_float4(xh.x * fg.x + fb.x, xh.y * fg.y + fb.y, xh.z * fg.z + fb.z, xh.w * fg.w + fb.w));
+        if (a.out) st4(a.out + (size_t)r * a.ldo + c0, y);
         if (lane == 0) a.fin_rstd[r] = rstd;
+        dot = y.x * fw.x + y.y * fw.y + y.z * fw.z + y.w * fw.w;
+      }
+      if (fdot) {                                    // dos[bq][s] of row r = s * Bq + bq  (what dosx_ln_rowdot writes)
+        dot = wave_sum(dot);
+        if (lane == 0 && r < M) a.fin_dos[(size_t)(r % a.fin_Bq) * a.fin_S + (r / a.fin_Bq)] = dot + fbias;
       }
     }
   }
@@ -646,7 +655,9 @@ extern "C" int dosx_ffn_fwd(const DosxFfn* ap, dosx_stream_t stream) {
   const DosxFfn& a = *ap;
   if (a.M <= 0) return 0;
   DOSX_CHECK_ARG(dosx_ffn_supported(a.H), "dosx_ffn_fwd: H=%d unsupported (multiple of 32, <= 128)", a.H);
-  DOSX_CHECK_ARG(a.x && a.stats && a.gamma && a.beta && a.w1 && a.b1 && a.w2 && a.b2 && a.h && a.out, "dosx_ffn_fwd: null operand");
+  DOSX_CHECK_ARG(a.x && a.stats && a.gamma && a.beta && a.w1 && a.b1 && a.w2 && a.b2 && a.h && (a.out || a.fin_dos), "dosx_ffn_fwd: null operand");
+  if (a.fin_dos) DOSX_CHECK_ARG(a.fin_gamma && a.fin_w && a.fin_b && a.fin_S > 0 && a.fin_Bq > 0 && a.fin_S * a.fin_Bq == a.M,
+                                "dosx_ffn_fwd: output-layer epilogue needs the final LayerNorm, w, b and S * Bq == M");
   DOSX_CHECK_ARG((a.ldx & 3) == 0 && (a.ldh & 3) == 0 && (a.ldo & 3) == 0, "dosx_ffn_fwd: leading dimensions must be multiples of 4");
   if (a.fin_gamma) DOSX_CHECK_ARG(a.fin_beta && a.fin_xhat && a.fin_rstd, "dosx_ffn_fwd: final LayerNorm needs beta / xhat / rstd");
   const long long span = (const char*)a.w1 > (const char*)a.w2 ? (const char*)a.w1 - (const char*)a.w2 : (const char*)a.w2 - (const char*)a.w1;

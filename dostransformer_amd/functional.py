@@ -230,11 +230,19 @@ def _attn_desc(Sq, Bq, Nk, Bk, H, qs, qb, x, kvhat, gam, bet) -> Attn:
 DROP_MASK_LOG: Optional[list] = None      # tests: set to a list to receive (prefix, layer, mask tensor) of every drawn mask
 
 
+def head_fused_fwd(H: int, T: int) -> bool:
+    """Whether encoder_fwd(head=...) computes final LayerNorm + output layer in its last ffn_fwd launch."""
+    return bool(ops.ffn_supported(H) and _FUSED_HEAD_FWD and T > 0)
+
+
 def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int, qb: int, kvhat: torch.Tensor,
-                Nk: int, Bk: int, H: int, T: int, final_ln: bool = True, drop=None):
+                Nk: int, Bk: int, H: int, T: int, final_ln: bool = True, drop=None, head=None):
     """x: query rows (row (s,bq) at (s*qs + bq*qb)); kvhat: [Nk*Bk, H] normalised keys (stale across layers).
     drop: None or (p, seed_dev, stream_base): attention dropout in training mode (multihead_attention.py:70) - every
-    layer draws its own [Bq,Sq,Nk] multiplier mask (ops.dropout_mask) that the backward re-uses."""
+    layer draws its own [Bq,Sq,Nk] multiplier mask (ops.dropout_mask) that the backward re-uses.
+    head = (gamma, beta, w, b, xhat [rows,H], rstd [rows], dos [Bq,Sq]) (with final_ln False, head_fused_fwd(H, T)): the
+    model head - LayerNorm + H->1 output layer on the encoder's output - in the last layer's ffn_fwd epilogue; the
+    encoder output itself is then not materialised (None is returned for it)."""
     dev = kvhat.device
     rows = Sq * Bq
     lay = []
@@ -265,6 +273,11 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
             if final_ln and t == T - 1:
                 fin_fused = (_empty(dev, rows, H), _empty(dev, rows))
                 fin_args = (P[pre + ".layer_norm.weight"], P[pre + ".layer_norm.bias"]) + fin_fused
+            elif head is not None and t == T - 1:
+                assert not final_ln and head_fused_fwd(H, T)
+                hg, hb, hw, hbias, hxh, hrs, hdos = head
+                fin_args = (hg, hb, hxh, hrs, hw, hbias, hdos, Sq, Bq)
+                x2 = None
             ops.ffn_fwd(rows, H, x1, st1, P[lp + ".layer_norms.1.weight"], P[lp + ".layer_norms.1.bias"],
                         P[lp + ".fc1.weight"], P[lp + ".fc1.bias"], P[lp + ".fc2.weight"], P[lp + ".fc2.bias"], h, x2,
                         fin=fin_args)
@@ -290,6 +303,7 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
 
 _FUSED_FFN_BWD = __import__("os").environ.get("DOSX_FUSED_FFN_BWD", "1") == "1"
 _FUSED_FIN_BWD = __import__("os").environ.get("DOSX_FUSED_FIN_BWD", "1") == "1"
+_FUSED_HEAD_FWD = __import__("os").environ.get("DOSX_FUSED_HEAD_FWD", "1") == "1"
 
 
 def head_fused_bwd(H: int, T: int) -> bool:
@@ -553,12 +567,17 @@ def dostransformer_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta, drop=None):
     rstd_s = _empty(dev, S * 2 * B)
     ops.rownorm(dosin, kvs, rstd_s, S * 2 * B, H)
     hs, c2 = encoder_fwd(P, "transformer_self", dosin, S, 2 * B, 2 * B, 1, kvs, S, 2 * B, H, T, drop=dr(64))
-    hsrc, c3 = encoder_fwd(P, "transformer_source", hs, S, 2 * B, 2 * B, 1, kvhat, nmax, B, H, T, final_ln=False, drop=dr(128))
     xhat_f = _empty(dev, S * 2 * B, H)
     rstd_f = _empty(dev, S * 2 * B)
     dos = _empty(dev, 2 * B, S)
-    ops.ln_rowdot(hsrc, P["transformer_source.layer_norm.weight"], P["transformer_source.layer_norm.bias"],
-                  P["out_layer.weight"], P["out_layer.bias"], xhat_f, rstd_f, dos, S, 2 * B, H)
+    gf, bf = P["transformer_source.layer_norm.weight"], P["transformer_source.layer_norm.bias"]
+    if head_fused_fwd(H, T):     # final LayerNorm + out_layer in the last ffn_fwd launch of the source encoder
+        _, c3 = encoder_fwd(P, "transformer_source", hs, S, 2 * B, 2 * B, 1, kvhat, nmax, B, H, T, final_ln=False,
+                            drop=dr(128), head=(gf, bf, P["out_layer.weight"], P["out_layer.bias"], xhat_f, rstd_f, dos))
+    else:
+        hsrc, c3 = encoder_fwd(P, "transformer_source", hs, S, 2 * B, 2 * B, 1, kvhat, nmax, B, H, T, final_ln=False,
+                               drop=dr(128))
+        ops.ln_rowdot(hsrc, gf, bf, P["out_layer.weight"], P["out_layer.bias"], xhat_f, rstd_f, dos, S, 2 * B, H)
     ctx = (ctrunk, kvhat, rstd_n, c1, dec_segs, sysidx, prow, dosin, a_g, a_s, kvs, rstd_s, c2, c3, xhat_f, rstd_f, xL)
     return dos, xL, ctx
 

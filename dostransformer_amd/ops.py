@@ -335,7 +335,8 @@ def ffn_supported(H: int) -> bool:
 def ffn_fwd(M: int, H: int, x: torch.Tensor, stats: torch.Tensor, gamma, beta, w1, b1, w2, b2, h: torch.Tensor,
             out: torch.Tensor, fin=None) -> None:
     """out = x + fc2(relu(fc1(LN1(x)))), h = relu(fc1(LN1(x))) in one launch (include/dosx.h: DosxFfn).
-    ``fin = (gamma, beta, xhat, rstd)``: also apply the encoder's final LayerNorm (out = LN(...), xhat / rstd saved)."""
+    ``fin = (gamma, beta, xhat, rstd)``: also apply the encoder's final LayerNorm (out = LN(...), xhat / rstd saved);
+    ``fin = (gamma, beta, xhat, rstd, w, b, dos, S, Bq)``: ... and the H -> 1 output layer behind it (``out`` may be None)."""
     a = Ffn()
     a.M, a.H = int(M), int(H)
     a.x, a.ldx = x.data_ptr(), int(x.stride(0))
@@ -343,9 +344,12 @@ def ffn_fwd(M: int, H: int, x: torch.Tensor, stats: torch.Tensor, gamma, beta, w
     a.gamma, a.beta = gamma.data_ptr(), beta.data_ptr()
     a.w1, a.b1, a.w2, a.b2 = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
     a.h, a.ldh = h.data_ptr(), int(h.stride(0))
-    a.out, a.ldo = out.data_ptr(), int(out.stride(0))
+    if out is not None:
+        a.out, a.ldo = out.data_ptr(), int(out.stride(0))
     if fin is not None:
-        a.fin_gamma, a.fin_beta, a.fin_xhat, a.fin_rstd = (t.data_ptr() for t in fin)
+        a.fin_gamma, a.fin_beta, a.fin_xhat, a.fin_rstd = (t.data_ptr() for t in fin[:4])
+        if len(fin) > 4:          # (.., w, b, dos [Bq,S], S, Bq): the model head's H -> 1 output layer on the normalised rows
+            a.fin_w, a.fin_b, a.fin_dos, a.fin_S, a.fin_Bq = fin[4].data_ptr(), fin[5].data_ptr(), fin[6].data_ptr(), int(fin[7]), int(fin[8])
     _call("dosx_ffn_fwd", C.byref(a), _stream(),
           w=lambda: (f"ffn_fwd[M{M},H{H}]", "ffn_fwd_kernel", "mfma", 16.0 * M * H * H))
 

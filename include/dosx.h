@@ -338,6 +338,11 @@ typedef struct DosxFfn {
    * normalised rows and fin_rstd [M] their 1/sigma (what dosx_layernorm would have produced from the un-normalised sum) */
   const float* fin_gamma; const float* fin_beta;
   float* fin_xhat; float* fin_rstd;
+  /* optional, with the final LayerNorm: the H -> 1 output layer of the model head on the normalised rows
+   * (DOSTransformer_phonon.py:116-117), dos[r % Bq][r / Bq] = LN(..)[r] . fin_w + fin_b[0] for the [S, Bq] row space
+   * (fin_dos [Bq, S]; what dosx_ln_rowdot computes as a launch of its own); `out` may then be NULL */
+  const float* fin_w; const float* fin_b; float* fin_dos;
+  int32_t fin_S, fin_Bq;
 } DosxFfn;
 int dosx_ffn_supported(int H);
 int dosx_ffn_fwd(const DosxFfn* a, dosx_stream_t stream);
