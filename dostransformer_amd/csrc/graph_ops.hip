@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void dense_normalize_slots_kernel(const float*
 // generic "no-affine LN backward" for one row: dx = rstd * (g - mean(g) - xhat * mean(g*xhat))
 __device__ __forceinline__ void rownorm_bwd_row(const float* __restrict__ g, const float* __restrict__ xh,
                                                 float rstd, float* __restrict__ dx, int H, int lane,
-                                                int accumulate) {
+                                                int accumulate, const float* __restrict__ addend = nullptr) {
   float s1 = 0.f, s2 = 0.f;
   for (int c = lane * 4; c < H; c += 256) {
     const float4 a = ld4(g + c), b = ld4(xh + c);
@@ -341,27 +341,41 @@ __device__ __forceinline__ void rownorm_bwd_row(const float* __restrict__ g, con
     float4 o = make_float4(rstd * (a.x - m1 - b.x * m2), rstd * (a.y - m1 - b.y * m2),
                            rstd * (a.z - m1 - b.z * m2), rstd * (a.w - m1 - b.w * m2));
     if (accumulate) o = f4add(o, ld4(dx + c));
+    if (addend) o = f4add(ld4(addend + c), o);
     st4(dx + c, o);
   }
 }
 
+// dpool / node_graph (optional): the sum-pooling backward of the decoder input rides along - dx[n] += dpool[node_graph[n]]
+// (scatter_sum(x, batch) backward, DOSTransformer_phonon.py:178-181), ghost nodes (graph id >= num_graphs) get nothing
 __global__ __launch_bounds__(256) void dense_normalize_bwd_kernel(const float* __restrict__ dkvhat,
                                                                   const float* __restrict__ kvhat,
                                                                   const float* __restrict__ rstd_nodes,
                                                                   const int* __restrict__ dense_row,
                                                                   float* __restrict__ dx, int N, int H,
-                                                                  int accumulate, int ghost_row) {
+                                                                  int accumulate, int ghost_row,
+                                                                  const float* __restrict__ dpool, int ld_dpool,
+                                                                  const int* __restrict__ node_graph, int num_graphs) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
   const int dr = dense_row[n];
+  const float* add = nullptr;
+  if (dpool) {
+    const int gph = node_graph[n];
+    if (gph < num_graphs) add = dpool + (size_t)gph * ld_dpool;
+  }
   if (dr == ghost_row) {            // ghost / padding node: zero gradient, rstd_nodes[n] was never written
-    if (!accumulate)
-      for (int c = lane * 4; c < H; c += 256) st4(dx + (size_t)n * H + c, f4zero());
+    if (!accumulate || add)
+      for (int c = lane * 4; c < H; c += 256) {
+        float4 o = accumulate ? ld4(dx + (size_t)n * H + c) : f4zero();
+        if (add) o = f4add(ld4(add + c), o);
+        st4(dx + (size_t)n * H + c, o);
+      }
     return;
   }
   const size_t d = (size_t)dr * H;
-  rownorm_bwd_row(dkvhat + d, kvhat + d, rstd_nodes[n], dx + (size_t)n * H, H, lane, accumulate);
+  rownorm_bwd_row(dkvhat + d, kvhat + d, rstd_nodes[n], dx + (size_t)n * H, H, lane, accumulate, add);
 }
 
 __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ x, float* __restrict__ xhat,
@@ -626,7 +640,21 @@ extern "C" int dosx_dense_normalize_bwd(const float* dkvhat, const float* kvhat,
   CHECK_H(H);
   DOSX_CHECK_ARG(dkvhat && kvhat && rstd_nodes && dense_row && dx, "dosx_dense_normalize_bwd: bad args");
   hipLaunchKernelGGL(dense_normalize_bwd_kernel, dim3(ceil_div(N, 4)), dim3(256), 0, to_stream(stream), dkvhat, kvhat,
-                     rstd_nodes, dense_row, dx, N, H, accumulate, ghost_row);
+                     rstd_nodes, dense_row, dx, N, H, accumulate, ghost_row, (const float*)nullptr, 0, (const int*)nullptr, 0);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_dense_normalize_pool_bwd(const float* dkvhat, const float* kvhat, const float* rstd_nodes,
+                                             const int32_t* dense_row, const float* dpool, int ld_dpool,
+                                             const int32_t* node_graph, int num_graphs, float* dx, int N, int H,
+                                             int accumulate, int ghost_row, dosx_stream_t stream) {
+  if (N <= 0) return 0;
+  CHECK_H(H);
+  DOSX_CHECK_ARG(dkvhat && kvhat && rstd_nodes && dense_row && dx && dpool && node_graph && num_graphs > 0 && (ld_dpool & 3) == 0,
+                 "dosx_dense_normalize_pool_bwd: bad args");
+  hipLaunchKernelGGL(dense_normalize_bwd_kernel, dim3(ceil_div(N, 4)), dim3(256), 0, to_stream(stream), dkvhat, kvhat,
+                     rstd_nodes, dense_row, dx, N, H, accumulate, ghost_row, dpool, ld_dpool, node_graph, num_graphs);
   DOSX_LAUNCH_CHECK();
   return 0;
 }

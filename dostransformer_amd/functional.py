@@ -510,16 +510,24 @@ def decoder_fwd(P: Params, cfg: ModelCfg, m: GraphMeta, xL: torch.Tensor, u: Opt
     return graph, segs
 
 
-def decoder_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, segs: SegList, dgraph: torch.Tensor, dxL: torch.Tensor,
-                sink: GradSink) -> Optional[Seg]:
-    """Adds the pooled-node gradient into dxL; returns the Seg of du (eDOS) or None."""
+def decoder_dgrad(P: Params, cfg: ModelCfg, m: GraphMeta, segs: SegList, dgraph: torch.Tensor) -> torch.Tensor:
+    """dL/d[u | pooled] of the decoder's Linear, [B, K] (the pooled block is its last H columns)."""
+    dcat = _empty(dgraph.device, m.num_graphs, segs.K)
+    ops.gemm(m.num_graphs, segs.K, [seg(dgraph)], P["GN_decoder.mlp.0.weight"], dcat, w_layout=1)
+    return dcat
+
+
+def decoder_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, segs: SegList, dgraph: torch.Tensor, dxL: Optional[torch.Tensor],
+                sink: GradSink, dcat: Optional[torch.Tensor] = None) -> Optional[Seg]:
+    """Adds the pooled-node gradient into dxL (dxL None: the caller folds it into another launch, see
+    ops.dense_normalize_pool_bwd; dcat: the dgrad already computed with decoder_dgrad); returns the Seg of du (eDOS) or None."""
     H, B, N = cfg.H, m.num_graphs, m.num_nodes
-    dev = dgraph.device
     _wgrad_linear(sink, G, "GN_decoder.mlp.0.weight", "GN_decoder.mlp.0.bias", B, H, seg(dgraph), segs.segs, keep=(dgraph,))
     K = segs.K
-    dcat = _empty(dev, B, K)
-    ops.gemm(B, K, [seg(dgraph)], P["GN_decoder.mlp.0.weight"], dcat, w_layout=1)
-    ops.graph_pool_bwd(dcat.data_ptr() + 4 * (K - H), K, m.node_graph, dxL, N, H, True, num_graphs=B)   # ghost nodes: zero
+    if dcat is None:
+        dcat = decoder_dgrad(P, cfg, m, segs, dgraph)
+    if dxL is not None:
+        ops.graph_pool_bwd(dcat.data_ptr() + 4 * (K - H), K, m.node_graph, dxL, N, H, True, num_graphs=B)   # ghost nodes: zero
     sink._keep.append(dcat)
     return seg(dcat, width=H, col=0) if K == 2 * H else None
 
@@ -641,6 +649,10 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
         ops.gemm(B, H, [seg(R[B:])], Wfp[:, H:2 * H], dgraph, w_layout=1, res=dgraph)
         ops.gemm(B, hp, [seg(R[B:])], Wfp[:, 2 * H:], dprow, w_layout=1)
         ops.embed_rows_bwd(dprow.data_ptr(), hp, sysidx, G[cfg.prompt_key], B, G[cfg.prompt_key].shape[0], hp)
+        # the decoder's dgrad needs only dgraph: it runs here, off the main chain, and its pooled block is added to the
+        # node gradient by the dense-key backward launch below (one launch on the main stream instead of three)
+        box_d["dcat"] = decoder_dgrad(P, cfg, m, dec_segs, dgraph)
+    box_d = {}
     sink.on_side(_const_inputs_bwd, (dpre, R, dgraph, dprow))
     # first encoder (queries = energy embeddings broadcast over the batch)
     dX1 = encoder_bwd(P, G, "transformer", c1, dE1, dkv, sink, kv_needed_next=True)
@@ -654,8 +666,11 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
         mid_hook(sink)                #  stream and the dk/dv kernels it is waiting for)
     # node embeddings: dense keys + pooled decoder input (+ external grad on the returned x)
     dxL = _empty(dev, N, H)
-    ops.dense_normalize_bwd(dkv, kvhat, rstd_n, m.dense_row, dxL, N, H, False, ghost_row=nmax * B)
-    du_seg = decoder_bwd(P, G, cfg, m, dec_segs, dgraph, dxL, sink)
+    dcat = box_d["dcat"]
+    Kd = dec_segs.K
+    ops.dense_normalize_pool_bwd(dkv, kvhat, rstd_n, m.dense_row, dcat.data_ptr() + 4 * (Kd - H), Kd, m.node_graph, B, dxL, N, H,
+                                 False, ghost_row=nmax * B)
+    du_seg = decoder_bwd(P, G, cfg, m, dec_segs, dgraph, None, sink, dcat=dcat)
     if dx_ext is not None:
         dxL.add_(dx_ext)
     gnn_trunk_bwd(P, G, cfg, m, ctrunk, dxL, du_seg, sink)

@@ -713,6 +713,14 @@ def dense_normalize_bwd(dkvhat, kvhat, rstd_nodes, dense_row, dx, N, H, accumula
           w=lambda: ("dense_normalize_bwd", "dense_normalize_bwd_kernel", "hbm", 4.0 * N * H * 3))
 
 
+def dense_normalize_pool_bwd(dkvhat, kvhat, rstd_nodes, dense_row, dpool_ptr, ld_dpool, node_graph, num_graphs, dx, N, H,
+                             accumulate, ghost_row=-1):
+    """dense_normalize_bwd + graph_pool_bwd in one launch (include/dosx.h: dosx_dense_normalize_pool_bwd)."""
+    _call("dosx_dense_normalize_pool_bwd", _p(dkvhat), _p(kvhat), _p(rstd_nodes), _p(dense_row), dpool_ptr, int(ld_dpool),
+          _p(node_graph), int(num_graphs), _p(dx), N, H, int(accumulate), int(ghost_row), _stream(),
+          w=lambda: ("dense_normalize_pool_bwd", "dense_normalize_bwd_kernel", "hbm", 4.0 * N * H * 4))
+
+
 def rownorm(x, xhat, rstd, M, H):
     _call("dosx_rownorm", _p(x), _p(xhat), _p(rstd), M, H, _stream(),
           w=lambda: ("rownorm", "rownorm_kernel", "hbm", 8.0 * M * H))

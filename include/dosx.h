@@ -217,6 +217,13 @@ int dosx_dense_normalize_slots(const float* x, const int32_t* graph_ptr, float* 
 int dosx_dense_normalize_bwd(const float* dkvhat, const float* kvhat, const float* rstd_nodes,
                              const int32_t* dense_row, float* dx, int N, int H, int accumulate, int ghost_row,
                              dosx_stream_t stream);
+/* ... with the backward of the decoder's sum pooling (scatter_sum(x, batch), DOSTransformer_phonon.py:178-181) in the same
+ * launch: dx[n] (+)= [the above] + dpool[node_graph[n]]  (dpool [B, >= H] with row stride ld_dpool; nodes whose graph id is
+ * >= num_graphs - ghost nodes - get no pooled term).  What dosx_dense_normalize_bwd followed by dosx_graph_pool_bwd do. */
+int dosx_dense_normalize_pool_bwd(const float* dkvhat, const float* kvhat, const float* rstd_nodes,
+                                  const int32_t* dense_row, const float* dpool, int ld_dpool, const int32_t* node_graph,
+                                  int num_graphs, float* dx, int N, int H, int accumulate, int ghost_row,
+                                  dosx_stream_t stream);
 
 /* Row LayerNorm without affine (key/value side of self attention) and with affine. */
 int dosx_rownorm(const float* x, float* xhat, float* rstd, int M, int H, dosx_stream_t stream);
