@@ -247,7 +247,9 @@ def node_mlp_case(name, M, H):
                  epi_beta=b, epi_alpha=al, partials=part2, partial_ld=pld)
         ops.gemm(M, 2 * H, [ops.seg(dz)], w1, dcat, w_layout=1)
     usb2 = timeit(twob)
-    print(f"nmlp  {name:30s} M={M} H={H}: fwd fused {us:6.1f} us | two GEMMs {us2:6.1f} us || bwd fused {usb:6.1f} us | two GEMMs {usb2:6.1f} us")
+    fl = 2.0 * M * 2 * H * 3 * H
+    print(f"nmlp  {name:30s} M={M} H={H}: fwd fused {us:6.1f} us ({fl / us / 1e6:5.1f} TF/s) | two GEMMs {us2:6.1f} us || "
+          f"bwd fused {usb:6.1f} us ({fl / usb / 1e6:5.1f} TF/s) | two GEMMs {usb2:6.1f} us")
 
 
 def main():
@@ -269,6 +271,7 @@ def main():
         node_mlp_case("one crystal", 7, H)
         node_mlp_case("cfg3 nodes (eDOS)", 1554, 256)
         node_mlp_case("4096 rows", 4096, H)
+        node_mlp_case("roofline scale", 262144, H)
     if w in ("all", "neighbors"):
         neighbor_case("phonon-set sized", 1500, 4.0)
         neighbor_case("phonon-set sized", 1500, 6.0)
