@@ -187,6 +187,67 @@ __device__ __forceinline__ void stream_stage(const DosxAttn& a, const Geo& g, co
   }
 }
 
+// ---- one key tile (Nk <= 32): RESIDENT keys, Q.K^T split over the feature dimension --------------------------------------
+// With a single 32-key tile the streamed Q.K^T runs on ONE matrix wave behind one barrier per 32-feature chunk (H = 128: four
+// chunks of 16 MFMAs each, ~2.4 us of a ~9.5 us kernel).  The whole key set of the crystal is only HP/32 chunks of 4.6 KB,
+// so the staging waves fetch ALL of them at once (one barrier), matrix wave w multiplies the feature chunks w, w+4 and leaves
+// its partial 32 x 32 score tile in LDS; the softmax phase adds the four partials while it reads the scores.
+constexpr int KCH = QT * LDK;          // floats of one resident K chunk [32 keys][36]
+constexpr int MAX_KCH = 8;             // H <= 256
+
+__device__ __forceinline__ void stage_resident(const DosxAttn& a, const Geo& g, float* CH, int bk, int st) {
+  const int H = a.H, Nk = a.Nk;
+  const __amdgpu_buffer_rsrc_t rK =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.kvhat, 0, (uint32_t)((size_t)Nk * a.Bk * H * 4), 0x00020000);
+  const int jr = st >> 3, q4 = (st & 7) * 4;
+  const int nkc = g.HP / 32;
+  const uint32_t vk = (uint32_t)((((size_t)jr * a.Bk + bk) * H + q4) * 4);     // key row jr (rows >= Nk: zeros by the bounds)
+  float4 rk[MAX_KCH], rv[SVC];
+#pragma unroll
+  for (int c = 0; c < MAX_KCH; ++c)
+    if (c < nkc) rk[c] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rK, vk, c * (KC * 4), 0));
+#pragma unroll
+  for (int i = 0; i < SVC; ++i) {      // the same rows again as the V chunk [32 keys][HP] (served by L2)
+    const int c = q4 + 32 * i;
+    if (i < nkc)
+      rv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+          rK, (uint32_t)((((size_t)jr * a.Bk + bk) * H + (c < H ? c : 0)) * 4), 0, 0));
+  }
+#pragma unroll
+  for (int c = 0; c < MAX_KCH; ++c)
+    if (c < nkc) st4(CH + c * KCH + jr * LDK + q4, rk[c]);
+  __syncthreads();                     // keys visible (matrix waves: Qs written)
+  __syncthreads();                     // partial scores stored: the key chunks are dead
+#pragma unroll
+  for (int i = 0; i < SVC; ++i)
+    if (i < nkc) st4(CH + jr * g.LDH + q4 + 32 * i, rv[i]);
+  __syncthreads();                     // softmax done, V visible
+  __syncthreads();                     // end of the (single) V chunk
+}
+
+// matrix wave w: Sp[w][32][36] = Qs[:, chunks w, w+4] . K^T   (partial over its share of the features)
+__device__ __forceinline__ void qk_resident(const float* As, int LDH, const float* CH, int nkc, float* Sp, int tid) {
+  const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int c = wave; c < nkc; c += 4) {
+    const float* Kc = CH + c * KCH;
+#pragma unroll
+    for (int kk = 0; kk < KC; kk += 8) {
+      const float4 av = ld4(As + l31 * LDH + c * KC + kk + 4 * hh);
+      const float4 b = ld4(Kc + l31 * LDK + kk + 4 * hh);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b.w, acc, 0, 0, 0);
+    }
+  }
+  float* mine = Sp + wave * KCH;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * hh) * LDK + l31] = acc[r];
+}
+
 // matrix waves: S[32][NKP] = A[32][HP] . kvhat^T, one barrier per streamed feature chunk
 __device__ __forceinline__ void stream_qk(f32x16 (&acc)[MAX_KT], const float* As, int LDH, const float* CH, const StreamGeo& sg,
                                           int NKP, int tid) {
@@ -269,8 +330,11 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const DosxAttn a) 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q16 = lane & 15;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int s0 = blockIdx.x * QT, bq = blockIdx.y, bk = bq % a.Bk;
+  constexpr bool RESIDENT = (NJ == 1);              // Nk <= 16: one key tile, keys resident, Q.K^T split over the features
+  float* Sp = CH + 2 * sg.CHB;                      // [4][32][36] partial score tiles (RESIDENT only)
   if (wave_u >= 4) {
-    stream_stage(a, g, sg, CH, bk, tid - 256);
+    if constexpr (RESIDENT) stage_resident(a, g, CH, bk, tid - 256);
+    else stream_stage(a, g, sg, CH, bk, tid - 256);
     return;                                         // (the epilogue barrier below counts live waves only)
   }
   const int H = a.H, Sq = a.Sq, Nk = a.Nk;
@@ -341,9 +405,13 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const DosxAttn a) 
   }
   __syncthreads();
 
-  f32x16 sacc[MAX_KT];
-  stream_qk(sacc, Qs, g.LDH, CH, sg, g.NKP, tid);
-  store_scores1(sacc, Ss, g.LDS_, g.NKP, tid);
+  if constexpr (RESIDENT) {
+    qk_resident(Qs, g.LDH, CH, sg.nkc, Sp, tid);
+  } else {
+    f32x16 sacc[MAX_KT];
+    stream_qk(sacc, Qs, g.LDH, CH, sg, g.NKP, tid);
+    store_scores1(sacc, Ss, g.LDS_, g.NKP, tid);
+  }
   __syncthreads();
 
   float psum[RP];
@@ -356,11 +424,15 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const DosxAttn a) 
 #pragma unroll
     for (int p = 0; p < RP; ++p) {
       const float* row = Ss + row_of(wave, p, lane) * g.LDS_;
+      const float* prow = Sp + row_of(wave, p, lane) * LDK;
       mx[p] = -INFINITY;
 #pragma unroll
       for (int jj = 0; jj < NJ; ++jj) {
         const int j = q16 + 16 * jj;
-        const float t = j < Nk ? row[j] * scale : -INFINITY;
+        float sc_ = 0.f;
+        if constexpr (RESIDENT) sc_ = (prow[j] + prow[KCH + j]) + (prow[2 * KCH + j] + prow[3 * KCH + j]);
+        else sc_ = row[j];
+        const float t = j < Nk ? sc_ * scale : -INFINITY;
         v[p][jj] = t;
         mx[p] = fmaxf(mx[p], t);
       }
@@ -499,11 +571,14 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(const DosxAttn 
   float* Ps2 = CH + max(2 * sg.CHB, 32 * g.HP);     // PKV: [32][LDS_] P tile
   float* dOr = Ps2 + QT * g.LDS_;                   // PKV: [32][LDH] raw dO rows
   float* Ql = Ds;                                   // PKV: [32][LDH] LN0(x) gamma0 + beta0 - takes over Ds once dP is done
+  constexpr bool RESIDENT = (NJ == 1);              // Nk <= 16: resident keys, dP split over the features (see qk_resident)
+  float* Sp = PKV ? dOr + QT * g.LDH + 64 : Ps2;    // RESIDENT: [4][32][36] partial dP tiles, behind everything else
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q16 = lane & 15;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int s0 = blockIdx.x * QT, bq = blockIdx.y, bk = bq % a.Bk;
   if (wave_u >= 4) {
-    stream_stage(a, g, sg, CH, bk, tid - 256);
+    if constexpr (RESIDENT) stage_resident(a, g, CH, bk, tid - 256);
+    else stream_stage(a, g, sg, CH, bk, tid - 256);
     return;
   }
   const int H = a.H, Sq = a.Sq, Nk = a.Nk;
@@ -579,9 +654,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(const DosxAttn 
   __syncthreads();
 
   // dP (up to a row constant) = (dO gamma) . k̂^T
-  f32x16 sacc[MAX_KT];
-  stream_qk(sacc, Ds, g.LDH, CH, sg, g.NKP, tid);
-  store_scores1(sacc, Ss, g.LDS_, g.NKP, tid);
+  if constexpr (RESIDENT) {
+    qk_resident(Ds, g.LDH, CH, sg.nkc, Sp, tid);
+  } else {
+    f32x16 sacc[MAX_KT];
+    stream_qk(sacc, Ds, g.LDH, CH, sg, g.NKP, tid);
+    store_scores1(sacc, Ss, g.LDS_, g.NKP, tid);
+  }
   __syncthreads();
 
   // dS = P * (dP - rowsum(P*dP)) * scale
@@ -591,11 +670,14 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(const DosxAttn 
 #pragma unroll
     for (int p = 0; p < RP; ++p) {
       const float* row = Ss + row_of(wave, p, lane) * g.LDS_;
+      const float* prow = Sp + row_of(wave, p, lane) * LDK;
       dot[p] = 0.f;
 #pragma unroll
       for (int jj = 0; jj < NJ; ++jj) {
         const int j = q16 + 16 * jj;
-        float t = j < Nk ? row[j] : 0.f;
+        float t = 0.f;
+        if constexpr (RESIDENT) { if (j < Nk) t = (prow[j] + prow[KCH + j]) + (prow[2 * KCH + j] + prow[3 * KCH + j]); }
+        else t = j < Nk ? row[j] : 0.f;
         if (a.drop_mask) t = (t + cq[p]) * mk[p][jj];
         if (j < Nk) dot[p] += pr[p][jj] * t;
         dp[p][jj] = t;
@@ -1093,16 +1175,17 @@ __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(const DosxAttn a, 
   }
 }
 
-size_t fwd_smem(const Geo& g) {
-  return sizeof(float) * (size_t)(QT * g.LDH + QT * g.LDS_ + 2 * chunk_buf_floats(g.NKP, g.LDH));
+size_t fwd_smem(const Geo& g) {      // (+ the four partial score tiles of the resident-key path)
+  return sizeof(float) * (size_t)(QT * g.LDH + QT * g.LDS_ + 2 * chunk_buf_floats(g.NKP, g.LDH) + 4 * KCH);
 }
-size_t dq_smem(const Geo& g, bool pkv = false) {    // (the [16][2][HP] column partial sums reuse the chunk buffers)
+size_t dq_smem(const Geo& g, bool pkv = false, bool resident = false) {    // (the [16][2][HP] column partial sums reuse the chunk buffers)
   size_t fl = (size_t)QT * g.LDH + (size_t)QT * g.LDS_ + (size_t)max(2 * chunk_buf_floats(g.NKP, g.LDH), 32 * g.HP);
   if (pkv) fl += (size_t)QT * g.LDS_ + (size_t)QT * g.LDH + 64;      // P tile, raw dO rows (the query rows take over Ds)
+  if (resident) fl += 4 * KCH;                                         // partial dP tiles of the resident-key path (Nk <= 16)
   return sizeof(float) * fl;
 }
 inline bool pkv_ok(const DosxAttn& a) {
-  return a.dkv_part != nullptr && a.Nk <= 64 && dq_smem(make_geo(a.H, a.Nk), true) <= 160 * 1024;
+  return a.dkv_part != nullptr && a.Nk <= 64 && dq_smem(make_geo(a.H, a.Nk), true, a.Nk <= 16) <= 160 * 1024;
 }
 size_t dkv_smem(const Geo& g, int kg) {
   const size_t stage = 2 * (size_t)(2 * DQC * g.LDH + 2 * DQC * (32 * kg + 4));
@@ -1122,7 +1205,7 @@ int check_attn(const DosxAttn& a, const char* who) {
 }  // namespace
 
 extern "C" int dosx_attention_pkv_supported(int Nk, int H) {
-  return Nk > 0 && Nk <= 64 && H > 0 && H <= 256 && dq_smem(make_geo(H, Nk), true) <= 160 * 1024;
+  return Nk > 0 && Nk <= 64 && H > 0 && H <= 256 && dq_smem(make_geo(H, Nk), true, Nk <= 16) <= 160 * 1024;
 }
 
 extern "C" int dosx_attention_fwd(const DosxAttn* ap, dosx_stream_t stream) {
@@ -1160,7 +1243,7 @@ extern "C" int dosx_attention_bwd(const DosxAttn* ap, dosx_stream_t stream) {
   const Geo g = make_geo(a.H, a.Nk);
   const int kg = a.Nk > 32 ? 2 : 1;
   const bool pkv = pkv_ok(a);
-  const size_t s1 = dq_smem(g, pkv), s2 = dkv_smem(g, kg);
+  const size_t s1 = dq_smem(g, pkv, a.Nk <= 16), s2 = dkv_smem(g, kg);
   DOSX_CHECK_ARG(s1 <= 160 * 1024 && s2 <= 160 * 1024, "dosx_attention_bwd: LDS need %zu/%zu > 160 KiB", s1, s2);
   static bool attr_set = false;
   if (!attr_set) {
