@@ -359,7 +359,7 @@ def main():
                                     f"{N_DISTINCT_BATCHES} distinct pre-collated batches"),
                        "global_batch": n_global, "parallelism": f"dp{world}",
                        "launch": {"graph": "hip-graph replay per (N,E) bucket, exact ghost padding",
-                                  "replay": "recorded launch list per (N,E) bucket (exact ghost padding), 2 HIP streams",
+                                  "replay": "recorded launch list per (N,E) bucket (exact ghost padding), 3 HIP streams (dgrad chain | key-gradient / constant-input side work | weight gradients)",
                                   "eager": "eager"}[mode],
                        "bucket": list(bucket),
                        "kernel_timing": {"replay": "HIP event pair around every launch of the REPLAYED step (dosx_replay_timed, each "
