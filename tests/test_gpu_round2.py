@@ -643,3 +643,66 @@ def test_final_layernorm_backward_inside_ffn_bwd(H, S, B, mode, monkeypatch):
     assert set(g1) == set(g0) and "layer_norm.weight" in g1
     for k in g0:
         assert float((g1[k] - g0[k]).abs().max()) <= 5e-6 * sc(g0[k]), k
+
+
+def test_dense_normalize_pool_bwd_is_the_two_launches():
+    """dosx_dense_normalize_pool_bwd == dosx_dense_normalize_bwd followed by dosx_graph_pool_bwd, bit for bit (ghost nodes
+    included: spare dense row, graph id >= B)."""
+    from dostransformer_amd import ops
+    torch.manual_seed(0)
+    B, H, nmax = 5, 128, 7
+    counts = [3, 7, 1, 4, 6]
+    N_real = sum(counts)
+    N = N_real + 3                                   # 3 ghost (padding) nodes
+    node_graph = torch.tensor(sum(([b] * c for b, c in enumerate(counts)), []) + [B] * 3, dtype=torch.int32, device=DEV)
+    dense_row = []
+    for b, c in enumerate(counts):
+        dense_row += [pos * B + b for pos in range(c)]
+    dense_row += [nmax * B] * 3
+    dense_row = torch.tensor(dense_row, dtype=torch.int32, device=DEV)
+    dkv = torch.randn(nmax * B + 1, H, device=DEV)
+    kvhat = torch.randn(nmax * B + 1, H, device=DEV)
+    rstd = torch.rand(N, device=DEV) + 0.5
+    K = 2 * H
+    dcat = torch.randn(B, K, device=DEV)
+    a = torch.full((N, H), float("nan"), device=DEV)
+    ops.dense_normalize_bwd(dkv, kvhat, rstd, dense_row, a, N, H, False, ghost_row=nmax * B)
+    ops.graph_pool_bwd(dcat.data_ptr() + 4 * (K - H), K, node_graph, a, N, H, True, num_graphs=B)
+    b = torch.full((N, H), float("nan"), device=DEV)
+    ops.dense_normalize_pool_bwd(dkv, kvhat, rstd, dense_row, dcat.data_ptr() + 4 * (K - H), K, node_graph, B, b, N, H, False,
+                                 ghost_row=nmax * B)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert float(b[N_real:].abs().max()) == 0.0      # ghost nodes: exact zeros
+
+
+@pytest.mark.parametrize("H,S,B", [(128, 51, 4), (64, 51, 3)])
+def test_head_inside_ffn_kernels_matches_standalone_launches(H, S, B, monkeypatch):
+    """Final LayerNorm + out_layer in the last ffn_fwd epilogue / first ffn_bwd prologue of the source encoder against the
+    ln_rowdot(_bwd) launches they replace: same DOS, same gradients (fp32 rounding of a different summation tree only)."""
+    from dostransformer_amd import functional as Fn
+    from dostransformer_amd.batch import collate
+    from dostransformer_amd import synth
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    torch.manual_seed(1)
+    model = DOSTransformer_phonon(2, 2, 118, 4, H, DEV, 0.0).to(DEV)
+    g = collate(synth.phonon_crystals(B, 77, torch.float32)).to(DEV)
+
+    def run(fused):
+        monkeypatch.setattr(Fn, "_FUSED_HEAD_FWD", fused)
+        monkeypatch.setattr(Fn, "_FUSED_FIN_BWD", fused)
+        model.zero_grad(set_to_none=True)
+        out = model(g)
+        loss = (out[0] ** 2).sum() + 0.5 * (out[2] ** 2).sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        return [o.detach().clone() for o in (out[0], out[2])], {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    o1, g1 = run(True)
+    o0, g0 = run(False)
+    sc = lambda t: float(t.abs().max()) + 1e-30
+    for a, b in zip(o1, o0):
+        assert float((a - b).abs().max()) <= 2e-6 * sc(b)
+    assert set(g1) == set(g0)
+    for k in g0:
+        assert float((g1[k] - g0[k]).abs().max()) <= 1e-5 * sc(g0[k]), k
