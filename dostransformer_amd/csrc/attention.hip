@@ -187,52 +187,69 @@ __device__ __forceinline__ void stream_stage(const DosxAttn& a, const Geo& g, co
   }
 }
 
-// ---- one key tile (Nk <= 32): RESIDENT keys, Q.K^T split over the feature dimension --------------------------------------
-// With a single 32-key tile the streamed Q.K^T runs on ONE matrix wave behind one barrier per 32-feature chunk (H = 128: four
-// chunks of 16 MFMAs each, ~2.4 us of a ~9.5 us kernel).  The whole key set of the crystal is only HP/32 chunks of 4.6 KB,
-// so the staging waves fetch ALL of them at once (one barrier), matrix wave w multiplies the feature chunks w, w+4 and leaves
-// its partial 32 x 32 score tile in LDS; the softmax phase adds the four partials while it reads the scores.
-constexpr int KCH = QT * LDK;          // floats of one resident K chunk [32 keys][36]
+// ---- one or two key tiles (Nk <= 64): RESIDENT keys, Q.K^T split over the feature dimension -------------------------------
+// With a single 32-key tile the streamed Q.K^T runs on ONE matrix wave (two tiles: on two) behind one barrier per 32-feature
+// chunk (H = 128: four chunks of 16 MFMAs each, ~2.4 us of a ~9.5 us kernel).  The whole key set of the crystal is only HP/32
+// chunks of 4.6 / 9.2 KB, so the staging waves fetch ALL of them at once (one barrier); matrix wave w multiplies key tile
+// w % tiles with the feature chunks w / tiles, + 4 / tiles, ... and leaves its partial 32 x 32 score tile in LDS; the softmax
+// / dS phase adds the 4 / tiles partials of a key while it reads the scores.
+constexpr int KCH = QT * LDK;          // floats of one partial score tile [32][36] (= one 32-key K chunk)
 constexpr int MAX_KCH = 8;             // H <= 256
 
-__device__ __forceinline__ void stage_resident(const DosxAttn& a, const Geo& g, float* CH, int bk, int st) {
+__host__ __device__ inline int resident_k_floats(const Geo& g) { return (g.HP / 32) * g.NKP * LDK; }
+
+__device__ __forceinline__ void stage_resident(const DosxAttn& a, const Geo& g, const StreamGeo& sg, float* CH, int bk, int st) {
   const int H = a.H, Nk = a.Nk;
   const __amdgpu_buffer_rsrc_t rK =
       __builtin_amdgcn_make_buffer_rsrc((void*)a.kvhat, 0, (uint32_t)((size_t)Nk * a.Bk * H * 4), 0x00020000);
   const int jr = st >> 3, q4 = (st & 7) * 4;
-  const int nkc = g.HP / 32;
-  const uint32_t vk = (uint32_t)((((size_t)jr * a.Bk + bk) * H + q4) * 4);     // key row jr (rows >= Nk: zeros by the bounds)
-  float4 rk[MAX_KCH], rv[SVC];
+  const int nkc = g.HP / 32, nrb = g.NKP / 32, kcf = g.NKP * LDK;
+  float4 rk[MAX_KCH][2], rv[SVC][2];
 #pragma unroll
-  for (int c = 0; c < MAX_KCH; ++c)
-    if (c < nkc) rk[c] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rK, vk, c * (KC * 4), 0));
+  for (int t = 0; t < 2; ++t) {
+    if (t < nrb) {
+      const uint32_t vk = (uint32_t)((((size_t)(jr + 32 * t) * a.Bk + bk) * H + q4) * 4);   // key row (rows >= Nk: zeros by the bounds)
 #pragma unroll
-  for (int i = 0; i < SVC; ++i) {      // the same rows again as the V chunk [32 keys][HP] (served by L2)
-    const int c = q4 + 32 * i;
-    if (i < nkc)
-      rv[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
-          rK, (uint32_t)((((size_t)jr * a.Bk + bk) * H + (c < H ? c : 0)) * 4), 0, 0));
+      for (int c = 0; c < MAX_KCH; ++c)
+        if (c < nkc) rk[c][t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rK, vk, c * (KC * 4), 0));
+#pragma unroll
+      for (int i = 0; i < SVC; ++i) {  // the same rows again as the V chunks [32 keys][HP] (served by L2)
+        const int c = q4 + 32 * i;
+        if (i < nkc)
+          rv[i][t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+              rK, (uint32_t)((((size_t)(jr + 32 * t) * a.Bk + bk) * H + (c < H ? c : 0)) * 4), 0, 0));
+      }
+    }
   }
 #pragma unroll
-  for (int c = 0; c < MAX_KCH; ++c)
-    if (c < nkc) st4(CH + c * KCH + jr * LDK + q4, rk[c]);
+  for (int t = 0; t < 2; ++t)
+    if (t < nrb) {
+#pragma unroll
+      for (int c = 0; c < MAX_KCH; ++c)
+        if (c < nkc) st4(CH + c * kcf + (jr + 32 * t) * LDK + q4, rk[c][t]);
+    }
   __syncthreads();                     // keys visible (matrix waves: Qs written)
   __syncthreads();                     // partial scores stored: the key chunks are dead
 #pragma unroll
-  for (int i = 0; i < SVC; ++i)
-    if (i < nkc) st4(CH + jr * g.LDH + q4 + 32 * i, rv[i]);
+  for (int t = 0; t < 2; ++t)
+    if (t < nrb) {
+#pragma unroll
+      for (int i = 0; i < SVC; ++i)
+        if (i < nkc) st4(CH + t * sg.CHB + jr * g.LDH + q4 + 32 * i, rv[i][t]);
+    }
   __syncthreads();                     // softmax done, V visible
-  __syncthreads();                     // end of the (single) V chunk
+  for (int c = 0; c < nrb; ++c) __syncthreads();       // one per V chunk (stream_pv)
 }
 
-// matrix wave w: Sp[w][32][36] = Qs[:, chunks w, w+4] . K^T   (partial over its share of the features)
-__device__ __forceinline__ void qk_resident(const float* As, int LDH, const float* CH, int nkc, float* Sp, int tid) {
+// matrix wave w: Sp[w][32][36] = Qs[:, its feature chunks] . K[key tile w % tiles]^T   (partial over its share of the features)
+__device__ __forceinline__ void qk_resident(const float* As, int LDH, const float* CH, int nkc, int NKP, float* Sp, int tid) {
   const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int nkt = NKP >> 5, jt = wave % nkt, step = 4 / nkt, kcf = NKP * LDK;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int c = wave; c < nkc; c += 4) {
-    const float* Kc = CH + c * KCH;
+  for (int c = wave / nkt; c < nkc; c += step) {
+    const float* Kc = CH + c * kcf + jt * 32 * LDK;
 #pragma unroll
     for (int kk = 0; kk < KC; kk += 8) {
       const float4 av = ld4(As + l31 * LDH + c * KC + kk + 4 * hh);
@@ -246,6 +263,14 @@ __device__ __forceinline__ void qk_resident(const float* As, int LDH, const floa
   float* mine = Sp + wave * KCH;
 #pragma unroll
   for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * hh) * LDK + l31] = acc[r];
+}
+
+// the score of (query row of `prow`, key j): sum of the partial tiles of the waves that own key tile j / 32
+__device__ __forceinline__ float resident_score(const float* prow, int j, int NKP) {
+  const int jl = j & 31;
+  if (NKP <= 32) return (prow[jl] + prow[KCH + jl]) + (prow[2 * KCH + jl] + prow[3 * KCH + jl]);
+  const int jt = j >> 5;
+  return prow[jt * KCH + jl] + prow[(jt + 2) * KCH + jl];
 }
 
 // matrix waves: S[32][NKP] = A[32][HP] . kvhat^T, one barrier per streamed feature chunk
@@ -318,7 +343,7 @@ __device__ __forceinline__ void store_scores1(const f32x16 (&acc)[MAX_KT], float
   }
 }
 
-template <int NJ>
+template <int NJ, bool RESIDENT>
 __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const DosxAttn a) {
   extern __shared__ __align__(16) float sm[];
   const Geo g = make_geo(a.H, a.Nk);
@@ -330,10 +355,10 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const DosxAttn a) 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q16 = lane & 15;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int s0 = blockIdx.x * QT, bq = blockIdx.y, bk = bq % a.Bk;
-  constexpr bool RESIDENT = (NJ == 1);              // Nk <= 16: one key tile, keys resident, Q.K^T split over the features
-  float* Sp = CH + 2 * sg.CHB;                      // [4][32][36] partial score tiles (RESIDENT only)
+  // RESIDENT (Nk <= 64 when it fits the LDS): keys resident, Q.K^T split over the features (see qk_resident)
+  float* Sp = CH + max(2 * sg.CHB, resident_k_floats(g));      // [4][32][36] partial score tiles (RESIDENT only)
   if (wave_u >= 4) {
-    if constexpr (RESIDENT) stage_resident(a, g, CH, bk, tid - 256);
+    if constexpr (RESIDENT) stage_resident(a, g, sg, CH, bk, tid - 256);
     else stream_stage(a, g, sg, CH, bk, tid - 256);
     return;                                         // (the epilogue barrier below counts live waves only)
   }
@@ -406,7 +431,7 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const DosxAttn a) 
   __syncthreads();
 
   if constexpr (RESIDENT) {
-    qk_resident(Qs, g.LDH, CH, sg.nkc, Sp, tid);
+    qk_resident(Qs, g.LDH, CH, sg.nkc, g.NKP, Sp, tid);
   } else {
     f32x16 sacc[MAX_KT];
     stream_qk(sacc, Qs, g.LDH, CH, sg, g.NKP, tid);
@@ -430,7 +455,7 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const DosxAttn a) 
       for (int jj = 0; jj < NJ; ++jj) {
         const int j = q16 + 16 * jj;
         float sc_ = 0.f;
-        if constexpr (RESIDENT) sc_ = (prow[j] + prow[KCH + j]) + (prow[2 * KCH + j] + prow[3 * KCH + j]);
+        if constexpr (RESIDENT) { if (j < Nk) sc_ = resident_score(prow, j, g.NKP); }
         else sc_ = row[j];
         const float t = j < Nk ? sc_ * scale : -INFINITY;
         v[p][jj] = t;
@@ -558,7 +583,7 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const DosxAttn a) 
 // and applies the key-side chain rule.  That replaces attn_bwd_dkv_kernel for NKP <= 64 (cfg2: cross attention over
 // <= 12 atoms, self attention over 51 bins): that kernel re-streamed every dO / x row and the dS round trip through HBM
 // behind one barrier per 16 queries - 27 us per launch for 0.08 GF - where this costs 32-64 MFMAs per wave.
-template <int NJ, bool PKV>
+template <int NJ, bool PKV, bool RESIDENT>
 __global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(const DosxAttn a) {
   extern __shared__ __align__(16) float sm[];
   const Geo g = make_geo(a.H, a.Nk);
@@ -568,16 +593,15 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(const DosxAttn 
   float* Ss = Ds + QT * g.LDH;                      // [32][LDS_] dP -> dS
   float* CH = Ss + QT * g.LDS_;                     // two chunk buffers; later [16][2][HP] column partial sums
   float* Pp = CH;
-  float* Ps2 = CH + max(2 * sg.CHB, 32 * g.HP);     // PKV: [32][LDS_] P tile
+  float* Ps2 = CH + max(max(2 * sg.CHB, 32 * g.HP), RESIDENT ? resident_k_floats(g) : 0);     // PKV: [32][LDS_] P tile
   float* dOr = Ps2 + QT * g.LDS_;                   // PKV: [32][LDH] raw dO rows
   float* Ql = Ds;                                   // PKV: [32][LDH] LN0(x) gamma0 + beta0 - takes over Ds once dP is done
-  constexpr bool RESIDENT = (NJ == 1);              // Nk <= 16: resident keys, dP split over the features (see qk_resident)
   float* Sp = PKV ? dOr + QT * g.LDH + 64 : Ps2;    // RESIDENT: [4][32][36] partial dP tiles, behind everything else
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q16 = lane & 15;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int s0 = blockIdx.x * QT, bq = blockIdx.y, bk = bq % a.Bk;
   if (wave_u >= 4) {
-    if constexpr (RESIDENT) stage_resident(a, g, CH, bk, tid - 256);
+    if constexpr (RESIDENT) stage_resident(a, g, sg, CH, bk, tid - 256);
     else stream_stage(a, g, sg, CH, bk, tid - 256);
     return;
   }
@@ -655,7 +679,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(const DosxAttn 
 
   // dP (up to a row constant) = (dO gamma) . k̂^T
   if constexpr (RESIDENT) {
-    qk_resident(Ds, g.LDH, CH, sg.nkc, Sp, tid);
+    qk_resident(Ds, g.LDH, CH, sg.nkc, g.NKP, Sp, tid);
   } else {
     f32x16 sacc[MAX_KT];
     stream_qk(sacc, Ds, g.LDH, CH, sg, g.NKP, tid);
@@ -676,7 +700,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(const DosxAttn 
       for (int jj = 0; jj < NJ; ++jj) {
         const int j = q16 + 16 * jj;
         float t = 0.f;
-        if constexpr (RESIDENT) { if (j < Nk) t = (prow[j] + prow[KCH + j]) + (prow[2 * KCH + j] + prow[3 * KCH + j]); }
+        if constexpr (RESIDENT) { if (j < Nk) t = resident_score(prow, j, g.NKP); }
         else t = j < Nk ? row[j] : 0.f;
         if (a.drop_mask) t = (t + cq[p]) * mk[p][jj];
         if (j < Nk) dot[p] += pr[p][jj] * t;
@@ -1175,18 +1199,22 @@ __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(const DosxAttn a, 
   }
 }
 
-size_t fwd_smem(const Geo& g) {      // (+ the four partial score tiles of the resident-key path)
-  return sizeof(float) * (size_t)(QT * g.LDH + QT * g.LDS_ + 2 * chunk_buf_floats(g.NKP, g.LDH) + 4 * KCH);
+size_t fwd_smem(const Geo& g, bool resident = false) {      // (resident: all key chunks at once + the four partial score tiles)
+  const int ch = 2 * chunk_buf_floats(g.NKP, g.LDH);
+  return sizeof(float) * (size_t)(QT * g.LDH + QT * g.LDS_ + (resident ? max(ch, resident_k_floats(g)) + 4 * KCH : ch));
 }
+inline bool fwd_resident(const DosxAttn& a) { return a.Nk <= 64 && fwd_smem(make_geo(a.H, a.Nk), true) <= 160 * 1024; }
 size_t dq_smem(const Geo& g, bool pkv = false, bool resident = false) {    // (the [16][2][HP] column partial sums reuse the chunk buffers)
-  size_t fl = (size_t)QT * g.LDH + (size_t)QT * g.LDS_ + (size_t)max(2 * chunk_buf_floats(g.NKP, g.LDH), 32 * g.HP);
+  size_t fl = (size_t)QT * g.LDH + (size_t)QT * g.LDS_ +
+              (size_t)max(max(2 * chunk_buf_floats(g.NKP, g.LDH), 32 * g.HP), resident ? resident_k_floats(g) : 0);
   if (pkv) fl += (size_t)QT * g.LDS_ + (size_t)QT * g.LDH + 64;      // P tile, raw dO rows (the query rows take over Ds)
-  if (resident) fl += 4 * KCH;                                         // partial dP tiles of the resident-key path (Nk <= 16)
+  if (resident) fl += 4 * KCH;                                         // partial dP tiles of the resident-key path
   return sizeof(float) * fl;
 }
-inline bool pkv_ok(const DosxAttn& a) {
-  return a.dkv_part != nullptr && a.Nk <= 64 && dq_smem(make_geo(a.H, a.Nk), true, a.Nk <= 16) <= 160 * 1024;
-}
+// the partial-dK/dV path needs its tiles in LDS; the resident-key path on top of it only where both still fit
+inline bool pkv_fits(int H, int Nk) { return Nk <= 64 && dq_smem(make_geo(H, Nk), true, false) <= 160 * 1024; }
+inline bool dq_resident(int H, int Nk, bool pkv) { return Nk <= 64 && dq_smem(make_geo(H, Nk), pkv, true) <= 160 * 1024; }
+inline bool pkv_ok(const DosxAttn& a) { return a.dkv_part != nullptr && pkv_fits(a.H, a.Nk); }
 size_t dkv_smem(const Geo& g, int kg) {
   const size_t stage = 2 * (size_t)(2 * DQC * g.LDH + 2 * DQC * (32 * kg + 4));
   const size_t epi = (size_t)32 * kg * g.LDH + 32 * 2 * g.HP;
@@ -1205,7 +1233,7 @@ int check_attn(const DosxAttn& a, const char* who) {
 }  // namespace
 
 extern "C" int dosx_attention_pkv_supported(int Nk, int H) {
-  return Nk > 0 && Nk <= 64 && H > 0 && H <= 256 && dq_smem(make_geo(H, Nk), true, Nk <= 16) <= 160 * 1024;
+  return Nk > 0 && H > 0 && H <= 256 && pkv_fits(H, Nk);
 }
 
 extern "C" int dosx_attention_fwd(const DosxAttn* ap, dosx_stream_t stream) {
@@ -1214,21 +1242,24 @@ extern "C" int dosx_attention_fwd(const DosxAttn* ap, dosx_stream_t stream) {
   if (int rc = check_attn(a, "dosx_attention_fwd")) return rc;
   DOSX_CHECK_ARG(a.out, "dosx_attention_fwd: null out");
   const Geo g = make_geo(a.H, a.Nk);
-  const size_t smem = fwd_smem(g);
+  const bool res = fwd_resident(a);
+  const size_t smem = fwd_smem(g, res);
   DOSX_CHECK_ARG(smem <= 160 * 1024, "dosx_attention_fwd: LDS need %zu > 160 KiB", smem);
   const dim3 grid(ceil_div(a.Sq, QT), a.Bq);
   const int nj = a.Nk <= 16 ? 1 : (a.Nk <= 64 ? 4 : (a.Nk <= 208 ? 13 : 20));
-#define DOSX_FWDS(NJ_)                                                                                      \
+#define DOSX_FWDS(NJ_, RES_)                                                                                \
   do {                                                                                                      \
     static bool attr_set = false;                                                                           \
     if (!attr_set) {                                                                                        \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_stream_kernel<NJ_>),                \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_stream_kernel<NJ_, RES_>),          \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
       attr_set = true;                                                                                      \
     }                                                                                                       \
-    hipLaunchKernelGGL((attn_fwd_stream_kernel<NJ_>), grid, dim3(512), smem, to_stream(stream), a);         \
+    hipLaunchKernelGGL((attn_fwd_stream_kernel<NJ_, RES_>), grid, dim3(512), smem, to_stream(stream), a);   \
   } while (0)
-  if (nj == 1) DOSX_FWDS(1); else if (nj == 4) DOSX_FWDS(4); else if (nj == 13) DOSX_FWDS(13); else DOSX_FWDS(20);
+  if (nj == 1) { if (res) DOSX_FWDS(1, true); else DOSX_FWDS(1, false); }
+  else if (nj == 4) { if (res) DOSX_FWDS(4, true); else DOSX_FWDS(4, false); }
+  else if (nj == 13) DOSX_FWDS(13, false); else DOSX_FWDS(20, false);
 #undef DOSX_FWDS
   DOSX_LAUNCH_CHECK();
   return 0;
@@ -1243,7 +1274,8 @@ extern "C" int dosx_attention_bwd(const DosxAttn* ap, dosx_stream_t stream) {
   const Geo g = make_geo(a.H, a.Nk);
   const int kg = a.Nk > 32 ? 2 : 1;
   const bool pkv = pkv_ok(a);
-  const size_t s1 = dq_smem(g, pkv, a.Nk <= 16), s2 = dkv_smem(g, kg);
+  const bool res = dq_resident(a.H, a.Nk, pkv);
+  const size_t s1 = dq_smem(g, pkv, res), s2 = dkv_smem(g, kg);
   DOSX_CHECK_ARG(s1 <= 160 * 1024 && s2 <= 160 * 1024, "dosx_attention_bwd: LDS need %zu/%zu > 160 KiB", s1, s2);
   static bool attr_set = false;
   if (!attr_set) {
@@ -1256,19 +1288,21 @@ extern "C" int dosx_attention_bwd(const DosxAttn* ap, dosx_stream_t stream) {
   const dim3 grid(ceil_div(a.Sq, QT), a.Bq);
   if (!(a.flags & DOSX_ATTN_BWD_SKIP_DQ)) {
     const int nj = a.Nk <= 16 ? 1 : (a.Nk <= 64 ? 4 : (a.Nk <= 208 ? 13 : 20));
-#define DOSX_DQS(NJ_, PKV_)                                                                                 \
+#define DOSX_DQS(NJ_, PKV_, RES_)                                                                           \
   do {                                                                                                      \
     static bool attr_dq = false;                                                                            \
     if (!attr_dq) {                                                                                         \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_stream_kernel<NJ_, PKV_>),       \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_stream_kernel<NJ_, PKV_, RES_>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
       attr_dq = true;                                                                                       \
     }                                                                                                       \
-    hipLaunchKernelGGL((attn_bwd_dq_stream_kernel<NJ_, PKV_>), grid, dim3(512), s1, to_stream(stream), a);  \
+    hipLaunchKernelGGL((attn_bwd_dq_stream_kernel<NJ_, PKV_, RES_>), grid, dim3(512), s1, to_stream(stream), a); \
   } while (0)
-    if (pkv) { if (nj == 1) DOSX_DQS(1, true); else DOSX_DQS(4, true); }
-    else if (nj == 1) DOSX_DQS(1, false); else if (nj == 4) DOSX_DQS(4, false); else if (nj == 13) DOSX_DQS(13, false);
-    else DOSX_DQS(20, false);
+#define DOSX_DQS2(NJ_, PKV_) do { if (res) DOSX_DQS(NJ_, PKV_, true); else DOSX_DQS(NJ_, PKV_, false); } while (0)
+    if (pkv) { if (nj == 1) DOSX_DQS2(1, true); else DOSX_DQS2(4, true); }
+    else if (nj == 1) DOSX_DQS2(1, false); else if (nj == 4) DOSX_DQS2(4, false); else if (nj == 13) DOSX_DQS(13, false, false);
+    else DOSX_DQS(20, false, false);
+#undef DOSX_DQS2
 #undef DOSX_DQS
     DOSX_LAUNCH_CHECK();
   }
