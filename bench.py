@@ -88,7 +88,7 @@ def cpu_baseline(kind, L, T, H, B, budget_s=15.0):
             break
     # the same step in fp32 on the same threads (phonon only: the reference runs it in fp64, main_phDOS.py:15-16, the
     # GPU path computes in fp32 — so the like-for-like arithmetic comparison is this figure, not the fp64 one)
-    f32_note = ""
+    f32_value = None
     if dt == torch.float64:
         p32 = {k: (v.float() if v.is_floating_point() else v) for k, v in params.items()}
         g32 = collate(make_crystals(kind, B, 1000, torch.float32))
@@ -102,7 +102,7 @@ def cpu_baseline(kind, L, T, H, B, budget_s=15.0):
             e32 = time.perf_counter() - t0
             if e32 > max(2.0, budget_s / 4) or n32 >= 100:
                 break
-        f32_note = f"; same port in fp32 on the same threads: {B * n32 / e32:.1f} crystals/s ({1e3 * e32 / n32:.1f} ms/step)"
+        f32_value = round(B * n32 / e32, 1)
     cpu_model = "unknown CPU"
     try:
         for line in open("/proc/cpuinfo"):
@@ -111,11 +111,13 @@ def cpu_baseline(kind, L, T, H, B, budget_s=15.0):
                 break
     except OSError:
         pass
+    # value: the reference's arithmetic (fp64 for phonon); value_f32: the same port in the GPU path's arithmetic - the
+    # like-for-like GPU/CPU ratio is against THAT one; value_ref_threads: with the reference's own torch.set_num_threads(2)
     return {"value": round(B * n / el, 2), "unit": "crystals/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} full train steps (fwd+loss+bwd+AdamW) of one batch of {B} crystals, "
-                      f"{'fp64' if dt == torch.float64 else 'fp32'}, {el:.1f}s, ms/step {1e3 * el / n:.1f}; "
-                      f"host: {cpu_model}, {os.cpu_count()} logical CPUs, fastest of 2/8/16/32 threads; with the "
-                      f"reference's own 2 threads: {B / t2:.1f} crystals/s" + f32_note}
+            "value_f32": f32_value, "value_ref_threads": round(B / t2, 1), "ref_threads": 2,
+            "host": f"{cpu_model}, {os.cpu_count()} logical CPUs",
+            "sample": f"{n} full train steps of one {B}-crystal batch, {'fp64' if dt == torch.float64 else 'fp32'}, "
+                      f"{el:.1f}s, {1e3 * el / n:.1f} ms/step, fastest of 2/8/16/32 threads"}
 
 
 def algorithmic_flops(kind, L, T, H, N, E, B, n_max):
@@ -160,6 +162,176 @@ def traffic_of(kernels, key):
     return int(tot / n) if n else None
 
 
+LINE_BUDGET = 3000          # bytes of the ONE stdout line (the driver keeps an 8 KB tail of stdout)
+
+
+def _round_sig(v, n=4):
+    if isinstance(v, float):
+        return float(f"{v:.{n}g}")
+    return v
+
+
+def compact_record(out: dict, sites: list, budget: int = LINE_BUDGET) -> dict:
+    """The record that goes on the ONE stdout line: headline fields + the dominant site + the five largest sites in short
+    form.  The full per-site table NEVER goes on the line (round 2 lost its record to a 38 KB line); it is written to a side
+    file by the caller.  Optional fields are dropped, least important first, until the line fits ``budget``."""
+    rec = dict(out)
+    rec["top_sites"] = [{"site": r["site"][:48], "frac": r["frac"], "us_per_step": r.get("us_per_step"), "bound": r["bound"]}
+                        for r in sites[:5]]
+    for drop in (None, "top_sites", "traffic_source", "slots", "secondary"):
+        if drop is not None:
+            rec.pop(drop, None)
+        if len(json.dumps(rec)) <= budget:
+            return rec
+    # last resort: shorten the free-text fields
+    if "cpu_baseline" in rec:
+        rec["cpu_baseline"] = dict(rec["cpu_baseline"], sample=rec["cpu_baseline"]["sample"][:120])
+    rec["config"] = {"workload": rec["config"]["workload"][:160]}
+    return rec
+
+
+def run_workload(name, *, device, world, rank, dp, mode, shuffle, steps, warmup, bucket, pool, instrument=True):
+    """Train `steps` timed steps of configuration `name` (after `warmup` untimed ones) and return the measurements of this
+    rank: elapsed seconds, host enqueue seconds, per-site kernel timing of the replayed step, slot statistics."""
+    import numpy as np
+    import torch.distributed as td
+    from dostransformer_amd import ops
+    from dostransformer_amd.batch import bucket_sizes, pad_batch
+    from dostransformer_amd.dist import shard_batch
+    from dostransformer_amd.loader import DeviceDataset
+    from dostransformer_amd.train import Trainer
+
+    kind, L, T, H, B = CONFIGS[name]
+    model = build_model(kind, L, T, H, device).to(device)
+    use_graph = mode in ("graph", "replay")          # both run on ghost-padded (N,E) shape buckets
+    trainer = Trainer(model, lr=1e-4, beta=1.0, dist=dp, graph=(mode == "graph"), replay=(mode == "replay"), bucket=bucket)
+    n_global = B * world
+
+    real_dims = []          # (N, E, n_max) of the un-padded batches: the algorithmic-flop count uses real rows only
+    if shuffle:
+        # Every rank holds its own pool (data-parallel shards of a shuffled epoch are disjoint anyway); the global
+        # n_max is fixed to the pool-wide maximum so that ranks need no exchange to agree on it.
+        crystals = make_crystals(kind, pool, seed=12345 + rank, dtype=torch.float32)
+        ds = DeviceDataset(crystals, device)
+        pool_nmax = int(max(c["x"].shape[0] for c in crystals))
+        rng = np.random.default_rng(777 + rank)
+        order = {"perm": rng.permutation(len(ds)), "pos": 0}
+
+        def next_indices():
+            if order["pos"] + B > len(ds):            # next epoch: reshuffle
+                order["perm"], order["pos"] = rng.permutation(len(ds)), 0
+            idx = order["perm"][order["pos"]:order["pos"] + B]
+            order["pos"] += B
+            N, E = int(ds.n_nodes[idx].sum()), int(ds.n_edges[idx].sum())
+            real_dims.append((N, E, pool_nmax))
+            n_pad, e_pad = bucket_sizes(N, E, *bucket)
+            ops.REAL_ROWS.clear()
+            ops.REAL_ROWS.update({n_pad: N, e_pad: E})
+            return idx
+
+        def next_batch():                             # (instrumented eager pass only)
+            return ds.collate(next_indices(), n_max=pool_nmax)
+
+        def do_step():
+            # collate straight into the bucket's static buffers (dosx_collate_padded) + replay
+            return trainer.step_dataset(ds, next_indices(), n_global, n_max=pool_nmax)
+    else:
+        # device-resident, pre-collated shards of N_DISTINCT_BATCHES global batches (global n_max per batch);
+        # in graph / replay mode each is padded (exactly: ghost nodes/edges) to its (N, E) shape bucket
+        batches = []
+        for k in range(N_DISTINCT_BATCHES):
+            crystals = make_crystals(kind, B * world, seed=k, dtype=torch.float32)
+            g = shard_batch(crystals, world, rank)
+            real_dims.append((g.meta.num_nodes, g.meta.num_edges, g.meta.n_max))
+            if use_graph:
+                g = pad_batch(g, *bucket_sizes(g.meta.num_nodes, g.meta.num_edges, *bucket))
+            batches.append(g.to(device))
+        it = {"i": 0}
+
+        def next_batch():
+            k = it["i"] % len(batches)
+            g = batches[k]
+            it["i"] += 1
+            ops.REAL_ROWS.clear()                     # (work records are evaluated while a bucket is RECORDED)
+            if use_graph:
+                ops.REAL_ROWS.update({g.meta.num_nodes: real_dims[k][0], g.meta.num_edges: real_dims[k][1]})
+            return g
+
+        def do_step():
+            return trainer.step(next_batch(), n_global)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dp is not None:
+            td.barrier()
+
+    n_warm = max(warmup, N_DISTINCT_BATCHES if (use_graph and not shuffle) else 0)   # record every fixed bucket
+    for i in range(n_warm):
+        do_step()
+    sync()
+    # eager mode: per-kernel HIP-event timing over the timed region itself (same stream as the launches);
+    # graph / replay mode: the timed region re-issues recorded launches (no per-kernel events possible), so the
+    # kernel timing comes from an instrumented pass of the same steps right after it.
+    ops.KERNEL_TIMER.reset(enabled=not use_graph)
+    hits0, miss0 = trainer.slot_hits, trainer.slot_misses
+    if shuffle:
+        real_dims.clear()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        do_step()
+    host = time.perf_counter() - t0                  # the host is done enqueueing here; the GPU may still be running
+    torch.cuda.synchronize()
+    if dp is not None:
+        td.barrier()
+    elapsed = time.perf_counter() - t0
+    ops.KERNEL_TIMER.enabled = False
+    hits, misses = trainer.slot_hits - hits0, trainer.slot_misses - miss0
+    n_slots = len(trainer._slots)
+    dims = list(real_dims) if shuffle else [real_dims[i % len(real_dims)] for i in range(steps)]
+    n_inst = 0
+    if not instrument:
+        pass
+    elif mode == "replay":
+        # per-launch durations INSIDE the replayed three-stream step: the recorded programs are re-issued through
+        # dosx_replay_timed (a HIP event pair around every entry, on the stream it launches on); the few launches outside
+        # the recordings (slot copy, AdamW) are bracketed by ops._call
+        trainer.kernel_timer = ops.KERNEL_TIMER
+        ops.KERNEL_TIMER.reset(enabled=True)
+        n_inst = min(steps, 24)
+        for i in range(n_inst):
+            do_step()
+            torch.cuda.synchronize()
+        ops.KERNEL_TIMER.enabled = False
+        trainer.kernel_timer = None
+    elif use_graph:
+        trainer.graph = trainer.replay = False
+        ops.KERNEL_TIMER.reset(enabled=True)
+        n_inst = min(steps, 24)
+        for i in range(n_inst):
+            # An eager step is host-bound (~17 us of Python per launch): without a head start the GPU
+            # would idle between a site's start event and its kernel and the bracket would time the host.
+            # A device-side spin lets the host enqueue the whole step first, so every bracket times
+            # back-to-back GPU execution (a bracket then adds ~1 us to a kernel: tools/event_overhead.py).
+            g = next_batch()
+            torch.cuda._sleep(int(1.5e7))
+            trainer.step(g, n_global)
+            torch.cuda.synchronize()
+        ops.KERNEL_TIMER.enabled = False
+    else:
+        n_inst = steps
+    ops.REAL_ROWS.clear()
+    roof = ops.KERNEL_TIMER.roofline(HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS) if instrument else {"dominant": None, "all": []}
+    ops.KERNEL_TIMER.reset(enabled=False)
+    flops_step = 3.0 * sum(algorithmic_flops(kind, L, T, H, n, e, B, nm) for n, e, nm in dims) / max(len(dims), 1)
+    res = {"kind": kind, "L": L, "T": T, "H": H, "B": B, "n_global": n_global, "elapsed": elapsed, "host": host,
+           "roof": roof, "n_inst": n_inst, "flops_step": flops_step,
+           "slots": {"hits": hits, "misses": misses, "hit_rate": round(hits / max(hits + misses, 1), 4),
+                     "live": n_slots, "max": trainer.max_slots} if use_graph else None}
+    del trainer, model
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     # Exactly ONE line may reach stdout (the JSON record): libraries print there too (RCCL emits a
     # version banner on fd 1), so fd 1 is pointed at stderr for the whole run and the record is
@@ -172,8 +344,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="phonon_h128_b64", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary measurements of the default run (eDOS H256 line, --shuffle line)")
+    ap.add_argument("--kernels-out", default=os.path.join(ROOT, "bench_kernels_last.json"),
+                    help="side file for the full per-site kernel table (never on the stdout line)")
     ap.add_argument("--launch", choices=["replay", "eager", "graph"], default="replay",
-                    help="replay: re-issue a recorded launch list on static buffers (2 HIP streams); eager: marshal "
+                    help="replay: re-issue a recorded launch list on static buffers (3 HIP streams); eager: marshal "
                          "every launch from Python; graph: torch/HIP graph replay")
     ap.add_argument("--graph", action="store_true", help="same as --launch graph")
     ap.add_argument("--shuffle", action="store_true",
@@ -213,136 +389,53 @@ def main():
         from dostransformer_amd.dist import DataParallel
         dp = DataParallel()
 
-    import numpy as np
-    from dostransformer_amd import ops
-    from dostransformer_amd.batch import bucket_sizes, pad_batch
-    from dostransformer_amd.dist import shard_batch
-    from dostransformer_amd.loader import DeviceDataset
-    from dostransformer_amd.train import Trainer
-
-    kind, L, T, H, B = CONFIGS[args.config]
-    model = build_model(kind, L, T, H, device).to(device)
     mode = "graph" if args.graph else args.launch
-    use_graph = mode in ("graph", "replay")          # both run on ghost-padded (N,E) shape buckets
     bucket = tuple(args.bucket) if args.bucket else ((64, 1280) if args.shuffle else (8, 128))
-    trainer = Trainer(model, lr=1e-4, beta=1.0, dist=dp, graph=(mode == "graph"), replay=(mode == "replay"), bucket=bucket)
-    n_global = B * world
+    common = dict(device=device, world=world, rank=rank, dp=dp, mode=mode, pool=args.pool)
+    r = run_workload(args.config, shuffle=args.shuffle, steps=args.steps, warmup=args.warmup, bucket=bucket, **common)
+    kind, L, T, H, B, n_global = r["kind"], r["L"], r["T"], r["H"], r["B"], r["n_global"]
 
-    real_dims = []          # (N, E, n_max) of the un-padded batches: the algorithmic-flop count uses real rows only
-    if args.shuffle:
-        # Every rank holds its own pool (data-parallel shards of a shuffled epoch are disjoint anyway); the global
-        # n_max is fixed to the pool-wide maximum so that ranks need no exchange to agree on it.
-        pool = make_crystals(kind, args.pool, seed=12345 + rank, dtype=torch.float32)
-        ds = DeviceDataset(pool, device)
-        pool_nmax = int(max(c["x"].shape[0] for c in pool))
-        rng = np.random.default_rng(777 + rank)
-        order = {"perm": rng.permutation(len(ds)), "pos": 0}
-
-        def next_indices():
-            if order["pos"] + B > len(ds):            # next epoch: reshuffle
-                order["perm"], order["pos"] = rng.permutation(len(ds)), 0
-            idx = order["perm"][order["pos"]:order["pos"] + B]
-            order["pos"] += B
-            real_dims.append((int(ds.n_nodes[idx].sum()), int(ds.n_edges[idx].sum()), pool_nmax))
-            return idx
-
-        def next_batch():                             # (instrumented eager pass only)
-            return ds.collate(next_indices(), n_max=pool_nmax)
-
-        def do_step():
-            # collate straight into the bucket's static buffers (dosx_collate_padded) + replay
-            return trainer.step_dataset(ds, next_indices(), n_global, n_max=pool_nmax)
-    else:
-        # device-resident, pre-collated shards of N_DISTINCT_BATCHES global batches (global n_max per batch);
-        # in graph / replay mode each is padded (exactly: ghost nodes/edges) to its (N, E) shape bucket
-        batches = []
-        for k in range(N_DISTINCT_BATCHES):
-            crystals = make_crystals(kind, B * world, seed=k, dtype=torch.float32)
-            g = shard_batch(crystals, world, rank)
-            real_dims.append((g.meta.num_nodes, g.meta.num_edges, g.meta.n_max))
-            if use_graph:
-                g = pad_batch(g, *bucket_sizes(g.meta.num_nodes, g.meta.num_edges, *bucket))
-            batches.append(g.to(device))
-        it = {"i": 0}
-
-        def next_batch():
-            g = batches[it["i"] % len(batches)]
-            it["i"] += 1
-            return g
-
-        def do_step():
-            return trainer.step(next_batch(), n_global)
-
-    def sync():
-        torch.cuda.synchronize()
-        if dp is not None:
-            td.barrier()
-
-    n_warm = max(args.warmup, N_DISTINCT_BATCHES if (use_graph and not args.shuffle) else 0)   # record every fixed bucket
-    for i in range(n_warm):
-        do_step()
-    sync()
-    # eager mode: per-kernel HIP-event timing over the timed region itself (same stream as the launches);
-    # graph / replay mode: the timed region re-issues recorded launches (no per-kernel events possible), so the
-    # kernel timing comes from an instrumented eager pass of the same steps right after it.
-    ops.KERNEL_TIMER.reset(enabled=not use_graph)
-    hits0, miss0 = trainer.slot_hits, trainer.slot_misses
-    if args.shuffle:
-        real_dims.clear()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        do_step()
-    torch.cuda.synchronize()
-    if dp is not None:
-        td.barrier()
-    elapsed = time.perf_counter() - t0
-    ops.KERNEL_TIMER.enabled = False
-    hits, misses = trainer.slot_hits - hits0, trainer.slot_misses - miss0
-    n_slots = len(trainer._slots)
-    n_inst = 0
-    if mode == "replay":
-        # per-launch durations INSIDE the replayed two-stream step: the recorded programs are re-issued through
-        # dosx_replay_timed (a HIP event pair around every entry, on the stream it launches on); the few launches outside
-        # the recordings (slot copy, AdamW) are bracketed by ops._call
-        trainer.kernel_timer = ops.KERNEL_TIMER
-        ops.KERNEL_TIMER.reset(enabled=True)
-        n_inst = min(args.steps, 24)
-        for i in range(n_inst):
-            do_step()
-            torch.cuda.synchronize()
-        ops.KERNEL_TIMER.enabled = False
-        trainer.kernel_timer = None
-    elif use_graph:
-        trainer.graph = trainer.replay = False
-        ops.KERNEL_TIMER.reset(enabled=True)
-        n_inst = min(args.steps, 24)
-        for i in range(n_inst):
-            # An eager step is host-bound (~17 us of Python per launch): without a head start the GPU
-            # would idle between a site's start event and its kernel and the bracket would time the host.
-            # A device-side spin lets the host enqueue the whole step first, so every bracket times
-            # back-to-back GPU execution (a bracket then adds ~1 us to a kernel: tools/event_overhead.py).
-            g = next_batch()
-            torch.cuda._sleep(int(1.5e7))
-            trainer.step(g, n_global)
-            torch.cuda.synchronize()
-        ops.KERNEL_TIMER.enabled = False
-    else:
-        n_inst = args.steps
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.dist_backend == "nccl" else "cpu")
+    t = torch.tensor([r["elapsed"], r["host"]], dtype=torch.float64, device=device if args.dist_backend == "nccl" else "cpu")
     if dp is not None:
         td.all_reduce(t, op=td.ReduceOp.MAX)
-    elapsed = float(t[0])
+    elapsed, host = float(t[0]), float(t[1])
+
+    # secondary measurements of the DEFAULT run (one GPU, default configuration): the other single-GPU BASELINE
+    # configuration and the steady-state (fresh batch every step) figure, so that the driver's record holds them too
+    secondary = {}
+    if world == 1 and dp is None and not args.no_secondary and args.config == "phonon_h128_b64" and not args.shuffle \
+            and mode == "replay":
+        def brief(x, steps):
+            ms = 1e3 * x["elapsed"] / steps
+            return {"value": round(x["n_global"] * steps / x["elapsed"], 1), "unit": "crystals/s", "ms_per_step": round(ms, 4),
+                    "steps": steps, "step_frac": round(x["flops_step"] / (ms * 1e-3) / (MFMA_F32_PEAK_TFLOPS * 1e12), 4),
+                    "host_ms_per_step": round(1e3 * x["host"] / steps, 4)}
+        try:
+            e = run_workload("edos_h256_b64", shuffle=False, steps=40, warmup=8, bucket=(8, 128), instrument=False, **common)
+            secondary["edos_h256_b64"] = brief(e, 40)
+            sh = run_workload("phonon_h128_b64", shuffle=True, steps=args.steps, warmup=max(args.warmup, 40),
+                              bucket=(64, 1280), instrument=False, **common)
+            secondary["shuffle"] = dict(brief(sh, args.steps), hit_rate=sh["slots"]["hit_rate"], live_buckets=sh["slots"]["live"])
+        except Exception as ex:  # a secondary line must never take the headline down with it
+            secondary["error"] = f"{type(ex).__name__}: {ex}"[:200]
 
     if rank == 0:
-        roof = ops.KERNEL_TIMER.roofline(HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS)
+        roof = r["roof"]
+        n_inst = r["n_inst"]
         kernels, traffic_src = load_traffic() if (args.config == "phonon_h128_b64" and world == 1 and not args.shuffle) \
             else ({}, "traffic is profiled for the default configuration only")
         for rec in roof["all"] + ([roof["dominant"]] if roof["dominant"] else []):
             rec["traffic"] = traffic_of(kernels, rec["kernel"])
             rec["us_per_step"] = round(1e3 * rec["total_ms"] / max(n_inst, 1), 2)
+            rec["launches_per_step"] = round(rec["launches"] / max(n_inst, 1), 2)
         ms_step = 1e3 * elapsed / args.steps
-        dims = real_dims if args.shuffle else [real_dims[i % len(real_dims)] for i in range(args.steps)]
-        flops_step = 3.0 * sum(algorithmic_flops(kind, L, T, H, n, e, B, nm) for n, e, nm in dims) / max(len(dims), 1)
+        flops_step = r["flops_step"]
+        dom = roof["dominant"]
+        if dom is not None:          # the roofline object of the contract: dominant site only, compact
+            dom = {k: _round_sig(dom[k], 5) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "site", "kernel",
+                                                       "avg_us", "launches_per_step", "us_per_step", "work_per_launch")}
+            dom["timing"] = "HIP event pair per launch inside the replayed step, on the launching stream" if mode == "replay" \
+                else "HIP events per launch"
         out = {
             "metric": "crystals/sec training throughput (Phonon DOS, hidden=128)" if kind == "phonon" else
                       "crystals/sec training throughput (Electron DOS)",
@@ -353,34 +446,35 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {kind} DOSTransformer layers={L} transformer={T} hidden={H}, "
-                                   f"{B} crystals/GPU (global batch {n_global}), full train step (fwd+loss+bwd+AdamW), " +
-                                   (f"a fresh random batch every step from a device-resident pool of {args.pool} crystals "
-                                    f"(collated on the GPU straight into the shape bucket's static buffers, inside the timed region)" if args.shuffle else
-                                    f"{N_DISTINCT_BATCHES} distinct pre-collated batches"),
-                       "global_batch": n_global, "parallelism": f"dp{world}",
-                       "launch": {"graph": "hip-graph replay per (N,E) bucket, exact ghost padding",
-                                  "replay": "recorded launch list per (N,E) bucket (exact ghost padding), 3 HIP streams (dgrad chain | key-gradient / constant-input side work | weight gradients)",
-                                  "eager": "eager"}[mode],
-                       "bucket": list(bucket),
-                       "kernel_timing": {"replay": "HIP event pair around every launch of the REPLAYED step (dosx_replay_timed, each "
-                                                   "on the stream it launches on), 24 steps right after the timed region",
-                                         "graph": "HIP events around every libdosx launch, instrumented eager pass after the timed region",
-                                         "eager": "HIP events around every libdosx launch inside the timed region"}[mode]},
+                                   f"{B} crystals/GPU, full train step (fwd+loss+bwd+AdamW), " +
+                                   (f"fresh random batch every step from a device-resident pool of {args.pool}, collated on the "
+                                    f"GPU inside the timed region" if args.shuffle else
+                                    f"{N_DISTINCT_BATCHES} distinct pre-collated HBM-resident batches"),
+                       "global_batch": n_global, "parallelism": f"dp{world}", "launch": mode, "bucket": list(bucket)},
             # whole-step figure: algorithmic flops of a train step (SURVEY.md §8d formula on the real, un-padded rows,
             # x3 for fwd+bwd) / measured step time / fp32 MFMA dense peak
             "step_frac": round(flops_step / (ms_step * 1e-3) / (MFMA_F32_PEAK_TFLOPS * 1e12), 4),
             "step_gflop": round(flops_step / 1e9, 2),
-            "roofline": roof["dominant"],
-            "traffic_source": traffic_src,
-            "kernels": roof["all"],
+            # host time to enqueue one replayed step (the loop returns before the GPU is done): the margin to the GPU step
+            "host_ms_per_step": round(1e3 * host / args.steps, 4),
+            "roofline": dom,
+            "traffic_source": traffic_src[:100],
         }
-        if use_graph:
-            out["slots"] = {"hits": hits, "misses": misses, "hit_rate": round(hits / max(hits + misses, 1), 4),
-                            "live": n_slots, "max": trainer.max_slots}
+        if r["slots"] is not None:
+            out["slots"] = r["slots"]
+        if secondary:
+            out["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kind, L, T, H, B, args.cpu_budget)
+        try:
+            with open(args.kernels_out, "w") as f:
+                json.dump({"config": args.config, "ms_per_step": ms_step, "instrumented_steps": n_inst, "sites": roof["all"]}, f, indent=1)
+            out["kernels_file"] = os.path.relpath(args.kernels_out, ROOT)
+        except OSError as ex:
+            print(f"bench.py: could not write {args.kernels_out}: {ex}", file=sys.stderr)
+        line = json.dumps(compact_record(out, roof["all"]))
         sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        os.write(real_stdout, (line + "\n").encode())
     if dp is not None:
         td.destroy_process_group()
 

@@ -274,6 +274,12 @@ class Decoder(nn.Module):
         N, H = x.shape
         bv = batch.detach().cpu().numpy().astype(np.int64)
         B = int(bv.max()) + 1 if bv.size else 0
+        order = None
+        if bv.size and np.any(bv[1:] < bv[:-1]):      # scatter_sum(x, batch) takes any order: pool a sorted copy
+            order_np = np.argsort(bv, kind="stable")
+            bv = bv[order_np]
+            order = torch.from_numpy(order_np).to(x.device)
+            x = x.index_select(0, order)              # (autograd scatters the gradient back)
         counts = np.bincount(bv, minlength=B)
         gptr = torch.from_numpy(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)).to(x.device)
         ngraph = torch.from_numpy(bv.astype(np.int32)).to(x.device)

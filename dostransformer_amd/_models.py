@@ -32,7 +32,11 @@ class DOSTransformerBase(FusedModel):
             return None
         seed = getattr(self, "_drop_seed", None)
         if seed is None or seed.device != device:
-            seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(device)
+            val = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+            import torch.distributed as td
+            if td.is_available() and td.is_initialized():      # data-parallel ranks seeded alike must not draw the same
+                val = (val + 0x9E3779B97F4A7C15 * (td.get_rank() + 1)) % (2 ** 62)              # masks for their shards
+            seed = torch.tensor([val], dtype=torch.int64).to(device)
             object.__setattr__(self, "_drop_seed", seed)
         elif bump:
             seed.add_(1)

@@ -81,6 +81,14 @@ class _KernelTimer:
 
 KERNEL_TIMER = _KernelTimer()
 
+# bench.py: ghost-padded row count -> real rows of the batch whose step is being recorded, so that the ALGORITHMIC work of a
+# site counts real rows only (the launches themselves run on the padded bucket).  Empty outside the bench.
+REAL_ROWS: dict = {}
+
+
+def _real(M) -> int:
+    return REAL_ROWS.get(int(M), int(M))
+
 
 class _Recorder:
     """Launch recorder: while active, every libdosx call (function pointer + fully marshalled ctypes
@@ -325,7 +333,8 @@ def _gemm_work(g: Gemm):
     buf = C.create_string_buffer(96)
     _lib.load().dosx_gemm_kernel_name(C.byref(g), buf, 96)
     sym = buf.value.decode()
-    return (f"gemm[M{g.M},N{g.N},K{g.K},{sym[11:]}]", sym, "mfma", 2.0 * g.M * g.N * g.K)
+    # keyed by kernel symbol + (N, K): the batches of a run differ in M only and belong to one site
+    return (f"gemm[N{g.N},K{g.K},{sym[11:]}]", sym, "mfma", 2.0 * _real(g.M) * g.N * g.K)
 
 
 def ffn_supported(H: int) -> bool:
@@ -351,7 +360,7 @@ def ffn_fwd(M: int, H: int, x: torch.Tensor, stats: torch.Tensor, gamma, beta, w
         if len(fin) > 4:          # (.., w, b, dos [Bq,S], S, Bq): the model head's H -> 1 output layer on the normalised rows
             a.fin_w, a.fin_b, a.fin_dos, a.fin_S, a.fin_Bq = fin[4].data_ptr(), fin[5].data_ptr(), fin[6].data_ptr(), int(fin[7]), int(fin[8])
     _call("dosx_ffn_fwd", C.byref(a), _stream(),
-          w=lambda: (f"ffn_fwd[M{M},H{H}]", "ffn_fwd_kernel", "mfma", 16.0 * M * H * H))
+          w=lambda: (f"ffn_fwd[H{H}]", "ffn_fwd_kernel", "mfma", 16.0 * M * H * H))
 
 
 def ffn_bwd_partial_rows(M: int) -> int:
@@ -382,7 +391,7 @@ def ffn_bwd(M: int, H: int, dy: torch.Tensor, h: torch.Tensor, x: torch.Tensor, 
     a.dx, a.lddx = dx.data_ptr(), int(dx.stride(0))
     a.partials, a.partial_ld = partials.data_ptr(), int(partials.stride(0))
     _call("dosx_ffn_bwd", C.byref(a), _stream(),
-          w=lambda: (f"ffn_bwd[M{M},H{H}]", "ffn_bwd_kernel", "mfma", 16.0 * M * H * H))
+          w=lambda: (f"ffn_bwd[H{H}]", "ffn_bwd_kernel", "mfma", 16.0 * M * H * H))
 
 
 MLP_LN_MAX_ROWS = int(__import__("os").environ.get("DOSX_MLP_LN_MAX_ROWS", "4096"))
@@ -413,7 +422,7 @@ def mlp_ln_fwd(M: int, a0: torch.Tensor, a1: Optional[torch.Tensor], w1, b1, gam
     d.xhat, d.rstd = xhat.data_ptr(), rstd.data_ptr()
     d.out, d.ldo = out.data_ptr(), int(out.stride(0))
     _call("dosx_mlp_ln_fwd", C.byref(d), _stream(),
-          w=lambda: (f"mlp_ln_fwd[M{d.M},K{d.K},NH{d.NH},NO{d.NO}]", "mlp_ln_fwd_kernel", "mfma", 2.0 * d.M * d.NH * (d.K + d.NO)))
+          w=lambda: (f"mlp_ln_fwd[K{d.K},NH{d.NH},NO{d.NO}]", "mlp_ln_fwd_kernel", "mfma", 2.0 * _real(d.M) * d.NH * (d.K + d.NO)))
 
 
 def mlp_ln_bwd_partial_rows(M: int) -> int:
@@ -434,7 +443,7 @@ def mlp_ln_bwd(M: int, dy: torch.Tensor, xhat: torch.Tensor, rstd: torch.Tensor,
     d.dcat, d.lddcat = dcat.data_ptr(), int(dcat.stride(0))
     d.partials, d.partial_ld = partials.data_ptr(), int(partials.stride(0))
     _call("dosx_mlp_ln_bwd", C.byref(d), _stream(),
-          w=lambda: (f"mlp_ln_bwd[M{d.M},K{d.K},NH{d.NH},NO{d.NO}]", "mlp_ln_bwd_kernel", "mfma", 2.0 * d.M * d.NH * (d.K + d.NO)))
+          w=lambda: (f"mlp_ln_bwd[K{d.K},NH{d.NH},NO{d.NO}]", "mlp_ln_bwd_kernel", "mfma", 2.0 * _real(d.M) * d.NH * (d.K + d.NO)))
 
 
 def gemm_partial_rows(M: int, N: int, epi: int) -> int:
@@ -463,7 +472,7 @@ def wgrad(M: int, N: int, dy: Seg, segs: Sequence[Seg], slab: torch.Tensor, slab
           nsplit: int, **pro) -> None:
     g = wgrad_desc(M, N, dy, segs, slab, slab_bias, nsplit, **pro)
     _call("dosx_wgrad", C.byref(g), _stream(),
-          w=lambda: (f"wgrad[M{g.M},N{g.N},K{g.K}]", "wgrad_kernel", "mfma", 2.0 * g.M * g.N * g.K))
+          w=lambda: (f"wgrad[N{g.N},K{g.K}]", "wgrad_kernel", "mfma", 2.0 * _real(g.M) * g.N * g.K))
 
 
 def wgrad_grouped(descs: Sequence[Wgrad]) -> None:
@@ -472,7 +481,7 @@ def wgrad_grouped(descs: Sequence[Wgrad]) -> None:
         return
     arr = (Wgrad * len(descs))(*descs)
     _call("dosx_wgrad_grouped", arr, len(descs), _stream(),
-          w=lambda: ("wgrad_grouped", "wgrad_grouped_kernel", "mfma", sum(2.0 * d.M * d.N * d.K for d in descs)))
+          w=lambda: ("wgrad_grouped", "wgrad_grouped_kernel", "mfma", sum(2.0 * _real(d.M) * d.N * d.K for d in descs)))
 
 
 _LPT = __import__("os").environ.get("DOSX_WGRAD_LPT", "1") == "1"
@@ -666,25 +675,25 @@ def segment_reduce(msg, rowptr, scale, agg, e_in, e_out, N, E, H):
     # algorithmic bytes: messages + CSR row pointers + aggregated output (+ the fused edge residual e_out = e_in + msg:
     # one more read and one write of [E,H])
     _call("dosx_segment_reduce", _p(msg), _p(rowptr), _p(scale), _p(agg), _p(e_in), _p(e_out), N, E, H, _stream(),
-          w=lambda: (f"scatter_add_fwd[N{N},E{E},H{H}{',res' if e_out is not None else ''}]", "segment_reduce_kernel", "hbm",
-                     4.0 * (E * H + (N + 1) + N * H + (2 * E * H if e_out is not None else 0))))
+          w=lambda: (f"scatter_add_fwd[H{H}{',res' if e_out is not None else ''}]", "segment_reduce_kernel", "hbm",
+                     4.0 * (_real(E) * H + (_real(N) + 1) + _real(N) * H + (2 * _real(E) * H if e_out is not None else 0))))
 
 
 def edge_grad_combine(de_new, dagg, ld_dagg, dst, scale, dmsg, E, H):
     """de_new: None or a 2-D tensor / view with unit inner stride ([E,H] or the e-block of an [E,3H] gradient)."""
     ld_de = int(de_new.stride(0)) if de_new is not None else 0
     _call("dosx_edge_grad_combine", _p(de_new), ld_de, dagg, ld_dagg, _p(dst), _p(scale), _p(dmsg), E, H, _stream(),
-          w=lambda: (f"edge_grad_combine[E{E},H{H}]", "edge_grad_combine_kernel", "hbm",
-                     4.0 * (E * H * (3 if de_new is not None else 2) + E)))
+          w=lambda: (f"edge_grad_combine[H{H}]", "edge_grad_combine_kernel", "hbm",
+                     4.0 * (_real(E) * H * (3 if de_new is not None else 2) + _real(E))))
 
 
 def gather_bwd(dcat, dnode_ptr, ld_dnode, dx_res, rowptr_dst, rowptr_src, perm_src, de_new, dx, de_out, N, E, H):
     # algorithmic bytes: dcat [E,3H] read once (+ de_new read, de_out written), 3 index arrays, 3 node-row streams
     _call("dosx_gather_bwd", _p(dcat), dnode_ptr, ld_dnode, _p(dx_res), _p(rowptr_dst), _p(rowptr_src),
           _p(perm_src), _p(de_new), _p(dx), _p(de_out), N, E, H, _stream(),
-          w=lambda: (f"gather_bwd[N{N},E{E},H{H}]", "gather_bwd_kernel", "hbm",
-                     4.0 * (E * H * ((3 if de_out is not None else 2) + (1 if de_new is not None else 0)
-                                     + (1 if de_out is not None else 0)) + E + 2 * (N + 1) + 3 * N * H)))
+          w=lambda: (f"gather_bwd[H{H}]", "gather_bwd_kernel", "hbm",
+                     4.0 * (_real(E) * H * ((3 if de_out is not None else 2) + (1 if de_new is not None else 0)
+                                            + (1 if de_out is not None else 0)) + _real(E) + 2 * (_real(N) + 1) + 3 * _real(N) * H)))
 
 
 def graph_pool(x, graph_ptr, out_ptr, ld_out, B, H):
@@ -748,7 +757,8 @@ def layernorm_bwd(dy, xhat, rstd, gamma, dx, partials, M, H):
 
 
 def _attn_shape(a: Attn) -> str:
-    return f"Sq{a.Sq},Bq{a.Bq},Nk{a.Nk},Bk{a.Bk},H{a.H}"
+    # (key-count CLASS, not Nk: the batches of a run differ in n_max and belong to one site per kernel path)
+    return f"Sq{a.Sq},Bq{a.Bq},Nk<={16 if a.Nk <= 16 else (64 if a.Nk <= 64 else 320)},Bk{a.Bk},H{a.H}"
 
 
 def attention_fwd(a: Attn):

@@ -175,8 +175,11 @@ class Trainer:
         return self._m, self._v
 
     # ---- the step, split where the data-parallel collectives go --------------------------------
-    def _part_a(self, fp, g, m):
-        """forward program (+ the phonon SSE pair).  Returns the state part B needs."""
+    def _part_a(self, fp, g, m, st_n_global: Optional[int] = None):
+        """forward program (+ the phonon SSE pair).  Returns the state part B needs.  st_n_global: crystals in the un-sharded
+        batch (None: this batch is the whole batch)."""
+        if st_n_global is None:
+            st_n_global = m.num_graphs
         model, dev, cfg = self.model, fp.flat.device, self.model._cfg
         B, S = m.num_graphs, cfg.S
         dg, xL, ds, (ctx, dos) = model._program_fwd(fp.P, g, m, bump_seed=False)     # (step() bumps the dropout seed)
@@ -184,8 +187,9 @@ class Trainer:
         if self.kind == "phonon":
             st["y"] = Fn._f32(g.phdos).reshape(B, S)
             st["sse"] = Fn._empty(dev, 2)
-            if self.dist is not None:      # ranks exchange the SSE pair between the two phases of the loss
-                ops.sse2(dos[:B], dos[B:], st["y"], st["sse"], B * S)
+            st["split_loss"] = self.dist is not None or int(st_n_global) != B
+            if st["split_loss"]:           # two-phase loss: ranks exchange the SSE pair in between, and / or the loss is
+                ops.sse2(dos[:B], dos[B:], st["y"], st["sse"], B * S)      # normalised by a GLOBAL count that is not B
         else:
             st["y"] = Fn._f32(g.y_ft).reshape(-1)
         return st
@@ -197,10 +201,12 @@ class Trainer:
         ddos = Fn._empty(dev, *dos.shape)
         if self.kind == "phonon":
             loss = Fn._empty(dev, 1)
-            if self.dist is not None:
+            if st["split_loss"] or int(n_global) != B:
+                if not st["split_loss"]:
+                    raise RuntimeError("n_global differs between the two halves of the step")
                 ops.loss_phonon_bwd(dos[:B], dos[B:], st["y"], st["sse"], self.beta, float(n_global * S), ddos[:B],
                                     ddos[B:], loss, B * S)
-            else:                          # one launch: SSE pair, loss and gradient
+            else:                          # one launch: SSE pair, loss and gradient (normalised by B*S: n_global == B)
                 ops.loss_phonon(dos[:B], dos[B:], st["y"], st["sse"], self.beta, ddos[:B], ddos[B:], loss, B * S)
             loss = loss[0]
         else:
@@ -252,9 +258,11 @@ class Trainer:
         return self.dist.global_count(B) if self.dist is not None else B
 
     # ---- eager path ------------------------------------------------------------------------------
-    def forward_backward(self, g, n_global: Optional[int] = None) -> torch.Tensor:
+    def forward_backward(self, g, n_global: Optional[int] = None, _bump: bool = True) -> torch.Tensor:
         """Forward + loss + backward; leaves the gradients in the flat buffer.  Returns the loss
         (0-dim device tensor; for eDOS under data parallelism it is this rank's share)."""
+        if _bump:                      # a direct forward_backward() + optimizer_step() loop draws fresh dropout masks too
+            self._bump_dropout_seed()
         model = self.model
         dev = model._module_device()
         fp = model._ensure_flat(dev, g)
@@ -262,7 +270,7 @@ class Trainer:
         m = graph_meta(g, dev)
         ng = self._n_global(m.num_graphs, n_global, g)
         with torch.no_grad():
-            st = self._part_a(fp, g, m)
+            st = self._part_a(fp, g, m, ng)
             self.last_outputs = st["out"]
             if self.kind == "phonon" and self.dist is not None:
                 self.dist.all_reduce_sse(st["sse"])
@@ -276,7 +284,7 @@ class Trainer:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():          # eager warm-up (lazy kernel attributes etc.)
-            st = self._part_a(fp, g, m)
+            st = self._part_a(fp, g, m, ng)
             self._part_b(fp, m, st, ng)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -284,7 +292,7 @@ class Trainer:
         with torch.no_grad():
             slot.graph_a = torch.cuda.CUDAGraph()
             with torch.cuda.graph(slot.graph_a):
-                st = self._part_a(fp, g, m)
+                st = self._part_a(fp, g, m, ng)
                 if not split:
                     loss = self._part_b(fp, m, st, ng)
             if split:
@@ -310,7 +318,7 @@ class Trainer:
                 plan = []
                 self._rec_parts = []
                 ops.RECORDER.begin()
-                st = self._part_a(fp, g, m)
+                st = self._part_a(fp, g, m, ng)
                 if split:
                     plan.append(("prog", ops.RECORDER.end()))
                     plan.append(("sse", None))
@@ -411,7 +419,9 @@ class Trainer:
         idx, N, E, n_max = ds.bucket_dims(indices, n_max)
         B = int(idx.shape[0])
         n_pad, e_pad = bucket_sizes(N, E, *self.bucket)
-        ng = int(n_global) if n_global is not None else (self.dist.global_count(B) if self.dist is not None else B)
+        # (no collective, no host read: ranks of a data-parallel job draw equally sized shards from their datasets; a caller
+        #  with ragged shards passes n_global)
+        ng = int(n_global) if n_global is not None else B * (self.dist.world if self.dist is not None else 1)
         tiled = ds.tile_cnt is not None
         key = (n_pad, e_pad, B, n_max, ng, tiled)
         slot = self._lookup(key)
@@ -454,7 +464,9 @@ class Trainer:
         m, v = self._state(fp)
         views = lambda buf: {n: buf[o:o + fp.P[n].numel()].view(fp.P[n].shape).detach().cpu().clone()
                              for n, o in zip(fp.names, fp.offsets)}
+        seed = getattr(self.model, "_drop_seed", None)
         return {"step": self.step_count, "exp_avg": views(m), "exp_avg_sq": views(v),
+                "drop_seed": None if seed is None else int(seed.item()),
                 "hyper": {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "beta": self.beta}}
 
     def load_state_dict(self, sd: dict) -> None:
@@ -469,6 +481,8 @@ class Trainer:
                 m[o:o + k].copy_(sd["exp_avg"][n].reshape(-1).to(m.device, torch.float32))
                 v[o:o + k].copy_(sd["exp_avg_sq"][n].reshape(-1).to(v.device, torch.float32))
         self.step_count = int(sd["step"])
+        if sd.get("drop_seed") is not None:          # resume draws the masks the uninterrupted run would have drawn
+            object.__setattr__(self.model, "_drop_seed", torch.tensor([int(sd["drop_seed"])], dtype=torch.int64, device=m.device))
         h = sd.get("hyper", {})
         self.lr, self.eps, self.wd = h.get("lr", self.lr), h.get("eps", self.eps), h.get("weight_decay", self.wd)
         self.betas, self.beta = tuple(h.get("betas", self.betas)), h.get("beta", self.beta)
@@ -482,6 +496,6 @@ class Trainer:
 
     def step(self, g, n_global: Optional[int] = None) -> torch.Tensor:
         self._bump_dropout_seed()
-        loss = self._graph_step(g, n_global) if (self.graph or self.replay) else self.forward_backward(g, n_global)
+        loss = self._graph_step(g, n_global) if (self.graph or self.replay) else self.forward_backward(g, n_global, _bump=False)
         self.optimizer_step()
         return loss
