@@ -63,7 +63,8 @@ class Wgrad(C.Structure):
         ("pro", C.c_int32),
         ("pro_gamma", C.c_void_p), ("pro_beta", C.c_void_p), ("pro_alpha", C.c_void_p), ("pro_stats", C.c_void_p),
         ("slab", C.c_void_p), ("slab_bias", C.c_void_p),
-        ("nsplit", C.c_int32),
+        ("nsplit", C.c_int32), ("accumulate", C.c_int32),
+        ("dst", C.c_void_p), ("dst_bias", C.c_void_p), ("counters", C.c_void_p),
     ]
 
 
@@ -175,7 +176,10 @@ _SIGS = {
     "dosx_gemm": [C.POINTER(Gemm), _P],
     "dosx_gemm_kernel_name": [C.POINTER(Gemm), C.c_char_p, _I],
     "dosx_wgrad_splits": [_I, _I, _I],
+    "dosx_wgrad_tiles": [_I, _I],
+    "dosx_wgrad_scratch_floats": [_I, _I, _I],
     "dosx_wgrad": [C.POINTER(Wgrad), _P],
+    "dosx_grad_flush": [C.POINTER(Wgrad), _I, C.POINTER(ReduceJob), _I, _P],
     "dosx_wgrad_grouped": [C.POINTER(Wgrad), _I, _P],
     "dosx_reduce_partials": [C.POINTER(ReduceJob), _I, _P],
     "dosx_edge_feat_sh1": [_P, _P, _I, _F, _P],
@@ -234,7 +238,7 @@ _SIGS = {
     "dosx_last_error": [],
     "dosx_version": [],
 }
-_RESTYPES = {"dosx_last_error": C.c_char_p}
+_RESTYPES = {"dosx_last_error": C.c_char_p, "dosx_wgrad_scratch_floats": C.c_int64}
 EXPORTS = tuple(_SIGS)
 
 _lib: Optional[C.CDLL] = None

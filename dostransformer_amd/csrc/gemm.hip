@@ -1259,6 +1259,114 @@ struct WgradLaunch {
 // beyond the prologue transform).  FAST = 0: generic pointer path (any map, ragged everything).
 constexpr int WSTG = 2 * BM * LDT;                        // floats of one stage buffer: Ys | Xs
 
+// ---- finished mode (DosxWgrad.dst != NULL): in-launch reduction over the M-splits by the last arriver of a tile ----
+// Protocol (cdna_hip_programming.md, in-launch split-K reduction, write-through form): every workgroup stores its 64x64
+// partial tile to its private slot of the scratch slab with 16-byte sc1 (write-through) stores, every wave drains its
+// stores (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, ONE lane draws a ticket with a relaxed agent-scope
+// fetch_add on the tile's counter; the workgroup that draws nsplit-1 reads ALL nsplit partial tiles back with sc1 loads
+// (they bypass this CU's L1; every load of handed-off bytes is such a load) and adds them in split order 0, 1, 2, ...:
+// a fixed order whoever arrives last, so results are bitwise reproducible.  Scratch layout is tile-major
+// ([split][tile][64][64]): every partial tile is one contiguous, 16-byte aligned 16 KB block whatever N and K are.
+constexpr int WTILE = WT * WT;                            // floats of one partial tile
+constexpr int W_FLAG = 3 * WSTG - 4;                      // LDS word that broadcasts the ticket
+
+__device__ __forceinline__ void wgrad_finish(const DosxWgrad& g, float* __restrict__ Sm, const float4 bs0, const float4 bs1,
+                                             const bool do_bias, const int z, const int bx, const int by, const int ntk) {
+  const int tid = threadIdx.x;
+  const int N = g.N, K = g.K, ns = g.nsplit;
+  const int n0 = by * WT, k0 = bx * WT;
+  const int tile = by * ntk + bx;
+  const int ntiles = ntk * ((N + WT - 1) / WT);
+  const int nb64 = ((N + WT - 1) / WT) * WT;              // row stride of the bias scratch
+  if (do_bias) {                                          // staged dY column sums: [32][LDT] behind the tile
+    float* Br = Sm + WT * LDT;
+    if (tid >= 256) {
+      const int st = tid - 256, r = st >> 3, c4 = (st & 7) * 4;
+      st4(&Br[r * LDT + c4], bs0);
+      st4(&Br[r * LDT + c4 + 32], bs1);
+    }
+  }
+  __syncthreads();                                        // tile (matrix waves) and bias rows (staging waves) are in LDS
+  WSTAMP(61);
+  float bsum = 0.f;
+  if (do_bias && tid < WT) {
+    const float* Br = Sm + WT * LDT;
+#pragma unroll 8
+    for (int rr = 0; rr < BM; ++rr) bsum += Br[rr * LDT + tid];
+  }
+  // lane -> two float4 of the tile: element index e = tid and tid + 512 (row e >> 4, columns 4 * (e & 15) ..)
+  auto write_dst = [&](const float4 (&v)[2], const float bfin) {
+    const bool vec_ok = ((K & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.dst) & 15) == 0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int e = tid + 512 * h, n = n0 + (e >> 4), k = k0 + (e & 15) * 4;
+      if (n >= N || k >= K) continue;
+      float* d = g.dst + (size_t)n * K + k;
+      if (vec_ok) {                                       // (K % 4 == 0: k < K means k + 3 < K)
+        st4(d, g.accumulate ? f4add(ld4(d), v[h]) : v[h]);
+      } else {
+        const float tv[4] = {v[h].x, v[h].y, v[h].z, v[h].w};
+        for (int c = 0; c < 4 && k + c < K; ++c) d[c] = tv[c] + (g.accumulate ? d[c] : 0.f);
+      }
+    }
+    if (do_bias && tid < WT && n0 + tid < N) g.dst_bias[n0 + tid] = bfin + (g.accumulate ? g.dst_bias[n0 + tid] : 0.f);
+  };
+  float4 v[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int e = tid + 512 * h;
+    v[h] = ld4(&Sm[(e >> 4) * LDT + (e & 15) * 4]);
+  }
+  if (ns == 1) {                                          // no split: this workgroup's tile IS the result
+    write_dst(v, bsum);
+    return;
+  }
+  const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)g.slab, 0, 0x7fffffff, 0x00020000);
+  const uint32_t zstride = (uint32_t)ntiles * WTILE * 4;  // bytes between the slots of consecutive splits (host checks < 2^31 / nsplit)
+  const uint32_t voff = ((uint32_t)tile * WTILE + (uint32_t)tid * 4) * 4;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i32, v[h]), rS, voff + h * 512 * 16, (uint32_t)z * zstride, 16);   // aux 16 = sc1
+  if (do_bias && tid < WT)
+    __hip_atomic_store(g.slab_bias + (size_t)z * nb64 + n0 + tid, bsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // (sc1 store)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // EVERY storing wave drains its write-through stores
+  __syncthreads();
+  WSTAMP(62);
+  int* flag = reinterpret_cast<int*>(Sm + W_FLAG);
+  if (tid == 0) *flag = __hip_atomic_fetch_add(g.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  WSTAMP(63);
+  if (*flag != ns - 1) return;                            // not the last arriver of this tile
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // (no instruction: keeps the loads below the ticket)
+  // ---- last arriver: sum the nsplit partial tiles in split order (sc1 loads, all issued before the first add) ----
+  constexpr int ZB = 16;                                  // loads in flight per lane and half: 16 x 16 B (one round trip per half at <= 16 splits)
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float4 s = f4zero();
+    for (int zb = 0; zb < ns; zb += ZB) {
+      float4 t[ZB];
+#pragma unroll
+      for (int q = 0; q < ZB; ++q) {
+        const int zz = min(zb + q, ns - 1);               // (clamped duplicates are loaded, never added)
+        t[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rS, voff + h * 512 * 16, (uint32_t)zz * zstride, 16));
+      }
+#pragma unroll
+      for (int q = 0; q < ZB; ++q)
+        if (zb + q < ns) s = (zb + q == 0) ? t[q] : f4add(s, t[q]);
+    }
+    v[h] = s;
+  }
+  float bfin = 0.f;
+  if (do_bias && tid < WT) {
+    for (int zz = 0; zz < ns; ++zz) {
+      const float b = __hip_atomic_load(g.slab_bias + (size_t)zz * nb64 + n0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bfin = zz == 0 ? b : bfin + b;
+    }
+  }
+  write_dst(v, bfin);
+  if (tid == 0) __hip_atomic_store(g.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+}
+
 template <int PRO, int VEC, int FAST>
 __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, float* __restrict__ Sm) {
   const DosxWgrad& g = L.g;
@@ -1276,7 +1384,7 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, 
   const int chunk = ((M + g.nsplit - 1) / g.nsplit + BM - 1) / BM * BM;
   const int ms = z * chunk, me = min(M, ms + chunk);
   const int nch = ms < me ? (me - ms + BM - 1) / BM : 0;
-  const bool do_bias = (g.slab_bias != nullptr) && (bx == 0);
+  const bool do_bias = ((g.dst != nullptr ? g.dst_bias : g.slab_bias) != nullptr) && (bx == 0);
 
   f32x16 acc;
 #pragma unroll
@@ -1302,43 +1410,44 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, 
       int idx;          // fast path: gathered row index of this lane's row, fetched two chunks ahead
       float mean, rstd;
     };
-    Set s0, s1;
-    // THREE stage buffers, the staging waves TWO chunks ahead of the matrix waves (chunk c+2 is stored while chunk c is
-    // multiplied): at the barrier that ends chunk c the data of chunk c+1 has been visible for a whole chunk, so the matrix
-    // waves fetch its fragments UNDER the MFMAs of chunk c.  With two buffers every chunk started with ~450 clk of exposed
-    // ds_read issue + latency behind the barrier (stamps, round 2: 1500 clk per chunk in the matrix waves for 1024 clk of
-    // MFMAs; chunk period 1900-2100 clk).  Chunk c travels in register set c & 1 and LDS buffer c % 3.
+    // THREE stage buffers, the staging waves TWO chunks ahead of the matrix waves in LDS (chunk c+2 is stored while chunk c
+    // is multiplied): at the barrier that ends chunk c the data of chunk c+1 has been visible for a whole chunk, so the
+    // matrix waves fetch its fragments UNDER the MFMAs of chunk c.  Chunk c travels in register set c % NSET and LDS
+    // buffer c % 3.  NSET register sets = every global load has NSET chunk periods to land: with 2 sets (round 2) a
+    // workgroup's chunk period was HALF THE MEMORY LATENCY (1900-2200 clk by stamps and by the single-job timings of
+    // tools/bench_wgroup.py: 35 us for 38 chunks) against 1024 clk of MFMAs per chunk, i.e. a workgroup was latency-bound
+    // and only three of them per CU hid it; with 4 sets one workgroup keeps ~4 chunks of loads in flight.
     // Every `issue` is UNCONDITIONAL (chunks past the end of the split read valid / bounds-zeroed rows that are never
     // stored): a conditionally issued batch of loads makes the number of loads in flight path-dependent, and hipcc then
-    // protects every later use with s_waitcnt vmcnt(0) - i.e. each store waited for the loads issued ONE chunk ago as well
-    // and the two-chunk-deep pipeline ran one deep: chunk period = memory latency (1900-2100 clk, stamps of round 2).
+    // protects every later use with s_waitcnt vmcnt(0) - i.e. each store waits for the loads issued LATER as well and the
+    // pipeline runs one deep.
+    constexpr int NSET = 2;       // (4 sets, 115 VGPRs: measured no faster - 78.1 vs 76 us per GNN-layer-pair group, 38 vs 37 us edge W1
+                                  //  alone: the chunk period of a lone workgroup, ~1650 clk, is LDS fragment reads + barrier, not loads)
+    Set sets[NSET];
     auto pipeline = [&](auto&& issue, auto&& store) {
       WSTAMP_S(0);
-      issue(s0, ms);
-      issue(s1, ms + BM);
-      if (nch > 0) store(Sm, s0);
-      issue(s0, ms + 2 * BM);
-      if (nch > 1) store(Sm + STG, s1);
-      issue(s1, ms + 3 * BM);
+#pragma unroll
+      for (int i = 0; i < NSET; ++i) issue(sets[i], ms + i * BM);
+      if (nch > 0) store(Sm, sets[0]);
+      issue(sets[0], ms + NSET * BM);
+      if (nch > 1) store(Sm + STG, sets[1]);
+      issue(sets[1], ms + (NSET + 1) * BM);
       WSTAMP_S(1);
       __syncthreads();                                    // chunks 0 and 1 are visible
       int b2 = 2;                                         // buffer of chunk c + 2
-      for (int c = 0; c < nch; c += 2) {
-        WSTAMP_S(2 + 3 * c);
-        if (c + 2 < nch) store(Sm + b2 * STG, s0);        // buffer (c+2) % 3 was last read during iteration c - 1
-        WSTAMP_S(3 + 3 * c);
-        issue(s0, ms + (c + 4) * BM);
-        b2 = b2 == 2 ? 0 : b2 + 1;
-        WSTAMP_S(4 + 3 * c);
-        __syncthreads();
-        if (c + 1 >= nch) break;
-        WSTAMP_S(5 + 3 * c);
-        if (c + 3 < nch) store(Sm + b2 * STG, s1);
-        WSTAMP_S(6 + 3 * c);
-        issue(s1, ms + (c + 5) * BM);
-        b2 = b2 == 2 ? 0 : b2 + 1;
-        WSTAMP_S(7 + 3 * c);
-        __syncthreads();
+      for (int c = 0; c < nch; c += NSET) {
+#pragma unroll
+        for (int u = 0; u < NSET; ++u) {                  // iteration c + u: chunk c+u+2 -> LDS, chunk c+u+2+NSET -> its set
+          if (u > 0 && c + u >= nch) break;
+          Set& q = sets[(u + 2) % NSET];
+          WSTAMP_S(2 + 3 * (c + u));
+          if (c + u + 2 < nch) store(Sm + b2 * STG, q);   // buffer (c+u+2) % 3 was last read during iteration c+u-1
+          WSTAMP_S(3 + 3 * (c + u));
+          issue(q, ms + (c + u + 2 + NSET) * BM);
+          b2 = b2 == 2 ? 0 : b2 + 1;
+          WSTAMP_S(4 + 3 * (c + u));
+          __syncthreads();
+        }
       }
     };
     if constexpr (FAST) {
@@ -1376,8 +1485,8 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, 
         const int cidx = __builtin_amdgcn_readfirstlane((m - ms) / BM);
         q.idx = __builtin_amdgcn_raw_buffer_load_b32(rI, vI, cidx * stepI, 0);      // (!gather: dummy, unused)
       };
-      load_idx(s0, ms);
-      load_idx(s1, ms + BM);
+#pragma unroll
+      for (int i = 0; i < NSET; ++i) load_idx(sets[i], ms + i * BM);
       auto issue = [&](Set& q, int m) {
         const int cidx = __builtin_amdgcn_readfirstlane((m - ms) / BM);
         q.y0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rY, vY0, cidx * stepY, 0));
@@ -1387,7 +1496,7 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, 
         const int soA = gather ? 0 : cidx * stepA;
         q.x0.v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rA, o0, soA, 0));
         q.x1.v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rA, o1, soA, 0));
-        load_idx(q, m + 2 * BM);                    // rows beyond M read index 0 through the buffer bounds
+        load_idx(q, m + NSET * BM);                 // rows beyond M read index 0 through the buffer bounds
         if (PRO == DOSX_PRO_ROWLN) {
           q.mean = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, vS, cidx * (BM * 8), 0));
           q.rstd = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rS, vS + 4, cidx * (BM * 8), 0));
@@ -1402,7 +1511,8 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, 
         st4(&buf[BM * LDT + r * LDT + c4 + 32], a_finish<PRO, VEC, 0>(t, q.x1, 0, K, gq1, bq1));
         if (do_bias) { bs0 = f4add(bs0, q.y0); bs1 = f4add(bs1, q.y1); }
       };
-      s0.mean = s0.rstd = s1.mean = s1.rstd = 0.f;
+#pragma unroll
+      for (int i = 0; i < NSET; ++i) sets[i].mean = sets[i].rstd = 0.f;
       pipeline(issue, store);
     } else {
       auto issue = [&](Set& q, int m) {
@@ -1491,13 +1601,23 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, 
     WSTAMP(60);
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] += acc2[i];
-    float* slab = g.slab + (size_t)z * N * K;
-    const int kcol = k0 + wk * 32 + l31;
+    if (g.dst != nullptr) {                                  // finished mode: the tile goes to LDS first (below)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int n = n0 + wn * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-      if (n < N && kcol < K) slab[(size_t)n * K + kcol] = acc[i];
+      for (int i = 0; i < 16; ++i)
+        Sm[(wn * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh) * LDT + wk * 32 + l31] = acc[i];
+    } else {
+      float* slab = g.slab + (size_t)z * N * K;
+      const int kcol = k0 + wk * 32 + l31;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int n = n0 + wn * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        if (n < N && kcol < K) slab[(size_t)n * K + kcol] = acc[i];
+      }
     }
+  }
+  if (g.dst != nullptr) {
+    wgrad_finish(g, Sm, bs0, bs1, do_bias, z, bx, by, ntk);
+    return;
   }
   if (do_bias) {          // workgroup-uniform: column sums of the staged dY rows -> slab_bias[z][n0 .. n0+63]
     float* Br = Sm;       // [32][LDT]   (the stage buffers are dead: the loop ended with a barrier)
@@ -1525,16 +1645,38 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradLaunch L) {
 // Grouped launch: ONE grid over several weight-gradient jobs (the jobs travel as a kernel argument like the slab
 // reduction's).  Interleaved one by one with the dgrad chain, each job is a kernel of 256-384 workgroups that shares the
 // matrix pipes with whatever the main stream runs; issued together they are one saturating grid with no tails.
-constexpr int WG_MAX_JOBS = 12;
+constexpr int WG_MAX_JOBS = 8;
+constexpr int WG_MAX_RJOBS = 40;
 struct WgradGroup {
   WgradLaunch job[WG_MAX_JOBS];
   int first_block[WG_MAX_JOBS + 1];
   int n;
+  // row-partial reductions riding in the same grid (blocks >= first_block[n]): dosx_grad_flush
+  DosxReduceJob rjob[WG_MAX_RJOBS];
+  int rfirst[WG_MAX_RJOBS + 1];
+  int nr;
 };
-static_assert(sizeof(WgradGroup) <= 4000, "WgradGroup must fit the kernel argument segment");
+static_assert(sizeof(WgradGroup) <= 4064, "WgradGroup must fit the kernel argument segment");
 
-__global__ __launch_bounds__(512) void wgrad_grouped_kernel(const WgradGroup G) {
+__device__ __forceinline__ void reduce_body(const DosxReduceJob& j, int slice, int t256, float4 (*red)[64]);
+
+// (two workgroups per CU: 4 waves per SIMD at <= 128 VGPRs.  Three per CU - 80 VGPRs, the LDS would hold them - measured
+//  no faster with two register sets, 76 vs 79 us per GNN-layer-pair group, and spills with four.)
+__global__ __launch_bounds__(512, 4) void wgrad_grouped_kernel(const WgradGroup G) {
   __shared__ __align__(16) float Sm[3 * WSTG];
+  if ((int)blockIdx.x >= G.first_block[G.n]) {
+    // ---- a reduction block: 2 slices of 256 elements (one per half of the workgroup) ----
+    const int rb = (int)blockIdx.x - G.first_block[G.n];
+    int lo = 0, hi = G.nr - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (G.rfirst[mid] <= rb) lo = mid; else hi = mid - 1;
+    }
+    const int half = (int)threadIdx.x >> 8;
+    reduce_body(G.rjob[lo], (rb - G.rfirst[lo]) * 2 + half, (int)threadIdx.x & 255,
+                reinterpret_cast<float4(*)[64]>(Sm + half * 4 * 64 * 4));
+    return;
+  }
   int lo = 0, hi = G.n - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
@@ -1562,17 +1704,12 @@ struct ReduceLaunch {
   int n;
 };
 
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceLaunch L) {
-  __shared__ float4 red[4][64];
-  // binary search: largest j with first_block[j] <= blockIdx.x
-  int lo = 0, hi = L.n - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (L.first_block[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
-  }
-  const DosxReduceJob j = L.job[lo];
-  const int q = threadIdx.x & 63, sl = threadIdx.x >> 6;      // wave sl sums slabs sl, sl+4, sl+8, ...
-  const int i = ((int)blockIdx.x - L.first_block[lo]) * RP_SLICE + q * 4;
+// One 256-element slice of one job, by 256 threads (t256 = thread within the slice's group; wave sl of the group sums
+// the partial rows sl, sl+4, sl+8, ...; `red`: [4][64] float4 of LDS).  NOTE: contains a barrier - both halves of a
+// 512-thread block (wgrad_grouped_kernel) must call it.
+__device__ __forceinline__ void reduce_body(const DosxReduceJob& j, int slice, int t256, float4 (*red)[64]) {
+  const int q = t256 & 63, sl = t256 >> 6;
+  const int i = slice * RP_SLICE + q * 4;
   const bool vec = ((j.stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(j.src) & 15) == 0) && ((j.count & 3) == 0);
   float4 s0 = f4zero(), s1 = f4zero();
   if (i < j.count) {
@@ -1609,6 +1746,17 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceLaunch
   }
 }
 
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceLaunch L) {
+  __shared__ float4 red[4][64];
+  // binary search: largest j with first_block[j] <= blockIdx.x
+  int lo = 0, hi = L.n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (L.first_block[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  reduce_body(L.job[lo], (int)blockIdx.x - L.first_block[lo], (int)threadIdx.x, red);
+}
+
 }  // namespace
 
 extern "C" int dosx_wgrad_splits(int M, int N, int K) {
@@ -1620,12 +1768,21 @@ extern "C" int dosx_wgrad_splits(int M, int N, int K) {
   static int max_split = 0;
   if (max_split == 0) {
     const char* e = getenv("DOSX_WGRAD_MAXSPLIT");
-    max_split = e ? atoi(e) : 16;
-    if (max_split < 1) max_split = 16;
+    // 8 (round 3, finished mode): half the partial tiles the last arriver has to read back, workgroups twice as long
+    // against ~12k clk of fixed prologue + publish cost each: GNN-layer-pair group alone 76 -> 69 us, encoder-stack group
+    // 54 -> 47 us, step 1.277 -> 1.271 ms (16 was the optimum of round 2's slab + reduce_partials scheme)
+    max_split = e ? atoi(e) : 8;
+    if (max_split < 1) max_split = 8;
   }
   if (s > max_split) s = max_split;
   if (s < 1) s = 1;
   return s;
+}
+
+extern "C" int dosx_wgrad_tiles(int N, int K) { return ceil_div(N, WT) * ceil_div(K, WT); }
+
+extern "C" int64_t dosx_wgrad_scratch_floats(int N, int K, int nsplit) {
+  return nsplit <= 1 ? 0 : (int64_t)nsplit * dosx_wgrad_tiles(N, K) * WTILE;
 }
 
 namespace {
@@ -1633,7 +1790,14 @@ namespace {
 // validation + launch parameters of one job; `fast` / `vec` select the kernel variant
 int wgrad_prepare(const DosxWgrad& g, WgradLaunch& L, int& vec, bool& fast, int& blocks) {
   DOSX_CHECK_ARG(g.N > 0 && g.K > 0 && g.nsplit >= 1, "dosx_wgrad: bad dims N=%d K=%d nsplit=%d", g.N, g.K, g.nsplit);
-  DOSX_CHECK_ARG(g.nseg >= 1 && g.nseg <= 3 && g.slab && g.dy.p, "dosx_wgrad: bad operands");
+  DOSX_CHECK_ARG(g.nseg >= 1 && g.nseg <= 3 && (g.slab || (g.dst && g.nsplit == 1)) && g.dy.p, "dosx_wgrad: bad operands");
+  if (g.dst != nullptr) {             // finished mode
+    DOSX_CHECK_ARG(g.counters != nullptr || g.nsplit == 1, "dosx_wgrad: finished mode needs tile counters");
+    DOSX_CHECK_ARG(!g.dst_bias || g.slab_bias || g.nsplit == 1, "dosx_wgrad: dst_bias needs the slab_bias scratch");
+    DOSX_CHECK_ARG(!g.slab_bias || g.dst_bias, "dosx_wgrad: finished mode with slab_bias needs dst_bias");
+    DOSX_CHECK_ARG(dosx_wgrad_scratch_floats(g.N, g.K, g.nsplit) * 4 < 0x7fffffffll, "dosx_wgrad: scratch slab beyond 2 GiB");
+    DOSX_CHECK_ARG(g.nsplit <= 64, "dosx_wgrad: nsplit=%d", g.nsplit);
+  }
   int ksum = 0;
   for (int i = 0; i < g.nseg; ++i) {
     DOSX_CHECK_ARG(g.a[i].p && g.a[i].width > 0 && g.a[i].map.d > 0, "dosx_wgrad: bad segment %d", i);
@@ -1700,20 +1864,39 @@ extern "C" int dosx_wgrad(const DosxWgrad* gp, dosx_stream_t stream) {
   return wgrad_launch_one(L, vec, fast, blocks, to_stream(stream));
 }
 
-extern "C" int dosx_wgrad_grouped(const DosxWgrad* jobs, int n_jobs, dosx_stream_t stream) {
-  if (n_jobs <= 0) return 0;
-  DOSX_CHECK_ARG(jobs != nullptr, "dosx_wgrad_grouped: null job table");
+extern "C" int dosx_grad_flush(const DosxWgrad* jobs, int n_jobs, const DosxReduceJob* rjobs, int n_rjobs,
+                               dosx_stream_t stream) {
+  if (n_jobs <= 0 && n_rjobs <= 0) return 0;
+  DOSX_CHECK_ARG(n_jobs <= 0 || jobs != nullptr, "dosx_grad_flush: null job table");
+  DOSX_CHECK_ARG(n_rjobs <= 0 || rjobs != nullptr, "dosx_grad_flush: null reduction table");
   hipStream_t st = to_stream(stream);
+  static int skip_w = -1;            // timing experiments only (tools/): leave the weight-gradient tiles out of the grid
+  if (skip_w < 0) skip_w = getenv("DOSX_DEBUG_SKIP_WGRAD") ? 1 : 0;
+  if (skip_w) n_jobs = 0;
   WgradGroup G;
   G.n = 0;
-  int blocks_total = 0;
+  G.nr = 0;
+  int blocks_total = 0, rblocks = 0, rdone = 0;
   auto flush = [&]() -> int {
-    if (G.n == 0) return 0;
+    // reduction jobs still waiting ride along (up to the table's capacity)
+    while (rdone < n_rjobs && G.nr < WG_MAX_RJOBS) {
+      const DosxReduceJob& j = rjobs[rdone];
+      DOSX_CHECK_ARG(j.src && j.dst && j.count > 0 && j.nsplit > 0, "dosx_grad_flush: bad reduction job %d", rdone);
+      G.rjob[G.nr] = j;
+      G.rfirst[G.nr] = rblocks;
+      rblocks += ceil_div(ceil_div(j.count, RP_SLICE), 2);        // two 256-element slices per 512-thread block
+      ++G.nr;
+      ++rdone;
+    }
+    if (G.n == 0 && G.nr == 0) return 0;
     G.first_block[G.n] = blocks_total;
-    hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(blocks_total), dim3(512), 0, st, G);
+    G.rfirst[G.nr] = rblocks;
+    hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(blocks_total + rblocks), dim3(512), 0, st, G);
     DOSX_LAUNCH_CHECK();
     G.n = 0;
+    G.nr = 0;
     blocks_total = 0;
+    rblocks = 0;
     return 0;
   };
   for (int i = 0; i < n_jobs; ++i) {
@@ -1721,7 +1904,7 @@ extern "C" int dosx_wgrad_grouped(const DosxWgrad* jobs, int n_jobs, dosx_stream
     int vec = 0, blocks = 0;
     bool fast = false;
     if (int rc = wgrad_prepare(jobs[i], L, vec, fast, blocks)) return rc;
-    if (L.variant < 0) {                      // (unaligned / non-affine operands: its own launch, as dosx_wgrad would)
+    if (L.variant < 0) {                      // (non-affine operands: its own launch, as dosx_wgrad would)
       if (int rc = wgrad_launch_one(L, vec, fast, blocks, st)) return rc;
       continue;
     }
@@ -1731,7 +1914,14 @@ extern "C" int dosx_wgrad_grouped(const DosxWgrad* jobs, int n_jobs, dosx_stream
     if (++G.n == WG_MAX_JOBS)
       if (int rc = flush()) return rc;
   }
-  return flush();
+  if (int rc = flush()) return rc;
+  while (rdone < n_rjobs)                     // more reductions than one table holds
+    if (int rc = flush()) return rc;
+  return 0;
+}
+
+extern "C" int dosx_wgrad_grouped(const DosxWgrad* jobs, int n_jobs, dosx_stream_t stream) {
+  return dosx_grad_flush(jobs, n_jobs, nullptr, 0, stream);
 }
 
 extern "C" int dosx_reduce_partials(const DosxReduceJob* jobs_host, int n_jobs, dosx_stream_t stream) {

@@ -49,16 +49,17 @@ def _wgrad_linear(sink: GradSink, G: Params, wkey: str, bkey: Optional[str], M: 
         return
     K = sum(s.width for s in segs)
     ns = ops.wgrad_splits(M, N, K)
-    slab = sink.scratch(ns, N, K)
-    slab_b = sink.scratch(ns, N) if bkey is not None else None
+    # finished mode (include/dosx.h: DosxWgrad.dst): the kernel sums the M-splits itself (last arriver of every tile, fixed
+    # order) and writes dW / db - no slab reduction launch; `slab` is its private tile-major scratch
+    nsc = ops.wgrad_scratch_floats(N, K, ns)
+    slab = sink.scratch(nsc) if nsc else None
+    slab_b = sink.scratch(ns * ((N + 63) // 64) * 64) if (bkey is not None and ns > 1) else None
+    kw = dict(dst=G[wkey], dst_bias=G[bkey] if bkey is not None else None, **pro)
+    keep = tuple(keep) + tuple(t for t in pro.values() if isinstance(t, torch.Tensor))
     if GradSink.group_wgrad:
-        sink.defer_wgrad(ops.wgrad_desc(M, N, dy, segs, slab, slab_b, ns, **pro),
-                         tuple(keep) + tuple(t for t in pro.values() if isinstance(t, torch.Tensor)))
+        sink.defer_wgrad(ops.wgrad_desc(M, N, dy, segs, slab, slab_b, ns, **kw), keep)
     else:
-        sink.on_side(lambda: ops.wgrad(M, N, dy, segs, slab, slab_b, ns, **pro), keep)
-    sink.add(slab, 0, G[wkey], ns, N * K, N * K)
-    if bkey is not None:
-        sink.add(slab_b, 0, G[bkey], ns, N, N)
+        sink.on_side(lambda: ops.wgrad(M, N, dy, segs, slab, slab_b, ns, **kw), keep)
 
 
 # ------------------------------------------------------------------------------------------------

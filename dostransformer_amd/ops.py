@@ -454,8 +454,45 @@ def wgrad_splits(M: int, N: int, K: int) -> int:
     return _lib.load().dosx_wgrad_splits(int(M), int(N), int(K))
 
 
-def wgrad_desc(M: int, N: int, dy: Seg, segs: Sequence[Seg], slab: torch.Tensor, slab_bias: Optional[torch.Tensor],
-               nsplit: int, *, pro: int = PRO_NONE, pro_gamma=None, pro_beta=None, pro_alpha=None, pro_stats=None) -> Wgrad:
+def wgrad_tiles(N: int, K: int) -> int:
+    return _lib.load().dosx_wgrad_tiles(int(N), int(K))
+
+
+def wgrad_scratch_floats(N: int, K: int, nsplit: int) -> int:
+    return int(_lib.load().dosx_wgrad_scratch_floats(int(N), int(K), int(nsplit)))
+
+
+class _CounterPool:
+    """Zeroed int32 tile counters of the finished-mode weight-gradient kernels (include/dosx.h: DosxWgrad.counters).  A
+    kernel leaves its counters at zero, so one pool per device is handed out round-robin; a step uses a few hundred of
+    the 2^16 entries, and launches that could touch the same entry are a whole step apart on the same stream."""
+    SIZE = 1 << 16
+
+    def __init__(self):
+        self._bufs = {}
+
+    def take(self, device, n: int) -> int:
+        key = str(device)
+        ent = self._bufs.get(key)
+        if ent is None:
+            ent = self._bufs[key] = [torch.zeros(self.SIZE, dtype=torch.int32, device=device), 0]
+        if n > self.SIZE:
+            raise ValueError(f"{n} tile counters requested, the pool holds {self.SIZE}")
+        if ent[1] + n > self.SIZE:
+            ent[1] = 0
+        off = ent[1]
+        ent[1] += n
+        return ent[0].data_ptr() + 4 * off
+
+
+COUNTERS = _CounterPool()
+
+
+def wgrad_desc(M: int, N: int, dy: Seg, segs: Sequence[Seg], slab: Optional[torch.Tensor], slab_bias: Optional[torch.Tensor],
+               nsplit: int, *, pro: int = PRO_NONE, pro_gamma=None, pro_beta=None, pro_alpha=None, pro_stats=None,
+               dst: Optional[torch.Tensor] = None, dst_bias: Optional[torch.Tensor] = None, accumulate: bool = False) -> Wgrad:
+    """``dst`` given: finished mode (the kernel reduces the M-splits itself and writes dW / db; ``slab`` / ``slab_bias`` are
+    scratch from :func:`wgrad_scratch_floats`); else slab mode (partial sums left for reduce_partials)."""
     g = Wgrad()
     g.M, g.N = int(M), int(N)
     g.K = int(sum(s.width for s in segs))
@@ -464,24 +501,44 @@ def wgrad_desc(M: int, N: int, dy: Seg, segs: Sequence[Seg], slab: torch.Tensor,
     _set_segs(g.a, segs)
     g.pro = pro
     g.pro_gamma, g.pro_beta, g.pro_alpha, g.pro_stats = _p(pro_gamma), _p(pro_beta), _p(pro_alpha), _p(pro_stats)
-    g.slab, g.slab_bias, g.nsplit = slab.data_ptr(), _p(slab_bias), int(nsplit)
+    g.slab, g.slab_bias, g.nsplit = _p(slab), _p(slab_bias), int(nsplit)
+    if dst is not None:
+        assert dst.is_contiguous() and dst.numel() == g.N * g.K and dst.dtype == torch.float32
+        g.dst, g.dst_bias, g.accumulate = dst.data_ptr(), _p(dst_bias), int(bool(accumulate))
+        if nsplit > 1:
+            g.counters = COUNTERS.take(dst.device, wgrad_tiles(g.N, g.K))
     return g
 
 
-def wgrad(M: int, N: int, dy: Seg, segs: Sequence[Seg], slab: torch.Tensor, slab_bias: Optional[torch.Tensor],
-          nsplit: int, **pro) -> None:
-    g = wgrad_desc(M, N, dy, segs, slab, slab_bias, nsplit, **pro)
+def wgrad(M: int, N: int, dy: Seg, segs: Sequence[Seg], slab: Optional[torch.Tensor], slab_bias: Optional[torch.Tensor],
+          nsplit: int, **kw) -> None:
+    g = wgrad_desc(M, N, dy, segs, slab, slab_bias, nsplit, **kw)
     _call("dosx_wgrad", C.byref(g), _stream(),
           w=lambda: (f"wgrad[N{g.N},K{g.K}]", "wgrad_kernel", "mfma", 2.0 * _real(g.M) * g.N * g.K))
 
 
+def _reduce_job_array(jobs):
+    arr = (ReduceJob * max(len(jobs), 1))()
+    for i, j in enumerate(jobs):
+        arr[i].src, arr[i].dst, arr[i].nsplit, arr[i].stride, arr[i].count, arr[i].accumulate = j
+    return arr
+
+
+def grad_flush(descs: Sequence[Wgrad], rjobs: Sequence[tuple] = ()) -> None:
+    """The weight-gradient jobs and the row-partial reductions of one flush point in as few launches as possible - one,
+    normally (include/dosx.h: dosx_grad_flush).  ``rjobs``: (src, dst, nsplit, stride, count, accumulate) tuples with
+    distinct destinations."""
+    if not descs and not rjobs:
+        return
+    arr = (Wgrad * max(len(descs), 1))(*descs)
+    rarr = _reduce_job_array(rjobs)
+    _call("dosx_grad_flush", arr, len(descs), rarr, len(rjobs), _stream(),
+          w=lambda: ("wgrad_grouped", "wgrad_grouped_kernel", "mfma", sum(2.0 * _real(d.M) * d.N * d.K for d in descs)))
+
+
 def wgrad_grouped(descs: Sequence[Wgrad]) -> None:
     """All the jobs in as few launches as possible (include/dosx.h: dosx_wgrad_grouped)."""
-    if not descs:
-        return
-    arr = (Wgrad * len(descs))(*descs)
-    _call("dosx_wgrad_grouped", arr, len(descs), _stream(),
-          w=lambda: ("wgrad_grouped", "wgrad_grouped_kernel", "mfma", sum(2.0 * _real(d.M) * d.N * d.K for d in descs)))
+    grad_flush(descs, ())
 
 
 _LPT = __import__("os").environ.get("DOSX_WGRAD_LPT", "1") == "1"
@@ -545,13 +602,38 @@ class GradSink:
             self._wjobs = []
         self._wjobs.append(desc)
 
-    def run_grouped(self) -> None:
+    def _take_wjobs(self):
         jobs = getattr(self, "_wjobs", [])
+        self._wjobs = []
+        if jobs and _LPT:      # biggest jobs first: the tail of the grid is then made of the small ones
+            jobs = sorted(jobs, key=lambda g: -(g.M * g.N * g.K))
+        return jobs
+
+    def run_grouped(self) -> None:
+        jobs = self._take_wjobs()
         if jobs:
-            self._wjobs = []
-            if _LPT:      # biggest jobs first: the tail of the grid is then made of the small ones
-                jobs = sorted(jobs, key=lambda g: -(g.M * g.N * g.K))
             wgrad_grouped(jobs)
+
+    def _flush_launch(self, rjobs) -> None:
+        """ONE launch for a flush point: the pending weight-gradient jobs (finished mode: they write the gradients
+        themselves) + the first wave of row-partial reductions; reductions that share a destination with an earlier one
+        follow in launches of their own (they accumulate)."""
+        wjobs = self._take_wjobs()
+        # finished-mode jobs that target the same gradient: the later ones accumulate, each in a later launch
+        waves_w: List[list] = []
+        occ = {}
+        for g in wjobs:
+            k = occ.get(g.dst, 0) if g.dst else 0
+            if g.dst:
+                occ[g.dst] = k + 1
+            while k >= len(waves_w):
+                waves_w.append([])
+            if k > 0:
+                g.accumulate = 1
+            waves_w[k].append(g)
+        waves_r = self._reduce_waves(rjobs)
+        for i in range(max(len(waves_w), len(waves_r), 0)):
+            grad_flush(waves_w[i] if i < len(waves_w) else [], waves_r[i] if i < len(waves_r) else [])
 
     def on_side(self, fn, keep=()) -> None:
         """Run ``fn`` (kernel launches) on the side stream, ordered after everything launched so far on
@@ -607,42 +689,42 @@ class GradSink:
                     RECORDER.prog.append((ev.record, (src,)))
                     RECORDER.prog.append((self.wside.wait_event, (ev,)))
             with torch.cuda.stream(self.wside):
-                self.run_grouped()
-                self._reduce(jobs)
+                self._flush_launch(jobs)
             self._wforked = True
             return
-        self.run_grouped()
         jobs, self.jobs = self.jobs, []
-        self.on_side(lambda: self._reduce(jobs))
+        if self.side is None:
+            self._flush_launch(jobs)
+        else:
+            self.run_grouped()
+            self.on_side(lambda: self._reduce(jobs))
 
     def flush(self):
         self.join()              # (first: deferred weight-gradient jobs may read tensors produced on the side stream)
-        self.run_grouped()
+        jobs, self.jobs = self.jobs, []
+        self._flush_launch(jobs)             # (nothing in it depends on the weight-gradient stream's earlier launches)
         if self.wside is not None and self._wforked:
             self.main.wait_stream(self.wside)
             if RECORDER.active:
                 RECORDER.prog.append((self.main.wait_stream, (self.wside,)))
             self._wforked = False
-        jobs, self.jobs = self.jobs, []
-        self._reduce(jobs)
 
-    def _reduce(self, jobs):
-        self_jobs = jobs
-        if not self_jobs:
-            return
+    @staticmethod
+    def _reduce_waves(jobs):
         # jobs that share a destination go to successive launches (later ones accumulate)
         occ = {}
         waves: List[List[tuple]] = []
-        for j in self_jobs:
+        for j in jobs:
             k = occ.get(j[1], 0)
             occ[j[1]] = k + 1
             if k >= len(waves):
                 waves.append([])
             waves[k].append(j if k == 0 else j[:5] + (1,))
-        for wv in waves:
-            arr = (ReduceJob * len(wv))()
-            for i, j in enumerate(wv):
-                arr[i].src, arr[i].dst, arr[i].nsplit, arr[i].stride, arr[i].count, arr[i].accumulate = j
+        return waves
+
+    def _reduce(self, jobs):
+        for wv in self._reduce_waves(jobs):
+            arr = _reduce_job_array(wv)
             _call("dosx_reduce_partials", arr, len(wv), _stream(),
                   w=lambda wv=wv: ("reduce_partials", "reduce_partials_kernel", "hbm",
                                    sum(4.0 * (j[2] + 1 + j[5]) * j[4] for j in wv)))

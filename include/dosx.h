@@ -124,9 +124,19 @@ int dosx_gemm(const DosxGemm* g, dosx_stream_t stream);
  * ("gemm_kernel<RT, NTW, WL, PRO, VEC, EPI>"), written to the HOST buffer buf[n]. */
 int dosx_gemm_kernel_name(const DosxGemm* g, char* buf, int n);
 
-/* dW partial slabs: slab[s][N][K] = sum_{m in split s} dY[m][n] * prologue(A)[m][k]
- * (nn.Linear weight gradient), optional bias partial slab_bias[s][N] = sum_m dY[m][n].
- * `nsplit` must come from dosx_wgrad_splits(). */
+/* dW of y = A W^T + b (nn.Linear weight gradient), split over the M rows into `nsplit` partial sums
+ *   part[s][n][k] = sum_{m in split s} dY[m][n] * prologue(A)[m][k],   bias part[s][n] = sum_m dY[m][n].
+ * `nsplit` must come from dosx_wgrad_splits().  Two modes:
+ *   dst == NULL (slab mode): the partial sums are left in slab[nsplit][N][K] / slab_bias[nsplit][N] for
+ *     dosx_reduce_partials;
+ *   dst != NULL (finished mode): the kernel itself finishes dW: every workgroup publishes its 64x64 partial tile
+ *     (write-through stores), draws a ticket on its tile's counter, and the LAST arriver of a tile adds the nsplit partial
+ *     tiles in split order (a fixed order whoever arrives last: bitwise reproducible, no float atomics) and writes
+ *     dst[N][K] (row stride K; `accumulate`: dst +=) and dst_bias[N].  No second launch, no slab re-read through HBM.
+ *     slab is then private scratch of dosx_wgrad_scratch_floats(N, K, nsplit) floats (tile-major; may be NULL when
+ *     nsplit == 1), slab_bias of nsplit * 64*ceil(N/64) floats, `counters` one int32 per 64x64 tile
+ *     (dosx_wgrad_tiles(N, K)), ZERO before the first launch that uses them and zero again when the launch is done
+ *     (the last arriver resets its counter), so a caller allocates them zeroed once. */
 typedef struct DosxWgrad {
   int32_t M, N, K;
   DosxSeg dy;        /* width = N */
@@ -137,14 +147,20 @@ typedef struct DosxWgrad {
   const float* pro_beta;
   const float* pro_alpha;
   const float* pro_stats;
-  float* slab;       /* [nsplit, N, K] */
-  float* slab_bias;  /* [nsplit, N] or NULL */
+  float* slab;       /* slab mode: [nsplit, N, K]; finished mode: scratch (see above) */
+  float* slab_bias;  /* slab mode: [nsplit, N] or NULL; finished mode: scratch or NULL */
   int32_t nsplit;
+  int32_t accumulate; /* finished mode: dst (+)= */
+  float* dst;        /* finished mode: [N, K] */
+  float* dst_bias;   /* finished mode: [N] or NULL (needs slab_bias) */
+  int32_t* counters; /* finished mode: [dosx_wgrad_tiles(N, K)] */
 } DosxWgrad;
 int dosx_wgrad_splits(int M, int N, int K);
+int dosx_wgrad_tiles(int N, int K);
+int64_t dosx_wgrad_scratch_floats(int N, int K, int nsplit);
 int dosx_wgrad(const DosxWgrad* g, dosx_stream_t stream);
-/* The same for `n_jobs` independent jobs in as few launches as possible (one grid over up to 12 jobs at a time; jobs
- * with unaligned or non-affine operands get their own launch).  Results are identical to n_jobs dosx_wgrad calls. */
+/* The same for `n_jobs` independent jobs in as few launches as possible (one grid over up to 8 jobs at a time; jobs
+ * with non-affine operands get their own launch).  Results are identical to n_jobs dosx_wgrad calls. */
 int dosx_wgrad_grouped(const DosxWgrad* jobs, int n_jobs, dosx_stream_t stream);
 
 /* Batched deterministic reduction of partial slabs: dst[i] (+)= sum_s src[s*stride + i]. */
@@ -159,6 +175,11 @@ typedef struct DosxReduceJob {
 /* jobs: HOST array of n_jobs entries (copied into kernel arguments, <= 64 jobs per launch: no device
  * table, no host->device copy, safe under graph capture).  Jobs of one call must have distinct dst. */
 int dosx_reduce_partials(const DosxReduceJob* jobs_host, int n_jobs, dosx_stream_t stream);
+/* One flush point of a backward pass in ONE launch: the weight-gradient jobs (dosx_wgrad_grouped) and the row-partial
+ * reductions of the fused LayerNorm / PReLU / bias epilogues (dosx_reduce_partials; they depend on earlier kernels only,
+ * not on the weight-gradient jobs) share a grid: the reduction blocks are appended behind the weight-gradient tiles.
+ * Up to 8 weight-gradient + 40 reduction jobs per launch (kernel-argument table); more jobs -> more launches. */
+int dosx_grad_flush(const DosxWgrad* jobs, int n_jobs, const DosxReduceJob* rjobs_host, int n_rjobs, dosx_stream_t stream);
 
 /* a1: edge_attr[E,4] = smooth_cutoff(|v|/r_max) * [1, sqrt3 * v/max(|v|,1e-12)]
  * (DOSTransformer_phonon.py:74-77; e3nn semantics restated in oracle/dos_oracle.py). */
