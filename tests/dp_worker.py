@@ -4,7 +4,11 @@ RCCL refuses two ranks on one device, so the group is gloo and `dist.DataParalle
 everything else — `shard_batch`, the SSE pre-reduce, the early-bucket hook, the split recording of replayed steps, the
 bucket logic of `optimizer_step` — is the production code path with world_size 2.
 
-usage: dp_worker.py <rank> <world> <port> <outdir>        (started as a fresh interpreter, never forked from a GPU process)"""
+usage: dp_worker.py <rank> <world> <port> <outdir> [suite]   (started as a fresh interpreter, never forked from a GPU process)
+
+suite "small" (default): B = 10, hidden 32, 3 steps.  suite "full": BASELINE.json configs[3] and [4] at FULL global size -
+Phonon-DOS layers 3 / transformer 2 / hidden 128, global batch 512, and Electron-DOS hidden 256 / transformer 4, global
+batch 256 - meant for world = 8 (64 resp. 32 crystals per rank, the per-GPU shards of the 8-GPU configurations)."""
 import os
 import sys
 
@@ -18,25 +22,34 @@ if ROOT not in sys.path:
 CASES = [("phonon", "eager"), ("phonon", "replay"), ("edos", "eager"), ("edos", "replay")]
 STEPS = 3
 B_GLOBAL = 10
+# suite -> kind -> (layers, t_layers, hidden, global batch); steps of the suite (indices into the crystal seeds)
+SUITES = {
+    "small": {"phonon": (3, 2, 32, 10), "edos": (3, 1, 32, 10), "steps": (0, 1, 0)},
+    "full": {"phonon": (3, 2, 128, 512), "edos": (3, 4, 256, 256), "steps": (0, 0)},     # BASELINE.json configs[3], [4]
+}
 
 
-def make_model(kind, dev):
+def make_model(kind, dev, suite="small"):
     torch.manual_seed(0)
+    L, T, H, _ = SUITES[suite][kind]
     if kind == "phonon":
         from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
-        return DOSTransformer_phonon(3, 2, 118, 4, 32, dev, 0.0).to(dev)
+        return DOSTransformer_phonon(L, T, 118, 4, H, dev, 0.0).to(dev)
     from dostransformer_amd.embedder_eDOS.DOSTransformer import DOSTransformer
-    return DOSTransformer(3, 1, 200, 41, 2, 32, dev, 0.0).to(dev)
+    return DOSTransformer(L, T, 200, 41, 2, H, dev, 0.0).to(dev)
 
 
-def make_crystals(kind, step):
+def make_crystals(kind, step, suite="small"):
     from dostransformer_amd import synth
-    return synth.phonon_crystals(B_GLOBAL, 300 + step, torch.float32) if kind == "phonon" else \
-        synth.edos_crystals(B_GLOBAL, 400 + step, torch.float32)
+    B = SUITES[suite][kind][3]
+    return synth.phonon_crystals(B, 300 + step, torch.float32) if kind == "phonon" else \
+        synth.edos_crystals(B, 400 + step, torch.float32)
 
 
 def main():
     rank, world, port, outdir = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    suite = sys.argv[5] if len(sys.argv) > 5 else "small"
+    steps = SUITES[suite]["steps"]
     import torch.distributed as td
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     td.init_process_group("gloo", rank=rank, world_size=world)
@@ -44,14 +57,16 @@ def main():
     from dostransformer_amd.train import Trainer
     dev = "cuda:0"
     out = {}
-    for kind, mode in CASES:
-        model = make_model(kind, dev)
+    # (full suite: replay mode only - its first step runs eagerly while it is recorded, the second one replays the plan)
+    for kind, mode in (CASES if suite == "small" else [c for c in CASES if c[1] == "replay"]):
+        model = make_model(kind, dev, suite)
+        b_global = SUITES[suite][kind][3]
         tr = Trainer(model, lr=1e-3, beta=1.0, dist=DataParallel(), replay=(mode == "replay"))
         losses = []
-        # steps 0 and 2 use the SAME crystals (same bucket: step 2 is a true replay in replay mode), step 1 others
-        for step in (0, 1, 0)[:STEPS]:
-            g = shard_batch(make_crystals(kind, step), world, rank).to(dev)
-            n_global = None if step == 1 else B_GLOBAL          # step 1: take it from the batch (shard_batch records it)
+        # steps with the SAME crystals hit the same bucket (the later one is a true replay in replay mode)
+        for step in steps:
+            g = shard_batch(make_crystals(kind, step, suite), world, rank).to(dev)
+            n_global = None if step == 1 else b_global          # step 1: take it from the batch (shard_batch records it)
             losses.append(float(tr.step(g, n_global)))
             if step == 0 and len(losses) == 1:
                 torch.cuda.synchronize()

@@ -27,26 +27,36 @@ def _free_port():
     return p
 
 
-@pytest.fixture(scope="module")
-def two_rank_run(tmp_path_factory):
-    out = tmp_path_factory.mktemp("dp2")
+def _run_ranks(out, world, suite):
     port = _free_port()
     env = dict(os.environ)
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(r), "2", str(port), str(out)],
-                              env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
-    logs = []
-    for p in procs:
-        try:
-            o, _ = p.communicate(timeout=900)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
-        logs.append(o.decode(errors="replace"))
+    logf = [open(os.path.join(out, f"rank{r}.log"), "wb") for r in range(world)]     # (files, not pipes: 8 chatty ranks must not block)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(r), str(world), str(port), str(out), suite],
+                              env=env, cwd=ROOT, stdout=logf[r], stderr=subprocess.STDOUT) for r in range(world)]
+    try:
+        for p in procs:
+            p.wait(timeout=1500)
+    except subprocess.TimeoutExpired:
+        for q in procs:
+            q.kill()
+        raise
+    finally:
+        for f in logf:
+            f.close()
     for r, p in enumerate(procs):
-        assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-4000:]}"
-    return [np.load(os.path.join(out, f"rank{r}.npz")) for r in range(2)]
+        assert p.returncode == 0, f"rank {r} failed:\n{open(os.path.join(out, f'rank{r}.log'), errors='replace').read()[-4000:]}"
+    return [np.load(os.path.join(out, f"rank{r}.npz")) for r in range(world)]
+
+
+@pytest.fixture(scope="module")
+def two_rank_run(tmp_path_factory):
+    return _run_ranks(str(tmp_path_factory.mktemp("dp2")), 2, "small")
+
+
+@pytest.fixture(scope="module")
+def eight_rank_full_run(tmp_path_factory):
+    return _run_ranks(str(tmp_path_factory.mktemp("dp8")), 8, "full")
 
 
 @pytest.mark.parametrize("kind,mode", [("phonon", "eager"), ("phonon", "replay"), ("edos", "eager"), ("edos", "replay")])
@@ -119,3 +129,148 @@ def test_bench_two_ranks_share_gpu(tmp_path):
     assert outs[1][1].strip() == ""                       # only rank 0 prints
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 16 and rec["scaling"] == "weak"
     assert rec["value"] > 0 and abs(rec["value"] - 16 * rec["steps"] / (rec["ms_per_step"] * 1e-3 * rec["steps"])) < 1e-2 * rec["value"]
+
+
+@pytest.mark.parametrize("kind,mode", [("phonon", "replay"), ("edos", "replay")])
+def test_eight_rank_full_size_configs_match_single_process(eight_rank_full_run, kind, mode):
+    """BASELINE.json configs[3] (Phonon-DOS L3 T2 H128, global batch 512) and configs[4] (Electron-DOS H256 T4, global batch
+    256) at FULL global size with the 8 ranks of the 8-GPU configuration - 8 fresh processes that share the box's one
+    MI355X over gloo, each training on its `shard_batch` shard (64 resp. 32 crystals) - against a single-process `Trainer` on
+    the un-sharded batch (it fits one GPU): global loss (`main_phDOS.py:109-114` is ONE rmse over all B*51 elements), the
+    all-reduced step-0 gradients, the parameters after 2 AdamW steps (step 0 runs eagerly while the replay plan - split
+    around the SSE and early-bucket collectives - is recorded, step 1 replays it); replicas bit-identical to each other.  No scaling claim
+    (one GPU, host-staged sums): this proves the 8-way sharded step computes the full-batch step."""
+    from dostransformer_amd.batch import collate
+    from dostransformer_amd.train import Trainer
+    from tests.dp_worker import SUITES, make_crystals, make_model
+    ranks = eight_rank_full_run
+    pre = f"{kind}/{mode}/"
+    for r in ranks[1:]:
+        for k in ranks[0].files:
+            if k.startswith(pre) and not k.endswith("/loss"):
+                assert np.array_equal(ranks[0][k], r[k]), k
+    dev = "cuda:0"
+    model = make_model(kind, dev, "full")
+    assert model._cfg.H == SUITES["full"][kind][2]
+    tr = Trainer(model, lr=1e-3, beta=1.0)
+    losses, grad0 = [], None
+    for step in SUITES["full"]["steps"]:
+        g = collate(make_crystals(kind, step, "full")).to(dev)
+        assert g.num_graphs == SUITES["full"][kind][3]
+        losses.append(float(tr.step(g)))
+        if grad0 is None:
+            torch.cuda.synchronize()
+            grad0 = model.flat_params().grad.detach().cpu().numpy().copy()
+    dp_loss = ranks[0][pre + "loss"] if kind == "phonon" else sum(r[pre + "loss"] for r in ranks)
+    assert np.allclose(dp_loss, losses, rtol=5e-5, atol=5e-6), (dp_loss, losses)
+    gd = ranks[0][pre + "grad0"]
+    assert gd.shape == grad0.shape
+    rel = np.abs(gd - grad0).max() / np.abs(grad0).max()
+    assert rel <= 1e-4, rel
+    # typical error, not just the maximum: the 99th percentile of the element errors stays two orders below the maximum bound
+    assert np.percentile(np.abs(gd - grad0), 99) <= 1e-5 * np.abs(grad0).max()
+    fp = model.flat_params()
+    for k, v in model.state_dict().items():
+        if not v.is_floating_point():
+            continue
+        a, b = ranks[0][pre + "p/" + k], v.detach().cpu().numpy()
+        if k in fp.G:
+            gk = fp.G[k].detach().cpu().numpy()
+            ok = np.abs(gk) >= 1e-2 * np.abs(gk).max()
+            assert np.abs(a - b)[ok].max() <= 1e-4, (k, np.abs(a - b)[ok].max())    # 5 % of the two steps' movement
+            assert np.abs(a - b).max() <= 2.1e-3, k              # 2 steps of lr 1e-3
+        else:
+            assert np.array_equal(a, b), k                      # dead parameters: untouched everywhere
+
+
+class _DelayedComm:
+    """Stand-in for the RCCL collective of a 2-rank job on a 1-GPU box, with NCCL's stream semantics: the collective runs on
+    a stream of the communicator, ordered after the work already queued on the caller's stream; `async_op=True` returns a
+    handle whose `wait()` makes the then-current stream wait for it.  STRICTER than NCCL in one respect: every collective
+    gets a stream of its own, so a later (synchronous) collective does not order the caller behind an earlier asynchronous
+    one by accident - only the handle's wait() does.  The "sum over ranks" adds a second rank with identical data (x2),
+    `delay` GPU cycles late."""
+
+    def __init__(self, real, delay):
+        self.real, self.delay, self.streams, self.calls = real, int(delay), [], 0
+
+    def __call__(self, t, op=None, group=None, async_op=False):
+        if not t.is_cuda:
+            return self.real(t, op=op, group=group, async_op=async_op)
+        self.calls += 1
+        comm = torch.cuda.Stream()
+        self.streams.append(comm)
+        comm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(comm):
+            if self.delay:
+                torch.cuda._sleep(self.delay)
+            t.mul_(2.0)
+
+        class Work:
+            def wait(self_w):
+                torch.cuda.current_stream().wait_stream(comm)
+                return True
+        w = Work()
+        if async_op:
+            return w
+        w.wait()
+        return None
+
+
+def test_optimizer_waits_for_a_late_early_bucket_allreduce_under_replay(monkeypatch):
+    """The NCCL branch of `DataParallel` (device buffers, `all_reduce(async_op=True)` for the early gradient bucket, started
+    on the weight-gradient stream underneath the GNN backward, `train.Trainer._mid_hook`) under REPLAY, with the collective
+    finishing ~40 ms late on the communicator's stream: `optimizer_step` must wait for it.  World size 1 (one GPU), the
+    collective replaced by a delayed x2 with NCCL's stream semantics.  Same parameters, bit for bit, with and without the
+    delay; and the negative control - the handle's wait() disabled - does NOT give them, i.e. the test can see a missing wait."""
+    import torch.distributed as td
+    from dostransformer_amd import dist as D
+    from dostransformer_amd import synth
+    from dostransformer_amd.batch import bucket_sizes, pad_batch
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    from dostransformer_amd.train import Trainer
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(_free_port()))
+    created = not td.is_initialized()
+    if created:
+        td.init_process_group("nccl", rank=0, world_size=1)
+    dev = "cuda:0"
+    try:
+        g = synth.phonon_batch(6, seed=21, dtype=torch.float32)
+        g = pad_batch(g, *bucket_sizes(g.meta.num_nodes, g.meta.num_edges)).to(dev)
+        real = td.all_reduce
+
+        def run(delay, steps, break_wait=False):
+            comm = _DelayedComm(real, delay)
+            monkeypatch.setattr(D.td, "all_reduce", comm)
+            torch.manual_seed(0)
+            model = DOSTransformer_phonon(3, 1, 118, 4, 32, dev, 0.0).to(dev)
+            dp = D.DataParallel()
+            assert not dp.staged                                   # the NCCL branch
+            if break_wait:
+                orig = dp.all_reduce_grads_async
+
+                def no_wait(flat):
+                    h = orig(flat)
+                    h.wait = lambda: True
+                    return h
+                dp.all_reduce_grads_async = no_wait
+            tr = Trainer(model, lr=1e-3, dist=dp, replay=True)
+            for _ in range(steps):
+                tr.step(g, 12)                                     # "two ranks" of 6 crystals
+            torch.cuda.synchronize()
+            monkeypatch.setattr(D.td, "all_reduce", real)
+            assert comm.calls >= 3 * steps                         # SSE pair, early bucket, GNN bucket per step
+            fp = model.flat_params()
+            assert 0 < fp.n_late < fp.total and tr._early_work is None
+            return {k: v.detach().cpu().clone() for k, v in model.state_dict().items() if v.is_floating_point()}
+
+        ref = run(0, 4)                        # step 0 records the plan (split around the collectives), steps 1-3 replay it
+        late = run(int(1e8), 4)
+        for k in ref:
+            assert torch.equal(ref[k], late[k]), k
+        one, broken = run(int(1e8), 1), run(int(1e8), 1, break_wait=True)
+        assert any(not torch.equal(one[k], broken[k]) for k in one), "negative control: a missing wait() went unnoticed"
+    finally:
+        if created:
+            td.destroy_process_group()

@@ -220,6 +220,11 @@ GRAD_TOL = {("phonon", 64, 1, 8): 3e-3, ("phonon", 128, 2, 16): 3e-3, ("edos", 6
             ("phonon", 128, 2, 64): 3e-3, ("edos", 256, 2, 64): 2e-2, ("edos", 256, 4, 32): 2e-2}
 
 
+# typical element error of a gradient tensor, relative to the tensor maximum (provisional bounds; see the printed values)
+GRAD_TOL_P99 = {"phonon": 1e-4, "edos": 1e-3}
+GRAD_TOL_MEDIAN = {"phonon": 2e-5, "edos": 2e-4}
+
+
 @pytest.mark.parametrize("kind,H,T,B", [("phonon", 64, 1, 8), ("phonon", 128, 2, 16), ("edos", 64, 2, 6),
                                          ("edos", 256, 2, 4),
                                          # BASELINE.json configs[1], [2] and the per-GPU shard of [4] at FULL size
@@ -262,14 +267,22 @@ def test_against_oracle_live(kind, H, T, B):
     fp = model.flat_params()
     tol = GRAD_TOL[(kind, H, T, B)]
     worst = (0.0, None)
-    for k, gr in grads.items():
+    worst99 = (0.0, None)          # TYPICAL error: the 99th percentile of the element errors of a tensor (tensors of >= 256
+    worst50 = (0.0, None)          # elements), and the median - a handful of activation-gate flips may reach
+    for k, gr in grads.items():    # `tol`, a uniform regression of the kernels cannot hide under it
         if gr is None:
             assert k not in fp.G, k
         else:
-            e = float((fp.G[k].cpu().double() - gr.double()).abs().max() / (gr.abs().max() + 1e-6))
-            worst = max(worst, (e, k))
-    print(f"oracle-live {kind} H{H} T{T} B{B}: worst per-tensor gradient error (relative to the tensor max) {worst[0]:.3e} at {worst[1]}")
+            err = (fp.G[k].cpu().double() - gr.double()).abs().reshape(-1) / (gr.abs().max() + 1e-6)
+            worst = max(worst, (float(err.max()), k))
+            if err.numel() >= 256:
+                worst99 = max(worst99, (float(torch.quantile(err[:1 << 24], 0.99)), k))
+                worst50 = max(worst50, (float(err.median()), k))
+    print(f"oracle-live {kind} H{H} T{T} B{B}: worst per-tensor gradient error (relative to the tensor max) {worst[0]:.3e} at {worst[1]}"
+          f"; worst 99th percentile {worst99[0]:.3e} at {worst99[1]}; worst median {worst50[0]:.3e} at {worst50[1]}")
     assert worst[0] < tol, worst
+    assert worst99[0] < GRAD_TOL_P99[kind], worst99
+    assert worst50[0] < GRAD_TOL_MEDIAN[kind], worst50
     tr.optimizer_step()
     # Adam's first step moves every element by ~lr*sign(g): where |g| is at the noise floor of the fp32
     # (GPU) vs fp64 (oracle) gradient the sign itself is ill-conditioned, so compare the update only
