@@ -220,9 +220,11 @@ GRAD_TOL = {("phonon", 64, 1, 8): 3e-3, ("phonon", 128, 2, 16): 3e-3, ("edos", 6
             ("phonon", 128, 2, 64): 3e-3, ("edos", 256, 2, 64): 2e-2, ("edos", 256, 4, 32): 2e-2}
 
 
-# typical element error of a gradient tensor, relative to the tensor maximum (provisional bounds; see the printed values)
-GRAD_TOL_P99 = {"phonon": 1e-4, "edos": 1e-3}
-GRAD_TOL_MEDIAN = {"phonon": 2e-5, "edos": 2e-4}
+# typical element error of a gradient tensor, relative to the tensor maximum: ~3-4 x the largest values observed on MI355X
+# over the seven cases (99th percentile 3.1e-4 - embeddings.weight, phonon H128 B64: one gate flip moves a whole 128-wide row
+# of a 51-row tensor -, median 2.2e-5); a uniform 1e-3 error of the kernels fails the median bound by a factor of ten
+GRAD_TOL_P99 = {"phonon": 1e-3, "edos": 1e-3}
+GRAD_TOL_MEDIAN = {"phonon": 1e-4, "edos": 1e-4}
 
 
 @pytest.mark.parametrize("kind,H,T,B", [("phonon", 64, 1, 8), ("phonon", 128, 2, 16), ("edos", 64, 2, 6),
