@@ -50,7 +50,7 @@ class Gemm(C.Structure):
         ("epi_gamma", C.c_void_p), ("epi_beta", C.c_void_p), ("epi_alpha", C.c_void_p),
         ("partials", C.c_void_p), ("partial_ld", C.c_int32),
         ("seg_tile", C.c_void_p), ("seg_ntiles", C.c_int32), ("seg_rowptr", C.c_void_p), ("seg_scale", C.c_void_p),
-        ("seg_agg", C.c_void_p), ("res_col0", C.c_int32),
+        ("seg_agg", C.c_void_p), ("seg_part", C.c_void_p), ("seg_cnt", C.c_void_p), ("res_col0", C.c_int32),
     ]
 
 
@@ -161,7 +161,7 @@ class Collate(C.Structure):
                                           "glob", "system", "src", "dst", "perm_src", "rowptr_dst", "rowptr_src", "graph_ptr",
                                           "node_graph", "dense_row", "inv_deg", "node_row", "edge_row")] + \
                [("T", C.c_int32), ("tile_rows", C.c_int32)] + \
-               [(k, C.c_void_p) for k in ("out_tile_ptr", "tile_off_all", "tile_e_all", "tile_n_all", "seg_tile")]
+               [(k, C.c_void_p) for k in ("out_tile_ptr", "tile_off_all", "tile_e_all", "tile_n_all", "seg_tile", "tile_p_all")]
 
 
 class Call(C.Structure):

@@ -49,10 +49,12 @@ class GraphMeta:
     node_graph: torch.Tensor   # [N] int32
     dense_row: torch.Tensor    # [N] int32: row of node n in the [Nmax*B] dense layout = pos*B + graph
     inv_deg: torch.Tensor      # [N] float32: 1/max(in-degree,1)  (scatter_mean divisor)
-    # [2, T+1] int32 or None: node-aligned row tiles of the message GEMM (DosxGemm EPI_SEGSUM): tile t owns the edges
+    # [3, T+1] int32 or None: node-aligned row tiles of the message GEMM (DosxGemm EPI_SEGSUM): tile t owns the edges
     # [seg_tile[0,t], seg_tile[0,t+1]) (<= SEG_TILE_ROWS) = the whole destination segments of the nodes
-    # [seg_tile[1,t], seg_tile[1,t+1]).  None: some node has more incoming edges than a tile holds, or the metadata came
-    # from a builder that does not produce tiles (the layers then run the stand-alone segment reduction).
+    # [seg_tile[1,t], seg_tile[1,t+1]); seg_tile[2,t] != 0 (= chunk << 16 | chunks): the tile's FIRST node, seg_tile[1,t],
+    # has more incoming edges than a tile holds and this tile owns chunk `chunk` of its `chunks` row chunks (all but the last
+    # are full tiles with no other node; the last one goes on with whole nodes) - see seg_tiles_host.  None: the metadata
+    # came from a builder that does not produce tiles (the layers then run the stand-alone segment reduction).
     seg_tile: Optional[torch.Tensor] = None
 
     def to(self, device) -> "GraphMeta":
@@ -66,26 +68,56 @@ SEG_TILE_ROWS = 48            # rows of a node-aligned tile = BMR of gemm_kernel
 
 
 def seg_tile_bound(n_pad: int, e_pad: int, num_graphs: int) -> int:
-    """Number of tile slots T of a shape bucket (the message GEMM's grid): any two consecutive greedy tiles hold more than
-    SEG_TILE_ROWS rows together, crystal-aligned tilings add at most one tile per crystal, + the ghost / node-only tiles."""
-    return (2 * e_pad + SEG_TILE_ROWS - 1) // SEG_TILE_ROWS + num_graphs + 2
+    """Number of tile slots T of a shape bucket (the message GEMM's grid): any two consecutive greedy tiles of a crystal hold
+    more than SEG_TILE_ROWS rows together (except a leading tile of isolated nodes in front of an over-full one),
+    crystal-aligned tilings add at most one tile per crystal, + the ghost / node-only tiles."""
+    return (2 * e_pad + SEG_TILE_ROWS - 1) // SEG_TILE_ROWS + 2 * num_graphs + 2
 
 
-def seg_tiles_host(rowptr: np.ndarray, rows: int = SEG_TILE_ROWS) -> Optional[np.ndarray]:
-    """Greedy node-aligned tiling of destination-sorted edges: [2, T+1] boundaries (edges, nodes), or None if a node has
-    more than ``rows`` incoming edges."""
+def seg_tiles_host(rowptr: np.ndarray, rows: int = SEG_TILE_ROWS) -> np.ndarray:
+    """Greedy node-aligned tiling of destination-sorted edges: [3, T+1] = edge boundaries, node boundaries, chunk info.
+
+    A node with MORE than ``rows`` incoming edges (periodic neighbour lists at r_max = 4 A produce them, `utils.py:267`)
+    closes the running tile and is cut into chunks of ``rows`` edges from the start of its segment: every full chunk is a
+    tile of its own that lists no whole node (node boundaries k, k), the remainder (if any) opens a tile that goes on
+    greedily with the following whole nodes.  Row 2 marks those tiles: ``chunk << 16 | chunks`` says that the tile's first
+    node is that node and which of its chunks the tile holds; the message GEMM then adds the chunk sums of a node in chunk
+    order (csrc/gemm.hip, EPI_SEGSUM), so a node's aggregate does not depend on what else shares the batch.  Any two
+    consecutive tiles still hold more than ``rows`` rows together (seg_tile_bound)."""
     n = int(rowptr.shape[0]) - 1
-    if n > 0 and int(np.max(rowptr[1:] - rowptr[:-1])) > rows:
-        return None
-    eb, nb, k = [0], [0], 0
+    eb, nb, pi, k = [0], [0], [], 0
     while k < n:
-        lim = rowptr[k] + rows
-        j = int(np.searchsorted(rowptr, lim, side="right")) - 1          # largest j with rowptr[j] <= rowptr[k] + rows
+        deg = int(rowptr[k + 1] - rowptr[k])
+        if deg > rows:
+            nfull, r = divmod(deg, rows)
+            nc = nfull + (1 if r else 0)
+            if nc >= (1 << 16):
+                raise ValueError(f"node {k} has {deg} incoming edges: more than {rows} * 65535")
+            for i in range(nfull):
+                pi.append((i << 16) | nc)
+                eb.append(int(rowptr[k]) + (i + 1) * rows)
+                nb.append(k + 1 if i == nc - 1 else k)
+            if not r:
+                k += 1
+                continue
+            lim = int(rowptr[k]) + nfull * rows + rows      # the remainder's tile goes on with whole nodes
+            info = (nfull << 16) | nc
+        else:
+            lim = int(rowptr[k]) + rows
+            info = 0
+        j = int(np.searchsorted(rowptr, lim, side="right")) - 1          # largest j with rowptr[j] <= lim
         j = min(max(j, k + 1), n)
+        if info == 0 and int(rowptr[j]) == eb[-1] and pi and pi[-1] != 0:
+            # only isolated nodes (no rows) in front of the next over-full node, right behind the full last chunk of the
+            # previous one: that tile takes them as whole nodes (a tile without rows would break seg_tile_bound's pairing)
+            nb[-1] = j
+            k = j
+            continue
+        pi.append(info)
         eb.append(int(rowptr[j]))
         nb.append(j)
         k = j
-    return np.stack([np.asarray(eb, np.int32), np.asarray(nb, np.int32)])
+    return np.stack([np.asarray(eb, np.int32), np.asarray(nb, np.int32), np.asarray(pi + [0], np.int32)])
 
 
 def _build_meta_host(edge_index: np.ndarray, batch: np.ndarray, num_graphs: int,
@@ -124,7 +156,7 @@ def _build_meta_host(edge_index: np.ndarray, batch: np.ndarray, num_graphs: int,
         rowptr_dst=i32(rowptr_dst), perm_src=i32(perm_src), rowptr_src=i32(rowptr_src),
         graph_ptr=i32(graph_ptr), node_graph=i32(batch), dense_row=i32(dense_row),
         inv_deg=torch.from_numpy((1.0 / np.maximum(deg_in, 1)).astype(np.float32)),
-        seg_tile=(lambda t: None if t is None else torch.from_numpy(t))(seg_tiles_host(rowptr_dst)),
+        seg_tile=torch.from_numpy(seg_tiles_host(rowptr_dst)),
     )
 
 
@@ -377,7 +409,7 @@ def bucket_sizes(num_nodes: int, num_edges: int, node_step: int = 8, edge_step: 
 
 
 def pad_seg_tiles(t: Optional[torch.Tensor], N: int, E: int, n_pad: int, e_pad: int, B: int) -> Optional[torch.Tensor]:
-    """Tile table of a ghost-padded batch, [2, T+1] with T = seg_tile_bound(...) slots: the real tiles, then the ghost edges
+    """Tile table of a ghost-padded batch, [3, T+1] with T = seg_tile_bound(...) slots: the real tiles, then the ghost edges
     in SEG_TILE_ROWS-row tiles (the first of them also owns every ghost node - their aggregate is a finite don't-care),
     then empty slots.  Mirrors what dosx_collate_padded writes on the device."""
     if t is None:
@@ -390,7 +422,7 @@ def pad_seg_tiles(t: Optional[torch.Tensor], N: int, E: int, n_pad: int, e_pad: 
     k = torch.arange(T + 1 - real, dtype=torch.int64, device=t.device)
     eb = torch.clamp(E + k * SEG_TILE_ROWS, max=e_pad)
     nb = torch.where(k == 0, torch.full_like(k, N), torch.full_like(k, n_pad))
-    tail = torch.stack([eb, nb]).to(torch.int32)
+    tail = torch.stack([eb, nb, torch.zeros_like(k)]).to(torch.int32)
     return torch.cat([t[:, :real], tail], 1).contiguous()
 
 

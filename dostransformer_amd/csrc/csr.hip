@@ -296,11 +296,12 @@ __global__ void collate_pad_tiles_kernel(const DosxCollate d) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t > d.T) return;
   const int real = d.out_tile_ptr[d.B];
-  int eb, nb;
+  int eb, nb, pi = 0;
   if (t < real) {
     const int b = seg_of(d.out_tile_ptr, d.B, t), c = d.sel[b], l = t - d.out_tile_ptr[b];
     eb = d.out_edge_ptr[b] + d.tile_e_all[d.tile_off_all[c] + l];
     nb = d.out_node_ptr[b] + d.tile_n_all[d.tile_off_all[c] + l];
+    pi = d.tile_p_all[d.tile_off_all[c] + l];
   } else {
     const int k = t - real;
     eb = min(d.E + k * d.tile_rows, d.E_pad);
@@ -308,6 +309,7 @@ __global__ void collate_pad_tiles_kernel(const DosxCollate d) {
   }
   d.seg_tile[t] = eb;
   d.seg_tile[d.T + 1 + t] = nb;
+  d.seg_tile[2 * (d.T + 1) + t] = pi;
 }
 
 // feature rows: x [N_pad,Fa], edge features [E_pad,Fe], per-crystal targets [B,S] / globals [B,n_glob] / system [B]
@@ -356,7 +358,7 @@ extern "C" int dosx_collate_padded(const DosxCollate* dp, dosx_stream_t stream) 
   hipLaunchKernelGGL(collate_pad_nodes_kernel, dim3(ceil_div(d.N_pad + 1, 256)), dim3(256), 0, s, d);
   if (d.E_pad > 0) hipLaunchKernelGGL(collate_pad_edges_kernel, dim3(ceil_div(d.E_pad, 256)), dim3(256), 0, s, d);
   if (d.seg_tile) {
-    DOSX_CHECK_ARG(d.T > 0 && d.tile_rows > 0 && d.out_tile_ptr && d.tile_off_all && d.tile_e_all && d.tile_n_all,
+    DOSX_CHECK_ARG(d.T > 0 && d.tile_rows > 0 && d.out_tile_ptr && d.tile_off_all && d.tile_e_all && d.tile_n_all && d.tile_p_all,
                    "dosx_collate_padded: seg_tile needs T, tile_rows and the per-crystal tile tables");
     hipLaunchKernelGGL(collate_pad_tiles_kernel, dim3(ceil_div(d.T + 1, 256)), dim3(256), 0, s, d);
   }

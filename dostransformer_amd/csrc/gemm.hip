@@ -950,7 +950,46 @@ void gemm_kernel(const GemmLaunch L) {
     // DOSTransformer_phonon.py:209 / DOSTransformer.py:187), one wave per node, rows in order (the summation order of the
     // stand-alone segment_reduce kernel's row loop, so the tiling never changes a bit).  Rows of a node outside this tile
     // can only be ghost rows of the first padding node: clipped.
-    for (int n = nlo_ + wave; n < nhi_; n += 8) {
+    // An OVER-FULL node (more than BMR incoming edges) is cut into chunks of BMR rows, one tile each (batch.seg_tiles_host):
+    // chunk info != 0 says this tile's first node, nlo_, is such a node and which chunk this is.  Its rows here (clipped
+    // to the tile) give a chunk sum, published write-through to seg_part[tile]; a ticket on the counter of the node's FIRST
+    // tile tells the last arriving tile, which adds the chunk sums in chunk order (a fixed order: deterministic) and writes
+    // the aggregate.  One wave does all of it, so the hand-off needs no workgroup barrier.  Whole nodes follow from nlo_ + 1.
+    const int pinfo = g.seg_tile[2 * (g.seg_ntiles + 1) + bx];
+    const int nfirst = pinfo ? nlo_ + 1 : nlo_;
+    if (pinfo && wave == 7 && g.seg_part != nullptr) {
+      const int n = nlo_, ci = pinfo >> 16, nc = pinfo & 0xffff, t0 = bx - ci;
+      const int re = min(g.seg_rowptr[n + 1], M) - m0;                  // (rows 0 .. re of the tile: the chunk starts the tile)
+      const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)g.seg_part, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+      for (int j = 0; j < CG; ++j) {
+        if (!on[j]) continue;
+        float4 t = f4zero();
+        for (int r = 0; r < re; ++r) t = f4add(t, f4add(ld4(&Cs[r * LDC + lane * 4 + 256 * j]), biasv[j]));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i32, t), rP, (uint32_t)(((size_t)bx * N + gcol[j]) * 4), 0, 16);   // sc1
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      int tk = 0;
+      if (lane == 0) tk = __hip_atomic_fetch_add(g.seg_cnt + t0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tk = __builtin_amdgcn_readfirstlane(tk);
+      if (tk == nc - 1) {                                                 // every chunk of the node has been published
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float sc = g.seg_scale ? g.seg_scale[n] : 1.f;
+#pragma unroll
+        for (int j = 0; j < CG; ++j) {
+          if (!on[j]) continue;
+          float4 t = f4zero();
+          for (int c = 0; c < nc; ++c) {
+            const float4 p = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                rP, (uint32_t)(((size_t)(t0 + c) * N + gcol[j]) * 4), 0, 16));                            // sc1
+            t = c == 0 ? p : f4add(t, p);
+          }
+          st4(g.seg_agg + (size_t)n * N + gcol[j], make_float4(t.x * sc, t.y * sc, t.z * sc, t.w * sc));
+        }
+        if (lane == 0) __hip_atomic_store(g.seg_cnt + t0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    for (int n = nfirst + wave; n < nhi_; n += 8) {
       const int rb = max(g.seg_rowptr[n], m0) - m0, re = min(g.seg_rowptr[n + 1], M) - m0;
       const float sc = g.seg_scale ? g.seg_scale[n] : 1.f;
 #pragma unroll

@@ -31,7 +31,7 @@ class DeviceDataset:
         self.node_ptr = np.concatenate([[0], np.cumsum(n_nodes)]).astype(np.int64)
         self.edge_ptr = np.concatenate([[0], np.cumsum(n_edges)]).astype(np.int64)
         srcs, dsts, perms, rpd, rps, invd, edge_feats = [], [], [], [], [], [], {k: [] for k in _EDGE_FIELDS}
-        tiles_e, tiles_n, tile_cnt = [], [], []            # per-crystal node-aligned row tiles (message GEMM, EPI_SEGSUM)
+        tiles_e, tiles_n, tiles_p, tile_cnt = [], [], [], []     # per-crystal node-aligned row tiles (message GEMM, EPI_SEGSUM)
         for c in crystals:
             ei = c["edge_index"].numpy().astype(np.int64)
             n = int(c["x"].shape[0])
@@ -42,12 +42,8 @@ class DeviceDataset:
             srcs.append(s); dsts.append(d)
             perms.append(np.argsort(s, kind="stable"))
             rpd.append(np.concatenate([[0], np.cumsum(deg_in)]))
-            if tiles_e is not None:
-                tl = seg_tiles_host(rpd[-1])
-                if tl is None:                               # a node with more incoming edges than a tile holds
-                    tiles_e = tiles_n = None
-                else:
-                    tiles_e.append(tl[0][:-1]); tiles_n.append(tl[1][:-1]); tile_cnt.append(tl.shape[1] - 1)
+            tl = seg_tiles_host(rpd[-1])
+            tiles_e.append(tl[0][:-1]); tiles_n.append(tl[1][:-1]); tiles_p.append(tl[2][:-1]); tile_cnt.append(tl.shape[1] - 1)
             rps.append(np.concatenate([[0], np.cumsum(deg_out)]))
             invd.append((1.0 / np.maximum(deg_in, 1)).astype(np.float32))
             for k in _EDGE_FIELDS:
@@ -57,11 +53,10 @@ class DeviceDataset:
         self._src, self._dst, self._perm = i32(srcs), i32(dsts), i32(perms)
         self._rpd, self._rps = i32(rpd), i32(rps)
         self._invd = torch.from_numpy(np.concatenate(invd)).to(self.device)
-        self.tile_cnt = None
-        if tiles_e is not None:
-            self.tile_cnt = np.asarray(tile_cnt, np.int64)
-            self._tile_e, self._tile_n = i32(tiles_e), i32(tiles_n)
-            self._tile_off = torch.from_numpy(np.concatenate([[0], np.cumsum(self.tile_cnt)]).astype(np.int32)).to(self.device)
+        self.tile_cnt = np.asarray(tile_cnt, np.int64)
+        self._tiles_host = (tiles_e, tiles_n, tiles_p)            # (collate() assembles a batch's table on the host)
+        self._tile_e, self._tile_n, self._tile_p = i32(tiles_e), i32(tiles_n), i32(tiles_p)
+        self._tile_off = torch.from_numpy(np.concatenate([[0], np.cumsum(self.tile_cnt)]).astype(np.int32)).to(self.device)
         self._node_ptr = torch.from_numpy(self.node_ptr.astype(np.int32)).to(self.device)
         self._edge_ptr = torch.from_numpy(self.edge_ptr.astype(np.int32)).to(self.device)
         f = lambda t: (t.to(dtype) if dtype is not None and t.is_floating_point() else t).to(self.device)
@@ -115,7 +110,13 @@ class DeviceDataset:
             fields[k] = g if k in ("phdos", "system") else g.reshape(-1)
         if self.mp_id is not None:
             fields["mp_id"] = [self.mp_id[i] for i in idx]
-        meta = GraphMeta(num_nodes=N, num_edges=E, num_graphs=B, n_max=int(n_max), edge_perm=None, graph_ptr=onp, **m)
+        # the message GEMM's tile table: the selected crystals' tables with the batch offsets added - the table
+        # dosx_collate_padded builds for step_dataset(), so that step(collate(...)) takes the same kernels and buckets
+        te, tn, tp = self._tiles_host
+        seg = np.concatenate([np.stack([te[c] + out_ep[b], tn[c] + out_np[b], tp[c]]) for b, c in enumerate(idx)] +
+                             [np.array([[E], [N], [0]], np.int32)], 1).astype(np.int32)
+        meta = GraphMeta(num_nodes=N, num_edges=E, num_graphs=B, n_max=int(n_max), edge_perm=None, graph_ptr=onp,
+                         seg_tile=torch.from_numpy(np.ascontiguousarray(seg)).to(dev, non_blocking=True), **m)
         return CrystalBatch(fields, B, meta)
 
     # ---- collate straight into a shape bucket's static buffers (train.Trainer.step_dataset) -------------------------
@@ -160,8 +161,6 @@ class DeviceDataset:
         parts = [idx.astype(np.int32), out_np, out_ep]
         tiled = m.seg_tile is not None
         if tiled:
-            if self.tile_cnt is None:
-                raise ValueError("this bucket was set up for tiled message GEMMs but the dataset has no tile tables")
             parts.append(np.concatenate([[0], np.cumsum(self.tile_cnt[idx])]).astype(np.int32))
         host = torch.from_numpy(np.concatenate(parts))
         small[:host.numel()].copy_(host, non_blocking=True)
@@ -189,6 +188,7 @@ class DeviceDataset:
                 raise ValueError("tile table of the bucket is too small for this batch")
             d.out_tile_ptr = base + 4 * (3 * B + 2)
             d.tile_off_all, d.tile_e_all, d.tile_n_all = self._tile_off.data_ptr(), self._tile_e.data_ptr(), self._tile_n.data_ptr()
+            d.tile_p_all = self._tile_p.data_ptr()
             d.seg_tile = m.seg_tile.data_ptr()
         ops._call("dosx_collate_padded", C.byref(d), ops._stream(),
                   w=lambda: ("collate_padded", "collate_pad", "hbm", 8.0 * (d.N_pad * d.Fa + d.E_pad * d.Fe)))

@@ -323,9 +323,13 @@ def gemm(M: int, N: int, segs: Sequence[Seg], w: torch.Tensor, out: torch.Tensor
     g.epi_gamma, g.epi_beta, g.epi_alpha = _p(epi_gamma), _p(epi_beta), _p(epi_alpha)
     g.partials, g.partial_ld = _p(partials), int(partial_ld)
     g.res_col0 = int(res_col0)
-    if seg_tile is not None:            # EPI_SEGSUM: [2, T+1] node-aligned tile table
+    if seg_tile is not None:            # EPI_SEGSUM: [3, T+1] node-aligned tile table
+        assert seg_tile.dim() == 2 and seg_tile.shape[0] == 3 and seg_tile.is_contiguous()
         g.seg_tile, g.seg_ntiles = seg_tile.data_ptr(), int(seg_tile.shape[1]) - 1
         g.seg_rowptr, g.seg_scale, g.seg_agg = _p(seg_rowptr), _p(seg_scale), _p(seg_agg)
+        # chunk sums of over-full nodes (in-degree > 48) + their arrival counters: always there, a table may hold such tiles
+        part = alloc(w.device, g.seg_ntiles, g.N)
+        g.seg_part, g.seg_cnt = part.data_ptr(), COUNTERS.take(w.device, g.seg_ntiles)
     _call("dosx_gemm", C.byref(g), _stream(), w=lambda: _gemm_work(g))
 
 

@@ -71,7 +71,7 @@ class _Slot:
                          src=i32(e_pad), dst=i32(e_pad), rowptr_dst=i32(n_pad + 1), perm_src=i32(e_pad),
                          rowptr_src=i32(n_pad + 1), graph_ptr=i32(B + 1), node_graph=i32(n_pad), dense_row=i32(n_pad),
                          inv_deg=f32(n_pad),
-                         seg_tile=i32(2, seg_tile_bound(n_pad, e_pad, B) + 1) if tiled else None)
+                         seg_tile=i32(3, seg_tile_bound(n_pad, e_pad, B) + 1) if tiled else None)
         self = cls.__new__(cls)
         self.fields = [k for k in f if k not in ("edge_index", "batch")]
         self.g = CrystalBatch(f, B, meta)
@@ -422,7 +422,7 @@ class Trainer:
         # (no collective, no host read: ranks of a data-parallel job draw equally sized shards from their datasets; a caller
         #  with ragged shards passes n_global)
         ng = int(n_global) if n_global is not None else B * (self.dist.world if self.dist is not None else 1)
-        tiled = ds.tile_cnt is not None
+        tiled = True
         key = (n_pad, e_pad, B, n_max, ng, tiled)
         slot = self._lookup(key)
         fresh = slot is None

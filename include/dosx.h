@@ -106,11 +106,17 @@ typedef struct DosxGemm {
   float* partials;    /* per-workgroup partial sums: row wg = [dgamma(N) | dbeta(N) | dalpha] */
   int32_t partial_ld;
   /* EPI_SEGSUM only */
-  const int32_t* seg_tile;   /* [2][seg_ntiles + 1]: row (edge) boundaries, then node boundaries, of the node-aligned tiles */
+  const int32_t* seg_tile;   /* [3][seg_ntiles + 1]: row (edge) boundaries, node boundaries, chunk info of the node-aligned tiles.
+                                chunk info != 0 (= chunk << 16 | chunks): the tile's first node has more than 48 incoming edges
+                                and the tile owns that chunk of its rows (all but the last chunk are full tiles without
+                                other nodes); the chunk sums of a node are published to seg_part and added in chunk order by
+                                the last arriving tile (ticket on seg_cnt) - deterministic, no second launch */
   int32_t seg_ntiles;
   const int32_t* seg_rowptr; /* [nodes + 1] CSR by destination */
   const float* seg_scale;    /* [nodes] 1/max(in-degree,1) for scatter_mean, NULL for scatter_sum */
   float* seg_agg;            /* [nodes, N] */
+  float* seg_part;           /* [seg_ntiles, N] scratch for the chunk sums of over-full nodes (may be NULL if no tile has chunk info) */
+  int32_t* seg_cnt;          /* [seg_ntiles] arrival counters, zero before the launch, zero again after it (like DosxWgrad.counters) */
   int32_t res_col0;   /* EPI_BIAS_ACT: the residual is added to the output columns [res_col0, N) only, res column c
                          to output column res_col0 + c (0 = all columns).  The backward of the edge residual
                          e += e' (DOSTransformer_phonon.py:84) rides on the e-block of the [E,3H] concat gradient. */
@@ -520,16 +526,17 @@ typedef struct DosxCollate {
   float* inv_deg;
   int32_t* node_row;
   int32_t* edge_row;
-  /* optional: node-aligned row tiles of the message GEMM (DosxGemm EPI_SEGSUM), seg_tile [2][T+1] (NULL = skip).  Crystal c
-   * owns the tiles [tile_off_all[c], tile_off_all[c+1]) of tile_e_all / tile_n_all (crystal-local START edge / node of each
-   * tile); out_tile_ptr [B+1] = prefix sums of the selected crystals' tile counts; ghost edges follow in tile_rows-row
-   * tiles, the first of which owns every ghost node; the remaining slots are empty. */
+  /* optional: node-aligned row tiles of the message GEMM (DosxGemm EPI_SEGSUM), seg_tile [3][T+1] (NULL = skip).  Crystal c
+   * owns the tiles [tile_off_all[c], tile_off_all[c+1]) of tile_e_all / tile_n_all / tile_p_all (crystal-local START edge /
+   * node and the chunk info of each tile); out_tile_ptr [B+1] = prefix sums of the selected crystals' tile counts; ghost
+   * edges follow in tile_rows-row tiles, the first of which owns every ghost node; the remaining slots are empty. */
   int32_t T, tile_rows;
   const int32_t* out_tile_ptr;
   const int32_t* tile_off_all;
   const int32_t* tile_e_all;
   const int32_t* tile_n_all;
   int32_t* seg_tile;
+  const int32_t* tile_p_all;
 } DosxCollate;
 int dosx_collate_padded(const DosxCollate* d, dosx_stream_t stream);
 

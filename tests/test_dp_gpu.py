@@ -197,3 +197,96 @@ def test_eight_rank_full_size_configs_match_single_process(eight_rank_full_run, 
     print(f"8-rank {kind}: worst per-tensor gradient error {worst_t[0]:.3e} at {worst_t[1]}")
     assert worst_t[0] <= 1e-3, worst_t
     assert not bad, bad
+
+
+class _DelayedComm:
+    """Stand-in for the RCCL collective of a 2-rank job on a 1-GPU box, with NCCL's stream semantics: the collective runs on
+    a stream of the communicator, ordered after the work already queued on the caller's stream; `async_op=True` returns a
+    handle whose `wait()` makes the then-current stream wait for it.  STRICTER than NCCL in one respect: every collective
+    gets a stream of its own, so a later (synchronous) collective does not order the caller behind an earlier asynchronous
+    one by accident - only the handle's wait() does.  The "sum over ranks" adds a second rank with identical data (x2),
+    `delay` GPU cycles late."""
+
+    def __init__(self, real, delay):
+        self.real, self.delay, self.streams, self.calls = real, int(delay), [], 0
+
+    def __call__(self, t, op=None, group=None, async_op=False):
+        if not t.is_cuda:
+            return self.real(t, op=op, group=group, async_op=async_op)
+        self.calls += 1
+        comm = torch.cuda.Stream()
+        self.streams.append(comm)
+        comm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(comm):
+            if self.delay:
+                torch.cuda._sleep(self.delay)
+            t.mul_(2.0)
+
+        class Work:
+            def wait(self_w):
+                torch.cuda.current_stream().wait_stream(comm)
+                return True
+        w = Work()
+        if async_op:
+            return w
+        w.wait()
+        return None
+
+
+def test_optimizer_waits_for_a_late_early_bucket_allreduce_under_replay(monkeypatch):
+    """The NCCL branch of `DataParallel` (device buffers, `all_reduce(async_op=True)` for the early gradient bucket, started
+    on the weight-gradient stream underneath the GNN backward, `train.Trainer._mid_hook`) under REPLAY, with the collective
+    finishing ~40 ms late on the communicator's stream: `optimizer_step` must wait for it.  World size 1 (one GPU), the
+    collective replaced by a delayed x2 with NCCL's stream semantics.  Same parameters, bit for bit, with and without the
+    delay; and the negative control - the handle's wait() disabled - does NOT give them, i.e. the test can see a missing wait."""
+    import torch.distributed as td
+    from dostransformer_amd import dist as D
+    from dostransformer_amd import synth
+    from dostransformer_amd.batch import bucket_sizes, pad_batch
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    from dostransformer_amd.train import Trainer
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(_free_port()))
+    created = not td.is_initialized()
+    if created:
+        td.init_process_group("nccl", rank=0, world_size=1)
+    dev = "cuda:0"
+    try:
+        g = synth.phonon_batch(6, seed=21, dtype=torch.float32)
+        g = pad_batch(g, *bucket_sizes(g.meta.num_nodes, g.meta.num_edges)).to(dev)
+        real = td.all_reduce
+
+        def run(delay, steps, break_wait=False):
+            comm = _DelayedComm(real, delay)
+            monkeypatch.setattr(D.td, "all_reduce", comm)
+            torch.manual_seed(0)
+            model = DOSTransformer_phonon(3, 1, 118, 4, 32, dev, 0.0).to(dev)
+            dp = D.DataParallel()
+            assert not dp.staged                                   # the NCCL branch
+            if break_wait:
+                orig = dp.all_reduce_grads_async
+
+                def no_wait(flat):
+                    h = orig(flat)
+                    h.wait = lambda: True
+                    return h
+                dp.all_reduce_grads_async = no_wait
+            tr = Trainer(model, lr=1e-3, dist=dp, replay=True)
+            for _ in range(steps):
+                tr.step(g, 12)                                     # "two ranks" of 6 crystals
+            torch.cuda.synchronize()
+            monkeypatch.setattr(D.td, "all_reduce", real)
+            assert comm.calls >= 3 * steps                         # SSE pair, early bucket, GNN bucket per step
+            fp = model.flat_params()
+            assert 0 < fp.n_late < fp.total and tr._early_work is None
+            return {k: v.detach().cpu().clone() for k, v in model.state_dict().items() if v.is_floating_point()}
+
+        ref = run(0, 4)                        # step 0 records the plan (split around the collectives), steps 1-3 replay it
+        late = run(int(1e8), 4)
+        for k in ref:
+            assert torch.equal(ref[k], late[k]), k
+        one, broken = run(int(1e8), 1), run(int(1e8), 1, break_wait=True)
+        assert any(not torch.equal(one[k], broken[k]) for k in one), "negative control: a missing wait() went unnoticed"
+    finally:
+        if created:
+            td.destroy_process_group()

@@ -187,3 +187,163 @@ def test_sink_serialises_jobs_that_share_a_gradient():
     torch.cuda.synchronize()
     assert err(G["w"], dy1.double().T @ a1.double() + dy2.double().T @ a2.double()) < TOL
     assert err(G["b"], dy1.double().sum(0) + dy2.double().sum(0)) < TOL
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# nodes with more incoming edges than a message-GEMM tile holds (48): periodic neighbour lists at r_max = 4 A give them
+# (`utils.py:267`); scatter_mean / scatter_sum of `DOSTransformer_phonon.py:209` / `DOSTransformer.py:187` have no limit
+# ---------------------------------------------------------------------------------------------------------------------
+def _fatten(c, node, extra, seed):
+    """`extra` more edges into `node` of crystal dict c (sources uniform over the real atoms, fresh edge features)."""
+    g = torch.Generator().manual_seed(seed)
+    n_real = int(c["x"].shape[0]) - (1 if "edge_attr" in c else 0)           # eDOS: the last node is the phantom node
+    src = torch.randint(0, n_real, (extra,), generator=g)
+    ei = torch.cat([c["edge_index"], torch.stack([src, torch.full((extra,), node, dtype=torch.int64)])], 1)
+    out = dict(c)
+    out["edge_index"] = ei
+    if "edge_vec" in c:
+        v = (torch.rand(extra, 3, generator=g, dtype=torch.float64) * 2 - 1) * 2.3
+        out["edge_vec"] = torch.cat([c["edge_vec"], v.to(c["edge_vec"].dtype)], 0)
+    else:
+        d = torch.rand(extra, generator=g, dtype=torch.float64) * 7.0 + 1.0
+        mu = torch.arange(41, dtype=torch.float64) * 0.2
+        out["edge_attr"] = torch.cat([c["edge_attr"], torch.exp(-((d[:, None] - mu[None, :]) ** 2) / 0.04).to(c["edge_attr"].dtype)], 0)
+    return out
+
+
+def _fat_crystals(kind, B, seed, dtype):
+    from dostransformer_amd import synth
+    cs = synth.phonon_crystals(B, seed, dtype) if kind == "phonon" else synth.edos_crystals(B, seed, dtype)
+    cs[0] = _fatten(cs[0], 0, 45, 1)            # in-degree ~ 60: one full chunk + a remainder that shares its tile
+    cs[1] = _fatten(cs[1], 1, 185, 2)           # ~ 200: four full chunks + remainder
+    cs[2] = _fatten(_fatten(cs[2], 0, 96 - int((cs[2]["edge_index"][1] == 0).sum()), 3), 1, 70, 4)   # exactly 96 (two full chunks,
+    return cs                                   # no remainder) next to another over-full node
+
+
+@pytest.mark.parametrize("H,mean", [(128, True), (64, False), (256, False)])
+def test_message_gemm_segment_sum_with_overfull_nodes(H, mean):
+    """DosxGemm EPI_SEGSUM on a batch with 60-, 96- and 200-in-degree nodes (chunk tiles + in-launch combination of the
+    chunk sums) == the same GEMM followed by the stand-alone dosx_segment_reduce, to rounding (the chunked order of the
+    adds differs from the sequential one for those nodes); ghost-padded too; twice in a row (counters back at zero)."""
+    from dostransformer_amd import functional as Fn, ops
+    from dostransformer_amd.batch import bucket_sizes, collate, pad_batch
+    g = collate(_fat_crystals("phonon", 6, 5, torch.float32))
+    deg = torch.bincount(g.edge_index[1], minlength=g.x.shape[0])
+    assert int(deg.max()) >= 200 and int((deg > 48).sum()) >= 4 and int((deg == 96).sum()) >= 1
+    for padded in (False, True):
+        b = pad_batch(g, *bucket_sizes(g.meta.num_nodes, g.meta.num_edges, 16, 256)) if padded else g
+        assert b.meta.seg_tile is not None and int((b.meta.seg_tile[2] != 0).sum()) >= 9
+        m = b.meta.to(DEV)
+        N, E = m.num_nodes, m.num_edges
+        gen = torch.Generator().manual_seed(1)
+        P = {"k.0.weight": torch.randn(2 * H, 3 * H, generator=gen) * 0.1, "k.0.bias": torch.randn(2 * H, generator=gen),
+             "k.1.weight": torch.randn(2 * H, generator=gen), "k.1.bias": torch.randn(2 * H, generator=gen),
+             "k.2.weight": torch.tensor([0.25]), "k.3.weight": torch.randn(H, 2 * H, generator=gen) * 0.1,
+             "k.3.bias": torch.randn(H, generator=gen)}
+        P = {k: v.to(DEV) for k, v in P.items()}
+        x = torch.randn(N, H, generator=gen).to(DEV)
+        e = torch.randn(E, H, generator=gen).to(DEV)
+        a = Fn.SegList([ops.seg(x, rmap=ops.rowmap(idx=m.src)), ops.seg(x, rmap=ops.rowmap(idx=m.dst)), ops.seg(e)], [x, e])
+        scale = m.inv_deg if mean else None
+        msg, _ = Fn.mlp_ln_fwd(P, "k", a, E, H)
+        agg0, e0 = torch.empty(N, H, device=DEV), torch.empty(E, H, device=DEV)
+        ops.segment_reduce(msg, m.rowptr_dst, scale, agg0, e, e0, N, E, H)
+        prev = None
+        for rep in range(2):
+            agg1 = torch.full((N, H), float("nan"), device=DEV)
+            e1 = torch.full((E, H), float("nan"), device=DEV)
+            Fn.mlp_ln_fwd(P, "k", a, E, H, segsum=(m.seg_tile, m.rowptr_dst, scale, agg1, e, e1))
+            torch.cuda.synchronize()
+            nr = getattr(b, "real_nodes", N)
+            assert bool(torch.isfinite(agg1).all())
+            assert float((agg1[:nr] - agg0[:nr]).abs().max()) <= 3e-6 * float(agg0[:nr].abs().max())
+            assert torch.equal(e1, e0)
+            if prev is not None:
+                assert torch.equal(agg1, prev)                         # deterministic, counters reset
+            prev = agg1
+
+
+@pytest.mark.parametrize("kind", ["phonon", "edos"])
+def test_models_with_overfull_nodes_match_the_oracle(kind):
+    """Full models (mean aggregation: phonon, sum: eDOS) on a batch with 60- / 96- / 200-in-degree nodes against the oracle:
+    outputs, loss, gradients; eager == replay bitwise; the crystal-aligned tile table of the device collate
+    (Trainer.step_dataset) gives bitwise the step on the host-collated batch (greedy table over the whole batch): an
+    over-full node is cut the same way whatever shares the batch."""
+    from oracle import dos_oracle as O
+    from dostransformer_amd.batch import collate
+    from dostransformer_amd.loader import DeviceDataset
+    from dostransformer_amd.train import Trainer
+    torch.manual_seed(0)
+    B = 6
+    if kind == "phonon":
+        from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+        mk = lambda: DOSTransformer_phonon(3, 1, 118, 4, 64, DEV, 0.0)
+        ref_dt, fwd = torch.float64, O.dostransformer_phonon_forward
+    else:
+        from dostransformer_amd.embedder_eDOS.DOSTransformer import DOSTransformer
+        mk = lambda: DOSTransformer(3, 1, 200, 41, 2, 64, DEV, 0.0)
+        ref_dt, fwd = torch.float32, O.dostransformer_forward
+    cs32 = _fat_crystals(kind, B, 9, torch.float32)
+    cs_ref = _fat_crystals(kind, B, 9, ref_dt)
+    g_ref, g = collate(cs_ref), collate(cs32)
+    assert int((g.meta.seg_tile[2] != 0).sum()) >= 9
+    model = mk()
+    params = {k: (v.detach().clone().to(ref_dt) if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    with torch.no_grad():
+        rg, rx, rs = fwd(params, g_ref, 3, 1)
+    tr = Trainer(model, lr=1e-3, beta=1.0)
+    loss = tr.forward_backward(g.to(DEV))
+    dg, xn, ds_ = tr.last_outputs
+    rmse = lambda a, b: float(torch.sqrt(((a.double().cpu() - b.double()) ** 2).mean()))
+    assert rmse(dg, rg) < 1e-4 and rmse(ds_, rs) < 1e-4 and rmse(xn, rx) < 1e-4 * max(1.0, float(rx.abs().max()))
+    ref_loss, grads = O.train_step(kind, params, {}, g_ref, 3, 1, lr=1e-3, beta=1.0)
+    assert abs(float(loss) - float(ref_loss)) < 2e-4
+    fp = model.flat_params()
+    for k, gr in grads.items():
+        if gr is not None:
+            e = float((fp.G[k].cpu().double() - gr.double()).abs().max() / (gr.abs().max() + 1e-6))
+            assert e < 3e-3, (k, e)
+    # eager, replay and device-collated replay: same trajectory, bit for bit
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    outs = []
+    dsd = DeviceDataset(cs32, DEV)
+    nmax = max(int(c["x"].shape[0]) for c in cs32)
+    for mode in ("eager", "replay", "dataset"):
+        m2 = mk()
+        m2.load_state_dict(sd0)
+        m2 = m2.to(DEV)
+        t2 = Trainer(m2, lr=1e-3, beta=1.0, replay=(mode != "eager"), bucket=(16, 256))
+        for _ in range(3):
+            if mode == "dataset":
+                t2.step_dataset(dsd, list(range(B)), n_max=nmax)
+            else:
+                t2.step(collate(cs32, n_max=nmax).to(DEV))
+        torch.cuda.synchronize()
+        outs.append({k: v.detach().cpu().clone() for k, v in m2.state_dict().items()})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), ("eager vs replay", k)
+        assert torch.equal(outs[1][k], outs[2][k]), ("host table vs crystal-aligned table", k)
+
+
+def test_shape_limits_are_explicit_errors():
+    """The two shape limits of the fused path fail LOUDLY, with the limit in the message, and leave the
+    library usable: more than 320 atoms in a crystal (LDS-resident softmax row), hidden > 256 (one-tile row epilogues)."""
+    from dostransformer_amd._lib import DosxError
+    from dostransformer_amd.layers import TransformerEncoder
+    enc = TransformerEncoder(embed_dim=32, num_heads=1, layers=1).to(DEV)
+    x = torch.randn(51, 2, 32, device=DEV)
+    kv = torch.randn(321, 2, 32, device=DEV)
+    with pytest.raises(DosxError, match="Nk=321"):
+        enc(x, kv, kv)
+    y = enc(x, kv[:320], kv[:320])                       # the limit itself works
+    assert bool(torch.isfinite(y).all())
+    from dostransformer_amd import synth
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    torch.manual_seed(0)
+    model = DOSTransformer_phonon(1, 1, 118, 4, 512, DEV, 0.0).to(DEV)
+    g = synth.phonon_batch(2, seed=1, dtype=torch.float32).to(DEV)
+    with pytest.raises(DosxError, match="hidden <= 256"):
+        model(g)
+    small = DOSTransformer_phonon(1, 1, 118, 4, 32, DEV, 0.0).to(DEV)
+    assert bool(torch.isfinite(small(g)[0]).all())
