@@ -309,6 +309,9 @@ def test_models_with_overfull_nodes_match_the_oracle(kind):
     outs = []
     dsd = DeviceDataset(cs32, DEV)
     nmax = max(int(c["x"].shape[0]) for c in cs32)
+    from dostransformer_amd.batch import bucket_sizes, pad_batch
+    gh = collate(cs32, n_max=nmax)
+    gp = pad_batch(gh, *bucket_sizes(gh.meta.num_nodes, gh.meta.num_edges, 16, 256)).to(DEV)   # (eager on the same padded batch)
     for mode in ("eager", "replay", "dataset"):
         m2 = mk()
         m2.load_state_dict(sd0)
@@ -317,6 +320,8 @@ def test_models_with_overfull_nodes_match_the_oracle(kind):
         for _ in range(3):
             if mode == "dataset":
                 t2.step_dataset(dsd, list(range(B)), n_max=nmax)
+            elif mode == "eager":
+                t2.step(gp)
             else:
                 t2.step(collate(cs32, n_max=nmax).to(DEV))
         torch.cuda.synchronize()
@@ -336,7 +341,8 @@ def test_shape_limits_are_explicit_errors():
     kv = torch.randn(321, 2, 32, device=DEV)
     with pytest.raises(DosxError, match="Nk=321"):
         enc(x, kv, kv)
-    y = enc(x, kv[:320], kv[:320])                       # the limit itself works
+    k320 = kv[:320].contiguous()
+    y = enc(x, k320, k320)                               # the limit itself works
     assert bool(torch.isfinite(y).all())
     from dostransformer_amd import synth
     from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
