@@ -81,7 +81,7 @@ class Attn(C.Structure):
         ("out", C.c_void_p), ("probs", C.c_void_p), ("qstats", C.c_void_p), ("out_stats", C.c_void_p),
         ("dout", C.c_void_p), ("dx", C.c_void_p), ("dscores", C.c_void_p), ("dkvhat", C.c_void_p),
         ("dkv_accumulate", C.c_int32),
-        ("partials_q", C.c_void_p), ("partials_kv", C.c_void_p), ("drop_mask", C.c_void_p), ("dkv_part", C.c_void_p),
+        ("partials_q", C.c_void_p), ("partials_kv", C.c_void_p), ("drop_mask", C.c_void_p), ("dkv_part", C.c_void_p), ("dkv_cnt", C.c_void_p),
     ]
 
 

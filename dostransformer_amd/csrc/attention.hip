@@ -345,6 +345,7 @@ __device__ __forceinline__ void store_scores1(const f32x16 (&acc)[MAX_KT], float
 
 template <int NJ, bool RESIDENT>
 __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const DosxAttn a) {
+  DOSX_SET_MAIN_PRIO();
   extern __shared__ __align__(16) float sm[];
   const Geo g = make_geo(a.H, a.Nk);
   StreamGeo sg;
@@ -583,8 +584,14 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const DosxAttn a) 
 // and applies the key-side chain rule.  That replaces attn_bwd_dkv_kernel for NKP <= 64 (cfg2: cross attention over
 // <= 12 atoms, self attention over 51 bins): that kernel re-streamed every dO / x row and the dS round trip through HBM
 // behind one barrier per 16 queries - 27 us per launch for 0.08 GF - where this costs 32-64 MFMAs per wave.
+constexpr int DKR = 16;          // key rows per reduction group = partial-sum rows per crystal: ceil(Nk / 16)
+template <bool SC1>
+__device__ __forceinline__ void dkv_reduce_group(const DosxAttn& a, const int nqt, const int grp, const int ngroups,
+                                                 const int bk, float (*Pp)[2 * 256], const int tid);
+
 template <int NJ, bool PKV, bool RESIDENT>
 __global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(const DosxAttn a) {
+  DOSX_SET_MAIN_PRIO();
   extern __shared__ __align__(16) float sm[];
   const Geo g = make_geo(a.H, a.Nk);
   StreamGeo sg;
@@ -862,6 +869,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(const DosxAttn 
       }
     }
     float* part = a.dkv_part + ((size_t)bq * gridDim.x + blockIdx.x) * (size_t)Nk * H;
+    const bool fused = a.dkv_cnt != nullptr;          // the last arriving workgroup of a key crystal finishes dK + dV itself
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
@@ -871,9 +879,37 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(const DosxAttn 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int j = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          if (j < Nk && col < H) part[(size_t)j * H + col] = dacc[kt][t][r] + dacc2[kt][t][r];
+          if (j < Nk && col < H) {
+            const float v = dacc[kt][t][r] + dacc2[kt][t][r];
+            if (fused) __hip_atomic_store(part + (size_t)j * H + col, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1
+            else part[(size_t)j * H + col] = v;
+          }
         }
       }
+    if (fused) {
+      // In-launch reduction of the partial key gradients (same protocol as DosxWgrad's finished mode: write-through
+      // publish, every wave drains, barrier, one ticket per workgroup on the key crystal's counter).  The workgroup that
+      // draws the last ticket of crystal bk - rep * tiles arrive - runs the reduction groups the stand-alone
+      // attn_dkv_reduce_kernel would run, in the same order with the same arithmetic: bitwise the two-launch result.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      int* flag = reinterpret_cast<int*>(sm);
+      const int arrivers = (a.Bq / a.Bk) * (int)gridDim.x;
+      if (tid == 0) *flag = __hip_atomic_fetch_add(a.dkv_cnt + bk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const bool last = *flag == arrivers - 1;
+      __syncthreads();                                  // (the flag word is about to be overwritten by the reduction's LDS rows)
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int ngroups = (Nk + DKR - 1) / DKR;
+        float (*PpR)[2 * 256] = reinterpret_cast<float (*)[2 * 256]>(sm);
+        for (int grp = 0; grp < ngroups; ++grp) {
+          dkv_reduce_group<true>(a, (int)gridDim.x, grp, ngroups, bk, PpR, tid);
+          __syncthreads();
+        }
+        if (tid == 0) __hip_atomic_store(a.dkv_cnt + bk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
 
 }
@@ -1133,13 +1169,15 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const DosxAttn a) {
 // One workgroup per (16 key rows, crystal), one quarter wave per key row, the partials of a row fetched 4 at a time.
 // (First version: one workgroup per crystal walking its rows 16 at a time - 7.3 us avg at cfg2, 67 us for the 37 MB of
 // partials of an eDOS cross-attention layer on 64 workgroups.)
-constexpr int DKR = 16;          // key rows per workgroup = partial-sum rows per crystal: ceil(Nk / 16)
-
-__global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(const DosxAttn a, int nqt) {
-  __shared__ float Pp[16][2 * 256];                 // per quarter-wave slot: [dgamma | dbeta] (H <= 256)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q16 = lane & 15, slot = wave * 4 + (lane >> 4);
-  const int bk = blockIdx.y, H = a.H, Nk = a.Nk, rep = a.Bq / a.Bk;
-  const int j = blockIdx.x * DKR + slot;
+// One group of DKR key rows of crystal bk, by 256 threads (tid256); Pp: [16][512] floats of LDS; ngroups = ceil(Nk / DKR).
+// SC1: the partials were published by OTHER workgroups of this launch (fused form: the last arriving dq workgroup of a
+// crystal runs this) - every load of them is then an sc1 load (bypasses this CU's L1).  Contains a barrier.
+template <bool SC1>
+__device__ __forceinline__ void dkv_reduce_group(const DosxAttn& a, const int nqt, const int grp, const int ngroups,
+                                                 const int bk, float (*Pp)[2 * 256], const int tid) {
+  const int lane = tid & 63, wave = tid >> 6, q16 = lane & 15, slot = wave * 4 + (lane >> 4);
+  const int H = a.H, Nk = a.Nk, rep = a.Bq / a.Bk;
+  const int j = grp * DKR + slot;
   const bool jv = j < Nk;
   const int jc = jv ? j : 0;
   const size_t krow = ((size_t)jc * a.Bk + bk) * H;
@@ -1154,16 +1192,20 @@ __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(const DosxAttn a, 
   }
   const int np = rep * nqt;                          // partials of this key row, in (i, tile) order
   const size_t pstride = (size_t)Nk * H;             // between consecutive tiles of one query batch entry
+  const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)a.dkv_part, 0, 0x7fffffff, 0x00020000);
   for (int p0 = 0; p0 < np; p0 += 4) {
     float4 v[4][KCB];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int pi = min(p0 + u, np - 1), i = pi / nqt, t = pi % nqt;
-      const float* p = a.dkv_part + ((size_t)(bk + i * a.Bk) * nqt + t) * pstride + (size_t)jc * H;
+      const size_t off = ((size_t)(bk + i * a.Bk) * nqt + t) * pstride + (size_t)jc * H;
 #pragma unroll
       for (int k = 0; k < KCB; ++k) {
         const int c = q16 * 4 + 64 * k;
-        v[u][k] = ld4(p + (c < H ? c : 0));
+        if constexpr (SC1)
+          v[u][k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rP, (uint32_t)((off + (c < H ? c : 0)) * 4), 0, 16));
+        else
+          v[u][k] = ld4(a.dkv_part + off + (c < H ? c : 0));
       }
     }
 #pragma unroll
@@ -1189,7 +1231,7 @@ __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(const DosxAttn a, 
     }
   }
   __syncthreads();
-  float* prow = a.partials_kv + ((size_t)bk * gridDim.x + blockIdx.x) * 2 * H;
+  float* prow = a.partials_kv + ((size_t)bk * ngroups + grp) * 2 * H;
   for (int c = tid; c < 2 * H; c += 256) {
     const int o = (c / H) * 256 + (c % H);
     float t = 0.f;
@@ -1197,6 +1239,11 @@ __global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(const DosxAttn a, 
     for (int sl = 0; sl < 16; ++sl) t += Pp[sl][o];
     prow[c] = t;
   }
+}
+
+__global__ __launch_bounds__(256) void attn_dkv_reduce_kernel(const DosxAttn a, int nqt) {
+  __shared__ float Pp[16][2 * 256];                 // per quarter-wave slot: [dgamma | dbeta] (H <= 256)
+  dkv_reduce_group<false>(a, nqt, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, Pp, (int)threadIdx.x);
 }
 
 size_t fwd_smem(const Geo& g, bool resident = false) {      // (resident: all key chunks at once + the four partial score tiles)
@@ -1275,7 +1322,13 @@ extern "C" int dosx_attention_bwd(const DosxAttn* ap, dosx_stream_t stream) {
   const int kg = a.Nk > 32 ? 2 : 1;
   const bool pkv = pkv_ok(a);
   const bool res = dq_resident(a.H, a.Nk, pkv);
-  const size_t s1 = dq_smem(g, pkv, res), s2 = dkv_smem(g, kg);
+  const bool fused = pkv && a.dkv_cnt != nullptr;     // dK + dV finished inside the dq launch by the last arriver of a crystal
+  DOSX_CHECK_ARG(!fused || !(a.flags & (DOSX_ATTN_BWD_SKIP_DQ | DOSX_ATTN_BWD_SKIP_DKV)),
+                 "dosx_attention_bwd: dkv_cnt (one-launch backward) excludes the SKIP_DQ / SKIP_DKV flags");
+  DOSX_CHECK_ARG(!fused || (size_t)a.Bq * ceil_div(a.Sq, QT) * a.Nk * a.H * 4 < 0x7fffffffull, "dosx_attention_bwd: dkv_part beyond 2 GiB");
+  size_t s1 = dq_smem(g, pkv, res);
+  const size_t s2 = dkv_smem(g, kg);
+  if (fused && s1 < sizeof(float) * 16 * 512 + 64) s1 = sizeof(float) * 16 * 512 + 64;
   DOSX_CHECK_ARG(s1 <= 160 * 1024 && s2 <= 160 * 1024, "dosx_attention_bwd: LDS need %zu/%zu > 160 KiB", s1, s2);
   static bool attr_set = false;
   if (!attr_set) {
@@ -1306,7 +1359,9 @@ extern "C" int dosx_attention_bwd(const DosxAttn* ap, dosx_stream_t stream) {
 #undef DOSX_DQS
     DOSX_LAUNCH_CHECK();
   }
-  if (!(a.flags & DOSX_ATTN_BWD_SKIP_DKV) && pkv) {
+  if (fused) {
+    // nothing else to launch
+  } else if (!(a.flags & DOSX_ATTN_BWD_SKIP_DKV) && pkv) {
     hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3(ceil_div(a.Nk, DKR), a.Bk), dim3(256), 0, to_stream(stream), a,
                        ceil_div(a.Sq, QT));
     DOSX_LAUNCH_CHECK();

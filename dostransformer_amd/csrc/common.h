@@ -11,6 +11,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define DOSX_WAVE 64
 
+// Wave priority of the kernels of the dgrad / forward chain (everything except the weight-gradient kernels, which keep the
+// default 0): where a chain kernel shares a SIMD with a weight-gradient workgroup, the instruction arbiter then issues the
+// chain's MFMAs first and the weight gradients fill the issue slots the chain leaves (barriers, load waits).
+#ifndef DOSX_MAIN_PRIO
+#define DOSX_MAIN_PRIO 0
+#endif
+#define DOSX_SET_MAIN_PRIO() do { if (DOSX_MAIN_PRIO) __builtin_amdgcn_s_setprio(DOSX_MAIN_PRIO); } while (0)
+
 void dosx_set_error(const char* fmt, ...);
 
 #define DOSX_CHECK_ARG(cond, ...)   \

@@ -37,6 +37,7 @@ constexpr int FBN = 128;         // columns per chunk / per column block
 // 32-column tile): twice the workgroups, half the MFMA time each, and two of them fit the LDS of one CU.
 template <bool HALF, int KB>
 __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
+  DOSX_SET_MAIN_PRIO();
   extern __shared__ __align__(16) float sm[];
   constexpr int FBK = KB, FLDW = KB + 4;           // chunk width, padded row of a staged weight chunk
   constexpr int R = HALF ? 16 : 32;                // rows per workgroup
@@ -323,6 +324,7 @@ constexpr int BLDW = FBN + 4;    // 132: padded rows of a k-major weight chunk
 
 template <bool HALF, int KB>
 __global__ __launch_bounds__(512) void ffn_bwd_kernel(const DosxFfnBwd a) {
+  DOSX_SET_MAIN_PRIO();
   extern __shared__ __align__(16) float sm[];
   constexpr int FBK = KB;
   constexpr int R = HALF ? 16 : 32;

@@ -182,6 +182,7 @@ __device__ __forceinline__ float4 a_finish(const AState& st, const ARaw& r, int 
 template <int RTP, int NTW, int WL, int PRO, int VEC, int EPI>
 __global__ __launch_bounds__(512, (NTW == 1 && (EPI == DOSX_EPI_BIAS_ACT || EPI == DOSX_EPI_LN || EPI == DOSX_EPI_RELU_MASK)) ? 4 : 2)
 void gemm_kernel(const GemmLaunch L) {
+  DOSX_SET_MAIN_PRIO();
   const DosxGemm& g = L.g;
   // RTP = 0: HALF tile.  The workgroup owns 16 rows and multiplies with the 16x16x4 MFMA (same flop rate, half the
   // rows per instruction): kernels with M of a few hundred rows get twice the workgroups, each with half the MFMA

@@ -129,6 +129,7 @@ __device__ __forceinline__ void wave_gemm_kn(f32x4 (&acc)[2], const float* w, in
 }
 
 __global__ __launch_bounds__(512) void mlp_ln_fwd_kernel(const DosxMlpLn a) {
+  DOSX_SET_MAIN_PRIO();
   extern __shared__ __align__(16) float sm[];
   const int K = a.K, NH = a.NH, NO = a.NO, M = a.M;
   const int LDX = K + 4, LDT = NH + 4, LDC = NO + 4;
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(512) void mlp_ln_fwd_kernel(const DosxMlpLn a) {
 //            dcat = dz . W1 ;  partials[wg] = [ sum dy'*xhat (NH) | sum dy' (NH) | pad | sum_{y<0} da*y ]
 // Both weight matrices are read as stored (k-major for these products: W2 [NO][NH], W1 [NH][K]).
 __global__ __launch_bounds__(512) void mlp_ln_bwd_kernel(const DosxMlpLnBwd a) {
+  DOSX_SET_MAIN_PRIO();
   extern __shared__ __align__(16) float sm[];
   const int K = a.K, NH = a.NH, NO = a.NO, M = a.M;
   const int LDY = NO + 4, LDT = NH + 4;

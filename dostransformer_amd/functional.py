@@ -303,6 +303,7 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
 
 
 _FUSED_FFN_BWD = __import__("os").environ.get("DOSX_FUSED_FFN_BWD", "1") == "1"
+_FUSED_DKV = __import__("os").environ.get("DOSX_FUSED_DKV", "1") == "1"          # one-launch attention backward (Nk <= 64)
 _FUSED_FIN_BWD = __import__("os").environ.get("DOSX_FUSED_FIN_BWD", "1") == "1"
 _FUSED_HEAD_FWD = __import__("os").environ.get("DOSX_FUSED_HEAD_FWD", "1") == "1"
 
@@ -403,19 +404,28 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: Optional[torch.Tensor],
             a.partials_kv = part.data_ptr() + 4 * Bq * nqt * 2 * H
             a.flags = flags
             return a
-        # dq (feeds the next layer's backward) on the main stream; dk+dv (feeds only the key-gradient
-        # consumers at the very end) on the side stream, in layer order so dkvhat accumulates in order
-        ops.attention_bwd(desc(8))          # DOSX_ATTN_BWD_SKIP_DKV
-        a2 = desc(4)                        # DOSX_ATTN_BWD_SKIP_DQ
-        if kv_needed_next and t == 0:
-            # the caller consumes dkvhat right after this call: the LAST key-gradient kernel runs on the main stream (behind
-            # a join that is already satisfied - the earlier layers' reductions finished long ago) instead of bouncing
-            # main -> side -> main through two cross-queue events
-            sink.join()
-            ops.attention_bwd(a2)
-            sink._keep.extend(t_ for t_ in (dsc, mask) if t_ is not None)
+        if small and _FUSED_DKV:
+            # ONE launch: every (query tile, crystal) workgroup publishes its share of dK + dV and the last one of a key
+            # crystal to arrive finishes that crystal's key gradient (include/dosx.h: DosxAttn.dkv_cnt) - no reduction
+            # launch, no side-stream round trip
+            a1 = desc(0)
+            a1.dkv_cnt = ops.COUNTERS.take(dev, Bk)
+            ops.attention_bwd(a1)
+            sink._keep.extend(t_ for t_ in (mask,) if t_ is not None)
         else:
-            sink.on_side(lambda a2=a2: ops.attention_bwd(a2), (dx1, dxin) + tuple(t_ for t_ in (dsc, mask) if t_ is not None))
+            # dq (feeds the next layer's backward) on the main stream; dk+dv (feeds only the key-gradient
+            # consumers at the very end) on the side stream, in layer order so dkvhat accumulates in order
+            ops.attention_bwd(desc(8))          # DOSX_ATTN_BWD_SKIP_DKV
+            a2 = desc(4)                        # DOSX_ATTN_BWD_SKIP_DQ
+            if kv_needed_next and t == 0:
+                # the caller consumes dkvhat right after this call: the LAST key-gradient kernel runs on the main stream
+                # (behind a join that is already satisfied - the earlier layers' reductions finished long ago) instead of
+                # bouncing main -> side -> main through two cross-queue events
+                sink.join()
+                ops.attention_bwd(a2)
+                sink._keep.extend(t_ for t_ in (dsc, mask) if t_ is not None)
+            else:
+                sink.on_side(lambda a2=a2: ops.attention_bwd(a2), (dx1, dxin) + tuple(t_ for t_ in (dsc, mask) if t_ is not None))
         sink.add(part, 0, G[lp + ".layer_norms.0.weight"], npart, 2 * H, H)
         sink.add(part, H, G[lp + ".layer_norms.0.bias"], npart, 2 * H, H)
         dx = dxin

@@ -304,6 +304,10 @@ typedef struct DosxAttn {
   float* dkv_part;     /* optional scratch [Bq * ceil(Sq/32), Nk, H]: with it (and Nk <= 64) the dq kernel also leaves each
                           query tile's share of dK + dV there and the dkv half is a small reduction over those partials
                           (no dscores round trip: dscores may then be NULL); without it the streamed dkv kernel runs */
+  int32_t* dkv_cnt;    /* optional, with dkv_part: [Bk] arrival counters, zero before the launch and zero again after it.  The
+                          backward is then ONE launch: the last query-tile workgroup of a key crystal to arrive (ticket)
+                          sums the partial key gradients of that crystal and writes dkvhat / partials_kv itself, in the
+                          reduction kernel's order (bitwise the two-launch result).  Excludes the SKIP_DQ / SKIP_DKV flags */
 } DosxAttn;
 /* 1 if dosx_attention_bwd takes the partial-dKV path for this key count / width when dkv_part is given (else it needs
  * dscores and runs the streamed dkv kernel) */

@@ -353,3 +353,58 @@ def test_shape_limits_are_explicit_errors():
         model(g)
     small = DOSTransformer_phonon(1, 1, 118, 4, 32, DEV, 0.0).to(DEV)
     assert bool(torch.isfinite(small(g)[0]).all())
+
+
+@pytest.mark.parametrize("Sq,Bq,Nk,Bk,H", [(51, 4, 12, 4, 128), (51, 6, 9, 3, 64), (70, 3, 64, 3, 128), (51, 128, 51, 128, 128),
+                                            (51, 128, 12, 64, 128), (201, 4, 41, 2, 256), (7, 3, 5, 3, 16)])
+@pytest.mark.parametrize("drop", [0.0, 0.3])
+def test_attention_backward_in_one_launch(Sq, Bq, Nk, Bk, H, drop):
+    """DosxAttn.dkv_cnt: the key gradient finished by the last arriving query-tile workgroup of each crystal, inside the dq
+    launch == the dq launch + attn_dkv_reduce_kernel, BITWISE (dx, dkvhat with the accumulate flag, both partial-sum
+    blocks); repeated launches on the same counters reproduce it (the counters are back at zero)."""
+    from dostransformer_amd import _lib
+    from dostransformer_amd._lib import Attn
+    if not _lib.load().dosx_attention_pkv_supported(Nk, H):
+        pytest.skip("partial-dKV path covers Nk <= 64 where its tiles fit the LDS")
+    o = ops()
+    x, kv = rnd(Sq * Bq, H, seed=1), rnd(Nk * Bk, H, seed=2)
+    gam, bet = rnd(H, seed=3), 0.3 * rnd(H, seed=4)
+    mask = None
+    if drop > 0:
+        mask = (torch.rand(Bq, Sq, Nk, generator=torch.Generator().manual_seed(9)) >= drop).float().to(DEV) / (1 - drop)
+    a = Attn()
+    a.Sq, a.Bq, a.Nk, a.Bk, a.H, a.q_stride_s, a.q_stride_b = Sq, Bq, Nk, Bk, H, Bq, 1
+    out, probs = torch.empty(Sq * Bq, H, device=DEV), torch.empty(Bq, Sq, Nk, device=DEV)
+    qstats, ostats = torch.empty(Sq * Bq, 2, device=DEV), torch.empty(Sq * Bq, 2, device=DEV)
+    a.x, a.kvhat, a.gamma0, a.beta0 = x.data_ptr(), kv.data_ptr(), gam.data_ptr(), bet.data_ptr()
+    a.out, a.probs, a.qstats, a.out_stats = out.data_ptr(), probs.data_ptr(), qstats.data_ptr(), ostats.data_ptr()
+    a.drop_mask = mask.data_ptr() if mask is not None else None
+    o.attention_fwd(a)
+    dout = rnd(Sq * Bq, H, seed=5)
+    nqt, nkt = (Sq + 31) // 32, (Nk + 15) // 16
+    base = rnd(Nk * Bk, H, seed=6)
+
+    def run(fused):
+        dx = torch.full((Sq * Bq, H), float("nan"), device=DEV)
+        dkv = base.clone()
+        part = torch.full((Bq * nqt + Bk * nkt, 2 * H), float("nan"), device=DEV)
+        kvp = torch.full((Bq * nqt * Nk, H), float("nan"), device=DEV)
+        a.dout, a.dx, a.dscores, a.dkvhat, a.dkv_accumulate = dout.data_ptr(), dx.data_ptr(), None, dkv.data_ptr(), 1
+        a.partials_q, a.partials_kv = part.data_ptr(), part.data_ptr() + 4 * Bq * nqt * 2 * H
+        a.dkv_part = kvp.data_ptr()
+        a.dkv_cnt = o.COUNTERS.take(DEV, Bk) if fused else None
+        reps = 3 if fused else 1
+        outs = []
+        for _ in range(reps):
+            dkv.copy_(base)
+            o.attention_bwd(a)
+            torch.cuda.synchronize()
+            outs.append((dx.clone(), dkv.clone(), part.clone()))
+        for r in outs[1:]:
+            assert all(torch.equal(u, v) for u, v in zip(r, outs[0]))
+        return outs[0]
+
+    two, one = run(False), run(True)
+    for name, u, v in zip(("dx", "dkvhat", "partials"), two, one):
+        assert not torch.isnan(v).any(), name
+        assert torch.equal(u, v), name
