@@ -1865,7 +1865,9 @@ int wgrad_prepare(const DosxWgrad& g, WgradLaunch& L, int& vec, bool& fast, int&
   if (!vec) DOSX_CHECK_ARG(g.pro == DOSX_PRO_NONE, "dosx_wgrad: prologue %d needs 4-float aligned operands", g.pro);
   DOSX_CHECK_ARG(g.pro >= DOSX_PRO_NONE && g.pro <= DOSX_PRO_ROWLN, "dosx_wgrad: bad prologue %d", g.pro);
   L.variant = (vec && fast) ? (g.pro == DOSX_PRO_NONE ? 0 : g.pro == DOSX_PRO_PRELU ? 1 : g.pro == DOSX_PRO_LN_PRELU ? 2 : 3)
-                            : (!vec ? 4 : -1);
+                            : (!vec ? 4 : -1);       // (the aligned generic-staging variant in the grouped kernel too made
+                                                      //  hipcc copy the whole job table to scratch, 3.8 KB per lane: those jobs -
+                                                      //  the two heads' div/mod row maps - keep their own launches)
   return 0;
 }
 

@@ -4,7 +4,7 @@
 # then copy gpurun_out/prof_<round>/summary/* into profiles/.  rocprofv3 passes are separate (kernel trace | one PMC
 # counter each), the program comes directly after `--`, outputs are CSV.
 set -u
-R=${1:-r02}
+R=${1:-r03}
 HEAD=${2:-unknown}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$R
@@ -16,7 +16,7 @@ cd "$ROOT"
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_$c" -o pmc -- \
-    python3 "$ROOT/bench.py" --steps 20 --warmup 10 --no-cpu-baseline > "$OUT/pmc_$c.log" 2>&1 < /dev/null
+    python3 "$ROOT/bench.py" --steps 20 --warmup 10 --no-cpu-baseline --no-secondary --kernels-out "$OUT/pmc_$c.kernels.json" > "$OUT/pmc_$c.log" 2>&1 < /dev/null
 done
 ff=$(find "$OUT/pmc_FETCH_SIZE" -name "*counter_collection.csv" | head -1)
 fw=$(find "$OUT/pmc_WRITE_SIZE" -name "*counter_collection.csv" | head -1)
@@ -27,18 +27,20 @@ if [ -n "$ff" ] && [ -n "$fw" ]; then
   python3 "$ROOT/tools/pmc_summary.py" "$fw" WRITE_SIZE "$S/${R}_pmc_write_size_summary.csv"
 fi
 cd "$ROOT"
-timeout 400 python3 bench.py > "$S/${R}_bench_phonon_h128_b64.json" 2> "$OUT/bench_phonon.err" < /dev/null
-timeout 400 python3 bench.py --shuffle --no-cpu-baseline > "$S/${R}_bench_phonon_h128_b64_shuffle.json" 2> "$OUT/bench_shuffle.err" < /dev/null
-timeout 500 python3 bench.py --config edos_h256_b64 > "$S/${R}_bench_edos_h256_b64.json" 2> "$OUT/bench_edos.err" < /dev/null
+# THE bench line (the driver's invocation: default flags; secondaries = eDOS H256 + shuffle inside the same record) + its per-site table
+timeout 600 python3 bench.py --kernels-out "$S/${R}_bench_phonon_h128_b64_sites.json" > "$S/${R}_bench_phonon_h128_b64.json" 2> "$OUT/bench_phonon.err" < /dev/null
+timeout 400 python3 bench.py --shuffle --no-cpu-baseline --no-secondary --kernels-out "$OUT/shuffle.kernels.json" > "$S/${R}_bench_phonon_h128_b64_shuffle.json" 2> "$OUT/bench_shuffle.err" < /dev/null
+timeout 500 python3 bench.py --config edos_h256_b64 --kernels-out "$S/${R}_bench_edos_h256_b64_sites.json" > "$S/${R}_bench_edos_h256_b64.json" 2> "$OUT/bench_edos.err" < /dev/null
+timeout 300 python3 tools/bench_wgroup.py > "$S/${R}_wgrad_groups.log" 2> /dev/null < /dev/null
 timeout 600 python3 tools/bench_kernels.py > "$S/${R}_kernel_microbench.log" 2> "$OUT/microbench.err" < /dev/null
 timeout 200 python3 tools/predict_latency.py 2> /dev/null | grep "^predict" >> "$S/${R}_kernel_microbench.log"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o st -- \
-  python3 "$ROOT/bench.py" --steps 100 --warmup 20 --no-cpu-baseline > "$OUT/trace.log" 2>&1 < /dev/null
+  python3 "$ROOT/bench.py" --steps 100 --warmup 20 --no-cpu-baseline --no-secondary --kernels-out "$OUT/trace.kernels.json" > "$OUT/trace.log" 2>&1 < /dev/null
 f=$(find "$OUT/trace" -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" "$S/${R}_bench_phonon_h128_b64_kernel_stats.csv"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_edos" -o st -- \
-  python3 "$ROOT/bench.py" --config edos_h256_b64 --steps 40 --warmup 10 --no-cpu-baseline > "$OUT/trace_edos.log" 2>&1 < /dev/null
+  python3 "$ROOT/bench.py" --config edos_h256_b64 --steps 40 --warmup 10 --no-cpu-baseline --kernels-out "$OUT/trace_edos.kernels.json" > "$OUT/trace_edos.log" 2>&1 < /dev/null
 f=$(find "$OUT/trace_edos" -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" "$S/${R}_bench_edos_h256_b64_kernel_stats.csv"
 ls -la "$S"
