@@ -195,6 +195,7 @@ _SIGS = {
     "dosx_dense_normalize_pool_bwd": [_P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
     "dosx_rownorm": [_P, _P, _P, _I, _I, _P],
     "dosx_rownorm_bwd": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "dosx_mask_residual": [_P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _P],
     "dosx_rownorm_bwd_act": [_P, _P, _P, _P, _P, _F, _P, _I, _I, _P],
     "dosx_layernorm": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
     "dosx_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _P],

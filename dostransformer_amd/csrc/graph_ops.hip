@@ -405,6 +405,41 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
   if (lane == 0) rstd_out[r] = rstd;
 }
 
+// out[r] = (res ? res[r] : 0) + a[r] o (mask ? mask[r] : 1), and optionally the LayerNorm statistics (mean, rstd) of the
+// out row: the dropout -> add-residual steps of the encoder layer (layers/transformer.py:137-138,145-148) for the
+// relu / res dropout path, where they cannot ride in the fused attention / feed-forward epilogues.  One wave per row.
+__global__ __launch_bounds__(256) void mask_residual_kernel(const float* __restrict__ a, int lda, const float* __restrict__ mask,
+                                                            const float* __restrict__ res, int ldr, float* __restrict__ out,
+                                                            int ldo, float* __restrict__ stats, int M, int H) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= M) return;
+  float s1 = 0.f;
+  for (int c = lane * 4; c < H; c += 256) {
+    float4 v = ld4(a + (size_t)r * lda + c);
+    if (mask) {
+      const float4 m = ld4(mask + (size_t)r * H + c);
+      v = make_float4(v.x * m.x, v.y * m.y, v.z * m.z, v.w * m.w);
+    }
+    if (res) v = f4add(v, ld4(res + (size_t)r * ldr + c));
+    st4(out + (size_t)r * ldo + c, v);
+    s1 += v.x + v.y + v.z + v.w;
+  }
+  if (stats == nullptr) return;
+  const float mean = wave_sum(s1) / (float)H;
+  float s2 = 0.f;
+  for (int c = lane * 4; c < H; c += 256) {                 // (this lane re-reads what it has just written)
+    const float4 v = ld4(out + (size_t)r * ldo + c);
+    const float x0 = v.x - mean, x1 = v.y - mean, x2 = v.z - mean, x3 = v.w - mean;
+    s2 += x0 * x0 + x1 * x1 + x2 * x2 + x3 * x3;
+  }
+  const float rstd = rsqrtf(wave_sum(s2) / (float)H + DOSX_LN_EPS);
+  if (lane == 0) {
+    stats[2 * (size_t)r] = mean;
+    stats[2 * (size_t)r + 1] = rstd;
+  }
+}
+
 __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const float* __restrict__ dxhat,
                                                           const float* __restrict__ xhat,
                                                           const float* __restrict__ rstd, float* __restrict__ dx,
@@ -664,6 +699,17 @@ extern "C" int dosx_rownorm(const float* x, float* xhat, float* rstd, int M, int
   CHECK_H(H);
   DOSX_CHECK_ARG(x && xhat && rstd, "dosx_rownorm: bad args");
   hipLaunchKernelGGL(rownorm_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, to_stream(stream), x, xhat, rstd, M, H);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_mask_residual(const float* a, int lda, const float* mask, const float* res, int ldr, float* out, int ldo,
+                                  float* stats, int M, int H, dosx_stream_t stream) {
+  if (M <= 0) return 0;
+  CHECK_H(H);
+  DOSX_CHECK_ARG(a && out && (lda & 3) == 0 && (ldo & 3) == 0 && (!res || (ldr & 3) == 0), "dosx_mask_residual: bad args");
+  hipLaunchKernelGGL(mask_residual_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, to_stream(stream), a, lda, mask, res, ldr, out,
+                     ldo, stats, M, H);
   DOSX_LAUNCH_CHECK();
   return 0;
 }

@@ -229,6 +229,7 @@ def _attn_desc(Sq, Bq, Nk, Bk, H, qs, qb, x, kvhat, gam, bet) -> Attn:
 
 
 DROP_MASK_LOG: Optional[list] = None      # tests: set to a list to receive (prefix, layer, mask tensor) of every drawn mask
+FDROP_MASK_LOG: Optional[list] = None     # ... and (prefix, layer, "res1" | "relu" | "res2", mask) of the relu / res dropout sites
 
 
 def head_fused_fwd(H: int, T: int) -> bool:
@@ -237,17 +238,23 @@ def head_fused_fwd(H: int, T: int) -> bool:
 
 
 def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int, qb: int, kvhat: torch.Tensor,
-                Nk: int, Bk: int, H: int, T: int, final_ln: bool = True, drop=None, head=None):
+                Nk: int, Bk: int, H: int, T: int, final_ln: bool = True, drop=None, head=None, fdrop=None):
     """x: query rows (row (s,bq) at (s*qs + bq*qb)); kvhat: [Nk*Bk, H] normalised keys (stale across layers).
     drop: None or (p, seed_dev, stream_base): attention dropout in training mode (multihead_attention.py:70) - every
     layer draws its own [Bq,Sq,Nk] multiplier mask (ops.dropout_mask) that the backward re-uses.
     head = (gamma, beta, w, b, xhat [rows,H], rstd [rows], dos [Bq,Sq]) (with final_ln False, head_fused_fwd(H, T)): the
     model head - LayerNorm + H->1 output layer on the encoder's output - in the last layer's ffn_fwd epilogue; the
-    encoder output itself is then not materialised (None is returned for it)."""
+    encoder output itself is then not materialised (None is returned for it).
+    fdrop = (p_relu, p_res, seed_dev, stream_base) or None: relu / res dropout of the layer (transformer.py:137,145-147) in
+    training mode.  The layer then runs UNFUSED - attention without its residual epilogue, the two feed-forward GEMMs, and
+    ops.mask_residual for the three "dropout -> add residual" steps - with one explicit multiplier mask per dropout site."""
     dev = kvhat.device
     rows = Sq * Bq
     lay = []
     fin_fused = None
+    if fdrop is not None and not (fdrop[0] > 0.0 or fdrop[1] > 0.0):
+        fdrop = None
+    assert fdrop is None or head is None
     for t in range(T):
         lp = f"{pre}.layers.{t}"
         g0, b0 = P[lp + ".layer_norms.0.weight"], P[lp + ".layer_norms.0.bias"]
@@ -264,6 +271,40 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
             a.drop_mask = mask.data_ptr()
             if DROP_MASK_LOG is not None:
                 DROP_MASK_LOG.append((pre, t, mask))
+        fm = None
+        if fdrop is not None:
+            # relu / res dropout: x1 = x + attn o M1 ; hd = relu(fc1(LN1(x1))) o M2 ; x2 = x1 + fc2(hd) o M3
+            p_relu, p_res, fseed, fbase = fdrop
+
+            def draw(shape, p, k):
+                if p <= 0.0:
+                    return None
+                m_ = _empty(dev, *shape)
+                ops.dropout_mask(m_, p, fseed, fbase + 3 * t + k)
+                if FDROP_MASK_LOG is not None:
+                    FDROP_MASK_LOG.append((pre, t, ("res1", "relu", "res2")[k], m_))
+                return m_
+            m1, m2, m3 = draw((rows, H), p_res, 0), draw((rows, 4 * H), p_relu, 1), draw((rows, H), p_res, 2)
+            fm = (m1, m2, m3)
+            a.flags |= 2                                   # DOSX_ATTN_NO_RESIDUAL: out = the attention output alone
+            att = _empty(dev, rows, H)
+            a.out = att.data_ptr()
+            ops.attention_fwd(a)
+            assert qs == Bq and qb == 1, "relu / res dropout: dense query rows only (layers.TransformerEncoder)"
+            ops.mask_residual(att, m1, x, x1, st1, rows, H)
+            h = _empty(dev, rows, 4 * H)
+            ops.gemm(rows, 4 * H, [seg(x1)], P[lp + ".fc1.weight"], h, pro=PRO_ROWLN,
+                     pro_gamma=P[lp + ".layer_norms.1.weight"], pro_beta=P[lp + ".layer_norms.1.bias"], pro_stats=st1,
+                     bias=P[lp + ".fc1.bias"], act=ACT_RELU)
+            if m2 is not None:
+                ops.mask_residual(h, m2, None, h, None, rows, 4 * H)       # in place: h is the DROPPED activation from here on
+            y2 = _empty(dev, rows, H)
+            ops.gemm(rows, H, [seg(h)], P[lp + ".fc2.weight"], y2, bias=P[lp + ".fc2.bias"])
+            x2 = _empty(dev, rows, H)
+            ops.mask_residual(y2, m3, x1, x2, None, rows, H)
+            lay.append((x, qs, qb, x1, probs, qstats, st1, h, mask, fm))
+            x, qs, qb = x2, Bq, 1
+            continue
         ops.attention_fwd(a)
         h = _empty(dev, rows, 4 * H)
         x2 = _empty(dev, rows, H)
@@ -287,7 +328,7 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
                      pro_gamma=P[lp + ".layer_norms.1.weight"], pro_beta=P[lp + ".layer_norms.1.bias"], pro_stats=st1,
                      bias=P[lp + ".fc1.bias"], act=ACT_RELU)
             ops.gemm(rows, H, [seg(h)], P[lp + ".fc2.weight"], x2, bias=P[lp + ".fc2.bias"], res=x1)
-        lay.append((x, qs, qb, x1, probs, qstats, st1, h, mask))
+        lay.append((x, qs, qb, x1, probs, qstats, st1, h, mask, None))
         x, qs, qb = x2, Bq, 1
     fin = None
     if final_ln and fin_fused is not None:
@@ -327,7 +368,9 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: Optional[torch.Tensor],
     rows = Sq * Bq
     r32 = _rows32(rows)
     dx = dy
-    fused = ops.ffn_supported(H) and _FUSED_FFN_BWD
+    fused_all = ops.ffn_supported(H) and _FUSED_FFN_BWD
+    last_plain = T > 0 and lay[T - 1][9] is None            # (a layer on the relu / res dropout path runs unfused)
+    fused = fused_all and last_plain
     fin_fused = None        # the final LayerNorm's backward rides in the last layer's ffn_bwd launch (csrc/ffn.hip)
     fin_keys = (pre + ".layer_norm.weight", pre + ".layer_norm.bias")
     if head is not None:
@@ -348,14 +391,20 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: Optional[torch.Tensor],
     nqt, nkt = (Sq + 31) // 32, (Nk + 31) // 32
     for t in reversed(range(T)):
         lp = f"{pre}.layers.{t}"
-        x_in, qs, qb, x1, probs, qstats, st1, h, mask = lay[t]
+        x_in, qs, qb, x1, probs, qstats, st1, h, mask, fm = lay[t]
         g1, b1 = P[lp + ".layer_norms.1.weight"], P[lp + ".layer_norms.1.bias"]
         g0, b0 = P[lp + ".layer_norms.0.weight"], P[lp + ".layer_norms.0.bias"]
+        dx_res2 = dx                      # gradient of x2 (the residual path of the feed-forward half carries it unchanged)
+        if fm is not None and fm[2] is not None:           # x2 = x1 + y o M3: the fc2 output sees dx o M3
+            dy2 = _empty(dev, rows, H)
+            ops.mask_residual(dx, fm[2], None, dy2, None, rows, H)
+            dx = dy2
         # fc2
         _wgrad_linear(sink, G, lp + ".fc2.weight", lp + ".fc2.bias", rows, H, seg(dx), [seg(h)], keep=(dx,))
         dh = _empty(dev, rows, 4 * H)
         dx1 = _empty(dev, rows, H)
         pld = 2 * H
+        fused = fused_all and fm is None
         if fused:           # both dgrad GEMMs + ReLU mask + LN1 backward + residual in one launch (csrc/ffn.hip)
             rgp = ops.ffn_bwd_partial_rows(rows)
             with_fin = fin_fused is not None and t == T - 1
@@ -371,6 +420,8 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: Optional[torch.Tensor],
                     sink.add(part, 5 * H, G[fin_keys[3]], rgp, pld, 1)
         else:
             ops.gemm(rows, 4 * H, [seg(dx)], P[lp + ".fc2.weight"], dh, w_layout=1, epi=EPI_RELU_MASK, aux=h)
+            if fm is not None and fm[1] is not None:       # h is the dropped activation: [h > 0] = [relu > 0][M2 > 0]; x 1/(1-p)
+                ops.mask_residual(dh, fm[1], None, dh, None, rows, 4 * H)
         # fc1 (+ LN1 backward + residual)
         _wgrad_linear(sink, G, lp + ".fc1.weight", lp + ".fc1.bias", rows, 4 * H, seg(dh), [seg(x1)], keep=(dh,),
                       pro=PRO_ROWLN, pro_gamma=g1, pro_beta=b1, pro_stats=st1)
@@ -378,7 +429,7 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: Optional[torch.Tensor],
             rgp = ops.gemm_partial_rows(rows, H, EPI_ROWLN_BWD)
             part = sink.scratch(rgp, 2 * H)
             ops.gemm(rows, H, [seg(dh)], P[lp + ".fc1.weight"], dx1, w_layout=1, epi=EPI_ROWLN_BWD, aux=x1, aux_stats=st1,
-                     epi_gamma=g1, res=dx, partials=part, partial_ld=2 * H)
+                     epi_gamma=g1, res=dx_res2, partials=part, partial_ld=2 * H)
         sink.add(part, 0, G[lp + ".layer_norms.1.weight"], rgp, pld, H)
         sink.add(part, H, G[lp + ".layer_norms.1.bias"], rgp, pld, H)
         # attention (+ LN0 backward on the query side + residual); key side accumulates into dkvhat
@@ -393,10 +444,17 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: Optional[torch.Tensor],
         kvp = sink.scratch(Bq * nqt * Nk, H) if small else None
         acc = 0 if (dkv_fresh and t == T - 1) else 1
 
+        dout_att = dx1
+        if fm is not None:                 # x1 = x + attn o M1: the attention output sees dx1 o M1, x the plain dx1 (added below)
+            dout_att = _empty(dev, rows, H)
+            ops.mask_residual(dx1, fm[0], None, dout_att, None, rows, H)
+
         def desc(flags):
             a = _attn_desc(Sq, Bq, Nk, Bk, H, qs, qb, x_in, kvhat, g0, b0)
             a.probs, a.qstats = probs.data_ptr(), qstats.data_ptr()
-            a.dout, a.dx, a.dkvhat, a.dkv_accumulate = dx1.data_ptr(), dxin.data_ptr(), dkvhat.data_ptr(), acc
+            a.dout, a.dx, a.dkvhat, a.dkv_accumulate = dout_att.data_ptr(), dxin.data_ptr(), dkvhat.data_ptr(), acc
+            if fm is not None:
+                flags |= 2                 # DOSX_ATTN_NO_RESIDUAL
             a.dscores = dsc.data_ptr() if dsc is not None else None
             a.dkv_part = kvp.data_ptr() if kvp is not None else None
             a.drop_mask = mask.data_ptr() if mask is not None else None
@@ -428,6 +486,11 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: Optional[torch.Tensor],
                 sink.on_side(lambda a2=a2: ops.attention_bwd(a2), (dx1, dxin) + tuple(t_ for t_ in (dsc, mask) if t_ is not None))
         sink.add(part, 0, G[lp + ".layer_norms.0.weight"], npart, 2 * H, H)
         sink.add(part, H, G[lp + ".layer_norms.0.bias"], npart, 2 * H, H)
+        if fm is not None:                 # + the residual path of the attention half
+            sink._keep.append(dout_att)
+            dsum = _empty(dev, rows, H)
+            ops.mask_residual(dxin, None, dx1, dsum, None, rows, H)
+            dxin = dsum
         dx = dxin
     return dx
 

@@ -60,7 +60,8 @@ class _EncoderFn(torch.autograd.Function):
         rstd = torch.empty(nk * b, device=dev)
         ops.rownorm(src, kvhat, rstd, nk * b, h)
         y, c = Fn.encoder_fwd(P, "enc", x2, sq, b, b, 1, kvhat, nk, b, h, len(enc.layers), final_ln=not skip_final,
-                              drop=enc._dropout(dev))
+                              drop=enc._dropout(dev), fdrop=enc._fdropout(dev))
+        enc._bump_seed()
         ctx.c, ctx.P, ctx.names, ctx.params = c, P, names, params
         ctx.kv = (kvhat, rstd, nk, self_attn)
         ctx.dims = (sq, b, h)
@@ -109,15 +110,28 @@ class TransformerEncoder(nn.Module):
             self.layer_norm = LayerNorm(embed_dim)
 
     def _check_dropouts(self):
-        """attn_dropout (the only one a reference call site sets: DOSTransformer*.py:27-38 via --attn_drop) is implemented
-        in the attention kernels.  relu / res dropout sit inside the fused FFN / residual epilogues and embed dropout
-        draws DIFFERENT masks for keys and values (transformer.py:61-68), i.e. K != V, which the K == V kernels cannot
-        express: those three raise instead of being silently ignored."""
-        if self.training and any(p > 0.0 for p in (self.dropout,) +
-                                 tuple(x for l in self.layers for x in (l.relu_dropout, l.res_dropout))):
-            raise NotImplementedError("relu / res / embed dropout > 0 is not implemented in the fused MI355X path "
-                                      "(no reference call site sets them: DOSTransformer_phonon.py:27-38; defaults "
-                                      "transformer.py:22-23); attn_dropout is supported")
+        """attn_dropout (the only one a reference call site sets: DOSTransformer*.py:27-38 via --attn_drop) is implemented in
+        the attention kernels; relu / res dropout (transformer.py:137,145-147) run the layer unfused with explicit
+        multiplier masks (functional.encoder_fwd, fdrop).  Embed dropout draws DIFFERENT masks for keys and values
+        (transformer.py:61-68), i.e. K != V, which the K == V kernels cannot express: it raises instead of being ignored."""
+        if self.training and self.dropout > 0.0:
+            raise NotImplementedError("embed_dropout > 0 is not implemented in the fused MI355X path: it makes K != V "
+                                      "(no reference call site sets it: DOSTransformer_phonon.py:27-38; default "
+                                      "transformer.py:22-23); attn / relu / res dropout are supported")
+
+    def _fdropout(self, device):
+        """None or (p_relu, p_res, seed_dev, stream_base) for Fn.encoder_fwd: relu / res dropout of the layers (all layers
+        of an encoder share the values, like upstream's constructor)."""
+        if not self.training or len(self.layers) == 0:
+            return None
+        p_relu, p_res = float(self.layers[0].relu_dropout or 0.0), float(self.layers[0].res_dropout or 0.0)
+        if p_relu <= 0.0 and p_res <= 0.0:
+            return None
+        seed = getattr(self, "_drop_seed", None)
+        if seed is None or seed.device != device:
+            seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(device)
+            object.__setattr__(self, "_drop_seed", seed)
+        return p_relu, p_res, seed, 1000
 
     def _dropout(self, device):
         """None (eval / p = 0) or (p, seed_dev, stream_base) for Fn.encoder_fwd; the seed starts from torch's RNG and is
@@ -129,9 +143,13 @@ class TransformerEncoder(nn.Module):
         if seed is None or seed.device != device:
             seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(device)
             object.__setattr__(self, "_drop_seed", seed)
-        else:
-            seed.add_(1)
         return p, seed, 0
+
+    def _bump_seed(self):
+        """one bump per forward call (after the call's masks have been drawn from the current value)"""
+        seed = getattr(self, "_drop_seed", None)
+        if seed is not None and self.training:
+            seed.add_(1)
 
     def forward(self, x_in, x_in_k=None, x_in_v=None, mask=None, _skip_final_ln=False):
         if x_in_k is None or x_in_v is None:

@@ -832,6 +832,13 @@ def rownorm_bwd_act(dxhat, xhat, rstd, dx_in, y, slope, out, M, H):
           w=lambda: ("rownorm_bwd_act", "rownorm_bwd_act_kernel", "hbm", 20.0 * M * H))
 
 
+def mask_residual(a, mask, res, out, stats, M, H):
+    """out = (res or 0) + a o (mask or 1), optionally with the LayerNorm statistics [M,2] of out (include/dosx.h)."""
+    _call("dosx_mask_residual", _p(a), int(a.stride(0)), _p(mask), _p(res), int(res.stride(0)) if res is not None else 0,
+          _p(out), int(out.stride(0)), _p(stats), M, H, _stream(),
+          w=lambda: ("mask_residual", "mask_residual_kernel", "hbm", 4.0 * M * H * (2 + (mask is not None) + (res is not None))))
+
+
 def layernorm(x, gamma, beta, y, xhat, rstd, M, H):
     _call("dosx_layernorm", _p(x), _p(gamma), _p(beta), _p(y), _p(xhat), _p(rstd), M, H, _stream(),
           w=lambda: ("layernorm", "ln_fwd_kernel", "hbm", 12.0 * M * H))

@@ -256,6 +256,11 @@ int dosx_dense_normalize_pool_bwd(const float* dkvhat, const float* kvhat, const
 int dosx_rownorm(const float* x, float* xhat, float* rstd, int M, int H, dosx_stream_t stream);
 int dosx_rownorm_bwd(const float* dxhat, const float* xhat, const float* rstd, float* dx, int M, int H,
                      int accumulate, dosx_stream_t stream);
+/* out[r] = (res ? res[r] : 0) + a[r] o (mask ? mask[r] : 1)  (+ the LayerNorm statistics [M,2] = (mean, rstd) of the out rows
+ * when `stats` is given): the "dropout -> add residual" steps of the encoder layer (layers/transformer.py:137-138,145-148)
+ * for relu / res dropout > 0, with the Bernoulli draw as an explicit multiplier (dosx_dropout_mask); mask is [M,H] dense. */
+int dosx_mask_residual(const float* a, int lda, const float* mask, const float* res, int ldr, float* out, int ldo,
+                       float* stats, int M, int H, dosx_stream_t stream);
 /* The same followed by the backward of the (Leaky)ReLU that produced the normalised rows' input y
  * (DOSTransformer_phonon.py:103,106 `F.leaky_relu(self.fc(...))` feeding the self-attention keys):
  *     out = (dx_in + rownorm_bwd(dxhat, xhat, rstd)) * (y > 0 ? 1 : slope)         one launch instead of two */

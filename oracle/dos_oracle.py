@@ -154,16 +154,21 @@ def multihead_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, drop_
 
 
 def encoder_layer(p: Params, prefix: str, x, x_k, x_v, drop_mask=None):
-    """Pre-norm block; layer_norms.0 is shared by q, k and v (`transformer.py:131-134`)."""
+    """Pre-norm block; layer_norms.0 is shared by q, k and v (`transformer.py:131-134`).
+    drop_mask: None, the attention-dropout multiplier [batch, tgt, src], or a dict of explicit multipliers for the layer's
+    dropout sites - "attn" (`multihead_attention.py:70`), "res1" (`transformer.py:137`, on the attention output), "relu"
+    (`:145`, on relu(fc1)) and "res2" (`:147`, on the fc2 output); missing keys = no dropout there."""
+    dm = drop_mask if isinstance(drop_mask, dict) else {"attn": drop_mask}
+    mul = lambda t, key: t if dm.get(key) is None else t * dm[key].to(t.dtype).reshape(t.shape)
     r = x
     q = _layer_norm(p, prefix + ".layer_norms.0", x)
     k = _layer_norm(p, prefix + ".layer_norms.0", x_k)
     v = _layer_norm(p, prefix + ".layer_norms.0", x_v)
-    x = r + multihead_attention(q, k, v, drop_mask)
+    x = r + mul(multihead_attention(q, k, v, dm.get("attn")), "res1")
     r = x
     y = _layer_norm(p, prefix + ".layer_norms.1", x)
-    y = _linear(p, prefix + ".fc2", F.relu(_linear(p, prefix + ".fc1", y)))
-    return r + y
+    y = _linear(p, prefix + ".fc2", mul(F.relu(_linear(p, prefix + ".fc1", y)), "relu"))
+    return r + mul(y, "res2")
 
 
 def transformer_encoder(p: Params, prefix: str, x, x_k, x_v, n_layers: int, drop_masks=None):

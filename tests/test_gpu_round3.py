@@ -408,3 +408,68 @@ def test_attention_backward_in_one_launch(Sq, Bq, Nk, Bk, H, drop):
     for name, u, v in zip(("dx", "dkvhat", "partials"), two, one):
         assert not torch.isnan(v).any(), name
         assert torch.equal(u, v), name
+
+
+@pytest.mark.parametrize("mode", ["cross", "self"])
+@pytest.mark.parametrize("p_attn,p_relu,p_res", [(0.0, 0.3, 0.0), (0.0, 0.0, 0.2), (0.25, 0.3, 0.2)])
+def test_transformer_encoder_relu_and_res_dropout_match_oracle(mode, p_attn, p_relu, p_res):
+    """TransformerEncoder(relu_dropout, res_dropout) (`transformer.py:137,145-147`) in training mode: outputs and every
+    gradient equal the oracle's with the SAME Bernoulli draws (the masks the kernels used, captured per layer and site);
+    eval mode ignores them; embed dropout (K != V) raises."""
+    from oracle import dos_oracle as O
+    from dostransformer_amd import functional as Fn
+    from dostransformer_amd.layers import TransformerEncoder
+    torch.manual_seed(0)
+    Hh, S, Bq, Nk, T = 32, 51, 5, 9, 2
+    enc = TransformerEncoder(embed_dim=Hh, num_heads=1, layers=T, attn_dropout=p_attn, relu_dropout=p_relu, res_dropout=p_res).to(DEV)
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if "layer_norm" in n or "bias" in n:
+                p.add_(0.1 * torch.randn_like(p))
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(S, Bq, Hh, generator=gen).to(DEV).requires_grad_(True)
+    kv = torch.randn(Nk, Bq, Hh, generator=gen).to(DEV).requires_grad_(True)
+    w = torch.randn(S, Bq, Hh, generator=gen).to(DEV)
+    Fn.DROP_MASK_LOG, Fn.FDROP_MASK_LOG = [], []
+    try:
+        enc.train()
+        y = enc(x, kv, kv) if mode == "cross" else enc(x, x, x)
+        amasks = [m.clone() for _, _, m in Fn.DROP_MASK_LOG]
+        fmasks = [(t, k, m.clone()) for _, t, k, m in Fn.FDROP_MASK_LOG]
+    finally:
+        Fn.DROP_MASK_LOG = Fn.FDROP_MASK_LOG = None
+    assert len(amasks) == (T if p_attn > 0 else 0)
+    assert len(fmasks) == T * ((1 if p_relu > 0 else 0) + (2 if p_res > 0 else 0))
+    (y * w).sum().backward()
+    masks = [dict() for _ in range(T)]
+    for t, m in enumerate(amasks):
+        masks[t]["attn"] = m.double().cpu()
+    for t, k, m in fmasks:
+        assert 0.4 < float((m > 0).float().mean()) < 0.95
+        masks[t][k] = m.double().cpu()
+    p64 = {"e." + k: v.detach().double().cpu().requires_grad_(True) for k, v in enc.state_dict().items() if v.is_floating_point()}
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    kv64 = kv.detach().double().cpu().requires_grad_(True)
+    src = kv64 if mode == "cross" else x64
+    yr = O.transformer_encoder(p64, "e", x64, src, src, T, masks)
+    (yr * w.double().cpu()).sum().backward()
+    assert float((y.detach().cpu().double() - yr.detach()).abs().max()) < 3e-5
+    assert float((x.grad.cpu().double() - x64.grad).abs().max() / x64.grad.abs().max()) < 1e-4
+    if mode == "cross":
+        assert float((kv.grad.cpu().double() - kv64.grad).abs().max() / kv64.grad.abs().max()) < 1e-4
+    for n, p in enc.named_parameters():
+        if ".self_attn." in n:
+            assert p.grad is None
+            continue
+        gr = p64["e." + n].grad
+        assert float((p.grad.cpu().double() - gr).abs().max() / (gr.abs().max() + 1e-12)) < 2e-4, n
+    y2 = enc(x, kv, kv) if mode == "cross" else enc(x, x, x)
+    assert not torch.equal(y.detach(), y2.detach())                          # a new call draws new masks
+    enc.eval()
+    with torch.no_grad():
+        ye = enc(x, kv, kv) if mode == "cross" else enc(x, x, x)
+        y0 = O.transformer_encoder({k: v.detach() for k, v in p64.items()}, "e", x64.detach(), src.detach(), src.detach(), T)
+    assert float((ye.cpu().double() - y0).abs().max()) < 3e-5
+    bad = TransformerEncoder(embed_dim=Hh, num_heads=1, layers=1, embed_dropout=0.1).to(DEV).train()
+    with pytest.raises(NotImplementedError, match="K != V"):
+        bad(x, kv, kv)
