@@ -1499,41 +1499,55 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, 
       const int kw = sa.width - (k0 - kbase);                         // columns of this tile inside K
       const int cy = g.dy.map.c, oy = g.dy.map.off, ca = sa.map.c, oa = sa.map.off;
       const bool gather = sa.map.idx != nullptr;
+      // Row maps on this path are affine (row = r*c + off) or BLOCKED div/mod maps (row = (r/d)*m + (r%d)*c + off with
+      // 32 | d, checked by the host): a chunk starts at a multiple of 32 rows, so the 32 rows of a chunk never wrap and
+      // the map splits into a per-lane part (r_local*c + off) and a per-chunk SCALAR part chunk_row0(R) - the heads'
+      // weight gradients (dY rows of one prediction branch, energies / graph rows broadcast over the other axis).
+      const bool by_blk = g.dy.map.d < (1 << 30), ba_blk = sa.map.d < (1 << 30);
+      auto row0 = [](const DosxRowMap& mp, bool blk, int R) { return blk ? (R / mp.d) * mp.m + (R % mp.d) * mp.c : R * mp.c; };
+      auto maxrow = [](const DosxRowMap& mp, bool blk, int Mr) {        // largest row a valid r < Mr maps to
+        if (!blk) return (Mr - 1) * mp.c + mp.off;
+        if (mp.m == 0) return (min(Mr, mp.d) - 1) * mp.c + mp.off;       // pure mod map: rows repeat
+        return ((Mr - 1) / mp.d) * mp.m + ((Mr - 1) % mp.d) * mp.c + mp.off;
+      };
       // bounds: rows >= M read as zero (dY) -> they add nothing to the sums; no masks anywhere
-      const uint32_t ybytes = (uint32_t)(((size_t)(M - 1) * cy + oy + 1) * (size_t)g.dy.ld * 4);
-      const uint32_t abytes = gather ? 0x7fffffffu : (uint32_t)(((size_t)(M - 1) * ca + oa + 1) * (size_t)sa.ld * 4);
+      const uint32_t ybytes = (uint32_t)(((size_t)maxrow(g.dy.map, by_blk, M) + 1) * (size_t)g.dy.ld * 4);
+      const uint32_t abytes = gather ? 0x7fffffffu : (uint32_t)(((size_t)maxrow(sa.map, ba_blk, M) + 1) * (size_t)sa.ld * 4);
       const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)g.dy.p, 0, ybytes, 0x00020000);
       const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)sa.p, 0, abytes, 0x00020000);
       const __amdgpu_buffer_rsrc_t rI = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(gather ? sa.map.idx : (const int*)g.dy.p), 0, (uint32_t)(((size_t)(M - 1) * ca + oa + 1) * 4), 0x00020000);
+          (void*)(gather ? sa.map.idx : (const int*)g.dy.p), 0, (uint32_t)(((size_t)maxrow(sa.map, ba_blk, M) + 1) * 4), 0x00020000);
       const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(PRO == DOSX_PRO_ROWLN ? g.pro_stats : g.dy.p), 0, (uint32_t)((size_t)M * 8), 0x00020000);
       const int ny0 = (n0 + c4) < N ? (n0 + c4) : 0, ny1 = (n0 + c4 + 32) < N ? (n0 + c4 + 32) : 0;
       const int kx0 = c4 < kw ? c4 : 0, kx1 = (c4 + 32) < kw ? (c4 + 32) : 0;
-      const uint32_t vY0 = (uint32_t)((((size_t)(ms + r) * cy + oy) * g.dy.ld + ny0) * 4);
-      const uint32_t vY1 = (uint32_t)((((size_t)(ms + r) * cy + oy) * g.dy.ld + ny1) * 4);
+      // per-lane parts (row r of the chunk), the chunk's first row comes in as a scalar offset
+      const uint32_t vY0 = (uint32_t)((((size_t)r * cy + oy) * g.dy.ld + ny0) * 4);
+      const uint32_t vY1 = (uint32_t)((((size_t)r * cy + oy) * g.dy.ld + ny1) * 4);
       const uint32_t colA0 = (uint32_t)((k0 - kbase + kx0) * 4), colA1 = (uint32_t)((k0 - kbase + kx1) * 4);
-      const uint32_t vA0 = (uint32_t)(((size_t)(ms + r) * ca + oa) * sa.ld * 4) + colA0;   // (!gather)
-      const uint32_t vA1 = (uint32_t)(((size_t)(ms + r) * ca + oa) * sa.ld * 4) + colA1;
-      const uint32_t vI = (uint32_t)(((size_t)(ms + r) * ca + oa) * 4);
+      const uint32_t vA0 = (uint32_t)(((size_t)r * ca + oa) * sa.ld * 4) + colA0;   // (!gather)
+      const uint32_t vA1 = (uint32_t)(((size_t)r * ca + oa) * sa.ld * 4) + colA1;
+      const uint32_t vI = (uint32_t)(((size_t)r * ca + oa) * 4);
       const uint32_t vS = (uint32_t)((ms + r) * 8);
-      const int stepY = BM * cy * g.dy.ld * 4, stepA = BM * ca * sa.ld * 4, stepI = BM * ca * 4;
+      const int ldy4 = g.dy.ld * 4, lda4 = sa.ld * 4;
       const float alpha = (PRO == DOSX_PRO_PRELU || PRO == DOSX_PRO_LN_PRELU) ? *g.pro_alpha : 0.f;
       // (every load below is unconditional: a load inside a run-time branch makes hipcc place s_waitcnt vmcnt(0)
       //  at the join, i.e. right behind the issue - measured 900-1850 clk per chunk in the staging waves)
       auto load_idx = [&](Set& q, int m) {
-        const int cidx = __builtin_amdgcn_readfirstlane((m - ms) / BM);
-        q.idx = __builtin_amdgcn_raw_buffer_load_b32(rI, vI, cidx * stepI, 0);      // (!gather: dummy, unused)
+        const int mu = __builtin_amdgcn_readfirstlane(m);
+        q.idx = __builtin_amdgcn_raw_buffer_load_b32(rI, vI, row0(sa.map, ba_blk, mu) * 4, 0);      // (!gather: dummy, unused)
       };
 #pragma unroll
       for (int i = 0; i < NSET; ++i) load_idx(sets[i], ms + i * BM);
       auto issue = [&](Set& q, int m) {
+        const int mu = __builtin_amdgcn_readfirstlane(m);
         const int cidx = __builtin_amdgcn_readfirstlane((m - ms) / BM);
-        q.y0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rY, vY0, cidx * stepY, 0));
-        q.y1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rY, vY1, cidx * stepY, 0));
-        const uint32_t rowb = (uint32_t)q.idx * (uint32_t)(sa.ld * 4);
+        const int soY = __builtin_amdgcn_readfirstlane(row0(g.dy.map, by_blk, mu) * ldy4);
+        q.y0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rY, vY0, soY, 0));
+        q.y1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rY, vY1, soY, 0));
+        const uint32_t rowb = (uint32_t)q.idx * (uint32_t)lda4;
         const uint32_t o0 = gather ? rowb + colA0 : vA0, o1 = gather ? rowb + colA1 : vA1;
-        const int soA = gather ? 0 : cidx * stepA;
+        const int soA = __builtin_amdgcn_readfirstlane(gather ? 0 : row0(sa.map, ba_blk, mu) * lda4);
         q.x0.v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rA, o0, soA, 0));
         q.x1.v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rA, o1, soA, 0));
         load_idx(q, m + NSET * BM);                 // rows beyond M read index 0 through the buffer bounds
@@ -1854,13 +1868,27 @@ int wgrad_prepare(const DosxWgrad& g, WgradLaunch& L, int& vec, bool& fast, int&
   vec = L.vecA && L.vecY;
   // fast (buffer-addressed) staging: affine row maps (+ optional gather on A), K tiles inside one segment,
   // every byte offset below 2^31
-  auto affine = [](const DosxRowMap& m) { return m.d >= (1 << 30) && m.c >= 1 && m.off >= 0; };
-  fast = vec && g.M > 0 && affine(g.dy.map) && g.dy.map.idx == nullptr &&
-         ((size_t)g.M * g.dy.map.c + g.dy.map.off) * (size_t)g.dy.ld * 4 < 0x7fffffffull;
+  // fast (buffer-addressed) staging: every row map affine, or a BLOCKED div/mod map (32 | d, d | M, blocks in row order or
+  // a pure mod map; dY's map must send rows >= M past its last valid row: they read as zero through the buffer bounds);
+  // an index gather only behind an affine map; K tiles inside one segment; every byte offset below 2^31
+  auto maxrow = [](const DosxRowMap& m, int M) -> long long {
+    if (m.d >= (1 << 30)) return (long long)(M - 1) * m.c + m.off;
+    if (m.m == 0) return (long long)((M < m.d ? M : m.d) - 1) * m.c + m.off;
+    return (long long)((M - 1) / m.d) * m.m + (long long)((M - 1) % m.d) * m.c + m.off;
+  };
+  auto fastmap = [&](const DosxRowMap& m, bool need_monotone) {
+    if (m.c < 0 || m.off < 0 || m.m < 0) return false;
+    if (m.d >= (1 << 30)) return m.c >= 1 || !need_monotone;
+    if ((m.d % BM) != 0 || (g.M % m.d) != 0 || m.idx != nullptr) return false;
+    const bool monotone = (long long)m.m >= (long long)(m.d - 1) * m.c + 1;
+    return need_monotone ? (monotone && m.c >= 1) : (monotone || m.m == 0);
+  };
+  fast = vec && g.M > 0 && fastmap(g.dy.map, true) && g.dy.map.idx == nullptr &&
+         (unsigned long long)(maxrow(g.dy.map, g.M) + 1) * (unsigned long long)g.dy.ld * 4 < 0x7fffffffull;
   for (int i = 0; fast && i < g.nseg; ++i) {
     const DosxSeg& sg = g.a[i];
-    fast = affine(sg.map) && (g.nseg == 1 || (sg.width % WT) == 0) && (size_t)sg.ld * 4 < 0x7fffffffull &&
-           ((size_t)g.M * sg.map.c + sg.map.off) * (size_t)(sg.map.idx ? 4 : (size_t)sg.ld * 4) < 0x7fffffffull;
+    fast = fastmap(sg.map, false) && (g.nseg == 1 || (sg.width % WT) == 0) && (size_t)sg.ld * 4 < 0x7fffffffull &&
+           (unsigned long long)(maxrow(sg.map, g.M) + 1) * (unsigned long long)(sg.map.idx ? 4 : (size_t)sg.ld * 4) < 0x7fffffffull;
   }
   if (!vec) DOSX_CHECK_ARG(g.pro == DOSX_PRO_NONE, "dosx_wgrad: prologue %d needs 4-float aligned operands", g.pro);
   DOSX_CHECK_ARG(g.pro >= DOSX_PRO_NONE && g.pro <= DOSX_PRO_ROWLN, "dosx_wgrad: bad prologue %d", g.pro);

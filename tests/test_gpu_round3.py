@@ -473,3 +473,29 @@ def test_transformer_encoder_relu_and_res_dropout_match_oracle(mode, p_attn, p_r
     bad = TransformerEncoder(embed_dim=Hh, num_heads=1, layers=1, embed_dropout=0.1).to(DEV).train()
     with pytest.raises(NotImplementedError, match="K != V"):
         bad(x, kv, kv)
+
+
+@pytest.mark.parametrize("B,S", [(64, 51), (32, 7), (8, 51), (64, 201)])
+def test_wgrad_blocked_row_maps(B, S):
+    """The heads' weight gradients (`DOSTransformer_phonon.py:93-95,105-109`): dY = the rows of ONE prediction branch inside a
+    [S*2B, H] tensor (div/mod row map), A = cat[energies broadcast over the crystals, graph broadcast over the bins] - through
+    the buffer-addressed fast path when the maps are chunk-aligned (32 | B) and through the generic path otherwise; finished
+    mode, grouped, against float64."""
+    o = ops()
+    H = 64
+    M = S * B
+    dpre = rnd(S * 2 * B, H, seed=1)
+    en, gr = rnd(S, H, seed=2), rnd(B, H, seed=3)
+    for branch in (0, 1):
+        dmap = o.rowmap(d=B, m=2 * B, c=1, off=branch * B)
+        segs = [o.seg(en, rmap=o.rowmap(d=B, m=1, c=0)), o.seg(gr, rmap=o.rowmap(d=B, m=0, c=1))]
+        ns = o.wgrad_splits(M, H, 2 * H)
+        slab, slab_b = _scratch(o, H, 2 * H, ns)
+        dw = torch.full((H, 2 * H), float("nan"), device=DEV)
+        db = torch.full((H,), float("nan"), device=DEV)
+        g = o.wgrad_desc(M, H, o.seg(dpre, rmap=dmap), segs, slab, slab_b, ns, dst=dw, dst_bias=db)
+        o.wgrad_grouped([g])
+        torch.cuda.synchronize()
+        dy = dpre.double().reshape(S, 2, B, H)[:, branch].reshape(M, H)
+        a = torch.cat([en.double()[:, None, :].expand(S, B, H), gr.double()[None, :, :].expand(S, B, H)], 2).reshape(M, 2 * H)
+        assert err(dw, dy.T @ a) < TOL and err(db, dy.sum(0)) < TOL
