@@ -1308,7 +1308,7 @@ constexpr int WSTG = 2 * BM * LDT;                        // floats of one stage
 // a fixed order whoever arrives last, so results are bitwise reproducible.  Scratch layout is tile-major
 // ([split][tile][64][64]): every partial tile is one contiguous, 16-byte aligned 16 KB block whatever N and K are.
 constexpr int WTILE = WT * WT;                            // floats of one partial tile
-constexpr int W_FLAG = 3 * WSTG - 4;                      // LDS word that broadcasts the ticket
+constexpr int W_FLAG = 2 * WSTG - 4;                      // LDS word that broadcasts the ticket (inside two stage buffers)
 
 __device__ __forceinline__ void wgrad_finish(const DosxWgrad& g, float* __restrict__ Sm, const float4 bs0, const float4 bs1,
                                              const bool do_bias, const int z, const int bx, const int by, const int ntk) {
@@ -1407,7 +1407,7 @@ __device__ __forceinline__ void wgrad_finish(const DosxWgrad& g, float* __restri
   if (tid == 0) __hip_atomic_store(g.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
 }
 
-template <int PRO, int VEC, int FAST>
+template <int PRO, int VEC, int FAST, int WNB = 3>
 __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, float* __restrict__ Sm) {
   const DosxWgrad& g = L.g;
   constexpr int STG = WSTG;
@@ -1468,6 +1468,23 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, 
       WSTAMP_S(0);
 #pragma unroll
       for (int i = 0; i < NSET; ++i) issue(sets[i], ms + i * BM);
+      if constexpr (WNB == 2) {
+        // TWO stage buffers (35 KB of LDS instead of 52: a weight-gradient workgroup then fits NEXT TO a 120 KB workgroup of
+        // the fused feed-forward kernels on one CU): chunk c+1 is stored while chunk c is multiplied
+        if (nch > 0) store(Sm, sets[0]);
+        issue(sets[0], ms + 2 * BM);
+        WSTAMP_S(1);
+        __syncthreads();                                  // chunk 0 is visible
+        for (int c = 0; c < nch; c += 2) {
+          if (c + 1 < nch) store(Sm + STG, sets[1]);      // buffer 1 was last read during iteration c - 1
+          issue(sets[1], ms + (c + 3) * BM);
+          __syncthreads();
+          if (c + 1 >= nch) break;
+          if (c + 2 < nch) store(Sm, sets[0]);
+          issue(sets[0], ms + (c + 4) * BM);
+          __syncthreads();
+        }
+      } else {
       if (nch > 0) store(Sm, sets[0]);
       issue(sets[0], ms + NSET * BM);
       if (nch > 1) store(Sm + STG, sets[1]);
@@ -1488,6 +1505,7 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, 
           WSTAMP_S(4 + 3 * (c + u));
           __syncthreads();
         }
+      }
       }
     };
     if constexpr (FAST) {
@@ -1639,6 +1657,15 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, 
       }
     };
     Frag f0, f1;
+    if constexpr (WNB == 2) {
+      for (int c = 0; c < nch; ++c) {
+        fetch(f0, c & 1, 0);
+        fetch(f1, c & 1, 1);
+        mma(f0);
+        mma(f1);
+        __syncthreads();
+      }
+    } else {
     int cur = 0;                                            // buffer of chunk c
     if (nch > 0) fetch(f0, 0, 0);
     for (int c = 0; c < nch; ++c) {
@@ -1651,6 +1678,7 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, 
       cur = nxt;
       WSTAMP(3 + 2 * c);
       __syncthreads();
+    }
     }
     WSTAMP(60);
 #pragma unroll
@@ -1716,8 +1744,9 @@ __device__ __forceinline__ void reduce_body(const DosxReduceJob& j, int slice, i
 
 // (two workgroups per CU: 4 waves per SIMD at <= 128 VGPRs.  Three per CU - 80 VGPRs, the LDS would hold them - measured
 //  no faster with two register sets, 76 vs 79 us per GNN-layer-pair group, and spills with four.)
+template <int WNB>
 __global__ __launch_bounds__(512, 4) void wgrad_grouped_kernel(const WgradGroup G) {
-  __shared__ __align__(16) float Sm[3 * WSTG];
+  __shared__ __align__(16) float Sm[WNB * WSTG];
   if ((int)blockIdx.x >= G.first_block[G.n]) {
     // ---- a reduction block: 2 slices of 256 elements (one per half of the workgroup) ----
     const int rb = (int)blockIdx.x - G.first_block[G.n];
@@ -1739,11 +1768,11 @@ __global__ __launch_bounds__(512, 4) void wgrad_grouped_kernel(const WgradGroup 
   const WgradLaunch& L = G.job[lo];
   const int bid = (int)blockIdx.x - G.first_block[lo];
   switch (L.variant) {             // workgroup-uniform
-    case 0: wgrad_body<DOSX_PRO_NONE, 1, 1>(L, bid, Sm); break;
-    case 1: wgrad_body<DOSX_PRO_PRELU, 1, 1>(L, bid, Sm); break;
-    case 2: wgrad_body<DOSX_PRO_LN_PRELU, 1, 1>(L, bid, Sm); break;
-    case 3: wgrad_body<DOSX_PRO_ROWLN, 1, 1>(L, bid, Sm); break;
-    case 4: wgrad_body<DOSX_PRO_NONE, 0, 0>(L, bid, Sm); break;      // unaligned operands (K = 118 atom features)
+    case 0: wgrad_body<DOSX_PRO_NONE, 1, 1, WNB>(L, bid, Sm); break;
+    case 1: wgrad_body<DOSX_PRO_PRELU, 1, 1, WNB>(L, bid, Sm); break;
+    case 2: wgrad_body<DOSX_PRO_LN_PRELU, 1, 1, WNB>(L, bid, Sm); break;
+    case 3: wgrad_body<DOSX_PRO_ROWLN, 1, 1, WNB>(L, bid, Sm); break;
+    case 4: wgrad_body<DOSX_PRO_NONE, 0, 0, WNB>(L, bid, Sm); break;      // unaligned operands (K = 118 atom features)
     default: break;
   }
 }
@@ -1961,7 +1990,13 @@ extern "C" int dosx_grad_flush(const DosxWgrad* jobs, int n_jobs, const DosxRedu
     if (G.n == 0 && G.nr == 0) return 0;
     G.first_block[G.n] = blocks_total;
     G.rfirst[G.nr] = rblocks;
-    hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(blocks_total + rblocks), dim3(512), 0, st, G);
+    static int wnb = 0;
+    if (wnb == 0) {
+      const char* e = getenv("DOSX_WGRAD_NB");
+      wnb = (e && atoi(e) == 2) ? 2 : 3;      // (2: 35 KB of LDS per workgroup - measured no faster in the step, 5 % slower alone)
+    }
+    if (wnb == 3) hipLaunchKernelGGL(wgrad_grouped_kernel<3>, dim3(blocks_total + rblocks), dim3(512), 0, st, G);
+    else hipLaunchKernelGGL(wgrad_grouped_kernel<2>, dim3(blocks_total + rblocks), dim3(512), 0, st, G);
     DOSX_LAUNCH_CHECK();
     G.n = 0;
     G.nr = 0;
