@@ -499,3 +499,63 @@ def test_wgrad_blocked_row_maps(B, S):
         dy = dpre.double().reshape(S, 2, B, H)[:, branch].reshape(M, H)
         a = torch.cat([en.double()[:, None, :].expand(S, B, H), gr.double()[None, :, :].expand(S, B, H)], 2).reshape(M, 2 * H)
         assert err(dw, dy.T @ a) < TOL and err(db, dy.sum(0)) < TOL
+
+
+def test_randomised_sweep_of_the_in_launch_reductions():
+    """Seeded random shapes through the two in-launch reductions of round 3: finished-mode weight gradients (any M, N, K incl.
+    unaligned K, with / without bias) and the message GEMM's segment sums over graphs with random in-degrees (isolated
+    nodes, over-full nodes of up to 400 edges, exact multiples of the tile height) - against float64 / the stand-alone
+    segment reduction."""
+    from dostransformer_amd import functional as Fn
+    from dostransformer_amd.batch import seg_tiles_host
+    o = ops()
+    rng = np.random.default_rng(7)
+    for trial in range(24):
+        M = int(rng.integers(1, 12000))
+        N = int(rng.choice([4, 16, 64, 100, 128, 256, 384]))
+        K = int(rng.choice([4, 24, 41, 64, 118, 128, 200, 256, 512]))
+        dy, a = rnd(M, N, seed=100 + trial), rnd(M, K, seed=200 + trial)
+        ns = o.wgrad_splits(M, N, K)
+        bias = bool(trial % 2)
+        slab, slab_b = _scratch(o, N, K, ns, bias)
+        dw = torch.full((N, K), float("nan"), device=DEV)
+        db = torch.full((N,), float("nan"), device=DEV) if bias else None
+        o.wgrad_grouped([o.wgrad_desc(M, N, o.seg(dy), [o.seg(a)], slab, slab_b, ns, dst=dw, dst_bias=db)])
+        torch.cuda.synchronize()
+        assert err(dw, dy.double().T @ a.double()) < TOL, (M, N, K)
+        if bias:
+            assert err(db, dy.double().sum(0)) < TOL, (M, N, K)
+    for trial in range(12):
+        n = int(rng.integers(1, 60))
+        deg = rng.integers(0, 30, size=n)
+        deg[rng.random(n) < 0.2] = 0
+        for _ in range(int(rng.integers(0, 4))):
+            deg[int(rng.integers(0, n))] = int(rng.choice([48, 49, 96, 97, 144, 200, 400]))
+        E = int(deg.sum())
+        if E == 0:
+            continue
+        H = int(rng.choice([16, 64, 128, 256]))
+        rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+        dst = torch.from_numpy(np.repeat(np.arange(n), deg).astype(np.int32)).to(DEV)
+        src = torch.from_numpy(rng.integers(0, n, size=E).astype(np.int32)).to(DEV)
+        tiles = torch.from_numpy(seg_tiles_host(rowptr)).to(DEV)
+        rp = torch.from_numpy(rowptr.astype(np.int32)).to(DEV)
+        inv = torch.from_numpy((1.0 / np.maximum(deg, 1)).astype(np.float32)).to(DEV)
+        gen = torch.Generator().manual_seed(trial)
+        P = {"k.0.weight": torch.randn(2 * H, 3 * H, generator=gen) * 0.1, "k.0.bias": torch.randn(2 * H, generator=gen),
+             "k.1.weight": torch.randn(2 * H, generator=gen), "k.1.bias": torch.randn(2 * H, generator=gen),
+             "k.2.weight": torch.tensor([0.25]), "k.3.weight": torch.randn(H, 2 * H, generator=gen) * 0.1,
+             "k.3.bias": torch.randn(H, generator=gen)}
+        P = {k: v.to(DEV) for k, v in P.items()}
+        x, e = torch.randn(n, H, generator=gen).to(DEV), torch.randn(E, H, generator=gen).to(DEV)
+        a = Fn.SegList([o.seg(x, rmap=o.rowmap(idx=src)), o.seg(x, rmap=o.rowmap(idx=dst)), o.seg(e)], [x, e])
+        scale = inv if trial % 2 else None
+        msg, _ = Fn.mlp_ln_fwd(P, "k", a, E, H)
+        agg0, e0 = torch.empty(n, H, device=DEV), torch.empty(E, H, device=DEV)
+        o.segment_reduce(msg, rp, scale, agg0, e, e0, n, E, H)
+        agg1, e1 = torch.full((n, H), float("nan"), device=DEV), torch.full((E, H), float("nan"), device=DEV)
+        Fn.mlp_ln_fwd(P, "k", a, E, H, segsum=(tiles, rp, scale, agg1, e, e1))
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(agg1).all()), (trial, deg.tolist())
+        assert float((agg1 - agg0).abs().max()) <= 4e-6 * float(agg0.abs().max() + 1e-6), (trial, deg.tolist())
+        assert torch.equal(e1, e0)
