@@ -20,8 +20,14 @@ extern "C" { __device__ unsigned long long dosx_attn_stamp_buf[64]; }
     if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0)                          \
       dosx_attn_stamp_buf[(slot)] = __builtin_amdgcn_s_memtime();                        \
   } while (0)
+#define ASTAMP_S(slot)                                                                   \
+  do {                                                                                   \
+    if (threadIdx.x == 256 && blockIdx.x == 0 && blockIdx.y == 0 && (slot) < 32)         \
+      dosx_attn_stamp_buf[32 + (slot)] = __builtin_amdgcn_s_memtime();                   \
+  } while (0)
 #else
 #define ASTAMP(slot) do { } while (0)
+#define ASTAMP_S(slot) do { } while (0)
 #endif
 
 namespace {
@@ -954,6 +960,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const DosxAttn a) {
   }
 
   f32x16 acc[KG][MAX_CT];
+  ASTAMP(0);
   if (wave_u >= 4) {
     // =============================== staging waves ===============================================
     const int st = tid - 256, row = st >> 4, cq = (st & 15) * 4;
@@ -1041,16 +1048,20 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const DosxAttn a) {
         Sc[row * LDP + jl] = ok ? q.ss[u] : 0.f;
       }
     };
+    ASTAMP_S(0);
     if (nit > 0) issue(s0, 0);
     if (nit > 1) issue(s1, 1);
     if (nit > 0) store(sm, s0);
     if (nit > 2) issue(s0, 2);
+    ASTAMP_S(1);
     __syncthreads();
     for (int c = 0; c < nit; c += 2) {
+      ASTAMP_S(2 + c);
       if (c + 1 < nit) {
         store(sm + STG, s1);
         if (c + 3 < nit) issue(s1, c + 3);
       }
+      ASTAMP_S(3 + c);
       __syncthreads();
       if (c + 1 >= nit) break;
       if (c + 2 < nit) {
@@ -1068,7 +1079,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const DosxAttn a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[kt][t][r] = 0.f;
     __syncthreads();
+    ASTAMP(1);
     for (int c = 0; c < nit; ++c) {
+      ASTAMP(2 + c);
       const float* dOs = sm + (c & 1) * STG;
       const float* Qs = dOs + DQC * g.LDH;
       const float* Pc = Qs + DQC * g.LDH;
@@ -1098,6 +1111,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const DosxAttn a) {
     }
   }
 
+  ASTAMP(30);
   // ---- result tile R[32*KG][LDH] (aliases the stage buffers) + 32 partial-sum slots behind it ----
   float* R = sm;
   float* Pp = sm + 32 * KG * g.LDH;                  // [32 slots][2][HP]
