@@ -202,6 +202,10 @@ _SIGS = {
     "dosx_attention_pkv_supported": [_I, _I],
     "dosx_attention_fwd": [C.POINTER(Attn), _P],
     "dosx_attention_bwd": [C.POINTER(Attn), _P],
+    "dosx_attn_pv": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dosx_attn_tv": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "dosx_attn_dp": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dosx_softmax_bwd": [_P, _P, _P, _P, _L, _I, _F, _P],
     "dosx_ln_rowdot": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "dosx_ln_rowdot_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "dosx_rowdot": [_P, _P, _P, _P, _I, _I, _I, _P],

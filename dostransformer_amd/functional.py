@@ -229,6 +229,7 @@ def _attn_desc(Sq, Bq, Nk, Bk, H, qs, qb, x, kvhat, gam, bet) -> Attn:
 
 
 DROP_MASK_LOG: Optional[list] = None      # tests: set to a list to receive (prefix, layer, mask tensor) of every drawn mask
+EDROP_MASK_LOG: Optional[list] = None     # ... (prefix, "x" | "k" | "v", mask) of the embed dropout (K != V path) ...
 FDROP_MASK_LOG: Optional[list] = None     # ... and (prefix, layer, "res1" | "relu" | "res2", mask) of the relu / res dropout sites
 
 
@@ -493,6 +494,151 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: Optional[torch.Tensor],
             dxin = dsum
         dx = dxin
     return dx
+
+
+# ------------------------------------------------------------------------------------------------
+# TransformerEncoder with K != V  (x_in_k is not x_in_v, or embed dropout: transformer.py:61-68 draws different masks for keys
+# and values).  No reference call site does this, so it is a correctness path: every layer runs unfused - three LayerNorm
+# launches (layer_norms[0] is shared by q, k and v, transformer.py:131-134), the softmax weights from the MFMA attention
+# kernel run on the keys, P.V and the whole attention backward from the building blocks of csrc/attention_kv.hip, the
+# feed-forward half as two GEMMs - with the four dropout sites as explicit multiplier masks.
+# ------------------------------------------------------------------------------------------------
+def encoder_kv_fwd(P: Params, pre: str, x: torch.Tensor, xk: torch.Tensor, xv: torch.Tensor, Sq: int, Bq: int, Nk: int, Bk: int,
+                   H: int, T: int, final_ln: bool = True, drop=None, fdrop=None):
+    """x [Sq*Bq, H] dense query rows, xk / xv [Nk*Bk, H] (the ORIGINAL keys / values: not updated between layers,
+    transformer.py:72-73).  drop = (p, seed, base) attention dropout, fdrop = (p_relu, p_res, seed, base)."""
+    dev = x.device
+    rows, krows = Sq * Bq, Nk * Bk
+    ones, zeros = torch.ones(H, device=dev), torch.zeros(H, device=dev)
+    lay = []
+    for t in range(T):
+        lp = f"{pre}.layers.{t}"
+        g0, b0 = P[lp + ".layer_norms.0.weight"], P[lp + ".layer_norms.0.bias"]
+
+        def ln(src, n):
+            y, xh, rs = _empty(dev, n, H), _empty(dev, n, H), _empty(dev, n)
+            ops.layernorm(src, g0, b0, y, xh, rs, n, H)
+            return y, xh, rs
+        q, qh, qr = ln(x, rows)
+        k, kh, kr = ln(xk, krows)
+        v, vh, vr = ln(xv, krows)
+        probs, scratch = _empty(dev, Bq, Sq, Nk), _empty(dev, rows, H)
+        a = _attn_desc(Sq, Bq, Nk, Bk, H, Bq, 1, q, k, ones, zeros)
+        a.flags = 1 | 2                                    # RAW_Q | NO_RESIDUAL: q and k are already normalised
+        a.out, a.probs = scratch.data_ptr(), probs.data_ptr()
+        ops.attention_fwd(a)                               # (only the softmax weights are used)
+        amask = None
+        if drop is not None and drop[0] > 0.0:
+            amask = _empty(dev, Bq, Sq, Nk)
+            ops.dropout_mask(amask, drop[0], drop[1], drop[2] + t)
+            if DROP_MASK_LOG is not None:
+                DROP_MASK_LOG.append((pre, t, amask))
+        att = _empty(dev, rows, H)
+        ops.attn_pv(probs, amask, v, att, Sq, Bq, Nk, Bk, H)
+        m1 = m2 = m3 = None
+        if fdrop is not None:
+            p_relu, p_res, fseed, fbase = fdrop
+
+            def draw(shape, p, kk):
+                if p <= 0.0:
+                    return None
+                m_ = _empty(dev, *shape)
+                ops.dropout_mask(m_, p, fseed, fbase + 3 * t + kk)
+                if FDROP_MASK_LOG is not None:
+                    FDROP_MASK_LOG.append((pre, t, ("res1", "relu", "res2")[kk], m_))
+                return m_
+            m1, m2, m3 = draw((rows, H), p_res, 0), draw((rows, 4 * H), p_relu, 1), draw((rows, H), p_res, 2)
+        x1, st1 = _empty(dev, rows, H), _empty(dev, rows, 2)
+        ops.mask_residual(att, m1, x, x1, st1, rows, H)
+        h = _empty(dev, rows, 4 * H)
+        ops.gemm(rows, 4 * H, [seg(x1)], P[lp + ".fc1.weight"], h, pro=PRO_ROWLN, pro_gamma=P[lp + ".layer_norms.1.weight"],
+                 pro_beta=P[lp + ".layer_norms.1.bias"], pro_stats=st1, bias=P[lp + ".fc1.bias"], act=ACT_RELU)
+        if m2 is not None:
+            ops.mask_residual(h, m2, None, h, None, rows, 4 * H)
+        y2, x2 = _empty(dev, rows, H), _empty(dev, rows, H)
+        ops.gemm(rows, H, [seg(h)], P[lp + ".fc2.weight"], y2, bias=P[lp + ".fc2.bias"])
+        ops.mask_residual(y2, m3, x1, x2, None, rows, H)
+        lay.append((q, qh, qr, k, kh, kr, v, vh, vr, probs, amask, x1, st1, h, (m1, m2, m3)))
+        x = x2
+    fin = None
+    if final_ln:
+        y, xhat, rstd = _empty(dev, rows, H), _empty(dev, rows, H), _empty(dev, rows)
+        ops.layernorm(x, P[pre + ".layer_norm.weight"], P[pre + ".layer_norm.bias"], y, xhat, rstd, rows, H)
+        fin, x = (xhat, rstd), y
+    return x, (lay, fin, Sq, Bq, Nk, Bk, H, T)
+
+
+def encoder_kv_bwd(P: Params, G: Params, pre: str, ctx, dy: torch.Tensor, sink: GradSink):
+    """Returns (dx [Sq*Bq,H], dxk [Nk*Bk,H], dxv [Nk*Bk,H])."""
+    lay, fin, Sq, Bq, Nk, Bk, H, T = ctx
+    dev = dy.device
+    rows, krows = Sq * Bq, Nk * Bk
+    r32, k32 = _rows32(rows), _rows32(krows)
+    dx = dy
+    if fin is not None:
+        part = sink.scratch(r32, 2 * H)
+        dx = _empty(dev, rows, H)
+        ops.layernorm_bwd(dy, fin[0], fin[1], P[pre + ".layer_norm.weight"], dx, part, rows, H)
+        sink.add(part, 0, G[pre + ".layer_norm.weight"], r32, 2 * H, H)
+        sink.add(part, H, G[pre + ".layer_norm.bias"], r32, 2 * H, H)
+    dxk = dxv = None
+    for t in reversed(range(T)):
+        lp = f"{pre}.layers.{t}"
+        q, qh, qr, k, kh, kr, v, vh, vr, probs, amask, x1, st1, h, (m1, m2, m3) = lay[t]
+        g0 = P[lp + ".layer_norms.0.weight"]
+        g1, b1 = P[lp + ".layer_norms.1.weight"], P[lp + ".layer_norms.1.bias"]
+        dx2 = dx
+        dyf = dx2
+        if m3 is not None:
+            dyf = _empty(dev, rows, H)
+            ops.mask_residual(dx2, m3, None, dyf, None, rows, H)
+        _wgrad_linear(sink, G, lp + ".fc2.weight", lp + ".fc2.bias", rows, H, seg(dyf), [seg(h)], keep=(dyf,))
+        dh = _empty(dev, rows, 4 * H)
+        ops.gemm(rows, 4 * H, [seg(dyf)], P[lp + ".fc2.weight"], dh, w_layout=1, epi=EPI_RELU_MASK, aux=h)
+        if m2 is not None:
+            ops.mask_residual(dh, m2, None, dh, None, rows, 4 * H)
+        _wgrad_linear(sink, G, lp + ".fc1.weight", lp + ".fc1.bias", rows, 4 * H, seg(dh), [seg(x1)], keep=(dh,),
+                      pro=PRO_ROWLN, pro_gamma=g1, pro_beta=b1, pro_stats=st1)
+        rgp = ops.gemm_partial_rows(rows, H, EPI_ROWLN_BWD)
+        part = sink.scratch(rgp, 2 * H)
+        dx1 = _empty(dev, rows, H)
+        ops.gemm(rows, H, [seg(dh)], P[lp + ".fc1.weight"], dx1, w_layout=1, epi=EPI_ROWLN_BWD, aux=x1, aux_stats=st1,
+                 epi_gamma=g1, res=dx2, partials=part, partial_ld=2 * H)
+        sink.add(part, 0, G[lp + ".layer_norms.1.weight"], rgp, 2 * H, H)
+        sink.add(part, H, G[lp + ".layer_norms.1.bias"], rgp, 2 * H, H)
+        datt = dx1
+        if m1 is not None:
+            datt = _empty(dev, rows, H)
+            ops.mask_residual(dx1, m1, None, datt, None, rows, H)
+        # attention: dV = (P o M)^T dAtt ; dP = dAtt V^T ; dS = softmax'(P, dP o M) ; dQ = dS K ; dK = dS^T Q
+        dv, dk, dq = _empty(dev, krows, H), _empty(dev, krows, H), _empty(dev, rows, H)
+        dpd, ds = _empty(dev, Bq, Sq, Nk), _empty(dev, Bq, Sq, Nk)
+        ops.attn_tv(probs, amask, datt, dv, Sq, Bq, Nk, Bk, H)
+        ops.attn_dp(datt, v, dpd, Sq, Bq, Nk, Bk, H)
+        ops.softmax_bwd(probs, amask, dpd, ds, Bq * Sq, Nk, H ** -0.5)
+        ops.attn_pv(ds, None, k, dq, Sq, Bq, Nk, Bk, H)
+        ops.attn_tv(ds, None, q, dk, Sq, Bq, Nk, Bk, H)
+        # the shared LayerNorm 0 behind q, k and v: three backward launches, their parameter-gradient partials accumulate
+        pq, pk, pv = sink.scratch(r32, 2 * H), sink.scratch(k32, 2 * H), sink.scratch(k32, 2 * H)
+        dxq, dk_in, dv_in = _empty(dev, rows, H), _empty(dev, krows, H), _empty(dev, krows, H)
+        ops.layernorm_bwd(dq, qh, qr, g0, dxq, pq, rows, H)
+        ops.layernorm_bwd(dk, kh, kr, g0, dk_in, pk, krows, H)
+        ops.layernorm_bwd(dv, vh, vr, g0, dv_in, pv, krows, H)
+        for prt, n32 in ((pq, r32), (pk, k32), (pv, k32)):
+            sink.add(prt, 0, G[lp + ".layer_norms.0.weight"], n32, 2 * H, H)
+            sink.add(prt, H, G[lp + ".layer_norms.0.bias"], n32, 2 * H, H)
+        dsum = _empty(dev, rows, H)
+        ops.mask_residual(dxq, None, dx1, dsum, None, rows, H)          # + the residual path of the attention half
+        dx = dsum
+        if dxk is None:
+            dxk, dxv = dk_in, dv_in
+        else:                                                           # the same keys / values feed every layer
+            nk_, nv_ = _empty(dev, krows, H), _empty(dev, krows, H)
+            ops.mask_residual(dk_in, None, dxk, nk_, None, krows, H)
+            ops.mask_residual(dv_in, None, dxv, nv_, None, krows, H)
+            dxk, dxv = nk_, nv_
+        sink._keep.extend([datt, dv, dk, dq, dpd, ds, dxq, dk_in, dv_in, dx1, dyf])
+    return dx, dxk, dxv
 
 
 # ------------------------------------------------------------------------------------------------

@@ -66,6 +66,50 @@ class _BareAttention(torch.autograd.Function):
         return dq.reshape(sq, b, h), dkv.reshape(nk, b, h), None
 
 
+class _BareAttentionKV(torch.autograd.Function):
+    """softmax(Q K^T * dim**-0.5) V with K is not V: the softmax weights from the MFMA kernel run on the keys, the products
+    with V (and the whole backward) from the plain building blocks of csrc/attention_kv.hip."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask=None):
+        sq, b, h = q.shape
+        nk = k.shape[0]
+        dev = q.device
+        q2, k2, v2 = q.contiguous().reshape(sq * b, h), k.contiguous().reshape(nk * b, h), v.contiguous().reshape(nk * b, h)
+        ones, zeros = torch.ones(h, device=dev), torch.zeros(h, device=dev)
+        scratch = torch.empty(sq * b, h, device=dev)
+        probs = torch.empty(b, sq, nk, device=dev)
+        a = Attn()
+        a.Sq, a.Bq, a.Nk, a.Bk, a.H = sq, b, nk, b, h
+        a.q_stride_s, a.q_stride_b, a.flags = b, 1, RAW_Q | NO_RESIDUAL
+        a.x, a.kvhat, a.gamma0, a.beta0 = q2.data_ptr(), k2.data_ptr(), ones.data_ptr(), zeros.data_ptr()
+        a.out, a.probs = scratch.data_ptr(), probs.data_ptr()
+        ops.attention_fwd(a)                                   # (its P.K output is discarded: only the weights are used)
+        out = torch.empty(sq * b, h, device=dev)
+        ops.attn_pv(probs, mask, v2, out, sq, b, nk, b, h)
+        ctx.mask = mask
+        ctx.save_for_backward(q2, k2, v2, probs)
+        ctx.dims = (sq, b, nk, h)
+        return out.reshape(sq, b, h)
+
+    @staticmethod
+    def backward(ctx, dout):
+        q2, k2, v2, probs = ctx.saved_tensors
+        sq, b, nk, h = ctx.dims
+        dev, mask = q2.device, ctx.mask
+        dout2 = dout.contiguous().reshape(sq * b, h).float()
+        dv = torch.empty(nk * b, h, device=dev)
+        ops.attn_tv(probs, mask, dout2, dv, sq, b, nk, b, h)
+        dpd = torch.empty(b, sq, nk, device=dev)
+        ops.attn_dp(dout2, v2, dpd, sq, b, nk, b, h)
+        ds = torch.empty(b, sq, nk, device=dev)
+        ops.softmax_bwd(probs, mask, dpd, ds, b * sq, nk, h ** -0.5)
+        dq, dk = torch.empty(sq * b, h, device=dev), torch.empty(nk * b, h, device=dev)
+        ops.attn_pv(ds, None, k2, dq, sq, b, nk, b, h)
+        ops.attn_tv(ds, None, q2, dk, sq, b, nk, b, h)
+        return dq.reshape(sq, b, h), dk.reshape(nk, b, h), dv.reshape(nk, b, h), None
+
+
 class MultiheadAttention(nn.Module):
     """Same constructor / parameters / forward contract as `multihead_attention.py:9-76`."""
 
@@ -105,9 +149,11 @@ class MultiheadAttention(nn.Module):
         assert embed_dim == self.embed_dim
         assert list(query.size()) == [tgt_len, bsz, embed_dim]
         assert key.size() == value.size()
-        if key is not value and not (key.data_ptr() == value.data_ptr() and key.stride() == value.stride()):
-            raise NotImplementedError("the fused kernel shares K and V (every reference call site passes the "
-                                      "same tensor, DOSTransformer_phonon.py:88,97,99)")
+        # every reference call site passes the same tensor for key and value (DOSTransformer_phonon.py:88,97,99): that is
+        # the fused kernel's case; a different value tensor takes the general path (_BareAttentionKV)
+        same_kv = key is value or (key.data_ptr() == value.data_ptr() and key.stride() == value.stride())
+        if not query.is_cuda:
+            raise RuntimeError("MultiheadAttention runs only on an MI355X through libdosx (no CPU fallback)")
         mask = None
         if self.training and self.attn_dropout > 0.0:          # F.dropout(attn_weights, p, training) (`:70`)
             seed = getattr(self, "_drop_seed", None)
@@ -119,5 +165,8 @@ class MultiheadAttention(nn.Module):
             mask = torch.empty(bsz, tgt_len, key.shape[0], device=query.device, dtype=torch.float32)
             ops.dropout_mask(mask, float(self.attn_dropout), seed, 0)
             self.last_drop_mask = mask
-        out = _BareAttention.apply(query.float(), key.float(), mask)
+        if same_kv:
+            out = _BareAttention.apply(query.float(), key.float(), mask)
+        else:
+            out = _BareAttentionKV.apply(query.float(), key.float(), value.float(), mask)
         return out.to(query.dtype)

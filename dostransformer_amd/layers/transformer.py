@@ -89,6 +89,62 @@ class _EncoderFn(torch.autograd.Function):
         return (dx.reshape(sq, b, h), dkv_in, None, None, None) + grads
 
 
+class _EncoderKVFn(torch.autograd.Function):
+    """The encoder with K != V (x_in_k is not x_in_v and / or embed dropout): functional.encoder_kv_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, x, xk, xv, enc, names, skip_final, *params):
+        sq, b, h = x.shape
+        nk = xk.shape[0]
+        dev = x.device
+        P = {"enc." + n: p.detach() for n, p in zip(names, params)}
+        x2 = x.detach().contiguous().reshape(sq * b, h)
+        k2 = xk.detach().contiguous().reshape(nk * b, h)
+        v2 = xv.detach().contiguous().reshape(nk * b, h)
+        emasks = (None, None, None)
+        pe = float(enc.dropout or 0.0)
+        if enc.training and pe > 0.0:                       # transformer.py:61-68: three independent draws
+            seed = enc._seed(dev)
+            ms = []
+            for i, (t, name) in enumerate(((x2, "x"), (k2, "k"), (v2, "v"))):
+                m = torch.empty_like(t)
+                ops.dropout_mask(m, pe, seed, 2000 + i)
+                if Fn.EDROP_MASK_LOG is not None:
+                    Fn.EDROP_MASK_LOG.append(("enc", name, m))
+                ms.append(m)
+            emasks = tuple(ms)
+            xd, kd, vd = torch.empty_like(x2), torch.empty_like(k2), torch.empty_like(v2)
+            ops.mask_residual(x2, emasks[0], None, xd, None, sq * b, h)
+            ops.mask_residual(k2, emasks[1], None, kd, None, nk * b, h)
+            ops.mask_residual(v2, emasks[2], None, vd, None, nk * b, h)
+            x2, k2, v2 = xd, kd, vd
+        y, c = Fn.encoder_kv_fwd(P, "enc", x2, k2, v2, sq, b, nk, b, h, len(enc.layers), final_ln=not skip_final,
+                                 drop=enc._dropout(dev), fdrop=enc._fdropout(dev))
+        enc._bump_seed()
+        ctx.c, ctx.P, ctx.names, ctx.emasks = c, P, names, emasks
+        ctx.dims = (sq, b, nk, h)
+        return y.reshape(sq, b, h)
+
+    @staticmethod
+    def backward(ctx, dy):
+        sq, b, nk, h = ctx.dims
+        dev = dy.device
+        G = {k: torch.zeros_like(v) for k, v in ctx.P.items() if ".self_attn." not in k}
+        sink = ops.GradSink(dev)
+        dx, dk, dv = Fn.encoder_kv_bwd(ctx.P, G, "enc", ctx.c, dy.contiguous().reshape(sq * b, h).float(), sink)
+        sink.flush()
+        sink.release()
+        outs = []
+        for g_, m, n in ((dx, ctx.emasks[0], sq * b), (dk, ctx.emasks[1], nk * b), (dv, ctx.emasks[2], nk * b)):
+            if m is not None:
+                o = torch.empty_like(g_)
+                ops.mask_residual(g_, m, None, o, None, n, h)
+                g_ = o
+            outs.append(g_)
+        grads = tuple(G.get("enc." + n) for n in ctx.names)
+        return (outs[0].reshape(sq, b, h), outs[1].reshape(nk, b, h), outs[2].reshape(nk, b, h), None, None, None) + grads
+
+
 class TransformerEncoder(nn.Module):
     """`transformer.py:8-44` constructor, `:46-79` forward contract ((seq, batch, dim) tensors)."""
 
@@ -109,15 +165,13 @@ class TransformerEncoder(nn.Module):
         if self.normalize:
             self.layer_norm = LayerNorm(embed_dim)
 
-    def _check_dropouts(self):
-        """attn_dropout (the only one a reference call site sets: DOSTransformer*.py:27-38 via --attn_drop) is implemented in
-        the attention kernels; relu / res dropout (transformer.py:137,145-147) run the layer unfused with explicit
-        multiplier masks (functional.encoder_fwd, fdrop).  Embed dropout draws DIFFERENT masks for keys and values
-        (transformer.py:61-68), i.e. K != V, which the K == V kernels cannot express: it raises instead of being ignored."""
-        if self.training and self.dropout > 0.0:
-            raise NotImplementedError("embed_dropout > 0 is not implemented in the fused MI355X path: it makes K != V "
-                                      "(no reference call site sets it: DOSTransformer_phonon.py:27-38; default "
-                                      "transformer.py:22-23); attn / relu / res dropout are supported")
+    def _seed(self, device):
+        """device-resident dropout seed (starts from torch's RNG; bumped once per forward call)"""
+        seed = getattr(self, "_drop_seed", None)
+        if seed is None or seed.device != device:
+            seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(device)
+            object.__setattr__(self, "_drop_seed", seed)
+        return seed
 
     def _fdropout(self, device):
         """None or (p_relu, p_res, seed_dev, stream_base) for Fn.encoder_fwd: relu / res dropout of the layers (all layers
@@ -127,11 +181,7 @@ class TransformerEncoder(nn.Module):
         p_relu, p_res = float(self.layers[0].relu_dropout or 0.0), float(self.layers[0].res_dropout or 0.0)
         if p_relu <= 0.0 and p_res <= 0.0:
             return None
-        seed = getattr(self, "_drop_seed", None)
-        if seed is None or seed.device != device:
-            seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(device)
-            object.__setattr__(self, "_drop_seed", seed)
-        return p_relu, p_res, seed, 1000
+        return p_relu, p_res, self._seed(device), 1000
 
     def _dropout(self, device):
         """None (eval / p = 0) or (p, seed_dev, stream_base) for Fn.encoder_fwd; the seed starts from torch's RNG and is
@@ -139,11 +189,7 @@ class TransformerEncoder(nn.Module):
         p = float(self.attn_dropout or 0.0)
         if not self.training or p <= 0.0:
             return None
-        seed = getattr(self, "_drop_seed", None)
-        if seed is None or seed.device != device:
-            seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(device)
-            object.__setattr__(self, "_drop_seed", seed)
-        return p, seed, 0
+        return p, self._seed(device), 0
 
     def _bump_seed(self):
         """one bump per forward call (after the call's masks have been drawn from the current value)"""
@@ -155,14 +201,17 @@ class TransformerEncoder(nn.Module):
         if x_in_k is None or x_in_v is None:
             # upstream leaves x_k unbound here and crashes (transformer.py:64-73); be explicit instead
             raise ValueError("TransformerEncoder needs x_in_k and x_in_v (pass x_in for self attention)")
-        if x_in_k is not x_in_v:
-            raise NotImplementedError("fused path shares K and V (every reference call site does)")
         if not x_in.is_cuda:
             raise RuntimeError("TransformerEncoder runs only on an MI355X through libdosx (no CPU fallback)")
-        self._check_dropouts()
         live = [(n, p) for n, p in self.named_parameters() if ".self_attn." not in n]
         names = tuple(n for n, _ in live)
         params = tuple(p for _, p in live)
+        if x_in_k is not x_in_v or (self.training and float(self.dropout or 0.0) > 0.0):
+            # K != V - different tensors, or embed dropout, which draws different masks for keys and values
+            # (transformer.py:61-68): the general, unfused path.  Every reference call site passes one tensor for both and
+            # leaves embed dropout at 0 (DOSTransformer_phonon.py:27-38,88,97,99): that is the fused path below.
+            y = _EncoderKVFn.apply(x_in.float(), x_in_k.float(), x_in_v.float(), self, names, _skip_final_ln, *params)
+            return y.to(x_in.dtype)
         kv = None if x_in_k is x_in else x_in_k.float()
         y = _EncoderFn.apply(x_in.float(), kv, self, names, _skip_final_ln, *params)
         return y.to(x_in.dtype)

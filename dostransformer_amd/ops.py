@@ -868,6 +868,24 @@ def attention_bwd(a: Attn):
           w=lambda: (f"{name}[{_attn_shape(a)}]", "attn_bwd", "mfma", 4.0 * halves * a.Bq * a.Sq * a.Nk * a.H))
 
 
+def attn_pv(A, mask, V, out, Sq, Bq, Nk, Bk, H):
+    """out[(s,bq)] = sum_j (A o mask)[bq,s,j] V[(j, bq % Bk)]   (K != V attention, include/dosx.h)"""
+    _call("dosx_attn_pv", _p(A), _p(mask), _p(V), _p(out), Sq, Bq, Nk, Bk, H, _stream())
+
+
+def attn_tv(A, mask, X, out, Sq, Bq, Nk, Bk, H, accumulate=False):
+    """out[(j,bk)] (+)= sum_bq sum_s (A o mask)[bq,s,j] X[(s,bq)]"""
+    _call("dosx_attn_tv", _p(A), _p(mask), _p(X), _p(out), Sq, Bq, Nk, Bk, H, int(accumulate), _stream())
+
+
+def attn_dp(X, V, dP, Sq, Bq, Nk, Bk, H):
+    _call("dosx_attn_dp", _p(X), _p(V), _p(dP), Sq, Bq, Nk, Bk, H, _stream())
+
+
+def softmax_bwd(P, mask, dPd, dS, rows, Nk, scale):
+    _call("dosx_softmax_bwd", _p(P), _p(mask), _p(dPd), _p(dS), int(rows), int(Nk), float(scale), _stream())
+
+
 def ln_rowdot(x, gamma, beta, w, b, xhat, rstd, dos, S, Bq, H):
     _call("dosx_ln_rowdot", _p(x), _p(gamma), _p(beta), _p(w), _p(b), _p(xhat), _p(rstd), _p(dos), S, Bq, H, _stream(),
           w=lambda: ("ln_rowdot", "ln_rowdot_kernel", "hbm", 8.0 * S * Bq * H))

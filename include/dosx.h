@@ -320,6 +320,22 @@ int dosx_attention_pkv_supported(int Nk, int H);
 int dosx_attention_fwd(const DosxAttn* a, dosx_stream_t stream);
 int dosx_attention_bwd(const DosxAttn* a, dosx_stream_t stream);
 
+/* Attention with K != V (`multihead_attention.py:49-76` takes any key / value pair; embed dropout, `transformer.py:61-68`,
+ * draws different masks for keys and values).  No reference call site does that, so the MFMA kernels above are built for
+ * K = V; the general case is composed from them and these building blocks (csrc/attention_kv.hip: one wave per output row,
+ * deterministic, not a hot path).  A / mask / dP: [Bq, Sq, Nk]; X, out rows (s, bq) at s*Bq + bq; V rows (j, bk) at j*Bk + bk:
+ *   dosx_attn_pv:     out[(s,bq)] = sum_j (A o mask)[bq,s,j] V[(j, bq % Bk)]                 (P.V, and dQ = dS.K)
+ *   dosx_attn_tv:     out[(j,bk)] (+)= sum_{bq = bk mod Bk} sum_s (A o mask)[bq,s,j] X[(s,bq)]   (dV = P^T dOut, dK = dS^T Q)
+ *   dosx_attn_dp:     dP[bq,s,j] = X[(s,bq)] . V[(j, bq % Bk)]
+ *   dosx_softmax_bwd: dS = scale * P o (dPd o mask - rowsum(dPd o mask o P))                   (rows = Bq*Sq) */
+int dosx_attn_pv(const float* A, const float* mask, const float* V, float* out, int Sq, int Bq, int Nk, int Bk, int H,
+                 dosx_stream_t stream);
+int dosx_attn_tv(const float* A, const float* mask, const float* X, float* out, int Sq, int Bq, int Nk, int Bk, int H,
+                 int accumulate, dosx_stream_t stream);
+int dosx_attn_dp(const float* X, const float* V, float* dP, int Sq, int Bq, int Nk, int Bk, int H, dosx_stream_t stream);
+int dosx_softmax_bwd(const float* P, const float* mask, const float* dPd, float* dS, long long rows, int Nk, float scale,
+                     dosx_stream_t stream);
+
 /* out_layer (nn.Linear(H,1), DOSTransformer_phonon.py:101,115) fused with the encoder's final
  * LayerNorm (layers/transformer.py:76-77) and the squeeze/transposed store:
  *   y[r] = (xhat[r]*gamma+beta) . w + b ;  dos[(r % Bq) , r / Bq] = y[r]   (dos is [Bq, S]) */

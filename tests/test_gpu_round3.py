@@ -415,7 +415,7 @@ def test_attention_backward_in_one_launch(Sq, Bq, Nk, Bk, H, drop):
 def test_transformer_encoder_relu_and_res_dropout_match_oracle(mode, p_attn, p_relu, p_res):
     """TransformerEncoder(relu_dropout, res_dropout) (`transformer.py:137,145-147`) in training mode: outputs and every
     gradient equal the oracle's with the SAME Bernoulli draws (the masks the kernels used, captured per layer and site);
-    eval mode ignores them; embed dropout (K != V) raises."""
+    eval mode ignores them."""
     from oracle import dos_oracle as O
     from dostransformer_amd import functional as Fn
     from dostransformer_amd.layers import TransformerEncoder
@@ -470,9 +470,6 @@ def test_transformer_encoder_relu_and_res_dropout_match_oracle(mode, p_attn, p_r
         ye = enc(x, kv, kv) if mode == "cross" else enc(x, x, x)
         y0 = O.transformer_encoder({k: v.detach() for k, v in p64.items()}, "e", x64.detach(), src.detach(), src.detach(), T)
     assert float((ye.cpu().double() - y0).abs().max()) < 3e-5
-    bad = TransformerEncoder(embed_dim=Hh, num_heads=1, layers=1, embed_dropout=0.1).to(DEV).train()
-    with pytest.raises(NotImplementedError, match="K != V"):
-        bad(x, kv, kv)
 
 
 @pytest.mark.parametrize("B,S", [(64, 51), (32, 7), (8, 51), (64, 201)])
@@ -559,3 +556,93 @@ def test_randomised_sweep_of_the_in_launch_reductions():
         assert bool(torch.isfinite(agg1).all()), (trial, deg.tolist())
         assert float((agg1 - agg0).abs().max()) <= 4e-6 * float(agg0.abs().max() + 1e-6), (trial, deg.tolist())
         assert torch.equal(e1, e0)
+
+
+def test_multihead_attention_with_key_is_not_value():
+    """`MultiheadAttention.forward(query, key, value)` with a value tensor that is not the key (`multihead_attention.py:49-76`
+    takes any pair of equal shape; no reference call site does): outputs and the three input gradients against float64
+    autograd of the same expression, with and without attention dropout (the mask the kernels used)."""
+    from dostransformer_amd.layers.multihead_attention import MultiheadAttention
+    torch.manual_seed(0)
+    for H, S, B, Nk, p in ((32, 51, 4, 9, 0.0), (128, 20, 3, 70, 0.3), (16, 7, 2, 5, 0.0)):
+        mha = MultiheadAttention(H, 1, attn_dropout=p).to(DEV).train()
+        gen = torch.Generator().manual_seed(3)
+        q = torch.randn(S, B, H, generator=gen).to(DEV).requires_grad_(True)
+        k = torch.randn(Nk, B, H, generator=gen).to(DEV).requires_grad_(True)
+        v = torch.randn(Nk, B, H, generator=gen).to(DEV).requires_grad_(True)
+        w = torch.randn(S, B, H, generator=gen).to(DEV)
+        out = mha(q, k, v)
+        (out * w).sum().backward()
+        m = mha.last_drop_mask.double() if p > 0 else None
+        q2, k2, v2 = (t.detach().double().requires_grad_(True) for t in (q, k, v))
+        a = torch.softmax(torch.bmm(q2.transpose(0, 1), k2.permute(1, 2, 0)) * H ** -0.5, -1)
+        if m is not None:
+            a = a * m
+        ref = torch.bmm(a, v2.transpose(0, 1)).transpose(0, 1)
+        (ref * w.double()).sum().backward()
+        assert err(out.detach(), ref.detach()) < 3e-5
+        for g_, r_ in ((q.grad, q2.grad), (k.grad, k2.grad), (v.grad, v2.grad)):
+            assert err(g_, r_) < 5e-5
+        assert mha.in_proj_weight.grad is None
+
+
+@pytest.mark.parametrize("case", ["kv_differ", "embed_dropout", "everything"])
+def test_transformer_encoder_with_k_not_v_matches_oracle(case):
+    """TransformerEncoder with x_in_k is not x_in_v, and with embed dropout (`transformer.py:61-68`: independent masks on the
+    queries, keys and values - so K != V even when one tensor is passed for both): outputs and every gradient against the
+    oracle with the same draws.  `everything`: all four dropouts at once on different key / value tensors."""
+    from oracle import dos_oracle as O
+    from dostransformer_amd import functional as Fn
+    from dostransformer_amd.layers import TransformerEncoder
+    torch.manual_seed(0)
+    Hh, S, Bq, Nk, T = 32, 51, 4, 9, 2
+    kw = {"kv_differ": {}, "embed_dropout": dict(embed_dropout=0.2),
+          "everything": dict(embed_dropout=0.2, attn_dropout=0.25, relu_dropout=0.3, res_dropout=0.2)}[case]
+    enc = TransformerEncoder(embed_dim=Hh, num_heads=1, layers=T, **kw).to(DEV).train()
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if "layer_norm" in n or "bias" in n:
+                p.add_(0.1 * torch.randn_like(p))
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(S, Bq, Hh, generator=gen).to(DEV).requires_grad_(True)
+    k = torch.randn(Nk, Bq, Hh, generator=gen).to(DEV).requires_grad_(True)
+    v = torch.randn(Nk, Bq, Hh, generator=gen).to(DEV).requires_grad_(True)
+    w = torch.randn(S, Bq, Hh, generator=gen).to(DEV)
+    same = case == "embed_dropout"
+    Fn.DROP_MASK_LOG, Fn.FDROP_MASK_LOG, Fn.EDROP_MASK_LOG = [], [], []
+    try:
+        y = enc(x, k, k) if same else enc(x, k, v)
+        amasks = [m.clone() for _, _, m in Fn.DROP_MASK_LOG]
+        fmasks = [(t, kk, m.clone()) for _, t, kk, m in Fn.FDROP_MASK_LOG]
+        emasks = {n: m.clone() for _, n, m in Fn.EDROP_MASK_LOG}
+    finally:
+        Fn.DROP_MASK_LOG = Fn.FDROP_MASK_LOG = Fn.EDROP_MASK_LOG = None
+    (y * w).sum().backward()
+    assert (len(emasks) == 3) == ("embed_dropout" in kw)
+    masks = [dict() for _ in range(T)]
+    for t, m in enumerate(amasks):
+        masks[t]["attn"] = m.double().cpu()
+    for t, kk, m in fmasks:
+        masks[t][kk] = m.double().cpu()
+    p64 = {"e." + n: t_.detach().double().cpu().requires_grad_(True) for n, t_ in enc.state_dict().items() if t_.is_floating_point()}
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    k64 = k.detach().double().cpu().requires_grad_(True)
+    v64 = k64 if same else v.detach().double().cpu().requires_grad_(True)
+    em = lambda t, n: t if n not in emasks else t * emasks[n].double().cpu().reshape(t.shape)
+    yr = O.transformer_encoder(p64, "e", em(x64, "x"), em(k64, "k"), em(v64, "v"), T, masks)
+    (yr * w.double().cpu()).sum().backward()
+    assert float((y.detach().cpu().double() - yr.detach()).abs().max()) < 3e-5
+    rel = lambda a, b: float((a.cpu().double() - b).abs().max() / (b.abs().max() + 1e-12))
+    assert rel(x.grad, x64.grad) < 1e-4 and rel(k.grad, k64.grad) < 1e-4
+    if not same:
+        assert rel(v.grad, v64.grad) < 1e-4
+    for n, p in enc.named_parameters():
+        if ".self_attn." in n:
+            assert p.grad is None
+        else:
+            assert rel(p.grad, p64["e." + n].grad) < 2e-4, n
+    enc.eval()                                             # eval mode: no dropout anywhere; K != V still honoured
+    with torch.no_grad():
+        ye = enc(x, k, k) if same else enc(x, k, v)
+        y0 = O.transformer_encoder({n: t_.detach() for n, t_ in p64.items()}, "e", x64.detach(), k64.detach(), v64.detach(), T)
+    assert float((ye.cpu().double() - y0).abs().max()) < 3e-5
