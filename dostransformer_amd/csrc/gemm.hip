@@ -1858,6 +1858,18 @@ extern "C" int dosx_wgrad_splits(int M, int N, int K) {
     if (max_split < 1) max_split = 8;
   }
   if (s > max_split) s = max_split;
+  // ... but no workgroup lives longer than max_chunks 32-row chunks: a weight-gradient workgroup cannot be pre-empted, and a
+  // kernel of the dgrad chain that arrives while long-lived ones hold the CUs waits for them (eDOS, M = 25728 rows at 8
+  // splits: 100 chunks = ~70 us per workgroup; the two 15-us head dgrad GEMMs behind the self encoder took 228 us each)
+  static int max_chunks = -1;
+  if (max_chunks < 0) {
+    const char* e = getenv("DOSX_WGRAD_MAXCHUNKS");
+    max_chunks = e ? atoi(e) : 0;
+  }
+  if (max_chunks > 0) {
+    const int need = ceil_div(M, BM * max_chunks);
+    if (s < need) s = need < 64 ? need : 64;
+  }
   if (s < 1) s = 1;
   return s;
 }
