@@ -345,7 +345,8 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
 
 
 _FUSED_FFN_BWD = __import__("os").environ.get("DOSX_FUSED_FFN_BWD", "1") == "1"
-_FUSED_DKV = __import__("os").environ.get("DOSX_FUSED_DKV", "1") == "1"          # one-launch attention backward (Nk <= 64)
+_FUSED_DKV = __import__("os").environ.get("DOSX_FUSED_DKV", "1") == "1"
+_LATE_SELF_FLUSH = __import__("os").environ.get("DOSX_LATE_SELF_FLUSH", "0") == "1"      # (measured: no gain)          # one-launch attention backward (Nk <= 64)
 _FUSED_FIN_BWD = __import__("os").environ.get("DOSX_FUSED_FIN_BWD", "1") == "1"
 _FUSED_HEAD_FWD = __import__("os").environ.get("DOSX_FUSED_HEAD_FWD", "1") == "1"
 
@@ -844,7 +845,7 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
         sink.flush_on_side()                  # (weight-gradient stream: this encoder's jobs run under the next one's backward)
     dkvs = _empty(dev, rows2, H)              # self-attention: every row is a key row, the first layer overwrites
     ddosin = encoder_bwd(P, G, "transformer_self", c2, dhs, dkvs, sink, dkv_fresh=True, kv_needed_next=True)
-    if sink.wside is not None:
+    if sink.wside is not None and not _LATE_SELF_FLUSH:
         sink.flush_on_side()
     sink.join()          # dkvs is produced on the side stream
     dpre = _empty(dev, rows2, H)         # key-side LN backward + the LeakyReLU backward behind it, one launch
@@ -856,6 +857,10 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
     dE1 = _empty(dev, S * B, H)
     ops.gemm(S * B, H, [seg(dpre, rmap=map0)], Wfc[:, :H], dE1, w_layout=1)
     ops.gemm(S * B, H, [seg(dpre, rmap=map1)], Wfp[:, :H], dE1, w_layout=1, res=dE1)
+    if sink.wside is not None and _LATE_SELF_FLUSH:
+        # experiment: the self encoder's weight gradients (+ the two heads') start behind the small head kernels above
+        # instead of in front of them (where the group's long-lived workgroups make these 8-15 us kernels wait)
+        sink.flush_on_side()
     # graph / prompt inputs are constant over the energy axis: reduce over s first, then a [2B,H] GEMM.  Their
     # consumers (decoder backward, prompt-embedding gradient) come after the first encoder's backward: side stream.
     R = _empty(dev, 2 * B, H)
