@@ -18,9 +18,6 @@ from . import ops
 from .batch import SEG_TILE_ROWS, CrystalBatch, GraphMeta, _EDGE_FIELDS, seg_tile_bound, seg_tiles_host
 
 
-_PIN_RING = int(__import__("os").environ.get("DOSX_PIN_RING", "64"))      # pinned staging buffers of collate_into (0: pageable)
-
-
 class DeviceDataset:
     def __init__(self, crystals: Sequence[Dict[str, object]], device, dtype: Optional[torch.dtype] = None):
         crystals = list(crystals)
@@ -165,22 +162,7 @@ class DeviceDataset:
         tiled = m.seg_tile is not None
         if tiled:
             parts.append(np.concatenate([[0], np.cumsum(self.tile_cnt[idx])]).astype(np.int32))
-        # the per-step index arrays travel through a ring of PINNED host buffers: a copy from pageable memory is synchronous
-        # for the host (it would wait until the stream reaches the copy, i.e. for the previous step to finish) - with pinned
-        # memory the host keeps running ahead of the GPU.  A slot is reused after _PIN_RING more collates: the replayed step
-        # in between bounds how far the host can run ahead (HIP's queue depth), far below that.
-        flat = np.concatenate(parts)
-        ring = getattr(self, "_pin_ring", None)
-        if ring is None or (ring and ring[0].numel() < flat.size):
-            ring = [torch.empty(max(flat.size, 1024), dtype=torch.int32).pin_memory() for _ in range(_PIN_RING)] \
-                if _PIN_RING > 0 else []
-            self._pin_ring, self._pin_pos = ring, 0
-        if ring:
-            host = ring[self._pin_pos][:flat.size]
-            self._pin_pos = (self._pin_pos + 1) % len(ring)
-            host.numpy()[:] = flat
-        else:
-            host = torch.from_numpy(flat)
+        host = torch.from_numpy(np.concatenate(parts))
         small[:host.numel()].copy_(host, non_blocking=True)
         d = Collate()
         d.B, d.N, d.E, d.N_pad, d.E_pad, d.n_max = B, int(out_np[-1]), int(out_ep[-1]), m.num_nodes, m.num_edges, m.n_max
