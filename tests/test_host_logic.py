@@ -208,3 +208,48 @@ def test_optimizer_moments_follow_rehomed_parameters():
     for n, o in zip(fp2.names, fp2.offsets):
         assert torch.equal(m2[o:o + fp2.P[n].numel()], want[n]), n
         assert float(v2[o:o + fp2.P[n].numel()].min()) == 2.0
+
+
+def test_seg_tiles_host_properties():
+    """Node-aligned row tiles of the message GEMM (batch.seg_tiles_host), incl. over-full nodes (> 48 incoming edges) cut into
+    chunk tiles and isolated nodes: monotone boundaries, <= 48 rows per tile, every node owned exactly once, every edge covered
+    exactly once, chunk k of a node starts 48*k rows into its segment whatever surrounds it, consecutive tiles hold more than
+    48 rows together (what seg_tile_bound relies on)."""
+    from dostransformer_amd.batch import SEG_TILE_ROWS, seg_tile_bound, seg_tiles_host
+    R = SEG_TILE_ROWS
+    rng = np.random.default_rng(0)
+    for trial in range(400):
+        n = int(rng.integers(1, 30))
+        deg = rng.integers(0, 30, size=n)
+        deg[rng.random(n) < 0.3] = 0
+        for _ in range(int(rng.integers(0, 5))):
+            deg[int(rng.integers(0, n))] = int(rng.choice([48, 49, 60, 96, 97, 144, 145, 200]))
+        rp = np.concatenate([[0], np.cumsum(deg)])
+        t = seg_tiles_host(rp)
+        assert t.shape[0] == 3 and t.dtype == np.int32
+        eb, nb, pi = t
+        T = t.shape[1] - 1
+        assert eb[0] == 0 and nb[0] == 0 and eb[-1] == rp[-1] and nb[-1] == n and pi[-1] == 0
+        assert (np.diff(eb) >= 0).all() and (np.diff(nb) >= 0).all() and np.diff(eb).max(initial=0) <= R
+        cover, owned = np.zeros(n, int), np.zeros(n, int)
+        for i in range(T):
+            lo, hi = nb[i], nb[i + 1]
+            whole = range(lo, hi)
+            if pi[i]:
+                ci, nc = pi[i] >> 16, pi[i] & 0xffff
+                assert deg[lo] > R and nc == -(-deg[lo] // R) and 0 <= ci < nc
+                assert eb[i] == rp[lo] + ci * R                        # the chunk is cut from the START of the node's segment
+                rows = min(rp[lo + 1], eb[i + 1]) - eb[i]
+                assert rows == (R if ci < nc - 1 else deg[lo] - ci * R)
+                assert (hi == lo) if ci < nc - 1 else (hi >= lo + 1)
+                cover[lo] += rows
+                owned[lo] += ci == nc - 1
+                whole = range(lo + 1, hi)
+            for k in whole:
+                assert deg[k] <= R and rp[k] >= eb[i] and rp[k + 1] <= eb[i + 1]
+                cover[k] += deg[k]
+                owned[k] += 1
+        assert (cover == deg).all() and (owned == 1).all()
+        rows = np.diff(eb)
+        assert all(i == 0 and rows[0] == 0 for i in range(T - 1) if rows[i] + rows[i + 1] <= R)
+        assert T <= seg_tile_bound(n, int(rp[-1]), 1)
