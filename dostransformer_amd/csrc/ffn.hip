@@ -322,8 +322,11 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
 // matrices are read as stored (k-major: W2 [H][4H], W1 [4H][H]), so a staged chunk is 32 k-rows x 128 columns.
 constexpr int BLDW = FBN + 4;    // 132: padded rows of a k-major weight chunk
 
+#ifndef DOSX_FFN_BWD_OCC
+#define DOSX_FFN_BWD_OCC 2      // waves per SIMD the register budget allows (2 = one workgroup per CU, 208 VGPRs)
+#endif
 template <bool HALF, int KB>
-__global__ __launch_bounds__(512) void ffn_bwd_kernel(const DosxFfnBwd a) {
+__global__ __launch_bounds__(512, DOSX_FFN_BWD_OCC) void ffn_bwd_kernel(const DosxFfnBwd a) {
   DOSX_SET_MAIN_PRIO();
   extern __shared__ __align__(16) float sm[];
   constexpr int FBK = KB;

@@ -1744,8 +1744,11 @@ __device__ __forceinline__ void reduce_body(const DosxReduceJob& j, int slice, i
 
 // (two workgroups per CU: 4 waves per SIMD at <= 128 VGPRs.  Three per CU - 80 VGPRs, the LDS would hold them - measured
 //  no faster with two register sets, 76 vs 79 us per GNN-layer-pair group, and spills with four.)
+#ifndef DOSX_WGRAD_OCC
+#define DOSX_WGRAD_OCC 4
+#endif
 template <int WNB>
-__global__ __launch_bounds__(512, 4) void wgrad_grouped_kernel(const WgradGroup G) {
+__global__ __launch_bounds__(512, DOSX_WGRAD_OCC) void wgrad_grouped_kernel(const WgradGroup G) {
   __shared__ __align__(16) float Sm[WNB * WSTG];
   if ((int)blockIdx.x >= G.first_block[G.n]) {
     // ---- a reduction block: 2 slices of 256 elements (one per half of the workgroup) ----

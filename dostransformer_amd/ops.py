@@ -768,6 +768,8 @@ def segment_reduce(msg, rowptr, scale, agg, e_in, e_out, N, E, H):
 def edge_grad_combine(de_new, dagg, ld_dagg, dst, scale, dmsg, E, H):
     """de_new: None or a 2-D tensor / view with unit inner stride ([E,H] or the e-block of an [E,3H] gradient)."""
     ld_de = int(de_new.stride(0)) if de_new is not None else 0
+    if __import__("os").environ.get("DOSX_DEBUG_SKIP_COMBINE"):      # timing experiments only (wrong numbers)
+        return
     _call("dosx_edge_grad_combine", _p(de_new), ld_de, dagg, ld_dagg, _p(dst), _p(scale), _p(dmsg), E, H, _stream(),
           w=lambda: (f"edge_grad_combine[H{H}]", "edge_grad_combine_kernel", "hbm",
                      4.0 * (_real(E) * H * (3 if de_new is not None else 2) + _real(E))))
