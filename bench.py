@@ -29,6 +29,10 @@ CONFIGS = {
     "edos_h256_t4_b32": ("edos", 3, 4, 256, 32),       # configs[4] per-GPU shape
 }
 N_DISTINCT_BATCHES = 8
+# epoch mode (--shuffle): granularity of the (nodes, edges) shape buckets.  Finer buckets = fewer ghost rows per step but
+# more buckets to record (one eager step each, once): 64/1280 1.401 ms (4 live buckets), 32/640 1.358 (8), 16/320 1.349
+# (16), 8/160 1.340 (30, at the slot cap) on the synthetic phonon set, misses inside the timed region included
+SHUFFLE_BUCKET = (16, 320)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA dense peak
 
@@ -370,7 +374,7 @@ def main():
                          "(loader.DeviceDataset), pads it to its shape bucket and trains on it; reports the slot hit rate")
     ap.add_argument("--pool", type=int, default=1536, help="--shuffle: crystals in the device-resident pool per GPU")
     ap.add_argument("--bucket", type=int, nargs=2, default=None, metavar=("NODES", "EDGES"),
-                    help="shape-bucket granularity (default 8 128; --shuffle: 64 1280)")
+                    help="shape-bucket granularity (default 8 128; --shuffle: 16 320)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL over xGMI (production); gloo = host-staged sums, only for running the N > 1 code path "
@@ -403,7 +407,7 @@ def main():
         dp = DataParallel()
 
     mode = "graph" if args.graph else args.launch
-    bucket = tuple(args.bucket) if args.bucket else ((64, 1280) if args.shuffle else (8, 128))
+    bucket = tuple(args.bucket) if args.bucket else (SHUFFLE_BUCKET if args.shuffle else (8, 128))
     common = dict(device=device, world=world, rank=rank, dp=dp, mode=mode, pool=args.pool)
     r = run_workload(args.config, shuffle=args.shuffle, steps=args.steps, warmup=args.warmup, bucket=bucket, **common)
     kind, L, T, H, B, n_global = r["kind"], r["L"], r["T"], r["H"], r["B"], r["n_global"]
@@ -426,8 +430,8 @@ def main():
         try:
             e = run_workload("edos_h256_b64", shuffle=False, steps=40, warmup=8, bucket=(8, 128), instrument=False, **common)
             secondary["edos_h256_b64"] = brief(e, 40)
-            sh = run_workload("phonon_h128_b64", shuffle=True, steps=args.steps, warmup=max(args.warmup, 40),
-                              bucket=(64, 1280), instrument=False, **common)
+            sh = run_workload("phonon_h128_b64", shuffle=True, steps=args.steps, warmup=max(args.warmup, 60),
+                              bucket=SHUFFLE_BUCKET, instrument=False, **common)
             secondary["shuffle"] = dict(brief(sh, args.steps), hit_rate=sh["slots"]["hit_rate"], live_buckets=sh["slots"]["live"])
         except Exception as ex:  # a secondary line must never take the headline down with it
             secondary["error"] = f"{type(ex).__name__}: {ex}"[:200]

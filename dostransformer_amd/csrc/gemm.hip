@@ -1289,6 +1289,7 @@ struct WgradLaunch {
   int vecA;
   int vecY;
   int variant;     // grouped launches: 0..3 = fast vectorised path with prologue NONE / PRELU / LN_PRELU / ROWLN, -1 = not groupable
+  int nt;          // 64-row sub-tiles of a workgroup's tile (1 or 2)
 };
 
 // Wave-specialised like gemm_kernel: waves 0-3 multiply (one 32x32 sub-tile each), waves 4-7 stage the
@@ -1297,48 +1298,53 @@ struct WgradLaunch {
 // tile lies inside one K-segment, so all lane offsets are fixed and a chunk advances scalar offsets
 // only (buffer loads; rows beyond M read as zero through the buffer bounds: no masks, no vector ALU
 // beyond the prologue transform).  FAST = 0: generic pointer path (any map, ragged everything).
-constexpr int WSTG = 2 * BM * LDT;                        // floats of one stage buffer: Ys | Xs
+// Tile of one workgroup: TN = 64 * NT rows of dW (columns of dY) x 64 columns of dW (columns of A).  NT = 2 (round 3):
+// every matrix wave multiplies TWO 32x32 sub-tiles that share their A-operand fragment, i.e. 32 MFMAs per 32-row chunk and
+// wave behind one barrier and 48 LDS fragment reads instead of 16 behind 32 - a lone workgroup's chunk period was ~1650 clk
+// for 1024 clk of MFMAs with the 64x64 tile (tools/stamp_wgrad.py) - and the ~12 k clk of fixed cost per workgroup
+// (prologue, publish, ticket) are spent once per 128x64 tile.  NT = 1 for N < 128 and the generic-staging variant.
+template <int NT> constexpr int wstg() { return BM * (64 * NT + 4) + BM * LDT; }   // floats of one stage buffer: Ys | Xs
+constexpr int WSTG = wstg<1>();
+constexpr int WSTG_MAX = wstg<2>();
 
 // ---- finished mode (DosxWgrad.dst != NULL): in-launch reduction over the M-splits by the last arriver of a tile ----
-// Protocol (cdna_hip_programming.md, in-launch split-K reduction, write-through form): every workgroup stores its 64x64
+// Protocol (cdna_hip_programming.md, in-launch split-K reduction, write-through form): every workgroup stores its TN x 64
 // partial tile to its private slot of the scratch slab with 16-byte sc1 (write-through) stores, every wave drains its
 // stores (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, ONE lane draws a ticket with a relaxed agent-scope
 // fetch_add on the tile's counter; the workgroup that draws nsplit-1 reads ALL nsplit partial tiles back with sc1 loads
 // (they bypass this CU's L1; every load of handed-off bytes is such a load) and adds them in split order 0, 1, 2, ...:
 // a fixed order whoever arrives last, so results are bitwise reproducible.  Scratch layout is tile-major
-// ([split][tile][64][64]): every partial tile is one contiguous, 16-byte aligned 16 KB block whatever N and K are.
-constexpr int WTILE = WT * WT;                            // floats of one partial tile
-constexpr int W_FLAG = 2 * WSTG - 4;                      // LDS word that broadcasts the ticket (inside two stage buffers)
-
-__device__ __forceinline__ void wgrad_finish(const DosxWgrad& g, float* __restrict__ Sm, const float4 bs0, const float4 bs1,
+// ([split][tile][TN][64]): every partial tile is one contiguous, 16-byte aligned block whatever N and K are.
+template <int NT>
+__device__ __forceinline__ void wgrad_finish(const DosxWgrad& g, float* __restrict__ Sm, const float4 (&bs)[2 * NT],
                                              const bool do_bias, const int z, const int bx, const int by, const int ntk) {
+  constexpr int TN = 64 * NT, LDY = TN + 4, WTILE = TN * WT, NH = 2 * NT;      // NH float4 per lane cover the tile
+  constexpr int W_FLAG = 3 * wstg<NT>() - 4;             // LDS word that broadcasts the ticket
   const int tid = threadIdx.x;
   const int N = g.N, K = g.K, ns = g.nsplit;
-  const int n0 = by * WT, k0 = bx * WT;
+  const int n0 = by * TN, k0 = bx * WT;
+  const int ntn = (N + TN - 1) / TN;
   const int tile = by * ntk + bx;
-  const int ntiles = ntk * ((N + WT - 1) / WT);
-  const int nb64 = ((N + WT - 1) / WT) * WT;              // row stride of the bias scratch
-  if (do_bias) {                                          // staged dY column sums: [32][LDT] behind the tile
-    float* Br = Sm + WT * LDT;
-    if (tid >= 256) {
-      const int st = tid - 256, r = st >> 3, c4 = (st & 7) * 4;
-      st4(&Br[r * LDT + c4], bs0);
-      st4(&Br[r * LDT + c4 + 32], bs1);
-    }
+  const int ntiles = ntk * ntn;
+  const int nbp = (N + WT - 1) / WT * WT;                 // row stride of the bias scratch
+  float* Br = Sm + TN * LDT;                              // staged dY column sums: [32][LDY] behind the tile
+  if (do_bias && tid >= 256) {
+    const int st = tid - 256, r = st >> 3, c4 = (st & 7) * 4;
+#pragma unroll
+    for (int j = 0; j < 2 * NT; ++j) st4(&Br[r * LDY + c4 + 32 * j], bs[j]);
   }
   __syncthreads();                                        // tile (matrix waves) and bias rows (staging waves) are in LDS
   WSTAMP(61);
   float bsum = 0.f;
-  if (do_bias && tid < WT) {
-    const float* Br = Sm + WT * LDT;
+  if (do_bias && tid < TN) {
 #pragma unroll 8
-    for (int rr = 0; rr < BM; ++rr) bsum += Br[rr * LDT + tid];
+    for (int rr = 0; rr < BM; ++rr) bsum += Br[rr * LDY + tid];
   }
-  // lane -> two float4 of the tile: element index e = tid and tid + 512 (row e >> 4, columns 4 * (e & 15) ..)
-  auto write_dst = [&](const float4 (&v)[2], const float bfin) {
+  // lane -> NH float4 of the tile: element index e = tid + 512 h (row e >> 4, columns 4 * (e & 15) ..)
+  auto write_dst = [&](const float4 (&v)[NH], const float bfin) {
     const bool vec_ok = ((K & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.dst) & 15) == 0);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NH; ++h) {
       const int e = tid + 512 * h, n = n0 + (e >> 4), k = k0 + (e & 15) * 4;
       if (n >= N || k >= K) continue;
       float* d = g.dst + (size_t)n * K + k;
@@ -1349,11 +1355,11 @@ __device__ __forceinline__ void wgrad_finish(const DosxWgrad& g, float* __restri
         for (int c = 0; c < 4 && k + c < K; ++c) d[c] = tv[c] + (g.accumulate ? d[c] : 0.f);
       }
     }
-    if (do_bias && tid < WT && n0 + tid < N) g.dst_bias[n0 + tid] = bfin + (g.accumulate ? g.dst_bias[n0 + tid] : 0.f);
+    if (do_bias && tid < TN && n0 + tid < N) g.dst_bias[n0 + tid] = bfin + (g.accumulate ? g.dst_bias[n0 + tid] : 0.f);
   };
-  float4 v[2];
+  float4 v[NH];
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < NH; ++h) {
     const int e = tid + 512 * h;
     v[h] = ld4(&Sm[(e >> 4) * LDT + (e & 15) * 4]);
   }
@@ -1362,13 +1368,13 @@ __device__ __forceinline__ void wgrad_finish(const DosxWgrad& g, float* __restri
     return;
   }
   const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)g.slab, 0, 0x7fffffff, 0x00020000);
-  const uint32_t zstride = (uint32_t)ntiles * WTILE * 4;  // bytes between the slots of consecutive splits (host checks < 2^31 / nsplit)
+  const uint32_t zstride = (uint32_t)ntiles * WTILE * 4;  // bytes between the slots of consecutive splits (host checks the total < 2^31)
   const uint32_t voff = ((uint32_t)tile * WTILE + (uint32_t)tid * 4) * 4;
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int h = 0; h < NH; ++h)
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i32, v[h]), rS, voff + h * 512 * 16, (uint32_t)z * zstride, 16);   // aux 16 = sc1
-  if (do_bias && tid < WT)
-    __hip_atomic_store(g.slab_bias + (size_t)z * nb64 + n0 + tid, bsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // (sc1 store)
+  if (do_bias && tid < TN && n0 + tid < N)
+    __hip_atomic_store(g.slab_bias + (size_t)z * nbp + n0 + tid, bsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // (sc1 store)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // EVERY storing wave drains its write-through stores
   __syncthreads();
   WSTAMP(62);
@@ -1379,9 +1385,9 @@ __device__ __forceinline__ void wgrad_finish(const DosxWgrad& g, float* __restri
   if (*flag != ns - 1) return;                            // not the last arriver of this tile
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // (no instruction: keeps the loads below the ticket)
   // ---- last arriver: sum the nsplit partial tiles in split order (sc1 loads, all issued before the first add) ----
-  constexpr int ZB = 16;                                  // loads in flight per lane and half: 16 x 16 B (one round trip per half at <= 16 splits)
+  constexpr int ZB = 16 / NT;                             // loads in flight per lane and float4 slot
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < NH; ++h) {
     float4 s = f4zero();
     for (int zb = 0; zb < ns; zb += ZB) {
       float4 t[ZB];
@@ -1397,9 +1403,9 @@ __device__ __forceinline__ void wgrad_finish(const DosxWgrad& g, float* __restri
     v[h] = s;
   }
   float bfin = 0.f;
-  if (do_bias && tid < WT) {
+  if (do_bias && tid < TN && n0 + tid < N) {
     for (int zz = 0; zz < ns; ++zz) {
-      const float b = __hip_atomic_load(g.slab_bias + (size_t)zz * nb64 + n0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float b = __hip_atomic_load(g.slab_bias + (size_t)zz * nbp + n0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       bfin = zz == 0 ? b : bfin + b;
     }
   }
@@ -1407,10 +1413,11 @@ __device__ __forceinline__ void wgrad_finish(const DosxWgrad& g, float* __restri
   if (tid == 0) __hip_atomic_store(g.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
 }
 
-template <int PRO, int VEC, int FAST, int WNB = 3>
+template <int PRO, int VEC, int FAST, int NT = 1>
 __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, float* __restrict__ Sm) {
   const DosxWgrad& g = L.g;
-  constexpr int STG = WSTG;
+  constexpr int TN = 64 * NT, LDY = TN + 4, NY = 2 * NT;   // NY float4 of dY per staging lane and chunk
+  constexpr int STG = wstg<NT>();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   // 1-D grid, the M-split index varies fastest: workgroups are dealt to the 8 XCDs round-robin by linear id,
@@ -1419,23 +1426,27 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, 
   const int ntk = (g.K + WT - 1) / WT;
   const int z = bid % g.nsplit, tile = bid / g.nsplit;
   const int bx = tile % ntk, by = tile / ntk;
-  const int k0 = bx * WT, n0 = by * WT;
+  const int k0 = bx * WT, n0 = by * TN;
   const int M = g.M, N = g.N, K = g.K;
   const int chunk = ((M + g.nsplit - 1) / g.nsplit + BM - 1) / BM * BM;
   const int ms = z * chunk, me = min(M, ms + chunk);
   const int nch = ms < me ? (me - ms + BM - 1) / BM : 0;
   const bool do_bias = ((g.dst != nullptr ? g.dst_bias : g.slab_bias) != nullptr) && (bx == 0);
 
-  f32x16 acc;
+  f32x16 acc[NT];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  float4 bs0 = f4zero(), bs1 = f4zero();                 // staging lanes: column sums of their dY values
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  float4 bs[NY];                                          // staging lanes: column sums of their dY values
+#pragma unroll
+  for (int j = 0; j < NY; ++j) bs[j] = f4zero();
   WSTAMP(0);
 
   if (wave_u >= 4) {
     // =============================== staging waves ===============================================
     const int st = tid - 256;
-    const int r = st >> 3, c4 = (st & 7) * 4;             // row r of the chunk, columns c4 and c4 + 32
+    const int r = st >> 3, c4 = (st & 7) * 4;             // row r of the chunk, columns c4 + 32 j
     float4 gq0 = f4zero(), gq1 = f4zero(), bq0 = f4zero(), bq1 = f4zero();
     if (VEC && (PRO == DOSX_PRO_LN_PRELU || PRO == DOSX_PRO_ROWLN)) {
       const int ka = (k0 + c4) < K ? (k0 + c4) : 0, kb = (k0 + c4 + 32) < K ? (k0 + c4 + 32) : 0;
@@ -1443,7 +1454,7 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, 
       gq1 = ld4(g.pro_gamma + kb); bq1 = ld4(g.pro_beta + kb);
     }
     struct Set {
-      float4 y0, y1;
+      float4 y[NY];
       ARaw x0, x1;
       AState st;        // generic path: row pointers / statistics of this lane's row
       bool row_ok;
@@ -1453,38 +1464,17 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, 
     // THREE stage buffers, the staging waves TWO chunks ahead of the matrix waves in LDS (chunk c+2 is stored while chunk c
     // is multiplied): at the barrier that ends chunk c the data of chunk c+1 has been visible for a whole chunk, so the
     // matrix waves fetch its fragments UNDER the MFMAs of chunk c.  Chunk c travels in register set c % NSET and LDS
-    // buffer c % 3.  NSET register sets = every global load has NSET chunk periods to land: with 2 sets (round 2) a
-    // workgroup's chunk period was HALF THE MEMORY LATENCY (1900-2200 clk by stamps and by the single-job timings of
-    // tools/bench_wgroup.py: 35 us for 38 chunks) against 1024 clk of MFMAs per chunk, i.e. a workgroup was latency-bound
-    // and only three of them per CU hid it; with 4 sets one workgroup keeps ~4 chunks of loads in flight.
-    // Every `issue` is UNCONDITIONAL (chunks past the end of the split read valid / bounds-zeroed rows that are never
-    // stored): a conditionally issued batch of loads makes the number of loads in flight path-dependent, and hipcc then
-    // protects every later use with s_waitcnt vmcnt(0) - i.e. each store waits for the loads issued LATER as well and the
-    // pipeline runs one deep.
-    constexpr int NSET = 2;       // (4 sets, 115 VGPRs: measured no faster - 78.1 vs 76 us per GNN-layer-pair group, 38 vs 37 us edge W1
-                                  //  alone: the chunk period of a lone workgroup, ~1650 clk, is LDS fragment reads + barrier, not loads)
+    // buffer c % 3.  Every `issue` is UNCONDITIONAL (chunks past the end of the split read valid / bounds-zeroed rows that
+    // are never stored): a conditionally issued batch of loads makes the number of loads in flight path-dependent, and
+    // hipcc then protects every later use with s_waitcnt vmcnt(0) - i.e. each store waits for the loads issued LATER as
+    // well and the pipeline runs one deep.
+    constexpr int NSET = 2;       // (4 sets, 115 VGPRs: measured no faster - the chunk period of a lone workgroup is LDS
+                                  //  fragment reads + barrier, not loads)
     Set sets[NSET];
     auto pipeline = [&](auto&& issue, auto&& store) {
       WSTAMP_S(0);
 #pragma unroll
       for (int i = 0; i < NSET; ++i) issue(sets[i], ms + i * BM);
-      if constexpr (WNB == 2) {
-        // TWO stage buffers (35 KB of LDS instead of 52: a weight-gradient workgroup then fits NEXT TO a 120 KB workgroup of
-        // the fused feed-forward kernels on one CU): chunk c+1 is stored while chunk c is multiplied
-        if (nch > 0) store(Sm, sets[0]);
-        issue(sets[0], ms + 2 * BM);
-        WSTAMP_S(1);
-        __syncthreads();                                  // chunk 0 is visible
-        for (int c = 0; c < nch; c += 2) {
-          if (c + 1 < nch) store(Sm + STG, sets[1]);      // buffer 1 was last read during iteration c - 1
-          issue(sets[1], ms + (c + 3) * BM);
-          __syncthreads();
-          if (c + 1 >= nch) break;
-          if (c + 2 < nch) store(Sm, sets[0]);
-          issue(sets[0], ms + (c + 4) * BM);
-          __syncthreads();
-        }
-      } else {
       if (nch > 0) store(Sm, sets[0]);
       issue(sets[0], ms + NSET * BM);
       if (nch > 1) store(Sm + STG, sets[1]);
@@ -1505,7 +1495,6 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, 
           WSTAMP_S(4 + 3 * (c + u));
           __syncthreads();
         }
-      }
       }
     };
     if constexpr (FAST) {
@@ -1537,11 +1526,14 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, 
           (void*)(gather ? sa.map.idx : (const int*)g.dy.p), 0, (uint32_t)(((size_t)maxrow(sa.map, ba_blk, M) + 1) * 4), 0x00020000);
       const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(PRO == DOSX_PRO_ROWLN ? g.pro_stats : g.dy.p), 0, (uint32_t)((size_t)M * 8), 0x00020000);
-      const int ny0 = (n0 + c4) < N ? (n0 + c4) : 0, ny1 = (n0 + c4 + 32) < N ? (n0 + c4 + 32) : 0;
       const int kx0 = c4 < kw ? c4 : 0, kx1 = (c4 + 32) < kw ? (c4 + 32) : 0;
       // per-lane parts (row r of the chunk), the chunk's first row comes in as a scalar offset
-      const uint32_t vY0 = (uint32_t)((((size_t)r * cy + oy) * g.dy.ld + ny0) * 4);
-      const uint32_t vY1 = (uint32_t)((((size_t)r * cy + oy) * g.dy.ld + ny1) * 4);
+      uint32_t vY[NY];
+#pragma unroll
+      for (int j = 0; j < NY; ++j) {
+        const int ny = (n0 + c4 + 32 * j) < N ? (n0 + c4 + 32 * j) : 0;
+        vY[j] = (uint32_t)((((size_t)r * cy + oy) * g.dy.ld + ny) * 4);
+      }
       const uint32_t colA0 = (uint32_t)((k0 - kbase + kx0) * 4), colA1 = (uint32_t)((k0 - kbase + kx1) * 4);
       const uint32_t vA0 = (uint32_t)(((size_t)r * ca + oa) * sa.ld * 4) + colA0;   // (!gather)
       const uint32_t vA1 = (uint32_t)(((size_t)r * ca + oa) * sa.ld * 4) + colA1;
@@ -1561,8 +1553,9 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, 
         const int mu = __builtin_amdgcn_readfirstlane(m);
         const int cidx = __builtin_amdgcn_readfirstlane((m - ms) / BM);
         const int soY = __builtin_amdgcn_readfirstlane(row0(g.dy.map, by_blk, mu) * ldy4);
-        q.y0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rY, vY0, soY, 0));
-        q.y1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rY, vY1, soY, 0));
+#pragma unroll
+        for (int j = 0; j < NY; ++j)
+          q.y[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rY, vY[j], soY, 0));
         const uint32_t rowb = (uint32_t)q.idx * (uint32_t)lda4;
         const uint32_t o0 = gather ? rowb + colA0 : vA0, o1 = gather ? rowb + colA1 : vA1;
         const int soA = __builtin_amdgcn_readfirstlane(gather ? 0 : row0(sa.map, ba_blk, mu) * lda4);
@@ -1577,11 +1570,14 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, 
       auto store = [&](float* buf, Set& q) {
         AState t;
         t.ok = true; t.mean = q.mean; t.rstd = q.rstd; t.alpha = alpha;
-        st4(&buf[r * LDT + c4], q.y0);
-        st4(&buf[r * LDT + c4 + 32], q.y1);
-        st4(&buf[BM * LDT + r * LDT + c4], a_finish<PRO, VEC, 0>(t, q.x0, 0, K, gq0, bq0));
-        st4(&buf[BM * LDT + r * LDT + c4 + 32], a_finish<PRO, VEC, 0>(t, q.x1, 0, K, gq1, bq1));
-        if (do_bias) { bs0 = f4add(bs0, q.y0); bs1 = f4add(bs1, q.y1); }
+#pragma unroll
+        for (int j = 0; j < NY; ++j) st4(&buf[r * LDY + c4 + 32 * j], q.y[j]);
+        st4(&buf[BM * LDY + r * LDT + c4], a_finish<PRO, VEC, 0>(t, q.x0, 0, K, gq0, bq0));
+        st4(&buf[BM * LDY + r * LDT + c4 + 32], a_finish<PRO, VEC, 0>(t, q.x1, 0, K, gq1, bq1));
+        if (do_bias) {
+#pragma unroll
+          for (int j = 0; j < NY; ++j) bs[j] = f4add(bs[j], q.y[j]);
+        }
       };
 #pragma unroll
       for (int i = 0; i < NSET; ++i) sets[i].mean = sets[i].rstd = 0.f;
@@ -1590,11 +1586,10 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, 
       auto issue = [&](Set& q, int m) {
         q.row_ok = (m + r) < me;
         const int gm = max(min(m + r, M - 1), 0);   // always a valid row (chunks past the split are loaded, never stored)
-        q.y0 = q.y1 = f4zero();
         const float* yp = g.dy.p + (size_t)dosx_map_row(g.dy.map, gm) * g.dy.ld;
 #pragma unroll
-        for (int hseg = 0; hseg < 2; ++hseg) {
-          const int n = n0 + c4 + 32 * hseg;
+        for (int j = 0; j < NY; ++j) {
+          const int n = n0 + c4 + 32 * j;
           float4 v = f4zero();
           if (VEC) {
             v = ld4(yp + (n < N ? n : 0));
@@ -1604,68 +1599,68 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, 
             if (n + 2 < N) v.z = yp[n + 2];
             if (n + 3 < N) v.w = yp[n + 3];
           }
-          if (hseg == 0) q.y0 = v; else q.y1 = v;
+          q.y[j] = v;
         }
         a_state_init(q.st, g.a, g.nseg, PRO, g.pro_stats, g.pro_alpha, gm, q.row_ok);
         q.x0 = a_issue<PRO, VEC>(q.st, k0 + c4, K, g.pro_gamma, g.pro_beta);
         q.x1 = a_issue<PRO, VEC>(q.st, k0 + c4 + 32, K, g.pro_gamma, g.pro_beta);
       };
       auto store = [&](float* buf, Set& q) {
-        float4 a0 = q.y0, a1 = q.y1;
-        if (VEC) {
-          if (!(q.row_ok && (n0 + c4) < N)) a0 = f4zero();
-          if (!(q.row_ok && (n0 + c4 + 32) < N)) a1 = f4zero();
+#pragma unroll
+        for (int j = 0; j < NY; ++j) {
+          float4 a0 = q.y[j];
+          if (VEC && !(q.row_ok && (n0 + c4 + 32 * j) < N)) a0 = f4zero();
+          st4(&buf[r * LDY + c4 + 32 * j], a0);
+          if (do_bias) bs[j] = f4add(bs[j], a0);
         }
-        st4(&buf[r * LDT + c4], a0);
-        st4(&buf[r * LDT + c4 + 32], a1);
-        st4(&buf[BM * LDT + r * LDT + c4], a_finish<PRO, VEC, 1>(q.st, q.x0, k0 + c4, K, gq0, bq0));
-        st4(&buf[BM * LDT + r * LDT + c4 + 32], a_finish<PRO, VEC, 1>(q.st, q.x1, k0 + c4 + 32, K, gq1, bq1));
-        if (do_bias) { bs0 = f4add(bs0, a0); bs1 = f4add(bs1, a1); }
+        st4(&buf[BM * LDY + r * LDT + c4], a_finish<PRO, VEC, 1>(q.st, q.x0, k0 + c4, K, gq0, bq0));
+        st4(&buf[BM * LDY + r * LDT + c4 + 32], a_finish<PRO, VEC, 1>(q.st, q.x1, k0 + c4 + 32, K, gq1, bq1));
       };
       pipeline(issue, store);
     }
   } else {
     // =============================== matrix waves ================================================
+    // wave -> (wn, wk): NT 32-row sub-tiles of dW rows [(wn*NT + t)*32, +32) x the 32 dW columns [wk*32, +32)
     const int wn = wave >> 1, wk = wave & 1;
-    f32x16 acc2;
+    // NT = 1: a second accumulator (even / odd row pairs) - MFMAs chained through ONE accumulator issue every ~87 clk
+    // instead of every 64 (dependent-issue latency of the 16-pass instruction).  NT = 2: the two sub-tiles ARE two chains.
+    constexpr int NA2 = NT == 1 ? 1 : 0;
+    f32x16 acc2[1];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
+    for (int i = 0; i < 16; ++i) acc2[0][i] = 0.f;
     __syncthreads();
     WSTAMP(1);
-    // Fragments travel in HALF chunks (16 rows = 8 MFMA steps): the reads of the next half are issued right before the 8
-    // MFMAs of the current one, so every LDS round trip hides under 512 clk of matrix work - across the barrier too: the
+    // Fragments travel in HALF chunks (16 rows = 8 MFMA steps per sub-tile): the reads of the next half are issued right
+    // before the MFMAs of the current one, so every LDS round trip hides under matrix work - across the barrier too: the
     // first half of chunk c+1 is fetched under the second half of chunk c (its buffer has been complete since the previous
-    // barrier).  Two half-fragment sets = 32 registers (the full-chunk version of round 1 held 32 as well, the
-    // full-chunk double buffer 64 -> 135 VGPRs, one workgroup per CU: slower).
-    struct Frag { float a[BM / 4], b[BM / 4]; };
+    // barrier).
+    struct Frag { float a[NT][BM / 4], b[BM / 4]; };
     auto fetch = [&](Frag& f, int buf, int half) {
       const float* Ys = Sm + buf * STG;
-      const float* Xs = Ys + BM * LDT;
+      const float* Xs = Ys + BM * LDY;
 #pragma unroll
       for (int i = 0; i < BM / 4; ++i) {
-        f.a[i] = Ys[(BM / 2 * half + 2 * i + hh) * LDT + wn * 32 + l31];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) f.a[t][i] = Ys[(BM / 2 * half + 2 * i + hh) * LDY + (wn * NT + t) * 32 + l31];
         f.b[i] = Xs[(BM / 2 * half + 2 * i + hh) * LDT + wk * 32 + l31];
       }
     };
-    // two accumulators (even / odd row pairs): MFMAs chained through ONE accumulator issue every ~87 clk
-    // instead of every 64 (dependent-issue latency of the 16-pass instruction)
     auto mma = [&](const Frag& f) {
 #pragma unroll
       for (int i = 0; i < BM / 4; i += 2) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i], f.b[i], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i + 1], f.b[i + 1], acc2, 0, 0, 0);
+        if constexpr (NA2) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[0][i], f.b[i], acc[0], 0, 0, 0);
+          acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[0][i + 1], f.b[i + 1], acc2[0], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t][i + u], f.b[i + u], acc[t], 0, 0, 0);
+        }
       }
     };
     Frag f0, f1;
-    if constexpr (WNB == 2) {
-      for (int c = 0; c < nch; ++c) {
-        fetch(f0, c & 1, 0);
-        fetch(f1, c & 1, 1);
-        mma(f0);
-        mma(f1);
-        __syncthreads();
-      }
-    } else {
     int cur = 0;                                            // buffer of chunk c
     if (nch > 0) fetch(f0, 0, 0);
     for (int c = 0; c < nch; ++c) {
@@ -1679,49 +1674,53 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, 
       WSTAMP(3 + 2 * c);
       __syncthreads();
     }
-    }
     WSTAMP(60);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] += acc2[i];
-    if (g.dst != nullptr) {                                  // finished mode: the tile goes to LDS first (below)
+    for (int t = 0; t < NT; ++t) {
+      if constexpr (NA2) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i)
-        Sm[(wn * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh) * LDT + wk * 32 + l31] = acc[i];
-    } else {
-      float* slab = g.slab + (size_t)z * N * K;
-      const int kcol = k0 + wk * 32 + l31;
+        for (int i = 0; i < 16; ++i) acc[t][i] += acc2[0][i];
+      }
+      if (g.dst != nullptr) {                                // finished mode: the tile goes to LDS first (below)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int n = n0 + wn * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-        if (n < N && kcol < K) slab[(size_t)n * K + kcol] = acc[i];
+        for (int i = 0; i < 16; ++i)
+          Sm[((wn * NT + t) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh) * LDT + wk * 32 + l31] = acc[t][i];
+      } else {
+        float* slab = g.slab + (size_t)z * N * K;
+        const int kcol = k0 + wk * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int n = n0 + (wn * NT + t) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          if (n < N && kcol < K) slab[(size_t)n * K + kcol] = acc[t][i];
+        }
       }
     }
   }
   if (g.dst != nullptr) {
-    wgrad_finish(g, Sm, bs0, bs1, do_bias, z, bx, by, ntk);
+    wgrad_finish<NT>(g, Sm, bs, do_bias, z, bx, by, ntk);
     return;
   }
-  if (do_bias) {          // workgroup-uniform: column sums of the staged dY rows -> slab_bias[z][n0 .. n0+63]
-    float* Br = Sm;       // [32][LDT]   (the stage buffers are dead: the loop ended with a barrier)
+  if (do_bias) {          // workgroup-uniform: column sums of the staged dY rows -> slab_bias[z][n0 .. n0+TN-1]
+    float* Br = Sm;       // [32][LDY]   (the stage buffers are dead: the loop ended with a barrier)
     if (wave_u >= 4) {
       const int st = tid - 256, r = st >> 3, c4 = (st & 7) * 4;
-      st4(&Br[r * LDT + c4], bs0);
-      st4(&Br[r * LDT + c4 + 32], bs1);
+#pragma unroll
+      for (int j = 0; j < NY; ++j) st4(&Br[r * LDY + c4 + 32 * j], bs[j]);
     }
     __syncthreads();
-    if (tid < WT && n0 + tid < N) {
+    if (tid < TN && n0 + tid < N) {
       float sum = 0.f;
 #pragma unroll 8
-      for (int rr = 0; rr < BM; ++rr) sum += Br[rr * LDT + tid];
+      for (int rr = 0; rr < BM; ++rr) sum += Br[rr * LDY + tid];
       g.slab_bias[(size_t)z * N + n0 + tid] = sum;
     }
   }
 }
 
-template <int PRO, int VEC, int FAST>
+template <int PRO, int VEC, int FAST, int NT>
 __global__ __launch_bounds__(512) void wgrad_kernel(const WgradLaunch L) {
-  __shared__ __align__(16) float Sm[3 * WSTG];
-  wgrad_body<PRO, VEC, FAST>(L, (int)blockIdx.x, Sm);
+  __shared__ __align__(16) float Sm[3 * wstg<NT>()];
+  wgrad_body<PRO, VEC, FAST, NT>(L, (int)blockIdx.x, Sm);
 }
 
 // Grouped launch: ONE grid over several weight-gradient jobs (the jobs travel as a kernel argument like the slab
@@ -1742,14 +1741,16 @@ static_assert(sizeof(WgradGroup) <= 4064, "WgradGroup must fit the kernel argume
 
 __device__ __forceinline__ void reduce_body(const DosxReduceJob& j, int slice, int t256, float4 (*red)[64]);
 
-// (two workgroups per CU: 4 waves per SIMD at <= 128 VGPRs.  Three per CU - 80 VGPRs, the LDS would hold them - measured
-//  no faster with two register sets, 76 vs 79 us per GNN-layer-pair group, and spills with four.)
+// (two workgroups per CU: 4 waves per SIMD at <= 128 VGPRs, 2 x 77 KB of LDS.  Three per CU - 80 VGPRs - measured no faster
+//  with the 64x64 tile, and spilled.)
 #ifndef DOSX_WGRAD_OCC
 #define DOSX_WGRAD_OCC 4
 #endif
-template <int WNB>
-__global__ __launch_bounds__(512, DOSX_WGRAD_OCC) void wgrad_grouped_kernel(const WgradGroup G) {
-  __shared__ __align__(16) float Sm[WNB * WSTG];
+__global__ __launch_bounds__(512, DOSX_WGRAD_OCC) void wgrad_grouped_kernel(const WgradGroup G_arg) {
+  __shared__ __align__(16) float Sm[3 * WSTG_MAX];
+  // the job table is read where it lies, in the kernel-argument segment (scalar loads through a constant-address-space
+  // pointer): indexing the by-value parameter with a run-time index made hipcc copy the whole 4 KB table to scratch
+  const WgradGroup& G = *(const WgradGroup*)__builtin_amdgcn_kernarg_segment_ptr();
   if ((int)blockIdx.x >= G.first_block[G.n]) {
     // ---- a reduction block: 2 slices of 256 elements (one per half of the workgroup) ----
     const int rb = (int)blockIdx.x - G.first_block[G.n];
@@ -1770,12 +1771,16 @@ __global__ __launch_bounds__(512, DOSX_WGRAD_OCC) void wgrad_grouped_kernel(cons
   }
   const WgradLaunch& L = G.job[lo];
   const int bid = (int)blockIdx.x - G.first_block[lo];
-  switch (L.variant) {             // workgroup-uniform
-    case 0: wgrad_body<DOSX_PRO_NONE, 1, 1, WNB>(L, bid, Sm); break;
-    case 1: wgrad_body<DOSX_PRO_PRELU, 1, 1, WNB>(L, bid, Sm); break;
-    case 2: wgrad_body<DOSX_PRO_LN_PRELU, 1, 1, WNB>(L, bid, Sm); break;
-    case 3: wgrad_body<DOSX_PRO_ROWLN, 1, 1, WNB>(L, bid, Sm); break;
-    case 4: wgrad_body<DOSX_PRO_NONE, 0, 0, WNB>(L, bid, Sm); break;      // unaligned operands (K = 118 atom features)
+  switch (L.variant + 8 * (L.nt - 1)) {             // workgroup-uniform
+    case 0: wgrad_body<DOSX_PRO_NONE, 1, 1, 1>(L, bid, Sm); break;
+    case 1: wgrad_body<DOSX_PRO_PRELU, 1, 1, 1>(L, bid, Sm); break;
+    case 2: wgrad_body<DOSX_PRO_LN_PRELU, 1, 1, 1>(L, bid, Sm); break;
+    case 3: wgrad_body<DOSX_PRO_ROWLN, 1, 1, 1>(L, bid, Sm); break;
+    case 4: wgrad_body<DOSX_PRO_NONE, 0, 0, 1>(L, bid, Sm); break;      // unaligned operands (K = 118 atom features)
+    case 8: wgrad_body<DOSX_PRO_NONE, 1, 1, 2>(L, bid, Sm); break;      // 128 x 64 tiles
+    case 9: wgrad_body<DOSX_PRO_PRELU, 1, 1, 2>(L, bid, Sm); break;
+    case 10: wgrad_body<DOSX_PRO_LN_PRELU, 1, 1, 2>(L, bid, Sm); break;
+    case 11: wgrad_body<DOSX_PRO_ROWLN, 1, 1, 2>(L, bid, Sm); break;
     default: break;
   }
 }
@@ -1845,9 +1850,25 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceLaunch
 
 }  // namespace
 
+namespace {
+// rows of dW per workgroup tile / 64: 128 x 64 tiles for the long jobs (M >= 16384 rows, N >= 128).  Measured (round 3):
+// eDOS H = 256 (M = 17880 / 25728) 8.29-8.38 -> 8.16-8.20 ms per step, the grouped launches 418 -> 398 us; the Phonon-DOS
+// step (M <= 9344: 35 chunks per workgroup at 8 splits) is 0.5 % SLOWER with them - half as many workgroups of twice the
+// length leave more of the 512 slots idle at the end of a group than the 25 % fewer L2 bytes per flop give back.
+int wgrad_nt(int M, int N) {
+  static int force = -1;
+  if (force < 0) {
+    const char* e = getenv("DOSX_WGRAD_NT");       // 1 / 2: every job that can (tests, tools/exp/ab_nt*.sh)
+    force = e ? atoi(e) : 0;
+  }
+  if (N < 2 * WT || force == 1) return 1;
+  return (force == 2 || M >= 16384) ? 2 : 1;
+}
+}  // namespace
+
 extern "C" int dosx_wgrad_splits(int M, int N, int K) {
   if (M <= 0) return 1;
-  const int tiles = ceil_div(N, WT) * ceil_div(K, WT);
+  const int tiles = ceil_div(N, WT * wgrad_nt(M, N)) * ceil_div(K, WT);
   int s = ceil_div(512, tiles);
   const int cap = ceil_div(M, 128);
   if (s > cap) s = cap;
@@ -1880,7 +1901,9 @@ extern "C" int dosx_wgrad_splits(int M, int N, int K) {
 extern "C" int dosx_wgrad_tiles(int N, int K) { return ceil_div(N, WT) * ceil_div(K, WT); }
 
 extern "C" int64_t dosx_wgrad_scratch_floats(int N, int K, int nsplit) {
-  return nsplit <= 1 ? 0 : (int64_t)nsplit * dosx_wgrad_tiles(N, K) * WTILE;
+  // (M is not known here: room for either tile height - N padded to 128 rows covers both)
+  const int nt = N >= 2 * WT ? 2 : 1;
+  return nsplit <= 1 ? 0 : (int64_t)nsplit * ceil_div(N, WT * nt) * ceil_div(K, WT) * (WT * nt * WT);
 }
 
 namespace {
@@ -1908,7 +1931,6 @@ int wgrad_prepare(const DosxWgrad& g, WgradLaunch& L, int& vec, bool& fast, int&
   if (g.pro == DOSX_PRO_LN_PRELU || g.pro == DOSX_PRO_ROWLN)
     L.vecA = L.vecA && aligned16(g.pro_gamma) && aligned16(g.pro_beta);
   L.vecY = ((g.dy.ld & 3) == 0) && aligned16(g.dy.p) && (g.N & 3) == 0;
-  blocks = ceil_div(g.K, WT) * ceil_div(g.N, WT) * g.nsplit;
   vec = L.vecA && L.vecY;
   // fast (buffer-addressed) staging: affine row maps (+ optional gather on A), K tiles inside one segment,
   // every byte offset below 2^31
@@ -1940,6 +1962,8 @@ int wgrad_prepare(const DosxWgrad& g, WgradLaunch& L, int& vec, bool& fast, int&
                             : (!vec ? 4 : -1);       // (the aligned generic-staging variant in the grouped kernel too made
                                                       //  hipcc copy the whole job table to scratch, 3.8 KB per lane: those jobs -
                                                       //  the two heads' div/mod row maps - keep their own launches)
+  L.nt = (L.variant >= 0 && L.variant <= 3) ? wgrad_nt(g.M, g.N) : 1;
+  blocks = ceil_div(g.K, WT) * ceil_div(g.N, WT * L.nt) * g.nsplit;
   return 0;
 }
 
@@ -1947,20 +1971,27 @@ int wgrad_launch_one(const WgradLaunch& L, int vec, bool fast, int blocks, hipSt
   const DosxWgrad& g = L.g;
   dim3 grid(blocks);
   if (!vec) {
-    hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_NONE, 0, 0>), grid, dim3(512), 0, st, L);
+    hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_NONE, 0, 0, 1>), grid, dim3(512), 0, st, L);
+  } else if (fast && L.nt == 2) {
+    switch (g.pro) {
+      case DOSX_PRO_NONE: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_NONE, 1, 1, 2>), grid, dim3(512), 0, st, L); break;
+      case DOSX_PRO_PRELU: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_PRELU, 1, 1, 2>), grid, dim3(512), 0, st, L); break;
+      case DOSX_PRO_LN_PRELU: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_LN_PRELU, 1, 1, 2>), grid, dim3(512), 0, st, L); break;
+      default: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_ROWLN, 1, 1, 2>), grid, dim3(512), 0, st, L); break;
+    }
   } else if (fast) {
     switch (g.pro) {
-      case DOSX_PRO_NONE: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_NONE, 1, 1>), grid, dim3(512), 0, st, L); break;
-      case DOSX_PRO_PRELU: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_PRELU, 1, 1>), grid, dim3(512), 0, st, L); break;
-      case DOSX_PRO_LN_PRELU: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_LN_PRELU, 1, 1>), grid, dim3(512), 0, st, L); break;
-      default: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_ROWLN, 1, 1>), grid, dim3(512), 0, st, L); break;
+      case DOSX_PRO_NONE: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_NONE, 1, 1, 1>), grid, dim3(512), 0, st, L); break;
+      case DOSX_PRO_PRELU: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_PRELU, 1, 1, 1>), grid, dim3(512), 0, st, L); break;
+      case DOSX_PRO_LN_PRELU: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_LN_PRELU, 1, 1, 1>), grid, dim3(512), 0, st, L); break;
+      default: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_ROWLN, 1, 1, 1>), grid, dim3(512), 0, st, L); break;
     }
   } else {
     switch (g.pro) {
-      case DOSX_PRO_NONE: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_NONE, 1, 0>), grid, dim3(512), 0, st, L); break;
-      case DOSX_PRO_PRELU: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_PRELU, 1, 0>), grid, dim3(512), 0, st, L); break;
-      case DOSX_PRO_LN_PRELU: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_LN_PRELU, 1, 0>), grid, dim3(512), 0, st, L); break;
-      default: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_ROWLN, 1, 0>), grid, dim3(512), 0, st, L); break;
+      case DOSX_PRO_NONE: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_NONE, 1, 0, 1>), grid, dim3(512), 0, st, L); break;
+      case DOSX_PRO_PRELU: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_PRELU, 1, 0, 1>), grid, dim3(512), 0, st, L); break;
+      case DOSX_PRO_LN_PRELU: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_LN_PRELU, 1, 0, 1>), grid, dim3(512), 0, st, L); break;
+      default: hipLaunchKernelGGL((wgrad_kernel<DOSX_PRO_ROWLN, 1, 0, 1>), grid, dim3(512), 0, st, L); break;
     }
   }
   DOSX_LAUNCH_CHECK();
@@ -2005,13 +2036,7 @@ extern "C" int dosx_grad_flush(const DosxWgrad* jobs, int n_jobs, const DosxRedu
     if (G.n == 0 && G.nr == 0) return 0;
     G.first_block[G.n] = blocks_total;
     G.rfirst[G.nr] = rblocks;
-    static int wnb = 0;
-    if (wnb == 0) {
-      const char* e = getenv("DOSX_WGRAD_NB");
-      wnb = (e && atoi(e) == 2) ? 2 : 3;      // (2: 35 KB of LDS per workgroup - measured no faster in the step, 5 % slower alone)
-    }
-    if (wnb == 3) hipLaunchKernelGGL(wgrad_grouped_kernel<3>, dim3(blocks_total + rblocks), dim3(512), 0, st, G);
-    else hipLaunchKernelGGL(wgrad_grouped_kernel<2>, dim3(blocks_total + rblocks), dim3(512), 0, st, G);
+    hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(blocks_total + rblocks), dim3(512), 0, st, G);
     DOSX_LAUNCH_CHECK();
     G.n = 0;
     G.nr = 0;

@@ -36,7 +36,9 @@ def _scratch(o, N, K, ns, bias=True):
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 256, 384), (333, 128, 118), (70, 64, 64), (5000, 128, 512), (40, 16, 24),
-                                    (9344, 256, 384), (6528, 512, 128), (456, 256, 256), (64, 128, 320), (3, 8, 4)])
+                                    (9344, 256, 384), (6528, 512, 128), (456, 256, 256), (64, 128, 320), (3, 8, 4),
+                                    # M >= 16384 and N >= 128: 128 x 64 tiles (two sub-tiles per matrix wave); ragged N and K
+                                    (20000, 256, 384), (16500, 192, 128), (16400, 128, 64), (17000, 328, 72)])
 def test_wgrad_finished_mode(M, N, K):
     """dW = dY^T A and db = sum_m dY written by the weight-gradient kernel itself (no reduce_partials launch), against
     float64; a second launch on the same counters (they must be back at zero) gives the same bits; accumulate adds."""
@@ -87,6 +89,17 @@ def _mixed_jobs(o):
         add(500 + 100 * k, 64, 64, 20 + 2 * k)
     add(9344, 256, 384, 70)
     add(6528, 128, 512, 72)
+    # long jobs: 128 x 64 tiles, every prologue and a gathered operand
+    add(17880, 256, 128, 80, pro=o.PRO_PRELU, pro_alpha=torch.tensor([0.25], device=DEV))
+    add(16384, 128, 256, 82, pro=o.PRO_LN_PRELU, pro_gamma=rnd(256, seed=54), pro_beta=rnd(256, seed=55),
+        pro_alpha=torch.tensor([0.1], device=DEV))
+    add(25728, 512, 128, 84, pro=o.PRO_ROWLN, pro_gamma=rnd(128, seed=56), pro_beta=rnd(128, seed=57),
+        pro_stats=torch.rand(25728, 2, device=DEV))
+    x2 = rnd(700, H, seed=62)
+    idx2 = torch.randint(0, 700, (17000,), device=DEV, dtype=torch.int32)
+    e2 = rnd(17000, H, seed=63)
+    add(17000, 192, 2 * H, 86, segs=[o.seg(x2, rmap=o.rowmap(idx=idx2)), o.seg(e2)])
+    jobs[-1]["keep"] = (x2, idx2, e2)
     return jobs
 
 
