@@ -179,6 +179,13 @@ __device__ __forceinline__ float4 a_finish(const AState& st, const ARaw& r, int 
 // The epilogue uses all 8 waves (4 rows each per 32-row block).
 // ---------------------------------------------------------------------------------------------
 // (128-column tiles with a light epilogue are held to 128 VGPRs = 4 waves per SIMD: two workgroups per CU)
+// Tiles of NTW >= DOSX_HOIST_MAX_NTW x 128 columns fetch the row operands of their epilogue AFTER the k-loop: with 512-column
+// tiles (eDOS, 2H = 512) the hoisted rows pushed the staging waves past 256 VGPRs - 13-76 spilled registers, reloaded with
+// scratch loads INSIDE the staging loop, where they queue behind the chunk loads (vmcnt is in-order).  Round 3: the edge
+// dgrad GEMM with the PReLU/LayerNorm-backward epilogue 196 -> 184 us in the eDOS step, no spills left in the backward tiles.
+#ifndef DOSX_HOIST_MAX_NTW
+#define DOSX_HOIST_MAX_NTW 4
+#endif
 template <int RTP, int NTW, int WL, int PRO, int VEC, int EPI>
 __global__ __launch_bounds__(512, (NTW == 1 && (EPI == DOSX_EPI_BIAS_ACT || EPI == DOSX_EPI_LN || EPI == DOSX_EPI_RELU_MASK)) ? 4 : 2)
 void gemm_kernel(const GemmLaunch L) {
@@ -310,8 +317,8 @@ void gemm_kernel(const GemmLaunch L) {
   // The per-row operands are hoisted above the k-loop only for the backward epilogues (they always have
   // them).  The plain bias/activation epilogue keeps its registers for occupancy instead: at <= 128
   // VGPRs two 8-wave workgroups share a CU, which matters more for its (larger) grids; its optional
-  // residual rows are fetched after the k-loop.
-  constexpr bool HOIST = (epi != DOSX_EPI_BIAS_ACT);
+  // residual rows are fetched after the k-loop; so do the 512-column tiles (DOSX_HOIST_MAX_NTW).
+  constexpr bool HOIST = (epi != DOSX_EPI_BIAS_ACT) && (NTW < DOSX_HOIST_MAX_NTW);
   auto prefetch_rows = [&]() {
 #pragma unroll
   for (int rt = 0; rt < RTE; ++rt) {
@@ -1482,10 +1489,13 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, 
       WSTAMP_S(1);
       __syncthreads();                                    // chunks 0 and 1 are visible
       int b2 = 2;                                         // buffer of chunk c + 2
+      // (the staging waves always run an EVEN number of chunk periods - the matrix waves add a barrier when nch is odd:
+      //  a `break` between the two halves made the number of loads in flight path-dependent, hipcc then waited for the
+      //  gathered-row index with vmcnt(2) instead of vmcnt(7), i.e. for every load of the other register set too, and the
+      //  pipeline ran one chunk deep)
       for (int c = 0; c < nch; c += NSET) {
 #pragma unroll
         for (int u = 0; u < NSET; ++u) {                  // iteration c + u: chunk c+u+2 -> LDS, chunk c+u+2+NSET -> its set
-          if (u > 0 && c + u >= nch) break;
           Set& q = sets[(u + 2) % NSET];
           WSTAMP_S(2 + 3 * (c + u));
           if (c + u + 2 < nch) store(Sm + b2 * STG, q);   // buffer (c+u+2) % 3 was last read during iteration c+u-1
@@ -1674,6 +1684,7 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, 
       WSTAMP(3 + 2 * c);
       __syncthreads();
     }
+    if (nch & 1) __syncthreads();                           // (the staging waves' loop runs an even number of periods)
     WSTAMP(60);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {

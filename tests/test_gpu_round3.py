@@ -38,7 +38,9 @@ def _scratch(o, N, K, ns, bias=True):
 @pytest.mark.parametrize("M,N,K", [(1000, 256, 384), (333, 128, 118), (70, 64, 64), (5000, 128, 512), (40, 16, 24),
                                     (9344, 256, 384), (6528, 512, 128), (456, 256, 256), (64, 128, 320), (3, 8, 4),
                                     # M >= 16384 and N >= 128: 128 x 64 tiles (two sub-tiles per matrix wave); ragged N and K
-                                    (20000, 256, 384), (16500, 192, 128), (16400, 128, 64), (17000, 328, 72)])
+                                    # (eDOS-size jobs)
+                                    (20000, 256, 384), (16500, 192, 128), (16400, 128, 64), (17000, 328, 72),
+                                    (25728, 1024, 256), (17880, 512, 768), (16390, 136, 200)])
 def test_wgrad_finished_mode(M, N, K):
     """dW = dY^T A and db = sum_m dY written by the weight-gradient kernel itself (no reduce_partials launch), against
     float64; a second launch on the same counters (they must be back at zero) gives the same bits; accumulate adds."""

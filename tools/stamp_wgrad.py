@@ -7,7 +7,8 @@ from dostransformer_amd import ops, _lib
 DEV = "cuda"
 lib = _lib.load()
 lib.dosx_debug_read_stamps.argtypes = [C.c_void_p]
-for name, M, N, K, pro in [("fc1 wgrad (ROWLN)", 6528, 512, 128, ops.PRO_ROWLN), ("fc2 wgrad", 6528, 128, 512, 0), ("edge W1", 9344, 256, 384, 0)]:
+for name, M, N, K, pro in [("fc1 wgrad (ROWLN)", 6528, 512, 128, ops.PRO_ROWLN), ("fc2 wgrad", 6528, 128, 512, 0), ("edge W1", 9344, 256, 384, 0),
+                            ("saturated (512 workgroups of 100 chunks)", 25728, 1024, 256, 0)]:
     dy = torch.randn(M, N, device=DEV); a = torch.randn(M, K, device=DEV)
     ns = ops.wgrad_splits(M, N, K)
     slab = torch.empty(max(ops.wgrad_scratch_floats(N, K, ns), 1), device=DEV)
