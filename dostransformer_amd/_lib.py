@@ -206,6 +206,7 @@ _SIGS = {
     "dosx_attn_tv": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "dosx_attn_dp": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dosx_softmax_bwd": [_P, _P, _P, _P, _L, _I, _F, _P],
+    "dosx_softmax_fwd": [_P, _P, _L, _I, _F, _P],
     "dosx_ln_rowdot": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "dosx_ln_rowdot_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "dosx_rowdot": [_P, _P, _P, _P, _I, _I, _I, _P],

@@ -89,6 +89,28 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
   for (int j = lane; j < Nk; j += 64) dS[o + j] = scale * P[o + j] * ((mask ? dPd[o + j] * mask[o + j] : dPd[o + j]) - t);
 }
 
+// P[r,:] = softmax_fp32(scale * S[r,:])   (multihead_attention.py:68-70 for ANY number of keys: dosx_attention_fwd keeps the
+// score row of a query in LDS, Nk <= 320; with S from dosx_attn_dp this pair is the general form).  One wave per row.
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ S, float* __restrict__ P, long long rows, int Nk,
+                                                          float scale) {
+  const int lane = threadIdx.x & 63;
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const size_t o = (size_t)r * Nk;
+  float m = -INFINITY;
+  for (int j = lane; j < Nk; j += 64) m = fmaxf(m, scale * S[o + j]);
+  m = wave_max(m);
+  float t = 0.f;
+  for (int j = lane; j < Nk; j += 64) {
+    const float e = expf(scale * S[o + j] - m);
+    P[o + j] = e;                                  // (the same lane re-reads it below)
+    t += e;
+  }
+  t = wave_sum(t);
+  const float inv = 1.f / t;
+  for (int j = lane; j < Nk; j += 64) P[o + j] *= inv;
+}
+
 int check_kv(int Sq, int Bq, int Nk, int Bk, int H, const char* who) {
   DOSX_CHECK_ARG(Sq > 0 && Bq > 0 && Nk > 0 && Bk > 0 && Bq % Bk == 0 && H > 0 && (H & 3) == 0,
                  "%s: bad dims Sq=%d Bq=%d Nk=%d Bk=%d H=%d (H %% 4 == 0, Bq %% Bk == 0)", who, Sq, Bq, Nk, Bk, H);
@@ -133,6 +155,14 @@ extern "C" int dosx_softmax_bwd(const float* P, const float* mask, const float* 
   DOSX_CHECK_ARG(P && dPd && dS && Nk > 0, "dosx_softmax_bwd: bad args");
   hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, to_stream(stream), P, mask, dPd, dS,
                      rows, Nk, scale);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_softmax_fwd(const float* S, float* P, long long rows, int Nk, float scale, dosx_stream_t stream) {
+  if (rows <= 0) return 0;
+  DOSX_CHECK_ARG(S && P && Nk > 0 && S != P, "dosx_softmax_fwd: bad args");
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, to_stream(stream), S, P, rows, Nk, scale);
   DOSX_LAUNCH_CHECK();
   return 0;
 }

@@ -67,8 +67,9 @@ class _BareAttention(torch.autograd.Function):
 
 
 class _BareAttentionKV(torch.autograd.Function):
-    """softmax(Q K^T * dim**-0.5) V with K is not V: the softmax weights from the MFMA kernel run on the keys, the products
-    with V (and the whole backward) from the plain building blocks of csrc/attention_kv.hip."""
+    """softmax(Q K^T * dim**-0.5) V in general form - K is not V, more than 320 keys, or an embedding wider than 256: the
+    softmax weights from the MFMA kernel where the shape fits it (else scores + row softmax), the products with V and the
+    whole backward from the plain building blocks of csrc/attention_kv.hip."""
 
     @staticmethod
     def forward(ctx, q, k, v, mask=None):
@@ -76,15 +77,8 @@ class _BareAttentionKV(torch.autograd.Function):
         nk = k.shape[0]
         dev = q.device
         q2, k2, v2 = q.contiguous().reshape(sq * b, h), k.contiguous().reshape(nk * b, h), v.contiguous().reshape(nk * b, h)
-        ones, zeros = torch.ones(h, device=dev), torch.zeros(h, device=dev)
-        scratch = torch.empty(sq * b, h, device=dev)
         probs = torch.empty(b, sq, nk, device=dev)
-        a = Attn()
-        a.Sq, a.Bq, a.Nk, a.Bk, a.H = sq, b, nk, b, h
-        a.q_stride_s, a.q_stride_b, a.flags = b, 1, RAW_Q | NO_RESIDUAL
-        a.x, a.kvhat, a.gamma0, a.beta0 = q2.data_ptr(), k2.data_ptr(), ones.data_ptr(), zeros.data_ptr()
-        a.out, a.probs = scratch.data_ptr(), probs.data_ptr()
-        ops.attention_fwd(a)                                   # (its P.K output is discarded: only the weights are used)
+        ops.attention_weights(q2, k2, probs, sq, b, nk, b, h)  # (MFMA kernel where the shape fits it, general form otherwise)
         out = torch.empty(sq * b, h, device=dev)
         ops.attn_pv(probs, mask, v2, out, sq, b, nk, b, h)
         ctx.mask = mask
@@ -165,7 +159,8 @@ class MultiheadAttention(nn.Module):
             mask = torch.empty(bsz, tgt_len, key.shape[0], device=query.device, dtype=torch.float32)
             ops.dropout_mask(mask, float(self.attn_dropout), seed, 0)
             self.last_drop_mask = mask
-        if same_kv:
+        fits = key.shape[0] <= ops.ATTN_MAX_NK and embed_dim <= ops.ATTN_MAX_H
+        if same_kv and fits:
             out = _BareAttention.apply(query.float(), key.float(), mask)
         else:
             out = _BareAttentionKV.apply(query.float(), key.float(), value.float(), mask)

@@ -888,6 +888,36 @@ def softmax_bwd(P, mask, dPd, dS, rows, Nk, scale):
     _call("dosx_softmax_bwd", _p(P), _p(mask), _p(dPd), _p(dS), int(rows), int(Nk), float(scale), _stream())
 
 
+# shapes the MFMA attention kernels take (csrc/attention.hip: the score row of a query lives in LDS); beyond them the
+# K != V building blocks are the general path (any Nk, any H % 4 == 0)
+ATTN_MAX_NK, ATTN_MAX_H = 320, 256
+
+
+def attention_weights(q, k, probs, Sq, Bq, Nk, Bk, H):
+    """probs[bq, s, :] = softmax_fp32(H**-0.5 * q[(s,bq)] . k[(j, bq % Bk)]) for rows that are ALREADY normalised / projected
+    (multihead_attention.py:68-70): the MFMA kernel where it fits, ``attn_dp`` + ``softmax_fwd`` for any shape."""
+    if Nk <= ATTN_MAX_NK and H <= ATTN_MAX_H and H % 8 == 0:
+        dev = q.device
+        ones, zeros = torch.ones(H, device=dev), torch.zeros(H, device=dev)
+        scratch = torch.empty(Sq * Bq, H, device=dev)
+        a = _lib.Attn()
+        a.Sq, a.Bq, a.Nk, a.Bk, a.H = Sq, Bq, Nk, Bk, H
+        a.q_stride_s, a.q_stride_b, a.flags = Bq, 1, 1 | 2            # RAW_Q | NO_RESIDUAL
+        a.x, a.kvhat, a.gamma0, a.beta0 = q.data_ptr(), k.data_ptr(), ones.data_ptr(), zeros.data_ptr()
+        a.out, a.probs = scratch.data_ptr(), probs.data_ptr()
+        attention_fwd(a)                                               # (its P.K output is discarded)
+        return (ones, zeros, scratch)                                  # keep-alive for recorded programs
+    scores = torch.empty(Bq, Sq, Nk, device=q.device)
+    attn_dp(q, k, scores, Sq, Bq, Nk, Bk, H)
+    softmax_fwd(scores, probs, Bq * Sq, Nk, H ** -0.5)
+    return (scores,)
+
+
+def softmax_fwd(S, P, rows, Nk, scale):
+    """P = softmax_fp32(scale * S) row by row (any Nk); with ``attn_dp(Q, K, S)`` the general attention weights."""
+    _call("dosx_softmax_fwd", _p(S), _p(P), int(rows), int(Nk), float(scale), _stream())
+
+
 def ln_rowdot(x, gamma, beta, w, b, xhat, rstd, dos, S, Bq, H):
     _call("dosx_ln_rowdot", _p(x), _p(gamma), _p(beta), _p(w), _p(b), _p(xhat), _p(rstd), _p(dos), S, Bq, H, _stream(),
           w=lambda: ("ln_rowdot", "ln_rowdot_kernel", "hbm", 8.0 * S * Bq * H))

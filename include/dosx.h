@@ -327,7 +327,9 @@ int dosx_attention_bwd(const DosxAttn* a, dosx_stream_t stream);
  *   dosx_attn_pv:     out[(s,bq)] = sum_j (A o mask)[bq,s,j] V[(j, bq % Bk)]                 (P.V, and dQ = dS.K)
  *   dosx_attn_tv:     out[(j,bk)] (+)= sum_{bq = bk mod Bk} sum_s (A o mask)[bq,s,j] X[(s,bq)]   (dV = P^T dOut, dK = dS^T Q)
  *   dosx_attn_dp:     dP[bq,s,j] = X[(s,bq)] . V[(j, bq % Bk)]
- *   dosx_softmax_bwd: dS = scale * P o (dPd o mask - rowsum(dPd o mask o P))                   (rows = Bq*Sq) */
+ *   dosx_softmax_bwd: dS = scale * P o (dPd o mask - rowsum(dPd o mask o P))                   (rows = Bq*Sq)
+ *   dosx_softmax_fwd: P = softmax_fp32(scale * S) row by row - with S from dosx_attn_dp(Q, K) the attention weights for ANY
+ *                     number of keys and any H % 4 == 0 (dosx_attention_fwd: Nk <= 320, H <= 256) */
 int dosx_attn_pv(const float* A, const float* mask, const float* V, float* out, int Sq, int Bq, int Nk, int Bk, int H,
                  dosx_stream_t stream);
 int dosx_attn_tv(const float* A, const float* mask, const float* X, float* out, int Sq, int Bq, int Nk, int Bk, int H,
@@ -335,6 +337,7 @@ int dosx_attn_tv(const float* A, const float* mask, const float* X, float* out, 
 int dosx_attn_dp(const float* X, const float* V, float* dP, int Sq, int Bq, int Nk, int Bk, int H, dosx_stream_t stream);
 int dosx_softmax_bwd(const float* P, const float* mask, const float* dPd, float* dS, long long rows, int Nk, float scale,
                      dosx_stream_t stream);
+int dosx_softmax_fwd(const float* S, float* P, long long rows, int Nk, float scale, dosx_stream_t stream);
 
 /* out_layer (nn.Linear(H,1), DOSTransformer_phonon.py:101,115) fused with the encoder's final
  * LayerNorm (layers/transformer.py:76-77) and the squeeze/transposed store:

@@ -348,17 +348,27 @@ def test_models_with_overfull_nodes_match_the_oracle(kind):
 
 def test_shape_limits_are_explicit_errors():
     """The two shape limits of the fused path fail LOUDLY, with the limit in the message, and leave the
-    library usable: more than 320 atoms in a crystal (LDS-resident softmax row), hidden > 256 (one-tile row epilogues)."""
-    from dostransformer_amd._lib import DosxError
-    from dostransformer_amd.layers import TransformerEncoder
-    enc = TransformerEncoder(embed_dim=32, num_heads=1, layers=1).to(DEV)
-    x = torch.randn(51, 2, 32, device=DEV)
-    kv = torch.randn(321, 2, 32, device=DEV)
-    with pytest.raises(DosxError, match="Nk=321"):
-        enc(x, kv, kv)
-    k320 = kv[:320].contiguous()
-    y = enc(x, k320, k320)                               # the limit itself works
-    assert bool(torch.isfinite(y).all())
+    library usable: more than 320 keys in the fused attention kernel (LDS-resident softmax row; the `layers` modules route
+    such shapes to the general path, test_layers_take_any_number_of_keys_and_wide_embeddings), hidden > 256 in the models
+    (one-tile row epilogues of the GNN kernels)."""
+    from dostransformer_amd._lib import DosxError, Attn
+    o = ops()
+    H, Sq, Bq = 32, 51, 2
+    for Nk, ok in ((320, True), (321, False)):           # the fused kernel itself: the limit works, one more key does not
+        x, kv = torch.randn(Sq * Bq, H, device=DEV), torch.randn(Nk * Bq, H, device=DEV)
+        ones, zeros = torch.ones(H, device=DEV), torch.zeros(H, device=DEV)
+        out, probs = torch.empty(Sq * Bq, H, device=DEV), torch.empty(Bq, Sq, Nk, device=DEV)
+        a = Attn()
+        a.Sq, a.Bq, a.Nk, a.Bk, a.H, a.q_stride_s, a.q_stride_b, a.flags = Sq, Bq, Nk, Bq, H, Bq, 1, 1 | 2
+        a.x, a.kvhat, a.gamma0, a.beta0 = x.data_ptr(), kv.data_ptr(), ones.data_ptr(), zeros.data_ptr()
+        a.out, a.probs = out.data_ptr(), probs.data_ptr()
+        if ok:
+            o.attention_fwd(a)
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(out).all())
+        else:
+            with pytest.raises(DosxError, match="Nk=321"):
+                o.attention_fwd(a)
     from dostransformer_amd import synth
     from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
     torch.manual_seed(0)
@@ -599,6 +609,55 @@ def test_multihead_attention_with_key_is_not_value():
         for g_, r_ in ((q.grad, q2.grad), (k.grad, k2.grad), (v.grad, v2.grad)):
             assert err(g_, r_) < 5e-5
         assert mha.in_proj_weight.grad is None
+
+
+@pytest.mark.parametrize("H,S,B,Nk", [(32, 51, 2, 400), (32, 20, 3, 1000), (256, 10, 2, 330), (128, 12, 3, 700), (512, 12, 2, 9)])
+def test_layers_take_any_number_of_keys_and_wide_embeddings(H, S, B, Nk):
+    """`layers.MultiheadAttention` and `layers.TransformerEncoder` called with the SAME tensor for keys and values (every
+    reference call site) on shapes beyond the fused kernels - more than 320 keys (both modules), embed_dim 512 (attention module):
+    the general path (scores by dosx_attn_dp, dosx_softmax_fwd, the K != V building blocks) against float64 autograd of
+    `multihead_attention.py:62-74` and against the oracle's encoder, outputs and every gradient."""
+    from oracle import dos_oracle as O
+    from dostransformer_amd.layers import TransformerEncoder
+    from dostransformer_amd.layers.multihead_attention import MultiheadAttention
+    torch.manual_seed(0)
+    gen = torch.Generator().manual_seed(5)
+    mha = MultiheadAttention(H, 1).to(DEV)
+    q = torch.randn(S, B, H, generator=gen).to(DEV).requires_grad_(True)
+    kv = torch.randn(Nk, B, H, generator=gen).to(DEV).requires_grad_(True)
+    w = torch.randn(S, B, H, generator=gen).to(DEV)
+    out = mha(q, kv, kv)
+    (out * w).sum().backward()
+    q2, k2 = (t.detach().double().requires_grad_(True) for t in (q, kv))
+    a = torch.softmax(torch.bmm(q2.transpose(0, 1), k2.permute(1, 2, 0)) * H ** -0.5, -1)
+    ref = torch.bmm(a, k2.transpose(0, 1)).transpose(0, 1)
+    (ref * w.double()).sum().backward()
+    assert err(out.detach(), ref.detach()) < 3e-5
+    assert err(q.grad, q2.grad) < 5e-5 and err(kv.grad, k2.grad) < 5e-5
+    if H > 256:
+        return                                             # (the encoder's row kernels stop at 256 columns: DESIGN.md §7)
+    T = 2
+    enc = TransformerEncoder(embed_dim=H, num_heads=1, layers=T).to(DEV)
+    with torch.no_grad():
+        for n, p in enc.named_parameters():
+            if "layer_norm" in n or "bias" in n:
+                p.add_(0.1 * torch.randn_like(p))
+    x = torch.randn(S, B, H, generator=gen).to(DEV).requires_grad_(True)
+    k = torch.randn(Nk, B, H, generator=gen).to(DEV).requires_grad_(True)
+    y = enc(x, k, k)
+    (y * w).sum().backward()
+    p64 = {"e." + n: t_.detach().double().cpu().requires_grad_(True) for n, t_ in enc.state_dict().items() if t_.is_floating_point()}
+    x64, k64 = x.detach().double().cpu().requires_grad_(True), k.detach().double().cpu().requires_grad_(True)
+    yr = O.transformer_encoder(p64, "e", x64, k64, k64, T)
+    (yr * w.double().cpu()).sum().backward()
+    assert float((y.detach().cpu().double() - yr.detach()).abs().max()) < 5e-5
+    rel = lambda a_, b_: float((a_.cpu().double() - b_).abs().max() / (b_.abs().max() + 1e-12))
+    assert rel(x.grad, x64.grad) < 1e-4 and rel(k.grad, k64.grad) < 1e-4
+    for n, p in enc.named_parameters():
+        if ".self_attn." in n:
+            assert p.grad is None
+        else:
+            assert rel(p.grad, p64["e." + n].grad) < 2e-4, n
 
 
 @pytest.mark.parametrize("case", ["kv_differ", "embed_dropout", "everything"])
