@@ -46,7 +46,7 @@ class _BlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, fwd, bwd, names, n_in, *args):
         ins, params = args[:n_in], args[n_in:]
-        P = {n: p.detach() for n, p in zip(names, params)}
+        P = Fn.pack_params({n: p.detach() for n, p in zip(names, params)})
         with torch.no_grad():
             outs, saved = fwd(P, *[t.detach() if torch.is_tensor(t) else t for t in ins])
         ctx.bwd, ctx.P, ctx.names, ctx.saved, ctx.n_in = bwd, P, names, saved, n_in

@@ -41,6 +41,24 @@ class SegList:
         self.plain = plain          # the segments as whole row-major tensors, when that is all they are (no row maps)
 
 
+def pack_params(P: Params) -> Params:
+    """The parameters as views of ONE buffer when torch allocated them far apart: the fused feed-forward and NodeModel
+    kernels address the two weight matrices of a layer through one 2 GiB buffer window (dosx_ffn_*, dosx_mlp_ln_*).  The
+    models keep all parameters in one flat buffer anyway; a standalone module's parameters are separate allocations that
+    drift apart in a long-lived process."""
+    ptrs = [t.data_ptr() for t in P.values()]
+    if not ptrs or max(ptrs) - min(ptrs) < (1 << 30):
+        return P
+    flat = torch.empty(sum((t.numel() + 3) // 4 * 4 for t in P.values()), device=next(iter(P.values())).device)
+    out, o = {}, 0
+    for k, t in P.items():
+        v = flat[o:o + t.numel()].view(t.shape)
+        v.copy_(t)
+        out[k] = v
+        o += (t.numel() + 3) // 4 * 4
+    return out
+
+
 def _wgrad_linear(sink: GradSink, G: Params, wkey: str, bkey: Optional[str], M: int, N: int, dy: Seg,
                   segs: Sequence[Seg], keep=(), **pro) -> None:
     """dW (and db) of y = A W^T + b as split slabs + reduce jobs (launched on the sink's side stream;

@@ -52,7 +52,7 @@ class _EncoderFn(torch.autograd.Function):
         sq, b, h = x.shape
         self_attn = kv is None
         dev = x.device
-        P = {"enc." + n: p.detach() for n, p in zip(names, params)}
+        P = Fn.pack_params({"enc." + n: p.detach() for n, p in zip(names, params)})
         x2 = x.detach().contiguous().reshape(sq * b, h)
         src = x2 if self_attn else kv.detach().contiguous().reshape(-1, h)
         nk = sq if self_attn else kv.shape[0]

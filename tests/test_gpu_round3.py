@@ -660,6 +660,49 @@ def test_layers_take_any_number_of_keys_and_wide_embeddings(H, S, B, Nk):
             assert rel(p.grad, p64["e." + n].grad) < 2e-4, n
 
 
+def test_standalone_modules_with_parameters_far_apart():
+    """The fused feed-forward / NodeModel kernels reach both weight matrices of a layer through one 2 GiB buffer window.  A
+    standalone module's parameters are separate torch allocations: put fc1 and fc2 (and the NodeModel's two Linears) at the two
+    ends of a 3 GiB buffer - the modules pack them into one buffer for the call (functional.pack_params) and give the same
+    bits as before."""
+    from dostransformer_amd.layers import TransformerEncoder
+    from dostransformer_amd._blocks import NodeModel
+    torch.manual_seed(0)
+    H = 64
+    enc = TransformerEncoder(embed_dim=H, num_heads=1, layers=2).to(DEV)
+    node = NodeModel(H).to(DEV)
+    x = torch.randn(51, 3, H, device=DEV, requires_grad=True)
+    kv = torch.randn(9, 3, H, device=DEV)
+    xn = torch.randn(10, H, device=DEV, requires_grad=True)
+    ei = torch.randint(0, 10, (2, 40), device=DEV)
+    ea = torch.randn(40, H, device=DEV)
+
+    def run():
+        for t in (x, xn):
+            t.grad = None
+        enc.zero_grad(); node.zero_grad()
+        y = enc(x, kv, kv)
+        z = node(xn, ei, ea)
+        (y.sum() + z.sum()).backward()
+        return [y.detach().clone(), z.detach().clone(), x.grad.clone(), xn.grad.clone()] + \
+            [p.grad.clone() for p in list(enc.parameters()) + list(node.parameters()) if p.grad is not None]
+    ref = run()
+    big = torch.empty(3 * 2 ** 30 // 4, device=DEV)
+    with torch.no_grad():
+        pairs = [(lay.fc1.weight, lay.fc2.weight) for lay in enc.layers] + [(node.node_mlp_2[0].weight, node.node_mlp_2[3].weight)]
+        lo, hi = 0, big.numel()
+        for w1, w2 in pairs:                              # first matrix from the front of the buffer, second from its end
+            a_, b_ = big[lo:lo + w1.numel()].view_as(w1), big[hi - w2.numel():hi].view_as(w2)
+            a_.copy_(w1); b_.copy_(w2)
+            w1.data, w2.data = a_, b_
+            lo, hi = lo + w1.numel(), hi - w2.numel()
+    assert abs(enc.layers[0].fc1.weight.data_ptr() - enc.layers[0].fc2.weight.data_ptr()) > 2 ** 31
+    far = run()
+    assert len(ref) == len(far)
+    for a_, b_ in zip(ref, far):
+        assert torch.equal(a_, b_)
+
+
 @pytest.mark.parametrize("case", ["kv_differ", "embed_dropout", "everything"])
 def test_transformer_encoder_with_k_not_v_matches_oracle(case):
     """TransformerEncoder with x_in_k is not x_in_v, and with embed dropout (`transformer.py:61-68`: independent masks on the
