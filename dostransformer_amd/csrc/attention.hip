@@ -4,6 +4,7 @@
 //
 // (layers/transformer.py:131-138 + layers/multihead_attention.py:68-74: no q/k/v/out projection,
 //  no mask, no head split; zero-padded atoms are real keys with value beta0 — SURVEY.md §0.2-0.3.)
+// (More than 320 keys: attention_general.hip, same contract.)
 // One workgroup owns a 32-query tile of one crystal; the key set of the crystal (Nk <= 320: atoms <= Nmax,
 // or the 51/201 energy bins for self attention) is streamed twice through LDS in 32-wide chunks by four
 // staging waves while four matrix waves run the row phases and the MFMAs; the whole score row of a
@@ -1282,9 +1283,11 @@ size_t dkv_smem(const Geo& g, int kg) {
   return sizeof(float) * (stage > epi ? stage : epi);
 }
 
+constexpr int MAX_FUSED_NK = 320;      // the score row of a query lives in LDS
+
 int check_attn(const DosxAttn& a, const char* who) {
   DOSX_CHECK_ARG(a.H > 0 && (a.H & 3) == 0 && a.H <= 32 * 4 * MAX_CT, "%s: H=%d unsupported (multiple of 4, <= 256)", who, a.H);
-  DOSX_CHECK_ARG(a.Nk > 0 && a.Nk <= 320, "%s: Nk=%d unsupported (1..320 keys per crystal)", who, a.Nk);
+  DOSX_CHECK_ARG(a.Nk > 0, "%s: Nk=%d", who, a.Nk);       // (more than MAX_FUSED_NK keys: attention_general.hip)
   DOSX_CHECK_ARG(a.Sq > 0 && a.Bq > 0 && a.Bk > 0 && a.Bq % a.Bk == 0, "%s: bad Sq/Bq/Bk = %d/%d/%d", who, a.Sq, a.Bq, a.Bk);
   DOSX_CHECK_ARG(a.x && a.kvhat && a.gamma0 && a.beta0 && a.probs, "%s: null operand", who);
   DOSX_CHECK_ARG(a.qstats || (a.flags & DOSX_ATTN_RAW_Q), "%s: qstats required unless RAW_Q", who);
@@ -1292,6 +1295,11 @@ int check_attn(const DosxAttn& a, const char* who) {
 }
 
 }  // namespace
+
+namespace dosx_detail {            // attention_general.hip: the same contract for any number of keys
+int attn_general_fwd(const DosxAttn& a, hipStream_t st);
+int attn_general_bwd(const DosxAttn& a, hipStream_t st);
+}  // namespace dosx_detail
 
 extern "C" int dosx_attention_pkv_supported(int Nk, int H) {
   return Nk > 0 && H > 0 && H <= 256 && pkv_fits(H, Nk);
@@ -1302,6 +1310,7 @@ extern "C" int dosx_attention_fwd(const DosxAttn* ap, dosx_stream_t stream) {
   const DosxAttn& a = *ap;
   if (int rc = check_attn(a, "dosx_attention_fwd")) return rc;
   DOSX_CHECK_ARG(a.out, "dosx_attention_fwd: null out");
+  if (a.Nk > MAX_FUSED_NK) return dosx_detail::attn_general_fwd(a, to_stream(stream));
   const Geo g = make_geo(a.H, a.Nk);
   const bool res = fwd_resident(a);
   const size_t smem = fwd_smem(g, res);
@@ -1332,6 +1341,7 @@ extern "C" int dosx_attention_bwd(const DosxAttn* ap, dosx_stream_t stream) {
   if (int rc = check_attn(a, "dosx_attention_bwd")) return rc;
   DOSX_CHECK_ARG(a.dout && a.dx && (a.dscores || pkv_ok(a)) && a.dkvhat && a.partials_q && a.partials_kv,
                  "dosx_attention_bwd: null operand");
+  if (a.Nk > MAX_FUSED_NK) return dosx_detail::attn_general_bwd(a, to_stream(stream));
   const Geo g = make_geo(a.H, a.Nk);
   const int kg = a.Nk > 32 ? 2 : 1;
   const bool pkv = pkv_ok(a);

@@ -542,13 +542,13 @@ def encoder_kv_fwd(P: Params, pre: str, x: torch.Tensor, xk: torch.Tensor, xv: t
         k, kh, kr = ln(xk, krows)
         v, vh, vr = ln(xv, krows)
         probs = _empty(dev, Bq, Sq, Nk)
-        if Nk <= ops.ATTN_MAX_NK and H <= ops.ATTN_MAX_H and H % 8 == 0:
+        if H <= ops.ATTN_MAX_H:
             scratch = _empty(dev, rows, H)
             a = _attn_desc(Sq, Bq, Nk, Bk, H, Bq, 1, q, k, ones, zeros)
             a.flags = 1 | 2                                # RAW_Q | NO_RESIDUAL: q and k are already normalised
             a.out, a.probs = scratch.data_ptr(), probs.data_ptr()
             ops.attention_fwd(a)                           # (only the softmax weights are used)
-        else:                                              # any number of keys / any width: scores + row softmax
+        else:                                              # wider rows: scores + row softmax
             scores = _empty(dev, Bq, Sq, Nk)
             ops.attn_dp(q, k, scores, Sq, Bq, Nk, Bk, H)
             ops.softmax_fwd(scores, probs, Bq * Sq, Nk, H ** -0.5)

@@ -67,7 +67,7 @@ class _BareAttention(torch.autograd.Function):
 
 
 class _BareAttentionKV(torch.autograd.Function):
-    """softmax(Q K^T * dim**-0.5) V in general form - K is not V, more than 320 keys, or an embedding wider than 256: the
+    """softmax(Q K^T * dim**-0.5) V in general form - K is not V, or an embedding wider than 256: the
     softmax weights from the MFMA kernel where the shape fits it (else scores + row softmax), the products with V and the
     whole backward from the plain building blocks of csrc/attention_kv.hip."""
 
@@ -159,7 +159,7 @@ class MultiheadAttention(nn.Module):
             mask = torch.empty(bsz, tgt_len, key.shape[0], device=query.device, dtype=torch.float32)
             ops.dropout_mask(mask, float(self.attn_dropout), seed, 0)
             self.last_drop_mask = mask
-        fits = key.shape[0] <= ops.ATTN_MAX_NK and embed_dim <= ops.ATTN_MAX_H
+        fits = embed_dim <= ops.ATTN_MAX_H                     # (any number of keys; wider rows take the building blocks)
         if same_kv and fits:
             out = _BareAttention.apply(query.float(), key.float(), mask)
         else:

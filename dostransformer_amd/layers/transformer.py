@@ -206,11 +206,9 @@ class TransformerEncoder(nn.Module):
         live = [(n, p) for n, p in self.named_parameters() if ".self_attn." not in n]
         names = tuple(n for n, _ in live)
         params = tuple(p for _, p in live)
-        big = x_in_k.shape[0] > ops.ATTN_MAX_NK
-        if x_in_k is not x_in_v or big or (self.training and float(self.dropout or 0.0) > 0.0):
+        if x_in_k is not x_in_v or (self.training and float(self.dropout or 0.0) > 0.0):
             # K != V - different tensors, or embed dropout, which draws different masks for keys and values
-            # (transformer.py:61-68) - or more keys than the fused kernels take (320): the
-            # general, unfused path.  Every reference call site passes one tensor for both and
+            # (transformer.py:61-68): the general, unfused path.  Every reference call site passes one tensor for both and
             # leaves embed dropout at 0 (DOSTransformer_phonon.py:27-38,88,97,99): that is the fused path below.
             y = _EncoderKVFn.apply(x_in.float(), x_in_k.float(), x_in_v.float(), self, names, _skip_final_ln, *params)
             return y.to(x_in.dtype)

@@ -888,15 +888,15 @@ def softmax_bwd(P, mask, dPd, dS, rows, Nk, scale):
     _call("dosx_softmax_bwd", _p(P), _p(mask), _p(dPd), _p(dS), int(rows), int(Nk), float(scale), _stream())
 
 
-# shapes the MFMA attention kernels take (csrc/attention.hip: the score row of a query lives in LDS); beyond them the
-# K != V building blocks are the general path (any Nk, any H % 4 == 0)
-ATTN_MAX_NK, ATTN_MAX_H = 320, 256
+# widest row of dosx_attention_* (any number of keys: <= 320 the MFMA kernels, more the general kernels of
+# csrc/attention_general.hip); wider rows go through the K != V building blocks (any Nk, any H % 4 == 0)
+ATTN_MAX_H = 256
 
 
 def attention_weights(q, k, probs, Sq, Bq, Nk, Bk, H):
     """probs[bq, s, :] = softmax_fp32(H**-0.5 * q[(s,bq)] . k[(j, bq % Bk)]) for rows that are ALREADY normalised / projected
     (multihead_attention.py:68-70): the MFMA kernel where it fits, ``attn_dp`` + ``softmax_fwd`` for any shape."""
-    if Nk <= ATTN_MAX_NK and H <= ATTN_MAX_H and H % 8 == 0:
+    if H <= ATTN_MAX_H:
         dev = q.device
         ones, zeros = torch.ones(H, device=dev), torch.zeros(H, device=dev)
         scratch = torch.empty(Sq * Bq, H, device=dev)

@@ -277,7 +277,9 @@ int dosx_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, co
  *   x1 = x + softmax_fp32( LN0(x) K^T * H^-1/2 ) K ,  K = kvhat*gamma0 + beta0   (K == V)
  * (layers/transformer.py:131-138, layers/multihead_attention.py:68-74: no projections, no
  *  mask, no heads).  Query row (s, bq) is at x + (s*q_stride_s + bq*q_stride_b)*H; output
- *  row (s,bq) at s*Bq + bq; key row (j, bk) at j*Bk + bk with bk = bq % Bk. */
+ *  row (s,bq) at s*Bq + bq; key row (j, bk) at j*Bk + bk with bk = bq % Bk.
+ *  H <= 256, H % 4 == 0; ANY number of keys: up to 320 per crystal the MFMA kernels (score row of a query in LDS), more
+ *  through one-wave-per-row kernels with the same results contract (csrc/attention_general.hip; they need `dscores`). */
 /* BWD_SKIP_*: dosx_attention_bwd launches two kernels (dq: needs dout,P -> dx,dS ; dkv: needs dS -> dkvhat);
  * a caller may issue them separately (e.g. dkv on a second stream: only the final key-gradient consumers need it). */
 enum { DOSX_ATTN_RAW_Q = 1, DOSX_ATTN_NO_RESIDUAL = 2, DOSX_ATTN_BWD_SKIP_DQ = 4, DOSX_ATTN_BWD_SKIP_DKV = 8 };
@@ -329,7 +331,7 @@ int dosx_attention_bwd(const DosxAttn* a, dosx_stream_t stream);
  *   dosx_attn_dp:     dP[bq,s,j] = X[(s,bq)] . V[(j, bq % Bk)]
  *   dosx_softmax_bwd: dS = scale * P o (dPd o mask - rowsum(dPd o mask o P))                   (rows = Bq*Sq)
  *   dosx_softmax_fwd: P = softmax_fp32(scale * S) row by row - with S from dosx_attn_dp(Q, K) the attention weights for ANY
- *                     number of keys and any H % 4 == 0 (dosx_attention_fwd: Nk <= 320, H <= 256) */
+ *                     number of keys and any H % 4 == 0 (dosx_attention_fwd: H <= 256) */
 int dosx_attn_pv(const float* A, const float* mask, const float* V, float* out, int Sq, int Bq, int Nk, int Bk, int H,
                  dosx_stream_t stream);
 int dosx_attn_tv(const float* A, const float* mask, const float* X, float* out, int Sq, int Bq, int Nk, int Bk, int H,

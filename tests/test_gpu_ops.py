@@ -452,7 +452,10 @@ def _attn_ref(x, kvhat, gam, bet, Sq, Bq, Nk, Bk, H, qs, qb, mask=None):
 @pytest.mark.parametrize("Sq,Bq,Nk,Bk,H,bcast", [(51, 4, 12, 4, 128, False), (51, 6, 9, 3, 64, False),
                                                    (201, 2, 41, 2, 256, False), (70, 3, 70, 3, 128, False),
                                                    (51, 5, 7, 5, 128, True), (201, 2, 201, 2, 256, False),
-                                                   (7, 3, 5, 3, 16, False)])
+                                                   (7, 3, 5, 3, 16, False),
+                                                   # more than 320 keys: the general kernels behind the same contract
+                                                   (51, 4, 330, 2, 128, False), (20, 3, 700, 3, 64, False),
+                                                   (51, 4, 321, 4, 128, True), (9, 2, 400, 2, 256, False)])
 @pytest.mark.parametrize("drop", [0.0, 0.35])
 @pytest.mark.parametrize("pkv", [False, True])
 def test_attention_fwd_bwd(Sq, Bq, Nk, Bk, H, bcast, pkv, drop):

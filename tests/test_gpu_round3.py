@@ -348,13 +348,13 @@ def test_models_with_overfull_nodes_match_the_oracle(kind):
 
 def test_shape_limits_are_explicit_errors():
     """The two shape limits of the fused path fail LOUDLY, with the limit in the message, and leave the
-    library usable: more than 320 keys in the fused attention kernel (LDS-resident softmax row; the `layers` modules route
-    such shapes to the general path, test_layers_take_any_number_of_keys_and_wide_embeddings), hidden > 256 in the models
-    (one-tile row epilogues of the GNN kernels)."""
+    library usable: hidden > 256 (one-tile row epilogues of the GNN kernels, one float4 per lane in the row kernels).  The
+    number of keys has no limit: more than 320 (the LDS-resident score row of the MFMA kernels) take the general kernels of
+    csrc/attention_general.hip behind the same descriptor (tests/test_gpu_ops.py::test_attention_fwd_bwd)."""
     from dostransformer_amd._lib import DosxError, Attn
     o = ops()
     H, Sq, Bq = 32, 51, 2
-    for Nk, ok in ((320, True), (321, False)):           # the fused kernel itself: the limit works, one more key does not
+    for Nk in (320, 321, 1000):                          # no limit on the keys: 321+ take the general kernels (same contract)
         x, kv = torch.randn(Sq * Bq, H, device=DEV), torch.randn(Nk * Bq, H, device=DEV)
         ones, zeros = torch.ones(H, device=DEV), torch.zeros(H, device=DEV)
         out, probs = torch.empty(Sq * Bq, H, device=DEV), torch.empty(Bq, Sq, Nk, device=DEV)
@@ -362,13 +362,12 @@ def test_shape_limits_are_explicit_errors():
         a.Sq, a.Bq, a.Nk, a.Bk, a.H, a.q_stride_s, a.q_stride_b, a.flags = Sq, Bq, Nk, Bq, H, Bq, 1, 1 | 2
         a.x, a.kvhat, a.gamma0, a.beta0 = x.data_ptr(), kv.data_ptr(), ones.data_ptr(), zeros.data_ptr()
         a.out, a.probs = out.data_ptr(), probs.data_ptr()
-        if ok:
-            o.attention_fwd(a)
-            torch.cuda.synchronize()
-            assert bool(torch.isfinite(out).all())
-        else:
-            with pytest.raises(DosxError, match="Nk=321"):
-                o.attention_fwd(a)
+        o.attention_fwd(a)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(out).all()) and float((probs.sum(-1) - 1).abs().max()) < 1e-5
+    a.H = 260                                            # ... but the row kernels stop at 256 columns
+    with pytest.raises(DosxError, match="H=260"):
+        o.attention_fwd(a)
     from dostransformer_amd import synth
     from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
     torch.manual_seed(0)
@@ -658,6 +657,53 @@ def test_layers_take_any_number_of_keys_and_wide_embeddings(H, S, B, Nk):
             assert p.grad is None
         else:
             assert rel(p.grad, p64["e." + n].grad) < 2e-4, n
+
+
+@pytest.mark.parametrize("mode", ["eager", "replay"])
+def test_crystal_with_more_than_320_atoms(mode):
+    """A crystal of 330 atoms next to one of 5: the cross attention over atoms runs over 330 keys (zero-padded for the small
+    crystal, `DOSTransformer_phonon.py:86-88`) - beyond the MFMA attention kernels, through csrc/attention_general.hip behind the
+    same descriptor.  Outputs, loss and every gradient against the oracle in float64; replay = eager bitwise."""
+    from oracle import dos_oracle as O
+    from dostransformer_amd import synth
+    from dostransformer_amd.batch import collate
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    from dostransformer_amd.train import Trainer
+    torch.manual_seed(0)
+    H, T = 32, 2
+    model = DOSTransformer_phonon(2, T, 118, 4, H, DEV, 0.0)
+    params = {k: (v.detach().clone().double() if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    gen = torch.Generator().manual_seed(4)
+    cr = [synth.phonon_crystal(gen, n_atoms=330, n_out=4), synth.phonon_crystal(gen, n_atoms=5, n_out=4)]
+    g_ref = collate(cr)
+    g = collate([{k: (v.float() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in c.items()} for c in cr]).to(DEV)
+    with torch.no_grad():
+        rg, rx, rs = O.dostransformer_phonon_forward(params, g_ref, 2, T)
+    tr = Trainer(model, lr=1e-4, beta=1.0, replay=(mode == "replay"))
+    if mode == "replay":
+        losses = [float(tr.step(g)) for _ in range(2)]     # the second step replays the recorded program
+        model2 = DOSTransformer_phonon(2, T, 118, 4, H, DEV, 0.0)
+        model2.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in params.items()})
+        tr2 = Trainer(model2.to(DEV), lr=1e-4, beta=1.0)
+        eager = [float(tr2.step(g)) for _ in range(2)]
+        assert losses == eager
+        for (k, v), (_, v2) in zip(model.state_dict().items(), model2.state_dict().items()):
+            assert torch.equal(v, v2), k
+        return
+    loss = tr.forward_backward(g)
+    dg, xn, ds = tr.last_outputs
+    rm = lambda a_, b_: float(torch.sqrt(((a_.double() - b_.double()) ** 2).mean()))
+    assert rm(dg.cpu(), rg) < 1e-4 and rm(ds.cpu(), rs) < 1e-4
+    ref_loss, grads = O.train_step("phonon", params, {}, g_ref, 2, T, lr=1e-4, beta=1.0)
+    assert abs(float(loss) - float(ref_loss)) < 2e-4
+    fp = model.flat_params()
+    for k, gr in grads.items():
+        if gr is None:
+            assert k not in fp.G, k
+        else:
+            e = float((fp.G[k].cpu().double() - gr.double()).abs().max() / (gr.abs().max() + 1e-6))
+            assert e < 2e-3, (k, e)
 
 
 def test_standalone_modules_with_parameters_far_apart():
