@@ -269,7 +269,9 @@ def run_workload(name, *, device, world, rank, dp, mode, shuffle, steps, warmup,
         if dp is not None:
             td.barrier()
 
-    n_warm = max(warmup, N_DISTINCT_BATCHES if (use_graph and not shuffle) else 0)   # record every fixed bucket
+    # warm-up: every fixed bucket is RECORDED once (an eager step) and REPLAYED once before the clock starts - the first replay
+    # of a recorded program still pays one-time costs (20 timed steps: 1.316 ms with 8 warm-up steps, 1.292 with 16)
+    n_warm = max(warmup, 2 * N_DISTINCT_BATCHES if (use_graph and not shuffle) else 0)
     for i in range(n_warm):
         do_step()
     sync()
@@ -341,7 +343,7 @@ def run_workload(name, *, device, world, rank, dp, mode, shuffle, steps, warmup,
     ops.KERNEL_TIMER.reset(enabled=False)
     flops_step = 3.0 * sum(algorithmic_flops(kind, L, T, H, n, e, B, nm) for n, e, nm in dims) / max(len(dims), 1)
     res = {"kind": kind, "L": L, "T": T, "H": H, "B": B, "n_global": n_global, "elapsed": elapsed, "host": host, "host_enqueue": host_enqueue,
-           "roof": roof, "n_inst": n_inst, "flops_step": flops_step,
+           "roof": roof, "n_inst": n_inst, "flops_step": flops_step, "warmup_used": n_warm,
            "slots": {"hits": hits, "misses": misses, "hit_rate": round(hits / max(hits + misses, 1), 4),
                      "live": n_slots, "max": trainer.max_slots} if use_graph else None}
     del trainer, model
@@ -458,7 +460,7 @@ def main():
                       "crystals/sec training throughput (Electron DOS)",
             "value": round(n_global * args.steps / elapsed, 2),
             "unit": "crystals/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": r["warmup_used"],
             "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
