@@ -840,7 +840,7 @@ void gemm_kernel(const GemmLaunch L) {
         if (rvalid) st4(orow + gcol[j], v[j]);
         s1 += v[j].x + v[j].y + v[j].z + v[j].w;
       }
-      if (g.stats_out) {
+      if (g.stats_out || g.norm_out) {
         const float mean = wave_sum(s1) * invN;
         float s2 = 0.f;
 #pragma unroll
@@ -850,9 +850,18 @@ void gemm_kernel(const GemmLaunch L) {
           s2 += a * a + b * b + c2 * c2 + d * d;
         }
         const float var = wave_sum(s2) * invN;
-        if (lane == 0 && rvalid) {
+        const float rstd = rsqrtf(var + DOSX_LN_EPS);
+        if (g.stats_out && lane == 0 && rvalid) {
           g.stats_out[2 * (size_t)r] = mean;
-          g.stats_out[2 * (size_t)r + 1] = rsqrtf(var + DOSX_LN_EPS);
+          g.stats_out[2 * (size_t)r + 1] = rstd;
+        }
+        if (g.norm_out && rvalid) {          // the normalised rows next to the plain ones (same mapped row, same ld)
+          float* const nrow = g.norm_out + orow_[rt][i];
+#pragma unroll
+          for (int j = 0; j < CG; ++j)
+            if (on[j]) st4(nrow + gcol[j], make_float4((v[j].x - mean) * rstd, (v[j].y - mean) * rstd, (v[j].z - mean) * rstd,
+                                                       (v[j].w - mean) * rstd));
+          if (lane == 0) g.norm_rstd[dosx_map_row(g.out_map, r)] = rstd;
         }
       }
     } else if (epi == DOSX_EPI_LN) {
@@ -1206,7 +1215,7 @@ static int gemm_plan(const DosxGemm& g, GemmLaunch& L) {
   L.vecW = ((g.ldw & 3) == 0) && aligned16(g.w) && (g.w_layout == 0 ? (g.K & 3) == 0 : (g.N & 3) == 0);
   L.rt = gemm_rt(g.M, g.N, g.epi);
   int bn = gemm_bn(g.M, g.N, g.epi);
-  if (g.stats_out && bn < g.N) bn = g.N <= 256 ? 256 : 512;
+  if ((g.stats_out || g.norm_out) && bn < g.N) bn = g.N <= 256 ? 256 : 512;
   if (bn == 512 && L.rt >= 2) L.rt = 1;
   if (g.epi == DOSX_EPI_SEGSUM) {          // node-aligned 48-row tiles, one column tile
     L.rt = 3;
@@ -1252,6 +1261,8 @@ extern "C" int dosx_gemm(const DosxGemm* gp, dosx_stream_t stream) {
   const bool full_row = (g.epi == DOSX_EPI_LN || g.epi == DOSX_EPI_PRELU_LN_BWD || g.epi == DOSX_EPI_ROWLN_BWD);
   DOSX_CHECK_ARG(!full_row || g.N <= 512, "dosx_gemm: row-wise epilogue needs N <= 512 (hidden <= 256), got %d", g.N);
   DOSX_CHECK_ARG(!g.stats_out || g.N <= 128 * 4, "dosx_gemm: stats_out needs N <= 512");
+  DOSX_CHECK_ARG(!g.norm_out || (g.N <= 128 * 4 && g.norm_rstd && g.epi == DOSX_EPI_BIAS_ACT && aligned16(g.norm_out)),
+                 "dosx_gemm: norm_out needs the plain epilogue, N <= 512 and norm_rstd");
   DOSX_CHECK_ARG(g.out_map.d > 0, "dosx_gemm: out_map.d must be > 0");
   if (g.res) DOSX_CHECK_ARG(g.res_map.d > 0 && (g.ldr & 3) == 0 && aligned16(g.res), "dosx_gemm: bad residual");
   DOSX_CHECK_ARG(g.res_col0 >= 0 && (g.res_col0 & 3) == 0 && (g.res_col0 == 0 || (g.res && g.epi == DOSX_EPI_BIAS_ACT)),

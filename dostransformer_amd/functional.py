@@ -367,6 +367,7 @@ _FUSED_DKV = __import__("os").environ.get("DOSX_FUSED_DKV", "1") == "1"
 _LATE_SELF_FLUSH = __import__("os").environ.get("DOSX_LATE_SELF_FLUSH", "0") == "1"      # (measured: no gain)          # one-launch attention backward (Nk <= 64)
 _FUSED_FIN_BWD = __import__("os").environ.get("DOSX_FUSED_FIN_BWD", "1") == "1"
 _FUSED_HEAD_FWD = __import__("os").environ.get("DOSX_FUSED_HEAD_FWD", "1") == "1"
+_FUSED_HEAD_NORM = __import__("os").environ.get("DOSX_FUSED_HEAD_NORM", "1") == "1"     # DosxGemm.norm_out in the two heads
 
 
 def head_fused_bwd(H: int, T: int) -> bool:
@@ -812,13 +813,17 @@ def dostransformer_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta, drop=None):
     a_s = SegList([seg(E1), seg(graph, rmap=modB), seg(prow, rmap=modB)], [E1, graph, prow])
     # (the two heads write disjoint row sets of dosin; running fc_prompt on the side stream next to fc was measured: the two
     #  cross-queue events cost more than the 11 us GEMM they hide - 1.385 vs 1.370 ms per step)
-    ops.gemm(S * B, H, a_g.segs, P["fc.weight"], dosin, bias=P["fc.bias"], act=ACT_LEAKY, act_slope=0.01,
-             out_map=rowmap(d=B, m=2 * B, c=1, off=0))
-    ops.gemm(S * B, H, a_s.segs, P["fc_prompt.weight"], dosin, bias=P["fc_prompt.bias"], act=ACT_LEAKY,
-             act_slope=0.01, out_map=rowmap(d=B, m=2 * B, c=1, off=B))
+    # the self-attention encoder's stale keys are the NORMALISED head outputs: the heads' epilogues write them next to the
+    # plain rows (DosxGemm.norm_out) - no dosx_rownorm launch between the heads and the encoder
     kvs = _empty(dev, S * 2 * B, H)
     rstd_s = _empty(dev, S * 2 * B)
-    ops.rownorm(dosin, kvs, rstd_s, S * 2 * B, H)
+    nk = dict(norm_out=kvs, norm_rstd=rstd_s) if _FUSED_HEAD_NORM else {}
+    ops.gemm(S * B, H, a_g.segs, P["fc.weight"], dosin, bias=P["fc.bias"], act=ACT_LEAKY, act_slope=0.01,
+             out_map=rowmap(d=B, m=2 * B, c=1, off=0), **nk)
+    ops.gemm(S * B, H, a_s.segs, P["fc_prompt.weight"], dosin, bias=P["fc_prompt.bias"], act=ACT_LEAKY,
+             act_slope=0.01, out_map=rowmap(d=B, m=2 * B, c=1, off=B), **nk)
+    if not _FUSED_HEAD_NORM:
+        ops.rownorm(dosin, kvs, rstd_s, S * 2 * B, H)
     hs, c2 = encoder_fwd(P, "transformer_self", dosin, S, 2 * B, 2 * B, 1, kvs, S, 2 * B, H, T, drop=dr(64))
     xhat_f = _empty(dev, S * 2 * B, H)
     rstd_f = _empty(dev, S * 2 * B)

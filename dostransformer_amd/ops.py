@@ -298,7 +298,7 @@ def gemm(M: int, N: int, segs: Sequence[Seg], w: torch.Tensor, out: torch.Tensor
          out_map: Optional[RowMap] = None, res=None, res_map: Optional[RowMap] = None,
          stats_out=None, aux_out=None, aux=None, aux_stats=None, epi_gamma=None, epi_beta=None,
          epi_alpha=None, partials=None, partial_ld: int = 0, res_col0: int = 0, seg_tile=None, seg_rowptr=None,
-         seg_scale=None, seg_agg=None, keep: Optional[list] = None) -> None:
+         seg_scale=None, seg_agg=None, keep: Optional[list] = None, norm_out=None, norm_rstd=None) -> None:
     """out[M,N] = epilogue(prologue(A) @ B); see include/dosx.h:DosxGemm."""
     g = Gemm()
     g.M, g.N = int(M), int(N)
@@ -317,6 +317,9 @@ def gemm(M: int, N: int, segs: Sequence[Seg], w: torch.Tensor, out: torch.Tensor
     g.ldr = int(res.stride(0)) if res is not None else 0
     g.res_map = res_map if res_map is not None else ident()
     g.stats_out, g.aux_out = _p(stats_out), _p(aux_out)
+    if norm_out is not None:
+        assert norm_rstd is not None and out is not None and norm_out.stride(0) == out.stride(0)
+        g.norm_out, g.norm_rstd = norm_out.data_ptr(), norm_rstd.data_ptr()
     g.aux = _p(aux)
     g.ldaux = int(aux.stride(0)) if aux is not None else 0
     g.aux_stats = _p(aux_stats)

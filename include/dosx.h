@@ -120,6 +120,12 @@ typedef struct DosxGemm {
   int32_t res_col0;   /* EPI_BIAS_ACT: the residual is added to the output columns [res_col0, N) only, res column c
                          to output column res_col0 + c (0 = all columns).  The backward of the edge residual
                          e += e' (DOSTransformer_phonon.py:84) rides on the e-block of the [E,3H] concat gradient. */
+  float* norm_out;    /* EPI_BIAS_ACT, optional (N <= 512): ALSO the LayerNorm-normalised output rows without affine,
+                         (y - mean) * rstd, eps 1e-5, at the same (mapped) rows and leading dimension as `out` - the
+                         stale keys of the self-attention encoder are the normalised head outputs (layers/transformer.py:
+                         131-134 on DOSTransformer_phonon.py:97's input), so the heads' GEMMs write them and no
+                         dosx_rownorm launch follows */
+  float* norm_rstd;   /* with norm_out: rstd per OUTPUT row [rows of out] */
 } DosxGemm;
 
 /* exact number of workgroup rows dosx_gemm writes into `partials` for this epilogue: ceil(M/32) for

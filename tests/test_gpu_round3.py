@@ -659,6 +659,36 @@ def test_layers_take_any_number_of_keys_and_wide_embeddings(H, S, B, Nk):
             assert rel(p.grad, p64["e." + n].grad) < 2e-4, n
 
 
+@pytest.mark.parametrize("M,N,K,mapped", [(6528, 128, 256, True), (300, 256, 128, False), (4000, 64, 96, True), (33, 512, 64, False)])
+def test_gemm_writes_normalised_rows_too(M, N, K, mapped):
+    """DosxGemm.norm_out: the plain epilogue also writes LayerNorm(out) without affine and its rstd at the OUTPUT rows (through
+    out_map) - what dosx_rownorm on the finished output gives (the heads' GEMMs feed the self-attention encoder's stale keys
+    this way, DOSTransformer_phonon.py:90-97)."""
+    o = ops()
+    a, w, bias = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2), rnd(N, seed=3)
+    rows = 2 * M if mapped else M
+    d = 64 if mapped else 1
+    omap = o.rowmap(d=d, m=2 * d, c=1, off=d) if mapped else None       # blocks of d rows into every other block of 2d
+    if mapped and M % d:
+        pytest.skip("mapped case wants M % 64 == 0")
+    out = torch.full((rows, N), float("nan"), device=DEV)
+    nrm = torch.full((rows, N), float("nan"), device=DEV)
+    rstd = torch.full((rows,), float("nan"), device=DEV)
+    o.gemm(M, N, [o.seg(a)], w, out, bias=bias, act=o.ACT_LEAKY, act_slope=0.01, out_map=omap, norm_out=nrm, norm_rstd=rstd)
+    torch.cuda.synchronize()
+    y = torch.nn.functional.leaky_relu(a.double() @ w.double().T + bias.double(), 0.01)
+    idx = torch.arange(M, device=DEV)
+    if mapped:
+        idx = (idx // d) * 2 * d + idx % d + d
+    assert err(out[idx], y) < 2e-5
+    mu, var = y.mean(1, keepdim=True), y.var(1, unbiased=False, keepdim=True)
+    assert err(nrm[idx], (y - mu) / torch.sqrt(var + 1e-5)) < 5e-5
+    assert err(rstd[idx], 1 / torch.sqrt(var[:, 0] + 1e-5)) < 5e-5
+    other = torch.ones(rows, dtype=torch.bool, device=DEV)
+    other[idx] = False
+    assert bool(torch.isnan(nrm[other]).all()) and bool(torch.isnan(rstd[other]).all())      # nothing else touched
+
+
 @pytest.mark.parametrize("mode", ["eager", "replay"])
 def test_crystal_with_more_than_320_atoms(mode):
     """A crystal of 330 atoms next to one of 5: the cross attention over atoms runs over 330 keys (zero-padded for the small
