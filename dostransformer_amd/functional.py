@@ -712,9 +712,6 @@ def gnn_trunk_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta, node_key: str = "GN
     """Encoder + L processors (+ eDOS global encoder).  Returns x_L [N,H], u [B,H] or None, ctx."""
     H, N, E, B = cfg.H, m.num_nodes, m.num_edges, m.num_graphs
     xin = _f32(g.x)
-    # (measured, round 3: the node encoder's two launches on the side stream next to the edge encoder - they are independent -
-    #  cost the cfg2 step 5 us instead of saving the ~20 us they take in line: 1.2997 vs 1.2943 ms, tools/exp/ab_side_enc.sh;
-    #  the fork / join events cost more than two 10-us kernels return.  eDOS: no difference)
     x0, cn = mlp_prelu_fwd(P, node_key, SegList([seg(xin)], [xin]), N, H)
     if cfg.kind == "phonon" and P["GN_encoder.edge_encoder.0.weight"].shape[1] == 4:
         # SH(l<=1) * cutoff features (r_max = 4, DOSTransformer_phonon.py:77) and the K = 4 Linear on them in one launch
