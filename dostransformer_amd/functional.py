@@ -59,6 +59,11 @@ def pack_params(P: Params) -> Params:
     return out
 
 
+# M-splits of the weight gradients that run alone at the end of the step (round 3: 1.2918 -> 1.2841 ms per cfg2 step with 32,
+# 1.2845 with 16; 0 = the throughput-oriented count of dosx_wgrad_splits, tools/exp/ab_tail.sh)
+_TAIL_SPLITS = int(__import__("os").environ.get("DOSX_WGRAD_TAIL_SPLITS", "32"))
+
+
 def _wgrad_linear(sink: GradSink, G: Params, wkey: str, bkey: Optional[str], M: int, N: int, dy: Seg,
                   segs: Sequence[Seg], keep=(), **pro) -> None:
     """dW (and db) of y = A W^T + b as split slabs + reduce jobs (launched on the sink's side stream;
@@ -67,6 +72,10 @@ def _wgrad_linear(sink: GradSink, G: Params, wkey: str, bkey: Optional[str], M: 
         return
     K = sum(s.width for s in segs)
     ns = ops.wgrad_splits(M, N, K)
+    if _TAIL_SPLITS > 0 and wkey.startswith("GN_encoder."):
+        # the node / edge encoder's weight gradients are the LAST group of the step (their dY exists only at the very end of
+        # the backward pass) and run with the GPU to themselves: latency, not throughput, is what counts there
+        ns = max(ns, min(_TAIL_SPLITS, max(M // 128, 1)))
     # finished mode (include/dosx.h: DosxWgrad.dst): the kernel sums the M-splits itself (last arriver of every tile, fixed
     # order) and writes dW / db - no slab reduction launch; `slab` is its private tile-major scratch
     nsc = ops.wgrad_scratch_floats(N, K, ns)
