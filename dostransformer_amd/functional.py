@@ -65,16 +65,16 @@ _TAIL_SPLITS = int(__import__("os").environ.get("DOSX_WGRAD_TAIL_SPLITS", "32"))
 
 
 def _wgrad_linear(sink: GradSink, G: Params, wkey: str, bkey: Optional[str], M: int, N: int, dy: Seg,
-                  segs: Sequence[Seg], keep=(), **pro) -> None:
+                  segs: Sequence[Seg], keep=(), tail: bool = False, **pro) -> None:
     """dW (and db) of y = A W^T + b as split slabs + reduce jobs (launched on the sink's side stream;
     ``keep``: the tensor(s) behind ``dy`` that the caller may drop before the side stream has run)."""
     if wkey not in G:
         return
     K = sum(s.width for s in segs)
     ns = ops.wgrad_splits(M, N, K)
-    if _TAIL_SPLITS > 0 and wkey.startswith("GN_encoder."):
-        # the node / edge encoder's weight gradients are the LAST group of the step (their dY exists only at the very end of
-        # the backward pass) and run with the GPU to themselves: latency, not throughput, is what counts there
+    if _TAIL_SPLITS > 0 and tail:
+        # (tail: a weight gradient of the LAST group of the step - its dY exists only at the very end of the backward pass
+        #  and it runs with the GPU to itself: latency, not throughput, is what counts there)
         ns = max(ns, min(_TAIL_SPLITS, max(M // 128, 1)))
     # finished mode (include/dosx.h: DosxWgrad.dst): the kernel sums the M-splits itself (last arriver of every tile, fixed
     # order) and writes dW / db - no slab reduction launch; `slab` is its private tile-major scratch
@@ -104,20 +104,21 @@ def mlp_prelu_fwd(P: Params, key: str, a: SegList, M: int, H: int, z: Optional[t
     return y, (a, z, M, H)
 
 
-def mlp_prelu_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: GradSink, dy_seg: Optional[Seg] = None):
+def mlp_prelu_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: GradSink, dy_seg: Optional[Seg] = None,
+                  tail: bool = False):
     a, z, M, H = ctx
     dev = z.device
     alpha = P[key + ".1.weight"]
     dys = dy_seg if dy_seg is not None else seg(dy)
     _wgrad_linear(sink, G, key + ".2.weight", key + ".2.bias", M, H, dys, [seg(z)], keep=(dy,) if dy is not None else (),
-                  pro=PRO_PRELU, pro_alpha=alpha)
+                  tail=tail, pro=PRO_PRELU, pro_alpha=alpha)
     rows = ops.gemm_partial_rows(M, H, EPI_PRELU_BWD)
     part = sink.scratch(rows, 1)
     dz = _empty(dev, M, H)
     ops.gemm(M, H, [dys], P[key + ".2.weight"], dz, w_layout=1, epi=EPI_PRELU_BWD, aux=z, epi_alpha=alpha,
              partials=part, partial_ld=1)
     sink.add(part, 0, G[key + ".1.weight"], rows, 1, 1)
-    _wgrad_linear(sink, G, key + ".0.weight", key + ".0.bias", M, H, seg(dz), a.segs, keep=(dz,))
+    _wgrad_linear(sink, G, key + ".0.weight", key + ".0.bias", M, H, seg(dz), a.segs, keep=(dz,), tail=tail)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -745,12 +746,14 @@ def gnn_trunk_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, dxL: t
                   sink: GradSink):
     cn, ce, cu, cg, node_key = ctx
     dx0, de0 = gnn_bwd(P, G, m, cg, dxL, sink, cfg.L, cfg.mean, cfg.H)
-    mlp_prelu_bwd(P, G, node_key, cn, dx0, sink)
-    # (measured: the edge encoder's backward moved to the side stream right after dL/de_0 exists - ahead of the first
-    #  layer's gather backward - costs the step 15 us instead of saving the ~12 us it takes at the tail: DESIGN.md 3.2)
-    mlp_prelu_bwd(P, G, "GN_encoder.edge_encoder", ce, de0, sink)
+    mlp_prelu_bwd(P, G, node_key, cn, dx0, sink, tail=True)
+    # (measured: the edge encoder's backward moved ahead of the first layer's gather backward, where dL/de_0 already exists,
+    #  so that its weight gradients join layer 0's group instead of the tail: on the side stream +15 us (round 2), on the main
+    #  stream +5 us at cfg2 and +90 us for eDOS (round 3, tools/exp/ab_early.sh) - at the tail they run as many short
+    #  workgroups on an idle GPU, in the group they queue behind layer 0's long ones)
+    mlp_prelu_bwd(P, G, "GN_encoder.edge_encoder", ce, de0, sink, tail=True)
     if cu is not None and du_seg is not None:
-        mlp_prelu_bwd(P, G, "GN_encoder.global_encoder", cu, None, sink, dy_seg=du_seg)
+        mlp_prelu_bwd(P, G, "GN_encoder.global_encoder", cu, None, sink, dy_seg=du_seg, tail=True)
 
 
 def decoder_fwd(P: Params, cfg: ModelCfg, m: GraphMeta, xL: torch.Tensor, u: Optional[torch.Tensor]):
