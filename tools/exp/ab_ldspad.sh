@@ -1,3 +1,4 @@
+# (needs the DOSX_WGRAD_LDS_PAD knob of the experiment: extra dynamic LDS bytes on the wgrad_grouped_kernel launch in dosx_grad_flush)
 # A/B: one weight-gradient workgroup per CU (LDS pad) instead of two
 for v in 0 8192 0 8192; do
   export DOSX_WGRAD_LDS_PAD=$v
