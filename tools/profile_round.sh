@@ -26,6 +26,12 @@ if [ -n "$ff" ] && [ -n "$fw" ]; then
   python3 "$ROOT/tools/pmc_summary.py" "$ff" FETCH_SIZE "$S/${R}_pmc_fetch_size_summary.csv"
   python3 "$ROOT/tools/pmc_summary.py" "$fw" WRITE_SIZE "$S/${R}_pmc_write_size_summary.csv"
 fi
+# MFMA utilisation of the attention kernels from the counters (north_star: "MFMA utilisation for attention against CDNA4 peak"):
+# the attention microbenchmark (BASELINE shapes + roofline scale) under ONE pmc pass
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma_attn" -o pmc -- \
+  python3 "$ROOT/tools/bench_kernels.py" --what attn > "$OUT/pmc_mfma_attn.log" 2>&1 < /dev/null
+fm=$(find "$OUT/pmc_mfma_attn" -name "*counter_collection.csv" | head -1)
+[ -n "$fm" ] && python3 "$ROOT/tools/pmc_mfma.py" "$fm" "$S/${R}_pmc_mfma_attention.csv" attn > "$OUT/pmc_mfma_attn.summary" 2>&1
 cd "$ROOT"
 # THE bench line (the driver's invocation: default flags; secondaries = eDOS H256 + shuffle inside the same record) + its per-site table
 timeout 600 python3 bench.py --kernels-out "$S/${R}_bench_phonon_h128_b64_sites.json" > "$S/${R}_bench_phonon_h128_b64.json" 2> "$OUT/bench_phonon.err" < /dev/null
