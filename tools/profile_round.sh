@@ -32,6 +32,15 @@ timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-fo
   python3 "$ROOT/tools/bench_kernels.py" --what attn > "$OUT/pmc_mfma_attn.log" 2>&1 < /dev/null
 fm=$(find "$OUT/pmc_mfma_attn" -name "*counter_collection.csv" | head -1)
 [ -n "$fm" ] && python3 "$ROOT/tools/pmc_mfma.py" "$fm" "$S/${R}_pmc_mfma_attention.csv" attn > "$OUT/pmc_mfma_attn.summary" 2>&1
+# ... and the achieved HBM rate of the scatter-add kernel from the counters (north_star: "rocprof-reported achieved HBM GB/s for
+# the scatter-add"): the scatter microbenchmark (cfg2 size + roofline scale) under the two traffic passes
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_scatter_$c" -o pmc -- \
+    python3 "$ROOT/tools/bench_kernels.py" --what scatter > "$OUT/pmc_scatter_$c.log" 2>&1 < /dev/null
+done
+sf=$(find "$OUT/pmc_scatter_FETCH_SIZE" -name "*counter_collection.csv" | head -1)
+sw=$(find "$OUT/pmc_scatter_WRITE_SIZE" -name "*counter_collection.csv" | head -1)
+[ -n "$sf" ] && [ -n "$sw" ] && python3 "$ROOT/tools/pmc_scatter.py" "$sf" "$sw" "$S/${R}_pmc_scatter_add.csv" > "$OUT/pmc_scatter.summary" 2>&1
 cd "$ROOT"
 # THE bench line (the driver's invocation: default flags; secondaries = eDOS H256 + shuffle inside the same record) + its per-site table
 timeout 600 python3 bench.py --kernels-out "$S/${R}_bench_phonon_h128_b64_sites.json" > "$S/${R}_bench_phonon_h128_b64.json" 2> "$OUT/bench_phonon.err" < /dev/null
