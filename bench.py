@@ -2,7 +2,9 @@
 """Training-throughput benchmark of the DOSTransformer hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under a launcher that sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* - python -m torch.distributed.run
+     --nnodes=1 --nproc-per-node N ... bench.py --gpus N ... - or bare: without WORLD_SIZE in the environment the process
+     starts its N ranks itself, as fresh child processes, BEFORE it has touched the GPU, and relays rank 0's line)
 
 Metric (BASELINE.json): crystals/s of full training steps (forward + loss + backward + AdamW) of the
 Phonon-DOS model, --layers 3 --transformer 2 --hidden 128, batch 64 crystals per GPU (weak
@@ -166,6 +168,31 @@ def traffic_of(kernels, key):
     return int(tot / n) if n else None
 
 
+def rccl_choices(path, world):
+    """What RCCL's tuner chose for the collectives of the run, per message size: parsed from the TUNING lines of the debug
+    file rank 0 wrote (`<bytes> Bytes -> Algo <a> proto <p> ...`; the spelling differs between RCCL releases, so the
+    parser keeps whatever follows `Algo` / `proto`)."""
+    import re
+    if world <= 1:
+        return "1 rank: RCCL reduces in place, no algorithm is selected"
+    if not path:
+        return "not logged (NCCL_DEBUG was set by the caller, or the backend is not nccl)"
+    seen = {}
+    try:
+        for line in open(path, errors="replace"):
+            m = re.search(r"(\d+)\s+Bytes\s*->\s*Algo\s+(\S+)\s+proto\s+(\S+)(.*)", line)
+            if m:
+                k = int(m.group(1))
+                ent = seen.setdefault(k, {"bytes": k, "algo": m.group(2), "proto": m.group(3), "n": 0,
+                                          "detail": (m.group(4) or "").strip()[:48]})
+                ent["n"] += 1
+    except OSError as ex:
+        return f"unreadable: {ex}"
+    if not seen:
+        return "no TUNING lines in the RCCL debug file"
+    return sorted(seen.values(), key=lambda e: -e["bytes"])[:4]
+
+
 LINE_BUDGET = 3000          # bytes of the ONE stdout line (the driver keeps an 8 KB tail of stdout)
 
 
@@ -269,10 +296,14 @@ def run_workload(name, *, device, world, rank, dp, mode, shuffle, steps, warmup,
         if dp is not None:
             td.barrier()
 
-    # warm-up: every fixed bucket is RECORDED once (an eager step) and REPLAYED once before the clock starts - the first replay
-    # of a recorded program still pays one-time costs (20 timed steps: 1.316 ms with 8 warm-up steps, 1.292 with 16)
-    n_warm = max(warmup, 2 * N_DISTINCT_BATCHES if (use_graph and not shuffle) else 0)
-    for i in range(n_warm):
+    # prepare (NOT warm-up, reported separately as `prepare_steps`): every fixed bucket is RECORDED once (an eager step that
+    # builds the bucket's launch list) and REPLAYED once - the first replay of a recorded program still pays one-time costs
+    # (20 timed steps: 1.316 ms after 8 such steps, 1.292 after 16).  Then exactly `warmup` untimed steps, as asked.
+    n_prep = 2 * N_DISTINCT_BATCHES if (use_graph and not shuffle) else 0
+    for i in range(n_prep):
+        do_step()
+    sync()
+    for i in range(warmup):
         do_step()
     sync()
     # eager mode: per-kernel HIP-event timing over the timed region itself (same stream as the launches);
@@ -342,8 +373,16 @@ def run_workload(name, *, device, world, rank, dp, mode, shuffle, steps, warmup,
     roof = ops.KERNEL_TIMER.roofline(HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS) if instrument else {"dominant": None, "all": []}
     ops.KERNEL_TIMER.reset(enabled=False)
     flops_step = 3.0 * sum(algorithmic_flops(kind, L, T, H, n, e, B, nm) for n, e, nm in dims) / max(len(dims), 1)
+    dp_info = None
+    if dp is not None and trainer._fp is not None:
+        fp = trainer._fp              # the two gradient buckets of the data-parallel step and the replay plan
+        plan = next((s.plan for s in trainer._slots.values() if s.plan), [])
+        dp_info = {"grad_bucket_bytes": {"early": 4 * int(fp.total - fp.n_late), "late": 4 * int(fp.n_late)},
+                   "collectives_per_step": sum(1 for k, _ in plan if k != "prog") + 1,
+                   "plan": [k for k, _ in plan] + ["late", "adamw"], "backend": td.get_backend(),
+                   "staged_through_host": bool(dp.staged)}
     res = {"kind": kind, "L": L, "T": T, "H": H, "B": B, "n_global": n_global, "elapsed": elapsed, "host": host, "host_enqueue": host_enqueue,
-           "roof": roof, "n_inst": n_inst, "flops_step": flops_step, "warmup_used": n_warm,
+           "roof": roof, "n_inst": n_inst, "flops_step": flops_step, "prepare_steps": n_prep, "dp_info": dp_info,
            "slots": {"hits": hits, "misses": misses, "hit_rate": round(hits / max(hits + misses, 1), 4),
                      "live": n_slots, "max": trainer.max_slots} if use_graph else None}
     del trainer, model
@@ -351,7 +390,82 @@ def run_workload(name, *, device, world, rank, dp, mode, shuffle, steps, warmup,
     return res
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def rank_env(rank: int, world: int, port: int, base=None) -> dict:
+    """Environment of rank `rank` of a one-node job of `world` processes (what torch.distributed.run would set)."""
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL's cross-process buffers need it on this stack
+    return env
+
+
+def self_launch(world: int, argv, *, grace_s: float = 30.0, script=None) -> int:
+    """`python bench.py --gpus N` with no launcher: start the N ranks as FRESH child processes of this same script (one per
+    GPU, rank r -> cuda:r), relay rank 0's single JSON line to stdout and return the worst exit code.  The calling process
+    has not initialised the GPU and never does (no HIP call, no exec of a process that used the GPU); a rank that dies takes
+    the others down after `grace_s` seconds (they would wait in a collective for ever) - by their exact PIDs."""
+    import signal
+    import subprocess
+    import threading
+    port = _free_port()
+    cmd = [sys.executable, script or os.path.abspath(__file__)] + list(argv)
+    procs = []
+    for r in range(world):
+        procs.append(subprocess.Popen(cmd, env=rank_env(r, world, port), cwd=os.getcwd(),
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=None))
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+
+    def forward(signum, _frame):          # the driver's timeout / ^C reaches the ranks too
+        for p in procs:
+            if p.poll() is None:
+                p.send_signal(signum)
+    old = {sg: signal.signal(sg, forward) for sg in (signal.SIGTERM, signal.SIGINT)}
+    ended = set()                     # ranks this launcher ended itself: their codes say nothing
+    try:
+        failed_at = None
+        while any(p.poll() is None for p in procs):
+            if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
+                failed_at = time.monotonic()
+            if failed_at is not None and time.monotonic() - failed_at > grace_s:
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+                        ended.add(p.pid)
+            time.sleep(0.1)
+    finally:
+        for sg, h in old.items():
+            signal.signal(sg, h)
+    reader.join(timeout=10)
+    rcs = [p.returncode for p in procs]
+    text = (out0[0] if out0 else b"").decode(errors="replace").strip()
+    if text:
+        sys.stdout.write(text.splitlines()[-1] + "\n")
+        sys.stdout.flush()
+    own = [p.returncode for p in procs if p.pid not in ended] or rcs
+    worst = max(own, key=lambda c: (c != 0, abs(c)))
+    if worst != 0:
+        print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
+    return worst if worst >= 0 else 128 - worst
+
+
 def main():
+    if "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`, N > 1: become the launcher - decided on the command line alone, before anything
+        # below (or any import side effect) can touch the GPU
+        pre = argparse.ArgumentParser(add_help=False)
+        pre.add_argument("--gpus", type=int, default=1)
+        n = pre.parse_known_args()[0].gpus
+        if n > 1:
+            raise SystemExit(self_launch(n, sys.argv[1:]))
     # Exactly ONE line may reach stdout (the JSON record): libraries print there too (RCCL emits a
     # version banner on fd 1), so fd 1 is pointed at stderr for the whole run and the record is
     # written to the saved descriptor at the end.
@@ -390,17 +504,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     device = torch.device("cuda:0" if args.share_gpu else f"cuda:{local_rank}")
     torch.cuda.set_device(device)
 
     import torch.distributed as td
     dp = None
+    rccl_log = None
     if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
+        if args.dist_backend == "nccl" and world > 1 and rank == 0 and "NCCL_DEBUG" not in os.environ:
+            # SURVEY.md §5 "verify which algorithm RCCL selects": the tuner's decision per collective size goes to a side
+            # file on rank 0 (one short line per collective; read back after the timed region, see rccl_choices)
+            import tempfile
+            rccl_log = os.path.join(tempfile.gettempdir(), f"dosx_rccl_tuning_{os.getpid()}.log")
+            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="TUNING", NCCL_DEBUG_FILE=rccl_log)
         # (no device_id=: the eager communicator it creates costs every later kernel launch of this process
         #  ~3 us on this stack: 2.42 vs 1.92 ms/step measured with tools/dist_overhead.py; the device is
         #  already selected with torch.cuda.set_device above)
@@ -437,6 +556,22 @@ def main():
             secondary["shuffle"] = dict(brief(sh, args.steps), hit_rate=sh["slots"]["hit_rate"], live_buckets=sh["slots"]["live"])
         except Exception as ex:  # a secondary line must never take the headline down with it
             secondary["error"] = f"{type(ex).__name__}: {ex}"[:200]
+        # the same headline workload through the DATA-PARALLEL step on a 1-rank RCCL group: the replay plan split around
+        # the collectives (SSE pair, early gradient bucket, late bucket), i.e. what data parallelism costs a rank before
+        # any byte crosses xGMI - the figure a 1-GPU box can give about the N > 1 path
+        try:
+            from dostransformer_amd.dist import DataParallel
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ["MASTER_PORT"] = str(_free_port())
+            td.init_process_group("nccl", rank=0, world_size=1)
+            try:
+                d1 = run_workload("phonon_h128_b64", shuffle=False, steps=args.steps, warmup=args.warmup, bucket=(8, 128),
+                                  instrument=False, **dict(common, dp=DataParallel()))
+                secondary["dp1_nccl"] = dict(brief(d1, args.steps), **(d1["dp_info"] or {}))
+            finally:
+                td.destroy_process_group()
+        except Exception as ex:
+            secondary["dp1_nccl"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
 
     if rank == 0:
         roof = r["roof"]
@@ -460,7 +595,7 @@ def main():
                       "crystals/sec training throughput (Electron DOS)",
             "value": round(n_global * args.steps / elapsed, 2),
             "unit": "crystals/s",
-            "n_gpus": world, "steps": args.steps, "warmup": r["warmup_used"],
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prepare_steps": r["prepare_steps"],
             "ms_per_step": round(ms_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -483,6 +618,8 @@ def main():
         }
         if r["slots"] is not None:
             out["slots"] = r["slots"]
+        if r["dp_info"] is not None:
+            out["dp"] = dict(r["dp_info"], rccl=rccl_choices(rccl_log, world))
         if secondary:
             out["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:

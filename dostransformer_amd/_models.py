@@ -11,6 +11,18 @@ from . import functional as Fn
 from ._fused import FusedModel
 
 
+_SEED_MOD = 2 ** 62
+
+
+def rank_seed_offset() -> int:
+    """What a data-parallel rank adds to the (rank-independent) dropout base seed: ranks seeded alike must not draw the
+    same masks for their different shards.  0 outside torch.distributed."""
+    import torch.distributed as td
+    if td.is_available() and td.is_initialized():
+        return (0x9E3779B97F4A7C15 * (td.get_rank() + 1)) % _SEED_MOD
+    return 0
+
+
 def dos_device(P):
     return P["embeddings.weight"].device
 
@@ -32,10 +44,7 @@ class DOSTransformerBase(FusedModel):
             return None
         seed = getattr(self, "_drop_seed", None)
         if seed is None or seed.device != device:
-            val = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
-            import torch.distributed as td
-            if td.is_available() and td.is_initialized():      # data-parallel ranks seeded alike must not draw the same
-                val = (val + 0x9E3779B97F4A7C15 * (td.get_rank() + 1)) % (2 ** 62)              # masks for their shards
+            val = (int(torch.randint(0, _SEED_MOD, (1,), dtype=torch.int64).item()) + rank_seed_offset()) % _SEED_MOD
             seed = torch.tensor([val], dtype=torch.int64).to(device)
             object.__setattr__(self, "_drop_seed", seed)
         elif bump:

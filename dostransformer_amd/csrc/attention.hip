@@ -902,7 +902,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_stream_kernel(const DosxAttn 
       __syncthreads();
       int* flag = reinterpret_cast<int*>(sm);
       const int arrivers = (a.Bq / a.Bk) * (int)gridDim.x;
-      if (tid == 0) *flag = __hip_atomic_fetch_add(a.dkv_cnt + bk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) *flag = dosx_ticket(a.dkv_cnt + bk);
       __syncthreads();
       const bool last = *flag == arrivers - 1;
       __syncthreads();                                  // (the flag word is about to be overwritten by the reduction's LDS rows)

@@ -112,3 +112,22 @@ __device__ __forceinline__ float f4get(const float4& v, int i) {
 // Row statistics of a row held as `per` float4 per lane of one wave (whole row over 64 lanes).
 // Two-pass (mean, then centred second moment) like torch's LayerNorm; eps = 1e-5.
 #define DOSX_LN_EPS 1e-5f
+
+// ---- in-launch reductions: publish / ticket / read-back (gemm.hip wgrad_finish + EPI_SEGSUM, attention.hip dK/dV) ----------
+// Protocol: a workgroup PUBLISHES its partial result with sc1 stores (buffer stores with aux bit 4, or agent-scope relaxed
+// atomic stores - on gfx942 / gfx950 both are `... sc1`: written through to the agent-coherent level, not left dirty in this
+// XCD's L2), every storing wave DRAINS (`s_waitcnt vmcnt(0)`: its stores have completed there), a workgroup barrier, then ONE
+// lane draws a TICKET with an agent-scope fetch_add; the workgroup that draws the last ticket READS the partials BACK with
+// sc1 loads (agent-scope: served from the coherent level, never from a stale line of this CU's L1 / this XCD's L2).
+// That is the agent-scope release / acquire pair of the gfx942 memory model spelled out access by access (LLVM AMDGPU usage,
+// memory model gfx942: agent-scope atomic load / store = `sc1=1`; release = complete prior stores before the atomic, which
+// the drain does for the write-through stores; acquire = later loads must not hit stale lines, which sc1 loads do not) -
+// instead of the whole-cache `buffer_wbl2 sc1` / `buffer_inv sc1` an __ATOMIC_ACQ_REL ticket would emit.  Build with
+// -DDOSX_TICKET_ORDER=__ATOMIC_ACQ_REL to get exactly that stronger form (measured cost: DESIGN.md §2, round 4); the stress
+// tests (tests/test_gpu_round4.py: thousands of launches under a bandwidth hog, every one compared bitwise) run on either.
+#ifndef DOSX_TICKET_ORDER
+#define DOSX_TICKET_ORDER __ATOMIC_RELAXED
+#endif
+__device__ __forceinline__ int dosx_ticket(int* counter) {
+  return __hip_atomic_fetch_add(counter, 1, DOSX_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT);
+}

@@ -987,7 +987,7 @@ void gemm_kernel(const GemmLaunch L) {
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       int tk = 0;
-      if (lane == 0) tk = __hip_atomic_fetch_add(g.seg_cnt + t0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) tk = dosx_ticket(g.seg_cnt + t0);
       tk = __builtin_amdgcn_readfirstlane(tk);
       if (tk == nc - 1) {                                                 // every chunk of the node has been published
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1283,8 +1283,10 @@ extern "C" int dosx_gemm(const DosxGemm* gp, dosx_stream_t stream) {
   if (g.epi == DOSX_EPI_PRELU_BWD) DOSX_CHECK_ARG(g.aux && g.epi_alpha && (g.ldaux & 3) == 0, "dosx_gemm: PRELU_BWD needs aux/alpha");
   if (g.epi == DOSX_EPI_SEGSUM)
     DOSX_CHECK_ARG(g.seg_tile && g.seg_ntiles > 0 && g.seg_rowptr && g.seg_agg && g.N <= 256 && (!g.out || g.res) &&
-                       g.out_map.d >= (1 << 30) && g.out_map.idx == nullptr && g.out_map.c == 1 && g.out_map.off == 0,
-                   "dosx_gemm: EPI_SEGSUM needs seg_tile / seg_rowptr / seg_agg, N <= 256, an identity out_map and res with out");
+                       g.out_map.d >= (1 << 30) && g.out_map.idx == nullptr && g.out_map.c == 1 && g.out_map.off == 0 &&
+                       g.seg_part && g.seg_cnt,
+                   "dosx_gemm: EPI_SEGSUM needs seg_tile / seg_rowptr / seg_agg / seg_part / seg_cnt, N <= 256, an identity "
+                   "out_map and res with out");
 
   GemmLaunch L;
   const int bn = gemm_plan(g, L);
@@ -1397,7 +1399,7 @@ __device__ __forceinline__ void wgrad_finish(const DosxWgrad& g, float* __restri
   __syncthreads();
   WSTAMP(62);
   int* flag = reinterpret_cast<int*>(Sm + W_FLAG);
-  if (tid == 0) *flag = __hip_atomic_fetch_add(g.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) *flag = dosx_ticket(g.counters + tile);
   __syncthreads();
   WSTAMP(63);
   if (*flag != ns - 1) return;                            // not the last arriver of this tile

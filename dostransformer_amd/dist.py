@@ -102,6 +102,12 @@ class DataParallel:
         td.all_reduce(t, op=td.ReduceOp.SUM, group=self.group)
         return int(round(float(t[0])))
 
+    def min_max(self, value: int) -> Tuple[int, int]:
+        """(min, max) over ranks of a per-rank integer.  Blocking + host read: for one-time consistency checks, never per step."""
+        t = torch.tensor([float(value), -float(value)], dtype=torch.float64, device="cpu" if self.staged else "cuda")
+        td.all_reduce(t, op=td.ReduceOp.MIN, group=self.group)
+        return int(round(float(t[0]))), int(round(-float(t[1])))
+
     def all_reduce_grads(self, flat_grad: torch.Tensor) -> None:
         self._sum(flat_grad)
 

@@ -720,6 +720,11 @@ def _edge_inputs(cfg: ModelCfg, g, m: GraphMeta):
 
 def gnn_trunk_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta, node_key: str = "GN_encoder.node_encoder"):
     """Encoder + L processors (+ eDOS global encoder).  Returns x_L [N,H], u [B,H] or None, ctx."""
+    with ops.graph_rows():
+        return _gnn_trunk_fwd(P, cfg, g, m, node_key)
+
+
+def _gnn_trunk_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta, node_key: str):
     H, N, E, B = cfg.H, m.num_nodes, m.num_edges, m.num_graphs
     xin = _f32(g.x)
     x0, cn = mlp_prelu_fwd(P, node_key, SegList([seg(xin)], [xin]), N, H)
@@ -744,6 +749,12 @@ def gnn_trunk_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta, node_key: str = "GN
 
 def gnn_trunk_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, dxL: torch.Tensor, du_seg: Optional[Seg],
                   sink: GradSink):
+    with ops.graph_rows():
+        _gnn_trunk_bwd(P, G, cfg, m, ctx, dxL, du_seg, sink)
+
+
+def _gnn_trunk_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, dxL: torch.Tensor, du_seg: Optional[Seg],
+                   sink: GradSink):
     cn, ce, cu, cg, node_key = ctx
     dx0, de0 = gnn_bwd(P, G, m, cg, dxL, sink, cfg.L, cfg.mean, cfg.H)
     mlp_prelu_bwd(P, G, node_key, cn, dx0, sink, tail=True)

@@ -82,12 +82,25 @@ class _KernelTimer:
 KERNEL_TIMER = _KernelTimer()
 
 # bench.py: ghost-padded row count -> real rows of the batch whose step is being recorded, so that the ALGORITHMIC work of a
-# site counts real rows only (the launches themselves run on the padded bucket).  Empty outside the bench.
+# site counts real rows only (the launches themselves run on the padded bucket).  Empty outside the bench.  The mapping
+# applies ONLY to launches issued inside a ``graph_rows()`` scope - the GNN trunk, whose row counts are nodes / edges: a
+# transformer GEMM whose M = S * 2B happens to equal a padded edge count keeps its own M.
 REAL_ROWS: dict = {}
+_GRAPH_SCOPE = [0]
+
+
+class graph_rows:
+    """Scope whose launches have per-node / per-edge row counts (functional.gnn_trunk_fwd / _bwd)."""
+
+    def __enter__(self):
+        _GRAPH_SCOPE[0] += 1
+
+    def __exit__(self, *exc):
+        _GRAPH_SCOPE[0] -= 1
 
 
 def _real(M) -> int:
-    return REAL_ROWS.get(int(M), int(M))
+    return REAL_ROWS.get(int(M), int(M)) if _GRAPH_SCOPE[0] else int(M)
 
 
 class _Recorder:
@@ -231,6 +244,7 @@ def _call(name: str, *args, w=None) -> None:
     ev = KERNEL_TIMER.start() if KERNEL_TIMER.enabled else None
     rc = fn(*args)
     if rc:
+        COUNTERS.poison()
         _lib.check(rc, name)
     if ev is not None:
         site, kernel, bound, work = w() if w is not None else (name[5:], name[5:] + "_kernel", "hbm", 0.0)
@@ -470,26 +484,45 @@ def wgrad_scratch_floats(N: int, K: int, nsplit: int) -> int:
 
 
 class _CounterPool:
-    """Zeroed int32 tile counters of the finished-mode weight-gradient kernels (include/dosx.h: DosxWgrad.counters).  A
-    kernel leaves its counters at zero, so one pool per device is handed out round-robin; a step uses a few hundred of
-    the 2^16 entries, and launches that could touch the same entry are a whole step apart on the same stream."""
+    """Zeroed int32 arrival counters of the in-launch reductions (include/dosx.h: DosxWgrad.counters, DosxGemm.seg_cnt,
+    DosxAttn.dkv_cnt).  A kernel leaves its counters at zero, so they are re-usable - but two launches that can be in
+    flight at the same time (different streams) must never share an entry:
+
+    * while a step is RECORDED every request gets memory of its own, kept alive with the program: a replayed program's
+      counters are its own for as long as it exists, whatever else runs;
+    * eagerly issued launches draw from a per-device ring.  Before the ring hands out an entry a second time the device
+      is synchronised (every earlier user has finished and left zeros), and a request larger than the ring replaces it
+      with a larger one - a wrap can therefore never alias a launch in flight, and no request is too large;
+    * ``poison()`` (a libdosx call failed: an aborted launch may have left tickets behind) drops the ring."""
     SIZE = 1 << 16
 
     def __init__(self):
         self._bufs = {}
 
     def take(self, device, n: int) -> int:
+        n = int(n)
+        if RECORDER.active:
+            t = torch.zeros(max(n, 1), dtype=torch.int32, device=device)
+            RECORDER.keep.append(t)
+            return t.data_ptr()
         key = str(device)
         ent = self._bufs.get(key)
-        if ent is None:
-            ent = self._bufs[key] = [torch.zeros(self.SIZE, dtype=torch.int32, device=device), 0]
-        if n > self.SIZE:
-            raise ValueError(f"{n} tile counters requested, the pool holds {self.SIZE}")
-        if ent[1] + n > self.SIZE:
+        if ent is None or n > ent[0].numel():
+            if ent is not None:
+                torch.cuda.synchronize(device)
+            size = self.SIZE
+            while size < n:
+                size *= 2
+            ent = self._bufs[key] = [torch.zeros(size, dtype=torch.int32, device=device), 0]
+        if ent[1] + n > ent[0].numel():
+            torch.cuda.synchronize(device)        # every earlier user of the ring is done: its entries are zero again
             ent[1] = 0
         off = ent[1]
         ent[1] += n
         return ent[0].data_ptr() + 4 * off
+
+    def poison(self) -> None:
+        self._bufs = {}
 
 
 COUNTERS = _CounterPool()
@@ -509,6 +542,7 @@ def wgrad_desc(M: int, N: int, dy: Seg, segs: Sequence[Seg], slab: Optional[torc
     g.pro = pro
     g.pro_gamma, g.pro_beta, g.pro_alpha, g.pro_stats = _p(pro_gamma), _p(pro_beta), _p(pro_alpha), _p(pro_stats)
     g.slab, g.slab_bias, g.nsplit = _p(slab), _p(slab_bias), int(nsplit)
+    g._real_M = _real(g.M)            # (the job is launched later, at a flush point outside the scope it was described in)
     if dst is not None:
         assert dst.is_contiguous() and dst.numel() == g.N * g.K and dst.dtype == torch.float32
         g.dst, g.dst_bias, g.accumulate = dst.data_ptr(), _p(dst_bias), int(bool(accumulate))
@@ -521,7 +555,7 @@ def wgrad(M: int, N: int, dy: Seg, segs: Sequence[Seg], slab: Optional[torch.Ten
           nsplit: int, **kw) -> None:
     g = wgrad_desc(M, N, dy, segs, slab, slab_bias, nsplit, **kw)
     _call("dosx_wgrad", C.byref(g), _stream(),
-          w=lambda: (f"wgrad[N{g.N},K{g.K}]", "wgrad_kernel", "mfma", 2.0 * _real(g.M) * g.N * g.K))
+          w=lambda: (f"wgrad[N{g.N},K{g.K}]", "wgrad_kernel", "mfma", 2.0 * g._real_M * g.N * g.K))
 
 
 def _reduce_job_array(jobs):
@@ -540,7 +574,7 @@ def grad_flush(descs: Sequence[Wgrad], rjobs: Sequence[tuple] = ()) -> None:
     arr = (Wgrad * max(len(descs), 1))(*descs)
     rarr = _reduce_job_array(rjobs)
     _call("dosx_grad_flush", arr, len(descs), rarr, len(rjobs), _stream(),
-          w=lambda: ("wgrad_grouped", "wgrad_grouped_kernel", "mfma", sum(2.0 * _real(d.M) * d.N * d.K for d in descs)))
+          w=lambda: ("wgrad_grouped", "wgrad_grouped_kernel", "mfma", sum(2.0 * getattr(d, "_real_M", d.M) * d.N * d.K for d in descs)))
 
 
 def wgrad_grouped(descs: Sequence[Wgrad]) -> None:

@@ -24,10 +24,11 @@ import torch
 
 from . import functional as Fn
 from . import ops
-from ._models import DOSTransformerBase
+from ._models import DOSTransformerBase, _SEED_MOD, rank_seed_offset
 from .batch import CrystalBatch, GraphMeta, bucket_sizes, graph_meta, pad_batch, seg_tile_bound
 
 _EARLY_REDUCE = __import__("os").environ.get("DOSX_EARLY_REDUCE", "1") == "1"
+_DP_CHECK = __import__("os").environ.get("DOSX_DP_CHECK", "0") == "1"
 _META_TENSORS = ("src", "dst", "rowptr_dst", "perm_src", "rowptr_src", "graph_ptr", "node_graph", "dense_row", "inv_deg")
 
 
@@ -150,6 +151,7 @@ class Trainer:
         self.max_slots = int(max_slots)
         self.slot_hits = self.slot_misses = 0
         self.kernel_timer = None          # ops._KernelTimer: replayed programs then run through dosx_replay_timed
+        self._ds_checked = set()          # datasets whose per-rank size was compared across the ranks (step_dataset)
 
     def _state(self, fp):
         """AdamW moments laid out like ``fp``.  When the parameters are re-homed (module moved to another device after
@@ -419,9 +421,28 @@ class Trainer:
         idx, N, E, n_max = ds.bucket_dims(indices, n_max)
         B = int(idx.shape[0])
         n_pad, e_pad = bucket_sizes(N, E, *self.bucket)
-        # (no collective, no host read: ranks of a data-parallel job draw equally sized shards from their datasets; a caller
-        #  with ragged shards passes n_global)
-        ng = int(n_global) if n_global is not None else B * (self.dist.world if self.dist is not None else 1)
+        # No per-step collective and no host read: without an explicit n_global the ranks of a data-parallel job must draw
+        # EQUALLY sized shards every step, then n_global = B * world.  That holds for every batch of an epoch, the last one
+        # included, iff all ranks hold equally many crystals and cut them with the same batch size - checked ONCE per
+        # dataset (one blocking min/max over ranks at its first step); ragged shards must pass the true n_global, or the
+        # loss would be normalised by the wrong count (`main_phDOS.py:109-114` is ONE rmse over the un-sharded batch).
+        # DOSX_DP_CHECK=1 cross-checks B itself across the ranks on every step (debugging; blocking).
+        if n_global is not None:
+            ng = int(n_global)
+        elif self.dist is None:
+            ng = B
+        else:
+            if id(ds) not in self._ds_checked:
+                lo, hi = self.dist.min_max(len(ds))
+                if lo != hi:
+                    raise ValueError(f"data-parallel ranks hold {lo}..{hi} crystals: with ragged shards the last batches of "
+                                     f"an epoch differ in size across ranks - pass the global batch size as n_global")
+                self._ds_checked.add(id(ds))
+            if _DP_CHECK:
+                lo, hi = self.dist.min_max(B)
+                if lo != hi:
+                    raise ValueError(f"ranks stepped on {lo}..{hi} crystals without an explicit n_global")
+            ng = B * self.dist.world
         tiled = True
         key = (n_pad, e_pad, B, n_max, ng, tiled)
         slot = self._lookup(key)
@@ -464,9 +485,11 @@ class Trainer:
         m, v = self._state(fp)
         views = lambda buf: {n: buf[o:o + fp.P[n].numel()].view(fp.P[n].shape).detach().cpu().clone()
                              for n, o in zip(fp.names, fp.offsets)}
+        # the dropout seed is stored WITHOUT the saving rank's offset (rank-independent base + steps taken): every rank of a
+        # resumed data-parallel job re-applies its own offset and goes on drawing the masks its uninterrupted self would have
         seed = getattr(self.model, "_drop_seed", None)
         return {"step": self.step_count, "exp_avg": views(m), "exp_avg_sq": views(v),
-                "drop_seed": None if seed is None else int(seed.item()),
+                "drop_seed_base": None if seed is None else (int(seed.item()) - rank_seed_offset()) % _SEED_MOD,
                 "hyper": {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "beta": self.beta}}
 
     def load_state_dict(self, sd: dict) -> None:
@@ -481,8 +504,13 @@ class Trainer:
                 m[o:o + k].copy_(sd["exp_avg"][n].reshape(-1).to(m.device, torch.float32))
                 v[o:o + k].copy_(sd["exp_avg_sq"][n].reshape(-1).to(v.device, torch.float32))
         self.step_count = int(sd["step"])
-        if sd.get("drop_seed") is not None:          # resume draws the masks the uninterrupted run would have drawn
-            object.__setattr__(self.model, "_drop_seed", torch.tensor([int(sd["drop_seed"])], dtype=torch.int64, device=m.device))
+        val = None
+        if sd.get("drop_seed_base") is not None:     # resume draws the masks THIS rank's uninterrupted run would have drawn
+            val = (int(sd["drop_seed_base"]) + rank_seed_offset()) % _SEED_MOD
+        elif sd.get("drop_seed") is not None:        # (files of round 3: the saving rank's own seed)
+            val = int(sd["drop_seed"])
+        if val is not None:
+            object.__setattr__(self.model, "_drop_seed", torch.tensor([val], dtype=torch.int64, device=m.device))
         h = sd.get("hyper", {})
         self.lr, self.eps, self.wd = h.get("lr", self.lr), h.get("eps", self.eps), h.get("weight_decay", self.wd)
         self.betas, self.beta = tuple(h.get("betas", self.betas)), h.get("beta", self.beta)

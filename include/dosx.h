@@ -115,7 +115,9 @@ typedef struct DosxGemm {
   const int32_t* seg_rowptr; /* [nodes + 1] CSR by destination */
   const float* seg_scale;    /* [nodes] 1/max(in-degree,1) for scatter_mean, NULL for scatter_sum */
   float* seg_agg;            /* [nodes, N] */
-  float* seg_part;           /* [seg_ntiles, N] scratch for the chunk sums of over-full nodes (may be NULL if no tile has chunk info) */
+  float* seg_part;           /* [seg_ntiles, N] scratch for the chunk sums of over-full nodes.  REQUIRED (like seg_cnt): the table lives in
+                                device memory, so the host cannot know whether a tile carries chunk info; a call without it is
+                                refused (-22) instead of silently dropping an over-full node's aggregate */
   int32_t* seg_cnt;          /* [seg_ntiles] arrival counters, zero before the launch, zero again after it (like DosxWgrad.counters) */
   int32_t res_col0;   /* EPI_BIAS_ACT: the residual is added to the output columns [res_col0, N) only, res column c
                          to output column res_col0 + c (0 = all columns).  The backward of the edge residual

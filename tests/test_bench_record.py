@@ -60,6 +60,96 @@ def test_record_drops_optional_fields_before_growing():
     assert len(json.dumps(rec)) < 4000 and "value" in rec and "roofline" in rec and "cpu_baseline" in rec
 
 
+_RANK_SCRIPT = """
+import json, os, sys, time
+r = int(os.environ["RANK"])
+json.dump({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                          "HSA_ENABLE_IPC_MODE_LEGACY")} | {"argv": sys.argv[1:]},
+          open(os.path.join(sys.argv[1], f"rank{r}.json"), "w"))
+mode = sys.argv[2]
+if r == 0:
+    print("library banner on stdout")
+    print(json.dumps({"n_gpus": int(os.environ["WORLD_SIZE"]), "value": 1.0}))
+if mode == "fail" and r == 1:
+    sys.exit(3)
+if mode == "fail" and r != 1:
+    time.sleep(120)            # waits 'in a collective' for the dead rank
+"""
+
+
+def test_self_launch_starts_one_process_per_rank_and_relays_rank0(tmp_path, capfd):
+    """`python bench.py --gpus N` without a launcher: N child processes with the environment torch.distributed.run would
+    set, the command line passed through, rank 0's LAST stdout line relayed, exit code 0."""
+    import bench
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    rc = bench.self_launch(3, [str(tmp_path), "ok", "--gpus", "3"], script=str(script))
+    assert rc == 0
+    out = capfd.readouterr().out.strip().splitlines()
+    assert len(out) == 1 and json.loads(out[0]) == {"n_gpus": 3, "value": 1.0}
+    envs = [json.loads((tmp_path / f"rank{r}.json").read_text()) for r in range(3)]
+    assert [e["RANK"] for e in envs] == ["0", "1", "2"] and [e["LOCAL_RANK"] for e in envs] == ["0", "1", "2"]
+    assert {e["WORLD_SIZE"] for e in envs} == {"3"} and {e["MASTER_ADDR"] for e in envs} == {"127.0.0.1"}
+    assert len({e["MASTER_PORT"] for e in envs}) == 1 and int(envs[0]["MASTER_PORT"]) > 0
+    assert all(e["HSA_ENABLE_IPC_MODE_LEGACY"] is not None for e in envs)
+    assert all(e["argv"] == [str(tmp_path), "ok", "--gpus", "3"] for e in envs)
+
+
+def test_self_launch_returns_the_failing_ranks_code_and_ends_the_others(tmp_path):
+    import time
+    import bench
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    t0 = time.monotonic()
+    rc = bench.self_launch(2, [str(tmp_path), "fail"], script=str(script), grace_s=1.0)
+    assert rc == 3 and time.monotonic() - t0 < 60
+
+
+def test_bare_multi_gpu_invocation_becomes_the_launcher_before_touching_the_gpu(monkeypatch):
+    """No WORLD_SIZE + --gpus 2: main() hands over to self_launch with the untouched command line and exits with its code;
+    nothing GPU-side may run in that process (`python3 bench.py --gpus 8` used to exit 1)."""
+    import bench
+    import torch
+    seen = {}
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2", "--share-gpu"])
+    monkeypatch.setattr(bench, "self_launch", lambda n, argv, **kw: seen.update(n=n, argv=list(argv)) or 7)
+
+    def boom(*a, **k):
+        raise AssertionError("the launcher process touched the GPU")
+    for name in ("set_device", "synchronize", "current_stream", "is_available", "init"):
+        monkeypatch.setattr(torch.cuda, name, boom)
+    with pytest.raises(SystemExit) as ei:
+        bench.main()
+    assert ei.value.code == 7 and seen == {"n": 2, "argv": ["--gpus", "2", "--steps", "6", "--warmup", "2", "--share-gpu"]}
+
+
+def test_rccl_tuning_lines_are_parsed(tmp_path):
+    import bench
+    f = tmp_path / "t.log"
+    f.write_text("h:1:1 [0] NCCL INFO 3407872 Bytes -> Algo 1 proto 2 time 45.0\n"
+                 "h:1:1 [0] NCCL INFO AllReduce: 3116032 Bytes -> Algo RING proto SIMPLE channel{Lo..Hi}={0..31}\n"
+                 "h:1:1 [0] NCCL INFO 3116032 Bytes -> Algo RING proto SIMPLE\nnoise\n")
+    got = bench.rccl_choices(str(f), 8)
+    assert [(e["bytes"], e["algo"], e["proto"], e["n"]) for e in got] == [(3407872, "1", "2", 1), (3116032, "RING", "SIMPLE", 2)]
+    assert isinstance(bench.rccl_choices(None, 8), str) and isinstance(bench.rccl_choices(str(f), 1), str)
+
+
+@pytest.mark.gpu
+def test_bare_two_rank_bench_launches_itself(tmp_path):
+    """VERDICT r3 item 1's acceptance line, from a clean environment (no RANK / WORLD_SIZE): one JSON line, rc 0, n_gpus 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--share-gpu",
+                        "--steps", "6", "--warmup", "2", "--config", "phonon_h64_b8", "--no-cpu-baseline"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    lines = p.stdout.decode().strip().splitlines()
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 16 and rec["warmup"] == 2 and rec["steps"] == 6
+    assert rec["dp"]["collectives_per_step"] == 3 and rec["dp"]["staged_through_host"] is True
+
+
 @pytest.mark.gpu
 def test_bench_default_line_is_one_small_json_record(tmp_path):
     """The driver's own invocation shape (no flags except fewer steps): exactly one stdout line, < 4000 bytes, parseable,
@@ -79,5 +169,9 @@ def test_bench_default_line_is_one_small_json_record(tmp_path):
     assert "error" not in rec.get("secondary", {}), rec["secondary"]
     assert rec["secondary"]["edos_h256_b64"]["value"] > 0 and rec["secondary"]["shuffle"]["value"] > 0
     assert rec["host_ms_per_step"] > 0
+    assert rec["warmup"] == 8 and rec["prepare_steps"] == 16          # the driver's consistency check: warm-up as requested
+    d1 = rec["secondary"]["dp1_nccl"]                                 # the data-parallel step on a 1-rank RCCL group
+    assert "error" not in d1 and d1["value"] > 0 and d1["collectives_per_step"] == 3 and d1["backend"] == "nccl"
+    assert d1["grad_bucket_bytes"]["early"] > 0 and d1["grad_bucket_bytes"]["late"] > 0
     table = json.loads(kout.read_text())
     assert len(table["sites"]) >= 10 and not any(s["site"].startswith("gemm[M") for s in table["sites"])

@@ -125,3 +125,32 @@ def test_wrong_nmax_changes_the_result():
         padded = O.dostransformer_phonon_forward(p, collate(cs[:1], n_max=9), 2, 1)[0]
     assert float((own[0] - full[0]).abs().max()) > 1e-4
     assert float((padded[0] - full[0]).abs().max()) < 1e-5
+
+
+def _minmax_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dostransformer_amd.dist import DataParallel
+        dp = DataParallel()
+        q.put((rank, dp.min_max(1500), dp.min_max(1500 + rank)))
+    finally:
+        td.barrier()
+        td.destroy_process_group()
+
+
+def test_min_max_over_ranks_detects_ragged_shards():
+    """Trainer.step_dataset's once-per-dataset check: equal per-rank dataset sizes give (n, n), ragged ones do not."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_minmax_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=10) for _ in range(2))
+    assert [g[1] for g in got] == [(1500, 1500)] * 2 and [g[2] for g in got] == [(1500, 1501)] * 2

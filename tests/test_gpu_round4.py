@@ -1,0 +1,322 @@
+"""Round 4: hardening of the in-launch reductions (stress under a bandwidth hog), the ADVICE r3 fixes, and the new paths of
+the round (see the individual tests)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+TOL = 2e-5
+
+
+def ops():
+    from dostransformer_amd import ops as o
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g, dtype=torch.float64) * scale).to(torch.float32).to(DEV)
+
+
+def err(a, b):
+    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-12))
+
+
+class _Hog:
+    """Keeps a second stream busy streaming 2 x 512 MiB buffers through HBM (every XCD's L2 is being thrashed and the
+    memory channels are loaded while the kernels under test publish / read back their partial results)."""
+
+    def __init__(self):
+        self.stream = torch.cuda.Stream()
+        self.a = torch.empty(128 << 20, device=DEV)
+        self.b = torch.empty(128 << 20, device=DEV)
+        self.n = 0
+
+    def feed(self, k=1):
+        with torch.cuda.stream(self.stream):
+            for _ in range(k):
+                self.b.copy_(self.a)
+                self.n += 1
+
+
+def _scratch(o, N, K, ns, bias=True):
+    n = o.wgrad_scratch_floats(N, K, ns)
+    slab = torch.full((max(n, 1),), float("nan"), device=DEV) if n else None
+    slab_b = torch.full((ns * ((N + 63) // 64) * 64,), float("nan"), device=DEV) if (bias and ns > 1) else None
+    return slab, slab_b
+
+
+def test_stress_weight_gradient_tickets_under_a_bandwidth_hog():
+    """VERDICT r3 item 5(a), weight gradients: 2 000 back-to-back grouped finished-mode launches (3 jobs each, their
+    M-splits reduced by the last arriving workgroup of every tile - write-through publish + ticket, csrc/gemm.hip
+    wgrad_finish) while a second stream streams 1 GiB per copy through HBM.  EVERY launch is compared on the device, bit for
+    bit, with the result of the same jobs through the single-job launches; the destinations are NaN-filled in between."""
+    o = ops()
+    shapes = [(3000, 256, 128), (9344, 256, 384), (6528, 128, 512)]
+    descs, dsts, refs = [], [], []
+    for i, (M, N, K) in enumerate(shapes):
+        dy, a = rnd(M, N, seed=10 + i), rnd(M, K, seed=20 + i)
+        ns = o.wgrad_splits(M, N, K)
+        assert ns > 1
+        slab, slab_b = _scratch(o, N, K, ns)
+        dw, db = torch.full((N, K), float("nan"), device=DEV), torch.full((N,), float("nan"), device=DEV)
+        g = o.wgrad_desc(M, N, o.seg(dy), [o.seg(a)], slab, slab_b, ns, dst=dw, dst_bias=db)
+        o._call("dosx_wgrad", C.byref(g), o._stream())           # the single-job launch: the reference bits
+        torch.cuda.synchronize()
+        assert err(dw, dy.double().T @ a.double()) < TOL
+        refs.append((dw.clone(), db.clone()))
+        descs.append(g)
+        dsts.append((dw, db, dy, a, slab, slab_b))
+    hog = _Hog()
+    bad = torch.zeros((), dtype=torch.int64, device=DEV)
+    n_launch = 2000
+    for it in range(n_launch):
+        if it % 4 == 0:
+            hog.feed()
+        for dw, db, *_ in dsts:
+            dw.fill_(float("nan"))
+            db.fill_(float("nan"))
+        o.wgrad_grouped(descs)
+        for (dw, db, *_), (rw, rb) in zip(dsts, refs):
+            bad += (dw != rw).sum() + (db != rb).sum()          # NaN != x counts too
+    torch.cuda.synchronize()
+    assert hog.n >= n_launch // 4 and int(bad) == 0, int(bad)
+
+
+def test_stress_segment_sum_and_key_gradient_tickets_under_a_bandwidth_hog():
+    """... the other two in-launch reductions: the message GEMM's chunk sums of over-full nodes (EPI_SEGSUM, ticket on the
+    node's first tile; 2 000 launches, counters drawn from the eager ring every time) and the attention backward's key
+    gradients finished by the last arriving query tile of a crystal (1 500 launches), under the same hog.  The attention
+    launches are compared bitwise with the TWO-launch result (dq kernel + attn_dkv_reduce_kernel); the chunked segment sums
+    have no two-launch twin with the same summation order, so they are compared bitwise with their own first launch and to
+    rounding with GEMM + dosx_segment_reduce."""
+    from dostransformer_amd import _lib, functional as Fn
+    from dostransformer_amd._lib import Attn
+    from dostransformer_amd.batch import seg_tiles_host
+    o = ops()
+    hog = _Hog()
+    bad = torch.zeros((), dtype=torch.int64, device=DEV)
+    # ---- segment sums: 40 nodes, a third of them over-full (49 .. 400 incoming edges)
+    rng = np.random.default_rng(3)
+    n, H = 40, 128
+    deg = rng.integers(0, 30, size=n)
+    deg[::3] = rng.choice([49, 96, 97, 144, 200, 400], size=len(deg[::3]))
+    E = int(deg.sum())
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    dst = torch.from_numpy(np.repeat(np.arange(n), deg).astype(np.int32)).to(DEV)
+    src = torch.from_numpy(rng.integers(0, n, size=E).astype(np.int32)).to(DEV)
+    tiles = torch.from_numpy(seg_tiles_host(rowptr)).to(DEV)
+    assert int((tiles[2] != 0).sum()) >= 20
+    rp = torch.from_numpy(rowptr.astype(np.int32)).to(DEV)
+    inv = torch.from_numpy((1.0 / np.maximum(deg, 1)).astype(np.float32)).to(DEV)
+    gen = torch.Generator().manual_seed(5)
+    P = {"k.0.weight": torch.randn(2 * H, 3 * H, generator=gen) * 0.1, "k.0.bias": torch.randn(2 * H, generator=gen),
+         "k.1.weight": torch.randn(2 * H, generator=gen), "k.1.bias": torch.randn(2 * H, generator=gen),
+         "k.2.weight": torch.tensor([0.25]), "k.3.weight": torch.randn(H, 2 * H, generator=gen) * 0.1,
+         "k.3.bias": torch.randn(H, generator=gen)}
+    P = {k: v.to(DEV) for k, v in P.items()}
+    x, e = torch.randn(n, H, generator=gen).to(DEV), torch.randn(E, H, generator=gen).to(DEV)
+    a = Fn.SegList([o.seg(x, rmap=o.rowmap(idx=src)), o.seg(x, rmap=o.rowmap(idx=dst)), o.seg(e)], [x, e])
+    msg, _ = Fn.mlp_ln_fwd(P, "k", a, E, H)
+    agg0, e0 = torch.empty(n, H, device=DEV), torch.empty(E, H, device=DEV)
+    o.segment_reduce(msg, rp, inv, agg0, e, e0, n, E, H)
+    agg1, e1 = torch.full((n, H), float("nan"), device=DEV), torch.full((E, H), float("nan"), device=DEV)
+    Fn.mlp_ln_fwd(P, "k", a, E, H, segsum=(tiles, rp, inv, agg1, e, e1))
+    torch.cuda.synchronize()
+    assert float((agg1 - agg0).abs().max()) <= 4e-6 * float(agg0.abs().max()) and torch.equal(e1, e0)
+    ref_agg = agg1.clone()
+    for it in range(2000):
+        if it % 4 == 0:
+            hog.feed()
+        agg1.fill_(float("nan"))
+        Fn.mlp_ln_fwd(P, "k", a, E, H, segsum=(tiles, rp, inv, agg1, e, e1))
+        bad += (agg1 != ref_agg).sum()
+    torch.cuda.synchronize()
+    assert int(bad) == 0, ("segment sums", int(bad))
+    # ---- attention key gradients: the cfg2 self-attention shape (51 keys, 128 pseudo-crystals, 2 query tiles each)
+    Sq, Bq, Nk, Bk, Hh = 51, 128, 51, 128, 128
+    assert _lib.load().dosx_attention_pkv_supported(Nk, Hh)
+    xq, kv = rnd(Sq * Bq, Hh, seed=1), rnd(Nk * Bk, Hh, seed=2)
+    gam, bet = rnd(Hh, seed=3), 0.3 * rnd(Hh, seed=4)
+    at = Attn()
+    at.Sq, at.Bq, at.Nk, at.Bk, at.H, at.q_stride_s, at.q_stride_b = Sq, Bq, Nk, Bk, Hh, Bq, 1
+    out, probs = torch.empty(Sq * Bq, Hh, device=DEV), torch.empty(Bq, Sq, Nk, device=DEV)
+    qstats, ostats = torch.empty(Sq * Bq, 2, device=DEV), torch.empty(Sq * Bq, 2, device=DEV)
+    at.x, at.kvhat, at.gamma0, at.beta0 = xq.data_ptr(), kv.data_ptr(), gam.data_ptr(), bet.data_ptr()
+    at.out, at.probs, at.qstats, at.out_stats = out.data_ptr(), probs.data_ptr(), qstats.data_ptr(), ostats.data_ptr()
+    o.attention_fwd(at)
+    dout = rnd(Sq * Bq, Hh, seed=5)
+    nqt, nkt = (Sq + 31) // 32, (Nk + 15) // 16
+    base = rnd(Nk * Bk, Hh, seed=6)
+    dx = torch.full((Sq * Bq, Hh), float("nan"), device=DEV)
+    dkv = base.clone()
+    part = torch.full((Bq * nqt + Bk * nkt, 2 * Hh), float("nan"), device=DEV)
+    kvp = torch.full((Bq * nqt * Nk, Hh), float("nan"), device=DEV)
+    at.dout, at.dx, at.dscores, at.dkvhat, at.dkv_accumulate = dout.data_ptr(), dx.data_ptr(), None, dkv.data_ptr(), 1
+    at.partials_q, at.partials_kv = part.data_ptr(), part.data_ptr() + 4 * Bq * nqt * 2 * Hh
+    at.dkv_part = kvp.data_ptr()
+    at.dkv_cnt = None
+    o.attention_bwd(at)                                       # two launches: dq kernel + attn_dkv_reduce_kernel
+    torch.cuda.synchronize()
+    ref = (dx.clone(), dkv.clone(), part.clone())
+    at.dkv_cnt = o.COUNTERS.take(DEV, Bk)
+    bad.zero_()
+    for it in range(1500):
+        if it % 4 == 0:
+            hog.feed()
+        dkv.copy_(base)
+        dx.fill_(float("nan"))
+        part.fill_(float("nan"))
+        o.attention_bwd(at)
+        bad += (dx != ref[0]).sum() + (dkv != ref[1]).sum() + (part != ref[2]).sum()
+    torch.cuda.synchronize()
+    assert int(bad) == 0, ("attention key gradients", int(bad))
+    assert hog.n >= 800
+
+
+# ---- ADVICE r3 -------------------------------------------------------------------------------------------------------
+
+class _FakeDist:
+    """Two-rank stand-in whose collectives are no-ops (the sums of a rank with an identical twin would double everything,
+    which this test does not look at): what is under test is the n_global / shard-size logic of Trainer.step_dataset."""
+    world, rank, staged = 2, 0, False
+
+    def __init__(self, sizes):
+        self.sizes, self.calls = sizes, 0
+
+    def min_max(self, v):
+        self.calls += 1
+        return self.sizes if self.sizes is not None else (v, v)
+
+    def all_reduce_sse(self, t):
+        pass
+
+    def all_reduce_grads(self, t):
+        pass
+
+    def all_reduce_grads_async(self, t):
+        from dostransformer_amd.dist import _Done
+        return _Done()
+
+
+def test_step_dataset_checks_shard_sizes_once_per_dataset():
+    """without an explicit n_global, step_dataset assumes B * world crystals in the un-sharded batch -
+    true for every batch of an epoch iff all ranks hold equally many crystals.  That is verified once per dataset with one
+    min/max over the ranks; ragged shards are refused with a message that asks for n_global; an explicit n_global is taken
+    as is."""
+    from dostransformer_amd import synth
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    from dostransformer_amd.loader import DeviceDataset
+    from dostransformer_amd.train import Trainer
+    torch.manual_seed(0)
+    ds = DeviceDataset(synth.phonon_crystals(16, 3, torch.float32), DEV)
+    nmax = 12
+    model = DOSTransformer_phonon(2, 1, 118, 4, 64, DEV, 0.0).to(DEV)
+    d = _FakeDist((16, 16))
+    tr = Trainer(model, replay=True, dist=d)
+    for _ in range(3):
+        tr.step_dataset(ds, list(range(8)), n_max=nmax)
+    torch.cuda.synchronize()
+    assert d.calls == 1                                        # once per dataset, not per step
+    assert all(k[4] == 16 for k in tr._slots)                  # n_global = B * world in the bucket key
+    ragged = _FakeDist((16, 17))
+    tr2 = Trainer(DOSTransformer_phonon(2, 1, 118, 4, 64, DEV, 0.0).to(DEV), replay=True, dist=ragged)
+    with pytest.raises(ValueError, match="n_global"):
+        tr2.step_dataset(ds, list(range(8)), n_max=nmax)
+    tr2.step_dataset(ds, list(range(8)), n_global=15, n_max=nmax)      # the caller knows: no check, its count is used
+    torch.cuda.synchronize()
+    assert ragged.calls == 1 and all(k[4] == 15 for k in tr2._slots)
+
+
+def test_checkpointed_dropout_seed_is_rank_independent(monkeypatch):
+    """Trainer.state_dict stores the dropout seed WITHOUT the saving rank's offset; a rank that loads it
+    re-applies its own offset, so resumed data-parallel ranks keep drawing different masks for their different shards - the
+    masks their uninterrupted selves would have drawn."""
+    from dostransformer_amd import _models, synth, train
+    from dostransformer_amd.batch import collate
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    off = lambda r: (0x9E3779B97F4A7C15 * (r + 1)) % _models._SEED_MOD
+    g = collate(synth.phonon_crystals(4, 1, torch.float32)).to(DEV)
+    seeds = {}
+    for r in (0, 3):
+        monkeypatch.setattr(_models, "rank_seed_offset", lambda r=r: off(r))
+        monkeypatch.setattr(train, "rank_seed_offset", lambda r=r: off(r))
+        torch.manual_seed(11)
+        model = DOSTransformer_phonon(2, 1, 118, 4, 64, DEV, 0.25).to(DEV)
+        tr = train.Trainer(model)
+        model.train()
+        for _ in range(2):
+            tr.step(g)
+        seeds[r] = (int(model._drop_seed.item()), tr.state_dict())
+    assert seeds[0][0] != seeds[3][0] and seeds[0][1]["drop_seed_base"] == seeds[3][1]["drop_seed_base"]
+    # rank 3 resumes from the file rank 0 wrote: it gets ITS seed back, not rank 0's
+    monkeypatch.setattr(train, "rank_seed_offset", lambda: off(3))
+    monkeypatch.setattr(_models, "rank_seed_offset", lambda: off(3))
+    torch.manual_seed(99)
+    model = DOSTransformer_phonon(2, 1, 118, 4, 64, DEV, 0.25).to(DEV)
+    tr = train.Trainer(model)
+    tr.load_state_dict(seeds[0][1])
+    assert int(model._drop_seed.item()) == seeds[3][0]
+
+
+def test_counter_pool_never_aliases_launches_in_flight(monkeypatch):
+    """recorded programs own their arrival counters; the eager ring synchronises before it hands an entry
+    out a second time and grows for a request larger than itself; a failed call drops the ring."""
+    o = ops()
+    pool = o._CounterPool()
+    monkeypatch.setattr(pool, "SIZE", 64)
+    syncs = []
+    real_sync = torch.cuda.synchronize
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: (syncs.append(1), real_sync(*a, **k))[1])
+    a = pool.take(DEV, 40)
+    b = pool.take(DEV, 20)
+    assert b == a + 160 and not syncs
+    c = pool.take(DEV, 10)                     # 40 + 20 + 10 > 64: wraps - after a device synchronisation
+    assert c == a and len(syncs) == 1
+    big = pool.take(DEV, 1000)                 # larger than the ring: a new, larger ring (zeroed), not an error
+    assert len(syncs) == 2 and pool._bufs[str(DEV)][0].numel() >= 1000 and big == pool._bufs[str(DEV)][0].data_ptr()
+    assert int(pool._bufs[str(DEV)][0].abs().sum()) == 0
+    o.RECORDER.begin()
+    try:
+        r1, r2 = pool.take(DEV, 8), pool.take(DEV, 8)
+        own = list(o.RECORDER.keep)
+    finally:
+        o.RECORDER.end()
+    ring = pool._bufs[str(DEV)][0]
+    lo, hi = ring.data_ptr(), ring.data_ptr() + 4 * ring.numel()
+    assert r1 != r2 and not (lo <= r1 < hi) and not (lo <= r2 < hi) and len(own) == 2
+    pool.poison()
+    assert pool._bufs == {}
+
+
+def test_segment_sum_gemm_refuses_a_call_without_chunk_scratch():
+    """DosxGemm EPI_SEGSUM without seg_part / seg_cnt would silently skip over-full nodes (the tile table is
+    device memory, the host cannot tell): the C ABI refuses it."""
+    from dostransformer_amd import _lib
+    from dostransformer_amd._lib import Gemm
+    from dostransformer_amd.batch import seg_tiles_host
+    o = ops()
+    n, H = 6, 64
+    deg = np.array([3, 60, 2, 0, 5, 100])
+    E = int(deg.sum())
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    tiles = torch.from_numpy(seg_tiles_host(rowptr)).to(DEV)
+    rp = torch.from_numpy(rowptr.astype(np.int32)).to(DEV)
+    xhat, stats = rnd(E, 2 * H, seed=1), torch.rand(E, 2, device=DEV)
+    w, agg = rnd(H, 2 * H, seed=2), torch.empty(n, H, device=DEV)
+    gam, bet, alpha = rnd(2 * H, seed=3), rnd(2 * H, seed=4), torch.tensor([0.25], device=DEV)
+    g = Gemm()
+    g.M, g.N, g.K, g.nseg = E, H, 2 * H, 1
+    g.a[0] = o.seg(xhat)
+    g.pro, g.pro_gamma, g.pro_beta, g.pro_alpha, g.pro_stats = o.PRO_LN_PRELU, gam.data_ptr(), bet.data_ptr(), alpha.data_ptr(), stats.data_ptr()
+    g.w, g.ldw, g.w_layout, g.epi = w.data_ptr(), 2 * H, 0, o.EPI_SEGSUM
+    g.ldo, g.out_map, g.res_map = H, o.ident(), o.ident()
+    g.seg_tile, g.seg_ntiles, g.seg_rowptr, g.seg_agg = tiles.data_ptr(), tiles.shape[1] - 1, rp.data_ptr(), agg.data_ptr()
+    rc = _lib.load().dosx_gemm(C.byref(g), o._stream())
+    assert rc == -22
+    with pytest.raises(_lib.DosxError, match="seg_part"):
+        _lib.check(rc, "dosx_gemm")
