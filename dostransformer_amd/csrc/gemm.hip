@@ -1760,6 +1760,7 @@ struct WgradGroup {
   DosxReduceJob rjob[WG_MAX_RJOBS];
   int rfirst[WG_MAX_RJOBS + 1];
   int nr;
+  int block_off;     // this launch covers the blocks [block_off, block_off + gridDim.x) of the group (dosx_grad_flush: rounds)
 };
 static_assert(sizeof(WgradGroup) <= 4064, "WgradGroup must fit the kernel argument segment");
 
@@ -1775,9 +1776,10 @@ __global__ __launch_bounds__(512, DOSX_WGRAD_OCC) void wgrad_grouped_kernel(cons
   // the job table is read where it lies, in the kernel-argument segment (scalar loads through a constant-address-space
   // pointer): indexing the by-value parameter with a run-time index made hipcc copy the whole 4 KB table to scratch
   const WgradGroup& G = *(const WgradGroup*)__builtin_amdgcn_kernarg_segment_ptr();
-  if ((int)blockIdx.x >= G.first_block[G.n]) {
+  const int bx = (int)blockIdx.x + G.block_off;
+  if (bx >= G.first_block[G.n]) {
     // ---- a reduction block: 2 slices of 256 elements (one per half of the workgroup) ----
-    const int rb = (int)blockIdx.x - G.first_block[G.n];
+    const int rb = bx - G.first_block[G.n];
     int lo = 0, hi = G.nr - 1;
     while (lo < hi) {
       const int mid = (lo + hi + 1) >> 1;
@@ -1791,10 +1793,10 @@ __global__ __launch_bounds__(512, DOSX_WGRAD_OCC) void wgrad_grouped_kernel(cons
   int lo = 0, hi = G.n - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
-    if (G.first_block[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    if (G.first_block[mid] <= bx) lo = mid; else hi = mid - 1;
   }
   const WgradLaunch& L = G.job[lo];
-  const int bid = (int)blockIdx.x - G.first_block[lo];
+  const int bid = bx - G.first_block[lo];
   switch (L.variant + 8 * (L.nt - 1)) {             // workgroup-uniform
     case 0: wgrad_body<DOSX_PRO_NONE, 1, 1, 1>(L, bid, Sm); break;
     case 1: wgrad_body<DOSX_PRO_PRELU, 1, 1, 1>(L, bid, Sm); break;
@@ -1905,7 +1907,14 @@ extern "C" int dosx_wgrad_splits(int M, int N, int K) {
     max_split = e ? atoi(e) : 8;
     if (max_split < 1) max_split = 8;
   }
-  if (s > max_split) s = max_split;
+  // The cap scales with M (round 4): 8 is the optimum where it was tuned - the BASELINE shapes, M <= 25728 rows, whose jobs
+  // run in groups that fill the chip together - but a LONG job (M > 32768) with few tiles is a grid of tiles x 8 <= 128-192
+  // workgroups on 256 CUs whatever its length (M = 262144, N = 512, K = 128: 17.5 % of the MFMA peak).  Every workgroup keeps
+  // at least 4096 rows (128 chunks of MFMAs against its ~12 k clk of fixed cost), up to the 64 partial tiles a counter /
+  // scratch slot set is laid out for; the last arriver of a tile then sums up to 64 partials, 8 loads in flight at a time.
+  int cap_m = M / 4096;
+  if (cap_m > 64) cap_m = 64;
+  if (s > (max_split > cap_m ? max_split : cap_m)) s = max_split > cap_m ? max_split : cap_m;
   // ... but no workgroup lives longer than max_chunks 32-row chunks: a weight-gradient workgroup cannot be pre-empted, and a
   // kernel of the dgrad chain that arrives while long-lived ones hold the CUs waits for them (eDOS, M = 25728 rows at 8
   // splits: 100 chunks = ~70 us per workgroup; the two 15-us head dgrad GEMMs behind the self encoder took 228 us each)
@@ -2060,8 +2069,22 @@ extern "C" int dosx_grad_flush(const DosxWgrad* jobs, int n_jobs, const DosxRedu
     if (G.n == 0 && G.nr == 0) return 0;
     G.first_block[G.n] = blocks_total;
     G.rfirst[G.nr] = rblocks;
-    hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(blocks_total + rblocks), dim3(512), 0, st, G);
-    DOSX_LAUNCH_CHECK();
+    // DOSX_WGRAD_ROUND = r > 0: the group goes out as successive launches of at most r workgroups.  A kernel of the dgrad
+    // chain that arrives while a weight-gradient grid is being dispatched waits until a CU is EMPTY (its workgroups need
+    // > 100 KB of LDS / > 128 VGPRs; a freed half-CU slot is refilled at once from the weight-gradient grid's backlog); at
+    // a launch boundary the backlog is empty and CUs drain completely, one after the other.
+    static int round = -1;
+    if (round < 0) {
+      const char* e = getenv("DOSX_WGRAD_ROUND");
+      round = e ? atoi(e) : 0;
+    }
+    const int total = blocks_total + rblocks;
+    const int per = round > 0 ? round : total;
+    for (int off = 0; off < total; off += per) {
+      G.block_off = off;
+      hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(total - off < per ? total - off : per), dim3(512), 0, st, G);
+      DOSX_LAUNCH_CHECK();
+    }
     G.n = 0;
     G.nr = 0;
     blocks_total = 0;

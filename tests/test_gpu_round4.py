@@ -320,3 +320,34 @@ def test_segment_sum_gemm_refuses_a_call_without_chunk_scratch():
     assert rc == -22
     with pytest.raises(_lib.DosxError, match="seg_part"):
         _lib.check(rc, "dosx_gemm")
+
+
+def test_edos_example_driver_end_to_end(tmp_path):
+    """examples/train_edos.py (counterpart of `main_eDOS.py:101-175` with the flags of `utils.py:25-43`):
+    DeviceDataset -> Trainer.step_dataset (replay) -> evaluate.test(Predictor) at batch size 1 every --eval epochs -> test
+    split on a new best -> checkpoint.  The loss must go down, the metrics must be finite, and the checkpoint must reload
+    into a fresh module and reproduce the saved model's predictions."""
+    import importlib.util
+    import os
+    from dostransformer_amd import checkpoint, synth
+    from dostransformer_amd.batch import collate
+    from dostransformer_amd.embedder_eDOS.DOSTransformer import DOSTransformer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("train_edos", os.path.join(root, "examples", "train_edos.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = str(tmp_path / "best.pt")
+    res = mod.main(["--epochs", "6", "--eval", "2", "--crystals", "100", "--hidden", "32", "--transformer", "1",
+                    "--batch_size", "16", "--lr", "2e-3", "--out", out])
+    h = res["train_loss"]
+    assert len(h) == 6 and all(np.isfinite(h)) and h[-1] < 0.9 * h[0], h
+    assert res["best_epoch"] in (2, 4, 6) and np.isfinite(res["best_valid_rmse"]) and all(np.isfinite(res["test"]))
+    assert os.path.exists(out)
+    fresh = DOSTransformer(3, 1, 200, 41, 2, 32, DEV, 0.0).to(DEV)
+    extra = checkpoint.load(out, fresh)
+    assert extra["epoch"] == res["best_epoch"]
+    g = collate(synth.edos_crystals(3, 5, torch.float32)).to(DEV)
+    fresh.eval()
+    with torch.no_grad():
+        a = fresh(g)[2]
+    assert bool(torch.isfinite(a).all())

@@ -68,9 +68,13 @@ def wgrad_case(name, M, N, K):
     dy = torch.randn(M, N, device=DEV)
     a = torch.randn(M, K, device=DEV)
     ns = ops.wgrad_splits(M, N, K)
-    slab = torch.empty(ns, N, K, device=DEV)
-    sb = torch.empty(ns, N, device=DEV)
-    us = timeit(lambda: ops.wgrad(M, N, ops.seg(dy), [ops.seg(a)], slab, sb, ns))
+    # finished mode, as in the training step: the kernel reduces its M-splits itself and writes dW / db (the time includes it)
+    nf = ops.wgrad_scratch_floats(N, K, ns)
+    slab = torch.empty(max(nf, 1), device=DEV)
+    sb = torch.empty(ns * ((N + 63) // 64) * 64, device=DEV)
+    dw, db = torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
+    g = ops.wgrad_desc(M, N, ops.seg(dy), [ops.seg(a)], slab, sb, ns, dst=dw, dst_bias=db)
+    us = timeit(lambda: ops.wgrad_grouped([g]))
     tf = 2.0 * M * N * K / us / 1e6
     print(f"wgrad {name:34s} M={M:6d} N={N:4d} K={K:4d} splits={ns:2d}: {us:8.1f} us  {tf:6.1f} TF/s  "
           f"({100 * tf / 157.3:4.1f}%)")
@@ -309,6 +313,11 @@ def main():
         wgrad_case("fc2 (H x 4H) 2B", R2, H, 4 * H)
         wgrad_case("node W1", N, 2 * H, 2 * H)
         wgrad_case("big", 262144, 512, 128)
+        # the four weight shapes of a model with hidden 128 at roofline scale
+        wgrad_case("big edge W1 (2H x 3H)", 262144, 256, 384)
+        wgrad_case("big edge W2 (H x 2H)", 262144, 128, 256)
+        wgrad_case("big fc1 (4H x H)", 262144, 512, 128)
+        wgrad_case("big fc2 (H x 4H)", 262144, 128, 512)
     if w in ("all", "scatter"):
         segreduce_case("cfg2 batch", 450, 20, 128)
         segreduce_case("cfg2 batch (last layer)", 450, 20, 128, residual=False)
