@@ -158,6 +158,27 @@ def load_traffic():
     return rec.get("kernels", {}), f"{os.path.basename(files[-1])} (git {rec.get('git_head', '?')[:12]})"
 
 
+def load_north_star():
+    """The two counter-based figures of BASELINE.json's north_star (scatter-add HBM fraction, attention MFMA utilisation)
+    from the committed rocprofv3 PMC passes (tools/pmc_north_star.py), under the same rule as `traffic`: a file measured on
+    other sources is refused."""
+    import glob
+    from dostransformer_amd._lib import source_hash
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_north_star.json")))
+    if not files:
+        return {"scatter_hbm_frac": None, "attn_mfma_util": None, "source": "no profiles/r*_north_star.json"}
+    name = os.path.basename(files[-1])
+    try:
+        rec = json.load(open(files[-1]))
+    except Exception as e:  # pragma: no cover
+        return {"scatter_hbm_frac": None, "attn_mfma_util": None, "source": f"{name}: {e}"[:100]}
+    if rec.get("source_hash") != source_hash():
+        return {"scatter_hbm_frac": None, "attn_mfma_util": None,
+                "source": f"{name} was measured on other sources ({rec.get('source_hash')} != {source_hash()}): refused"}
+    return {"scatter_hbm_frac": rec.get("scatter_hbm_frac"), "attn_mfma_util": rec.get("attn_mfma_util"),
+            "source": f"{name} (rocprofv3 --pmc, git {str(rec.get('git_head', '?'))[:12]})"}
+
+
 def traffic_of(kernels, key):
     """launch-weighted mean bytes per launch over the profiled symbols that contain `key`"""
     tot = n = 0
@@ -193,7 +214,7 @@ def rccl_choices(path, world):
     return sorted(seen.values(), key=lambda e: -e["bytes"])[:4]
 
 
-LINE_BUDGET = 3000          # bytes of the ONE stdout line (the driver keeps an 8 KB tail of stdout)
+LINE_BUDGET = 3600          # bytes of the ONE stdout line (the driver keeps an 8 KB tail of stdout)
 
 
 def _round_sig(v, n=4):
@@ -209,7 +230,7 @@ def compact_record(out: dict, sites: list, budget: int = LINE_BUDGET) -> dict:
     rec = dict(out)
     rec["top_sites"] = [{"site": r["site"][:48], "frac": r["frac"], "us_per_step": r.get("us_per_step"), "bound": r["bound"]}
                         for r in sites[:5]]
-    for drop in (None, "top_sites", "traffic_source", "slots", "secondary"):
+    for drop in (None, "top_sites", "traffic_source", "slots", "dp", "secondary"):
         if drop is not None:
             rec.pop(drop, None)
         if len(json.dumps(rec)) <= budget:
@@ -567,7 +588,9 @@ def main():
             try:
                 d1 = run_workload("phonon_h128_b64", shuffle=False, steps=args.steps, warmup=args.warmup, bucket=(8, 128),
                                   instrument=False, **dict(common, dp=DataParallel()))
-                secondary["dp1_nccl"] = dict(brief(d1, args.steps), **(d1["dp_info"] or {}))
+                info = d1["dp_info"] or {}
+                secondary["dp1_nccl"] = dict(brief(d1, args.steps), **{k: info.get(k) for k in
+                                                                       ("grad_bucket_bytes", "collectives_per_step", "backend")})
             finally:
                 td.destroy_process_group()
         except Exception as ex:
@@ -616,6 +639,8 @@ def main():
             "roofline": dom,
             "traffic_source": traffic_src[:100],
         }
+        if world == 1 and args.config == "phonon_h128_b64":
+            out["north_star"] = load_north_star()
         if r["slots"] is not None:
             out["slots"] = r["slots"]
         if r["dp_info"] is not None:

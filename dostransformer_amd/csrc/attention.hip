@@ -1283,6 +1283,15 @@ size_t dkv_smem(const Geo& g, int kg) {
   return sizeof(float) * (stage > epi ? stage : epi);
 }
 
+inline int attn_nj3() {               // DOSX_ATTN_NJ3=0: the 33-48-key shapes on the 64-entry row phases again (A/B)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("DOSX_ATTN_NJ3");
+    v = (e && atoi(e) == 0) ? 4 : 3;
+  }
+  return v;
+}
+
 constexpr int MAX_FUSED_NK = 320;      // the score row of a query lives in LDS
 
 int check_attn(const DosxAttn& a, const char* who) {
@@ -1316,7 +1325,9 @@ extern "C" int dosx_attention_fwd(const DosxAttn* ap, dosx_stream_t stream) {
   const size_t smem = fwd_smem(g, res);
   DOSX_CHECK_ARG(smem <= 160 * 1024, "dosx_attention_fwd: LDS need %zu > 160 KiB", smem);
   const dim3 grid(ceil_div(a.Sq, QT), a.Bq);
-  const int nj = a.Nk <= 16 ? 1 : (a.Nk <= 64 ? 4 : (a.Nk <= 208 ? 13 : 20));
+  // (NJ = keys per lane of the row phases, in units of 16.  3: 33-48 keys - the 41-key Electron-DOS cross attention - runs
+  //  the softmax phases on 48 instead of 64 entries per row; the MFMA tiles stay 32 keys wide)
+  const int nj = a.Nk <= 16 ? 1 : (a.Nk <= 48 ? attn_nj3() : (a.Nk <= 64 ? 4 : (a.Nk <= 208 ? 13 : 20)));
 #define DOSX_FWDS(NJ_, RES_)                                                                                \
   do {                                                                                                      \
     static bool attr_set = false;                                                                           \
@@ -1328,6 +1339,7 @@ extern "C" int dosx_attention_fwd(const DosxAttn* ap, dosx_stream_t stream) {
     hipLaunchKernelGGL((attn_fwd_stream_kernel<NJ_, RES_>), grid, dim3(512), smem, to_stream(stream), a);   \
   } while (0)
   if (nj == 1) { if (res) DOSX_FWDS(1, true); else DOSX_FWDS(1, false); }
+  else if (nj == 3) { if (res) DOSX_FWDS(3, true); else DOSX_FWDS(3, false); }
   else if (nj == 4) { if (res) DOSX_FWDS(4, true); else DOSX_FWDS(4, false); }
   else if (nj == 13) DOSX_FWDS(13, false); else DOSX_FWDS(20, false);
 #undef DOSX_FWDS
@@ -1364,7 +1376,7 @@ extern "C" int dosx_attention_bwd(const DosxAttn* ap, dosx_stream_t stream) {
   }
   const dim3 grid(ceil_div(a.Sq, QT), a.Bq);
   if (!(a.flags & DOSX_ATTN_BWD_SKIP_DQ)) {
-    const int nj = a.Nk <= 16 ? 1 : (a.Nk <= 64 ? 4 : (a.Nk <= 208 ? 13 : 20));
+    const int nj = a.Nk <= 16 ? 1 : (a.Nk <= 48 ? attn_nj3() : (a.Nk <= 64 ? 4 : (a.Nk <= 208 ? 13 : 20)));
 #define DOSX_DQS(NJ_, PKV_, RES_)                                                                           \
   do {                                                                                                      \
     static bool attr_dq = false;                                                                            \
@@ -1376,8 +1388,8 @@ extern "C" int dosx_attention_bwd(const DosxAttn* ap, dosx_stream_t stream) {
     hipLaunchKernelGGL((attn_bwd_dq_stream_kernel<NJ_, PKV_, RES_>), grid, dim3(512), s1, to_stream(stream), a); \
   } while (0)
 #define DOSX_DQS2(NJ_, PKV_) do { if (res) DOSX_DQS(NJ_, PKV_, true); else DOSX_DQS(NJ_, PKV_, false); } while (0)
-    if (pkv) { if (nj == 1) DOSX_DQS2(1, true); else DOSX_DQS2(4, true); }
-    else if (nj == 1) DOSX_DQS2(1, false); else if (nj == 4) DOSX_DQS2(4, false); else if (nj == 13) DOSX_DQS(13, false, false);
+    if (pkv) { if (nj == 1) DOSX_DQS2(1, true); else if (nj == 3) DOSX_DQS2(3, true); else DOSX_DQS2(4, true); }
+    else if (nj == 1) DOSX_DQS2(1, false); else if (nj == 3) DOSX_DQS2(3, false); else if (nj == 4) DOSX_DQS2(4, false); else if (nj == 13) DOSX_DQS(13, false, false);
     else DOSX_DQS(20, false, false);
 #undef DOSX_DQS2
 #undef DOSX_DQS

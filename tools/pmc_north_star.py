@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""The two counter-based figures BASELINE.json's north_star asks for, in one small file bench.py can put on its line:
+
+  scatter_hbm_frac  achieved HBM rate of the scatter-add kernel / 8 TB/s, from the FETCH_SIZE / WRITE_SIZE passes over
+                    `tools/bench_kernels.py --what scatter` (summarised by tools/pmc_scatter.py): the BASELINE configs[1]
+                    size (9 000 edges, H 128) and the roofline-scale case (4 Mi edges, H 128, with the edge residual);
+  attn_mfma_util    MFMA-busy cycles of all 1024 SIMDs / (1024 x the kernels' cycles at 2.4 GHz), from ONE pass with
+                    SQ_VALU_MFMA_BUSY_CYCLES over `tools/bench_kernels.py --what attn`, forward + backward kernels of a
+                    shape class together.  The classes are told apart by (template arguments, grid size): the key-tile
+                    count NJ = 1 kernels are the 12-key Phonon-DOS cross attention, NJ = 4 at 2 query tiles x 128 entries the
+                    51-key Phonon-DOS self attention, NJ = 4 at 7 query tiles the 41-key Electron-DOS cross attention,
+                    NJ = 13 at 7 x 128 the 201-key Electron-DOS self attention (the roofline-scale launches are left out).
+
+The file carries the hash of the sources it was measured on (dostransformer_amd._lib.source_hash); bench.py reports the
+figures only while that hash is the hash of the sources it runs - like roofline.traffic.
+usage: pmc_north_star.py <attn counter_collection.csv> <scatter summary csv of pmc_scatter.py> <out.json> [git_head]"""
+import csv
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+SIMDS, GHZ = 256 * 4, 2.4
+
+
+def attn_classes(path):
+    rows = defaultdict(dict)
+    for r in csv.DictReader(open(path)):
+        d = rows[r["Dispatch_Id"]]
+        d["name"], d["grid"] = r["Kernel_Name"], int(r["Grid_Size"])
+        d["ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    agg = defaultdict(lambda: [0.0, 0.0, 0])
+    for d in rows.values():
+        m = re.search(r"attn_(fwd_stream|bwd_dq_stream|bwd_dkv)_kernel<(\d+)", d["name"])
+        if not m or d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) <= 0:
+            continue
+        nj, wgs = int(m.group(2)), d["grid"] // 512
+        if m.group(1) == "bwd_dkv":
+            cls = "edos_self" if nj == 2 and wgs <= 4 * 128 else None      # KG = 2 key groups x 128 crystals; roofline scale: more
+        elif nj == 1:
+            cls = "cfg2_cross"
+        elif nj == 4:
+            cls = "cfg2_self" if wgs <= 2 * 128 else ("edos_cross" if wgs <= 7 * 128 else None)
+        elif nj == 13:
+            cls = "edos_self" if wgs <= 7 * 128 else None
+        else:
+            cls = None
+        if cls is None:
+            continue
+        a = agg[cls]
+        a[0] += d["SQ_VALU_MFMA_BUSY_CYCLES"]
+        a[1] += d["ns"]
+        a[2] += 1
+    return {k: {"util": round(b / (SIMDS * ns * GHZ), 4), "launches": n} for k, (b, ns, n) in sorted(agg.items())}
+
+
+def scatter_classes(path):
+    out = {}
+    for r in csv.DictReader(open(path)):
+        grid, frac = int(r["grid_size"]), round(float(r["pct_of_8TBs"]) / 100.0, 4)
+        mb = float(r["HBM_MB_per_launch"])
+        if grid < 100000:
+            out["cfg2"] = {"frac": frac, "avg_us": float(r["avg_us"]), "hbm_mb": mb}
+        elif "4Mi" not in out and 6000 < mb < 7000 and grid < 10_000_000:     # 4 Mi edges x H 128 with the edge residual: 6.55 GB
+            out["4Mi"] = {"frac": frac, "avg_us": float(r["avg_us"]), "hbm_mb": mb}
+    return out
+
+
+def main():
+    from dostransformer_amd._lib import source_hash
+    att, sc = attn_classes(sys.argv[1]), scatter_classes(sys.argv[2])
+    out = {"_note": __doc__.split("usage:")[0].strip(), "source_hash": source_hash(),
+           "git_head": sys.argv[4] if len(sys.argv) > 4 else "unknown",
+           "scatter_hbm_frac": {k: v["frac"] for k, v in sc.items()}, "scatter_detail": sc,
+           "attn_mfma_util": {k: v["util"] for k, v in att.items()}, "attn_detail": att}
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    print(json.dumps({k: out[k] for k in ("scatter_hbm_frac", "attn_mfma_util", "source_hash")}))
+
+
+if __name__ == "__main__":
+    main()

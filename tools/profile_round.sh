@@ -4,7 +4,7 @@
 # then copy gpurun_out/prof_<round>/summary/* into profiles/.  rocprofv3 passes are separate (kernel trace | one PMC
 # counter each), the program comes directly after `--`, outputs are CSV.
 set -u
-R=${1:-r03}
+R=${1:-r04}
 HEAD=${2:-unknown}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$R
@@ -41,6 +41,11 @@ done
 sf=$(find "$OUT/pmc_scatter_FETCH_SIZE" -name "*counter_collection.csv" | head -1)
 sw=$(find "$OUT/pmc_scatter_WRITE_SIZE" -name "*counter_collection.csv" | head -1)
 [ -n "$sf" ] && [ -n "$sw" ] && python3 "$ROOT/tools/pmc_scatter.py" "$sf" "$sw" "$S/${R}_pmc_scatter_add.csv" > "$OUT/pmc_scatter.summary" 2>&1
+# the two north_star figures in one hash-tagged file (bench.py puts it on its line as `north_star`)
+if [ -n "$fm" ] && [ -f "$S/${R}_pmc_scatter_add.csv" ]; then
+  python3 "$ROOT/tools/pmc_north_star.py" "$fm" "$S/${R}_pmc_scatter_add.csv" "$S/${R}_north_star.json" "$HEAD" > "$OUT/north_star.log" 2>&1
+  cp "$S/${R}_north_star.json" "$ROOT/profiles/${R}_north_star.json"
+fi
 cd "$ROOT"
 # THE bench line (the driver's invocation: default flags; secondaries = eDOS H256 + shuffle inside the same record) + its per-site table
 timeout 600 python3 bench.py --kernels-out "$S/${R}_bench_phonon_h128_b64_sites.json" > "$S/${R}_bench_phonon_h128_b64.json" 2> "$OUT/bench_phonon.err" < /dev/null
