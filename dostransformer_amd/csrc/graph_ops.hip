@@ -325,6 +325,34 @@ __global__ __launch_bounds__(256) void dense_normalize_slots_kernel(const float*
   if (lane == 0) rstd_nodes[n] = rstd;
 }
 
+// to_dense_batch alone (DOSTransformer_phonon.py:86-87), without the key normalisation: slot (pos, b) = the node's row or
+// zeros.  The keys of the unfused attention path (hidden > 256: functional.encoder_kv_fwd normalises them itself).
+__global__ __launch_bounds__(256) void dense_slots_kernel(const float* __restrict__ x, const int* __restrict__ graph_ptr,
+                                                          float* __restrict__ dense, int B, int n_max, int H) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n_max * B) return;
+  const int pos = r / B, b = r % B;
+  const int beg = graph_ptr[b], end = graph_ptr[b + 1];
+  const float* row = beg + pos < end ? x + (size_t)(beg + pos) * H : nullptr;
+  for (int c = lane * 4; c < H; c += 256) st4(dense + (size_t)r * H + c, row ? ld4(row + c) : f4zero());
+}
+
+// ... and its backward: dx[n] (+)= ddense[dense_row[n]]; ghost / padding nodes (dense_row == ghost_row) get nothing
+__global__ __launch_bounds__(256) void dense_slots_bwd_kernel(const float* __restrict__ ddense, const int* __restrict__ dense_row,
+                                                              float* __restrict__ dx, int N, int H, int accumulate,
+                                                              int ghost_row) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int dr = dense_row[n];
+  for (int c = lane * 4; c < H; c += 256) {
+    float4 o = accumulate ? ld4(dx + (size_t)n * H + c) : f4zero();
+    if (dr != ghost_row) o = f4add(o, ld4(ddense + (size_t)dr * H + c));
+    st4(dx + (size_t)n * H + c, o);
+  }
+}
+
 // generic "no-affine LN backward" for one row: dx = rstd * (g - mean(g) - xhat * mean(g*xhat))
 __device__ __forceinline__ void rownorm_bwd_row(const float* __restrict__ g, const float* __restrict__ xh,
                                                 float rstd, float* __restrict__ dx, int H, int lane,
@@ -559,8 +587,9 @@ inline int grid_1d(size_t total, int block) {
 
 }  // namespace
 
-#define CHECK_H(H) DOSX_CHECK_ARG((H) > 0 && ((H) & 3) == 0 && ((H) >= 256 ? ((H) % 256) == 0 : (256 % (H)) == 0), \
-                                  "%s: H=%d must be a power-of-two multiple of 4 (or a multiple of 256)", __func__, (H))
+// (row kernels: H / 4 lanes per row below 256 columns - a divisor of 64 - and column blocks of 256 with a guarded tail above)
+#define CHECK_H(H) DOSX_CHECK_ARG((H) > 0 && ((H) & 3) == 0 && ((H) >= 256 || (256 % (H)) == 0), \
+                                  "%s: H=%d must be a power-of-two multiple of 4 (or any multiple of 4 from 256)", __func__, (H))
 
 extern "C" int dosx_edge_feat_sh1(const float* edge_vec, float* edge_attr, int E, float r_max, dosx_stream_t stream) {
   if (E <= 0) return 0;
@@ -664,6 +693,28 @@ extern "C" int dosx_dense_normalize_slots(const float* x, const int32_t* graph_p
   DOSX_CHECK_ARG(x && graph_ptr && kvhat && rstd_nodes && B > 0 && n_max >= 0, "dosx_dense_normalize_slots: bad args");
   hipLaunchKernelGGL(dense_normalize_slots_kernel, dim3(ceil_div(n_max * B + 1, 4)), dim3(256), 0, to_stream(stream), x,
                      graph_ptr, kvhat, rstd_nodes, B, n_max, H);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_dense_slots(const float* x, const int32_t* graph_ptr, float* dense, int B, int n_max, int H,
+                                dosx_stream_t stream) {
+  if (B * n_max <= 0) return 0;
+  CHECK_H(H);
+  DOSX_CHECK_ARG(x && graph_ptr && dense, "dosx_dense_slots: bad args");
+  hipLaunchKernelGGL(dense_slots_kernel, dim3(ceil_div(n_max * B, 4)), dim3(256), 0, to_stream(stream), x, graph_ptr, dense, B,
+                     n_max, H);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_dense_slots_bwd(const float* ddense, const int32_t* dense_row, float* dx, int N, int H, int accumulate,
+                                    int ghost_row, dosx_stream_t stream) {
+  if (N <= 0) return 0;
+  CHECK_H(H);
+  DOSX_CHECK_ARG(ddense && dense_row && dx, "dosx_dense_slots_bwd: bad args");
+  hipLaunchKernelGGL(dense_slots_bwd_kernel, dim3(ceil_div(N, 4)), dim3(256), 0, to_stream(stream), ddense, dense_row, dx, N,
+                     H, accumulate, ghost_row);
   DOSX_LAUNCH_CHECK();
   return 0;
 }

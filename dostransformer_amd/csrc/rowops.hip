@@ -149,6 +149,112 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   }
 }
 
+// ---- rows wider than 256 floats (hidden > 256; the LayerNorm of the GNN blocks spans 2 x hidden) --------------------
+// The same three backward passes for ANY row width up to 1024: one wave per row, a lane owns the float4 columns
+// lane*4 + 256 k (k < 4), a workgroup (4 waves) walks its 32 rows 8 per wave and leaves ONE partial row like the
+// register-resident kernel above: the column sums of a wave are register accumulators, combined over the 4 waves in a
+// fixed order through LDS.  A correctness path: these widths are outside every BASELINE configuration.
+//   MODE 0: dx = LN_bwd(dy)                                         partial row [dgamma(W) | dbeta(W)]
+//   MODE 1: dy[r] = ddos[r % Bq][r / Bq] * w (ln_rowdot backward)   partial row [dgamma | dbeta | dw | db]
+//   MODE 2: dy is the gradient BEHIND the PReLU that follows the LayerNorm (DOSTransformer_phonon.py:193,204
+//           `LayerNorm -> PReLU`): y = xhat*gamma+beta, dy *= (y < 0 ? alpha : 1), dalpha += dy*y where y < 0 - what the
+//           EPI_PRELU_LN_BWD epilogue of dosx_gemm does for rows of up to 512 floats.  partial row [dgamma | dbeta | pad(3) | dalpha]
+constexpr int LNW_K = 4;
+template <int MODE>
+__global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const float* __restrict__ dy, const float* __restrict__ ddos,
+                                                          const float* __restrict__ xhat, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ w, const float* __restrict__ alpha,
+                                                          float* __restrict__ dx, float* __restrict__ partials, int M, int W,
+                                                          int S, int Bq) {
+  extern __shared__ __align__(16) float sm[];   // [4 waves][NV*W] + [4]
+  constexpr int NV = MODE == 1 ? 3 : 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pld = MODE == 1 ? 3 * W + 1 : (MODE == 2 ? 2 * W + 4 : 2 * W);
+  const float invW = 1.f / (float)W;
+  const float al = MODE == 2 ? *alpha : 0.f;
+  float4 g[LNW_K], bt[LNW_K], ww[LNW_K], pg[LNW_K], pb[LNW_K], pw[LNW_K];
+#pragma unroll
+  for (int k = 0; k < LNW_K; ++k) {
+    const int c = lane * 4 + 256 * k, cc = c < W ? c : 0;
+    g[k] = ld4(gamma + cc);
+    bt[k] = MODE != 0 ? ld4(beta + cc) : f4zero();
+    ww[k] = MODE == 1 ? ld4(w + cc) : f4zero();
+    pg[k] = f4zero(); pb[k] = f4zero(); pw[k] = f4zero();
+  }
+  float psc = 0.f;                              // db (MODE 1) / dalpha (MODE 2)
+  for (int i = 0; i < 8; ++i) {
+    const int r = blockIdx.x * 32 + wave * 8 + i;
+    if (r >= M) break;                          // (wave-uniform)
+    const float rs = rstd[r];
+    float dyr = 0.f;
+    if (MODE == 1) {
+      dyr = ddos[(size_t)(r % Bq) * S + (r / Bq)];
+      if (lane == 0) psc += dyr;
+    }
+    float4 xh[LNW_K], d[LNW_K];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < LNW_K; ++k) {
+      const int c = lane * 4 + 256 * k;
+      xh[k] = f4zero(); d[k] = f4zero();
+      if (c >= W) continue;
+      xh[k] = ld4(xhat + (size_t)r * W + c);
+      if (MODE == 1) d[k] = make_float4(dyr * ww[k].x, dyr * ww[k].y, dyr * ww[k].z, dyr * ww[k].w);
+      else d[k] = ld4(dy + (size_t)r * W + c);
+      const float4 h = xh[k];
+      if (MODE == 2) {
+        const float y0 = h.x * g[k].x + bt[k].x, y1 = h.y * g[k].y + bt[k].y, y2 = h.z * g[k].z + bt[k].z,
+                    y3 = h.w * g[k].w + bt[k].w;
+        if (y0 < 0.f) { psc += d[k].x * y0; d[k].x *= al; }
+        if (y1 < 0.f) { psc += d[k].y * y1; d[k].y *= al; }
+        if (y2 < 0.f) { psc += d[k].z * y2; d[k].z *= al; }
+        if (y3 < 0.f) { psc += d[k].w * y3; d[k].w *= al; }
+      }
+      const float4 dd = d[k];
+      if (MODE == 1) {
+        pw[k].x += dyr * (h.x * g[k].x + bt[k].x); pw[k].y += dyr * (h.y * g[k].y + bt[k].y);
+        pw[k].z += dyr * (h.z * g[k].z + bt[k].z); pw[k].w += dyr * (h.w * g[k].w + bt[k].w);
+      }
+      pg[k].x += dd.x * h.x; pg[k].y += dd.y * h.y; pg[k].z += dd.z * h.z; pg[k].w += dd.w * h.w;
+      pb[k] = f4add(pb[k], dd);
+      const float4 dh = make_float4(dd.x * g[k].x, dd.y * g[k].y, dd.z * g[k].z, dd.w * g[k].w);
+      s1 += (dh.x + dh.y) + (dh.z + dh.w);
+      s2 += (dh.x * h.x + dh.y * h.y) + (dh.z * h.z + dh.w * h.w);
+    }
+    s1 = wave_sum(s1) * invW;
+    s2 = wave_sum(s2) * invW;
+#pragma unroll
+    for (int k = 0; k < LNW_K; ++k) {
+      const int c = lane * 4 + 256 * k;
+      if (c >= W) continue;
+      const float4 dd = d[k], h = xh[k];
+      st4(dx + (size_t)r * W + c,
+          make_float4(rs * (dd.x * g[k].x - s1 - h.x * s2), rs * (dd.y * g[k].y - s1 - h.y * s2),
+                      rs * (dd.z * g[k].z - s1 - h.z * s2), rs * (dd.w * g[k].w - s1 - h.w * s2)));
+    }
+  }
+  float* my = sm + (size_t)wave * (NV * W);
+#pragma unroll
+  for (int k = 0; k < LNW_K; ++k) {
+    const int c = lane * 4 + 256 * k;
+    if (c >= W) continue;
+    st4(my + c, pg[k]);
+    st4(my + W + c, pb[k]);
+    if (MODE == 1) st4(my + 2 * W + c, pw[k]);
+  }
+  if (MODE != 0) {
+    const float t = wave_sum(psc);
+    if (lane == 0) sm[4 * NV * W + wave] = t;
+  }
+  __syncthreads();
+  float* prow = partials + (size_t)blockIdx.x * pld;
+  for (int c = threadIdx.x; c < NV * W; c += 256)
+    prow[c] = ((sm[c] + sm[NV * W + c]) + sm[2 * NV * W + c]) + sm[3 * NV * W + c];
+  if (MODE != 0 && threadIdx.x == 0)
+    prow[pld - 1] = ((sm[4 * NV * W] + sm[4 * NV * W + 1]) + sm[4 * NV * W + 2]) + sm[4 * NV * W + 3];
+}
+
 // y[r] = (LN(x[r])*gamma+beta) . w + b   ->  dos[(r % Bq)*S + r / Bq]
 __global__ __launch_bounds__(256) void ln_rowdot_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ w,
@@ -454,7 +560,13 @@ extern "C" int dosx_layernorm_bwd(const float* dy, const float* xhat, const floa
   if (M <= 0) return 0;
   CHECK_H4(H);
   DOSX_CHECK_ARG(dy && xhat && rstd && gamma && dx && partials, "dosx_layernorm_bwd: bad args");
-  DOSX_CHECK_ARG(H <= 256, "dosx_layernorm_bwd: H=%d > 256", H);
+  if (H > 256) {                     // wide rows (hidden > 256): the one-wave-per-row kernel
+    DOSX_CHECK_ARG(H <= 256 * LNW_K, "dosx_layernorm_bwd: H=%d > %d", H, 256 * LNW_K);
+    hipLaunchKernelGGL((ln_bwd_wide_kernel<0>), dim3(ceil_div(M, 32)), dim3(256), (4 * (size_t)(2 * H) + 4) * sizeof(float),
+                       to_stream(stream), dy, nullptr, xhat, rstd, gamma, nullptr, nullptr, nullptr, dx, partials, M, H, 0, 1);
+    DOSX_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t smem = (16 * (size_t)(2 * H) + 16) * sizeof(float);
   hipLaunchKernelGGL((ln_bwd_kernel<false>), dim3(ceil_div(M, 32)), dim3(256), smem, to_stream(stream), dy, nullptr, xhat,
                      rstd, gamma, nullptr, nullptr, dx, partials, M, H, 0, 1);
@@ -480,10 +592,29 @@ extern "C" int dosx_ln_rowdot_bwd(const float* ddos, const float* xhat, const fl
   if (M <= 0) return 0;
   CHECK_H4(H);
   DOSX_CHECK_ARG(ddos && xhat && rstd && gamma && beta && w && dx && partials, "dosx_ln_rowdot_bwd: bad args");
-  DOSX_CHECK_ARG(H <= 256, "dosx_ln_rowdot_bwd: H=%d > 256", H);
+  if (H > 256) {
+    DOSX_CHECK_ARG(H <= 256 * LNW_K, "dosx_ln_rowdot_bwd: H=%d > %d", H, 256 * LNW_K);
+    hipLaunchKernelGGL((ln_bwd_wide_kernel<1>), dim3(ceil_div(M, 32)), dim3(256), (4 * (size_t)(3 * H) + 4) * sizeof(float),
+                       to_stream(stream), nullptr, ddos, xhat, rstd, gamma, beta, w, nullptr, dx, partials, M, H, S, Bq);
+    DOSX_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t smem = (16 * (size_t)(3 * H) + 16) * sizeof(float);
   hipLaunchKernelGGL((ln_bwd_kernel<true>), dim3(ceil_div(M, 32)), dim3(256), smem, to_stream(stream), nullptr, ddos, xhat,
                      rstd, gamma, beta, w, dx, partials, M, H, S, Bq);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_ln_prelu_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma,
+                                 const float* beta, const float* alpha, float* dz, float* partials, int M, int W,
+                                 dosx_stream_t stream) {
+  if (M <= 0) return 0;
+  CHECK_H4(W);
+  DOSX_CHECK_ARG(dy && xhat && rstd && gamma && beta && alpha && dz && partials, "dosx_ln_prelu_bwd: bad args");
+  DOSX_CHECK_ARG(W <= 256 * LNW_K, "dosx_ln_prelu_bwd: row width %d > %d", W, 256 * LNW_K);
+  hipLaunchKernelGGL((ln_bwd_wide_kernel<2>), dim3(ceil_div(M, 32)), dim3(256), (4 * (size_t)(2 * W) + 4) * sizeof(float),
+                     to_stream(stream), dy, nullptr, xhat, rstd, gamma, beta, nullptr, alpha, dz, partials, M, W, 0, 1);
   DOSX_LAUNCH_CHECK();
   return 0;
 }

@@ -124,6 +124,11 @@ def mlp_prelu_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: G
 # ------------------------------------------------------------------------------------------------
 # Edge / Node MLP: Linear -> LayerNorm -> PReLU -> Linear     (DOSTransformer_phonon.py:193,204)
 # ------------------------------------------------------------------------------------------------
+def _wide_ln(H: int) -> bool:
+    """2H-wide LayerNorm rows beyond dosx_gemm's full-row epilogues (N <= 512): the unfused row-kernel path."""
+    return 2 * H > 512
+
+
 def _mlp_ln_fused(a: SegList, M: int, H: int) -> bool:
     return a.plain is not None and len(a.plain) <= 2 and ops.mlp_ln_supported(M, a.K, 2 * H, H)
 
@@ -142,7 +147,18 @@ def mlp_ln_fwd(P: Params, key: str, a: SegList, M: int, H: int, res: Optional[to
                        P[key + ".1.weight"], P[key + ".1.bias"], P[key + ".2.weight"], P[key + ".3.weight"],
                        P[key + ".3.bias"], res, xhat, rstd, y)
         return y, (a, xhat, rstd, M, H)
-    ops.gemm(M, 2 * H, a.segs, P[key + ".0.weight"], xhat, bias=P[key + ".0.bias"], epi=EPI_LN, aux_out=rstd)
+    if _wide_ln(H):
+        # hidden > 256: the 2H-wide LayerNorm row no longer fits the one-tile row epilogue of dosx_gemm - plain GEMM, then
+        # the parameter-free normalisation as a row kernel (the affine + PReLU stay in the second GEMM's prologue)
+        assert segsum is None
+        if 2 * H > 1024:
+            from ._lib import DosxError
+            raise DosxError(f"hidden <= 512: the LayerNorm prologue of dosx_gemm holds rows of up to 1024 floats, 2 * hidden = {2 * H}")
+        z = _empty(dev, M, 2 * H)
+        ops.gemm(M, 2 * H, a.segs, P[key + ".0.weight"], z, bias=P[key + ".0.bias"])
+        ops.rownorm(z, xhat, rstd, M, 2 * H)
+    else:
+        ops.gemm(M, 2 * H, a.segs, P[key + ".0.weight"], xhat, bias=P[key + ".0.bias"], epi=EPI_LN, aux_out=rstd)
     if segsum is not None:
         tile, rowptr, scale, agg, e_in, e_out = segsum
         ops.gemm(M, H, [seg(xhat)], P[key + ".3.weight"], e_out, pro=PRO_LN_PRELU, pro_gamma=P[key + ".1.weight"],
@@ -165,13 +181,20 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
     _wgrad_linear(sink, G, key + ".3.weight", key + ".3.bias", M, H, seg(dy), [seg(xhat)], keep=(dy,), pro=PRO_LN_PRELU,
                   pro_gamma=gam, pro_beta=bet, pro_alpha=alpha)
     fused = res is None and _mlp_ln_fused(a, M, H) and dy.stride(1) == 1
-    rows = ops.mlp_ln_bwd_partial_rows(M) if fused else ops.gemm_partial_rows(M, 2 * H, EPI_PRELU_LN_BWD)
+    wide = _wide_ln(H)
+    rows = ops.mlp_ln_bwd_partial_rows(M) if fused else (ops.ln_prelu_bwd_partial_rows(M) if wide else
+                                                         ops.gemm_partial_rows(M, 2 * H, EPI_PRELU_LN_BWD))
     pld = 4 * H + 4          # [dgamma(2H) | dbeta(2H) | pad(3) | dalpha]; multiple of 4 -> vector reduce
     part = sink.scratch(rows, pld)
     dz = _empty(dev, M, 2 * H)
     dcat = _empty(dev, M, a.K)
     if fused:
         ops.mlp_ln_bwd(M, dy, xhat, rstd, P[key + ".0.weight"], P[key + ".3.weight"], gam, bet, alpha, dz, dcat, part)
+    elif wide:          # plain dgrad GEMM, then PReLU + LayerNorm backward of the 2H-wide rows as a row kernel
+        dact = _empty(dev, M, 2 * H)
+        ops.gemm(M, 2 * H, [seg(dy)], P[key + ".3.weight"], dact, w_layout=1)
+        ops.ln_prelu_bwd(dact, xhat, rstd, gam, bet, alpha, dz, part, M, 2 * H)
+        sink._keep.append(dact)
     else:
         ops.gemm(M, 2 * H, [seg(dy)], P[key + ".3.weight"], dz, w_layout=1, epi=EPI_PRELU_LN_BWD, aux=xhat,
                  aux_stats=rstd, epi_gamma=gam, epi_beta=bet, epi_alpha=alpha, partials=part, partial_ld=pld)
@@ -807,6 +830,8 @@ def dostransformer_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta, drop=None):
     drop: None (eval mode / attn_drop 0) or (p, seed_dev): attention dropout of the three encoders."""
     dr = (lambda base: None) if drop is None else (lambda base: (drop[0], drop[1], base))
     H, S, T, B, N = cfg.H, cfg.S, cfg.T, m.num_graphs, m.num_nodes
+    if H > ops.ATTN_MAX_H:
+        return _dostransformer_fwd_wide(P, cfg, g, m, dr)
     nmax = m.n_max
     dev = P["embeddings.weight"].device
     xL, u, ctrunk = gnn_trunk_fwd(P, cfg, g, m)
@@ -867,6 +892,8 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
                        dx_ext: Optional[torch.Tensor], sink: GradSink, mid_hook=None) -> None:
     """Backward; ddos [2B,S] (rows [0,B): d dos_global, [B,2B): d dos_system); dx_ext: optional
     gradient w.r.t. the returned node embeddings.  Writes every live parameter gradient into G."""
+    if ctx[0] == "wide":
+        return _dostransformer_bwd_wide(P, G, cfg, m, ctx, ddos, dx_ext, sink, mid_hook)
     (ctrunk, kvhat, rstd_n, c1, dec_segs, sysidx, prow, dosin, a_g, a_s, kvs, rstd_s, c2, c3, xhat_f, rstd_f, xL) = ctx
     H, S, B, N = cfg.H, cfg.S, m.num_graphs, m.num_nodes
     nmax = m.n_max
@@ -948,6 +975,116 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
     ops.dense_normalize_pool_bwd(dkv, kvhat, rstd_n, m.dense_row, dcat.data_ptr() + 4 * (Kd - H), Kd, m.node_graph, B, dxL, N, H,
                                  False, ghost_row=nmax * B)
     du_seg = decoder_bwd(P, G, cfg, m, dec_segs, dgraph, None, sink, dcat=dcat)
+    if dx_ext is not None:
+        dxL.add_(dx_ext)
+    gnn_trunk_bwd(P, G, cfg, m, ctrunk, dxL, du_seg, sink)
+    sink.flush()
+
+
+# ---- hidden > 256 (`utils.py:25-43` takes any --hidden) --------------------------------------------------------------------
+# The MFMA attention kernels, the fused feed-forward / NodeModel kernels and the one-tile row epilogues stop at 256-wide
+# rows.  Wider models run the SAME math through the unfused building blocks: the K != V encoder path (layer_norms[0] as
+# three LayerNorm launches, scores / softmax / P.V from csrc/attention_kv.hip, the feed-forward half as two GEMMs) on the RAW
+# dense keys (dosx_dense_slots = to_dense_batch alone), plain GEMMs + row kernels for the 2H-wide LayerNorms of the GNN
+# blocks (mlp_ln_fwd / _bwd above).  One stream, no launch-saving tricks: a correctness path for rare shapes, pinned against
+# the oracle like every other path (tests/test_gpu_round4.py).  Limit: hidden <= 512 (LayerNorm prologues of dosx_gemm).
+def _sum_rows(dev, terms, rows, H, keep):
+    """sum of equally shaped [rows, H] tensors (ops.mask_residual: out = res + a)"""
+    acc = terms[0]
+    for t in terms[1:]:
+        out = _empty(dev, rows, H)
+        ops.mask_residual(t, None, acc, out, None, rows, H)
+        keep.extend([t, acc])
+        acc = out
+    return acc
+
+
+def _dostransformer_fwd_wide(P: Params, cfg: ModelCfg, g, m: GraphMeta, dr):
+    H, S, T, B, N = cfg.H, cfg.S, cfg.T, m.num_graphs, m.num_nodes
+    nmax = m.n_max
+    dev = P["embeddings.weight"].device
+    xL, u, ctrunk = gnn_trunk_fwd(P, cfg, g, m)
+    dense = _empty(dev, nmax * B, H)
+    ops.dense_slots(xL, m.graph_ptr, dense, B, nmax, H)
+    graph, dec_segs = decoder_fwd(P, cfg, m, xL, u)
+    sysidx = _i32(g.system)
+    hp = H // 2
+    prow = _empty(dev, B, hp)
+    ops.embed_rows(P[cfg.prompt_key], sysidx, prow, B, hp)
+    # the energy embeddings expanded over the batch (`embeddings.weight.unsqueeze(1).expand(S, B, H)`): row (s, b) = row s.
+    # The index is a constant of the (S, B) shape: built once by torch, also valid when the program is replayed.
+    sidx = torch.arange(S, device=dev, dtype=torch.int32).repeat_interleave(B).contiguous()
+    x0 = _empty(dev, S * B, H)
+    ops.embed_rows(P["embeddings.weight"], sidx, x0, S * B, H)
+    E1, c1 = encoder_kv_fwd(P, "transformer", x0, dense, dense, S, B, nmax, B, H, T, drop=dr(0))
+    dosin = _empty(dev, S * 2 * B, H)
+    modB = rowmap(d=B, m=0, c=1)
+    a_g = SegList([seg(E1), seg(graph, rmap=modB)], [E1, graph])
+    a_s = SegList([seg(E1), seg(graph, rmap=modB), seg(prow, rmap=modB)], [E1, graph, prow])
+    ops.gemm(S * B, H, a_g.segs, P["fc.weight"], dosin, bias=P["fc.bias"], act=ACT_LEAKY, act_slope=0.01,
+             out_map=rowmap(d=B, m=2 * B, c=1, off=0))
+    ops.gemm(S * B, H, a_s.segs, P["fc_prompt.weight"], dosin, bias=P["fc_prompt.bias"], act=ACT_LEAKY, act_slope=0.01,
+             out_map=rowmap(d=B, m=2 * B, c=1, off=B))
+    hs, c2 = encoder_kv_fwd(P, "transformer_self", dosin, dosin, dosin, S, 2 * B, S, 2 * B, H, T, drop=dr(64))
+    hsrc, c3 = encoder_kv_fwd(P, "transformer_source", hs, dense, dense, S, 2 * B, nmax, B, H, T, final_ln=False, drop=dr(128))
+    xhat_f, rstd_f, dos = _empty(dev, S * 2 * B, H), _empty(dev, S * 2 * B), _empty(dev, 2 * B, S)
+    ops.ln_rowdot(hsrc, P["transformer_source.layer_norm.weight"], P["transformer_source.layer_norm.bias"],
+                  P["out_layer.weight"], P["out_layer.bias"], xhat_f, rstd_f, dos, S, 2 * B, H)
+    ctx = ("wide", ctrunk, c1, dec_segs, sysidx, sidx, prow, dosin, a_g, a_s, c2, c3, xhat_f, rstd_f, xL, x0, dense, hsrc)
+    return dos, xL, ctx
+
+
+def _dostransformer_bwd_wide(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, ddos: torch.Tensor,
+                             dx_ext: Optional[torch.Tensor], sink: GradSink, mid_hook=None) -> None:
+    (_, ctrunk, c1, dec_segs, sysidx, sidx, prow, dosin, a_g, a_s, c2, c3, xhat_f, rstd_f, xL, x0, dense, hsrc) = ctx
+    H, S, B, N = cfg.H, cfg.S, m.num_graphs, m.num_nodes
+    nmax = m.n_max
+    dev = ddos.device
+    rows2 = S * 2 * B
+    r32 = _rows32(rows2)
+    keep = sink._keep
+    pld = 3 * H + 1
+    part = sink.scratch(r32, pld)
+    dx = _empty(dev, rows2, H)
+    ops.ln_rowdot_bwd(ddos, xhat_f, rstd_f, P["transformer_source.layer_norm.weight"], P["transformer_source.layer_norm.bias"],
+                      P["out_layer.weight"], dx, part, S, 2 * B, H)
+    sink.add(part, 0, G["transformer_source.layer_norm.weight"], r32, pld, H)
+    sink.add(part, H, G["transformer_source.layer_norm.bias"], r32, pld, H)
+    sink.add(part, 2 * H, G["out_layer.weight"], r32, pld, H)
+    sink.add(part, 3 * H, G["out_layer.bias"], r32, pld, 1)
+    dhs, dk3, dv3 = encoder_kv_bwd(P, G, "transformer_source", c3, dx, sink)
+    ddosin, dk2, dv2 = encoder_kv_bwd(P, G, "transformer_self", c2, dhs, sink)
+    dsum = _sum_rows(dev, [ddosin, dk2, dv2], rows2, H, keep)        # dosin is query, key and value of the self encoder
+    dpre = _empty(dev, rows2, H)
+    ops.act_bwd(dsum, dosin, 0.01, dpre)                             # F.leaky_relu behind fc / fc_prompt
+    keep.extend([dx, dhs, dsum])
+    map0, map1 = rowmap(d=B, m=2 * B, c=1, off=0), rowmap(d=B, m=2 * B, c=1, off=B)
+    _wgrad_linear(sink, G, "fc.weight", "fc.bias", S * B, H, seg(dpre, rmap=map0), a_g.segs, keep=(dpre,))
+    _wgrad_linear(sink, G, "fc_prompt.weight", "fc_prompt.bias", S * B, H, seg(dpre, rmap=map1), a_s.segs, keep=(dpre,))
+    Wfc, Wfp = P["fc.weight"], P["fc_prompt.weight"]
+    dE1 = _empty(dev, S * B, H)
+    ops.gemm(S * B, H, [seg(dpre, rmap=map0)], Wfc[:, :H], dE1, w_layout=1)
+    ops.gemm(S * B, H, [seg(dpre, rmap=map1)], Wfp[:, :H], dE1, w_layout=1, res=dE1)
+    R = _empty(dev, 2 * B, H)                                        # graph / prompt inputs are constant over the energy axis
+    dgraph = _empty(dev, B, H)
+    hp = H // 2
+    dprow = _empty(dev, B, hp)
+    ops.reduce_rows(dpre.data_ptr(), H, R.data_ptr(), H, 2 * B, S, 1, 2 * B, H)
+    ops.gemm(B, H, [seg(R[:B])], Wfc[:, H:2 * H], dgraph, w_layout=1)
+    ops.gemm(B, H, [seg(R[B:])], Wfp[:, H:2 * H], dgraph, w_layout=1, res=dgraph)
+    ops.gemm(B, hp, [seg(R[B:])], Wfp[:, 2 * H:], dprow, w_layout=1)
+    ops.embed_rows_bwd(dprow.data_ptr(), hp, sysidx, G[cfg.prompt_key], B, G[cfg.prompt_key].shape[0], hp)
+    keep.extend([R, dprow])
+    dX1, dk1, dv1 = encoder_kv_bwd(P, G, "transformer", c1, dE1, sink)
+    ops.reduce_rows(dX1.data_ptr(), H, G["embeddings.weight"].data_ptr(), H, S, B, B, 1, H)       # sum over the batch
+    keep.extend([dX1, dE1])
+    if mid_hook is not None:
+        mid_hook(sink)
+    ddense = _sum_rows(dev, [dk1, dv1, dk3, dv3], nmax * B, H, keep)
+    dxL = _empty(dev, N, H)
+    ops.dense_slots_bwd(ddense, m.dense_row, dxL, N, H, False, ghost_row=nmax * B)
+    keep.append(ddense)
+    du_seg = decoder_bwd(P, G, cfg, m, dec_segs, dgraph, dxL, sink)
     if dx_ext is not None:
         dxL.add_(dx_ext)
     gnn_trunk_bwd(P, G, cfg, m, ctrunk, dxL, du_seg, sink)

@@ -855,6 +855,28 @@ def dense_normalize_pool_bwd(dkvhat, kvhat, rstd_nodes, dense_row, dpool_ptr, ld
           w=lambda: ("dense_normalize_pool_bwd", "dense_normalize_bwd_kernel", "hbm", 4.0 * N * H * 4))
 
 
+def dense_slots(x, graph_ptr, dense, B, n_max, H):
+    """dense [n_max*B, H] = to_dense_batch(x) (zero rows for padded slots), no normalisation (include/dosx.h)."""
+    _call("dosx_dense_slots", _p(x), _p(graph_ptr), _p(dense), B, n_max, H, _stream(),
+          w=lambda: ("dense_slots", "dense_slots_kernel", "hbm", 4.0 * H * (x.shape[0] + n_max * B)))
+
+
+def dense_slots_bwd(ddense, dense_row, dx, N, H, accumulate, ghost_row=-1):
+    _call("dosx_dense_slots_bwd", _p(ddense), _p(dense_row), _p(dx), N, H, int(accumulate), int(ghost_row), _stream(),
+          w=lambda: ("dense_slots_bwd", "dense_slots_bwd_kernel", "hbm", 4.0 * N * H * (3 if accumulate else 2)))
+
+
+def ln_prelu_bwd_partial_rows(M: int) -> int:
+    return (int(M) + 31) // 32
+
+
+def ln_prelu_bwd(dy, xhat, rstd, gamma, beta, alpha, dz, partials, M, W):
+    """dz = LayerNorm-PReLU backward of dy on rows of W <= 1024 floats + [dgamma | dbeta | pad | dalpha] partial rows
+    (include/dosx.h: dosx_ln_prelu_bwd)."""
+    _call("dosx_ln_prelu_bwd", _p(dy), _p(xhat), _p(rstd), _p(gamma), _p(beta), _p(alpha), _p(dz), _p(partials), M, W, _stream(),
+          w=lambda: ("ln_prelu_bwd", "ln_bwd_wide_kernel", "hbm", 12.0 * M * W))
+
+
 def rownorm(x, xhat, rstd, M, H):
     _call("dosx_rownorm", _p(x), _p(xhat), _p(rstd), M, H, _stream(),
           w=lambda: ("rownorm", "rownorm_kernel", "hbm", 8.0 * M * H))

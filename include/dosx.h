@@ -260,6 +260,14 @@ int dosx_dense_normalize_pool_bwd(const float* dkvhat, const float* kvhat, const
                                   int num_graphs, float* dx, int N, int H, int accumulate, int ghost_row,
                                   dosx_stream_t stream);
 
+/* to_dense_batch alone (DOSTransformer_phonon.py:86-87; torch_geometric.utils.to_dense_batch with the mask dropped): dense
+ * [n_max*B, H], slot (pos, b) at row pos*B + b = node graph_ptr[b] + pos, or zeros.  The keys of the UNFUSED attention
+ * path (hidden > 256), which applies layer_norms[0] to them itself; and its backward: dx[n] (+)= ddense[dense_row[n]],
+ * nothing for nodes whose dense_row is ghost_row (padding nodes). */
+int dosx_dense_slots(const float* x, const int32_t* graph_ptr, float* dense, int B, int n_max, int H, dosx_stream_t stream);
+int dosx_dense_slots_bwd(const float* ddense, const int32_t* dense_row, float* dx, int N, int H, int accumulate,
+                         int ghost_row, dosx_stream_t stream);
+
 /* Row LayerNorm without affine (key/value side of self attention) and with affine. */
 int dosx_rownorm(const float* x, float* xhat, float* rstd, int M, int H, dosx_stream_t stream);
 int dosx_rownorm_bwd(const float* dxhat, const float* xhat, const float* rstd, float* dx, int M, int H,
@@ -277,7 +285,13 @@ int dosx_rownorm_bwd_act(const float* dxhat, const float* xhat, const float* rst
 /* y = LN(x)*gamma+beta (layers/transformer.py:76-77); saves xhat, rstd. */
 int dosx_layernorm(const float* x, const float* gamma, const float* beta, float* y, float* xhat, float* rstd,
                    int M, int H, dosx_stream_t stream);
-/* dx = LNbwd(dy); partials: ceil(M/32) rows of [dgamma(H) | dbeta(H)] */
+/* Backward of `LayerNorm -> PReLU` on rows of W <= 1024 floats (the Edge / Node MLPs, DOSTransformer_phonon.py:193,204, when
+ * 2 * hidden > 512 - narrower rows run this in the EPI_PRELU_LN_BWD epilogue of dosx_gemm): dy [M,W] is the gradient behind
+ * the PReLU, xhat / rstd what the forward saved; dz [M,W] = gradient in front of the LayerNorm; partials: ceil(M/32) rows
+ * of [dgamma(W) | dbeta(W) | pad(3) | dalpha]  (row stride 2W + 4). */
+int dosx_ln_prelu_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, const float* beta,
+                      const float* alpha, float* dz, float* partials, int M, int W, dosx_stream_t stream);
+/* dx = LNbwd(dy); partials: ceil(M/32) rows of [dgamma(H) | dbeta(H)]   (H <= 1024) */
 int dosx_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dx,
                        float* partials, int M, int H, dosx_stream_t stream);
 

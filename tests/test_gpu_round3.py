@@ -347,10 +347,11 @@ def test_models_with_overfull_nodes_match_the_oracle(kind):
 
 
 def test_shape_limits_are_explicit_errors():
-    """The two shape limits of the fused path fail LOUDLY, with the limit in the message, and leave the
-    library usable: hidden > 256 (one-tile row epilogues of the GNN kernels, one float4 per lane in the row kernels).  The
-    number of keys has no limit: more than 320 (the LDS-resident score row of the MFMA kernels) take the general kernels of
-    csrc/attention_general.hip behind the same descriptor (tests/test_gpu_ops.py::test_attention_fwd_bwd)."""
+    """The shape limits fail LOUDLY, with the limit in the message, and leave the library usable: the MFMA
+    attention kernels stop at 256-wide rows (wider models take the unfused path, round 4: tests/test_gpu_round4.py), and
+    hidden > 512 exceeds the LayerNorm prologue of dosx_gemm.  The number of keys has no limit: more than 320 (the
+    LDS-resident score row of the MFMA kernels) take the general kernels of csrc/attention_general.hip behind the same
+    descriptor (tests/test_gpu_ops.py::test_attention_fwd_bwd)."""
     from dostransformer_amd._lib import DosxError, Attn
     o = ops()
     H, Sq, Bq = 32, 51, 2
@@ -371,9 +372,9 @@ def test_shape_limits_are_explicit_errors():
     from dostransformer_amd import synth
     from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
     torch.manual_seed(0)
-    model = DOSTransformer_phonon(1, 1, 118, 4, 512, DEV, 0.0).to(DEV)
+    model = DOSTransformer_phonon(1, 1, 118, 4, 640, DEV, 0.0).to(DEV)
     g = synth.phonon_batch(2, seed=1, dtype=torch.float32).to(DEV)
-    with pytest.raises(DosxError, match="hidden <= 256"):
+    with pytest.raises(DosxError, match="hidden <= 512"):
         model(g)
     small = DOSTransformer_phonon(1, 1, 118, 4, 32, DEV, 0.0).to(DEV)
     assert bool(torch.isfinite(small(g)[0]).all())

@@ -351,3 +351,181 @@ def test_edos_example_driver_end_to_end(tmp_path):
     with torch.no_grad():
         a = fresh(g)[2]
     assert bool(torch.isfinite(a).all())
+
+
+# ---- hidden > 256 (`utils.py:25-43` takes any --hidden) ----------------------------------------------------
+
+@pytest.mark.parametrize("M,W", [(100, 768), (33, 1024), (5, 260), (70, 512)])
+def test_wide_row_kernels_match_float64_autograd(M, W):
+    """The one-wave-per-row backward kernels for rows of up to 1024 floats: LayerNorm -> PReLU backward (dosx_ln_prelu_bwd),
+    LayerNorm backward (dosx_layernorm_bwd beyond 256) and the LayerNorm + H -> 1 output layer backward (dosx_ln_rowdot_bwd
+    beyond 256), against float64 autograd - dx and the column sums of the partial rows."""
+    o = ops()
+    z = rnd(M, W, seed=1).double().requires_grad_(True)
+    gam = rnd(W, seed=2).double().requires_grad_(True)
+    bet = (0.3 * rnd(W, seed=3)).double().requires_grad_(True)
+    alpha = torch.tensor([0.25], dtype=torch.float64, device=DEV, requires_grad=True)
+    dy = rnd(M, W, seed=4)
+    mean, var = z.mean(1, keepdim=True), z.var(1, unbiased=False, keepdim=True)
+    rstd64 = (var + 1e-5).rsqrt()
+    xhat64 = (z - mean) * rstd64
+    ln = xhat64 * gam + bet
+    act = torch.where(ln >= 0, ln, alpha * ln)
+    act.backward(dy.double())
+    xhat, rstd = xhat64.detach().float().contiguous(), rstd64.detach().float().reshape(-1).contiguous()
+    rows = o.ln_prelu_bwd_partial_rows(M)
+    part = torch.full((rows, 2 * W + 4), float("nan"), device=DEV)
+    dz = torch.full((M, W), float("nan"), device=DEV)
+    o.ln_prelu_bwd(dy, xhat, rstd, gam.detach().float(), bet.detach().float(), alpha.detach().float(), dz, part, M, W)
+    torch.cuda.synchronize()
+    assert err(dz, z.grad) < TOL
+    ps = part.double().sum(0)
+    assert err(ps[:W], gam.grad) < TOL and err(ps[W:2 * W], bet.grad) < TOL
+    assert abs(float(ps[2 * W + 3]) - float(alpha.grad)) < TOL * max(1.0, abs(float(alpha.grad)))
+    # plain LayerNorm backward on the same rows
+    z.grad = gam.grad = bet.grad = None
+    ln2 = ((z - z.mean(1, keepdim=True)) * (z.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()) * gam + bet
+    ln2.backward(dy.double())
+    part2 = torch.full(((M + 31) // 32, 2 * W), float("nan"), device=DEV)
+    dx = torch.full((M, W), float("nan"), device=DEV)
+    o.layernorm_bwd(dy, xhat, rstd, gam.detach().float(), dx, part2, M, W)
+    torch.cuda.synchronize()
+    assert err(dx, z.grad) < TOL
+    assert err(part2.double().sum(0)[:W], gam.grad) < TOL and err(part2.double().sum(0)[W:], bet.grad) < TOL
+    # LayerNorm + output layer: rows are (s, bq), ddos is [Bq, S]
+    S, Bq = (M // 3, 3) if M % 3 == 0 else (M, 1)
+    if S * Bq == M:
+        z.grad = gam.grad = bet.grad = None
+        wv = rnd(W, seed=6).double().requires_grad_(True)
+        ddos = rnd(Bq, S, seed=7)
+        ln3 = ((z - z.mean(1, keepdim=True)) * (z.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()) * gam + bet
+        y = (ln3 @ wv).reshape(S, Bq).T
+        y.backward(ddos.double())
+        part3 = torch.full(((M + 31) // 32, 3 * W + 1), float("nan"), device=DEV)
+        dx3 = torch.full((M, W), float("nan"), device=DEV)
+        o.ln_rowdot_bwd(ddos, xhat, rstd, gam.detach().float(), bet.detach().float(), wv.detach().float(), dx3, part3, S, Bq, W)
+        torch.cuda.synchronize()
+        p3 = part3.double().sum(0)
+        assert err(dx3, z.grad) < TOL and err(p3[:W], gam.grad) < TOL and err(p3[W:2 * W], bet.grad) < TOL
+        assert err(p3[2 * W:3 * W], wv.grad) < TOL and abs(float(p3[3 * W]) - float(ddos.double().sum())) < 1e-4
+
+
+def test_dense_slots_is_to_dense_batch():
+    """dosx_dense_slots / _bwd = torch_geometric.utils.to_dense_batch (mask dropped) and its adjoint, on a ghost-padded batch."""
+    from dostransformer_amd import synth
+    from dostransformer_amd.batch import bucket_sizes, collate, pad_batch
+    o = ops()
+    H = 384
+    g = collate(synth.phonon_crystals(5, 3, torch.float32))
+    g = pad_batch(g, *bucket_sizes(g.meta.num_nodes, g.meta.num_edges, 16, 256)).to(DEV)
+    m = g.meta
+    N, B, nmax = m.num_nodes, m.num_graphs, m.n_max
+    x = rnd(N, H, seed=1)
+    dense = torch.full((nmax * B, H), float("nan"), device=DEV)
+    o.dense_slots(x, m.graph_ptr, dense, B, nmax, H)
+    gp = m.graph_ptr.cpu().tolist()
+    ref = torch.zeros(nmax * B, H, device=DEV)
+    for b in range(B):
+        for pos in range(gp[b + 1] - gp[b]):
+            ref[pos * B + b] = x[gp[b] + pos]
+    torch.cuda.synchronize()
+    assert torch.equal(dense, ref)
+    dd = rnd(nmax * B, H, seed=2)
+    dx = torch.full((N, H), float("nan"), device=DEV)
+    o.dense_slots_bwd(dd, m.dense_row, dx, N, H, False, ghost_row=nmax * B)
+    refdx = torch.zeros(N, H, device=DEV)
+    for b in range(B):
+        for pos in range(gp[b + 1] - gp[b]):
+            refdx[gp[b] + pos] = dd[pos * B + b]
+    torch.cuda.synchronize()
+    assert torch.equal(dx, refdx)                      # ghost nodes: zero
+
+
+@pytest.mark.parametrize("kind,H", [("phonon", 384), ("edos", 384), ("phonon", 512)])
+def test_models_with_hidden_beyond_256_match_the_oracle(kind, H):
+    """DOSTransformer_phonon / DOSTransformer with hidden 384 and 512 (the unfused path: K != V encoder building blocks on
+    the raw dense keys, row kernels for the 2H-wide LayerNorms of the GNN blocks) against the oracle: the three outputs, the
+    loss, every live gradient; dead parameters stay dead; eager and replay give the same trajectory bit for bit."""
+    from oracle import dos_oracle as O
+    from dostransformer_amd import synth
+    from dostransformer_amd.batch import collate
+    from dostransformer_amd.train import Trainer
+    torch.manual_seed(0)
+    B, L, T = 5, 2, 2
+    if kind == "phonon":
+        from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+        mk = lambda: DOSTransformer_phonon(L, T, 118, 4, H, DEV, 0.0)
+        ref_dt, fwd, cs_of = torch.float64, O.dostransformer_phonon_forward, synth.phonon_crystals
+    else:
+        from dostransformer_amd.embedder_eDOS.DOSTransformer import DOSTransformer
+        mk = lambda: DOSTransformer(L, T, 200, 41, 2, H, DEV, 0.0)
+        ref_dt, fwd, cs_of = torch.float32, O.dostransformer_forward, synth.edos_crystals
+    g_ref, g = collate(cs_of(B, 11, ref_dt)), collate(cs_of(B, 11, torch.float32))
+    model = mk()
+    params = {k: (v.detach().clone().to(ref_dt) if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    with torch.no_grad():
+        rg, rx, rs = fwd(params, g_ref, L, T)
+    tr = Trainer(model, lr=1e-3, beta=1.0)
+    loss = tr.forward_backward(g.to(DEV))
+    dg, xn, ds_ = tr.last_outputs
+    rmse = lambda a, b: float(torch.sqrt(((a.double().cpu() - b.double()) ** 2).mean()))
+    assert rmse(dg, rg) < 1e-4 and rmse(ds_, rs) < 1e-4 and rmse(xn, rx) < 1e-4 * max(1.0, float(rx.abs().max()))
+    ref_loss, grads = O.train_step(kind, params, {}, g_ref, L, T, lr=1e-3, beta=1.0)
+    assert abs(float(loss) - float(ref_loss)) < 2e-4
+    fp = model.flat_params()
+    worst = 0.0
+    for k, gr in grads.items():
+        if gr is not None:
+            assert k in fp.G, k
+            e = float((fp.G[k].cpu().double() - gr.double()).abs().max() / (gr.abs().max() + 1e-6))
+            worst = max(worst, e)
+            assert e < (3e-3 if kind == "phonon" else 2e-2), (k, e)
+        else:
+            assert k not in fp.G, k
+    print(f"hidden {H} {kind}: worst gradient error / tensor max {worst:.2e}")
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    outs = []
+    gd = g.to(DEV)
+    for replay in (False, True):
+        m2 = mk()
+        m2.load_state_dict(sd0)
+        m2 = m2.to(DEV)
+        t2 = Trainer(m2, lr=1e-3, beta=1.0, replay=replay)
+        from dostransformer_amd.batch import bucket_sizes, pad_batch
+        gp = pad_batch(collate(cs_of(B, 11, torch.float32)), *bucket_sizes(g.meta.num_nodes, g.meta.num_edges, 8, 128)).to(DEV)
+        for _ in range(3):
+            t2.step(gp)
+        torch.cuda.synchronize()
+        outs.append({k: v.detach().cpu().clone() for k, v in m2.state_dict().items()})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), ("eager vs replay", k)
+
+
+def test_graphnetwork_with_hidden_384_matches_the_oracle():
+    """The GNN-only variant (graphnetwork_phonon.py:48-72) at hidden 384: outputs and gradients against the oracle."""
+    from oracle import dos_oracle as O
+    from dostransformer_amd import synth
+    from dostransformer_amd.batch import collate
+    from dostransformer_amd.embedder_phDOS.graphnetwork_phonon import Graphnetwork_phonon
+    torch.manual_seed(0)
+    H, L, B = 384, 2, 4
+    model = Graphnetwork_phonon(L, 118, 4, H, 51, DEV)
+    params = {k: (v.detach().clone().double() if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    g64, g = collate(synth.phonon_crystals(B, 13, torch.float64)), collate(synth.phonon_crystals(B, 13, torch.float32)).to(DEV)
+    out = model(g)
+    p = {k: v.clone().requires_grad_(True) if v.is_floating_point() else v for k, v in params.items()}
+    ref = O.graphnetwork_phonon_forward(p, g64, L)
+    ref = ref[0] if isinstance(ref, tuple) else ref
+    assert float(torch.sqrt(((out.detach().cpu().double() - ref.detach()) ** 2).mean())) < 1e-4
+    w = torch.randn(ref.shape, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
+    (ref * w).sum().backward()
+    (out * w.float().to(DEV)).sum().backward()
+    for k, v in model.named_parameters():
+        rgd = p[k].grad
+        if rgd is None:
+            assert v.grad is None, k
+            continue
+        e = float((v.grad.cpu().double() - rgd).abs().max() / (rgd.abs().max() + 1e-6))
+        assert e < 3e-3, (k, e)
