@@ -357,7 +357,11 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
             lay.append((x, qs, qb, x1, probs, qstats, st1, h, mask, fm))
             x, qs, qb = x2, Bq, 1
             continue
-        ops.attention_fwd(a)
+        # <= 16 keys per crystal (the cross attention over the atoms of a crystal): the attention half runs in the prologue of
+        # the feed-forward launch (DosxFfn.att_*) - one launch per layer; same saved tensors, the backward is unchanged
+        att_fused = _FUSED_ATT_FFN and ops.ffn_att_supported(H, Nk)
+        if not att_fused:
+            ops.attention_fwd(a)
         h = _empty(dev, rows, 4 * H)
         x2 = _empty(dev, rows, H)
         if ops.ffn_supported(H):
@@ -372,9 +376,13 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
                 hg, hb, hw, hbias, hxh, hrs, hdos = head
                 fin_args = (hg, hb, hxh, hrs, hw, hbias, hdos, Sq, Bq)
                 x2 = None
-            ops.ffn_fwd(rows, H, x1, st1, P[lp + ".layer_norms.1.weight"], P[lp + ".layer_norms.1.bias"],
-                        P[lp + ".fc1.weight"], P[lp + ".fc1.bias"], P[lp + ".fc2.weight"], P[lp + ".fc2.bias"], h, x2,
-                        fin=fin_args)
+            att_args = None
+            if att_fused:
+                att_args = dict(kvhat=kvhat, gamma0=g0, beta0=b0, Nk=Nk, Bk=Bk, Bq=Bq, Sq=Sq, qs=qs, qb=qb, probs=probs,
+                                qstats=qstats, x1=x1, st1=st1, mask=mask)
+            ops.ffn_fwd(rows, H, x if att_fused else x1, None if att_fused else st1, P[lp + ".layer_norms.1.weight"],
+                        P[lp + ".layer_norms.1.bias"], P[lp + ".fc1.weight"], P[lp + ".fc1.bias"], P[lp + ".fc2.weight"],
+                        P[lp + ".fc2.bias"], h, x2, fin=fin_args, att=att_args)
         else:
             ops.gemm(rows, 4 * H, [seg(x1)], P[lp + ".fc1.weight"], h, pro=PRO_ROWLN,
                      pro_gamma=P[lp + ".layer_norms.1.weight"], pro_beta=P[lp + ".layer_norms.1.bias"], pro_stats=st1,
@@ -396,6 +404,7 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
 
 
 _FUSED_FFN_BWD = __import__("os").environ.get("DOSX_FUSED_FFN_BWD", "1") == "1"
+_FUSED_ATT_FFN = __import__("os").environ.get("DOSX_FUSED_ATT_FFN", "1") == "1"       # <= 16-key attention inside dosx_ffn_fwd
 _FUSED_DKV = __import__("os").environ.get("DOSX_FUSED_DKV", "1") == "1"
 _LATE_SELF_FLUSH = __import__("os").environ.get("DOSX_LATE_SELF_FLUSH", "0") == "1"      # (measured: no gain)          # one-launch attention backward (Nk <= 64)
 _FUSED_FIN_BWD = __import__("os").environ.get("DOSX_FUSED_FIN_BWD", "1") == "1"

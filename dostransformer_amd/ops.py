@@ -362,26 +362,41 @@ def ffn_supported(H: int) -> bool:
     return bool(_lib.load().dosx_ffn_supported(int(H)))
 
 
-def ffn_fwd(M: int, H: int, x: torch.Tensor, stats: torch.Tensor, gamma, beta, w1, b1, w2, b2, h: torch.Tensor,
-            out: torch.Tensor, fin=None) -> None:
+def ffn_att_supported(H: int, Nk: int) -> bool:
+    return bool(_lib.load().dosx_ffn_att_supported(int(H), int(Nk)))
+
+
+def ffn_fwd(M: int, H: int, x: torch.Tensor, stats: Optional[torch.Tensor], gamma, beta, w1, b1, w2, b2, h: torch.Tensor,
+            out: torch.Tensor, fin=None, att=None) -> None:
     """out = x + fc2(relu(fc1(LN1(x)))), h = relu(fc1(LN1(x))) in one launch (include/dosx.h: DosxFfn).
     ``fin = (gamma, beta, xhat, rstd)``: also apply the encoder's final LayerNorm (out = LN(...), xhat / rstd saved);
     ``fin = (gamma, beta, xhat, rstd, w, b, dos, S, Bq)``: ... and the H -> 1 output layer behind it (``out`` may be None)."""
     a = Ffn()
     a.M, a.H = int(M), int(H)
     a.x, a.ldx = x.data_ptr(), int(x.stride(0))
-    a.stats = stats.data_ptr()
+    a.stats = _p(stats)
     a.gamma, a.beta = gamma.data_ptr(), beta.data_ptr()
     a.w1, a.b1, a.w2, a.b2 = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
     a.h, a.ldh = h.data_ptr(), int(h.stride(0))
     if out is not None:
         a.out, a.ldo = out.data_ptr(), int(out.stride(0))
+    nk_att = 0
+    if att is not None:
+        # the attention half of the layer in the same launch (include/dosx.h: DosxFfn.att_*): ``x`` is then the layer input
+        # and att = dict(kvhat, gamma0, beta0, Nk, Bk, Bq, Sq, qs, qb, probs, qstats, x1, st1, mask=None)
+        a.att_kvhat, a.att_gamma0, a.att_beta0 = att["kvhat"].data_ptr(), att["gamma0"].data_ptr(), att["beta0"].data_ptr()
+        a.att_mask = _p(att.get("mask"))
+        a.att_probs, a.att_qstats = att["probs"].data_ptr(), att["qstats"].data_ptr()
+        a.att_x1, a.att_ldx1, a.att_st1 = att["x1"].data_ptr(), int(att["x1"].stride(0)), att["st1"].data_ptr()
+        a.att_Nk, a.att_Bk, a.att_Bq, a.att_Sq = int(att["Nk"]), int(att["Bk"]), int(att["Bq"]), int(att["Sq"])
+        a.att_qs, a.att_qb = int(att["qs"]), int(att["qb"])
+        nk_att = a.att_Nk
     if fin is not None:
         a.fin_gamma, a.fin_beta, a.fin_xhat, a.fin_rstd = (t.data_ptr() for t in fin[:4])
         if len(fin) > 4:          # (.., w, b, dos [Bq,S], S, Bq): the model head's H -> 1 output layer on the normalised rows
             a.fin_w, a.fin_b, a.fin_dos, a.fin_S, a.fin_Bq = fin[4].data_ptr(), fin[5].data_ptr(), fin[6].data_ptr(), int(fin[7]), int(fin[8])
     _call("dosx_ffn_fwd", C.byref(a), _stream(),
-          w=lambda: (f"ffn_fwd[H{H}]", "ffn_fwd_kernel", "mfma", 16.0 * M * H * H))
+          w=lambda: (f"ffn_fwd[H{H}{',att' if nk_att else ''}]", "ffn_fwd_kernel", "mfma", 16.0 * M * H * H + 4.0 * M * nk_att * H))
 
 
 def ffn_bwd_partial_rows(M: int) -> int:

@@ -429,8 +429,21 @@ typedef struct DosxFfn {
    * (fin_dos [Bq, S]; what dosx_ln_rowdot computes as a launch of its own); `out` may then be NULL */
   const float* fin_w; const float* fin_b; float* fin_dos;
   int32_t fin_S, fin_Bq;
+  /* optional (round 4): the ATTENTION half of the layer in front of the feed-forward half, for key sets of at most 16 rows
+   * per crystal (the prompt-guided cross attention over the atoms of a crystal, layers/transformer.py:131-138 +
+   * multihead_attention.py:68-74) - one launch per encoder layer instead of dosx_attention_fwd + dosx_ffn_fwd.  With
+   * att_kvhat != NULL:  `x` is the layer INPUT (the query rows: row r = s*att_Bq + bq at x + (s*att_qs + bq*att_qb)*ldx),
+   * `stats` is ignored, and per row   q = LN0(x)*g0+b0,  P = softmax_fp32(q . (khat_j*g0+b0) / sqrt(H)) over the att_Nk keys
+   * khat_j = att_kvhat[j*att_Bk + bq % att_Bk] (pre-normalised keys, dosx_dense_normalize_slots),  x1 = x + (P o mask) . K
+   * is what the feed-forward half then reads.  Outputs, in the formats dosx_attention_fwd writes (its backward reads them):
+   * att_probs [Bq,Sq,Nk] (un-dropped P), att_qstats [M,2] (mean, rstd of the query rows), att_x1 [M,H] (row stride
+   * att_ldx1), att_st1 [M,2] (LayerNorm-1 statistics of x1).  att_mask: NULL or the dropout multipliers [Bq,Sq,Nk]. */
+  const float* att_kvhat; const float* att_gamma0; const float* att_beta0; const float* att_mask;
+  float* att_probs; float* att_qstats; float* att_x1; float* att_st1;
+  int32_t att_Nk, att_Bk, att_Bq, att_Sq, att_qs, att_qb, att_ldx1;
 } DosxFfn;
 int dosx_ffn_supported(int H);
+int dosx_ffn_att_supported(int H, int Nk);   /* whether dosx_ffn_fwd takes the att_* fields for this shape (H, Nk <= 16) */
 int dosx_ffn_fwd(const DosxFfn* a, dosx_stream_t stream);
 
 /* Backward of the same half layer in one launch (what autograd derives from layers/transformer.py:141-148):
