@@ -33,8 +33,131 @@ namespace {
 // per wave and each barrier costs ~450 clk of ds_read round trip and skew, tools/stamp_ffn.py) is a template argument
 constexpr int FBN = 128;         // columns per chunk / per column block
 
-// HALF: the workgroup owns 16 rows and multiplies with the 16x16x4 MFMA (two 16-column tiles per wave instead of one
-// 32-column tile): twice the workgroups, half the MFMA time each, and two of them fit the LDS of one CU.
+// One query row of the fused attention prologue (ffn_fwd_kernel<.., ATT = true>), by one QUARTER wave: lane q16 owns the
+// float4 columns 4 q16 + 64 k (k < 2: H <= 128).  Writes probs / qstats / x1 / st1 of row m0 + lr and the LN1-normalised row
+// into the Xs tile.
+__device__ __forceinline__ void ffn_att_row(const DosxFfn& a, float* __restrict__ Xs, const int LDX, const int lr, const int m0,
+                                            const int lane) {
+  const int H = a.H, M = a.M;
+  const int q16 = lane & 15;
+  const float scale = rsqrtf((float)H), invH = 1.f / (float)H;
+  const int Nk = a.att_Nk, Bq = a.att_Bq, Bk = a.att_Bk, Sq = a.att_Sq;
+  float4 g0[2], b0[2], g1[2], bb1[2];
+  bool on[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int c = q16 * 4 + 64 * k, cc = c < H ? c : 0;
+    on[k] = c < H;
+    g0[k] = ld4(a.att_gamma0 + cc); b0[k] = ld4(a.att_beta0 + cc);
+    g1[k] = ld4(a.gamma + cc); bb1[k] = ld4(a.beta + cc);
+  }
+  {
+    const int r = m0 + lr, rc = min(r, M - 1);
+    const bool rv = r < M;
+    const int s = rc / Bq, bq = rc - s * Bq, bk = bq % Bk;
+    const float* xrow = a.x + ((size_t)s * a.att_qs + (size_t)bq * a.att_qb) * a.ldx;
+    float4 xr[2];
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      xr[k] = on[k] ? ld4(xrow + q16 * 4 + 64 * k) : f4zero();
+      t += (xr[k].x + xr[k].y) + (xr[k].z + xr[k].w);
+    }
+    // the crystal's key rows (pre-normalised; row j of crystal bk at (j * Bk + bk)): all requested before the first use
+    float4 kv[16][2];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float* kr = a.att_kvhat + ((size_t)(j < Nk ? j : 0) * Bk + bk) * H;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) kv[j][k] = on[k] ? ld4(kr + q16 * 4 + 64 * k) : f4zero();
+    }
+    const float mean = row16_sum(t) * invH;
+    t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (!on[k]) continue;
+      const float p0 = xr[k].x - mean, p1 = xr[k].y - mean, p2 = xr[k].z - mean, p3 = xr[k].w - mean;
+      t += (p0 * p0 + p1 * p1) + (p2 * p2 + p3 * p3);
+    }
+    const float rstd = rsqrtf(row16_sum(t) * invH + DOSX_LN_EPS);
+    float4 qg[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float4 v = xr[k];
+      float4 q = make_float4((v.x - mean) * rstd * g0[k].x + b0[k].x, (v.y - mean) * rstd * g0[k].y + b0[k].y,
+                             (v.z - mean) * rstd * g0[k].z + b0[k].z, (v.w - mean) * rstd * g0[k].w + b0[k].w);
+      q = make_float4(q.x * g0[k].x, q.y * g0[k].y, q.z * g0[k].z, q.w * g0[k].w);      // key gamma folded into Q
+      qg[k] = on[k] ? q : f4zero();
+    }
+    float sc[16], mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float d = 0.f;
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        d += (qg[k].x * kv[j][k].x + qg[k].y * kv[j][k].y) + (qg[k].z * kv[j][k].z + qg[k].w * kv[j][k].w);
+      sc[j] = row16_sum(d) * scale;
+      if (j < Nk) mx = fmaxf(mx, sc[j]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float e = j < Nk ? expf(sc[j] - mx) : 0.f;
+      sc[j] = e;
+      sum += e;
+    }
+    const float inv = 1.f / sum;
+    const size_t prow = ((size_t)bq * Sq + s) * Nk;
+    float psum = 0.f;
+    float4 o[2] = {f4zero(), f4zero()};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float pr = sc[j] * inv;                                   // 0 beyond Nk
+      const float mk = (a.att_mask && j < Nk) ? a.att_mask[prow + j] : 1.f;
+      const float pm = pr * mk;
+      psum += pm;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        o[k].x += pm * kv[j][k].x; o[k].y += pm * kv[j][k].y; o[k].z += pm * kv[j][k].z; o[k].w += pm * kv[j][k].w;
+      }
+      if (rv && q16 == j && j < Nk) a.att_probs[prow + j] = pr;       // the un-dropped P (the backward reads it)
+    }
+    if (!a.att_mask) psum = 1.f;
+    float4 x1[2];
+    t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      x1[k] = f4zero();
+      if (!on[k]) continue;
+      x1[k] = make_float4(o[k].x * g0[k].x + b0[k].x * psum + xr[k].x, o[k].y * g0[k].y + b0[k].y * psum + xr[k].y,
+                          o[k].z * g0[k].z + b0[k].z * psum + xr[k].z, o[k].w * g0[k].w + b0[k].w * psum + xr[k].w);
+      if (rv) st4(a.att_x1 + (size_t)r * a.att_ldx1 + q16 * 4 + 64 * k, x1[k]);
+      t += (x1[k].x + x1[k].y) + (x1[k].z + x1[k].w);
+    }
+    const float mean1 = row16_sum(t) * invH;
+    t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (!on[k]) continue;
+      const float p0 = x1[k].x - mean1, p1 = x1[k].y - mean1, p2 = x1[k].z - mean1, p3 = x1[k].w - mean1;
+      t += (p0 * p0 + p1 * p1) + (p2 * p2 + p3 * p3);
+    }
+    const float rstd1 = rsqrtf(row16_sum(t) * invH + DOSX_LN_EPS);
+    if (rv && q16 == 0) {
+      a.att_qstats[2 * (size_t)r] = mean; a.att_qstats[2 * (size_t)r + 1] = rstd;
+      a.att_st1[2 * (size_t)r] = mean1;   a.att_st1[2 * (size_t)r + 1] = rstd1;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (!on[k]) continue;
+      const float4 v = x1[k];
+      st4(Xs + lr * LDX + q16 * 4 + 64 * k,
+          make_float4((v.x - mean1) * rstd1 * g1[k].x + bb1[k].x, (v.y - mean1) * rstd1 * g1[k].y + bb1[k].y,
+                      (v.z - mean1) * rstd1 * g1[k].z + bb1[k].z, (v.w - mean1) * rstd1 * g1[k].w + bb1[k].w));
+    }
+  }
+}
+
 // ATT (round 4): the attention half of the layer runs in the prologue, for key sets of <= 16 rows per crystal (DosxFfn.att_*):
 // per query row - one QUARTER WAVE per row, like the row phases of attention.hip - LayerNorm-0, the <= 16 scores against
 // the crystal's pre-normalised key rows (read straight from L2: 16 x 512 B per row, the key set of a crystal is shared by
@@ -43,6 +166,8 @@ constexpr int FBN = 128;         // columns per chunk / per column block
 // feed-forward half's.  The key affine is folded out exactly as in attn_fwd_stream_kernel: (q.(khat g + b)) = (q o g).khat
 // + q.b, the second term is the same for every key of the row (padded keys included: khat = 0) and cancels in the softmax;
 // P.(khat g + b) = (P.khat) o g + b sum(P).
+// HALF: the workgroup owns 16 rows and multiplies with the 16x16x4 MFMA (two 16-column tiles per wave instead of one
+// 32-column tile): twice the workgroups, half the MFMA time each, and two of them fit the LDS of one CU.
 template <bool HALF, int KB, bool ATT>
 __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
   DOSX_SET_MAIN_PRIO();
@@ -141,126 +266,10 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
       b1r[cb][1] = HALF ? a.b1[col + 16] : 0.f;
     }
     if constexpr (ATT) {
-      constexpr int NP = R / 16;                   // passes of 16 rows over the 4 matrix waves
-      const int q16 = lane & 15;
-      const float scale = rsqrtf((float)H), invH = 1.f / (float)H;
-      const int Nk = a.att_Nk, Bq = a.att_Bq, Bk = a.att_Bk, Sq = a.att_Sq;
-      float4 g0[2], b0[2], g1[2], bb1[2];
-      bool on[2];
+      // 16 rows per pass over the 4 matrix waves.  (All 8 waves in one pass - the staging waves taking rows 16-31 while their
+      // first weight chunks are in flight - was built and spills: the 16 x 2 float4 key registers next to the staged chunks.)
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int c = q16 * 4 + 64 * k, cc = c < H ? c : 0;
-        on[k] = c < H;
-        g0[k] = ld4(a.att_gamma0 + cc); b0[k] = ld4(a.att_beta0 + cc);
-        g1[k] = ld4(a.gamma + cc); bb1[k] = ld4(a.beta + cc);
-      }
-#pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        const int lr = p * 16 + wave * 4 + (lane >> 4);
-        const int r = m0 + lr, rc = min(r, M - 1);
-        const bool rv = r < M;
-        const int s = rc / Bq, bq = rc - s * Bq, bk = bq % Bk;
-        const float* xrow = a.x + ((size_t)s * a.att_qs + (size_t)bq * a.att_qb) * a.ldx;
-        float4 xr[2];
-        float t = 0.f;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          xr[k] = on[k] ? ld4(xrow + q16 * 4 + 64 * k) : f4zero();
-          t += (xr[k].x + xr[k].y) + (xr[k].z + xr[k].w);
-        }
-        // the crystal's key rows (pre-normalised; row j of crystal bk at (j * Bk + bk)): all requested before the first use
-        float4 kv[16][2];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const float* kr = a.att_kvhat + ((size_t)(j < Nk ? j : 0) * Bk + bk) * H;
-#pragma unroll
-          for (int k = 0; k < 2; ++k) kv[j][k] = on[k] ? ld4(kr + q16 * 4 + 64 * k) : f4zero();
-        }
-        const float mean = row16_sum(t) * invH;
-        t = 0.f;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          if (!on[k]) continue;
-          const float p0 = xr[k].x - mean, p1 = xr[k].y - mean, p2 = xr[k].z - mean, p3 = xr[k].w - mean;
-          t += (p0 * p0 + p1 * p1) + (p2 * p2 + p3 * p3);
-        }
-        const float rstd = rsqrtf(row16_sum(t) * invH + DOSX_LN_EPS);
-        float4 qg[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const float4 v = xr[k];
-          float4 q = make_float4((v.x - mean) * rstd * g0[k].x + b0[k].x, (v.y - mean) * rstd * g0[k].y + b0[k].y,
-                                 (v.z - mean) * rstd * g0[k].z + b0[k].z, (v.w - mean) * rstd * g0[k].w + b0[k].w);
-          q = make_float4(q.x * g0[k].x, q.y * g0[k].y, q.z * g0[k].z, q.w * g0[k].w);      // key gamma folded into Q
-          qg[k] = on[k] ? q : f4zero();
-        }
-        float sc[16], mx = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          float d = 0.f;
-#pragma unroll
-          for (int k = 0; k < 2; ++k)
-            d += (qg[k].x * kv[j][k].x + qg[k].y * kv[j][k].y) + (qg[k].z * kv[j][k].z + qg[k].w * kv[j][k].w);
-          sc[j] = row16_sum(d) * scale;
-          if (j < Nk) mx = fmaxf(mx, sc[j]);
-        }
-        float sum = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const float e = j < Nk ? expf(sc[j] - mx) : 0.f;
-          sc[j] = e;
-          sum += e;
-        }
-        const float inv = 1.f / sum;
-        const size_t prow = ((size_t)bq * Sq + s) * Nk;
-        float psum = 0.f;
-        float4 o[2] = {f4zero(), f4zero()};
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const float pr = sc[j] * inv;                                   // 0 beyond Nk
-          const float mk = (a.att_mask && j < Nk) ? a.att_mask[prow + j] : 1.f;
-          const float pm = pr * mk;
-          psum += pm;
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            o[k].x += pm * kv[j][k].x; o[k].y += pm * kv[j][k].y; o[k].z += pm * kv[j][k].z; o[k].w += pm * kv[j][k].w;
-          }
-          if (rv && q16 == j && j < Nk) a.att_probs[prow + j] = pr;       // the un-dropped P (the backward reads it)
-        }
-        if (!a.att_mask) psum = 1.f;
-        float4 x1[2];
-        t = 0.f;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          x1[k] = f4zero();
-          if (!on[k]) continue;
-          x1[k] = make_float4(o[k].x * g0[k].x + b0[k].x * psum + xr[k].x, o[k].y * g0[k].y + b0[k].y * psum + xr[k].y,
-                              o[k].z * g0[k].z + b0[k].z * psum + xr[k].z, o[k].w * g0[k].w + b0[k].w * psum + xr[k].w);
-          if (rv) st4(a.att_x1 + (size_t)r * a.att_ldx1 + q16 * 4 + 64 * k, x1[k]);
-          t += (x1[k].x + x1[k].y) + (x1[k].z + x1[k].w);
-        }
-        const float mean1 = row16_sum(t) * invH;
-        t = 0.f;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          if (!on[k]) continue;
-          const float p0 = x1[k].x - mean1, p1 = x1[k].y - mean1, p2 = x1[k].z - mean1, p3 = x1[k].w - mean1;
-          t += (p0 * p0 + p1 * p1) + (p2 * p2 + p3 * p3);
-        }
-        const float rstd1 = rsqrtf(row16_sum(t) * invH + DOSX_LN_EPS);
-        if (rv && q16 == 0) {
-          a.att_qstats[2 * (size_t)r] = mean; a.att_qstats[2 * (size_t)r + 1] = rstd;
-          a.att_st1[2 * (size_t)r] = mean1;   a.att_st1[2 * (size_t)r + 1] = rstd1;
-        }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          if (!on[k]) continue;
-          const float4 v = x1[k];
-          st4(Xs + lr * LDX + q16 * 4 + 64 * k,
-              make_float4((v.x - mean1) * rstd1 * g1[k].x + bb1[k].x, (v.y - mean1) * rstd1 * g1[k].y + bb1[k].y,
-                          (v.z - mean1) * rstd1 * g1[k].z + bb1[k].z, (v.w - mean1) * rstd1 * g1[k].w + bb1[k].w));
-        }
-      }
+      for (int p = 0; p < R / 16; ++p) ffn_att_row(a, Xs, LDX, p * 16 + wave * 4 + (lane >> 4), m0, lane);
     } else {   // LN1(x) tile -> Xs  (row r = tid/8, 4-float groups tid%8 + 8 i)
       const int r = tid >> 3, rr = min(m0 + r, M - 1);
       const float mean = a.stats[2 * (size_t)rr], rstd = a.stats[2 * (size_t)rr + 1];

@@ -592,7 +592,7 @@ def test_encoder_layer_with_attention_inside_the_ffn_launch(Sq, Bq, Nk, Bk, H, b
             Fn._FUSED_ATT_FFN = True
     (y0, lay0, dx0, dkv0, G0), (y1, lay1, dx1, dkv1, G1) = res[False], res[True]
     rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-12))
-    assert rel(y1, y0) < 2e-6
+    assert rel(y1, y0) < 5e-6
     for t in range(T):
         for name, idx in (("x1", 3), ("probs", 4), ("qstats", 5), ("st1", 6), ("h", 7)):
             assert not torch.isnan(lay1[t][idx]).any(), (t, name)

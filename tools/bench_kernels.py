@@ -143,6 +143,35 @@ def ffn_case(name, M, H):
           f"two GEMMs {us2:6.1f} us")
 
 
+def layer_case(name, Sq, Bq, Nk, Bk, H):
+    """one cross-attention encoder layer forward: dosx_attention_fwd + dosx_ffn_fwd against the one-launch form (DosxFfn.att_*)"""
+    from dostransformer_amd._lib import Attn
+    M = Sq * Bq
+    x = torch.randn(M, H, device=DEV)
+    kv = torch.randn(Nk * Bk, H, device=DEV)
+    g0, b0, g1, b1n = (torch.randn(H, device=DEV) for _ in range(4))
+    w1, b1 = torch.randn(4 * H, H, device=DEV), torch.randn(4 * H, device=DEV)
+    w2, b2 = torch.randn(H, 4 * H, device=DEV), torch.randn(H, device=DEV)
+    h = torch.empty(M, 4 * H, device=DEV); out = torch.empty(M, H, device=DEV); x1 = torch.empty(M, H, device=DEV)
+    probs = torch.empty(Bq, Sq, Nk, device=DEV)
+    qs, st1 = torch.empty(M, 2, device=DEV), torch.empty(M, 2, device=DEV)
+    a = Attn()
+    a.Sq, a.Bq, a.Nk, a.Bk, a.H, a.q_stride_s, a.q_stride_b = Sq, Bq, Nk, Bk, H, Bq, 1
+    a.x, a.kvhat, a.gamma0, a.beta0 = x.data_ptr(), kv.data_ptr(), g0.data_ptr(), b0.data_ptr()
+    a.out, a.probs, a.qstats, a.out_stats = x1.data_ptr(), probs.data_ptr(), qs.data_ptr(), st1.data_ptr()
+
+    def two():
+        ops.attention_fwd(a)
+        ops.ffn_fwd(M, H, x1, st1, g1, b1n, w1, b1, w2, b2, h, out)
+    att = dict(kvhat=kv, gamma0=g0, beta0=b0, Nk=Nk, Bk=Bk, Bq=Bq, Sq=Sq, qs=Bq, qb=1, probs=probs, qstats=qs, x1=x1, st1=st1)
+    us2 = timeit(two)
+    usa = timeit(lambda: ops.attention_fwd(a))
+    usf = timeit(lambda: ops.ffn_fwd(M, H, x1, st1, g1, b1n, w1, b1, w2, b2, h, out))
+    us1 = timeit(lambda: ops.ffn_fwd(M, H, x, None, g1, b1n, w1, b1, w2, b2, h, out, att=att))
+    print(f"layer {name:30s} Sq={Sq} Bq={Bq} Nk={Nk} H={H}: one launch {us1:6.1f} us | attention {usa:5.1f} + ffn {usf:5.1f} us, "
+          f"back to back {us2:6.1f} us")
+
+
 def ffn_bwd_case(name, M, H):
     x = torch.randn(M, H, device=DEV); stats = torch.rand(M, 2, device=DEV)
     g = torch.randn(H, device=DEV)
@@ -270,6 +299,10 @@ def main():
         ffn_bwd_case("FFN bwd 2B", R2, H)
         ffn_bwd_case("FFN bwd B", R1, H)
         ffn_bwd_case("FFN bwd roofline scale", 262144, H)
+    if w in ("all", "ffn", "layer"):
+        layer_case("cross layer B (16-row tiles)", 51, 64, 12, 64, H)
+        layer_case("cross layer 2B", 51, 128, 12, 64, H)
+        layer_case("cross layer roofline scale", 51, 4096, 12, 2048, H)
     if w in ("all", "nmlp"):
         node_mlp_case("cfg2 nodes", N, H)
         node_mlp_case("one crystal", 7, H)
