@@ -572,6 +572,9 @@ def main():
         try:
             e = run_workload("edos_h256_b64", shuffle=False, steps=40, warmup=8, bucket=(8, 128), instrument=False, **common)
             secondary["edos_h256_b64"] = brief(e, 40)
+            # BASELINE.json configs[4]'s per-GPU shard (Electron-DOS H256 T4, 32 crystals per GPU of the 8 x 32 job)
+            e4 = run_workload("edos_h256_t4_b32", shuffle=False, steps=30, warmup=6, bucket=(8, 128), instrument=False, **common)
+            secondary["edos_h256_t4_b32"] = brief(e4, 30)
             sh = run_workload("phonon_h128_b64", shuffle=True, steps=args.steps, warmup=max(args.warmup, 60),
                               bucket=SHUFFLE_BUCKET, instrument=False, **common)
             secondary["shuffle"] = dict(brief(sh, args.steps), hit_rate=sh["slots"]["hit_rate"], live_buckets=sh["slots"]["live"])

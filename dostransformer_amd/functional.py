@@ -359,7 +359,11 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
             continue
         # <= 16 keys per crystal (the cross attention over the atoms of a crystal): the attention half runs in the prologue of
         # the feed-forward launch (DosxFfn.att_*) - one launch per layer; same saved tensors, the backward is unchanged
-        att_fused = _FUSED_ATT_FFN and ops.ffn_att_supported(H, Nk)
+        # ... while the feed-forward launch runs 16-row workgroups (<= 4096 rows: one pass of the row prologue, one launch
+        # 20.5 us against 6.9 + 16.4 us + a launch gap at M = 3264); with 32-row workgroups the prologue takes two passes and
+        # buys nothing (33.2 vs 33.1 us at M = 6528), at 200 k rows it loses to the MFMA attention kernel (828 vs 738 us):
+        # profiles/r04_kernel_microbench.log, `layer`
+        att_fused = _FUSED_ATT_FFN and rows <= _ATT_FFN_MAX_ROWS and ops.ffn_att_supported(H, Nk)
         if not att_fused:
             ops.attention_fwd(a)
         h = _empty(dev, rows, 4 * H)
@@ -405,6 +409,7 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
 
 _FUSED_FFN_BWD = __import__("os").environ.get("DOSX_FUSED_FFN_BWD", "1") == "1"
 _FUSED_ATT_FFN = __import__("os").environ.get("DOSX_FUSED_ATT_FFN", "1") == "1"       # <= 16-key attention inside dosx_ffn_fwd
+_ATT_FFN_MAX_ROWS = int(__import__("os").environ.get("DOSX_ATT_FFN_MAX_ROWS", "4096"))
 _FUSED_DKV = __import__("os").environ.get("DOSX_FUSED_DKV", "1") == "1"
 _LATE_SELF_FLUSH = __import__("os").environ.get("DOSX_LATE_SELF_FLUSH", "0") == "1"      # (measured: no gain)          # one-launch attention backward (Nk <= 64)
 _FUSED_FIN_BWD = __import__("os").environ.get("DOSX_FUSED_FIN_BWD", "1") == "1"

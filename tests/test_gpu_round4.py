@@ -575,8 +575,10 @@ def test_encoder_layer_with_attention_inside_the_ffn_launch(Sq, Bq, Nk, Bk, H, b
     qs, qb = (1, 0) if bcast else (Bq, 1)
     seed = torch.tensor([1234], dtype=torch.int64, device=DEV)
     res = {}
+    cap = Fn._ATT_FFN_MAX_ROWS
     for fused in (False, True):
         Fn._FUSED_ATT_FFN = fused
+        Fn._ATT_FFN_MAX_ROWS = 1 << 30            # (the shipped policy fuses up to 4096 rows; the kernel takes any)
         try:
             o.KERNEL_TIMER.reset(enabled=False)
             y, ctx = Fn.encoder_fwd(P, "e", x, Sq, Bq, qs, qb, kvhat, Nk, Bk, H, T, drop=(drop, seed, 0) if drop > 0 else None)
@@ -590,6 +592,7 @@ def test_encoder_layer_with_attention_inside_the_ffn_launch(Sq, Bq, Nk, Bk, H, b
             res[fused] = (y, ctx[0], dx, dkv, {k: v.clone() for k, v in G.items()})
         finally:
             Fn._FUSED_ATT_FFN = True
+            Fn._ATT_FFN_MAX_ROWS = cap
     (y0, lay0, dx0, dkv0, G0), (y1, lay1, dx1, dkv1, G1) = res[False], res[True]
     rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-12))
     assert rel(y1, y0) < 5e-6
