@@ -513,12 +513,19 @@ class _CounterPool:
 
     def __init__(self):
         self._bufs = {}
+        self._graph_owned = []
 
     def take(self, device, n: int) -> int:
         n = int(n)
         if RECORDER.active:
             t = torch.zeros(max(n, 1), dtype=torch.int32, device=device)
             RECORDER.keep.append(t)
+            return t.data_ptr()
+        if torch.cuda.is_current_stream_capturing():
+            # a captured HIP graph replays for as long as it lives, like a recorded program: counters of its own (the
+            # allocation belongs to the graph's memory pool; the zero fill becomes a memset node of the graph)
+            t = torch.zeros(max(n, 1), dtype=torch.int32, device=device)
+            self._graph_owned.append(t)
             return t.data_ptr()
         key = str(device)
         ent = self._bufs.get(key)

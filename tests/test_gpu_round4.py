@@ -605,3 +605,58 @@ def test_encoder_layer_with_attention_inside_the_ffn_launch(Sq, Bq, Nk, Bk, H, b
     assert rel(dx1, dx0) < 2e-5 and rel(dkv1, dkv0) < 2e-5
     for k in G0:
         assert rel(G1[k], G0[k]) < 5e-5, k
+
+
+def test_wide_hidden_through_predictor_dataset_and_edos_graphnetwork():
+    """hidden 384 on the surrounding paths: replayed inference (predict.Predictor) == the eager forward bit for bit,
+    Trainer.step_dataset (device collate straight into the bucket) == step(collate(...)) bit for bit, and the Electron-DOS
+    GNN-only variant (graphnetwork.py:26-43) against the oracle."""
+    from oracle import dos_oracle as O
+    from dostransformer_amd import synth
+    from dostransformer_amd.batch import collate
+    from dostransformer_amd.embedder_eDOS.graphnetwork import Graphnetwork
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    from dostransformer_amd.loader import DeviceDataset
+    from dostransformer_amd.predict import Predictor
+    from dostransformer_amd.train import Trainer
+    torch.manual_seed(0)
+    H = 384
+    model = DOSTransformer_phonon(2, 1, 118, 4, H, DEV, 0.0).to(DEV)
+    cs = synth.phonon_crystals(6, 21, torch.float32)
+    g = collate(cs).to(DEV)
+    model.eval()
+    with torch.no_grad():
+        a = [t.clone() for t in model(g)]
+    pred = Predictor(model)
+    b1 = [t.clone() for t in pred(g)]
+    b2 = [t.clone() for t in pred(g)]                  # second call: the recorded program
+    for x, y, z in zip(a, b1, b2):
+        assert torch.equal(x, y) and torch.equal(x, z)
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    outs = []
+    ds = DeviceDataset(cs, DEV)
+    nmax = max(int(c["x"].shape[0]) for c in cs)
+    for mode in ("batch", "dataset"):
+        m2 = DOSTransformer_phonon(2, 1, 118, 4, H, DEV, 0.0)
+        m2.load_state_dict(sd0)
+        m2 = m2.to(DEV)
+        t2 = Trainer(m2, lr=1e-3, replay=True, bucket=(16, 256))
+        for _ in range(3):
+            if mode == "dataset":
+                t2.step_dataset(ds, list(range(6)), n_max=nmax)
+            else:
+                t2.step(ds.collate(list(range(6)), n_max=nmax))
+        torch.cuda.synchronize()
+        outs.append({k: v.detach().cpu().clone() for k, v in m2.state_dict().items()})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    # Electron-DOS GNN-only model
+    gm = Graphnetwork(2, 200, 41, 2, H, 201, DEV)
+    params = {k: v.detach().clone() for k, v in gm.state_dict().items()}
+    gm = gm.to(DEV)
+    ge = collate(synth.edos_crystals(3, 5, torch.float32))
+    out, xn = gm(ge.to(DEV))
+    with torch.no_grad():
+        ref, rx = O.graphnetwork_forward(params, ge, 2)
+    rmse = lambda u, v: float(torch.sqrt(((u.detach().cpu().double() - v.double()) ** 2).mean()))
+    assert rmse(out, ref) < 1e-4 and rmse(xn, rx) < 1e-4 * max(1.0, float(rx.abs().max()))
