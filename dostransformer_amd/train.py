@@ -151,7 +151,7 @@ class Trainer:
         self.max_slots = int(max_slots)
         self.slot_hits = self.slot_misses = 0
         self.kernel_timer = None          # ops._KernelTimer: replayed programs then run through dosx_replay_timed
-        self._ds_checked = set()          # datasets whose per-rank size was compared across the ranks (step_dataset)
+        self._ds_checked = []             # datasets whose per-rank size was compared across the ranks (step_dataset)
 
     def _state(self, fp):
         """AdamW moments laid out like ``fp``.  When the parameters are re-homed (module moved to another device after
@@ -432,12 +432,12 @@ class Trainer:
         elif self.dist is None:
             ng = B
         else:
-            if id(ds) not in self._ds_checked:
+            if not any(d is ds for d in self._ds_checked):
                 lo, hi = self.dist.min_max(len(ds))
                 if lo != hi:
                     raise ValueError(f"data-parallel ranks hold {lo}..{hi} crystals: with ragged shards the last batches of "
                                      f"an epoch differ in size across ranks - pass the global batch size as n_global")
-                self._ds_checked.add(id(ds))
+                self._ds_checked.append(ds)
             if _DP_CHECK:
                 lo, hi = self.dist.min_max(B)
                 if lo != hi:

@@ -654,8 +654,8 @@ def test_wide_hidden_through_predictor_dataset_and_edos_graphnetwork():
     gm = Graphnetwork(2, 200, 41, 2, H, 201, DEV)
     params = {k: v.detach().clone() for k, v in gm.state_dict().items()}
     gm = gm.to(DEV)
-    ge = collate(synth.edos_crystals(3, 5, torch.float32))
-    out, xn = gm(ge.to(DEV))
+    ge = collate(synth.edos_crystals(3, 5, torch.float32))                 # (CrystalBatch.to moves in place: one per side)
+    out, xn = gm(collate(synth.edos_crystals(3, 5, torch.float32)).to(DEV))
     with torch.no_grad():
         ref, rx = O.graphnetwork_forward(params, ge, 2)
     rmse = lambda u, v: float(torch.sqrt(((u.detach().cpu().double() - v.double()) ** 2).mean()))
