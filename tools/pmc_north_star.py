@@ -8,7 +8,7 @@
                     SQ_VALU_MFMA_BUSY_CYCLES over `tools/bench_kernels.py --what attn`, forward + backward kernels of a
                     shape class together.  The classes are told apart by (template arguments, grid size): the key-tile
                     count NJ = 1 kernels are the 12-key Phonon-DOS cross attention, NJ = 4 at 2 query tiles x 128 entries the
-                    51-key Phonon-DOS self attention, NJ = 4 at 7 query tiles the 41-key Electron-DOS cross attention,
+                    51-key Phonon-DOS self attention, NJ = 3 / 4 at 7 query tiles the 41-key Electron-DOS cross attention,
                     NJ = 13 at 7 x 128 the 201-key Electron-DOS self attention (the roofline-scale launches are left out).
 
 The file carries the hash of the sources it was measured on (dostransformer_amd._lib.source_hash); bench.py reports the
@@ -43,8 +43,8 @@ def attn_classes(path):
             cls = "edos_self" if nj == 2 and wgs <= 4 * 128 else None      # KG = 2 key groups x 128 crystals; roofline scale: more
         elif nj == 1:
             cls = "cfg2_cross"
-        elif nj == 4:
-            cls = "cfg2_self" if wgs <= 2 * 128 else ("edos_cross" if wgs <= 7 * 128 else None)
+        elif nj in (3, 4):           # (NJ = 3: the 33-48-key row phases of round 4 - the 41-key Electron-DOS cross attention)
+            cls = "cfg2_self" if (nj == 4 and wgs <= 2 * 128) else ("edos_cross" if 2 * 128 < wgs <= 7 * 128 else None)
         elif nj == 13:
             cls = "edos_self" if wgs <= 7 * 128 else None
         else:
