@@ -2055,6 +2055,7 @@ extern "C" int dosx_grad_flush(const DosxWgrad* jobs, int n_jobs, const DosxRedu
   G.n = 0;
   G.nr = 0;
   int blocks_total = 0, rblocks = 0, rdone = 0;
+  int group_chunks = 0;            // longest workgroup of the current launch table, in 32-row chunks
   auto flush = [&]() -> int {
     // reduction jobs still waiting ride along (up to the table's capacity)
     while (rdone < n_rjobs && G.nr < WG_MAX_RJOBS) {
@@ -2069,17 +2070,23 @@ extern "C" int dosx_grad_flush(const DosxWgrad* jobs, int n_jobs, const DosxRedu
     if (G.n == 0 && G.nr == 0) return 0;
     G.first_block[G.n] = blocks_total;
     G.rfirst[G.nr] = rblocks;
-    // DOSX_WGRAD_ROUND = r > 0: the group goes out as successive launches of at most r workgroups.  A kernel of the dgrad
-    // chain that arrives while a weight-gradient grid is being dispatched waits until a CU is EMPTY (its workgroups need
-    // > 100 KB of LDS / > 128 VGPRs; a freed half-CU slot is refilled at once from the weight-gradient grid's backlog); at
-    // a launch boundary the backlog is empty and CUs drain completely, one after the other.
-    static int round = -1;
-    if (round < 0) {
+    // The group goes out as successive launches of at most `per` workgroups (round 4).  A kernel of the dgrad chain that
+    // arrives while a weight-gradient grid is being dispatched waits until a CU is EMPTY (its workgroups need > 100 KB of LDS
+    // / > 128 VGPRs; a freed half-CU slot is refilled at once from the weight-gradient grid's backlog); at a launch boundary
+    // the backlog is empty and CUs drain completely, one after the other.  A boundary costs the round's tail, i.e. about one
+    // workgroup lifetime of partly idle CUs: one round of 2 workgroups per CU (512) where workgroups are short-lived (<= 40
+    // chunks of 32 rows: the Phonon-DOS shapes, -0.6 % per step in five interleaved pairs), two rounds' worth (1024) where
+    // they live 50-100 chunks (Electron-DOS: -0.55 %; 512 there: +0.9 %, 256: +4.7 %).  DOSX_WGRAD_ROUND = r overrides
+    // (0: one launch per group, as in round 3).  tools/exp/ab_round2.sh, profiles/r04_ab_wgrad_round.log.
+    static int round = -2;
+    if (round == -2) {
       const char* e = getenv("DOSX_WGRAD_ROUND");
-      round = e ? atoi(e) : 0;
+      round = e ? atoi(e) : -1;
     }
     const int total = blocks_total + rblocks;
-    const int per = round > 0 ? round : total;
+    int per = total;
+    if (round > 0) per = round;
+    else if (round < 0) per = group_chunks <= 40 ? 512 : 1024;
     for (int off = 0; off < total; off += per) {
       G.block_off = off;
       hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(total - off < per ? total - off : per), dim3(512), 0, st, G);
@@ -2089,6 +2096,7 @@ extern "C" int dosx_grad_flush(const DosxWgrad* jobs, int n_jobs, const DosxRedu
     G.nr = 0;
     blocks_total = 0;
     rblocks = 0;
+    group_chunks = 0;
     return 0;
   };
   for (int i = 0; i < n_jobs; ++i) {
@@ -2103,6 +2111,11 @@ extern "C" int dosx_grad_flush(const DosxWgrad* jobs, int n_jobs, const DosxRedu
     G.job[G.n] = L;
     G.first_block[G.n] = blocks_total;
     blocks_total += blocks;
+    {
+      const int ns = jobs[i].nsplit > 0 ? jobs[i].nsplit : 1;
+      const int ch = ceil_div(ceil_div(jobs[i].M, ns), BM);
+      if (ch > group_chunks) group_chunks = ch;
+    }
     if (++G.n == WG_MAX_JOBS)
       if (int rc = flush()) return rc;
   }
