@@ -2055,7 +2055,6 @@ extern "C" int dosx_grad_flush(const DosxWgrad* jobs, int n_jobs, const DosxRedu
   G.n = 0;
   G.nr = 0;
   int blocks_total = 0, rblocks = 0, rdone = 0;
-  int group_chunks = 0;            // longest workgroup of the current launch table, in 32-row chunks
   auto flush = [&]() -> int {
     // reduction jobs still waiting ride along (up to the table's capacity)
     while (rdone < n_rjobs && G.nr < WG_MAX_RJOBS) {
@@ -2073,11 +2072,12 @@ extern "C" int dosx_grad_flush(const DosxWgrad* jobs, int n_jobs, const DosxRedu
     // The group goes out as successive launches of at most `per` workgroups (round 4).  A kernel of the dgrad chain that
     // arrives while a weight-gradient grid is being dispatched waits until a CU is EMPTY (its workgroups need > 100 KB of LDS
     // / > 128 VGPRs; a freed half-CU slot is refilled at once from the weight-gradient grid's backlog); at a launch boundary
-    // the backlog is empty and CUs drain completely, one after the other.  A boundary costs the round's tail, i.e. about one
-    // workgroup lifetime of partly idle CUs: one round of 2 workgroups per CU (512) where workgroups are short-lived (<= 40
-    // chunks of 32 rows: the Phonon-DOS shapes, -0.6 % per step in five interleaved pairs), two rounds' worth (1024) where
-    // they live 50-100 chunks (Electron-DOS: -0.55 %; 512 there: +0.9 %, 256: +4.7 %).  DOSX_WGRAD_ROUND = r overrides
-    // (0: one launch per group, as in round 3).  tools/exp/ab_round2.sh, profiles/r04_ab_wgrad_round.log.
+    // the backlog is empty and CUs drain completely, one after the other.  A boundary costs the round's tail (partly idle
+    // CUs for up to a workgroup lifetime), so: one round of 2 workgroups per CU (512) for the small groups - up to 1024
+    // workgroups, the Phonon-DOS shapes: -0.6 % per step in five interleaved pairs - and 1024 per launch for the large ones
+    // (Electron-DOS H = 256, 1000-4000 workgroups per group: -0.55 % at batch 64, -0.9 % on the T4 / 32-crystal shard; 512
+    // there: +0.9 % / -0.4 %, 256: +4.7 %).  DOSX_WGRAD_ROUND = r overrides (0: one launch per group, as in round 3).
+    // tools/exp/ab_round2.sh, ab_round3.sh; profiles/r04_ab_wgrad_round.log.
     static int round = -2;
     if (round == -2) {
       const char* e = getenv("DOSX_WGRAD_ROUND");
@@ -2086,7 +2086,7 @@ extern "C" int dosx_grad_flush(const DosxWgrad* jobs, int n_jobs, const DosxRedu
     const int total = blocks_total + rblocks;
     int per = total;
     if (round > 0) per = round;
-    else if (round < 0) per = group_chunks <= 40 ? 512 : 1024;
+    else if (round < 0) per = total <= 1024 ? 512 : 1024;
     for (int off = 0; off < total; off += per) {
       G.block_off = off;
       hipLaunchKernelGGL(wgrad_grouped_kernel, dim3(total - off < per ? total - off : per), dim3(512), 0, st, G);
@@ -2096,7 +2096,6 @@ extern "C" int dosx_grad_flush(const DosxWgrad* jobs, int n_jobs, const DosxRedu
     G.nr = 0;
     blocks_total = 0;
     rblocks = 0;
-    group_chunks = 0;
     return 0;
   };
   for (int i = 0; i < n_jobs; ++i) {
@@ -2111,11 +2110,6 @@ extern "C" int dosx_grad_flush(const DosxWgrad* jobs, int n_jobs, const DosxRedu
     G.job[G.n] = L;
     G.first_block[G.n] = blocks_total;
     blocks_total += blocks;
-    {
-      const int ns = jobs[i].nsplit > 0 ? jobs[i].nsplit : 1;
-      const int ch = ceil_div(ceil_div(jobs[i].M, ns), BM);
-      if (ch > group_chunks) group_chunks = ch;
-    }
     if (++G.n == WG_MAX_JOBS)
       if (int rc = flush()) return rc;
   }
