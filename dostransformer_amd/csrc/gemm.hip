@@ -2069,19 +2069,19 @@ extern "C" int dosx_grad_flush(const DosxWgrad* jobs, int n_jobs, const DosxRedu
     if (G.n == 0 && G.nr == 0) return 0;
     G.first_block[G.n] = blocks_total;
     G.rfirst[G.nr] = rblocks;
-    // The group goes out as successive launches of at most `per` workgroups (round 4).  A kernel of the dgrad chain that
-    // arrives while a weight-gradient grid is being dispatched waits until a CU is EMPTY (its workgroups need > 100 KB of LDS
-    // / > 128 VGPRs; a freed half-CU slot is refilled at once from the weight-gradient grid's backlog); at a launch boundary
-    // the backlog is empty and CUs drain completely, one after the other.  A boundary costs the round's tail (partly idle
-    // CUs for up to a workgroup lifetime), so: one round of 2 workgroups per CU (512) for the small groups - up to 1024
-    // workgroups, the Phonon-DOS shapes: -0.6 % per step in five interleaved pairs - and 1024 per launch for the large ones
-    // (Electron-DOS H = 256, 1000-4000 workgroups per group: -0.55 % at batch 64, -0.9 % on the T4 / 32-crystal shard; 512
-    // there: +0.9 % / -0.4 %, 256: +4.7 %).  DOSX_WGRAD_ROUND = r overrides (0: one launch per group, as in round 3).
-    // tools/exp/ab_round2.sh, ab_round3.sh; profiles/r04_ab_wgrad_round.log.
+    // DOSX_WGRAD_ROUND (round 4, default 0 = one launch per group): the group as successive launches of at most r workgroups
+    // ("auto": 512 for groups of up to 1024 workgroups, else 1024).  A kernel of the dgrad chain that arrives while a
+    // weight-gradient grid is being dispatched waits until a CU is EMPTY (its workgroups need > 100 KB of LDS / > 128 VGPRs; a
+    // freed half-CU slot is refilled at once from the weight-gradient grid's backlog); at a launch boundary the backlog is
+    // empty and CUs drain completely.  Measured (tools/exp/ab_round*.sh, profiles/r04_ab_wgrad_round.log, interleaved): "auto"
+    // takes 0.3-0.6 % off the Phonon-DOS step, 0.4-0.6 % off the Electron-DOS step, 0.9 % off its T4 / 32-crystal shard -
+    // and costs the weight-gradient kernels themselves 23 % (387 vs 314 us of kernel time per cfg2 step: every boundary is a
+    // tail of partly idle CUs), i.e. the chain gains slightly more than the groups lose.  Not worth a dominant kernel at
+    // 0.26 instead of 0.32 of its roofline: off by default.
     static int round = -2;
     if (round == -2) {
       const char* e = getenv("DOSX_WGRAD_ROUND");
-      round = e ? atoi(e) : -1;
+      round = !e ? 0 : (e[0] == 'a' ? -1 : atoi(e));
     }
     const int total = blocks_total + rblocks;
     int per = total;
