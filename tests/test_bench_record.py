@@ -35,6 +35,16 @@ def _synthetic(n_sites):
                             "value_ref_threads": 92.0, "ref_threads": 2, "host": "AMD EPYC 9575F 64-Core Processor, 256 logical CPUs",
                             "sample": "62 full train steps of one 64-crystal batch, fp64, 15.1s, 243.5 ms/step, fastest of 2/8/16/32 threads"},
            "kernels_file": "bench_kernels_last.json"}
+    # round 4: the counter-based north_star figures, the data-parallel secondaries, the configs[4] shard
+    out["prepare_steps"] = 16
+    out["north_star"] = {"scatter_hbm_frac": {"cfg2": 0.29, "4Mi": 0.679},
+                         "attn_mfma_util": {"cfg2_cross": 0.0838, "cfg2_self": 0.1589, "edos_cross": 0.22, "edos_self": 0.3352},
+                         "source": "r04_north_star.json (rocprofv3 --pmc, git 182ada2ca2c9)"}
+    out["secondary"]["edos_h256_t4_b32"] = {"value": 4194.0, "unit": "crystals/s", "ms_per_step": 7.6291, "steps": 30, "step_frac": 0.455,
+                                            "host_ms_per_step": 0.68}
+    out["secondary"]["dp1_nccl"] = {"value": 49064.0, "unit": "crystals/s", "ms_per_step": 1.3044, "steps": 200, "step_frac": 0.249,
+                                    "host_ms_per_step": 0.37, "grad_bucket_bytes": {"early": 3501056, "late": 3037696},
+                                    "collectives_per_step": 3, "backend": "nccl"}
     return out, sites
 
 
@@ -48,6 +58,7 @@ def test_record_line_stays_small_with_200_sites():
               "dtype", "data", "config", "roofline", "cpu_baseline", "step_frac"):
         assert k in rec, k
     assert "kernels" not in rec and rec["roofline"]["frac"] == sites[0]["frac"]
+    assert "north_star" in rec and "dp1_nccl" in rec["secondary"] and "top_sites" in rec       # nothing had to be dropped
     assert rec["config"]["workload"].startswith("phonon_h128_b64")
     assert len(rec.get("top_sites", [])) <= 5
 
@@ -168,6 +179,9 @@ def test_bench_default_line_is_one_small_json_record(tmp_path):
     assert rec["cpu_baseline"]["kind"] == "port" and rec["cpu_baseline"]["value"] > 0
     assert "error" not in rec.get("secondary", {}), rec["secondary"]
     assert rec["secondary"]["edos_h256_b64"]["value"] > 0 and rec["secondary"]["shuffle"]["value"] > 0
+    assert rec["secondary"]["edos_h256_t4_b32"]["value"] > 0
+    ns = rec["north_star"]                                # figures only when the committed PMC file matches the sources
+    assert ns["source"] and (ns["scatter_hbm_frac"] is None or 0 < ns["scatter_hbm_frac"]["cfg2"] < 1)
     assert rec["host_ms_per_step"] > 0
     assert rec["warmup"] == 8 and rec["prepare_steps"] == 16          # the driver's consistency check: warm-up as requested
     d1 = rec["secondary"]["dp1_nccl"]                                 # the data-parallel step on a 1-rank RCCL group
@@ -175,3 +189,41 @@ def test_bench_default_line_is_one_small_json_record(tmp_path):
     assert d1["grad_bucket_bytes"]["early"] > 0 and d1["grad_bucket_bytes"]["late"] > 0
     table = json.loads(kout.read_text())
     assert len(table["sites"]) >= 10 and not any(s["site"].startswith("gemm[M") for s in table["sites"])
+
+
+def test_north_star_tool_classifies_the_attention_launches(tmp_path):
+    """tools/pmc_north_star.py: the shape classes are told apart by (template arguments, grid size); utilisation = MFMA-busy
+    cycles of the 1024 SIMDs / (1024 x kernel cycles at 2.4 GHz); the scatter rows by grid / traffic."""
+    import csv
+    rows = []
+
+    def add(did, name, grid, ns, busy):
+        rows.append({"Dispatch_Id": did, "Kernel_Name": name, "Grid_Size": grid, "Start_Timestamp": 1000, "End_Timestamp": 1000 + ns,
+                     "Counter_Name": "SQ_VALU_MFMA_BUSY_CYCLES", "Counter_Value": busy})
+    ns = 10000                                             # 10 us = 24 000 cycles at 2.4 GHz
+    add(1, "void (anonymous namespace)::attn_fwd_stream_kernel<1, true>(DosxAttn)", 2 * 64 * 512, ns, 0.10 * 1024 * 24000)
+    add(2, "void (anonymous namespace)::attn_bwd_dq_stream_kernel<4, true, true>(DosxAttn)", 2 * 128 * 512, ns, 0.20 * 1024 * 24000)
+    add(3, "void (anonymous namespace)::attn_fwd_stream_kernel<3, true>(DosxAttn)", 7 * 128 * 512, ns, 0.25 * 1024 * 24000)
+    add(4, "void (anonymous namespace)::attn_fwd_stream_kernel<13, false>(DosxAttn)", 7 * 128 * 512, ns, 0.40 * 1024 * 24000)
+    add(5, "void (anonymous namespace)::attn_fwd_stream_kernel<13, false>(DosxAttn)", 7 * 2048 * 512, ns, 0.50 * 1024 * 24000)   # roofline scale: left out
+    add(6, "void (anonymous namespace)::attn_bwd_dkv_kernel<2>(DosxAttn)", 4 * 128 * 512, ns, 0.50 * 1024 * 24000)
+    f = tmp_path / "cc.csv"
+    with open(f, "w", newline="") as fh:
+        w = csv.DictWriter(fh, fieldnames=list(rows[0]))
+        w.writeheader()
+        w.writerows(rows)
+    sc = tmp_path / "sc.csv"
+    sc.write_text("kernel,grid_size,launches,avg_us,HBM_MB_per_launch,GB_per_s,pct_of_8TBs\n"
+                  "segment_reduce,28800,110,4.14,9.53,2300.1,28.8\nsegment_reduce,6710912,55,1204.04,6553.23,5442.7,68.0\n"
+                  "segment_reduce,13421824,110,744.62,4409.12,5921.3,74.0\n")
+    out = tmp_path / "ns.json"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_north_star.py"), str(f), str(sc), str(out), "abc"],
+                       cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()
+    rec = json.loads(out.read_text())
+    assert rec["scatter_hbm_frac"] == {"cfg2": 0.288, "4Mi": 0.68}
+    u = rec["attn_mfma_util"]
+    assert abs(u["cfg2_cross"] - 0.10) < 1e-3 and abs(u["cfg2_self"] - 0.20) < 1e-3 and abs(u["edos_cross"] - 0.25) < 1e-3
+    assert abs(u["edos_self"] - 0.45) < 1e-3                 # forward + dK/dV kernels of the class together, roofline scale left out
+    from dostransformer_amd._lib import source_hash
+    assert rec["source_hash"] == source_hash() and rec["git_head"] == "abc"
