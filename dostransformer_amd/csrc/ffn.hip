@@ -158,130 +158,6 @@ __device__ __forceinline__ void ffn_att_row(const DosxFfn& a, float* __restrict_
   }
 }
 
-// The same row (see ffn_att_row) with the key set in LDS - Ks [Nk][H + 4], shared by the rows of a crystal-aligned tile
-// (ATT = 2), Nk <= 64 - and the row's scores / probabilities in its own LDS row Sc [68].  r: global row or -1, s / bq: its
-// (clamped) coordinates.  The hand-over between the lanes of the quarter wave goes through LDS in program order (LDS
-// operations of one wave execute in order: a compiler fence, no s_barrier).
-__device__ __forceinline__ void ffn_att_row_lds(const DosxFfn& a, float* __restrict__ Xs, const int LDX, const int lr, const int r,
-                                                const int s, const int bq, const float* __restrict__ Ks, float* __restrict__ Sc,
-                                                const int lane) {
-  const int H = a.H, LDKK = a.H + 4;
-  const int q16 = lane & 15;
-  const float scale = rsqrtf((float)H), invH = 1.f / (float)H;
-  const int Nk = a.att_Nk, Sq = a.att_Sq;
-  const bool rv = r >= 0;
-  float4 g0[2], b0[2], g1[2], bb1[2], xr[2];
-  bool on[2];
-  const float* xrow = a.x + ((size_t)s * a.att_qs + (size_t)bq * a.att_qb) * a.ldx;
-  float t = 0.f;
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int c = q16 * 4 + 64 * k, cc = c < H ? c : 0;
-    on[k] = c < H;
-    g0[k] = ld4(a.att_gamma0 + cc); b0[k] = ld4(a.att_beta0 + cc);
-    g1[k] = ld4(a.gamma + cc); bb1[k] = ld4(a.beta + cc);
-    xr[k] = on[k] ? ld4(xrow + c) : f4zero();
-    t += (xr[k].x + xr[k].y) + (xr[k].z + xr[k].w);
-  }
-  const float mean = row16_sum(t) * invH;
-  t = 0.f;
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    if (!on[k]) continue;
-    const float p0 = xr[k].x - mean, p1 = xr[k].y - mean, p2 = xr[k].z - mean, p3 = xr[k].w - mean;
-    t += (p0 * p0 + p1 * p1) + (p2 * p2 + p3 * p3);
-  }
-  const float rstd = rsqrtf(row16_sum(t) * invH + DOSX_LN_EPS);
-  float4 qg[2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const float4 v = xr[k];
-    float4 q = make_float4((v.x - mean) * rstd * g0[k].x + b0[k].x, (v.y - mean) * rstd * g0[k].y + b0[k].y,
-                           (v.z - mean) * rstd * g0[k].z + b0[k].z, (v.w - mean) * rstd * g0[k].w + b0[k].w);
-    q = make_float4(q.x * g0[k].x, q.y * g0[k].y, q.z * g0[k].z, q.w * g0[k].w);
-    qg[k] = on[k] ? q : f4zero();
-  }
-  // scores: one key per iteration, the quarter wave's 16 partial dot products summed by DPP; lane j % 16 keeps score j
-  const int c0_ = q16 * 4, c1_ = on[1] ? q16 * 4 + 64 : 0;
-  for (int j = 0; j < Nk; ++j) {
-    const float4 k0 = ld4(Ks + j * LDKK + c0_), k1 = ld4(Ks + j * LDKK + c1_);
-    float d = (qg[0].x * k0.x + qg[0].y * k0.y) + (qg[0].z * k0.z + qg[0].w * k0.w);
-    d += (qg[1].x * k1.x + qg[1].y * k1.y) + (qg[1].z * k1.z + qg[1].w * k1.w);       // (qg[1] = 0 where the row ends before column 64)
-    d = row16_sum(d) * scale;
-    if (q16 == (j & 15)) Sc[j] = d;
-  }
-  __builtin_amdgcn_wave_barrier();
-  float v[4], mx = -INFINITY;
-#pragma unroll
-  for (int jj = 0; jj < 4; ++jj) {
-    const int j = q16 + 16 * jj;
-    v[jj] = j < Nk ? Sc[j] : -INFINITY;
-    mx = fmaxf(mx, v[jj]);
-  }
-  mx = row16_max(mx);
-  float sum = 0.f;
-#pragma unroll
-  for (int jj = 0; jj < 4; ++jj) {
-    const float e = (q16 + 16 * jj) < Nk ? expf(v[jj] - mx) : 0.f;
-    v[jj] = e;
-    sum += e;
-  }
-  const float inv = 1.f / row16_sum(sum);
-  const size_t prow = ((size_t)bq * Sq + s) * Nk;
-  float ps = 0.f;
-#pragma unroll
-  for (int jj = 0; jj < 4; ++jj) {
-    const int j = q16 + 16 * jj;
-    if (j >= Nk) continue;
-    const float pr = v[jj] * inv;
-    const float pm = a.att_mask ? pr * a.att_mask[prow + j] : pr;
-    Sc[j] = pm;
-    ps += pm;
-    if (rv) a.att_probs[prow + j] = pr;              // the un-dropped P (the backward reads it)
-  }
-  const float psum = a.att_mask ? row16_sum(ps) : 1.f;
-  __builtin_amdgcn_wave_barrier();
-  float4 o[2] = {f4zero(), f4zero()};
-  for (int j = 0; j < Nk; ++j) {
-    const float pm = Sc[j];
-    const float4 k0 = ld4(Ks + j * LDKK + c0_), k1 = ld4(Ks + j * LDKK + c1_);
-    o[0].x += pm * k0.x; o[0].y += pm * k0.y; o[0].z += pm * k0.z; o[0].w += pm * k0.w;
-    o[1].x += pm * k1.x; o[1].y += pm * k1.y; o[1].z += pm * k1.z; o[1].w += pm * k1.w;
-  }
-  float4 x1[2];
-  t = 0.f;
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    x1[k] = f4zero();
-    if (!on[k]) continue;
-    x1[k] = make_float4(o[k].x * g0[k].x + b0[k].x * psum + xr[k].x, o[k].y * g0[k].y + b0[k].y * psum + xr[k].y,
-                        o[k].z * g0[k].z + b0[k].z * psum + xr[k].z, o[k].w * g0[k].w + b0[k].w * psum + xr[k].w);
-    if (rv) st4(a.att_x1 + (size_t)r * a.att_ldx1 + q16 * 4 + 64 * k, x1[k]);
-    t += (x1[k].x + x1[k].y) + (x1[k].z + x1[k].w);
-  }
-  const float mean1 = row16_sum(t) * invH;
-  t = 0.f;
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    if (!on[k]) continue;
-    const float p0 = x1[k].x - mean1, p1 = x1[k].y - mean1, p2 = x1[k].z - mean1, p3 = x1[k].w - mean1;
-    t += (p0 * p0 + p1 * p1) + (p2 * p2 + p3 * p3);
-  }
-  const float rstd1 = rsqrtf(row16_sum(t) * invH + DOSX_LN_EPS);
-  if (rv && q16 == 0) {
-    a.att_qstats[2 * (size_t)r] = mean; a.att_qstats[2 * (size_t)r + 1] = rstd;
-    a.att_st1[2 * (size_t)r] = mean1;   a.att_st1[2 * (size_t)r + 1] = rstd1;
-  }
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    if (!on[k]) continue;
-    const float4 vv = x1[k];
-    st4(Xs + lr * LDX + q16 * 4 + 64 * k,
-        make_float4((vv.x - mean1) * rstd1 * g1[k].x + bb1[k].x, (vv.y - mean1) * rstd1 * g1[k].y + bb1[k].y,
-                    (vv.z - mean1) * rstd1 * g1[k].z + bb1[k].z, (vv.w - mean1) * rstd1 * g1[k].w + bb1[k].w));
-  }
-}
-
 // ATT (round 4): the attention half of the layer runs in the prologue, for key sets of <= 16 rows per crystal (DosxFfn.att_*):
 // per query row - one QUARTER WAVE per row, like the row phases of attention.hip - LayerNorm-0, the <= 16 scores against
 // the crystal's pre-normalised key rows (read straight from L2: 16 x 512 B per row, the key set of a crystal is shared by
@@ -292,12 +168,7 @@ __device__ __forceinline__ void ffn_att_row_lds(const DosxFfn& a, float* __restr
 // P.(khat g + b) = (P.khat) o g + b sum(P).
 // HALF: the workgroup owns 16 rows and multiplies with the 16x16x4 MFMA (two 16-column tiles per wave instead of one
 // 32-column tile): twice the workgroups, half the MFMA time each, and two of them fit the LDS of one CU.
-// ATT = 2 (round 4, second form): CRYSTAL-ALIGNED tiles - a workgroup owns R consecutive query rows s of ONE query batch
-// entry bq (row r = s * Bq + bq, grid = Bq x ceil(Sq / R)), so the tile's rows share one key set: the crystal's <= 64
-// pre-normalised key rows are copied to LDS once (into the stage-buffer region, which the weight chunks take over after the
-// prologue) and every query row reads them from there - the 51-key self attention and the 32-row launches, where the
-// per-row global key fetch of ATT = 1 does not pay, take this form while the grid stays one round of workgroups.
-template <bool HALF, int KB, int ATT>
+template <bool HALF, int KB, bool ATT>
 __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
   DOSX_SET_MAIN_PRIO();
   extern __shared__ __align__(16) float sm[];
@@ -314,26 +185,6 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
   const int l15 = lane & 15, g4 = lane >> 4;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int m0 = blockIdx.x * R;
-  // tile row lr -> global row (-1: beyond the data).  ATT = 2: rows s0 .. s0 + R - 1 of query batch entry al_bq
-  int al_bq = 0, al_s0 = 0;
-  if constexpr (ATT == 2) {
-    const int tpc = (a.att_Sq + R - 1) / R;
-    al_bq = (int)blockIdx.x / tpc;
-    al_s0 = ((int)blockIdx.x % tpc) * R;
-  }
-  auto grow = [&](const int lr) -> int {
-    if constexpr (ATT == 2) {
-      const int s = al_s0 + lr;
-      return s < a.att_Sq ? s * a.att_Bq + al_bq : -1;
-    } else {
-      const int r = m0 + lr;
-      return r < M ? r : -1;
-    }
-  };
-  auto growc = [&](const int lr) -> int {          // clamped to a valid row of the tile (duplicates are never stored)
-    const int r = grow(lr);
-    return r >= 0 ? r : grow(0);
-  };
   FSTAMP(0);
   const int nk1 = H / FBK, nb1 = H4 / FBN, n1 = nb1 * nk1, n2 = H4 / FBK, nch = n1 + n2;
 
@@ -342,21 +193,12 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
   const bool con = c0 < H;
   float4 xres[ER], bias2 = f4zero();
   if (con) bias2 = ld4(a.b2 + c0);
-  if constexpr (ATT == 0) {
+  if constexpr (!ATT) {
 #pragma unroll
     for (int i = 0; i < ER; ++i) {
-      const int r = growc(wave * ER + i);
+      const int r = min(m0 + wave * ER + i, M - 1);
       xres[i] = ld4(a.x + (size_t)r * a.ldx + (con ? c0 : 0));
     }
-  }
-  if constexpr (ATT == 2) {
-    // the crystal's key rows -> LDS (all 8 waves), in the stage-buffer region: [Nk][H + 4], the score rows [R][68] behind them
-    const int Nk = a.att_Nk, bk = al_bq % a.att_Bk, h4 = H >> 2;
-    for (int e = tid; e < Nk * h4; e += 512) {
-      const int j = e / h4, c = (e - j * h4) * 4;
-      st4(ST + j * (H + 4) + c, ld4(a.att_kvhat + ((size_t)j * a.att_Bk + bk) * H + c));
-    }
-    __syncthreads();
   }
 
   if (wave_u >= 4) {
@@ -394,7 +236,6 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
     };
     issue(r0, 0);
     issue(r1, 1);
-    if constexpr (ATT == 2) __syncthreads();       // the attention prologue is done with the keys / scores in the stage buffers
     store(ST, r0);
     issue(r0, 2);
     __syncthreads();                               // (matrix waves: Xs written) chunk 0 visible
@@ -424,20 +265,13 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
       b1r[cb][0] = a.b1[col];
       b1r[cb][1] = HALF ? a.b1[col + 16] : 0.f;
     }
-    if constexpr (ATT == 2) {
-#pragma unroll 1
-      for (int p = 0; p < R / 16; ++p) {
-        const int lr = p * 16 + wave * 4 + (lane >> 4);
-        ffn_att_row_lds(a, Xs, LDX, lr, grow(lr), min(al_s0 + lr, a.att_Sq - 1), al_bq, ST, ST + a.att_Nk * (H + 4) + lr * 68, lane);
-      }
-      __syncthreads();                             // keys / scores dead: the staging waves may store the first weight chunk
-    } else if constexpr (ATT == 1) {
+    if constexpr (ATT) {
       // 16 rows per pass over the 4 matrix waves.  (All 8 waves in one pass - the staging waves taking rows 16-31 while their
       // first weight chunks are in flight - was built and spills: the 16 x 2 float4 key registers next to the staged chunks.)
 #pragma unroll
       for (int p = 0; p < R / 16; ++p) ffn_att_row(a, Xs, LDX, p * 16 + wave * 4 + (lane >> 4), m0, lane);
     } else {   // LN1(x) tile -> Xs  (row r = tid/8, 4-float groups tid%8 + 8 i)
-      const int r = tid >> 3, rr = growc(min(r, R - 1));
+      const int r = tid >> 3, rr = min(m0 + r, M - 1);
       const float mean = a.stats[2 * (size_t)rr], rstd = a.stats[2 * (size_t)rr + 1];
       for (int c = (tid & 7) * 4; c < H && r < R; c += 32) {
         const float4 v = ld4(a.x + (size_t)rr * a.ldx + c), g = ld4(a.gamma + c), b = ld4(a.beta + c);
@@ -479,10 +313,9 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
           const float h0 = fmaxf(acc0[r] + b1a, 0.f), h1 = fmaxf(acc1[r] + b1b, 0.f);
           T[(4 * g4 + r) * LDT + col] = h0;
           T[(4 * g4 + r) * LDT + col + 16] = h1;
-          const int gr = grow(4 * g4 + r);
-          if (gr >= 0) {                           // h -> HBM straight from the accumulators (64-byte row segments)
-            a.h[(size_t)gr * a.ldh + col] = h0;
-            a.h[(size_t)gr * a.ldh + col + 16] = h1;
+          if (m0 + 4 * g4 + r < M) {               // h -> HBM straight from the accumulators (64-byte row segments)
+            a.h[(size_t)(m0 + 4 * g4 + r) * a.ldh + col] = h0;
+            a.h[(size_t)(m0 + 4 * g4 + r) * a.ldh + col + 16] = h1;
           }
         }
       }
@@ -542,8 +375,7 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
         const float hvv = fmaxf(acc[r] + b1, 0.f);
         T[row * LDT + col] = hvv;
-        const int gr = grow(row);
-        if (gr >= 0) a.h[(size_t)gr * a.ldh + col] = hvv;
+        if (m0 + row < M) a.h[(size_t)(m0 + row) * a.ldh + col] = hvv;
       }
     }
     FSTAMP(2);
@@ -575,10 +407,10 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
   }
   __syncthreads();
   FSTAMP(5);
-  if constexpr (ATT != 0) {    // the residual rows are the x1 rows the prologue wrote (this workgroup's own stores: many barriers ago)
+  if constexpr (ATT) {         // the residual rows are the x1 rows the prologue wrote (this workgroup's own stores: many barriers ago)
 #pragma unroll
     for (int i = 0; i < ER; ++i) {
-      const int r = growc(wave * ER + i);
+      const int r = min(m0 + wave * ER + i, M - 1);
       xres[i] = ld4(a.att_x1 + (size_t)r * a.att_ldx1 + (con ? c0 : 0));
     }
   }
@@ -594,8 +426,8 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
     const float invH = 1.f / (float)H;
 #pragma unroll
     for (int i = 0; i < ER; ++i) {
-      const int lr = wave * ER + i, r = grow(lr);
-      const bool ok = con && r >= 0;               // (wave-uniform)
+      const int lr = wave * ER + i, r = m0 + lr;
+      const bool ok = con && r < M;                // (r < M is wave-uniform)
       float4 o = f4zero();
       if (ok) {
         const float4 v = ld4(Cs + lr * (FBN + 4) + c0);
@@ -620,7 +452,7 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
       }
       if (fdot) {                                    // dos[bq][s] of row r = s * Bq + bq  (what dosx_ln_rowdot writes)
         dot = wave_sum(dot);
-        if (lane == 0 && r >= 0) a.fin_dos[(size_t)(r % a.fin_Bq) * a.fin_S + (r / a.fin_Bq)] = dot + fbias;
+        if (lane == 0 && r < M) a.fin_dos[(size_t)(r % a.fin_Bq) * a.fin_S + (r / a.fin_Bq)] = dot + fbias;
       }
     }
   }
@@ -970,12 +802,6 @@ static int ffn_chunk(int H) {
 
 extern "C" int dosx_ffn_supported(int H) { return (H % 32) == 0 && H >= 32 && H <= 128; }
 extern "C" int dosx_ffn_att_supported(int H, int Nk) { return dosx_ffn_supported(H) && Nk >= 1 && Nk <= 16; }
-// ... with crystal-aligned tiles (DosxFfn.att_aligned): <= 64 keys whose rows fit the stage-buffer region next to 32 score rows
-extern "C" int dosx_ffn_att_aligned_supported(int H, int Nk) {
-  if (!dosx_ffn_supported(H) || Nk < 1 || Nk > 64) return 0;
-  const int kb = (H % 64 == 0) ? 64 : 32;
-  return (size_t)Nk * (H + 4) + 32 * 68 <= 2 * (size_t)128 * (kb + 4);
-}
 
 extern "C" int dosx_ffn_fwd(const DosxFfn* ap, dosx_stream_t stream) {
   DOSX_CHECK_ARG(ap != nullptr, "dosx_ffn_fwd: null descriptor");
@@ -985,7 +811,7 @@ extern "C" int dosx_ffn_fwd(const DosxFfn* ap, dosx_stream_t stream) {
   const bool att = a.att_kvhat != nullptr;
   DOSX_CHECK_ARG(a.x && (a.stats || att) && a.gamma && a.beta && a.w1 && a.b1 && a.w2 && a.b2 && a.h && (a.out || a.fin_dos), "dosx_ffn_fwd: null operand");
   if (att)
-    DOSX_CHECK_ARG((a.att_aligned ? dosx_ffn_att_aligned_supported(a.H, a.att_Nk) : dosx_ffn_att_supported(a.H, a.att_Nk)) && a.att_gamma0 && a.att_beta0 && a.att_probs && a.att_qstats && a.att_x1 &&
+    DOSX_CHECK_ARG(dosx_ffn_att_supported(a.H, a.att_Nk) && a.att_gamma0 && a.att_beta0 && a.att_probs && a.att_qstats && a.att_x1 &&
                        a.att_st1 && a.att_Bk > 0 && a.att_Bq > 0 && a.att_Bq % a.att_Bk == 0 && a.att_Sq > 0 &&
                        a.att_Sq * a.att_Bq == a.M && (a.att_ldx1 & 3) == 0 && a.att_ldx1 >= a.H && a.att_qs >= 0 && a.att_qb >= 0,
                    "dosx_ffn_fwd: fused attention needs <= 16 keys, gamma0 / beta0 / probs / qstats / x1 / st1 and Sq * Bq == M");
@@ -998,29 +824,23 @@ extern "C" int dosx_ffn_fwd(const DosxFfn* ap, dosx_stream_t stream) {
   const int H = a.H, H4 = 4 * H;
   static int half_max = -1;
   if (half_max < 0) { const char* e = getenv("DOSX_FFN_HALF_MAX"); half_max = e ? atoi(e) : 128; }
-  const bool aligned = att && a.att_aligned != 0;        // crystal-aligned tiles (ATT = 2): grid = Bq x ceil(Sq / R)
-  const bool half = (aligned ? a.att_Bq * ceil_div(a.att_Sq, 32) : ceil_div(a.M, 32)) <= half_max;   // 16-row workgroups while the 32-row grid is one partial round
+  const bool half = ceil_div(a.M, 32) <= half_max;       // 16-row workgroups while the 32-row grid is one partial round
   const int R = half ? 16 : 32;
   const int kb = ffn_chunk(H);
   const size_t smem = sizeof(float) * ((size_t)R * (H + 4) + (size_t)R * (H4 + 4) + 2 * (size_t)FBN * (kb + 4));
-  if (aligned)
-    DOSX_CHECK_ARG(a.att_Nk <= 64 && ((size_t)a.att_Nk * (H + 4) + (size_t)R * 68) <= 2 * (size_t)FBN * (kb + 4),
-                   "dosx_ffn_fwd: crystal-aligned attention needs <= 64 keys that fit the stage buffers (Nk=%d, H=%d)", a.att_Nk, H);
   static bool attr_set = false;
   if (!attr_set) {
 #define DOSX_FFN_ATTR(HALF_, KB_, ATT_) \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fwd_kernel<HALF_, KB_, ATT_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-    DOSX_FFN_ATTR(false, 32, 0); DOSX_FFN_ATTR(true, 32, 0); DOSX_FFN_ATTR(false, 64, 0); DOSX_FFN_ATTR(true, 64, 0);
-    DOSX_FFN_ATTR(false, 32, 1); DOSX_FFN_ATTR(true, 32, 1); DOSX_FFN_ATTR(false, 64, 1); DOSX_FFN_ATTR(true, 64, 1);
-    DOSX_FFN_ATTR(false, 32, 2); DOSX_FFN_ATTR(true, 32, 2); DOSX_FFN_ATTR(false, 64, 2); DOSX_FFN_ATTR(true, 64, 2);
+    DOSX_FFN_ATTR(false, 32, false); DOSX_FFN_ATTR(true, 32, false); DOSX_FFN_ATTR(false, 64, false); DOSX_FFN_ATTR(true, 64, false);
+    DOSX_FFN_ATTR(false, 32, true); DOSX_FFN_ATTR(true, 32, true); DOSX_FFN_ATTR(false, 64, true); DOSX_FFN_ATTR(true, 64, true);
 #undef DOSX_FFN_ATTR
     attr_set = true;
   }
-  const dim3 grid(aligned ? a.att_Bq * ceil_div(a.att_Sq, R) : ceil_div(a.M, R));
+  const dim3 grid(ceil_div(a.M, R));
 #define DOSX_FFN_GO(HALF_, KB_) \
-  do { if (aligned) hipLaunchKernelGGL((ffn_fwd_kernel<HALF_, KB_, 2>), grid, dim3(512), smem, to_stream(stream), a); \
-       else if (att) hipLaunchKernelGGL((ffn_fwd_kernel<HALF_, KB_, 1>), grid, dim3(512), smem, to_stream(stream), a); \
-       else hipLaunchKernelGGL((ffn_fwd_kernel<HALF_, KB_, 0>), grid, dim3(512), smem, to_stream(stream), a); } while (0)
+  do { if (att) hipLaunchKernelGGL((ffn_fwd_kernel<HALF_, KB_, true>), grid, dim3(512), smem, to_stream(stream), a); \
+       else hipLaunchKernelGGL((ffn_fwd_kernel<HALF_, KB_, false>), grid, dim3(512), smem, to_stream(stream), a); } while (0)
   if (half && kb == 64) DOSX_FFN_GO(true, 64);
   else if (half) DOSX_FFN_GO(true, 32);
   else if (kb == 64) DOSX_FFN_GO(false, 64);

@@ -546,23 +546,17 @@ def test_graphnetwork_with_hidden_384_matches_the_oracle():
 
 # ---- attention half inside the feed-forward launch ---------------------------------------------------
 
-@pytest.mark.parametrize("form", ["rows", "aligned"])
 @pytest.mark.parametrize("Sq,Bq,Nk,Bk,H,bcast,drop", [(51, 64, 12, 64, 128, True, 0.0), (51, 128, 12, 64, 128, False, 0.0),
                                                       (51, 4, 9, 2, 128, False, 0.0), (51, 6, 16, 3, 64, False, 0.3),
                                                       (7, 3, 1, 3, 32, True, 0.0), (201, 8, 5, 8, 96, False, 0.25),
-                                                      (51, 128, 12, 64, 128, False, 0.2),
-                                                      # more than 16 keys: the crystal-aligned form only (self attention: 51 keys)
-                                                      (51, 128, 51, 128, 128, False, 0.0), (51, 64, 51, 64, 128, False, 0.3),
-                                                      (40, 5, 64, 5, 64, False, 0.0), (33, 3, 17, 3, 32, False, 0.0)])
-def test_encoder_layer_with_attention_inside_the_ffn_launch(Sq, Bq, Nk, Bk, H, bcast, drop, form):
+                                                      (51, 128, 12, 64, 128, False, 0.2)])
+def test_encoder_layer_with_attention_inside_the_ffn_launch(Sq, Bq, Nk, Bk, H, bcast, drop):
     """DosxFfn.att_*: <= 16-key cross attention in the prologue of dosx_ffn_fwd == dosx_attention_fwd + dosx_ffn_fwd: encoder
     output and every tensor the backward reads (x1, softmax weights, both LayerNorm statistics, h), T = 2 layers, broadcast
     query rows (the energy embeddings: stride 0 over the batch) and dense ones, 16- and 32-row workgroups, dropout masks; and
     the gradients through the (unchanged) backward agree."""
     from dostransformer_amd import functional as Fn
     o = ops()
-    if form == "rows" and Nk > 16:
-        pytest.skip("the per-row form takes at most 16 keys")
     T = 2
     gen = torch.Generator().manual_seed(Sq * 7 + Nk)
     P, G = {}, {}
@@ -581,12 +575,10 @@ def test_encoder_layer_with_attention_inside_the_ffn_launch(Sq, Bq, Nk, Bk, H, b
     qs, qb = (1, 0) if bcast else (Bq, 1)
     seed = torch.tensor([1234], dtype=torch.int64, device=DEV)
     res = {}
-    cap, cap_al, al, rf = Fn._ATT_FFN_MAX_ROWS, Fn._ATT_ALIGNED_MAX_WGS, Fn._ATT_ALIGNED, Fn._ATT_ROWS_FIRST
+    cap = Fn._ATT_FFN_MAX_ROWS
     for fused in (False, True):
         Fn._FUSED_ATT_FFN = fused
-        # (the shipped policy fuses by shape; the kernels take any: force the form under test)
-        Fn._ATT_FFN_MAX_ROWS = (1 << 30) if form == "rows" else 0
-        Fn._ATT_ALIGNED, Fn._ATT_ALIGNED_MAX_WGS, Fn._ATT_ROWS_FIRST = form == "aligned", 1 << 30, form == "rows"
+        Fn._ATT_FFN_MAX_ROWS = 1 << 30            # (the shipped policy fuses up to 4096 rows; the kernel takes any)
         try:
             o.KERNEL_TIMER.reset(enabled=False)
             y, ctx = Fn.encoder_fwd(P, "e", x, Sq, Bq, qs, qb, kvhat, Nk, Bk, H, T, drop=(drop, seed, 0) if drop > 0 else None)
@@ -600,7 +592,7 @@ def test_encoder_layer_with_attention_inside_the_ffn_launch(Sq, Bq, Nk, Bk, H, b
             res[fused] = (y, ctx[0], dx, dkv, {k: v.clone() for k, v in G.items()})
         finally:
             Fn._FUSED_ATT_FFN = True
-            Fn._ATT_FFN_MAX_ROWS, Fn._ATT_ALIGNED_MAX_WGS, Fn._ATT_ALIGNED, Fn._ATT_ROWS_FIRST = cap, cap_al, al, rf
+            Fn._ATT_FFN_MAX_ROWS = cap
     (y0, lay0, dx0, dkv0, G0), (y1, lay1, dx1, dkv1, G1) = res[False], res[True]
     rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-12))
     assert rel(y1, y0) < 5e-6
