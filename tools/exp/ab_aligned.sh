@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B: attention inside the feed-forward launch with crystal-aligned tiles (DosxFfn.att_aligned) on / off, and which form
-# the <= 16-key / <= 4096-row layers take
+# the <= 16-key / <= 4096-row layers take.  Needs tools/exp/patches/ffn_att_aligned.diff applied (git apply) and a rebuild:
+# the form was measured slower (profiles/r04_ab_att_aligned.log) and is not in the tree.
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
 ms() { python3 -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])"; }
 for rep in 1 2 3 4; do
