@@ -38,6 +38,11 @@ def main():
     # a real light chain kernel for comparison: the node-MLP dgrad of the Electron-DOS step
     xa, w, out = torch.randn(1554, 512, device=DEV), torch.randn(512, 512, device=DEV), torch.empty(1554, 512, device=DEV)
     probes = {
+        "sliver  4 waves  52 VGPR   4 KB LDS, 256 WGs, short": lambda s: lib.sliver_launch(buf.data_ptr(), 256, 30, 4096, s),
+        "sliver  4 waves  52 VGPR   4 KB LDS,  64 WGs, short": lambda s: lib.sliver_launch(buf.data_ptr(), 64, 30, 4096, s),
+        "sliver  4 waves  52 VGPR  24 KB LDS, 256 WGs, short": lambda s: lib.sliver_launch(buf.data_ptr(), 256, 30, 24576, s),
+        "fat     8 waves 150 VGPR  96 KB LDS, 256 WGs, short": lambda s: lib.fat_launch(buf.data_ptr(), 256, 5, 96 * 1024, s),
+        "fat     8 waves 150 VGPR   8 KB LDS,  64 WGs, short": lambda s: lib.fat_launch(buf.data_ptr(), 64, 5, 8192, s),
         "sliver  4 waves  52 VGPR   4 KB LDS, 256 WGs": lambda s: lib.sliver_launch(buf.data_ptr(), 256, 400, 4096, s),
         "sliver  4 waves  52 VGPR   8 KB LDS, 512 WGs": lambda s: lib.sliver_launch(buf.data_ptr(), 512, 200, 8192, s),
         "sliver  4 waves  52 VGPR  24 KB LDS, 256 WGs": lambda s: lib.sliver_launch(buf.data_ptr(), 256, 400, 24576, s),
