@@ -67,6 +67,15 @@ def main():
     for _ in range(3):
         g_alone = group_us()
     print(f"weight-gradient group alone: {g_alone:.1f} us")
+    big = group
+    for label, grp, strm in (("4 jobs (>= 1024 workgroups: a backlog)", big, B), ("2 jobs (512 workgroups: no backlog)", big[:2], B),
+                             ("4 jobs, probe on a high-priority stream", big, torch.cuda.Stream(priority=-1))):
+        group = grp
+        print(f"--- group: {label}: alone {group_us():.1f} us")
+        run_probes(probes, group, A, strm)
+
+
+def run_probes(probes, group, A, B):
     for name, fn in probes.items():
         def timed(under):
             res = []
