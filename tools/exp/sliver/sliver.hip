@@ -8,7 +8,9 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+template <int PRIO, bool VALU>
 __global__ __launch_bounds__(256) void sliver_kernel(float* __restrict__ buf, int iters) {
+  if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
   extern __shared__ float sm[];
   const int tid = threadIdx.x;
   sm[tid] = (float)tid;
@@ -18,8 +20,16 @@ __global__ __launch_bounds__(256) void sliver_kernel(float* __restrict__ buf, in
   for (int j = 0; j < 12; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float a = sm[(tid * 7) & 255], b = 1.0001f;
   for (int i = 0; i < iters; ++i) {
+    if (VALU) {                                    // the same number of instructions on the vector ALU instead of the matrix pipe
 #pragma unroll
-    for (int j = 0; j < 12; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j], 0, 0, 0);
+      for (int j = 0; j < 12; ++j) {
+        acc[j][0] = fmaf(a, b, acc[j][0]); acc[j][1] = fmaf(a, b, acc[j][1]);
+        acc[j][2] = fmaf(a, b, acc[j][2]); acc[j][3] = fmaf(a, b, acc[j][3]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j], 0, 0, 0);
+    }
     a += 1e-6f;
   }
   float s = 0.f;
@@ -49,7 +59,19 @@ __global__ __launch_bounds__(512, 2) void fat_kernel(float* __restrict__ buf, in
 }
 
 extern "C" int sliver_launch(float* buf, int nwg, int iters, int lds_bytes, void* stream) {
-  hipLaunchKernelGGL(sliver_kernel, dim3(nwg), dim3(256), (size_t)lds_bytes, (hipStream_t)stream, buf, iters);
+  hipLaunchKernelGGL((sliver_kernel<0, false>), dim3(nwg), dim3(256), (size_t)lds_bytes, (hipStream_t)stream, buf, iters);
+  return (int)hipGetLastError();
+}
+extern "C" int sliver_prio_launch(float* buf, int nwg, int iters, int lds_bytes, void* stream) {
+  hipLaunchKernelGGL((sliver_kernel<3, false>), dim3(nwg), dim3(256), (size_t)lds_bytes, (hipStream_t)stream, buf, iters);
+  return (int)hipGetLastError();
+}
+extern "C" int sliver_valu_launch(float* buf, int nwg, int iters, int lds_bytes, void* stream) {
+  hipLaunchKernelGGL((sliver_kernel<0, true>), dim3(nwg), dim3(256), (size_t)lds_bytes, (hipStream_t)stream, buf, iters);
+  return (int)hipGetLastError();
+}
+extern "C" int sliver_valu_prio_launch(float* buf, int nwg, int iters, int lds_bytes, void* stream) {
+  hipLaunchKernelGGL((sliver_kernel<3, true>), dim3(nwg), dim3(256), (size_t)lds_bytes, (hipStream_t)stream, buf, iters);
   return (int)hipGetLastError();
 }
 extern "C" int fat_launch(float* buf, int nwg, int iters, int lds_bytes, void* stream) {

@@ -14,7 +14,7 @@ from dostransformer_amd import ops  # noqa: E402
 
 DEV = "cuda"
 lib = C.CDLL(os.path.join(ROOT, "tools", "exp", "sliver", "libsliver.so"))
-for f in (lib.sliver_launch, lib.fat_launch):
+for f in (lib.sliver_launch, lib.fat_launch, lib.sliver_prio_launch, lib.sliver_valu_launch, lib.sliver_valu_prio_launch):
     f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     f.restype = C.c_int
 keep = []
@@ -38,6 +38,9 @@ def main():
     # a real light chain kernel for comparison: the node-MLP dgrad of the Electron-DOS step
     xa, w, out = torch.randn(1554, 512, device=DEV), torch.randn(512, 512, device=DEV), torch.empty(1554, 512, device=DEV)
     probes = {
+        "sliver  MFMA, s_setprio 3,           256 WGs, short": lambda s: lib.sliver_prio_launch(buf.data_ptr(), 256, 30, 4096, s),
+        "sliver  vector ALU only,             256 WGs, short": lambda s: lib.sliver_valu_launch(buf.data_ptr(), 256, 120, 4096, s),
+        "sliver  vector ALU only, s_setprio 3, 256 WGs, short": lambda s: lib.sliver_valu_prio_launch(buf.data_ptr(), 256, 120, 4096, s),
         "sliver  4 waves  52 VGPR   4 KB LDS, 256 WGs, short": lambda s: lib.sliver_launch(buf.data_ptr(), 256, 30, 4096, s),
         "sliver  4 waves  52 VGPR   4 KB LDS,  64 WGs, short": lambda s: lib.sliver_launch(buf.data_ptr(), 64, 30, 4096, s),
         "sliver  4 waves  52 VGPR  24 KB LDS, 256 WGs, short": lambda s: lib.sliver_launch(buf.data_ptr(), 256, 30, 24576, s),
@@ -68,8 +71,7 @@ def main():
         g_alone = group_us()
     print(f"weight-gradient group alone: {g_alone:.1f} us")
     big = group
-    for label, grp, strm in (("4 jobs (>= 1024 workgroups: a backlog)", big, B), ("2 jobs (512 workgroups: no backlog)", big[:2], B),
-                             ("4 jobs, probe on a high-priority stream", big, torch.cuda.Stream(priority=-1))):
+    for label, grp, strm in (("4 jobs (>= 1024 workgroups: a backlog)", big, B), ("2 jobs (512 workgroups: no backlog)", big[:2], B)):
         group = grp
         print(f"--- group: {label}: alone {group_us():.1f} us")
         run_probes(probes, group, A, strm)
