@@ -53,6 +53,32 @@ def main():
         "fat     8 waves 150 VGPR   8 KB LDS, 256 WGs": lambda s: lib.fat_launch(buf.data_ptr(), 256, 70, 8192, s),
     }
 
+    lib.sliver_gemm_launch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.sliver_gemm_launch.restype = C.c_int
+    shapes = {"head dgrad M 12864 N 256 K 256": (12864, 256, 256), "node-MLP dgrad M 1554 N 512 K 512": (1554, 512, 512),
+              "cfg2 dgrad M 6528 N 128 K 128": (6528, 128, 128)}
+    for label, (Mm, Nn, Kk) in shapes.items():
+        a_, w_ = torch.randn(Mm, Kk, device=DEV), torch.randn(Kk, Nn, device=DEV)
+        c_, c2_ = torch.empty(Mm, Nn, device=DEV), torch.empty(Mm, Nn, device=DEV)
+        keep.extend([a_, w_, c_, c2_])
+        rc = lib.sliver_gemm_launch(a_.data_ptr(), Kk, w_.data_ptr(), Nn, None, 0, c_.data_ptr(), Nn, Mm, Nn, Kk, 1,
+                                    torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        ref = a_.double() @ w_.double()
+        print(f"sliver GEMM {label}: rc {rc}, max rel err {float((c_.double() - ref).abs().max() / ref.abs().max()):.2e}")
+        fl = 2.0 * Mm * Nn * Kk
+        for prio in (0, 1):
+            probes[f"VALU sliver GEMM {label} prio {3 * prio} [{fl / 1e9:.2f} GF]"] = \
+                (lambda s, a_=a_, w_=w_, c_=c_, Mm=Mm, Nn=Nn, Kk=Kk, prio=prio:
+                 lib.sliver_gemm_launch(a_.data_ptr(), Kk, w_.data_ptr(), Nn, None, 0, c_.data_ptr(), Nn, Mm, Nn, Kk, prio, s))
+
+        def mfma(s, a_=a_, w_=w_, c2_=c2_, Mm=Mm, Nn=Nn):
+            with torch.cuda.stream(torch.cuda.ExternalStream(s)):
+                ops.gemm(Mm, Nn, [ops.seg(a_)], w_, c2_, w_layout=1)
+            return 0
+        probes[f"MFMA  dosx_gemm  {label}"] = mfma
+
     def gemm_probe(s):
         with torch.cuda.stream(torch.cuda.ExternalStream(s)):
             ops.gemm(1554, 512, [ops.seg(xa)], w, out, w_layout=1)
@@ -79,6 +105,8 @@ def main():
 
 def run_probes(probes, group, A, B):
     for name, fn in probes.items():
+        if not ("GEMM" in name or "gemm" in name):
+            continue
         def timed(under):
             res = []
             for _ in range(8):
