@@ -1224,10 +1224,93 @@ static int gemm_plan(const DosxGemm& g, GemmLaunch& L) {
   return bn;
 }
 
+// ---- vector-ALU "sliver" GEMM (round 4) ----------------------------------------------------------------------------------
+// C[M,N] = A[M,K] . W[K,N] (+ R[M,N]) for the SMALL plain dgrad GEMMs of the backward pass (w_layout 1, no prologue, no
+// bias / activation; <= DOSX_SLIVER_MAX_GF GF): 256 threads = 16 x 16, a 64 x 64 output tile, 4 x 4 per thread, k-chunks of 16
+// through 8.5 KB of LDS (A chunk stored k-major), the next chunk prefetched into registers, PACKED fp32 FMAs on the vector ALU
+// (v_pk_fma_f32: the same 157 TF/s peak as the fp32 MFMA), raised wave priority.  Why: these kernels run while a
+// weight-gradient group owns the chip - two workgroups of 8 waves / 107 VGPRs / 75 KB of LDS per CU, their matrix waves
+// issuing MFMAs back to back.  An MFMA kernel of the chain then waits for an EMPTY CU (it needs > 100 KB of LDS or > 128
+// VGPRs), and even a tiny co-resident MFMA workgroup gets ~1/15 of the matrix pipe (tools/exp/sliver_probe.py: a 10-us MFMA
+// probe takes 150-180 us behind a group whatever its footprint and priority).  This workgroup - 4 waves, 56 VGPRs, 8.5 KB -
+// FITS next to the two resident weight-gradient workgroups and computes on the pipe they leave idle: the same probe on the
+// vector ALU with s_setprio 3 takes 31-34 us; a 6528 x 128 x 128 dgrad 32 us behind a group against 170-190 us for the MFMA
+// kernel, the 1554 x 512 x 512 node-MLP dgrad 105 against 200-215 us (profiles/r04_sliver_probe.log).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int SG_T = 64, SG_K = 16;
+__global__ __launch_bounds__(256) void sliver_gemm_kernel(const DosxGemm g) {
+  __builtin_amdgcn_s_setprio(3);
+  __shared__ __align__(16) float As[SG_K][SG_T + 4];
+  __shared__ __align__(16) float Bs[SG_K][SG_T + 4];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int M = g.M, N = g.N, K = g.K;
+  const int m0 = blockIdx.x * SG_T, n0 = blockIdx.y * SG_T;
+  // staging: A chunk = 64 rows x 16 k (thread -> row tid / 4, k (tid % 4) * 4 ..+3), W chunk = 16 k x 64 n (thread -> k tid / 16, n (tid % 16) * 4)
+  const int ar = tid >> 2, ak = (tid & 3) * 4;
+  const int wk = tid >> 4, wn = (tid & 15) * 4;
+  const float* ap = g.a[0].p + (size_t)dosx_map_row(g.a[0].map, min(m0 + ar, M - 1)) * (size_t)g.a[0].ld + ak;
+  const float* wp = g.w + (size_t)wk * g.ldw + min(n0 + wn, N - 4);
+  float4 ra = ld4(ap), rw = ld4(wp);
+  f32x2 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { acc[i][0] = f32x2{0.f, 0.f}; acc[i][1] = f32x2{0.f, 0.f}; }
+  for (int k0 = 0; k0 < K; k0 += SG_K) {
+    __syncthreads();
+    As[ak + 0][ar] = ra.x; As[ak + 1][ar] = ra.y; As[ak + 2][ar] = ra.z; As[ak + 3][ar] = ra.w;
+    st4(&Bs[wk][wn], rw);
+    __syncthreads();
+    if (k0 + SG_K < K) {
+      ra = ld4(ap + k0 + SG_K);
+      rw = ld4(wp + (size_t)(k0 + SG_K) * g.ldw);
+    }
+#pragma unroll
+    for (int k = 0; k < SG_K; ++k) {
+      const float4 a = ld4(&As[k][ty * 4]);
+      const float4 b = ld4(&Bs[k][tx * 4]);
+      const f32x2 b01 = {b.x, b.y}, b23 = {b.z, b.w};
+      acc[0][0] += f32x2{a.x, a.x} * b01; acc[0][1] += f32x2{a.x, a.x} * b23;
+      acc[1][0] += f32x2{a.y, a.y} * b01; acc[1][1] += f32x2{a.y, a.y} * b23;
+      acc[2][0] += f32x2{a.z, a.z} * b01; acc[2][1] += f32x2{a.z, a.z} * b23;
+      acc[3][0] += f32x2{a.w, a.w} * b01; acc[3][1] += f32x2{a.w, a.w} * b23;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = m0 + ty * 4 + i, c = n0 + tx * 4;
+    if (r < M && c < N) {
+      float4 o = make_float4(acc[i][0][0], acc[i][0][1], acc[i][1][0], acc[i][1][1]);
+      if (g.res) o = f4add(o, ld4(g.res + (size_t)r * g.ldr + c));
+      st4(g.out + (size_t)r * g.ldo + c, o);
+    }
+  }
+}
+
+// which calls take the sliver kernel (host side): plain dgrad GEMMs small enough that latency under a weight-gradient group,
+// not throughput, is what they cost.  DOSX_SLIVER_MAX_GF (default 1.0; 0 = never): the flop limit in GF.
+static bool sliver_ok(const DosxGemm& g) {
+  static double max_flop = -1.0;
+  if (max_flop < 0.0) {
+    const char* e = getenv("DOSX_SLIVER_MAX_GF");
+    max_flop = (e ? atof(e) : 1.0) * 1e9;
+  }
+  if (max_flop <= 0.0 || 2.0 * g.M * (double)g.N * g.K > max_flop) return false;
+  const bool ident_out = g.out_map.d >= (1 << 30) && g.out_map.idx == nullptr && g.out_map.c == 1 && g.out_map.off == 0;
+  const bool ident_res = !g.res || (g.res_map.d >= (1 << 30) && g.res_map.idx == nullptr && g.res_map.c == 1 && g.res_map.off == 0 &&
+                                    g.res_col0 == 0 && (g.ldr & 3) == 0 && aligned16(g.res));
+  return g.w_layout == 1 && g.pro == DOSX_PRO_NONE && g.epi == DOSX_EPI_BIAS_ACT && g.act == 0 && !g.bias &&
+         g.nseg == 1 && !g.stats_out && !g.norm_out && !g.aux_out && g.out && ident_out && ident_res && (g.K % SG_K) == 0 &&
+         (g.N & 3) == 0 && g.N >= 4 && g.M >= 1 && (g.a[0].ld & 3) == 0 && aligned16(g.a[0].p) && (g.ldw & 3) == 0 &&
+         aligned16(g.w) && (g.ldo & 3) == 0 && aligned16(g.out);
+}
+
 // The device symbol dosx_gemm would launch for this descriptor, as rocprofv3 prints it ("gemm_kernel<RT, NTW, WL, PRO,
 // VEC, EPI>"): lets a profiler-side tool (bench.py's roofline, tools/pmc_traffic.py) tie a call site to its kernel.
 extern "C" int dosx_gemm_kernel_name(const DosxGemm* gp, char* buf, int n) {
   DOSX_CHECK_ARG(gp && buf && n > 0, "dosx_gemm_kernel_name: bad args");
+  if (sliver_ok(*gp)) {
+    snprintf(buf, (size_t)n, "sliver_gemm_kernel");
+    return 0;
+  }
   GemmLaunch L;
   const int bn = gemm_plan(*gp, L);
   const int vec = L.vecA && L.vecW;
@@ -1288,9 +1371,14 @@ extern "C" int dosx_gemm(const DosxGemm* gp, dosx_stream_t stream) {
                    "dosx_gemm: EPI_SEGSUM needs seg_tile / seg_rowptr / seg_agg / seg_part / seg_cnt, N <= 256, an identity "
                    "out_map and res with out");
 
+  hipStream_t s = to_stream(stream);
+  if (sliver_ok(g)) {
+    hipLaunchKernelGGL(sliver_gemm_kernel, dim3(ceil_div(g.M, SG_T), ceil_div(g.N, SG_T)), dim3(256), 0, s, g);
+    DOSX_LAUNCH_CHECK();
+    return 0;
+  }
   GemmLaunch L;
   const int bn = gemm_plan(g, L);
-  hipStream_t s = to_stream(stream);
   if (bn == 128) return dispatch_gemm<1>(L, s);
   if (bn == 256) return dispatch_gemm<2>(L, s);
   return dispatch_gemm<4>(L, s);

@@ -660,3 +660,41 @@ def test_wide_hidden_through_predictor_dataset_and_edos_graphnetwork():
         ref, rx = O.graphnetwork_forward(params, ge, 2)
     rmse = lambda u, v: float(torch.sqrt(((u.detach().cpu().double() - v.double()) ** 2).mean()))
     assert rmse(out, ref) < 1e-4 and rmse(xn, rx) < 1e-4 * max(1.0, float(rx.abs().max()))
+
+
+# ---- vector-ALU sliver GEMM for the small dgrad GEMMs of the backward pass ----------------------------------------------------
+
+@pytest.mark.parametrize("M,N,K,mapped,res", [(6528, 128, 128, False, False), (1554, 512, 512, False, True), (450, 256, 256, False, False),
+                                              (3264, 128, 256, True, True), (70, 68, 48, False, True), (1, 4, 16, False, False),
+                                              (12864, 256, 256, True, False)])
+def test_sliver_gemm_matches_float64(M, N, K, mapped, res):
+    """dosx_gemm routes small plain dgrad GEMMs (w_layout 1, no prologue / bias / activation, <= 1 GF) to the vector-ALU
+    kernel with the co-residable footprint (csrc/gemm.hip: sliver_gemm_kernel): against float64, with a div/mod row map on A
+    (the heads' dgrad), a residual, ragged tiles; larger problems keep the MFMA kernels."""
+    from dostransformer_amd import _lib
+    from dostransformer_amd._lib import Gemm
+    o = ops()
+    rows_a = 2 * M if mapped else M
+    a, w = rnd(rows_a, K, seed=1), rnd(K, N, seed=2)
+    r = rnd(M, N, seed=3) if res else None
+    out = torch.full((M, N), float("nan"), device=DEV)
+    B = max(M // 51, 1)
+    rm = o.rowmap(d=B, m=2 * B, c=1, off=B) if (mapped and M % 51 == 0) else None
+    if mapped and rm is None:
+        pytest.skip("row-map case needs M = 51 * B")
+    o.gemm(M, N, [o.seg(a, rmap=rm)], w, out, w_layout=1, res=r)
+    torch.cuda.synchronize()
+    idx = torch.arange(M, device=DEV)
+    if rm is not None:
+        idx = (idx // B) * (2 * B) + (idx % B) + B
+    ref = a.double()[idx] @ w.double() + (r.double() if res else 0.0)
+    assert not torch.isnan(out).any() and err(out, ref) < TOL
+    g = Gemm()
+    g.M, g.N, g.K, g.nseg = M, N, K, 1
+    g.a[0] = o.seg(a, rmap=rm)
+    g.w, g.ldw, g.w_layout = w.data_ptr(), N, 1
+    g.out, g.ldo, g.out_map, g.res_map = out.data_ptr(), N, o.ident(), o.ident()
+    buf = C.create_string_buffer(96)
+    _lib.load().dosx_gemm_kernel_name(C.byref(g), buf, 96)
+    small = 2.0 * M * N * K <= 1e9
+    assert (buf.value.decode() == "sliver_gemm_kernel") == small, buf.value
