@@ -1226,7 +1226,7 @@ static int gemm_plan(const DosxGemm& g, GemmLaunch& L) {
 
 // ---- vector-ALU "sliver" GEMM (round 4) ----------------------------------------------------------------------------------
 // C[M,N] = A[M,K] . W[K,N] (+ R[M,N]) for the SMALL plain dgrad GEMMs of the backward pass (w_layout 1, no prologue, no
-// bias / activation; <= DOSX_SLIVER_MAX_GF GF): 256 threads = 16 x 16, a 64 x 64 output tile, 4 x 4 per thread, k-chunks of 16
+// bias / activation; <= DOSX_SLIVER_MAX_GF = 2 GF): 256 threads = 16 x 16, a 64 x 64 output tile, 4 x 4 per thread, k-chunks of 16
 // through 8.5 KB of LDS (A chunk stored k-major), the next chunk prefetched into registers, PACKED fp32 FMAs on the vector ALU
 // (v_pk_fma_f32: the same 157 TF/s peak as the fp32 MFMA), raised wave priority.  Why: these kernels run while a
 // weight-gradient group owns the chip - two workgroups of 8 waves / 107 VGPRs / 75 KB of LDS per CU, their matrix waves
@@ -1286,12 +1286,12 @@ __global__ __launch_bounds__(256) void sliver_gemm_kernel(const DosxGemm g) {
 }
 
 // which calls take the sliver kernel (host side): plain dgrad GEMMs small enough that latency under a weight-gradient group,
-// not throughput, is what they cost.  DOSX_SLIVER_MAX_GF (default 1.0; 0 = never): the flop limit in GF.
+// not throughput, is what they cost.  DOSX_SLIVER_MAX_GF (default 2.0; 0 = never): the flop limit in GF.
 static bool sliver_ok(const DosxGemm& g) {
   static double max_flop = -1.0;
   if (max_flop < 0.0) {
     const char* e = getenv("DOSX_SLIVER_MAX_GF");
-    max_flop = (e ? atof(e) : 1.0) * 1e9;
+    max_flop = (e ? atof(e) : 2.0) * 1e9;
   }
   if (max_flop <= 0.0 || 2.0 * g.M * (double)g.N * g.K > max_flop) return false;
   const bool ident_out = g.out_map.d >= (1 << 30) && g.out_map.idx == nullptr && g.out_map.c == 1 && g.out_map.off == 0;

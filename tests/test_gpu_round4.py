@@ -666,10 +666,10 @@ def test_wide_hidden_through_predictor_dataset_and_edos_graphnetwork():
 
 @pytest.mark.parametrize("M,N,K,mapped,res", [(6528, 128, 128, False, False), (1554, 512, 512, False, True), (450, 256, 256, False, False),
                                               (3264, 128, 256, True, True), (70, 68, 48, False, True), (1, 4, 16, False, False),
-                                              (12864, 256, 256, True, False)])
+                                              (12864, 256, 256, True, False), (25728, 256, 256, False, False)])
 def test_sliver_gemm_matches_float64(M, N, K, mapped, res):
     """dosx_gemm routes small plain dgrad GEMMs (w_layout 1, no prologue / bias / activation, <= 1 GF) to the vector-ALU
-    kernel with the co-residable footprint (csrc/gemm.hip: sliver_gemm_kernel): against float64, with a div/mod row map on A
+    kernel with the co-residable footprint (csrc/gemm.hip: sliver_gemm_kernel; <= 2 GF): against float64, with a div/mod row map on A
     (the heads' dgrad), a residual, ragged tiles; larger problems keep the MFMA kernels."""
     from dostransformer_amd import _lib
     from dostransformer_amd._lib import Gemm
@@ -696,5 +696,5 @@ def test_sliver_gemm_matches_float64(M, N, K, mapped, res):
     g.out, g.ldo, g.out_map, g.res_map = out.data_ptr(), N, o.ident(), o.ident()
     buf = C.create_string_buffer(96)
     _lib.load().dosx_gemm_kernel_name(C.byref(g), buf, 96)
-    small = 2.0 * M * N * K <= 1e9
+    small = 2.0 * M * N * K <= 2e9
     assert (buf.value.decode() == "sliver_gemm_kernel") == small, buf.value
