@@ -178,6 +178,7 @@ class Call(C.Structure):
 _P, _I, _F, _L, _D = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_double
 _SIGS = {
     "dosx_gemm_partial_rows": [_I, _I, _I],
+    "dosx_set_sliver_max_gf": [_D],
     "dosx_gemm": [C.POINTER(Gemm), _P],
     "dosx_gemm_kernel_name": [C.POINTER(Gemm), C.c_char_p, _I],
     "dosx_wgrad_splits": [_I, _I, _I],

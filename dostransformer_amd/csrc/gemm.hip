@@ -1226,7 +1226,7 @@ static int gemm_plan(const DosxGemm& g, GemmLaunch& L) {
 
 // ---- vector-ALU "sliver" GEMM (round 4) ----------------------------------------------------------------------------------
 // C[M,N] = A[M,K] . W[K,N] (+ R[M,N]) for the SMALL plain dgrad GEMMs of the backward pass (w_layout 1, no prologue, no
-// bias / activation; <= DOSX_SLIVER_MAX_GF = 2 GF): 256 threads = 16 x 16, a 64 x 64 output tile, 4 x 4 per thread, k-chunks of 16
+// bias / activation; up to DOSX_SLIVER_MAX_GF GF - an experiment, OFF by default): 256 threads = 16 x 16, a 64 x 64 output tile, 4 x 4 per thread, k-chunks of 16
 // through 8.5 KB of LDS (A chunk stored k-major), the next chunk prefetched into registers, PACKED fp32 FMAs on the vector ALU
 // (v_pk_fma_f32: the same 157 TF/s peak as the fp32 MFMA), raised wave priority.  Why: these kernels run while a
 // weight-gradient group owns the chip - two workgroups of 8 waves / 107 VGPRs / 75 KB of LDS per CU, their matrix waves
@@ -1286,13 +1286,17 @@ __global__ __launch_bounds__(256) void sliver_gemm_kernel(const DosxGemm g) {
 }
 
 // which calls take the sliver kernel (host side): plain dgrad GEMMs small enough that latency under a weight-gradient group,
-// not throughput, is what they cost.  DOSX_SLIVER_MAX_GF (default 2.0; 0 = never): the flop limit in GF.
+// not throughput, is what they cost.  DOSX_SLIVER_MAX_GF / dosx_set_sliver_max_gf: the flop limit in GF; DEFAULT 0 = never.
+// Measured in the step (tools/exp/ab_sliver*.sh, tools/exp/sliver_sites.sh): the routed kernels do get faster
+// (Electron-DOS: the head dgrads 237 -> 101 us, the node-MLP dgrad 99 -> 65 us) but the kernels BEHIND them then wait longer
+// for the same weight-gradient group - the step moves by -0.2 .. -0.4 % (Electron-DOS) and by +-1 % box-to-box noise (Phonon-DOS).
+static double g_sliver_max_flop = -1.0;
 static bool sliver_ok(const DosxGemm& g) {
-  static double max_flop = -1.0;
-  if (max_flop < 0.0) {
+  if (g_sliver_max_flop < 0.0) {
     const char* e = getenv("DOSX_SLIVER_MAX_GF");
-    max_flop = (e ? atof(e) : 2.0) * 1e9;
+    g_sliver_max_flop = (e ? atof(e) : 0.0) * 1e9;
   }
+  const double max_flop = g_sliver_max_flop;
   if (max_flop <= 0.0 || 2.0 * g.M * (double)g.N * g.K > max_flop) return false;
   const bool ident_out = g.out_map.d >= (1 << 30) && g.out_map.idx == nullptr && g.out_map.c == 1 && g.out_map.off == 0;
   const bool ident_res = !g.res || (g.res_map.d >= (1 << 30) && g.res_map.idx == nullptr && g.res_map.c == 1 && g.res_map.off == 0 &&
@@ -1301,6 +1305,11 @@ static bool sliver_ok(const DosxGemm& g) {
          g.nseg == 1 && !g.stats_out && !g.norm_out && !g.aux_out && g.out && ident_out && ident_res && (g.K % SG_K) == 0 &&
          (g.N & 3) == 0 && g.N >= 4 && g.M >= 1 && (g.a[0].ld & 3) == 0 && aligned16(g.a[0].p) && (g.ldw & 3) == 0 &&
          aligned16(g.w) && (g.ldo & 3) == 0 && aligned16(g.out);
+}
+
+extern "C" int dosx_set_sliver_max_gf(double gf) {      // experiments / tests: route plain dgrad GEMMs of up to `gf` GF to sliver_gemm_kernel
+  g_sliver_max_flop = gf > 0.0 ? gf * 1e9 : 0.0;
+  return 0;
 }
 
 // The device symbol dosx_gemm would launch for this descriptor, as rocprofv3 prints it ("gemm_kernel<RT, NTW, WL, PRO,

@@ -132,6 +132,10 @@ typedef struct DosxGemm {
 
 /* exact number of workgroup rows dosx_gemm writes into `partials` for this epilogue: ceil(M/32) for
  * the row-wise epilogues, ceil(M/32)*ceil(N/128) for the element-wise PRELU_BWD epilogue. */
+/* Experiment switch (round 4, default 0 = off; also DOSX_SLIVER_MAX_GF in the environment): plain dgrad GEMMs (w_layout 1, no
+ * prologue / bias / activation, one segment, identity out / residual maps) of up to `gf` GFLOP run on a vector-ALU kernel whose
+ * workgroups (4 waves, 56 VGPRs, 8.5 KB of LDS) fit next to two resident weight-gradient workgroups. */
+int dosx_set_sliver_max_gf(double gf);
 int dosx_gemm_partial_rows(int M, int N, int epi);
 int dosx_gemm(const DosxGemm* g, dosx_stream_t stream);
 /* diagnostic: the device symbol dosx_gemm launches for this descriptor, as a profiler prints it

@@ -668,12 +668,20 @@ def test_wide_hidden_through_predictor_dataset_and_edos_graphnetwork():
                                               (3264, 128, 256, True, True), (70, 68, 48, False, True), (1, 4, 16, False, False),
                                               (12864, 256, 256, True, False), (25728, 256, 256, False, False)])
 def test_sliver_gemm_matches_float64(M, N, K, mapped, res):
-    """dosx_gemm routes small plain dgrad GEMMs (w_layout 1, no prologue / bias / activation, <= 1 GF) to the vector-ALU
-    kernel with the co-residable footprint (csrc/gemm.hip: sliver_gemm_kernel; <= 2 GF): against float64, with a div/mod row map on A
+    """With dosx_set_sliver_max_gf(2) dosx_gemm routes small plain dgrad GEMMs (w_layout 1, no prologue / bias / activation) to
+    the vector-ALU kernel with the co-residable footprint (csrc/gemm.hip: sliver_gemm_kernel): against float64, with a div/mod row map on A
     (the heads' dgrad), a residual, ragged tiles; larger problems keep the MFMA kernels."""
     from dostransformer_amd import _lib
     from dostransformer_amd._lib import Gemm
     o = ops()
+    _lib.load().dosx_set_sliver_max_gf(2.0)             # (an experiment switch: off by default)
+    try:
+        _sliver_case(o, _lib, Gemm, M, N, K, mapped, res)
+    finally:
+        _lib.load().dosx_set_sliver_max_gf(0.0)
+
+
+def _sliver_case(o, _lib, Gemm, M, N, K, mapped, res):
     rows_a = 2 * M if mapped else M
     a, w = rnd(rows_a, K, seed=1), rnd(K, N, seed=2)
     r = rnd(M, N, seed=3) if res else None
