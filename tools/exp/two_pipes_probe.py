@@ -52,6 +52,31 @@ def main():
     _, tb = timed(None, sliver_loop)
     fls = 2.0 * Ms * Ns * Ks * n_s
     print(f"sliver GEMMs alone: {n_s} x 1.69 GF in {tb:.0f} us = {fls / tb / 1e6:.1f} TF/s")
+    # the co-residable MFMA kernel: a weight-gradient group (2 workgroups of 107 VGPRs / 75 KB per CU leave room for a sliver)
+    keep = []
+
+    def job(Mw, Nw, Kw):
+        dy, a_ = torch.randn(Mw, Nw, device=DEV), torch.randn(Mw, Kw, device=DEV)
+        ns = ops.wgrad_splits(Mw, Nw, Kw)
+        slab = torch.empty(max(ops.wgrad_scratch_floats(Nw, Kw, ns), 1), device=DEV)
+        sb = torch.empty(ns * ((Nw + 63) // 64) * 64, device=DEV)
+        dw, db = torch.empty(Nw, Kw, device=DEV), torch.empty(Nw, device=DEV)
+        keep.extend([dy, a_, slab, sb, dw, db])
+        return ops.wgrad_desc(Mw, Nw, ops.seg(dy), [ops.seg(a_)], slab, sb, ns, dst=dw, dst_bias=db)
+    group = [job(M, 1024, 256), job(M, 256, 1024), job(M, 1024, 256), job(M, 256, 1024)]
+    n_g = 4
+
+    def wgrad_loop():
+        for _ in range(n_g):
+            ops.wgrad_grouped(group)
+    for _ in range(2):
+        timed(wgrad_loop, None)
+    tg, _ = timed(wgrad_loop, None)
+    flg = 2.0 * M * 1024 * 256 * 4 * n_g
+    tg2, tb2 = timed(wgrad_loop, sliver_loop)
+    tot = max(tg2, tb2)
+    print(f"weight-gradient groups: alone {tg:.0f} us ({flg / tg / 1e6:.1f} TF/s) | together: groups {tg2:.0f} us, sliver {tb2:.0f} us -> "
+          f"aggregate {(flg + fls) / tot / 1e6:.1f} TF/s in {tot:.0f} us (serial would be {tg + tb:.0f} us)")
     for name, c in cases.items():
         N, K = c["N"], c["K"]
         a = torch.randn(M, K, device=DEV)
