@@ -65,7 +65,7 @@ class Wgrad(C.Structure):
         ("pro_gamma", C.c_void_p), ("pro_beta", C.c_void_p), ("pro_alpha", C.c_void_p), ("pro_stats", C.c_void_p),
         ("slab", C.c_void_p), ("slab_bias", C.c_void_p),
         ("nsplit", C.c_int32), ("accumulate", C.c_int32),
-        ("dst", C.c_void_p), ("dst_bias", C.c_void_p), ("counters", C.c_void_p),
+        ("dst", C.c_void_p), ("dst_bias", C.c_void_p), ("counters", C.c_void_p), ("ldd", C.c_int32),
     ]
 
 
@@ -191,6 +191,7 @@ _SIGS = {
     "dosx_edge_feat_sh1": [_P, _P, _I, _F, _P],
     "dosx_edge_embed_sh1": [_P, _P, _P, _P, _P, _I, _I, _F, _P],
     "dosx_segment_reduce": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "dosx_segment_reduce_perm": [_P, _P, _P, _P, _I, _I, _I, _P],
     "dosx_edge_grad_combine": [_P, _I, _P, _I, _P, _P, _P, _I, _I, _P],
     "dosx_gather_bwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "dosx_graph_pool": [_P, _P, _P, _I, _I, _I, _P],

@@ -1459,12 +1459,13 @@ __device__ __forceinline__ void wgrad_finish(const DosxWgrad& g, float* __restri
   }
   // lane -> NH float4 of the tile: element index e = tid + 512 h (row e >> 4, columns 4 * (e & 15) ..)
   auto write_dst = [&](const float4 (&v)[NH], const float bfin) {
-    const bool vec_ok = ((K & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.dst) & 15) == 0);
+    const size_t ldd = g.ldd > 0 ? (size_t)g.ldd : (size_t)K;
+    const bool vec_ok = ((K & 3) == 0) && ((ldd & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.dst) & 15) == 0);
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       const int e = tid + 512 * h, n = n0 + (e >> 4), k = k0 + (e & 15) * 4;
       if (n >= N || k >= K) continue;
-      float* d = g.dst + (size_t)n * K + k;
+      float* d = g.dst + (size_t)n * ldd + k;
       if (vec_ok) {                                       // (K % 4 == 0: k < K means k + 3 < K)
         st4(d, g.accumulate ? f4add(ld4(d), v[h]) : v[h]);
       } else {
@@ -2046,6 +2047,7 @@ int wgrad_prepare(const DosxWgrad& g, WgradLaunch& L, int& vec, bool& fast, int&
     DOSX_CHECK_ARG(g.counters != nullptr || g.nsplit == 1, "dosx_wgrad: finished mode needs tile counters");
     DOSX_CHECK_ARG(!g.dst_bias || g.slab_bias || g.nsplit == 1, "dosx_wgrad: dst_bias needs the slab_bias scratch");
     DOSX_CHECK_ARG(!g.slab_bias || g.dst_bias, "dosx_wgrad: finished mode with slab_bias needs dst_bias");
+    DOSX_CHECK_ARG(g.ldd == 0 || g.ldd >= g.K, "dosx_wgrad: ldd=%d < K=%d", g.ldd, g.K);
     DOSX_CHECK_ARG(dosx_wgrad_scratch_floats(g.N, g.K, g.nsplit) * 4 < 0x7fffffffll, "dosx_wgrad: scratch slab beyond 2 GiB");
     DOSX_CHECK_ARG(g.nsplit <= 64, "dosx_wgrad: nsplit=%d", g.nsplit);
   }

@@ -129,6 +129,37 @@ __global__ __launch_bounds__(128) void segment_reduce_kernel(const float* __rest
   }
 }
 
+// agg[n] = sum_{j in seg(n)} msg[perm[j]]: the segment sums over a permuted row order (rowptr_src / perm_src: the edges that
+// leave node n).  One wave per node, two per workgroup, up to SR_U rows per lane slot in flight (their indices first).
+__global__ __launch_bounds__(128) void segment_reduce_perm_kernel(const float* __restrict__ msg, const int* __restrict__ rowptr,
+                                                                  const int* __restrict__ perm, float* __restrict__ agg, int N,
+                                                                  int H) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 2 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const RowLanes rl = row_lanes(H, lane);
+  const int beg = rowptr[n], end = rowptr[n + 1];
+  for (int cb = 0; cb < H; cb += 256) {
+    const int c = cb + rl.c4;
+    const bool cok = c < H;
+    const int cc = cok ? c : 0;
+    float4 acc = f4zero();
+    for (int j0 = beg + rl.slot; j0 < end; j0 += SR_U * rl.rps) {
+      int ei[SR_U];
+#pragma unroll
+      for (int u = 0; u < SR_U; ++u) ei[u] = perm[min(j0 + u * rl.rps, end - 1)];
+      float4 m[SR_U];
+#pragma unroll
+      for (int u = 0; u < SR_U; ++u) m[u] = ld4(msg + (size_t)ei[u] * H + cc);
+#pragma unroll
+      for (int u = 0; u < SR_U; ++u)
+        if (j0 + u * rl.rps < end) acc = f4add(acc, m[u]);
+    }
+    acc = slots_sum(acc, rl.lpr);
+    if (cok && rl.slot == 0) st4(agg + (size_t)n * H + c, acc);
+  }
+}
+
 // dmsg[e] = de_new[e] + scale[dst[e]] * dagg[dst[e]]   (element-wise over E*H/4 float4; de_new rows ld_de floats apart:
 // it is the e-block of the previous layer's [E,3H] concat gradient)
 __global__ void edge_grad_combine_kernel(const float* __restrict__ de_new, int ld_de, const float* __restrict__ dagg,
@@ -618,6 +649,17 @@ extern "C" int dosx_segment_reduce(const float* msg, const int32_t* rowptr, cons
   DOSX_CHECK_ARG(msg && rowptr && agg && (!e_out || e_in), "dosx_segment_reduce: bad args");
   hipLaunchKernelGGL(segment_reduce_kernel, dim3(ceil_div(N, 2)), dim3(128), 0, to_stream(stream), msg, rowptr, scale,
                      agg, e_in, e_out, N, H);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_segment_reduce_perm(const float* msg, const int32_t* rowptr, const int32_t* perm, float* agg, int N, int E,
+                                        int H, dosx_stream_t stream) {
+  (void)E;
+  if (N <= 0) return 0;
+  CHECK_H(H);
+  DOSX_CHECK_ARG(msg && rowptr && perm && agg, "dosx_segment_reduce_perm: bad args");
+  hipLaunchKernelGGL(segment_reduce_perm_kernel, dim3(ceil_div(N, 2)), dim3(128), 0, to_stream(stream), msg, rowptr, perm, agg, N, H);
   DOSX_LAUNCH_CHECK();
   return 0;
 }

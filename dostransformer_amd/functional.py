@@ -65,7 +65,7 @@ _TAIL_SPLITS = int(__import__("os").environ.get("DOSX_WGRAD_TAIL_SPLITS", "32"))
 
 
 def _wgrad_linear(sink: GradSink, G: Params, wkey: str, bkey: Optional[str], M: int, N: int, dy: Seg,
-                  segs: Sequence[Seg], keep=(), tail: bool = False, **pro) -> None:
+                  segs: Sequence[Seg], keep=(), tail: bool = False, dst: Optional[torch.Tensor] = None, **pro) -> None:
     """dW (and db) of y = A W^T + b as split slabs + reduce jobs (launched on the sink's side stream;
     ``keep``: the tensor(s) behind ``dy`` that the caller may drop before the side stream has run)."""
     if wkey not in G:
@@ -81,7 +81,7 @@ def _wgrad_linear(sink: GradSink, G: Params, wkey: str, bkey: Optional[str], M: 
     nsc = ops.wgrad_scratch_floats(N, K, ns)
     slab = sink.scratch(nsc) if nsc else None
     slab_b = sink.scratch(ns * ((N + 63) // 64) * 64) if (bkey is not None and ns > 1) else None
-    kw = dict(dst=G[wkey], dst_bias=G[bkey] if bkey is not None else None, **pro)
+    kw = dict(dst=G[wkey] if dst is None else dst, dst_bias=G[bkey] if bkey is not None else None, **pro)
     keep = tuple(keep) + tuple(t for t in pro.values() if isinstance(t, torch.Tensor))
     if GradSink.group_wgrad:
         sink.defer_wgrad(ops.wgrad_desc(M, N, dy, segs, slab, slab_b, ns, **kw), keep)
@@ -201,7 +201,29 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
     sink.add(part, 0, G[key + ".1.weight"], rows, pld, 2 * H)
     sink.add(part, 2 * H, G[key + ".1.bias"], rows, pld, 2 * H)
     sink.add(part, pld - 1, G[key + ".2.weight"], rows, pld, 1)
-    _wgrad_linear(sink, G, key + ".0.weight", key + ".0.bias", M, 2 * H, seg(dz), a.segs, keep=(dz,))
+    fac = getattr(a, "factor", None)
+    if fac is not None and _FACTOR_EDGE_WGRAD and key + ".0.weight" in G:
+        # The first Linear reads cat[x[row], x[col], e] (DOSTransformer_phonon.py:193-195): its weight gradient is
+        #   sum_e dz_e (x) [x[row(e)] | x[col(e)] | e_e]  =  [ sum_n S_n (x) x_n | sum_n D_n (x) x_n | sum_e dz_e (x) e_e ],
+        # S_n / D_n = the sums of dz over the edges that leave / enter node n.  The two node blocks become N-row jobs (20 x
+        # fewer rows at 20 edges per node) behind two memory-bound segment sums that run on the weight-gradient stream in
+        # front of the group; the edge block keeps its E rows on a third of the columns.  Three jobs write the three column
+        # blocks of the one gradient (DosxWgrad.ldd); fixed summation orders, like everything else here.
+        x, e, m = fac
+        N_, E_ = m.num_nodes, m.num_edges
+        aggS, aggD = sink.scratch(N_, 2 * H), sink.scratch(N_, 2 * H)
+
+        def node_sums(dz=dz, aggS=aggS, aggD=aggD, m=m):
+            ops.segment_reduce_perm(dz, m.rowptr_src, m.perm_src, aggS, N_, E_, 2 * H)
+            ops.segment_reduce(dz, m.rowptr_dst, None, aggD, None, None, N_, E_, 2 * H)
+        sink.defer_pre(node_sums, keep=(dz,))
+        Gw = G[key + ".0.weight"]                      # [2H, 3H]
+        with ops.graph_rows():
+            _wgrad_linear(sink, G, key + ".0.weight", None, N_, 2 * H, seg(aggS), [seg(x)], keep=(aggS, x), dst=Gw[:, :H])
+            _wgrad_linear(sink, G, key + ".0.weight", None, N_, 2 * H, seg(aggD), [seg(x)], keep=(aggD, x), dst=Gw[:, H:2 * H])
+            _wgrad_linear(sink, G, key + ".0.weight", key + ".0.bias", M, 2 * H, seg(dz), [seg(e)], keep=(dz, e), dst=Gw[:, 2 * H:])
+    else:
+        _wgrad_linear(sink, G, key + ".0.weight", key + ".0.bias", M, 2 * H, seg(dz), a.segs, keep=(dz,))
     if not fused:
         ops.gemm(M, a.K, [seg(dz)], P[key + ".0.weight"], dcat, w_layout=1, res=res, res_col0=res_col0 if res is not None else 0)
     return dcat
@@ -218,6 +240,7 @@ def gnn_fwd(P: Params, m: GraphMeta, x: torch.Tensor, e: torch.Tensor, L: int, m
     for l in range(L):
         pre = f"stacked_processor.{l}"
         a_e = SegList([seg(x, rmap=rowmap(idx=m.src)), seg(x, rmap=rowmap(idx=m.dst)), seg(e)], [x, e])
+        a_e.factor = (x, e, m)                  # (the parts behind the gathered concat: mlp_ln_bwd factors the weight gradient)
         agg = _empty(dev, N, H)
         last = l == L - 1                       # the last layer's edge update is dead
         e_new = None if last else _empty(dev, E, H)
@@ -408,6 +431,7 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
 
 
 _FUSED_FFN_BWD = __import__("os").environ.get("DOSX_FUSED_FFN_BWD", "1") == "1"
+_FACTOR_EDGE_WGRAD = __import__("os").environ.get("DOSX_FACTOR_EDGE_WGRAD", "1") == "1"   # node blocks of the EdgeModel weight gradient as N-row jobs
 _FUSED_ATT_FFN = __import__("os").environ.get("DOSX_FUSED_ATT_FFN", "1") == "1"       # <= 16-key attention inside dosx_ffn_fwd
 _ATT_FFN_MAX_ROWS = int(__import__("os").environ.get("DOSX_ATT_FFN_MAX_ROWS", "4096"))
 _FUSED_DKV = __import__("os").environ.get("DOSX_FUSED_DKV", "1") == "1"

@@ -566,8 +566,11 @@ def wgrad_desc(M: int, N: int, dy: Seg, segs: Sequence[Seg], slab: Optional[torc
     g.slab, g.slab_bias, g.nsplit = _p(slab), _p(slab_bias), int(nsplit)
     g._real_M = _real(g.M)            # (the job is launched later, at a flush point outside the scope it was described in)
     if dst is not None:
-        assert dst.is_contiguous() and dst.numel() == g.N * g.K and dst.dtype == torch.float32
+        # [N, K] contiguous, or a column block of a wider gradient (unit inner stride): DosxWgrad.ldd
+        assert dst.dtype == torch.float32 and dst.numel() == g.N * g.K and (dst.is_contiguous() or (dst.dim() == 2 and dst.stride(1) == 1))
         g.dst, g.dst_bias, g.accumulate = dst.data_ptr(), _p(dst_bias), int(bool(accumulate))
+        if not dst.is_contiguous():
+            g.ldd = int(dst.stride(0))
         if nsplit > 1:
             g.counters = COUNTERS.take(dst.device, wgrad_tiles(g.N, g.K))
     return g
@@ -673,14 +676,32 @@ class GradSink:
         return jobs
 
     def run_grouped(self) -> None:
+        self._run_pre()
         jobs = self._take_wjobs()
         if jobs:
             wgrad_grouped(jobs)
+
+    def defer_pre(self, fn, keep=()) -> None:
+        """``fn`` (kernel launches) runs on the stream of the next flush, right in front of its grouped launch: producers of
+        operands that only the deferred weight-gradient jobs read (the per-node sums of functional.mlp_ln_bwd)."""
+        self._keep.extend(keep)
+        if not GradSink.group_wgrad:          # jobs are launched as they are described: so are their producers
+            fn()
+            return
+        if not hasattr(self, "_pre"):
+            self._pre = []
+        self._pre.append(fn)
+
+    def _run_pre(self) -> None:
+        for fn in getattr(self, "_pre", []):
+            fn()
+        self._pre = []
 
     def _flush_launch(self, rjobs) -> None:
         """ONE launch for a flush point: the pending weight-gradient jobs (finished mode: they write the gradients
         themselves) + the first wave of row-partial reductions; reductions that share a destination with an earlier one
         follow in launches of their own (they accumulate)."""
+        self._run_pre()
         wjobs = self._take_wjobs()
         # finished-mode jobs that target the same gradient: the later ones accumulate, each in a later launch
         waves_w: List[list] = []
@@ -822,6 +843,12 @@ def segment_reduce(msg, rowptr, scale, agg, e_in, e_out, N, E, H):
     _call("dosx_segment_reduce", _p(msg), _p(rowptr), _p(scale), _p(agg), _p(e_in), _p(e_out), N, E, H, _stream(),
           w=lambda: (f"scatter_add_fwd[H{H}{',res' if e_out is not None else ''}]", "segment_reduce_kernel", "hbm",
                      4.0 * (_real(E) * H + (_real(N) + 1) + _real(N) * H + (2 * _real(E) * H if e_out is not None else 0))))
+
+
+def segment_reduce_perm(msg, rowptr, perm, agg, N, E, H):
+    """agg[n] = sum of msg[perm[j]] over j in [rowptr[n], rowptr[n+1])   (include/dosx.h: dosx_segment_reduce_perm)"""
+    _call("dosx_segment_reduce_perm", _p(msg), _p(rowptr), _p(perm), _p(agg), N, E, H, _stream(),
+          w=lambda: (f"segment_sum_perm[H{H}]", "segment_reduce_perm_kernel", "hbm", 4.0 * (_real(E) * H + _real(E) + (_real(N) + 1) + _real(N) * H)))
 
 
 def edge_grad_combine(de_new, dagg, ld_dagg, dst, scale, dmsg, E, H):

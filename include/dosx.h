@@ -172,6 +172,9 @@ typedef struct DosxWgrad {
   float* dst;        /* finished mode: [N, K] */
   float* dst_bias;   /* finished mode: [N] or NULL (needs slab_bias) */
   int32_t* counters; /* finished mode: [dosx_wgrad_tiles(N, K)] */
+  int32_t ldd;       /* finished mode: row stride of dst in floats (0 = K: contiguous).  A column block of a wider gradient -
+                        the three K-segments of the EdgeModel's first Linear are separate jobs (round 4, see
+                        dosx_segment_reduce_perm) - is written in place. */
 } DosxWgrad;
 int dosx_wgrad_splits(int M, int N, int K);
 int dosx_wgrad_tiles(int N, int K);
@@ -213,6 +216,13 @@ int dosx_edge_embed_sh1(const float* edge_vec, const float* w0, const float* b0,
  *   e_out[e] = e_in[e] + msg[e]   (edge residual, DOSTransformer_phonon.py:84; skipped if e_out NULL) */
 int dosx_segment_reduce(const float* msg, const int32_t* rowptr, const float* scale, float* agg,
                         const float* e_in, float* e_out, int N, int E, int H, dosx_stream_t stream);
+/* The same segment sums over a PERMUTED row order: agg[n] = sum_{j in [rowptr[n], rowptr[n+1])} msg[perm[j]]  (no scale, no
+ * residual).  With rowptr_src / perm_src: the sum of a per-edge tensor over the edges that LEAVE node n.  Round 4 uses the pair
+ * (this, dosx_segment_reduce) to factor the weight gradient of `Linear(cat[x[row], x[col], e])` (DOSTransformer_phonon.py:
+ * 190-197): sum_e dz_e (x) x[row(e)] = sum_n (sum_{e: row(e) = n} dz_e) (x) x_n - the node blocks of that gradient become
+ * N-row jobs instead of E-row ones (20 x fewer rows at 20 edges per node). */
+int dosx_segment_reduce_perm(const float* msg, const int32_t* rowptr, const int32_t* perm, float* agg, int N, int E, int H,
+                             dosx_stream_t stream);
 
 /* backward of the aggregation + residual:  dmsg[e] = (de_new ? de_new[e] : 0) + scale[dst[e]] * dagg[dst[e]]
  * dagg has row stride ld_dagg (it is a column block of the node-MLP input gradient), de_new row stride ld_de_new

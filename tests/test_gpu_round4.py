@@ -706,3 +706,85 @@ def _sliver_case(o, _lib, Gemm, M, N, K, mapped, res):
     _lib.load().dosx_gemm_kernel_name(C.byref(g), buf, 96)
     small = 2.0 * M * N * K <= 2e9
     assert (buf.value.decode() == "sliver_gemm_kernel") == small, buf.value
+
+
+# ---- factored weight gradient of the EdgeModel's first Linear (aggregate, then multiply) ---------------------------------------
+
+@pytest.mark.parametrize("H", [64, 128, 256])
+def test_segment_reduce_perm_and_strided_wgrad(H):
+    """dosx_segment_reduce_perm = the sums of a per-edge tensor over the edges that LEAVE each node (rowptr_src / perm_src),
+    against index_add; and a finished-mode weight-gradient job that writes a COLUMN BLOCK of a wider gradient (DosxWgrad.ldd)."""
+    from dostransformer_amd import synth
+    from dostransformer_amd.batch import collate
+    o = ops()
+    g = collate(synth.phonon_crystals(7, 3, torch.float32)).to(DEV)
+    m = g.meta
+    N, E = m.num_nodes, m.num_edges
+    dz = rnd(E, H, seed=1)
+    agg = torch.full((N, H), float("nan"), device=DEV)
+    o.segment_reduce_perm(dz, m.rowptr_src, m.perm_src, agg, N, E, H)
+    ref = torch.zeros(N, H, dtype=torch.float64, device=DEV).index_add_(0, m.src.long(), dz.double())
+    torch.cuda.synchronize()
+    assert err(agg, ref) < TOL
+    # strided destination: three column blocks of one [Nn, 3K] gradient
+    M, Nn, K = 900, 64, 32
+    dy, a = rnd(M, Nn, seed=2), rnd(M, 3 * K, seed=3)
+    dw = torch.full((Nn, 3 * K), float("nan"), device=DEV)
+    db = torch.full((Nn,), float("nan"), device=DEV)
+    jobs = []
+    for j in range(3):
+        ns = o.wgrad_splits(M, Nn, K)
+        nf = o.wgrad_scratch_floats(Nn, K, ns)
+        slab = torch.empty(max(nf, 1), device=DEV)
+        sb = torch.empty(ns * 64, device=DEV) if j == 2 else None
+        jobs.append((o.wgrad_desc(M, Nn, o.seg(dy), [o.seg(a, width=K, col=j * K)], slab, sb, ns, dst=dw[:, j * K:(j + 1) * K],
+                                  dst_bias=db if j == 2 else None), slab, sb))
+    o.wgrad_grouped([j[0] for j in jobs])
+    torch.cuda.synchronize()
+    assert err(dw, dy.double().T @ a.double()) < TOL and err(db, dy.double().sum(0)) < TOL
+
+
+@pytest.mark.parametrize("kind", ["phonon", "edos"])
+def test_factored_edge_weight_gradient_equals_the_plain_one(kind):
+    """functional.mlp_ln_bwd with the EdgeModel's first weight gradient as [node sums (x) x | node sums (x) x | dz (x) e] (N-row
+    jobs behind two segment sums) against the one E-row job on the gathered concat: all gradients of a training step agree to
+    rounding; eager and replay give the same bits; ghost-padded batches included."""
+    from dostransformer_amd import functional as Fn, synth
+    from dostransformer_amd.batch import bucket_sizes, collate, pad_batch
+    from dostransformer_amd.train import Trainer
+    torch.manual_seed(0)
+    if kind == "phonon":
+        from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+        mk = lambda: DOSTransformer_phonon(3, 1, 118, 4, 64, DEV, 0.0)
+        cs = synth.phonon_crystals(6, 5, torch.float32)
+    else:
+        from dostransformer_amd.embedder_eDOS.DOSTransformer import DOSTransformer
+        mk = lambda: DOSTransformer(3, 1, 200, 41, 2, 64, DEV, 0.0)
+        cs = synth.edos_crystals(6, 5, torch.float32)
+    g = collate(cs)
+    gp = pad_batch(g, *bucket_sizes(g.meta.num_nodes, g.meta.num_edges, 16, 256)).to(DEV)
+    m0 = mk()
+    sd0 = {k: v.detach().clone() for k, v in m0.state_dict().items()}
+    grads, params = {}, {}
+    for fac in (False, True):
+        Fn._FACTOR_EDGE_WGRAD = fac
+        try:
+            for replay in (False, True):
+                model = mk()
+                model.load_state_dict(sd0)
+                model = model.to(DEV)
+                tr = Trainer(model, lr=1e-3, replay=replay)
+                tr.forward_backward(gp)
+                torch.cuda.synchronize()
+                fp = model.flat_params()
+                grads[(fac, replay)] = {k: v.clone() for k, v in fp.G.items()}
+                for _ in range(2):
+                    tr.step(gp)
+                torch.cuda.synchronize()
+                params[(fac, replay)] = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        finally:
+            Fn._FACTOR_EDGE_WGRAD = True
+    for k, v in grads[(False, False)].items():
+        assert err(grads[(True, False)][k], v) < 2e-5, k
+    for k in params[(True, False)]:
+        assert torch.equal(params[(True, False)][k], params[(True, True)][k]), ("eager vs replay", k)
