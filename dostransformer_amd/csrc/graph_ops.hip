@@ -467,6 +467,51 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
 // out[r] = (res ? res[r] : 0) + a[r] o (mask ? mask[r] : 1), and optionally the LayerNorm statistics (mean, rstd) of the
 // out row: the dropout -> add-residual steps of the encoder layer (layers/transformer.py:137-138,145-148) for the
 // relu / res dropout path, where they cannot ride in the fused attention / feed-forward epilogues.  One wave per row.
+// xhat[e] = rownorm( z[e] + p[src[e]] + q[dst[e]] ): the LayerNorm input of the EdgeModel when its first Linear is FACTORED
+// (functional.mlp_ln_fwd): Linear(cat[x[row], x[col], e]) = x[row] Wa^T + x[col] Wb^T + e Wc^T + b with the two node terms
+// computed once per NODE (p = x Wa^T, q = x Wb^T: N rows) and gathered here, the edge term z = e Wc^T + b from an E-row GEMM
+// on a third of the columns.  One wave per edge row, rows of up to 1024 floats kept in registers (W / 256 float4 per lane).
+__global__ __launch_bounds__(256) void gather_add_rownorm_kernel(const float* __restrict__ z, const float* __restrict__ p, int ldp,
+                                                                 const float* __restrict__ q, int ldq,
+                                                                 const int* __restrict__ src, const int* __restrict__ dst,
+                                                                 float* __restrict__ xhat, float* __restrict__ rstd_out, int E, int W) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= E) return;
+  const float* pr = p + (size_t)src[r] * ldp;
+  const float* qr = q + (size_t)dst[r] * ldq;
+  const float* zr = z + (size_t)r * W;
+  float4 v[4];
+  float s1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = lane * 4 + 256 * k;
+    v[k] = f4zero();
+    if (c < W) {
+      v[k] = f4add(ld4(zr + c), f4add(ld4(pr + c), ld4(qr + c)));
+      s1 += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+  }
+  const float mean = wave_sum(s1) / (float)W;
+  float s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (lane * 4 + 256 * k < W) {
+      const float a = v[k].x - mean, b = v[k].y - mean, c2 = v[k].z - mean, d = v[k].w - mean;
+      s2 += a * a + b * b + c2 * c2 + d * d;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(s2) / (float)W + DOSX_LN_EPS);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = lane * 4 + 256 * k;
+    if (c < W)
+      st4(xhat + (size_t)r * W + c, make_float4((v[k].x - mean) * rstd, (v[k].y - mean) * rstd, (v[k].z - mean) * rstd,
+                                                (v[k].w - mean) * rstd));
+  }
+  if (lane == 0) rstd_out[r] = rstd;
+}
+
 __global__ __launch_bounds__(256) void mask_residual_kernel(const float* __restrict__ a, int lda, const float* __restrict__ mask,
                                                             const float* __restrict__ res, int ldr, float* __restrict__ out,
                                                             int ldo, float* __restrict__ stats, int M, int H) {
@@ -783,6 +828,17 @@ extern "C" int dosx_dense_normalize_pool_bwd(const float* dkvhat, const float* k
                  "dosx_dense_normalize_pool_bwd: bad args");
   hipLaunchKernelGGL(dense_normalize_bwd_kernel, dim3(ceil_div(N, 4)), dim3(256), 0, to_stream(stream), dkvhat, kvhat,
                      rstd_nodes, dense_row, dx, N, H, accumulate, ghost_row, dpool, ld_dpool, node_graph, num_graphs);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_gather_add_rownorm(const float* z, const float* p, int ldp, const float* q, int ldq, const int32_t* src,
+                                       const int32_t* dst, float* xhat, float* rstd, int E, int W, dosx_stream_t stream) {
+  if (E <= 0) return 0;
+  DOSX_CHECK_ARG(z && p && q && src && dst && xhat && rstd && W > 0 && (W & 3) == 0 && W <= 1024 && (ldp & 3) == 0 && (ldq & 3) == 0,
+                 "dosx_gather_add_rownorm: bad args (W=%d: multiple of 4, <= 1024)", W);
+  hipLaunchKernelGGL(gather_add_rownorm_kernel, dim3(ceil_div(E, 4)), dim3(256), 0, to_stream(stream), z, p, ldp, q, ldq, src, dst,
+                     xhat, rstd, E, W);
   DOSX_LAUNCH_CHECK();
   return 0;
 }

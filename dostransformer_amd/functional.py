@@ -129,6 +129,13 @@ def _wide_ln(H: int) -> bool:
     return 2 * H > 512
 
 
+def _factor_edge(E: int, H: int) -> bool:
+    """Whether the EdgeModel's first Linear (forward product and weight gradient) is factored into node parts + edge part:
+    where that GEMM is throughput-bound - from DOSX_FACTOR_MIN_GF (4) GF: Electron-DOS H 256 (14 GF at batch 64, 6 GF on the
+    32-crystal shard); the Phonon-DOS benchmark shape (1.8 GF, launch-latency-bound) measured 0.7 % slower with it."""
+    return _FACTOR_EDGE_WGRAD and 2.0 * E * (2 * H) * (3 * H) >= _FACTOR_MIN_GF * 1e9
+
+
 def _mlp_ln_fused(a: SegList, M: int, H: int) -> bool:
     return a.plain is not None and len(a.plain) <= 2 and ops.mlp_ln_supported(M, a.K, 2 * H, H)
 
@@ -147,7 +154,22 @@ def mlp_ln_fwd(P: Params, key: str, a: SegList, M: int, H: int, res: Optional[to
                        P[key + ".1.weight"], P[key + ".1.bias"], P[key + ".2.weight"], P[key + ".3.weight"],
                        P[key + ".3.bias"], res, xhat, rstd, y)
         return y, (a, xhat, rstd, M, H)
-    if _wide_ln(H):
+    fac = getattr(a, "factor", None)
+    if fac is not None and _factor_edge(M, H):
+        # Large edge sets (throughput-bound): the first Linear FACTORED - Linear(cat[x[row], x[col], e]) = (x Wa^T)[row] +
+        # (x Wb^T)[col] + e Wc^T + b.  The two node products are N-row GEMMs, the E-row GEMM keeps a third of the columns, and one
+        # row kernel gathers, adds and normalises: a third of the flops of the gathered-concat GEMM (Electron-DOS: 14.1 -> 5.5 GF
+        # per layer) for one extra pass over [E, 2H].  Same saved tensors (xhat, rstd): the backward does not care.
+        x, e, m = fac
+        W1 = P[key + ".0.weight"]
+        N_ = m.num_nodes
+        pq = _empty(dev, N_, 4 * H)
+        ops.gemm(N_, 2 * H, [seg(x)], W1[:, :H], pq[:, :2 * H])
+        ops.gemm(N_, 2 * H, [seg(x)], W1[:, H:2 * H], pq[:, 2 * H:])
+        z = _empty(dev, M, 2 * H)
+        ops.gemm(M, 2 * H, [seg(e)], W1[:, 2 * H:], z, bias=P[key + ".0.bias"])
+        ops.gather_add_rownorm(z, pq[:, :2 * H], pq[:, 2 * H:], m.src, m.dst, xhat, rstd, M, 2 * H)
+    elif _wide_ln(H):
         # hidden > 256: the 2H-wide LayerNorm row no longer fits the one-tile row epilogue of dosx_gemm - plain GEMM, then
         # the parameter-free normalisation as a row kernel (the affine + PReLU stay in the second GEMM's prologue)
         assert segsum is None
@@ -202,7 +224,7 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
     sink.add(part, 2 * H, G[key + ".1.bias"], rows, pld, 2 * H)
     sink.add(part, pld - 1, G[key + ".2.weight"], rows, pld, 1)
     fac = getattr(a, "factor", None)
-    if fac is not None and _FACTOR_EDGE_WGRAD and key + ".0.weight" in G:
+    if fac is not None and _factor_edge(M, H) and key + ".0.weight" in G:
         # The first Linear reads cat[x[row], x[col], e] (DOSTransformer_phonon.py:193-195): its weight gradient is
         #   sum_e dz_e (x) [x[row(e)] | x[col(e)] | e_e]  =  [ sum_n S_n (x) x_n | sum_n D_n (x) x_n | sum_e dz_e (x) e_e ],
         # S_n / D_n = the sums of dz over the edges that leave / enter node n.  The two node blocks become N-row jobs (20 x
@@ -431,7 +453,8 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
 
 
 _FUSED_FFN_BWD = __import__("os").environ.get("DOSX_FUSED_FFN_BWD", "1") == "1"
-_FACTOR_EDGE_WGRAD = __import__("os").environ.get("DOSX_FACTOR_EDGE_WGRAD", "1") == "1"   # node blocks of the EdgeModel weight gradient as N-row jobs
+_FACTOR_EDGE_WGRAD = __import__("os").environ.get("DOSX_FACTOR_EDGE_WGRAD", "1") == "1"   # EdgeModel first Linear factored into node / edge parts
+_FACTOR_MIN_GF = float(__import__("os").environ.get("DOSX_FACTOR_MIN_GF", "4"))
 _FUSED_ATT_FFN = __import__("os").environ.get("DOSX_FUSED_ATT_FFN", "1") == "1"       # <= 16-key attention inside dosx_ffn_fwd
 _ATT_FFN_MAX_ROWS = int(__import__("os").environ.get("DOSX_ATT_FFN_MAX_ROWS", "4096"))
 _FUSED_DKV = __import__("os").environ.get("DOSX_FUSED_DKV", "1") == "1"

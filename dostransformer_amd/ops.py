@@ -926,6 +926,12 @@ def ln_prelu_bwd(dy, xhat, rstd, gamma, beta, alpha, dz, partials, M, W):
           w=lambda: ("ln_prelu_bwd", "ln_bwd_wide_kernel", "hbm", 12.0 * M * W))
 
 
+def gather_add_rownorm(z, p, q, src, dst, xhat, rstd, E, W):
+    """xhat = rownorm(z + p[src] + q[dst]) (include/dosx.h: dosx_gather_add_rownorm); p / q: 2-D views with unit inner stride."""
+    _call("dosx_gather_add_rownorm", _p(z), _p(p), int(p.stride(0)), _p(q), int(q.stride(0)), _p(src), _p(dst), _p(xhat), _p(rstd),
+          E, W, _stream(), w=lambda: ("gather_add_rownorm", "gather_add_rownorm_kernel", "hbm", 4.0 * _real(E) * W * 4))
+
+
 def rownorm(x, xhat, rstd, M, H):
     _call("dosx_rownorm", _p(x), _p(xhat), _p(rstd), M, H, _stream(),
           w=lambda: ("rownorm", "rownorm_kernel", "hbm", 8.0 * M * H))

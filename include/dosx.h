@@ -282,6 +282,13 @@ int dosx_dense_slots(const float* x, const int32_t* graph_ptr, float* dense, int
 int dosx_dense_slots_bwd(const float* ddense, const int32_t* dense_row, float* dx, int N, int H, int accumulate,
                          int ghost_row, dosx_stream_t stream);
 
+/* xhat[e] = (v - mean(v)) * rstd(v),  v = z[e] + p[src[e]] + q[dst[e]]   (rows of W <= 1024 floats; rstd [E] saved):
+ * the LayerNorm input of the EdgeModel (DOSTransformer_phonon.py:193-195) when its first Linear is FACTORED -
+ * Linear(cat[x[row], x[col], e]) = (x Wa^T)[row] + (x Wb^T)[col] + e Wc^T + b: p and q are N-row products (row strides
+ * ldp / ldq), z the E-row product on a third of the columns.  Used for large edge sets (functional._factor_edge). */
+int dosx_gather_add_rownorm(const float* z, const float* p, int ldp, const float* q, int ldq, const int32_t* src,
+                            const int32_t* dst, float* xhat, float* rstd, int E, int W, dosx_stream_t stream);
+
 /* Row LayerNorm without affine (key/value side of self attention) and with affine. */
 int dosx_rownorm(const float* x, float* xhat, float* rstd, int M, int H, dosx_stream_t stream);
 int dosx_rownorm_bwd(const float* dxhat, const float* xhat, const float* rstd, float* dx, int M, int H,

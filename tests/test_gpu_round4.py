@@ -746,9 +746,10 @@ def test_segment_reduce_perm_and_strided_wgrad(H):
 
 @pytest.mark.parametrize("kind", ["phonon", "edos"])
 def test_factored_edge_weight_gradient_equals_the_plain_one(kind):
-    """functional.mlp_ln_bwd with the EdgeModel's first weight gradient as [node sums (x) x | node sums (x) x | dz (x) e] (N-row
-    jobs behind two segment sums) against the one E-row job on the gathered concat: all gradients of a training step agree to
-    rounding; eager and replay give the same bits; ghost-padded batches included."""
+    """The EdgeModel's first Linear FACTORED - forward: (x Wa^T)[row] + (x Wb^T)[col] + e Wc^T + b through N-row GEMMs, a
+    third-width E-row GEMM and dosx_gather_add_rownorm; weight gradient: [node sums (x) x | node sums (x) x | dz (x) e] (N-row jobs
+    behind two segment sums) - against the gathered-concat GEMM / the one E-row job: outputs and all gradients of a training
+    step agree to rounding; eager and replay give the same bits; ghost-padded batch."""
     from dostransformer_amd import functional as Fn, synth
     from dostransformer_amd.batch import bucket_sizes, collate, pad_batch
     from dostransformer_amd.train import Trainer
@@ -765,9 +766,10 @@ def test_factored_edge_weight_gradient_equals_the_plain_one(kind):
     gp = pad_batch(g, *bucket_sizes(g.meta.num_nodes, g.meta.num_edges, 16, 256)).to(DEV)
     m0 = mk()
     sd0 = {k: v.detach().clone() for k, v in m0.state_dict().items()}
-    grads, params = {}, {}
+    grads, params, outs = {}, {}, {}
+    min_gf = Fn._FACTOR_MIN_GF
     for fac in (False, True):
-        Fn._FACTOR_EDGE_WGRAD = fac
+        Fn._FACTOR_EDGE_WGRAD, Fn._FACTOR_MIN_GF = fac, 0.0        # (the shipped policy factors from 4 GF; the path takes any size)
         try:
             for replay in (False, True):
                 model = mk()
@@ -778,13 +780,16 @@ def test_factored_edge_weight_gradient_equals_the_plain_one(kind):
                 torch.cuda.synchronize()
                 fp = model.flat_params()
                 grads[(fac, replay)] = {k: v.clone() for k, v in fp.G.items()}
+                outs[(fac, replay)] = [t.clone() for t in tr.last_outputs]
                 for _ in range(2):
                     tr.step(gp)
                 torch.cuda.synchronize()
                 params[(fac, replay)] = {k: v.detach().clone() for k, v in model.state_dict().items()}
         finally:
-            Fn._FACTOR_EDGE_WGRAD = True
+            Fn._FACTOR_EDGE_WGRAD, Fn._FACTOR_MIN_GF = True, min_gf
+    for u, v in zip(outs[(True, False)], outs[(False, False)]):
+        assert err(u, v) < 5e-6                          # the forward product factored too: same numbers to rounding
     for k, v in grads[(False, False)].items():
-        assert err(grads[(True, False)][k], v) < 2e-5, k
+        assert err(grads[(True, False)][k], v) < 1e-4, k
     for k in params[(True, False)]:
         assert torch.equal(params[(True, False)][k], params[(True, True)][k]), ("eager vs replay", k)
