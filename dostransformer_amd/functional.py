@@ -209,7 +209,8 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
     pld = 4 * H + 4          # [dgamma(2H) | dbeta(2H) | pad(3) | dalpha]; multiple of 4 -> vector reduce
     part = sink.scratch(rows, pld)
     dz = _empty(dev, M, 2 * H)
-    dcat = _empty(dev, M, a.K)
+    fac_dgrad = getattr(a, "factor", None) is not None and _factor_edge(M, H) and _FACTOR_DGRAD and not fused
+    dcat = None if fac_dgrad else _empty(dev, M, a.K)
     if fused:
         ops.mlp_ln_bwd(M, dy, xhat, rstd, P[key + ".0.weight"], P[key + ".3.weight"], gam, bet, alpha, dz, dcat, part)
     elif wide:          # plain dgrad GEMM, then PReLU + LayerNorm backward of the 2H-wide rows as a row kernel
@@ -238,7 +239,11 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
         def node_sums(dz=dz, aggS=aggS, aggD=aggD, m=m):
             ops.segment_reduce_perm(dz, m.rowptr_src, m.perm_src, aggS, N_, E_, 2 * H)
             ops.segment_reduce(dz, m.rowptr_dst, None, aggD, None, None, N_, E_, 2 * H)
-        sink.defer_pre(node_sums, keep=(dz,))
+        if _FACTOR_DGRAD:
+            node_sums()                                # the input gradient below reads them too: on the main stream, now
+            sink._keep.append(dz)
+        else:
+            sink.defer_pre(node_sums, keep=(dz,))
         Gw = G[key + ".0.weight"]                      # [2H, 3H]
         with ops.graph_rows():
             _wgrad_linear(sink, G, key + ".0.weight", None, N_, 2 * H, seg(aggS), [seg(x)], keep=(aggS, x), dst=Gw[:, :H])
@@ -246,6 +251,14 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
             _wgrad_linear(sink, G, key + ".0.weight", key + ".0.bias", M, 2 * H, seg(dz), [seg(e)], keep=(dz, e), dst=Gw[:, 2 * H:])
     else:
         _wgrad_linear(sink, G, key + ".0.weight", key + ".0.bias", M, 2 * H, seg(dz), a.segs, keep=(dz,))
+    if fac is not None and _factor_edge(M, H) and _FACTOR_DGRAD and not fused:
+        # ... and the INPUT gradient factored the same way: dL/de = dz Wc (+ the incoming edge-state gradient) is the only
+        # E-row product left (a third of the columns of the [E,3H] concat gradient); the node parts come from the node sums,
+        # sum_{e: row(e) = n} dz_e Wa = S_n Wa - the caller (gnn_bwd) multiplies N rows instead of gathering E of them back
+        W0 = P[key + ".0.weight"]
+        de_new = _empty(dev, M, H)
+        ops.gemm(M, H, [seg(dz)], W0[:, 2 * H:], de_new, w_layout=1, res=res)
+        return ("factored", de_new, aggS, aggD)
     if not fused:
         ops.gemm(M, a.K, [seg(dz)], P[key + ".0.weight"], dcat, w_layout=1, res=res, res_col0=res_col0 if res is not None else 0)
     return dcat
@@ -302,6 +315,19 @@ def gnn_bwd(P: Params, G: Params, m: GraphMeta, ctxs, dx: torch.Tensor, sink: Gr
         if l == 0 and sink.wside is not None:
             sink.flush_on_side()     # layer 0's weight gradients start now, under the gather backward and the encoders' backward
         dx_old = _empty(dev, N, H)
+        if isinstance(dcat_e, tuple):
+            # factored input gradient (large edge sets): dx_l = dx_{l+1} + S Wa + D Wb + (node-MLP input gradient)[:, :H]
+            _, de_new, aggS, aggD = dcat_e
+            W0 = P[pre + ".edge_model.edge_mlp.0.weight"]
+            t1, t2 = _empty(dev, N, H), _empty(dev, N, H)
+            ops.gemm(N, H, [seg(aggS)], W0[:, :H], t1, w_layout=1, res=dx)
+            ops.gemm(N, H, [seg(aggD)], W0[:, H:2 * H], t2, w_layout=1, res=t1)
+            ops.mask_residual(dcat_n[:, :H], None, t2, dx_old, None, N, H)
+            sink._keep.extend([dcat_n, t1, t2, dx])
+            dx, de = dx_old, de_new
+            if sink.side is not None and ((_SPLIT_LATE_FLUSH == 1 and l == 1) or (_SPLIT_LATE_FLUSH == 2 and l >= 1)):
+                sink.flush_on_side()
+            continue
         ops.gather_bwd(dcat_e, dcat_n.data_ptr(), 2 * H, dx, m.rowptr_dst, m.rowptr_src, m.perm_src, None, dx_old,
                        None, N, E, H)
         sink._keep.append(dcat_n)
@@ -455,6 +481,7 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
 _FUSED_FFN_BWD = __import__("os").environ.get("DOSX_FUSED_FFN_BWD", "1") == "1"
 _FACTOR_EDGE_WGRAD = __import__("os").environ.get("DOSX_FACTOR_EDGE_WGRAD", "1") == "1"   # EdgeModel first Linear factored into node / edge parts
 _FACTOR_MIN_GF = float(__import__("os").environ.get("DOSX_FACTOR_MIN_GF", "4"))
+_FACTOR_DGRAD = __import__("os").environ.get("DOSX_FACTOR_DGRAD", "1") == "1"             # ... and its input gradient
 _FUSED_ATT_FFN = __import__("os").environ.get("DOSX_FUSED_ATT_FFN", "1") == "1"       # <= 16-key attention inside dosx_ffn_fwd
 _ATT_FFN_MAX_ROWS = int(__import__("os").environ.get("DOSX_ATT_FFN_MAX_ROWS", "4096"))
 _FUSED_DKV = __import__("os").environ.get("DOSX_FUSED_DKV", "1") == "1"
