@@ -203,6 +203,9 @@ _SIGS = {
     "dosx_dense_slots": [_P, _P, _P, _I, _I, _I, _P],
     "dosx_dense_slots_bwd": [_P, _P, _P, _I, _I, _I, _I, _P],
     "dosx_ln_prelu_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "dosx_ln_prelu_bwd_gather": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "dosx_act_segment_sum": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "dosx_seg_count_scale": [_P, _I, _P, _I, _P, _I, _I, _P],
     "dosx_gather_add_rownorm": [_P, _P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _P],
     "dosx_rownorm": [_P, _P, _P, _I, _I, _P],
     "dosx_rownorm_bwd": [_P, _P, _P, _P, _I, _I, _I, _P],

@@ -160,6 +160,68 @@ __global__ __launch_bounds__(128) void segment_reduce_perm_kernel(const float* _
   }
 }
 
+// S[n] = scale[n] * sum_{e in seg(n)} prelu(xhat[e] * gamma + beta)  (rows of W floats; the segments are contiguous row ranges:
+// edges sorted by destination) and R[n] = c_n * bias (Hout floats), c_n = the number of rows of the segment (scale == null:
+// scatter_sum) or [segment not empty] (scatter_mean).  With these, scale * sum_e (act_e W^T + b) = S[n] W^T + R[n]: the second
+// Linear of the LAST message-passing layer (whose per-edge output nobody reads, DOSTransformer_phonon.py:84 - the edge update
+// of the last layer is dead) runs on N aggregated rows instead of E.  One wave per (node, 256-column block), 8 rows in flight,
+// rows added in segment order (fixed).
+constexpr int AS_U = 8;
+__global__ __launch_bounds__(256) void act_segment_sum_kernel(const float* __restrict__ xhat, const int* __restrict__ rowptr,
+                                                              const float* __restrict__ scale, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ alpha,
+                                                              const float* __restrict__ bias, float* __restrict__ S,
+                                                              float* __restrict__ R, int N, int W, int Hout) {
+  const int lane = threadIdx.x & 63;
+  const int nblk = (W + 255) >> 8;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int n = wid / nblk, cb = (wid - n * nblk) << 8;
+  if (n >= N) return;
+  const int c = cb + lane * 4;
+  const bool cok = c < W;
+  const int cc = cok ? c : 0;
+  const int beg = rowptr[n], end = rowptr[n + 1];
+  const float4 g = ld4(gamma + cc), b = ld4(beta + cc);
+  const float al = *alpha;
+  float4 acc = f4zero();
+  for (int e0 = beg; e0 < end; e0 += AS_U) {
+    float4 v[AS_U];
+#pragma unroll
+    for (int u = 0; u < AS_U; ++u) v[u] = ld4(xhat + (size_t)min(e0 + u, end - 1) * W + cc);
+#pragma unroll
+    for (int u = 0; u < AS_U; ++u) {
+      if (e0 + u >= end) break;
+      float4 y = make_float4(v[u].x * g.x + b.x, v[u].y * g.y + b.y, v[u].z * g.z + b.z, v[u].w * g.w + b.w);
+      y.x = y.x < 0.f ? al * y.x : y.x; y.y = y.y < 0.f ? al * y.y : y.y;
+      y.z = y.z < 0.f ? al * y.z : y.z; y.w = y.w < 0.f ? al * y.w : y.w;
+      acc = f4add(acc, y);
+    }
+  }
+  const float sc = scale ? scale[n] : 1.f;
+  if (cok) st4(S + (size_t)n * W + c, make_float4(acc.x * sc, acc.y * sc, acc.z * sc, acc.w * sc));
+  if (cb == 0 && R) {
+    const float cn = scale ? (end > beg ? 1.f : 0.f) : (float)(end - beg);
+    for (int h = lane * 4; h < Hout; h += 256) {
+      const float4 bb = ld4(bias + h);
+      st4(R + (size_t)n * Hout + h, make_float4(bb.x * cn, bb.y * cn, bb.z * cn, bb.w * cn));
+    }
+  }
+}
+
+// out[n] = c_n * in[n] (c_n as above): the bias gradient of that Linear is the column sum of these rows
+__global__ void seg_count_scale_kernel(const float* __restrict__ in, int ld_in, const int* __restrict__ rowptr, int mean,
+                                       float* __restrict__ out, int N, int H) {
+  const int h4 = H >> 2;
+  const size_t total = (size_t)N * h4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / h4), c = (int)(i % h4) * 4;
+    const int deg = rowptr[n + 1] - rowptr[n];
+    const float cn = mean ? (deg > 0 ? 1.f : 0.f) : (float)deg;
+    const float4 v = ld4(in + (size_t)n * ld_in + c);
+    st4(out + (size_t)n * H + c, make_float4(v.x * cn, v.y * cn, v.z * cn, v.w * cn));
+  }
+}
+
 // dmsg[e] = de_new[e] + scale[dst[e]] * dagg[dst[e]]   (element-wise over E*H/4 float4; de_new rows ld_de floats apart:
 // it is the e-block of the previous layer's [E,3H] concat gradient)
 __global__ void edge_grad_combine_kernel(const float* __restrict__ de_new, int ld_de, const float* __restrict__ dagg,
@@ -705,6 +767,30 @@ extern "C" int dosx_segment_reduce_perm(const float* msg, const int32_t* rowptr,
   CHECK_H(H);
   DOSX_CHECK_ARG(msg && rowptr && perm && agg, "dosx_segment_reduce_perm: bad args");
   hipLaunchKernelGGL(segment_reduce_perm_kernel, dim3(ceil_div(N, 2)), dim3(128), 0, to_stream(stream), msg, rowptr, perm, agg, N, H);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_act_segment_sum(const float* xhat, const int32_t* rowptr, const float* scale, const float* gamma,
+                                    const float* beta, const float* alpha, const float* bias, float* S, float* R, int N, int W,
+                                    int Hout, dosx_stream_t stream) {
+  if (N <= 0) return 0;
+  DOSX_CHECK_ARG(xhat && rowptr && gamma && beta && alpha && S && (!R || bias), "dosx_act_segment_sum: bad args");
+  DOSX_CHECK_ARG(W > 0 && (W & 3) == 0 && (Hout & 3) == 0, "dosx_act_segment_sum: widths %d / %d must be multiples of 4", W, Hout);
+  const int nblk = (W + 255) >> 8;
+  hipLaunchKernelGGL(act_segment_sum_kernel, dim3(ceil_div(N * nblk, 4)), dim3(256), 0, to_stream(stream), xhat, rowptr, scale,
+                     gamma, beta, alpha, bias, S, R, N, W, Hout);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_seg_count_scale(const float* in, int ld_in, const int32_t* rowptr, int mean, float* out, int N, int H,
+                                    dosx_stream_t stream) {
+  if (N <= 0) return 0;
+  DOSX_CHECK_ARG(in && rowptr && out && (H & 3) == 0 && (ld_in & 3) == 0, "dosx_seg_count_scale: bad args");
+  const size_t total = (size_t)N * (H >> 2);
+  hipLaunchKernelGGL(seg_count_scale_kernel, dim3((unsigned)std::min<size_t>(ceil_div(total, (size_t)256), 2048)), dim3(256), 0,
+                     to_stream(stream), in, ld_in, rowptr, mean, out, N, H);
   DOSX_LAUNCH_CHECK();
   return 0;
 }

@@ -166,7 +166,10 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const float* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ w, const float* __restrict__ alpha,
                                                           float* __restrict__ dx, float* __restrict__ partials, int M, int W,
-                                                          int S, int Bq) {
+                                                          int S, int Bq, const int* __restrict__ dyidx = nullptr,
+                                                          const float* __restrict__ dyscale = nullptr) {
+  // dyidx / dyscale (MODE 2): row r reads dy[dyidx[r]] * dyscale[dyidx[r]] - the gradient behind the PReLU is one row per
+  // destination NODE (the last message-passing layer, whose second Linear runs on the aggregated rows)
   extern __shared__ __align__(16) float sm[];   // [4 waves][NV*W] + [4]
   constexpr int NV = MODE == 1 ? 3 : 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -194,6 +197,8 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const float* __restric
     }
     float4 xh[LNW_K], d[LNW_K];
     float s1 = 0.f, s2 = 0.f;
+    const size_t dr = (MODE == 2 && dyidx) ? (size_t)dyidx[r] : (size_t)r;
+    const float dsc = (MODE == 2 && dyscale) ? dyscale[dr] : 1.f;
 #pragma unroll
     for (int k = 0; k < LNW_K; ++k) {
       const int c = lane * 4 + 256 * k;
@@ -201,7 +206,10 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const float* __restric
       if (c >= W) continue;
       xh[k] = ld4(xhat + (size_t)r * W + c);
       if (MODE == 1) d[k] = make_float4(dyr * ww[k].x, dyr * ww[k].y, dyr * ww[k].z, dyr * ww[k].w);
-      else d[k] = ld4(dy + (size_t)r * W + c);
+      else {
+        d[k] = ld4(dy + dr * W + c);
+        if (MODE == 2 && dyscale) d[k] = make_float4(d[k].x * dsc, d[k].y * dsc, d[k].z * dsc, d[k].w * dsc);
+      }
       const float4 h = xh[k];
       if (MODE == 2) {
         const float y0 = h.x * g[k].x + bt[k].x, y1 = h.y * g[k].y + bt[k].y, y2 = h.z * g[k].z + bt[k].z,
@@ -615,6 +623,19 @@ extern "C" int dosx_ln_prelu_bwd(const float* dy, const float* xhat, const float
   DOSX_CHECK_ARG(W <= 256 * LNW_K, "dosx_ln_prelu_bwd: row width %d > %d", W, 256 * LNW_K);
   hipLaunchKernelGGL((ln_bwd_wide_kernel<2>), dim3(ceil_div(M, 32)), dim3(256), (4 * (size_t)(2 * W) + 4) * sizeof(float),
                      to_stream(stream), dy, nullptr, xhat, rstd, gamma, beta, nullptr, alpha, dz, partials, M, W, 0, 1);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int dosx_ln_prelu_bwd_gather(const float* dy, const int32_t* idx, const float* scale, const float* xhat,
+                                        const float* rstd, const float* gamma, const float* beta, const float* alpha, float* dz,
+                                        float* partials, int M, int W, dosx_stream_t stream) {
+  if (M <= 0) return 0;
+  CHECK_H4(W);
+  DOSX_CHECK_ARG(dy && idx && xhat && rstd && gamma && beta && alpha && dz && partials, "dosx_ln_prelu_bwd_gather: bad args");
+  DOSX_CHECK_ARG(W <= 256 * LNW_K, "dosx_ln_prelu_bwd_gather: row width %d > %d", W, 256 * LNW_K);
+  hipLaunchKernelGGL((ln_bwd_wide_kernel<2>), dim3(ceil_div(M, 32)), dim3(256), (4 * (size_t)(2 * W) + 4) * sizeof(float),
+                     to_stream(stream), dy, nullptr, xhat, rstd, gamma, beta, nullptr, alpha, dz, partials, M, W, 0, 1, idx, scale);
   DOSX_LAUNCH_CHECK();
   return 0;
 }

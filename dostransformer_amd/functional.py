@@ -140,10 +140,12 @@ def _mlp_ln_fused(a: SegList, M: int, H: int) -> bool:
     return a.plain is not None and len(a.plain) <= 2 and ops.mlp_ln_supported(M, a.K, 2 * H, H)
 
 
-def mlp_ln_fwd(P: Params, key: str, a: SegList, M: int, H: int, res: Optional[torch.Tensor] = None, segsum=None):
+def mlp_ln_fwd(P: Params, key: str, a: SegList, M: int, H: int, res: Optional[torch.Tensor] = None, segsum=None, aggsum=None):
     """segsum = (seg_tile, rowptr, scale, agg, e_in, e_out): the second Linear aggregates its rows per destination node in
     its epilogue (DosxGemm EPI_SEGSUM): agg = scale * segment sums of the output, e_out = e_in + output (None: skipped);
-    the output itself (the messages) is not written and None is returned for it."""
+    the output itself (the messages) is not written and None is returned for it.
+    aggsum = (rowptr, scale, agg, N): the aggregation moved IN FRONT of the second Linear (the last message-passing layer of
+    a large edge set: nobody reads its per-edge output) - activation rows summed per destination node, then an N-row GEMM."""
     dev = P[key + ".0.weight"].device
     xhat = _empty(dev, M, 2 * H)
     rstd = _empty(dev, M)
@@ -181,6 +183,15 @@ def mlp_ln_fwd(P: Params, key: str, a: SegList, M: int, H: int, res: Optional[to
         ops.rownorm(z, xhat, rstd, M, 2 * H)
     else:
         ops.gemm(M, 2 * H, a.segs, P[key + ".0.weight"], xhat, bias=P[key + ".0.bias"], epi=EPI_LN, aux_out=rstd)
+    if aggsum is not None:
+        # scale_n * sum_{e -> n} (act_e W^T + b) = (scale_n * sum act_e) W^T + c_n b: E / N times fewer rows through the GEMM
+        rowptr, scale, agg, N_ = aggsum
+        S, R = _empty(dev, N_, 2 * H), _empty(dev, N_, H)
+        ops.act_segment_sum(xhat, rowptr, scale, P[key + ".1.weight"], P[key + ".1.bias"], P[key + ".2.weight"],
+                            P[key + ".3.bias"], S, R, N_, M, 2 * H, H)
+        ops.gemm(N_, H, [seg(S)], P[key + ".3.weight"], agg, res=R)
+        a.aggsum = (S, rowptr, scale, N_, R)
+        return None, (a, xhat, rstd, M, H)
     if segsum is not None:
         tile, rowptr, scale, agg, e_in, e_out = segsum
         ops.gemm(M, H, [seg(xhat)], P[key + ".3.weight"], e_out, pro=PRO_LN_PRELU, pro_gamma=P[key + ".1.weight"],
@@ -200,10 +211,25 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
     a, xhat, rstd, M, H = ctx
     dev = xhat.device
     gam, bet, alpha = P[key + ".1.weight"], P[key + ".1.bias"], P[key + ".2.weight"]
-    _wgrad_linear(sink, G, key + ".3.weight", key + ".3.bias", M, H, seg(dy), [seg(xhat)], keep=(dy,), pro=PRO_LN_PRELU,
-                  pro_gamma=gam, pro_beta=bet, pro_alpha=alpha)
-    fused = res is None and _mlp_ln_fused(a, M, H) and dy.stride(1) == 1
-    wide = _wide_ln(H)
+    agg_first = getattr(a, "aggsum", None)
+    if agg_first is not None:
+        # forward aggregated in front of the second Linear (mlp_ln_fwd, aggsum): dy = dL/d agg, one row per NODE (a strided
+        # view of the node-MLP input gradient).  Weight gradient sum_n dagg_n (x) S_n on N rows; bias gradient = column sums of
+        # c_n * dagg_n (rides in the flush launch as a row-partial reduction); dL/d act_e = scale_n * (dagg_n W)[dst(e)].
+        S, rowptr, scale, N_, R = agg_first
+        with ops.graph_rows():
+            _wgrad_linear(sink, G, key + ".3.weight", None, N_, H, seg(dy), [seg(S)], keep=(dy, S, R))
+        daggc = sink.scratch(N_, H)
+        ops.seg_count_scale(dy.data_ptr(), int(dy.stride(0)), rowptr, scale is not None, daggc, N_, H)
+        sink.add(daggc, 0, G[key + ".3.bias"], N_, H, H)
+        dnode = _empty(dev, N_, 2 * H)
+        ops.gemm(N_, 2 * H, [seg(dy)], P[key + ".3.weight"], dnode, w_layout=1)
+        sink._keep.append(dnode)
+    else:
+        _wgrad_linear(sink, G, key + ".3.weight", key + ".3.bias", M, H, seg(dy), [seg(xhat)], keep=(dy,), pro=PRO_LN_PRELU,
+                      pro_gamma=gam, pro_beta=bet, pro_alpha=alpha)
+    fused = agg_first is None and res is None and _mlp_ln_fused(a, M, H) and dy.stride(1) == 1
+    wide = _wide_ln(H) or agg_first is not None
     rows = ops.mlp_ln_bwd_partial_rows(M) if fused else (ops.ln_prelu_bwd_partial_rows(M) if wide else
                                                          ops.gemm_partial_rows(M, 2 * H, EPI_PRELU_LN_BWD))
     pld = 4 * H + 4          # [dgamma(2H) | dbeta(2H) | pad(3) | dalpha]; multiple of 4 -> vector reduce
@@ -213,6 +239,8 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
     dcat = None if fac_dgrad else _empty(dev, M, a.K)
     if fused:
         ops.mlp_ln_bwd(M, dy, xhat, rstd, P[key + ".0.weight"], P[key + ".3.weight"], gam, bet, alpha, dz, dcat, part)
+    elif agg_first is not None:
+        ops.ln_prelu_bwd_gather(dnode, a.factor[2].dst, agg_first[2], xhat, rstd, gam, bet, alpha, dz, part, M, 2 * H)
     elif wide:          # plain dgrad GEMM, then PReLU + LayerNorm backward of the 2H-wide rows as a row kernel
         dact = _empty(dev, M, 2 * H)
         ops.gemm(M, 2 * H, [seg(dy)], P[key + ".3.weight"], dact, w_layout=1)
@@ -279,7 +307,9 @@ def gnn_fwd(P: Params, m: GraphMeta, x: torch.Tensor, e: torch.Tensor, L: int, m
         agg = _empty(dev, N, H)
         last = l == L - 1                       # the last layer's edge update is dead
         e_new = None if last else _empty(dev, E, H)
-        if m.seg_tile is not None and H <= 256:
+        if last and _FACTOR_LAST and _factor_edge(E, H) and not _wide_ln(H):
+            _, cxe = mlp_ln_fwd(P, pre + ".edge_model.edge_mlp", a_e, E, H, aggsum=(m.rowptr_dst, scale, agg, N))
+        elif m.seg_tile is not None and H <= 256:
             # scatter_mean / scatter_sum + the edge residual inside the message GEMM's epilogue (node-aligned row tiles):
             # the messages never reach HBM and the layer is 4 launches instead of 5
             _, cxe = mlp_ln_fwd(P, pre + ".edge_model.edge_mlp", a_e, E, H, segsum=(m.seg_tile, m.rowptr_dst, scale, agg, e, e_new))
@@ -306,8 +336,12 @@ def gnn_bwd(P: Params, G: Params, m: GraphMeta, ctxs, dx: torch.Tensor, sink: Gr
         pre = f"stacked_processor.{l}"
         cxe, cxn = ctxs[l]
         dcat_n = mlp_ln_bwd(P, G, pre + ".node_model.node_mlp_2", cxn, dx, sink)          # [N, 2H]
-        dmsg = _empty(dev, E, H)
-        ops.edge_grad_combine(de, dcat_n.data_ptr() + 4 * H, 2 * H, m.dst, scale, dmsg, E, H)
+        if getattr(cxe[0], "aggsum", None) is not None:
+            assert de is None                        # (the last layer: no edge-state gradient arrives)
+            dmsg = dcat_n[:, H:]                     # dL/d agg [N,H]: mlp_ln_bwd expands it per edge inside its row kernel
+        else:
+            dmsg = _empty(dev, E, H)
+            ops.edge_grad_combine(de, dcat_n.data_ptr() + 4 * H, 2 * H, m.dst, scale, dmsg, E, H)
         # e_{l+1} = e_l + msg_l (DOSTransformer_phonon.py:84): dL/de_l = dL/de_{l+1} + (edge-MLP input gradient)[:, 2H:3H].
         # The dgrad GEMM adds dL/de_{l+1} to exactly those columns, so the e-block of dcat_e IS dL/de_l and no kernel
         # ever streams the edge gradient on its own.
@@ -482,6 +516,7 @@ _FUSED_FFN_BWD = __import__("os").environ.get("DOSX_FUSED_FFN_BWD", "1") == "1"
 _FACTOR_EDGE_WGRAD = __import__("os").environ.get("DOSX_FACTOR_EDGE_WGRAD", "1") == "1"   # EdgeModel first Linear factored into node / edge parts
 _FACTOR_MIN_GF = float(__import__("os").environ.get("DOSX_FACTOR_MIN_GF", "4"))
 _FACTOR_DGRAD = __import__("os").environ.get("DOSX_FACTOR_DGRAD", "1") == "1"             # ... and its input gradient
+_FACTOR_LAST = __import__("os").environ.get("DOSX_FACTOR_LAST", "1") == "1"               # last layer: aggregate, then the second Linear
 _FUSED_ATT_FFN = __import__("os").environ.get("DOSX_FUSED_ATT_FFN", "1") == "1"       # <= 16-key attention inside dosx_ffn_fwd
 _ATT_FFN_MAX_ROWS = int(__import__("os").environ.get("DOSX_ATT_FFN_MAX_ROWS", "4096"))
 _FUSED_DKV = __import__("os").environ.get("DOSX_FUSED_DKV", "1") == "1"

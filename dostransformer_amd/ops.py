@@ -926,6 +926,24 @@ def ln_prelu_bwd(dy, xhat, rstd, gamma, beta, alpha, dz, partials, M, W):
           w=lambda: ("ln_prelu_bwd", "ln_bwd_wide_kernel", "hbm", 12.0 * M * W))
 
 
+def ln_prelu_bwd_gather(dy, idx, scale, xhat, rstd, gamma, beta, alpha, dz, partials, M, W):
+    """The same with dy rows gathered: row r reads dy[idx[r]] * scale[idx[r]] (include/dosx.h: dosx_ln_prelu_bwd_gather)."""
+    _call("dosx_ln_prelu_bwd_gather", _p(dy), _p(idx), _p(scale), _p(xhat), _p(rstd), _p(gamma), _p(beta), _p(alpha), _p(dz),
+          _p(partials), M, W, _stream(), w=lambda: ("ln_prelu_bwd_gather", "ln_bwd_wide_kernel", "hbm", 8.0 * _real(M) * W))
+
+
+def act_segment_sum(xhat, rowptr, scale, gamma, beta, alpha, bias, S, R, N, E, W, Hout):
+    """S[n] = scale[n] * sum over the segment of PReLU(xhat*gamma+beta), R[n] = c_n * bias (include/dosx.h: dosx_act_segment_sum)."""
+    _call("dosx_act_segment_sum", _p(xhat), _p(rowptr), _p(scale), _p(gamma), _p(beta), _p(alpha), _p(bias), _p(S), _p(R), N, W, Hout,
+          _stream(), w=lambda: (f"act_segment_sum[W{W}]", "act_segment_sum_kernel", "hbm", 4.0 * (_real(E) * W + _real(N) * (W + Hout))))
+
+
+def seg_count_scale(src, ld_src, rowptr, mean, out, N, H):
+    """out[n] = c_n * src[n], c_n = segment length (mean False) or [segment not empty]; src: tensor or raw pointer with row stride ld_src."""
+    _call("dosx_seg_count_scale", src if isinstance(src, int) else _p(src), int(ld_src), _p(rowptr), int(bool(mean)), _p(out), N, H,
+          _stream(), w=lambda: ("seg_count_scale", "seg_count_scale_kernel", "hbm", 8.0 * _real(N) * H))
+
+
 def gather_add_rownorm(z, p, q, src, dst, xhat, rstd, E, W):
     """xhat = rownorm(z + p[src] + q[dst]) (include/dosx.h: dosx_gather_add_rownorm); p / q: 2-D views with unit inner stride."""
     _call("dosx_gather_add_rownorm", _p(z), _p(p), int(p.stride(0)), _p(q), int(q.stride(0)), _p(src), _p(dst), _p(xhat), _p(rstd),

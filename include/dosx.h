@@ -224,6 +224,19 @@ int dosx_segment_reduce(const float* msg, const int32_t* rowptr, const float* sc
 int dosx_segment_reduce_perm(const float* msg, const int32_t* rowptr, const int32_t* perm, float* agg, int N, int E, int H,
                              dosx_stream_t stream);
 
+/* The LAST message-passing layer's second Linear on aggregated rows (round 4).  Its per-edge output feeds only the aggregation
+ * (`edge_attr += out` of the last layer is dead, DOSTransformer_phonon.py:84,209 / DOSTransformer.py:59,187), and the Linear
+ * commutes with the segment sum:  scale_n * sum_{e -> n} (act_e W^T + b) = S[n] W^T + R[n]  with
+ *   S[n] = scale[n] * sum_{e in [rowptr[n], rowptr[n+1])} PReLU(xhat[e] * gamma + beta)     [N, W]   (W = 2 * hidden)
+ *   R[n] = c_n * bias, c_n = segment length (scale == NULL: scatter_sum) or [segment not empty] (scatter_mean)   [N, Hout]
+ * so an N-row dosx_gemm (res = R) replaces the E-row one; backward: dosx_gemm on N rows, dosx_ln_prelu_bwd_gather for the
+ * LayerNorm -> PReLU backward of the edge rows, an N-row weight-gradient job on (dagg, S), and the bias gradient as the column
+ * sum of dosx_seg_count_scale's rows  out[n] = c_n * in[n]. */
+int dosx_act_segment_sum(const float* xhat, const int32_t* rowptr, const float* scale, const float* gamma, const float* beta,
+                         const float* alpha, const float* bias, float* S, float* R, int N, int W, int Hout, dosx_stream_t stream);
+int dosx_seg_count_scale(const float* in, int ld_in, const int32_t* rowptr, int mean, float* out, int N, int H,
+                         dosx_stream_t stream);
+
 /* backward of the aggregation + residual:  dmsg[e] = (de_new ? de_new[e] : 0) + scale[dst[e]] * dagg[dst[e]]
  * dagg has row stride ld_dagg (it is a column block of the node-MLP input gradient), de_new row stride ld_de_new
  * (it is the e-block of the next layer's [E,3H] concat gradient, or a plain [E,H] tensor). */
@@ -312,6 +325,11 @@ int dosx_layernorm(const float* x, const float* gamma, const float* beta, float*
  * of [dgamma(W) | dbeta(W) | pad(3) | dalpha]  (row stride 2W + 4). */
 int dosx_ln_prelu_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, const float* beta,
                       const float* alpha, float* dz, float* partials, int M, int W, dosx_stream_t stream);
+/* The same with the gradient rows gathered and scaled: row r reads dy[idx[r]] * (scale ? scale[idx[r]] : 1) - dy holds one row per
+ * destination node (see dosx_act_segment_sum). */
+int dosx_ln_prelu_bwd_gather(const float* dy, const int32_t* idx, const float* scale, const float* xhat, const float* rstd,
+                             const float* gamma, const float* beta, const float* alpha, float* dz, float* partials, int M, int W,
+                             dosx_stream_t stream);
 /* dx = LNbwd(dy); partials: ceil(M/32) rows of [dgamma(H) | dbeta(H)]   (H <= 1024) */
 int dosx_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dx,
                        float* partials, int M, int H, dosx_stream_t stream);

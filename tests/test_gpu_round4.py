@@ -793,3 +793,54 @@ def test_factored_edge_weight_gradient_equals_the_plain_one(kind):
         assert err(grads[(True, False)][k], v) < 1e-4, k
     for k in params[(True, False)]:
         assert torch.equal(params[(True, False)][k], params[(True, True)][k]), ("eager vs replay", k)
+
+
+@pytest.mark.parametrize("mean", [False, True])
+@pytest.mark.parametrize("W,Hout", [(128, 64), (512, 256), (1024, 512)])
+def test_act_segment_sum_and_gathered_ln_prelu_backward(mean, W, Hout):
+    """The last message-passing layer with the aggregation in front of its second Linear (dosx_act_segment_sum,
+    dosx_seg_count_scale, dosx_ln_prelu_bwd_gather) against the per-edge formulation in torch (DOSTransformer_phonon.py:193-197,209 /
+    DOSTransformer.py:187); empty segments (nodes without incoming edges) included; bitwise repeatable."""
+    from dostransformer_amd import ops
+    torch.manual_seed(1)
+    N, E = 37, 411
+    dst = torch.sort(torch.randint(0, N - 3, (E,), device=DEV))[0].to(torch.int32)      # the last three nodes: empty segments
+    deg = torch.bincount(dst.long(), minlength=N)
+    rowptr = torch.zeros(N + 1, device=DEV, dtype=torch.int32)
+    rowptr[1:] = torch.cumsum(deg, 0).to(torch.int32)
+    scale = torch.where(deg > 0, 1.0 / deg.clamp(min=1).float(), torch.zeros((), device=DEV)) if mean else None
+    xhat = torch.randn(E, W, device=DEV)
+    rstd = torch.rand(E, device=DEV) + 0.5
+    gam, bet = torch.randn(W, device=DEV), torch.randn(W, device=DEV)
+    alpha = torch.tensor([0.25], device=DEV)
+    Wt, bias = torch.randn(Hout, W, device=DEV) / W ** 0.5, torch.randn(Hout, device=DEV)
+    S, R = torch.empty(N, W, device=DEV), torch.empty(N, Hout, device=DEV)
+    ops.act_segment_sum(xhat, rowptr, scale, gam, bet, alpha, bias, S, R, N, E, W, Hout)
+    S2, R2 = torch.empty_like(S), torch.empty_like(R)
+    ops.act_segment_sum(xhat, rowptr, scale, gam, bet, alpha, bias, S2, R2, N, E, W, Hout)
+    assert torch.equal(S, S2) and torch.equal(R, R2)
+    # reference: per-edge activation -> Linear -> scatter_sum / scatter_mean
+    y = xhat.double() * gam.double() + bet.double()
+    act = torch.where(y < 0, 0.25 * y, y)
+    msg = act @ Wt.double().T + bias.double()
+    agg_ref = torch.zeros(N, Hout, device=DEV, dtype=torch.float64).index_add_(0, dst.long(), msg)
+    if mean:
+        agg_ref = agg_ref * scale.double()[:, None]
+    agg = S.double() @ Wt.double().T + R.double()
+    assert err(agg, agg_ref) < 2e-5
+    # backward: a node-row gradient (a strided column block, like the node MLP's input gradient) expanded per edge
+    dcat_n = torch.randn(N, 2 * Hout, device=DEV)
+    dagg = dcat_n[:, Hout:]
+    daggc = torch.empty(N, Hout, device=DEV)
+    ops.seg_count_scale(dagg.data_ptr(), 2 * Hout, rowptr, mean, daggc, N, Hout)
+    c = (deg > 0).float() if mean else deg.float()
+    assert torch.equal(daggc, dagg * c[:, None])
+    dnode = (dagg.double() @ Wt.double()).float()                                        # [N, W]
+    rows = ops.ln_prelu_bwd_partial_rows(E)
+    pld = 2 * W + 4
+    dz, part = torch.empty(E, W, device=DEV), torch.zeros(rows, pld, device=DEV)
+    ops.ln_prelu_bwd_gather(dnode, dst, scale, xhat, rstd, gam, bet, alpha, dz, part, E, W)
+    dact = dnode[dst.long()] * (scale[dst.long()][:, None] if mean else 1.0)
+    dz_ref, part_ref = torch.empty(E, W, device=DEV), torch.zeros(rows, pld, device=DEV)
+    ops.ln_prelu_bwd(dact.contiguous(), xhat, rstd, gam, bet, alpha, dz_ref, part_ref, E, W)
+    assert torch.equal(dz, dz_ref) and torch.equal(part, part_ref)                        # the same arithmetic on gathered rows

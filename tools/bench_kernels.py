@@ -339,6 +339,12 @@ def main():
         gemm_case("cfg2 edge da (PRELU_LN_BWD epi)", 9000, 256, 128, wl=1, epi=ops.EPI_PRELU_LN_BWD)
         gemm_case("node encoder dz (PRELU_BWD epi)", 424, 128, 128, wl=1, epi=ops.EPI_PRELU_BWD)
         gemm_case("edge encoder dz (PRELU_BWD epi)", 9344, 128, 128, wl=1, epi=ops.EPI_PRELU_BWD)
+    if w == "edosffn":      # the four feed-forward GEMMs of the Electron-DOS step (tile-policy experiments: DOSX_GEMM_RT / _BN)
+        for M_ in (201 * 128, 24576, 201 * 64):
+            gemm_case("eDOS fc1 fwd (rowLN pro)", M_, 1024, 256, pro=ops.PRO_ROWLN)
+            gemm_case("eDOS fc2 fwd", M_, 256, 1024)
+            gemm_case("eDOS fc2 dgrad (dy->dh)", M_, 1024, 256, wl=1)
+            gemm_case("eDOS fc1 dgrad (dh->dx)", M_, 256, 1024, wl=1)
     if w in ("all", "wgrad"):
         wgrad_case("edge W1 (2H x 3H)", E, 2 * H, 3 * H)
         wgrad_case("edge W2 (H x 2H)", E, H, 2 * H)
