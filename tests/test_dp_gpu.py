@@ -214,7 +214,9 @@ def test_eight_rank_full_size_configs_match_single_process(eight_rank_full_run, 
             ok = (np.abs(gk) >= 5e-2 * np.abs(gk).max()) & (np.abs(g0s) >= 5e-2 * np.abs(g0s).max())
             if ok.any() and np.abs(a - b)[ok].max() > 2e-4:              # 10 % of the two steps' movement
                 bad.append((k, "resolved", float(np.abs(a - b)[ok].max())))
-            if np.abs(a - b).max() > 2.1e-3:                              # 2 steps of lr 1e-3
+            # an element moves by at most ~lr per step, so two runs are at most 2 steps x 2 lr apart (an element at the noise
+            # floor of both gradients may go opposite ways in both steps)
+            if np.abs(a - b).max() > 4.2e-3:
                 bad.append((k, "bound", float(np.abs(a - b).max())))
         elif not np.array_equal(a, b):                                    # dead parameters: untouched everywhere
             bad.append((k, "dead", 0.0))

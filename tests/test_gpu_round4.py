@@ -787,7 +787,10 @@ def test_factored_edge_weight_gradient_equals_the_plain_one(kind):
                 params[(fac, replay)] = {k: v.detach().clone() for k, v in model.state_dict().items()}
         finally:
             Fn._FACTOR_EDGE_WGRAD, Fn._FACTOR_MIN_GF = True, min_gf
+    n_real, n_pad = g.meta.num_nodes, gp.meta.num_nodes
     for u, v in zip(outs[(True, False)], outs[(False, False)]):
+        if u.shape[0] == n_pad:                          # node embeddings: the ghost rows are finite don't-cares (batch.pad_batch) -
+            u, v = u[:n_real], v[:n_real]                # the last layer's aggregate-first form sums the ghost self loops differently
         assert err(u, v) < 5e-6                          # the forward product factored too: same numbers to rounding
     for k, v in grads[(False, False)].items():
         assert err(grads[(True, False)][k], v) < 1e-4, k
