@@ -59,6 +59,8 @@ struct GemmLaunch {
   int vecA;
   int vecW;
   int rt;    // 32-row blocks per workgroup (1 or 2)
+  int m_base = 0;     // first row of this launch (tail launch of a split call, see gemm_tail_split)
+  int part_base = 0;  // first partial-row block of this launch
 };
 
 __device__ __forceinline__ float prelu_f(float v, float a) { return v >= 0.f ? v : a * v; }
@@ -229,7 +231,7 @@ void gemm_kernel(const GemmLaunch L) {
   // 1-D grid.  Workgroups go to the 8 XCDs round-robin by linear id: within a group of 8 consecutive row
   // blocks the column blocks are enumerated next, so all column blocks of one row block run on the same XCD
   // (id % 8 == row block % 8) and its A rows cross the fabric once, not once per column block.
-  const int gx = (g.M + BMR - 1) / BMR, gy = (g.N + BN - 1) / BN;
+  const int gx = (g.M - L.m_base + BMR - 1) / BMR, gy = (g.N + BN - 1) / BN;
   int bx, by;
   {
     const int lin = blockIdx.x, grp = lin / (8 * gy), rem = lin % (8 * gy);
@@ -240,7 +242,7 @@ void gemm_kernel(const GemmLaunch L) {
   // EPI_SEGSUM: the row tiles are NODE-ALIGNED and of variable height (<= BMR): workgroup t owns the rows
   // [seg_tile[t], seg_tile[t+1]) = the whole destination segments of the nodes [seg_tile[T+1+t], seg_tile[T+2+t]).
   // Every bound below that says M means "end of this workgroup's rows".
-  int m0_ = bx * BMR, mend_ = g.M, nlo_ = 0, nhi_ = 0;
+  int m0_ = L.m_base + bx * BMR, mend_ = g.M, nlo_ = 0, nhi_ = 0;
   if constexpr (EPI == DOSX_EPI_SEGSUM) {
     bx = (int)blockIdx.x;
     by = 0;
@@ -1021,7 +1023,7 @@ void gemm_kernel(const GemmLaunch L) {
   STAMP(58);
   // ---- per-workgroup partial sums for the parameter gradients of the fused LN / PReLU ----------
   if (g.partials && (epi == DOSX_EPI_PRELU_LN_BWD || epi == DOSX_EPI_ROWLN_BWD || epi == DOSX_EPI_PRELU_BWD)) {
-    float* prow = g.partials + (size_t)(bx * gy + by) * g.partial_ld;
+    float* prow = g.partials + (size_t)((L.part_base + bx) * gy + by) * g.partial_ld;
     __syncthreads();                    // (the C tile rows of other waves are still being read above)
     if (epi != DOSX_EPI_PRELU_BWD) {
 #pragma unroll
@@ -1075,7 +1077,7 @@ constexpr size_t gemm_smem_bytes() {
 template <int RT, int NTW, int WL, int PRO, int VEC, int EPI>
 int launch_gemm3(const GemmLaunch& L, hipStream_t s) {
   constexpr int BN = 128 * NTW;
-  dim3 grid(ceil_div(L.g.M, RT == 0 ? 16 : (RT == 3 ? 48 : BM * RT)) * ceil_div(L.g.N, BN));
+  dim3 grid(ceil_div(L.g.M - L.m_base, RT == 0 ? 16 : (RT == 3 ? 48 : BM * RT)) * ceil_div(L.g.N, BN));
   if (EPI == DOSX_EPI_SEGSUM) grid = dim3(L.g.seg_ntiles);          // one workgroup per node-aligned row tile
   constexpr size_t smem = gemm_smem_bytes<RT, NTW, WL, (VEC && (PRO == DOSX_PRO_LN_PRELU || PRO == DOSX_PRO_ROWLN)) ? 1 : 0>();
   if constexpr (smem > 160 * 1024) {     // (512-column tile + LayerNorm prologue: no caller has this shape)
@@ -1199,6 +1201,30 @@ inline int gemm_rt(int M, int N, int epi) {
   if (wg2 >= 192) return 2;
   if (wg1 > 256 && wg1 <= 400 && wg2 >= 128) return 2;
   return 1;
+}
+
+// TAIL SPLIT (round 4).  A grid of W workgroups on 256 CUs runs ceil(W / 256) rounds: 804 tiles of 64 x 128 (the Electron-DOS
+// feed-forward GEMMs, M = 25728) take 4 rounds where 3.14 would do - measured 137.0 us against 99.5 us for M = 24576 (768 tiles:
+// 3 full rounds), i.e. 37 us for the last 4.7 % of the rows (profiles/r04_ab_gemm_tiles.log).  Such a call becomes TWO launches:
+// the rows of the full rounds with the large tile, then the remaining rows as their own small problem under the normal tile
+// policy (16- / 32- / 48-row tiles: one short round).  Returns the first row of the tail (0 = no split).
+inline int gemm_tail_split(int M, int N, int epi) {
+  static int on = -1, max_tail = 160;
+  if (on < 0) {
+    const char* e = getenv("DOSX_GEMM_SPLIT");
+    on = e ? atoi(e) : 1;
+    const char* t = getenv("DOSX_GEMM_SPLIT_MAXTAIL");
+    if (t) max_tail = atoi(t);
+  }
+  if (!on || epi == DOSX_EPI_SEGSUM) return 0;
+  if (gemm_rt(M, N, epi) != 2) return 0;                   // the large-problem regime only (64-row tiles)
+  const int gy = ceil_div(N, gemm_bn(M, N, epi));
+  if (256 % gy) return 0;
+  const int rows_round = 256 / gy * 2 * BM;                // rows of one full round of 64-row tiles
+  const int full = M / rows_round;
+  const int tail_wg = ceil_div(M - full * rows_round, 2 * BM) * gy;
+  if (full < 1 || tail_wg == 0 || tail_wg > max_tail) return 0;
+  return full * rows_round;
 }
 
 inline int gemm_rows_per_wg(int M, int N, int epi) {
@@ -1331,7 +1357,8 @@ extern "C" int dosx_gemm_kernel_name(const DosxGemm* gp, char* buf, int n) {
 extern "C" int dosx_gemm_partial_rows(int M, int N, int epi) {
   // one partial row per workgroup; row-wise epilogues run as one N tile (N <= 512), the
   // element-wise PRELU_BWD epilogue tiles N by 128.
-  const int rows = ceil_div(M, gemm_rows_per_wg(M, N, epi));
+  const int mA = gemm_tail_split(M, N, epi);
+  const int rows = mA ? mA / (2 * BM) + ceil_div(M - mA, gemm_rows_per_wg(M - mA, N, epi)) : ceil_div(M, gemm_rows_per_wg(M, N, epi));
   if (epi == DOSX_EPI_PRELU_BWD) return rows * ceil_div(N, 128);
   return rows;
 }
@@ -1388,9 +1415,25 @@ extern "C" int dosx_gemm(const DosxGemm* gp, dosx_stream_t stream) {
   }
   GemmLaunch L;
   const int bn = gemm_plan(g, L);
-  if (bn == 128) return dispatch_gemm<1>(L, s);
-  if (bn == 256) return dispatch_gemm<2>(L, s);
-  return dispatch_gemm<4>(L, s);
+  auto go = [&](const GemmLaunch& X) {
+    if (bn == 128) return dispatch_gemm<1>(X, s);
+    if (bn == 256) return dispatch_gemm<2>(X, s);
+    return dispatch_gemm<4>(X, s);
+  };
+  const int mA = (L.rt == 2 && !g.stats_out && !g.norm_out) ? gemm_tail_split(g.M, g.N, g.epi) : 0;
+  if (mA > 0 && gemm_bn(g.M - mA, g.N, g.epi) == bn) {
+    GemmLaunch A = L;                        // the full rounds: rows [0, mA)
+    A.g.M = mA;
+    const int rc = go(A);
+    if (rc) return rc;
+    GemmLaunch T = L;                        // the tail: rows [mA, M) under the tile policy of a problem of that size
+    T.m_base = mA;
+    T.part_base = mA / (2 * BM);
+    T.rt = gemm_rt(g.M - mA, g.N, g.epi);
+    if (bn == 512 && T.rt >= 2) T.rt = 1;
+    return go(T);
+  }
+  return go(L);
 }
 
 // =============================================================================================

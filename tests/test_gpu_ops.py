@@ -38,7 +38,10 @@ def prelu(x, a):
                                     # 48-row tiles (8192 < M <= 12288, one column tile): aligned, ragged, unaligned K
                                     (9000, 128, 256), (10001, 96, 41), (12288, 128, 118), (8193, 256, 64),
                                     # 32- and 64-row tiles with ragged edges
-                                    (5000, 100, 64), (20011, 128, 96)])
+                                    (5000, 100, 64), (20011, 128, 96),
+                                    # two launches: the full rounds of 64-row tiles, then the tail rows as 16- / 48-row / 64-row tiles
+                                    # (gemm_tail_split; 20011 above: 16384 + 3627 rows)
+                                    (25728, 256, 128), (25728, 1024, 64), (16384 + 9001, 128, 41), (12864, 1024, 32)])
 @pytest.mark.parametrize("wl", [0, 1])
 def test_gemm_plain(M, N, K, wl):
     o = ops()
@@ -241,7 +244,7 @@ def test_wgrad_gather_fast_path():
     assert err(slab.sum(0), dz.double().T @ cat) < TOL
 
 
-@pytest.mark.parametrize("M,H2", [(100, 256), (45, 512), (33, 32), (4500, 256), (9000, 256)])
+@pytest.mark.parametrize("M,H2", [(100, 256), (45, 512), (33, 32), (4500, 256), (9000, 256), (25728, 256), (17880, 512), (24576 + 700, 128)])
 def test_gemm_prelu_ln_bwd_epilogue(M, H2):
     o = ops()
     H = H2 // 2
@@ -270,7 +273,7 @@ def test_gemm_prelu_ln_bwd_epilogue(M, H2):
     assert abs(float(ps[2 * H2]) - float(alpha.grad)) < 5e-5 * (1 + abs(float(alpha.grad)))
 
 
-@pytest.mark.parametrize("M", [150, 5000, 13000])
+@pytest.mark.parametrize("M", [150, 5000, 13000, 25728])
 def test_gemm_rowln_bwd_relu_mask_prelu_bwd(M):
     o = ops()
     H = 64
