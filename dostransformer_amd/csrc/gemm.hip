@@ -1208,11 +1208,15 @@ inline int gemm_rt(int M, int N, int epi) {
 // 3 full rounds), i.e. 37 us for the last 4.7 % of the rows (profiles/r04_ab_gemm_tiles.log).  Such a call becomes TWO launches:
 // the rows of the full rounds with the large tile, then the remaining rows as their own small problem under the normal tile
 // policy (16- / 32- / 48-row tiles: one short round).  Returns the first row of the tail (0 = no split).
+// RESULT (profiles/r04_ab_gemm_split.log): a tile of a quarter of the rows is NOT a quarter of the time - its k-loop is the same
+// 32 chunks of barrier + weight-tile staging - so the 1152-row tail takes 26 us instead of 37 (fc2 forward 137.7 -> 126.5 us,
+// fc1 input gradient 130.8 -> 120.4), the M = 12864 calls lose (65.9 -> 74.0 us) and the Electron-DOS step is 1.8 % SLOWER
+// (7.54 -> 7.67 ms, four interleaved pairs), configs[4]'s shard 3.7 %.  Kept as an experiment: DOSX_GEMM_SPLIT=1.
 inline int gemm_tail_split(int M, int N, int epi) {
   static int on = -1, max_tail = 160;
   if (on < 0) {
     const char* e = getenv("DOSX_GEMM_SPLIT");
-    on = e ? atoi(e) : 1;
+    on = e ? atoi(e) : 0;          // measured: the kernels gain up to 8 %, the steps lose 2-4 % - off
     const char* t = getenv("DOSX_GEMM_SPLIT_MAXTAIL");
     if (t) max_tail = atoi(t);
   }

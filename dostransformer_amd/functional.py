@@ -493,10 +493,18 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
                         P[lp + ".layer_norms.1.bias"], P[lp + ".fc1.weight"], P[lp + ".fc1.bias"], P[lp + ".fc2.weight"],
                         P[lp + ".fc2.bias"], h, x2, fin=fin_args, att=att_args)
         else:
-            ops.gemm(rows, 4 * H, [seg(x1)], P[lp + ".fc1.weight"], h, pro=PRO_ROWLN,
-                     pro_gamma=P[lp + ".layer_norms.1.weight"], pro_beta=P[lp + ".layer_norms.1.bias"], pro_stats=st1,
-                     bias=P[lp + ".fc1.bias"], act=ACT_RELU)
-            ops.gemm(rows, H, [seg(h)], P[lp + ".fc2.weight"], x2, bias=P[lp + ".fc2.bias"], res=x1)
+            def ffn_rows(r0, r1, x1=x1, st1=st1, h=h, x2=x2, lp=lp):
+                ops.gemm(r1 - r0, 4 * H, [seg(x1[r0:r1])], P[lp + ".fc1.weight"], h[r0:r1], pro=PRO_ROWLN,
+                         pro_gamma=P[lp + ".layer_norms.1.weight"], pro_beta=P[lp + ".layer_norms.1.bias"], pro_stats=st1[r0:r1],
+                         bias=P[lp + ".fc1.bias"], act=ACT_RELU)
+                ops.gemm(r1 - r0, H, [seg(h[r0:r1])], P[lp + ".fc2.weight"], x2[r0:r1], bias=P[lp + ".fc2.bias"], res=x1[r0:r1])
+            mt = _ffn_tail_start(rows)
+            if mt:
+                # the rows beyond the last FULL round of 64-row tiles (25728 = 3 x 8192 + 1152) as their own two-GEMM chain on
+                # the side stream, next to the main rows instead of behind them as a fourth, 14 %-full round of workgroups
+                ops.concurrent(dev, lambda: ffn_rows(mt, rows), lambda: ffn_rows(0, mt))
+            else:
+                ffn_rows(0, rows)
         lay.append((x, qs, qb, x1, probs, qstats, st1, h, mask, None))
         x, qs, qb = x2, Bq, 1
     fin = None
@@ -510,6 +518,21 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
         fin = (xhat, rstd)
         x = y
     return x, (lay, fin, Sq, Bq, Nk, Bk, H, T, kvhat)
+
+
+# Unfused feed-forward layers (hidden > 128), FORWARD: tail rows as a concurrent two-GEMM chain.  Electron-DOS step 7.535 ->
+# 7.473 ms (four interleaved rounds, profiles/r04_ab_ffn_tail.log); the same split in the backward pass, where the weight-
+# gradient groups already fill every gap, gave the gain back (7.526 ms) and is not built in.
+_FFN_TAIL = int(__import__("os").environ.get("DOSX_FFN_TAIL", "1"))
+
+
+def _ffn_tail_start(rows: int) -> int:
+    """First row of the tail of an unfused feed-forward layer (0: no split): the part beyond the last full round of 256
+    workgroups of 64 x 128 tiles at N = H = 256 (8192 rows), when it is small (<= 2048 rows)."""
+    if not _FFN_TAIL or rows < 8192:
+        return 0
+    mt = rows // 8192 * 8192
+    return mt if 0 < rows - mt <= 2048 else 0
 
 
 _FUSED_FFN_BWD = __import__("os").environ.get("DOSX_FUSED_FFN_BWD", "1") == "1"

@@ -610,6 +610,33 @@ def wgrad_grouped(descs: Sequence[Wgrad]) -> None:
 _LPT = __import__("os").environ.get("DOSX_WGRAD_LPT", "1") == "1"
 
 
+def concurrent(device, side_fn, main_fn) -> None:
+    """``side_fn`` (kernel launches) on a dedicated stream NEXT TO ``main_fn`` on the current one: both ordered after
+    everything issued so far on the current stream, which waits for the side work at the end.  Recorded like every stream
+    fork / join (replayed programs, HIP-graph capture); eagerly issued steps run the two one after the other."""
+    if not GradSink.use_side_stream:
+        side_fn()
+        main_fn()
+        return
+    main = torch.cuda.current_stream()
+    key = (str(device), torch.cuda.is_current_stream_capturing(), "t")
+    if key not in GradSink._side_streams:
+        GradSink._side_streams[key] = torch.cuda.Stream(device=device)
+    st = GradSink._side_streams[key]
+    ev = torch.cuda.Event()
+    ev.record(main)
+    st.wait_event(ev)
+    if RECORDER.active:
+        RECORDER.prog.append((ev.record, (main,)))
+        RECORDER.prog.append((st.wait_event, (ev,)))
+    with torch.cuda.stream(st):
+        side_fn()
+    main_fn()
+    main.wait_stream(st)
+    if RECORDER.active:
+        RECORDER.prog.append((main.wait_stream, (st,)))
+
+
 class GradSink:
     """Collects the partial-sum slabs produced during a backward pass and reduces all of them
     into the parameter-gradient buffers with ONE deterministic kernel launch per 'wave'
