@@ -524,6 +524,7 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
 # 7.473 ms (four interleaved rounds, profiles/r04_ab_ffn_tail.log); the same split in the backward pass, where the weight-
 # gradient groups already fill every gap, gave the gain back (7.526 ms) and is not built in.
 _FFN_TAIL = int(__import__("os").environ.get("DOSX_FFN_TAIL", "1"))
+_FFN_TAIL_MAX = int(__import__("os").environ.get("DOSX_FFN_TAIL_MAX", "2048"))
 
 
 def _ffn_tail_start(rows: int) -> int:
@@ -532,7 +533,7 @@ def _ffn_tail_start(rows: int) -> int:
     if not _FFN_TAIL or rows < 8192:
         return 0
     mt = rows // 8192 * 8192
-    return mt if 0 < rows - mt <= 2048 else 0
+    return mt if 0 < rows - mt <= _FFN_TAIL_MAX else 0
 
 
 _FUSED_FFN_BWD = __import__("os").environ.get("DOSX_FUSED_FFN_BWD", "1") == "1"
