@@ -136,6 +136,12 @@ def _factor_edge(E: int, H: int) -> bool:
     return _FACTOR_EDGE_WGRAD and 2.0 * E * (2 * H) * (3 * H) >= _FACTOR_MIN_GF * 1e9
 
 
+def _factor_last(E: int, H: int) -> bool:
+    """Whether the LAST message-passing layer aggregates its activations per node in front of its second Linear (mlp_ln_fwd,
+    aggsum): from DOSX_FACTOR_LAST_MIN_GF GF of that Linear's E-row product."""
+    return _FACTOR_LAST and not _wide_ln(H) and 2.0 * E * (2 * H) * H >= _FACTOR_LAST_MIN_GF * 1e9
+
+
 def _mlp_ln_fused(a: SegList, M: int, H: int) -> bool:
     return a.plain is not None and len(a.plain) <= 2 and ops.mlp_ln_supported(M, a.K, 2 * H, H)
 
@@ -307,7 +313,7 @@ def gnn_fwd(P: Params, m: GraphMeta, x: torch.Tensor, e: torch.Tensor, L: int, m
         agg = _empty(dev, N, H)
         last = l == L - 1                       # the last layer's edge update is dead
         e_new = None if last else _empty(dev, E, H)
-        if last and _FACTOR_LAST and _factor_edge(E, H) and not _wide_ln(H):
+        if last and _factor_last(E, H):
             _, cxe = mlp_ln_fwd(P, pre + ".edge_model.edge_mlp", a_e, E, H, aggsum=(m.rowptr_dst, scale, agg, N))
         elif m.seg_tile is not None and H <= 256:
             # scatter_mean / scatter_sum + the edge residual inside the message GEMM's epilogue (node-aligned row tiles):
@@ -541,6 +547,7 @@ _FACTOR_EDGE_WGRAD = __import__("os").environ.get("DOSX_FACTOR_EDGE_WGRAD", "1")
 _FACTOR_MIN_GF = float(__import__("os").environ.get("DOSX_FACTOR_MIN_GF", "4"))
 _FACTOR_DGRAD = __import__("os").environ.get("DOSX_FACTOR_DGRAD", "1") == "1"             # ... and its input gradient
 _FACTOR_LAST = __import__("os").environ.get("DOSX_FACTOR_LAST", "1") == "1"               # last layer: aggregate, then the second Linear
+_FACTOR_LAST_MIN_GF = float(__import__("os").environ.get("DOSX_FACTOR_LAST_MIN_GF", "1.3"))
 _FUSED_ATT_FFN = __import__("os").environ.get("DOSX_FUSED_ATT_FFN", "1") == "1"       # <= 16-key attention inside dosx_ffn_fwd
 _ATT_FFN_MAX_ROWS = int(__import__("os").environ.get("DOSX_ATT_FFN_MAX_ROWS", "4096"))
 _FUSED_DKV = __import__("os").environ.get("DOSX_FUSED_DKV", "1") == "1"
