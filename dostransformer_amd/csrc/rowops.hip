@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 //           `LayerNorm -> PReLU`): y = xhat*gamma+beta, dy *= (y < 0 ? alpha : 1), dalpha += dy*y where y < 0 - what the
 //           EPI_PRELU_LN_BWD epilogue of dosx_gemm does for rows of up to 512 floats.  partial row [dgamma | dbeta | pad(3) | dalpha]
 constexpr int LNW_K = 4;
-template <int MODE>
+template <int MODE, int KN = LNW_K>
 __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const float* __restrict__ dy, const float* __restrict__ ddos,
                                                           const float* __restrict__ xhat, const float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -176,9 +176,9 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const float* __restric
   const int pld = MODE == 1 ? 3 * W + 1 : (MODE == 2 ? 2 * W + 4 : 2 * W);
   const float invW = 1.f / (float)W;
   const float al = MODE == 2 ? *alpha : 0.f;
-  float4 g[LNW_K], bt[LNW_K], ww[LNW_K], pg[LNW_K], pb[LNW_K], pw[LNW_K];
+  float4 g[KN], bt[KN], ww[KN], pg[KN], pb[KN], pw[KN];
 #pragma unroll
-  for (int k = 0; k < LNW_K; ++k) {
+  for (int k = 0; k < KN; ++k) {
     const int c = lane * 4 + 256 * k, cc = c < W ? c : 0;
     g[k] = ld4(gamma + cc);
     bt[k] = MODE != 0 ? ld4(beta + cc) : f4zero();
@@ -186,6 +186,18 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const float* __restric
     pg[k] = f4zero(); pb[k] = f4zero(); pw[k] = f4zero();
   }
   float psc = 0.f;                              // db (MODE 1) / dalpha (MODE 2)
+  int gi[8];                                    // gathered rows: indices and scales of this wave's 8 rows, fetched up front
+  float gs[8];
+  if (MODE == 2 && dyidx) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = min(blockIdx.x * 32 + wave * 8 + i, M - 1);
+      gi[i] = dyidx[r];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gs[i] = dyscale ? dyscale[gi[i]] : 1.f;
+  }
+#pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int r = blockIdx.x * 32 + wave * 8 + i;
     if (r >= M) break;                          // (wave-uniform)
@@ -195,12 +207,12 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const float* __restric
       dyr = ddos[(size_t)(r % Bq) * S + (r / Bq)];
       if (lane == 0) psc += dyr;
     }
-    float4 xh[LNW_K], d[LNW_K];
+    float4 xh[KN], d[KN];
     float s1 = 0.f, s2 = 0.f;
-    const size_t dr = (MODE == 2 && dyidx) ? (size_t)dyidx[r] : (size_t)r;
-    const float dsc = (MODE == 2 && dyscale) ? dyscale[dr] : 1.f;
+    const size_t dr = (MODE == 2 && dyidx) ? (size_t)gi[i] : (size_t)r;
+    const float dsc = (MODE == 2 && dyidx) ? gs[i] : 1.f;
 #pragma unroll
-    for (int k = 0; k < LNW_K; ++k) {
+    for (int k = 0; k < KN; ++k) {
       const int c = lane * 4 + 256 * k;
       xh[k] = f4zero(); d[k] = f4zero();
       if (c >= W) continue;
@@ -208,7 +220,7 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const float* __restric
       if (MODE == 1) d[k] = make_float4(dyr * ww[k].x, dyr * ww[k].y, dyr * ww[k].z, dyr * ww[k].w);
       else {
         d[k] = ld4(dy + dr * W + c);
-        if (MODE == 2 && dyscale) d[k] = make_float4(d[k].x * dsc, d[k].y * dsc, d[k].z * dsc, d[k].w * dsc);
+        if (MODE == 2 && dyidx) d[k] = make_float4(d[k].x * dsc, d[k].y * dsc, d[k].z * dsc, d[k].w * dsc);
       }
       const float4 h = xh[k];
       if (MODE == 2) {
@@ -233,7 +245,7 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const float* __restric
     s1 = wave_sum(s1) * invW;
     s2 = wave_sum(s2) * invW;
 #pragma unroll
-    for (int k = 0; k < LNW_K; ++k) {
+    for (int k = 0; k < KN; ++k) {
       const int c = lane * 4 + 256 * k;
       if (c >= W) continue;
       const float4 dd = d[k], h = xh[k];
@@ -244,7 +256,7 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const float* __restric
   }
   float* my = sm + (size_t)wave * (NV * W);
 #pragma unroll
-  for (int k = 0; k < LNW_K; ++k) {
+  for (int k = 0; k < KN; ++k) {
     const int c = lane * 4 + 256 * k;
     if (c >= W) continue;
     st4(my + c, pg[k]);
@@ -634,8 +646,12 @@ extern "C" int dosx_ln_prelu_bwd_gather(const float* dy, const int32_t* idx, con
   CHECK_H4(W);
   DOSX_CHECK_ARG(dy && idx && xhat && rstd && gamma && beta && alpha && dz && partials, "dosx_ln_prelu_bwd_gather: bad args");
   DOSX_CHECK_ARG(W <= 256 * LNW_K, "dosx_ln_prelu_bwd_gather: row width %d > %d", W, 256 * LNW_K);
-  hipLaunchKernelGGL((ln_bwd_wide_kernel<2>), dim3(ceil_div(M, 32)), dim3(256), (4 * (size_t)(2 * W) + 4) * sizeof(float),
-                     to_stream(stream), dy, nullptr, xhat, rstd, gamma, beta, nullptr, alpha, dz, partials, M, W, 0, 1, idx, scale);
+  if (W <= 512)        // (two float4 column groups per lane: half the registers of the general form)
+    hipLaunchKernelGGL((ln_bwd_wide_kernel<2, 2>), dim3(ceil_div(M, 32)), dim3(256), (4 * (size_t)(2 * W) + 4) * sizeof(float),
+                       to_stream(stream), dy, nullptr, xhat, rstd, gamma, beta, nullptr, alpha, dz, partials, M, W, 0, 1, idx, scale);
+  else
+    hipLaunchKernelGGL((ln_bwd_wide_kernel<2>), dim3(ceil_div(M, 32)), dim3(256), (4 * (size_t)(2 * W) + 4) * sizeof(float),
+                       to_stream(stream), dy, nullptr, xhat, rstd, gamma, beta, nullptr, alpha, dz, partials, M, W, 0, 1, idx, scale);
   DOSX_LAUNCH_CHECK();
   return 0;
 }

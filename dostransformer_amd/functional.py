@@ -39,6 +39,8 @@ class SegList:
         self.keep = list(keep)
         self.K = sum(s.width for s in segs)
         self.plain = plain          # the segments as whole row-major tensors, when that is all they are (no row maps)
+        self.factor = None          # (x, e, graph meta) behind cat[x[row], x[col], e]: the EdgeModel input (gnn_fwd)
+        self.aggsum = None          # (S, rowptr, scale, N, R) when the second Linear ran on aggregated rows (mlp_ln_fwd)
 
 
 def pack_params(P: Params) -> Params:
@@ -162,7 +164,7 @@ def mlp_ln_fwd(P: Params, key: str, a: SegList, M: int, H: int, res: Optional[to
                        P[key + ".1.weight"], P[key + ".1.bias"], P[key + ".2.weight"], P[key + ".3.weight"],
                        P[key + ".3.bias"], res, xhat, rstd, y)
         return y, (a, xhat, rstd, M, H)
-    fac = getattr(a, "factor", None)
+    fac = a.factor
     if fac is not None and _factor_edge(M, H):
         # Large edge sets (throughput-bound): the first Linear FACTORED - Linear(cat[x[row], x[col], e]) = (x Wa^T)[row] +
         # (x Wb^T)[col] + e Wc^T + b.  The two node products are N-row GEMMs, the E-row GEMM keeps a third of the columns, and one
@@ -217,7 +219,7 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
     a, xhat, rstd, M, H = ctx
     dev = xhat.device
     gam, bet, alpha = P[key + ".1.weight"], P[key + ".1.bias"], P[key + ".2.weight"]
-    agg_first = getattr(a, "aggsum", None)
+    agg_first = a.aggsum
     if agg_first is not None:
         # forward aggregated in front of the second Linear (mlp_ln_fwd, aggsum): dy = dL/d agg, one row per NODE (a strided
         # view of the node-MLP input gradient).  Weight gradient sum_n dagg_n (x) S_n on N rows; bias gradient = column sums of
@@ -241,7 +243,7 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
     pld = 4 * H + 4          # [dgamma(2H) | dbeta(2H) | pad(3) | dalpha]; multiple of 4 -> vector reduce
     part = sink.scratch(rows, pld)
     dz = _empty(dev, M, 2 * H)
-    fac_dgrad = getattr(a, "factor", None) is not None and _factor_edge(M, H) and _FACTOR_DGRAD and not fused
+    fac_dgrad = a.factor is not None and _factor_edge(M, H) and _FACTOR_DGRAD and not fused
     dcat = None if fac_dgrad else _empty(dev, M, a.K)
     if fused:
         ops.mlp_ln_bwd(M, dy, xhat, rstd, P[key + ".0.weight"], P[key + ".3.weight"], gam, bet, alpha, dz, dcat, part)
@@ -258,7 +260,7 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
     sink.add(part, 0, G[key + ".1.weight"], rows, pld, 2 * H)
     sink.add(part, 2 * H, G[key + ".1.bias"], rows, pld, 2 * H)
     sink.add(part, pld - 1, G[key + ".2.weight"], rows, pld, 1)
-    fac = getattr(a, "factor", None)
+    fac = a.factor
     if fac is not None and _factor_edge(M, H) and key + ".0.weight" in G:
         # The first Linear reads cat[x[row], x[col], e] (DOSTransformer_phonon.py:193-195): its weight gradient is
         #   sum_e dz_e (x) [x[row(e)] | x[col(e)] | e_e]  =  [ sum_n S_n (x) x_n | sum_n D_n (x) x_n | sum_e dz_e (x) e_e ],
@@ -342,7 +344,7 @@ def gnn_bwd(P: Params, G: Params, m: GraphMeta, ctxs, dx: torch.Tensor, sink: Gr
         pre = f"stacked_processor.{l}"
         cxe, cxn = ctxs[l]
         dcat_n = mlp_ln_bwd(P, G, pre + ".node_model.node_mlp_2", cxn, dx, sink)          # [N, 2H]
-        if getattr(cxe[0], "aggsum", None) is not None:
+        if cxe[0].aggsum is not None:
             assert de is None                        # (the last layer: no edge-state gradient arrives)
             dmsg = dcat_n[:, H:]                     # dL/d agg [N,H]: mlp_ln_bwd expands it per edge inside its row kernel
         else:
@@ -504,7 +506,7 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
                          pro_gamma=P[lp + ".layer_norms.1.weight"], pro_beta=P[lp + ".layer_norms.1.bias"], pro_stats=st1[r0:r1],
                          bias=P[lp + ".fc1.bias"], act=ACT_RELU)
                 ops.gemm(r1 - r0, H, [seg(h[r0:r1])], P[lp + ".fc2.weight"], x2[r0:r1], bias=P[lp + ".fc2.bias"], res=x1[r0:r1])
-            mt = _ffn_tail_start(rows)
+            mt = _ffn_tail_start(rows, H)
             if mt:
                 # the rows beyond the last FULL round of 64-row tiles (25728 = 3 x 8192 + 1152) as their own two-GEMM chain on
                 # the side stream, next to the main rows instead of behind them as a fourth, 14 %-full round of workgroups
@@ -533,13 +535,15 @@ _FFN_TAIL = int(__import__("os").environ.get("DOSX_FFN_TAIL", "1"))
 _FFN_TAIL_MAX = int(__import__("os").environ.get("DOSX_FFN_TAIL_MAX", "2048"))
 
 
-def _ffn_tail_start(rows: int) -> int:
+def _ffn_tail_start(rows: int, H: int) -> int:
     """First row of the tail of an unfused feed-forward layer (0: no split): the part beyond the last full round of 256
-    workgroups of 64 x 128 tiles at N = H = 256 (8192 rows), when it is small (<= 2048 rows)."""
-    if not _FFN_TAIL or rows < 8192:
+    workgroups of 64 x 128 tiles of the H-wide GEMM (H = 256: 8192 rows), when it is small (<= DOSX_FFN_TAIL_MAX rows)."""
+    gy = (H + 127) // 128
+    if not _FFN_TAIL or 256 % gy:
         return 0
-    mt = rows // 8192 * 8192
-    return mt if 0 < rows - mt <= _FFN_TAIL_MAX else 0
+    per_round = 256 // gy * 64
+    mt = rows // per_round * per_round
+    return mt if mt > 0 and 0 < rows - mt <= _FFN_TAIL_MAX else 0
 
 
 _FUSED_FFN_BWD = __import__("os").environ.get("DOSX_FUSED_FFN_BWD", "1") == "1"
