@@ -180,6 +180,7 @@ _SIGS = {
     "dosx_gemm_partial_rows": [_I, _I, _I],
     "dosx_set_sliver_max_gf": [_D],
     "dosx_gemm": [C.POINTER(Gemm), _P],
+    "dosx_gemm_pair": [C.POINTER(Gemm), C.POINTER(Gemm), _P],
     "dosx_gemm_kernel_name": [C.POINTER(Gemm), C.c_char_p, _I],
     "dosx_wgrad_splits": [_I, _I, _I],
     "dosx_wgrad_tiles": [_I, _I],

@@ -189,8 +189,7 @@ __device__ __forceinline__ float4 a_finish(const AState& st, const ARaw& r, int 
 #define DOSX_HOIST_MAX_NTW 4
 #endif
 template <int RTP, int NTW, int WL, int PRO, int VEC, int EPI>
-__global__ __launch_bounds__(512, (NTW == 1 && (EPI == DOSX_EPI_BIAS_ACT || EPI == DOSX_EPI_LN || EPI == DOSX_EPI_RELU_MASK)) ? 4 : 2)
-void gemm_kernel(const GemmLaunch L) {
+__device__ __forceinline__ void gemm_body(const GemmLaunch& L, const int bid) {     // bid: this workgroup's index in L's grid
   DOSX_SET_MAIN_PRIO();
   const DosxGemm& g = L.g;
   // RTP = 0: HALF tile.  The workgroup owns 16 rows and multiplies with the 16x16x4 MFMA (same flop rate, half the
@@ -234,7 +233,7 @@ void gemm_kernel(const GemmLaunch L) {
   const int gx = (g.M - L.m_base + BMR - 1) / BMR, gy = (g.N + BN - 1) / BN;
   int bx, by;
   {
-    const int lin = blockIdx.x, grp = lin / (8 * gy), rem = lin % (8 * gy);
+    const int lin = bid, grp = lin / (8 * gy), rem = lin % (8 * gy);
     const int rows_in_grp = min(8, gx - grp * 8);          // last group may be short
     bx = grp * 8 + rem % rows_in_grp;
     by = rem / rows_in_grp;
@@ -244,7 +243,7 @@ void gemm_kernel(const GemmLaunch L) {
   // Every bound below that says M means "end of this workgroup's rows".
   int m0_ = L.m_base + bx * BMR, mend_ = g.M, nlo_ = 0, nhi_ = 0;
   if constexpr (EPI == DOSX_EPI_SEGSUM) {
-    bx = (int)blockIdx.x;
+    bx = bid;
     by = 0;
     m0_ = g.seg_tile[bx];
     mend_ = g.seg_tile[bx + 1];
@@ -1060,6 +1059,23 @@ void gemm_kernel(const GemmLaunch L) {
   }
 }
 
+template <int RTP, int NTW, int WL, int PRO, int VEC, int EPI>
+__global__ __launch_bounds__(512, (NTW == 1 && (EPI == DOSX_EPI_BIAS_ACT || EPI == DOSX_EPI_LN || EPI == DOSX_EPI_RELU_MASK)) ? 4 : 2)
+void gemm_kernel(const GemmLaunch L) {
+  gemm_body<RTP, NTW, WL, PRO, VEC, EPI>(L, (int)blockIdx.x);
+}
+
+// TWO independent problems of the same tile configuration in ONE grid (dosx_gemm_pair: the two output heads `fc` and
+// `fc_prompt`, DOSTransformer_phonon.py:93-109 - same N, disjoint output rows): workgroups [0, nblk1) run the first, the rest
+// the second.  Each head alone is one partial round of workgroups (102 of 32 rows at the benchmark shape); together they are
+// still one round, so the pair costs one kernel's latency instead of two + a launch.  Plain epilogue, W[N,K], aligned operands.
+template <int RTP, int NTW>
+__global__ __launch_bounds__(512, NTW == 1 ? 4 : 2)
+void gemm_pair_kernel(const GemmLaunch L1, const GemmLaunch L2, const int nblk1) {
+  const bool second = (int)blockIdx.x >= nblk1;
+  gemm_body<RTP, NTW, 0, DOSX_PRO_NONE, 1, DOSX_EPI_BIAS_ACT>(second ? L2 : L1, second ? (int)blockIdx.x - nblk1 : (int)blockIdx.x);
+}
+
 template <int RTP, int NTW, int WL, int PROLN>
 constexpr size_t gemm_smem_bytes() {
   constexpr int RT = RTP == 0 ? 1 : (RTP == 3 ? 2 : RTP);
@@ -1367,10 +1383,7 @@ extern "C" int dosx_gemm_partial_rows(int M, int N, int epi) {
   return rows;
 }
 
-extern "C" int dosx_gemm(const DosxGemm* gp, dosx_stream_t stream) {
-  DOSX_CHECK_ARG(gp != nullptr, "dosx_gemm: null descriptor");
-  const DosxGemm& g = *gp;
-  if (g.M <= 0 || g.N <= 0) return 0;
+static int gemm_validate(const DosxGemm& g) {
   DOSX_CHECK_ARG(g.K > 0, "dosx_gemm: K=%d", g.K);
   DOSX_CHECK_ARG(g.nseg >= 1 && g.nseg <= 3, "dosx_gemm: nseg=%d", g.nseg);
   int ksum = 0;
@@ -1411,6 +1424,15 @@ extern "C" int dosx_gemm(const DosxGemm* gp, dosx_stream_t stream) {
                    "dosx_gemm: EPI_SEGSUM needs seg_tile / seg_rowptr / seg_agg / seg_part / seg_cnt, N <= 256, an identity "
                    "out_map and res with out");
 
+  return 0;
+}
+
+extern "C" int dosx_gemm(const DosxGemm* gp, dosx_stream_t stream) {
+  DOSX_CHECK_ARG(gp != nullptr, "dosx_gemm: null descriptor");
+  const DosxGemm& g = *gp;
+  if (g.M <= 0 || g.N <= 0) return 0;
+  if (const int rc = gemm_validate(g)) return rc;
+
   hipStream_t s = to_stream(stream);
   if (sliver_ok(g)) {
     hipLaunchKernelGGL(sliver_gemm_kernel, dim3(ceil_div(g.M, SG_T), ceil_div(g.N, SG_T)), dim3(256), 0, s, g);
@@ -1438,6 +1460,65 @@ extern "C" int dosx_gemm(const DosxGemm* gp, dosx_stream_t stream) {
     return go(T);
   }
   return go(L);
+}
+
+template <int RT, int NTW>
+static int launch_gemm_pair(const GemmLaunch& A, const GemmLaunch& B, hipStream_t s) {
+  constexpr int BN = 128 * NTW, ROWS = RT == 0 ? 16 : (RT == 3 ? 48 : BM * RT);
+  const int n1 = ceil_div(A.g.M, ROWS) * ceil_div(A.g.N, BN), n2 = ceil_div(B.g.M, ROWS) * ceil_div(B.g.N, BN);
+  constexpr size_t smem = gemm_smem_bytes<RT, NTW, 0, 0>();
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pair_kernel<RT, NTW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_pair_kernel<RT, NTW>), dim3(n1 + n2), dim3(512), smem, s, A, B, n1);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+// Two GEMMs in one launch when they share a tile configuration (see gemm_pair_kernel), otherwise one after the other.
+extern "C" int dosx_gemm_pair(const DosxGemm* ap, const DosxGemm* bp, dosx_stream_t stream) {
+  DOSX_CHECK_ARG(ap != nullptr && bp != nullptr, "dosx_gemm_pair: null descriptor");
+  const DosxGemm &a = *ap, &b = *bp;
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("DOSX_GEMM_PAIR");
+    on = e ? atoi(e) : 1;
+  }
+  bool one = on && a.M > 0 && b.M > 0 && a.N == b.N && a.N > 0 && a.w_layout == 0 && b.w_layout == 0 && a.pro == DOSX_PRO_NONE &&
+             b.pro == DOSX_PRO_NONE && a.epi == DOSX_EPI_BIAS_ACT && b.epi == DOSX_EPI_BIAS_ACT && !sliver_ok(a) && !sliver_ok(b);
+  GemmLaunch A, B;
+  int bn = 0;
+  if (one) {
+    if (const int rc = gemm_validate(a)) return rc;
+    if (const int rc = gemm_validate(b)) return rc;
+    bn = gemm_plan(a, A);
+    one = gemm_plan(b, B) == bn && bn <= 256 && A.vecA && A.vecW && B.vecA && B.vecW;
+  }
+  if (!one) {
+    if (const int rc = dosx_gemm(ap, stream)) return rc;
+    return dosx_gemm(bp, stream);
+  }
+  // the tile height of ONE problem with all the rows: the pair shares the CUs like one grid
+  const int rt = gemm_rt(a.M + b.M, a.N, a.epi);
+  A.rt = B.rt = rt;
+  hipStream_t s = to_stream(stream);
+  if (bn == 128) {
+    switch (rt) {
+      case 0: return launch_gemm_pair<0, 1>(A, B, s);
+      case 1: return launch_gemm_pair<1, 1>(A, B, s);
+      case 2: return launch_gemm_pair<2, 1>(A, B, s);
+      default: return launch_gemm_pair<3, 1>(A, B, s);
+    }
+  }
+  switch (rt) {
+    case 0: return launch_gemm_pair<0, 2>(A, B, s);
+    case 1: return launch_gemm_pair<1, 2>(A, B, s);
+    case 2: return launch_gemm_pair<2, 2>(A, B, s);
+    default: return launch_gemm_pair<3, 2>(A, B, s);
+  }
 }
 
 // =============================================================================================

@@ -174,8 +174,8 @@ def mlp_ln_fwd(P: Params, key: str, a: SegList, M: int, H: int, res: Optional[to
         W1 = P[key + ".0.weight"]
         N_ = m.num_nodes
         pq = _empty(dev, N_, 4 * H)
-        ops.gemm(N_, 2 * H, [seg(x)], W1[:, :H], pq[:, :2 * H])
-        ops.gemm(N_, 2 * H, [seg(x)], W1[:, H:2 * H], pq[:, 2 * H:])
+        ops.gemm_pair(dict(M=N_, N=2 * H, segs=[seg(x)], w=W1[:, :H], out=pq[:, :2 * H]),
+                      dict(M=N_, N=2 * H, segs=[seg(x)], w=W1[:, H:2 * H], out=pq[:, 2 * H:]))
         z = _empty(dev, M, 2 * H)
         ops.gemm(M, 2 * H, [seg(e)], W1[:, 2 * H:], z, bias=P[key + ".0.bias"])
         ops.gather_add_rownorm(z, pq[:, :2 * H], pq[:, 2 * H:], m.src, m.dst, xhat, rstd, M, 2 * H)
@@ -1024,10 +1024,10 @@ def dostransformer_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta, drop=None):
     kvs = _empty(dev, S * 2 * B, H)
     rstd_s = _empty(dev, S * 2 * B)
     nk = dict(norm_out=kvs, norm_rstd=rstd_s) if _FUSED_HEAD_NORM else {}
-    ops.gemm(S * B, H, a_g.segs, P["fc.weight"], dosin, bias=P["fc.bias"], act=ACT_LEAKY, act_slope=0.01,
-             out_map=rowmap(d=B, m=2 * B, c=1, off=0), **nk)
-    ops.gemm(S * B, H, a_s.segs, P["fc_prompt.weight"], dosin, bias=P["fc_prompt.bias"], act=ACT_LEAKY,
-             act_slope=0.01, out_map=rowmap(d=B, m=2 * B, c=1, off=B), **nk)
+    ops.gemm_pair(dict(M=S * B, N=H, segs=a_g.segs, w=P["fc.weight"], out=dosin, bias=P["fc.bias"], act=ACT_LEAKY, act_slope=0.01,
+                       out_map=rowmap(d=B, m=2 * B, c=1, off=0), **nk),
+                  dict(M=S * B, N=H, segs=a_s.segs, w=P["fc_prompt.weight"], out=dosin, bias=P["fc_prompt.bias"], act=ACT_LEAKY,
+                       act_slope=0.01, out_map=rowmap(d=B, m=2 * B, c=1, off=B), **nk))
     if not _FUSED_HEAD_NORM:
         ops.rownorm(dosin, kvs, rstd_s, S * 2 * B, H)
     hs, c2 = encoder_fwd(P, "transformer_self", dosin, S, 2 * B, 2 * B, 1, kvs, S, 2 * B, H, T, drop=dr(64))

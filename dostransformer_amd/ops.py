@@ -314,6 +314,33 @@ def gemm(M: int, N: int, segs: Sequence[Seg], w: torch.Tensor, out: torch.Tensor
          epi_alpha=None, partials=None, partial_ld: int = 0, res_col0: int = 0, seg_tile=None, seg_rowptr=None,
          seg_scale=None, seg_agg=None, keep: Optional[list] = None, norm_out=None, norm_rstd=None) -> None:
     """out[M,N] = epilogue(prologue(A) @ B); see include/dosx.h:DosxGemm."""
+    g = _gemm_desc(M, N, segs, w, out, w_layout=w_layout, pro=pro, pro_gamma=pro_gamma, pro_beta=pro_beta, pro_alpha=pro_alpha,
+                   pro_stats=pro_stats, epi=epi, act=act, act_slope=act_slope, bias=bias, out_map=out_map, res=res, res_map=res_map,
+                   stats_out=stats_out, aux_out=aux_out, aux=aux, aux_stats=aux_stats, epi_gamma=epi_gamma, epi_beta=epi_beta,
+                   epi_alpha=epi_alpha, partials=partials, partial_ld=partial_ld, res_col0=res_col0, seg_tile=seg_tile,
+                   seg_rowptr=seg_rowptr, seg_scale=seg_scale, seg_agg=seg_agg, norm_out=norm_out, norm_rstd=norm_rstd)
+    _call("dosx_gemm", C.byref(g), _stream(), w=lambda: _gemm_work(g))
+
+
+def gemm_pair(first: dict, second: dict) -> None:
+    """Two independent GEMMs (keyword dictionaries of :func:`gemm`: M, N, segs, w, out, ...) as ONE launch when they share a
+    tile configuration - same N, W[N,K], plain epilogue, aligned operands - else one after the other (include/dosx.h:
+    dosx_gemm_pair)."""
+    g1, g2 = _gemm_desc(**first), _gemm_desc(**second)
+
+    def work():
+        t1, t2 = _gemm_work(g1), _gemm_work(g2)
+        return (f"gemm_pair[N{g1.N},K{g1.K}+{g2.K}]", "gemm_pair_kernel", "mfma", t1[3] + t2[3])
+    _call("dosx_gemm_pair", C.byref(g1), C.byref(g2), _stream(), w=work)
+
+
+def _gemm_desc(M: int, N: int, segs: Sequence[Seg], w: torch.Tensor, out: torch.Tensor, *, w_layout: int = 0,
+               pro: int = PRO_NONE, pro_gamma=None, pro_beta=None, pro_alpha=None, pro_stats=None,
+               epi: int = EPI_BIAS_ACT, act: int = ACT_NONE, act_slope: float = 0.01, bias=None,
+               out_map: Optional[RowMap] = None, res=None, res_map: Optional[RowMap] = None,
+               stats_out=None, aux_out=None, aux=None, aux_stats=None, epi_gamma=None, epi_beta=None,
+               epi_alpha=None, partials=None, partial_ld: int = 0, res_col0: int = 0, seg_tile=None, seg_rowptr=None,
+               seg_scale=None, seg_agg=None, norm_out=None, norm_rstd=None) -> "Gemm":
     g = Gemm()
     g.M, g.N = int(M), int(N)
     g.K = int(sum(s.width for s in segs))
@@ -347,7 +374,7 @@ def gemm(M: int, N: int, segs: Sequence[Seg], w: torch.Tensor, out: torch.Tensor
         # chunk sums of over-full nodes (in-degree > 48) + their arrival counters: always there, a table may hold such tiles
         part = alloc(w.device, g.seg_ntiles, g.N)
         g.seg_part, g.seg_cnt = part.data_ptr(), COUNTERS.take(w.device, g.seg_ntiles)
-    _call("dosx_gemm", C.byref(g), _stream(), w=lambda: _gemm_work(g))
+    return g
 
 
 def _gemm_work(g: Gemm):

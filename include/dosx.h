@@ -138,6 +138,11 @@ typedef struct DosxGemm {
 int dosx_set_sliver_max_gf(double gf);
 int dosx_gemm_partial_rows(int M, int N, int epi);
 int dosx_gemm(const DosxGemm* g, dosx_stream_t stream);
+/* Two independent GEMMs in ONE launch when they share a tile configuration (same N, W[N,K], no prologue, the plain epilogue,
+ * 4-float aligned operands), one after the other otherwise - the two output heads `fc` / `fc_prompt`
+ * (DOSTransformer_phonon.py:93-95,105-109; DOSTransformer.py:64-66,76-80) write disjoint rows of one tensor and are each one
+ * partial round of workgroups: together still one round.  Tile height chosen for the rows of both. */
+int dosx_gemm_pair(const DosxGemm* a, const DosxGemm* b, dosx_stream_t stream);
 /* diagnostic: the device symbol dosx_gemm launches for this descriptor, as a profiler prints it
  * ("gemm_kernel<RT, NTW, WL, PRO, VEC, EPI>"), written to the HOST buffer buf[n]. */
 int dosx_gemm_kernel_name(const DosxGemm* g, char* buf, int n);

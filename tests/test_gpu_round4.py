@@ -848,3 +848,43 @@ def test_act_segment_sum_and_gathered_ln_prelu_backward(mean, W, Hout):
     dz_ref, part_ref = torch.empty(E, W, device=DEV), torch.zeros(rows, pld, device=DEV)
     ops.ln_prelu_bwd(dact.contiguous(), xhat, rstd, gam, bet, alpha, dz_ref, part_ref, E, W)
     assert torch.equal(dz, dz_ref) and torch.equal(part, part_ref)                        # the same arithmetic on gathered rows
+
+
+@pytest.mark.parametrize("M1,M2,N,K1,K2", [(3264, 3264, 128, 256, 320), (51, 51, 128, 256, 320), (12864, 12864, 256, 512, 640),
+                                            (700, 1900, 64, 128, 160), (3264, 3264, 128, 256, 118)])
+def test_gemm_pair_is_the_two_gemms(M1, M2, N, K1, K2):
+    """dosx_gemm_pair: two problems (the output heads `fc` / `fc_prompt`, DOSTransformer_phonon.py:93-109: mod-B gathered segments,
+    LeakyReLU, remapped output rows, normalised copy) in one grid against the two separate launches - same tile arithmetic per
+    row when the tile height agrees, rounding otherwise; the last case (unaligned K) falls back to two launches."""
+    from dostransformer_amd import ops
+    torch.manual_seed(3)
+    B = 8
+    a1, a2 = torch.randn(M1, K1 - 64, device=DEV), torch.randn(M2, K2 - 64, device=DEV)
+    gr = torch.randn(B, 64, device=DEV)
+    modB = ops.rowmap(d=B, m=0, c=1)
+    w1, w2 = torch.randn(N, K1, device=DEV) / K1 ** 0.5, torch.randn(N, K2, device=DEV) / K2 ** 0.5
+    b1, b2 = torch.randn(N, device=DEV), torch.randn(N, device=DEV)
+
+    def run(pair):
+        out = torch.zeros(M1 + M2, N, device=DEV)
+        nrm, rs = torch.zeros(M1 + M2, N, device=DEV), torch.zeros(M1 + M2, device=DEV)
+        kw1 = dict(M=M1, N=N, segs=[ops.seg(a1), ops.seg(gr, rmap=modB)], w=w1, out=out, bias=b1, act=ops.ACT_LEAKY, act_slope=0.01,
+                   out_map=ops.rowmap(d=1 << 30, m=0, c=1, off=0), norm_out=nrm, norm_rstd=rs)
+        kw2 = dict(M=M2, N=N, segs=[ops.seg(a2), ops.seg(gr, rmap=modB)], w=w2, out=out, bias=b2, act=ops.ACT_LEAKY, act_slope=0.01,
+                   out_map=ops.rowmap(d=1 << 30, m=0, c=1, off=M1), norm_out=nrm, norm_rstd=rs)
+        if pair:
+            ops.gemm_pair(kw1, kw2)
+        else:
+            ops.gemm(**kw1)
+            ops.gemm(**kw2)
+        return out, nrm, rs
+    o2, n2, r2 = run(False)
+    o1, n1, r1 = run(True)
+    ref1 = torch.cat([a1, gr[torch.arange(M1, device=DEV) % B]], 1).double() @ w1.double().T + b1.double()
+    ref2 = torch.cat([a2, gr[torch.arange(M2, device=DEV) % B]], 1).double() @ w2.double().T + b2.double()
+    ref = torch.cat([ref1, ref2])
+    ref = torch.where(ref >= 0, ref, 0.01 * ref)
+    assert err(o1, ref) < 1e-5 and err(o2, ref) < 1e-5
+    assert err(o1, o2) < 2e-6 and err(n1, n2) < 2e-5 and err(r1, r2) < 2e-5
+    o1b, _, _ = run(True)
+    assert torch.equal(o1, o1b)
