@@ -253,3 +253,22 @@ def test_seg_tiles_host_properties():
         rows = np.diff(eb)
         assert all(i == 0 and rows[0] == 0 for i in range(T - 1) if rows[i] + rows[i + 1] <= R)
         assert T <= seg_tile_bound(n, int(rp[-1]), 1)
+
+
+def test_size_policies_of_the_factored_forms():
+    """The size limits that switch the EdgeModel between its fused and its factored forms, and the tail split of the unfused
+    feed-forward layers (functional._factor_edge / _factor_last / _ffn_tail_start): the BASELINE shapes land where DESIGN.md
+    says they do."""
+    from dostransformer_amd import functional as Fn
+    # Phonon-DOS benchmark shape (H 128, ~9000 edges): fused forms; Electron-DOS (H 256, 17880 edges; the 32-crystal shard
+    # has about half of them): factored first Linear and aggregate-first last layer
+    assert not Fn._factor_edge(9000, 128) and not Fn._factor_last(9000, 128)
+    assert Fn._factor_edge(17880, 256) and Fn._factor_last(17880, 256)
+    assert Fn._factor_edge(8900, 256) and Fn._factor_last(8900, 256)
+    assert not Fn._factor_last(17880, 384)                    # 2 * hidden > 512: the unfused wide-row path keeps the per-edge form
+    # feed-forward tail: 25728 = 3 full rounds of 8192 rows + 1152; 12864 = 1 round + 4672 (too large a tail); small problems never
+    assert Fn._ffn_tail_start(25728, 256) == 24576
+    assert Fn._ffn_tail_start(12864, 256) == 0
+    assert Fn._ffn_tail_start(8192, 256) == 0 and Fn._ffn_tail_start(6528, 256) == 0
+    assert Fn._ffn_tail_start(25728, 384) == 0                # 3 column tiles do not divide the 256 CUs: no split
+    assert Fn._ffn_tail_start(16384 + 100, 512) == 16384      # 4 column tiles: rounds of 4096 rows
