@@ -638,7 +638,7 @@ _LPT = __import__("os").environ.get("DOSX_WGRAD_LPT", "1") == "1"
 
 
 def concurrent(device, side_fn, main_fn) -> None:
-    """``side_fn`` (kernel launches) on a dedicated stream NEXT TO ``main_fn`` on the current one: both ordered after
+    """``side_fn`` (kernel launches) on the side stream NEXT TO ``main_fn`` on the current one: both ordered after
     everything issued so far on the current stream, which waits for the side work at the end.  Recorded like every stream
     fork / join (replayed programs, HIP-graph capture); eagerly issued steps run the two one after the other."""
     if not GradSink.use_side_stream:
@@ -646,7 +646,10 @@ def concurrent(device, side_fn, main_fn) -> None:
         main_fn()
         return
     main = torch.cuda.current_stream()
-    key = (str(device), torch.cuda.is_current_stream_capturing(), "t")
+    # the SIDE stream of the recorded programs, not a stream of its own: a process has a handful of hardware queues (main,
+    # side, weight-gradient, RCCL's), and a fifth software stream shares one of them - measured: the data-parallel step of a
+    # process that had merely CREATED one more stream went from 1.31 to 1.38 ms
+    key = (str(device), torch.cuda.is_current_stream_capturing())
     if key not in GradSink._side_streams:
         GradSink._side_streams[key] = torch.cuda.Stream(device=device)
     st = GradSink._side_streams[key]
