@@ -888,3 +888,34 @@ def test_gemm_pair_is_the_two_gemms(M1, M2, N, K1, K2):
     assert err(o1, o2) < 2e-6 and err(n1, n2) < 2e-5 and err(r1, r2) < 2e-5
     o1b, _, _ = run(True)
     assert torch.equal(o1, o1b)
+
+
+@pytest.mark.parametrize("mode", ["graph", "replay"])
+def test_concurrent_feed_forward_tail_is_bitwise_in_every_launch_mode(mode):
+    """The tail rows of the unfused feed-forward layers run as a concurrent chain on the side stream (functional._ffn_tail_start,
+    ops.concurrent): an Electron-DOS model with hidden 256 and 21 crystals has 2 * 21 * 201 = 8442 rows = one full round of
+    8192 + 250.  Recorded replay and HIP-graph capture (stream fork / join recorded resp. captured) against the eagerly issued
+    step on the same ghost-padded batch (one stream, the two chains one after the other): the same bits after 3 steps."""
+    import copy
+    from dostransformer_amd import functional as Fn, synth
+    from dostransformer_amd.batch import bucket_sizes, pad_batch
+    from dostransformer_amd.embedder_eDOS.DOSTransformer import DOSTransformer
+    from dostransformer_amd.train import Trainer
+    assert Fn._ffn_tail_start(2 * 21 * 201, 256) == 8192
+    torch.manual_seed(0)
+    b = synth.edos_batch(21, seed=77, dtype=torch.float32).to(DEV)
+    bp = pad_batch(b, *bucket_sizes(b.meta.num_nodes, b.meta.num_edges))
+    mk = lambda: DOSTransformer(3, 1, 200, 41, 2, 256, DEV, 0.0)
+    m_e = mk().to(DEV)
+    m_r = mk()
+    m_r.load_state_dict(copy.deepcopy(m_e.state_dict()))
+    m_r = m_r.to(DEV)
+    te = Trainer(m_e, lr=1e-3)
+    tr = Trainer(m_r, lr=1e-3, graph=(mode == "graph"), replay=(mode == "replay"))
+    for i in range(3):
+        le, lr_ = te.step(bp), tr.step(b)
+        assert float(le) == float(lr_), i
+    torch.cuda.synchronize()
+    for (k, a), (_, c) in zip(m_e.state_dict().items(), m_r.state_dict().items()):
+        if a.is_floating_point():
+            assert torch.equal(a, c), k
