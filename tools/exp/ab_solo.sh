@@ -1,5 +1,6 @@
 #!/bin/bash
 # one workgroup per CU for the large 64-row-tile GEMMs (DOSX_GEMM_SOLO_WG = smallest grid that gets the LDS pad)
+# (the knob is not in the tree: git apply tools/exp/patches/gemm_solo_wg.diff, rebuild, run; result: profiles/r04_ab_gemm_solo.log)
 cd "${GRAFT_REPO_ROOT:-$(pwd)}"
 ms() { python3 -c "import json,sys; r=json.loads(sys.stdin.read()); print(r['ms_per_step'])"; }
 for v in 0 300; do echo "== DOSX_GEMM_SOLO_WG=$v"; DOSX_GEMM_SOLO_WG=$v python3 tools/bench_kernels.py --what edosffn 2>/dev/null | grep gemm; done
