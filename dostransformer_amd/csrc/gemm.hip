@@ -1076,6 +1076,16 @@ void gemm_pair_kernel(const GemmLaunch L1, const GemmLaunch L2, const int nblk1)
   gemm_body<RTP, NTW, 0, DOSX_PRO_NONE, 1, DOSX_EPI_BIAS_ACT>(second ? L2 : L1, second ? (int)blockIdx.x - nblk1 : (int)blockIdx.x);
 }
 
+// ONE problem, TWO tile heights in one grid (gemm_tail_split): workgroups [0, nblk1) own the rows of the full rounds as
+// RTA-high tiles (L1: rows [0, L1.g.M)), the rest the remaining rows as RTB-high tiles (L2: rows [L2.m_base, M)).  The small
+// tiles are dispatched last and share their CUs with the last large ones instead of forming a nearly empty round of their own.
+template <int RTA, int RTB, int NTW, int WL, int PRO, int VEC, int EPI>
+__global__ __launch_bounds__(512, (NTW == 1 && (EPI == DOSX_EPI_BIAS_ACT || EPI == DOSX_EPI_LN || EPI == DOSX_EPI_RELU_MASK)) ? 4 : 2)
+void gemm_mixed_kernel(const GemmLaunch L1, const GemmLaunch L2, const int nblk1) {
+  if ((int)blockIdx.x < nblk1) gemm_body<RTA, NTW, WL, PRO, VEC, EPI>(L1, (int)blockIdx.x);
+  else gemm_body<RTB, NTW, WL, PRO, VEC, EPI>(L2, (int)blockIdx.x - nblk1);
+}
+
 template <int RTP, int NTW, int WL, int PROLN>
 constexpr size_t gemm_smem_bytes() {
   constexpr int RT = RTP == 0 ? 1 : (RTP == 3 ? 2 : RTP);
@@ -1224,19 +1234,27 @@ inline int gemm_rt(int M, int N, int epi) {
 // 3 full rounds), i.e. 37 us for the last 4.7 % of the rows (profiles/r04_ab_gemm_tiles.log).  Such a call becomes TWO launches:
 // the rows of the full rounds with the large tile, then the remaining rows as their own small problem under the normal tile
 // policy (16- / 32- / 48-row tiles: one short round).  Returns the first row of the tail (0 = no split).
-// RESULT (profiles/r04_ab_gemm_split.log): a tile of a quarter of the rows is NOT a quarter of the time - its k-loop is the same
+// RESULT of the first form - TWO launches, the tail behind the full rounds - (profiles/r04_ab_gemm_split.log): a tile of a quarter of the rows is NOT a quarter of the time - its k-loop is the same
 // 32 chunks of barrier + weight-tile staging - so the 1152-row tail takes 26 us instead of 37 (fc2 forward 137.7 -> 126.5 us,
 // fc1 input gradient 130.8 -> 120.4), the M = 12864 calls lose (65.9 -> 74.0 us) and the Electron-DOS step is 1.8 % SLOWER
-// (7.54 -> 7.67 ms, four interleaved pairs), configs[4]'s shard 3.7 %.  Kept as an experiment: DOSX_GEMM_SPLIT=1.
+// (7.54 -> 7.67 ms, four interleaved pairs), configs[4]'s shard 3.7 %.  SECOND form (shipped): the same split in ONE launch -
+// gemm_mixed_kernel, the tail's 32- / 48-row tiles at the end of the grid, no launch boundary in between: the same kernel
+// times (fc2 forward 138.9 -> 126.5 us, fc1 input gradient 129.9 -> 119.5), and the steps no longer lose: Electron-DOS
+// 7.40 ms either way (its forward tails already run as a concurrent chain), configs[4]'s shard 7.28 -> 7.23 ms
+// (profiles/r04_ab_gemm_mixed.log).  DOSX_GEMM_SPLIT=0 switches it off.
 inline int gemm_tail_split(int M, int N, int epi) {
   static int on = -1, max_tail = 160;
   if (on < 0) {
     const char* e = getenv("DOSX_GEMM_SPLIT");
-    on = e ? atoi(e) : 0;          // measured: the kernels gain up to 8 %, the steps lose 2-4 % - off
+    on = e ? atoi(e) : 1;          // (the one-launch mixed-height form; the two-launch form lost 2-4 % per step)
     const char* t = getenv("DOSX_GEMM_SPLIT_MAXTAIL");
     if (t) max_tail = atoi(t);
   }
-  if (!on || epi == DOSX_EPI_SEGSUM) return 0;
+  // (the mixed-height kernel exists for the plain / ReLU-mask epilogues on 128-column tiles and for the LayerNorm-backward
+  //  epilogue on one 256-column tile: the feed-forward GEMMs of a hidden-256 model and the plain large GEMMs around them)
+  if (!on) return 0;
+  const int bn_ = gemm_bn(M, N, epi);
+  if (!((bn_ == 128 && (epi == DOSX_EPI_BIAS_ACT || epi == DOSX_EPI_RELU_MASK)) || (bn_ == 256 && epi == DOSX_EPI_ROWLN_BWD))) return 0;
   if (gemm_rt(M, N, epi) != 2) return 0;                   // the large-problem regime only (64-row tiles)
   const int gy = ceil_div(N, gemm_bn(M, N, epi));
   if (256 % gy) return 0;
@@ -1245,6 +1263,12 @@ inline int gemm_tail_split(int M, int N, int epi) {
   const int tail_wg = ceil_div(M - full * rows_round, 2 * BM) * gy;
   if (full < 1 || tail_wg == 0 || tail_wg > max_tail) return 0;
   return full * rows_round;
+}
+
+// tile height (in gemm_kernel's RT code) of the tail rows of a split call: 48-row tiles where the normal policy picks them
+// (LayerNorm-backward epilogue only), 32-row tiles otherwise
+inline int gemm_tail_rt(int Mt, int N, int epi) {
+  return (epi == DOSX_EPI_ROWLN_BWD && gemm_rt(Mt, N, epi) == 3) ? 3 : 1;
 }
 
 inline int gemm_rows_per_wg(int M, int N, int epi) {
@@ -1378,9 +1402,47 @@ extern "C" int dosx_gemm_partial_rows(int M, int N, int epi) {
   // one partial row per workgroup; row-wise epilogues run as one N tile (N <= 512), the
   // element-wise PRELU_BWD epilogue tiles N by 128.
   const int mA = gemm_tail_split(M, N, epi);
-  const int rows = mA ? mA / (2 * BM) + ceil_div(M - mA, gemm_rows_per_wg(M - mA, N, epi)) : ceil_div(M, gemm_rows_per_wg(M, N, epi));
+  const int rows = mA ? mA / (2 * BM) + ceil_div(M - mA, gemm_tail_rt(M - mA, N, epi) == 3 ? 48 : BM) : ceil_div(M, gemm_rows_per_wg(M, N, epi));
   if (epi == DOSX_EPI_PRELU_BWD) return rows * ceil_div(N, 128);
   return rows;
+}
+
+template <int RTB, int NTW, int WL, int PRO, int EPI>
+static int launch_gemm_mixed3(const GemmLaunch& A, const GemmLaunch& T, hipStream_t s) {
+  constexpr int BN = 128 * NTW, ROWS_B = RTB == 3 ? 48 : BM * RTB;
+  const int n1 = ceil_div(A.g.M, 2 * BM) * ceil_div(A.g.N, BN), n2 = ceil_div(T.g.M - T.m_base, ROWS_B) * ceil_div(T.g.N, BN);
+  constexpr int PROLN = (PRO == DOSX_PRO_LN_PRELU || PRO == DOSX_PRO_ROWLN) ? 1 : 0;
+  constexpr size_t sa = gemm_smem_bytes<2, NTW, WL, PROLN>(), sb = gemm_smem_bytes<RTB, NTW, WL, PROLN>();
+  constexpr size_t smem = sa > sb ? sa : sb;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mixed_kernel<2, RTB, NTW, WL, PRO, 1, EPI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_mixed_kernel<2, RTB, NTW, WL, PRO, 1, EPI>), dim3(n1 + n2), dim3(512), smem, s, A, T, n1);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+// -1: no mixed-height kernel for this combination (the caller launches the plain grid)
+static int launch_gemm_mixed(int bn, const GemmLaunch& A, const GemmLaunch& T, hipStream_t s) {
+  const DosxGemm& g = A.g;
+  if (bn == 128 && T.rt == 1) {
+    if (g.epi == DOSX_EPI_BIAS_ACT && g.w_layout == 0 && g.pro == DOSX_PRO_NONE)
+      return launch_gemm_mixed3<1, 1, 0, DOSX_PRO_NONE, DOSX_EPI_BIAS_ACT>(A, T, s);
+    if (g.epi == DOSX_EPI_BIAS_ACT && g.w_layout == 0 && g.pro == DOSX_PRO_ROWLN)
+      return launch_gemm_mixed3<1, 1, 0, DOSX_PRO_ROWLN, DOSX_EPI_BIAS_ACT>(A, T, s);
+    if (g.epi == DOSX_EPI_BIAS_ACT && g.w_layout == 1 && g.pro == DOSX_PRO_NONE)
+      return launch_gemm_mixed3<1, 1, 1, DOSX_PRO_NONE, DOSX_EPI_BIAS_ACT>(A, T, s);
+    if (g.epi == DOSX_EPI_RELU_MASK && g.w_layout == 1 && g.pro == DOSX_PRO_NONE)
+      return launch_gemm_mixed3<1, 1, 1, DOSX_PRO_NONE, DOSX_EPI_RELU_MASK>(A, T, s);
+  }
+  if (bn == 256 && g.epi == DOSX_EPI_ROWLN_BWD && g.w_layout == 1 && g.pro == DOSX_PRO_NONE) {
+    if (T.rt == 1) return launch_gemm_mixed3<1, 2, 1, DOSX_PRO_NONE, DOSX_EPI_ROWLN_BWD>(A, T, s);
+    if (T.rt == 3) return launch_gemm_mixed3<3, 2, 1, DOSX_PRO_NONE, DOSX_EPI_ROWLN_BWD>(A, T, s);
+  }
+  return -1;
 }
 
 static int gemm_validate(const DosxGemm& g) {
@@ -1446,18 +1508,17 @@ extern "C" int dosx_gemm(const DosxGemm* gp, dosx_stream_t stream) {
     if (bn == 256) return dispatch_gemm<2>(X, s);
     return dispatch_gemm<4>(X, s);
   };
-  const int mA = (L.rt == 2 && !g.stats_out && !g.norm_out) ? gemm_tail_split(g.M, g.N, g.epi) : 0;
-  if (mA > 0 && gemm_bn(g.M - mA, g.N, g.epi) == bn) {
-    GemmLaunch A = L;                        // the full rounds: rows [0, mA)
+  const int mA = (L.rt == 2 && L.vecA && L.vecW && !g.stats_out && !g.norm_out) ? gemm_tail_split(g.M, g.N, g.epi) : 0;
+  if (mA > 0) {
+    GemmLaunch A = L;                        // the full rounds: rows [0, mA) as 64-row tiles
     A.g.M = mA;
-    const int rc = go(A);
-    if (rc) return rc;
-    GemmLaunch T = L;                        // the tail: rows [mA, M) under the tile policy of a problem of that size
+    GemmLaunch T = L;                        // the tail: rows [mA, M) as 32- / 48-row tiles, same grid
     T.m_base = mA;
     T.part_base = mA / (2 * BM);
-    T.rt = gemm_rt(g.M - mA, g.N, g.epi);
-    if (bn == 512 && T.rt >= 2) T.rt = 1;
-    return go(T);
+    T.rt = gemm_tail_rt(g.M - mA, g.N, g.epi);
+    const int rc = launch_gemm_mixed(bn, A, T, s);
+    if (rc != -1) return rc;
+    DOSX_CHECK_ARG(g.partials == nullptr, "dosx_gemm: split policy and kernel set disagree (epilogue %d)", g.epi);
   }
   return go(L);
 }
