@@ -919,3 +919,36 @@ def test_concurrent_feed_forward_tail_is_bitwise_in_every_launch_mode(mode):
     for (k, a), (_, c) in zip(m_e.state_dict().items(), m_r.state_dict().items()):
         if a.is_floating_point():
             assert torch.equal(a, c), k
+
+
+@pytest.mark.parametrize("M", [16384 + 700, 25728, 16384 + 9000])
+def test_mixed_tile_heights_with_the_layernorm_backward_epilogue(M):
+    """dosx_gemm's mixed-height grid (gemm_tail_split / gemm_mixed_kernel) on the one epilogue that leaves partial rows: fc1's
+    input gradient of a hidden-256 feed-forward layer (transformer.py:141-148 backward) - 64 x 256 tiles for the first 16384
+    rows, 32-row tiles (700 tail rows) or 48-row tiles (9344 / 9000 tail rows) behind them, partial-row blocks numbered through
+    both parts.  Against torch autograd in fp64; NaN-filled partial buffer: every block is written exactly once."""
+    import torch.nn.functional as F
+    from dostransformer_amd import ops as o
+    H = 256
+    g_ = torch.Generator(device="cpu").manual_seed(5)
+    rnd = lambda *s, scale=1.0: (torch.randn(*s, generator=g_) * scale).to(DEV)
+    x = rnd(M, H).double().requires_grad_(True)
+    gam = rnd(H).double().requires_grad_(True)
+    bet = rnd(H).double().requires_grad_(True)
+    w1 = rnd(4 * H, H, scale=0.1)
+    dh = rnd(M, 4 * H)
+    res = rnd(M, H)
+    (F.layer_norm(x, (H,), gam, bet, 1e-5) @ w1.double().T).backward(dh.double())
+    mu = x.detach().mean(1)
+    rs = 1 / torch.sqrt(x.detach().var(1, unbiased=False) + 1e-5)
+    stats = torch.stack([mu, rs], 1).float().contiguous()
+    dx = torch.empty(M, H, device=DEV)
+    rows = o.gemm_partial_rows(M, H, o.EPI_ROWLN_BWD)
+    assert rows == 256 + ((M - 16384 + 47) // 48 if M - 16384 > 8192 else (M - 16384 + 31) // 32)
+    part = torch.full((rows, 2 * H), float('nan'), device=DEV)
+    o.gemm(M, H, [o.seg(dh)], w1, dx, w_layout=1, epi=o.EPI_ROWLN_BWD, aux=x.detach().float(), aux_stats=stats,
+           epi_gamma=gam.detach().float(), res=res, partials=part, partial_ld=2 * H)
+    assert err(dx, x.grad + res.double()) < 5e-5
+    ps = part.double().sum(0)
+    assert not torch.isnan(ps).any()
+    assert err(ps[:H], gam.grad) < 5e-5 and err(ps[H:], bet.grad) < 5e-5
