@@ -35,6 +35,7 @@ N_DISTINCT_BATCHES = 8
 # more buckets to record (one eager step each, once): 64/1280 1.401 ms (4 live buckets), 32/640 1.358 (8), 16/320 1.349
 # (16), 8/160 1.340 (30, at the slot cap) on the synthetic phonon set, misses inside the timed region included
 SHUFFLE_BUCKET = (16, 320)
+PROMOTE = float(os.environ.get("DOSX_BENCH_PROMOTE", "0.08"))   # Trainer(promote=...) of the --shuffle runs
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA dense peak
 
@@ -256,7 +257,8 @@ def run_workload(name, *, device, world, rank, dp, mode, shuffle, steps, warmup,
     kind, L, T, H, B = CONFIGS[name]
     model = build_model(kind, L, T, H, device).to(device)
     use_graph = mode in ("graph", "replay")          # both run on ghost-padded (N,E) shape buckets
-    trainer = Trainer(model, lr=1e-4, beta=1.0, dist=dp, graph=(mode == "graph"), replay=(mode == "replay"), bucket=bucket)
+    trainer = Trainer(model, lr=1e-4, beta=1.0, dist=dp, graph=(mode == "graph"), replay=(mode == "replay"), bucket=bucket,
+                      promote=PROMOTE if shuffle else 0.0)      # (fresh random batches: rare shapes borrow a live bucket)
     n_global = B * world
 
     real_dims = []          # (N, E, n_max) of the un-padded batches: the algorithmic-flop count uses real rows only
@@ -331,7 +333,7 @@ def run_workload(name, *, device, world, rank, dp, mode, shuffle, steps, warmup,
     # graph / replay mode: the timed region re-issues recorded launches (no per-kernel events possible), so the
     # kernel timing comes from an instrumented pass of the same steps right after it.
     ops.KERNEL_TIMER.reset(enabled=not use_graph)
-    hits0, miss0 = trainer.slot_hits, trainer.slot_misses
+    hits0, miss0, prom0 = trainer.slot_hits, trainer.slot_misses, trainer.slot_promoted
     if shuffle:
         real_dims.clear()
     t0 = time.perf_counter()
@@ -343,7 +345,7 @@ def run_workload(name, *, device, world, rank, dp, mode, shuffle, steps, warmup,
         td.barrier()
     elapsed = time.perf_counter() - t0
     ops.KERNEL_TIMER.enabled = False
-    hits, misses = trainer.slot_hits - hits0, trainer.slot_misses - miss0
+    hits, misses, promoted = trainer.slot_hits - hits0, trainer.slot_misses - miss0, trainer.slot_promoted - prom0
     n_slots = len(trainer._slots)
     # host time to ENQUEUE one step with an empty queue in front of it (inside the timed loop the host also blocks on the
     # HIP queue's back pressure whenever it runs ahead of the GPU, so `host` above is an upper bound, not the enqueue cost)
@@ -405,7 +407,7 @@ def run_workload(name, *, device, world, rank, dp, mode, shuffle, steps, warmup,
     res = {"kind": kind, "L": L, "T": T, "H": H, "B": B, "n_global": n_global, "elapsed": elapsed, "host": host, "host_enqueue": host_enqueue,
            "roof": roof, "n_inst": n_inst, "flops_step": flops_step, "prepare_steps": n_prep, "dp_info": dp_info,
            "slots": {"hits": hits, "misses": misses, "hit_rate": round(hits / max(hits + misses, 1), 4),
-                     "live": n_slots, "max": trainer.max_slots} if use_graph else None}
+                     "promoted": promoted, "live": n_slots, "max": trainer.max_slots} if use_graph else None}
     del trainer, model
     torch.cuda.empty_cache()
     return res
@@ -577,7 +579,7 @@ def main():
             secondary["edos_h256_t4_b32"] = brief(e4, 30)
             sh = run_workload("phonon_h128_b64", shuffle=True, steps=args.steps, warmup=max(args.warmup, 60),
                               bucket=SHUFFLE_BUCKET, instrument=False, **common)
-            secondary["shuffle"] = dict(brief(sh, args.steps), hit_rate=sh["slots"]["hit_rate"], live_buckets=sh["slots"]["live"])
+            secondary["shuffle"] = dict(brief(sh, args.steps), hit_rate=sh["slots"]["hit_rate"], promoted=sh["slots"]["promoted"], live_buckets=sh["slots"]["live"])
         except Exception as ex:  # a secondary line must never take the headline down with it
             secondary["error"] = f"{type(ex).__name__}: {ex}"[:200]
         # the same headline workload through the DATA-PARALLEL step on a 1-rank RCCL group: the replay plan split around

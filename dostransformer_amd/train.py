@@ -116,6 +116,22 @@ class _Slot:
         ops.copy_many(pairs)
 
 
+def promote_key(live_keys, key, tol: float):
+    """The live bucket key a batch of bucket ``key`` = (n_pad, e_pad, *rest) can run in: same ``rest`` (batch size, key-slot
+    count, global count, tiling), at least as many node and edge rows, at most ``tol`` (relative) more of either; the
+    smallest such by (edges, nodes), or None."""
+    n, e, rest = key[0], key[1], tuple(key[2:])
+    best = None
+    for k in live_keys:
+        if tuple(k[2:]) != rest or k[0] < n or k[1] < e:
+            continue
+        if k[0] > n * (1.0 + tol) + 1e-9 or k[1] > e * (1.0 + tol) + 1e-9:
+            continue
+        if best is None or (k[1], k[0]) < (best[1], best[0]):
+            best = k
+    return best
+
+
 class Trainer:
     """AdamW(lr, weight_decay=1e-2) training of a DOSTransformer(_phonon) module, all on libdosx.
 
@@ -126,7 +142,7 @@ class Trainer:
 
     def __init__(self, model: DOSTransformerBase, lr: float = 1e-4, beta: float = 1.0, weight_decay: float = 1e-2,
                  betas=(0.9, 0.999), eps: float = 1e-8, dist=None, graph: bool = False, replay: bool = False,
-                 bucket=(8, 128), max_slots: int = 32):
+                 bucket=(8, 128), max_slots: int = 32, promote: float = 0.0):
         if not isinstance(model, DOSTransformerBase):
             raise TypeError("Trainer drives DOSTransformer / DOSTransformer_phonon modules")
         self.model, self.lr, self.beta, self.wd, self.betas, self.eps = model, lr, beta, weight_decay, betas, eps
@@ -149,7 +165,11 @@ class Trainer:
         # per-epoch shuffling new (N, E) buckets keep appearing, each holding a step's worth of activations
         self._slots: "OrderedDict[tuple, _Slot]" = OrderedDict()
         self.max_slots = int(max_slots)
-        self.slot_hits = self.slot_misses = 0
+        self.slot_hits = self.slot_misses = self.slot_promoted = 0
+        # largest relative excess of nodes / edges a first-time bucket accepts from a live one (step_dataset; 0 = every
+        # bucket records its own launch list: bitwise the step on the batch padded to its own bucket)
+        self.promote = float(promote)
+        self._seen = {}
         self.kernel_timer = None          # ops._KernelTimer: replayed programs then run through dosx_replay_timed
         self._ds_checked = []             # datasets whose per-rank size was compared across the ranks (step_dataset)
 
@@ -343,9 +363,23 @@ class Trainer:
         slot.keep = (st, loss)
         slot.loss, slot.out, slot.sse = loss, st["out"], st.get("sse")
 
-    def _lookup(self, key):
-        """(slot or None) of a bucket key, with the LRU / hit-rate bookkeeping."""
+    def _lookup(self, key, allow_promote: bool = False):
+        """(slot or None) of a bucket key, with the LRU / hit-rate bookkeeping.  ``allow_promote`` (step_dataset: the batch is
+        collated straight into whatever bucket it gets): a bucket that is asked for the FIRST time runs
+        in the smallest live bucket that holds it with at most ``promote`` more nodes / edges, if there is one (ghost padding
+        is exact whatever the bucket): recording a launch list costs two to three steps, so the rare shapes of a reshuffled
+        epoch - seen once - never pay it, and a shape that comes back is recorded on its second visit."""
         slot = self._slots.get(key)
+        if slot is None and allow_promote and self.promote > 0:
+            seen = self._seen.get(key, 0)
+            self._seen[key] = seen + 1
+            if seen == 0:
+                host = promote_key(self._slots.keys(), key, self.promote)
+                if host is not None:
+                    self.slot_hits += 1
+                    self.slot_promoted += 1
+                    self._slots.move_to_end(host)
+                    return self._slots[host]
         if slot is None:
             self.slot_misses += 1
             while len(self._slots) >= self.max_slots:          # evict the least recently used bucket
@@ -445,7 +479,7 @@ class Trainer:
             ng = B * self.dist.world
         tiled = True
         key = (n_pad, e_pad, B, n_max, ng, tiled)
-        slot = self._lookup(key)
+        slot = self._lookup(key, allow_promote=True)
         fresh = slot is None
         if fresh:
             t = ds._f32_tables()

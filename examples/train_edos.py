@@ -69,7 +69,7 @@ def main(argv=None):
     # coarse shape buckets: reshuffled batches fall into a few dozen (N, E) buckets, each recorded once (ghost padding is
     # exact); every batch pads its keys to the training set's largest crystal so that n_max is not a bucket dimension
     bucket = (32, 512)
-    trainer = Trainer(model, lr=args.lr, beta=args.beta, replay=True, bucket=bucket)      # AdamW(lr, weight_decay=1e-2), `:91`
+    trainer = Trainer(model, lr=args.lr, beta=args.beta, replay=True, bucket=bucket, promote=0.08)      # AdamW(lr, weight_decay=1e-2), `:91`
     predictor = Predictor(model, bucket=bucket)
     criterion_2 = torch.nn.L1Loss()                                                       # `main_eDOS.py:93`
     nmax_train = int(ds["train"].n_nodes.max())

@@ -56,7 +56,7 @@ def main(argv=None):
     model = DOSTransformer_phonon(args.layers, args.transformer, 118, 4, args.hidden, dev, 0.0).to(dev)
     # coarse shape buckets: reshuffled batches then fall into a few dozen (N, E, n_max) buckets that are all recorded
     # within the first epoch (ghost padding is exact; it costs a few per cent of extra rows)
-    trainer = Trainer(model, lr=args.lr, beta=args.beta, replay=True, bucket=(32, 1024))
+    trainer = Trainer(model, lr=args.lr, beta=args.beta, replay=True, bucket=(32, 1024), promote=0.08)
     predictor = Predictor(model, bucket=(32, 1024))
     best, history = float("inf"), []
     for epoch in range(args.epochs):

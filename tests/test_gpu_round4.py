@@ -952,3 +952,39 @@ def test_mixed_tile_heights_with_the_layernorm_backward_epilogue(M):
     ps = part.double().sum(0)
     assert not torch.isnan(ps).any()
     assert err(ps[:H], gam.grad) < 5e-5 and err(ps[H:], bet.grad) < 5e-5
+
+
+def test_first_time_bucket_runs_in_a_live_one():
+    """Trainer(promote=...) + step_dataset: a shape bucket asked for the first time borrows the smallest live bucket that holds
+    it (ghost rows are exact don't-cares whatever the padding) instead of recording a launch list of its own; the second time it
+    is asked for, it records.  Losses and parameters against a trainer without promotion (every bucket its own program): the same
+    step up to the summation order of the weight-gradient splits (padding moves the split points)."""
+    import copy
+    from dostransformer_amd import synth
+    from dostransformer_amd.loader import DeviceDataset
+    from dostransformer_amd.train import Trainer
+    cs = synth.phonon_crystals(40, seed=91, dtype=torch.float32)
+    ds = DeviceDataset(cs, DEV)
+    nmax = max(int(c["x"].shape[0]) for c in cs)
+    order = sorted(range(40), key=lambda i: int(cs[i]["x"].shape[0]))
+    big, small = order[-8:], order[:8]                       # 8 largest / 8 smallest crystals: different (N, E) buckets
+    torch.manual_seed(2)
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    _phonon = lambda H, T: DOSTransformer_phonon(3, T, 118, 4, H, DEV, 0.0)
+    m_a = _phonon(32, 1).to(DEV)
+    m_b = _phonon(32, 1)
+    m_b.load_state_dict(copy.deepcopy(m_a.state_dict()))
+    m_b = m_b.to(DEV)
+    ta = Trainer(m_a, lr=1e-3, replay=True, bucket=(8, 64), promote=10.0)        # (any live bucket that is large enough)
+    tb = Trainer(m_b, lr=1e-3, replay=True, bucket=(8, 64))
+    seq = [big, small, big, small, small]
+    for k, sel in enumerate(seq):
+        la, lb = ta.step_dataset(ds, sel, n_max=nmax), tb.step_dataset(ds, sel, n_max=nmax)
+        assert abs(float(la) - float(lb)) < 1e-5 * max(1.0, abs(float(lb))), k
+    # small: first sighting -> ran in big's bucket (promoted), second sighting -> recorded its own, third -> exact hit
+    assert ta.slot_promoted == 1 and len(ta._slots) == 2 and ta.slot_misses == 2
+    assert tb.slot_promoted == 0 and len(tb._slots) == 2 and tb.slot_misses == 2
+    for (k, a), (_, b) in zip(m_a.state_dict().items(), m_b.state_dict().items()):
+        if a.is_floating_point():
+            assert float((a - b).abs().max()) < 5e-3, k          # 5 steps of lr 1e-3 bound any element's drift
+            assert float((a - b).abs().median()) < 1e-5, k

@@ -272,3 +272,19 @@ def test_size_policies_of_the_factored_forms():
     assert Fn._ffn_tail_start(8192, 256) == 0 and Fn._ffn_tail_start(6528, 256) == 0
     assert Fn._ffn_tail_start(25728, 384) == 0                # 3 column tiles do not divide the 256 CUs: no split
     assert Fn._ffn_tail_start(16384 + 100, 512) == 16384      # 4 column tiles: rounds of 4096 rows
+
+
+def test_bucket_promotion_picks_the_smallest_live_bucket_that_fits():
+    """train.promote_key: a first-time bucket runs in a live one of the same batch size / key-slot count / tiling with at
+    least as many rows and at most `tol` more of either, the smallest by (edges, nodes); never in a smaller or a foreign one."""
+    from dostransformer_amd.train import promote_key
+    rest = (64, 12, 64, True)
+    live = [(448, 8960) + rest, (464, 9280) + rest, (480, 9600) + rest, (464, 9280, 32, 12, 32, True), (432, 8640) + rest]
+    assert promote_key(live, (448, 9280) + rest, 0.08) == (464, 9280) + rest          # exact edges, one node step up
+    assert promote_key(live, (448, 9000) + rest, 0.08) == (464, 9280) + rest          # (448, 8960) has too few edges
+    assert promote_key(live, (432, 8640) + rest, 0.08) == (432, 8640) + rest          # itself, if it were live
+    assert promote_key(live, (480, 9920) + rest, 0.08) is None                        # nothing large enough
+    assert promote_key(live, (400, 8000) + rest, 0.08) == (432, 8640) + rest          # exactly 8 % more of both
+    assert promote_key(live, (400, 7900) + rest, 0.08) is None                        # ... and just beyond
+    assert promote_key(live, (464, 9280, 16, 12, 16, True), 0.5) is None              # other batch size: never
+    assert promote_key([], (448, 8960) + rest, 0.08) is None
