@@ -275,6 +275,89 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(const float* __restric
     prow[pld - 1] = ((sm[4 * NV * W] + sm[4 * NV * W + 1]) + sm[4 * NV * W + 2]) + sm[4 * NV * W + 3];
 }
 
+// MODE 2 of the kernel above for rows of up to 512 floats, built to RUN NEXT TO a weight-gradient group: those workgroups hold
+// a CU's LDS (2 x 75 KB) and 448 of the 512 vector registers of every SIMD lane for hundreds of microseconds, and a kernel
+// that does not fit into what is left - one wave of <= 64 registers per SIMD, < 10 KB of LDS - waits for an EMPTY CU (the
+// general kernel, 98 registers + 16 KB: 97 us in the Electron-DOS step for 19 us of work).  Memory-bound row kernels and the
+// matrix waves want different pipes, so co-residency is not zero-sum here.  64 registers (gamma / beta re-read per row from
+// L1 instead of held), 4 KB of LDS (the four waves add their column sums one after the other into ONE row).
+__global__ __launch_bounds__(256, 8) void ln_prelu_bwd_lean_kernel(const float* __restrict__ dy, const int* __restrict__ dyidx,
+                                                                   const float* __restrict__ dyscale,
+                                                                   const float* __restrict__ xhat, const float* __restrict__ rstd,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   const float* __restrict__ alpha, float* __restrict__ dx,
+                                                                   float* __restrict__ partials, int M, int W) {
+  extern __shared__ __align__(16) float sm[];   // [2 * W] + [4]
+  constexpr int KN = 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pld = 2 * W + 4;
+  const float invW = 1.f / (float)W;
+  const float al = *alpha;
+  float4 pg[KN], pb[KN];
+#pragma unroll
+  for (int k = 0; k < KN; ++k) { pg[k] = f4zero(); pb[k] = f4zero(); }
+  float psc = 0.f;
+  const int r0 = blockIdx.x * 32 + wave * 8;
+  for (int i = 0; i < 8; ++i) {
+    const int r = r0 + i;
+    if (r >= M) break;                          // (wave-uniform)
+    const size_t dr = dyidx ? (size_t)dyidx[r] : (size_t)r;
+    const float dsc = dyscale ? dyscale[dr] : 1.f;
+    const float rs = rstd[r];
+    float4 xh[KN], d[KN];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < KN; ++k) {
+      const int c = lane * 4 + 256 * k;
+      xh[k] = f4zero(); d[k] = f4zero();
+      if (c >= W) continue;
+      xh[k] = ld4(xhat + (size_t)r * W + c);
+      d[k] = ld4(dy + dr * W + c);
+      const float4 g = ld4(gamma + c), bt = ld4(beta + c), h = xh[k];
+      d[k] = make_float4(d[k].x * dsc, d[k].y * dsc, d[k].z * dsc, d[k].w * dsc);
+      const float y0 = h.x * g.x + bt.x, y1 = h.y * g.y + bt.y, y2 = h.z * g.z + bt.z, y3 = h.w * g.w + bt.w;
+      if (y0 < 0.f) { psc += d[k].x * y0; d[k].x *= al; }
+      if (y1 < 0.f) { psc += d[k].y * y1; d[k].y *= al; }
+      if (y2 < 0.f) { psc += d[k].z * y2; d[k].z *= al; }
+      if (y3 < 0.f) { psc += d[k].w * y3; d[k].w *= al; }
+      const float4 dd = d[k];
+      pg[k].x += dd.x * h.x; pg[k].y += dd.y * h.y; pg[k].z += dd.z * h.z; pg[k].w += dd.w * h.w;
+      pb[k] = f4add(pb[k], dd);
+      d[k] = make_float4(dd.x * g.x, dd.y * g.y, dd.z * g.z, dd.w * g.w);      // dy * gamma
+      s1 += (d[k].x + d[k].y) + (d[k].z + d[k].w);
+      s2 += (d[k].x * h.x + d[k].y * h.y) + (d[k].z * h.z + d[k].w * h.w);
+    }
+    s1 = wave_sum(s1) * invW;
+    s2 = wave_sum(s2) * invW;
+#pragma unroll
+    for (int k = 0; k < KN; ++k) {
+      const int c = lane * 4 + 256 * k;
+      if (c >= W) continue;
+      const float4 dh = d[k], h = xh[k];
+      st4(dx + (size_t)r * W + c, make_float4(rs * (dh.x - s1 - h.x * s2), rs * (dh.y - s1 - h.y * s2),
+                                              rs * (dh.z - s1 - h.z * s2), rs * (dh.w - s1 - h.w * s2)));
+    }
+  }
+  // column sums: wave 0 stores, waves 1..3 add in order (fixed summation order), then all write the partial row
+  const float pt = wave_sum(psc);
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int k = 0; k < KN; ++k) {
+        const int c = lane * 4 + 256 * k;
+        if (c >= W) continue;
+        if (w == 0) { st4(sm + c, pg[k]); st4(sm + W + c, pb[k]); }
+        else { st4(sm + c, f4add(ld4(sm + c), pg[k])); st4(sm + W + c, f4add(ld4(sm + W + c), pb[k])); }
+      }
+      if (lane == 0) sm[2 * W] = (w == 0 ? 0.f : sm[2 * W]) + pt;
+    }
+    __syncthreads();
+  }
+  float* prow = partials + (size_t)blockIdx.x * pld;
+  for (int c = threadIdx.x; c < 2 * W; c += 256) prow[c] = sm[c];
+  if (threadIdx.x == 0) prow[pld - 1] = sm[2 * W];
+}
+
 // y[r] = (LN(x[r])*gamma+beta) . w + b   ->  dos[(r % Bq)*S + r / Bq]
 __global__ __launch_bounds__(256) void ln_rowdot_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ w,
@@ -626,6 +709,15 @@ extern "C" int dosx_ln_rowdot_bwd(const float* ddos, const float* xhat, const fl
   return 0;
 }
 
+static bool ln_lean_on() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("DOSX_LN_LEAN");
+    on = e ? atoi(e) : 1;
+  }
+  return on != 0;
+}
+
 extern "C" int dosx_ln_prelu_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma,
                                  const float* beta, const float* alpha, float* dz, float* partials, int M, int W,
                                  dosx_stream_t stream) {
@@ -633,8 +725,12 @@ extern "C" int dosx_ln_prelu_bwd(const float* dy, const float* xhat, const float
   CHECK_H4(W);
   DOSX_CHECK_ARG(dy && xhat && rstd && gamma && beta && alpha && dz && partials, "dosx_ln_prelu_bwd: bad args");
   DOSX_CHECK_ARG(W <= 256 * LNW_K, "dosx_ln_prelu_bwd: row width %d > %d", W, 256 * LNW_K);
-  hipLaunchKernelGGL((ln_bwd_wide_kernel<2>), dim3(ceil_div(M, 32)), dim3(256), (4 * (size_t)(2 * W) + 4) * sizeof(float),
-                     to_stream(stream), dy, nullptr, xhat, rstd, gamma, beta, nullptr, alpha, dz, partials, M, W, 0, 1);
+  if (W <= 512 && ln_lean_on())
+    hipLaunchKernelGGL(ln_prelu_bwd_lean_kernel, dim3(ceil_div(M, 32)), dim3(256), ((size_t)(2 * W) + 4) * sizeof(float),
+                       to_stream(stream), dy, nullptr, nullptr, xhat, rstd, gamma, beta, alpha, dz, partials, M, W);
+  else
+    hipLaunchKernelGGL((ln_bwd_wide_kernel<2>), dim3(ceil_div(M, 32)), dim3(256), (4 * (size_t)(2 * W) + 4) * sizeof(float),
+                       to_stream(stream), dy, nullptr, xhat, rstd, gamma, beta, nullptr, alpha, dz, partials, M, W, 0, 1);
   DOSX_LAUNCH_CHECK();
   return 0;
 }
@@ -646,7 +742,10 @@ extern "C" int dosx_ln_prelu_bwd_gather(const float* dy, const int32_t* idx, con
   CHECK_H4(W);
   DOSX_CHECK_ARG(dy && idx && xhat && rstd && gamma && beta && alpha && dz && partials, "dosx_ln_prelu_bwd_gather: bad args");
   DOSX_CHECK_ARG(W <= 256 * LNW_K, "dosx_ln_prelu_bwd_gather: row width %d > %d", W, 256 * LNW_K);
-  if (W <= 512)        // (two float4 column groups per lane: half the registers of the general form)
+  if (W <= 512 && ln_lean_on())
+    hipLaunchKernelGGL(ln_prelu_bwd_lean_kernel, dim3(ceil_div(M, 32)), dim3(256), ((size_t)(2 * W) + 4) * sizeof(float),
+                       to_stream(stream), dy, idx, scale, xhat, rstd, gamma, beta, alpha, dz, partials, M, W);
+  else if (W <= 512)        // (two float4 column groups per lane: half the registers of the general form)
     hipLaunchKernelGGL((ln_bwd_wide_kernel<2, 2>), dim3(ceil_div(M, 32)), dim3(256), (4 * (size_t)(2 * W) + 4) * sizeof(float),
                        to_stream(stream), dy, nullptr, xhat, rstd, gamma, beta, nullptr, alpha, dz, partials, M, W, 0, 1, idx, scale);
   else
