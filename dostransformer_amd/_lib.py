@@ -51,7 +51,7 @@ class Gemm(C.Structure):
         ("partials", C.c_void_p), ("partial_ld", C.c_int32),
         ("seg_tile", C.c_void_p), ("seg_ntiles", C.c_int32), ("seg_rowptr", C.c_void_p), ("seg_scale", C.c_void_p),
         ("seg_agg", C.c_void_p), ("seg_part", C.c_void_p), ("seg_cnt", C.c_void_p), ("res_col0", C.c_int32),
-        ("norm_out", C.c_void_p), ("norm_rstd", C.c_void_p),
+        ("norm_out", C.c_void_p), ("norm_rstd", C.c_void_p), ("res_pre", C.c_int32),
     ]
 
 

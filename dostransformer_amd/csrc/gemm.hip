@@ -829,6 +829,7 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch& L, const int bid) { 
       for (int j = 0; j < CG; ++j) {
         if (!on[j]) continue;
         v[j] = f4add(v[j], biasv[j]);
+        if (g.res_pre) v[j] = f4add(v[j], pv1[rt][i][j]);       // pre-activation row term (zeros when absent)
         if (g.act == 1) {
           v[j].x = fmaxf(v[j].x, 0.f); v[j].y = fmaxf(v[j].y, 0.f);
           v[j].z = fmaxf(v[j].z, 0.f); v[j].w = fmaxf(v[j].w, 0.f);
@@ -837,7 +838,7 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch& L, const int bid) { 
           v[j].x = v[j].x >= 0.f ? v[j].x : sl * v[j].x; v[j].y = v[j].y >= 0.f ? v[j].y : sl * v[j].y;
           v[j].z = v[j].z >= 0.f ? v[j].z : sl * v[j].z; v[j].w = v[j].w >= 0.f ? v[j].w : sl * v[j].w;
         }
-        v[j] = f4add(v[j], pv1[rt][i][j]);   // residual (zeros when absent)
+        if (!g.res_pre) v[j] = f4add(v[j], pv1[rt][i][j]);   // residual (zeros when absent)
         if (rvalid) st4(orow + gcol[j], v[j]);
         s1 += v[j].x + v[j].y + v[j].z + v[j].w;
       }
@@ -1463,6 +1464,7 @@ static int gemm_validate(const DosxGemm& g) {
                  "dosx_gemm: norm_out needs the plain epilogue, N <= 512 and norm_rstd");
   DOSX_CHECK_ARG(g.out_map.d > 0, "dosx_gemm: out_map.d must be > 0");
   if (g.res) DOSX_CHECK_ARG(g.res_map.d > 0 && (g.ldr & 3) == 0 && aligned16(g.res), "dosx_gemm: bad residual");
+  DOSX_CHECK_ARG(!g.res_pre || (g.res && g.epi == DOSX_EPI_BIAS_ACT && g.res_col0 == 0), "dosx_gemm: res_pre needs a residual and the plain epilogue");
   DOSX_CHECK_ARG(g.res_col0 >= 0 && (g.res_col0 & 3) == 0 && (g.res_col0 == 0 || (g.res && g.epi == DOSX_EPI_BIAS_ACT)),
                  "dosx_gemm: res_col0=%d needs a residual, the plain epilogue and a multiple of 4", g.res_col0);
   if (g.pro == DOSX_PRO_LN_PRELU || g.pro == DOSX_PRO_ROWLN)

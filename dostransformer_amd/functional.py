@@ -550,6 +550,7 @@ _FUSED_FFN_BWD = __import__("os").environ.get("DOSX_FUSED_FFN_BWD", "1") == "1"
 _FACTOR_EDGE_WGRAD = __import__("os").environ.get("DOSX_FACTOR_EDGE_WGRAD", "1") == "1"   # EdgeModel first Linear factored into node / edge parts
 _FACTOR_MIN_GF = float(__import__("os").environ.get("DOSX_FACTOR_MIN_GF", "4"))
 _FACTOR_DGRAD = __import__("os").environ.get("DOSX_FACTOR_DGRAD", "1") == "1"             # ... and its input gradient
+_FACTOR_HEADS = __import__("os").environ.get("DOSX_FACTOR_HEADS", "1") == "1"             # heads: per-crystal K-segments multiplied once per crystal
 _FACTOR_LAST = __import__("os").environ.get("DOSX_FACTOR_LAST", "1") == "1"               # last layer: aggregate, then the second Linear
 _FACTOR_LAST_MIN_GF = float(__import__("os").environ.get("DOSX_FACTOR_LAST_MIN_GF", "1.3"))
 _FUSED_ATT_FFN = __import__("os").environ.get("DOSX_FUSED_ATT_FFN", "1") == "1"       # <= 16-key attention inside dosx_ffn_fwd
@@ -1009,6 +1010,13 @@ def dostransformer_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta, drop=None):
         box["graph"], box["segs"] = decoder_fwd(P, cfg, m, xL, u)
         box["prow"] = _empty(dev, B, hp)
         ops.embed_rows(P[cfg.prompt_key], sysidx, box["prow"], B, hp)
+        if _FACTOR_HEADS:
+            # the heads read cat[E1, graph(, prompt)] with the crystal's pooled vector (and prompt row) repeated for every energy:
+            # those K-segments are multiplied ONCE per crystal here (B rows) and enter the per-energy GEMM as a pre-activation
+            # row term (DosxGemm.res_pre) - the heads' K shrinks from 2H / 2.5H to H
+            box["qg"], box["qs"] = _empty(dev, B, H), _empty(dev, B, H)
+            ops.gemm(B, H, [seg(box["graph"])], P["fc.weight"][:, H:], box["qg"])
+            ops.gemm(B, H, [seg(box["graph"]), seg(box["prow"])], P["fc_prompt.weight"][:, H:], box["qs"])
     side.on_side(_decoder_branch)
     E1, c1 = encoder_fwd(P, "transformer", emb, S, B, 1, 0, kvhat, nmax, B, H, T, drop=dr(0))
     side.join()
@@ -1024,10 +1032,15 @@ def dostransformer_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta, drop=None):
     kvs = _empty(dev, S * 2 * B, H)
     rstd_s = _empty(dev, S * 2 * B)
     nk = dict(norm_out=kvs, norm_rstd=rstd_s) if _FUSED_HEAD_NORM else {}
-    ops.gemm_pair(dict(M=S * B, N=H, segs=a_g.segs, w=P["fc.weight"], out=dosin, bias=P["fc.bias"], act=ACT_LEAKY, act_slope=0.01,
-                       out_map=rowmap(d=B, m=2 * B, c=1, off=0), **nk),
-                  dict(M=S * B, N=H, segs=a_s.segs, w=P["fc_prompt.weight"], out=dosin, bias=P["fc_prompt.bias"], act=ACT_LEAKY,
-                       act_slope=0.01, out_map=rowmap(d=B, m=2 * B, c=1, off=B), **nk))
+    if _FACTOR_HEADS:
+        hg = dict(segs=[seg(E1)], w=P["fc.weight"][:, :H], res=box["qg"], res_map=modB, res_pre=True)
+        hs = dict(segs=[seg(E1)], w=P["fc_prompt.weight"][:, :H], res=box["qs"], res_map=modB, res_pre=True)
+    else:
+        hg, hs = dict(segs=a_g.segs, w=P["fc.weight"]), dict(segs=a_s.segs, w=P["fc_prompt.weight"])
+    ops.gemm_pair(dict(M=S * B, N=H, out=dosin, bias=P["fc.bias"], act=ACT_LEAKY, act_slope=0.01,
+                       out_map=rowmap(d=B, m=2 * B, c=1, off=0), **hg, **nk),
+                  dict(M=S * B, N=H, out=dosin, bias=P["fc_prompt.bias"], act=ACT_LEAKY,
+                       act_slope=0.01, out_map=rowmap(d=B, m=2 * B, c=1, off=B), **hs, **nk))
     if not _FUSED_HEAD_NORM:
         ops.rownorm(dosin, kvs, rstd_s, S * 2 * B, H)
     hs, c2 = encoder_fwd(P, "transformer_self", dosin, S, 2 * B, 2 * B, 1, kvs, S, 2 * B, H, T, drop=dr(64))
@@ -1042,6 +1055,7 @@ def dostransformer_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta, drop=None):
         hsrc, c3 = encoder_fwd(P, "transformer_source", hs, S, 2 * B, 2 * B, 1, kvhat, nmax, B, H, T, final_ln=False,
                                drop=dr(128))
         ops.ln_rowdot(hsrc, gf, bf, P["out_layer.weight"], P["out_layer.bias"], xhat_f, rstd_f, dos, S, 2 * B, H)
+    a_g.keep.extend(t for t in (box.get("qg"), box.get("qs")) if t is not None)
     ctx = (ctrunk, kvhat, rstd_n, c1, dec_segs, sysidx, prow, dosin, a_g, a_s, kvs, rstd_s, c2, c3, xhat_f, rstd_f, xL)
     return dos, xL, ctx
 
@@ -1088,8 +1102,20 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
     dpre = _empty(dev, rows2, H)         # key-side LN backward + the LeakyReLU backward behind it, one launch
     ops.rownorm_bwd_act(dkvs, kvs, rstd_s, ddosin, dosin, 0.01, dpre, rows2, H)
     map0, map1 = rowmap(d=B, m=2 * B, c=1, off=0), rowmap(d=B, m=2 * B, c=1, off=B)
-    _wgrad_linear(sink, G, "fc.weight", "fc.bias", S * B, H, seg(dpre, rmap=map0), a_g.segs, keep=(dpre,))
-    _wgrad_linear(sink, G, "fc_prompt.weight", "fc_prompt.bias", S * B, H, seg(dpre, rmap=map1), a_s.segs, keep=(dpre,))
+    R = _empty(dev, 2 * B, H)            # sum over the energy axis of dpre (filled on the side stream below)
+    if _FACTOR_HEADS and GradSink.group_wgrad and "fc.weight" in G and "fc_prompt.weight" in G:      # (R is filled later, on the side stream: deferred jobs only)
+        # the same factoring for the weight gradients: the column blocks that multiply the per-crystal inputs are
+        # (sum_s dpre[s, b]) (x) [graph_b (| prompt_b)] - B-row jobs on R - and only the E1 block keeps its S * B rows
+        E1_, graph_ = a_g.keep[0], a_g.keep[1]
+        Gfc, Gfp = G["fc.weight"], G["fc_prompt.weight"]
+        _wgrad_linear(sink, G, "fc.weight", "fc.bias", S * B, H, seg(dpre, rmap=map0), [seg(E1_)], keep=(dpre, E1_), dst=Gfc[:, :H])
+        _wgrad_linear(sink, G, "fc_prompt.weight", "fc_prompt.bias", S * B, H, seg(dpre, rmap=map1), [seg(E1_)], keep=(dpre,),
+                      dst=Gfp[:, :H])
+        _wgrad_linear(sink, G, "fc.weight", None, B, H, seg(R[:B]), [seg(graph_)], keep=(R, graph_), dst=Gfc[:, H:])
+        _wgrad_linear(sink, G, "fc_prompt.weight", None, B, H, seg(R[B:]), [seg(graph_), seg(prow)], keep=(R, prow), dst=Gfp[:, H:])
+    else:
+        _wgrad_linear(sink, G, "fc.weight", "fc.bias", S * B, H, seg(dpre, rmap=map0), a_g.segs, keep=(dpre,))
+        _wgrad_linear(sink, G, "fc_prompt.weight", "fc_prompt.bias", S * B, H, seg(dpre, rmap=map1), a_s.segs, keep=(dpre,))
     Wfc, Wfp = P["fc.weight"], P["fc_prompt.weight"]
     dE1 = _empty(dev, S * B, H)
     ops.gemm(S * B, H, [seg(dpre, rmap=map0)], Wfc[:, :H], dE1, w_layout=1)
@@ -1100,7 +1126,6 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
         sink.flush_on_side()
     # graph / prompt inputs are constant over the energy axis: reduce over s first, then a [2B,H] GEMM.  Their
     # consumers (decoder backward, prompt-embedding gradient) come after the first encoder's backward: side stream.
-    R = _empty(dev, 2 * B, H)
     dgraph = _empty(dev, B, H)
     hp = H // 2
     dprow = _empty(dev, B, hp)

@@ -312,13 +312,13 @@ def gemm(M: int, N: int, segs: Sequence[Seg], w: torch.Tensor, out: torch.Tensor
          out_map: Optional[RowMap] = None, res=None, res_map: Optional[RowMap] = None,
          stats_out=None, aux_out=None, aux=None, aux_stats=None, epi_gamma=None, epi_beta=None,
          epi_alpha=None, partials=None, partial_ld: int = 0, res_col0: int = 0, seg_tile=None, seg_rowptr=None,
-         seg_scale=None, seg_agg=None, keep: Optional[list] = None, norm_out=None, norm_rstd=None) -> None:
+         seg_scale=None, seg_agg=None, keep: Optional[list] = None, norm_out=None, norm_rstd=None, res_pre: bool = False) -> None:
     """out[M,N] = epilogue(prologue(A) @ B); see include/dosx.h:DosxGemm."""
     g = _gemm_desc(M, N, segs, w, out, w_layout=w_layout, pro=pro, pro_gamma=pro_gamma, pro_beta=pro_beta, pro_alpha=pro_alpha,
                    pro_stats=pro_stats, epi=epi, act=act, act_slope=act_slope, bias=bias, out_map=out_map, res=res, res_map=res_map,
                    stats_out=stats_out, aux_out=aux_out, aux=aux, aux_stats=aux_stats, epi_gamma=epi_gamma, epi_beta=epi_beta,
                    epi_alpha=epi_alpha, partials=partials, partial_ld=partial_ld, res_col0=res_col0, seg_tile=seg_tile,
-                   seg_rowptr=seg_rowptr, seg_scale=seg_scale, seg_agg=seg_agg, norm_out=norm_out, norm_rstd=norm_rstd)
+                   seg_rowptr=seg_rowptr, seg_scale=seg_scale, seg_agg=seg_agg, norm_out=norm_out, norm_rstd=norm_rstd, res_pre=res_pre)
     _call("dosx_gemm", C.byref(g), _stream(), w=lambda: _gemm_work(g))
 
 
@@ -340,7 +340,7 @@ def _gemm_desc(M: int, N: int, segs: Sequence[Seg], w: torch.Tensor, out: torch.
                out_map: Optional[RowMap] = None, res=None, res_map: Optional[RowMap] = None,
                stats_out=None, aux_out=None, aux=None, aux_stats=None, epi_gamma=None, epi_beta=None,
                epi_alpha=None, partials=None, partial_ld: int = 0, res_col0: int = 0, seg_tile=None, seg_rowptr=None,
-               seg_scale=None, seg_agg=None, norm_out=None, norm_rstd=None) -> "Gemm":
+               seg_scale=None, seg_agg=None, norm_out=None, norm_rstd=None, res_pre: bool = False) -> "Gemm":
     g = Gemm()
     g.M, g.N = int(M), int(N)
     g.K = int(sum(s.width for s in segs))
@@ -367,6 +367,7 @@ def _gemm_desc(M: int, N: int, segs: Sequence[Seg], w: torch.Tensor, out: torch.
     g.epi_gamma, g.epi_beta, g.epi_alpha = _p(epi_gamma), _p(epi_beta), _p(epi_alpha)
     g.partials, g.partial_ld = _p(partials), int(partial_ld)
     g.res_col0 = int(res_col0)
+    g.res_pre = 1 if res_pre else 0
     if seg_tile is not None:            # EPI_SEGSUM: [3, T+1] node-aligned tile table
         assert seg_tile.dim() == 2 and seg_tile.shape[0] == 3 and seg_tile.is_contiguous()
         g.seg_tile, g.seg_ntiles = seg_tile.data_ptr(), int(seg_tile.shape[1]) - 1

@@ -128,6 +128,10 @@ typedef struct DosxGemm {
                          131-134 on DOSTransformer_phonon.py:97's input), so the heads' GEMMs write them and no
                          dosx_rownorm launch follows */
   float* norm_rstd;   /* with norm_out: rstd per OUTPUT row [rows of out] */
+  int32_t res_pre;    /* EPI_BIAS_ACT: 1 = the residual rows are added BEFORE the activation, out = act(A W + bias + res[res_map(r)]).
+                         The K-segments of an output head that are constant along the energy axis - cat[x, graph(, prompt)]
+                         (DOSTransformer_phonon.py:93-95,105-109) repeats the pooled crystal vector for every energy - are
+                         multiplied once per crystal and enter the per-energy GEMM as such a row-mapped pre-activation term. */
 } DosxGemm;
 
 /* exact number of workgroup rows dosx_gemm writes into `partials` for this epilogue: ceil(M/32) for
