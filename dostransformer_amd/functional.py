@@ -138,6 +138,13 @@ def _factor_edge(E: int, H: int) -> bool:
     return _FACTOR_EDGE_WGRAD and 2.0 * E * (2 * H) * (3 * H) >= _FACTOR_MIN_GF * 1e9
 
 
+def _factor_heads(rows: int, H: int) -> bool:
+    """Whether the two output heads multiply their per-crystal K-segments (graph, prompt) once per crystal instead of once per
+    energy: from DOSX_FACTOR_HEADS_MIN_GF (1) GF of saved products - the Electron-DOS shapes (4.2 / 2.1 GF); the Phonon-DOS
+    benchmark shape (0.27 GF) and small-batch inference keep the two launches fewer."""
+    return _FACTOR_HEADS and 2.0 * rows * H * (2.5 * H) >= _FACTOR_HEADS_MIN_GF * 1e9
+
+
 def _factor_last(E: int, H: int) -> bool:
     """Whether the LAST message-passing layer aggregates its activations per node in front of its second Linear (mlp_ln_fwd,
     aggsum): from DOSX_FACTOR_LAST_MIN_GF GF of that Linear's E-row product."""
@@ -551,6 +558,7 @@ _FACTOR_EDGE_WGRAD = __import__("os").environ.get("DOSX_FACTOR_EDGE_WGRAD", "1")
 _FACTOR_MIN_GF = float(__import__("os").environ.get("DOSX_FACTOR_MIN_GF", "4"))
 _FACTOR_DGRAD = __import__("os").environ.get("DOSX_FACTOR_DGRAD", "1") == "1"             # ... and its input gradient
 _FACTOR_HEADS = __import__("os").environ.get("DOSX_FACTOR_HEADS", "1") == "1"             # heads: per-crystal K-segments multiplied once per crystal
+_FACTOR_HEADS_MIN_GF = float(__import__("os").environ.get("DOSX_FACTOR_HEADS_MIN_GF", "1"))
 _FACTOR_LAST = __import__("os").environ.get("DOSX_FACTOR_LAST", "1") == "1"               # last layer: aggregate, then the second Linear
 _FACTOR_LAST_MIN_GF = float(__import__("os").environ.get("DOSX_FACTOR_LAST_MIN_GF", "1.3"))
 _FUSED_ATT_FFN = __import__("os").environ.get("DOSX_FUSED_ATT_FFN", "1") == "1"       # <= 16-key attention inside dosx_ffn_fwd
@@ -1006,11 +1014,13 @@ def dostransformer_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta, drop=None):
     side = ops.GradSink(dev)
     box = {}
 
+    fh = _factor_heads(S * B, H)
+
     def _decoder_branch():
         box["graph"], box["segs"] = decoder_fwd(P, cfg, m, xL, u)
         box["prow"] = _empty(dev, B, hp)
         ops.embed_rows(P[cfg.prompt_key], sysidx, box["prow"], B, hp)
-        if _FACTOR_HEADS:
+        if fh:
             # the heads read cat[E1, graph(, prompt)] with the crystal's pooled vector (and prompt row) repeated for every energy:
             # those K-segments are multiplied ONCE per crystal here (B rows) and enter the per-energy GEMM as a pre-activation
             # row term (DosxGemm.res_pre) - the heads' K shrinks from 2H / 2.5H to H
@@ -1032,7 +1042,7 @@ def dostransformer_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta, drop=None):
     kvs = _empty(dev, S * 2 * B, H)
     rstd_s = _empty(dev, S * 2 * B)
     nk = dict(norm_out=kvs, norm_rstd=rstd_s) if _FUSED_HEAD_NORM else {}
-    if _FACTOR_HEADS:
+    if fh:
         hg = dict(segs=[seg(E1)], w=P["fc.weight"][:, :H], res=box["qg"], res_map=modB, res_pre=True)
         hs = dict(segs=[seg(E1)], w=P["fc_prompt.weight"][:, :H], res=box["qs"], res_map=modB, res_pre=True)
     else:
@@ -1103,7 +1113,7 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
     ops.rownorm_bwd_act(dkvs, kvs, rstd_s, ddosin, dosin, 0.01, dpre, rows2, H)
     map0, map1 = rowmap(d=B, m=2 * B, c=1, off=0), rowmap(d=B, m=2 * B, c=1, off=B)
     R = _empty(dev, 2 * B, H)            # sum over the energy axis of dpre (filled on the side stream below)
-    if _FACTOR_HEADS and GradSink.group_wgrad and "fc.weight" in G and "fc_prompt.weight" in G:      # (R is filled later, on the side stream: deferred jobs only)
+    if len(a_g.keep) > 2 and GradSink.group_wgrad and "fc.weight" in G and "fc_prompt.weight" in G:  # (forward factored; R is filled later, on the side stream: deferred jobs only)
         # the same factoring for the weight gradients: the column blocks that multiply the per-crystal inputs are
         # (sum_s dpre[s, b]) (x) [graph_b (| prompt_b)] - B-row jobs on R - and only the E1 block keeps its S * B rows
         E1_, graph_ = a_g.keep[0], a_g.keep[1]

@@ -159,11 +159,14 @@ def test_eight_rank_full_size_configs_match_single_process(eight_rank_full_run, 
     # below keep measuring the sharding alone; the full batch's own form (if it differs) is compared right after, at the
     # tolerance of the fp32-vs-fp64 oracle comparison (tests/test_gpu_models.py: GRAD_TOL).
     g0 = collate(make_crystals(kind, SUITES["full"]["steps"][0], "full"))
-    policy = (Fn._FACTOR_EDGE_WGRAD, Fn._FACTOR_MIN_GF, Fn._FACTOR_LAST, Fn._FACTOR_LAST_MIN_GF)
+    policy = (Fn._FACTOR_EDGE_WGRAD, Fn._FACTOR_MIN_GF, Fn._FACTOR_LAST, Fn._FACTOR_LAST_MIN_GF, Fn._FACTOR_HEADS, Fn._FACTOR_HEADS_MIN_GF)
+    S_, B1 = model._cfg.S, g0.meta.num_graphs
     E8, E1 = g0.meta.num_edges // 8, g0.meta.num_edges
-    shard_form, full_form = (Fn._factor_edge(E8, H), Fn._factor_last(E8, H)), (Fn._factor_edge(E1, H), Fn._factor_last(E1, H))
+    shard_form = (Fn._factor_edge(E8, H), Fn._factor_last(E8, H), Fn._factor_heads(S_ * B1 // 8, H))
+    full_form = (Fn._factor_edge(E1, H), Fn._factor_last(E1, H), Fn._factor_heads(S_ * B1, H))
     try:
         Fn._FACTOR_EDGE_WGRAD, Fn._FACTOR_MIN_GF, Fn._FACTOR_LAST, Fn._FACTOR_LAST_MIN_GF = shard_form[0], 0.0, shard_form[1], 0.0
+        Fn._FACTOR_HEADS, Fn._FACTOR_HEADS_MIN_GF = shard_form[2], 0.0
         tr = Trainer(model, lr=1e-3, beta=1.0)
         losses, grad0 = [], None
         for step in SUITES["full"]["steps"]:
@@ -174,7 +177,7 @@ def test_eight_rank_full_size_configs_match_single_process(eight_rank_full_run, 
                 torch.cuda.synchronize()
                 grad0 = model.flat_params().grad.detach().cpu().numpy().copy()
     finally:
-        Fn._FACTOR_EDGE_WGRAD, Fn._FACTOR_MIN_GF, Fn._FACTOR_LAST, Fn._FACTOR_LAST_MIN_GF = policy
+        Fn._FACTOR_EDGE_WGRAD, Fn._FACTOR_MIN_GF, Fn._FACTOR_LAST, Fn._FACTOR_LAST_MIN_GF, Fn._FACTOR_HEADS, Fn._FACTOR_HEADS_MIN_GF = policy
     if full_form != shard_form:
         m2 = make_model(kind, dev, "full")
         Trainer(m2, lr=1e-3, beta=1.0).forward_backward(g0.to(dev))

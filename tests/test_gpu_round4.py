@@ -767,10 +767,11 @@ def test_factored_edge_weight_gradient_equals_the_plain_one(kind):
     m0 = mk()
     sd0 = {k: v.detach().clone() for k, v in m0.state_dict().items()}
     grads, params, outs = {}, {}, {}
-    min_gf, last_gf = Fn._FACTOR_MIN_GF, Fn._FACTOR_LAST_MIN_GF
+    min_gf, last_gf, heads_gf = Fn._FACTOR_MIN_GF, Fn._FACTOR_LAST_MIN_GF, Fn._FACTOR_HEADS_MIN_GF
     for fac in (False, True):
         Fn._FACTOR_EDGE_WGRAD, Fn._FACTOR_MIN_GF = fac, 0.0        # (the shipped policy factors from 4 GF; the path takes any size)
         Fn._FACTOR_LAST_MIN_GF = 0.0 if fac else 1e9               # ... and the last layer's aggregate-first form with it
+        Fn._FACTOR_HEADS_MIN_GF = 0.0 if fac else 1e9              # ... and the output heads' per-crystal K-segments (res_pre)
         try:
             for replay in (False, True):
                 model = mk()
@@ -787,7 +788,7 @@ def test_factored_edge_weight_gradient_equals_the_plain_one(kind):
                 torch.cuda.synchronize()
                 params[(fac, replay)] = {k: v.detach().clone() for k, v in model.state_dict().items()}
         finally:
-            Fn._FACTOR_EDGE_WGRAD, Fn._FACTOR_MIN_GF, Fn._FACTOR_LAST_MIN_GF = True, min_gf, last_gf
+            Fn._FACTOR_EDGE_WGRAD, Fn._FACTOR_MIN_GF, Fn._FACTOR_LAST_MIN_GF, Fn._FACTOR_HEADS_MIN_GF = True, min_gf, last_gf, heads_gf
     n_real, n_pad = g.meta.num_nodes, gp.meta.num_nodes
     for u, v in zip(outs[(True, False)], outs[(False, False)]):
         if u.shape[0] == n_pad:                          # node embeddings: the ghost rows are finite don't-cares (batch.pad_batch) -

@@ -266,6 +266,9 @@ def test_size_policies_of_the_factored_forms():
     assert Fn._factor_edge(17880, 256) and Fn._factor_last(17880, 256)
     assert Fn._factor_edge(8900, 256) and Fn._factor_last(8900, 256)
     assert not Fn._factor_last(17880, 384)                    # 2 * hidden > 512: the unfused wide-row path keeps the per-edge form
+    # output heads: factored at the Electron-DOS shapes (B * S = 64 * 201 and 32 * 201 rows, H 256), not at 64 * 51 rows / H 128
+    assert Fn._factor_heads(64 * 201, 256) and Fn._factor_heads(32 * 201, 256)
+    assert not Fn._factor_heads(64 * 51, 128) and not Fn._factor_heads(51, 128)
     # feed-forward tail: 25728 = 3 full rounds of 8192 rows + 1152; 12864 = 1 round + 4672 (too large a tail); small problems never
     assert Fn._ffn_tail_start(25728, 256) == 24576
     assert Fn._ffn_tail_start(12864, 256) == 0
