@@ -480,6 +480,10 @@ def self_launch(world: int, argv, *, grace_s: float = 30.0, script=None) -> int:
     return worst if worst >= 0 else 128 - worst
 
 
+class _SkipDp1(Exception):
+    pass
+
+
 def main():
     if "WORLD_SIZE" not in os.environ:
         # bare `python bench.py --gpus N`, N > 1: become the launcher - decided on the command line alone, before anything
@@ -502,6 +506,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary measurements of the default run (eDOS H256 line, --shuffle line)")
+    ap.add_argument("--no-dp1", action="store_true",
+                    help="skip the `dp1_nccl` secondary (the headline workload through the data-parallel step on a 1-rank RCCL "
+                         "group: it initialises a process group inside this process)")
     ap.add_argument("--kernels-out", default=os.path.join(ROOT, "bench_kernels_last.json"),
                     help="side file for the full per-site kernel table (never on the stdout line)")
     ap.add_argument("--launch", choices=["replay", "eager", "graph"], default="replay",
@@ -586,6 +593,8 @@ def main():
         # the collectives (SSE pair, early gradient bucket, late bucket), i.e. what data parallelism costs a rank before
         # any byte crosses xGMI - the figure a 1-GPU box can give about the N > 1 path
         try:
+            if args.no_dp1:
+                raise _SkipDp1()
             from dostransformer_amd.dist import DataParallel
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ["MASTER_PORT"] = str(_free_port())
@@ -598,6 +607,8 @@ def main():
                                                                        ("grad_bucket_bytes", "collectives_per_step", "backend")})
             finally:
                 td.destroy_process_group()
+        except _SkipDp1:
+            pass
         except Exception as ex:
             secondary["dp1_nccl"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
 
@@ -650,6 +661,11 @@ def main():
             out["slots"] = r["slots"]
         if r["dp_info"] is not None:
             out["dp"] = dict(r["dp_info"], rccl=rccl_choices(rccl_log, world))
+            if rccl_log is not None:          # (the tuner's side file has been read: do not leave it in the temp directory)
+                try:
+                    os.unlink(rccl_log)
+                except OSError:
+                    pass
         if secondary:
             out["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:

@@ -52,6 +52,8 @@ class Gemm(C.Structure):
         ("seg_tile", C.c_void_p), ("seg_ntiles", C.c_int32), ("seg_rowptr", C.c_void_p), ("seg_scale", C.c_void_p),
         ("seg_agg", C.c_void_p), ("seg_part", C.c_void_p), ("seg_cnt", C.c_void_p), ("res_col0", C.c_int32),
         ("norm_out", C.c_void_p), ("norm_rstd", C.c_void_p), ("res_pre", C.c_int32),
+        ("add_p", C.c_void_p), ("add_ip", C.c_void_p), ("add_q", C.c_void_p), ("add_iq", C.c_void_p), ("ld_add", C.c_int32),
+        ("w_seg_off", C.c_int32),
     ]
 
 
@@ -150,7 +152,23 @@ class MlpLnBwd(C.Structure):
         ("gamma", C.c_void_p), ("beta", C.c_void_p), ("alpha", C.c_void_p),
         ("dz", C.c_void_p),
         ("dcat", C.c_void_p), ("lddcat", C.c_int32),
-        ("partials", C.c_void_p), ("partial_ld", C.c_int32),
+        ("partials", C.c_void_p), ("partial_ld", C.c_int32), ("add_dy", C.c_int32),
+    ]
+
+
+class EdgeMlp(C.Structure):
+    _fields_ = [
+        ("E", C.c_int32), ("H", C.c_int32),
+        ("e", C.c_void_p), ("lde", C.c_int32),
+        ("pq", C.c_void_p), ("ldpq", C.c_int32),
+        ("src", C.c_void_p), ("dst", C.c_void_p),
+        ("w1", C.c_void_p), ("ldw1", C.c_int32), ("b1", C.c_void_p),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p), ("alpha", C.c_void_p),
+        ("w3", C.c_void_p), ("b3", C.c_void_p),
+        ("xhat", C.c_void_p), ("rstd", C.c_void_p),
+        ("e_out", C.c_void_p), ("ldeo", C.c_int32),
+        ("seg_tile", C.c_void_p), ("seg_ntiles", C.c_int32),
+        ("seg_rowptr", C.c_void_p), ("seg_scale", C.c_void_p), ("seg_agg", C.c_void_p), ("seg_part", C.c_void_p), ("seg_cnt", C.c_void_p),
     ]
 
 
@@ -241,6 +259,8 @@ _SIGS = {
     "dosx_mlp_ln_fwd": [C.POINTER(MlpLn), _P],
     "dosx_mlp_ln_bwd_partial_rows": [_I],
     "dosx_mlp_ln_bwd": [C.POINTER(MlpLnBwd), _P],
+    "dosx_edge_mlp_supported": [_I],
+    "dosx_edge_mlp_fwd": [C.POINTER(EdgeMlp), _P],
     "dosx_csr_workspace_bytes": [_I, C.POINTER(C.c_size_t)],
     "dosx_csr_build": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P],
     "dosx_collate": [_P] * 5 + [_I] * 3 + [_P] * 18 + [_P],

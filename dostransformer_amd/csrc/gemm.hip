@@ -241,8 +241,9 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch& L, const int bid) { 
   // EPI_SEGSUM: the row tiles are NODE-ALIGNED and of variable height (<= BMR): workgroup t owns the rows
   // [seg_tile[t], seg_tile[t+1]) = the whole destination segments of the nodes [seg_tile[T+1+t], seg_tile[T+2+t]).
   // Every bound below that says M means "end of this workgroup's rows".
+  constexpr bool SEGT = (EPI == DOSX_EPI_SEGSUM || EPI == DOSX_EPI_PRELU_LN_BWD_SEG);   // node-aligned row tiles + segment sums
   int m0_ = L.m_base + bx * BMR, mend_ = g.M, nlo_ = 0, nhi_ = 0;
-  if constexpr (EPI == DOSX_EPI_SEGSUM) {
+  if constexpr (SEGT) {
     bx = bid;
     by = 0;
     m0_ = g.seg_tile[bx];
@@ -253,6 +254,8 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch& L, const int bid) { 
       const int w4 = g.N >> 2;                            // padding nodes behind the last real tile): aggregate = 0
       for (int i = (int)threadIdx.x; i < (nhi_ - nlo_) * w4; i += 512)
         st4(g.seg_agg + (size_t)(nlo_ + i / w4) * g.N + (i % w4) * 4, f4zero());
+      if (EPI == DOSX_EPI_PRELU_LN_BWD_SEG && g.partials != nullptr)      // one partial row per tile slot: an empty one adds zeros
+        for (int i = (int)threadIdx.x; i < g.partial_ld; i += 512) g.partials[(size_t)bx * g.partial_ld + i] = 0.f;
       return;
     }
   }
@@ -273,7 +276,7 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch& L, const int bid) { 
   const int ncols = min(BN, N - n0);
   const float invN = 1.f / (float)N;
   constexpr int epi = EPI;     // compile-time: only this epilogue's code exists in the kernel
-  constexpr bool is_prelu_ln = (epi == DOSX_EPI_PRELU_LN_BWD), is_rowln = (epi == DOSX_EPI_ROWLN_BWD);
+  constexpr bool is_prelu_ln = (epi == DOSX_EPI_PRELU_LN_BWD || epi == DOSX_EPI_PRELU_LN_BWD_SEG), is_rowln = (epi == DOSX_EPI_ROWLN_BWD);
   constexpr bool aux_first = (epi != DOSX_EPI_BIAS_ACT && epi != DOSX_EPI_LN && epi != DOSX_EPI_SEGSUM);   // operand 1 is `aux`
   constexpr bool use_stats = is_prelu_ln || is_rowln;
   const bool has1 = aux_first ? (g.aux != nullptr)
@@ -286,7 +289,7 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch& L, const int bid) { 
 #pragma unroll
   for (int j = 0; j < CG; ++j) { pg[j] = f4zero(); pb[j] = f4zero(); }
   float e_alpha = 0.f;
-  if (epi == DOSX_EPI_PRELU_LN_BWD || epi == DOSX_EPI_PRELU_BWD) e_alpha = *g.epi_alpha;
+  if (is_prelu_ln || epi == DOSX_EPI_PRELU_BWD) e_alpha = *g.epi_alpha;
   bool on[CG];
   int gcol[CG];
   float4 biasv[CG], gamv[CG], betv[CG];
@@ -368,6 +371,38 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch& L, const int bid) { 
   }
   };
   if constexpr (HOIST) prefetch_rows();
+  // EPI_LN with gathered row addends (DosxGemm.add_p / add_q: the node products of the factored EdgeModel Linear): the two rows
+  // of every output row this lane normalises are requested here, above the k-loop (L2-resident [nodes, N] tensors; K is H, so
+  // the loop is short - behind it the gathers would be an exposed index -> row round-trip pair), in the layout of the epilogue
+  // that consumes them: quarter wave per row (NTW <= 2), or whole wave per row fetched after the loop (512-column tiles).
+  constexpr int LNP = (ER + 3) / 4;                 // quarter-wave passes over a wave's ER rows
+  float4 adq[(EPI == DOSX_EPI_LN && NTW <= 2) ? RTE : 1][(EPI == DOSX_EPI_LN && NTW <= 2) ? LNP : 1][2][KQ];
+  const bool has_add = (EPI == DOSX_EPI_LN) && g.add_p != nullptr;
+  if constexpr (EPI == DOSX_EPI_LN && NTW <= 2) {
+    if (has_add) {
+      int ip[RTE][LNP], iq[RTE][LNP];
+#pragma unroll
+      for (int rt = 0; rt < RTE; ++rt)
+#pragma unroll
+        for (int p = 0; p < LNP; ++p) {
+          const int li = 4 * p + (lane >> 4);
+          const int rc = min(m0 + 32 * rt + wave * ER + (li < ER ? li : 0), M - 1);
+          ip[rt][p] = g.add_ip[rc];
+          iq[rt][p] = g.add_iq[rc];
+        }
+#pragma unroll
+      for (int rt = 0; rt < RTE; ++rt)
+#pragma unroll
+        for (int p = 0; p < LNP; ++p)
+#pragma unroll
+          for (int k = 0; k < KQ; ++k) {
+            const int c = (lane & 15) * 4 + 64 * k;
+            const int cc = n0 + (c < ncols ? c : 0);
+            adq[rt][p][0][k] = ld4(g.add_p + (size_t)ip[rt][p] * g.ld_add + cc);
+            adq[rt][p][1][k] = ld4(g.add_q + (size_t)iq[rt][p] * g.ld_add + cc);
+          }
+    }
+  }
 
   if (wave_u >= 4) {
     // =============================== staging waves ===============================================
@@ -414,10 +449,17 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch& L, const int bid) { 
           const int lin = st + 256 * i;
           const int r = lin / (BN / 4), c4 = (lin % (BN / 4)) * 4;
           const int k = k0 + r, n = n0 + c4;
+          int kr = min(k, K - 1), wofs = 0;          // DosxGemm.w_seg_off: every K-segment multiplies its own block of W
+          if (g.w_seg_off != 0) {
+            const int w0_ = g.a[0].width, w01_ = g.nseg > 2 ? w0_ + g.a[1].width : 0x7fffffff;
+            const int sg = kr < w0_ ? 0 : (kr < w01_ ? 1 : 2);
+            kr -= sg == 0 ? 0 : (sg == 1 ? w0_ : w01_);
+            wofs = sg * g.w_seg_off;
+          }
           if (VEC) {
-            v = ld4(g.w + (size_t)min(k, K - 1) * g.ldw + (n < N ? n : 0));
+            v = ld4(g.w + (size_t)kr * g.ldw + wofs + (n < N ? n : 0));
           } else if (k < K && n < N) {
-            const float* p = g.w + (size_t)k * g.ldw + n;
+            const float* p = g.w + (size_t)kr * g.ldw + wofs + n;
             v.x = p[0];
             if (n + 1 < N) v.y = p[1];
             if (n + 2 < N) v.z = p[2];
@@ -573,7 +615,12 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch& L, const int bid) { 
           else v = __builtin_amdgcn_raw_buffer_load_b128(rA2, voffA[r][2], soffA, 0);
           ar[r].v = __builtin_bit_cast(float4, v);
         }
-        const int soffW = __builtin_amdgcn_readfirstlane((WL == 0) ? k0u * 4 : k0u * g.ldw * 4);   // (keeps it in an SGPR: no waterfall loop)
+        int kw = k0u, wso = 0;
+        if (WL == 1 && g.w_seg_off != 0) {           // every K-segment multiplies its own block of W (rows restart at 0)
+          kw = k0u - (sgi == 0 ? 0 : (sgi == 1 ? e0 : e1));
+          wso = sgi * g.w_seg_off;
+        }
+        const int soffW = __builtin_amdgcn_readfirstlane((WL == 0) ? k0u * 4 : (kw * g.ldw + wso) * 4);   // (keeps it in an SGPR: no waterfall loop)
 #pragma unroll
         for (int i = 0; i < NW4; ++i)
           wr[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rW, voffW[i], soffW, 0));
@@ -787,6 +834,7 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch& L, const int bid) { 
           v[k] = f4zero();
           if (c < ncols) {
             v[k] = f4add(ld4(&Cs[rt * CTILE + lr * LDC + c]), biasq[k]);
+            if (has_add) v[k] = f4add(v[k], f4add(adq[rt][p][0][k], adq[rt][p][1][k]));
             s1 += v[k].x + v[k].y + v[k].z + v[k].w;
           }
         }
@@ -868,6 +916,18 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch& L, const int bid) { 
       }
     } else if (epi == DOSX_EPI_LN) {
       float s1 = 0.f;
+      if (has_add) {                   // (512-column tiles: the gathered addends of this row, requested together)
+        const int rc = min(r, M - 1);
+        const int ip = g.add_ip[rc], iq = g.add_iq[rc];
+        float4 ap[CG], aq[CG];
+#pragma unroll
+        for (int j = 0; j < CG; ++j) {
+          ap[j] = ld4(g.add_p + (size_t)ip * g.ld_add + gcol[j]);
+          aq[j] = ld4(g.add_q + (size_t)iq * g.ld_add + gcol[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < CG; ++j) v[j] = f4add(v[j], f4add(ap[j], aq[j]));
+      }
 #pragma unroll
       for (int j = 0; j < CG; ++j) {
         if (!on[j]) continue;
@@ -958,13 +1018,15 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch& L, const int bid) { 
                                rstd * (dxh[j].z - m1 - xh[j].z * m2), rstd * (dxh[j].w - m1 - xh[j].w * m2));
         if (is_rowln) o = f4add(o, pv2[rt][i][j]);
         st4(orow + gcol[j], o);
+        if constexpr (epi == DOSX_EPI_PRELU_LN_BWD_SEG) st4(&Cs[rt * CTILE + lr * LDC + lane * 4 + 256 * j], o);   // dz row for the node sums below
       }
     }
   }
 
   }   // rt
   }   // epilogues other than LN
-  if constexpr (epi == DOSX_EPI_SEGSUM) {
+  if constexpr (epi == DOSX_EPI_PRELU_LN_BWD_SEG) __syncthreads();       // the C tile now holds dz: every wave's rows are in place
+  if constexpr (SEGT) {
     // ---- segment sums: agg[n] = scale[n] * sum_{e in seg(n)} (acc[e] + bias)  (scatter_mean / scatter_sum by `col`,
     // DOSTransformer_phonon.py:209 / DOSTransformer.py:187), one wave per node, rows in order (the summation order of the
     // stand-alone segment_reduce kernel's row loop, so the tiling never changes a bit).  Rows of a node outside this tile
@@ -1022,7 +1084,7 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch& L, const int bid) { 
   }
   STAMP(58);
   // ---- per-workgroup partial sums for the parameter gradients of the fused LN / PReLU ----------
-  if (g.partials && (epi == DOSX_EPI_PRELU_LN_BWD || epi == DOSX_EPI_ROWLN_BWD || epi == DOSX_EPI_PRELU_BWD)) {
+  if (g.partials && (is_prelu_ln || epi == DOSX_EPI_ROWLN_BWD || epi == DOSX_EPI_PRELU_BWD)) {
     float* prow = g.partials + (size_t)((L.part_base + bx) * gy + by) * g.partial_ld;
     __syncthreads();                    // (the C tile rows of other waves are still being read above)
     if (epi != DOSX_EPI_PRELU_BWD) {
@@ -1105,7 +1167,7 @@ template <int RT, int NTW, int WL, int PRO, int VEC, int EPI>
 int launch_gemm3(const GemmLaunch& L, hipStream_t s) {
   constexpr int BN = 128 * NTW;
   dim3 grid(ceil_div(L.g.M - L.m_base, RT == 0 ? 16 : (RT == 3 ? 48 : BM * RT)) * ceil_div(L.g.N, BN));
-  if (EPI == DOSX_EPI_SEGSUM) grid = dim3(L.g.seg_ntiles);          // one workgroup per node-aligned row tile
+  if (EPI == DOSX_EPI_SEGSUM || EPI == DOSX_EPI_PRELU_LN_BWD_SEG) grid = dim3(L.g.seg_ntiles);          // one workgroup per node-aligned row tile
   constexpr size_t smem = gemm_smem_bytes<RT, NTW, WL, (VEC && (PRO == DOSX_PRO_LN_PRELU || PRO == DOSX_PRO_ROWLN)) ? 1 : 0>();
   if constexpr (smem > 160 * 1024) {     // (512-column tile + LayerNorm prologue: no caller has this shape)
     dosx_set_error("dosx_gemm: tile %dx%d with prologue %d exceeds the 160 KB LDS", BM * RT, BN, PRO);
@@ -1168,6 +1230,9 @@ int dispatch_gemm(const GemmLaunch& L, hipStream_t s) {
     switch (epi) {
       case DOSX_EPI_BIAS_ACT: return launch_gemm<NTW, 1, DOSX_PRO_NONE, 1, DOSX_EPI_BIAS_ACT>(L, s);
       case DOSX_EPI_PRELU_LN_BWD: return launch_gemm<NTW, 1, DOSX_PRO_NONE, 1, DOSX_EPI_PRELU_LN_BWD>(L, s);
+      case DOSX_EPI_PRELU_LN_BWD_SEG:
+        if constexpr (NTW <= 2) return launch_gemm3<3, NTW, 1, DOSX_PRO_NONE, 1, DOSX_EPI_PRELU_LN_BWD_SEG>(L, s);
+        break;
       case DOSX_EPI_RELU_MASK: return launch_gemm<NTW, 1, DOSX_PRO_NONE, 1, DOSX_EPI_RELU_MASK>(L, s);
       case DOSX_EPI_ROWLN_BWD: return launch_gemm<NTW, 1, DOSX_PRO_NONE, 1, DOSX_EPI_ROWLN_BWD>(L, s);
       case DOSX_EPI_PRELU_BWD: return launch_gemm<NTW, 1, DOSX_PRO_NONE, 1, DOSX_EPI_PRELU_BWD>(L, s);
@@ -1186,7 +1251,7 @@ int seg_vec_ok(const DosxSeg* segs, int nseg) {
 }
 
 int gemm_bn(int M, int N, int epi) {
-  const bool full_row = (epi == DOSX_EPI_LN || epi == DOSX_EPI_PRELU_LN_BWD || epi == DOSX_EPI_ROWLN_BWD);
+  const bool full_row = (epi == DOSX_EPI_LN || epi == DOSX_EPI_PRELU_LN_BWD || epi == DOSX_EPI_ROWLN_BWD || epi == DOSX_EPI_PRELU_LN_BWD_SEG);
   if (full_row) return N <= 128 ? 128 : (N <= 256 ? 256 : 512);
   static int forced = -1;
   if (forced < 0) {
@@ -1288,7 +1353,7 @@ static int gemm_plan(const DosxGemm& g, GemmLaunch& L) {
   int bn = gemm_bn(g.M, g.N, g.epi);
   if ((g.stats_out || g.norm_out) && bn < g.N) bn = g.N <= 256 ? 256 : 512;
   if (bn == 512 && L.rt >= 2) L.rt = 1;
-  if (g.epi == DOSX_EPI_SEGSUM) {          // node-aligned 48-row tiles, one column tile
+  if (g.epi == DOSX_EPI_SEGSUM || g.epi == DOSX_EPI_PRELU_LN_BWD_SEG) {          // node-aligned 48-row tiles, one column tile
     L.rt = 3;
     bn = g.N <= 128 ? 128 : 256;
   }
@@ -1457,7 +1522,7 @@ static int gemm_validate(const DosxGemm& g) {
   DOSX_CHECK_ARG(ksum == g.K, "dosx_gemm: segment widths sum to %d, K=%d", ksum, g.K);
   DOSX_CHECK_ARG((g.N & 3) == 0 && (g.ldo & 3) == 0 && aligned16(g.out), "dosx_gemm: N/ldo/out must be 4-float aligned");
   DOSX_CHECK_ARG(g.w && (g.out || g.epi == DOSX_EPI_SEGSUM), "dosx_gemm: null w/out");
-  const bool full_row = (g.epi == DOSX_EPI_LN || g.epi == DOSX_EPI_PRELU_LN_BWD || g.epi == DOSX_EPI_ROWLN_BWD);
+  const bool full_row = (g.epi == DOSX_EPI_LN || g.epi == DOSX_EPI_PRELU_LN_BWD || g.epi == DOSX_EPI_ROWLN_BWD || g.epi == DOSX_EPI_PRELU_LN_BWD_SEG);
   DOSX_CHECK_ARG(!full_row || g.N <= 512, "dosx_gemm: row-wise epilogue needs N <= 512 (hidden <= 256), got %d", g.N);
   DOSX_CHECK_ARG(!g.stats_out || g.N <= 128 * 4, "dosx_gemm: stats_out needs N <= 512");
   DOSX_CHECK_ARG(!g.norm_out || (g.N <= 128 * 4 && g.norm_rstd && g.epi == DOSX_EPI_BIAS_ACT && aligned16(g.norm_out)),
@@ -1474,13 +1539,26 @@ static int gemm_validate(const DosxGemm& g) {
     DOSX_CHECK_ARG(g.K <= GEMM_KMAX, "dosx_gemm: LayerNorm prologue needs K <= %d, got %d", GEMM_KMAX, g.K);
   if (g.pro == DOSX_PRO_PRELU || g.pro == DOSX_PRO_LN_PRELU) DOSX_CHECK_ARG(g.pro_alpha, "dosx_gemm: prologue needs alpha");
   if (g.epi == DOSX_EPI_LN) DOSX_CHECK_ARG(g.aux_out, "dosx_gemm: EPI_LN needs aux_out (rstd)");
-  if (g.epi == DOSX_EPI_PRELU_LN_BWD)
+  if (g.epi == DOSX_EPI_PRELU_LN_BWD || g.epi == DOSX_EPI_PRELU_LN_BWD_SEG)
     DOSX_CHECK_ARG(g.aux && g.aux_stats && g.epi_gamma && g.epi_beta && g.epi_alpha && (g.ldaux & 3) == 0,
                    "dosx_gemm: PRELU_LN_BWD needs aux/aux_stats/gamma/beta/alpha");
   if (g.epi == DOSX_EPI_ROWLN_BWD)
     DOSX_CHECK_ARG(g.aux && g.aux_stats && g.epi_gamma && (g.ldaux & 3) == 0, "dosx_gemm: ROWLN_BWD needs aux/aux_stats/gamma");
   if (g.epi == DOSX_EPI_RELU_MASK) DOSX_CHECK_ARG(g.aux && (g.ldaux & 3) == 0, "dosx_gemm: RELU_MASK needs aux");
   if (g.epi == DOSX_EPI_PRELU_BWD) DOSX_CHECK_ARG(g.aux && g.epi_alpha && (g.ldaux & 3) == 0, "dosx_gemm: PRELU_BWD needs aux/alpha");
+  if (g.epi == DOSX_EPI_PRELU_LN_BWD_SEG)
+    DOSX_CHECK_ARG(g.seg_tile && g.seg_ntiles > 0 && g.seg_rowptr && g.seg_agg && g.N <= 256 && g.out && g.w_layout == 1 &&
+                       g.pro == DOSX_PRO_NONE && !g.bias && g.seg_part && g.seg_cnt && (!g.partials || g.partial_ld >= 2 * g.N + 1),
+                   "dosx_gemm: EPI_PRELU_LN_BWD_SEG needs seg_tile / seg_rowptr / seg_agg / seg_part / seg_cnt, N <= 256, W[K,N], "
+                   "no prologue / bias");
+  if (g.add_p || g.add_q)
+    DOSX_CHECK_ARG(g.epi == DOSX_EPI_LN && g.add_p && g.add_q && g.add_ip && g.add_iq && g.ld_add >= g.N && (g.ld_add & 3) == 0 &&
+                       aligned16(g.add_p) && aligned16(g.add_q),
+                   "dosx_gemm: add_p / add_q need EPI_LN, both tensors with their row indices, and 4-float aligned rows");
+  if (g.w_seg_off != 0) {
+    DOSX_CHECK_ARG(g.w_layout == 1 && g.nseg > 1 && (g.w_seg_off & 3) == 0, "dosx_gemm: w_seg_off needs w_layout 1, several segments and a multiple of 4");
+    for (int i = 0; i < g.nseg; ++i) DOSX_CHECK_ARG((g.a[i].width & 31) == 0, "dosx_gemm: w_seg_off needs segment widths that are multiples of 32");
+  }
   if (g.epi == DOSX_EPI_SEGSUM)
     DOSX_CHECK_ARG(g.seg_tile && g.seg_ntiles > 0 && g.seg_rowptr && g.seg_agg && g.N <= 256 && (!g.out || g.res) &&
                        g.out_map.d >= (1 << 30) && g.out_map.idx == nullptr && g.out_map.c == 1 && g.out_map.off == 0 &&
@@ -1511,6 +1589,10 @@ extern "C" int dosx_gemm(const DosxGemm* gp, dosx_stream_t stream) {
     return dispatch_gemm<4>(X, s);
   };
   const int mA = (L.rt == 2 && L.vecA && L.vecW && !g.stats_out && !g.norm_out) ? gemm_tail_split(g.M, g.N, g.epi) : 0;
+  // dosx_gemm_partial_rows() knows (M, N, epi) only: a call that reduces partial rows must take the split it reports
+  DOSX_CHECK_ARG(g.partials == nullptr || mA == gemm_tail_split(g.M, g.N, g.epi),
+                 "dosx_gemm: this descriptor (alignment / stats_out / norm_out) cannot take the tail split dosx_gemm_partial_rows "
+                 "reports for M=%d N=%d epilogue %d", g.M, g.N, g.epi);
   if (mA > 0) {
     GemmLaunch A = L;                        // the full rounds: rows [0, mA) as 64-row tiles
     A.g.M = mA;

@@ -387,8 +387,13 @@ __global__ __launch_bounds__(512) void mlp_ln_bwd_kernel(const DosxMlpLnBwd a) {
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + 4 * g4 + r;
         if (row < M) {
-          a.dcat[(size_t)row * a.lddcat + cb + l15] = acc[0][r];
-          a.dcat[(size_t)row * a.lddcat + cb + l15 + 16] = acc[1][r];
+          float o0 = acc[0][r], o1 = acc[1][r];
+          if (a.add_dy) {          // + dy on the first NO columns: the residual connection around the block (Ys still holds the dy tile)
+            if (cb + l15 < NO) o0 += Ys[(4 * g4 + r) * LDY + cb + l15];
+            if (cb + l15 + 16 < NO) o1 += Ys[(4 * g4 + r) * LDY + cb + l15 + 16];
+          }
+          a.dcat[(size_t)row * a.lddcat + cb + l15] = o0;
+          a.dcat[(size_t)row * a.lddcat + cb + l15 + 16] = o1;
         }
       }
     }

@@ -17,7 +17,7 @@ from . import ops
 from ._lib import Attn, Seg
 from ._lib import load as _lib_load
 from .batch import GraphMeta
-from .ops import (ACT_LEAKY, ACT_RELU, EPI_LN, EPI_PRELU_BWD, EPI_PRELU_LN_BWD, EPI_RELU_MASK, EPI_ROWLN_BWD, EPI_SEGSUM,
+from .ops import (ACT_LEAKY, ACT_RELU, EPI_LN, EPI_PRELU_BWD, EPI_PRELU_LN_BWD, EPI_PRELU_LN_BWD_SEG, EPI_RELU_MASK, EPI_ROWLN_BWD, EPI_SEGSUM,
                   PRO_LN_PRELU, PRO_PRELU, PRO_ROWLN, GradSink, rowmap, seg)
 
 Params = Dict[str, torch.Tensor]
@@ -132,10 +132,18 @@ def _wide_ln(H: int) -> bool:
 
 
 def _factor_edge(E: int, H: int) -> bool:
-    """Whether the EdgeModel's first Linear (forward product and weight gradient) is factored into node parts + edge part:
-    where that GEMM is throughput-bound - from DOSX_FACTOR_MIN_GF (4) GF: Electron-DOS H 256 (14 GF at batch 64, 6 GF on the
-    32-crystal shard); the Phonon-DOS benchmark shape (1.8 GF, launch-latency-bound) measured 0.7 % slower with it."""
+    """Whether the EdgeModel's first Linear (forward product, weight gradient, input gradient) is factored into node parts +
+    edge part: from DOSX_FACTOR_MIN_GF GF of the un-factored product.  Round 4 (gather / add / normalise as a row kernel of
+    its own, three extra launches per layer and direction): 4 GF - Electron-DOS only; round 5 (the gathered addends inside the
+    E-row GEMM's LayerNorm epilogue, the destination sums inside the dgrad GEMM's epilogue): 0.5 GF, so the Phonon-DOS
+    benchmark shape (1.8 GF) factors too."""
     return _FACTOR_EDGE_WGRAD and 2.0 * E * (2 * H) * (3 * H) >= _FACTOR_MIN_GF * 1e9
+
+
+def _factor_fused(m, H: int) -> bool:
+    """Round 5: the factored form with its gather / add inside dosx_gemm's epilogues (forward: DosxGemm.add_p / add_q in
+    EPI_LN; backward: EPI_PRELU_LN_BWD_SEG on the batch's node-aligned row tiles, N = 2H <= 256)."""
+    return _FACTOR_FUSED and not _wide_ln(H)
 
 
 def _factor_heads(rows: int, H: int) -> bool:
@@ -153,6 +161,11 @@ def _factor_last(E: int, H: int) -> bool:
 
 def _mlp_ln_fused(a: SegList, M: int, H: int) -> bool:
     return a.plain is not None and len(a.plain) <= 2 and ops.mlp_ln_supported(M, a.K, 2 * H, H)
+
+
+def mlp_ln_bwd_fused(a: SegList, M: int, H: int, dy: torch.Tensor) -> bool:
+    """Whether mlp_ln_bwd runs the block's backward as ONE launch (csrc/mlp2.hip) for this input and gradient layout."""
+    return _mlp_ln_fused(a, M, H) and dy.stride(1) == 1
 
 
 def mlp_ln_fwd(P: Params, key: str, a: SegList, M: int, H: int, res: Optional[torch.Tensor] = None, segsum=None, aggsum=None):
@@ -183,9 +196,23 @@ def mlp_ln_fwd(P: Params, key: str, a: SegList, M: int, H: int, res: Optional[to
         pq = _empty(dev, N_, 4 * H)
         ops.gemm_pair(dict(M=N_, N=2 * H, segs=[seg(x)], w=W1[:, :H], out=pq[:, :2 * H]),
                       dict(M=N_, N=2 * H, segs=[seg(x)], w=W1[:, H:2 * H], out=pq[:, 2 * H:]))
-        z = _empty(dev, M, 2 * H)
-        ops.gemm(M, 2 * H, [seg(e)], W1[:, 2 * H:], z, bias=P[key + ".0.bias"])
-        ops.gather_add_rownorm(z, pq[:, :2 * H], pq[:, 2 * H:], m.src, m.dst, xhat, rstd, M, 2 * H)
+        if _factor_fused(m, H) and _EDGE_ONE_LAUNCH and segsum is not None and ops.edge_mlp_supported(H):
+            # the whole EdgeModel + aggregation + edge residual in ONE launch on the node-aligned row tiles (csrc/edge_mlp.hip):
+            # the [48, 2H] intermediate stays in LDS, the messages never exist in HBM
+            tile, rowptr, scale, agg, e_in, e_out = segsum
+            ops.edge_mlp_fwd(M, H, e, pq, m.src, m.dst, W1[:, 2 * H:], P[key + ".0.bias"], P[key + ".1.weight"], P[key + ".1.bias"],
+                             P[key + ".2.weight"], P[key + ".3.weight"], P[key + ".3.bias"], xhat, rstd, e_out, tile, rowptr, scale, agg)
+            a.keep.append(pq)
+            return None, (a, xhat, rstd, M, H)
+        if _factor_fused(m, H):
+            # the E-row product of K = H with the two gathered node rows added in front of its LayerNorm statistics
+            ops.gemm(M, 2 * H, [seg(e)], W1[:, 2 * H:], xhat, bias=P[key + ".0.bias"], epi=EPI_LN, aux_out=rstd,
+                     add_p=pq[:, :2 * H], add_ip=m.src, add_q=pq[:, 2 * H:], add_iq=m.dst)
+        else:
+            z = _empty(dev, M, 2 * H)
+            ops.gemm(M, 2 * H, [seg(e)], W1[:, 2 * H:], z, bias=P[key + ".0.bias"])
+            ops.gather_add_rownorm(z, pq[:, :2 * H], pq[:, 2 * H:], m.src, m.dst, xhat, rstd, M, 2 * H)
+        a.keep.append(pq)
     elif _wide_ln(H):
         # hidden > 256: the 2H-wide LayerNorm row no longer fits the one-tile row epilogue of dosx_gemm - plain GEMM, then
         # the parameter-free normalisation as a row kernel (the affine + PReLU stay in the second GEMM's prologue)
@@ -221,8 +248,10 @@ def mlp_ln_fwd(P: Params, key: str, a: SegList, M: int, H: int, res: Optional[to
 
 
 def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: GradSink, res: Optional[torch.Tensor] = None,
-               res_col0: int = 0) -> torch.Tensor:
-    """Returns dL/d(concatenated input) [M, K_in] (+ ``res`` added to its columns [res_col0, K_in))."""
+               res_col0: int = 0, add_dy: bool = False) -> torch.Tensor:
+    """Returns dL/d(concatenated input) [M, K_in] (+ ``res`` added to its columns [res_col0, K_in)).
+    add_dy (one-launch path only, see mlp_ln_bwd_fused): + dy on the first H columns - the residual connection around the
+    block, x' = x + MLP(cat[x, .]), differentiated in the same launch."""
     a, xhat, rstd, M, H = ctx
     dev = xhat.device
     gam, bet, alpha = P[key + ".1.weight"], P[key + ".1.bias"], P[key + ".2.weight"]
@@ -243,17 +272,28 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
     else:
         _wgrad_linear(sink, G, key + ".3.weight", key + ".3.bias", M, H, seg(dy), [seg(xhat)], keep=(dy,), pro=PRO_LN_PRELU,
                       pro_gamma=gam, pro_beta=bet, pro_alpha=alpha)
-    fused = agg_first is None and res is None and _mlp_ln_fused(a, M, H) and dy.stride(1) == 1
+    fused = mlp_ln_bwd_fused(a, M, H, dy) and agg_first is None and res is None
+    assert fused or not add_dy
     wide = _wide_ln(H) or agg_first is not None
-    rows = ops.mlp_ln_bwd_partial_rows(M) if fused else (ops.ln_prelu_bwd_partial_rows(M) if wide else
-                                                         ops.gemm_partial_rows(M, 2 * H, EPI_PRELU_LN_BWD))
+    fac_dgrad = a.factor is not None and _factor_edge(M, H) and _FACTOR_DGRAD and not fused
+    # round 5: the destination-node sums of dz (the factored weight / input gradients below need them) inside the dgrad GEMM's
+    # epilogue, on the batch's node-aligned row tiles - one partial row per tile
+    seg_bwd = (fac_dgrad and agg_first is None and not wide and _factor_fused(a.factor[2], H) and a.factor[2].seg_tile is not None
+               and 2 * H <= 256)
+    aggD_epi = None
+    if seg_bwd:
+        m_ = a.factor[2]
+        rows = int(m_.seg_tile.shape[1]) - 1
+        aggD_epi = sink.scratch(m_.num_nodes, 2 * H)
+    else:
+        rows = ops.mlp_ln_bwd_partial_rows(M) if fused else (ops.ln_prelu_bwd_partial_rows(M) if wide else
+                                                             ops.gemm_partial_rows(M, 2 * H, EPI_PRELU_LN_BWD))
     pld = 4 * H + 4          # [dgamma(2H) | dbeta(2H) | pad(3) | dalpha]; multiple of 4 -> vector reduce
     part = sink.scratch(rows, pld)
     dz = _empty(dev, M, 2 * H)
-    fac_dgrad = a.factor is not None and _factor_edge(M, H) and _FACTOR_DGRAD and not fused
     dcat = None if fac_dgrad else _empty(dev, M, a.K)
     if fused:
-        ops.mlp_ln_bwd(M, dy, xhat, rstd, P[key + ".0.weight"], P[key + ".3.weight"], gam, bet, alpha, dz, dcat, part)
+        ops.mlp_ln_bwd(M, dy, xhat, rstd, P[key + ".0.weight"], P[key + ".3.weight"], gam, bet, alpha, dz, dcat, part, add_dy=add_dy)
     elif agg_first is not None:
         ops.ln_prelu_bwd_gather(dnode, a.factor[2].dst, agg_first[2], xhat, rstd, gam, bet, alpha, dz, part, M, 2 * H)
     elif wide:          # plain dgrad GEMM, then PReLU + LayerNorm backward of the 2H-wide rows as a row kernel
@@ -261,6 +301,10 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
         ops.gemm(M, 2 * H, [seg(dy)], P[key + ".3.weight"], dact, w_layout=1)
         ops.ln_prelu_bwd(dact, xhat, rstd, gam, bet, alpha, dz, part, M, 2 * H)
         sink._keep.append(dact)
+    elif seg_bwd:
+        ops.gemm(M, 2 * H, [seg(dy)], P[key + ".3.weight"], dz, w_layout=1, epi=EPI_PRELU_LN_BWD_SEG, aux=xhat,
+                 aux_stats=rstd, epi_gamma=gam, epi_beta=bet, epi_alpha=alpha, partials=part, partial_ld=pld,
+                 seg_tile=m_.seg_tile, seg_rowptr=m_.rowptr_dst, seg_agg=aggD_epi)
     else:
         ops.gemm(M, 2 * H, [seg(dy)], P[key + ".3.weight"], dz, w_layout=1, epi=EPI_PRELU_LN_BWD, aux=xhat,
                  aux_stats=rstd, epi_gamma=gam, epi_beta=bet, epi_alpha=alpha, partials=part, partial_ld=pld)
@@ -268,7 +312,8 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
     sink.add(part, 2 * H, G[key + ".1.bias"], rows, pld, 2 * H)
     sink.add(part, pld - 1, G[key + ".2.weight"], rows, pld, 1)
     fac = a.factor
-    if fac is not None and _factor_edge(M, H) and key + ".0.weight" in G:
+    aggS = aggD = None
+    if fac is not None and _factor_edge(M, H) and (key + ".0.weight" in G or fac_dgrad):
         # The first Linear reads cat[x[row], x[col], e] (DOSTransformer_phonon.py:193-195): its weight gradient is
         #   sum_e dz_e (x) [x[row(e)] | x[col(e)] | e_e]  =  [ sum_n S_n (x) x_n | sum_n D_n (x) x_n | sum_e dz_e (x) e_e ],
         # S_n / D_n = the sums of dz over the edges that leave / enter node n.  The two node blocks become N-row jobs (20 x
@@ -277,24 +322,27 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
         # blocks of the one gradient (DosxWgrad.ldd); fixed summation orders, like everything else here.
         x, e, m = fac
         N_, E_ = m.num_nodes, m.num_edges
-        aggS, aggD = sink.scratch(N_, 2 * H), sink.scratch(N_, 2 * H)
+        aggS = sink.scratch(N_, 2 * H)
+        aggD = aggD_epi if aggD_epi is not None else sink.scratch(N_, 2 * H)
 
-        def node_sums(dz=dz, aggS=aggS, aggD=aggD, m=m):
+        def node_sums(dz=dz, aggS=aggS, aggD=aggD, m=m, with_dst=aggD_epi is None):
             ops.segment_reduce_perm(dz, m.rowptr_src, m.perm_src, aggS, N_, E_, 2 * H)
-            ops.segment_reduce(dz, m.rowptr_dst, None, aggD, None, None, N_, E_, 2 * H)
-        if _FACTOR_DGRAD:
+            if with_dst:                               # (else: written by the dgrad GEMM's epilogue above)
+                ops.segment_reduce(dz, m.rowptr_dst, None, aggD, None, None, N_, E_, 2 * H)
+        if fac_dgrad:
             node_sums()                                # the input gradient below reads them too: on the main stream, now
             sink._keep.append(dz)
         else:
             sink.defer_pre(node_sums, keep=(dz,))
-        Gw = G[key + ".0.weight"]                      # [2H, 3H]
-        with ops.graph_rows():
-            _wgrad_linear(sink, G, key + ".0.weight", None, N_, 2 * H, seg(aggS), [seg(x)], keep=(aggS, x), dst=Gw[:, :H])
-            _wgrad_linear(sink, G, key + ".0.weight", None, N_, 2 * H, seg(aggD), [seg(x)], keep=(aggD, x), dst=Gw[:, H:2 * H])
-            _wgrad_linear(sink, G, key + ".0.weight", key + ".0.bias", M, 2 * H, seg(dz), [seg(e)], keep=(dz, e), dst=Gw[:, 2 * H:])
+        if key + ".0.weight" in G:
+            Gw = G[key + ".0.weight"]                  # [2H, 3H]
+            with ops.graph_rows():
+                _wgrad_linear(sink, G, key + ".0.weight", None, N_, 2 * H, seg(aggS), [seg(x)], keep=(aggS, x), dst=Gw[:, :H])
+                _wgrad_linear(sink, G, key + ".0.weight", None, N_, 2 * H, seg(aggD), [seg(x)], keep=(aggD, x), dst=Gw[:, H:2 * H])
+                _wgrad_linear(sink, G, key + ".0.weight", key + ".0.bias", M, 2 * H, seg(dz), [seg(e)], keep=(dz, e), dst=Gw[:, 2 * H:])
     else:
         _wgrad_linear(sink, G, key + ".0.weight", key + ".0.bias", M, 2 * H, seg(dz), a.segs, keep=(dz,))
-    if fac is not None and _factor_edge(M, H) and _FACTOR_DGRAD and not fused:
+    if fac_dgrad:
         # ... and the INPUT gradient factored the same way: dL/de = dz Wc (+ the incoming edge-state gradient) is the only
         # E-row product left (a third of the columns of the [E,3H] concat gradient); the node parts come from the node sums,
         # sum_{e: row(e) = n} dz_e Wa = S_n Wa - the caller (gnn_bwd) multiplies N rows instead of gathering E of them back
@@ -350,7 +398,10 @@ def gnn_bwd(P: Params, G: Params, m: GraphMeta, ctxs, dx: torch.Tensor, sink: Gr
     for l in reversed(range(L)):
         pre = f"stacked_processor.{l}"
         cxe, cxn = ctxs[l]
-        dcat_n = mlp_ln_bwd(P, G, pre + ".node_model.node_mlp_2", cxn, dx, sink)          # [N, 2H]
+        # factored edge layer + one-launch NodeModel backward: the residual path's dx rides on the first H columns of dcat_n
+        fold_dx = (cxe[0].factor is not None and _factor_edge(E, H) and _FACTOR_DGRAD and _factor_fused(m, H)
+                   and mlp_ln_bwd_fused(cxn[0], N, H, dx))
+        dcat_n = mlp_ln_bwd(P, G, pre + ".node_model.node_mlp_2", cxn, dx, sink, add_dy=fold_dx)          # [N, 2H]
         if cxe[0].aggsum is not None:
             assert de is None                        # (the last layer: no edge-state gradient arrives)
             dmsg = dcat_n[:, H:]                     # dL/d agg [N,H]: mlp_ln_bwd expands it per edge inside its row kernel
@@ -368,11 +419,22 @@ def gnn_bwd(P: Params, G: Params, m: GraphMeta, ctxs, dx: torch.Tensor, sink: Gr
             # factored input gradient (large edge sets): dx_l = dx_{l+1} + S Wa + D Wb + (node-MLP input gradient)[:, :H]
             _, de_new, aggS, aggD = dcat_e
             W0 = P[pre + ".edge_model.edge_mlp.0.weight"]
-            t1, t2 = _empty(dev, N, H), _empty(dev, N, H)
-            ops.gemm(N, H, [seg(aggS)], W0[:, :H], t1, w_layout=1, res=dx)
-            ops.gemm(N, H, [seg(aggD)], W0[:, H:2 * H], t2, w_layout=1, res=t1)
-            ops.mask_residual(dcat_n[:, :H], None, t2, dx_old, None, N, H)
-            sink._keep.extend([dcat_n, t1, t2, dx])
+            if _factor_fused(m, H):
+                # ONE N-row product on the two node sums, each against its own column block of W0 (DosxGemm.w_seg_off)
+                if fold_dx:
+                    ops.gemm(N, H, [seg(aggS), seg(aggD)], W0[:, :H], dx_old, w_layout=1, w_seg_off=H, res=dcat_n[:, :H])
+                else:
+                    t1 = _empty(dev, N, H)
+                    ops.gemm(N, H, [seg(aggS), seg(aggD)], W0[:, :H], t1, w_layout=1, w_seg_off=H, res=dx)
+                    ops.mask_residual(dcat_n[:, :H], None, t1, dx_old, None, N, H)
+                    sink._keep.append(t1)
+                sink._keep.extend([dcat_n, dx])
+            else:
+                t1, t2 = _empty(dev, N, H), _empty(dev, N, H)
+                ops.gemm(N, H, [seg(aggS)], W0[:, :H], t1, w_layout=1, res=dx)
+                ops.gemm(N, H, [seg(aggD)], W0[:, H:2 * H], t2, w_layout=1, res=t1)
+                ops.mask_residual(dcat_n[:, :H], None, t2, dx_old, None, N, H)
+                sink._keep.extend([dcat_n, t1, t2, dx])
             dx, de = dx_old, de_new
             if sink.side is not None and ((_SPLIT_LATE_FLUSH == 1 and l == 1) or (_SPLIT_LATE_FLUSH == 2 and l >= 1)):
                 sink.flush_on_side()
@@ -555,7 +617,9 @@ def _ffn_tail_start(rows: int, H: int) -> int:
 
 _FUSED_FFN_BWD = __import__("os").environ.get("DOSX_FUSED_FFN_BWD", "1") == "1"
 _FACTOR_EDGE_WGRAD = __import__("os").environ.get("DOSX_FACTOR_EDGE_WGRAD", "1") == "1"   # EdgeModel first Linear factored into node / edge parts
-_FACTOR_MIN_GF = float(__import__("os").environ.get("DOSX_FACTOR_MIN_GF", "4"))
+_FACTOR_FUSED = __import__("os").environ.get("DOSX_FACTOR_FUSED", "1") == "1"               # ... with the gathers / node sums inside dosx_gemm's epilogues (round 5)
+_EDGE_ONE_LAUNCH = __import__("os").environ.get("DOSX_EDGE_ONE_LAUNCH", "1") == "1"       # ... and the whole EdgeModel forward as one launch (H <= 128)
+_FACTOR_MIN_GF = float(__import__("os").environ.get("DOSX_FACTOR_MIN_GF", "0.5" if _FACTOR_FUSED else "4"))
 _FACTOR_DGRAD = __import__("os").environ.get("DOSX_FACTOR_DGRAD", "1") == "1"             # ... and its input gradient
 _FACTOR_HEADS = __import__("os").environ.get("DOSX_FACTOR_HEADS", "1") == "1"             # heads: per-crystal K-segments multiplied once per crystal
 _FACTOR_HEADS_MIN_GF = float(__import__("os").environ.get("DOSX_FACTOR_HEADS_MIN_GF", "1"))
@@ -1113,7 +1177,9 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
     ops.rownorm_bwd_act(dkvs, kvs, rstd_s, ddosin, dosin, 0.01, dpre, rows2, H)
     map0, map1 = rowmap(d=B, m=2 * B, c=1, off=0), rowmap(d=B, m=2 * B, c=1, off=B)
     R = _empty(dev, 2 * B, H)            # sum over the energy axis of dpre (filled on the side stream below)
-    if len(a_g.keep) > 2 and GradSink.group_wgrad and "fc.weight" in G and "fc_prompt.weight" in G:  # (forward factored; R is filled later, on the side stream: deferred jobs only)
+    # (forward factored; R is filled later, on the side stream: deferred jobs only - and not with the late-flush experiment,
+    #  whose flush_on_side() below would launch the B-row jobs before the reduce_rows that writes R is even queued)
+    if len(a_g.keep) > 2 and GradSink.group_wgrad and "fc.weight" in G and "fc_prompt.weight" in G and not _LATE_SELF_FLUSH:
         # the same factoring for the weight gradients: the column blocks that multiply the per-crystal inputs are
         # (sum_s dpre[s, b]) (x) [graph_b (| prompt_b)] - B-row jobs on R - and only the E1 block keeps its S * B rows
         E1_, graph_ = a_g.keep[0], a_g.keep[1]

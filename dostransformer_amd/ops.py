@@ -16,7 +16,7 @@ from . import _lib
 from ._lib import Ffn, BIG, Attn, Gemm, ReduceJob, RowMap, Seg, Wgrad
 
 PRO_NONE, PRO_PRELU, PRO_LN_PRELU, PRO_ROWLN = 0, 1, 2, 3
-EPI_BIAS_ACT, EPI_LN, EPI_PRELU_LN_BWD, EPI_RELU_MASK, EPI_ROWLN_BWD, EPI_PRELU_BWD, EPI_SEGSUM = 0, 1, 2, 3, 4, 5, 6
+EPI_BIAS_ACT, EPI_LN, EPI_PRELU_LN_BWD, EPI_RELU_MASK, EPI_ROWLN_BWD, EPI_PRELU_BWD, EPI_SEGSUM, EPI_PRELU_LN_BWD_SEG = 0, 1, 2, 3, 4, 5, 6, 7
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 
 
@@ -312,13 +312,15 @@ def gemm(M: int, N: int, segs: Sequence[Seg], w: torch.Tensor, out: torch.Tensor
          out_map: Optional[RowMap] = None, res=None, res_map: Optional[RowMap] = None,
          stats_out=None, aux_out=None, aux=None, aux_stats=None, epi_gamma=None, epi_beta=None,
          epi_alpha=None, partials=None, partial_ld: int = 0, res_col0: int = 0, seg_tile=None, seg_rowptr=None,
-         seg_scale=None, seg_agg=None, keep: Optional[list] = None, norm_out=None, norm_rstd=None, res_pre: bool = False) -> None:
+         seg_scale=None, seg_agg=None, keep: Optional[list] = None, norm_out=None, norm_rstd=None, res_pre: bool = False,
+         add_p=None, add_ip=None, add_q=None, add_iq=None, w_seg_off: int = 0) -> None:
     """out[M,N] = epilogue(prologue(A) @ B); see include/dosx.h:DosxGemm."""
     g = _gemm_desc(M, N, segs, w, out, w_layout=w_layout, pro=pro, pro_gamma=pro_gamma, pro_beta=pro_beta, pro_alpha=pro_alpha,
                    pro_stats=pro_stats, epi=epi, act=act, act_slope=act_slope, bias=bias, out_map=out_map, res=res, res_map=res_map,
                    stats_out=stats_out, aux_out=aux_out, aux=aux, aux_stats=aux_stats, epi_gamma=epi_gamma, epi_beta=epi_beta,
                    epi_alpha=epi_alpha, partials=partials, partial_ld=partial_ld, res_col0=res_col0, seg_tile=seg_tile,
-                   seg_rowptr=seg_rowptr, seg_scale=seg_scale, seg_agg=seg_agg, norm_out=norm_out, norm_rstd=norm_rstd, res_pre=res_pre)
+                   seg_rowptr=seg_rowptr, seg_scale=seg_scale, seg_agg=seg_agg, norm_out=norm_out, norm_rstd=norm_rstd, res_pre=res_pre,
+                   add_p=add_p, add_ip=add_ip, add_q=add_q, add_iq=add_iq, w_seg_off=w_seg_off)
     _call("dosx_gemm", C.byref(g), _stream(), w=lambda: _gemm_work(g))
 
 
@@ -340,7 +342,8 @@ def _gemm_desc(M: int, N: int, segs: Sequence[Seg], w: torch.Tensor, out: torch.
                out_map: Optional[RowMap] = None, res=None, res_map: Optional[RowMap] = None,
                stats_out=None, aux_out=None, aux=None, aux_stats=None, epi_gamma=None, epi_beta=None,
                epi_alpha=None, partials=None, partial_ld: int = 0, res_col0: int = 0, seg_tile=None, seg_rowptr=None,
-               seg_scale=None, seg_agg=None, norm_out=None, norm_rstd=None, res_pre: bool = False) -> "Gemm":
+               seg_scale=None, seg_agg=None, norm_out=None, norm_rstd=None, res_pre: bool = False,
+               add_p=None, add_ip=None, add_q=None, add_iq=None, w_seg_off: int = 0) -> "Gemm":
     g = Gemm()
     g.M, g.N = int(M), int(N)
     g.K = int(sum(s.width for s in segs))
@@ -368,7 +371,13 @@ def _gemm_desc(M: int, N: int, segs: Sequence[Seg], w: torch.Tensor, out: torch.
     g.partials, g.partial_ld = _p(partials), int(partial_ld)
     g.res_col0 = int(res_col0)
     g.res_pre = 1 if res_pre else 0
-    if seg_tile is not None:            # EPI_SEGSUM: [3, T+1] node-aligned tile table
+    g.w_seg_off = int(w_seg_off)
+    if add_p is not None:               # EPI_LN: gathered row addends (the factored EdgeModel Linear)
+        assert add_q is not None and add_ip is not None and add_iq is not None and add_p.stride(0) == add_q.stride(0)
+        assert add_ip.dtype == torch.int32 and add_iq.dtype == torch.int32
+        g.add_p, g.add_ip, g.add_q, g.add_iq = add_p.data_ptr(), add_ip.data_ptr(), add_q.data_ptr(), add_iq.data_ptr()
+        g.ld_add = int(add_p.stride(0))
+    if seg_tile is not None:            # EPI_SEGSUM / EPI_PRELU_LN_BWD_SEG: [3, T+1] node-aligned tile table
         assert seg_tile.dim() == 2 and seg_tile.shape[0] == 3 and seg_tile.is_contiguous()
         g.seg_tile, g.seg_ntiles = seg_tile.data_ptr(), int(seg_tile.shape[1]) - 1
         g.seg_rowptr, g.seg_scale, g.seg_agg = _p(seg_rowptr), _p(seg_scale), _p(seg_agg)
@@ -494,7 +503,7 @@ def mlp_ln_bwd_partial_rows(M: int) -> int:
 
 
 def mlp_ln_bwd(M: int, dy: torch.Tensor, xhat: torch.Tensor, rstd: torch.Tensor, w1, w2, gamma, beta, alpha, dz: torch.Tensor,
-               dcat: torch.Tensor, partials: torch.Tensor) -> None:
+               dcat: torch.Tensor, partials: torch.Tensor, add_dy: bool = False) -> None:
     """dz = LN/PReLU backward of (dy W2), dcat = dz W1, [dgamma | dbeta | .. | dalpha] partial rows - one launch
     (include/dosx.h: DosxMlpLnBwd)."""
     d = _lib.MlpLnBwd()
@@ -506,8 +515,38 @@ def mlp_ln_bwd(M: int, dy: torch.Tensor, xhat: torch.Tensor, rstd: torch.Tensor,
     d.dz = dz.data_ptr()
     d.dcat, d.lddcat = dcat.data_ptr(), int(dcat.stride(0))
     d.partials, d.partial_ld = partials.data_ptr(), int(partials.stride(0))
+    d.add_dy = 1 if add_dy else 0
     _call("dosx_mlp_ln_bwd", C.byref(d), _stream(),
           w=lambda: (f"mlp_ln_bwd[K{d.K},NH{d.NH},NO{d.NO}]", "mlp_ln_bwd_kernel", "mfma", 2.0 * _real(d.M) * d.NH * (d.K + d.NO)))
+
+
+def edge_mlp_supported(H: int) -> bool:
+    return bool(_lib.load().dosx_edge_mlp_supported(int(H)))
+
+
+def edge_mlp_fwd(E: int, H: int, e: torch.Tensor, pq: torch.Tensor, src, dst, w1c: torch.Tensor, b1, gamma, beta, alpha, w3, b3,
+                 xhat: torch.Tensor, rstd: torch.Tensor, e_out: Optional[torch.Tensor], seg_tile, seg_rowptr, seg_scale, seg_agg) -> None:
+    """The EdgeModel (first Linear factored: ``pq`` = the two node products, ``w1c`` = its edge block [2H, H] as a view of the
+    [2H, 3H] weight) + scatter_mean / scatter_sum + the edge residual in one launch (include/dosx.h: DosxEdgeMlp)."""
+    d = _lib.EdgeMlp()
+    d.E, d.H = int(E), int(H)
+    d.e, d.lde = e.data_ptr(), int(e.stride(0))
+    d.pq, d.ldpq = pq.data_ptr(), int(pq.stride(0))
+    d.src, d.dst = src.data_ptr(), dst.data_ptr()
+    assert w1c.stride(1) == 1 and w3.is_contiguous()
+    d.w1, d.ldw1, d.b1 = w1c.data_ptr(), int(w1c.stride(0)), b1.data_ptr()
+    d.gamma, d.beta, d.alpha = gamma.data_ptr(), beta.data_ptr(), alpha.data_ptr()
+    d.w3, d.b3 = w3.data_ptr(), b3.data_ptr()
+    d.xhat, d.rstd = xhat.data_ptr(), rstd.data_ptr()
+    if e_out is not None:
+        d.e_out, d.ldeo = e_out.data_ptr(), int(e_out.stride(0))
+    assert seg_tile.dim() == 2 and seg_tile.shape[0] == 3 and seg_tile.is_contiguous()
+    d.seg_tile, d.seg_ntiles = seg_tile.data_ptr(), int(seg_tile.shape[1]) - 1
+    d.seg_rowptr, d.seg_scale, d.seg_agg = seg_rowptr.data_ptr(), _p(seg_scale), seg_agg.data_ptr()
+    part = alloc(e.device, d.seg_ntiles, H)
+    d.seg_part, d.seg_cnt = part.data_ptr(), COUNTERS.take(e.device, d.seg_ntiles)
+    _call("dosx_edge_mlp_fwd", C.byref(d), _stream(),
+          w=lambda: (f"edge_mlp_fwd[H{d.H}]", f"edge_fwd_kernel<{2 * d.H}>", "mfma", 2.0 * _real(d.E) * (2 * d.H) * (2 * d.H)))
 
 
 def gemm_partial_rows(M: int, N: int, epi: int) -> int:

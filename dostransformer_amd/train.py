@@ -488,7 +488,9 @@ class Trainer:
             self._slots[key] = slot
         elif getattr(slot, "scratch", None) is None:               # bucket first filled from a batch object
             i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)
-            slot.scratch = {"small": i32(4 * B + 3), "node_row": i32(n_pad), "edge_row": i32(e_pad)}
+            # (sized from the SLOT: a promoted host bucket is larger than the requested one, and the collate kernels write
+            #  node_row / edge_row up to the slot's own padded counts)
+            slot.scratch = {"small": i32(4 * B + 3), "node_row": i32(slot.g.meta.num_nodes), "edge_row": i32(slot.g.meta.num_edges)}
         ds.collate_into(slot.g, idx, slot.scratch)
         self._bump_dropout_seed()
         loss = self._run_slot(slot, fp, ng, fresh)

@@ -63,11 +63,17 @@ enum {
   DOSX_EPI_RELU_MASK = 3,    /* out = acc * (aux > 0)                                                 */
   DOSX_EPI_ROWLN_BWD = 4,    /* acc = dL/d LN(x) -> out = res + dL/dx ; x = aux, stats = aux_stats    */
   DOSX_EPI_PRELU_BWD = 5,    /* out = acc * (aux >= 0 ? 1 : alpha); partial dalpha                    */
-  DOSX_EPI_SEGSUM = 6        /* message GEMM of a GNN layer with the aggregation in its epilogue (a5 + a6):
+  DOSX_EPI_SEGSUM = 6,       /* message GEMM of a GNN layer with the aggregation in its epilogue (a5 + a6):
                                 msg = acc + bias stays in LDS;  seg_agg[n] = seg_scale[n] * sum_{e in seg(n)} msg[e];
                                 out = msg + res (the edge residual e' = e + msg) unless out is NULL.  Row tiles are
                                 node-aligned: workgroup t owns rows [seg_tile[t], seg_tile[t+1]) (<= 48) = the whole
                                 destination segments of the nodes [seg_tile[T+1+t], seg_tile[T+2+t]), T = seg_ntiles    */
+  DOSX_EPI_PRELU_LN_BWD_SEG = 7 /* EPI_PRELU_LN_BWD on the node-aligned row tiles of EPI_SEGSUM (same seg_* fields, w_layout 1,
+                                N <= 256): out = dL/dz as before AND seg_agg[n] = seg_scale[n] * sum_{e in seg(n)} out[e] - the
+                                destination-node sums of dz that the FACTORED first Linear of the EdgeModel needs for its
+                                weight and input gradients (DOSTransformer_phonon.py:190-197: cat[x[row], x[col], e] W1^T =
+                                (x Wa^T)[row] + (x Wb^T)[col] + e Wc^T, so dWb = (sum_{e: col(e)=n} dz_e)^T x).  One partial
+                                row per TILE (seg_ntiles rows, empty tiles write zeros).                                  */
 };
 
 /* C[M,N] = epilogue( prologue(A)[M,K] * B ),  fp32 MFMA (v_mfma_f32_32x32x2_f32).
@@ -132,6 +138,22 @@ typedef struct DosxGemm {
                          The K-segments of an output head that are constant along the energy axis - cat[x, graph(, prompt)]
                          (DOSTransformer_phonon.py:93-95,105-109) repeats the pooled crystal vector for every energy - are
                          multiplied once per crystal and enter the per-energy GEMM as such a row-mapped pre-activation term. */
+  /* EPI_LN, optional: two GATHERED row addends in front of the LayerNorm statistics (round 5),
+   *     xhat[r] = LN_noaffine( acc[r] + bias + add_p[add_ip[r]] + add_q[add_iq[r]] ),   rows of add_p / add_q: N floats, stride ld_add.
+   * The EdgeModel's first Linear on cat[x[row], x[col], e] (DOSTransformer_phonon.py:190-197) FACTORED: the two node products
+   * P = x Wa^T, Q = x Wb^T are N-row GEMMs (dosx_gemm_pair), this call multiplies the E edge rows by Wc only (K = H instead of
+   * 3H) and gathers P[row(e)] + Q[col(e)] from the L2-resident [nodes, 4H] product in its epilogue. */
+  const float* add_p;
+  const int32_t* add_ip;
+  const float* add_q;
+  const int32_t* add_iq;
+  int32_t ld_add;
+  /* w_layout 1 with nseg > 1, optional: K-segment s of A multiplies its OWN block of W - rows restart at 0 and the block is
+   * shifted by s * w_seg_off floats:  B(k, n) = w[(k - k0_s) * ldw + s * w_seg_off + n]  (0 = one [K,N] matrix as usual).
+   * The node part of the factored EdgeModel input gradient, dx = [S | D] . [Wa ; Wb] with Wa = W1[:, :H], Wb = W1[:, H:2H] two
+   * column blocks of ONE [2H,3H] matrix: segments S, D of width 2H, ldw = 3H, w_seg_off = H.  Needs aligned operands and
+   * segment widths that are multiples of 32. */
+  int32_t w_seg_off;
 } DosxGemm;
 
 /* exact number of workgroup rows dosx_gemm writes into `partials` for this epilogue: ceil(M/32) for
@@ -566,9 +588,36 @@ typedef struct DosxMlpLnBwd {
   float* dz;                              /* [M,NH], row stride NH */
   float* dcat; int32_t lddcat;            /* [M,K] */
   float* partials; int32_t partial_ld;
+  int32_t add_dy;                         /* 1: dcat[:, :NO] += dy - the block's residual connection out = res + MLP(cat[res, .])
+                                             (NodeModel, DOSTransformer_phonon.py:204-212 + :83) differentiated in the same launch */
 } DosxMlpLnBwd;
 int dosx_mlp_ln_bwd_partial_rows(int M);
 int dosx_mlp_ln_bwd(const DosxMlpLnBwd* a, dosx_stream_t stream);
+
+/* The EdgeModel of one message-passing layer + the aggregation behind it in ONE launch (round 5; SURVEY.md §7 step 4;
+ * DOSTransformer_phonon.py:186-197,209 and the edge residual :84), first Linear FACTORED (see DosxGemm.add_p):
+ *     z    = e . Wc^T + b1 + pq[src[r], 0:2H] + pq[dst[r], 2H:4H]          Wc = first Linear's weight block [2H, H], row stride ldw1
+ *     xhat = (z - mean) * rstd  (eps 1e-5; written with rstd: the backward and dosx_wgrad read them)
+ *     msg  = prelu(xhat * gamma + beta) . W3^T + b3                        W3 [H, 2H]
+ *     e_out = e + msg (skipped when NULL) ;  seg_agg[n] = seg_scale[n] * sum_{r in seg(n)} msg[r]
+ * What dosx_gemm (EPI_LN + add_p / add_q) followed by dosx_gemm (PRO_LN_PRELU, EPI_SEGSUM) compute, for hidden 64 / 128: one
+ * workgroup per node-aligned row tile of the batch's tile table (seg_* exactly as in DosxGemm), the [48, 2H] intermediate in LDS.
+ * pq [nodes, >= 4H] holds the two node products P | Q (dosx_gemm_pair on the N node rows). */
+typedef struct DosxEdgeMlp {
+  int32_t E, H;
+  const float* e; int32_t lde;
+  const float* pq; int32_t ldpq;
+  const int32_t* src; const int32_t* dst;
+  const float* w1; int32_t ldw1; const float* b1;
+  const float* gamma; const float* beta; const float* alpha;
+  const float* w3; const float* b3;
+  float* xhat; float* rstd;
+  float* e_out; int32_t ldeo;
+  const int32_t* seg_tile; int32_t seg_ntiles;
+  const int32_t* seg_rowptr; const float* seg_scale; float* seg_agg; float* seg_part; int32_t* seg_cnt;
+} DosxEdgeMlp;
+int dosx_edge_mlp_supported(int H);
+int dosx_edge_mlp_fwd(const DosxEdgeMlp* a, dosx_stream_t stream);
 
 /* Graph metadata ("CSR build") on the device, stream-ordered, no host round trip — counterpart of what PyG's
  * collate / to_dense_batch / torch_scatter derive per call from `edge_index` and `batch`

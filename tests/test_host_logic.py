@@ -260,9 +260,12 @@ def test_size_policies_of_the_factored_forms():
     feed-forward layers (functional._factor_edge / _factor_last / _ffn_tail_start): the BASELINE shapes land where DESIGN.md
     says they do."""
     from dostransformer_amd import functional as Fn
-    # Phonon-DOS benchmark shape (H 128, ~9000 edges): fused forms; Electron-DOS (H 256, 17880 edges; the 32-crystal shard
-    # has about half of them): factored first Linear and aggregate-first last layer
-    assert not Fn._factor_edge(9000, 128) and not Fn._factor_last(9000, 128)
+    # Phonon-DOS benchmark shape (H 128, ~9000 edges): factored first Linear since round 5 (gathers / node sums inside the GEMM
+    # epilogues), per-edge last layer; the CPU-reference shape (H 64, ~1100 edges: 0.05 GF) keeps the gathered-concat GEMM;
+    # Electron-DOS (H 256, 17880 edges; the 32-crystal shard has about half of them): factored first Linear and aggregate-first
+    # last layer
+    assert Fn._factor_edge(9000, 128) and not Fn._factor_last(9000, 128)
+    assert not Fn._factor_edge(1100, 64) and not Fn._factor_last(1100, 64)
     assert Fn._factor_edge(17880, 256) and Fn._factor_last(17880, 256)
     assert Fn._factor_edge(8900, 256) and Fn._factor_last(8900, 256)
     assert not Fn._factor_last(17880, 384)                    # 2 * hidden > 512: the unfused wide-row path keeps the per-edge form
