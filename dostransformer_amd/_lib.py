@@ -172,6 +172,38 @@ class EdgeMlp(C.Structure):
     ]
 
 
+class EdgeMlpBwd(C.Structure):
+    _fields_ = [
+        ("E", C.c_int32), ("H", C.c_int32),
+        ("dagg", C.c_void_p), ("lddagg", C.c_int32),
+        ("de_next", C.c_void_p), ("ldden", C.c_int32),
+        ("dst", C.c_void_p),
+        ("xhat", C.c_void_p), ("rstd", C.c_void_p),
+        ("w3", C.c_void_p),
+        ("w1", C.c_void_p), ("ldw1", C.c_int32),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p), ("alpha", C.c_void_p),
+        ("dmsg", C.c_void_p), ("dz", C.c_void_p),
+        ("de", C.c_void_p), ("ldde", C.c_int32),
+        ("partials", C.c_void_p), ("partial_ld", C.c_int32),
+        ("seg_tile", C.c_void_p), ("seg_ntiles", C.c_int32),
+        ("seg_rowptr", C.c_void_p), ("seg_scale", C.c_void_p), ("seg_agg", C.c_void_p), ("seg_part", C.c_void_p), ("seg_cnt", C.c_void_p),
+    ]
+
+
+class NodeGrad(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32), ("H", C.c_int32),
+        ("dz", C.c_void_p),
+        ("rowptr_src", C.c_void_p), ("perm_src", C.c_void_p),
+        ("aggd", C.c_void_p),
+        ("w", C.c_void_p), ("ldw", C.c_int32),
+        ("res", C.c_void_p), ("ldres", C.c_int32),
+        ("res2", C.c_void_p), ("ldres2", C.c_int32),
+        ("aggs", C.c_void_p),
+        ("dx", C.c_void_p), ("lddx", C.c_int32),
+    ]
+
+
 class CopyJob(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("dwords", C.c_int64)]
 
@@ -261,6 +293,8 @@ _SIGS = {
     "dosx_mlp_ln_bwd": [C.POINTER(MlpLnBwd), _P],
     "dosx_edge_mlp_supported": [_I],
     "dosx_edge_mlp_fwd": [C.POINTER(EdgeMlp), _P],
+    "dosx_edge_mlp_bwd": [C.POINTER(EdgeMlpBwd), _P],
+    "dosx_node_grad": [C.POINTER(NodeGrad), _P],
     "dosx_csr_workspace_bytes": [_I, C.POINTER(C.c_size_t)],
     "dosx_csr_build": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P],
     "dosx_collate": [_P] * 5 + [_I] * 3 + [_P] * 18 + [_P],

@@ -325,8 +325,12 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
         aggS = sink.scratch(N_, 2 * H)
         aggD = aggD_epi if aggD_epi is not None else sink.scratch(N_, 2 * H)
 
-        def node_sums(dz=dz, aggS=aggS, aggD=aggD, m=m, with_dst=aggD_epi is None):
-            ops.segment_reduce_perm(dz, m.rowptr_src, m.perm_src, aggS, N_, E_, 2 * H)
+        # (the source sums: by the caller's dosx_node_grad launch when that form runs, gnn_bwd)
+        node_one = fac_dgrad and _NODE_GRAD_ONE_LAUNCH and _factor_fused(m, H) and H in (64, 128, 256)
+
+        def node_sums(dz=dz, aggS=aggS, aggD=aggD, m=m, with_dst=aggD_epi is None, with_src=not node_one):
+            if with_src:
+                ops.segment_reduce_perm(dz, m.rowptr_src, m.perm_src, aggS, N_, E_, 2 * H)
             if with_dst:                               # (else: written by the dgrad GEMM's epilogue above)
                 ops.segment_reduce(dz, m.rowptr_dst, None, aggD, None, None, N_, E_, 2 * H)
         if fac_dgrad:
@@ -349,10 +353,52 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
         W0 = P[key + ".0.weight"]
         de_new = _empty(dev, M, H)
         ops.gemm(M, H, [seg(dz)], W0[:, 2 * H:], de_new, w_layout=1, res=res)
-        return ("factored", de_new, aggS, aggD)
+        return ("factored", de_new, aggS, aggD, dz if node_one else None)
     if not fused:
         ops.gemm(M, a.K, [seg(dz)], P[key + ".0.weight"], dcat, w_layout=1, res=res, res_col0=res_col0 if res is not None else 0)
     return dcat
+
+
+def edge_bwd_one_launch_ok(a: SegList, M: int, H: int) -> bool:
+    """Whether the EdgeModel's backward runs as ONE launch (csrc/edge_mlp.hip, edge_bwd_kernel): factored first Linear, the
+    batch's node-aligned row tiles, hidden 64 / 128, per-edge second Linear."""
+    return (a.factor is not None and a.aggsum is None and _factor_edge(M, H) and _FACTOR_DGRAD and _factor_fused(a.factor[2], H)
+            and _EDGE_ONE_LAUNCH_BWD and a.factor[2].seg_tile is not None and ops.edge_mlp_supported(H))
+
+
+def edge_mlp_bwd_one_launch(P: Params, G: Params, key: str, ctx, dagg: torch.Tensor, de_next: Optional[torch.Tensor], scale,
+                            sink: GradSink):
+    """dagg [N, H] (a strided view): gradient of the aggregate; de_next: gradient of e_{l+1} or None.  Returns what
+    mlp_ln_bwd's factored branch returns: ("factored", dL/de_l [E,H], aggS, aggD)."""
+    a, xhat, rstd, M, H = ctx
+    x, e, m = a.factor
+    dev = xhat.device
+    N_, E_ = m.num_nodes, m.num_edges
+    gam, bet, alpha = P[key + ".1.weight"], P[key + ".1.bias"], P[key + ".2.weight"]
+    W0 = P[key + ".0.weight"]
+    rows = int(m.seg_tile.shape[1]) - 1
+    pld = 4 * H + 4
+    part = sink.scratch(rows, pld)
+    dmsg, dz, de_new = _empty(dev, M, H), _empty(dev, M, 2 * H), _empty(dev, M, H)
+    aggS, aggD = sink.scratch(N_, 2 * H), sink.scratch(N_, 2 * H)
+    ops.edge_mlp_bwd(M, H, dagg, de_next, m.dst, xhat, rstd, P[key + ".3.weight"], W0[:, 2 * H:], gam, bet, alpha, dmsg, dz, de_new,
+                     part, m.seg_tile, m.rowptr_dst, scale, aggD)
+    _wgrad_linear(sink, G, key + ".3.weight", key + ".3.bias", M, H, seg(dmsg), [seg(xhat)], keep=(dmsg,), pro=PRO_LN_PRELU,
+                  pro_gamma=gam, pro_beta=bet, pro_alpha=alpha)
+    sink.add(part, 0, G[key + ".1.weight"], rows, pld, 2 * H)
+    sink.add(part, 2 * H, G[key + ".1.bias"], rows, pld, 2 * H)
+    sink.add(part, pld - 1, G[key + ".2.weight"], rows, pld, 1)
+    node_one = _NODE_GRAD_ONE_LAUNCH          # the source sums are then made by the caller's dosx_node_grad launch (gnn_bwd)
+    if not node_one:
+        ops.segment_reduce_perm(dz, m.rowptr_src, m.perm_src, aggS, N_, E_, 2 * H)
+    sink._keep.extend(t for t in (dz, dagg, de_next) if t is not None)
+    if key + ".0.weight" in G:
+        Gw = G[key + ".0.weight"]
+        with ops.graph_rows():
+            _wgrad_linear(sink, G, key + ".0.weight", None, N_, 2 * H, seg(aggS), [seg(x)], keep=(aggS, x), dst=Gw[:, :H])
+            _wgrad_linear(sink, G, key + ".0.weight", None, N_, 2 * H, seg(aggD), [seg(x)], keep=(aggD, x), dst=Gw[:, H:2 * H])
+            _wgrad_linear(sink, G, key + ".0.weight", key + ".0.bias", M, 2 * H, seg(dz), [seg(e)], keep=(dz, e), dst=Gw[:, 2 * H:])
+    return ("factored", de_new, aggS, aggD, dz if node_one else None)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -402,24 +448,36 @@ def gnn_bwd(P: Params, G: Params, m: GraphMeta, ctxs, dx: torch.Tensor, sink: Gr
         fold_dx = (cxe[0].factor is not None and _factor_edge(E, H) and _FACTOR_DGRAD and _factor_fused(m, H)
                    and mlp_ln_bwd_fused(cxn[0], N, H, dx))
         dcat_n = mlp_ln_bwd(P, G, pre + ".node_model.node_mlp_2", cxn, dx, sink, add_dy=fold_dx)          # [N, 2H]
-        if cxe[0].aggsum is not None:
-            assert de is None                        # (the last layer: no edge-state gradient arrives)
-            dmsg = dcat_n[:, H:]                     # dL/d agg [N,H]: mlp_ln_bwd expands it per edge inside its row kernel
+        if edge_bwd_one_launch_ok(cxe[0], E, H):
+            # gather + add of the message gradient, both input-gradient products with the PReLU / LayerNorm backward between
+            # them, the destination-node sums: one launch on the node-aligned row tiles (csrc/edge_mlp.hip)
+            dcat_e = edge_mlp_bwd_one_launch(P, G, pre + ".edge_model.edge_mlp", cxe, dcat_n[:, H:], de, scale, sink)
         else:
-            dmsg = _empty(dev, E, H)
-            ops.edge_grad_combine(de, dcat_n.data_ptr() + 4 * H, 2 * H, m.dst, scale, dmsg, E, H)
-        # e_{l+1} = e_l + msg_l (DOSTransformer_phonon.py:84): dL/de_l = dL/de_{l+1} + (edge-MLP input gradient)[:, 2H:3H].
-        # The dgrad GEMM adds dL/de_{l+1} to exactly those columns, so the e-block of dcat_e IS dL/de_l and no kernel
-        # ever streams the edge gradient on its own.
-        dcat_e = mlp_ln_bwd(P, G, pre + ".edge_model.edge_mlp", cxe, dmsg, sink, res=de, res_col0=2 * H)   # [E, 3H]
-        if l == 0 and sink.wside is not None:
+            if cxe[0].aggsum is not None:
+                assert de is None                        # (the last layer: no edge-state gradient arrives)
+                dmsg = dcat_n[:, H:]                     # dL/d agg [N,H]: mlp_ln_bwd expands it per edge inside its row kernel
+            else:
+                dmsg = _empty(dev, E, H)
+                ops.edge_grad_combine(de, dcat_n.data_ptr() + 4 * H, 2 * H, m.dst, scale, dmsg, E, H)
+            # e_{l+1} = e_l + msg_l (DOSTransformer_phonon.py:84): dL/de_l = dL/de_{l+1} + (edge-MLP input gradient)[:, 2H:3H].
+            # The dgrad GEMM adds dL/de_{l+1} to exactly those columns, so the e-block of dcat_e IS dL/de_l and no kernel
+            # ever streams the edge gradient on its own.
+            dcat_e = mlp_ln_bwd(P, G, pre + ".edge_model.edge_mlp", cxe, dmsg, sink, res=de, res_col0=2 * H)   # [E, 3H]
+        node_one = isinstance(dcat_e, tuple) and len(dcat_e) > 4 and dcat_e[4] is not None
+        if l == 0 and sink.wside is not None and not node_one:
             sink.flush_on_side()     # layer 0's weight gradients start now, under the gather backward and the encoders' backward
         dx_old = _empty(dev, N, H)
         if isinstance(dcat_e, tuple):
             # factored input gradient (large edge sets): dx_l = dx_{l+1} + S Wa + D Wb + (node-MLP input gradient)[:, :H]
-            _, de_new, aggS, aggD = dcat_e
+            _, de_new, aggS, aggD = dcat_e[:4]
             W0 = P[pre + ".edge_model.edge_mlp.0.weight"]
-            if _factor_fused(m, H):
+            if node_one:
+                # source sums of dz + both node products + the residual terms: ONE launch (csrc/edge_mlp.hip, node_grad_kernel)
+                ops.node_grad(N, H, dcat_e[4], m.rowptr_src, m.perm_src, aggD, W0, dcat_n[:, :H], None if fold_dx else dx, aggS, dx_old)
+                sink._keep.extend([dcat_n, dx])
+                if l == 0 and sink.wside is not None:
+                    sink.flush_on_side()     # (layer 0's jobs read the source sums that launch has just queued)
+            elif _factor_fused(m, H):
                 # ONE N-row product on the two node sums, each against its own column block of W0 (DosxGemm.w_seg_off)
                 if fold_dx:
                     ops.gemm(N, H, [seg(aggS), seg(aggD)], W0[:, :H], dx_old, w_layout=1, w_seg_off=H, res=dcat_n[:, :H])
@@ -619,6 +677,8 @@ _FUSED_FFN_BWD = __import__("os").environ.get("DOSX_FUSED_FFN_BWD", "1") == "1"
 _FACTOR_EDGE_WGRAD = __import__("os").environ.get("DOSX_FACTOR_EDGE_WGRAD", "1") == "1"   # EdgeModel first Linear factored into node / edge parts
 _FACTOR_FUSED = __import__("os").environ.get("DOSX_FACTOR_FUSED", "1") == "1"               # ... with the gathers / node sums inside dosx_gemm's epilogues (round 5)
 _EDGE_ONE_LAUNCH = __import__("os").environ.get("DOSX_EDGE_ONE_LAUNCH", "1") == "1"       # ... and the whole EdgeModel forward as one launch (H <= 128)
+_EDGE_ONE_LAUNCH_BWD = __import__("os").environ.get("DOSX_EDGE_ONE_LAUNCH_BWD", "1") == "1"   # ... and its backward
+_NODE_GRAD_ONE_LAUNCH = __import__("os").environ.get("DOSX_NODE_GRAD_ONE_LAUNCH", "1") == "1"   # ... and the node side of the input gradient
 _FACTOR_MIN_GF = float(__import__("os").environ.get("DOSX_FACTOR_MIN_GF", "0.5" if _FACTOR_FUSED else "4"))
 _FACTOR_DGRAD = __import__("os").environ.get("DOSX_FACTOR_DGRAD", "1") == "1"             # ... and its input gradient
 _FACTOR_HEADS = __import__("os").environ.get("DOSX_FACTOR_HEADS", "1") == "1"             # heads: per-crystal K-segments multiplied once per crystal

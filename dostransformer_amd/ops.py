@@ -549,6 +549,53 @@ def edge_mlp_fwd(E: int, H: int, e: torch.Tensor, pq: torch.Tensor, src, dst, w1
           w=lambda: (f"edge_mlp_fwd[H{d.H}]", f"edge_fwd_kernel<{2 * d.H}>", "mfma", 2.0 * _real(d.E) * (2 * d.H) * (2 * d.H)))
 
 
+def edge_mlp_bwd(E: int, H: int, dagg: torch.Tensor, de_next: Optional[torch.Tensor], dst, xhat, rstd, w3, w1c, gamma, beta, alpha,
+                 dmsg: torch.Tensor, dz: torch.Tensor, de: torch.Tensor, partials: torch.Tensor, seg_tile, seg_rowptr, seg_scale,
+                 seg_agg: torch.Tensor) -> None:
+    """Backward of :func:`edge_mlp_fwd` in one launch (include/dosx.h: DosxEdgeMlpBwd): dagg [nodes, H] (any row stride) and
+    de_next [E, H] (None: last layer) -> dmsg, dz, de = dz Wc + de_next, the destination-node sums of dz, the LayerNorm / PReLU
+    parameter-gradient partial rows (one per tile)."""
+    d = _lib.EdgeMlpBwd()
+    d.E, d.H = int(E), int(H)
+    d.dagg, d.lddagg = dagg.data_ptr(), int(dagg.stride(0))
+    if de_next is not None:
+        d.de_next, d.ldden = de_next.data_ptr(), int(de_next.stride(0))
+    d.dst = dst.data_ptr()
+    d.xhat, d.rstd = xhat.data_ptr(), rstd.data_ptr()
+    assert w1c.stride(1) == 1 and w3.is_contiguous() and dmsg.is_contiguous() and dz.is_contiguous()
+    d.w3, d.w1, d.ldw1 = w3.data_ptr(), w1c.data_ptr(), int(w1c.stride(0))
+    d.gamma, d.beta, d.alpha = gamma.data_ptr(), beta.data_ptr(), alpha.data_ptr()
+    d.dmsg, d.dz = dmsg.data_ptr(), dz.data_ptr()
+    d.de, d.ldde = de.data_ptr(), int(de.stride(0))
+    d.partials, d.partial_ld = partials.data_ptr(), int(partials.stride(0))
+    assert seg_tile.dim() == 2 and seg_tile.shape[0] == 3 and seg_tile.is_contiguous()
+    d.seg_tile, d.seg_ntiles = seg_tile.data_ptr(), int(seg_tile.shape[1]) - 1
+    assert partials.shape[0] >= d.seg_ntiles
+    d.seg_rowptr, d.seg_scale, d.seg_agg = seg_rowptr.data_ptr(), _p(seg_scale), seg_agg.data_ptr()
+    part = alloc(dz.device, d.seg_ntiles, 2 * H)
+    d.seg_part, d.seg_cnt = part.data_ptr(), COUNTERS.take(dz.device, d.seg_ntiles)
+    _call("dosx_edge_mlp_bwd", C.byref(d), _stream(),
+          w=lambda: (f"edge_mlp_bwd[H{d.H}]", f"edge_bwd_kernel<{2 * d.H}>", "mfma", 2.0 * _real(d.E) * (2 * d.H) * (2 * d.H)))
+
+
+def node_grad(N: int, H: int, dz: torch.Tensor, rowptr_src, perm_src, aggd: torch.Tensor, w: torch.Tensor, res, res2,
+              aggs: torch.Tensor, dx: torch.Tensor) -> None:
+    """aggs = source-node sums of dz; dx = res + res2 + aggs W[:, :H] + aggd W[:, H:2H] - one launch (include/dosx.h: DosxNodeGrad)."""
+    d = _lib.NodeGrad()
+    d.N, d.H = int(N), int(H)
+    assert dz.is_contiguous() and aggd.is_contiguous() and aggs.is_contiguous() and w.stride(1) == 1
+    d.dz, d.rowptr_src, d.perm_src, d.aggd = dz.data_ptr(), rowptr_src.data_ptr(), perm_src.data_ptr(), aggd.data_ptr()
+    d.w, d.ldw = w.data_ptr(), int(w.stride(0))
+    if res is not None:
+        d.res, d.ldres = res.data_ptr(), int(res.stride(0))
+    if res2 is not None:
+        d.res2, d.ldres2 = res2.data_ptr(), int(res2.stride(0))
+    d.aggs = aggs.data_ptr()
+    d.dx, d.lddx = dx.data_ptr(), int(dx.stride(0))
+    _call("dosx_node_grad", C.byref(d), _stream(),
+          w=lambda: (f"node_grad[H{d.H}]", f"node_grad_kernel<{d.H}>", "mfma", 2.0 * _real(d.N) * d.H * 4 * d.H))
+
+
 def gemm_partial_rows(M: int, N: int, epi: int) -> int:
     return _lib.load().dosx_gemm_partial_rows(int(M), int(N), int(epi))
 

@@ -616,6 +616,47 @@ typedef struct DosxEdgeMlp {
   const int32_t* seg_tile; int32_t seg_ntiles;
   const int32_t* seg_rowptr; const float* seg_scale; float* seg_agg; float* seg_part; int32_t* seg_cnt;
 } DosxEdgeMlp;
+/* Backward of the same block in one launch (what dosx_edge_grad_combine + dosx_gemm EPI_PRELU_LN_BWD_SEG + the E-row input-
+ * gradient GEMM compute):
+ *     dmsg[r] = de_next[r] + seg_scale[dst[r]] * dagg[dst[r]]     (written: W3's weight gradient reads it; de_next NULL: the last layer)
+ *     dz = LayerNorm_bwd(PReLU_bwd(dmsg . W3))  [E,2H] written ;  seg_agg[n] = sum_{r in seg(n)} dz[r]  [nodes, 2H]  (unscaled)
+ *     de[r] = dz[r] . Wc + de_next[r]                              (gradient of the layer's edge state)
+ *     partials[tile] = [ dgamma (2H) | dbeta (2H) | pad | dalpha ]  - seg_ntiles rows, the layout of DOSX_EPI_PRELU_LN_BWD. */
+typedef struct DosxEdgeMlpBwd {
+  int32_t E, H;
+  const float* dagg; int32_t lddagg;
+  const float* de_next; int32_t ldden;
+  const int32_t* dst;
+  const float* xhat; const float* rstd;
+  const float* w3;
+  const float* w1; int32_t ldw1;
+  const float* gamma; const float* beta; const float* alpha;
+  float* dmsg;
+  float* dz;
+  float* de; int32_t ldde;
+  float* partials; int32_t partial_ld;
+  const int32_t* seg_tile; int32_t seg_ntiles;
+  const int32_t* seg_rowptr; const float* seg_scale; float* seg_agg; float* seg_part; int32_t* seg_cnt;
+} DosxEdgeMlpBwd;
+int dosx_edge_mlp_bwd(const DosxEdgeMlpBwd* a, dosx_stream_t stream);
+/* The NODE side of the factored EdgeModel input gradient in one launch (what dosx_segment_reduce_perm + a two-segment dosx_gemm
+ * with w_seg_off compute; hidden 64 / 128 / 256):
+ *     aggs[n] = sum_{e: src(e) = n} dz[e]   (rows perm_src[rowptr_src[n] .. rowptr_src[n+1]) of dz [E,2H]; written: the weight
+ *                                            gradient of the source block reads it)
+ *     dx[n]   = res[n] + res2[n] + aggs[n] . w[:, :H] + aggd[n] . w[:, H:2H]        w: the first Linear's weight [2H, 3H], row stride ldw
+ * (DOSTransformer_phonon.py:166,190-197 differentiated w.r.t. x[row] / x[col]; res / res2 optional [N,H] addends). */
+typedef struct DosxNodeGrad {
+  int32_t N, H;
+  const float* dz;
+  const int32_t* rowptr_src; const int32_t* perm_src;
+  const float* aggd;
+  const float* w; int32_t ldw;
+  const float* res; int32_t ldres;
+  const float* res2; int32_t ldres2;
+  float* aggs;
+  float* dx; int32_t lddx;
+} DosxNodeGrad;
+int dosx_node_grad(const DosxNodeGrad* a, dosx_stream_t stream);
 int dosx_edge_mlp_supported(int H);
 int dosx_edge_mlp_fwd(const DosxEdgeMlp* a, dosx_stream_t stream);
 

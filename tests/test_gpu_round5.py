@@ -208,10 +208,13 @@ def test_fused_factored_edge_layer_equals_the_plain_one(kind, H):
     m0 = mk()
     sd0 = {k: v.detach().clone() for k, v in m0.state_dict().items()}
     grads, params, outs = {}, {}, {}
-    saved = (Fn._FACTOR_EDGE_WGRAD, Fn._FACTOR_MIN_GF, Fn._FACTOR_FUSED)
+    saved = (Fn._FACTOR_EDGE_WGRAD, Fn._FACTOR_MIN_GF, Fn._FACTOR_FUSED, Fn._EDGE_ONE_LAUNCH, Fn._EDGE_ONE_LAUNCH_BWD)
     try:
-        for form in ("plain", "rowkernels", "fused"):
-            Fn._FACTOR_EDGE_WGRAD, Fn._FACTOR_MIN_GF, Fn._FACTOR_FUSED = form != "plain", 0.0, form == "fused"
+        # plain: gathered-concat GEMM; rowkernels: round 4's factored form; epilogues: gathers / node sums inside dosx_gemm;
+        # fused: the shipped default - hidden <= 128: EdgeModel forward and backward one launch each (csrc/edge_mlp.hip)
+        for form in ("plain", "rowkernels", "epilogues", "fused"):
+            Fn._FACTOR_EDGE_WGRAD, Fn._FACTOR_MIN_GF, Fn._FACTOR_FUSED = form != "plain", 0.0, form in ("epilogues", "fused")
+            Fn._EDGE_ONE_LAUNCH = Fn._EDGE_ONE_LAUNCH_BWD = form == "fused"
             for replay in (False, True):
                 model = mk()
                 model.load_state_dict(sd0)
@@ -226,9 +229,9 @@ def test_fused_factored_edge_layer_equals_the_plain_one(kind, H):
                 torch.cuda.synchronize()
                 params[(form, replay)] = {k: v.detach().clone() for k, v in model.state_dict().items()}
     finally:
-        Fn._FACTOR_EDGE_WGRAD, Fn._FACTOR_MIN_GF, Fn._FACTOR_FUSED = saved
+        Fn._FACTOR_EDGE_WGRAD, Fn._FACTOR_MIN_GF, Fn._FACTOR_FUSED, Fn._EDGE_ONE_LAUNCH, Fn._EDGE_ONE_LAUNCH_BWD = saved
     n_real, n_pad = g.meta.num_nodes, gp.meta.num_nodes
-    for other in ("plain", "rowkernels"):
+    for other in ("plain", "rowkernels", "epilogues"):
         for u, v in zip(outs[("fused", False)], outs[(other, False)]):
             if u.shape[0] == n_pad:
                 u, v = u[:n_real], v[:n_real]
@@ -265,7 +268,7 @@ def test_edge_model_forward_in_one_launch(n, H, fat, mean, last):
          "k.1.weight": torch.randn(2 * H, generator=gen), "k.1.bias": torch.randn(2 * H, generator=gen),
          "k.2.weight": torch.tensor([0.25]), "k.3.weight": torch.randn(H, 2 * H, generator=gen) * (2 * H) ** -0.5,
          "k.3.bias": torch.randn(H, generator=gen)}
-    P = {k: v.to(DEV) for k, v in P.items()}
+    P = Fn.pack_params({k: v.to(DEV) for k, v in P.items()})        # (one buffer window for the two weight matrices)
     x, e = torch.randn(n, H, generator=gen).to(DEV), torch.randn(E, H, generator=gen).to(DEV)
     scale = torch.from_numpy((1.0 / np.maximum(deg, 1)).astype(np.float32)).to(DEV) if mean else None
 
@@ -309,3 +312,79 @@ def test_edge_model_forward_in_one_launch(n, H, fat, mean, last):
     assert err(xh1, xh) < 2e-5 and err(agg1, ref) < 2e-5
     if not last:
         assert err(e1, e.double() + msg) < 2e-5
+
+
+@pytest.mark.parametrize("n,H,fat,mean,last", [(300, 128, (), True, False), (60, 128, (60, 96, 200), False, False),
+                                               (45, 64, (49, 48), True, True), (5, 64, (), False, True), (700, 128, (97,), True, False)])
+def test_edge_model_backward_in_one_launch(n, H, fat, mean, last):
+    """dosx_edge_mlp_bwd (round 5, csrc/edge_mlp.hip) against the three launches it replaces - dosx_edge_grad_combine, dosx_gemm
+    with EPI_PRELU_LN_BWD_SEG, the E-row input-gradient GEMM dz Wc + de_next: message gradient, dz, the destination-node sums,
+    de, the summed parameter-gradient partial rows; over-full / isolated nodes; last layer (no incoming edge-state gradient);
+    twice (counters back at zero, same bits)."""
+    o = ops()
+    src, dst, rp, deg, tiles, E = _graph(n, 13 * n + H, fat)
+    W2 = 2 * H
+    dcat_n, de_next = rnd(n, W2, seed=1), (None if last else rnd(E, H, seed=2))
+    dagg = dcat_n[:, H:]
+    xhat, rstd = rnd(E, W2, seed=3), rnd(E, seed=4).abs() + 0.5
+    gam, bet, alpha = rnd(W2, seed=5), rnd(W2, seed=6), torch.tensor([0.25], device=DEV)
+    # (the kernel addresses both weight matrices through one 2 GiB buffer window: one allocation, as in the models' flat buffer)
+    wflat = torch.empty(H * W2 + W2 * 3 * H, device=DEV)
+    W3, W1 = wflat[:H * W2].view(H, W2), wflat[H * W2:].view(W2, 3 * H)
+    W3.copy_(rnd(H, W2, seed=7, scale=H ** -0.5))
+    W1.copy_(rnd(W2, 3 * H, seed=8, scale=W2 ** -0.5))
+    scale = torch.from_numpy((1.0 / np.maximum(deg, 1)).astype(np.float32)).to(DEV) if mean else None
+    pld = 2 * W2 + 4
+    T = tiles.shape[1] - 1
+    # the three-launch form
+    dmsg0 = torch.empty(E, H, device=DEV)
+    o.edge_grad_combine(de_next, dcat_n.data_ptr() + 4 * H, W2, dst, scale, dmsg0, E, H)
+    dz0, part0, agg0 = torch.empty(E, W2, device=DEV), torch.empty(T, pld, device=DEV), torch.empty(n, W2, device=DEV)
+    o.gemm(E, W2, [o.seg(dmsg0)], W3, dz0, w_layout=1, epi=o.EPI_PRELU_LN_BWD_SEG, aux=xhat, aux_stats=rstd, epi_gamma=gam, epi_beta=bet,
+           epi_alpha=alpha, partials=part0, partial_ld=pld, seg_tile=tiles, seg_rowptr=rp, seg_agg=agg0)
+    de0 = torch.empty(E, H, device=DEV)
+    o.gemm(E, H, [o.seg(dz0)], W1[:, W2:], de0, w_layout=1, res=de_next)
+    prev = None
+    for rep in range(2):
+        dmsg1, dz1, de1 = (torch.full((E, w), float("nan"), device=DEV) for w in (H, W2, H))
+        part1, agg1 = torch.full((T, pld), float("nan"), device=DEV), torch.full((n, W2), float("nan"), device=DEV)
+        o.edge_mlp_bwd(E, H, dagg, de_next, dst, xhat, rstd, W3, W1[:, W2:], gam, bet, alpha, dmsg1, dz1, de1, part1, tiles, rp, scale, agg1)
+        torch.cuda.synchronize()
+        assert err(dmsg1, dmsg0) < 1e-6
+        assert err(dz1, dz0) < 2e-5 and err(de1, de0) < 2e-5
+        assert bool(torch.isfinite(agg1).all())
+        assert float((agg1 - agg0).abs().max()) <= 2e-5 * float(agg0.abs().max() + 1e-6)
+        p0, p1 = part0.double().sum(0), part1.double().sum(0)
+        assert err(p1[:2 * W2], p0[:2 * W2]) < 2e-5 and abs(float(p1[-1] - p0[-1])) < 2e-5 * (abs(float(p0[-1])) + 1.0)
+        if prev is not None:
+            assert all(torch.equal(u, v) for u, v in zip(prev, (dmsg1, dz1, de1, agg1)))
+        prev = (dmsg1, dz1, de1, agg1)
+
+
+@pytest.mark.parametrize("n,H,two", [(450, 128, False), (1554, 256, True), (37, 64, True), (16, 128, False), (3, 64, False)])
+def test_node_side_of_the_factored_input_gradient_in_one_launch(n, H, two):
+    """dosx_node_grad (round 5): aggS = source-node sums of dz (CSR by source, isolated nodes included) and
+    dx = res (+ res2) + aggS Wa + aggD Wb in one launch, against dosx_segment_reduce_perm + float64 products."""
+    o = ops()
+    rng = np.random.default_rng(n + H)
+    deg = rng.integers(0, 30, size=n)
+    deg[rng.random(n) < 0.15] = 0
+    E = max(int(deg.sum()), 1)
+    if deg.sum() == 0:
+        deg[0] = 1
+    rowptr = torch.from_numpy(np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)).to(DEV)
+    perm = torch.from_numpy(rng.permutation(E).astype(np.int32)).to(DEV)
+    W2 = 2 * H
+    dz, aggd, W = rnd(E, W2, seed=1), rnd(n, W2, seed=2), rnd(W2, 3 * H, seed=3, scale=W2 ** -0.5)
+    dcat = rnd(n, W2, seed=4)
+    res2 = rnd(n, H, seed=5) if two else None
+    aggs0 = torch.empty(n, W2, device=DEV)
+    o.segment_reduce_perm(dz, rowptr, perm, aggs0, n, E, W2)
+    aggs1, dx1 = torch.full((n, W2), float("nan"), device=DEV), torch.full((n, H), float("nan"), device=DEV)
+    o.node_grad(n, H, dz, rowptr, perm, aggd, W, dcat[:, :H], res2, aggs1, dx1)
+    torch.cuda.synchronize()
+    assert float((aggs1 - aggs0).abs().max()) <= 2e-6 * float(aggs0.abs().max() + 1e-6)
+    ref = dcat[:, :H].double() + aggs0.double() @ W[:, :H].double() + aggd.double() @ W[:, H:W2].double()
+    if two:
+        ref = ref + res2.double()
+    assert err(dx1, ref) < 2e-5
