@@ -29,6 +29,10 @@ CONFIGS = {
     "phonon_h64_b8": ("phonon", 3, 1, 64, 8),          # configs[0] (the reference's CPU-runnable case)
     "edos_h256_b64": ("edos", 3, 2, 256, 64),          # configs[2]
     "edos_h256_t4_b32": ("edos", 3, 4, 256, 32),       # configs[4] per-GPU shape
+    # the headline model at larger per-GPU batches (`secondary.batch_sweep`: where the step leaves the launch-latency regime)
+    "phonon_h128_b128": ("phonon", 3, 2, 128, 128),
+    "phonon_h128_b256": ("phonon", 3, 2, 128, 256),
+    "phonon_h128_b512": ("phonon", 3, 2, 128, 512),
 }
 N_DISTINCT_BATCHES = 8
 # epoch mode (--shuffle): granularity of the (nodes, edges) shape buckets.  Finer buckets = fewer ghost rows per step but
@@ -142,14 +146,18 @@ def algorithmic_flops(kind, L, T, H, N, E, B, n_max):
     return f
 
 
-def load_traffic():
-    """HBM bytes per kernel launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.py).  The file records the
-    hash of the sources it was measured on; a file measured on different sources is REFUSED (traffic stays null)."""
+def load_traffic(config="phonon_h128_b64"):
+    """HBM bytes per kernel launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.py) over THIS configuration's
+    replayed step: profiles/r*_pmc_traffic.json for the headline, r*_pmc_traffic_edos.json for edos_h256_b64.  The file records
+    the hash of the sources it was measured on; a file measured on different sources is REFUSED (traffic stays null)."""
     import glob
     from dostransformer_amd._lib import source_hash
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    suffix = {"phonon_h128_b64": "", "edos_h256_b64": "_edos"}.get(config)
+    if suffix is None:
+        return {}, "traffic is profiled for phonon_h128_b64 and edos_h256_b64 only"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic{suffix}.json")))
     if not files:
-        return {}, "no profiles/r*_pmc_traffic.json"
+        return {}, f"no profiles/r*_pmc_traffic{suffix}.json"
     try:
         rec = json.load(open(files[-1]))
     except Exception as e:  # pragma: no cover
@@ -587,6 +595,15 @@ def main():
             sh = run_workload("phonon_h128_b64", shuffle=True, steps=args.steps, warmup=max(args.warmup, 60),
                               bucket=SHUFFLE_BUCKET, instrument=False, **common)
             secondary["shuffle"] = dict(brief(sh, args.steps), hit_rate=sh["slots"]["hit_rate"], promoted=sh["slots"]["promoted"], live_buckets=sh["slots"]["live"])
+            # the headline model at 128 / 256 / 512 crystals on this ONE GPU: where the step leaves the launch-latency regime
+            # (what per-GPU batch a multi-GPU run should use); the headline itself stays on 64
+            sweep = {"64": {"value": round(n_global * args.steps / elapsed, 1), "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+                            "step_frac": round(r["flops_step"] / (elapsed / args.steps) / (MFMA_F32_PEAK_TFLOPS * 1e12), 4)}}
+            for bsz in (128, 256, 512):
+                w = run_workload(f"phonon_h128_b{bsz}", shuffle=False, steps=30, warmup=6, bucket=(8, 128), instrument=False, **common)
+                b_ = brief(w, 30)
+                sweep[str(bsz)] = {k: b_[k] for k in ("value", "ms_per_step", "step_frac")}
+            secondary["batch_sweep"] = sweep
         except Exception as ex:  # a secondary line must never take the headline down with it
             secondary["error"] = f"{type(ex).__name__}: {ex}"[:200]
         # the same headline workload through the DATA-PARALLEL step on a 1-rank RCCL group: the replay plan split around
@@ -615,8 +632,8 @@ def main():
     if rank == 0:
         roof = r["roof"]
         n_inst = r["n_inst"]
-        kernels, traffic_src = load_traffic() if (args.config == "phonon_h128_b64" and world == 1 and not args.shuffle) \
-            else ({}, "traffic is profiled for the default configuration only")
+        kernels, traffic_src = load_traffic(args.config) if (world == 1 and not args.shuffle) \
+            else ({}, "traffic is profiled for the single-GPU fixed-batch runs only")
         for rec in roof["all"] + ([roof["dominant"]] if roof["dominant"] else []):
             rec["traffic"] = traffic_of(kernels, rec["kernel"])
             rec["us_per_step"] = round(1e3 * rec["total_ms"] / max(n_inst, 1), 2)

@@ -8,7 +8,7 @@ counters are in KiB.)  bench.py looks a roofline site's kernel symbol up in this
 `source_hash` is not the hash of the sources it is running (dostransformer_amd._lib.source_hash), so a stale file can
 never be reported as `roofline.traffic`.
 
-usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [git_head]"""
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [git_head] [bench config]"""
 import csv
 import json
 import os
@@ -47,10 +47,12 @@ def main():
     from dostransformer_amd._lib import source_hash
     fetch, nf = per_kernel(sys.argv[1], "FETCH_SIZE")
     write, nw = per_kernel(sys.argv[2], "WRITE_SIZE")
-    out = {"_note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps 20 "
-                    "--warmup 10 --no-cpu-baseline` (phonon_h128_b64, the replayed step itself), averaged per launch of each kernel "
+    config = sys.argv[5] if len(sys.argv) > 5 else "phonon_h128_b64"
+    out = {"_note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --config " + config +
+                    " --no-cpu-baseline --no-secondary` (the replayed step itself), averaged per launch of each kernel "
                     "symbol; hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction, "
                     "MI355X_MICROARCH.md HBM section).",
+           "config": config,
            "source_hash": source_hash(),
            "git_head": sys.argv[4] if len(sys.argv) > 4 else "unknown",
            "kernels": {}}

@@ -4,7 +4,7 @@
 # then copy gpurun_out/prof_<round>/summary/* into profiles/.  rocprofv3 passes are separate (kernel trace | one PMC
 # counter each), the program comes directly after `--`, outputs are CSV.
 set -u
-R=${1:-r04}
+R=${1:-r05}
 HEAD=${2:-unknown}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$R
@@ -25,6 +25,17 @@ if [ -n "$ff" ] && [ -n "$fw" ]; then
   cp "$S/${R}_pmc_traffic.json" "$ROOT/profiles/${R}_pmc_traffic.json"       # bench.py below reads it from profiles/
   python3 "$ROOT/tools/pmc_summary.py" "$ff" FETCH_SIZE "$S/${R}_pmc_fetch_size_summary.csv"
   python3 "$ROOT/tools/pmc_summary.py" "$fw" WRITE_SIZE "$S/${R}_pmc_write_size_summary.csv"
+fi
+# the same two passes over the Electron-DOS configuration: its sites carry `traffic` too
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 900 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_edos_$c" -o pmc -- \
+    python3 "$ROOT/bench.py" --config edos_h256_b64 --steps 10 --warmup 5 --no-cpu-baseline --no-secondary --kernels-out "$OUT/pmc_edos_$c.kernels.json" > "$OUT/pmc_edos_$c.log" 2>&1 < /dev/null
+done
+ef=$(find "$OUT/pmc_edos_FETCH_SIZE" -name "*counter_collection.csv" | head -1)
+ew=$(find "$OUT/pmc_edos_WRITE_SIZE" -name "*counter_collection.csv" | head -1)
+if [ -n "$ef" ] && [ -n "$ew" ]; then
+  python3 "$ROOT/tools/pmc_traffic.py" "$ef" "$ew" "$S/${R}_pmc_traffic_edos.json" "$HEAD" edos_h256_b64 > "$OUT/pmc_traffic_edos.log" 2>&1
+  cp "$S/${R}_pmc_traffic_edos.json" "$ROOT/profiles/${R}_pmc_traffic_edos.json"
 fi
 # MFMA utilisation of the attention kernels from the counters (north_star: "MFMA utilisation for attention against CDNA4 peak"):
 # the attention microbenchmark (BASELINE shapes + roofline scale) under ONE pmc pass
