@@ -131,13 +131,20 @@ def _wide_ln(H: int) -> bool:
     return 2 * H > 512
 
 
-def _factor_edge(E: int, H: int) -> bool:
+def _factor_edge(E: int, H: int, m=None) -> bool:
     """Whether the EdgeModel's first Linear (forward product, weight gradient, input gradient) is factored into node parts +
-    edge part: from DOSX_FACTOR_MIN_GF GF of the un-factored product.  Round 4 (gather / add / normalise as a row kernel of
-    its own, three extra launches per layer and direction): 4 GF - Electron-DOS only; round 5 (the gathered addends inside the
-    E-row GEMM's LayerNorm epilogue, the destination sums inside the dgrad GEMM's epilogue): 0.5 GF, so the Phonon-DOS
-    benchmark shape (1.8 GF) factors too."""
-    return _FACTOR_EDGE_WGRAD and 2.0 * E * (2 * H) * (3 * H) >= _FACTOR_MIN_GF * 1e9
+    edge part.  Round 4 (gather / add / normalise as a row kernel of its own, three extra launches per layer and direction):
+    from 4 GF of the un-factored product - Electron-DOS only.  Round 5: (a) where the one-launch kernels of csrc/edge_mlp.hip take
+    the layer (hidden 64 / 128, a batch `m` with node-aligned row tiles) ALWAYS - the factored layer is then fewer launches
+    (backward: 3 instead of 5) as well as fewer flops, also at the CPU-reference shape (Phonon-DOS H 64, 8 crystals: 0.573 ->
+    0.557 ms per step, tools/exp/r5_ab_small.sh); (b) otherwise (gathered addends / destination sums inside dosx_gemm's
+    epilogues) from DOSX_FACTOR_MIN_GF = 0.5 GF."""
+    if not _FACTOR_EDGE_WGRAD:
+        return False
+    if (m is not None and getattr(m, "seg_tile", None) is not None and _FACTOR_FUSED and _EDGE_ONE_LAUNCH and _EDGE_ONE_LAUNCH_BWD
+            and _FACTOR_DGRAD and _FACTOR_ONE_LAUNCH_ALWAYS and ops.edge_mlp_supported(H)):
+        return True
+    return 2.0 * E * (2 * H) * (3 * H) >= _FACTOR_MIN_GF * 1e9
 
 
 def _factor_fused(m, H: int) -> bool:
@@ -185,7 +192,7 @@ def mlp_ln_fwd(P: Params, key: str, a: SegList, M: int, H: int, res: Optional[to
                        P[key + ".3.bias"], res, xhat, rstd, y)
         return y, (a, xhat, rstd, M, H)
     fac = a.factor
-    if fac is not None and _factor_edge(M, H):
+    if fac is not None and _factor_edge(M, H, fac[2]):
         # Large edge sets (throughput-bound): the first Linear FACTORED - Linear(cat[x[row], x[col], e]) = (x Wa^T)[row] +
         # (x Wb^T)[col] + e Wc^T + b.  The two node products are N-row GEMMs, the E-row GEMM keeps a third of the columns, and one
         # row kernel gathers, adds and normalises: a third of the flops of the gathered-concat GEMM (Electron-DOS: 14.1 -> 5.5 GF
@@ -275,7 +282,7 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
     fused = mlp_ln_bwd_fused(a, M, H, dy) and agg_first is None and res is None
     assert fused or not add_dy
     wide = _wide_ln(H) or agg_first is not None
-    fac_dgrad = a.factor is not None and _factor_edge(M, H) and _FACTOR_DGRAD and not fused
+    fac_dgrad = a.factor is not None and _factor_edge(M, H, a.factor[2]) and _FACTOR_DGRAD and not fused
     # round 5: the destination-node sums of dz (the factored weight / input gradients below need them) inside the dgrad GEMM's
     # epilogue, on the batch's node-aligned row tiles - one partial row per tile
     seg_bwd = (fac_dgrad and agg_first is None and not wide and _factor_fused(a.factor[2], H) and a.factor[2].seg_tile is not None
@@ -313,7 +320,7 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
     sink.add(part, pld - 1, G[key + ".2.weight"], rows, pld, 1)
     fac = a.factor
     aggS = aggD = None
-    if fac is not None and _factor_edge(M, H) and (key + ".0.weight" in G or fac_dgrad):
+    if fac is not None and _factor_edge(M, H, fac[2]) and (key + ".0.weight" in G or fac_dgrad):
         # The first Linear reads cat[x[row], x[col], e] (DOSTransformer_phonon.py:193-195): its weight gradient is
         #   sum_e dz_e (x) [x[row(e)] | x[col(e)] | e_e]  =  [ sum_n S_n (x) x_n | sum_n D_n (x) x_n | sum_e dz_e (x) e_e ],
         # S_n / D_n = the sums of dz over the edges that leave / enter node n.  The two node blocks become N-row jobs (20 x
@@ -362,7 +369,7 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
 def edge_bwd_one_launch_ok(a: SegList, M: int, H: int) -> bool:
     """Whether the EdgeModel's backward runs as ONE launch (csrc/edge_mlp.hip, edge_bwd_kernel): factored first Linear, the
     batch's node-aligned row tiles, hidden 64 / 128, per-edge second Linear."""
-    return (a.factor is not None and a.aggsum is None and _factor_edge(M, H) and _FACTOR_DGRAD and _factor_fused(a.factor[2], H)
+    return (a.factor is not None and a.aggsum is None and _factor_edge(M, H, a.factor[2]) and _FACTOR_DGRAD and _factor_fused(a.factor[2], H)
             and _EDGE_ONE_LAUNCH_BWD and a.factor[2].seg_tile is not None and ops.edge_mlp_supported(H))
 
 
@@ -392,13 +399,20 @@ def edge_mlp_bwd_one_launch(P: Params, G: Params, key: str, ctx, dagg: torch.Ten
     if not node_one:
         ops.segment_reduce_perm(dz, m.rowptr_src, m.perm_src, aggS, N_, E_, 2 * H)
     sink._keep.extend(t for t in (dz, dagg, de_next) if t is not None)
+    src_job = None
     if key + ".0.weight" in G:
         Gw = G[key + ".0.weight"]
+
+        def src_job(Gw=Gw, aggS=aggS, x=x):           # the source block's job reads aggS: described once that exists (see gnn_bwd)
+            with ops.graph_rows():
+                _wgrad_linear(sink, G, key + ".0.weight", None, N_, 2 * H, seg(aggS), [seg(x)], keep=(aggS, x), dst=Gw[:, :H])
+        if not (node_one and _GNN_FLUSH_BEFORE_NODE):
+            src_job()
+            src_job = None
         with ops.graph_rows():
-            _wgrad_linear(sink, G, key + ".0.weight", None, N_, 2 * H, seg(aggS), [seg(x)], keep=(aggS, x), dst=Gw[:, :H])
             _wgrad_linear(sink, G, key + ".0.weight", None, N_, 2 * H, seg(aggD), [seg(x)], keep=(aggD, x), dst=Gw[:, H:2 * H])
             _wgrad_linear(sink, G, key + ".0.weight", key + ".0.bias", M, 2 * H, seg(dz), [seg(e)], keep=(dz, e), dst=Gw[:, 2 * H:])
-    return ("factored", de_new, aggS, aggD, dz if node_one else None)
+    return ("factored", de_new, aggS, aggD, dz if node_one else None, src_job)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -445,7 +459,7 @@ def gnn_bwd(P: Params, G: Params, m: GraphMeta, ctxs, dx: torch.Tensor, sink: Gr
         pre = f"stacked_processor.{l}"
         cxe, cxn = ctxs[l]
         # factored edge layer + one-launch NodeModel backward: the residual path's dx rides on the first H columns of dcat_n
-        fold_dx = (cxe[0].factor is not None and _factor_edge(E, H) and _FACTOR_DGRAD and _factor_fused(m, H)
+        fold_dx = (cxe[0].factor is not None and _factor_edge(E, H, m) and _FACTOR_DGRAD and _factor_fused(m, H)
                    and mlp_ln_bwd_fused(cxn[0], N, H, dx))
         dcat_n = mlp_ln_bwd(P, G, pre + ".node_model.node_mlp_2", cxn, dx, sink, add_dy=fold_dx)          # [N, 2H]
         if edge_bwd_one_launch_ok(cxe[0], E, H):
@@ -472,9 +486,17 @@ def gnn_bwd(P: Params, G: Params, m: GraphMeta, ctxs, dx: torch.Tensor, sink: Gr
             _, de_new, aggS, aggD = dcat_e[:4]
             W0 = P[pre + ".edge_model.edge_mlp.0.weight"]
             if node_one:
+                src_job = dcat_e[5] if len(dcat_e) > 5 else None
+                early = src_job is not None            # the layer's group starts BEFORE the node-side launch, under it
+                if early and sink.wside is not None and (l == 0 or (_SPLIT_LATE_FLUSH == 1 and l == 1) or (_SPLIT_LATE_FLUSH == 2 and l >= 1)):
+                    sink.flush_on_side()
                 # source sums of dz + both node products + the residual terms: ONE launch (csrc/edge_mlp.hip, node_grad_kernel)
                 ops.node_grad(N, H, dcat_e[4], m.rowptr_src, m.perm_src, aggD, W0, dcat_n[:, :H], None if fold_dx else dx, aggS, dx_old)
                 sink._keep.extend([dcat_n, dx])
+                if early:
+                    src_job()                          # (reads the source sums that launch has just queued: next group)
+                    dx, de = dx_old, de_new
+                    continue
                 if l == 0 and sink.wside is not None:
                     sink.flush_on_side()     # (layer 0's jobs read the source sums that launch has just queued)
             elif _factor_fused(m, H):
@@ -679,6 +701,12 @@ _FACTOR_FUSED = __import__("os").environ.get("DOSX_FACTOR_FUSED", "1") == "1"   
 _EDGE_ONE_LAUNCH = __import__("os").environ.get("DOSX_EDGE_ONE_LAUNCH", "1") == "1"       # ... and the whole EdgeModel forward as one launch (H <= 128)
 _EDGE_ONE_LAUNCH_BWD = __import__("os").environ.get("DOSX_EDGE_ONE_LAUNCH_BWD", "1") == "1"   # ... and its backward
 _NODE_GRAD_ONE_LAUNCH = __import__("os").environ.get("DOSX_NODE_GRAD_ONE_LAUNCH", "1") == "1"   # ... and the node side of the input gradient
+_FACTOR_ONE_LAUNCH_ALWAYS = __import__("os").environ.get("DOSX_FACTOR_ONE_LAUNCH_ALWAYS", "1") == "1"   # ... at every size where they apply
+# a layer's weight-gradient group is flushed BEFORE its node-side launch (dosx_node_grad: 57 workgroups) and runs under it and the
+# next NodeModel backward (27 workgroups) - the two windows of the GNN backward that leave most CUs idle - instead of behind them,
+# under the next EdgeModel backward (213 workgroups of a CU each); only the source block's job, which reads the source sums that
+# launch makes, moves to the next group: 1.187 -> 1.173 ms per cfg2 step (three interleaved pairs, tools/exp/r5_ab_flush.sh)
+_GNN_FLUSH_BEFORE_NODE = __import__("os").environ.get("DOSX_GNN_FLUSH_BEFORE_NODE", "1") == "1"
 _FACTOR_MIN_GF = float(__import__("os").environ.get("DOSX_FACTOR_MIN_GF", "0.5" if _FACTOR_FUSED else "4"))
 _FACTOR_DGRAD = __import__("os").environ.get("DOSX_FACTOR_DGRAD", "1") == "1"             # ... and its input gradient
 _FACTOR_HEADS = __import__("os").environ.get("DOSX_FACTOR_HEADS", "1") == "1"             # heads: per-crystal K-segments multiplied once per crystal
