@@ -270,7 +270,7 @@ def test_size_policies_of_the_factored_forms():
     class _M:                                                  # a batch with node-aligned row tiles: the one-launch kernels of
         seg_tile = object()                                    # csrc/edge_mlp.hip take hidden 64 / 128 at EVERY size
     assert Fn._factor_edge(1100, 64, _M()) and Fn._factor_edge(140, 128, _M())
-    assert not Fn._factor_edge(1100, 256, _M())                # hidden 256: the epilogue forms, by size
+    assert not Fn._factor_edge(300, 256, _M()) and Fn._factor_edge(1100, 256, _M())    # hidden 256: the epilogue forms, by size (0.5 GF)
     assert Fn._factor_edge(17880, 256) and Fn._factor_last(17880, 256)
     assert Fn._factor_edge(8900, 256) and Fn._factor_last(8900, 256)
     assert not Fn._factor_last(17880, 384)                    # 2 * hidden > 512: the unfused wide-row path keeps the per-edge form
