@@ -36,6 +36,8 @@ def job(M, Nn, K, segs=None, **kw):
         segs = [ops.seg(a)]
         keep.append(a)
     ns = ops.wgrad_splits(M, Nn, K)
+    if M > 4096 and os.environ.get("WG_NS_E"):          # experiment: split count of the edge-row jobs
+        ns = int(os.environ["WG_NS_E"])
     nsc = ops.wgrad_scratch_floats(Nn, K, ns)
     slab = torch.empty(max(nsc, 1), device=DEV)
     sb = torch.empty(ns * ((Nn + 63) // 64) * 64, device=DEV)
@@ -56,6 +58,16 @@ def gnn_layer():
     return [job(E, 2 * H, 3 * H, segs=segs), job(E, H, 2 * H, **lnp(2 * H)), job(N, 2 * H, 2 * H), job(N, H, 2 * H, **lnp(2 * H))]
 
 
+def gnn_layer_factored():
+    """the jobs of a message-passing layer with the first EdgeModel Linear factored (round 5: the shipped form): second Linear on
+    the message gradient, the three column blocks of dW1 - source / destination node sums (N rows), dz on the edge rows -, the
+    two NodeModel jobs"""
+    lnp = lambda K: dict(pro=ops.PRO_LN_PRELU, pro_gamma=torch.randn(K, device=DEV), pro_beta=torch.randn(K, device=DEV),
+                         pro_alpha=torch.tensor([0.25], device=DEV))
+    return [job(E, H, 2 * H, **lnp(2 * H)), job(E, 2 * H, H), job(N, 2 * H, H), job(N, 2 * H, H), job(N, 2 * H, 2 * H),
+            job(N, H, 2 * H, **lnp(2 * H))]
+
+
 def enc_layer(R):
     rl = dict(pro=ops.PRO_ROWLN, pro_gamma=torch.randn(H, device=DEV), pro_beta=torch.randn(H, device=DEV),
               pro_stats=torch.rand(R, 2, device=DEV))
@@ -67,14 +79,16 @@ def run(name, descs):
     fl = sum(2.0 * d.M * d.N * d.K for d in descs)
     us = timeit(lambda: ops.grad_flush(descs, ()))
     wgs = sum(ops.wgrad_tiles(d.N, d.K) * d.nsplit for d in descs)
-    print(f"wgroup {name:30s} jobs={len(descs):2d} workgroups={wgs:5d} {fl / 1e9:6.2f} GF: {us:7.1f} us  {fl / us / 1e6:6.1f} TF/s "
+    print(f"wgroup {name:34s} jobs={len(descs):2d} workgroups={wgs:5d} {fl / 1e9:6.2f} GF: {us:7.1f} us  {fl / us / 1e6:6.1f} TF/s "
           f"({100 * fl / us / 1e6 / 157.3:4.1f}% of fp32 MFMA peak)")
 
 
 if __name__ == "__main__":
     print("DOSX_WGRAD_OCC =", os.environ.get("DOSX_WGRAD_OCC", "(default)"), " DOSX_WGRAD_MAXSPLIT =", os.environ.get("DOSX_WGRAD_MAXSPLIT", "(default)"))
-    run("GNN layer pair", gnn_layer() + gnn_layer())
-    run("one GNN layer", gnn_layer())
+    run("GNN layer pair (factored)", gnn_layer_factored() + gnn_layer_factored())
+    run("one GNN layer (factored)", gnn_layer_factored())
+    run("GNN layer pair (gathered concat)", gnn_layer() + gnn_layer())
+    run("one GNN layer (gathered concat)", gnn_layer())
     run("encoder stack T=2, 2B rows", enc_layer(R2) + enc_layer(R2))
     run("encoder stack T=2, B rows", enc_layer(R2 // 2) + enc_layer(R2 // 2))
     run("edge W1 alone", gnn_layer()[:1])
