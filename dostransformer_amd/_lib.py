@@ -124,7 +124,7 @@ class Ffn(C.Structure):
         ("att_kvhat", C.c_void_p), ("att_gamma0", C.c_void_p), ("att_beta0", C.c_void_p), ("att_mask", C.c_void_p),
         ("att_probs", C.c_void_p), ("att_qstats", C.c_void_p), ("att_x1", C.c_void_p), ("att_st1", C.c_void_p),
         ("att_Nk", C.c_int32), ("att_Bk", C.c_int32), ("att_Bq", C.c_int32), ("att_Sq", C.c_int32),
-        ("att_qs", C.c_int32), ("att_qb", C.c_int32), ("att_ldx1", C.c_int32),
+        ("att_qs", C.c_int32), ("att_qb", C.c_int32), ("att_ldx1", C.c_int32), ("att_aligned", C.c_int32),
     ]
 
 
@@ -284,6 +284,7 @@ _SIGS = {
     "dosx_adamw": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P],
     "dosx_ffn_supported": [_I],
     "dosx_ffn_att_supported": [_I, _I],
+    "dosx_ffn_att_aligned_supported": [_I, _I],
     "dosx_ffn_fwd": [C.POINTER(Ffn), _P],
     "dosx_ffn_bwd_partial_rows": [_I],
     "dosx_ffn_bwd": [C.POINTER(FfnBwd), _P],

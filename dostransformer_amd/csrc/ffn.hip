@@ -158,6 +158,213 @@ __device__ __forceinline__ void ffn_att_row(const DosxFfn& a, float* __restrict_
   }
 }
 
+// The attention half of a CRYSTAL-ALIGNED tile (ATT = 2) on the MFMA (round 5): the R query rows of the tile share one key set
+// (Ks [NkP][H + 4] in LDS, rows >= Nk zeroed), so scores and P.K are two small products on v_mfma_f32_16x16x4_f32 instead of one
+// key per iteration on the vector ALU (round 4's form: 0.4 us per key and pass, the 51-key self attention 47 us per layer):
+//   A: one quarter wave per row - LayerNorm-0, the key gamma folded into q (see ffn_att_row) -> Qs [R][H + 4]
+//   B: S = Qs . Ks^T (scaled) -> Sc [R][68]          (job = 16 rows x 16 keys, K = H: H / 4 MFMAs; jobs dealt over the 8 waves)
+//   C: one quarter wave per row - exact fp32 softmax over the Nk scores, P written out, P o mask -> Sc (zeros beyond Nk)
+//   D: O = Sc . Ks -> Qs                             (job = 16 rows x 16 columns, K = NkP: NkP / 4 MFMAs)
+//   E: one quarter wave per row - x1 = O o g0 + b0 sum(P) + x, both statistics, LN1(x1) -> Xs
+// All 8 waves run it (R = 32: four rows per wave, one pass; the staging waves have their first weight chunks in flight); four
+// workgroup barriers inside, the caller adds the one that frees the key / score region.
+template <int R>
+__device__ __forceinline__ void ffn_att_tile(const DosxFfn& a, float* __restrict__ Xs, const int LDX, float* __restrict__ Ks,
+                                             float* __restrict__ Sc, float* __restrict__ Qs, const int al_s0, const int al_bq,
+                                             const int tid) {
+  const int H = a.H, LDK = a.H + 4;
+  const int lane = tid & 63, wave = tid >> 6, q16 = lane & 15, l15 = lane & 15, g4 = lane >> 4;
+  const int Nk = a.att_Nk, NkP = (Nk + 15) & ~15, Sq = a.att_Sq;
+  const float scale = rsqrtf((float)H), invH = 1.f / (float)H;
+  // this quarter wave's row (R = 16: waves 0-3 only)
+  const int lr = wave * 4 + g4;
+  const bool rowok = lr < R;
+  const int s = min(al_s0 + (rowok ? lr : 0), Sq - 1);
+  const bool rv = rowok && (al_s0 + lr) < Sq;
+  const int r = s * a.att_Bq + al_bq;                  // global row (valid memory also for the clamped duplicates)
+  float4 g0[2], b0[2], xr[2], g1[2], bb1[2];         // (g1 / bb1: LayerNorm-1's affine for phase E, requested with everything else)
+  bool on[2];
+  float mean = 0.f, rstd = 0.f;
+  {
+    const float* xrow = a.x + ((size_t)s * a.att_qs + (size_t)al_bq * a.att_qb) * a.ldx;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int c = q16 * 4 + 64 * k, cc = c < H ? c : 0;
+      on[k] = c < H;
+      g0[k] = ld4(a.att_gamma0 + cc); b0[k] = ld4(a.att_beta0 + cc);
+      g1[k] = ld4(a.gamma + cc); bb1[k] = ld4(a.beta + cc);
+      xr[k] = on[k] ? ld4(xrow + c) : f4zero();
+    }
+    {   // the crystal's key rows -> Ks (all 8 waves; rows beyond Nk zero): requested right behind the row operands above
+      const int bk = al_bq % a.att_Bk, h4 = H >> 2;
+      float4 kr[4];                                  // NkP * h4 <= 64 * 32 = 4 float4 per thread
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = tid + 512 * i, j = e / h4, c = (e - j * h4) * 4;
+        kr[i] = (e < NkP * h4 && j < Nk) ? ld4(a.att_kvhat + ((size_t)j * a.att_Bk + bk) * H + c) : f4zero();
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = tid + 512 * i, j = e / h4, c = (e - j * h4) * 4;
+        if (e < NkP * h4) st4(Ks + j * LDK + c, kr[i]);
+      }
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) t += (xr[k].x + xr[k].y) + (xr[k].z + xr[k].w);
+    mean = row16_sum(t) * invH;
+    t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (!on[k]) continue;
+      const float p0 = xr[k].x - mean, p1 = xr[k].y - mean, p2 = xr[k].z - mean, p3 = xr[k].w - mean;
+      t += (p0 * p0 + p1 * p1) + (p2 * p2 + p3 * p3);
+    }
+    rstd = rsqrtf(row16_sum(t) * invH + DOSX_LN_EPS);
+    if (rowok) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (!on[k]) continue;
+        const float4 v = xr[k];
+        float4 q = make_float4((v.x - mean) * rstd * g0[k].x + b0[k].x, (v.y - mean) * rstd * g0[k].y + b0[k].y,
+                               (v.z - mean) * rstd * g0[k].z + b0[k].z, (v.w - mean) * rstd * g0[k].w + b0[k].w);
+        st4(Qs + lr * LDK + q16 * 4 + 64 * k, make_float4(q.x * g0[k].x, q.y * g0[k].y, q.z * g0[k].z, q.w * g0[k].w));   // key gamma folded into Q
+      }
+    }
+  }
+  FSTAMP(10);
+  __syncthreads();
+  FSTAMP(11);
+  // ---- B: scores ----
+  // (fewer than 8 jobs - <= 16 keys: 2 - would leave six waves idle behind a chain of H / 4 dependent MFMAs: the K range is
+  //  split KS ways, every wave leaves a partial tile in Sp [KS][R][68] and phase C adds them in a fixed order)
+  const int nctS = NkP >> 4, njobsS = (R / 16) * nctS;
+  int KS = njobsS >= 8 ? 1 : (njobsS >= 4 ? 2 : 4);
+  while (KS > 1 && ((H % (16 * KS)) != 0 || LDK + (KS - 1) * 68 > 4 * H + 4)) KS >>= 1;   // (whole 16-wide MFMA steps; the partial tiles fit the T region)
+  const int klen = H / KS;
+  {
+    for (int unit = wave; unit < njobsS * KS; unit += 8) {
+      const int job = unit / KS, kq = unit - job * KS;
+      const int rt = job / nctS, ct = job - rt * nctS;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int kk = kq * klen; kk < (kq + 1) * klen; kk += 16) {
+        const float4 av = ld4(Qs + (16 * rt + l15) * LDK + kk + 4 * g4);
+        const float4 bv = ld4(Ks + (16 * ct + l15) * LDK + kk + 4 * g4);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
+      }
+      float* Sp = kq == 0 ? Sc : Qs + R * LDK + (kq - 1) * R * 68;      // (partials 1 .. KS - 1 behind the Q tile, in the T region)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Sp[(16 * rt + 4 * g4 + i) * 68 + 16 * ct + l15] = acc[i] * scale;
+    }
+  }
+  FSTAMP(12);
+  __syncthreads();
+  // ---- C: softmax of this quarter wave's row ----
+  float psum = 1.f;
+  if (rowok) {
+    float* Sr = Sc + lr * 68;
+    float v[4], mx = -INFINITY;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = q16 + 16 * jj;
+      v[jj] = -INFINITY;
+      if (j < Nk) {
+        v[jj] = Sr[j];
+        for (int kq = 1; kq < KS; ++kq) v[jj] += Qs[R * LDK + (kq - 1) * R * 68 + lr * 68 + j];
+      }
+      mx = fmaxf(mx, v[jj]);
+    }
+    mx = row16_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const float e = (q16 + 16 * jj) < Nk ? expf(v[jj] - mx) : 0.f;
+      v[jj] = e;
+      sum += e;
+    }
+    const float inv = 1.f / row16_sum(sum);
+    const size_t prow = ((size_t)al_bq * Sq + s) * Nk;
+    float ps = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = q16 + 16 * jj;
+      if (j >= NkP) continue;
+      float pm = 0.f;
+      if (j < Nk) {
+        const float pr = v[jj] * inv;
+        pm = a.att_mask ? pr * a.att_mask[prow + j] : pr;
+        if (rv) a.att_probs[prow + j] = pr;            // the un-dropped P (the backward reads it)
+      }
+      Sr[j] = pm;                                      // (zeros beyond Nk: the padded keys of the second product)
+      ps += pm;
+    }
+    psum = a.att_mask ? row16_sum(ps) : 1.f;
+  }
+  FSTAMP(13);
+  __syncthreads();
+  // ---- D: O = P . K ----
+  {
+    const int nct = H >> 4, njobs = (R / 16) * nct;
+    for (int job = wave; job < njobs; job += 8) {
+      const int rt = job / nct, ct = job - rt * nct;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int kk = 0; kk < NkP; kk += 16) {
+        const float4 av = ld4(Sc + (16 * rt + l15) * 68 + kk + 4 * g4);
+        const float* bp = Ks + (kk + 4 * g4) * LDK + 16 * ct + l15;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bp[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bp[LDK], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bp[2 * LDK], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bp[3 * LDK], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Qs[(16 * rt + 4 * g4 + i) * LDK + 16 * ct + l15] = acc[i];
+    }
+  }
+  FSTAMP(14);
+  __syncthreads();
+  FSTAMP(15);
+  // ---- E: residual, statistics, LN1 -> Xs ----
+  if (rowok) {
+    float4 x1[2];
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int c = q16 * 4 + 64 * k;
+      x1[k] = f4zero();
+      if (!on[k]) continue;
+      const float4 o = ld4(Qs + lr * LDK + c);
+      x1[k] = make_float4(o.x * g0[k].x + b0[k].x * psum + xr[k].x, o.y * g0[k].y + b0[k].y * psum + xr[k].y,
+                          o.z * g0[k].z + b0[k].z * psum + xr[k].z, o.w * g0[k].w + b0[k].w * psum + xr[k].w);
+      if (rv) st4(a.att_x1 + (size_t)r * a.att_ldx1 + c, x1[k]);
+      t += (x1[k].x + x1[k].y) + (x1[k].z + x1[k].w);
+    }
+    const float mean1 = row16_sum(t) * invH;
+    t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (!on[k]) continue;
+      const float p0 = x1[k].x - mean1, p1 = x1[k].y - mean1, p2 = x1[k].z - mean1, p3 = x1[k].w - mean1;
+      t += (p0 * p0 + p1 * p1) + (p2 * p2 + p3 * p3);
+    }
+    const float rstd1 = rsqrtf(row16_sum(t) * invH + DOSX_LN_EPS);
+    if (rv && q16 == 0) {
+      a.att_qstats[2 * (size_t)r] = mean; a.att_qstats[2 * (size_t)r + 1] = rstd;
+      a.att_st1[2 * (size_t)r] = mean1;   a.att_st1[2 * (size_t)r + 1] = rstd1;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (!on[k]) continue;
+      const float4 vv = x1[k];
+      st4(Xs + lr * LDX + q16 * 4 + 64 * k,
+          make_float4((vv.x - mean1) * rstd1 * g1[k].x + bb1[k].x, (vv.y - mean1) * rstd1 * g1[k].y + bb1[k].y,
+                      (vv.z - mean1) * rstd1 * g1[k].z + bb1[k].z, (vv.w - mean1) * rstd1 * g1[k].w + bb1[k].w));
+    }
+  }
+}
+
 // ATT (round 4): the attention half of the layer runs in the prologue, for key sets of <= 16 rows per crystal (DosxFfn.att_*):
 // per query row - one QUARTER WAVE per row, like the row phases of attention.hip - LayerNorm-0, the <= 16 scores against
 // the crystal's pre-normalised key rows (read straight from L2: 16 x 512 B per row, the key set of a crystal is shared by
@@ -168,7 +375,13 @@ __device__ __forceinline__ void ffn_att_row(const DosxFfn& a, float* __restrict_
 // P.(khat g + b) = (P.khat) o g + b sum(P).
 // HALF: the workgroup owns 16 rows and multiplies with the 16x16x4 MFMA (two 16-column tiles per wave instead of one
 // 32-column tile): twice the workgroups, half the MFMA time each, and two of them fit the LDS of one CU.
-template <bool HALF, int KB, bool ATT>
+// ATT = 2 (round 4: tile layout, one key per iteration on the vector ALU - slower than two launches; round 5: the two products
+// on the MFMA, ffn_att_tile): CRYSTAL-ALIGNED tiles - a workgroup owns R consecutive query rows s of ONE query batch entry bq
+// (row r = s * Bq + bq, grid = Bq x ceil(Sq / R)), so the tile's rows share one key set: the crystal's <= 64 pre-normalised key
+// rows are copied to LDS once (into the stage-buffer region, which the weight chunks take over after the prologue) - the 51-key
+// self attention and the 32-row launches, where the per-row global key fetch of ATT = 1 does not pay, take this form while the
+// grid stays one round of workgroups.
+template <bool HALF, int KB, int ATT>
 __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
   DOSX_SET_MAIN_PRIO();
   extern __shared__ __align__(16) float sm[];
@@ -185,6 +398,26 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
   const int l15 = lane & 15, g4 = lane >> 4;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int m0 = blockIdx.x * R;
+  // tile row lr -> global row (-1: beyond the data).  ATT = 2: rows s0 .. s0 + R - 1 of query batch entry al_bq
+  int al_bq = 0, al_s0 = 0;
+  if constexpr (ATT == 2) {
+    const int tpc = (a.att_Sq + R - 1) / R;
+    al_bq = (int)blockIdx.x / tpc;
+    al_s0 = ((int)blockIdx.x % tpc) * R;
+  }
+  auto grow = [&](const int lr) -> int {
+    if constexpr (ATT == 2) {
+      const int s = al_s0 + lr;
+      return s < a.att_Sq ? s * a.att_Bq + al_bq : -1;
+    } else {
+      const int r = m0 + lr;
+      return r < M ? r : -1;
+    }
+  };
+  auto growc = [&](const int lr) -> int {          // clamped to a valid row of the tile (duplicates are never stored)
+    const int r = grow(lr);
+    return r >= 0 ? r : grow(0);
+  };
   FSTAMP(0);
   const int nk1 = H / FBK, nb1 = H4 / FBN, n1 = nb1 * nk1, n2 = H4 / FBK, nch = n1 + n2;
 
@@ -193,13 +426,20 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
   const bool con = c0 < H;
   float4 xres[ER], bias2 = f4zero();
   if (con) bias2 = ld4(a.b2 + c0);
-  if constexpr (!ATT) {
+  if constexpr (ATT == 0) {
 #pragma unroll
     for (int i = 0; i < ER; ++i) {
-      const int r = min(m0 + wave * ER + i, M - 1);
+      const int r = growc(wave * ER + i);
       xres[i] = ld4(a.x + (size_t)r * a.ldx + (con ? c0 : 0));
     }
   }
+  if constexpr (ATT == 2) {
+    // the crystal's key rows -> LDS (all 8 waves), in the stage-buffer region: [Nk][H + 4], the score rows [R][68] behind them
+    // (the crystal's key rows go to LDS inside ffn_att_tile, behind the loads of its row phase A: one round trip, not two)
+  }
+  // ATT = 2: keys Ks [NkP][H + 4] and scores Sc [R][68] in the stage-buffer region, Q / O tile [R][H + 4] in the (still unused) T region
+  float* const attKs = ST;
+  float* const attSc = ST + ((a.att_Nk + 15) & ~15) * (H + 4);
 
   if (wave_u >= 4) {
     // =============================== staging waves ===============================================
@@ -236,6 +476,10 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
     };
     issue(r0, 0);
     issue(r1, 1);
+    if constexpr (ATT == 2) {
+      ffn_att_tile<R>(a, Xs, LDX, attKs, attSc, T, al_s0, al_bq, tid);
+      __syncthreads();                             // the attention prologue is done with the keys / scores in the stage buffers
+    }
     store(ST, r0);
     issue(r0, 2);
     __syncthreads();                               // (matrix waves: Xs written) chunk 0 visible
@@ -265,13 +509,16 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
       b1r[cb][0] = a.b1[col];
       b1r[cb][1] = HALF ? a.b1[col + 16] : 0.f;
     }
-    if constexpr (ATT) {
+    if constexpr (ATT == 2) {
+      ffn_att_tile<R>(a, Xs, LDX, attKs, attSc, T, al_s0, al_bq, tid);
+      __syncthreads();                             // keys / scores dead: the staging waves may store the first weight chunk
+    } else if constexpr (ATT == 1) {
       // 16 rows per pass over the 4 matrix waves.  (All 8 waves in one pass - the staging waves taking rows 16-31 while their
       // first weight chunks are in flight - was built and spills: the 16 x 2 float4 key registers next to the staged chunks.)
 #pragma unroll
       for (int p = 0; p < R / 16; ++p) ffn_att_row(a, Xs, LDX, p * 16 + wave * 4 + (lane >> 4), m0, lane);
     } else {   // LN1(x) tile -> Xs  (row r = tid/8, 4-float groups tid%8 + 8 i)
-      const int r = tid >> 3, rr = min(m0 + r, M - 1);
+      const int r = tid >> 3, rr = growc(min(r, R - 1));
       const float mean = a.stats[2 * (size_t)rr], rstd = a.stats[2 * (size_t)rr + 1];
       for (int c = (tid & 7) * 4; c < H && r < R; c += 32) {
         const float4 v = ld4(a.x + (size_t)rr * a.ldx + c), g = ld4(a.gamma + c), b = ld4(a.beta + c);
@@ -313,9 +560,10 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
           const float h0 = fmaxf(acc0[r] + b1a, 0.f), h1 = fmaxf(acc1[r] + b1b, 0.f);
           T[(4 * g4 + r) * LDT + col] = h0;
           T[(4 * g4 + r) * LDT + col + 16] = h1;
-          if (m0 + 4 * g4 + r < M) {               // h -> HBM straight from the accumulators (64-byte row segments)
-            a.h[(size_t)(m0 + 4 * g4 + r) * a.ldh + col] = h0;
-            a.h[(size_t)(m0 + 4 * g4 + r) * a.ldh + col + 16] = h1;
+          const int gr = grow(4 * g4 + r);
+          if (gr >= 0) {                           // h -> HBM straight from the accumulators (64-byte row segments)
+            a.h[(size_t)gr * a.ldh + col] = h0;
+            a.h[(size_t)gr * a.ldh + col + 16] = h1;
           }
         }
       }
@@ -375,7 +623,8 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
         const float hvv = fmaxf(acc[r] + b1, 0.f);
         T[row * LDT + col] = hvv;
-        if (m0 + row < M) a.h[(size_t)(m0 + row) * a.ldh + col] = hvv;
+        const int gr = grow(row);
+        if (gr >= 0) a.h[(size_t)gr * a.ldh + col] = hvv;
       }
     }
     FSTAMP(2);
@@ -407,10 +656,10 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
   }
   __syncthreads();
   FSTAMP(5);
-  if constexpr (ATT) {         // the residual rows are the x1 rows the prologue wrote (this workgroup's own stores: many barriers ago)
+  if constexpr (ATT != 0) {    // the residual rows are the x1 rows the prologue wrote (this workgroup's own stores: many barriers ago)
 #pragma unroll
     for (int i = 0; i < ER; ++i) {
-      const int r = min(m0 + wave * ER + i, M - 1);
+      const int r = growc(wave * ER + i);
       xres[i] = ld4(a.att_x1 + (size_t)r * a.att_ldx1 + (con ? c0 : 0));
     }
   }
@@ -426,8 +675,8 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
     const float invH = 1.f / (float)H;
 #pragma unroll
     for (int i = 0; i < ER; ++i) {
-      const int lr = wave * ER + i, r = m0 + lr;
-      const bool ok = con && r < M;                // (r < M is wave-uniform)
+      const int lr = wave * ER + i, r = grow(lr);
+      const bool ok = con && r >= 0;               // (wave-uniform)
       float4 o = f4zero();
       if (ok) {
         const float4 v = ld4(Cs + lr * (FBN + 4) + c0);
@@ -452,7 +701,7 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
       }
       if (fdot) {                                    // dos[bq][s] of row r = s * Bq + bq  (what dosx_ln_rowdot writes)
         dot = wave_sum(dot);
-        if (lane == 0 && r < M) a.fin_dos[(size_t)(r % a.fin_Bq) * a.fin_S + (r / a.fin_Bq)] = dot + fbias;
+        if (lane == 0 && r >= 0) a.fin_dos[(size_t)(r % a.fin_Bq) * a.fin_S + (r / a.fin_Bq)] = dot + fbias;
       }
     }
   }
@@ -802,6 +1051,12 @@ static int ffn_chunk(int H) {
 
 extern "C" int dosx_ffn_supported(int H) { return (H % 32) == 0 && H >= 32 && H <= 128; }
 extern "C" int dosx_ffn_att_supported(int H, int Nk) { return dosx_ffn_supported(H) && Nk >= 1 && Nk <= 16; }
+// ... with crystal-aligned tiles (DosxFfn.att_aligned): <= 64 keys whose rows fit the stage-buffer region next to 32 score rows
+extern "C" int dosx_ffn_att_aligned_supported(int H, int Nk) {
+  if (!dosx_ffn_supported(H) || Nk < 1 || Nk > 64) return 0;
+  const int kb = (H % 64 == 0) ? 64 : 32;
+  return (size_t)((Nk + 15) & ~15) * (H + 4) + 32 * 68 <= 2 * (size_t)128 * (kb + 4);
+}
 
 extern "C" int dosx_ffn_fwd(const DosxFfn* ap, dosx_stream_t stream) {
   DOSX_CHECK_ARG(ap != nullptr, "dosx_ffn_fwd: null descriptor");
@@ -811,7 +1066,7 @@ extern "C" int dosx_ffn_fwd(const DosxFfn* ap, dosx_stream_t stream) {
   const bool att = a.att_kvhat != nullptr;
   DOSX_CHECK_ARG(a.x && (a.stats || att) && a.gamma && a.beta && a.w1 && a.b1 && a.w2 && a.b2 && a.h && (a.out || a.fin_dos), "dosx_ffn_fwd: null operand");
   if (att)
-    DOSX_CHECK_ARG(dosx_ffn_att_supported(a.H, a.att_Nk) && a.att_gamma0 && a.att_beta0 && a.att_probs && a.att_qstats && a.att_x1 &&
+    DOSX_CHECK_ARG((a.att_aligned ? dosx_ffn_att_aligned_supported(a.H, a.att_Nk) : dosx_ffn_att_supported(a.H, a.att_Nk)) && a.att_gamma0 && a.att_beta0 && a.att_probs && a.att_qstats && a.att_x1 &&
                        a.att_st1 && a.att_Bk > 0 && a.att_Bq > 0 && a.att_Bq % a.att_Bk == 0 && a.att_Sq > 0 &&
                        a.att_Sq * a.att_Bq == a.M && (a.att_ldx1 & 3) == 0 && a.att_ldx1 >= a.H && a.att_qs >= 0 && a.att_qb >= 0,
                    "dosx_ffn_fwd: fused attention needs <= 16 keys, gamma0 / beta0 / probs / qstats / x1 / st1 and Sq * Bq == M");
@@ -824,23 +1079,29 @@ extern "C" int dosx_ffn_fwd(const DosxFfn* ap, dosx_stream_t stream) {
   const int H = a.H, H4 = 4 * H;
   static int half_max = -1;
   if (half_max < 0) { const char* e = getenv("DOSX_FFN_HALF_MAX"); half_max = e ? atoi(e) : 128; }
-  const bool half = ceil_div(a.M, 32) <= half_max;       // 16-row workgroups while the 32-row grid is one partial round
+  const bool aligned = att && a.att_aligned != 0;        // crystal-aligned tiles (ATT = 2): grid = Bq x ceil(Sq / R)
+  const bool half = (aligned ? a.att_Bq * ceil_div(a.att_Sq, 32) : ceil_div(a.M, 32)) <= half_max;   // 16-row workgroups while the 32-row grid is one partial round
   const int R = half ? 16 : 32;
   const int kb = ffn_chunk(H);
   const size_t smem = sizeof(float) * ((size_t)R * (H + 4) + (size_t)R * (H4 + 4) + 2 * (size_t)FBN * (kb + 4));
+  if (aligned)
+    DOSX_CHECK_ARG(a.att_Nk <= 64 && ((size_t)((a.att_Nk + 15) & ~15) * (H + 4) + (size_t)R * 68) <= 2 * (size_t)FBN * (kb + 4),
+                   "dosx_ffn_fwd: crystal-aligned attention needs <= 64 keys that fit the stage buffers (Nk=%d, H=%d)", a.att_Nk, H);
   static bool attr_set = false;
   if (!attr_set) {
 #define DOSX_FFN_ATTR(HALF_, KB_, ATT_) \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fwd_kernel<HALF_, KB_, ATT_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-    DOSX_FFN_ATTR(false, 32, false); DOSX_FFN_ATTR(true, 32, false); DOSX_FFN_ATTR(false, 64, false); DOSX_FFN_ATTR(true, 64, false);
-    DOSX_FFN_ATTR(false, 32, true); DOSX_FFN_ATTR(true, 32, true); DOSX_FFN_ATTR(false, 64, true); DOSX_FFN_ATTR(true, 64, true);
+    DOSX_FFN_ATTR(false, 32, 0); DOSX_FFN_ATTR(true, 32, 0); DOSX_FFN_ATTR(false, 64, 0); DOSX_FFN_ATTR(true, 64, 0);
+    DOSX_FFN_ATTR(false, 32, 1); DOSX_FFN_ATTR(true, 32, 1); DOSX_FFN_ATTR(false, 64, 1); DOSX_FFN_ATTR(true, 64, 1);
+    DOSX_FFN_ATTR(false, 32, 2); DOSX_FFN_ATTR(true, 32, 2); DOSX_FFN_ATTR(false, 64, 2); DOSX_FFN_ATTR(true, 64, 2);
 #undef DOSX_FFN_ATTR
     attr_set = true;
   }
-  const dim3 grid(ceil_div(a.M, R));
+  const dim3 grid(aligned ? a.att_Bq * ceil_div(a.att_Sq, R) : ceil_div(a.M, R));
 #define DOSX_FFN_GO(HALF_, KB_) \
-  do { if (att) hipLaunchKernelGGL((ffn_fwd_kernel<HALF_, KB_, true>), grid, dim3(512), smem, to_stream(stream), a); \
-       else hipLaunchKernelGGL((ffn_fwd_kernel<HALF_, KB_, false>), grid, dim3(512), smem, to_stream(stream), a); } while (0)
+  do { if (aligned) hipLaunchKernelGGL((ffn_fwd_kernel<HALF_, KB_, 2>), grid, dim3(512), smem, to_stream(stream), a); \
+       else if (att) hipLaunchKernelGGL((ffn_fwd_kernel<HALF_, KB_, 1>), grid, dim3(512), smem, to_stream(stream), a); \
+       else hipLaunchKernelGGL((ffn_fwd_kernel<HALF_, KB_, 0>), grid, dim3(512), smem, to_stream(stream), a); } while (0)
   if (half && kb == 64) DOSX_FFN_GO(true, 64);
   else if (half) DOSX_FFN_GO(true, 32);
   else if (kb == 64) DOSX_FFN_GO(false, 64);

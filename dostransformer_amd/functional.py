@@ -626,6 +626,14 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
         # buys nothing (33.2 vs 33.1 us at M = 6528), at 200 k rows it loses to the MFMA attention kernel (828 vs 738 us):
         # profiles/r04_kernel_microbench.log, `layer`
         att_fused = _FUSED_ATT_FFN and rows <= _ATT_FFN_MAX_ROWS and ops.ffn_att_supported(H, Nk)
+        # ... and with CRYSTAL-ALIGNED tiles (round 5: a workgroup = consecutive query rows of ONE crystal, its <= 64 key rows
+        # staged in LDS once, scores and P.K on the MFMA): the 51-key self attention and the 32-row launches too, while that
+        # grid - Sq padded to the tile height per crystal - is one round of workgroups
+        att_aligned = False
+        if _FUSED_ATT_FFN and _ATT_ALIGNED and fdrop is None and ops.ffn_supported(H) and ops.ffn_att_aligned_supported(H, Nk):
+            r_al = 16 if Bq * ((Sq + 31) // 32) <= 128 else 32
+            if Bq * ((Sq + r_al - 1) // r_al) <= _ATT_ALIGNED_MAX_WGS and not (att_fused and _ATT_ROWS_FIRST):
+                att_fused = att_aligned = True
         if not att_fused:
             ops.attention_fwd(a)
         h = _empty(dev, rows, 4 * H)
@@ -645,7 +653,7 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
             att_args = None
             if att_fused:
                 att_args = dict(kvhat=kvhat, gamma0=g0, beta0=b0, Nk=Nk, Bk=Bk, Bq=Bq, Sq=Sq, qs=qs, qb=qb, probs=probs,
-                                qstats=qstats, x1=x1, st1=st1, mask=mask)
+                                qstats=qstats, x1=x1, st1=st1, mask=mask, aligned=att_aligned)
             ops.ffn_fwd(rows, H, x if att_fused else x1, None if att_fused else st1, P[lp + ".layer_norms.1.weight"],
                         P[lp + ".layer_norms.1.bias"], P[lp + ".fc1.weight"], P[lp + ".fc1.bias"], P[lp + ".fc2.weight"],
                         P[lp + ".fc2.bias"], h, x2, fin=fin_args, att=att_args)
@@ -715,6 +723,9 @@ _FACTOR_LAST = __import__("os").environ.get("DOSX_FACTOR_LAST", "1") == "1"     
 _FACTOR_LAST_MIN_GF = float(__import__("os").environ.get("DOSX_FACTOR_LAST_MIN_GF", "1.3"))
 _FUSED_ATT_FFN = __import__("os").environ.get("DOSX_FUSED_ATT_FFN", "1") == "1"       # <= 16-key attention inside dosx_ffn_fwd
 _ATT_FFN_MAX_ROWS = int(__import__("os").environ.get("DOSX_ATT_FFN_MAX_ROWS", "4096"))
+_ATT_ALIGNED = __import__("os").environ.get("DOSX_ATT_ALIGNED", "1") == "1"           # crystal-aligned tiles (DosxFfn.att_aligned)
+_ATT_ALIGNED_MAX_WGS = int(__import__("os").environ.get("DOSX_ATT_ALIGNED_MAX_WGS", "256"))
+_ATT_ROWS_FIRST = __import__("os").environ.get("DOSX_ATT_ROWS_FIRST", "1") == "1"     # <= 16 keys and <= 4096 rows: the per-row form
 _FUSED_DKV = __import__("os").environ.get("DOSX_FUSED_DKV", "1") == "1"
 _LATE_SELF_FLUSH = __import__("os").environ.get("DOSX_LATE_SELF_FLUSH", "0") == "1"      # (measured: no gain)          # one-launch attention backward (Nk <= 64)
 _FUSED_FIN_BWD = __import__("os").environ.get("DOSX_FUSED_FIN_BWD", "1") == "1"

@@ -403,6 +403,10 @@ def ffn_att_supported(H: int, Nk: int) -> bool:
     return bool(_lib.load().dosx_ffn_att_supported(int(H), int(Nk)))
 
 
+def ffn_att_aligned_supported(H: int, Nk: int) -> bool:
+    return bool(_lib.load().dosx_ffn_att_aligned_supported(int(H), int(Nk)))
+
+
 def ffn_fwd(M: int, H: int, x: torch.Tensor, stats: Optional[torch.Tensor], gamma, beta, w1, b1, w2, b2, h: torch.Tensor,
             out: torch.Tensor, fin=None, att=None) -> None:
     """out = x + fc2(relu(fc1(LN1(x)))), h = relu(fc1(LN1(x))) in one launch (include/dosx.h: DosxFfn).
@@ -427,6 +431,7 @@ def ffn_fwd(M: int, H: int, x: torch.Tensor, stats: Optional[torch.Tensor], gamm
         a.att_x1, a.att_ldx1, a.att_st1 = att["x1"].data_ptr(), int(att["x1"].stride(0)), att["st1"].data_ptr()
         a.att_Nk, a.att_Bk, a.att_Bq, a.att_Sq = int(att["Nk"]), int(att["Bk"]), int(att["Bq"]), int(att["Sq"])
         a.att_qs, a.att_qb = int(att["qs"]), int(att["qb"])
+        a.att_aligned = int(bool(att.get("aligned", False)))
         nk_att = a.att_Nk
     if fin is not None:
         a.fin_gamma, a.fin_beta, a.fin_xhat, a.fin_rstd = (t.data_ptr() for t in fin[:4])

@@ -511,9 +511,15 @@ typedef struct DosxFfn {
   const float* att_kvhat; const float* att_gamma0; const float* att_beta0; const float* att_mask;
   float* att_probs; float* att_qstats; float* att_x1; float* att_st1;
   int32_t att_Nk, att_Bk, att_Bq, att_Sq, att_qs, att_qb, att_ldx1;
+  /* att_aligned != 0: CRYSTAL-ALIGNED tiles - a workgroup owns consecutive query rows s of ONE query batch entry (grid =
+   * att_Bq x ceil(att_Sq / rows per workgroup)), the crystal's key rows are staged in LDS once per workgroup: up to 64 keys
+   * (dosx_ffn_att_aligned_supported), e.g. the 51-key self attention over the energy bins; same outputs.  The caller chooses
+   * it while that grid is about one round of workgroups: Sq is padded to the tile height per crystal. */
+  int32_t att_aligned;
 } DosxFfn;
 int dosx_ffn_supported(int H);
 int dosx_ffn_att_supported(int H, int Nk);   /* whether dosx_ffn_fwd takes the att_* fields for this shape (H, Nk <= 16) */
+int dosx_ffn_att_aligned_supported(int H, int Nk);   /* ... with att_aligned (Nk <= 64 and the key rows fit the stage buffers) */
 int dosx_ffn_fwd(const DosxFfn* a, dosx_stream_t stream);
 
 /* Backward of the same half layer in one launch (what autograd derives from layers/transformer.py:141-148):

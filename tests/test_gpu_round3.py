@@ -343,7 +343,17 @@ def test_models_with_overfull_nodes_match_the_oracle(kind):
         outs.append({k: v.detach().cpu().clone() for k, v in m2.state_dict().items()})
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), ("eager vs replay", k)
-        assert torch.equal(outs[1][k], outs[2][k]), ("host table vs crystal-aligned table", k)
+        # host-greedy vs crystal-aligned tile table: every aggregate is the same sum in the same order (over-full nodes are cut
+        # identically), so rounds 3-4 had bitwise equal trajectories here.  Round 5: the one-launch EdgeModel backward
+        # (csrc/edge_mlp.hip) leaves ONE partial row of the LayerNorm / PReLU parameter gradients per TILE, so those three
+        # gradients are the same sums grouped by another tiling - equal to rounding, and AdamW turns a rounding difference of a
+        # near-zero gradient element into up to lr per step: the promotion test's bounds (3 steps of lr 1e-3)
+        a, b = outs[1][k], outs[2][k]
+        if a.is_floating_point():
+            assert float((a - b).abs().max()) < 7e-3, ("host table vs crystal-aligned table", k)
+            assert float((a - b).abs().median()) < 1e-5, ("host table vs crystal-aligned table", k)
+        else:
+            assert torch.equal(a, b), k
 
 
 def test_shape_limits_are_explicit_errors():

@@ -167,9 +167,13 @@ def layer_case(name, Sq, Bq, Nk, Bk, H):
     us2 = timeit(two)
     usa = timeit(lambda: ops.attention_fwd(a))
     usf = timeit(lambda: ops.ffn_fwd(M, H, x1, st1, g1, b1n, w1, b1, w2, b2, h, out))
-    us1 = timeit(lambda: ops.ffn_fwd(M, H, x, None, g1, b1n, w1, b1, w2, b2, h, out, att=att))
-    print(f"layer {name:30s} Sq={Sq} Bq={Bq} Nk={Nk} H={H}: one launch {us1:6.1f} us | attention {usa:5.1f} + ffn {usf:5.1f} us, "
-          f"back to back {us2:6.1f} us")
+    us1 = timeit(lambda: ops.ffn_fwd(M, H, x, None, g1, b1n, w1, b1, w2, b2, h, out, att=att)) if ops.ffn_att_supported(H, Nk) else float("nan")
+    usl = float("nan")
+    if ops.ffn_att_aligned_supported(H, Nk):
+        att2 = dict(att, aligned=True)
+        usl = timeit(lambda: ops.ffn_fwd(M, H, x, None, g1, b1n, w1, b1, w2, b2, h, out, att=att2))
+    print(f"layer {name:30s} Sq={Sq} Bq={Bq} Nk={Nk} H={H}: one launch {us1:6.1f} us (per-row keys) / {usl:6.1f} us (crystal-aligned tiles) | "
+          f"attention {usa:5.1f} + ffn {usf:5.1f} us, back to back {us2:6.1f} us")
 
 
 def ffn_bwd_case(name, M, H):
@@ -303,6 +307,8 @@ def main():
         layer_case("cross layer B (16-row tiles)", 51, 64, 12, 64, H)
         layer_case("cross layer 2B", 51, 128, 12, 64, H)
         layer_case("cross layer roofline scale", 51, 4096, 12, 2048, H)
+        layer_case("self layer 2B (51 keys)", 51, 128, 51, 128, H)
+        layer_case("self layer B (51 keys)", 51, 64, 51, 64, H)
     if w in ("all", "nmlp"):
         node_mlp_case("cfg2 nodes", N, H)
         node_mlp_case("one crystal", 7, H)

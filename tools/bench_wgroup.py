@@ -38,6 +38,8 @@ def job(M, Nn, K, segs=None, **kw):
     ns = ops.wgrad_splits(M, Nn, K)
     if M > 4096 and os.environ.get("WG_NS_E"):          # experiment: split count of the edge-row jobs
         ns = int(os.environ["WG_NS_E"])
+    if M <= 4096 and os.environ.get("WG_NS_N"):         # experiment: split count of the node-row jobs
+        ns = int(os.environ["WG_NS_N"])
     nsc = ops.wgrad_scratch_floats(Nn, K, ns)
     slab = torch.empty(max(nsc, 1), device=DEV)
     sb = torch.empty(ns * ((Nn + 63) // 64) * 64, device=DEV)
