@@ -104,6 +104,13 @@ class FfnBwd(C.Structure):
         ("fin_dy", C.c_void_p),
         ("fin_ddos", C.c_void_p), ("fin_w", C.c_void_p), ("fin_beta", C.c_void_p),
         ("fin_S", C.c_int32), ("fin_Bq", C.c_int32),
+        ("att_x", C.c_void_p), ("att_ldxin", C.c_int32),
+        ("att_kvhat", C.c_void_p), ("att_gamma0", C.c_void_p), ("att_beta0", C.c_void_p),
+        ("att_probs", C.c_void_p), ("att_qstats", C.c_void_p), ("att_mask", C.c_void_p),
+        ("att_dxin", C.c_void_p), ("att_lddxin", C.c_int32),
+        ("att_partials_q", C.c_void_p), ("att_partials_kv", C.c_void_p), ("att_dkv_part", C.c_void_p), ("att_dkv_cnt", C.c_void_p),
+        ("att_dkvhat", C.c_void_p), ("att_dkv_accumulate", C.c_int32),
+        ("att_Nk", C.c_int32), ("att_Bk", C.c_int32), ("att_Bq", C.c_int32), ("att_Sq", C.c_int32), ("att_qs", C.c_int32), ("att_qb", C.c_int32),
     ]
 
 
@@ -287,6 +294,8 @@ _SIGS = {
     "dosx_ffn_att_aligned_supported": [_I, _I],
     "dosx_ffn_fwd": [C.POINTER(Ffn), _P],
     "dosx_ffn_bwd_partial_rows": [_I],
+    "dosx_ffn_att_bwd_supported": [_I, _I, _I, _I],
+    "dosx_ffn_att_bwd_partial_rows": [_I, _I],
     "dosx_ffn_bwd": [C.POINTER(FfnBwd), _P],
     "dosx_mlp_ln_supported": [_I, _I, _I],
     "dosx_mlp_ln_fwd": [C.POINTER(MlpLn), _P],

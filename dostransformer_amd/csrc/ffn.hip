@@ -716,12 +716,330 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
 //     partials[wg] = [ sum_rows dyl*xhat | sum_rows dyl ]    (dgamma | dbeta of LN1; dyl = dh . W1)
 // Same structure as the forward: the R x 4H tile of dh stays in LDS as the A operand of the second GEMM.  Both weight
 // matrices are read as stored (k-major: W2 [H][4H], W1 [4H][H]), so a staged chunk is 32 k-rows x 128 columns.
+// ------------------------------------------------------------------------------------------------------------------
+// The attention half's BACKWARD for a crystal-aligned tile, behind the feed-forward half's (ffn_bwd_kernel<.., ATT = 2>,
+// round 5): what dosx_attention_bwd's one-launch form (attention.hip: attn_bwd_dq_stream_kernel<NJ, PKV = true> + the
+// in-launch key-gradient reduction) computes, on the tile's R rows whose gradient dO = dL/dx1 the row epilogue has just left
+// in LDS (Os) - the tile's rows share one key set, so the four products are small 16x16x4 MFMA jobs dealt over the 8 waves:
+//   a: quarter wave per row - Ds = dO o g0                          e: quarter wave per row - dq_ln = (dS.K) o g0, LayerNorm-0
+//   b: dP = Ds . Ks^T -> Sc (K split over idle waves)                  backward + residual -> dxin; query-side dg0 / db0 slots;
+//   c: quarter wave per row - dS = P o (dP' - sum P dP') scale,        Ql = LN0(x) g0 + b0
+//      dP' = (dP + dO.b0) o M with a dropout mask; P' = P o M       f: dK^ share = P'^T . dO + dS^T . Ql  [NkP, H] -> the tile's slot
+//   d: dq = dS . Ks -> Ds                                              of dkv_part (write-through), ticket on the key crystal's
+//                                                                      counter, the last arriver reduces (ffn_dkv_reduce)
+// Same saved tensors, scratch layout (dkv_part [Bq][tiles][Nk][H], partials_q [Bq][tiles][2H], partials_kv [Bk][groups][2H]) and
+// summation orders of the partials as the stand-alone kernel with 32-query tiles, so the two forms are interchangeable per layer.
+struct AttBwdSm {
+  float *Os, *Ds, *Ql, *Sp, *Ks, *Sc, *Ss, *Ps2, *Pp;
+};
+
+// one group of 16 key rows of crystal bk: sum of the partial key gradients in (query batch entry, tile) order, key-side chain
+// rule, dkvhat (+)=, the group's [dg0 | db0] row - attention.hip's dkv_reduce_group for one HALF of a 512-thread workgroup
+// (t256: thread within the half; grp >= ngroups: nothing stored).  Pp: [16][512] floats of LDS of this half.  Contains a barrier.
+__device__ __forceinline__ void ffn_dkv_reduce(const DosxFfnBwd& a, const int nqt, const int grp, const int ngroups, const int bk,
+                                               float (*Pp)[2 * 256], const int t256) {
+  const int lane = t256 & 63, wave = t256 >> 6, q16 = lane & 15, slot = wave * 4 + (lane >> 4);
+  const int H = a.H, Nk = a.att_Nk, rep = a.att_Bq / a.att_Bk;
+  const int j = grp * 16 + slot;
+  const bool jv = j < Nk && grp < ngroups;
+  const int jc = jv ? j : 0;
+  const size_t krow = ((size_t)jc * a.att_Bk + bk) * H;
+  float4 g0[2], d[2], kh[2], d0[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int c = q16 * 4 + 64 * k, cc = c < H ? c : 0;
+    g0[k] = ld4(a.att_gamma0 + cc);
+    kh[k] = ld4(a.att_kvhat + krow + cc);
+    d0[k] = a.att_dkv_accumulate ? ld4(a.att_dkvhat + krow + cc) : f4zero();
+    d[k] = f4zero();
+  }
+  const int np = rep * nqt;
+  const size_t pstride = (size_t)Nk * H;
+  const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)a.att_dkv_part, 0, 0x7fffffff, 0x00020000);
+  for (int p0 = 0; p0 < np; p0 += 4) {
+    float4 v[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int pi = min(p0 + u, np - 1), i = pi / nqt, t = pi % nqt;
+      const size_t off = ((size_t)(bk + i * a.att_Bk) * nqt + t) * pstride + (size_t)jc * H;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int c = q16 * 4 + 64 * k;
+        v[u][k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rP, (uint32_t)((off + (c < H ? c : 0)) * 4), 0, 16));   // sc1
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (p0 + u < np) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) d[k] = f4add(d[k], v[u][k]);
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int c = q16 * 4 + 64 * k;
+    float4 pg = f4zero(), pb = f4zero();
+    if (jv && c < H) {
+      pg = make_float4(d[k].x * kh[k].x, d[k].y * kh[k].y, d[k].z * kh[k].z, d[k].w * kh[k].w);
+      pb = d[k];
+      st4(a.att_dkvhat + krow + c, make_float4(d[k].x * g0[k].x + d0[k].x, d[k].y * g0[k].y + d0[k].y,
+                                               d[k].z * g0[k].z + d0[k].z, d[k].w * g0[k].w + d0[k].w));
+    }
+    st4(&Pp[slot][c], pg);
+    st4(&Pp[slot][256 + c], pb);
+  }
+  __syncthreads();
+  if (grp < ngroups) {
+    float* prow = a.att_partials_kv + ((size_t)bk * ngroups + grp) * 2 * H;
+    for (int c = t256; c < 2 * H; c += 256) {
+      const int o = (c / H) * 256 + (c % H);
+      float t = 0.f;
+#pragma unroll
+      for (int sl = 0; sl < 16; ++sl) t += Pp[sl][o];
+      prow[c] = t;
+    }
+  }
+}
+
+template <int R>
+__device__ __forceinline__ void ffn_att_bwd_tile(const DosxFfnBwd& a, float* __restrict__ sm, const AttBwdSm& L, const int al_s0,
+                                                 const int al_bq, const int tile, const int nqt, const int tid) {
+  const int H = a.H, LDK = a.H + 4;
+  const int lane = tid & 63, wave = tid >> 6, q16 = lane & 15, l15 = lane & 15, g4 = lane >> 4;
+  const int Nk = a.att_Nk, NkP = (Nk + 15) & ~15, Sq = a.att_Sq, bk = al_bq % a.att_Bk;
+  const float scale = rsqrtf((float)H), invH = 1.f / (float)H;
+  const int lr = wave * 4 + g4;                        // this quarter wave's row (R = 16: waves 0-3 only)
+  const bool rowok = lr < R;
+  const int s = min(al_s0 + (rowok ? lr : 0), Sq - 1);
+  const bool rv = rowok && (al_s0 + lr) < Sq;
+  const size_t orow = (size_t)s * a.att_Bq + al_bq;    // global row (valid memory also for the clamped duplicates)
+  // ---- operands of the row phases (one round trip) + the crystal's key rows -> Ks ----
+  float4 g0[2], b0[2], xr[2], go[2];
+  bool on[2];
+  float pr[4], mk[4];
+  const float* xrow = a.att_x + ((size_t)s * a.att_qs + (size_t)al_bq * a.att_qb) * a.att_ldxin;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int c = q16 * 4 + 64 * k, cc = c < H ? c : 0;
+    on[k] = c < H;
+    g0[k] = ld4(a.att_gamma0 + cc); b0[k] = ld4(a.att_beta0 + cc);
+    xr[k] = on[k] ? ld4(xrow + c) : f4zero();
+  }
+  const float mean = a.att_qstats[2 * orow], rstd = a.att_qstats[2 * orow + 1];
+  const size_t prow_ = ((size_t)al_bq * Sq + s) * Nk;
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const int j = q16 + 16 * jj, jc = j < Nk ? j : 0;
+    pr[jj] = a.att_probs[prow_ + jc];
+    mk[jj] = a.att_mask ? a.att_mask[prow_ + jc] : 1.f;
+  }
+  {
+    const int h4 = H >> 2;
+    float4 kr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 512 * i, j = e / h4, c = (e - j * h4) * 4;
+      kr[i] = (e < NkP * h4 && j < Nk) ? ld4(a.att_kvhat + ((size_t)j * a.att_Bk + bk) * H + c) : f4zero();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 512 * i, j = e / h4, c = (e - j * h4) * 4;
+      if (e < NkP * h4) st4(L.Ks + j * LDK + c, kr[i]);
+    }
+  }
+  // ---- a: dO rows (left in Os by the row epilogue; zeros beyond the data) -> Ds = dO o g0;  cq = dO . b0 (dropout only) ----
+  float cq = 0.f;
+  if (rowok) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      go[k] = f4zero();
+      if (!on[k]) continue;
+      go[k] = ld4(L.Os + lr * LDK + q16 * 4 + 64 * k);
+      st4(L.Ds + lr * LDK + q16 * 4 + 64 * k, make_float4(go[k].x * g0[k].x, go[k].y * g0[k].y, go[k].z * g0[k].z, go[k].w * g0[k].w));
+      t += (go[k].x * b0[k].x + go[k].y * b0[k].y) + (go[k].z * b0[k].z + go[k].w * b0[k].w);
+    }
+    if (a.att_mask) cq = row16_sum(t);
+  }
+  __syncthreads();
+  // ---- b: dP (up to a row constant) = Ds . Ks^T ----
+  const int nctS = NkP >> 4, njobsS = (R / 16) * nctS;
+  int KS = njobsS >= 8 ? 1 : (njobsS >= 4 ? 2 : 4);
+  while (KS > 1 && (H % (16 * KS)) != 0) KS >>= 1;
+  const int klen = H / KS;
+  for (int unit = wave; unit < njobsS * KS; unit += 8) {
+    const int job = unit / KS, kq = unit - job * KS;
+    const int rt = job / nctS, ct = job - rt * nctS;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int kk = kq * klen; kk < (kq + 1) * klen; kk += 16) {
+      const float4 av = ld4(L.Ds + (16 * rt + l15) * LDK + kk + 4 * g4);
+      const float4 bv = ld4(L.Ks + (16 * ct + l15) * LDK + kk + 4 * g4);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
+    }
+    float* Sq_ = kq == 0 ? L.Sc : L.Sp + (kq - 1) * R * 68;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Sq_[(16 * rt + 4 * g4 + i) * 68 + 16 * ct + l15] = acc[i];
+  }
+  __syncthreads();
+  // ---- c: dS = P o (dP' - sum_j P dP') scale -> Ss;  P' = P o M -> Ps2 (zeros beyond Nk / the data) ----
+  if (rowok) {
+    float dp[4], dot = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = q16 + 16 * jj;
+      float t = 0.f;
+      if (j < Nk) {
+        t = L.Sc[lr * 68 + j];
+        for (int kq = 1; kq < KS; ++kq) t += L.Sp[(kq - 1) * R * 68 + lr * 68 + j];
+      }
+      if (a.att_mask) t = (t + cq) * mk[jj];
+      if (j < Nk) dot += pr[jj] * t;
+      dp[jj] = t;
+    }
+    dot = row16_sum(dot);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = q16 + 16 * jj;
+      if (j >= NkP) continue;
+      const bool v = j < Nk && rv;
+      L.Ss[lr * 68 + j] = v ? pr[jj] * (dp[jj] - dot) * scale : 0.f;
+      L.Ps2[lr * 68 + j] = v ? pr[jj] * mk[jj] : 0.f;
+    }
+  }
+  __syncthreads();
+  // ---- d: dq = dS . Ks -> Ds ----
+  {
+    const int nct = H >> 4, njobs = (R / 16) * nct;
+    for (int job = wave; job < njobs; job += 8) {
+      const int rt = job / nct, ct = job - rt * nct;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int kk = 0; kk < NkP; kk += 16) {
+        const float4 av = ld4(L.Ss + (16 * rt + l15) * 68 + kk + 4 * g4);
+        const float* bp = L.Ks + (kk + 4 * g4) * LDK + 16 * ct + l15;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bp[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bp[LDK], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bp[2 * LDK], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bp[3 * LDK], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) L.Ds[(16 * rt + 4 * g4 + i) * LDK + 16 * ct + l15] = acc[i];
+    }
+  }
+  __syncthreads();
+  // ---- e: LayerNorm-0 backward on the query rows + residual -> dxin; query-side dg0 / db0; Ql = LN0(x) g0 + b0 ----
+  {
+    float4 pg[2] = {f4zero(), f4zero()}, pb[2] = {f4zero(), f4zero()};
+    if (rowok) {
+      float4 d[2], xh[2];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        d[k] = f4zero(); xh[k] = f4zero();
+        if (!(on[k] && rv)) continue;
+        float4 dd = ld4(L.Ds + lr * LDK + q16 * 4 + 64 * k);
+        dd = make_float4(dd.x * g0[k].x, dd.y * g0[k].y, dd.z * g0[k].z, dd.w * g0[k].w);
+        const float4 xv = xr[k];
+        const float4 h = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+        d[k] = dd; xh[k] = h;
+        pg[k] = make_float4(dd.x * h.x, dd.y * h.y, dd.z * h.z, dd.w * h.w);
+        pb[k] = dd;
+        const float4 dh = make_float4(dd.x * g0[k].x, dd.y * g0[k].y, dd.z * g0[k].z, dd.w * g0[k].w);
+        s1 += (dh.x + dh.y) + (dh.z + dh.w);
+        s2 += (dh.x * h.x + dh.y * h.y) + (dh.z * h.z + dh.w * h.w);
+      }
+      s1 = row16_sum(s1) * invH; s2 = row16_sum(s2) * invH;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (!on[k]) continue;
+        const float4 dd = d[k], h = xh[k];
+        if (rv)
+          st4(a.att_dxin + orow * a.att_lddxin + q16 * 4 + 64 * k,
+              make_float4(rstd * (dd.x * g0[k].x - s1 - h.x * s2) + go[k].x, rstd * (dd.y * g0[k].y - s1 - h.y * s2) + go[k].y,
+                          rstd * (dd.z * g0[k].z - s1 - h.z * s2) + go[k].z, rstd * (dd.w * g0[k].w - s1 - h.w * s2) + go[k].w));
+        st4(L.Ql + lr * LDK + q16 * 4 + 64 * k,
+            rv ? make_float4(h.x * g0[k].x + b0[k].x, h.y * g0[k].y + b0[k].y, h.z * g0[k].z + b0[k].z, h.w * g0[k].w + b0[k].w)
+               : f4zero());
+      }
+    }
+    // quarter-wave slots [32][2][128] (R = 16: the upper sixteen hold zeros)
+    const int slot = wave * 4 + g4;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int c = q16 * 4 + 64 * k;
+      st4(L.Pp + slot * 256 + c, pg[k]);
+      st4(L.Pp + slot * 256 + 128 + c, pb[k]);
+    }
+  }
+  __syncthreads();
+  {
+    float* prow = a.att_partials_q + ((size_t)al_bq * nqt + tile) * 2 * H;
+    for (int c = tid; c < 2 * H; c += 512) {
+      const int o = (c / H) * 128 + (c % H);
+      float t = 0.f;
+#pragma unroll
+      for (int sl = 0; sl < 32; ++sl) t += L.Pp[sl * 256 + o];
+      prow[c] = t;
+    }
+  }
+  // ---- f: this tile's share of dK + dV: [NkP keys] x [R queries] . [R queries] x [H] -> its slot of dkv_part (write-through) ----
+  {
+    float* part = a.att_dkv_part + ((size_t)al_bq * nqt + tile) * (size_t)Nk * H;
+    const int nct = H >> 4, njobs = nctS * nct;
+    for (int job = wave; job < njobs; job += 8) {
+      const int jt = job / nct, ct = job - jt * nct;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < R; kk += 16) {
+        const float* pa = L.Ps2 + (kk + 4 * g4) * 68 + 16 * jt + l15;
+        const float* sa = L.Ss + (kk + 4 * g4) * 68 + 16 * jt + l15;
+        const float* b1 = L.Os + (kk + 4 * g4) * LDK + 16 * ct + l15;
+        const float* b2 = L.Ql + (kk + 4 * g4) * LDK + 16 * ct + l15;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[i * 68], b1[i * LDK], acc, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(sa[i * 68], b2[i * LDK], acc2, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = 16 * jt + 4 * g4 + i, col = 16 * ct + l15;
+        if (j < Nk) __hip_atomic_store(part + (size_t)j * H + col, acc[i] + acc2[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1
+      }
+    }
+  }
+  // ---- publish / ticket: the last arriving tile of key crystal bk finishes its key gradient ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int* flag = reinterpret_cast<int*>(sm);
+  const int arrivers = (a.att_Bq / a.att_Bk) * nqt;
+  if (tid == 0) *flag = dosx_ticket(a.att_dkv_cnt + bk);
+  __syncthreads();
+  const bool last = *flag == arrivers - 1;
+  __syncthreads();                                  // (the flag word is about to be overwritten by the reduction's LDS rows)
+  if (last) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int ngroups = (Nk + 15) / 16;
+    float (*PpR)[2 * 256] = reinterpret_cast<float (*)[2 * 256]>(sm + (tid >> 8) * 16 * 512);
+    for (int g0_ = 0; g0_ < ngroups; g0_ += 2) {       // the two halves of the workgroup take alternate groups
+      ffn_dkv_reduce(a, nqt, g0_ + (tid >> 8), ngroups, bk, PpR, tid & 255);
+      __syncthreads();
+    }
+    if (tid == 0) __hip_atomic_store(a.att_dkv_cnt + bk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 constexpr int BLDW = FBN + 4;    // 132: padded rows of a k-major weight chunk
 
 #ifndef DOSX_FFN_BWD_OCC
 #define DOSX_FFN_BWD_OCC 2      // waves per SIMD the register budget allows (2 = one workgroup per CU, 208 VGPRs)
 #endif
-template <bool HALF, int KB>
+// ATT = 2 (round 5): CRYSTAL-ALIGNED tiles like ffn_fwd_kernel<.., 2> (a workgroup = R consecutive query rows s of ONE query
+// batch entry, row r = s * Bq + bq, grid = Bq x ceil(Sq / R)), and the attention half's backward behind the row epilogue
+// (ffn_att_bwd_tile): dx1 never reaches HBM, the layer's backward is one launch.
+template <bool HALF, int KB, int ATT = 0>
 __global__ __launch_bounds__(512, DOSX_FFN_BWD_OCC) void ffn_bwd_kernel(const DosxFfnBwd a) {
   DOSX_SET_MAIN_PRIO();
   extern __shared__ __align__(16) float sm[];
@@ -740,6 +1058,27 @@ __global__ __launch_bounds__(512, DOSX_FFN_BWD_OCC) void ffn_bwd_kernel(const Do
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int m0 = blockIdx.x * R;
   const int nk1 = H / FBK, nb1 = H4 / FBN, n1 = nb1 * nk1, n2 = H4 / FBK, nch = n1 + n2;
+  // tile row lr -> global row (-1: beyond the data).  ATT = 2: rows s0 .. s0 + R - 1 of query batch entry al_bq
+  int al_bq = 0, al_s0 = 0, al_tile = 0, al_tpc = 1;
+  if constexpr (ATT == 2) {
+    al_tpc = (a.att_Sq + R - 1) / R;
+    al_bq = (int)blockIdx.x / al_tpc;
+    al_tile = (int)blockIdx.x % al_tpc;
+    al_s0 = al_tile * R;
+  }
+  auto grow = [&](const int lr) -> int {
+    if constexpr (ATT == 2) {
+      const int s = al_s0 + lr;
+      return s < a.att_Sq ? s * a.att_Bq + al_bq : -1;
+    } else {
+      const int r = m0 + lr;
+      return r < M ? r : -1;
+    }
+  };
+  auto growc = [&](const int lr) -> int {          // clamped to a valid row of the tile (duplicates are never stored)
+    const int r = grow(lr);
+    return r >= 0 ? r : grow(0);
+  };
 
   // epilogue operands of this wave's ER rows, fetched at kernel start (all 8 waves)
   const int c0 = lane * 4;
@@ -749,7 +1088,7 @@ __global__ __launch_bounds__(512, DOSX_FFN_BWD_OCC) void ffn_bwd_kernel(const Do
   if (con) gam = ld4(a.gamma + c0);
 #pragma unroll
   for (int i = 0; i < ER; ++i) {
-    const int r = min(m0 + wave * ER + i, M - 1);
+    const int r = growc(wave * ER + i);
     dyr[i] = f4zero();
     if (a.dy) dyr[i] = ld4(a.dy + (size_t)r * a.lddy + (con ? c0 : 0));
     xr[i] = ld4(a.x + (size_t)r * a.ldx + (con ? c0 : 0));
@@ -772,8 +1111,8 @@ __global__ __launch_bounds__(512, DOSX_FFN_BWD_OCC) void ffn_bwd_kernel(const Do
     const float invH = 1.f / (float)a.H;
 #pragma unroll
     for (int i = 0; i < ER; ++i) {
-      const int lr = wave * ER + i, r = m0 + lr, rc = min(r, M - 1);
-      const bool ok = con && r < M;
+      const int lr = wave * ER + i, r = grow(lr), rc = growc(lr);
+      const bool ok = con && r >= 0;
       const float4 fx = ld4(a.fin_xhat + (size_t)rc * a.H + (con ? c0 : 0));
       const float frs = a.fin_rstd[rc];
       float4 d = dyr[i], dh = f4zero();
@@ -785,7 +1124,7 @@ __global__ __launch_bounds__(512, DOSX_FFN_BWD_OCC) void ffn_bwd_kernel(const Do
           pwf.x += dd * (fx.x * gf.x + bf.x); pwf.y += dd * (fx.y * gf.y + bf.y);
           pwf.z += dd * (fx.z * gf.z + bf.z); pwf.w += dd * (fx.w * gf.w + bf.w);
         }
-        if (lane == 0 && r < M) pdb += dd;
+        if (lane == 0 && r >= 0) pdb += dd;
       }
       float s1 = 0.f, s2 = 0.f;
       if (con) {
@@ -868,7 +1207,7 @@ __global__ __launch_bounds__(512, DOSX_FFN_BWD_OCC) void ffn_bwd_kernel(const Do
     // =============================== matrix waves ================================================
     if (fin) fin_rows();
     if (!fin) {   // dy tile -> Ys
-      const int r = tid >> 3, rr = min(m0 + r, M - 1);
+      const int r = tid >> 3, rr = growc(min(r, R - 1));
       for (int c = (tid & 7) * 4; c < H && r < R; c += 32) st4(Ys + r * LDX + c, ld4(a.dy + (size_t)rr * a.lddy + c));
     }
     __syncthreads();
@@ -882,7 +1221,7 @@ __global__ __launch_bounds__(512, DOSX_FFN_BWD_OCC) void ffn_bwd_kernel(const Do
       float hv[NV];                                // relu mask operand, in flight under the k-loop of the block
 #pragma unroll
       for (int v = 0; v < NV; ++v)
-        hv[v] = a.h[(size_t)min(m0 + crow(v), M - 1) * a.ldh + cb * FBN + ccol(v)];
+        hv[v] = a.h[(size_t)growc(crow(v)) * a.ldh + cb * FBN + ccol(v)];
       if constexpr (HALF) {
         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
         for (int kc = 0; kc < nk1; ++kc, ++c) {
@@ -928,7 +1267,8 @@ __global__ __launch_bounds__(512, DOSX_FFN_BWD_OCC) void ffn_bwd_kernel(const Do
       for (int v = 0; v < NV; ++v) {
         const float d = hv[v] > 0.f ? acc[v] : 0.f;
         T[crow(v) * LDT + cb * FBN + ccol(v)] = d;
-        if (m0 + crow(v) < M) a.dh[(size_t)(m0 + crow(v)) * a.lddh + cb * FBN + ccol(v)] = d;     // (see ffn_fwd_kernel)
+        const int gr = grow(crow(v));
+        if (gr >= 0) a.dh[(size_t)gr * a.lddh + cb * FBN + ccol(v)] = d;     // (see ffn_fwd_kernel)
       }
     }
     __syncthreads();                               // T complete (the staging waves copy it out from here on)
@@ -986,8 +1326,8 @@ __global__ __launch_bounds__(512, DOSX_FFN_BWD_OCC) void ffn_bwd_kernel(const Do
     const float invH = 1.f / (float)H;
 #pragma unroll
     for (int i = 0; i < ER; ++i) {
-      const int lr = wave * ER + i, r = m0 + lr;
-      const bool ok = con && r < M;                // (r < M is wave-uniform)
+      const int lr = wave * ER + i, r = grow(lr);
+      const bool ok = con && r >= 0;               // (wave-uniform)
       float4 xh = f4zero(), dxh = f4zero();
       float s1 = 0.f, s2 = 0.f;
       if (ok) {
@@ -1001,10 +1341,15 @@ __global__ __launch_bounds__(512, DOSX_FFN_BWD_OCC) void ffn_bwd_kernel(const Do
         s2 = dxh.x * xh.x + dxh.y * xh.y + dxh.z * xh.z + dxh.w * xh.w;
       }
       const float m1 = wave_sum(s1) * invH, m2 = wave_sum(s2) * invH;
+      float4 o = f4zero();
       if (ok)
-        st4(a.dx + (size_t)r * a.lddx + c0,
-            make_float4(rstd[i] * (dxh.x - m1 - xh.x * m2) + dyr[i].x, rstd[i] * (dxh.y - m1 - xh.y * m2) + dyr[i].y,
-                        rstd[i] * (dxh.z - m1 - xh.z * m2) + dyr[i].z, rstd[i] * (dxh.w - m1 - xh.w * m2) + dyr[i].w));
+        o = make_float4(rstd[i] * (dxh.x - m1 - xh.x * m2) + dyr[i].x, rstd[i] * (dxh.y - m1 - xh.y * m2) + dyr[i].y,
+                        rstd[i] * (dxh.z - m1 - xh.z * m2) + dyr[i].z, rstd[i] * (dxh.w - m1 - xh.w * m2) + dyr[i].w);
+      if constexpr (ATT == 2) {                    // dO = dL/dx1 stays in LDS for the attention half's backward (zeros beyond the data)
+        if (con) st4(sm + lr * LDX + c0, o);
+      } else if (ok) {
+        st4(a.dx + (size_t)r * a.lddx + c0, o);
+      }
     }
   }
   {
@@ -1038,9 +1383,35 @@ __global__ __launch_bounds__(512, DOSX_FFN_BWD_OCC) void ffn_bwd_kernel(const Do
       prow[5 * H] = s;
     }
   }
+  if constexpr (ATT == 2) {
+    __syncthreads();                               // the column sums are out of T / the C tile: everything but Os (= Ys) is free
+    AttBwdSm L;
+    const int LDK = H + 4, NkP = (a.att_Nk + 15) & ~15;
+    L.Os = sm;
+    L.Ds = sm + R * LDK;
+    L.Ql = L.Ds + R * LDK;
+    L.Sc = L.Ql + R * LDK;
+    L.Ss = L.Sc + R * 68;
+    L.Ps2 = L.Ss + R * 68;
+    L.Sp = L.Ps2 + R * 68;                         // [3][R][68] partial dP tiles; afterwards the 32 quarter-wave slots Pp [32][256]
+    L.Ks = L.Sp + 3 * R * 68;
+    L.Pp = L.Sp;
+    (void)NkP;
+    ffn_att_bwd_tile<R>(a, sm, L, al_s0, al_bq, al_tile, al_tpc, tid);
+  }
 }
 
 }  // namespace
+
+// floats of LDS the attention epilogue of ffn_bwd_kernel<.., 2> lays out (R rows per workgroup)
+static size_t ffn_att_bwd_floats(int H, int Nk, int R) {
+  const size_t LDK = (size_t)H + 4, NkP = (size_t)((Nk + 15) & ~15);
+  const size_t tiles = 3 * R * LDK + 6 * (size_t)R * 68 + NkP * LDK;
+  const size_t pp = 3 * R * LDK + 3 * (size_t)R * 68 + 32 * 256;          // (the query-side slots alias Sp | Ks)
+  const size_t red = 2 * 16 * 512;                                          // key-gradient reduction, both halves
+  size_t m = tiles > pp ? tiles : pp;
+  return m > red ? m : red;
+}
 
 static int ffn_chunk(int H) {
   static int forced = -1;
@@ -1119,12 +1490,29 @@ static int ffn_bwd_half(int M) {
 
 extern "C" int dosx_ffn_bwd_partial_rows(int M) { return M <= 0 ? 0 : ceil_div(M, ffn_bwd_half(M) ? 16 : 32); }
 
+// rows per workgroup of the crystal-aligned backward launch (DosxFfnBwd.att_*): 16 while the 32-row grid is at most half a round
+static int ffn_bwd_att_rows(int Sq, int Bq) {
+  static int half_max = -1;
+  if (half_max < 0) { const char* e = getenv("DOSX_FFN_HALF_MAX"); half_max = e ? atoi(e) : 128; }
+  return Bq * ceil_div(Sq, 32) <= half_max ? 16 : 32;
+}
+// whether dosx_ffn_bwd takes the att_* fields for this shape: hidden 64 / 128 (64-wide weight chunks), <= 64 keys, and the
+// attention tiles fit the launch's LDS;  *_partial_rows: workgroups = partial rows of such a launch
+extern "C" int dosx_ffn_att_bwd_supported(int H, int Nk, int Sq, int Bq) {
+  if (!dosx_ffn_supported(H) || (H % 64) != 0 || Nk < 1 || Nk > 64 || Sq < 1 || Bq < 1) return 0;
+  const int R = ffn_bwd_att_rows(Sq, Bq);
+  const size_t ffn = (size_t)R * (H + 4) + (size_t)R * (4 * H + 4) + 2 * (size_t)64 * (FBN + 4);
+  const size_t att = ffn_att_bwd_floats(H, Nk, R);
+  return (ffn > att ? ffn : att) * sizeof(float) <= 160 * 1024;
+}
+extern "C" int dosx_ffn_att_bwd_partial_rows(int Sq, int Bq) { return Bq * ceil_div(Sq, ffn_bwd_att_rows(Sq, Bq)); }
+
 extern "C" int dosx_ffn_bwd(const DosxFfnBwd* ap, dosx_stream_t stream) {
   DOSX_CHECK_ARG(ap != nullptr, "dosx_ffn_bwd: null descriptor");
   const DosxFfnBwd& a = *ap;
   if (a.M <= 0) return 0;
   DOSX_CHECK_ARG(dosx_ffn_supported(a.H), "dosx_ffn_bwd: H=%d unsupported (multiple of 32, <= 128)", a.H);
-  DOSX_CHECK_ARG((a.dy || a.fin_ddos) && a.h && a.x && a.stats && a.gamma && a.w1 && a.w2 && a.dh && a.dx && a.partials, "dosx_ffn_bwd: null operand");
+  DOSX_CHECK_ARG((a.dy || a.fin_ddos) && a.h && a.x && a.stats && a.gamma && a.w1 && a.w2 && a.dh && (a.dx || a.att_kvhat) && a.partials, "dosx_ffn_bwd: null operand");
   DOSX_CHECK_ARG((a.lddy & 3) == 0 && (a.ldh & 3) == 0 && (a.ldx & 3) == 0 && (a.lddh & 3) == 0 && (a.lddx & 3) == 0,
                  "dosx_ffn_bwd: leading dimensions must be multiples of 4");
   const int npv = a.fin_gamma ? (a.fin_ddos ? 5 : 4) : 2;
@@ -1135,20 +1523,34 @@ extern "C" int dosx_ffn_bwd(const DosxFfnBwd* ap, dosx_stream_t stream) {
   const long long span = (const char*)a.w1 > (const char*)a.w2 ? (const char*)a.w1 - (const char*)a.w2 : (const char*)a.w2 - (const char*)a.w1;
   DOSX_CHECK_ARG(span + (long long)16 * a.H * a.H < 0x7fffffffLL, "dosx_ffn_bwd: fc1 / fc2 weights more than 2 GiB apart");
   const int H = a.H, H4 = 4 * H;
-  const bool half = ffn_bwd_half(a.M);
+  const bool att = a.att_kvhat != nullptr;
+  if (att) {
+    DOSX_CHECK_ARG(dosx_ffn_att_bwd_supported(H, a.att_Nk, a.att_Sq, a.att_Bq) && ffn_chunk(H) == 64, "dosx_ffn_bwd: fused attention backward unsupported for H=%d Nk=%d", H, a.att_Nk);
+    DOSX_CHECK_ARG(a.att_x && a.att_gamma0 && a.att_beta0 && a.att_probs && a.att_qstats && a.att_dxin && a.att_partials_q && a.att_partials_kv &&
+                       a.att_dkv_part && a.att_dkv_cnt && a.att_dkvhat && a.att_Bk > 0 && a.att_Bq % a.att_Bk == 0 && a.att_Sq * a.att_Bq == a.M &&
+                       (a.att_ldxin & 3) == 0 && (a.att_lddxin & 3) == 0 && a.att_qs >= 0 && a.att_qb >= 0,
+                   "dosx_ffn_bwd: fused attention backward needs x / gamma0 / beta0 / probs / qstats / dxin / partials / dkv scratch + counters and Sq * Bq == M");
+  }
+  const bool half = att ? ffn_bwd_att_rows(a.att_Sq, a.att_Bq) == 16 : ffn_bwd_half(a.M);
   const int R = half ? 16 : 32;
   const int kb = ffn_chunk(H);
-  const size_t smem = sizeof(float) * ((size_t)R * (H + 4) + (size_t)R * (H4 + 4) + 2 * (size_t)kb * (FBN + 4));
+  size_t fl = (size_t)R * (H + 4) + (size_t)R * (H4 + 4) + 2 * (size_t)kb * (FBN + 4);
+  if (att && ffn_att_bwd_floats(H, a.att_Nk, R) > fl) fl = ffn_att_bwd_floats(H, a.att_Nk, R);
+  const size_t smem = sizeof(float) * fl;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_bwd_kernel<false, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_bwd_kernel<true, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_bwd_kernel<false, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_bwd_kernel<true, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_bwd_kernel<false, 64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_bwd_kernel<true, 64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  const dim3 grid(ceil_div(a.M, R));
-  if (half && kb == 64) hipLaunchKernelGGL((ffn_bwd_kernel<true, 64>), grid, dim3(512), smem, to_stream(stream), a);
+  const dim3 grid(att ? a.att_Bq * ceil_div(a.att_Sq, R) : ceil_div(a.M, R));
+  if (att && half) hipLaunchKernelGGL((ffn_bwd_kernel<true, 64, 2>), grid, dim3(512), smem, to_stream(stream), a);
+  else if (att) hipLaunchKernelGGL((ffn_bwd_kernel<false, 64, 2>), grid, dim3(512), smem, to_stream(stream), a);
+  else if (half && kb == 64) hipLaunchKernelGGL((ffn_bwd_kernel<true, 64>), grid, dim3(512), smem, to_stream(stream), a);
   else if (half) hipLaunchKernelGGL((ffn_bwd_kernel<true, 32>), grid, dim3(512), smem, to_stream(stream), a);
   else if (kb == 64) hipLaunchKernelGGL((ffn_bwd_kernel<false, 64>), grid, dim3(512), smem, to_stream(stream), a);
   else hipLaunchKernelGGL((ffn_bwd_kernel<false, 32>), grid, dim3(512), smem, to_stream(stream), a);

@@ -726,6 +726,7 @@ _ATT_FFN_MAX_ROWS = int(__import__("os").environ.get("DOSX_ATT_FFN_MAX_ROWS", "4
 _ATT_ALIGNED = __import__("os").environ.get("DOSX_ATT_ALIGNED", "1") == "1"           # crystal-aligned tiles (DosxFfn.att_aligned)
 _ATT_ALIGNED_MAX_WGS = int(__import__("os").environ.get("DOSX_ATT_ALIGNED_MAX_WGS", "256"))
 _ATT_ROWS_FIRST = __import__("os").environ.get("DOSX_ATT_ROWS_FIRST", "1") == "1"     # <= 16 keys and <= 4096 rows: the per-row form
+_FUSED_ATT_BWD = __import__("os").environ.get("DOSX_FUSED_ATT_BWD", "1") == "1"        # attention backward inside dosx_ffn_bwd (crystal-aligned tiles)
 _FUSED_DKV = __import__("os").environ.get("DOSX_FUSED_DKV", "1") == "1"
 _LATE_SELF_FLUSH = __import__("os").environ.get("DOSX_LATE_SELF_FLUSH", "0") == "1"      # (measured: no gain)          # one-launch attention backward (Nk <= 64)
 _FUSED_FIN_BWD = __import__("os").environ.get("DOSX_FUSED_FIN_BWD", "1") == "1"
@@ -789,13 +790,29 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: Optional[torch.Tensor],
         dx1 = _empty(dev, rows, H)
         pld = 2 * H
         fused = fused_all and fm is None
+        small = bool(_lib_load().dosx_attention_pkv_supported(int(Nk), int(H)))
+        # round 5: the attention half's backward INSIDE the feed-forward half's launch (crystal-aligned tiles, DosxFfnBwd.att_*):
+        # the layer's backward is one launch and dL/dx1 never reaches HBM - while that grid is one round of workgroups
+        att_in_ffn = (fused and small and _FUSED_DKV and _FUSED_ATT_BWD and ops.ffn_att_bwd_supported(H, Nk, Sq, Bq)
+                      and ops.ffn_att_bwd_partial_rows(Sq, Bq) <= _ATT_ALIGNED_MAX_WGS)
+        att_bwd_args = None
+        if att_in_ffn:
+            nqt_al = ops.ffn_att_bwd_partial_rows(Sq, Bq) // Bq                # query tiles per batch entry (16- or 32-row tiles)
+            npart_a = Bq * nqt_al + Bk * ((Nk + 15) // 16)
+            part_a = sink.scratch(npart_a, 2 * H)
+            dxin_a = _empty(dev, rows, H)
+            kvp_a = sink.scratch(Bq * nqt_al * Nk, H)
+            att_bwd_args = dict(x=x_in, kvhat=kvhat, gamma0=g0, beta0=b0, probs=probs, qstats=qstats, mask=mask, dxin=dxin_a,
+                                partials_q=part_a.data_ptr(), partials_kv=part_a.data_ptr() + 4 * Bq * nqt_al * 2 * H, dkv_part=kvp_a,
+                                dkv_cnt=ops.COUNTERS.take(dev, Bk), dkvhat=dkvhat, accumulate=0 if (dkv_fresh and t == T - 1) else 1,
+                                Nk=Nk, Bk=Bk, Bq=Bq, Sq=Sq, qs=qs, qb=qb)
         if fused:           # both dgrad GEMMs + ReLU mask + LN1 backward + residual in one launch (csrc/ffn.hip)
-            rgp = ops.ffn_bwd_partial_rows(rows)
+            rgp = ops.ffn_att_bwd_partial_rows(Sq, Bq) if att_in_ffn else ops.ffn_bwd_partial_rows(rows)
             with_fin = fin_fused is not None and t == T - 1
             pld = (5 * H + 4 if head is not None else 4 * H) if with_fin else 2 * H
             part = sink.scratch(rgp, pld)
-            ops.ffn_bwd(rows, H, dy if with_fin else dx, h, x1, st1, g1, P[lp + ".fc1.weight"], P[lp + ".fc2.weight"], dh, dx1,
-                        part, fin=fin_fused if with_fin else None)
+            ops.ffn_bwd(rows, H, dy if with_fin else dx, h, x1, st1, g1, P[lp + ".fc1.weight"], P[lp + ".fc2.weight"], dh,
+                        None if att_in_ffn else dx1, part, fin=fin_fused if with_fin else None, att=att_bwd_args)
             if with_fin:
                 sink.add(part, 2 * H, G[fin_keys[0]], rgp, pld, H)
                 sink.add(part, 3 * H, G[fin_keys[1]], rgp, pld, H)
@@ -820,7 +837,12 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: Optional[torch.Tensor],
         # Nk <= 64 (atoms of a crystal, the 51 phonon bins): the dq kernel leaves every query tile's share of dK + dV in
         # `kvp` and the dk+dv half is a small reduction over those partials; larger key sets (201 eDOS bins) stream the
         # dS round trip through `dsc` into the dkv kernel
-        small = bool(_lib_load().dosx_attention_pkv_supported(int(Nk), int(H)))
+        if att_in_ffn:          # (the attention half ran inside the ffn_bwd launch above)
+            sink.add(part_a, 0, G[lp + ".layer_norms.0.weight"], npart_a, 2 * H, H)
+            sink.add(part_a, H, G[lp + ".layer_norms.0.bias"], npart_a, 2 * H, H)
+            sink._keep.extend(t_ for t_ in (mask, x_in) if t_ is not None)
+            dx = dxin_a
+            continue
         npart = Bq * nqt + Bk * ((Nk + 15) // 16 if small else nkt)        # key-side partial rows: per 16 / 32 keys
         part = sink.scratch(npart, 2 * H)
         dxin = _empty(dev, rows, H)

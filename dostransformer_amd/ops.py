@@ -445,8 +445,16 @@ def ffn_bwd_partial_rows(M: int) -> int:
     return _lib.load().dosx_ffn_bwd_partial_rows(int(M))
 
 
+def ffn_att_bwd_supported(H: int, Nk: int, Sq: int, Bq: int) -> bool:
+    return bool(_lib.load().dosx_ffn_att_bwd_supported(int(H), int(Nk), int(Sq), int(Bq)))
+
+
+def ffn_att_bwd_partial_rows(Sq: int, Bq: int) -> int:
+    return _lib.load().dosx_ffn_att_bwd_partial_rows(int(Sq), int(Bq))
+
+
 def ffn_bwd(M: int, H: int, dy: torch.Tensor, h: torch.Tensor, x: torch.Tensor, stats: torch.Tensor, gamma, w1, w2,
-            dh: torch.Tensor, dx: torch.Tensor, partials: torch.Tensor, fin=None) -> None:
+            dh: torch.Tensor, dx: Optional[torch.Tensor], partials: torch.Tensor, fin=None, att=None) -> None:
     """dh = (dy W2) o [h>0], dx = dy + LN1_bwd(dh W1), LN1 dgamma|dbeta partial rows — one launch
     (include/dosx.h: DosxFfnBwd).  ``fin = (gamma, xhat, rstd, dy_out)``: ``dy`` is the gradient behind the encoder's
     final LayerNorm, whose backward runs first in the same launch (dy_out receives the result, the partial rows two more
@@ -466,10 +474,25 @@ def ffn_bwd(M: int, H: int, dy: torch.Tensor, h: torch.Tensor, x: torch.Tensor, 
     a.stats, a.gamma = stats.data_ptr(), gamma.data_ptr()
     a.w1, a.w2 = w1.data_ptr(), w2.data_ptr()
     a.dh, a.lddh = dh.data_ptr(), int(dh.stride(0))
-    a.dx, a.lddx = dx.data_ptr(), int(dx.stride(0))
+    if dx is not None:
+        a.dx, a.lddx = dx.data_ptr(), int(dx.stride(0))
     a.partials, a.partial_ld = partials.data_ptr(), int(partials.stride(0))
+    nk_att = 0
+    if att is not None:
+        # the attention half's backward in the same launch (include/dosx.h: DosxFfnBwd.att_*): att = dict(x, kvhat, gamma0, beta0,
+        # probs, qstats, mask, dxin, partials_q, partials_kv, dkv_part, dkv_cnt, dkvhat, accumulate, Nk, Bk, Bq, Sq, qs, qb)
+        a.att_x, a.att_ldxin = att["x"].data_ptr(), int(att["x"].stride(0))
+        a.att_kvhat, a.att_gamma0, a.att_beta0 = att["kvhat"].data_ptr(), att["gamma0"].data_ptr(), att["beta0"].data_ptr()
+        a.att_probs, a.att_qstats, a.att_mask = att["probs"].data_ptr(), att["qstats"].data_ptr(), _p(att.get("mask"))
+        a.att_dxin, a.att_lddxin = att["dxin"].data_ptr(), int(att["dxin"].stride(0))
+        a.att_partials_q, a.att_partials_kv = att["partials_q"], att["partials_kv"]
+        a.att_dkv_part, a.att_dkv_cnt = att["dkv_part"].data_ptr(), att["dkv_cnt"]
+        a.att_dkvhat, a.att_dkv_accumulate = att["dkvhat"].data_ptr(), int(att["accumulate"])
+        a.att_Nk, a.att_Bk, a.att_Bq, a.att_Sq = int(att["Nk"]), int(att["Bk"]), int(att["Bq"]), int(att["Sq"])
+        a.att_qs, a.att_qb = int(att["qs"]), int(att["qb"])
+        nk_att = a.att_Nk
     _call("dosx_ffn_bwd", C.byref(a), _stream(),
-          w=lambda: (f"ffn_bwd[H{H}]", "ffn_bwd_kernel", "mfma", 16.0 * M * H * H))
+          w=lambda: (f"ffn_bwd[H{H}{',att' if nk_att else ''}]", "ffn_bwd_kernel", "mfma", 16.0 * M * H * H + 10.0 * M * nk_att * H))
 
 
 MLP_LN_MAX_ROWS = int(__import__("os").environ.get("DOSX_MLP_LN_MAX_ROWS", "4096"))
@@ -1143,10 +1166,15 @@ def attention_fwd(a: Attn):
           w=lambda: (f"attention_fwd[{_attn_shape(a)}]", "attn_fwd", "mfma", 4.0 * a.Bq * a.Sq * a.Nk * a.H))
 
 
+_SKIP_ATTN_BWD = int(__import__("os").environ.get("DOSX_DEBUG_SKIP_ATTN_BWD", "0"))
+
+
 def attention_bwd(a: Attn):
     # dP = dO.K^T and dQ = dS.K (dq half), dK = dS^T.Q and dV = P^T.dO (dkv half): 4*Bq*Sq*Nk*H flops each half
     halves = (0 if a.flags & 4 else 1) + (0 if a.flags & 8 else 1)
     name = "attention_bwd" + ("_dkv" if (a.flags & 4) else ("_dq" if (a.flags & 8) else ""))
+    if _SKIP_ATTN_BWD and a.Bq >= _SKIP_ATTN_BWD:      # timing experiments only (wrong numbers): what the launches cost the step
+        return
     _call("dosx_attention_bwd", C.byref(a), _stream(),
           w=lambda: (f"{name}[{_attn_shape(a)}]", "attn_bwd", "mfma", 4.0 * halves * a.Bq * a.Sq * a.Nk * a.H))
 

@@ -552,8 +552,27 @@ typedef struct DosxFfnBwd {
    * groups (columns [4H, 5H] : partial_ld >= 5H + 1).  What dosx_ln_rowdot_bwd computes as a launch of its own. */
   const float* fin_ddos; const float* fin_w; const float* fin_beta;
   int32_t fin_S, fin_Bq;
+  /* optional (round 5; att_kvhat != NULL): the ATTENTION half's backward of the same encoder layer behind the feed-forward
+   * half's, same launch (layers/transformer.py:131-138 + layers/multihead_attention.py:68-74 differentiated) - what
+   * dosx_attention_bwd's one-launch form computes from `dx` as its `dout`, which then never reaches HBM (`dx` may be NULL).
+   * Crystal-aligned tiles: a workgroup owns consecutive query rows s of ONE query batch entry (row r = s * att_Bq + bq; grid =
+   * att_Bq x ceil(att_Sq / rows per workgroup) = dosx_ffn_att_bwd_partial_rows workgroups and partial rows).
+   *   att_x [rows, att_ldxin]: the LAYER input (row (s, bq) at s * att_qs + bq * att_qb); att_qstats / att_probs / att_mask: saved
+   *   by the forward; att_kvhat [Nk * Bk, H]: the pre-normalised keys; att_dxin [M, att_lddxin]: gradient w.r.t. the layer input;
+   *   att_partials_q [Bq * tiles, 2H], att_partials_kv [Bk * ceil(Nk / 16), 2H], att_dkv_part [Bq * tiles * Nk, H] scratch,
+   *   att_dkv_cnt [Bk] arrival counters (zero before and after), att_dkvhat (+)= the key gradient (att_dkv_accumulate)
+   * - the fields of DosxAttn with the same names, same layouts (32-query tiles), same summation orders. */
+  const float* att_x; int32_t att_ldxin;
+  const float* att_kvhat; const float* att_gamma0; const float* att_beta0;
+  const float* att_probs; const float* att_qstats; const float* att_mask;
+  float* att_dxin; int32_t att_lddxin;
+  float* att_partials_q; float* att_partials_kv; float* att_dkv_part; int32_t* att_dkv_cnt;
+  float* att_dkvhat; int32_t att_dkv_accumulate;
+  int32_t att_Nk, att_Bk, att_Bq, att_Sq, att_qs, att_qb;
 } DosxFfnBwd;
 int dosx_ffn_bwd_partial_rows(int M);
+int dosx_ffn_att_bwd_supported(int H, int Nk, int Sq, int Bq);   /* whether dosx_ffn_bwd takes the att_* fields for this shape */
+int dosx_ffn_att_bwd_partial_rows(int Sq, int Bq);               /* workgroups = partial rows of such a launch */
 int dosx_ffn_bwd(const DosxFfnBwd* a, dosx_stream_t stream);
 
 /* Linear -> LayerNorm -> PReLU -> Linear (+ residual) in ONE launch for small row counts: the NodeModel MLP of a GNN layer

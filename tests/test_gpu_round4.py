@@ -587,6 +587,8 @@ def test_encoder_layer_with_attention_inside_the_ffn_launch(Sq, Bq, Nk, Bk, H, b
         # (the shipped policy fuses by shape; the kernels take any: force the form under test)
         Fn._ATT_FFN_MAX_ROWS = (1 << 30) if form == "rows" else 0
         Fn._ATT_ALIGNED, Fn._ATT_ALIGNED_MAX_WGS, Fn._ATT_ROWS_FIRST = form == "aligned", 1 << 30, form == "rows"
+        fab = Fn._FUSED_ATT_BWD
+        Fn._FUSED_ATT_BWD = fused and form == "aligned"      # (round 5: ... and the attention half's backward inside dosx_ffn_bwd)
         try:
             o.KERNEL_TIMER.reset(enabled=False)
             y, ctx = Fn.encoder_fwd(P, "e", x, Sq, Bq, qs, qb, kvhat, Nk, Bk, H, T, drop=(drop, seed, 0) if drop > 0 else None)
@@ -601,6 +603,7 @@ def test_encoder_layer_with_attention_inside_the_ffn_launch(Sq, Bq, Nk, Bk, H, b
         finally:
             Fn._FUSED_ATT_FFN = True
             Fn._ATT_FFN_MAX_ROWS, Fn._ATT_ALIGNED_MAX_WGS, Fn._ATT_ALIGNED, Fn._ATT_ROWS_FIRST = cap, cap_al, al, rf
+            Fn._FUSED_ATT_BWD = fab
     (y0, lay0, dx0, dkv0, G0), (y1, lay1, dx1, dkv1, G1) = res[False], res[True]
     rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-12))
     assert rel(y1, y0) < 5e-6
