@@ -158,6 +158,51 @@ __device__ __forceinline__ void ffn_att_row(const DosxFfn& a, float* __restrict_
   }
 }
 
+// One 16 x 16 job of the attention tiles' small products on v_mfma_f32_16x16x4_f32, n <= MAXS steps of 16 along k: ALL fragments of
+// the job are requested before the first MFMA (the trip counts are run-time values - a rolled loop would expose one LDS round trip
+// per step: 500-660 clk per step measured against 4 x 32 of MFMA issue).  Ap / Bp: this lane's fragment base.
+//   mma_kk: both operands k-contiguous (one ds_read_b128 per step each):   A[l15][k], B[l15][k]
+//   mma_kn: B stored [k][n] (four ds_read_b32 per step):                    A[l15][k], B[k][l15]
+template <int MAXS>
+__device__ __forceinline__ f32x4 mma_kk(const float* __restrict__ Ap, const float* __restrict__ Bp, const int n) {
+  float4 av[MAXS], bv[MAXS];
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s)
+    if (s < n) { av[s] = ld4(Ap + 16 * s); bv[s] = ld4(Bp + 16 * s); }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s)
+    if (s < n) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s].x, bv[s].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s].y, bv[s].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s].z, bv[s].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s].w, bv[s].w, acc, 0, 0, 0);
+    }
+  return acc;
+}
+template <int MAXS>
+__device__ __forceinline__ f32x4 mma_kn(const float* __restrict__ Ap, const float* __restrict__ Bp, const int ldb, const int n) {
+  float4 av[MAXS];
+  float bv[MAXS][4];
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s)
+    if (s < n) {
+      av[s] = ld4(Ap + 16 * s);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[s][j] = Bp[(16 * s + j) * ldb];
+    }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s)
+    if (s < n) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s].x, bv[s][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s].y, bv[s][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s].z, bv[s][2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s].w, bv[s][3], acc, 0, 0, 0);
+    }
+  return acc;
+}
+
 // The attention half of a CRYSTAL-ALIGNED tile (ATT = 2) on the MFMA (round 5): the R query rows of the tile share one key set
 // (Ks [NkP][H + 4] in LDS, rows >= Nk zeroed), so scores and P.K are two small products on v_mfma_f32_16x16x4_f32 instead of one
 // key per iteration on the vector ALU (round 4's form: 0.4 us per key and pass, the 51-key self attention 47 us per layer):
@@ -246,15 +291,7 @@ __device__ __forceinline__ void ffn_att_tile(const DosxFfn& a, float* __restrict
     for (int unit = wave; unit < njobsS * KS; unit += 8) {
       const int job = unit / KS, kq = unit - job * KS;
       const int rt = job / nctS, ct = job - rt * nctS;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      for (int kk = kq * klen; kk < (kq + 1) * klen; kk += 16) {
-        const float4 av = ld4(Qs + (16 * rt + l15) * LDK + kk + 4 * g4);
-        const float4 bv = ld4(Ks + (16 * ct + l15) * LDK + kk + 4 * g4);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
-      }
+      const f32x4 acc = mma_kk<8>(Qs + (16 * rt + l15) * LDK + kq * klen + 4 * g4, Ks + (16 * ct + l15) * LDK + kq * klen + 4 * g4, klen >> 4);
       float* Sp = kq == 0 ? Sc : Qs + R * LDK + (kq - 1) * R * 68;      // (partials 1 .. KS - 1 behind the Q tile, in the T region)
 #pragma unroll
       for (int i = 0; i < 4; ++i) Sp[(16 * rt + 4 * g4 + i) * 68 + 16 * ct + l15] = acc[i] * scale;
@@ -310,15 +347,7 @@ __device__ __forceinline__ void ffn_att_tile(const DosxFfn& a, float* __restrict
     const int nct = H >> 4, njobs = (R / 16) * nct;
     for (int job = wave; job < njobs; job += 8) {
       const int rt = job / nct, ct = job - rt * nct;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      for (int kk = 0; kk < NkP; kk += 16) {
-        const float4 av = ld4(Sc + (16 * rt + l15) * 68 + kk + 4 * g4);
-        const float* bp = Ks + (kk + 4 * g4) * LDK + 16 * ct + l15;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bp[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bp[LDK], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bp[2 * LDK], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bp[3 * LDK], acc, 0, 0, 0);
-      }
+      const f32x4 acc = mma_kn<4>(Sc + (16 * rt + l15) * 68 + 4 * g4, Ks + (4 * g4) * LDK + 16 * ct + l15, LDK, NkP >> 4);
 #pragma unroll
       for (int i = 0; i < 4; ++i) Qs[(16 * rt + 4 * g4 + i) * LDK + 16 * ct + l15] = acc[i];
     }
@@ -733,77 +762,123 @@ struct AttBwdSm {
   float *Os, *Ds, *Ql, *Sp, *Ks, *Sc, *Ss, *Ps2, *Pp;
 };
 
-// one group of 16 key rows of crystal bk: sum of the partial key gradients in (query batch entry, tile) order, key-side chain
-// rule, dkvhat (+)=, the group's [dg0 | db0] row - attention.hip's dkv_reduce_group for one HALF of a 512-thread workgroup
-// (t256: thread within the half; grp >= ngroups: nothing stored).  Pp: [16][512] floats of LDS of this half.  Contains a barrier.
-__device__ __forceinline__ void ffn_dkv_reduce(const DosxFfnBwd& a, const int nqt, const int grp, const int ngroups, const int bk,
-                                               float (*Pp)[2 * 256], const int t256) {
-  const int lane = t256 & 63, wave = t256 >> 6, q16 = lane & 15, slot = wave * 4 + (lane >> 4);
-  const int H = a.H, Nk = a.att_Nk, rep = a.att_Bq / a.att_Bk;
-  const int j = grp * 16 + slot;
-  const bool jv = j < Nk && grp < ngroups;
-  const int jc = jv ? j : 0;
-  const size_t krow = ((size_t)jc * a.att_Bk + bk) * H;
-  float4 g0[2], d[2], kh[2], d0[2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int c = q16 * 4 + 64 * k, cc = c < H ? c : 0;
-    g0[k] = ld4(a.att_gamma0 + cc);
-    kh[k] = ld4(a.att_kvhat + krow + cc);
-    d0[k] = a.att_dkv_accumulate ? ld4(a.att_dkvhat + krow + cc) : f4zero();
-    d[k] = f4zero();
-  }
+// ALL key rows of crystal bk at once (<= 64: two rows per quarter-wave slot, their loads requested together - the last arriving
+// tile runs this alone at the end of its launch, so it is one round trip, not one per group): sum of the partial key gradients in
+// (query batch entry, tile) order, key-side chain rule, dkvhat (+)=, and per group of 16 key rows the [dg0 | db0] partial row,
+// slots added in row order - the arithmetic and orders of attention.hip's dkv_reduce_group.  Pp: [64][256] floats of LDS.
+// Contains a barrier.
+__device__ __forceinline__ void ffn_dkv_reduce(const DosxFfnBwd& a, const int nqt, const int bk, float* __restrict__ Pp, const int tid) {
+  const int lane = tid & 63, q16 = lane & 15, slot = tid >> 4;                 // 32 slots
+  const int H = a.H, Nk = a.att_Nk, rep = a.att_Bq / a.att_Bk, ngroups = (Nk + 15) / 16;
   const int np = rep * nqt;
   const size_t pstride = (size_t)Nk * H;
   const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)a.att_dkv_part, 0, 0x7fffffff, 0x00020000);
-  for (int p0 = 0; p0 < np; p0 += 4) {
-    float4 v[4][2];
+  float4 g0[2], d[2][2], kh[2][2], d0[2][2];
+  bool jv[2];
+  size_t krow[2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int pi = min(p0 + u, np - 1), i = pi / nqt, t = pi % nqt;
-      const size_t off = ((size_t)(bk + i * a.att_Bk) * nqt + t) * pstride + (size_t)jc * H;
+  for (int k = 0; k < 2; ++k) g0[k] = ld4(a.att_gamma0 + ((q16 * 4 + 64 * k) < H ? (q16 * 4 + 64 * k) : 0));
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int c = q16 * 4 + 64 * k;
-        v[u][k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rP, (uint32_t)((off + (c < H ? c : 0)) * 4), 0, 16));   // sc1
-      }
+  for (int p = 0; p < 2; ++p) {
+    const int j = slot + 32 * p;
+    jv[p] = j < Nk;
+    krow[p] = ((size_t)(jv[p] ? j : 0) * a.att_Bk + bk) * H;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int c = q16 * 4 + 64 * k, cc = c < H ? c : 0;
+      kh[p][k] = ld4(a.att_kvhat + krow[p] + cc);
+      d0[p][k] = a.att_dkv_accumulate ? ld4(a.att_dkvhat + krow[p] + cc) : f4zero();
+      d[p][k] = f4zero();
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (p0 + u < np) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) d[k] = f4add(d[k], v[u][k]);
-      }
   }
+  for (int p0 = 0; p0 < np; p0 += 4) {
+    float4 v[2][4][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pi = min(p0 + u, np - 1), i = pi / nqt, t = pi % nqt;
+        const size_t off = ((size_t)(bk + i * a.att_Bk) * nqt + t) * pstride + (size_t)(jv[p] ? slot + 32 * p : 0) * H;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int c = q16 * 4 + 64 * k;
+          v[p][u][k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rP, (uint32_t)((off + (c < H ? c : 0)) * 4), 0, 16));   // sc1
+        }
+      }
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (p0 + u < np) {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) d[p][k] = f4add(d[p][k], v[p][u][k]);
+        }
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int c = q16 * 4 + 64 * k;
+      float4 pg = f4zero(), pb = f4zero();
+      if (jv[p] && c < H) {
+        pg = make_float4(d[p][k].x * kh[p][k].x, d[p][k].y * kh[p][k].y, d[p][k].z * kh[p][k].z, d[p][k].w * kh[p][k].w);
+        pb = d[p][k];
+        st4(a.att_dkvhat + krow[p] + c, make_float4(d[p][k].x * g0[k].x + d0[p][k].x, d[p][k].y * g0[k].y + d0[p][k].y,
+                                                    d[p][k].z * g0[k].z + d0[p][k].z, d[p][k].w * g0[k].w + d0[p][k].w));
+      }
+      st4(Pp + (slot + 32 * p) * 256 + c, pg);
+      st4(Pp + (slot + 32 * p) * 256 + 128 + c, pb);
+    }
+  __syncthreads();
+  for (int o = tid; o < ngroups * 2 * H; o += 512) {
+    const int grp = o / (2 * H), c = o - grp * 2 * H;
+    const int col = (c / H) * 128 + (c % H);
+    float t = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl) t += Pp[(grp * 16 + sl) * 256 + col];
+    a.att_partials_kv[((size_t)bk * ngroups + grp) * 2 * H + c] = t;
+  }
+}
+
+// the global operands of the attention epilogue's row phases + this thread's share of the crystal's key rows: requested by
+// ffn_bwd_kernel right behind its row epilogue, so the round trip runs under the column-sum block in between
+struct AttBwdRegs {
+  float4 g0[2], b0[2], xr[2], kr[4];
+  float mean, rstd, pr[4], mk[4];
+};
+template <int R>
+__device__ __forceinline__ void ffn_att_bwd_prefetch(const DosxFfnBwd& a, AttBwdRegs& q, const int al_s0, const int al_bq, const int tid) {
+  const int H = a.H, lane = tid & 63, wave = tid >> 6, q16 = lane & 15, g4 = lane >> 4;
+  const int Nk = a.att_Nk, NkP = (Nk + 15) & ~15, Sq = a.att_Sq, bk = al_bq % a.att_Bk;
+  const int lr = wave * 4 + g4;
+  const int s = min(al_s0 + (lr < R ? lr : 0), Sq - 1);
+  const size_t orow = (size_t)s * a.att_Bq + al_bq;
+  const float* xrow = a.att_x + ((size_t)s * a.att_qs + (size_t)al_bq * a.att_qb) * a.att_ldxin;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    const int c = q16 * 4 + 64 * k;
-    float4 pg = f4zero(), pb = f4zero();
-    if (jv && c < H) {
-      pg = make_float4(d[k].x * kh[k].x, d[k].y * kh[k].y, d[k].z * kh[k].z, d[k].w * kh[k].w);
-      pb = d[k];
-      st4(a.att_dkvhat + krow + c, make_float4(d[k].x * g0[k].x + d0[k].x, d[k].y * g0[k].y + d0[k].y,
-                                               d[k].z * g0[k].z + d0[k].z, d[k].w * g0[k].w + d0[k].w));
-    }
-    st4(&Pp[slot][c], pg);
-    st4(&Pp[slot][256 + c], pb);
+    const int c = q16 * 4 + 64 * k, cc = c < H ? c : 0;
+    q.g0[k] = ld4(a.att_gamma0 + cc); q.b0[k] = ld4(a.att_beta0 + cc);
+    q.xr[k] = c < H ? ld4(xrow + c) : f4zero();
   }
-  __syncthreads();
-  if (grp < ngroups) {
-    float* prow = a.att_partials_kv + ((size_t)bk * ngroups + grp) * 2 * H;
-    for (int c = t256; c < 2 * H; c += 256) {
-      const int o = (c / H) * 256 + (c % H);
-      float t = 0.f;
+  q.mean = a.att_qstats[2 * orow]; q.rstd = a.att_qstats[2 * orow + 1];
+  const size_t prow_ = ((size_t)al_bq * Sq + s) * Nk;
 #pragma unroll
-      for (int sl = 0; sl < 16; ++sl) t += Pp[sl][o];
-      prow[c] = t;
-    }
+  for (int jj = 0; jj < 4; ++jj) {
+    const int j = q16 + 16 * jj, jc = j < Nk ? j : 0;
+    q.pr[jj] = a.att_probs[prow_ + jc];
+    q.mk[jj] = a.att_mask ? a.att_mask[prow_ + jc] : 1.f;
+  }
+  const int h4 = H >> 2;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = tid + 512 * i, j = e / h4, c = (e - j * h4) * 4;
+    q.kr[i] = (e < NkP * h4 && j < Nk) ? ld4(a.att_kvhat + ((size_t)j * a.att_Bk + bk) * H + c) : f4zero();
   }
 }
 
 template <int R>
-__device__ __forceinline__ void ffn_att_bwd_tile(const DosxFfnBwd& a, float* __restrict__ sm, const AttBwdSm& L, const int al_s0,
-                                                 const int al_bq, const int tile, const int nqt, const int tid) {
+__device__ __forceinline__ void ffn_att_bwd_tile(const DosxFfnBwd& a, float* __restrict__ sm, const AttBwdSm& L, const AttBwdRegs& q,
+                                                 const int al_s0, const int al_bq, const int tile, const int nqt, const int tid) {
   const int H = a.H, LDK = a.H + 4;
   const int lane = tid & 63, wave = tid >> 6, q16 = lane & 15, l15 = lane & 15, g4 = lane >> 4;
   const int Nk = a.att_Nk, NkP = (Nk + 15) & ~15, Sq = a.att_Sq, bk = al_bq % a.att_Bk;
@@ -813,40 +888,26 @@ __device__ __forceinline__ void ffn_att_bwd_tile(const DosxFfnBwd& a, float* __r
   const int s = min(al_s0 + (rowok ? lr : 0), Sq - 1);
   const bool rv = rowok && (al_s0 + lr) < Sq;
   const size_t orow = (size_t)s * a.att_Bq + al_bq;    // global row (valid memory also for the clamped duplicates)
-  // ---- operands of the row phases (one round trip) + the crystal's key rows -> Ks ----
   float4 g0[2], b0[2], xr[2], go[2];
   bool on[2];
   float pr[4], mk[4];
-  const float* xrow = a.att_x + ((size_t)s * a.att_qs + (size_t)al_bq * a.att_qb) * a.att_ldxin;
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    const int c = q16 * 4 + 64 * k, cc = c < H ? c : 0;
-    on[k] = c < H;
-    g0[k] = ld4(a.att_gamma0 + cc); b0[k] = ld4(a.att_beta0 + cc);
-    xr[k] = on[k] ? ld4(xrow + c) : f4zero();
+    on[k] = (q16 * 4 + 64 * k) < H;
+    g0[k] = q.g0[k]; b0[k] = q.b0[k]; xr[k] = q.xr[k];
   }
-  const float mean = a.att_qstats[2 * orow], rstd = a.att_qstats[2 * orow + 1];
-  const size_t prow_ = ((size_t)al_bq * Sq + s) * Nk;
+  const float mean = q.mean, rstd = q.rstd;
 #pragma unroll
-  for (int jj = 0; jj < 4; ++jj) {
-    const int j = q16 + 16 * jj, jc = j < Nk ? j : 0;
-    pr[jj] = a.att_probs[prow_ + jc];
-    mk[jj] = a.att_mask ? a.att_mask[prow_ + jc] : 1.f;
-  }
-  {
+  for (int jj = 0; jj < 4; ++jj) { pr[jj] = q.pr[jj]; mk[jj] = q.mk[jj]; }
+  {   // the crystal's key rows -> Ks
     const int h4 = H >> 2;
-    float4 kr[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int e = tid + 512 * i, j = e / h4, c = (e - j * h4) * 4;
-      kr[i] = (e < NkP * h4 && j < Nk) ? ld4(a.att_kvhat + ((size_t)j * a.att_Bk + bk) * H + c) : f4zero();
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int e = tid + 512 * i, j = e / h4, c = (e - j * h4) * 4;
-      if (e < NkP * h4) st4(L.Ks + j * LDK + c, kr[i]);
+      if (e < NkP * h4) st4(L.Ks + j * LDK + c, q.kr[i]);
     }
   }
+  FSTAMP(17);
   // ---- a: dO rows (left in Os by the row epilogue; zeros beyond the data) -> Ds = dO o g0;  cq = dO . b0 (dropout only) ----
   float cq = 0.f;
   if (rowok) {
@@ -861,7 +922,9 @@ __device__ __forceinline__ void ffn_att_bwd_tile(const DosxFfnBwd& a, float* __r
     }
     if (a.att_mask) cq = row16_sum(t);
   }
+  FSTAMP(18);
   __syncthreads();
+  FSTAMP(19);
   // ---- b: dP (up to a row constant) = Ds . Ks^T ----
   const int nctS = NkP >> 4, njobsS = (R / 16) * nctS;
   int KS = njobsS >= 8 ? 1 : (njobsS >= 4 ? 2 : 4);
@@ -870,19 +933,12 @@ __device__ __forceinline__ void ffn_att_bwd_tile(const DosxFfnBwd& a, float* __r
   for (int unit = wave; unit < njobsS * KS; unit += 8) {
     const int job = unit / KS, kq = unit - job * KS;
     const int rt = job / nctS, ct = job - rt * nctS;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int kk = kq * klen; kk < (kq + 1) * klen; kk += 16) {
-      const float4 av = ld4(L.Ds + (16 * rt + l15) * LDK + kk + 4 * g4);
-      const float4 bv = ld4(L.Ks + (16 * ct + l15) * LDK + kk + 4 * g4);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
-    }
+    const f32x4 acc = mma_kk<8>(L.Ds + (16 * rt + l15) * LDK + kq * klen + 4 * g4, L.Ks + (16 * ct + l15) * LDK + kq * klen + 4 * g4, klen >> 4);
     float* Sq_ = kq == 0 ? L.Sc : L.Sp + (kq - 1) * R * 68;
 #pragma unroll
     for (int i = 0; i < 4; ++i) Sq_[(16 * rt + 4 * g4 + i) * 68 + 16 * ct + l15] = acc[i];
   }
+  FSTAMP(20);
   __syncthreads();
   // ---- c: dS = P o (dP' - sum_j P dP') scale -> Ss;  P' = P o M -> Ps2 (zeros beyond Nk / the data) ----
   if (rowok) {
@@ -909,26 +965,21 @@ __device__ __forceinline__ void ffn_att_bwd_tile(const DosxFfnBwd& a, float* __r
       L.Ps2[lr * 68 + j] = v ? pr[jj] * mk[jj] : 0.f;
     }
   }
+  FSTAMP(21);
   __syncthreads();
   // ---- d: dq = dS . Ks -> Ds ----
   {
     const int nct = H >> 4, njobs = (R / 16) * nct;
     for (int job = wave; job < njobs; job += 8) {
       const int rt = job / nct, ct = job - rt * nct;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      for (int kk = 0; kk < NkP; kk += 16) {
-        const float4 av = ld4(L.Ss + (16 * rt + l15) * 68 + kk + 4 * g4);
-        const float* bp = L.Ks + (kk + 4 * g4) * LDK + 16 * ct + l15;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bp[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bp[LDK], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bp[2 * LDK], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bp[3 * LDK], acc, 0, 0, 0);
-      }
+      const f32x4 acc = mma_kn<4>(L.Ss + (16 * rt + l15) * 68 + 4 * g4, L.Ks + (4 * g4) * LDK + 16 * ct + l15, LDK, NkP >> 4);
 #pragma unroll
       for (int i = 0; i < 4; ++i) L.Ds[(16 * rt + 4 * g4 + i) * LDK + 16 * ct + l15] = acc[i];
     }
   }
+  FSTAMP(22);
   __syncthreads();
+  FSTAMP(23);
   // ---- e: LayerNorm-0 backward on the query rows + residual -> dxin; query-side dg0 / db0; Ql = LN0(x) g0 + b0 ----
   {
     float4 pg[2] = {f4zero(), f4zero()}, pb[2] = {f4zero(), f4zero()};
@@ -984,6 +1035,7 @@ __device__ __forceinline__ void ffn_att_bwd_tile(const DosxFfnBwd& a, float* __r
       prow[c] = t;
     }
   }
+  FSTAMP(24);
   // ---- f: this tile's share of dK + dV: [NkP keys] x [R queries] . [R queries] x [H] -> its slot of dkv_part (write-through) ----
   {
     float* part = a.att_dkv_part + ((size_t)al_bq * nqt + tile) * (size_t)Nk * H;
@@ -1011,23 +1063,22 @@ __device__ __forceinline__ void ffn_att_bwd_tile(const DosxFfnBwd& a, float* __r
     }
   }
   // ---- publish / ticket: the last arriving tile of key crystal bk finishes its key gradient ----
+  FSTAMP(25);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  FSTAMP(26);
   int* flag = reinterpret_cast<int*>(sm);
   const int arrivers = (a.att_Bq / a.att_Bk) * nqt;
   if (tid == 0) *flag = dosx_ticket(a.att_dkv_cnt + bk);
   __syncthreads();
   const bool last = *flag == arrivers - 1;
   __syncthreads();                                  // (the flag word is about to be overwritten by the reduction's LDS rows)
+  FSTAMP(27);
   if (last) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int ngroups = (Nk + 15) / 16;
-    float (*PpR)[2 * 256] = reinterpret_cast<float (*)[2 * 256]>(sm + (tid >> 8) * 16 * 512);
-    for (int g0_ = 0; g0_ < ngroups; g0_ += 2) {       // the two halves of the workgroup take alternate groups
-      ffn_dkv_reduce(a, nqt, g0_ + (tid >> 8), ngroups, bk, PpR, tid & 255);
-      __syncthreads();
-    }
+    ffn_dkv_reduce(a, nqt, bk, sm, tid);
     if (tid == 0) __hip_atomic_store(a.att_dkv_cnt + bk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    FSTAMP(28);
   }
 }
 
@@ -1057,6 +1108,7 @@ __global__ __launch_bounds__(512, DOSX_FFN_BWD_OCC) void ffn_bwd_kernel(const Do
   const int l15 = lane & 15, g4 = lane >> 4;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int m0 = blockIdx.x * R;
+  FSTAMP(0);
   const int nk1 = H / FBK, nb1 = H4 / FBN, n1 = nb1 * nk1, n2 = H4 / FBK, nch = n1 + n2;
   // tile row lr -> global row (-1: beyond the data).  ATT = 2: rows s0 .. s0 + R - 1 of query batch entry al_bq
   int al_bq = 0, al_s0 = 0, al_tile = 0, al_tpc = 1;
@@ -1352,6 +1404,8 @@ __global__ __launch_bounds__(512, DOSX_FFN_BWD_OCC) void ffn_bwd_kernel(const Do
       }
     }
   }
+  AttBwdRegs attq;
+  if constexpr (ATT == 2) ffn_att_bwd_prefetch<R>(a, attq, al_s0, al_bq, tid);
   {
     // column sums of the 8 waves: [8][npv][128] (+ 8 scalars) in the dh tile's LDS (dead since the second product)
     float* Ps = T;
@@ -1397,7 +1451,9 @@ __global__ __launch_bounds__(512, DOSX_FFN_BWD_OCC) void ffn_bwd_kernel(const Do
     L.Ks = L.Sp + 3 * R * 68;
     L.Pp = L.Sp;
     (void)NkP;
-    ffn_att_bwd_tile<R>(a, sm, L, al_s0, al_bq, al_tile, al_tpc, tid);
+    FSTAMP(16);
+    ffn_att_bwd_tile<R>(a, sm, L, attq, al_s0, al_bq, al_tile, al_tpc, tid);
+    FSTAMP(29);
   }
 }
 
@@ -1408,7 +1464,7 @@ static size_t ffn_att_bwd_floats(int H, int Nk, int R) {
   const size_t LDK = (size_t)H + 4, NkP = (size_t)((Nk + 15) & ~15);
   const size_t tiles = 3 * R * LDK + 6 * (size_t)R * 68 + NkP * LDK;
   const size_t pp = 3 * R * LDK + 3 * (size_t)R * 68 + 32 * 256;          // (the query-side slots alias Sp | Ks)
-  const size_t red = 2 * 16 * 512;                                          // key-gradient reduction, both halves
+  const size_t red = 64 * 256;                                              // key-gradient reduction: [64 key rows][dg0 | db0]
   size_t m = tiles > pp ? tiles : pp;
   return m > red ? m : red;
 }
