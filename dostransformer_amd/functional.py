@@ -728,7 +728,11 @@ _ATT_ALIGNED_MAX_WGS = int(__import__("os").environ.get("DOSX_ATT_ALIGNED_MAX_WG
 _ATT_ROWS_FIRST = __import__("os").environ.get("DOSX_ATT_ROWS_FIRST", "1") == "1"     # <= 16 keys and <= 4096 rows: the per-row form
 _FUSED_ATT_BWD = __import__("os").environ.get("DOSX_FUSED_ATT_BWD", "1") == "1"        # attention backward inside dosx_ffn_bwd (crystal-aligned tiles)
 _FUSED_DKV = __import__("os").environ.get("DOSX_FUSED_DKV", "1") == "1"
-_LATE_SELF_FLUSH = __import__("os").environ.get("DOSX_LATE_SELF_FLUSH", "0") == "1"      # (measured: no gain)          # one-launch attention backward (Nk <= 64)
+# the self encoder's weight-gradient group starts BEHIND the small head kernels (rownorm_bwd_act, the two dE1 dgrads) instead of in
+# front of them: "1" / "0", or "auto" = where the heads' weight gradients are not factored (their B-row jobs read a row sum that
+# is made later, on the side stream).  Round 3: no gain; round 5, with the encoder layers' backward one launch
+# each: 1.1224-1.1284 vs 1.1298-1.1331 ms per cfg2 step, three interleaved pairs (tools/exp/r5_ab_rowsfirst.sh)
+_LATE_SELF_FLUSH = __import__("os").environ.get("DOSX_LATE_SELF_FLUSH", "auto")
 _FUSED_FIN_BWD = __import__("os").environ.get("DOSX_FUSED_FIN_BWD", "1") == "1"
 _FUSED_HEAD_FWD = __import__("os").environ.get("DOSX_FUSED_HEAD_FWD", "1") == "1"
 _FUSED_HEAD_NORM = __import__("os").environ.get("DOSX_FUSED_HEAD_NORM", "1") == "1"     # DosxGemm.norm_out in the two heads
@@ -1291,7 +1295,8 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
         sink.flush_on_side()                  # (weight-gradient stream: this encoder's jobs run under the next one's backward)
     dkvs = _empty(dev, rows2, H)              # self-attention: every row is a key row, the first layer overwrites
     ddosin = encoder_bwd(P, G, "transformer_self", c2, dhs, dkvs, sink, dkv_fresh=True, kv_needed_next=True)
-    if sink.wside is not None and not _LATE_SELF_FLUSH:
+    late_flush = _LATE_SELF_FLUSH == "1" or (_LATE_SELF_FLUSH == "auto" and len(a_g.keep) <= 2)
+    if sink.wside is not None and not late_flush:
         sink.flush_on_side()
     sink.join()          # dkvs is produced on the side stream
     dpre = _empty(dev, rows2, H)         # key-side LN backward + the LeakyReLU backward behind it, one launch
@@ -1300,7 +1305,7 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
     R = _empty(dev, 2 * B, H)            # sum over the energy axis of dpre (filled on the side stream below)
     # (forward factored; R is filled later, on the side stream: deferred jobs only - and not with the late-flush experiment,
     #  whose flush_on_side() below would launch the B-row jobs before the reduce_rows that writes R is even queued)
-    if len(a_g.keep) > 2 and GradSink.group_wgrad and "fc.weight" in G and "fc_prompt.weight" in G and not _LATE_SELF_FLUSH:
+    if len(a_g.keep) > 2 and GradSink.group_wgrad and "fc.weight" in G and "fc_prompt.weight" in G and not late_flush:
         # the same factoring for the weight gradients: the column blocks that multiply the per-crystal inputs are
         # (sum_s dpre[s, b]) (x) [graph_b (| prompt_b)] - B-row jobs on R - and only the E1 block keeps its S * B rows
         E1_, graph_ = a_g.keep[0], a_g.keep[1]
@@ -1317,7 +1322,7 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
     dE1 = _empty(dev, S * B, H)
     ops.gemm(S * B, H, [seg(dpre, rmap=map0)], Wfc[:, :H], dE1, w_layout=1)
     ops.gemm(S * B, H, [seg(dpre, rmap=map1)], Wfp[:, :H], dE1, w_layout=1, res=dE1)
-    if sink.wside is not None and _LATE_SELF_FLUSH:
+    if sink.wside is not None and late_flush:
         # experiment: the self encoder's weight gradients (+ the two heads') start behind the small head kernels above
         # instead of in front of them (where the group's long-lived workgroups make these 8-15 us kernels wait)
         sink.flush_on_side()
