@@ -64,8 +64,8 @@ timeout 400 python3 bench.py --shuffle --no-cpu-baseline --no-secondary --kernel
 timeout 500 python3 bench.py --config edos_h256_b64 --kernels-out "$S/${R}_bench_edos_h256_b64_sites.json" > "$S/${R}_bench_edos_h256_b64.json" 2> "$OUT/bench_edos.err" < /dev/null
 timeout 300 python3 tools/bench_wgroup.py > "$S/${R}_wgrad_groups.log" 2> /dev/null < /dev/null
 # the three launches of a factored message-passing layer alone + their phase stamps (stamps build, if it travelled)
-timeout 200 python3 tools/bench_edge.py phonon 64 2> /dev/null | grep -v amdgpu.ids > "$S/${R}_edge_kernels.log" < /dev/null
-[ -f dostransformer_amd/csrc/build/libdosx_stamps.so ] && DOSX_LIB=dostransformer_amd/csrc/build/libdosx_stamps.so timeout 200 python3 tools/bench_edge.py phonon 64 2> /dev/null | grep -E "wave 0" >> "$S/${R}_edge_kernels.log" < /dev/null
+timeout 200 python3 tools/bench_edge.py phonon 64 2> /dev/null < /dev/null | grep -v amdgpu.ids > "$S/${R}_edge_kernels.log"
+[ -f dostransformer_amd/csrc/build/libdosx_stamps.so ] && DOSX_LIB=dostransformer_amd/csrc/build/libdosx_stamps.so timeout 200 python3 tools/bench_edge.py phonon 64 2> /dev/null < /dev/null | grep -E "wave 0" >> "$S/${R}_edge_kernels.log"
 # the N > 1 bench path on this one GPU (two ranks share cuda:0 over gloo: plumbing check of the split replay plan, no scaling meaning)
 timeout 400 python3 bench.py --gpus 2 --dist-backend gloo --share-gpu --steps 20 --warmup 5 --no-cpu-baseline > "$S/${R}_bench_2ranks_shared_gpu.json" 2> "$OUT/bench_2ranks.err" < /dev/null
 timeout 600 python3 tools/bench_kernels.py > "$S/${R}_kernel_microbench.log" 2> "$OUT/microbench.err" < /dev/null
