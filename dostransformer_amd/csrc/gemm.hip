@@ -1642,6 +1642,29 @@ extern "C" int dosx_gemm_pair(const DosxGemm* ap, const DosxGemm* bp, dosx_strea
     bn = gemm_plan(a, A);
     one = gemm_plan(b, B) == bn && bn <= 256 && A.vecA && A.vecW && B.vecA && B.vecW;
   }
+  if (!one && on && a.M > 0 && b.M > 0 && a.N == b.N && a.N == 128 && a.w_layout == 1 && b.w_layout == 1 && a.pro == DOSX_PRO_NONE &&
+      b.pro == DOSX_PRO_NONE && a.epi == DOSX_EPI_PRELU_BWD && b.epi == DOSX_EPI_PRELU_BWD && !sliver_ok(a) && !sliver_ok(b)) {
+    // The two encoders' backward (node rows: 16-row tiles; edge rows: 48-row tiles) at the tail of the step: each problem at
+    // ITS tile height in one grid (gemm_mixed_kernel with two independent descriptors; partial rows numbered per problem)
+    if (const int rc = gemm_validate(a)) return rc;
+    if (const int rc = gemm_validate(b)) return rc;
+    if (gemm_plan(a, A) == 128 && gemm_plan(b, B) == 128 && A.vecA && A.vecW && B.vecA && B.vecW && A.rt == 0 && B.rt == 3 &&
+        gemm_tail_split(a.M, a.N, a.epi) == 0 && gemm_tail_split(b.M, b.N, b.epi) == 0) {
+      constexpr size_t sa = gemm_smem_bytes<0, 1, 1, 0>(), sb = gemm_smem_bytes<3, 1, 1, 0>();
+      constexpr size_t smem = sa > sb ? sa : sb;
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mixed_kernel<0, 3, 1, 1, DOSX_PRO_NONE, 1, DOSX_EPI_PRELU_BWD>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+      }
+      const int n1 = ceil_div(a.M, 16), n2 = ceil_div(b.M, 48);
+      hipLaunchKernelGGL((gemm_mixed_kernel<0, 3, 1, 1, DOSX_PRO_NONE, 1, DOSX_EPI_PRELU_BWD>), dim3(n1 + n2), dim3(512), smem,
+                         to_stream(stream), A, B, n1);
+      DOSX_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   if (!one) {
     if (const int rc = dosx_gemm(ap, stream)) return rc;
     return dosx_gemm(bp, stream);

@@ -33,111 +33,155 @@ constexpr int WP_FLOATS = 32 * WLD_NK > WQ * WLD_KN ? 32 * WLD_NK : WQ * WLD_KN;
 //   version 2 (B fragments straight from global memory, 16 cache lines per load instruction): 17 us;
 //   the two dosx_gemm launches this kernel replaces: 9.7 + 9.6 us + the gap between them.
 
+// Both streams keep D chunks in flight in registers (a ring: the slot of chunk q takes chunk q + D as soon as its data
+// has been handed to the LDS) and separate the FIRST D requests from the loop, so that a kernel can put them in front of
+// whatever precedes the product - round 5: with one chunk ahead every chunk paid most of an L2 round trip (~2 k clk x 8
+// chunks = most of the kernel's 14 us at M = 424); the weights depend on nothing, so at hidden 128 ALL of a wave's W1
+// chunks are requested before the input tile is and all of its W2 chunks before the LayerNorm row phase.
+
 // acc[t] += As[16][kdim] . W[col_base + 16 t + (0..15)][0..kdim)^T,  W row-major [n][ldw]  (nn.Linear weight)
-template <int NC>
-__device__ __forceinline__ void wave_gemm_nk(f32x4 (&acc)[NC / 16], const float* w, int ldw, int col_base, int kdim,
-                                             const float* As, int lda, float* Wp, int lane) {
-  constexpr int NR = NC / 4;                       // float4 per lane per chunk (4 rows of 16 lanes per instruction)
-  const int l15 = lane & 15, g4 = lane >> 4;
-  const float* src = w + (size_t)(col_base + g4) * ldw + l15 * 4;
-  float4 r0[NR], r1[NR];
-  auto issue = [&](float4(&r)[NR], int q) {
+template <int NC, int D, bool STATIC>
+struct NkStream {
+  static constexpr int NR = NC / 4;                // float4 per lane per chunk (4 rows of 16 lanes per instruction)
+  float4 r[D][NR];
+  const float* src;
+  int ldw;
+  __device__ __forceinline__ void issue(float4 (&x)[NR], int q) {
 #pragma unroll
-    for (int i = 0; i < NR; ++i) r[i] = ld4(src + (size_t)(4 * i) * ldw + q * WQ);
-  };
-  auto store = [&](const float4(&r)[NR]) {
-#pragma unroll
-    for (int i = 0; i < NR; ++i) st4(Wp + (g4 + 4 * i) * WLD_NK + l15 * 4, r[i]);
-  };
-  auto mma = [&](int q) {
-#pragma unroll
-    for (int kk = 0; kk < WQ; kk += 16) {
-      const float4 av = ld4(As + l15 * lda + q * WQ + kk + 4 * g4);
-#pragma unroll
-      for (int t = 0; t < NC / 16; ++t) {
-        const float4 b = ld4(Wp + (16 * t + l15) * WLD_NK + kk + 4 * g4);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b.x, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b.y, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b.z, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b.w, acc[t], 0, 0, 0);
-      }
-    }
-  };
-  const int nq = kdim / WQ;
-  issue(r0, 0);
-  for (int q = 0; q < nq; q += 2) {
-    if (q + 1 < nq) issue(r1, q + 1);
-    store(r0);
-    __builtin_amdgcn_wave_barrier();
-    mma(q);
-    __builtin_amdgcn_wave_barrier();
-    if (q + 1 >= nq) break;
-    if (q + 2 < nq) issue(r0, q + 2);
-    store(r1);
-    __builtin_amdgcn_wave_barrier();
-    mma(q + 1);
-    __builtin_amdgcn_wave_barrier();
+    for (int i = 0; i < NR; ++i) x[i] = ld4(src + (size_t)(4 * i) * ldw + q * WQ);
+    __builtin_amdgcn_sched_barrier(0);             // (chunks are consumed in request order: keep the scheduler from mixing them)
   }
-}
+  __device__ __forceinline__ void prefetch(const float* w, int ldw_, int col_base, int kdim, int lane) {
+    ldw = ldw_;
+    src = w + (size_t)(col_base + (lane >> 4)) * ldw + (lane & 15) * 4;
+    const int nq = kdim / WQ;
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (d < nq) issue(r[d], d);
+  }
+  __device__ __forceinline__ void run(f32x4 (&acc)[NC / 16], int kdim, const float* As, int lda, float* Wp, int lane) {
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int nq = kdim / WQ;
+    auto round = [&](int q0) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int q = q0 + d;
+        if (q >= nq) break;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) st4(Wp + (g4 + 4 * i) * WLD_NK + l15 * 4, r[d][i]);
+        if (q + D < nq) issue(r[d], q + D);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int kk = 0; kk < WQ; kk += 16) {
+          const float4 av = ld4(As + l15 * lda + q * WQ + kk + 4 * g4);
+#pragma unroll
+          for (int t = 0; t < NC / 16; ++t) {
+            const float4 b = ld4(Wp + (16 * t + l15) * WLD_NK + kk + 4 * g4);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, b.x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, b.y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, b.z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, b.w, acc[t], 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    };
+    if constexpr (STATIC) {
+#pragma unroll
+      for (int q0 = 0; q0 < nq; q0 += D) round(q0);
+    } else {
+#pragma unroll 1
+      for (int q0 = 0; q0 < nq; q0 += D) round(q0);
+    }
+  }
+};
 
 // acc[t] += As[16][kdim] . W[0..kdim)[col_base + 16 t + (0..15)],  W row-major [k][ldw]  (a stored weight read as its
 // transpose: the dgrad products).  32 columns per wave.
-__device__ __forceinline__ void wave_gemm_kn(f32x4 (&acc)[2], const float* w, int ldw, int col_base, int kdim, const float* As,
-                                             int lda, float* Wp, int lane) {
-  constexpr int NR = 8;                            // 8 k rows of 8 lanes per instruction, 64 rows per chunk
-  const int l15 = lane & 15, g4 = lane >> 4, kr = lane >> 3, n4 = (lane & 7) * 4;
-  const float* src = w + (size_t)kr * ldw + col_base + n4;
-  float4 r0[NR], r1[NR];
-  auto issue = [&](float4(&r)[NR], int q) {
+template <int D, bool STATIC>
+struct KnStream {
+  static constexpr int NR = 8;                     // 8 k rows of 8 lanes per instruction, 64 rows per chunk
+  float4 r[D][NR];
+  const float* src;
+  int ldw;
+  __device__ __forceinline__ void issue(float4 (&x)[NR], int q) {
 #pragma unroll
-    for (int i = 0; i < NR; ++i) r[i] = ld4(src + (size_t)(q * WQ + 8 * i) * ldw);
-  };
-  auto store = [&](const float4(&r)[NR]) {
-#pragma unroll
-    for (int i = 0; i < NR; ++i) st4(Wp + (kr + 8 * i) * WLD_KN + n4, r[i]);
-  };
-  auto mma = [&](int q) {
-#pragma unroll
-    for (int kk = 0; kk < WQ; kk += 16) {
-      const float4 av = ld4(As + l15 * lda + q * WQ + kk + 4 * g4);
-      const float* bp = Wp + (kk + 4 * g4) * WLD_KN + l15;
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bp[0], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bp[16], acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bp[WLD_KN], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bp[WLD_KN + 16], acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bp[2 * WLD_KN], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bp[2 * WLD_KN + 16], acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bp[3 * WLD_KN], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bp[3 * WLD_KN + 16], acc[1], 0, 0, 0);
-    }
-  };
-  const int nq = kdim / WQ;
-  issue(r0, 0);
-  for (int q = 0; q < nq; q += 2) {
-    if (q + 1 < nq) issue(r1, q + 1);
-    store(r0);
-    __builtin_amdgcn_wave_barrier();
-    mma(q);
-    __builtin_amdgcn_wave_barrier();
-    if (q + 1 >= nq) break;
-    if (q + 2 < nq) issue(r0, q + 2);
-    store(r1);
-    __builtin_amdgcn_wave_barrier();
-    mma(q + 1);
-    __builtin_amdgcn_wave_barrier();
+    for (int i = 0; i < NR; ++i) x[i] = ld4(src + (size_t)(q * WQ + 8 * i) * ldw);
+    __builtin_amdgcn_sched_barrier(0);
   }
-}
+  __device__ __forceinline__ void prefetch(const float* w, int ldw_, int col_base, int kdim, int lane) {
+    ldw = ldw_;
+    src = w + (size_t)(lane >> 3) * ldw + col_base + (lane & 7) * 4;
+    const int nq = kdim / WQ;
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (d < nq) issue(r[d], d);
+  }
+  __device__ __forceinline__ void run(f32x4 (&acc)[2], int kdim, const float* As, int lda, float* Wp, int lane) {
+    const int l15 = lane & 15, g4 = lane >> 4, kr = lane >> 3, n4 = (lane & 7) * 4;
+    const int nq = kdim / WQ;
+    auto round = [&](int q0) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int q = q0 + d;
+        if (q >= nq) break;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) st4(Wp + (kr + 8 * i) * WLD_KN + n4, r[d][i]);
+        if (q + D < nq) issue(r[d], q + D);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int kk = 0; kk < WQ; kk += 16) {
+          const float4 av = ld4(As + l15 * lda + q * WQ + kk + 4 * g4);
+          const float* bp = Wp + (kk + 4 * g4) * WLD_KN + l15;
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bp[0], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bp[16], acc[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bp[WLD_KN], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bp[WLD_KN + 16], acc[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bp[2 * WLD_KN], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bp[2 * WLD_KN + 16], acc[1], 0, 0, 0);
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bp[3 * WLD_KN], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bp[3 * WLD_KN + 16], acc[1], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    };
+    if constexpr (STATIC) {
+#pragma unroll
+      for (int q0 = 0; q0 < nq; q0 += D) round(q0);
+    } else {
+#pragma unroll 1
+      for (int q0 = 0; q0 < nq; q0 += D) round(q0);
+    }
+  }
+};
 
+// HC = hidden / 64 when (K, NH, NO) = (2, 2, 1) x hidden - the NodeModel - so that every chunk loop unrolls; 0: run-time shapes
+template <int HC>
 __global__ __launch_bounds__(512) void mlp_ln_fwd_kernel(const DosxMlpLn a) {
   DOSX_SET_MAIN_PRIO();
   extern __shared__ __align__(16) float sm[];
-  const int K = a.K, NH = a.NH, NO = a.NO, M = a.M;
+  constexpr int D = HC == 4 ? 3 : HC ? 4 : 2;
+  const int K = HC ? 128 * HC : a.K, NH = HC ? 128 * HC : a.NH, NO = HC ? 64 * HC : a.NO, M = a.M;
   const int LDX = K + 4, LDT = NH + 4, LDC = NO + 4;
   float* Xs = sm;                                  // [16][LDX]  input tile (A operand of the first product); later the C tile
   float* T = Xs + MR * LDX;                        // [16][LDT]  z -> prelu(LN(z)) (A operand of the second product)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
   float* Wp = T + MR * LDT + wave * WP_FLOATS;     // this wave's private weight-chunk buffer
   const int m0 = blockIdx.x * MR;
+  NkStream<32, D, HC != 0> s1;
+  NkStream<16, D, HC != 0> s2;
+  // [a0 | a1] tile (row tid/32, 4-float groups tid%32 + 32 j): requested FIRST - loads return in order, and the first
+  // product waits for these only, with the weight chunks behind them still in flight
+  float4 xin[4];
+  {
+    const int rr = min(m0 + (tid >> 5), M - 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = (tid & 31) * 4 + 128 * j;
+      if (c < K) xin[j] = ld4(c < a.k0 ? a.a0 + (size_t)rr * a.lda0 + c : a.a1 + (size_t)rr * a.lda1 + (c - a.k0));
+    }
+  }
+  s1.prefetch(a.w1, K, wave * 32 < NH ? wave * 32 : 0, K, lane);          // (the first column block's chunks, before anything else)
 
   // epilogue operands of this wave's 2 rows, fetched at kernel start
   const int c0 = lane * 4;
@@ -147,9 +191,11 @@ __global__ __launch_bounds__(512) void mlp_ln_fwd_kernel(const DosxMlpLn a) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int r = min(m0 + wave * 2 + i, M - 1);
-    rres[i] = f4zero();
-    if (a.res) rres[i] = ld4(a.res + (size_t)r * a.ldres + (con ? c0 : 0));
+    // (an unconditional load - of the bias when there is no residual - so that no branch joins in front of the products
+    //  and waits for everything requested so far)
+    rres[i] = ld4(a.res ? a.res + (size_t)r * a.ldres + (con ? c0 : 0) : a.b2 + (con ? c0 : 0));
   }
+  const bool has_res = a.res != nullptr;
   // operands of the row phase (rows 2*wave, 2*wave+1; columns lane*4 + 256 j)
   float4 gam[NCG], bet[NCG];
   bool on[NCG];
@@ -161,12 +207,10 @@ __global__ __launch_bounds__(512) void mlp_ln_fwd_kernel(const DosxMlpLn a) {
     bet[j] = ld4(a.beta + (on[j] ? c : 0));
   }
   const float alpha = *a.alpha;
-  {   // [a0 | a1] tile -> Xs   (row r = tid/32, 4-float groups tid%32 + 32 i)
-    const int r = tid >> 5, rr = min(m0 + r, M - 1);
-    for (int c = (tid & 31) * 4; c < K; c += 128) {
-      const float* p = c < a.k0 ? a.a0 + (size_t)rr * a.lda0 + c : a.a1 + (size_t)rr * a.lda1 + (c - a.k0);
-      st4(Xs + r * LDX + c, ld4(p));
-    }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = (tid & 31) * 4 + 128 * j;
+    if (c < K) st4(Xs + (tid >> 5) * LDX + c, xin[j]);
   }
   __syncthreads();                                         // Xs visible
   // ---- first product: 256-column blocks (this wave: columns wave*32 .. +31 of the block = two 16-column tiles) ----
@@ -175,7 +219,9 @@ __global__ __launch_bounds__(512) void mlp_ln_fwd_kernel(const DosxMlpLn a) {
     const bool cok = cb < NH;                              // (wave-uniform: NH is a multiple of 128)
     f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     const float b1a = a.b1[(cok ? cb : 0) + l15], b1b = a.b1[(cok ? cb : 0) + l15 + 16];
-    wave_gemm_nk<32>(acc, a.w1, K, cok ? cb : 0, K, Xs, LDX, Wp, lane);
+    if (blk) s1.prefetch(a.w1, K, cok ? cb : 0, K, lane);
+    s1.run(acc, K, Xs, LDX, Wp, lane);
+    if ((blk + 1) * 256 >= NH) s2.prefetch(a.w2, NH, wave * 16 < NO ? wave * 16 : 0, NH, lane);   // in flight under the row phase
     if (cok) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -232,7 +278,8 @@ __global__ __launch_bounds__(512) void mlp_ln_fwd_kernel(const DosxMlpLn a) {
     const int oc = blk * 128 + wave * 16;
     const bool ook = oc < NO;
     f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-    wave_gemm_nk<16>(acc, a.w2, NH, ook ? oc : 0, NH, T, LDT, Wp, lane);
+    if (blk) s2.prefetch(a.w2, NH, ook ? oc : 0, NH, lane);
+    s2.run(acc, NH, T, LDT, Wp, lane);
     if (ook) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) Cs[(4 * g4 + r) * LDC + oc + l15] = acc[0][r];
@@ -245,8 +292,9 @@ __global__ __launch_bounds__(512) void mlp_ln_fwd_kernel(const DosxMlpLn a) {
     const int lr = wave * 2 + i, r = m0 + lr;
     if (con && r < M) {
       const float4 v = ld4(Cs + lr * LDC + c0);
-      st4(a.out + (size_t)r * a.ldo + c0, make_float4(v.x + bias2.x + rres[i].x, v.y + bias2.y + rres[i].y,
-                                                       v.z + bias2.z + rres[i].z, v.w + bias2.w + rres[i].w));
+      const float4 rr = has_res ? rres[i] : f4zero();
+      st4(a.out + (size_t)r * a.ldo + c0, make_float4(v.x + bias2.x + rr.x, v.y + bias2.y + rr.y,
+                                                       v.z + bias2.z + rr.z, v.w + bias2.w + rr.w));
     }
   }
 }
@@ -255,10 +303,12 @@ __global__ __launch_bounds__(512) void mlp_ln_fwd_kernel(const DosxMlpLn a) {
 // Backward:  da = dy . W2 ;  dy' = da o prelu'(xhat*gamma+beta) ;  dz = LN_bwd(dy' * gamma)  (written out) ;
 //            dcat = dz . W1 ;  partials[wg] = [ sum dy'*xhat (NH) | sum dy' (NH) | pad | sum_{y<0} da*y ]
 // Both weight matrices are read as stored (k-major for these products: W2 [NO][NH], W1 [NH][K]).
+template <int HC>
 __global__ __launch_bounds__(512) void mlp_ln_bwd_kernel(const DosxMlpLnBwd a) {
   DOSX_SET_MAIN_PRIO();
   extern __shared__ __align__(16) float sm[];
-  const int K = a.K, NH = a.NH, NO = a.NO, M = a.M;
+  constexpr int D = HC ? 4 : 2;
+  const int K = HC ? 128 * HC : a.K, NH = HC ? 128 * HC : a.NH, NO = HC ? 64 * HC : a.NO, M = a.M;
   const int LDY = NO + 4, LDT = NH + 4;
   float* Ys = sm;                                  // [16][LDY]  dy tile
   float* T = Ys + MR * LDY;                        // [16][LDT]  da -> dz
@@ -266,6 +316,17 @@ __global__ __launch_bounds__(512) void mlp_ln_bwd_kernel(const DosxMlpLnBwd a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
   float* Wp = Ps + 16 * NH + 8 + wave * WP_FLOATS; // this wave's private weight-chunk buffer
   const int m0 = blockIdx.x * MR;
+  KnStream<D, HC != 0> s1, s2;
+  float4 yin[2];                                   // dy tile (row tid/32, 4-float groups tid%32 + 32 j; NO <= 256): requested first
+  {
+    const int rr = min(m0 + (tid >> 5), M - 1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = (tid & 31) * 4 + 128 * j;
+      if (c < NO) yin[j] = ld4(a.dy + (size_t)rr * a.lddy + c);
+    }
+  }
+  s1.prefetch(a.w2, NH, wave * 32 < NH ? wave * 32 : 0, NO, lane);        // (the first column block's chunks, before anything else)
 
   // operands of the row phase (rows 2*wave, 2*wave+1; columns lane*4 + 256 j), in flight under the first product
   float4 gam[NCG], bet[NCG], xh[2][NCG];
@@ -286,9 +347,10 @@ __global__ __launch_bounds__(512) void mlp_ln_bwd_kernel(const DosxMlpLnBwd a) {
 #pragma unroll
     for (int j = 0; j < NCG; ++j) xh[i][j] = ld4(a.xhat + (size_t)r * NH + (on[j] ? lane * 4 + 256 * j : 0));
   }
-  {   // dy tile -> Ys
-    const int r = tid >> 5, rr = min(m0 + r, M - 1);
-    for (int c = (tid & 31) * 4; c < NO; c += 128) st4(Ys + r * LDY + c, ld4(a.dy + (size_t)rr * a.lddy + c));
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = (tid & 31) * 4 + 128 * j;
+    if (c < NO) st4(Ys + (tid >> 5) * LDY + c, yin[j]);
   }
   __syncthreads();                                         // Ys visible
   // ---- first product: da tile, 256-column blocks (this wave: two 16-column tiles), k over NO ----
@@ -296,7 +358,9 @@ __global__ __launch_bounds__(512) void mlp_ln_bwd_kernel(const DosxMlpLnBwd a) {
     const int cb = blk * 256 + wave * 32;
     const bool cok = cb < NH;
     f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    wave_gemm_kn(acc, a.w2, NH, cok ? cb : 0, NO, Ys, LDY, Wp, lane);
+    if (blk) s1.prefetch(a.w2, NH, cok ? cb : 0, NO, lane);
+    s1.run(acc, NO, Ys, LDY, Wp, lane);
+    if ((blk + 1) * 256 >= NH) s2.prefetch(a.w1, K, wave * 32 < K ? wave * 32 : 0, NH, lane);     // in flight under the row phase
     if (cok) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -381,7 +445,8 @@ __global__ __launch_bounds__(512) void mlp_ln_bwd_kernel(const DosxMlpLnBwd a) {
     const int cb = blk * 256 + wave * 32;
     const bool cok = cb < K;
     f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    wave_gemm_kn(acc, a.w1, K, cok ? cb : 0, NH, T, LDT, Wp, lane);
+    if (blk) s2.prefetch(a.w1, K, cok ? cb : 0, NH, lane);
+    s2.run(acc, NH, T, LDT, Wp, lane);
     if (cok) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -401,6 +466,9 @@ __global__ __launch_bounds__(512) void mlp_ln_bwd_kernel(const DosxMlpLnBwd a) {
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// hidden / 64 for the NodeModel's shapes (K, NH, NO) = (2, 2, 1) x hidden, hidden in {64, 128, 256}; 0: anything else
+inline int node_shape(int K, int NH, int NO) { return (K == NH && NH == 2 * NO && (NO == 64 || NO == 128 || NO == 256)) ? NO / 64 : 0; }
 
 }  // namespace
 
@@ -425,10 +493,19 @@ extern "C" int dosx_mlp_ln_fwd(const DosxMlpLn* ap, dosx_stream_t stream) {
   const size_t smem = sizeof(float) * ((size_t)MR * (a.K + 4) + (size_t)MR * (a.NH + 4) + 8 * (size_t)WP_FLOATS);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_ln_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_ln_fwd_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_ln_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_ln_fwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_ln_fwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(mlp_ln_fwd_kernel, dim3(ceil_div(a.M, MR)), dim3(512), smem, to_stream(stream), a);
+  const dim3 grid(ceil_div(a.M, MR));
+  switch (node_shape(a.K, a.NH, a.NO)) {
+    case 1: hipLaunchKernelGGL(mlp_ln_fwd_kernel<1>, grid, dim3(512), smem, to_stream(stream), a); break;
+    case 2: hipLaunchKernelGGL(mlp_ln_fwd_kernel<2>, grid, dim3(512), smem, to_stream(stream), a); break;
+    case 4: hipLaunchKernelGGL(mlp_ln_fwd_kernel<4>, grid, dim3(512), smem, to_stream(stream), a); break;
+    default: hipLaunchKernelGGL(mlp_ln_fwd_kernel<0>, grid, dim3(512), smem, to_stream(stream), a);
+  }
   DOSX_LAUNCH_CHECK();
   return 0;
 }
@@ -450,10 +527,19 @@ extern "C" int dosx_mlp_ln_bwd(const DosxMlpLnBwd* ap, dosx_stream_t stream) {
   const size_t smem = sizeof(float) * ((size_t)MR * (a.NO + 4) + (size_t)MR * (a.NH + 4) + 16 * (size_t)a.NH + 8 + 8 * (size_t)WP_FLOATS);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_ln_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_ln_bwd_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_ln_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_ln_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_ln_bwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(mlp_ln_bwd_kernel, dim3(ceil_div(a.M, MR)), dim3(512), smem, to_stream(stream), a);
+  const dim3 grid(ceil_div(a.M, MR));
+  switch (node_shape(a.K, a.NH, a.NO)) {
+    case 1: hipLaunchKernelGGL(mlp_ln_bwd_kernel<1>, grid, dim3(512), smem, to_stream(stream), a); break;
+    case 2: hipLaunchKernelGGL(mlp_ln_bwd_kernel<2>, grid, dim3(512), smem, to_stream(stream), a); break;
+    case 4: hipLaunchKernelGGL(mlp_ln_bwd_kernel<4>, grid, dim3(512), smem, to_stream(stream), a); break;
+    default: hipLaunchKernelGGL(mlp_ln_bwd_kernel<0>, grid, dim3(512), smem, to_stream(stream), a);
+  }
   DOSX_LAUNCH_CHECK();
   return 0;
 }

@@ -123,6 +123,31 @@ def mlp_prelu_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: G
     _wgrad_linear(sink, G, key + ".0.weight", key + ".0.bias", M, H, seg(dz), a.segs, keep=(dz,), tail=tail)
 
 
+_ENC_BWD_PAIR = __import__("os").environ.get("DOSX_ENC_BWD_PAIR", "1") == "1"
+
+
+def mlp_prelu_bwd_pair(P: Params, G: Params, first, second, sink: GradSink, tail: bool = False):
+    """The backward of TWO encoder MLPs (first / second = (key, ctx, dy)) whose output gradients exist at the same time - the
+    node and the edge encoder at the tail of the step: their two input-gradient products as ONE launch (dosx_gemm_pair: each at
+    its own tile height in one grid), the same weight-gradient jobs as mlp_prelu_bwd twice."""
+    descs, later = [], []
+    for key, ctx, dy in (first, second):
+        a, z, M, H = ctx
+        alpha = P[key + ".1.weight"]
+        _wgrad_linear(sink, G, key + ".2.weight", key + ".2.bias", M, H, seg(dy), [seg(z)], keep=(dy,), tail=tail,
+                      pro=PRO_PRELU, pro_alpha=alpha)
+        rows = ops.gemm_partial_rows(M, H, EPI_PRELU_BWD)
+        part = sink.scratch(rows, 1)
+        dz = _empty(z.device, M, H)
+        descs.append(dict(M=M, N=H, segs=[seg(dy)], w=P[key + ".2.weight"], out=dz, w_layout=1, epi=EPI_PRELU_BWD, aux=z,
+                          epi_alpha=alpha, partials=part, partial_ld=1))
+        later.append((key, a, M, H, dz, part, rows))
+    ops.gemm_pair(descs[0], descs[1])
+    for key, a, M, H, dz, part, rows in later:
+        sink.add(part, 0, G[key + ".1.weight"], rows, 1, 1)
+        _wgrad_linear(sink, G, key + ".0.weight", key + ".0.bias", M, H, seg(dz), a.segs, keep=(dz,), tail=tail)
+
+
 # ------------------------------------------------------------------------------------------------
 # Edge / Node MLP: Linear -> LayerNorm -> PReLU -> Linear     (DOSTransformer_phonon.py:193,204)
 # ------------------------------------------------------------------------------------------------
@@ -1136,6 +1161,11 @@ def _gnn_trunk_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, dxL: 
                    sink: GradSink):
     cn, ce, cu, cg, node_key = ctx
     dx0, de0 = gnn_bwd(P, G, m, cg, dxL, sink, cfg.L, cfg.mean, cfg.H)
+    if _ENC_BWD_PAIR and de0 is not None and cn[3] == ce[3]:
+        mlp_prelu_bwd_pair(P, G, (node_key, cn, dx0), ("GN_encoder.edge_encoder", ce, de0), sink, tail=True)
+        if cu is not None and du_seg is not None:
+            mlp_prelu_bwd(P, G, "GN_encoder.global_encoder", cu, None, sink, dy_seg=du_seg, tail=True)
+        return
     mlp_prelu_bwd(P, G, node_key, cn, dx0, sink, tail=True)
     # (measured: the edge encoder's backward moved ahead of the first layer's gather backward, where dL/de_0 already exists,
     #  so that its weight gradients join layer 0's group instead of the tail: on the side stream +15 us (round 2), on the main

@@ -388,3 +388,41 @@ def test_node_side_of_the_factored_input_gradient_in_one_launch(n, H, two):
     if two:
         ref = ref + res2.double()
     assert err(dx1, ref) < 2e-5
+
+
+@pytest.mark.parametrize("Mn,Me,H", [(417, 8340, 128), (450, 9000, 128), (17, 300, 128), (417, 8340, 64)])
+def test_the_two_encoders_backward_products_as_one_launch(Mn, Me, H):
+    """dosx_gemm_pair with two EPI_PRELU_BWD problems of different heights (node rows: 16-row tiles, edge rows: 48-row tiles
+    - one grid, gemm_mixed_kernel with two independent descriptors) == the two dosx_gemm launches: dz and the per-workgroup
+    PReLU-slope partial rows bitwise (shapes outside the paired form - H 64, few edges - take the two launches inside)."""
+    o = ops()
+    from dostransformer_amd.functional import seg
+    from dostransformer_amd.ops import EPI_PRELU_BWD
+    outs = []
+    for paired in (False, True):
+        res, descs, alive = [], [], []                       # (a Seg holds a pointer, not the tensor)
+        for i, M in enumerate((Mn, Me)):
+            dy, z, W = rnd(M, H, seed=5 + i), rnd(M, H, seed=7 + i), rnd(H, H, seed=9 + i, scale=H ** -0.5)
+            alpha = torch.tensor([0.25 + 0.1 * i], device=DEV)
+            rows = o.gemm_partial_rows(M, H, EPI_PRELU_BWD)
+            part, dz = torch.zeros(rows, 1, device=DEV), torch.empty(M, H, device=DEV)
+            d = dict(M=M, N=H, segs=[seg(dy)], w=W, out=dz, w_layout=1, epi=EPI_PRELU_BWD, aux=z, epi_alpha=alpha, partials=part,
+                     partial_ld=1)
+            descs.append(d)
+            alive += [dy, z, W, alpha]
+            res += [dz, part]
+            if i == 0:
+                # reference for the first problem: da = dy W, dz = da * (z >= 0 ? 1 : alpha), dalpha = sum da * z over z < 0
+                da = dy.double() @ W.double()
+                ref_dz = torch.where(z >= 0, da, da * alpha.double())
+                ref_al = float((da * z.double())[z < 0].sum())
+        if paired:
+            o.gemm_pair(descs[0], descs[1])
+        else:
+            o.gemm(**descs[0])
+            o.gemm(**descs[1])
+        torch.cuda.synchronize()
+        outs.append(res)
+    assert err(outs[0][0], ref_dz) < 1e-5 and abs(float(outs[0][1].sum()) - ref_al) < 1e-3 * max(1.0, abs(ref_al))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
