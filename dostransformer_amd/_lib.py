@@ -272,6 +272,7 @@ _SIGS = {
     "dosx_layernorm": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
     "dosx_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _P],
     "dosx_attention_pkv_supported": [_I, _I],
+    "dosx_attention_aligned_mode": [_I],
     "dosx_attention_fwd": [C.POINTER(Attn), _P],
     "dosx_attention_bwd": [C.POINTER(Attn), _P],
     "dosx_attn_pv": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],

@@ -1308,6 +1308,9 @@ int check_attn(const DosxAttn& a, const char* who) {
 namespace dosx_detail {            // attention_general.hip: the same contract for any number of keys
 int attn_general_fwd(const DosxAttn& a, hipStream_t st);
 int attn_general_bwd(const DosxAttn& a, hipStream_t st);
+// attention_aligned.hip: <= 64 keys on crystal-aligned query tiles (1: launched, 0: not this shape, < 0: error)
+int attn_aligned_fwd(const DosxAttn& a, hipStream_t st);
+int attn_aligned_bwd(const DosxAttn& a, hipStream_t st);
 }  // namespace dosx_detail
 
 extern "C" int dosx_attention_pkv_supported(int Nk, int H) {
@@ -1319,6 +1322,7 @@ extern "C" int dosx_attention_fwd(const DosxAttn* ap, dosx_stream_t stream) {
   const DosxAttn& a = *ap;
   if (int rc = check_attn(a, "dosx_attention_fwd")) return rc;
   DOSX_CHECK_ARG(a.out, "dosx_attention_fwd: null out");
+  if (const int rc = dosx_detail::attn_aligned_fwd(a, to_stream(stream))) return rc < 0 ? rc : 0;
   if (a.Nk > MAX_FUSED_NK) return dosx_detail::attn_general_fwd(a, to_stream(stream));
   const Geo g = make_geo(a.H, a.Nk);
   const bool res = fwd_resident(a);
@@ -1353,6 +1357,7 @@ extern "C" int dosx_attention_bwd(const DosxAttn* ap, dosx_stream_t stream) {
   if (int rc = check_attn(a, "dosx_attention_bwd")) return rc;
   DOSX_CHECK_ARG(a.dout && a.dx && (a.dscores || pkv_ok(a)) && a.dkvhat && a.partials_q && a.partials_kv,
                  "dosx_attention_bwd: null operand");
+  if (const int rc = dosx_detail::attn_aligned_bwd(a, to_stream(stream))) return rc < 0 ? rc : 0;
   if (a.Nk > MAX_FUSED_NK) return dosx_detail::attn_general_bwd(a, to_stream(stream));
   const Geo g = make_geo(a.H, a.Nk);
   const int kg = a.Nk > 32 ? 2 : 1;

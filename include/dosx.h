@@ -411,6 +411,11 @@ typedef struct DosxAttn {
 /* 1 if dosx_attention_bwd takes the partial-dKV path for this key count / width when dkv_part is given (else it needs
  * dscores and runs the streamed dkv kernel) */
 int dosx_attention_pkv_supported(int Nk, int H);
+/* Which shapes dosx_attention_fwd / dosx_attention_bwd (one-launch form: dkv_part + dkv_cnt) route to the crystal-aligned
+ * kernels (csrc/attention_aligned.hip: flags 0, Nk <= 64, H in {64, 128, 256}): 0 = none, 1 = H > 128 only (the default, also
+ * from the environment variable DOSX_ATTN_ALIGNED: where the layer's feed-forward half cannot share the launch), 2 = all of
+ * them (tests).  Sets the mode unless `mode` < 0; returns the previous one. */
+int dosx_attention_aligned_mode(int mode);
 int dosx_attention_fwd(const DosxAttn* a, dosx_stream_t stream);
 int dosx_attention_bwd(const DosxAttn* a, dosx_stream_t stream);
 

@@ -439,7 +439,13 @@ def test_attention_backward_in_one_launch(Sq, Bq, Nk, Bk, H, drop):
             assert all(torch.equal(u, v) for u, v in zip(r, outs[0]))
         return outs[0]
 
-    two, one = run(False), run(True)
+    # (round 5: hidden 256 with <= 64 keys takes csrc/attention_aligned.hip in the one-launch form - other tiles, other summation
+    #  orders; this test is about attention.hip's two forms: keep both on those kernels)
+    prev = _lib.load().dosx_attention_aligned_mode(0)
+    try:
+        two, one = run(False), run(True)
+    finally:
+        _lib.load().dosx_attention_aligned_mode(prev)
     for name, u, v in zip(("dx", "dkvhat", "partials"), two, one):
         assert not torch.isnan(v).any(), name
         assert torch.equal(u, v), name

@@ -426,3 +426,77 @@ def test_the_two_encoders_backward_products_as_one_launch(Mn, Me, H):
     assert err(outs[0][0], ref_dz) < 1e-5 and abs(float(outs[0][1].sum()) - ref_al) < 1e-3 * max(1.0, abs(ref_al))
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("Sq,Bq,Nk,Bk,H,bcast", [(201, 6, 41, 3, 256, False), (201, 5, 64, 5, 256, False), (51, 4, 12, 4, 128, False),
+                                                   (51, 6, 9, 3, 64, False), (70, 3, 48, 3, 128, False), (33, 300, 17, 150, 64, False),
+                                                   (201, 140, 16, 70, 128, False), (7, 3, 1, 3, 256, False), (51, 5, 7, 5, 128, True),
+                                                   (64, 9, 33, 9, 256, True)])
+@pytest.mark.parametrize("drop", [0.0, 0.35])
+def test_attention_on_crystal_aligned_tiles(Sq, Bq, Nk, Bk, H, bcast, drop):
+    """csrc/attention_aligned.hip behind dosx_attention_fwd / dosx_attention_bwd (one-launch form): <= 64 keys, hidden 64 / 128 /
+    256, workgroups that own one, several (Bq = 140: 2 per crystal) or all (Bq = 300) query tiles of a crystal, broadcast query
+    rows, dropout masks - against the float64 reference of multihead_attention.py:49-76 + the LayerNorm / residual around it;
+    repeated launches bitwise equal (counters back at zero); with the mode switched off the same call takes attention.hip's
+    kernels and agrees to rounding."""
+    from tests.test_gpu_ops import _attn_ref
+    from dostransformer_amd import _lib
+    from dostransformer_amd._lib import Attn
+    o = ops()
+    lib = _lib.load()
+    qs, qb = (1, 0) if bcast else (Bq, 1)
+    x = rnd(Sq if bcast else Sq * Bq, H, seed=1).double().requires_grad_(True)
+    kv = rnd(Nk * Bk, H, seed=2)
+    kv[-Bk:] = 0                        # zero-padded atoms
+    kv = kv.double().requires_grad_(True)
+    gam, bet = rnd(H, seed=3).double().requires_grad_(True), (0.3 * rnd(H, seed=4)).double().requires_grad_(True)
+    mask = None
+    if drop > 0:
+        mask = (torch.rand(Bq, Sq, Nk, generator=torch.Generator().manual_seed(9)) >= drop).float().to(DEV) / (1 - drop)
+    ref, pref = _attn_ref(x, kv, gam, bet, Sq, Bq, Nk, Bk, H, qs, qb, None if mask is None else mask.double())
+    dout = rnd(Sq * Bq, H, seed=5)
+    ref.backward(dout.double())
+    f = lambda t: t.detach().float().contiguous()
+    xf, kvf, gf, bf = f(x), f(kv), f(gam), f(bet)
+    nqt, nkt = (Sq + 31) // 32, (Nk + 15) // 16
+    base = rnd(Nk * Bk, H, seed=6)
+
+    def run(mode):
+        prev = lib.dosx_attention_aligned_mode(mode)
+        try:
+            a = Attn()
+            a.Sq, a.Bq, a.Nk, a.Bk, a.H, a.q_stride_s, a.q_stride_b = Sq, Bq, Nk, Bk, H, qs, qb
+            out, probs = torch.full((Sq * Bq, H), float("nan"), device=DEV), torch.full((Bq, Sq, Nk), float("nan"), device=DEV)
+            qstats, ostats = torch.full((Sq * Bq, 2), float("nan"), device=DEV), torch.full((Sq * Bq, 2), float("nan"), device=DEV)
+            a.x, a.kvhat, a.gamma0, a.beta0 = xf.data_ptr(), kvf.data_ptr(), gf.data_ptr(), bf.data_ptr()
+            a.out, a.probs, a.qstats, a.out_stats = out.data_ptr(), probs.data_ptr(), qstats.data_ptr(), ostats.data_ptr()
+            a.drop_mask = mask.data_ptr() if mask is not None else None
+            o.attention_fwd(a)
+            dx = torch.full((Sq * Bq, H), float("nan"), device=DEV)
+            dkv = base.clone()
+            part = torch.full((Bq * nqt + Bk * nkt, 2 * H), float("nan"), device=DEV)
+            kvp = torch.full((Bq * nqt * Nk, H), float("nan"), device=DEV)
+            a.dout, a.dx, a.dscores, a.dkvhat, a.dkv_accumulate = dout.data_ptr(), dx.data_ptr(), None, dkv.data_ptr(), 1
+            a.partials_q, a.partials_kv = part.data_ptr(), part.data_ptr() + 4 * Bq * nqt * 2 * H
+            a.dkv_part, a.dkv_cnt = kvp.data_ptr(), o.COUNTERS.take(DEV, Bk)
+            outs = []
+            for _ in range(2):
+                dkv.copy_(base)
+                o.attention_bwd(a)
+                torch.cuda.synchronize()
+                outs.append((dx.clone(), dkv.clone(), part.clone()))
+            assert all(torch.equal(u, v) for u, v in zip(*outs))
+            return out, probs, qstats, ostats, dx, dkv - base, part
+        finally:
+            lib.dosx_attention_aligned_mode(prev)
+
+    new, old = run(2), run(0)
+    for out, probs, qstats, ostats, dx, dkv, part in (new, old):
+        assert err(out, ref) < 3e-5 and err(probs, pref) < 3e-5
+        assert err(ostats[:, 0], ref.detach().mean(1)) < 5e-5
+        assert err(ostats[:, 1], 1 / torch.sqrt(ref.detach().var(1, unbiased=False) + 1e-5)) < 5e-5
+        ps = part.double().sum(0)
+        dxr = dx.double().reshape(Sq, Bq, H).sum(1) if bcast else dx
+        assert err(dxr, x.grad) < 5e-5 and err(dkv, kv.grad) < 5e-5
+        assert err(ps[:H], gam.grad) < 5e-5 and err(ps[H:], bet.grad) < 5e-5
+    assert err(new[2], old[2]) < 1e-5               # the LayerNorm-0 statistics of the query rows

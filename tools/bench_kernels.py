@@ -123,6 +123,17 @@ def attn_case(name, Sq, Bq, Nk, Bk, H):
         a.dkv_part = kvp.data_ptr()
         usp = timeit(lambda: ops.attention_bwd(a))
         note = f" | bwd(dq + in-kernel dK/dV partials + reduce) {usp:7.1f} us {2.5 * fl / usp / 1e6:6.2f} TF/s"
+        # the ONE-launch form of the training step (counters), and the crystal-aligned kernels behind the same two entry points
+        # (csrc/attention_aligned.hip; mode 2 = every shape they take, 0 = attention.hip's kernels)
+        lib = _lib.load()
+        a.dkv_cnt = ops.COUNTERS.take(DEV, Bk)
+        res = {}
+        for mode in (0, 2):
+            prev = lib.dosx_attention_aligned_mode(mode)
+            res[mode] = (timeit(lambda: ops.attention_fwd(a)), timeit(lambda: ops.attention_bwd(a)))
+            lib.dosx_attention_aligned_mode(prev)
+        note += (f" || one launch: fwd {res[0][0]:6.1f} bwd {res[0][1]:6.1f} us | crystal-aligned tiles: fwd {res[2][0]:6.1f} us "
+                 f"({100 * fl / res[2][0] / 1e6 / 157.3:4.1f}%) bwd {res[2][1]:6.1f} us ({100 * 2.5 * fl / res[2][1] / 1e6 / 157.3:4.1f}%)")
     print(f"attn  {name:30s} Sq={Sq} Bq={Bq} Nk={Nk} H={H}: fwd {us:7.1f} us {fl / us / 1e6:6.2f} TF/s "
           f"({100 * fl / us / 1e6 / 157.3:4.1f}%) | bwd(dq+streamed dkv) {usb:7.1f} us {2.5 * fl / usb / 1e6:6.2f} TF/s" + note)
 
@@ -373,7 +384,9 @@ def main():
         attn_case("phonon cross (energies->atoms)", 51, 64, 12, 64, 128)
         attn_case("phonon cross 2B", 51, 128, 12, 64, 128)
         attn_case("phonon self 2B", 51, 128, 51, 128, 128)
+        attn_case("eDOS cross B", 201, 64, 41, 64, 256)
         attn_case("eDOS cross 2B", 201, 128, 41, 64, 256)
+        attn_case("eDOS cross 2B, 64 atoms", 201, 128, 64, 64, 256)
         attn_case("eDOS self 2B", 201, 128, 201, 128, 256)
         attn_case("roofline scale self", 201, 2048, 201, 2048, 256)
 
