@@ -85,6 +85,7 @@ class Attn(C.Structure):
         ("dout", C.c_void_p), ("dx", C.c_void_p), ("dscores", C.c_void_p), ("dkvhat", C.c_void_p),
         ("dkv_accumulate", C.c_int32),
         ("partials_q", C.c_void_p), ("partials_kv", C.c_void_p), ("drop_mask", C.c_void_p), ("dkv_part", C.c_void_p), ("dkv_cnt", C.c_void_p),
+        ("ln1_gamma", C.c_void_p), ("ln1_beta", C.c_void_p), ("ln1_out", C.c_void_p),
     ]
 
 

@@ -581,6 +581,23 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const DosxAttn a) 
           a.out_stats[2 * ((size_t)s * a.Bq + bq) + 1] = rsqrtf(var[p] + DOSX_LN_EPS);
         }
       }
+      if (a.ln1_out) {      // the next LayerNorm on the rows still in registers (DosxAttn.ln1_*)
+#pragma unroll
+        for (int k = 0; k < KCB; ++k) {
+          const int c = q16 * 4 + 64 * k;
+          if (c >= H) continue;
+          const float4 g1 = ld4(a.ln1_gamma + c), b1 = ld4(a.ln1_beta + c);
+#pragma unroll
+          for (int p = 0; p < RP; ++p) {
+            const int s = s0 + row_of(wave, p, lane);
+            const float m = mean[p], rs = rsqrtf(var[p] + DOSX_LN_EPS);
+            if (s < Sq)
+              st4(a.ln1_out + ((size_t)s * a.Bq + bq) * H + c,
+                  make_float4((o[p][k].x - m) * rs * g1.x + b1.x, (o[p][k].y - m) * rs * g1.y + b1.y,
+                              (o[p][k].z - m) * rs * g1.z + b1.z, (o[p][k].w - m) * rs * g1.w + b1.w));
+          }
+        }
+      }
     }
   }
 }
@@ -1322,6 +1339,8 @@ extern "C" int dosx_attention_fwd(const DosxAttn* ap, dosx_stream_t stream) {
   const DosxAttn& a = *ap;
   if (int rc = check_attn(a, "dosx_attention_fwd")) return rc;
   DOSX_CHECK_ARG(a.out, "dosx_attention_fwd: null out");
+  DOSX_CHECK_ARG(!a.ln1_out || (a.out_stats && a.ln1_gamma && a.ln1_beta && a.Nk <= MAX_FUSED_NK && !(a.flags & DOSX_ATTN_NO_RESIDUAL)),
+                 "dosx_attention_fwd: ln1_out needs out_stats, ln1_gamma / ln1_beta, <= %d keys and the residual", MAX_FUSED_NK);
   if (const int rc = dosx_detail::attn_aligned_fwd(a, to_stream(stream))) return rc < 0 ? rc : 0;
   if (a.Nk > MAX_FUSED_NK) return dosx_detail::attn_general_fwd(a, to_stream(stream));
   const Geo g = make_geo(a.H, a.Nk);

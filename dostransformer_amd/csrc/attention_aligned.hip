@@ -197,6 +197,16 @@ __global__ __launch_bounds__(512) void attn_al_fwd_kernel(const DosxAttn a, cons
         }
         const float rstd1 = rsqrtf(row16_sum(u) * invH + DOSX_LN_EPS);
         if (rv && q16 == 0) { a.out_stats[2 * r] = mean1; a.out_stats[2 * r + 1] = rstd1; }
+        if (a.ln1_out && rv) {         // the next LayerNorm on the row still in registers (DosxAttn.ln1_*)
+#pragma unroll
+          for (int k = 0; k < NG; ++k) {
+            const int c = q16 * 4 + 64 * k;
+            const float4 g1 = ld4(a.ln1_gamma + c), b1 = ld4(a.ln1_beta + c);
+            st4(a.ln1_out + r * H + c,
+                make_float4((x1[k].x - mean1) * rstd1 * g1.x + b1.x, (x1[k].y - mean1) * rstd1 * g1.y + b1.y,
+                            (x1[k].z - mean1) * rstd1 * g1.z + b1.z, (x1[k].w - mean1) * rstd1 * g1.w + b1.w));
+          }
+        }
       }
       if (rv && q16 == 0) { a.qstats[2 * r] = mean; a.qstats[2 * r + 1] = rstd; }
     }
@@ -569,10 +579,11 @@ __global__ __launch_bounds__(512) void attn_al_bwd_kernel(const DosxAttn a, cons
 
 int g_al_mode = -1;
 inline int al_mode() {
-  // DOSX_ATTN_ALIGNED: 0 = never, 1 = hidden > 128 only (default: where the layer's feed-forward half is not fused), 2 = every shape
+  // DOSX_ATTN_ALIGNED: 0 = never, 1 = hidden > 128 only, 2 = every shape these kernels take (default: faster than attention.hip's
+  // at every BASELINE shape with <= 64 keys, profiles/r05_kernel_microbench.log `attn`)
   if (g_al_mode < 0) {
     const char* e = getenv("DOSX_ATTN_ALIGNED");
-    g_al_mode = e ? atoi(e) : 1;
+    g_al_mode = e ? atoi(e) : 2;
   }
   return g_al_mode;
 }

@@ -659,7 +659,16 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
             r_al = 16 if Bq * ((Sq + 31) // 32) <= 128 else 32
             if Bq * ((Sq + r_al - 1) // r_al) <= _ATT_ALIGNED_MAX_WGS and not (att_fused and _ATT_ROWS_FIRST):
                 att_fused = att_aligned = True
+        xln = None
         if not att_fused:
+            if _LN1_IN_ATTN and not ops.ffn_supported(H) and Nk <= 320:
+                # unfused feed-forward half (hidden > 128): the attention kernel also writes LN1 of its output rows - they are
+                # in its registers with their statistics - and fc1 reads a plain operand instead of normalising its A tile in the
+                # prologue of every one of its 4H / 128 column tiles (M = 25728: 163 -> 139 us, DosxAttn.ln1_out)
+                xln = _empty(dev, rows, H)
+                a.ln1_gamma, a.ln1_beta = P[lp + ".layer_norms.1.weight"].data_ptr(), P[lp + ".layer_norms.1.bias"].data_ptr()
+                a.ln1_out = xln.data_ptr()
+                x1._dosx_ln1 = xln             # (eager mode: lives as long as the saved x1; the tail rows read it on the side stream)
             ops.attention_fwd(a)
         h = _empty(dev, rows, 4 * H)
         x2 = _empty(dev, rows, H)
@@ -683,10 +692,13 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
                         P[lp + ".layer_norms.1.bias"], P[lp + ".fc1.weight"], P[lp + ".fc1.bias"], P[lp + ".fc2.weight"],
                         P[lp + ".fc2.bias"], h, x2, fin=fin_args, att=att_args)
         else:
-            def ffn_rows(r0, r1, x1=x1, st1=st1, h=h, x2=x2, lp=lp):
-                ops.gemm(r1 - r0, 4 * H, [seg(x1[r0:r1])], P[lp + ".fc1.weight"], h[r0:r1], pro=PRO_ROWLN,
-                         pro_gamma=P[lp + ".layer_norms.1.weight"], pro_beta=P[lp + ".layer_norms.1.bias"], pro_stats=st1[r0:r1],
-                         bias=P[lp + ".fc1.bias"], act=ACT_RELU)
+            def ffn_rows(r0, r1, x1=x1, st1=st1, h=h, x2=x2, lp=lp, xln=xln):
+                if xln is not None:
+                    ops.gemm(r1 - r0, 4 * H, [seg(xln[r0:r1])], P[lp + ".fc1.weight"], h[r0:r1], bias=P[lp + ".fc1.bias"], act=ACT_RELU)
+                else:
+                    ops.gemm(r1 - r0, 4 * H, [seg(x1[r0:r1])], P[lp + ".fc1.weight"], h[r0:r1], pro=PRO_ROWLN,
+                             pro_gamma=P[lp + ".layer_norms.1.weight"], pro_beta=P[lp + ".layer_norms.1.bias"], pro_stats=st1[r0:r1],
+                             bias=P[lp + ".fc1.bias"], act=ACT_RELU)
                 ops.gemm(r1 - r0, H, [seg(h[r0:r1])], P[lp + ".fc2.weight"], x2[r0:r1], bias=P[lp + ".fc2.bias"], res=x1[r0:r1])
             mt = _ffn_tail_start(rows, H)
             if mt:
@@ -729,6 +741,7 @@ def _ffn_tail_start(rows: int, H: int) -> int:
 
 
 _FUSED_FFN_BWD = __import__("os").environ.get("DOSX_FUSED_FFN_BWD", "1") == "1"
+_LN1_IN_ATTN = __import__("os").environ.get("DOSX_LN1_IN_ATTN", "1") == "1"
 _FACTOR_EDGE_WGRAD = __import__("os").environ.get("DOSX_FACTOR_EDGE_WGRAD", "1") == "1"   # EdgeModel first Linear factored into node / edge parts
 _FACTOR_FUSED = __import__("os").environ.get("DOSX_FACTOR_FUSED", "1") == "1"               # ... with the gathers / node sums inside dosx_gemm's epilogues (round 5)
 _EDGE_ONE_LAUNCH = __import__("os").environ.get("DOSX_EDGE_ONE_LAUNCH", "1") == "1"       # ... and the whole EdgeModel forward as one launch (H <= 128)

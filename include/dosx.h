@@ -407,14 +407,21 @@ typedef struct DosxAttn {
                           backward is then ONE launch: the last query-tile workgroup of a key crystal to arrive (ticket)
                           sums the partial key gradients of that crystal and writes dkvhat / partials_kv itself, in the
                           reduction kernel's order (bitwise the two-launch result).  Excludes the SKIP_DQ / SKIP_DKV flags */
+  /* forward only, optional (round 5; needs out_stats, <= 320 keys): the layer's NEXT LayerNorm applied to the output rows while
+   * they are in registers - ln1_out[r] = (out[r] - mean) * rstd * ln1_gamma + ln1_beta (layers/transformer.py:141: the input of
+   * fc1) - so that the fc1 GEMM of a layer whose feed-forward half is not fused reads a plain A operand instead of normalising
+   * it in its prologue for every one of its column tiles (hidden 256, M = 25728: 163 -> 139 us) */
+  const float* ln1_gamma;
+  const float* ln1_beta;
+  float* ln1_out;      /* [Sq*Bq, H] */
 } DosxAttn;
 /* 1 if dosx_attention_bwd takes the partial-dKV path for this key count / width when dkv_part is given (else it needs
  * dscores and runs the streamed dkv kernel) */
 int dosx_attention_pkv_supported(int Nk, int H);
 /* Which shapes dosx_attention_fwd / dosx_attention_bwd (one-launch form: dkv_part + dkv_cnt) route to the crystal-aligned
- * kernels (csrc/attention_aligned.hip: flags 0, Nk <= 64, H in {64, 128, 256}): 0 = none, 1 = H > 128 only (the default, also
- * from the environment variable DOSX_ATTN_ALIGNED: where the layer's feed-forward half cannot share the launch), 2 = all of
- * them (tests).  Sets the mode unless `mode` < 0; returns the previous one. */
+ * kernels (csrc/attention_aligned.hip: flags 0, Nk <= 64, H in {64, 128, 256}): 0 = none (attention.hip's kernels), 1 = H > 128
+ * only, 2 = all of them (the default; also from the environment variable DOSX_ATTN_ALIGNED).  Sets the mode unless `mode` < 0;
+ * returns the previous one. */
 int dosx_attention_aligned_mode(int mode);
 int dosx_attention_fwd(const DosxAttn* a, dosx_stream_t stream);
 int dosx_attention_bwd(const DosxAttn* a, dosx_stream_t stream);

@@ -460,6 +460,7 @@ def test_attention_on_crystal_aligned_tiles(Sq, Bq, Nk, Bk, H, bcast, drop):
     xf, kvf, gf, bf = f(x), f(kv), f(gam), f(bet)
     nqt, nkt = (Sq + 31) // 32, (Nk + 15) // 16
     base = rnd(Nk * Bk, H, seed=6)
+    g1, b1 = 1 + 0.2 * rnd(H, seed=7), 0.3 * rnd(H, seed=8)
 
     def run(mode):
         prev = lib.dosx_attention_aligned_mode(mode)
@@ -471,7 +472,10 @@ def test_attention_on_crystal_aligned_tiles(Sq, Bq, Nk, Bk, H, bcast, drop):
             a.x, a.kvhat, a.gamma0, a.beta0 = xf.data_ptr(), kvf.data_ptr(), gf.data_ptr(), bf.data_ptr()
             a.out, a.probs, a.qstats, a.out_stats = out.data_ptr(), probs.data_ptr(), qstats.data_ptr(), ostats.data_ptr()
             a.drop_mask = mask.data_ptr() if mask is not None else None
+            ln1 = torch.full((Sq * Bq, H), float("nan"), device=DEV)      # DosxAttn.ln1_*: the layer's next LayerNorm on the output rows
+            a.ln1_gamma, a.ln1_beta, a.ln1_out = g1.data_ptr(), b1.data_ptr(), ln1.data_ptr()
             o.attention_fwd(a)
+            assert err(ln1, torch.nn.functional.layer_norm(ref.detach(), (H,), g1.double(), b1.double(), 1e-5)) < 5e-5
             dx = torch.full((Sq * Bq, H), float("nan"), device=DEV)
             dkv = base.clone()
             part = torch.full((Bq * nqt + Bk * nkt, 2 * H), float("nan"), device=DEV)
@@ -500,3 +504,34 @@ def test_attention_on_crystal_aligned_tiles(Sq, Bq, Nk, Bk, H, bcast, drop):
         assert err(dxr, x.grad) < 5e-5 and err(dkv, kv.grad) < 5e-5
         assert err(ps[:H], gam.grad) < 5e-5 and err(ps[H:], bet.grad) < 5e-5
     assert err(new[2], old[2]) < 1e-5               # the LayerNorm-0 statistics of the query rows
+
+
+@pytest.mark.parametrize("Sq,Bq,Nk,H", [(201, 3, 201, 256), (70, 3, 70, 128), (51, 4, 12, 128)])
+def test_attention_forward_also_writes_the_next_layernorm(Sq, Bq, Nk, H):
+    """DosxAttn.ln1_out on attention.hip's kernels (more than 64 keys: the 201-key Electron-DOS self attention; mode 0 for the
+    small shape): LN1 of the output rows == F.layer_norm of the rows the same call writes; refused beyond 320 keys."""
+    from dostransformer_amd import _lib
+    from dostransformer_amd._lib import Attn, DosxError
+    o = ops()
+    lib = _lib.load()
+    x, kv, gam, bet = rnd(Sq * Bq, H, seed=1), rnd(Nk * Bq, H, seed=2), rnd(H, seed=3), 0.3 * rnd(H, seed=4)
+    g1, b1 = 1 + 0.2 * rnd(H, seed=7), 0.3 * rnd(H, seed=8)
+    a = Attn()
+    a.Sq, a.Bq, a.Nk, a.Bk, a.H, a.q_stride_s, a.q_stride_b = Sq, Bq, Nk, Bq, H, Bq, 1
+    out, probs = torch.empty(Sq * Bq, H, device=DEV), torch.empty(Bq, Sq, Nk, device=DEV)
+    qstats, ostats = torch.empty(Sq * Bq, 2, device=DEV), torch.empty(Sq * Bq, 2, device=DEV)
+    ln1 = torch.full((Sq * Bq, H), float("nan"), device=DEV)
+    a.x, a.kvhat, a.gamma0, a.beta0 = x.data_ptr(), kv.data_ptr(), gam.data_ptr(), bet.data_ptr()
+    a.out, a.probs, a.qstats, a.out_stats = out.data_ptr(), probs.data_ptr(), qstats.data_ptr(), ostats.data_ptr()
+    a.ln1_gamma, a.ln1_beta, a.ln1_out = g1.data_ptr(), b1.data_ptr(), ln1.data_ptr()
+    prev = lib.dosx_attention_aligned_mode(0)
+    try:
+        o.attention_fwd(a)
+    finally:
+        lib.dosx_attention_aligned_mode(prev)
+    assert err(ln1, torch.nn.functional.layer_norm(out.double(), (H,), g1.double(), b1.double(), 1e-5)) < 2e-5
+    a.Nk = 330
+    big_kv, big_p = rnd(330 * Bq, H, seed=2), torch.empty(Bq, Sq, 330, device=DEV)
+    a.kvhat, a.probs = big_kv.data_ptr(), big_p.data_ptr()
+    with pytest.raises(DosxError, match="ln1_out"):
+        o.attention_fwd(a)

@@ -359,6 +359,7 @@ def main():
     if w == "edosffn":      # the four feed-forward GEMMs of the Electron-DOS step (tile-policy experiments: DOSX_GEMM_RT / _BN)
         for M_ in (201 * 128, 24576, 201 * 64):
             gemm_case("eDOS fc1 fwd (rowLN pro)", M_, 1024, 256, pro=ops.PRO_ROWLN)
+            gemm_case("eDOS fc1 fwd, plain A", M_, 1024, 256)
             gemm_case("eDOS fc2 fwd", M_, 256, 1024)
             gemm_case("eDOS fc2 dgrad (dy->dh)", M_, 1024, 256, wl=1)
             gemm_case("eDOS fc1 dgrad (dh->dx)", M_, 256, 1024, wl=1)
