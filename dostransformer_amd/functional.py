@@ -742,6 +742,7 @@ def _ffn_tail_start(rows: int, H: int) -> int:
 
 _FUSED_FFN_BWD = __import__("os").environ.get("DOSX_FUSED_FFN_BWD", "1") == "1"
 _LN1_IN_ATTN = __import__("os").environ.get("DOSX_LN1_IN_ATTN", "1") == "1"
+_LN1_WGRAD = __import__("os").environ.get("DOSX_LN1_WGRAD", "0") == "1"     # (measured: 7.033 vs 7.036 ms - nothing; off)
 _FACTOR_EDGE_WGRAD = __import__("os").environ.get("DOSX_FACTOR_EDGE_WGRAD", "1") == "1"   # EdgeModel first Linear factored into node / edge parts
 _FACTOR_FUSED = __import__("os").environ.get("DOSX_FACTOR_FUSED", "1") == "1"               # ... with the gathers / node sums inside dosx_gemm's epilogues (round 5)
 _EDGE_ONE_LAUNCH = __import__("os").environ.get("DOSX_EDGE_ONE_LAUNCH", "1") == "1"       # ... and the whole EdgeModel forward as one launch (H <= 128)
@@ -866,8 +867,12 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: Optional[torch.Tensor],
             if fm is not None and fm[1] is not None:       # h is the dropped activation: [h > 0] = [relu > 0][M2 > 0]; x 1/(1-p)
                 ops.mask_residual(dh, fm[1], None, dh, None, rows, 4 * H)
         # fc1 (+ LN1 backward + residual)
-        _wgrad_linear(sink, G, lp + ".fc1.weight", lp + ".fc1.bias", rows, 4 * H, seg(dh), [seg(x1)], keep=(dh,),
-                      pro=PRO_ROWLN, pro_gamma=g1, pro_beta=b1, pro_stats=st1)
+        xln = getattr(x1, "_dosx_ln1", None) if _LN1_WGRAD else None
+        if xln is not None:         # the forward left LN1(x1) behind (DosxAttn.ln1_out): a plain operand for the weight gradient too
+            _wgrad_linear(sink, G, lp + ".fc1.weight", lp + ".fc1.bias", rows, 4 * H, seg(dh), [seg(xln)], keep=(dh, xln))
+        else:
+            _wgrad_linear(sink, G, lp + ".fc1.weight", lp + ".fc1.bias", rows, 4 * H, seg(dh), [seg(x1)], keep=(dh,),
+                          pro=PRO_ROWLN, pro_gamma=g1, pro_beta=b1, pro_stats=st1)
         if not fused:
             rgp = ops.gemm_partial_rows(rows, H, EPI_ROWLN_BWD)
             part = sink.scratch(rgp, 2 * H)
