@@ -209,7 +209,7 @@ def mlp_ln_fwd(P: Params, key: str, a: SegList, M: int, H: int, res: Optional[to
     dev = P[key + ".0.weight"].device
     xhat = _empty(dev, M, 2 * H)
     rstd = _empty(dev, M)
-    if segsum is None and _mlp_ln_fused(a, M, H):
+    if segsum is None and a.plain is not None and len(a.plain) <= 2 and ops.mlp_ln_fwd_supported(M, a.K, 2 * H, H):
         # a few hundred rows (the NodeModel: one row per atom): both Linear layers in ONE launch, the intermediate in LDS
         y = _empty(dev, M, H)
         ops.mlp_ln_fwd(M, a.plain[0], a.plain[1] if len(a.plain) > 1 else None, P[key + ".0.weight"], P[key + ".0.bias"],

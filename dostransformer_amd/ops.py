@@ -497,6 +497,9 @@ def ffn_bwd(M: int, H: int, dy: torch.Tensor, h: torch.Tensor, x: torch.Tensor, 
 
 MLP_LN_MAX_ROWS = int(__import__("os").environ.get("DOSX_MLP_LN_MAX_ROWS", "4096"))
 MLP_LN_MAX_KN = int(__import__("os").environ.get("DOSX_MLP_LN_MAX_KN", str(256 * 256)))
+# the FORWARD kernel alone also at hidden 256 (round 5: weight chunks four deep - 37.4 us against 30 + 13.5 + a launch gap for the
+# two GEMMs at 1554 rows; the backward stays on its two GEMMs there: 39.7 against 35.0)
+MLP_LN_MAX_KN_FWD = int(__import__("os").environ.get("DOSX_MLP_LN_MAX_KN_FWD", str(512 * 512)))
 
 
 def mlp_ln_supported(M: int, K: int, NH: int, NO: int) -> bool:
@@ -505,6 +508,11 @@ def mlp_ln_supported(M: int, K: int, NH: int, NO: int) -> bool:
     serial share of the weights is small (hidden <= 128: 13.7 + 14.5 us fwd + bwd against 2 x 2 launches of ~9.7 us at
     450 rows; at hidden 256 / 1554 rows the backward measured 42.9 against 33.9 us - tools/bench_kernels.py --what nmlp)."""
     return 0 < M <= MLP_LN_MAX_ROWS and K * NH <= MLP_LN_MAX_KN and bool(_lib.load().dosx_mlp_ln_supported(int(K), int(NH), int(NO)))
+
+
+def mlp_ln_fwd_supported(M: int, K: int, NH: int, NO: int) -> bool:
+    """... for the forward launch alone (the backward of the same block may run as two GEMMs: same saved tensors)."""
+    return 0 < M <= MLP_LN_MAX_ROWS and K * NH <= MLP_LN_MAX_KN_FWD and bool(_lib.load().dosx_mlp_ln_supported(int(K), int(NH), int(NO)))
 
 
 def mlp_ln_fwd(M: int, a0: torch.Tensor, a1: Optional[torch.Tensor], w1, b1, gamma, beta, alpha, w2, b2,

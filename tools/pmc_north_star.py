@@ -10,6 +10,9 @@
                     count NJ = 1 kernels are the 12-key Phonon-DOS cross attention, NJ = 4 at 2 query tiles x 128 entries the
                     51-key Phonon-DOS self attention, NJ = 3 / 4 at 7 query tiles the 41-key Electron-DOS cross attention,
                     NJ = 13 at 7 x 128 the 201-key Electron-DOS self attention (the roofline-scale launches are left out).
+                    `*_aligned`: the same shape classes on the crystal-aligned kernels of csrc/attention_aligned.hip (round 5:
+                    what dosx_attention_fwd / bwd run for <= 64 keys; the unsuffixed classes are attention.hip's kernels,
+                    which the microbenchmark still times through dosx_attention_aligned_mode(0)).
 
 The file carries the hash of the sources it was measured on (dostransformer_amd._lib.source_hash); bench.py reports the
 figures only while that hash is the hash of the sources it runs - like roofline.traffic.
@@ -31,12 +34,35 @@ def attn_classes(path):
     for r in csv.DictReader(open(path)):
         d = rows[r["Dispatch_Id"]]
         d["name"], d["grid"] = r["Kernel_Name"], int(r["Grid_Size"])
+        d["lds"] = int(r.get("LDS_Block_Size", 0) or 0)
         d["ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     agg = defaultdict(lambda: [0.0, 0.0, 0])
     for d in rows.values():
+        if d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) <= 0:
+            continue
+        # round 5: the crystal-aligned kernels (attention_aligned.hip; bench_kernels.py runs both forms).  NG = hidden / 64:
+        # 4 = the Electron-DOS cross attention (41 / 64 keys), 2 = Phonon-DOS, told apart by the LDS size (64 key rows resident
+        # for the 51-key self attention: forward 59392 B with one score tile, backward > 80 KB; 16 key rows for the 12-key cross)
+        m = re.search(r"attn_al_(fwd|bwd)_kernel<(\d+)", d["name"])
+        if m:
+            ng, lds, wgs = int(m.group(2)), d.get("lds", 0), d["grid"] // 512
+            if wgs > 512:
+                continue
+            if ng == 4:
+                cls = "edos_cross_aligned"
+            elif ng == 2:
+                self_ = (lds == 59392) if m.group(1) == "fwd" else (lds > 80000)
+                cls = "cfg2_self_aligned" if self_ else "cfg2_cross_aligned"
+            else:
+                continue
+            a = agg[cls]
+            a[0] += d["SQ_VALU_MFMA_BUSY_CYCLES"]
+            a[1] += d["ns"]
+            a[2] += 1
+            continue
         m = re.search(r"attn_(fwd_stream|bwd_dq_stream|bwd_dkv)_kernel<(\d+)", d["name"])
-        if not m or d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) <= 0:
+        if not m:
             continue
         nj, wgs = int(m.group(2)), d["grid"] // 512
         if m.group(1) == "bwd_dkv":
