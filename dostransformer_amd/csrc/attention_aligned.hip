@@ -20,6 +20,17 @@
 #include "common.h"
 #include "mma16.h"
 
+#ifdef DOSX_STAMPS
+__device__ unsigned long long dosx_al_stamp_buf[64];
+extern "C" int dosx_debug_read_attn_aligned_stamps(unsigned long long* host64) {
+  return (int)hipMemcpyFromSymbol(host64, HIP_SYMBOL(dosx_al_stamp_buf), sizeof(unsigned long long) * 64);
+}
+// workgroup 0, wave 0: slot + 16 * (tile ordinal, first two tiles); slot 0 = kernel start, 15 = end (ordinal 3)
+#define ASTAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x == 0) dosx_al_stamp_buf[(slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ASTAMP(slot) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int R = 32;          // query rows per tile (one quarter wave per row)
@@ -27,6 +38,130 @@ constexpr int R = 32;          // query rows per tile (one quarter wave per row)
 struct AlGeo {
   int wpc, KS;
 };
+
+// The two product shapes of a tile as PIPELINED job streams (stamps of the first version, tools/stamp_attn_aligned.py: a wave's jobs
+// ran load-all-fragments -> wait -> MFMAs one after the other - 5.0-5.3 k clk per phase for 3.1 k clk of MFMA issue per SIMD):
+// the fragments of the NEXT (half-)job are requested before the MFMAs of the current one, two register sets.
+//
+// kk: C[r][j] = sum_k A[r][k] B[j][k] (scores, dP): both operands k-contiguous rows of pitch LDK.  Unit (job, kq) = the 16 x 16
+// tile job = (rt, ct) over the k-blocks [kq HPU, (kq + 1) HPU) of 64, HPU = NG / KS; partial tile kq of Sc gets `scale` x its sum.
+// Units are dealt over the 8 waves; a wave walks its units k-block by k-block.
+template <int NG, int LDK>
+__device__ __forceinline__ void al_kk_phase(const float* __restrict__ As, const float* __restrict__ Ks, float* __restrict__ Sc,
+                                            const int nctS, const int njobsS, const int KS, const float scale, const int wave,
+                                            const int l15, const int g4) {
+  // (KS and HPU = NG / KS are powers of two, a tile has two row blocks: shifts and one compare - run-time integer divisions
+  //  cost ~40 instructions each, six per half-job were most of this phase's 5.5 k clk)
+  const int ksl = KS == 4 ? 2 : (KS == 2 ? 1 : 0), hpl = (NG == 4 ? 2 : (NG == 2 ? 1 : 0)) - ksl;
+  const int HPU = 1 << hpl, nunits = njobsS << ksl;
+  // unit = wave + 8 i: waves w and w + 4 share a SIMD, so a partial last round (12 units: waves 0-3) still gives every SIMD the
+  // same number of units (dealing the extra units to the even waves instead was measured: slower, 54.1 -> 56.9 us backward)
+  const int nmine = wave < nunits ? (nunits - wave + 7) >> 3 : 0;
+  const int nh = nmine << hpl;
+  if (nh == 0) return;
+  auto unit_of = [&](const int i) { return wave + 8 * i; };
+  auto req = [&](const int hj, float4(&fa)[4], float4(&fb)[4]) {
+    const int u = unit_of(hj >> hpl), kbi = hj & (HPU - 1);
+    const int job = u >> ksl, kq = u & (KS - 1), rt = job >= nctS ? 1 : 0, ct = job - rt * nctS;
+    const int k0 = 64 * ((kq << hpl) + kbi) + 4 * g4;
+    const float* Ap = As + (16 * rt + l15) * LDK + k0;
+    const float* Bp = Ks + (16 * ct + l15) * LDK + k0;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) { fa[st] = ld4(Ap + 16 * st); fb[st] = ld4(Bp + 16 * st); }
+  };
+  // TWO accumulator chains per wave (even / odd steps, added at the end of the unit): a wave that is alone on its SIMD - the
+  // waves with the extra unit of a partial round - cannot issue DEPENDENT MFMAs back to back
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+  auto mul = [&](const int hj, const float4(&fa)[4], const float4(&fb)[4]) {
+#pragma unroll
+    for (int st = 0; st < 4; st += 2) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[st].x, fb[st].x, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[st + 1].x, fb[st + 1].x, acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[st].y, fb[st].y, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[st + 1].y, fb[st + 1].y, acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[st].z, fb[st].z, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[st + 1].z, fb[st + 1].z, acc2, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[st].w, fb[st].w, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[st + 1].w, fb[st + 1].w, acc2, 0, 0, 0);
+    }
+    const int ui = hj >> hpl;
+    if ((hj & (HPU - 1)) == HPU - 1) {               // the unit's last k-block: its partial tile
+      const int u = unit_of(ui), job = u >> ksl, kq = u & (KS - 1), rt = job >= nctS ? 1 : 0, ct = job - rt * nctS;
+      float* Sp = Sc + kq * R * 68;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Sp[(16 * rt + 4 * g4 + i) * 68 + 16 * ct + l15] = (acc[i] + acc2[i]) * scale;
+      acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  float4 a0[4], b0[4], a1[4], b1[4];
+  req(0, a0, b0);
+  for (int hj = 0; hj < nh; hj += 2) {
+    if (hj + 1 < nh) req(hj + 1, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    mul(hj, a0, b0);
+    if (hj + 1 >= nh) break;
+    if (hj + 2 < nh) req(hj + 2, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    mul(hj + 1, a1, b1);
+  }
+}
+
+// kn: C[r][c] = sum_j A[r][j] B[j][c] (P.K, dS.K): A = [R][68] rows (j-contiguous), B = the key rows ([j][LDK], four ds_read_b32 per
+// step), NkP / 16 steps of 16 keys per job; the 2 x H / 16 jobs are dealt over the 8 waves, output rows of pitch LDK.
+template <int NG, int LDK, bool PIPE = true>
+__device__ __forceinline__ void al_kn_phase(const float* __restrict__ Ss, const float* __restrict__ Ks, float* __restrict__ Os,
+                                            const int nsteps, const int wave, const int l15, const int g4) {
+  constexpr int nct = 4 * NG, njobs = (R / 16) * nct, NJ = njobs / 8;       // NJ = NG jobs per wave
+  auto req = [&](const int i, float4(&fa)[4], float(&fb)[4][4]) {
+    const int job = wave + 8 * i, rt = job / nct, ct = job - rt * nct;
+    const float* Ap = Ss + (16 * rt + l15) * 68 + 4 * g4;
+    const float* Bp = Ks + (4 * g4) * LDK + 16 * ct + l15;
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+      if (st < nsteps) {
+        fa[st] = ld4(Ap + 16 * st);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[st][j] = Bp[(16 * st + j) * LDK];
+      }
+  };
+  auto mul = [&](const int i, const float4(&fa)[4], const float(&fb)[4][4]) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+      if (st < nsteps) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[st].x, fb[st][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[st].y, fb[st][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[st].z, fb[st][2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[st].w, fb[st][3], acc, 0, 0, 0);
+      }
+    const int job = wave + 8 * i, rt = job / nct, ct = job - rt * nct;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Os[(16 * rt + 4 * g4 + r) * LDK + 16 * ct + l15] = acc[r];
+  };
+  float4 a0[4], a1[4];
+  float b0[4][4], b1[4][4];
+  if constexpr (!PIPE) {               // (the backward kernel at hidden 256 has no registers for the second set)
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+      req(i, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      mul(i, a0, b0);
+    }
+    return;
+  }
+  req(0, a0, b0);
+#pragma unroll
+  for (int i = 0; i < NJ; i += 2) {
+    if (i + 1 < NJ) req(i + 1, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    mul(i, a0, b0);
+    if (i + 1 >= NJ) break;
+    if (i + 2 < NJ) req(i + 2, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    mul(i + 1, a1, b1);
+  }
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // forward
@@ -61,6 +196,7 @@ __global__ __launch_bounds__(512) void attn_al_fwd_kernel(const DosxAttn a, cons
 #pragma unroll
     for (int k = 0; k < NG; ++k) x[k] = on[k] ? ld4(xrow + q16 * 4 + 64 * k) : f4zero();
   };
+  ASTAMP(0);
   float4 xr[NG], xn[NG];
   load_x(w, xr);
   {   // the crystal's key rows -> Ks (rows beyond Nk zero), behind the first tile's rows
@@ -107,17 +243,15 @@ __global__ __launch_bounds__(512) void attn_al_fwd_kernel(const DosxAttn a, cons
       }
     }
     if (t + wpc < nqt) load_x(t + wpc, xn);           // the next tile's rows: in flight under this tile's products
+    const int so = t == w ? 0 : (t == w + wpc ? 16 : 48);     // (stamps of the first two tiles)
+    ASTAMP(so + 1);
     __syncthreads();
+    ASTAMP(so + 2);
     // ---- B: S = Qs . Ks^T (scaled); the K range split KS ways, partial tiles added in a fixed order by phase C ----
-    for (int unit = wave; unit < njobsS * KS; unit += 8) {
-      const int job = unit / KS, kq = unit - job * KS;
-      const int rt = job / nctS, ct = job - rt * nctS;
-      const f32x4 acc = mma_kk<8>(Qs + (16 * rt + l15) * LDK + kq * klen + 4 * g4, Ks + (16 * ct + l15) * LDK + kq * klen + 4 * g4, klen >> 4);
-      float* Sp = Sc + kq * R * 68;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) Sp[(16 * rt + 4 * g4 + i) * 68 + 16 * ct + l15] = acc[i] * scale;
-    }
+    al_kk_phase<NG, LDK>(Qs, Ks, Sc, nctS, njobsS, KS, scale, wave, l15, g4);
+    ASTAMP(so + 3);
     __syncthreads();
+    ASTAMP(so + 4);
     // ---- C: exact fp32 softmax of this quarter wave's row; P written out; P o mask -> Sc ----
     float psum = 1.f;
     {
@@ -159,18 +293,14 @@ __global__ __launch_bounds__(512) void attn_al_fwd_kernel(const DosxAttn a, cons
       }
       psum = a.drop_mask ? row16_sum(ps) : 1.f;
     }
+    ASTAMP(so + 5);
     __syncthreads();
+    ASTAMP(so + 6);
     // ---- D: O = (P o mask) . Ks -> Qs ----
-    {
-      constexpr int nct = H >> 4, njobs = (R / 16) * nct;
-      for (int job = wave; job < njobs; job += 8) {
-        const int rt = job / nct, ct = job - rt * nct;
-        const f32x4 acc = mma_kn<4>(Sc + (16 * rt + l15) * 68 + 4 * g4, Ks + (4 * g4) * LDK + 16 * ct + l15, LDK, NkP >> 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Qs[(16 * rt + 4 * g4 + i) * LDK + 16 * ct + l15] = acc[i];
-      }
-    }
+    al_kn_phase<NG, LDK>(Sc, Ks, Qs, NkP >> 4, wave, l15, g4);
+    ASTAMP(so + 7);
     __syncthreads();
+    ASTAMP(so + 8);
     // ---- E: x1 = O o g0 + b0 sum(P o mask) + x; both rows of statistics ----
     {
       float4 x1[NG];
@@ -212,9 +342,11 @@ __global__ __launch_bounds__(512) void attn_al_fwd_kernel(const DosxAttn a, cons
     }
     // (no barrier: phase A of the next tile writes only this quarter wave's own row of Qs, which phase E has just read; the
     //  other waves read Qs / Sc again only behind the next tile's first barrier)
+    ASTAMP(so + 9);
 #pragma unroll
     for (int k = 0; k < NG; ++k) xr[k] = xn[k];
   }
+  ASTAMP(63);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -335,6 +467,7 @@ __global__ __launch_bounds__(512) void attn_al_bwd_kernel(const DosxAttn a, cons
 #pragma unroll
     for (int k = 0; k < NG; ++k) go[k] = on[k] ? ld4(a.dout + orow * H + q16 * 4 + 64 * k) : f4zero();
   };
+  ASTAMP(0);
   float4 ngo[NG];                      // the NEXT tile's dO row (requested one tile ahead)
   load_go(w, ngo);
   {   // the crystal's key rows -> Ks
@@ -398,21 +531,15 @@ __global__ __launch_bounds__(512) void attn_al_bwd_kernel(const DosxAttn a, cons
       if (a.drop_mask) cq = row16_sum(u);
     }
     if (t + wpc < nqt) load_go(t + wpc, ngo);
+    const int so = t == w ? 0 : (t == w + wpc ? 16 : 48);
+    ASTAMP(so + 1);
     __syncthreads();
+    ASTAMP(so + 2);
     // ---- b: dP (up to a row constant) = Ds . Ks^T ----
-    for (int unit = wave; unit < njobsS * KS; unit += 8) {
-      const int job = unit / KS, kq = unit - job * KS;
-      const int rt = job / nctS, ct = job - rt * nctS;
-      const float* Ap = Ds + (16 * rt + l15) * LDK + kq * klen + 4 * g4;
-      const float* Bp = Ks + (16 * ct + l15) * LDK + kq * klen + 4 * g4;
-      const int n = klen >> 4;
-      f32x4 acc = mma_kk<4>(Ap, Bp, n);                    // (two halves of <= 4 steps: 32 fragment registers, not 64)
-      if (n > 4) acc = mma_kk<4>(Ap + 64, Bp + 64, n - 4, acc);
-      float* Sp = Sc + kq * R * 68;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) Sp[(16 * rt + 4 * g4 + i) * 68 + 16 * ct + l15] = acc[i];
-    }
+    al_kk_phase<NG, LDK>(Ds, Ks, Sc, nctS, njobsS, KS, 1.f, wave, l15, g4);
+    ASTAMP(so + 3);
     __syncthreads();
+    ASTAMP(so + 4);
     // ---- c: dS = P o (dP' - sum_j P dP') scale -> Ss;  P' = P o M -> Ps2 (zeros beyond Nk / the data); in place, row-wise ----
     {
       float dp[4], dot = 0.f;
@@ -446,18 +573,14 @@ __global__ __launch_bounds__(512) void attn_al_bwd_kernel(const DosxAttn a, cons
       for (int k = 0; k < NG; ++k) xr[k] = on[k] ? ld4(xrow + q16 * 4 + 64 * k) : f4zero();
     }
     const float mean = a.qstats[2 * orow], rstd = a.qstats[2 * orow + 1];
+    ASTAMP(so + 5);
     __syncthreads();
+    ASTAMP(so + 6);
     // ---- d: dq = dS . Ks -> Ds ----
-    {
-      constexpr int njobs = (R / 16) * nct;
-      for (int job = wave; job < njobs; job += 8) {
-        const int rt = job / nct, ct = job - rt * nct;
-        const f32x4 acc = mma_kn<4>(Ss + (16 * rt + l15) * 68 + 4 * g4, Ks + (4 * g4) * LDK + 16 * ct + l15, LDK, NkP >> 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Ds[(16 * rt + 4 * g4 + i) * LDK + 16 * ct + l15] = acc[i];
-      }
-    }
+    al_kn_phase<NG, LDK, (NG < 4)>(Ss, Ks, Ds, NkP >> 4, wave, l15, g4);
+    ASTAMP(so + 7);
     __syncthreads();
+    ASTAMP(so + 8);
     // ---- e: LayerNorm-0 backward on the query rows + residual -> dx; query-side dg0 / db0 (kept per row slot across the
     //         tiles); Ql = LN0(x) g0 + b0 over this quarter wave's own row of Ds ----
     {
@@ -494,7 +617,9 @@ __global__ __launch_bounds__(512) void attn_al_bwd_kernel(const DosxAttn a, cons
                : f4zero());
       }
     }
+    ASTAMP(so + 9);
     __syncthreads();
+    ASTAMP(so + 10);
     // ---- f: this workgroup's share of dK + dV += P'^T . dO + dS^T . Ql   ([NkP keys] x [R queries] . [R queries] x [H]) ----
 #pragma unroll
     for (int i = 0; i < NJW; ++i) {
@@ -522,8 +647,11 @@ __global__ __launch_bounds__(512) void attn_al_bwd_kernel(const DosxAttn a, cons
       }
       __builtin_amdgcn_sched_barrier(0);               // (one job's 32 fragments at a time: the unrolled jobs must not be merged)
     }
+    ASTAMP(so + 11);
     __syncthreads();                   // (the next tile's phase a overwrites Os / Ds)
+    ASTAMP(so + 12);
   }
+  ASTAMP(60);
   // ---- publish this workgroup's share (write-through) ----
   {
     float* part = a.dkv_part + ((size_t)bq * nqt + w) * (size_t)Nk * H;
@@ -562,6 +690,7 @@ __global__ __launch_bounds__(512) void attn_al_bwd_kernel(const DosxAttn a, cons
     }
   }
   // ---- ticket: the last arriving workgroup of key crystal bk finishes its key gradient ----
+  ASTAMP(61);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int* flag = reinterpret_cast<int*>(sm);
@@ -575,6 +704,7 @@ __global__ __launch_bounds__(512) void attn_al_bwd_kernel(const DosxAttn a, cons
     al_dkv_reduce<NG>(a, nqt, wpc, bk, sm, tid);
     if (tid == 0) __hip_atomic_store(a.dkv_cnt + bk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  ASTAMP(63);
 }
 
 int g_al_mode = -1;
@@ -601,10 +731,11 @@ inline AlGeo al_geo(const DosxAttn& a, const bool bwd) {
   if (g.wpc < 1) g.wpc = 1;
   if (g.wpc > nqt) g.wpc = nqt;
   const int njobsS = (R / 16) * (NkP >> 4);
+  // K split of the score / dP jobs over otherwise idle waves, in whole k-blocks of 64 (KS divides NG = H / 64)
   int KS = njobsS >= 8 ? 1 : (njobsS >= 4 ? 2 : 4);
   if (bwd && KS > 2) KS = 2;                               // (two partial tiles of LDS in the backward kernel)
-  while (a.H / KS > 128) KS *= 2;                          // a job holds <= 8 steps of 16 along k
-  while (KS > 1 && (a.H % (16 * KS)) != 0) KS >>= 1;
+  const int ng = a.H / 64;
+  while (KS > ng) KS >>= 1;
   g.KS = KS;
   return g;
 }
@@ -628,7 +759,6 @@ namespace dosx_detail {
 int attn_aligned_fwd(const DosxAttn& a, hipStream_t st) {
   if (!al_shape_ok(a)) return 0;
   const AlGeo g = al_geo(a, false);
-  if (a.H / g.KS > 128) return 0;
   const size_t smem = al_fwd_smem(a, g);
   if (smem > 160 * 1024) return 0;
   const dim3 grid(a.Bq * g.wpc);
@@ -654,7 +784,7 @@ int attn_aligned_fwd(const DosxAttn& a, hipStream_t st) {
 int attn_aligned_bwd(const DosxAttn& a, hipStream_t st) {
   if (!al_shape_ok(a) || !a.dkv_part || !a.dkv_cnt) return 0;
   const AlGeo g = al_geo(a, true);
-  if (g.KS > 2 || a.H / g.KS > 128) return 0;
+  if (g.KS > 2) return 0;
   const size_t smem = al_bwd_smem(a);
   if (smem > 160 * 1024 || (size_t)a.Bq * ceil_div(a.Sq, R) * a.Nk * a.H * 4 >= 0x7fffffffull) return 0;
   const dim3 grid(a.Bq * g.wpc);
