@@ -148,6 +148,8 @@ class MlpLn(C.Structure):
         ("res", C.c_void_p), ("ldres", C.c_int32),
         ("xhat", C.c_void_p), ("rstd", C.c_void_p),
         ("out", C.c_void_p), ("ldo", C.c_int32),
+        ("w3", C.c_void_p), ("ldw3", C.c_int32), ("n3", C.c_int32), ("nb3", C.c_int32),
+        ("pq", C.c_void_p), ("ldpq", C.c_int32),
     ]
 
 

@@ -285,18 +285,42 @@ __global__ __launch_bounds__(512) void mlp_ln_fwd_kernel(const DosxMlpLn a) {
       for (int r = 0; r < 4; ++r) Cs[(4 * g4 + r) * LDC + oc + l15] = acc[0][r];
     }
   }
+  // (third product: its first weight chunks are requested here, behind the second product's last ones)
+  NkStream<32, D, HC != 0> s3;
+  const bool third = a.w3 != nullptr;
+  if (third) s3.prefetch(a.w3, a.ldw3, wave * 32, NO, lane);
   __syncthreads();
   // ---- row epilogue (8 waves x 2 rows): out = C + b2 (+ res) ----
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int lr = wave * 2 + i, r = m0 + lr;
-    if (con && r < M) {
+    if (con) {
       const float4 v = ld4(Cs + lr * LDC + c0);
       const float4 rr = has_res ? rres[i] : f4zero();
-      st4(a.out + (size_t)r * a.ldo + c0, make_float4(v.x + bias2.x + rr.x, v.y + bias2.y + rr.y,
-                                                       v.z + bias2.z + rr.z, v.w + bias2.w + rr.w));
+      const float4 o = make_float4(v.x + bias2.x + rr.x, v.y + bias2.y + rr.y, v.z + bias2.z + rr.z, v.w + bias2.w + rr.w);
+      if (r < M) st4(a.out + (size_t)r * a.ldo + c0, o);
+      if (third) st4(Cs + lr * LDC + c0, o);         // the finished rows: A operand of the third product
     }
   }
+  if (!third) return;
+  __syncthreads();
+  // ---- third product (DosxMlpLn.w3): pq[:, b n3 + n] = out . w3[n, b NO + k]; 256-column blocks, two 16-column tiles per wave,
+  //      k over NO; C straight to HBM ----
+  for (int b = 0; b < a.nb3; ++b)
+    for (int blk = 0; blk * 256 < a.n3; ++blk) {
+      const int cb = blk * 256 + wave * 32;
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      if (b | blk) s3.prefetch(a.w3 + b * NO, a.ldw3, cb, NO, lane);
+      s3.run(acc, NO, Cs, LDC, Wp, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + 4 * g4 + r;
+        if (row < M) {
+          a.pq[(size_t)row * a.ldpq + b * a.n3 + cb + l15] = acc[0][r];
+          a.pq[(size_t)row * a.ldpq + b * a.n3 + cb + l15 + 16] = acc[1][r];
+        }
+      }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -490,6 +514,10 @@ extern "C" int dosx_mlp_ln_fwd(const DosxMlpLn* ap, dosx_stream_t stream) {
                  "dosx_mlp_ln_fwd: operands must be 16-byte aligned with leading dimensions that are multiples of 4");
   const long long span = (const char*)a.w1 > (const char*)a.w2 ? (const char*)a.w1 - (const char*)a.w2 : (const char*)a.w2 - (const char*)a.w1;
   DOSX_CHECK_ARG(span + (long long)4 * a.NH * (a.K + a.NO) < 0x7fffffffLL, "dosx_mlp_ln_fwd: the two weight matrices are more than 2 GiB apart");
+  if (a.w3)
+    DOSX_CHECK_ARG(a.pq && a.nb3 >= 1 && a.n3 >= 256 && a.n3 % 256 == 0 && (a.ldw3 & 3) == 0 && a.ldw3 >= a.nb3 * a.NO && aligned16(a.w3) &&
+                       a.ldpq >= a.nb3 * a.n3,
+                   "dosx_mlp_ln_fwd: third product needs pq, n3 a multiple of 256, ldw3 >= nb3 * NO (multiple of 4), ldpq >= nb3 * n3");
   const size_t smem = sizeof(float) * ((size_t)MR * (a.K + 4) + (size_t)MR * (a.NH + 4) + 8 * (size_t)WP_FLOATS);
   static bool attr_set = false;
   if (!attr_set) {

@@ -124,6 +124,9 @@ def mlp_prelu_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: G
 
 
 _ENC_BWD_PAIR = __import__("os").environ.get("DOSX_ENC_BWD_PAIR", "1") == "1"
+# the next layer's node products inside the NodeModel launch (DosxMlpLn.w3): measured 1.1014 vs 1.1018 ms at cfg2, 6.978 vs 6.963 ms
+# Electron-DOS (three / two interleaved pairs) - the launch it removes costs what the longer kernel adds; off
+_PQ_IN_NODE_MLP = __import__("os").environ.get("DOSX_PQ_IN_NODE_MLP", "0") == "1"
 
 
 def mlp_prelu_bwd_pair(P: Params, G: Params, first, second, sink: GradSink, tail: bool = False):
@@ -200,7 +203,8 @@ def mlp_ln_bwd_fused(a: SegList, M: int, H: int, dy: torch.Tensor) -> bool:
     return _mlp_ln_fused(a, M, H) and dy.stride(1) == 1
 
 
-def mlp_ln_fwd(P: Params, key: str, a: SegList, M: int, H: int, res: Optional[torch.Tensor] = None, segsum=None, aggsum=None):
+def mlp_ln_fwd(P: Params, key: str, a: SegList, M: int, H: int, res: Optional[torch.Tensor] = None, segsum=None, aggsum=None,
+               pq_next=None):
     """segsum = (seg_tile, rowptr, scale, agg, e_in, e_out): the second Linear aggregates its rows per destination node in
     its epilogue (DosxGemm EPI_SEGSUM): agg = scale * segment sums of the output, e_out = e_in + output (None: skipped);
     the output itself (the messages) is not written and None is returned for it.
@@ -212,9 +216,11 @@ def mlp_ln_fwd(P: Params, key: str, a: SegList, M: int, H: int, res: Optional[to
     if segsum is None and a.plain is not None and len(a.plain) <= 2 and ops.mlp_ln_fwd_supported(M, a.K, 2 * H, H):
         # a few hundred rows (the NodeModel: one row per atom): both Linear layers in ONE launch, the intermediate in LDS
         y = _empty(dev, M, H)
+        # pq_next = (W1 of the NEXT layer's EdgeModel, pq [N, 4H]): that layer's two node products on the finished rows, same launch
+        w3, pq3 = pq_next if pq_next is not None else (None, None)
         ops.mlp_ln_fwd(M, a.plain[0], a.plain[1] if len(a.plain) > 1 else None, P[key + ".0.weight"], P[key + ".0.bias"],
                        P[key + ".1.weight"], P[key + ".1.bias"], P[key + ".2.weight"], P[key + ".3.weight"],
-                       P[key + ".3.bias"], res, xhat, rstd, y)
+                       P[key + ".3.bias"], res, xhat, rstd, y, w3=w3, nb3=2 if w3 is not None else 0, pq=pq3)
         return y, (a, xhat, rstd, M, H)
     fac = a.factor
     if fac is not None and _factor_edge(M, H, fac[2]):
@@ -225,9 +231,11 @@ def mlp_ln_fwd(P: Params, key: str, a: SegList, M: int, H: int, res: Optional[to
         x, e, m = fac
         W1 = P[key + ".0.weight"]
         N_ = m.num_nodes
-        pq = _empty(dev, N_, 4 * H)
-        ops.gemm_pair(dict(M=N_, N=2 * H, segs=[seg(x)], w=W1[:, :H], out=pq[:, :2 * H]),
-                      dict(M=N_, N=2 * H, segs=[seg(x)], w=W1[:, H:2 * H], out=pq[:, 2 * H:]))
+        pq = getattr(a, "pq_ready", None)       # (the previous layer's NodeModel launch already multiplied them: DosxMlpLn.w3)
+        if pq is None:
+            pq = _empty(dev, N_, 4 * H)
+            ops.gemm_pair(dict(M=N_, N=2 * H, segs=[seg(x)], w=W1[:, :H], out=pq[:, :2 * H]),
+                          dict(M=N_, N=2 * H, segs=[seg(x)], w=W1[:, H:2 * H], out=pq[:, 2 * H:]))
         if _factor_fused(m, H) and _EDGE_ONE_LAUNCH and segsum is not None and ops.edge_mlp_supported(H):
             # the whole EdgeModel + aggregation + edge residual in ONE launch on the node-aligned row tiles (csrc/edge_mlp.hip):
             # the [48, 2H] intermediate stays in LDS, the messages never exist in HBM
@@ -448,10 +456,13 @@ def gnn_fwd(P: Params, m: GraphMeta, x: torch.Tensor, e: torch.Tensor, L: int, m
     dev = x.device
     scale = m.inv_deg if mean else None
     ctxs = []
+    pq_ready = None
     for l in range(L):
         pre = f"stacked_processor.{l}"
         a_e = SegList([seg(x, rmap=rowmap(idx=m.src)), seg(x, rmap=rowmap(idx=m.dst)), seg(e)], [x, e])
         a_e.factor = (x, e, m)                  # (the parts behind the gathered concat: mlp_ln_bwd factors the weight gradient)
+        a_e.pq_ready = pq_ready
+        pq_ready = None
         agg = _empty(dev, N, H)
         last = l == L - 1                       # the last layer's edge update is dead
         e_new = None if last else _empty(dev, E, H)
@@ -465,7 +476,13 @@ def gnn_fwd(P: Params, m: GraphMeta, x: torch.Tensor, e: torch.Tensor, L: int, m
             msg, cxe = mlp_ln_fwd(P, pre + ".edge_model.edge_mlp", a_e, E, H)
             ops.segment_reduce(msg, m.rowptr_dst, scale, agg, e, e_new, N, E, H)
         a_n = SegList([seg(x), seg(agg)], [x, agg], plain=(x, agg))
-        x_new, cxn = mlp_ln_fwd(P, pre + ".node_model.node_mlp_2", a_n, N, H, res=x)
+        pq_next = None
+        if (_PQ_IN_NODE_MLP and l + 1 < L and _factor_edge(E, H, m) and (2 * H) % 256 == 0 and
+                ops.mlp_ln_fwd_supported(N, 2 * H, 2 * H, H)):
+            # the next layer's node products (x_new Wa^T | x_new Wb^T) ride in this NodeModel launch: one launch fewer per layer
+            pq_ready = _empty(dev, N, 4 * H)
+            pq_next = (P[f"stacked_processor.{l + 1}.edge_model.edge_mlp.0.weight"], pq_ready)
+        x_new, cxn = mlp_ln_fwd(P, pre + ".node_model.node_mlp_2", a_n, N, H, res=x, pq_next=pq_next)
         ctxs.append((cxe, cxn))
         x, e = x_new, e_new
     return x, ctxs

@@ -516,8 +516,10 @@ def mlp_ln_fwd_supported(M: int, K: int, NH: int, NO: int) -> bool:
 
 
 def mlp_ln_fwd(M: int, a0: torch.Tensor, a1: Optional[torch.Tensor], w1, b1, gamma, beta, alpha, w2, b2,
-               res: Optional[torch.Tensor], xhat: torch.Tensor, rstd: torch.Tensor, out: torch.Tensor) -> None:
-    """out = prelu(LN([a0|a1] W1^T + b1)) W2^T + b2 (+ res); xhat / rstd saved (include/dosx.h: DosxMlpLn)."""
+               res: Optional[torch.Tensor], xhat: torch.Tensor, rstd: torch.Tensor, out: torch.Tensor,
+               w3: Optional[torch.Tensor] = None, nb3: int = 0, pq: Optional[torch.Tensor] = None) -> None:
+    """out = prelu(LN([a0|a1] W1^T + b1)) W2^T + b2 (+ res); xhat / rstd saved (include/dosx.h: DosxMlpLn).
+    w3 [n3, >= nb3 * NO] + pq [M, nb3 * n3]: the third product pq[:, b n3 + n] = out . w3[n, b NO:(b + 1) NO]."""
     d = _lib.MlpLn()
     k0 = int(a0.shape[1])
     d.M, d.K, d.NH, d.NO, d.k0 = int(M), k0 + (int(a1.shape[1]) if a1 is not None else 0), int(w1.shape[0]), int(w2.shape[0]), k0
@@ -530,8 +532,13 @@ def mlp_ln_fwd(M: int, a0: torch.Tensor, a1: Optional[torch.Tensor], w1, b1, gam
         d.res, d.ldres = res.data_ptr(), int(res.stride(0))
     d.xhat, d.rstd = xhat.data_ptr(), rstd.data_ptr()
     d.out, d.ldo = out.data_ptr(), int(out.stride(0))
+    if w3 is not None:
+        assert pq is not None and w3.stride(1) == 1 and pq.stride(1) == 1 and pq.shape[1] == nb3 * w3.shape[0]
+        d.w3, d.ldw3, d.n3, d.nb3 = w3.data_ptr(), int(w3.stride(0)), int(w3.shape[0]), int(nb3)
+        d.pq, d.ldpq = pq.data_ptr(), int(pq.stride(0))
     _call("dosx_mlp_ln_fwd", C.byref(d), _stream(),
-          w=lambda: (f"mlp_ln_fwd[K{d.K},NH{d.NH},NO{d.NO}]", "mlp_ln_fwd_kernel", "mfma", 2.0 * _real(d.M) * d.NH * (d.K + d.NO)))
+          w=lambda: (f"mlp_ln_fwd[K{d.K},NH{d.NH},NO{d.NO}" + (",pq" if d.w3 else "") + "]", "mlp_ln_fwd_kernel", "mfma",
+                     2.0 * _real(d.M) * (d.NH * (d.K + d.NO) + d.nb3 * d.n3 * d.NO)))
 
 
 def mlp_ln_bwd_partial_rows(M: int) -> int:

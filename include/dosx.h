@@ -606,6 +606,12 @@ typedef struct DosxMlpLn {
   const float* res; int32_t ldres;        /* optional residual added to the output (NULL: none) */
   float* xhat; float* rstd;               /* [M,NH] (row stride NH), [M] */
   float* out; int32_t ldo;
+  /* optional third product on the finished output rows (round 5: the NEXT message-passing layer's node products of the
+   * factored EdgeModel Linear, DosxGemm.add_p / add_q - the dosx_gemm_pair launch between two layers):
+   *     pq[r, b * n3 + n] = sum_k out[r, k] * w3[n * ldw3 + b * NO + k]      b < nb3, n < n3 (a multiple of 256)
+   * NULL w3: none */
+  const float* w3; int32_t ldw3, n3, nb3;
+  float* pq; int32_t ldpq;
 } DosxMlpLn;
 int dosx_mlp_ln_supported(int K, int NH, int NO);
 int dosx_mlp_ln_fwd(const DosxMlpLn* a, dosx_stream_t stream);

@@ -86,3 +86,35 @@ def test_mlp_ln_fused_is_reproducible_and_row_local():
     assert torch.equal(o1, o2)
     o_row = fwd(x[37:38].contiguous(), agg[37:38].contiguous())
     assert torch.equal(o_row[0], o1[37])
+
+
+@pytest.mark.parametrize("M,H", [(450, 128), (1554, 256), (17, 128), (1, 256)])
+def test_mlp_ln_forward_also_multiplies_the_next_layers_node_products(M, H):
+    """DosxMlpLn.w3 (round 5): pq = out . [Wa | Wb]^T of the NEXT message-passing layer's factored EdgeModel Linear (Wa, Wb: the
+    first two H-column blocks of its [2H, 3H] weight) in the NodeModel launch == dosx_gemm_pair on the written output rows, to
+    rounding; `out` itself, xhat, rstd bitwise the launch without the third product."""
+    from dostransformer_amd import functional as Fn
+    from dostransformer_amd import ops
+    from dostransformer_amd.ops import seg
+    dev = "cuda:0"
+    gen = torch.Generator().manual_seed(M * 3 + H)
+    r = lambda *s: (torch.randn(*s, generator=gen)).to(dev)
+    x, agg = r(M, H), r(M, H)
+    P = {"m.0.weight": r(2 * H, 2 * H) / (2 * H) ** 0.5, "m.0.bias": 0.1 * r(2 * H), "m.1.weight": 1 + 0.1 * r(2 * H),
+         "m.1.bias": 0.1 * r(2 * H), "m.2.weight": torch.tensor([0.25], device=dev), "m.3.weight": r(H, 2 * H) / (2 * H) ** 0.5,
+         "m.3.bias": 0.1 * r(H)}
+    W1n = r(2 * H, 3 * H) / (3 * H) ** 0.5
+    assert ops.mlp_ln_fwd_supported(M, 2 * H, 2 * H, H)
+    a = Fn.SegList([seg(x), seg(agg)], [x, agg], plain=(x, agg))
+    y0, c0 = Fn.mlp_ln_fwd(P, "m", a, M, H, res=x)
+    pq = torch.full((M, 4 * H), float("nan"), device=dev)
+    y1, c1 = Fn.mlp_ln_fwd(P, "m", a, M, H, res=x, pq_next=(W1n, pq))
+    ref = torch.empty(M, 4 * H, device=dev)
+    ops.gemm_pair(dict(M=M, N=2 * H, segs=[seg(y0)], w=W1n[:, :H], out=ref[:, :2 * H]),
+                  dict(M=M, N=2 * H, segs=[seg(y0)], w=W1n[:, H:2 * H], out=ref[:, 2 * H:]))
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1) and torch.equal(c0[1], c1[1]) and torch.equal(c0[2], c1[2])
+    assert not torch.isnan(pq).any()
+    assert float((pq - ref).abs().max()) <= 5e-6 * float(ref.abs().max())
+    exact = torch.cat([y0.double() @ W1n[:, :H].double().t(), y0.double() @ W1n[:, H:2 * H].double().t()], 1)
+    assert float((pq.double() - exact).abs().max()) <= 2e-5 * float(exact.abs().max())
