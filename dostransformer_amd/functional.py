@@ -1360,7 +1360,7 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
         sink.flush_on_side()                  # (weight-gradient stream: this encoder's jobs run under the next one's backward)
     dkvs = _empty(dev, rows2, H)              # self-attention: every row is a key row, the first layer overwrites
     ddosin = encoder_bwd(P, G, "transformer_self", c2, dhs, dkvs, sink, dkv_fresh=True, kv_needed_next=True)
-    late_flush = _LATE_SELF_FLUSH == "1" or (_LATE_SELF_FLUSH == "auto" and len(a_g.keep) <= 2)
+    late_flush = _LATE_SELF_FLUSH in ("1", "2") or (_LATE_SELF_FLUSH == "auto" and len(a_g.keep) <= 2)
     if sink.wside is not None and not late_flush:
         sink.flush_on_side()
     sink.join()          # dkvs is produced on the side stream
@@ -1387,7 +1387,7 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
     dE1 = _empty(dev, S * B, H)
     ops.gemm(S * B, H, [seg(dpre, rmap=map0)], Wfc[:, :H], dE1, w_layout=1)
     ops.gemm(S * B, H, [seg(dpre, rmap=map1)], Wfp[:, :H], dE1, w_layout=1, res=dE1)
-    if sink.wside is not None and late_flush:
+    if sink.wside is not None and late_flush and _LATE_SELF_FLUSH != "2":
         # experiment: the self encoder's weight gradients (+ the two heads') start behind the small head kernels above
         # instead of in front of them (where the group's long-lived workgroups make these 8-15 us kernels wait)
         sink.flush_on_side()
@@ -1410,6 +1410,8 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
     sink.on_side(_const_inputs_bwd, (dpre, R, dgraph, dprow))
     # first encoder (queries = energy embeddings broadcast over the batch)
     dX1 = encoder_bwd(P, G, "transformer", c1, dE1, dkv, sink, kv_needed_next=True)
+    if sink.wside is not None and _LATE_SELF_FLUSH == "2":
+        sink.flush_on_side()             # (experiment: the self encoder's group together with the first encoder's, under the GNN backward)
     # Every gradient of the transformer stacks, the heads and the embeddings is complete (or queued on the side
     # stream) here; what follows only touches the GNN trunk's parameters.  mid_hook: data-parallel training reduces
     # and all-reduces that early bucket now, underneath the GNN backward (train.Trainer).
