@@ -16,6 +16,15 @@
 
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 
+// x / d for a wave-uniform run-time d: a shift when d is a power of two (hidden 64 / 128: every divisor of the attention tiles'
+// job and staging index arithmetic is), else the division.  A run-time integer division is ~40 instructions; the tile code did
+// 8-16 of them per thread and launch (tools/stamp_attn_aligned.py found the same in the stand-alone kernels: 5.5 -> 4.9 k clk).
+struct UDiv {
+  int d, sh;
+  __device__ __forceinline__ explicit UDiv(int d_) : d(d_), sh((d_ & (d_ - 1)) == 0 ? __builtin_ctz(d_) : -1) {}
+  __device__ __forceinline__ int div(int x) const { return sh >= 0 ? (x >> sh) : x / d; }
+};
+
 #ifdef DOSX_STAMPS
 __device__ unsigned long long dosx_ffn_stamp_buf[64];
 extern "C" int dosx_debug_read_ffn_stamps(unsigned long long* host64) {
@@ -198,15 +207,16 @@ __device__ __forceinline__ void ffn_att_tile(const DosxFfn& a, float* __restrict
     }
     {   // the crystal's key rows -> Ks (all 8 waves; rows beyond Nk zero): requested right behind the row operands above
       const int bk = al_bq % a.att_Bk, h4 = H >> 2;
+      const UDiv dh4(h4);
       float4 kr[4];                                  // NkP * h4 <= 64 * 32 = 4 float4 per thread
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int e = tid + 512 * i, j = e / h4, c = (e - j * h4) * 4;
+        const int e = tid + 512 * i, j = dh4.div(e), c = (e - j * h4) * 4;
         kr[i] = (e < NkP * h4 && j < Nk) ? ld4(a.att_kvhat + ((size_t)j * a.att_Bk + bk) * H + c) : f4zero();
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int e = tid + 512 * i, j = e / h4, c = (e - j * h4) * 4;
+        const int e = tid + 512 * i, j = dh4.div(e), c = (e - j * h4) * 4;
         if (e < NkP * h4) st4(Ks + j * LDK + c, kr[i]);
       }
     }
@@ -243,10 +253,11 @@ __device__ __forceinline__ void ffn_att_tile(const DosxFfn& a, float* __restrict
   int KS = njobsS >= 8 ? 1 : (njobsS >= 4 ? 2 : 4);
   while (KS > 1 && ((H % (16 * KS)) != 0 || LDK + (KS - 1) * 68 > 4 * H + 4)) KS >>= 1;   // (whole 16-wide MFMA steps; the partial tiles fit the T region)
   const int klen = H / KS;
+  const UDiv dKS(KS);
   {
     for (int unit = wave; unit < njobsS * KS; unit += 8) {
-      const int job = unit / KS, kq = unit - job * KS;
-      const int rt = job / nctS, ct = job - rt * nctS;
+      const int job = dKS.div(unit), kq = unit - job * KS;
+      const int rt = job >= nctS ? job / nctS : 0, ct = job - rt * nctS;
       const f32x4 acc = mma_kk<8>(Qs + (16 * rt + l15) * LDK + kq * klen + 4 * g4, Ks + (16 * ct + l15) * LDK + kq * klen + 4 * g4, klen >> 4);
       float* Sp = kq == 0 ? Sc : Qs + R * LDK + (kq - 1) * R * 68;      // (partials 1 .. KS - 1 behind the Q tile, in the T region)
 #pragma unroll
@@ -301,8 +312,9 @@ __device__ __forceinline__ void ffn_att_tile(const DosxFfn& a, float* __restrict
   // ---- D: O = P . K ----
   {
     const int nct = H >> 4, njobs = (R / 16) * nct;
+    const UDiv dnct(nct);
     for (int job = wave; job < njobs; job += 8) {
-      const int rt = job / nct, ct = job - rt * nct;
+      const int rt = dnct.div(job), ct = job - rt * nct;
       const f32x4 acc = mma_kn<4>(Sc + (16 * rt + l15) * 68 + 4 * g4, Ks + (4 * g4) * LDK + 16 * ct + l15, LDK, NkP >> 4);
 #pragma unroll
       for (int i = 0; i < 4; ++i) Qs[(16 * rt + 4 * g4 + i) * LDK + 16 * ct + l15] = acc[i];
@@ -727,6 +739,7 @@ __device__ __forceinline__ void ffn_dkv_reduce(const DosxFfnBwd& a, const int nq
   const int lane = tid & 63, q16 = lane & 15, slot = tid >> 4;                 // 32 slots
   const int H = a.H, Nk = a.att_Nk, rep = a.att_Bq / a.att_Bk, ngroups = (Nk + 15) / 16;
   const int np = rep * nqt;
+  const UDiv dnqt(nqt);
   const size_t pstride = (size_t)Nk * H;
   const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)a.att_dkv_part, 0, 0x7fffffff, 0x00020000);
   float4 g0[2], d[2][2], kh[2][2], d0[2][2];
@@ -753,7 +766,7 @@ __device__ __forceinline__ void ffn_dkv_reduce(const DosxFfnBwd& a, const int nq
     for (int p = 0; p < 2; ++p)
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int pi = min(p0 + u, np - 1), i = pi / nqt, t = pi % nqt;
+        const int pi = min(p0 + u, np - 1), i = dnqt.div(pi), t = pi - i * nqt;
         const size_t off = ((size_t)(bk + i * a.att_Bk) * nqt + t) * pstride + (size_t)(jv[p] ? slot + 32 * p : 0) * H;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -786,9 +799,10 @@ __device__ __forceinline__ void ffn_dkv_reduce(const DosxFfnBwd& a, const int nq
       st4(Pp + (slot + 32 * p) * 256 + 128 + c, pb);
     }
   __syncthreads();
+  const UDiv dH(H), d2H(2 * H);
   for (int o = tid; o < ngroups * 2 * H; o += 512) {
-    const int grp = o / (2 * H), c = o - grp * 2 * H;
-    const int col = (c / H) * 128 + (c % H);
+    const int grp = d2H.div(o), c = o - grp * 2 * H;
+    const int hi = dH.div(c), col = hi * 128 + (c - hi * H);
     float t = 0.f;
 #pragma unroll
     for (int sl = 0; sl < 16; ++sl) t += Pp[(grp * 16 + sl) * 256 + col];
@@ -825,9 +839,10 @@ __device__ __forceinline__ void ffn_att_bwd_prefetch(const DosxFfnBwd& a, AttBwd
     q.mk[jj] = a.att_mask ? a.att_mask[prow_ + jc] : 1.f;
   }
   const int h4 = H >> 2;
+  const UDiv dh4(h4);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int e = tid + 512 * i, j = e / h4, c = (e - j * h4) * 4;
+    const int e = tid + 512 * i, j = dh4.div(e), c = (e - j * h4) * 4;
     q.kr[i] = (e < NkP * h4 && j < Nk) ? ld4(a.att_kvhat + ((size_t)j * a.att_Bk + bk) * H + c) : f4zero();
   }
 }
@@ -857,9 +872,10 @@ __device__ __forceinline__ void ffn_att_bwd_tile(const DosxFfnBwd& a, float* __r
   for (int jj = 0; jj < 4; ++jj) { pr[jj] = q.pr[jj]; mk[jj] = q.mk[jj]; }
   {   // the crystal's key rows -> Ks
     const int h4 = H >> 2;
+    const UDiv dh4(h4);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int e = tid + 512 * i, j = e / h4, c = (e - j * h4) * 4;
+      const int e = tid + 512 * i, j = dh4.div(e), c = (e - j * h4) * 4;
       if (e < NkP * h4) st4(L.Ks + j * LDK + c, q.kr[i]);
     }
   }
@@ -886,9 +902,10 @@ __device__ __forceinline__ void ffn_att_bwd_tile(const DosxFfnBwd& a, float* __r
   int KS = njobsS >= 8 ? 1 : (njobsS >= 4 ? 2 : 4);
   while (KS > 1 && (H % (16 * KS)) != 0) KS >>= 1;
   const int klen = H / KS;
+  const UDiv dKS(KS);
   for (int unit = wave; unit < njobsS * KS; unit += 8) {
-    const int job = unit / KS, kq = unit - job * KS;
-    const int rt = job / nctS, ct = job - rt * nctS;
+    const int job = dKS.div(unit), kq = unit - job * KS;
+    const int rt = job >= nctS ? job / nctS : 0, ct = job - rt * nctS;
     const f32x4 acc = mma_kk<8>(L.Ds + (16 * rt + l15) * LDK + kq * klen + 4 * g4, L.Ks + (16 * ct + l15) * LDK + kq * klen + 4 * g4, klen >> 4);
     float* Sq_ = kq == 0 ? L.Sc : L.Sp + (kq - 1) * R * 68;
 #pragma unroll
@@ -926,8 +943,9 @@ __device__ __forceinline__ void ffn_att_bwd_tile(const DosxFfnBwd& a, float* __r
   // ---- d: dq = dS . Ks -> Ds ----
   {
     const int nct = H >> 4, njobs = (R / 16) * nct;
+    const UDiv dnct(nct);
     for (int job = wave; job < njobs; job += 8) {
-      const int rt = job / nct, ct = job - rt * nct;
+      const int rt = dnct.div(job), ct = job - rt * nct;
       const f32x4 acc = mma_kn<4>(L.Ss + (16 * rt + l15) * 68 + 4 * g4, L.Ks + (4 * g4) * LDK + 16 * ct + l15, LDK, NkP >> 4);
 #pragma unroll
       for (int i = 0; i < 4; ++i) L.Ds[(16 * rt + 4 * g4 + i) * LDK + 16 * ct + l15] = acc[i];
@@ -984,7 +1002,7 @@ __device__ __forceinline__ void ffn_att_bwd_tile(const DosxFfnBwd& a, float* __r
   {
     float* prow = a.att_partials_q + ((size_t)al_bq * nqt + tile) * 2 * H;
     for (int c = tid; c < 2 * H; c += 512) {
-      const int o = (c / H) * 128 + (c % H);
+      const int hi = c >= H ? 1 : 0, o = hi * 128 + (c - hi * H);
       float t = 0.f;
 #pragma unroll
       for (int sl = 0; sl < 32; ++sl) t += L.Pp[sl * 256 + o];
@@ -996,8 +1014,9 @@ __device__ __forceinline__ void ffn_att_bwd_tile(const DosxFfnBwd& a, float* __r
   {
     float* part = a.att_dkv_part + ((size_t)al_bq * nqt + tile) * (size_t)Nk * H;
     const int nct = H >> 4, njobs = nctS * nct;
+    const UDiv dnct(nct);
     for (int job = wave; job < njobs; job += 8) {
-      const int jt = job / nct, ct = job - jt * nct;
+      const int jt = dnct.div(job), ct = job - jt * nct;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kk = 0; kk < R; kk += 16) {
@@ -1379,8 +1398,9 @@ __global__ __launch_bounds__(512, DOSX_FFN_BWD_OCC) void ffn_bwd_kernel(const Do
     if (fdot && lane == 0) Ps[8 * 5 * FBN + wave] = pdb;
     __syncthreads();
     float* prow = a.partials + (size_t)blockIdx.x * a.partial_ld;
+    const UDiv dHp(H);
     for (int c = tid; c < npv * H; c += 512) {
-      const int which = c / H, col = c % H;
+      const int which = dHp.div(c), col = c - which * H;
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) s += Ps[(w * npv + which) * FBN + col];

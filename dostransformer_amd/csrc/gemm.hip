@@ -231,9 +231,9 @@ __device__ __forceinline__ void gemm_body(const GemmLaunch& L, const int bid) { 
   // blocks the column blocks are enumerated next, so all column blocks of one row block run on the same XCD
   // (id % 8 == row block % 8) and its A rows cross the fabric once, not once per column block.
   const int gx = (g.M - L.m_base + BMR - 1) / BMR, gy = (g.N + BN - 1) / BN;
-  int bx, by;
-  {
-    const int lin = bid, grp = lin / (8 * gy), rem = lin % (8 * gy);
+  int bx = bid, by = 0;
+  if (gy > 1) {                                            // (one column tile: the mapping is the identity - skip its four run-time
+    const int lin = bid, grp = lin / (8 * gy), rem = lin % (8 * gy);     //  integer divisions, ~40 instructions each)
     const int rows_in_grp = min(8, gx - grp * 8);          // last group may be short
     bx = grp * 8 + rem % rows_in_grp;
     by = rem / rows_in_grp;

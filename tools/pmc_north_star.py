@@ -42,8 +42,7 @@ def attn_classes(path):
         if d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) <= 0:
             continue
         # round 5: the crystal-aligned kernels (attention_aligned.hip; bench_kernels.py runs both forms).  NG = hidden / 64:
-        # 4 = the Electron-DOS cross attention (41 / 64 keys), 2 = Phonon-DOS, told apart by the LDS size (64 key rows resident
-        # for the 51-key self attention: forward 59392 B with one score tile, backward > 80 KB; 16 key rows for the 12-key cross)
+        # 4 = the Electron-DOS cross attention (41 / 64 keys), 2 = Phonon-DOS
         m = re.search(r"attn_al_(fwd|bwd)_kernel<(\d+)", d["name"])
         if m:
             ng, lds, wgs = int(m.group(2)), d.get("lds", 0), d["grid"] // 512
@@ -52,7 +51,10 @@ def attn_classes(path):
             if ng == 4:
                 cls = "edos_cross_aligned"
             elif ng == 2:
-                self_ = (lds == 59392) if m.group(1) == "fwd" else (lds > 80000)
+                # (rocprofv3 reports 0 for dynamic LDS: the 51-key self attention is told from the 12-key cross attention of the
+                #  same grid - 128 crystals x 2 workgroups - by its MFMA work, 4 x the key tiles)
+                busy = d["SQ_VALU_MFMA_BUSY_CYCLES"]
+                self_ = wgs == 256 and busy > (2.0e6 if m.group(1) == "fwd" else 5.0e6)
                 cls = "cfg2_self_aligned" if self_ else "cfg2_cross_aligned"
             else:
                 continue
