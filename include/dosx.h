@@ -167,7 +167,10 @@ int dosx_gemm(const DosxGemm* g, dosx_stream_t stream);
 /* Two independent GEMMs in ONE launch when they share a tile configuration (same N, W[N,K], no prologue, the plain epilogue,
  * 4-float aligned operands), one after the other otherwise - the two output heads `fc` / `fc_prompt`
  * (DOSTransformer_phonon.py:93-95,105-109; DOSTransformer.py:64-66,76-80) write disjoint rows of one tensor and are each one
- * partial round of workgroups: together still one round.  Tile height chosen for the rows of both. */
+ * partial round of workgroups: together still one round.  Tile height chosen for the rows of both.
+ * Round 5: also two EPI_PRELU_BWD problems (W[K,N], N = 128) of different heights - the node and the edge encoder's backward at
+ * the tail of a step (DOSTransformer_phonon.py:129-130,141-142 differentiated): each at ITS tile height in one grid (16-row tiles
+ * for the few hundred node rows, 48-row tiles for the edge rows), partial rows numbered per problem as dosx_gemm would. */
 int dosx_gemm_pair(const DosxGemm* a, const DosxGemm* b, dosx_stream_t stream);
 /* diagnostic: the device symbol dosx_gemm launches for this descriptor, as a profiler prints it
  * ("gemm_kernel<RT, NTW, WL, PRO, VEC, EPI>"), written to the HOST buffer buf[n]. */
