@@ -283,6 +283,12 @@ def test_size_policies_of_the_factored_forms():
     assert Fn._ffn_tail_start(8192, 256) == 0 and Fn._ffn_tail_start(6528, 256) == 0
     assert Fn._ffn_tail_start(25728, 384) == 0                # 3 column tiles do not divide the 256 CUs: no split
     assert Fn._ffn_tail_start(16384 + 100, 512) == 16384      # 4 column tiles: rounds of 4096 rows
+    # round 5: the NodeModel FORWARD runs as one launch up to hidden 256 (1554 nodes of the Electron-DOS batch), its backward only up
+    # to hidden 128; unfused encoder layers (hidden 256) take LN1 from the attention kernel; the measured-neutral forms are off
+    from dostransformer_amd import ops
+    assert ops.mlp_ln_fwd_supported(1554, 512, 512, 256) and not ops.mlp_ln_supported(1554, 512, 512, 256)
+    assert ops.mlp_ln_supported(450, 256, 256, 128) and not ops.mlp_ln_fwd_supported(5000, 256, 256, 128)
+    assert Fn._LN1_IN_ATTN and not Fn._LN1_WGRAD and not Fn._PQ_IN_NODE_MLP and Fn._ENC_BWD_PAIR
 
 
 def test_bucket_promotion_picks_the_smallest_live_bucket_that_fits():
