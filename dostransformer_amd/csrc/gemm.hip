@@ -1320,6 +1320,15 @@ inline int gemm_tail_split(int M, int N, int epi) {
   //  epilogue on one 256-column tile: the feed-forward GEMMs of a hidden-256 model and the plain large GEMMs around them)
   if (!on) return 0;
   const int bn_ = gemm_bn(M, N, epi);
+  if (bn_ == 512 && (epi == DOSX_EPI_LN || epi == DOSX_EPI_PRELU_LN_BWD) && gemm_rt(M, N, epi) == 1) {
+    // Round 5: the 512-column row-epilogue GEMMs of the hidden-256 message passing (E = 17880 edge rows: 559 tiles of 32 rows, one
+    // workgroup per CU = 2.18 rounds run as 3 - 64.9 us against 49.8 at E = 16384, 81.1 / 61.3 with the PReLU-LayerNorm-backward
+    // epilogue; the 32-crystal shard: 42.8 against 23.9 us, tools/exp/r5_quant512.py): the rows of the full rounds as 32-row tiles,
+    // the rest as 16-row tiles (16 x 16 x 4 MFMA) behind them in the same grid
+    const int full = M / (256 * BM), tail_wg = ceil_div(M - full * 256 * BM, BM);
+    if (full < 1 || tail_wg == 0 || tail_wg > max_tail) return 0;
+    return full * 256 * BM;
+  }
   if (!((bn_ == 128 && (epi == DOSX_EPI_BIAS_ACT || epi == DOSX_EPI_RELU_MASK)) || (bn_ == 256 && epi == DOSX_EPI_ROWLN_BWD))) return 0;
   if (gemm_rt(M, N, epi) != 2) return 0;                   // the large-problem regime only (64-row tiles)
   const int gy = ceil_div(N, gemm_bn(M, N, epi));
@@ -1334,8 +1343,12 @@ inline int gemm_tail_split(int M, int N, int epi) {
 // tile height (in gemm_kernel's RT code) of the tail rows of a split call: 48-row tiles where the normal policy picks them
 // (LayerNorm-backward epilogue only), 32-row tiles otherwise
 inline int gemm_tail_rt(int Mt, int N, int epi) {
+  if (epi == DOSX_EPI_LN || epi == DOSX_EPI_PRELU_LN_BWD) return 0;       // (the 512-column split: 16-row tiles)
   return (epi == DOSX_EPI_ROWLN_BWD && gemm_rt(Mt, N, epi) == 3) ? 3 : 1;
 }
+// rows per workgroup of the HEAD part of a split call (64-row tiles; 32-row tiles for the 512-column epilogues)
+inline int gemm_head_rows(int epi) { return (epi == DOSX_EPI_LN || epi == DOSX_EPI_PRELU_LN_BWD) ? BM : 2 * BM; }
+inline int gemm_tail_rows(int rt) { return rt == 0 ? 16 : (rt == 3 ? 48 : BM); }
 
 inline int gemm_rows_per_wg(int M, int N, int epi) {
   const int rt = gemm_rt(M, N, epi);
@@ -1468,25 +1481,26 @@ extern "C" int dosx_gemm_partial_rows(int M, int N, int epi) {
   // one partial row per workgroup; row-wise epilogues run as one N tile (N <= 512), the
   // element-wise PRELU_BWD epilogue tiles N by 128.
   const int mA = gemm_tail_split(M, N, epi);
-  const int rows = mA ? mA / (2 * BM) + ceil_div(M - mA, gemm_tail_rt(M - mA, N, epi) == 3 ? 48 : BM) : ceil_div(M, gemm_rows_per_wg(M, N, epi));
+  const int rows = mA ? mA / gemm_head_rows(epi) + ceil_div(M - mA, gemm_tail_rows(gemm_tail_rt(M - mA, N, epi)))
+                      : ceil_div(M, gemm_rows_per_wg(M, N, epi));
   if (epi == DOSX_EPI_PRELU_BWD) return rows * ceil_div(N, 128);
   return rows;
 }
 
-template <int RTB, int NTW, int WL, int PRO, int EPI>
+template <int RTB, int NTW, int WL, int PRO, int EPI, int RTA = 2>
 static int launch_gemm_mixed3(const GemmLaunch& A, const GemmLaunch& T, hipStream_t s) {
-  constexpr int BN = 128 * NTW, ROWS_B = RTB == 3 ? 48 : BM * RTB;
-  const int n1 = ceil_div(A.g.M, 2 * BM) * ceil_div(A.g.N, BN), n2 = ceil_div(T.g.M - T.m_base, ROWS_B) * ceil_div(T.g.N, BN);
+  constexpr int BN = 128 * NTW, ROWS_A = BM * RTA, ROWS_B = RTB == 0 ? 16 : (RTB == 3 ? 48 : BM * RTB);
+  const int n1 = ceil_div(A.g.M, ROWS_A) * ceil_div(A.g.N, BN), n2 = ceil_div(T.g.M - T.m_base, ROWS_B) * ceil_div(T.g.N, BN);
   constexpr int PROLN = (PRO == DOSX_PRO_LN_PRELU || PRO == DOSX_PRO_ROWLN) ? 1 : 0;
-  constexpr size_t sa = gemm_smem_bytes<2, NTW, WL, PROLN>(), sb = gemm_smem_bytes<RTB, NTW, WL, PROLN>();
+  constexpr size_t sa = gemm_smem_bytes<RTA, NTW, WL, PROLN>(), sb = gemm_smem_bytes<RTB, NTW, WL, PROLN>();
   constexpr size_t smem = sa > sb ? sa : sb;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mixed_kernel<2, RTB, NTW, WL, PRO, 1, EPI>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mixed_kernel<RTA, RTB, NTW, WL, PRO, 1, EPI>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_mixed_kernel<2, RTB, NTW, WL, PRO, 1, EPI>), dim3(n1 + n2), dim3(512), smem, s, A, T, n1);
+  hipLaunchKernelGGL((gemm_mixed_kernel<RTA, RTB, NTW, WL, PRO, 1, EPI>), dim3(n1 + n2), dim3(512), smem, s, A, T, n1);
   DOSX_LAUNCH_CHECK();
   return 0;
 }
@@ -1507,6 +1521,10 @@ static int launch_gemm_mixed(int bn, const GemmLaunch& A, const GemmLaunch& T, h
   if (bn == 256 && g.epi == DOSX_EPI_ROWLN_BWD && g.w_layout == 1 && g.pro == DOSX_PRO_NONE) {
     if (T.rt == 1) return launch_gemm_mixed3<1, 2, 1, DOSX_PRO_NONE, DOSX_EPI_ROWLN_BWD>(A, T, s);
     if (T.rt == 3) return launch_gemm_mixed3<3, 2, 1, DOSX_PRO_NONE, DOSX_EPI_ROWLN_BWD>(A, T, s);
+  }
+  if (bn == 512 && T.rt == 0 && A.rt == 1 && g.pro == DOSX_PRO_NONE) {           // 32-row tiles + a tail of 16-row tiles
+    if (g.epi == DOSX_EPI_LN && g.w_layout == 0) return launch_gemm_mixed3<0, 4, 0, DOSX_PRO_NONE, DOSX_EPI_LN, 1>(A, T, s);
+    if (g.epi == DOSX_EPI_PRELU_LN_BWD && g.w_layout == 1) return launch_gemm_mixed3<0, 4, 1, DOSX_PRO_NONE, DOSX_EPI_PRELU_LN_BWD, 1>(A, T, s);
   }
   return -1;
 }
@@ -1588,17 +1606,17 @@ extern "C" int dosx_gemm(const DosxGemm* gp, dosx_stream_t stream) {
     if (bn == 256) return dispatch_gemm<2>(X, s);
     return dispatch_gemm<4>(X, s);
   };
-  const int mA = (L.rt == 2 && L.vecA && L.vecW && !g.stats_out && !g.norm_out) ? gemm_tail_split(g.M, g.N, g.epi) : 0;
+  const int mA = ((L.rt == 2 || (L.rt == 1 && bn == 512)) && L.vecA && L.vecW && !g.stats_out && !g.norm_out) ? gemm_tail_split(g.M, g.N, g.epi) : 0;
   // dosx_gemm_partial_rows() knows (M, N, epi) only: a call that reduces partial rows must take the split it reports
   DOSX_CHECK_ARG(g.partials == nullptr || mA == gemm_tail_split(g.M, g.N, g.epi),
                  "dosx_gemm: this descriptor (alignment / stats_out / norm_out) cannot take the tail split dosx_gemm_partial_rows "
                  "reports for M=%d N=%d epilogue %d", g.M, g.N, g.epi);
   if (mA > 0) {
-    GemmLaunch A = L;                        // the full rounds: rows [0, mA) as 64-row tiles
+    GemmLaunch A = L;                        // the full rounds: rows [0, mA) as 64-row tiles (32-row: the 512-column epilogues)
     A.g.M = mA;
-    GemmLaunch T = L;                        // the tail: rows [mA, M) as 32- / 48-row tiles, same grid
+    GemmLaunch T = L;                        // the tail: rows [mA, M) as 32- / 48- (16-)row tiles, same grid
     T.m_base = mA;
-    T.part_base = mA / (2 * BM);
+    T.part_base = mA / gemm_head_rows(g.epi);
     T.rt = gemm_tail_rt(g.M - mA, g.N, g.epi);
     const int rc = launch_gemm_mixed(bn, A, T, s);
     if (rc != -1) return rc;

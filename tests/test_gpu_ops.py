@@ -244,7 +244,8 @@ def test_wgrad_gather_fast_path():
     assert err(slab.sum(0), dz.double().T @ cat) < TOL
 
 
-@pytest.mark.parametrize("M,H2", [(100, 256), (45, 512), (33, 32), (4500, 256), (9000, 256), (25728, 256), (17880, 512), (24576 + 700, 128)])
+@pytest.mark.parametrize("M,H2", [(100, 256), (45, 512), (33, 32), (4500, 256), (9000, 256), (25728, 256), (17880, 512), (24576 + 700, 128),
+                                  (8940, 512), (8192 + 33, 512)])       # (512 columns: 32-row tiles + a tail of 16-row tiles, round 5)
 def test_gemm_prelu_ln_bwd_epilogue(M, H2):
     o = ops()
     H = H2 // 2

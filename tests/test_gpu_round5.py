@@ -82,7 +82,10 @@ def _graph(n, seed, fat=()):
     return src, dst, torch.from_numpy(rowptr.astype(np.int32)).to(DEV), deg, tiles, E
 
 
-@pytest.mark.parametrize("n,N,K", [(400, 256, 128), (37, 128, 64), (700, 512, 256), (20, 256, 128), (330, 64, 32)])
+@pytest.mark.parametrize("n,N,K", [(400, 256, 128), (37, 128, 64), (700, 512, 256), (20, 256, 128), (330, 64, 32),
+                                   # ~17900 / ~8950 edge rows x 512 columns: full rounds of 32-row tiles + a tail of 16-row tiles in
+                                   # one grid (gemm_tail_split's 512-column form: the Electron-DOS batch and its 32-crystal shard)
+                                   (1450, 512, 256), (725, 512, 256)])
 def test_gemm_layernorm_epilogue_with_gathered_addends(n, N, K):
     """DosxGemm.add_p / add_q (round 5): xhat = LN_noaffine(e Wc^T + b + P[src] + Q[dst]) in ONE launch - the EdgeModel's first
     Linear (DOSTransformer_phonon.py:190-197) factored into node products and an edge product of K = H - against float64, at the
