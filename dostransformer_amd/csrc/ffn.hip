@@ -16,15 +16,6 @@
 
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 
-// x / d for a wave-uniform run-time d: a shift when d is a power of two (hidden 64 / 128: every divisor of the attention tiles'
-// job and staging index arithmetic is), else the division.  A run-time integer division is ~40 instructions; the tile code did
-// 8-16 of them per thread and launch (tools/stamp_attn_aligned.py found the same in the stand-alone kernels: 5.5 -> 4.9 k clk).
-struct UDiv {
-  int d, sh;
-  __device__ __forceinline__ explicit UDiv(int d_) : d(d_), sh((d_ & (d_ - 1)) == 0 ? __builtin_ctz(d_) : -1) {}
-  __device__ __forceinline__ int div(int x) const { return sh >= 0 ? (x >> sh) : x / d; }
-};
-
 #ifdef DOSX_STAMPS
 __device__ unsigned long long dosx_ffn_stamp_buf[64];
 extern "C" int dosx_debug_read_ffn_stamps(unsigned long long* host64) {

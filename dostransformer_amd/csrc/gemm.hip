@@ -1855,12 +1855,15 @@ __device__ __forceinline__ void wgrad_body(const WgradLaunch& L, const int bid, 
   // 1-D grid, the M-split index varies fastest: workgroups are dealt to the 8 XCDs round-robin by linear id,
   // so (with 8 | nsplit) all the (n, k) tiles of one M-split land on the SAME XCD and share its L2: every
   // dY / A row of the split crosses the fabric once instead of once per tile that uses it
+  // (split counts and K / 64 are powers of two at every shape of the BASELINE models: shifts instead of five run-time integer
+  //  divisions of ~40 instructions each in the fixed part of every workgroup)
   const int ntk = (g.K + WT - 1) / WT;
-  const int z = bid % g.nsplit, tile = bid / g.nsplit;
-  const int bx = tile % ntk, by = tile / ntk;
+  const UDiv dns(g.nsplit), dntk(ntk);
+  const int tile = dns.div(bid), z = bid - tile * g.nsplit;
+  const int by = dntk.div(tile), bx = tile - by * ntk;
   const int k0 = bx * WT, n0 = by * TN;
   const int M = g.M, N = g.N, K = g.K;
-  const int chunk = ((M + g.nsplit - 1) / g.nsplit + BM - 1) / BM * BM;
+  const int chunk = (dns.div(M + g.nsplit - 1) + BM - 1) / BM * BM;
   const int ms = z * chunk, me = min(M, ms + chunk);
   const int nch = ms < me ? (me - ms + BM - 1) / BM : 0;
   const bool do_bias = ((g.dst != nullptr ? g.dst_bias : g.slab_bias) != nullptr) && (bx == 0);
