@@ -226,6 +226,24 @@ def rccl_choices(path, world):
 LINE_BUDGET = 3600          # bytes of the ONE stdout line (the driver keeps an 8 KB tail of stdout)
 
 
+def tuning_env(environ=None) -> dict:
+    """Every DOSX_* variable of the environment: the tuning / path-selection switches of the package and of libdosx (read at
+    import / first use).  A benchmark number is only comparable when none is set - bench.py refuses to run with any of them
+    unless --allow-env is given, and the record always carries what was in effect (`env`)."""
+    environ = os.environ if environ is None else environ
+    return {k: environ[k] for k in sorted(environ) if k.startswith("DOSX_")}
+
+
+def refuse_tuning_env(argv, environ=None) -> dict:
+    """The effective DOSX_* switches; SystemExit(2) when there are any and --allow-env is not on the command line."""
+    env = tuning_env(environ)
+    if env and "--allow-env" not in argv:
+        raise SystemExit("bench.py: refusing to run with tuning switches in the environment (" +
+                         ", ".join(f"{k}={v}" for k, v in env.items()) + "): unset them, or pass --allow-env to run anyway - "
+                         "the record then lists them under `env`")
+    return env
+
+
 def _round_sig(v, n=4):
     if isinstance(v, float):
         return float(f"{v:.{n}g}")
@@ -344,14 +362,28 @@ def run_workload(name, *, device, world, rank, dp, mode, shuffle, steps, warmup,
     hits0, miss0, prom0 = trainer.slot_hits, trainer.slot_misses, trainer.slot_promoted
     if shuffle:
         real_dims.clear()
+    # `check` (what the timed steps did, read AFTER the timed region): the parameters as they stand now ...
+    params_before = trainer._fp.flat.clone() if trainer._fp is not None else None
+    torch.cuda.synchronize()
+    loss_first = loss = None
     t0 = time.perf_counter()
     for i in range(steps):
-        do_step()
+        loss = do_step()
+        if i == 0:
+            loss_first = loss.detach().clone()       # (the loss lives in the bucket's static buffer: one 4-byte device copy)
     host = time.perf_counter() - t0                  # the host is done enqueueing here; the GPU may still be running
     torch.cuda.synchronize()
     if dp is not None:
         td.barrier()
     elapsed = time.perf_counter() - t0
+    # ... the device loss of the first and the last timed step, every parameter finite, the parameters moved
+    fp_now = trainer._fp.flat
+    check = {"loss_first": _round_sig(float(loss_first), 6), "loss_last": _round_sig(float(loss), 6),
+             "finite": bool(torch.isfinite(fp_now).all()) and bool(torch.isfinite(loss_first)) and bool(torch.isfinite(loss)),
+             "params_changed_frac": None if params_before is None else
+             round(float((fp_now != params_before).float().mean()), 4),
+             "replay_eq_eager": None}
+    del params_before
     ops.KERNEL_TIMER.enabled = False
     hits, misses, promoted = trainer.slot_hits - hits0, trainer.slot_misses - miss0, trainer.slot_promoted - prom0
     n_slots = len(trainer._slots)
@@ -368,6 +400,31 @@ def run_workload(name, *, device, world, rank, dp, mode, shuffle, steps, warmup,
     host_enqueue = enq[len(enq) // 2]
     if shuffle:
         del real_dims[-9:]
+    # ... and ONE step on the same batch from the same state issued both ways - the replayed launch list (three streams) and the
+    # eager, single-stream marshalling of every call from Python - must leave the same parameters (state restored afterwards)
+    if mode == "replay" and not shuffle and dp is None:
+        fp = trainer._fp
+        saved = (fp.flat.clone(), trainer._m.clone(), trainer._v.clone(), trainer.step_count)
+
+        def restore():
+            fp.flat.copy_(saved[0]); trainer._m.copy_(saved[1]); trainer._v.copy_(saved[2])
+            trainer.step_count = saved[3]
+        ops.REAL_ROWS.clear()
+        g0 = batches[0]
+        loss_r = trainer.step(g0, n_global).detach().clone()
+        p_r = fp.flat.clone()
+        restore()
+        trainer.replay = False
+        try:
+            loss_e = trainer.step(g0, n_global).detach().clone()
+        finally:
+            trainer.replay = True
+        p_e = fp.flat.clone()
+        restore()
+        torch.cuda.synchronize()
+        check["replay_eq_eager"] = bool(torch.equal(p_r, p_e)) and bool(torch.equal(loss_r, loss_e))
+        check["replay_eager_max_abs_diff"] = _round_sig(float((p_r - p_e).abs().max()), 3)
+        del saved, p_r, p_e
     dims = list(real_dims) if shuffle else [real_dims[i % len(real_dims)] for i in range(steps)]
     n_inst = 0
     if not instrument:
@@ -413,7 +470,7 @@ def run_workload(name, *, device, world, rank, dp, mode, shuffle, steps, warmup,
                    "plan": [k for k, _ in plan] + ["late", "adamw"], "backend": td.get_backend(),
                    "staged_through_host": bool(dp.staged)}
     res = {"kind": kind, "L": L, "T": T, "H": H, "B": B, "n_global": n_global, "elapsed": elapsed, "host": host, "host_enqueue": host_enqueue,
-           "roof": roof, "n_inst": n_inst, "flops_step": flops_step, "prepare_steps": n_prep, "dp_info": dp_info,
+           "roof": roof, "n_inst": n_inst, "flops_step": flops_step, "prepare_steps": n_prep, "dp_info": dp_info, "check": check,
            "slots": {"hits": hits, "misses": misses, "hit_rate": round(hits / max(hits + misses, 1), 4),
                      "promoted": promoted, "live": n_slots, "max": trainer.max_slots} if use_graph else None}
     del trainer, model
@@ -493,6 +550,7 @@ class _SkipDp1(Exception):
 
 
 def main():
+    env_switches = refuse_tuning_env(sys.argv[1:])        # before anything can touch the GPU or read a switch
     if "WORLD_SIZE" not in os.environ:
         # bare `python bench.py --gpus N`, N > 1: become the launcher - decided on the command line alone, before anything
         # below (or any import side effect) can touch the GPU
@@ -534,6 +592,9 @@ def main():
                     help="nccl = RCCL over xGMI (production); gloo = host-staged sums, only for running the N > 1 code path "
                          "on a box with fewer GPUs than ranks (together with --share-gpu; no scaling meaning)")
     ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (test harness; see --dist-backend)")
+    ap.add_argument("--allow-env", action="store_true",
+                    help="run although DOSX_* tuning switches are set in the environment (A/B experiments); they are listed in the "
+                         "record's `env` field.  Without this flag bench.py aborts when any is set")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed/RCCL even for one rank (exercises the data-parallel code path on a 1-GPU box)")
     args = ap.parse_args()
@@ -671,6 +732,9 @@ def main():
             "host_loop_ms_per_step": round(1e3 * host / args.steps, 4),
             "roofline": dom,
             "traffic_source": traffic_src[:100],
+            # the DOSX_* switches in effect ({} = the shipped defaults) and the sanity checks of the timed run (run_workload)
+            "env": env_switches,
+            "check": r["check"],
         }
         if world == 1 and args.config == "phonon_h128_b64":
             out["north_star"] = load_north_star()

@@ -300,6 +300,7 @@ _SIGS = {
     "dosx_ffn_bwd_partial_rows": [_I],
     "dosx_ffn_att_bwd_supported": [_I, _I, _I, _I],
     "dosx_ffn_att_bwd_partial_rows": [_I, _I],
+    "dosx_ffn_att_aligned_rows": [_I, _I],
     "dosx_ffn_bwd": [C.POINTER(FfnBwd), _P],
     "dosx_mlp_ln_supported": [_I, _I, _I],
     "dosx_mlp_ln_fwd": [C.POINTER(MlpLn), _P],

@@ -1383,8 +1383,8 @@ extern "C" int dosx_attention_bwd(const DosxAttn* ap, dosx_stream_t stream) {
   const bool pkv = pkv_ok(a);
   const bool res = dq_resident(a.H, a.Nk, pkv);
   const bool fused = pkv && a.dkv_cnt != nullptr;     // dK + dV finished inside the dq launch by the last arriver of a crystal
-  DOSX_CHECK_ARG(!fused || !(a.flags & (DOSX_ATTN_BWD_SKIP_DQ | DOSX_ATTN_BWD_SKIP_DKV)),
-                 "dosx_attention_bwd: dkv_cnt (one-launch backward) excludes the SKIP_DQ / SKIP_DKV flags");
+  DOSX_CHECK_ARG(!fused || !(a.flags & (DOSX_ATTN_BWD_DKV_HALF | DOSX_ATTN_BWD_DQ_HALF)),
+                 "dosx_attention_bwd: dkv_cnt (one-launch backward) excludes the DKV_HALF / DQ_HALF flags");
   DOSX_CHECK_ARG(!fused || (size_t)a.Bq * ceil_div(a.Sq, QT) * a.Nk * a.H * 4 < 0x7fffffffull, "dosx_attention_bwd: dkv_part beyond 2 GiB");
   size_t s1 = dq_smem(g, pkv, res);
   const size_t s2 = dkv_smem(g, kg);
@@ -1399,7 +1399,7 @@ extern "C" int dosx_attention_bwd(const DosxAttn* ap, dosx_stream_t stream) {
     attr_set = true;
   }
   const dim3 grid(ceil_div(a.Sq, QT), a.Bq);
-  if (!(a.flags & DOSX_ATTN_BWD_SKIP_DQ)) {
+  if (!(a.flags & DOSX_ATTN_BWD_DKV_HALF)) {
     const int nj = a.Nk <= 16 ? 1 : (a.Nk <= 48 ? attn_nj3() : (a.Nk <= 64 ? 4 : (a.Nk <= 208 ? 13 : 20)));
 #define DOSX_DQS(NJ_, PKV_, RES_)                                                                           \
   do {                                                                                                      \
@@ -1421,11 +1421,11 @@ extern "C" int dosx_attention_bwd(const DosxAttn* ap, dosx_stream_t stream) {
   }
   if (fused) {
     // nothing else to launch
-  } else if (!(a.flags & DOSX_ATTN_BWD_SKIP_DKV) && pkv) {
+  } else if (!(a.flags & DOSX_ATTN_BWD_DQ_HALF) && pkv) {
     hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3(ceil_div(a.Nk, DKR), a.Bk), dim3(256), 0, to_stream(stream), a,
                        ceil_div(a.Sq, QT));
     DOSX_LAUNCH_CHECK();
-  } else if (!(a.flags & DOSX_ATTN_BWD_SKIP_DKV)) {
+  } else if (!(a.flags & DOSX_ATTN_BWD_DQ_HALF)) {
     if (kg == 2) hipLaunchKernelGGL((attn_bwd_dkv_kernel<2>), dim3(ceil_div(a.Nk, 64), a.Bk), dim3(512), s2, to_stream(stream), a);
     else hipLaunchKernelGGL((attn_bwd_dkv_kernel<1>), dim3(ceil_div(a.Nk, 32), a.Bk), dim3(512), s2, to_stream(stream), a);
     DOSX_LAUNCH_CHECK();

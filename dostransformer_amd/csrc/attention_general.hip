@@ -2,7 +2,7 @@
 // of layers/transformer.py:131-138 have no limit on the number of keys; a crystal of more than 320 atoms is a key set of
 // that size, DOSTransformer_phonon.py:86-88).  The MFMA kernels of attention.hip keep the score row of a query in LDS, which
 // is what limits them; these three kernels implement the SAME contract (include/dosx.h: DosxAttn - strided query rows, the
-// RAW_Q / NO_RESIDUAL / SKIP_DQ / SKIP_DKV flags, qstats / out_stats, dropout multiplier mask, accumulate flag, partial-sum
+// RAW_Q / NO_RESIDUAL / DKV_HALF / DQ_HALF flags, qstats / out_stats, dropout multiplier mask, accumulate flag, partial-sum
 // rows) with one wave per row, fp32 FMA chains in index order (deterministic) and no scratch beyond what the contract already
 // hands over (probs, dscores).  A correctness path for rare shapes, not a hot path: every key row is re-read (and its affine
 // re-applied) per query row from L2.  H <= 256: one float4 of the row per lane.
@@ -221,11 +221,11 @@ int attn_general_fwd(const DosxAttn& a, hipStream_t st) {
 int attn_general_bwd(const DosxAttn& a, hipStream_t st) {
   DOSX_CHECK_ARG(a.dscores, "dosx_attention_bwd: Nk=%d > 320 needs the dscores scratch [Bq, Sq, Nk]", a.Nk);
   DOSX_CHECK_ARG(!a.dkv_cnt, "dosx_attention_bwd: dkv_cnt (one-launch backward) is for Nk <= 64");
-  if (!(a.flags & DOSX_ATTN_BWD_SKIP_DQ)) {
+  if (!(a.flags & DOSX_ATTN_BWD_DKV_HALF)) {
     hipLaunchKernelGGL(attn_general_dq_kernel, dim3(ceil_div(a.Sq, TR), a.Bq), dim3(512), 0, st, a);
     DOSX_LAUNCH_CHECK();
   }
-  if (!(a.flags & DOSX_ATTN_BWD_SKIP_DKV)) {
+  if (!(a.flags & DOSX_ATTN_BWD_DQ_HALF)) {
     hipLaunchKernelGGL(attn_general_dkv_kernel, dim3(ceil_div(a.Nk, TR), a.Bk), dim3(512), 0, st, a);
     DOSX_LAUNCH_CHECK();
   }

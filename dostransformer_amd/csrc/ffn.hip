@@ -1436,6 +1436,8 @@ static size_t ffn_att_bwd_floats(int H, int Nk, int R) {
   return m > red ? m : red;
 }
 
+static int ffn_bwd_att_rows(int Sq, int Bq);
+
 static int ffn_chunk(int H) {
   static int forced = -1;
   if (forced < 0) { const char* e = getenv("DOSX_FFN_KB"); forced = e ? atoi(e) : 0; }
@@ -1448,7 +1450,7 @@ extern "C" int dosx_ffn_att_supported(int H, int Nk) { return dosx_ffn_supported
 // ... with crystal-aligned tiles (DosxFfn.att_aligned): <= 64 keys whose rows fit the stage-buffer region next to 32 score rows
 extern "C" int dosx_ffn_att_aligned_supported(int H, int Nk) {
   if (!dosx_ffn_supported(H) || Nk < 1 || Nk > 64) return 0;
-  const int kb = (H % 64 == 0) ? 64 : 32;
+  const int kb = ffn_chunk(H);          // (what the launch uses - not a second copy of the policy)
   return (size_t)((Nk + 15) & ~15) * (H + 4) + 32 * 68 <= 2 * (size_t)128 * (kb + 4);
 }
 
@@ -1474,7 +1476,7 @@ extern "C" int dosx_ffn_fwd(const DosxFfn* ap, dosx_stream_t stream) {
   static int half_max = -1;
   if (half_max < 0) { const char* e = getenv("DOSX_FFN_HALF_MAX"); half_max = e ? atoi(e) : 128; }
   const bool aligned = att && a.att_aligned != 0;        // crystal-aligned tiles (ATT = 2): grid = Bq x ceil(Sq / R)
-  const bool half = (aligned ? a.att_Bq * ceil_div(a.att_Sq, 32) : ceil_div(a.M, 32)) <= half_max;   // 16-row workgroups while the 32-row grid is one partial round
+  const bool half = aligned ? ffn_bwd_att_rows(a.att_Sq, a.att_Bq) == 16 : ceil_div(a.M, 32) <= half_max;   // 16-row workgroups while the 32-row grid is one partial round
   const int R = half ? 16 : 32;
   const int kb = ffn_chunk(H);
   const size_t smem = sizeof(float) * ((size_t)R * (H + 4) + (size_t)R * (H4 + 4) + 2 * (size_t)FBN * (kb + 4));
@@ -1522,13 +1524,15 @@ static int ffn_bwd_att_rows(int Sq, int Bq) {
 // whether dosx_ffn_bwd takes the att_* fields for this shape: hidden 64 / 128 (64-wide weight chunks), <= 64 keys, and the
 // attention tiles fit the launch's LDS;  *_partial_rows: workgroups = partial rows of such a launch
 extern "C" int dosx_ffn_att_bwd_supported(int H, int Nk, int Sq, int Bq) {
-  if (!dosx_ffn_supported(H) || (H % 64) != 0 || Nk < 1 || Nk > 64 || Sq < 1 || Bq < 1) return 0;
+  if (!dosx_ffn_supported(H) || ffn_chunk(H) != 64 || Nk < 1 || Nk > 64 || Sq < 1 || Bq < 1) return 0;
   const int R = ffn_bwd_att_rows(Sq, Bq);
   const size_t ffn = (size_t)R * (H + 4) + (size_t)R * (4 * H + 4) + 2 * (size_t)64 * (FBN + 4);
   const size_t att = ffn_att_bwd_floats(H, Nk, R);
   return (ffn > att ? ffn : att) * sizeof(float) <= 160 * 1024;
 }
 extern "C" int dosx_ffn_att_bwd_partial_rows(int Sq, int Bq) { return Bq * ceil_div(Sq, ffn_bwd_att_rows(Sq, Bq)); }
+// rows per workgroup of a crystal-aligned launch, forward and backward (the host's grid-size policy asks the library)
+extern "C" int dosx_ffn_att_aligned_rows(int Sq, int Bq) { return (Sq < 1 || Bq < 1) ? 0 : ffn_bwd_att_rows(Sq, Bq); }
 
 extern "C" int dosx_ffn_bwd(const DosxFfnBwd* ap, dosx_stream_t stream) {
   DOSX_CHECK_ARG(ap != nullptr, "dosx_ffn_bwd: null descriptor");

@@ -2464,9 +2464,12 @@ extern "C" int dosx_grad_flush(const DosxWgrad* jobs, int n_jobs, const DosxRedu
   DOSX_CHECK_ARG(n_jobs <= 0 || jobs != nullptr, "dosx_grad_flush: null job table");
   DOSX_CHECK_ARG(n_rjobs <= 0 || rjobs != nullptr, "dosx_grad_flush: null reduction table");
   hipStream_t st = to_stream(stream);
-  static int skip_w = -1;            // timing experiments only (tools/): leave the weight-gradient tiles out of the grid
+#ifdef DOSX_STAMPS
+  // diagnostic (stamps) build only, never the shipped library: leave the weight-gradient tiles out of the grid to time the rest
+  static int skip_w = -1;
   if (skip_w < 0) skip_w = getenv("DOSX_DEBUG_SKIP_WGRAD") ? 1 : 0;
   if (skip_w) n_jobs = 0;
+#endif
   WgradGroup G;
   G.n = 0;
   G.nr = 0;

@@ -380,11 +380,23 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
             sink.defer_pre(node_sums, keep=(dz,))
         if key + ".0.weight" in G:
             Gw = G[key + ".0.weight"]                  # [2H, 3H]
+
+            # the source block's job reads aggS.  With node_one that is written LATER, by the caller's dosx_node_grad launch:
+            # the job is handed back as a closure and gnn_bwd describes it behind that launch - whether jobs are grouped
+            # (described = queued for the next flush) or launched as they are described (GradSink.group_wgrad off)
+            def src_job(Gw=Gw, aggS=aggS, x=x):
+                with ops.graph_rows():
+                    _wgrad_linear(sink, G, key + ".0.weight", None, N_, 2 * H, seg(aggS), [seg(x)], keep=(aggS, x), dst=Gw[:, :H])
+            if not node_one:
+                src_job()
+                src_job = None
             with ops.graph_rows():
-                _wgrad_linear(sink, G, key + ".0.weight", None, N_, 2 * H, seg(aggS), [seg(x)], keep=(aggS, x), dst=Gw[:, :H])
                 _wgrad_linear(sink, G, key + ".0.weight", None, N_, 2 * H, seg(aggD), [seg(x)], keep=(aggD, x), dst=Gw[:, H:2 * H])
                 _wgrad_linear(sink, G, key + ".0.weight", key + ".0.bias", M, 2 * H, seg(dz), [seg(e)], keep=(dz, e), dst=Gw[:, 2 * H:])
+        else:
+            src_job = None
     else:
+        src_job = None
         _wgrad_linear(sink, G, key + ".0.weight", key + ".0.bias", M, 2 * H, seg(dz), a.segs, keep=(dz,))
     if fac_dgrad:
         # ... and the INPUT gradient factored the same way: dL/de = dz Wc (+ the incoming edge-state gradient) is the only
@@ -393,7 +405,7 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
         W0 = P[key + ".0.weight"]
         de_new = _empty(dev, M, H)
         ops.gemm(M, H, [seg(dz)], W0[:, 2 * H:], de_new, w_layout=1, res=res)
-        return ("factored", de_new, aggS, aggD, dz if node_one else None)
+        return ("factored", de_new, aggS, aggD, dz if node_one else None, src_job if node_one else None, False)
     if not fused:
         ops.gemm(M, a.K, [seg(dz)], P[key + ".0.weight"], dcat, w_layout=1, res=res, res_col0=res_col0 if res is not None else 0)
     return dcat
@@ -439,13 +451,14 @@ def edge_mlp_bwd_one_launch(P: Params, G: Params, key: str, ctx, dagg: torch.Ten
         def src_job(Gw=Gw, aggS=aggS, x=x):           # the source block's job reads aggS: described once that exists (see gnn_bwd)
             with ops.graph_rows():
                 _wgrad_linear(sink, G, key + ".0.weight", None, N_, 2 * H, seg(aggS), [seg(x)], keep=(aggS, x), dst=Gw[:, :H])
-        if not (node_one and _GNN_FLUSH_BEFORE_NODE):
+        if not node_one:             # (aggS exists: made by the segment_reduce_perm launch above)
             src_job()
             src_job = None
         with ops.graph_rows():
             _wgrad_linear(sink, G, key + ".0.weight", None, N_, 2 * H, seg(aggD), [seg(x)], keep=(aggD, x), dst=Gw[:, H:2 * H])
             _wgrad_linear(sink, G, key + ".0.weight", key + ".0.bias", M, 2 * H, seg(dz), [seg(e)], keep=(dz, e), dst=Gw[:, 2 * H:])
-    return ("factored", de_new, aggS, aggD, dz if node_one else None, src_job)
+    # last field: whether the layer's weight-gradient group may be flushed IN FRONT of the caller's node-side launch (gnn_bwd)
+    return ("factored", de_new, aggS, aggD, dz if node_one else None, src_job, node_one and _GNN_FLUSH_BEFORE_NODE)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -528,15 +541,16 @@ def gnn_bwd(P: Params, G: Params, m: GraphMeta, ctxs, dx: torch.Tensor, sink: Gr
             _, de_new, aggS, aggD = dcat_e[:4]
             W0 = P[pre + ".edge_model.edge_mlp.0.weight"]
             if node_one:
-                src_job = dcat_e[5] if len(dcat_e) > 5 else None
-                early = src_job is not None            # the layer's group starts BEFORE the node-side launch, under it
+                src_job = dcat_e[5]                    # the source block's weight-gradient job: reads the sums the launch below makes
+                early = bool(dcat_e[6])                # the layer's group starts BEFORE the node-side launch, under it
                 if early and sink.wside is not None and (l == 0 or (_SPLIT_LATE_FLUSH == 1 and l == 1) or (_SPLIT_LATE_FLUSH == 2 and l >= 1)):
                     sink.flush_on_side()
                 # source sums of dz + both node products + the residual terms: ONE launch (csrc/edge_mlp.hip, node_grad_kernel)
                 ops.node_grad(N, H, dcat_e[4], m.rowptr_src, m.perm_src, aggD, W0, dcat_n[:, :H], None if fold_dx else dx, aggS, dx_old)
                 sink._keep.extend([dcat_n, dx])
+                if src_job is not None:
+                    src_job()                          # (described BEHIND the launch that writes its operand; early: next group)
                 if early:
-                    src_job()                          # (reads the source sums that launch has just queued: next group)
                     dx, de = dx_old, de_new
                     continue
                 if l == 0 and sink.wside is not None:
@@ -673,7 +687,7 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
         # grid - Sq padded to the tile height per crystal - is one round of workgroups
         att_aligned = False
         if _FUSED_ATT_FFN and _ATT_ALIGNED and fdrop is None and ops.ffn_supported(H) and ops.ffn_att_aligned_supported(H, Nk):
-            r_al = 16 if Bq * ((Sq + 31) // 32) <= 128 else 32
+            r_al = _lib_load().dosx_ffn_att_aligned_rows(int(Sq), int(Bq))      # (16 / 32: the library's own tile-height policy)
             if Bq * ((Sq + r_al - 1) // r_al) <= _ATT_ALIGNED_MAX_WGS and not (att_fused and _ATT_ROWS_FIRST):
                 att_fused = att_aligned = True
         xln = None
@@ -943,8 +957,8 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: Optional[torch.Tensor],
         else:
             # dq (feeds the next layer's backward) on the main stream; dk+dv (feeds only the key-gradient
             # consumers at the very end) on the side stream, in layer order so dkvhat accumulates in order
-            ops.attention_bwd(desc(8))          # DOSX_ATTN_BWD_SKIP_DKV
-            a2 = desc(4)                        # DOSX_ATTN_BWD_SKIP_DQ
+            ops.attention_bwd(desc(8))          # DOSX_ATTN_BWD_DQ_HALF
+            a2 = desc(4)                        # DOSX_ATTN_BWD_DKV_HALF
             if kv_needed_next and t == 0:
                 # the caller consumes dkvhat right after this call: the LAST key-gradient kernel runs on the main stream
                 # (behind a join that is already satisfied - the earlier layers' reductions finished long ago) instead of

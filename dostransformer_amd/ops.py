@@ -1041,8 +1041,6 @@ def segment_reduce_perm(msg, rowptr, perm, agg, N, E, H):
 def edge_grad_combine(de_new, dagg, ld_dagg, dst, scale, dmsg, E, H):
     """de_new: None or a 2-D tensor / view with unit inner stride ([E,H] or the e-block of an [E,3H] gradient)."""
     ld_de = int(de_new.stride(0)) if de_new is not None else 0
-    if __import__("os").environ.get("DOSX_DEBUG_SKIP_COMBINE"):      # timing experiments only (wrong numbers)
-        return
     _call("dosx_edge_grad_combine", _p(de_new), ld_de, dagg, ld_dagg, _p(dst), _p(scale), _p(dmsg), E, H, _stream(),
           w=lambda: (f"edge_grad_combine[H{H}]", "edge_grad_combine_kernel", "hbm",
                      4.0 * (_real(E) * H * (3 if de_new is not None else 2) + _real(E))))
@@ -1181,15 +1179,10 @@ def attention_fwd(a: Attn):
           w=lambda: (f"attention_fwd[{_attn_shape(a)}]", "attn_fwd", "mfma", 4.0 * a.Bq * a.Sq * a.Nk * a.H))
 
 
-_SKIP_ATTN_BWD = int(__import__("os").environ.get("DOSX_DEBUG_SKIP_ATTN_BWD", "0"))
-
-
 def attention_bwd(a: Attn):
     # dP = dO.K^T and dQ = dS.K (dq half), dK = dS^T.Q and dV = P^T.dO (dkv half): 4*Bq*Sq*Nk*H flops each half
     halves = (0 if a.flags & 4 else 1) + (0 if a.flags & 8 else 1)
     name = "attention_bwd" + ("_dkv" if (a.flags & 4) else ("_dq" if (a.flags & 8) else ""))
-    if _SKIP_ATTN_BWD and a.Bq >= _SKIP_ATTN_BWD:      # timing experiments only (wrong numbers): what the launches cost the step
-        return
     _call("dosx_attention_bwd", C.byref(a), _stream(),
           w=lambda: (f"{name}[{_attn_shape(a)}]", "attn_bwd", "mfma", 4.0 * halves * a.Bq * a.Sq * a.Nk * a.H))
 

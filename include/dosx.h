@@ -375,9 +375,10 @@ int dosx_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, co
  *  row (s,bq) at s*Bq + bq; key row (j, bk) at j*Bk + bk with bk = bq % Bk.
  *  H <= 256, H % 4 == 0; ANY number of keys: up to 320 per crystal the MFMA kernels (score row of a query in LDS), more
  *  through one-wave-per-row kernels with the same results contract (csrc/attention_general.hip; they need `dscores`). */
-/* BWD_SKIP_*: dosx_attention_bwd launches two kernels (dq: needs dout,P -> dx,dS ; dkv: needs dS -> dkvhat);
- * a caller may issue them separately (e.g. dkv on a second stream: only the final key-gradient consumers need it). */
-enum { DOSX_ATTN_RAW_Q = 1, DOSX_ATTN_NO_RESIDUAL = 2, DOSX_ATTN_BWD_SKIP_DQ = 4, DOSX_ATTN_BWD_SKIP_DKV = 8 };
+/* BWD_*_HALF: the two-kernel form of dosx_attention_bwd (dq half: needs dout,P -> dx,dS ; dkv half: needs dS -> dkvhat) issued
+ * as TWO calls - one with DOSX_ATTN_BWD_DQ_HALF, one with DOSX_ATTN_BWD_DKV_HALF, e.g. the dkv half on a second stream (only the
+ * final key-gradient consumers need it).  A caller that sets one flag owes the other call: together they are the whole backward. */
+enum { DOSX_ATTN_RAW_Q = 1, DOSX_ATTN_NO_RESIDUAL = 2, DOSX_ATTN_BWD_DKV_HALF = 4, DOSX_ATTN_BWD_DQ_HALF = 8 };
 typedef struct DosxAttn {
   int32_t Sq, Bq, Nk, Bk, H;
   int32_t q_stride_s, q_stride_b;
@@ -409,7 +410,7 @@ typedef struct DosxAttn {
   int32_t* dkv_cnt;    /* optional, with dkv_part: [Bk] arrival counters, zero before the launch and zero again after it.  The
                           backward is then ONE launch: the last query-tile workgroup of a key crystal to arrive (ticket)
                           sums the partial key gradients of that crystal and writes dkvhat / partials_kv itself, in the
-                          reduction kernel's order (bitwise the two-launch result).  Excludes the SKIP_DQ / SKIP_DKV flags */
+                          reduction kernel's order (bitwise the two-launch result).  Excludes the DKV_HALF / DQ_HALF flags */
   /* forward only, optional (round 5; needs out_stats, <= 320 keys): the layer's NEXT LayerNorm applied to the output rows while
    * they are in registers - ln1_out[r] = (out[r] - mean) * rstd * ln1_gamma + ln1_beta (layers/transformer.py:141: the input of
    * fc1) - so that the fc1 GEMM of a layer whose feed-forward half is not fused reads a plain A operand instead of normalising
@@ -588,6 +589,7 @@ typedef struct DosxFfnBwd {
 int dosx_ffn_bwd_partial_rows(int M);
 int dosx_ffn_att_bwd_supported(int H, int Nk, int Sq, int Bq);   /* whether dosx_ffn_bwd takes the att_* fields for this shape */
 int dosx_ffn_att_bwd_partial_rows(int Sq, int Bq);               /* workgroups = partial rows of such a launch */
+int dosx_ffn_att_aligned_rows(int Sq, int Bq);                   /* rows per workgroup (16 / 32) of a crystal-aligned launch, fwd and bwd */
 int dosx_ffn_bwd(const DosxFfnBwd* a, dosx_stream_t stream);
 
 /* Linear -> LayerNorm -> PReLU -> Linear (+ residual) in ONE launch for small row counts: the NodeModel MLP of a GNN layer

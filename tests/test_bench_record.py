@@ -135,6 +135,50 @@ def test_bare_multi_gpu_invocation_becomes_the_launcher_before_touching_the_gpu(
     assert ei.value.code == 7 and seen == {"n": 2, "argv": ["--gpus", "2", "--steps", "6", "--warmup", "2", "--share-gpu"]}
 
 
+def test_bench_refuses_tuning_switches_in_the_environment(monkeypatch):
+    """VERDICT r5 item 4b: a DOSX_* variable in the environment aborts bench.py before it touches the GPU, unless --allow-env;
+    the effective switches are what the record's `env` field holds."""
+    import bench
+    import torch
+
+    def boom(*a, **k):
+        raise AssertionError("bench.py touched the GPU before refusing the environment")
+    for name in ("set_device", "synchronize", "current_stream", "is_available", "init"):
+        monkeypatch.setattr(torch.cuda, name, boom)
+    for k in [k for k in os.environ if k.startswith("DOSX_")]:
+        monkeypatch.delenv(k)
+    assert bench.tuning_env() == {} and bench.refuse_tuning_env([]) == {}
+    monkeypatch.setenv("DOSX_WGRAD_MAXSPLIT", "4")
+    monkeypatch.setenv("DOSX_LIB", "/tmp/other.so")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "4"])
+    with pytest.raises(SystemExit) as ei:
+        bench.main()
+    assert "DOSX_WGRAD_MAXSPLIT=4" in str(ei.value.code) and "DOSX_LIB" in str(ei.value.code) and "--allow-env" in str(ei.value.code)
+    assert bench.refuse_tuning_env(["--steps", "4", "--allow-env"]) == {"DOSX_LIB": "/tmp/other.so", "DOSX_WGRAD_MAXSPLIT": "4"}
+
+
+def test_bench_refusal_is_the_process_exit_code():
+    """... as a process: non-zero exit, the reason on stderr, nothing on stdout."""
+    env = dict(os.environ, DOSX_FUSED_ATT_BWD="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4"], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0 and p.stdout == b"" and b"DOSX_FUSED_ATT_BWD=0" in p.stderr
+
+
+def test_no_work_skipping_switch_ships_in_the_package():
+    """timing-experiment switches that leave launches out live in the stamps build / tools only."""
+    import glob
+    import re
+    pat = re.compile(r"DOSX_DEBUG_SKIP|environ[^\n]*SKIP")
+    for f in glob.glob(os.path.join(ROOT, "dostransformer_amd", "**", "*.py"), recursive=True) + [os.path.join(ROOT, "bench.py")]:
+        assert not pat.search(open(f).read()), f
+    for f in glob.glob(os.path.join(ROOT, "dostransformer_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "dostransformer_amd", "csrc", "*.cpp")):
+        src = open(f).read()
+        for m in re.finditer(r"DOSX_DEBUG_SKIP", src):
+            guard = src.rfind("#ifdef DOSX_STAMPS", 0, m.start())
+            assert guard >= 0 and src.find("#endif", guard) > m.start(), f"{f}: DOSX_DEBUG_SKIP outside the stamps build"
+
+
 def test_rccl_tuning_lines_are_parsed(tmp_path):
     import bench
     f = tmp_path / "t.log"
@@ -184,6 +228,9 @@ def test_bench_default_line_is_one_small_json_record(tmp_path):
     assert ns["source"] and (ns["scatter_hbm_frac"] is None or 0 < ns["scatter_hbm_frac"]["cfg2"] < 1)
     assert rec["host_ms_per_step"] > 0
     assert rec["warmup"] == 8 and rec["prepare_steps"] == 16          # the driver's consistency check: warm-up as requested
+    ck = rec["check"]
+    assert rec["env"] == {} and ck["finite"] is True and ck["replay_eq_eager"] is True, (rec["env"], ck)
+    assert 0 < ck["loss_last"] < ck["loss_first"] * 1.5 and ck["params_changed_frac"] > 0.5, ck
     d1 = rec["secondary"]["dp1_nccl"]                                 # the data-parallel step on a 1-rank RCCL group
     assert "error" not in d1 and d1["value"] > 0 and d1["collectives_per_step"] == 3 and d1["backend"] == "nccl"
     assert d1["grad_bucket_bytes"]["early"] > 0 and d1["grad_bucket_bytes"]["late"] > 0
