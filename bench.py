@@ -465,7 +465,12 @@ def run_workload(name, *, device, world, rank, dp, mode, shuffle, steps, warmup,
     if dp is not None and trainer._fp is not None:
         fp = trainer._fp              # the two gradient buckets of the data-parallel step and the replay plan
         plan = next((s.plan for s in trainer._slots.values() if s.plan), [])
-        dp_info = {"grad_bucket_bytes": {"early": 4 * int(fp.total - fp.n_late), "late": 4 * int(fp.n_late)},
+        has_mid = any(k == "mid" for k, _ in plan)
+        # early: transformers / heads / embeddings (all-reduced under the GNN backward); mid: GN_decoder + layers L-1 .. 1 (under
+        # layer 0's backward); late: encoders + layer 0 - the only bytes reduced BEHIND the backward pass (`exposed_bytes`)
+        dp_info = {"grad_bucket_bytes": {"early": 4 * int(fp.total - fp.n_late), "mid": 4 * int(fp.n_late - fp.n_last) if has_mid else 0,
+                                         "late": 4 * int(fp.n_last if has_mid else fp.n_late)},
+                   "exposed_bytes": 4 * int(fp.n_last if has_mid else fp.n_late),
                    "collectives_per_step": sum(1 for k, _ in plan if k != "prog") + 1,
                    "plan": [k for k, _ in plan] + ["late", "adamw"], "backend": td.get_backend(),
                    "staged_through_host": bool(dp.staged)}
@@ -682,7 +687,7 @@ def main():
                                   instrument=False, **dict(common, dp=DataParallel()))
                 info = d1["dp_info"] or {}
                 secondary["dp1_nccl"] = dict(brief(d1, args.steps), **{k: info.get(k) for k in
-                                                                       ("grad_bucket_bytes", "collectives_per_step", "backend")})
+                                                                       ("grad_bucket_bytes", "exposed_bytes", "collectives_per_step", "backend")})
             finally:
                 td.destroy_process_group()
         except _SkipDp1:

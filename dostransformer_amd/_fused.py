@@ -32,6 +32,7 @@ def is_dead_param(name: str) -> bool:
 
 
 _LATE = ("GN_encoder.", "stacked_processor.", "GN_decoder.")
+_LAST = ("GN_encoder.", "stacked_processor.0.")
 
 
 def is_late_param(name: str) -> bool:
@@ -41,22 +42,34 @@ def is_late_param(name: str) -> bool:
     return name.startswith(_LATE)
 
 
+def is_last_param(name: str) -> bool:
+    """The part of the GNN trunk whose gradients exist only at the END of the backward pass: the node / edge / global encoders and
+    message-passing layer 0.  The rest of the trunk (GN_decoder, layers 1 .. L-1: the MID bucket) is final once the backward reaches
+    layer 0 - its all-reduce starts there, under layer 0's backward, and only this bucket stays exposed behind the step."""
+    return name.startswith(_LAST)
+
+
 class FlatParams:
     """Flat fp32 parameter + gradient storage for the live parameters of a module."""
 
     def __init__(self, module: nn.Module, device: torch.device, extra_dead=()):
         live = [(n, p) for n, p in module.named_parameters() if not (is_dead_param(n) or n in extra_dead)]
-        # layout: [ late bucket (GNN trunk) | early bucket (everything else) ], each in module order
-        ordered = [x for x in live if is_late_param(x[0])] + [x for x in live if not is_late_param(x[0])]
+        # layout: [ last bucket (encoders + layer 0) | mid bucket (rest of the GNN trunk) | early bucket (everything else) ],
+        # each in module order; [last | mid] together are the "late" slice flat[:n_late]
+        ordered = [x for x in live if is_last_param(x[0])] + [x for x in live if is_late_param(x[0]) and not is_last_param(x[0])] + \
+                  [x for x in live if not is_late_param(x[0])]
         names, params = [n for n, _ in ordered], [p for _, p in ordered]
-        offs, tot, n_late = [], 0, 0
+        offs, tot, n_late, n_last = [], 0, 0, 0
         for n, p in ordered:
             offs.append(tot)
             tot += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
             if is_late_param(n):
                 n_late = tot
+            if is_last_param(n):
+                n_last = tot
         self.names, self.offsets, self.total = names, offs, tot
-        self.n_late = n_late          # floats: flat[:n_late] is the late bucket, flat[n_late:] the early one
+        self.n_late = n_late          # floats: flat[:n_late] is the GNN trunk, flat[n_late:] the early bucket
+        self.n_last = n_last          # floats: flat[:n_last] the last bucket, flat[n_last:n_late] the mid bucket
         self.flat = torch.zeros(tot, device=device, dtype=torch.float32)
         self.grad = torch.zeros(tot, device=device, dtype=torch.float32)
         self.P: Dict[str, torch.Tensor] = {}

@@ -510,6 +510,15 @@ def gnn_bwd(P: Params, G: Params, m: GraphMeta, ctxs, dx: torch.Tensor, sink: Gr
     dev = dx.device
     scale = m.inv_deg if mean else None
     de = None           # dL/de_{l+1}: the e-block (columns [2H,3H)) of the next layer's concat gradient
+
+    def flush_side(l):
+        """sink.flush_on_side(); a flush while layer 0 is being processed launches the last pending job of layers L-1 .. 1:
+        from there on their gradients are final - the data-parallel step starts their all-reduce (sink.gnn_hook, train.Trainer)"""
+        sink.flush_on_side()
+        hook = getattr(sink, "gnn_hook", None)
+        if l == 0 and hook is not None:
+            sink.gnn_hook = None
+            hook(sink)
     for l in reversed(range(L)):
         pre = f"stacked_processor.{l}"
         cxe, cxn = ctxs[l]
@@ -534,7 +543,7 @@ def gnn_bwd(P: Params, G: Params, m: GraphMeta, ctxs, dx: torch.Tensor, sink: Gr
             dcat_e = mlp_ln_bwd(P, G, pre + ".edge_model.edge_mlp", cxe, dmsg, sink, res=de, res_col0=2 * H)   # [E, 3H]
         node_one = isinstance(dcat_e, tuple) and len(dcat_e) > 4 and dcat_e[4] is not None
         if l == 0 and sink.wside is not None and not node_one:
-            sink.flush_on_side()     # layer 0's weight gradients start now, under the gather backward and the encoders' backward
+            flush_side(l)     # layer 0's weight gradients start now, under the gather backward and the encoders' backward
         dx_old = _empty(dev, N, H)
         if isinstance(dcat_e, tuple):
             # factored input gradient (large edge sets): dx_l = dx_{l+1} + S Wa + D Wb + (node-MLP input gradient)[:, :H]
@@ -544,7 +553,7 @@ def gnn_bwd(P: Params, G: Params, m: GraphMeta, ctxs, dx: torch.Tensor, sink: Gr
                 src_job = dcat_e[5]                    # the source block's weight-gradient job: reads the sums the launch below makes
                 early = bool(dcat_e[6])                # the layer's group starts BEFORE the node-side launch, under it
                 if early and sink.wside is not None and (l == 0 or (_SPLIT_LATE_FLUSH == 1 and l == 1) or (_SPLIT_LATE_FLUSH == 2 and l >= 1)):
-                    sink.flush_on_side()
+                    flush_side(l)
                 # source sums of dz + both node products + the residual terms: ONE launch (csrc/edge_mlp.hip, node_grad_kernel)
                 ops.node_grad(N, H, dcat_e[4], m.rowptr_src, m.perm_src, aggD, W0, dcat_n[:, :H], None if fold_dx else dx, aggS, dx_old)
                 sink._keep.extend([dcat_n, dx])
@@ -554,7 +563,7 @@ def gnn_bwd(P: Params, G: Params, m: GraphMeta, ctxs, dx: torch.Tensor, sink: Gr
                     dx, de = dx_old, de_new
                     continue
                 if l == 0 and sink.wside is not None:
-                    sink.flush_on_side()     # (layer 0's jobs read the source sums that launch has just queued)
+                    flush_side(l)     # (layer 0's jobs read the source sums that launch has just queued)
             elif _factor_fused(m, H):
                 # ONE N-row product on the two node sums, each against its own column block of W0 (DosxGemm.w_seg_off)
                 if fold_dx:
@@ -573,7 +582,7 @@ def gnn_bwd(P: Params, G: Params, m: GraphMeta, ctxs, dx: torch.Tensor, sink: Gr
                 sink._keep.extend([dcat_n, t1, t2, dx])
             dx, de = dx_old, de_new
             if sink.side is not None and ((_SPLIT_LATE_FLUSH == 1 and l == 1) or (_SPLIT_LATE_FLUSH == 2 and l >= 1)):
-                sink.flush_on_side()
+                flush_side(l)
             continue
         ops.gather_bwd(dcat_e, dcat_n.data_ptr(), 2 * H, dx, m.rowptr_dst, m.rowptr_src, m.perm_src, None, dx_old,
                        None, N, E, H)
@@ -582,7 +591,7 @@ def gnn_bwd(P: Params, G: Params, m: GraphMeta, ctxs, dx: torch.Tensor, sink: Gr
         if sink.side is not None and ((_SPLIT_LATE_FLUSH == 1 and l == 1) or (_SPLIT_LATE_FLUSH == 2 and l >= 1)):
             # the weight gradients of the layers finished so far go to the side stream NOW, underneath the first layer's
             # backward, instead of all of them at the tail of the step where nothing else is left to overlap with
-            sink.flush_on_side()
+            flush_side(l)
     return dx, de
 
 

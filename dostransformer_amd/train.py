@@ -154,6 +154,7 @@ class Trainer:
         self.bucket = tuple(bucket)
         self.bucketed = dist is not None and not graph       # early-bucket overlap (eager and replay modes)
         self._early_work = None
+        self._mid_work = None
         self._early_side = None
         self._rec_parts = []
         self.step_count = 0
@@ -237,6 +238,7 @@ class Trainer:
             ops.sum_to(lp, B, lp[B:])
             loss = lp[B]
         sink = ops.GradSink(dev)
+        sink.gnn_hook = self._gnn_hook(fp)          # (functional.gnn_bwd calls it behind the flush that completes layers L-1 .. 1)
         Fn.dostransformer_bwd(fp.P, fp.G, cfg, m, st["ctx"], ddos, None, sink, mid_hook=self._mid_hook(fp))
         sink.release()
         return loss
@@ -257,8 +259,25 @@ class Trainer:
             sink.flush_on_side()
             rec = ops.RECORDER.active
             if rec:                                   # the collective is not a libdosx call: split the recording
-                self._rec_parts.append(ops.RECORDER.end())
+                self._rec_parts.append((ops.RECORDER.end(), "early"))
             self._start_early(fp, sink.wside if sink.wside is not None else sink.side)
+            if rec:
+                ops.RECORDER.begin()
+        return hook
+
+    def _gnn_hook(self, fp):
+        """Backward reaches message-passing layer 0 and the weight-gradient group of the layers behind it has been flushed
+        (functional.gnn_bwd): the MID bucket - GN_decoder + layers L-1 .. 1, two thirds of the GNN trunk's gradient bytes - is
+        final, so its all-reduce starts on the gradient stream NOW, underneath layer 0's backward, the encoders' backward and the
+        last weight-gradient group; only the last bucket (encoders + layer 0) is reduced behind the step."""
+        if self.dist is None or not self.bucketed or not (0 < fp.n_late < fp.total) or not (0 < fp.n_last < fp.n_late):
+            return None
+
+        def hook(sink):
+            rec = ops.RECORDER.active
+            if rec:
+                self._rec_parts.append((ops.RECORDER.end(), "mid"))
+            self._start_mid(fp, sink.wside if sink.wside is not None else sink.side)
             if rec:
                 ops.RECORDER.begin()
         return hook
@@ -268,6 +287,11 @@ class Trainer:
         with torch.cuda.stream(stream):
             self._early_work = self.dist.all_reduce_grads_async(fp.grad[fp.n_late:])
         self._early_side = side
+
+    def _start_mid(self, fp, side) -> None:
+        stream = side if side is not None else torch.cuda.current_stream()
+        with torch.cuda.stream(stream):
+            self._mid_work = self.dist.all_reduce_grads_async(fp.grad[fp.n_last:fp.n_late])
 
     def _n_global(self, B: int, n_global: Optional[int], g=None) -> int:
         """Crystals in the un-sharded batch: the caller's value, else what the sharder recorded on the batch
@@ -348,9 +372,9 @@ class Trainer:
                     ops.RECORDER.begin()
                 loss = self._part_b(fp, m, st, ng)
                 last = ops.RECORDER.end()
-                for part in self._rec_parts:          # (_mid_hook closed these while recording)
+                for part, coll in self._rec_parts:    # (_mid_hook / _gnn_hook closed these while recording)
                     plan.append(("prog", part))
-                    plan.append(("early", None))
+                    plan.append((coll, None))
                 plan.append(("prog", last))
                 self._rec_parts = []
                 slot.plan = plan
@@ -406,6 +430,8 @@ class Trainer:
                         prog.run()
                 elif kind == "sse":
                     self.dist.all_reduce_sse(slot.sse)
+                elif kind == "mid":
+                    self._start_mid(fp, ops.GradSink.grad_stream(fp.flat.device))
                 else:
                     self._start_early(fp, ops.GradSink.grad_stream(fp.flat.device))
         else:
@@ -502,11 +528,17 @@ class Trainer:
         fp = self._fp if self._fp is not None else self.model.flat_params()
         m, v = self._state(fp)
         if self.dist is not None:
-            if self._early_work is not None:          # early bucket already in flight: only the GNN bucket is exposed
-                self.dist.all_reduce_grads(fp.grad[:fp.n_late])
+            if self._early_work is not None:          # early (+ mid) bucket already in flight: only the last bucket is exposed
+                if self._mid_work is not None:
+                    self.dist.all_reduce_grads(fp.grad[:fp.n_last])
+                    self._mid_work.wait()
+                    self._mid_work = None
+                else:
+                    self.dist.all_reduce_grads(fp.grad[:fp.n_late])
                 self._early_work.wait()
                 self._early_work = None
             else:
+                assert self._mid_work is None
                 self.dist.all_reduce_grads(fp.grad)
         self.step_count += 1
         ops.adamw(fp.flat, fp.grad, m, v, fp.total, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,

@@ -47,12 +47,16 @@ def make_crystals(kind, step, suite="small"):
 
 
 def main():
+    import time
+    t_start = time.time()
+    mark = lambda what: print(f"[dp_worker +{time.time() - t_start:7.1f}s] {what}", flush=True)
     rank, world, port, outdir = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     suite = sys.argv[5] if len(sys.argv) > 5 else "small"
     steps = SUITES[suite]["steps"]
     import torch.distributed as td
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     td.init_process_group("gloo", rank=rank, world_size=world)
+    mark("process group up")
     from dostransformer_amd.dist import DataParallel, shard_batch
     from dostransformer_amd.train import Trainer
     dev = "cuda:0"
@@ -68,12 +72,13 @@ def main():
             g = shard_batch(make_crystals(kind, step, suite), world, rank).to(dev)
             n_global = None if step == 1 else b_global          # step 1: take it from the batch (shard_batch records it)
             losses.append(float(tr.step(g, n_global)))
+            mark(f"{kind}/{mode} step {len(losses)} done")
             if step == 0 and len(losses) == 1:
                 torch.cuda.synchronize()
                 out[f"{kind}/{mode}/grad0"] = model.flat_params().grad.detach().cpu().numpy().copy()
         torch.cuda.synchronize()
         fp = model.flat_params()
-        assert 0 < fp.n_late < fp.total and tr._early_work is None
+        assert 0 < fp.n_last < fp.n_late < fp.total and tr._early_work is None and tr._mid_work is None
         out[f"{kind}/{mode}/loss"] = np.array(losses)
         for k, v in model.state_dict().items():
             if v.is_floating_point():

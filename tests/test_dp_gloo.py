@@ -154,3 +154,47 @@ def test_min_max_over_ranks_detects_ragged_shards():
         assert p.exitcode == 0
     got = sorted(q.get(timeout=10) for _ in range(2))
     assert [g[1] for g in got] == [(1500, 1500)] * 2 and [g[2] for g in got] == [(1500, 1501)] * 2
+
+
+def _bucket_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dostransformer_amd._fused import FlatParams
+        from dostransformer_amd.dist import DataParallel
+        from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+        torch.manual_seed(0)
+        fp = FlatParams(DOSTransformer_phonon(3, 1, 118, 4, 16, "cpu", 0.0), torch.device("cpu"))
+        dp = DataParallel()
+        gen = torch.Generator().manual_seed(100 + rank)
+        fp.grad.copy_(torch.randn(fp.total, generator=gen))
+        whole = fp.grad.clone()
+        dp.all_reduce_grads(whole)
+        # the order train.Trainer issues them in: early (backward reaches the GNN), mid (backward reaches layer 0), last (end)
+        early = dp.all_reduce_grads_async(fp.grad[fp.n_late:])
+        mid = dp.all_reduce_grads_async(fp.grad[fp.n_last:fp.n_late])
+        dp.all_reduce_grads(fp.grad[:fp.n_last])
+        mid.wait()
+        early.wait()
+        q.put((rank, bool(torch.equal(fp.grad, whole)), fp.n_last, fp.n_late, fp.total))
+    finally:
+        td.barrier()
+        td.destroy_process_group()
+
+
+def test_three_gradient_buckets_cover_the_flat_buffer_exactly_once():
+    """the flat gradient is all-reduced as [last | mid | early] slices (two of them asynchronously, started
+    during the backward pass); together they are the all-reduce of the whole buffer, on 2 gloo ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=10) for _ in range(2))
+    assert all(g[1] for g in got) and all(0 < g[2] < g[3] < g[4] for g in got)

@@ -304,7 +304,7 @@ def test_optimizer_waits_for_a_late_early_bucket_allreduce_under_replay(monkeypa
             assert comm.calls >= 3 * steps                         # SSE pair, early bucket, GNN bucket per step
             assert comm.waits >= 3 * steps                         # ... and every one of them was waited for
             fp = model.flat_params()
-            assert 0 < fp.n_late < fp.total and tr._early_work is None
+            assert 0 < fp.n_last < fp.n_late < fp.total and tr._early_work is None and tr._mid_work is None
             return {k: v.detach().cpu().clone() for k, v in model.state_dict().items() if v.is_floating_point()}
 
         ref = run(0, 4)                        # step 0 records the plan (split around the collectives), steps 1-3 replay it

@@ -477,7 +477,7 @@ def test_data_parallel_buckets_match_single_process(mode):
             out.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
             if dist is not None:
                 fp = model.flat_params()
-                assert 0 < fp.n_late < fp.total and tr._early_work is None
+                assert 0 < fp.n_last < fp.n_late < fp.total and tr._early_work is None and tr._mid_work is None
         for k in out[0]:
             assert torch.equal(out[0][k], out[1][k]), k
     finally:

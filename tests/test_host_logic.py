@@ -125,9 +125,9 @@ def test_drop_in_aliases():
 
 
 def test_flat_params_bucket_layout():
-    """[late = GNN trunk | early = the rest], both aligned, every live parameter exactly once."""
+    """[last = encoders + layer 0 | mid = rest of the GNN trunk | early = the rest], all aligned, every live parameter exactly once."""
     import torch
-    from dostransformer_amd._fused import FlatParams, is_dead_param, is_late_param
+    from dostransformer_amd._fused import FlatParams, is_dead_param, is_last_param, is_late_param
     from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
     model = DOSTransformer_phonon(3, 1, 118, 4, 16, "cpu", 0.0)
     fp = FlatParams(model, torch.device("cpu"))
@@ -138,6 +138,16 @@ def test_flat_params_bucket_layout():
     for n, o in zip(fp.names, fp.offsets):
         assert (o < fp.n_late) == is_late_param(n) and o % 64 == 0
     assert fp.n_late % 64 == 0 and 0 < fp.n_late < fp.total
+    # the GNN trunk's slice again in two: what is final only at the end of the backward pass (encoders, layer 0) comes first
+    for n, o in zip(fp.names, fp.offsets):
+        assert (o < fp.n_last) == is_last_param(n)
+    assert fp.n_last % 64 == 0 and 0 < fp.n_last < fp.n_late
+    mid = [n for n, o in zip(fp.names, fp.offsets) if fp.n_last <= o < fp.n_late]
+    assert any(n.startswith("GN_decoder.") for n in mid) and any(n.startswith("stacked_processor.2.") for n in mid)
+    assert not any(n.startswith(("GN_encoder.", "stacked_processor.0.")) for n in mid)
+    # at the headline shape (hidden 128, 3 layers) the exposed bucket is 1.12 MB of the trunk's 3.04 MB
+    fp2 = FlatParams(DOSTransformer_phonon(3, 2, 118, 4, 128, "cpu", 0.0), torch.device("cpu"))
+    assert 4 * fp2.n_last == 1121280 and 4 * (fp2.n_late - fp2.n_last) == 1916416 and 4 * (fp2.total - fp2.n_late) == 3501056
 
 
 def test_checkpoint_is_read_without_unpickling_objects(tmp_path):
