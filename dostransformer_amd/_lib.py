@@ -150,6 +150,7 @@ class MlpLn(C.Structure):
         ("out", C.c_void_p), ("ldo", C.c_int32),
         ("w3", C.c_void_p), ("ldw3", C.c_int32), ("n3", C.c_int32), ("nb3", C.c_int32),
         ("pq", C.c_void_p), ("ldpq", C.c_int32),
+        ("cs_buf", C.c_void_p), ("cs_cnt", C.c_void_p),
     ]
 
 
@@ -163,6 +164,7 @@ class MlpLnBwd(C.Structure):
         ("dz", C.c_void_p),
         ("dcat", C.c_void_p), ("lddcat", C.c_int32),
         ("partials", C.c_void_p), ("partial_ld", C.c_int32), ("add_dy", C.c_int32),
+        ("cs_buf", C.c_void_p), ("cs_cnt", C.c_void_p),
     ]
 
 
@@ -303,6 +305,9 @@ _SIGS = {
     "dosx_ffn_att_aligned_rows": [_I, _I],
     "dosx_ffn_bwd": [C.POINTER(FfnBwd), _P],
     "dosx_mlp_ln_supported": [_I, _I, _I],
+    "dosx_mlp_ln_cs_supported": [_I, _I, _I],
+    "dosx_mlp_ln_cs_tiles": [_I],
+    "dosx_mlp_ln_cs_scratch_floats": [_I, _I],
     "dosx_mlp_ln_fwd": [C.POINTER(MlpLn), _P],
     "dosx_mlp_ln_bwd_partial_rows": [_I],
     "dosx_mlp_ln_bwd": [C.POINTER(MlpLnBwd), _P],
@@ -329,7 +334,7 @@ _SIGS = {
     "dosx_last_error": [],
     "dosx_version": [],
 }
-_RESTYPES = {"dosx_last_error": C.c_char_p, "dosx_wgrad_scratch_floats": C.c_int64}
+_RESTYPES = {"dosx_last_error": C.c_char_p, "dosx_wgrad_scratch_floats": C.c_int64, "dosx_mlp_ln_cs_scratch_floats": C.c_int64}
 EXPORTS = tuple(_SIGS)
 
 _lib: Optional[C.CDLL] = None

@@ -489,6 +489,392 @@ __global__ __launch_bounds__(512) void mlp_ln_bwd_kernel(const DosxMlpLnBwd a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// COLUMN-SPLIT form of the two kernels above (round 6).  A batch of the benchmark configuration has ~450 node
+// rows = 29 tiles of 16 rows: the kernels above run 29 workgroups on a 256-CU chip, each pulling ALL of the block's weights
+// (384 KB at hidden 128) through one CU and issuing all of its MFMAs (5 us of matrix pipe per workgroup at 16 rows).  Here a
+// tile is shared by NS = hidden / 16 workgroups of 4 waves: workgroup (tile, j) owns 32 columns of the first product and 16
+// columns of the second (1 / NS of the weights, 1 / NS of the MFMAs: 0.6 us), its 4 waves split the k range and add their partial
+// tiles through LDS in wave order.  The LayerNorm in the middle needs whole rows, and the second product the whole activated tile
+// as its A operand, so the NS workgroups EXCHANGE their slices of the intermediate in-launch: publish with sc1 stores, drain, one
+// ticket per workgroup on the tile's counter, then - unlike the last-arriver reductions of gemm.hip - EVERY workgroup waits for
+// the counter to reach NS (one lane polls with agent-scope loads, bounded) and reads the whole 16 x NH tile back with sc1 loads;
+// row statistics and activations are recomputed by all NS workgroups (16 rows x NH elements: nothing next to a launch).
+// The siblings of a tile are consecutive workgroups of one grid of <= 512 small workgroups (25 KB of LDS, 4 waves: several fit a
+// CU, also next to the weight-gradient stream's workgroups), so they are dispatched together; the poll is bounded all the same -
+// a sibling that never arrives costs a wrong tile, not a hung GPU.  Every weight / input fragment is requested at kernel start,
+// straight from global memory into the MFMA operand registers (no LDS staging: a fragment is used by exactly one wave).
+// Counters: NS tickets per exchange + NS exit tickets; the workgroup that draws the last exit ticket stores zero.
+typedef int v2i32 __attribute__((ext_vector_type(2)));
+typedef int v4i32_ __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void cs_publish_done_and_wait(int* cnt, const int target) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's published stores have completed at the coherent level
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    dosx_ticket(cnt);
+    int it = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++it < (1 << 21)) __builtin_amdgcn_s_sleep(1);
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    // (compiler only: the read-back below stays below)
+}
+__device__ __forceinline__ void cs_exit(int* cnt, const int last_ticket) {
+  if (threadIdx.x == 0) {
+    const int tk = dosx_ticket(cnt);
+    if (tk == last_ticket) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+#define CS_MFMA4(ACC, A4, B4)                                              \
+  do {                                                                     \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A4).x, (B4).x, ACC, 0, 0, 0); \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A4).y, (B4).y, ACC, 0, 0, 0); \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A4).z, (B4).z, ACC, 0, 0, 0); \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32((A4).w, (B4).w, ACC, 0, 0, 0); \
+  } while (0)
+
+// H = hidden: (K, NH, NO) = (2H, 2H, H), k0 a multiple of H / 2.  grid = tiles * NS, 256 threads.
+template <int H>
+__global__ __launch_bounds__(256) void mlp_ln_cs_fwd_kernel(const DosxMlpLn a) {
+  DOSX_SET_MAIN_PRIO();
+  constexpr int K = 2 * H, NH = 2 * H, NO = H, NS = H / 16;
+  constexpr int KW = K / 4, S1 = KW / 16;           // k range of one wave (both products reduce over 2H), its 16-wide steps
+  constexpr int NG = NH / 64;                       // float4 column groups per lane in the row phase (16 lanes per row)
+  constexpr int LDT = NH + 4, LDR = 36;
+  constexpr int KW3 = NO / 4, S3 = KW3 / 16 > 0 ? KW3 / 16 : 1;   // third product: reduces over H (hidden 64: one 16-wide step, waves 0-3 .. see below)
+  __shared__ __align__(16) float T[16 * LDT];
+  __shared__ __align__(16) float Rd[4 * 16 * LDR * 2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+  const int row = tid >> 4, q = tid & 15;           // row-phase / epilogue coordinates: 16 lanes per tile row
+  const int tile = (int)blockIdx.x / NS, j = (int)blockIdx.x - tile * NS;
+  const int m0 = tile * 16, M = a.M;
+  int* cnt = a.cs_cnt + tile;
+  // ---- operands that depend on nothing: requested first, in the order they are used ----
+  const int kbase = wave * KW;
+  const int rowA = min(m0 + l15, M - 1);
+  const float* ap = kbase < a.k0 ? a.a0 + (size_t)rowA * a.lda0 + kbase : a.a1 + (size_t)rowA * a.lda1 + (kbase - a.k0);
+  float4 av[S1], bw1[2][S1], bw2[S1];
+#pragma unroll
+  for (int s = 0; s < S1; ++s) av[s] = ld4(ap + 16 * s + 4 * g4);
+  {
+    const float* w1p = a.w1 + (size_t)(32 * j + l15) * K + kbase + 4 * g4;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int s = 0; s < S1; ++s) bw1[t][s] = ld4(w1p + (size_t)(16 * t) * K + 16 * s);
+  }
+  const float2 b1v = *reinterpret_cast<const float2*>(a.b1 + 32 * j + 2 * q);
+  float4 gam[NG], bet[NG];
+#pragma unroll
+  for (int i = 0; i < NG; ++i) { gam[i] = ld4(a.gamma + 4 * q + 64 * i); bet[i] = ld4(a.beta + 4 * q + 64 * i); }
+  const float alpha = *a.alpha;
+  {
+    const float* w2p = a.w2 + (size_t)(16 * j + l15) * NH + kbase + 4 * g4;
+#pragma unroll
+    for (int s = 0; s < S1; ++s) bw2[s] = ld4(w2p + 16 * s);
+  }
+  const int grow = m0 + row;
+  const bool rvalid = grow < M;
+  const float b2v = a.b2[16 * j + q];
+  const float resv = (a.res && rvalid) ? a.res[(size_t)grow * a.ldres + 16 * j + q] : 0.f;
+  // ---- first product: this workgroup's 32 columns, this wave's k range; partial tiles -> LDS ----
+  {
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < S1; ++s) {
+      CS_MFMA4(acc[0], av[s], bw1[0][s]);
+      CS_MFMA4(acc[1], av[s], bw1[1][s]);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Rd[(wave * 16 + 4 * g4 + r) * LDR + 16 * t + l15] = acc[t][r];
+  }
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t rZ = __builtin_amdgcn_make_buffer_rsrc((void*)a.cs_buf, 0, 0x7fffffff, 0x00020000);
+  {
+    float2 z = b1v;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {                   // (wave order: fixed)
+      const float2 p = *reinterpret_cast<const float2*>(Rd + (w * 16 + row) * LDR + 2 * q);
+      z.x += p.x; z.y += p.y;
+    }
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i32, z), rZ, (uint32_t)(((size_t)(m0 + row) * NH + 32 * j + 2 * q) * 4), 0, 16);   // sc1
+  }
+  cs_publish_done_and_wait(cnt, NS);
+  // ---- row phase on the WHOLE tile (every sibling): LayerNorm statistics (two-pass, like torch), xhat / rstd out (rows dealt
+  //      over the siblings), prelu(xhat * gamma + beta) -> T ----
+  {
+    float4 z[NG];
+    float sm_ = 0.f;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      z[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rZ, (uint32_t)(((size_t)(m0 + row) * NH + 4 * q + 64 * i) * 4), 0, 16));   // sc1
+      sm_ += (z[i].x + z[i].y) + (z[i].z + z[i].w);
+    }
+    const float invN = 1.f / (float)NH;
+    const float mean = row16_sum(sm_) * invN;
+    float qq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      z[i] = make_float4(z[i].x - mean, z[i].y - mean, z[i].z - mean, z[i].w - mean);
+      qq += (z[i].x * z[i].x + z[i].y * z[i].y) + (z[i].z * z[i].z + z[i].w * z[i].w);
+    }
+    const float rstd = rsqrtf(row16_sum(qq) * invN + DOSX_LN_EPS);
+    const bool mine = rvalid && (row & (NS - 1)) == j;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const float4 xh = make_float4(z[i].x * rstd, z[i].y * rstd, z[i].z * rstd, z[i].w * rstd);
+      if (mine) st4(a.xhat + (size_t)grow * NH + 4 * q + 64 * i, xh);
+      float4 y = make_float4(xh.x * gam[i].x + bet[i].x, xh.y * gam[i].y + bet[i].y, xh.z * gam[i].z + bet[i].z, xh.w * gam[i].w + bet[i].w);
+      y.x = y.x >= 0.f ? y.x : alpha * y.x; y.y = y.y >= 0.f ? y.y : alpha * y.y;
+      y.z = y.z >= 0.f ? y.z : alpha * y.z; y.w = y.w >= 0.f ? y.w : alpha * y.w;
+      st4(T + row * LDT + 4 * q + 64 * i, y);
+    }
+    if (mine && q == 0) a.rstd[grow] = rstd;
+  }
+  __syncthreads();
+  // ---- second product: this workgroup's 16 output columns ----
+  {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < S1; ++s) {
+      const float4 t4 = ld4(T + l15 * LDT + kbase + 16 * s + 4 * g4);
+      CS_MFMA4(acc, t4, bw2[s]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Rd[(wave * 16 + 4 * g4 + r) * LDR + l15] = acc[r];
+  }
+  __syncthreads();
+  float o = b2v;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) o += Rd[(w * 16 + row) * LDR + q];
+  o += resv;
+  const bool third = a.w3 != nullptr;
+  if (!third) {
+    if (rvalid) a.out[(size_t)grow * a.ldo + 16 * j + q] = o;
+    cs_exit(cnt, 2 * NS - 1);
+    return;
+  }
+  // ---- third product (DosxMlpLn.w3: the next layer's node products): the finished rows are exchanged the same way - `out` itself
+  //      is the medium (sc1 stores, sc1 read-back of the 16 x NO tile) - then 4H / NS = 64 columns of pq per workgroup ----
+  const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, 0x7fffffff, 0x00020000);
+  // (its weight fragments: 64 columns c = 64 j + 16 t + l15 of pq <-> block b = c / n3, row n = c % n3 of w3; this wave reduces
+  //  over k in [wave * H / 4, +H / 4))
+  float4 bw3[4][S3];
+  {
+    constexpr bool full = KW3 >= 16;                // hidden 64: H / 4 = 16 -> one step per wave; (hidden 32 would need 8-wide steps: not instantiated)
+    static_assert(full, "hidden >= 64");
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int c = 64 * j + 16 * t + l15, b = c / a.n3, n = c - b * a.n3;
+      const float* wp = a.w3 + (size_t)n * a.ldw3 + b * NO + wave * KW3 + 4 * g4;
+#pragma unroll
+      for (int s = 0; s < S3; ++s) bw3[t][s] = ld4(wp + 16 * s);
+    }
+  }
+  if (rvalid) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, o), rO, (uint32_t)(((size_t)grow * a.ldo + 16 * j + q) * 4), 0, 16);   // sc1
+  cs_publish_done_and_wait(cnt, 2 * NS);
+  {
+    constexpr int LDO = NO + 4, OG = NO / 64;       // out tile [16][NO + 4] in T; float4 groups per lane
+    const int rr = min(grow, M - 1);
+#pragma unroll
+    for (int i = 0; i < OG; ++i) {
+      const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rO, (uint32_t)(((size_t)rr * a.ldo + 4 * q + 64 * i) * 4), 0, 16));   // sc1
+      st4(T + row * LDO + 4 * q + 64 * i, v);
+    }
+    __syncthreads();
+    f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < S3; ++s) {
+      const float4 t4 = ld4(T + l15 * LDO + wave * KW3 + 16 * s + 4 * g4);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) CS_MFMA4(acc[t], t4, bw3[t][s]);
+    }
+    constexpr int LDR3 = 68;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Rd[(wave * 16 + 4 * g4 + r) * LDR3 + 16 * t + l15] = acc[t][r];
+    __syncthreads();
+    float4 p = f4zero();
+#pragma unroll
+    for (int w = 0; w < 4; ++w) p = f4add(p, ld4(Rd + (w * 16 + row) * LDR3 + 4 * q));
+    if (rvalid) st4(a.pq + (size_t)grow * a.ldpq + 64 * j + 4 * q, p);
+  }
+  cs_exit(cnt, 3 * NS - 1);
+}
+
+// Backward, column-split the same way: da slice (32 columns) -> exchange -> PReLU / LayerNorm backward of the whole tile by every
+// sibling (dz rows dealt over the siblings; column sums of this workgroup's 32 columns; dalpha by sibling 0) -> 32 columns of dcat.
+template <int H>
+__global__ __launch_bounds__(256) void mlp_ln_cs_bwd_kernel(const DosxMlpLnBwd a) {
+  DOSX_SET_MAIN_PRIO();
+  constexpr int K = 2 * H, NH = 2 * H, NO = H, NS = H / 16;
+  constexpr int KW1 = NO / 4, S1 = KW1 / 16;        // first product reduces over NO = H
+  constexpr int KW2 = NH / 4, S2 = KW2 / 16;        // second over NH = 2H
+  constexpr int NG = NH / 64;
+  constexpr int LDT = NH + 4, LDR = 36;
+  static_assert(S1 >= 1, "hidden >= 64");
+  __shared__ __align__(16) float T[16 * LDT];
+  __shared__ __align__(16) float Rd[4 * 16 * LDR];
+  __shared__ __align__(16) float Sg[2 * 16 * 32];
+  __shared__ float Pal[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+  const int row = tid >> 4, q = tid & 15;
+  const int tile = (int)blockIdx.x / NS, j = (int)blockIdx.x - tile * NS;
+  const int m0 = tile * 16, M = a.M;
+  int* cnt = a.cs_cnt + tile;
+  const int rowA = min(m0 + l15, M - 1);
+  const int grow = m0 + row;
+  const bool rvalid = grow < M;
+  const int rc = min(grow, M - 1);
+  // ---- operands, requested first: dy fragments, W2 fragments ([k][n] as stored: one dword per MFMA), then the row-phase rows ----
+  float4 av[S1];
+  float bq1[2][S1][4];
+  {
+    const float* dyp = a.dy + (size_t)rowA * a.lddy + wave * KW1 + 4 * g4;
+#pragma unroll
+    for (int s = 0; s < S1; ++s) av[s] = ld4(dyp + 16 * s);
+    const float* wp = a.w2 + (size_t)(wave * KW1 + 4 * g4) * NH + 32 * j + l15;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int s = 0; s < S1; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bq1[t][s][i] = wp[(size_t)(16 * s + i) * NH + 16 * t];
+  }
+  float4 gam[NG], bet[NG], xh[NG];
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    gam[i] = ld4(a.gamma + 4 * q + 64 * i); bet[i] = ld4(a.beta + 4 * q + 64 * i);
+    xh[i] = ld4(a.xhat + (size_t)rc * NH + 4 * q + 64 * i);
+  }
+  const float rs = a.rstd[rc];
+  const float alpha = *a.alpha;
+  float bq2[2][S2][4];
+  {
+    const float* wp = a.w1 + (size_t)(wave * KW2 + 4 * g4) * K + 32 * j + l15;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int s = 0; s < S2; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bq2[t][s][i] = wp[(size_t)(16 * s + i) * K + 16 * t];
+  }
+  float2 dyres = make_float2(0.f, 0.f);
+  if (a.add_dy && 32 * j + 2 * q < NO) dyres = *reinterpret_cast<const float2*>(a.dy + (size_t)rc * a.lddy + 32 * j + 2 * q);
+  // ---- first product ----
+  {
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < S1; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s].x, bq1[t][s][0], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s].y, bq1[t][s][1], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s].z, bq1[t][s][2], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s].w, bq1[t][s][3], acc[t], 0, 0, 0);
+      }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Rd[(wave * 16 + 4 * g4 + r) * LDR + 16 * t + l15] = acc[t][r];
+  }
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t rZ = __builtin_amdgcn_make_buffer_rsrc((void*)a.cs_buf, 0, 0x7fffffff, 0x00020000);
+  {
+    float2 z = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float2 p = *reinterpret_cast<const float2*>(Rd + (w * 16 + row) * LDR + 2 * q);
+      z.x += p.x; z.y += p.y;
+    }
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i32, z), rZ, (uint32_t)(((size_t)(m0 + row) * NH + 32 * j + 2 * q) * 4), 0, 16);   // sc1
+  }
+  cs_publish_done_and_wait(cnt, NS);
+  // ---- row phase on the whole tile: PReLU backward, LayerNorm backward; dz out (rows dealt over the siblings) and -> T ----
+  {
+    const float invN = 1.f / (float)NH;
+    float4 dxh[NG];
+    float s1 = 0.f, s2 = 0.f, pal = 0.f;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      float4 dy = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rZ, (uint32_t)(((size_t)(m0 + row) * NH + 4 * q + 64 * i) * 4), 0, 16));   // sc1
+      if (!rvalid) dy = f4zero();
+      const float4 x = xh[i], gm = gam[i], bt = bet[i];
+      const float y0 = x.x * gm.x + bt.x, y1 = x.y * gm.y + bt.y, y2 = x.z * gm.z + bt.z, y3 = x.w * gm.w + bt.w;
+      if (y0 < 0.f) { pal += dy.x * y0; dy.x *= alpha; }
+      if (y1 < 0.f) { pal += dy.y * y1; dy.y *= alpha; }
+      if (y2 < 0.f) { pal += dy.z * y2; dy.z *= alpha; }
+      if (y3 < 0.f) { pal += dy.w * y3; dy.w *= alpha; }
+      if (2 * i + (q >> 3) == j) {                  // this column group lies in the workgroup's own 32 columns: column-sum operands
+        st4(Sg + row * 32 + 4 * (q & 7), make_float4(dy.x * x.x, dy.y * x.y, dy.z * x.z, dy.w * x.w));
+        st4(Sg + 16 * 32 + row * 32 + 4 * (q & 7), dy);
+      }
+      dxh[i] = make_float4(dy.x * gm.x, dy.y * gm.y, dy.z * gm.z, dy.w * gm.w);
+      s1 += (dxh[i].x + dxh[i].y) + (dxh[i].z + dxh[i].w);
+      s2 += (dxh[i].x * x.x + dxh[i].y * x.y) + (dxh[i].z * x.z + dxh[i].w * x.w);
+    }
+    const float m1 = row16_sum(s1) * invN, m2 = row16_sum(s2) * invN;
+    const bool mine = rvalid && (row & (NS - 1)) == j;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const float4 x = xh[i];
+      float4 o = f4zero();                          // rows beyond M feed zeros to the second product
+      if (rvalid) o = make_float4(rs * (dxh[i].x - m1 - x.x * m2), rs * (dxh[i].y - m1 - x.y * m2),
+                                  rs * (dxh[i].z - m1 - x.z * m2), rs * (dxh[i].w - m1 - x.w * m2));
+      if (mine) st4(a.dz + (size_t)grow * NH + 4 * q + 64 * i, o);
+      st4(T + row * LDT + 4 * q + 64 * i, o);
+    }
+    const float sal = wave_sum(pal);
+    if (lane == 0) Pal[wave] = sal;
+  }
+  __syncthreads();
+  {
+    float* prow = a.partials + (size_t)tile * a.partial_ld;
+    if (tid < 64) {
+      const int which = tid >> 5, c = tid & 31;
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += Sg[which * 16 * 32 + r * 32 + c];
+      prow[which * NH + 32 * j + c] = s;
+    }
+    if (tid == 64 && j == 0) prow[a.partial_ld - 1] = (Pal[0] + Pal[1]) + (Pal[2] + Pal[3]);
+  }
+  // ---- second product: 32 columns of dcat ----
+  {
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < S2; ++s) {
+      const float4 t4 = ld4(T + l15 * LDT + wave * KW2 + 16 * s + 4 * g4);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.x, bq2[t][s][0], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.y, bq2[t][s][1], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.z, bq2[t][s][2], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.w, bq2[t][s][3], acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Rd[(wave * 16 + 4 * g4 + r) * LDR + 16 * t + l15] = acc[t][r];
+  }
+  __syncthreads();
+  {
+    float2 o = dyres;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float2 p = *reinterpret_cast<const float2*>(Rd + (w * 16 + row) * LDR + 2 * q);
+      o.x += p.x; o.y += p.y;
+    }
+    if (rvalid) *reinterpret_cast<float2*>(a.dcat + (size_t)grow * a.lddcat + 32 * j + 2 * q) = o;
+  }
+  cs_exit(cnt, 2 * NS - 1);
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // hidden / 64 for the NodeModel's shapes (K, NH, NO) = (2, 2, 1) x hidden, hidden in {64, 128, 256}; 0: anything else
@@ -500,6 +886,14 @@ extern "C" int dosx_mlp_ln_supported(int K, int NH, int NO) {
   return K % 128 == 0 && K >= 128 && K <= 512 && NH % 128 == 0 && NH >= 128 && NH <= 512 && NO % 64 == 0 && NO >= 64 &&
          NO <= 256 && (NO <= 128 || NO % 128 == 0) && NO <= K;
 }
+
+// column-split form: the NodeModel shapes at hidden 64 / 128
+extern "C" int dosx_mlp_ln_cs_supported(int K, int NH, int NO) {
+  const int hc = node_shape(K, NH, NO);
+  return hc == 1 || hc == 2;
+}
+extern "C" int dosx_mlp_ln_cs_tiles(int M) { return M <= 0 ? 0 : ceil_div(M, MR); }
+extern "C" int64_t dosx_mlp_ln_cs_scratch_floats(int M, int NH) { return M <= 0 ? 0 : (int64_t)ceil_div(M, MR) * MR * NH; }
 
 extern "C" int dosx_mlp_ln_fwd(const DosxMlpLn* ap, dosx_stream_t stream) {
   DOSX_CHECK_ARG(ap != nullptr, "dosx_mlp_ln_fwd: null descriptor");
@@ -518,6 +912,19 @@ extern "C" int dosx_mlp_ln_fwd(const DosxMlpLn* ap, dosx_stream_t stream) {
     DOSX_CHECK_ARG(a.pq && a.nb3 >= 1 && a.n3 >= 256 && a.n3 % 256 == 0 && (a.ldw3 & 3) == 0 && a.ldw3 >= a.nb3 * a.NO && aligned16(a.w3) &&
                        a.ldpq >= a.nb3 * a.n3,
                    "dosx_mlp_ln_fwd: third product needs pq, n3 a multiple of 256, ldw3 >= nb3 * NO (multiple of 4), ldpq >= nb3 * n3");
+  if (a.cs_buf) {         // column-split form
+    DOSX_CHECK_ARG(dosx_mlp_ln_cs_supported(a.K, a.NH, a.NO) && a.cs_cnt, "dosx_mlp_ln_fwd: column-split form needs the NodeModel shape at hidden 64 / 128 and counters");
+    DOSX_CHECK_ARG(a.k0 % (a.K / 4) == 0 && a.ldo >= a.NO && aligned16(a.cs_buf) && aligned16(a.w1) && aligned16(a.w2) && aligned16(a.gamma) &&
+                   aligned16(a.beta) && (reinterpret_cast<uintptr_t>(a.b1) & 7) == 0,
+                   "dosx_mlp_ln_fwd: column-split form needs k0 a multiple of K / 4 and aligned weights");
+    if (a.w3) DOSX_CHECK_ARG(a.nb3 * a.n3 == 4 * a.NO && (a.ldpq & 3) == 0 && aligned16(a.pq), "dosx_mlp_ln_fwd: column-split third product needs nb3 * n3 == 4 * NO");
+    const int ns = a.NO / 16;
+    const dim3 grid(ceil_div(a.M, MR) * ns);
+    if (a.NO == 64) hipLaunchKernelGGL(mlp_ln_cs_fwd_kernel<64>, grid, dim3(256), 0, to_stream(stream), a);
+    else hipLaunchKernelGGL(mlp_ln_cs_fwd_kernel<128>, grid, dim3(256), 0, to_stream(stream), a);
+    DOSX_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t smem = sizeof(float) * ((size_t)MR * (a.K + 4) + (size_t)MR * (a.NH + 4) + 8 * (size_t)WP_FLOATS);
   static bool attr_set = false;
   if (!attr_set) {
@@ -552,6 +959,17 @@ extern "C" int dosx_mlp_ln_bwd(const DosxMlpLnBwd* ap, dosx_stream_t stream) {
   DOSX_CHECK_ARG(a.partial_ld >= 2 * a.NH + 1, "dosx_mlp_ln_bwd: partial_ld %d < 2*NH+1", a.partial_ld);
   const long long span = (const char*)a.w1 > (const char*)a.w2 ? (const char*)a.w1 - (const char*)a.w2 : (const char*)a.w2 - (const char*)a.w1;
   DOSX_CHECK_ARG(span + (long long)4 * a.NH * (a.K + a.NO) < 0x7fffffffLL, "dosx_mlp_ln_bwd: the two weight matrices are more than 2 GiB apart");
+  if (a.cs_buf) {         // column-split form
+    DOSX_CHECK_ARG(dosx_mlp_ln_cs_supported(a.K, a.NH, a.NO) && a.cs_cnt, "dosx_mlp_ln_bwd: column-split form needs the NodeModel shape at hidden 64 / 128 and counters");
+    DOSX_CHECK_ARG((a.lddcat & 1) == 0 && (reinterpret_cast<uintptr_t>(a.dcat) & 7) == 0 && aligned16(a.cs_buf) && aligned16(a.gamma) && aligned16(a.beta),
+                   "dosx_mlp_ln_bwd: column-split form needs an 8-byte aligned dcat with an even leading dimension");
+    const int ns = a.NO / 16;
+    const dim3 grid(ceil_div(a.M, MR) * ns);
+    if (a.NO == 64) hipLaunchKernelGGL(mlp_ln_cs_bwd_kernel<64>, grid, dim3(256), 0, to_stream(stream), a);
+    else hipLaunchKernelGGL(mlp_ln_cs_bwd_kernel<128>, grid, dim3(256), 0, to_stream(stream), a);
+    DOSX_LAUNCH_CHECK();
+    return 0;
+  }
   const size_t smem = sizeof(float) * ((size_t)MR * (a.NO + 4) + (size_t)MR * (a.NH + 4) + 16 * (size_t)a.NH + 8 + 8 * (size_t)WP_FLOATS);
   static bool attr_set = false;
   if (!attr_set) {

@@ -85,10 +85,11 @@ def _wgrad_linear(sink: GradSink, G: Params, wkey: str, bkey: Optional[str], M: 
     slab_b = sink.scratch(ns * ((N + 63) // 64) * 64) if (bkey is not None and ns > 1) else None
     kw = dict(dst=G[wkey] if dst is None else dst, dst_bias=G[bkey] if bkey is not None else None, **pro)
     keep = tuple(keep) + tuple(t for t in pro.values() if isinstance(t, torch.Tensor))
-    if GradSink.group_wgrad:
-        sink.defer_wgrad(ops.wgrad_desc(M, N, dy, segs, slab, slab_b, ns, **kw), keep)
-    else:
-        sink.on_side(lambda: ops.wgrad(M, N, dy, segs, slab, slab_b, ns, **kw), keep)
+    # Jobs are DESCRIBED here and launched at the sink's next flush, never on the spot: call sites describe a job where its
+    # operands' buffers exist, which may be in front of the launch that fills them (the fused final-LayerNorm backward writes dY of
+    # the last layer's fc2 job inside the ffn_bwd launch that follows).  Round 6 removed the launch-as-described mode
+    # (DOSX_GROUP_WGRAD=0): it had been unsound since those fusions and nothing ran it.
+    sink.defer_wgrad(ops.wgrad_desc(M, N, dy, segs, slab, slab_b, ns, **kw), keep)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -127,6 +128,7 @@ _ENC_BWD_PAIR = __import__("os").environ.get("DOSX_ENC_BWD_PAIR", "1") == "1"
 # the next layer's node products inside the NodeModel launch (DosxMlpLn.w3): measured 1.1014 vs 1.1018 ms at cfg2, 6.978 vs 6.963 ms
 # Electron-DOS (three / two interleaved pairs) - the launch it removes costs what the longer kernel adds; off
 _PQ_IN_NODE_MLP = __import__("os").environ.get("DOSX_PQ_IN_NODE_MLP", "0") == "1"
+_PQ_IN_NODE_MLP_CS = __import__("os").environ.get("DOSX_PQ_IN_NODE_MLP_CS", "1") == "1"     # ... inside the column-split NodeModel launch
 
 
 def mlp_prelu_bwd_pair(P: Params, G: Params, first, second, sink: GradSink, tail: bool = False):
@@ -382,8 +384,8 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
             Gw = G[key + ".0.weight"]                  # [2H, 3H]
 
             # the source block's job reads aggS.  With node_one that is written LATER, by the caller's dosx_node_grad launch:
-            # the job is handed back as a closure and gnn_bwd describes it behind that launch - whether jobs are grouped
-            # (described = queued for the next flush) or launched as they are described (GradSink.group_wgrad off)
+            # the job is handed back as a closure and gnn_bwd describes it behind that launch, so that no flush between here and
+            # there can launch it early
             def src_job(Gw=Gw, aggS=aggS, x=x):
                 with ops.graph_rows():
                     _wgrad_linear(sink, G, key + ".0.weight", None, N_, 2 * H, seg(aggS), [seg(x)], keep=(aggS, x), dst=Gw[:, :H])
@@ -490,8 +492,11 @@ def gnn_fwd(P: Params, m: GraphMeta, x: torch.Tensor, e: torch.Tensor, L: int, m
             ops.segment_reduce(msg, m.rowptr_dst, scale, agg, e, e_new, N, E, H)
         a_n = SegList([seg(x), seg(agg)], [x, agg], plain=(x, agg))
         pq_next = None
-        if (_PQ_IN_NODE_MLP and l + 1 < L and _factor_edge(E, H, m) and (2 * H) % 256 == 0 and
-                ops.mlp_ln_fwd_supported(N, 2 * H, 2 * H, H)):
+        # (round 6: with the COLUMN-SPLIT NodeModel launch - an eighth of the extra weights per workgroup, one more in-launch
+        #  exchange - it pays: always there; the one-workgroup-per-tile form keeps the launch, DOSX_PQ_IN_NODE_MLP)
+        cs_node = ops.mlp_ln_cs(N, 2 * H, 2 * H, H) and ops.mlp_ln_fwd_supported(N, 2 * H, 2 * H, H) and _PQ_IN_NODE_MLP_CS
+        if (l + 1 < L and _factor_edge(E, H, m) and ops.mlp_ln_fwd_supported(N, 2 * H, 2 * H, H) and
+                (cs_node or (_PQ_IN_NODE_MLP and (2 * H) % 256 == 0))):
             # the next layer's node products (x_new Wa^T | x_new Wb^T) ride in this NodeModel launch: one launch fewer per layer
             pq_ready = _empty(dev, N, 4 * H)
             pq_next = (P[f"stacked_processor.{l + 1}.edge_model.edge_mlp.0.weight"], pq_ready)
@@ -1393,7 +1398,7 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
     R = _empty(dev, 2 * B, H)            # sum over the energy axis of dpre (filled on the side stream below)
     # (forward factored; R is filled later, on the side stream: deferred jobs only - and not with the late-flush experiment,
     #  whose flush_on_side() below would launch the B-row jobs before the reduce_rows that writes R is even queued)
-    if len(a_g.keep) > 2 and GradSink.group_wgrad and "fc.weight" in G and "fc_prompt.weight" in G and not late_flush:
+    if len(a_g.keep) > 2 and "fc.weight" in G and "fc_prompt.weight" in G and not late_flush:
         # the same factoring for the weight gradients: the column blocks that multiply the per-crystal inputs are
         # (sum_s dpre[s, b]) (x) [graph_b (| prompt_b)] - B-row jobs on R - and only the E1 block keeps its S * B rows
         E1_, graph_ = a_g.keep[0], a_g.keep[1]

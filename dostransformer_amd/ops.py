@@ -515,11 +515,31 @@ def mlp_ln_fwd_supported(M: int, K: int, NH: int, NO: int) -> bool:
     return 0 < M <= MLP_LN_MAX_ROWS and K * NH <= MLP_LN_MAX_KN_FWD and bool(_lib.load().dosx_mlp_ln_supported(int(K), int(NH), int(NO)))
 
 
+# Column-split form of the one-launch NodeModel kernels (round 6, include/dosx.h: DosxMlpLn.cs_buf): hidden / 16 workgroups per
+# 16-row tile instead of one, while that grid stays a single round of small workgroups
+MLP_LN_CS = __import__("os").environ.get("DOSX_MLP_LN_CS", "1") == "1"
+MLP_LN_CS_MAX_WGS = int(__import__("os").environ.get("DOSX_MLP_LN_CS_MAX_WGS", "512"))
+
+
+def mlp_ln_cs(M: int, K: int, NH: int, NO: int) -> bool:
+    """Whether mlp_ln_fwd / mlp_ln_bwd run the column-split form for this block."""
+    return bool(MLP_LN_CS and M > 0 and _lib.load().dosx_mlp_ln_cs_supported(int(K), int(NH), int(NO))
+                and ((int(M) + 15) // 16) * (int(NO) // 16) <= MLP_LN_CS_MAX_WGS)
+
+
+def _mlp_ln_cs_scratch(d, dev, M: int, NH: int) -> None:
+    lib = _lib.load()
+    buf = alloc(dev, int(lib.dosx_mlp_ln_cs_scratch_floats(int(M), int(NH))))
+    d._cs_keep = buf
+    d.cs_buf, d.cs_cnt = buf.data_ptr(), COUNTERS.take(dev, lib.dosx_mlp_ln_cs_tiles(int(M)))
+
+
 def mlp_ln_fwd(M: int, a0: torch.Tensor, a1: Optional[torch.Tensor], w1, b1, gamma, beta, alpha, w2, b2,
                res: Optional[torch.Tensor], xhat: torch.Tensor, rstd: torch.Tensor, out: torch.Tensor,
-               w3: Optional[torch.Tensor] = None, nb3: int = 0, pq: Optional[torch.Tensor] = None) -> None:
+               w3: Optional[torch.Tensor] = None, nb3: int = 0, pq: Optional[torch.Tensor] = None, cs: Optional[bool] = None) -> None:
     """out = prelu(LN([a0|a1] W1^T + b1)) W2^T + b2 (+ res); xhat / rstd saved (include/dosx.h: DosxMlpLn).
-    w3 [n3, >= nb3 * NO] + pq [M, nb3 * n3]: the third product pq[:, b n3 + n] = out . w3[n, b NO:(b + 1) NO]."""
+    w3 [n3, >= nb3 * NO] + pq [M, nb3 * n3]: the third product pq[:, b n3 + n] = out . w3[n, b NO:(b + 1) NO].
+    cs: column-split form (None: the policy of :func:`mlp_ln_cs`)."""
     d = _lib.MlpLn()
     k0 = int(a0.shape[1])
     d.M, d.K, d.NH, d.NO, d.k0 = int(M), k0 + (int(a1.shape[1]) if a1 is not None else 0), int(w1.shape[0]), int(w2.shape[0]), k0
@@ -536,8 +556,13 @@ def mlp_ln_fwd(M: int, a0: torch.Tensor, a1: Optional[torch.Tensor], w1, b1, gam
         assert pq is not None and w3.stride(1) == 1 and pq.stride(1) == 1 and pq.shape[1] == nb3 * w3.shape[0]
         d.w3, d.ldw3, d.n3, d.nb3 = w3.data_ptr(), int(w3.stride(0)), int(w3.shape[0]), int(nb3)
         d.pq, d.ldpq = pq.data_ptr(), int(pq.stride(0))
+    if cs is None:
+        cs = mlp_ln_cs(d.M, d.K, d.NH, d.NO) and d.k0 % (d.K // 4) == 0
+    if cs:
+        _mlp_ln_cs_scratch(d, out.device, d.M, d.NH)
     _call("dosx_mlp_ln_fwd", C.byref(d), _stream(),
-          w=lambda: (f"mlp_ln_fwd[K{d.K},NH{d.NH},NO{d.NO}" + (",pq" if d.w3 else "") + "]", "mlp_ln_fwd_kernel", "mfma",
+          w=lambda: (f"mlp_ln_fwd[K{d.K},NH{d.NH},NO{d.NO}" + (",pq" if d.w3 else "") + (",cs" if cs else "") + "]",
+                     "mlp_ln_cs_fwd_kernel" if cs else "mlp_ln_fwd_kernel", "mfma",
                      2.0 * _real(d.M) * (d.NH * (d.K + d.NO) + d.nb3 * d.n3 * d.NO)))
 
 
@@ -546,7 +571,7 @@ def mlp_ln_bwd_partial_rows(M: int) -> int:
 
 
 def mlp_ln_bwd(M: int, dy: torch.Tensor, xhat: torch.Tensor, rstd: torch.Tensor, w1, w2, gamma, beta, alpha, dz: torch.Tensor,
-               dcat: torch.Tensor, partials: torch.Tensor, add_dy: bool = False) -> None:
+               dcat: torch.Tensor, partials: torch.Tensor, add_dy: bool = False, cs: Optional[bool] = None) -> None:
     """dz = LN/PReLU backward of (dy W2), dcat = dz W1, [dgamma | dbeta | .. | dalpha] partial rows - one launch
     (include/dosx.h: DosxMlpLnBwd)."""
     d = _lib.MlpLnBwd()
@@ -559,8 +584,13 @@ def mlp_ln_bwd(M: int, dy: torch.Tensor, xhat: torch.Tensor, rstd: torch.Tensor,
     d.dcat, d.lddcat = dcat.data_ptr(), int(dcat.stride(0))
     d.partials, d.partial_ld = partials.data_ptr(), int(partials.stride(0))
     d.add_dy = 1 if add_dy else 0
+    if cs is None:
+        cs = mlp_ln_cs(d.M, d.K, d.NH, d.NO) and d.lddcat % 2 == 0 and dcat.data_ptr() % 8 == 0
+    if cs:
+        _mlp_ln_cs_scratch(d, dz.device, d.M, d.NH)
     _call("dosx_mlp_ln_bwd", C.byref(d), _stream(),
-          w=lambda: (f"mlp_ln_bwd[K{d.K},NH{d.NH},NO{d.NO}]", "mlp_ln_bwd_kernel", "mfma", 2.0 * _real(d.M) * d.NH * (d.K + d.NO)))
+          w=lambda: (f"mlp_ln_bwd[K{d.K},NH{d.NH},NO{d.NO}" + (",cs" if cs else "") + "]",
+                     "mlp_ln_cs_bwd_kernel" if cs else "mlp_ln_bwd_kernel", "mfma", 2.0 * _real(d.M) * d.NH * (d.K + d.NO)))
 
 
 def edge_mlp_supported(H: int) -> bool:
@@ -845,9 +875,8 @@ class GradSink:
         """The stream the gradient reductions of recorded programs run on (weight-gradient stream, else the side stream)."""
         return GradSink._side_streams.get((str(device), False, "w")) or GradSink._side_streams.get((str(device), False))
 
-    # Weight-gradient jobs can be collected and issued as ONE grouped launch at the next flush instead of one kernel
-    # each on the side stream (DESIGN.md 3.1: interleaved they cost the dgrad chain ~0.45 ms per step of interference).
-    group_wgrad = __import__("os").environ.get("DOSX_GROUP_WGRAD", "1") == "1"
+    # Weight-gradient jobs are collected and issued as ONE grouped launch at the next flush instead of one kernel each on
+    # the side stream (interleaved they cost the dgrad chain ~0.45 ms per step of interference: round 1).
 
     def defer_wgrad(self, desc, keep=()) -> None:
         self._keep.extend(keep)
@@ -872,9 +901,6 @@ class GradSink:
         """``fn`` (kernel launches) runs on the stream of the next flush, right in front of its grouped launch: producers of
         operands that only the deferred weight-gradient jobs read (the per-node sums of functional.mlp_ln_bwd)."""
         self._keep.extend(keep)
-        if not GradSink.group_wgrad:          # jobs are launched as they are described: so are their producers
-            fn()
-            return
         if not hasattr(self, "_pre"):
             self._pre = []
         self._pre.append(fn)

@@ -617,8 +617,20 @@ typedef struct DosxMlpLn {
    * NULL w3: none */
   const float* w3; int32_t ldw3, n3, nb3;
   float* pq; int32_t ldpq;
+  /* round 6 - COLUMN-SPLIT form (cs_buf != NULL; shapes of dosx_mlp_ln_cs_supported: the NodeModel (K, NH, NO) = (2, 2, 1) x
+   * hidden, hidden 64 / 128): a 16-row tile is shared by hidden / 16 workgroups of 4 waves, each owning 32 columns of the first
+   * product and 16 of the second (1 / 8 of the weights and of the MFMAs at hidden 128) - 232 workgroups instead of 29 for the 450
+   * node rows of the benchmark batch; the siblings exchange the pre-LayerNorm tile (and, with w3, the output tile) IN the launch:
+   * publish with write-through stores, one ticket each on the tile's counter, every sibling waits for all tickets and reads the
+   * tile back (csrc/mlp2.hip).  cs_buf: dosx_mlp_ln_cs_scratch_floats(M, NH) floats of scratch; cs_cnt: dosx_mlp_ln_cs_tiles(M)
+   * arrival counters, zero before and after the launch.  Same outputs as the one-workgroup-per-tile form to fp32 rounding
+   * (k-split sums added in wave order: bitwise reproducible run to run). */
+  float* cs_buf; int32_t* cs_cnt;
 } DosxMlpLn;
 int dosx_mlp_ln_supported(int K, int NH, int NO);
+int dosx_mlp_ln_cs_supported(int K, int NH, int NO);      /* whether the column-split form exists for this block shape */
+int dosx_mlp_ln_cs_tiles(int M);                          /* counters it needs (= 16-row tiles) */
+int64_t dosx_mlp_ln_cs_scratch_floats(int M, int NH);     /* floats of cs_buf */
 int dosx_mlp_ln_fwd(const DosxMlpLn* a, dosx_stream_t stream);
 
 /* Backward of the same block in one launch:
@@ -638,6 +650,7 @@ typedef struct DosxMlpLnBwd {
   float* partials; int32_t partial_ld;
   int32_t add_dy;                         /* 1: dcat[:, :NO] += dy - the block's residual connection out = res + MLP(cat[res, .])
                                              (NodeModel, DOSTransformer_phonon.py:204-212 + :83) differentiated in the same launch */
+  float* cs_buf; int32_t* cs_cnt;         /* column-split form (see DosxMlpLn): the siblings exchange the `da` tile; same sizes */
 } DosxMlpLnBwd;
 int dosx_mlp_ln_bwd_partial_rows(int M);
 int dosx_mlp_ln_bwd(const DosxMlpLnBwd* a, dosx_stream_t stream);

@@ -118,3 +118,133 @@ def test_mlp_ln_forward_also_multiplies_the_next_layers_node_products(M, H):
     assert float((pq - ref).abs().max()) <= 5e-6 * float(ref.abs().max())
     exact = torch.cat([y0.double() @ W1n[:, :H].double().t(), y0.double() @ W1n[:, H:2 * H].double().t()], 1)
     assert float((pq.double() - exact).abs().max()) <= 2e-5 * float(exact.abs().max())
+
+
+def _node_block(M, H, seed, dev="cuda:0"):
+    gen = torch.Generator().manual_seed(seed)
+    r = lambda *s: (torch.randn(*s, generator=gen)).to(dev)
+    x, agg = r(M, H), r(M, H)
+    W = dict(w1=r(2 * H, 2 * H) / (2 * H) ** 0.5, b1=0.1 * r(2 * H), g=1 + 0.1 * r(2 * H), b=0.1 * r(2 * H),
+             al=torch.tensor([0.25], device=dev), w2=r(H, 2 * H) / (2 * H) ** 0.5, b2=0.1 * r(H))
+    return x, agg, W, r
+
+
+@pytest.mark.parametrize("M,H", [(450, 128), (1, 128), (17, 64), (33, 128), (1000, 64), (255, 128), (16, 64)])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_column_split_node_mlp_forward(M, H, with_res):
+    """Round 6: the column-split NodeModel forward - hidden / 16 workgroups per 16-row tile, the pre-LayerNorm
+    tile exchanged in-launch (publish / ticket / every sibling waits and reads back) - against the one-workgroup-per-tile kernel
+    (fp32 rounding: the k range is split over 4 waves) and float64; with and without the third product (the next layer's node
+    products, a second in-launch exchange of the output tile); launched repeatedly: same bits, counters back at zero."""
+    from dostransformer_amd import ops
+    dev = "cuda:0"
+    x, agg, W, r = _node_block(M, H, 11 * M + H)
+    res = x if with_res else None
+    W1n = r(2 * H, 3 * H) / (3 * H) ** 0.5
+    assert ops.mlp_ln_cs(M, 2 * H, 2 * H, H)
+
+    def fwd(cs, third):
+        xh, rs, out = (torch.full((M, 2 * H), float("nan"), device=dev), torch.full((M,), float("nan"), device=dev),
+                       torch.full((M, H), float("nan"), device=dev))
+        pq = torch.full((M, 4 * H), float("nan"), device=dev) if third else None
+        ops.mlp_ln_fwd(M, x, agg, W["w1"], W["b1"], W["g"], W["b"], W["al"], W["w2"], W["b2"], res, xh, rs, out,
+                       w3=W1n if third else None, nb3=2 if third else 0, pq=pq, cs=cs)
+        torch.cuda.synchronize()
+        return out, xh, rs, pq
+    sc = lambda t: float(t.abs().max()) + 1e-30
+    ref = fwd(False, False)
+    for third in (False, True):
+        got = fwd(True, third)
+        for a_, b_ in zip(got[:3], ref[:3]):
+            assert bool(torch.isfinite(a_).all())
+            assert float((a_ - b_).abs().max()) <= 5e-6 * sc(b_)
+        for _ in range(3):                          # counters are back at zero: the same launch again gives the same bits
+            again = fwd(True, third)
+            assert all(torch.equal(u, v) for u, v in zip(again[:3], got[:3]))
+            assert not third or torch.equal(again[3], got[3])
+        if third:
+            exact = torch.cat([got[0].double() @ W1n[:, :H].double().t(), got[0].double() @ W1n[:, H:2 * H].double().t()], 1)
+            assert float((got[3].double() - exact).abs().max()) <= 2e-5 * sc(exact)
+    # float64
+    z = torch.cat([x, agg], 1).double() @ W["w1"].double().t() + W["b1"].double()
+    y = torch.nn.functional.layer_norm(z, (2 * H,), W["g"].double(), W["b"].double(), 1e-5)
+    y = torch.where(y >= 0, y, 0.25 * y)
+    o64 = y @ W["w2"].double().t() + W["b2"].double() + (res.double() if res is not None else 0)
+    assert float((got[0].double() - o64).abs().max()) <= 2e-5 * sc(o64)
+
+
+@pytest.mark.parametrize("M,H", [(450, 128), (1, 128), (17, 64), (33, 128), (1000, 64), (255, 128)])
+@pytest.mark.parametrize("add_dy", [True, False])
+def test_column_split_node_mlp_backward(M, H, add_dy):
+    """... and the backward: dz, dcat (+ the residual connection's dy on its first H columns), the summed [dgamma | dbeta | dalpha]
+    partial rows against the one-workgroup-per-tile kernel and against float64 autograd; dcat as a strided [M, 2H] view."""
+    from dostransformer_amd import ops
+    dev = "cuda:0"
+    x, agg, W, r = _node_block(M, H, 13 * M + H)
+    dy = r(M, H)
+    xh, rs, out = torch.empty(M, 2 * H, device=dev), torch.empty(M, device=dev), torch.empty(M, H, device=dev)
+    ops.mlp_ln_fwd(M, x, agg, W["w1"], W["b1"], W["g"], W["b"], W["al"], W["w2"], W["b2"], None, xh, rs, out, cs=False)
+    rows = ops.mlp_ln_bwd_partial_rows(M)
+    pld = 4 * H + 4
+
+    def bwd(cs):
+        dz = torch.full((M, 2 * H), float("nan"), device=dev)
+        dcat = torch.full((M, 2 * H), float("nan"), device=dev)
+        part = torch.full((rows, pld), float("nan"), device=dev)
+        ops.mlp_ln_bwd(M, dy, xh, rs, W["w1"], W["w2"], W["g"], W["b"], W["al"], dz, dcat, part, add_dy=add_dy, cs=cs)
+        torch.cuda.synchronize()
+        return dz, dcat, part[:, :4 * H].sum(0), part[:, pld - 1].sum()
+    sc = lambda t: float(t.abs().max()) + 1e-30
+    ref, got = bwd(False), bwd(True)
+    for a_, b_ in zip(got, ref):
+        assert bool(torch.isfinite(a_).all())
+        assert float((a_ - b_).abs().max()) <= 2e-5 * sc(b_)
+    again = bwd(True)
+    assert all(torch.equal(u, v) for u, v in zip(again, got))
+    # float64 autograd
+    xa = torch.cat([x, agg], 1).double().requires_grad_(True)
+    g64, b64, al64 = (W[k].double().requires_grad_(True) for k in ("g", "b", "al"))
+    z = xa @ W["w1"].double().t() + W["b1"].double()
+    y = torch.nn.functional.layer_norm(z, (2 * H,), g64, b64, 1e-5)
+    o = torch.where(y >= 0, y, al64 * y) @ W["w2"].double().t()
+    o.backward(dy.double())
+    dcat64 = xa.grad + (torch.cat([dy.double(), torch.zeros(M, H, dtype=torch.float64, device=dev)], 1) if add_dy else 0)
+    assert float((got[1].double() - dcat64).abs().max()) <= 2e-5 * sc(dcat64)
+    assert float((got[2][:2 * H].double() - g64.grad).abs().max()) <= 5e-5 * sc(g64.grad)
+    assert float((got[2][2 * H:].double() - b64.grad).abs().max()) <= 5e-5 * sc(b64.grad)
+    assert abs(float(got[3]) - float(al64.grad)) <= 5e-5 * max(1.0, abs(float(al64.grad)))
+
+
+def test_column_split_exchange_under_a_bandwidth_hog():
+    """The in-launch exchange (write-through stores, ticket, agent-scope poll, write-through read-back) 400 times back to back while
+    a second stream streams 1 GiB copies through HBM (every XCD's L2 thrashed): every launch bitwise the first."""
+    from dostransformer_amd import ops
+    dev = "cuda:0"
+    M, H = 450, 128
+    x, agg, W, r = _node_block(M, H, 77)
+    W1n = r(2 * H, 3 * H) / (3 * H) ** 0.5
+    dy = r(M, H)
+    hog_a, hog_b = torch.empty(1 << 28, device=dev), torch.empty(1 << 28, device=dev)
+    side = torch.cuda.Stream()
+    outs = []
+    bad = torch.zeros(1, device=dev)
+    first = None
+    for it in range(400):
+        if it % 8 == 0:
+            with torch.cuda.stream(side):
+                hog_b.copy_(hog_a)
+        xh, rs, out, pq = (torch.full((M, 2 * H), float("nan"), device=dev), torch.full((M,), float("nan"), device=dev),
+                           torch.full((M, H), float("nan"), device=dev), torch.full((M, 4 * H), float("nan"), device=dev))
+        ops.mlp_ln_fwd(M, x, agg, W["w1"], W["b1"], W["g"], W["b"], W["al"], W["w2"], W["b2"], x, xh, rs, out, w3=W1n, nb3=2, pq=pq, cs=True)
+        dz, dcat, part = (torch.full((M, 2 * H), float("nan"), device=dev), torch.full((M, 2 * H), float("nan"), device=dev),
+                          torch.full((ops.mlp_ln_bwd_partial_rows(M), 4 * H + 4), float("nan"), device=dev))
+        ops.mlp_ln_bwd(M, dy, xh, rs, W["w1"], W["w2"], W["g"], W["b"], W["al"], dz, dcat, part, add_dy=True, cs=True)
+        cur = (out, xh, pq, dz, dcat, part[:, :4 * H].clone(), part[:, -1].clone())
+        if first is None:
+            first = cur
+        else:
+            for u, v in zip(cur, first):
+                bad += (u != v).any().float()          # compared on the device: no host sync in the loop
+    torch.cuda.synchronize()
+    assert float(bad) == 0.0
+    assert all(bool(torch.isfinite(t).all()) for t in first)

@@ -538,54 +538,3 @@ def test_attention_forward_also_writes_the_next_layernorm(Sq, Bq, Nk, H):
     a.kvhat, a.probs = big_kv.data_ptr(), big_p.data_ptr()
     with pytest.raises(DosxError, match="ln1_out"):
         o.attention_fwd(a)
-
-
-@pytest.mark.parametrize("kind,H", [("phonon", 128), ("edos", 256)])
-def test_weight_gradients_launched_as_they_are_described_match_the_grouped_ones(kind, H):
-    """with GradSink.group_wgrad off every weight-gradient job is LAUNCHED where it is described.  The source
-    block of the factored EdgeModel gradient reads the source-node sums that the node-side launch (dosx_node_grad) writes later
-    in gnn_bwd - its job must be described behind that launch (a closure handed to gnn_bwd), whatever the grouping: the gradients
-    of one step, eager (one stream) and recorded (side stream), equal the grouped ones."""
-    from dostransformer_amd import ops as O, synth
-    from dostransformer_amd.batch import bucket_sizes, collate, pad_batch
-    from dostransformer_amd.train import Trainer
-    torch.manual_seed(0)
-    if kind == "phonon":
-        from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
-        mk = lambda: DOSTransformer_phonon(3, 1, 118, 4, H, DEV, 0.0)
-        g = collate(synth.phonon_crystals(12, seed=5, dtype=torch.float32))
-    else:
-        from dostransformer_amd.embedder_eDOS.DOSTransformer import DOSTransformer
-        mk = lambda: DOSTransformer(3, 1, 200, 41, 2, H, DEV, 0.0)
-        g = collate(synth.edos_crystals(12, seed=5, dtype=torch.float32))
-    gp = pad_batch(g, *bucket_sizes(g.meta.num_nodes, g.meta.num_edges, 8, 128)).to(DEV)
-    sd0 = {k: v.detach().clone() for k, v in mk().state_dict().items()}
-    grads = {}
-    saved = O.GradSink.group_wgrad
-    try:
-        for grouped in (True, False):
-            O.GradSink.group_wgrad = grouped
-            for replay in (False, True):
-                model = mk()
-                model.load_state_dict(sd0)
-                model = model.to(DEV)
-                tr = Trainer(model, lr=1e-3, replay=replay)
-                model.flat_params().grad.fill_(float("nan"))           # a job that never ran / read garbage shows
-                tr.forward_backward(gp) if not replay else tr.step(gp)
-                if replay:                                             # (the recorded program's second issue: the replay itself)
-                    model.flat_params().grad.fill_(float("nan"))
-                    tr.step(gp)
-                torch.cuda.synchronize()
-                grads[(grouped, replay)] = {k: v.clone() for k, v in model.flat_params().G.items()}
-    finally:
-        O.GradSink.group_wgrad = saved
-    for k, v in grads[(True, False)].items():
-        assert bool(torch.isfinite(v).all()), k
-        u = grads[(False, False)][k]
-        assert bool(torch.isfinite(u).all()), ("ungrouped", k)
-        assert err(u, v) < 1e-6, ("eager", k, err(u, v))
-    # recorded: two steps were taken, so compare the recorded forms with each other (same two steps)
-    for k, v in grads[(True, True)].items():
-        u = grads[(False, True)][k]
-        assert bool(torch.isfinite(u).all()), ("ungrouped replay", k)
-        assert err(u, v) < 1e-6, ("replay", k, err(u, v))
