@@ -165,6 +165,14 @@ class MlpLnBwd(C.Structure):
         ("dcat", C.c_void_p), ("lddcat", C.c_int32),
         ("partials", C.c_void_p), ("partial_ld", C.c_int32), ("add_dy", C.c_int32),
         ("cs_buf", C.c_void_p), ("cs_cnt", C.c_void_p),
+        ("pre", C.c_int32), ("pre_dy", C.c_void_p),
+        ("pre_dz", C.c_void_p), ("pre_rowptr_src", C.c_void_p), ("pre_perm_src", C.c_void_p), ("pre_aggd", C.c_void_p),
+        ("pre_w", C.c_void_p), ("pre_ldw", C.c_int32),
+        ("pre_res", C.c_void_p), ("pre_ldres", C.c_int32), ("pre_res2", C.c_void_p), ("pre_ldres2", C.c_int32),
+        ("pre_aggs", C.c_void_p),
+        ("pre_dkv", C.c_void_p), ("pre_kvhat", C.c_void_p), ("pre_rstd_nodes", C.c_void_p), ("pre_dense_row", C.c_void_p),
+        ("pre_dpool", C.c_void_p), ("pre_ld_dpool", C.c_int32), ("pre_node_graph", C.c_void_p), ("pre_num_graphs", C.c_int32),
+        ("pre_ghost_row", C.c_int32),
     ]
 
 

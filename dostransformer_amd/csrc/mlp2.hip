@@ -708,18 +708,29 @@ __global__ __launch_bounds__(256) void mlp_ln_cs_fwd_kernel(const DosxMlpLn a) {
 
 // Backward, column-split the same way: da slice (32 columns) -> exchange -> PReLU / LayerNorm backward of the whole tile by every
 // sibling (dz rows dealt over the siblings; column sums of this workgroup's 32 columns; dalpha by sibling 0) -> 32 columns of dcat.
-template <int H>
+// PRE: what PRODUCES dy, in the same launch (DosxMlpLnBwd.pre) - the N-row kernel that used to run in front of this one:
+//   1  the node side of the LATER layer's factored input gradient (dosx_node_grad: source-node sums of dz, dx = res + res2 +
+//      aggS Wa + aggD Wb): the tile's 16 nodes are dealt over the siblings for the gather (16 / NS nodes each, their rows summed
+//      in CSR order; at hidden 128 two waves per node, halves added in order), the sums are exchanged (aggs itself is the medium),
+//      every sibling multiplies its 16 columns of dx, dx is exchanged (dy itself is the medium) - three exchanges per launch;
+//   2  the to_dense_batch / key-LayerNorm backward + the pooled decoder gradient (dosx_dense_normalize_pool_bwd): row-local, every
+//      sibling computes the tile's 16 rows, the rows are written by the sibling they are dealt to - no extra exchange.
+template <int H, int PRE>
 __global__ __launch_bounds__(256) void mlp_ln_cs_bwd_kernel(const DosxMlpLnBwd a) {
   DOSX_SET_MAIN_PRIO();
   constexpr int K = 2 * H, NH = 2 * H, NO = H, NS = H / 16;
   constexpr int KW1 = NO / 4, S1 = KW1 / 16;        // first product reduces over NO = H
   constexpr int KW2 = NH / 4, S2 = KW2 / 16;        // second over NH = 2H
-  constexpr int NG = NH / 64;
-  constexpr int LDT = NH + 4, LDR = 36;
+  constexpr int NG = NH / 64, OG = NO / 64;
+  constexpr int LDT = NH + 4, LDR = 36, LDY = NO + 4;
+  constexpr int NPW = 16 / NS, PARTS = 4 / NPW;     // PRE 1: nodes per workgroup, waves per node
+  constexpr int SP = H / 16;                        // PRE 1: 16-wide steps of one wave's k range (H of the 4H)
   static_assert(S1 >= 1, "hidden >= 64");
   __shared__ __align__(16) float T[16 * LDT];
   __shared__ __align__(16) float Rd[4 * 16 * LDR];
   __shared__ __align__(16) float Sg[2 * 16 * 32];
+  __shared__ __align__(16) float Ys[PRE ? 16 * LDY : 4];
+  __shared__ __align__(16) float Pg[PRE == 1 ? 4 * NH : 4];
   __shared__ float Pal[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
   const int row = tid >> 4, q = tid & 15;
@@ -730,13 +741,15 @@ __global__ __launch_bounds__(256) void mlp_ln_cs_bwd_kernel(const DosxMlpLnBwd a
   const int grow = m0 + row;
   const bool rvalid = grow < M;
   const int rc = min(grow, M - 1);
-  // ---- operands, requested first: dy fragments, W2 fragments ([k][n] as stored: one dword per MFMA), then the row-phase rows ----
+  // ---- operands, requested first: (PRE 0: dy fragments,) W2 fragments ([k][n] as stored: one dword per MFMA), the row-phase rows ----
   float4 av[S1];
   float bq1[2][S1][4];
   {
-    const float* dyp = a.dy + (size_t)rowA * a.lddy + wave * KW1 + 4 * g4;
+    if constexpr (PRE == 0) {
+      const float* dyp = a.dy + (size_t)rowA * a.lddy + wave * KW1 + 4 * g4;
 #pragma unroll
-    for (int s = 0; s < S1; ++s) av[s] = ld4(dyp + 16 * s);
+      for (int s = 0; s < S1; ++s) av[s] = ld4(dyp + 16 * s);
+    }
     const float* wp = a.w2 + (size_t)(wave * KW1 + 4 * g4) * NH + 32 * j + l15;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -744,6 +757,49 @@ __global__ __launch_bounds__(256) void mlp_ln_cs_bwd_kernel(const DosxMlpLnBwd a
       for (int s = 0; s < S1; ++s)
 #pragma unroll
         for (int i = 0; i < 4; ++i) bq1[t][s][i] = wp[(size_t)(16 * s + i) * NH + 16 * t];
+  }
+  // ---- PRE 1, part 1: this wave's share of a node's source segment (bounds -> edge ids -> rows, 12 in flight), the weight
+  //      fragments of the dx product, the aggD fragments (waves 2, 3) ----
+  float pw[PRE == 1 ? SP : 1][4];
+  float4 pa[PRE == 1 ? SP : 1];
+  if constexpr (PRE == 1) {
+    const int sgp = wave >> 1, kl0 = (wave & 1) * H;         // this wave multiplies rows [kl0, kl0 + H) of Wa (waves 0, 1) / Wb (2, 3)
+    {
+      const float* wp = a.pre_w + (size_t)(kl0 + 4 * g4) * a.pre_ldw + sgp * H + 16 * j + l15;
+#pragma unroll
+      for (int s = 0; s < SP; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pw[s][i] = wp[(size_t)(16 * s + i) * a.pre_ldw];
+    }
+    if (sgp == 1) {
+#pragma unroll
+      for (int s = 0; s < SP; ++s) pa[s] = ld4(a.pre_aggd + (size_t)rowA * NH + kl0 + 16 * s + 4 * g4);
+    }
+    const int ns = wave % NPW, part = wave / NPW;
+    const int n = m0 + j + NS * ns;
+    const bool nv = n < M;
+    const int beg = nv ? a.pre_rowptr_src[n] : 0, end = nv ? a.pre_rowptr_src[n + 1] : 0;
+    const int per = (end - beg + PARTS - 1) / PARTS;
+    const int pb = beg + part * per, pe = min(end, pb + per);
+    const int c = lane * 4, cc = c < NH ? c : 0;
+    float4 acc = f4zero();
+    constexpr int U = 12;
+    for (int j0 = pb; j0 < pe; j0 += 64) {
+      const int je = min(pe, j0 + 64);
+      const int myid = a.pre_perm_src[min(j0 + lane, je - 1)];
+      for (int u0 = j0; u0 < je; u0 += U) {
+        float4 m[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int ei = __builtin_amdgcn_readlane(myid, min(u0 - j0 + u, 63));
+          m[u] = ld4(a.pre_dz + (size_t)ei * NH + cc);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (u0 + u < je) acc = f4add(acc, m[u]);
+      }
+    }
+    if (c < NH) st4(Pg + (ns * PARTS + part) * NH + c, acc);
   }
   float4 gam[NG], bet[NG], xh[NG];
 #pragma unroll
@@ -764,7 +820,89 @@ __global__ __launch_bounds__(256) void mlp_ln_cs_bwd_kernel(const DosxMlpLnBwd a
         for (int i = 0; i < 4; ++i) bq2[t][s][i] = wp[(size_t)(16 * s + i) * K + 16 * t];
   }
   float2 dyres = make_float2(0.f, 0.f);
-  if (a.add_dy && 32 * j + 2 * q < NO) dyres = *reinterpret_cast<const float2*>(a.dy + (size_t)rc * a.lddy + 32 * j + 2 * q);
+  if constexpr (PRE == 0) {
+    if (a.add_dy && 32 * j + 2 * q < NO) dyres = *reinterpret_cast<const float2*>(a.dy + (size_t)rc * a.lddy + 32 * j + 2 * q);
+  }
+  int xphase = 0;                                   // exchanges done so far
+  if constexpr (PRE == 1) {
+    // ---- part 2: the source sums -> aggs (write-through: the siblings read them back; the weight-gradient job reads them later) ----
+    const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)a.pre_aggs, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)a.pre_dy, 0, 0x7fffffff, 0x00020000);
+    __syncthreads();
+    if (tid < NPW * (NH / 4)) {
+      const int ns = tid / (NH / 4), c4 = tid - ns * (NH / 4);
+      float4 v = ld4(Pg + (ns * PARTS) * NH + 4 * c4);
+      if constexpr (PARTS == 2) v = f4add(v, ld4(Pg + (ns * PARTS + 1) * NH + 4 * c4));
+      const int n = m0 + j + NS * ns;
+      if (n < M) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i32_, v), rS, (uint32_t)(((size_t)n * NH + 4 * c4) * 4), 0, 16);   // sc1
+    }
+    cs_publish_done_and_wait(cnt, NS * ++xphase);
+    // ---- part 3: 16 columns of dx = res + res2 + aggS Wa + aggD Wb (this wave: H of the 4H reduction) ----
+    const int sgp = wave >> 1, kl0 = (wave & 1) * H;
+    if (sgp == 0) {
+#pragma unroll
+      for (int s = 0; s < SP; ++s)
+        pa[s] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rS, (uint32_t)(((size_t)rowA * NH + kl0 + 16 * s + 4 * g4) * 4), 0, 16));   // sc1
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < SP; ++s) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s].x, pw[s][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s].y, pw[s][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s].z, pw[s][2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[s].w, pw[s][3], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Rd[(wave * 16 + 4 * g4 + r) * LDR + l15] = acc[r];
+    __syncthreads();
+    {
+      float o = (a.pre_res ? a.pre_res[(size_t)rc * a.pre_ldres + 16 * j + q] : 0.f) + (a.pre_res2 ? a.pre_res2[(size_t)rc * a.pre_ldres2 + 16 * j + q] : 0.f);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) o += Rd[(w * 16 + row) * LDR + q];
+      if (rvalid) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, o), rY, (uint32_t)(((size_t)grow * a.lddy + 16 * j + q) * 4), 0, 16);   // sc1
+    }
+    cs_publish_done_and_wait(cnt, NS * ++xphase);
+#pragma unroll
+    for (int i = 0; i < OG; ++i)
+      st4(Ys + row * LDY + 4 * q + 64 * i,
+          __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rY, (uint32_t)(((size_t)rc * a.lddy + 4 * q + 64 * i) * 4), 0, 16)));   // sc1
+    __syncthreads();
+  }
+  if constexpr (PRE == 2) {
+    // ---- dy rows = key-LayerNorm backward of the dense key gradient + the pooled decoder gradient (row-local; all 16 rows) ----
+    const int dr = a.pre_dense_row[rc];
+    const int gph = a.pre_node_graph[rc];
+    const float* add = gph < a.pre_num_graphs ? a.pre_dpool + (size_t)gph * a.pre_ld_dpool : nullptr;
+    const bool ghost = dr == a.pre_ghost_row;
+    float4 gk[OG], xk[OG], ad[OG];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < OG; ++i) {
+      const int c = 4 * q + 64 * i;
+      gk[i] = ghost ? f4zero() : ld4(a.pre_dkv + (size_t)dr * NO + c);
+      xk[i] = ghost ? f4zero() : ld4(a.pre_kvhat + (size_t)dr * NO + c);
+      ad[i] = add ? ld4(add + c) : f4zero();
+      s1 += (gk[i].x + gk[i].y) + (gk[i].z + gk[i].w);
+      s2 += (gk[i].x * xk[i].x + gk[i].y * xk[i].y) + (gk[i].z * xk[i].z + gk[i].w * xk[i].w);
+    }
+    const float rsn = ghost ? 0.f : a.pre_rstd_nodes[rc];
+    const float m1 = row16_sum(s1) * (1.f / (float)NO), m2 = row16_sum(s2) * (1.f / (float)NO);
+    const bool mine = rvalid && (row & (NS - 1)) == j;
+#pragma unroll
+    for (int i = 0; i < OG; ++i) {
+      const int c = 4 * q + 64 * i;
+      const float4 o = make_float4(ad[i].x + rsn * (gk[i].x - m1 - xk[i].x * m2), ad[i].y + rsn * (gk[i].y - m1 - xk[i].y * m2),
+                                   ad[i].z + rsn * (gk[i].z - m1 - xk[i].z * m2), ad[i].w + rsn * (gk[i].w - m1 - xk[i].w * m2));
+      st4(Ys + row * LDY + c, o);
+      if (mine) st4(a.pre_dy + (size_t)grow * a.lddy + c, o);
+    }
+    __syncthreads();
+  }
+  if constexpr (PRE != 0) {
+#pragma unroll
+    for (int s = 0; s < S1; ++s) av[s] = ld4(Ys + l15 * LDY + wave * KW1 + 16 * s + 4 * g4);
+    if (a.add_dy && 32 * j + 2 * q < NO) dyres = *reinterpret_cast<const float2*>(Ys + row * LDY + 32 * j + 2 * q);
+  }
   // ---- first product ----
   {
     f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -777,6 +915,7 @@ __global__ __launch_bounds__(256) void mlp_ln_cs_bwd_kernel(const DosxMlpLnBwd a
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s].z, bq1[t][s][2], acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s].w, bq1[t][s][3], acc[t], 0, 0, 0);
       }
+    if constexpr (PRE == 1) __syncthreads();        // (Rd: the dx product's partial tiles have been read)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -793,7 +932,7 @@ __global__ __launch_bounds__(256) void mlp_ln_cs_bwd_kernel(const DosxMlpLnBwd a
     }
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i32, z), rZ, (uint32_t)(((size_t)(m0 + row) * NH + 32 * j + 2 * q) * 4), 0, 16);   // sc1
   }
-  cs_publish_done_and_wait(cnt, NS);
+  cs_publish_done_and_wait(cnt, NS * ++xphase);
   // ---- row phase on the whole tile: PReLU backward, LayerNorm backward; dz out (rows dealt over the siblings) and -> T ----
   {
     const float invN = 1.f / (float)NH;
@@ -864,15 +1003,16 @@ __global__ __launch_bounds__(256) void mlp_ln_cs_bwd_kernel(const DosxMlpLnBwd a
   }
   __syncthreads();
   {
-    float2 o = dyres;
+    float2 o = make_float2(0.f, 0.f);
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       const float2 p = *reinterpret_cast<const float2*>(Rd + (w * 16 + row) * LDR + 2 * q);
       o.x += p.x; o.y += p.y;
     }
+    o.x += dyres.x; o.y += dyres.y;                 // (the residual path LAST: dcat with add_dy == dcat without + dy, to the bit)
     if (rvalid) *reinterpret_cast<float2*>(a.dcat + (size_t)grow * a.lddcat + 32 * j + 2 * q) = o;
   }
-  cs_exit(cnt, 2 * NS - 1);
+  cs_exit(cnt, NS * (xphase + 1) - 1);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -908,7 +1048,7 @@ extern "C" int dosx_mlp_ln_fwd(const DosxMlpLn* ap, dosx_stream_t stream) {
                  "dosx_mlp_ln_fwd: operands must be 16-byte aligned with leading dimensions that are multiples of 4");
   const long long span = (const char*)a.w1 > (const char*)a.w2 ? (const char*)a.w1 - (const char*)a.w2 : (const char*)a.w2 - (const char*)a.w1;
   DOSX_CHECK_ARG(span + (long long)4 * a.NH * (a.K + a.NO) < 0x7fffffffLL, "dosx_mlp_ln_fwd: the two weight matrices are more than 2 GiB apart");
-  if (a.w3)
+  if (a.w3 && !a.cs_buf)
     DOSX_CHECK_ARG(a.pq && a.nb3 >= 1 && a.n3 >= 256 && a.n3 % 256 == 0 && (a.ldw3 & 3) == 0 && a.ldw3 >= a.nb3 * a.NO && aligned16(a.w3) &&
                        a.ldpq >= a.nb3 * a.n3,
                    "dosx_mlp_ln_fwd: third product needs pq, n3 a multiple of 256, ldw3 >= nb3 * NO (multiple of 4), ldpq >= nb3 * n3");
@@ -917,7 +1057,7 @@ extern "C" int dosx_mlp_ln_fwd(const DosxMlpLn* ap, dosx_stream_t stream) {
     DOSX_CHECK_ARG(a.k0 % (a.K / 4) == 0 && a.ldo >= a.NO && aligned16(a.cs_buf) && aligned16(a.w1) && aligned16(a.w2) && aligned16(a.gamma) &&
                    aligned16(a.beta) && (reinterpret_cast<uintptr_t>(a.b1) & 7) == 0,
                    "dosx_mlp_ln_fwd: column-split form needs k0 a multiple of K / 4 and aligned weights");
-    if (a.w3) DOSX_CHECK_ARG(a.nb3 * a.n3 == 4 * a.NO && (a.ldpq & 3) == 0 && aligned16(a.pq), "dosx_mlp_ln_fwd: column-split third product needs nb3 * n3 == 4 * NO");
+    if (a.w3) DOSX_CHECK_ARG(a.pq && a.nb3 >= 1 && a.nb3 * a.n3 == 4 * a.NO && (a.ldw3 & 3) == 0 && a.ldw3 >= a.nb3 * a.NO && aligned16(a.w3) && (a.ldpq & 3) == 0 && aligned16(a.pq), "dosx_mlp_ln_fwd: column-split third product needs nb3 * n3 == 4 * NO");
     const int ns = a.NO / 16;
     const dim3 grid(ceil_div(a.M, MR) * ns);
     if (a.NO == 64) hipLaunchKernelGGL(mlp_ln_cs_fwd_kernel<64>, grid, dim3(256), 0, to_stream(stream), a);
@@ -963,13 +1103,31 @@ extern "C" int dosx_mlp_ln_bwd(const DosxMlpLnBwd* ap, dosx_stream_t stream) {
     DOSX_CHECK_ARG(dosx_mlp_ln_cs_supported(a.K, a.NH, a.NO) && a.cs_cnt, "dosx_mlp_ln_bwd: column-split form needs the NodeModel shape at hidden 64 / 128 and counters");
     DOSX_CHECK_ARG((a.lddcat & 1) == 0 && (reinterpret_cast<uintptr_t>(a.dcat) & 7) == 0 && aligned16(a.cs_buf) && aligned16(a.gamma) && aligned16(a.beta),
                    "dosx_mlp_ln_bwd: column-split form needs an 8-byte aligned dcat with an even leading dimension");
+    DOSX_CHECK_ARG(a.pre >= 0 && a.pre <= 2, "dosx_mlp_ln_bwd: pre %d", a.pre);
+    if (a.pre == 1)
+      DOSX_CHECK_ARG(a.pre_dz && a.pre_rowptr_src && a.pre_perm_src && a.pre_aggd && a.pre_w && a.pre_aggs && a.pre_dy == a.dy && a.pre_ldw >= 2 * a.NO &&
+                         aligned16(a.pre_dz) && aligned16(a.pre_aggd) && aligned16(a.pre_aggs) && aligned16(a.dy) && a.lddy >= a.NO,
+                     "dosx_mlp_ln_bwd: pre = 1 (node side of the factored input gradient) needs dz / rowptr_src / perm_src / aggd / w / aggs and pre_dy == dy");
+    if (a.pre == 2)
+      DOSX_CHECK_ARG(a.pre_dkv && a.pre_kvhat && a.pre_rstd_nodes && a.pre_dense_row && a.pre_dpool && a.pre_node_graph && a.pre_num_graphs > 0 &&
+                         (a.pre_ld_dpool & 3) == 0 && a.pre_dy == a.dy && aligned16(a.pre_dkv) && aligned16(a.pre_kvhat) && aligned16(a.pre_dpool) && aligned16(a.dy),
+                     "dosx_mlp_ln_bwd: pre = 2 (dense-key backward + pooled gradient) needs dkv / kvhat / rstd_nodes / dense_row / dpool / node_graph and pre_dy == dy");
     const int ns = a.NO / 16;
     const dim3 grid(ceil_div(a.M, MR) * ns);
-    if (a.NO == 64) hipLaunchKernelGGL(mlp_ln_cs_bwd_kernel<64>, grid, dim3(256), 0, to_stream(stream), a);
-    else hipLaunchKernelGGL(mlp_ln_cs_bwd_kernel<128>, grid, dim3(256), 0, to_stream(stream), a);
+    hipStream_t st = to_stream(stream);
+#define DOSX_CSB(HH)                                                                                           \
+  do {                                                                                                         \
+    if (a.pre == 1) hipLaunchKernelGGL((mlp_ln_cs_bwd_kernel<HH, 1>), grid, dim3(256), 0, st, a);              \
+    else if (a.pre == 2) hipLaunchKernelGGL((mlp_ln_cs_bwd_kernel<HH, 2>), grid, dim3(256), 0, st, a);         \
+    else hipLaunchKernelGGL((mlp_ln_cs_bwd_kernel<HH, 0>), grid, dim3(256), 0, st, a);                         \
+  } while (0)
+    if (a.NO == 64) DOSX_CSB(64);
+    else DOSX_CSB(128);
+#undef DOSX_CSB
     DOSX_LAUNCH_CHECK();
     return 0;
   }
+  DOSX_CHECK_ARG(a.pre == 0, "dosx_mlp_ln_bwd: pre needs the column-split form (cs_buf)");
   const size_t smem = sizeof(float) * ((size_t)MR * (a.NO + 4) + (size_t)MR * (a.NH + 4) + 16 * (size_t)a.NH + 8 + 8 * (size_t)WP_FLOATS);
   static bool attr_set = false;
   if (!attr_set) {

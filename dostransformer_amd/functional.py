@@ -290,7 +290,7 @@ def mlp_ln_fwd(P: Params, key: str, a: SegList, M: int, H: int, res: Optional[to
 
 
 def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: GradSink, res: Optional[torch.Tensor] = None,
-               res_col0: int = 0, add_dy: bool = False) -> torch.Tensor:
+               res_col0: int = 0, add_dy: bool = False, pre: Optional[dict] = None) -> torch.Tensor:
     """Returns dL/d(concatenated input) [M, K_in] (+ ``res`` added to its columns [res_col0, K_in)).
     add_dy (one-launch path only, see mlp_ln_bwd_fused): + dy on the first H columns - the residual connection around the
     block, x' = x + MLP(cat[x, .]), differentiated in the same launch."""
@@ -316,6 +316,7 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
                       pro_gamma=gam, pro_beta=bet, pro_alpha=alpha)
     fused = mlp_ln_bwd_fused(a, M, H, dy) and agg_first is None and res is None
     assert fused or not add_dy
+    assert pre is None or fused           # (pre: what produces dy, in the same column-split launch - see node_chain_ok)
     wide = _wide_ln(H) or agg_first is not None
     fac_dgrad = a.factor is not None and _factor_edge(M, H, a.factor[2]) and _FACTOR_DGRAD and not fused
     # round 5: the destination-node sums of dz (the factored weight / input gradients below need them) inside the dgrad GEMM's
@@ -335,7 +336,7 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
     dz = _empty(dev, M, 2 * H)
     dcat = None if fac_dgrad else _empty(dev, M, a.K)
     if fused:
-        ops.mlp_ln_bwd(M, dy, xhat, rstd, P[key + ".0.weight"], P[key + ".3.weight"], gam, bet, alpha, dz, dcat, part, add_dy=add_dy)
+        ops.mlp_ln_bwd(M, dy, xhat, rstd, P[key + ".0.weight"], P[key + ".3.weight"], gam, bet, alpha, dz, dcat, part, add_dy=add_dy, pre=pre)
     elif agg_first is not None:
         ops.ln_prelu_bwd_gather(dnode, a.factor[2].dst, agg_first[2], xhat, rstd, gam, bet, alpha, dz, part, M, 2 * H)
     elif wide:          # plain dgrad GEMM, then PReLU + LayerNorm backward of the 2H-wide rows as a row kernel
@@ -411,6 +412,29 @@ def mlp_ln_bwd(P: Params, G: Params, key: str, ctx, dy: torch.Tensor, sink: Grad
     if not fused:
         ops.gemm(M, a.K, [seg(dz)], P[key + ".0.weight"], dcat, w_layout=1, res=res, res_col0=res_col0 if res is not None else 0)
     return dcat
+
+
+# Round 6: the N-row launch in front of a NodeModel backward - the node side of the later layer's input gradient (dosx_node_grad),
+# or the dense-key / pooled-decoder backward in front of the last layer's - runs INSIDE that column-split launch (DosxMlpLnBwd.pre)
+# (measured, tools/exp/r6_run2.sh / r6_run3.sh, cfg2 step, three interleaved rounds each: the dense-key launch absorbed 1.0940 ->
+#  1.0726 ms - kept; the node side absorbed as well 1.0893 -> 1.1018 ms, with the layer's weight-gradient group flushed behind the
+#  launch instead of in front of it 1.1102 ms - three in-launch exchanges under a weight-gradient group cost more than the launch
+#  they save: off)
+_NODE_CHAIN = __import__("os").environ.get("DOSX_NODE_CHAIN", "0") == "1"
+_DENSE_CHAIN = __import__("os").environ.get("DOSX_DENSE_CHAIN", "1") == "1"
+# ... and the layer's weight-gradient group is then flushed BEHIND that launch (it runs alone, all CUs) instead of in front of it
+# the early gradient bucket's flush (transformers / heads: `mid_hook`) BEHIND the last layer's NodeModel backward launch instead of
+# in front of it - that launch then does not start under a freshly launched weight-gradient group: 1.0726 -> 1.0690 ms per cfg2
+# step, three interleaved rounds (tools/exp/r6_run4.sh)
+_MID_HOOK_LATE = __import__("os").environ.get("DOSX_MID_HOOK_LATE", "1") == "1"
+_FLUSH_AFTER_CHAIN = __import__("os").environ.get("DOSX_FLUSH_AFTER_CHAIN", "0") == "1"
+
+
+def node_chain_ok(cxn, N: int, H: int) -> bool:
+    """Whether the NodeModel backward described by ``cxn`` (mlp_ln_fwd's context) will run as the column-split one-launch kernel
+    on a contiguous [N, H] gradient - the form that takes ``pre``."""
+    a = cxn[0]
+    return (_mlp_ln_fused(a, N, H) and a.aggsum is None and ops.MLP_LN_CS_BWD != "0" and ops.mlp_ln_cs(N, 2 * H, 2 * H, H))
 
 
 def edge_bwd_one_launch_ok(a: SegList, M: int, H: int) -> bool:
@@ -509,10 +533,18 @@ def gnn_fwd(P: Params, m: GraphMeta, x: torch.Tensor, e: torch.Tensor, L: int, m
 _SPLIT_LATE_FLUSH = int(__import__("os").environ.get("DOSX_SPLIT_LATE_FLUSH", "1"))
 
 
-def gnn_bwd(P: Params, G: Params, m: GraphMeta, ctxs, dx: torch.Tensor, sink: GradSink, L: int, mean: bool, H: int):
-    """Returns (dL/dx_0 [N,H], dL/de_0 as a strided [E,H] view or None)."""
+def gnn_bwd(P: Params, G: Params, m: GraphMeta, ctxs, dx: torch.Tensor, sink: GradSink, L: int, mean: bool, H: int, dx_pre=None):
+    """Returns (dL/dx_0 [N,H], dL/de_0 as a strided [E,H] view or None).
+    dx_pre: None, or (pre, launch): ``dx`` has NOT been computed yet - ``pre`` is the ops.mlp_ln_bwd ``pre`` dictionary that makes
+    it inside the last layer's NodeModel backward launch, ``launch()`` the stand-alone launch for when that form does not apply."""
     N, E = m.num_nodes, m.num_edges
     dev = dx.device
+    pending = None          # the `pre` of the NEXT NodeModel backward: this layer's node-side launch, deferred into it
+    if dx_pre is not None:
+        if _DENSE_CHAIN and node_chain_ok(ctxs[L - 1][1], N, H) and dx.is_contiguous():
+            pending = dx_pre[0]
+        else:
+            dx_pre[1]()
     scale = m.inv_deg if mean else None
     de = None           # dL/de_{l+1}: the e-block (columns [2H,3H)) of the next layer's concat gradient
 
@@ -530,7 +562,14 @@ def gnn_bwd(P: Params, G: Params, m: GraphMeta, ctxs, dx: torch.Tensor, sink: Gr
         # factored edge layer + one-launch NodeModel backward: the residual path's dx rides on the first H columns of dcat_n
         fold_dx = (cxe[0].factor is not None and _factor_edge(E, H, m) and _FACTOR_DGRAD and _factor_fused(m, H)
                    and mlp_ln_bwd_fused(cxn[0], N, H, dx))
-        dcat_n = mlp_ln_bwd(P, G, pre + ".node_model.node_mlp_2", cxn, dx, sink, add_dy=fold_dx)          # [N, 2H]
+        dcat_n = mlp_ln_bwd(P, G, pre + ".node_model.node_mlp_2", cxn, dx, sink, add_dy=fold_dx, pre=pending)          # [N, 2H]
+        if pending is not None and pending.get("flush_after"):
+            flush_side(l)
+        pending = None
+        hook1 = getattr(sink, "after_first_node", None)
+        if hook1 is not None:
+            sink.after_first_node = None
+            hook1(sink)
         if edge_bwd_one_launch_ok(cxe[0], E, H):
             # gather + add of the message gradient, both input-gradient products with the PReLU / LayerNorm backward between
             # them, the destination-node sums: one launch on the node-aligned row tiles (csrc/edge_mlp.hip)
@@ -557,11 +596,18 @@ def gnn_bwd(P: Params, G: Params, m: GraphMeta, ctxs, dx: torch.Tensor, sink: Gr
             if node_one:
                 src_job = dcat_e[5]                    # the source block's weight-gradient job: reads the sums the launch below makes
                 early = bool(dcat_e[6])                # the layer's group starts BEFORE the node-side launch, under it
-                if early and sink.wside is not None and (l == 0 or (_SPLIT_LATE_FLUSH == 1 and l == 1) or (_SPLIT_LATE_FLUSH == 2 and l >= 1)):
+                chain = _NODE_CHAIN and l > 0 and node_chain_ok(ctxs[l - 1][1], N, H)
+                do_flush = early and sink.wside is not None and (l == 0 or (_SPLIT_LATE_FLUSH == 1 and l == 1) or (_SPLIT_LATE_FLUSH == 2 and l >= 1))
+                if do_flush and not (chain and _FLUSH_AFTER_CHAIN):
                     flush_side(l)
-                # source sums of dz + both node products + the residual terms: ONE launch (csrc/edge_mlp.hip, node_grad_kernel)
-                ops.node_grad(N, H, dcat_e[4], m.rowptr_src, m.perm_src, aggD, W0, dcat_n[:, :H], None if fold_dx else dx, aggS, dx_old)
-                sink._keep.extend([dcat_n, dx])
+                # source sums of dz + both node products + the residual terms: ONE launch (csrc/edge_mlp.hip, node_grad_kernel) -
+                # or, round 6, the front part of the NEXT layer's NodeModel backward launch (DosxMlpLnBwd.pre = 1)
+                if chain:
+                    pending = dict(kind="node_grad", dz=dcat_e[4], rowptr_src=m.rowptr_src, perm_src=m.perm_src, aggd=aggD, w=W0,
+                                   res=dcat_n[:, :H], res2=None if fold_dx else dx, aggs=aggS, flush_after=do_flush and _FLUSH_AFTER_CHAIN)
+                else:
+                    ops.node_grad(N, H, dcat_e[4], m.rowptr_src, m.perm_src, aggD, W0, dcat_n[:, :H], None if fold_dx else dx, aggS, dx_old)
+                sink._keep.extend([dcat_n, dx, dcat_e[4], aggD])
                 if src_job is not None:
                     src_job()                          # (described BEHIND the launch that writes its operand; early: next group)
                 if early:
@@ -1215,15 +1261,15 @@ def _gnn_trunk_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta, node_key: str):
 
 
 def gnn_trunk_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, dxL: torch.Tensor, du_seg: Optional[Seg],
-                  sink: GradSink):
+                  sink: GradSink, dx_pre=None):
     with ops.graph_rows():
-        _gnn_trunk_bwd(P, G, cfg, m, ctx, dxL, du_seg, sink)
+        _gnn_trunk_bwd(P, G, cfg, m, ctx, dxL, du_seg, sink, dx_pre)
 
 
 def _gnn_trunk_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, dxL: torch.Tensor, du_seg: Optional[Seg],
-                   sink: GradSink):
+                   sink: GradSink, dx_pre=None):
     cn, ce, cu, cg, node_key = ctx
-    dx0, de0 = gnn_bwd(P, G, m, cg, dxL, sink, cfg.L, cfg.mean, cfg.H)
+    dx0, de0 = gnn_bwd(P, G, m, cg, dxL, sink, cfg.L, cfg.mean, cfg.H, dx_pre=dx_pre)
     if _ENC_BWD_PAIR and de0 is not None and cn[3] == ce[3]:
         mlp_prelu_bwd_pair(P, G, (node_key, cn, dx0), ("GN_encoder.edge_encoder", ce, de0), sink, tail=True)
         if cu is not None and du_seg is not None:
@@ -1446,18 +1492,32 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
     sink.join()          # dkv (dense keys): the earlier layers' key-gradient kernels ran on the side stream
     # gradient of the energy embeddings (sum over the batch): nobody waits for it - side stream, under the GNN backward
     sink.on_side(lambda: ops.reduce_rows(dX1.data_ptr(), H, G["embeddings.weight"].data_ptr(), H, S, B, B, 1, H), (dX1,))
+    late_hook = None
     if mid_hook is not None:          # (after the join: the early bucket's reduction must not sit between the main
-        mid_hook(sink)                #  stream and the dk/dv kernels it is waiting for)
+        if _MID_HOOK_LATE and dx_ext is None and cfg.L >= 1:
+            late_hook = mid_hook      # (experiment: behind the last layer's NodeModel backward launch, gnn_bwd)
+        else:
+            mid_hook(sink)            #  stream and the dk/dv kernels it is waiting for)
     # node embeddings: dense keys + pooled decoder input (+ external grad on the returned x)
     dxL = _empty(dev, N, H)
     dcat = box_d["dcat"]
     Kd = dec_segs.K
-    ops.dense_normalize_pool_bwd(dkv, kvhat, rstd_n, m.dense_row, dcat.data_ptr() + 4 * (Kd - H), Kd, m.node_graph, B, dxL, N, H,
-                                 False, ghost_row=nmax * B)
+    def dense_launch():
+        ops.dense_normalize_pool_bwd(dkv, kvhat, rstd_n, m.dense_row, dcat.data_ptr() + 4 * (Kd - H), Kd, m.node_graph, B, dxL, N, H,
+                                     False, ghost_row=nmax * B)
+    dx_pre = None
+    if dx_ext is not None or cfg.L < 1:
+        dense_launch()
+    else:
+        # (round 6: inside the last message-passing layer's NodeModel backward launch, when that runs column-split: gnn_bwd)
+        dx_pre = (dict(kind="dense", dkv=dkv, kvhat=kvhat, rstd_nodes=rstd_n, dense_row=m.dense_row, dpool_ptr=dcat.data_ptr() + 4 * (Kd - H),
+                       ld_dpool=Kd, node_graph=m.node_graph, num_graphs=B, ghost_row=nmax * B), dense_launch)
+        sink._keep.extend([dkv, dcat])
     du_seg = decoder_bwd(P, G, cfg, m, dec_segs, dgraph, None, sink, dcat=dcat)
     if dx_ext is not None:
         dxL.add_(dx_ext)
-    gnn_trunk_bwd(P, G, cfg, m, ctrunk, dxL, du_seg, sink)
+    sink.after_first_node = late_hook
+    gnn_trunk_bwd(P, G, cfg, m, ctrunk, dxL, du_seg, sink, dx_pre=dx_pre)
     sink.flush()
 
 

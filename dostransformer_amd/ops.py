@@ -519,6 +519,12 @@ def mlp_ln_fwd_supported(M: int, K: int, NH: int, NO: int) -> bool:
 # 16-row tile instead of one, while that grid stays a single round of small workgroups
 MLP_LN_CS = __import__("os").environ.get("DOSX_MLP_LN_CS", "1") == "1"
 MLP_LN_CS_MAX_WGS = int(__import__("os").environ.get("DOSX_MLP_LN_CS_MAX_WGS", "512"))
+# ... the BACKWARD launch: "pre" (default) = only where it absorbs the launch in front of it (DosxMlpLnBwd.pre), "1" = always, "0" =
+# never.  Inside the step the backward N-row launches share the GPU with a weight-gradient group: 232 small workgroups that wait
+# for each other then cost MORE than 29 large ones (1.0940 vs 1.0855 ms per cfg2 step, three interleaved rounds) - unlike in the
+# forward pass, where the chip is otherwise idle (1.1018 -> 1.0940 with the forward launches alone) - but absorbing the dense-key
+# backward launch in front of the last layer's NodeModel backward pays well beyond that (1.0726; tools/exp/r6_run3.sh)
+MLP_LN_CS_BWD = __import__("os").environ.get("DOSX_MLP_LN_CS_BWD", "pre")
 
 
 def mlp_ln_cs(M: int, K: int, NH: int, NO: int) -> bool:
@@ -570,10 +576,20 @@ def mlp_ln_bwd_partial_rows(M: int) -> int:
     return _lib.load().dosx_mlp_ln_bwd_partial_rows(int(M))
 
 
+def mlp_ln_bwd_cs(M: int, K: int, NH: int, NO: int, dcat: torch.Tensor, with_pre: bool = False) -> bool:
+    """Whether mlp_ln_bwd runs the column-split form for this block and this dcat layout (``with_pre``: it is asked to absorb the
+    launch in front of it)."""
+    on = MLP_LN_CS_BWD == "1" or (MLP_LN_CS_BWD == "pre" and with_pre)
+    return on and mlp_ln_cs(M, K, NH, NO) and int(dcat.stride(0)) % 2 == 0 and dcat.data_ptr() % 8 == 0
+
+
 def mlp_ln_bwd(M: int, dy: torch.Tensor, xhat: torch.Tensor, rstd: torch.Tensor, w1, w2, gamma, beta, alpha, dz: torch.Tensor,
-               dcat: torch.Tensor, partials: torch.Tensor, add_dy: bool = False, cs: Optional[bool] = None) -> None:
+               dcat: torch.Tensor, partials: torch.Tensor, add_dy: bool = False, cs: Optional[bool] = None, pre: Optional[dict] = None) -> None:
     """dz = LN/PReLU backward of (dy W2), dcat = dz W1, [dgamma | dbeta | .. | dalpha] partial rows - one launch
-    (include/dosx.h: DosxMlpLnBwd)."""
+    (include/dosx.h: DosxMlpLnBwd).
+    pre (column-split form only): what produces ``dy`` in the same launch - dict(kind="node_grad", dz, rowptr_src, perm_src, aggd, w,
+    res, res2, aggs) = :func:`node_grad` with dx = dy, or dict(kind="dense", dkv, kvhat, rstd_nodes, dense_row, dpool_ptr, ld_dpool,
+    node_graph, num_graphs, ghost_row) = :func:`dense_normalize_pool_bwd` with dx = dy."""
     d = _lib.MlpLnBwd()
     d.M, d.K, d.NH, d.NO = int(M), int(w1.shape[1]), int(w1.shape[0]), int(w2.shape[0])
     d.dy, d.lddy = dy.data_ptr(), int(dy.stride(0))
@@ -585,12 +601,37 @@ def mlp_ln_bwd(M: int, dy: torch.Tensor, xhat: torch.Tensor, rstd: torch.Tensor,
     d.partials, d.partial_ld = partials.data_ptr(), int(partials.stride(0))
     d.add_dy = 1 if add_dy else 0
     if cs is None:
-        cs = mlp_ln_cs(d.M, d.K, d.NH, d.NO) and d.lddcat % 2 == 0 and dcat.data_ptr() % 8 == 0
+        cs = mlp_ln_bwd_cs(d.M, d.K, d.NH, d.NO, dcat, with_pre=pre is not None)
+    extra = 0.0
+    if pre is not None:
+        assert cs, "mlp_ln_bwd: pre needs the column-split form"
+        assert dy.stride(1) == 1
+        d.pre_dy = dy.data_ptr()
+        if pre["kind"] == "node_grad":
+            d.pre = 1
+            w = pre["w"]
+            assert pre["dz"].is_contiguous() and pre["aggd"].is_contiguous() and pre["aggs"].is_contiguous() and w.stride(1) == 1
+            d.pre_dz, d.pre_rowptr_src, d.pre_perm_src = pre["dz"].data_ptr(), pre["rowptr_src"].data_ptr(), pre["perm_src"].data_ptr()
+            d.pre_aggd, d.pre_aggs = pre["aggd"].data_ptr(), pre["aggs"].data_ptr()
+            d.pre_w, d.pre_ldw = w.data_ptr(), int(w.stride(0))
+            if pre.get("res") is not None:
+                d.pre_res, d.pre_ldres = pre["res"].data_ptr(), int(pre["res"].stride(0))
+            if pre.get("res2") is not None:
+                d.pre_res2, d.pre_ldres2 = pre["res2"].data_ptr(), int(pre["res2"].stride(0))
+            extra = 2.0 * _real(d.M) * d.NO * 4 * d.NO
+        else:
+            assert pre["kind"] == "dense"
+            d.pre = 2
+            d.pre_dkv, d.pre_kvhat, d.pre_rstd_nodes = pre["dkv"].data_ptr(), pre["kvhat"].data_ptr(), pre["rstd_nodes"].data_ptr()
+            d.pre_dense_row, d.pre_node_graph = pre["dense_row"].data_ptr(), pre["node_graph"].data_ptr()
+            d.pre_dpool, d.pre_ld_dpool = int(pre["dpool_ptr"]), int(pre["ld_dpool"])
+            d.pre_num_graphs, d.pre_ghost_row = int(pre["num_graphs"]), int(pre["ghost_row"])
     if cs:
         _mlp_ln_cs_scratch(d, dz.device, d.M, d.NH)
+    tag = "" if pre is None else ("," + pre["kind"])
     _call("dosx_mlp_ln_bwd", C.byref(d), _stream(),
-          w=lambda: (f"mlp_ln_bwd[K{d.K},NH{d.NH},NO{d.NO}" + (",cs" if cs else "") + "]",
-                     "mlp_ln_cs_bwd_kernel" if cs else "mlp_ln_bwd_kernel", "mfma", 2.0 * _real(d.M) * d.NH * (d.K + d.NO)))
+          w=lambda: (f"mlp_ln_bwd[K{d.K},NH{d.NH},NO{d.NO}" + (",cs" if cs else "") + tag + "]",
+                     "mlp_ln_cs_bwd_kernel" if cs else "mlp_ln_bwd_kernel", "mfma", 2.0 * _real(d.M) * d.NH * (d.K + d.NO) + extra))
 
 
 def edge_mlp_supported(H: int) -> bool:

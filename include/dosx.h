@@ -651,6 +651,21 @@ typedef struct DosxMlpLnBwd {
   int32_t add_dy;                         /* 1: dcat[:, :NO] += dy - the block's residual connection out = res + MLP(cat[res, .])
                                              (NodeModel, DOSTransformer_phonon.py:204-212 + :83) differentiated in the same launch */
   float* cs_buf; int32_t* cs_cnt;         /* column-split form (see DosxMlpLn): the siblings exchange the `da` tile; same sizes */
+  /* round 6, column-split form only: what PRODUCES dy, in the same launch - the N-row launch that used to run in front of it.
+   *   pre = 1: the node side of the LATER message-passing layer's factored input gradient (DosxNodeGrad: pre_dz [E,2H] that
+   *            layer's dz, pre_rowptr_src / pre_perm_src the CSR by source, pre_aggd [M,2H], pre_w [2H, >= 2H] row stride pre_ldw,
+   *            pre_res / pre_res2 optional [M,H] addends, pre_aggs [M,2H] OUT): dy = pre_res + pre_res2 + aggs Wa + aggd Wb;
+   *   pre = 2: dosx_dense_normalize_pool_bwd (pre_dkv / pre_kvhat dense [*,H], pre_rstd_nodes [M], pre_dense_row [M], pre_dpool
+   *            [graphs, pre_ld_dpool], pre_node_graph [M], pre_num_graphs, pre_ghost_row; no accumulation): dy = its dx.
+   * dy is then an OUTPUT (pre_dy = the same pointer, writable; [M,H], row stride lddy): the weight-gradient jobs read it. */
+  int32_t pre;
+  float* pre_dy;
+  const float* pre_dz; const int32_t* pre_rowptr_src; const int32_t* pre_perm_src; const float* pre_aggd;
+  const float* pre_w; int32_t pre_ldw;
+  const float* pre_res; int32_t pre_ldres; const float* pre_res2; int32_t pre_ldres2;
+  float* pre_aggs;
+  const float* pre_dkv; const float* pre_kvhat; const float* pre_rstd_nodes; const int32_t* pre_dense_row;
+  const float* pre_dpool; int32_t pre_ld_dpool; const int32_t* pre_node_graph; int32_t pre_num_graphs, pre_ghost_row;
 } DosxMlpLnBwd;
 int dosx_mlp_ln_bwd_partial_rows(int M);
 int dosx_mlp_ln_bwd(const DosxMlpLnBwd* a, dosx_stream_t stream);

@@ -248,3 +248,102 @@ def test_column_split_exchange_under_a_bandwidth_hog():
     torch.cuda.synchronize()
     assert float(bad) == 0.0
     assert all(bool(torch.isfinite(t).all()) for t in first)
+
+
+@pytest.mark.parametrize("n,H,two,add_dy", [(450, 128, False, True), (450, 128, True, False), (37, 64, True, True), (16, 128, False, True),
+                                            (3, 64, False, False), (1000, 64, False, True), (261, 128, True, True)])
+def test_node_side_gradient_inside_the_column_split_backward_launch(n, H, two, add_dy):
+    """DosxMlpLnBwd.pre = 1 (round 6): the node side of the later layer's factored input gradient (dosx_node_grad: source-node
+    sums of dz, dx = res + res2 + aggS Wa + aggD Wb) as the front part of the column-split NodeModel backward launch - three
+    in-launch exchanges - against the two launches: aggs, dx (= the block's dy), dz, dcat, the summed partial rows; isolated
+    nodes, long source segments; twice (same bits, counters back at zero)."""
+    import numpy as np
+    from dostransformer_amd import ops
+    dev = "cuda:0"
+    rng = np.random.default_rng(n + H)
+    deg = rng.integers(0, 30, size=n)
+    deg[rng.random(n) < 0.15] = 0
+    deg[0] = 150 if n > 3 else 5                        # one long source segment (more than 64 edges: two id chunks per wave)
+    E = int(deg.sum())
+    rowptr = torch.from_numpy(np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)).to(dev)
+    perm = torch.from_numpy(rng.permutation(E).astype(np.int32)).to(dev)
+    x, agg, W, r = _node_block(n, H, 17 * n + H)
+    W2 = 2 * H
+    dzE, aggd, W0 = r(E, W2), r(n, W2), r(W2, 3 * H) / W2 ** 0.5
+    dcat_prev = r(n, W2)
+    res2 = r(n, H) if two else None
+    xh, rs, out = torch.empty(n, W2, device=dev), torch.empty(n, device=dev), torch.empty(n, H, device=dev)
+    ops.mlp_ln_fwd(n, x, agg, W["w1"], W["b1"], W["g"], W["b"], W["al"], W["w2"], W["b2"], None, xh, rs, out, cs=False)
+    rows, pld = ops.mlp_ln_bwd_partial_rows(n), 4 * H + 4
+
+    def run(fused):
+        aggs, dx = torch.full((n, W2), float("nan"), device=dev), torch.full((n, H), float("nan"), device=dev)
+        dz, dcat = torch.full((n, W2), float("nan"), device=dev), torch.full((n, W2), float("nan"), device=dev)
+        part = torch.full((rows, pld), float("nan"), device=dev)
+        pre = None
+        if fused:
+            pre = dict(kind="node_grad", dz=dzE, rowptr_src=rowptr, perm_src=perm, aggd=aggd, w=W0, res=dcat_prev[:, :H], res2=res2, aggs=aggs)
+        else:
+            ops.node_grad(n, H, dzE, rowptr, perm, aggd, W0, dcat_prev[:, :H], res2, aggs, dx)
+        ops.mlp_ln_bwd(n, dx, xh, rs, W["w1"], W["w2"], W["g"], W["b"], W["al"], dz, dcat, part, add_dy=add_dy, cs=True, pre=pre)
+        torch.cuda.synchronize()
+        return aggs, dx, dz, dcat, part[:, :4 * H].sum(0), part[:, pld - 1].sum()
+    sc = lambda t: float(t.abs().max()) + 1e-30
+    ref, got = run(False), run(True)
+    for name, a_, b_ in zip(("aggs", "dx", "dz", "dcat", "dgamma|dbeta", "dalpha"), got, ref):
+        assert bool(torch.isfinite(a_).all()), name
+        assert float((a_ - b_).abs().max()) <= 3e-5 * sc(b_), (name, float((a_ - b_).abs().max()) / sc(b_))
+    again = run(True)
+    assert all(torch.equal(u, v) for u, v in zip(again, got))
+    exact = dcat_prev[:, :H].double() + got[0].double() @ W0[:, :H].double() + aggd.double() @ W0[:, H:W2].double()
+    if two:
+        exact = exact + res2.double()
+    assert float((got[1].double() - exact).abs().max()) <= 2e-5 * sc(exact)
+
+
+@pytest.mark.parametrize("n,H,B", [(450, 128, 64), (37, 64, 5), (16, 128, 1), (1000, 64, 100)])
+def test_dense_key_backward_inside_the_column_split_backward_launch(n, H, B):
+    """DosxMlpLnBwd.pre = 2 (round 6): dosx_dense_normalize_pool_bwd - the to_dense_batch / key-LayerNorm backward plus the
+    pooled decoder gradient, ghost nodes included - as the front part of the last layer's NodeModel backward launch: dx, dz,
+    dcat, partial rows bitwise the two launches (row-local: no exchange, the same arithmetic)."""
+    import numpy as np
+    from dostransformer_amd import ops
+    dev = "cuda:0"
+    rng = np.random.default_rng(n + H + B)
+    x, agg, W, r = _node_block(n, H, 19 * n + H)
+    n_ghost = min(5, n // 4)
+    n_real = n - n_ghost
+    sizes = np.diff(np.sort(np.concatenate([[0, n_real], rng.integers(0, n_real + 1, size=B - 1)])))
+    node_graph = np.concatenate([np.repeat(np.arange(B), sizes), np.full(n_ghost, B)]).astype(np.int32)
+    nmax = int(sizes.max())
+    pos = np.concatenate([np.arange(s) for s in sizes] + [np.zeros(n_ghost, dtype=np.int64)])
+    dense_row = np.where(node_graph < B, pos * B + np.minimum(node_graph, B - 1), nmax * B).astype(np.int32)
+    dense_row_t, node_graph_t = torch.from_numpy(dense_row).to(dev), torch.from_numpy(node_graph).to(dev)
+    dkv, kvhat = r(nmax * B + 1, H), r(nmax * B + 1, H)
+    rstd_n = r(n).abs() + 0.5
+    Kd = 2 * H
+    dpool = r(B, Kd)
+    xh, rs, out = torch.empty(n, 2 * H, device=dev), torch.empty(n, device=dev), torch.empty(n, H, device=dev)
+    ops.mlp_ln_fwd(n, x, agg, W["w1"], W["b1"], W["g"], W["b"], W["al"], W["w2"], W["b2"], None, xh, rs, out, cs=False)
+    rows, pld = ops.mlp_ln_bwd_partial_rows(n), 4 * H + 4
+
+    def run(fused):
+        dx = torch.full((n, H), float("nan"), device=dev)
+        dz, dcat = torch.full((n, 2 * H), float("nan"), device=dev), torch.full((n, 2 * H), float("nan"), device=dev)
+        part = torch.full((rows, pld), float("nan"), device=dev)
+        pre = None
+        if fused:
+            pre = dict(kind="dense", dkv=dkv, kvhat=kvhat, rstd_nodes=rstd_n, dense_row=dense_row_t, dpool_ptr=dpool.data_ptr() + 4 * (Kd - H),
+                       ld_dpool=Kd, node_graph=node_graph_t, num_graphs=B, ghost_row=nmax * B)
+        else:
+            ops.dense_normalize_pool_bwd(dkv, kvhat, rstd_n, dense_row_t, dpool.data_ptr() + 4 * (Kd - H), Kd, node_graph_t, B, dx, n, H,
+                                         False, ghost_row=nmax * B)
+        ops.mlp_ln_bwd(n, dx, xh, rs, W["w1"], W["w2"], W["g"], W["b"], W["al"], dz, dcat, part, add_dy=True, cs=True, pre=pre)
+        torch.cuda.synchronize()
+        return dx, dz, dcat, part[:, :4 * H].clone(), part[:, pld - 1].clone()
+    ref, got = run(False), run(True)
+    sc = lambda t: float(t.abs().max()) + 1e-30
+    for name, a_, b_ in zip(("dx", "dz", "dcat", "partials", "dalpha"), got, ref):
+        assert bool(torch.isfinite(a_).all()), name
+        assert float((a_ - b_).abs().max()) <= 2e-6 * sc(b_), name          # (row sums over 16 instead of 64 lanes: rounding)
+    assert float(got[0][n_real:].abs().max()) == 0.0 if n_ghost else True    # ghost nodes: zero gradient

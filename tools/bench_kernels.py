@@ -280,7 +280,13 @@ def node_mlp_case(name, M, H):
     g, b, al = torch.randn(2 * H, device=DEV), torch.randn(2 * H, device=DEV), torch.full((1,), 0.25, device=DEV)
     w2, b2 = torch.randn(H, 2 * H, device=DEV) / 16, torch.randn(H, device=DEV)
     xhat, rstd, out = torch.empty(M, 2 * H, device=DEV), torch.empty(M, device=DEV), torch.empty(M, H, device=DEV)
-    us = timeit(lambda: ops.mlp_ln_fwd(M, x, agg, w1, b1, g, b, al, w2, b2, x, xhat, rstd, out))
+    us = timeit(lambda: ops.mlp_ln_fwd(M, x, agg, w1, b1, g, b, al, w2, b2, x, xhat, rstd, out, cs=False))
+    cs_ok = ops.mlp_ln_cs(M, 2 * H, 2 * H, H)
+    us_cs = us_cs3 = usb_cs = float("nan")
+    if cs_ok:       # column-split form (round 6), alone and with the next layer's node products as its third phase
+        w3n, pq = torch.randn(2 * H, 3 * H, device=DEV) / 16, torch.empty(M, 4 * H, device=DEV)
+        us_cs = timeit(lambda: ops.mlp_ln_fwd(M, x, agg, w1, b1, g, b, al, w2, b2, x, xhat, rstd, out, cs=True))
+        us_cs3 = timeit(lambda: ops.mlp_ln_fwd(M, x, agg, w1, b1, g, b, al, w2, b2, x, xhat, rstd, out, w3=w3n, nb3=2, pq=pq, cs=True))
     def two():
         ops.gemm(M, 2 * H, [ops.seg(x), ops.seg(agg)], w1, xhat, bias=b1, epi=ops.EPI_LN, aux_out=rstd)
         ops.gemm(M, H, [ops.seg(xhat)], w2, out, pro=ops.PRO_LN_PRELU, pro_gamma=g, pro_beta=b, pro_alpha=al, bias=b2, res=x)
@@ -288,7 +294,9 @@ def node_mlp_case(name, M, H):
     dy, dz, dcat = torch.randn(M, H, device=DEV), torch.empty(M, 2 * H, device=DEV), torch.empty(M, 2 * H, device=DEV)
     pld = 4 * H + 4
     part = torch.empty(ops.mlp_ln_bwd_partial_rows(M), pld, device=DEV)
-    usb = timeit(lambda: ops.mlp_ln_bwd(M, dy, xhat, rstd, w1, w2, g, b, al, dz, dcat, part))
+    usb = timeit(lambda: ops.mlp_ln_bwd(M, dy, xhat, rstd, w1, w2, g, b, al, dz, dcat, part, cs=False))
+    if cs_ok:
+        usb_cs = timeit(lambda: ops.mlp_ln_bwd(M, dy, xhat, rstd, w1, w2, g, b, al, dz, dcat, part, cs=True))
     part2 = torch.empty(ops.gemm_partial_rows(M, 2 * H, ops.EPI_PRELU_LN_BWD), pld, device=DEV)
     def twob():
         ops.gemm(M, 2 * H, [ops.seg(dy)], w2, dz, w_layout=1, epi=ops.EPI_PRELU_LN_BWD, aux=xhat, aux_stats=rstd, epi_gamma=g,
@@ -297,7 +305,8 @@ def node_mlp_case(name, M, H):
     usb2 = timeit(twob)
     fl = 2.0 * M * 2 * H * 3 * H
     print(f"nmlp  {name:30s} M={M} H={H}: fwd fused {us:6.1f} us ({fl / us / 1e6:5.1f} TF/s) | two GEMMs {us2:6.1f} us || "
-          f"bwd fused {usb:6.1f} us ({fl / usb / 1e6:5.1f} TF/s) | two GEMMs {usb2:6.1f} us")
+          f"bwd fused {usb:6.1f} us ({fl / usb / 1e6:5.1f} TF/s) | two GEMMs {usb2:6.1f} us || column-split fwd {us_cs:6.1f} (+pq {us_cs3:6.1f}) bwd {usb_cs:6.1f} us"
+          f"  (eager launches: the host's ~10 us per launch is the floor of these readings - kernel times: rocprofv3 --kernel-trace)")
 
 
 def main():
