@@ -483,6 +483,34 @@ def run_workload(name, *, device, world, rank, dp, mode, shuffle, steps, warmup,
     return res
 
 
+def eval_throughput(device, B=64, n_batches=4, iters=100):
+    """crystals/s of replayed inference on B-crystal batches with per-crystal key counts (= B batch-1 forwards of the reference's
+    evaluation loop), and of the batch-1 loop itself for comparison."""
+    from dostransformer_amd.batch import collate
+    from dostransformer_amd.predict import Predictor
+    kind, L, T, H, _ = CONFIGS["phonon_h128_b64"]
+    model = build_model(kind, L, T, H, device).to(device).eval()
+    pred = Predictor(model, per_crystal_keys=True).eval()
+    cs = [make_crystals(kind, B, seed=900 + k, dtype=torch.float32) for k in range(n_batches)]
+    batches = [collate(c).to(device) for c in cs]
+    ones = [collate([c]).to(device) for c in cs[0][:16]]
+    for g in batches + ones:
+        pred(g); pred(g)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(iters):
+        pred(batches[i % n_batches])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for i in range(iters):
+        pred(ones[i % len(ones)])
+    torch.cuda.synchronize()
+    el1 = time.perf_counter() - t0
+    return {"value": round(B * iters / el, 1), "unit": "crystals/s", "ms_per_batch": round(1e3 * el / iters, 4),
+            "batch1_loop": round(iters / el1, 1)}
+
+
 def _free_port() -> int:
     import socket
     with socket.socket() as s:
@@ -672,6 +700,12 @@ def main():
             secondary["batch_sweep"] = sweep
         except Exception as ex:  # a secondary line must never take the headline down with it
             secondary["error"] = f"{type(ex).__name__}: {ex}"[:200]
+        # batch-size-1-equivalent EVALUATION in one pass: Predictor(per_crystal_keys=True) on 64-crystal
+        # batches of the headline model - the reference evaluates crystal by crystal (batch_size = 1, utils.py:61-143)
+        try:
+            secondary["eval_per_crystal_b64"] = eval_throughput(device)
+        except Exception as ex:
+            secondary["eval_per_crystal_b64"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
         # the same headline workload through the DATA-PARALLEL step on a 1-rank RCCL group: the replay plan split around
         # the collectives (SSE pair, early gradient bucket, late bucket), i.e. what data parallelism costs a rank before
         # any byte crosses xGMI - the figure a 1-GPU box can give about the N > 1 path

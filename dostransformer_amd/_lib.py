@@ -86,6 +86,7 @@ class Attn(C.Structure):
         ("dkv_accumulate", C.c_int32),
         ("partials_q", C.c_void_p), ("partials_kv", C.c_void_p), ("drop_mask", C.c_void_p), ("dkv_part", C.c_void_p), ("dkv_cnt", C.c_void_p),
         ("ln1_gamma", C.c_void_p), ("ln1_beta", C.c_void_p), ("ln1_out", C.c_void_p),
+        ("key_ptr", C.c_void_p),
     ]
 
 
@@ -133,6 +134,7 @@ class Ffn(C.Structure):
         ("att_probs", C.c_void_p), ("att_qstats", C.c_void_p), ("att_x1", C.c_void_p), ("att_st1", C.c_void_p),
         ("att_Nk", C.c_int32), ("att_Bk", C.c_int32), ("att_Bq", C.c_int32), ("att_Sq", C.c_int32),
         ("att_qs", C.c_int32), ("att_qb", C.c_int32), ("att_ldx1", C.c_int32), ("att_aligned", C.c_int32),
+        ("att_key_ptr", C.c_void_p),
     ]
 
 

@@ -51,8 +51,9 @@ class DOSTransformerBase(FusedModel):
             seed.add_(1)
         return p, seed
 
-    def _program_fwd(self, P, g, m, bump_seed: bool = True):
-        dos, xL, ctx = Fn.dostransformer_fwd(P, self._cfg, g, m, drop=self._dropout(dos_device(P), bump_seed))
+    def _program_fwd(self, P, g, m, bump_seed: bool = True, per_crystal_keys: bool = False):
+        dos, xL, ctx = Fn.dostransformer_fwd(P, self._cfg, g, m, drop=self._dropout(dos_device(P), bump_seed),
+                                             per_crystal_keys=per_crystal_keys)
         B = m.num_graphs
         return dos[:B], xL, dos[B:], (ctx, dos)
 

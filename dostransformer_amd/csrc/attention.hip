@@ -450,9 +450,11 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const DosxAttn a) 
   float psum[RP];
 #pragma unroll
   for (int p = 0; p < RP; ++p) psum[p] = 1.f;
-  // ---- exact fp32 softmax over the Nk keys (padded atoms included, like the reference) ----
+  // ---- exact fp32 softmax over the Nk keys (padded atoms included, like the reference; key_ptr: the crystal's own keys only) ----
   {
     const float scale = rsqrtf((float)H);
+    const int bk_ = bq % a.Bk;
+    const int nk = a.key_ptr ? min(a.key_ptr[bk_ + 1] - a.key_ptr[bk_], Nk) : Nk;
     float v[RP][NJ], mx[RP], sum[RP];
 #pragma unroll
     for (int p = 0; p < RP; ++p) {
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const DosxAttn a) 
         float sc_ = 0.f;
         if constexpr (RESIDENT) { if (j < Nk) sc_ = resident_score(prow, j, g.NKP); }
         else sc_ = row[j];
-        const float t = j < Nk ? sc_ * scale : -INFINITY;
+        const float t = j < nk ? sc_ * scale : -INFINITY;          // (nk: the crystal's own key count with DosxAttn.key_ptr, else Nk)
         v[p][jj] = t;
         mx[p] = fmaxf(mx[p], t);
       }
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const DosxAttn a) 
       sum[p] = 0.f;
 #pragma unroll
       for (int jj = 0; jj < NJ; ++jj) {
-        const float e = (q16 + 16 * jj) < Nk ? expf(v[p][jj] - mx[p]) : 0.f;
+        const float e = (q16 + 16 * jj) < nk ? expf(v[p][jj] - mx[p]) : 0.f;
         v[p][jj] = e;
         sum[p] += e;
       }
@@ -1342,6 +1344,7 @@ extern "C" int dosx_attention_fwd(const DosxAttn* ap, dosx_stream_t stream) {
   DOSX_CHECK_ARG(!a.ln1_out || (a.out_stats && a.ln1_gamma && a.ln1_beta && a.Nk <= MAX_FUSED_NK && !(a.flags & DOSX_ATTN_NO_RESIDUAL)),
                  "dosx_attention_fwd: ln1_out needs out_stats, ln1_gamma / ln1_beta, <= %d keys and the residual", MAX_FUSED_NK);
   if (const int rc = dosx_detail::attn_aligned_fwd(a, to_stream(stream))) return rc < 0 ? rc : 0;
+  DOSX_CHECK_ARG(!a.key_ptr || a.Nk <= MAX_FUSED_NK, "dosx_attention_fwd: key_ptr (per-crystal key counts) needs <= %d keys", MAX_FUSED_NK);
   if (a.Nk > MAX_FUSED_NK) return dosx_detail::attn_general_fwd(a, to_stream(stream));
   const Geo g = make_geo(a.H, a.Nk);
   const bool res = fwd_resident(a);
@@ -1377,6 +1380,7 @@ extern "C" int dosx_attention_bwd(const DosxAttn* ap, dosx_stream_t stream) {
   DOSX_CHECK_ARG(a.dout && a.dx && (a.dscores || pkv_ok(a)) && a.dkvhat && a.partials_q && a.partials_kv,
                  "dosx_attention_bwd: null operand");
   if (const int rc = dosx_detail::attn_aligned_bwd(a, to_stream(stream))) return rc < 0 ? rc : 0;
+  DOSX_CHECK_ARG(!a.key_ptr, "dosx_attention_bwd: key_ptr (per-crystal key counts) is a forward-only mode");
   if (a.Nk > MAX_FUSED_NK) return dosx_detail::attn_general_bwd(a, to_stream(stream));
   const Geo g = make_geo(a.H, a.Nk);
   const int kg = a.Nk > 32 ? 2 : 1;

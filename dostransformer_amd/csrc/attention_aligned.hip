@@ -175,6 +175,7 @@ __global__ __launch_bounds__(512) void attn_al_fwd_kernel(const DosxAttn a, cons
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q16 = lane & 15, l15 = q16, g4 = lane >> 4;
   const int wpc = geo.wpc, KS = geo.KS;
   const int bq = blockIdx.x / wpc, w = blockIdx.x - bq * wpc, bk = bq % a.Bk;
+  const int nk = a.key_ptr ? min(a.key_ptr[bk + 1] - a.key_ptr[bk], Nk) : Nk;      // keys this crystal attends over
   const int nqt = (Sq + R - 1) / R;
   float* Ks = sm;                      // [NkP][LDK]
   float* Qs = Ks + NkP * LDK;          // [R][LDK]   q o g0 -> O
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(512) void attn_al_fwd_kernel(const DosxAttn a, cons
       for (int jj = 0; jj < 4; ++jj) {
         const int j = q16 + 16 * jj;
         v[jj] = -INFINITY;
-        if (j < Nk) {
+        if (j < nk) {                                  // (nk: the crystal's own key count with DosxAttn.key_ptr, else Nk)
           v[jj] = Sr[j];
           for (int kq = 1; kq < KS; ++kq) v[jj] += Sr[kq * R * 68 + j];
         }
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(512) void attn_al_fwd_kernel(const DosxAttn a, cons
       float sum = 0.f;
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
-        const float e = (q16 + 16 * jj) < Nk ? expf(v[jj] - mx) : 0.f;
+        const float e = (q16 + 16 * jj) < nk ? expf(v[jj] - mx) : 0.f;
         v[jj] = e;
         sum += e;
       }

@@ -56,6 +56,7 @@ __device__ __forceinline__ void ffn_att_row(const DosxFfn& a, float* __restrict_
     const int r = m0 + lr, rc = min(r, M - 1);
     const bool rv = r < M;
     const int s = rc / Bq, bq = rc - s * Bq, bk = bq % Bk;
+    const int nk = a.att_key_ptr ? min(a.att_key_ptr[bk + 1] - a.att_key_ptr[bk], Nk) : Nk;      // keys this crystal attends over (DosxFfn.att_key_ptr)
     const float* xrow = a.x + ((size_t)s * a.att_qs + (size_t)bq * a.att_qb) * a.ldx;
     float4 xr[2];
     float t = 0.f;
@@ -98,12 +99,12 @@ __device__ __forceinline__ void ffn_att_row(const DosxFfn& a, float* __restrict_
       for (int k = 0; k < 2; ++k)
         d += (qg[k].x * kv[j][k].x + qg[k].y * kv[j][k].y) + (qg[k].z * kv[j][k].z + qg[k].w * kv[j][k].w);
       sc[j] = row16_sum(d) * scale;
-      if (j < Nk) mx = fmaxf(mx, sc[j]);
+      if (j < nk) mx = fmaxf(mx, sc[j]);
     }
     float sum = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const float e = j < Nk ? expf(sc[j] - mx) : 0.f;
+      const float e = j < nk ? expf(sc[j] - mx) : 0.f;
       sc[j] = e;
       sum += e;
     }
@@ -257,8 +258,10 @@ __device__ __forceinline__ void ffn_att_tile(const DosxFfn& a, float* __restrict
   }
   FSTAMP(12);
   __syncthreads();
-  // ---- C: softmax of this quarter wave's row ----
+  // ---- C: softmax of this quarter wave's row (over the crystal's own nk <= Nk keys with DosxFfn.att_key_ptr) ----
   float psum = 1.f;
+  const int bk_ = al_bq % a.att_Bk;
+  const int nk = a.att_key_ptr ? min(a.att_key_ptr[bk_ + 1] - a.att_key_ptr[bk_], Nk) : Nk;
   if (rowok) {
     float* Sr = Sc + lr * 68;
     float v[4], mx = -INFINITY;
@@ -266,7 +269,7 @@ __device__ __forceinline__ void ffn_att_tile(const DosxFfn& a, float* __restrict
     for (int jj = 0; jj < 4; ++jj) {
       const int j = q16 + 16 * jj;
       v[jj] = -INFINITY;
-      if (j < Nk) {
+      if (j < nk) {
         v[jj] = Sr[j];
         for (int kq = 1; kq < KS; ++kq) v[jj] += Qs[R * LDK + (kq - 1) * R * 68 + lr * 68 + j];
       }
@@ -276,7 +279,7 @@ __device__ __forceinline__ void ffn_att_tile(const DosxFfn& a, float* __restrict
     float sum = 0.f;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
-      const float e = (q16 + 16 * jj) < Nk ? expf(v[jj] - mx) : 0.f;
+      const float e = (q16 + 16 * jj) < nk ? expf(v[jj] - mx) : 0.f;
       v[jj] = e;
       sum += e;
     }

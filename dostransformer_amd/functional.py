@@ -668,13 +668,15 @@ def head_fused_fwd(H: int, T: int) -> bool:
 
 
 def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int, qb: int, kvhat: torch.Tensor,
-                Nk: int, Bk: int, H: int, T: int, final_ln: bool = True, drop=None, head=None, fdrop=None):
+                Nk: int, Bk: int, H: int, T: int, final_ln: bool = True, drop=None, head=None, fdrop=None, key_ptr=None):
     """x: query rows (row (s,bq) at (s*qs + bq*qb)); kvhat: [Nk*Bk, H] normalised keys (stale across layers).
     drop: None or (p, seed_dev, stream_base): attention dropout in training mode (multihead_attention.py:70) - every
     layer draws its own [Bq,Sq,Nk] multiplier mask (ops.dropout_mask) that the backward re-uses.
     head = (gamma, beta, w, b, xhat [rows,H], rstd [rows], dos [Bq,Sq]) (with final_ln False, head_fused_fwd(H, T)): the
     model head - LayerNorm + H->1 output layer on the encoder's output - in the last layer's ffn_fwd epilogue; the
     encoder output itself is then not materialised (None is returned for it).
+    key_ptr [Bk + 1] int32 (inference only; DosxAttn.key_ptr): crystal bk attends over its first key_ptr[bk + 1] - key_ptr[bk] key
+    rows only - the batch's graph_ptr makes a batched forward equal the reference's batch-size-1 evaluation (utils.py:61-143).
     fdrop = (p_relu, p_res, seed_dev, stream_base) or None: relu / res dropout of the layer (transformer.py:137,145-147) in
     training mode.  The layer then runs UNFUSED - attention without its residual epilogue, the two feed-forward GEMMs, and
     ops.mask_residual for the three "dropout -> add residual" steps - with one explicit multiplier mask per dropout site."""
@@ -694,6 +696,9 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
         st1 = _empty(dev, rows, 2)
         a = _attn_desc(Sq, Bq, Nk, Bk, H, qs, qb, x, kvhat, g0, b0)
         a.out, a.probs, a.qstats, a.out_stats = x1.data_ptr(), probs.data_ptr(), qstats.data_ptr(), st1.data_ptr()
+        if key_ptr is not None:
+            assert key_ptr.dtype == torch.int32 and key_ptr.numel() >= Bk + 1 and fdrop is None and drop is None
+            a.key_ptr = key_ptr.data_ptr()
         mask = None
         if drop is not None and drop[0] > 0.0:
             mask = _empty(dev, Bq, Sq, Nk)
@@ -778,7 +783,7 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
             att_args = None
             if att_fused:
                 att_args = dict(kvhat=kvhat, gamma0=g0, beta0=b0, Nk=Nk, Bk=Bk, Bq=Bq, Sq=Sq, qs=qs, qb=qb, probs=probs,
-                                qstats=qstats, x1=x1, st1=st1, mask=mask, aligned=att_aligned)
+                                qstats=qstats, x1=x1, st1=st1, mask=mask, aligned=att_aligned, key_ptr=key_ptr)
             ops.ffn_fwd(rows, H, x if att_fused else x1, None if att_fused else st1, P[lp + ".layer_norms.1.weight"],
                         P[lp + ".layer_norms.1.bias"], P[lp + ".fc1.weight"], P[lp + ".fc1.bias"], P[lp + ".fc2.weight"],
                         P[lp + ".fc2.bias"], h, x2, fin=fin_args, att=att_args)
@@ -1319,12 +1324,19 @@ def decoder_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, segs: SegList
     return seg(dcat, width=H, col=0) if K == 2 * H else None
 
 
-def dostransformer_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta, drop=None):
+def dostransformer_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta, drop=None, per_crystal_keys: bool = False):
     """Forward of DOSTransformer_phonon / DOSTransformer (DOSTransformer_phonon.py:66-119,
     DOSTransformer.py:45-93).  Returns (dos [2B,S] : rows [0,B) global, [B,2B) system; x_L; ctx).
-    drop: None (eval mode / attn_drop 0) or (p, seed_dev): attention dropout of the three encoders."""
+    drop: None (eval mode / attn_drop 0) or (p, seed_dev): attention dropout of the three encoders.
+    per_crystal_keys (inference only): the two cross attentions attend over each crystal's OWN atoms instead of the batch's
+    zero-padded Nmax rows - what the reference computes at batch size 1, its evaluation setting (main_eDOS.py:55-56,
+    utils.py:61-143; SURVEY.md 0.3: the padded rows take part in the softmax, so outputs depend on the batch's Nmax)."""
     dr = (lambda base: None) if drop is None else (lambda base: (drop[0], drop[1], base))
     H, S, T, B, N = cfg.H, cfg.S, cfg.T, m.num_graphs, m.num_nodes
+    if per_crystal_keys and (drop is not None or H > ops.ATTN_MAX_H or m.n_max > 320):
+        from ._lib import DosxError
+        raise DosxError("per_crystal_keys: inference mode (no dropout), hidden <= 256 and at most 320 atoms per crystal")
+    kp = m.graph_ptr if per_crystal_keys else None
     if H > ops.ATTN_MAX_H:
         return _dostransformer_fwd_wide(P, cfg, g, m, dr)
     nmax = m.n_max
@@ -1356,7 +1368,7 @@ def dostransformer_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta, drop=None):
             ops.gemm(B, H, [seg(box["graph"])], P["fc.weight"][:, H:], box["qg"])
             ops.gemm(B, H, [seg(box["graph"]), seg(box["prow"])], P["fc_prompt.weight"][:, H:], box["qs"])
     side.on_side(_decoder_branch)
-    E1, c1 = encoder_fwd(P, "transformer", emb, S, B, 1, 0, kvhat, nmax, B, H, T, drop=dr(0))
+    E1, c1 = encoder_fwd(P, "transformer", emb, S, B, 1, 0, kvhat, nmax, B, H, T, drop=dr(0), key_ptr=kp)
     side.join()
     graph, dec_segs, prow = box["graph"], box["segs"], box["prow"]
     dosin = _empty(dev, S * 2 * B, H)
@@ -1388,10 +1400,10 @@ def dostransformer_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta, drop=None):
     gf, bf = P["transformer_source.layer_norm.weight"], P["transformer_source.layer_norm.bias"]
     if head_fused_fwd(H, T):     # final LayerNorm + out_layer in the last ffn_fwd launch of the source encoder
         _, c3 = encoder_fwd(P, "transformer_source", hs, S, 2 * B, 2 * B, 1, kvhat, nmax, B, H, T, final_ln=False,
-                            drop=dr(128), head=(gf, bf, P["out_layer.weight"], P["out_layer.bias"], xhat_f, rstd_f, dos))
+                            drop=dr(128), head=(gf, bf, P["out_layer.weight"], P["out_layer.bias"], xhat_f, rstd_f, dos), key_ptr=kp)
     else:
         hsrc, c3 = encoder_fwd(P, "transformer_source", hs, S, 2 * B, 2 * B, 1, kvhat, nmax, B, H, T, final_ln=False,
-                               drop=dr(128))
+                               drop=dr(128), key_ptr=kp)
         ops.ln_rowdot(hsrc, gf, bf, P["out_layer.weight"], P["out_layer.bias"], xhat_f, rstd_f, dos, S, 2 * B, H)
     a_g.keep.extend(t for t in (box.get("qg"), box.get("qs")) if t is not None)
     ctx = (ctrunk, kvhat, rstd_n, c1, dec_segs, sysidx, prow, dosin, a_g, a_s, kvs, rstd_s, c2, c3, xhat_f, rstd_f, xL)

@@ -432,6 +432,8 @@ def ffn_fwd(M: int, H: int, x: torch.Tensor, stats: Optional[torch.Tensor], gamm
         a.att_Nk, a.att_Bk, a.att_Bq, a.att_Sq = int(att["Nk"]), int(att["Bk"]), int(att["Bq"]), int(att["Sq"])
         a.att_qs, a.att_qb = int(att["qs"]), int(att["qb"])
         a.att_aligned = int(bool(att.get("aligned", False)))
+        if att.get("key_ptr") is not None:
+            a.att_key_ptr = att["key_ptr"].data_ptr()
         nk_att = a.att_Nk
     if fin is not None:
         a.fin_gamma, a.fin_beta, a.fin_xhat, a.fin_rstd = (t.data_ptr() for t in fin[:4])

@@ -9,6 +9,12 @@ of the eager forward.  The returned tensors alias the bucket's buffers and are o
 that lands in the same bucket; ``.clone()`` them to keep them.
 
 It quacks like the module for the evaluation loops: ``evaluate.test(Predictor(model), loader)``.
+
+``Predictor(model, per_crystal_keys=True)``: the reference validates and tests at ``batch_size = 1`` (`main_eDOS.py:55-56`,
+`utils.py:61-143`), and its outputs depend on the batch's Nmax (the zero-padded atoms take part in the softmax,
+`DOSTransformer_phonon.py:86`), so reference metrics need batch-1 forwards - 300 us each, launch-bound.  With this flag the two
+cross attentions of a BATCHED forward attend over each crystal's own atoms only (``DosxAttn.key_ptr`` = the batch's graph_ptr):
+B crystals in one pass give what B batch-1 forwards give (to fp32 rounding), at the batched rate.
 """
 from __future__ import annotations
 
@@ -23,11 +29,12 @@ from .train import _Slot
 
 
 class Predictor:
-    def __init__(self, model: DOSTransformerBase, bucket=(8, 128)):
+    def __init__(self, model: DOSTransformerBase, bucket=(8, 128), per_crystal_keys: bool = False):
         if not isinstance(model, DOSTransformerBase):
             raise TypeError("Predictor drives DOSTransformer / DOSTransformer_phonon modules")
         self.model = model
         self.bucket = tuple(bucket)
+        self.per_crystal_keys = bool(per_crystal_keys)
         self.kind = model._cfg.kind
         self._fp = None
         self._slots: Dict[tuple, _Slot] = {}
@@ -43,7 +50,7 @@ class Predictor:
         try:
             with torch.no_grad():
                 ops.RECORDER.begin()
-                dg, xL, ds, keep = self.model._program_fwd(fp.P, g, g.meta)
+                dg, xL, ds, keep = self.model._program_fwd(fp.P, g, g.meta, per_crystal_keys=self.per_crystal_keys)
                 slot.prog_a = ops.RECORDER.end()
         finally:
             if ops.RECORDER.active:

@@ -418,6 +418,12 @@ typedef struct DosxAttn {
   const float* ln1_gamma;
   const float* ln1_beta;
   float* ln1_out;      /* [Sq*Bq, H] */
+  /* round 6 (forward only): per-crystal key counts.  key_ptr [Bk + 1] (NULL: every crystal attends over all Nk
+   * key rows - padded rows included, like the reference's unmasked to_dense_batch): crystal bk attends over its FIRST
+   * key_ptr[bk + 1] - key_ptr[bk] key rows only (the batch's graph_ptr: its own atoms).  A batch of B crystals then gives what B
+   * batch-size-1 forwards give - the reference evaluates at batch_size = 1 (main_eDOS.py:55-56, utils.py:61-143), where
+   * Nmax = the crystal's own atom count - in one pass.  probs beyond a crystal's count are written as zeros.  Nk <= 320. */
+  const int32_t* key_ptr;
 } DosxAttn;
 /* 1 if dosx_attention_bwd takes the partial-dKV path for this key count / width when dkv_part is given (else it needs
  * dscores and runs the streamed dkv kernel) */
@@ -532,6 +538,7 @@ typedef struct DosxFfn {
    * (dosx_ffn_att_aligned_supported), e.g. the 51-key self attention over the energy bins; same outputs.  The caller chooses
    * it while that grid is about one round of workgroups: Sq is padded to the tile height per crystal. */
   int32_t att_aligned;
+  const int32_t* att_key_ptr;   /* as DosxAttn.key_ptr: per-crystal key counts of the fused attention half (forward only) */
 } DosxFfn;
 int dosx_ffn_supported(int H);
 int dosx_ffn_att_supported(int H, int Nk);   /* whether dosx_ffn_fwd takes the att_* fields for this shape (H, Nk <= 16) */

@@ -1,0 +1,105 @@
+"""Inference on the GPU: replayed prediction and the batch-size-1-equivalent evaluation in one pass."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import batch_from, load, sub
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _batch1_loop(model, crystals, dtype=torch.float32):
+    """What the reference's evaluation computes: one forward per crystal at batch size 1 (main_eDOS.py:55-56, utils.py:61-143)."""
+    from dostransformer_amd.batch import collate
+    gs, ss, xs = [], [], []
+    with torch.no_grad():
+        for c in crystals:
+            dg, x, ds = model(collate([c]).to(DEV, dtype=dtype))
+            gs.append(dg.float().clone()); ss.append(ds.float().clone()); xs.append(x.float().clone())
+    return torch.cat(gs), torch.cat(xs), torch.cat(ss)
+
+
+@pytest.mark.parametrize("case", ["g9_phonon", "g9_edos", "phonon_h128_b64", "edos_h64_b24", "edos_h256_b16"])
+def test_batched_evaluation_with_per_crystal_keys_equals_the_batch_1_loop(case):
+    """Predictor(model, per_crystal_keys=True) - the two cross attentions over each crystal's OWN atoms
+    (DosxAttn.key_ptr = graph_ptr) - on a batch of B crystals gives the outputs of B batch-size-1 forwards, the reference's
+    evaluation setting: G9 fixture batches (reference-initialised weights) and synthetic sets covering every forward attention
+    form (<= 16 keys per-row, crystal-aligned inside the feed-forward launch, the stand-alone aligned kernels at hidden 256);
+    1e-6 of the output scale.  Without the flag the batched outputs differ (the padded rows take part in the softmax)."""
+    from dostransformer_amd import synth
+    from dostransformer_amd.batch import collate, split_crystals
+    from dostransformer_amd.embedder_eDOS.DOSTransformer import DOSTransformer
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    from dostransformer_amd.predict import Predictor
+    torch.manual_seed(0)
+    if case.startswith("g9"):
+        z = load("g9_eval.npz")
+        if case == "g9_phonon":
+            model = DOSTransformer_phonon(3, 1, 118, 4, 16, DEV, 0.0)
+            model.load_state_dict({k: (v.float() if v.is_floating_point() else v) for k, v in sub(z, "ph/p0/").items()})
+            batches = [batch_from(z, "ph/b0/").to("cpu", dtype=torch.float32), batch_from(z, "ph/b1/").to("cpu", dtype=torch.float32)]
+        else:
+            model = DOSTransformer(3, 2, 200, 41, 2, 16, DEV, 0.0)
+            model.load_state_dict(sub(z, "e/p0/"))
+            batches = [batch_from(z, "e/b0/"), batch_from(z, "e/b1/")]
+        crystals = [c for b in batches for c in split_crystals(b)]
+    elif case == "phonon_h128_b64":
+        model = DOSTransformer_phonon(3, 2, 118, 4, 128, DEV, 0.0)
+        crystals = synth.phonon_crystals(64, seed=77, dtype=torch.float32)
+    elif case == "edos_h64_b24":
+        model = DOSTransformer(3, 2, 200, 41, 2, 64, DEV, 0.0)
+        crystals = synth.edos_crystals(24, seed=78, dtype=torch.float32)
+    else:
+        model = DOSTransformer(3, 1, 200, 41, 2, 256, DEV, 0.0)
+        crystals = synth.edos_crystals(16, seed=79, dtype=torch.float32)
+    model = model.to(DEV).eval()
+    sizes = [int(c["x"].shape[0]) for c in crystals]
+    assert len(set(sizes)) > 1                                        # unequal crystals: the padding matters
+    ref_g, ref_x, ref_s = _batch1_loop(model, crystals)
+    g = collate(crystals).to(DEV, dtype=torch.float32)
+    pred = Predictor(model, per_crystal_keys=True).eval()
+    for _ in range(2):                                                # recorded, then replayed
+        dg, x, ds = pred(g)
+        torch.cuda.synchronize()
+        sc = float(ref_s.abs().max())
+        assert float((dg - ref_g).abs().max()) <= 1e-6 * max(sc, 1.0), float((dg - ref_g).abs().max())
+        assert float((ds - ref_s).abs().max()) <= 1e-6 * max(sc, 1.0), float((ds - ref_s).abs().max())
+        assert float((x - ref_x).abs().max()) <= 1e-6 * max(float(ref_x.abs().max()), 1.0)
+    # the plain batched forward is NOT that: the flag is what makes the difference
+    dg0, _, ds0 = Predictor(model).eval()(g)
+    torch.cuda.synchronize()
+    assert float((ds0 - ref_s).abs().max()) > 1e-4 * max(sc, 1e-3)
+
+
+def test_per_crystal_keys_against_the_oracle_at_batch_size_1():
+    """... and the batch-1 forwards themselves are the oracle's (fp64 restatement of the reference) to the north_star tolerance."""
+    from oracle import dos_oracle as O
+    from dostransformer_amd import synth
+    from dostransformer_amd.batch import collate
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    from dostransformer_amd.predict import Predictor
+    torch.manual_seed(1)
+    model = DOSTransformer_phonon(3, 2, 118, 4, 64, DEV, 0.0)
+    p64 = {k: (v.detach().clone().double() if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
+    model = model.to(DEV).eval()
+    crystals = synth.phonon_crystals(12, seed=5, dtype=torch.float64)
+    dg, _, ds = Predictor(model, per_crystal_keys=True).eval()(collate(crystals).to(DEV, dtype=torch.float32))
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        for b, c in enumerate(crystals):
+            og, _, os_ = O.dostransformer_phonon_forward(p64, collate([c]), 3, 2)
+            assert float(((dg[b].double().cpu() - og[0]) ** 2).mean().sqrt()) < 1e-4
+            assert float(((ds[b].double().cpu() - os_[0]) ** 2).mean().sqrt()) < 1e-4
+
+
+def test_per_crystal_keys_is_refused_where_it_does_not_apply():
+    from dostransformer_amd import synth
+    from dostransformer_amd._lib import DosxError
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    from dostransformer_amd.predict import Predictor
+    model = DOSTransformer_phonon(3, 1, 118, 4, 32, DEV, 0.2).to(DEV)      # attention dropout, training mode
+    g = synth.phonon_batch(3, seed=1, dtype=torch.float32).to(DEV)
+    model.train()
+    with pytest.raises((DosxError, RuntimeError)):
+        Predictor(model, per_crystal_keys=True)(g)
