@@ -28,6 +28,14 @@ from ._models import DOSTransformerBase, _SEED_MOD, rank_seed_offset
 from .batch import CrystalBatch, GraphMeta, bucket_sizes, graph_meta, pad_batch, seg_tile_bound
 
 _EARLY_REDUCE = __import__("os").environ.get("DOSX_EARLY_REDUCE", "1") == "1"
+# Data parallel: a THIRD gradient bucket (GN_decoder + message-passing layers L-1 .. 1: 1.9 of the GNN trunk's 3.0 MB at the
+# headline shape) all-reduced from the flush at layer 0, under layer 0's backward, so that only 1.1 MB stay behind the step
+# (VERDICT r5 item 6).  Built, tested (tests/test_dp_gpu.py, tests/test_dp_gloo.py) - and OFF: on a 1-rank RCCL group the extra
+# collective point costs 55 us per step (1.1118 -> 1.1667 ms, three interleaved rounds, tools/exp/r6_dp1.sh) - the communicator
+# stream's wait for the weight-gradient stream lands in a hardware queue it shares with the main stream (more hardware queues,
+# GPU_MAX_HW_QUEUES = 6 / 8, make the step 35 % slower: tools/exp/r6_dp2.sh) - while 1.9 MB less exposed traffic is worth about
+# 15 us on 8 xGMI-connected GPUs.  To be re-measured on a real multi-GPU node.
+_DP_MID_BUCKET = __import__("os").environ.get("DOSX_DP_MID_BUCKET", "0") == "1"
 _DP_CHECK = __import__("os").environ.get("DOSX_DP_CHECK", "0") == "1"
 _META_TENSORS = ("src", "dst", "rowptr_dst", "perm_src", "rowptr_src", "graph_ptr", "node_graph", "dense_row", "inv_deg")
 
@@ -287,7 +295,7 @@ class Trainer:
         (functional.gnn_bwd): the MID bucket - GN_decoder + layers L-1 .. 1, two thirds of the GNN trunk's gradient bytes - is
         final, so its all-reduce starts on the gradient stream NOW, underneath layer 0's backward, the encoders' backward and the
         last weight-gradient group; only the last bucket (encoders + layer 0) is reduced behind the step."""
-        if self.dist is None or not self.bucketed or not (0 < fp.n_late < fp.total) or not (0 < fp.n_last < fp.n_late):
+        if self.dist is None or not self.bucketed or not (0 < fp.n_late < fp.total) or not (0 < fp.n_last < fp.n_late) or not _DP_MID_BUCKET:
             return None
 
         def hook(sink):

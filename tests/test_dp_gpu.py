@@ -59,7 +59,8 @@ def eight_rank_full_run(tmp_path_factory):
     return _run_ranks(str(tmp_path_factory.mktemp("dp8")), 8, "full")
 
 
-@pytest.mark.parametrize("kind,mode", [("phonon", "eager"), ("phonon", "replay"), ("edos", "eager"), ("edos", "replay")])
+@pytest.mark.parametrize("kind,mode", [("phonon", "eager"), ("phonon", "replay"), ("edos", "eager"), ("edos", "replay"),
+                                       ("phonon", "replay_mid"), ("edos", "replay_mid")])
 def test_two_rank_trainer_matches_single_process(two_rank_run, kind, mode):
     from dostransformer_amd.batch import collate
     from dostransformer_amd.train import Trainer
@@ -142,7 +143,7 @@ def test_eight_rank_full_size_configs_match_single_process(eight_rank_full_run, 
     (one GPU, host-staged sums): this proves the 8-way sharded step computes the full-batch step."""
     from dostransformer_amd.batch import collate
     from dostransformer_amd.train import Trainer
-    from tests.dp_worker import SUITES, make_crystals, make_model
+    from tests.dp_worker import SUITES, make_crystals, make_model, suite_steps
     ranks = eight_rank_full_run
     pre = f"{kind}/{mode}/"
     for r in ranks[1:]:
@@ -169,7 +170,7 @@ def test_eight_rank_full_size_configs_match_single_process(eight_rank_full_run, 
         Fn._FACTOR_HEADS, Fn._FACTOR_HEADS_MIN_GF = shard_form[2], 0.0
         tr = Trainer(model, lr=1e-3, beta=1.0)
         losses, grad0 = [], None
-        for step in SUITES["full"]["steps"]:
+        for step in suite_steps("full", kind):
             g = collate(make_crystals(kind, step, "full")).to(dev)
             assert g.num_graphs == SUITES["full"][kind][3]
             losses.append(float(tr.step(g)))
