@@ -167,6 +167,27 @@ def load_traffic(config="phonon_h128_b64"):
     return rec.get("kernels", {}), f"{os.path.basename(files[-1])} (git {rec.get('git_head', '?')[:12]})"
 
 
+def load_kernel_only(config="phonon_h128_b64"):
+    """Per-site KERNEL-ONLY figures from the committed rocprofv3 --kernel-trace --stats run of the same command
+    (tools/kernel_only.py -> profiles/r*_kernel_only*.json): the site's algorithmic work per step / the summed durations of its
+    kernel symbol per step - no event brackets, no dispatch gaps, no waiting for CUs.  Hash-checked like `traffic`."""
+    import glob
+    from dostransformer_amd._lib import source_hash
+    suffix = {"phonon_h128_b64": "", "edos_h256_b64": "_edos"}.get(config)
+    if suffix is None:
+        return {}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_kernel_only{suffix}.json")))
+    if not files:
+        return {}
+    try:
+        rec = json.load(open(files[-1]))
+    except Exception:  # pragma: no cover
+        return {}
+    if rec.get("source_hash") != source_hash():
+        return {}
+    return rec.get("sites", {})
+
+
 def load_north_star():
     """The two counter-based figures of BASELINE.json's north_star (scatter-add HBM fraction, attention MFMA utilisation)
     from the committed rocprofv3 PMC passes (tools/pmc_north_star.py), under the same rule as `traffic`: a file measured on
@@ -175,16 +196,33 @@ def load_north_star():
     from dostransformer_amd._lib import source_hash
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_north_star.json")))
     if not files:
-        return {"scatter_hbm_frac": None, "attn_mfma_util": None, "source": "no profiles/r*_north_star.json"}
+        return {"scatter_hbm_frac": None, "attn_mfma_util": None, "in_step": None, "source": "no profiles/r*_north_star.json"}
     name = os.path.basename(files[-1])
     try:
         rec = json.load(open(files[-1]))
     except Exception as e:  # pragma: no cover
         return {"scatter_hbm_frac": None, "attn_mfma_util": None, "source": f"{name}: {e}"[:100]}
     if rec.get("source_hash") != source_hash():
-        return {"scatter_hbm_frac": None, "attn_mfma_util": None,
+        return {"scatter_hbm_frac": None, "attn_mfma_util": None, "in_step": None,
                 "source": f"{name} was measured on other sources ({rec.get('source_hash')} != {source_hash()}): refused"}
-    return {"scatter_hbm_frac": rec.get("scatter_hbm_frac"), "attn_mfma_util": rec.get("attn_mfma_util"),
+    # in_step: the same two questions asked of the kernels that RUN in the replayed steps (tools/pmc_step.py over rocprofv3 --pmc
+    # passes of bench.py itself): MFMA-busy of the launches that contain the attention, bytes / time of the launch that contains
+    # the scatter-add.  The two objects above are microbenchmarks of stand-alone kernels (`kind`).
+    in_step = None
+    sfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma_step.json")))
+    if sfiles:
+        try:
+            srec = json.load(open(sfiles[-1]))
+            if srec.get("source_hash") == source_hash():
+                # (the line carries one number per launch family: MFMA-busy fraction, or HBM fraction for the scatter-add rows;
+                #  durations / launch counts / per-symbol tables stay in the file)
+                in_step = {cfg: {k: (v.get("mfma_util") if "mfma_util" in v else v.get("hbm_frac")) for k, v in tab.items()}
+                           for cfg, tab in (srec.get("in_step") or {}).items()}
+                in_step["file"] = os.path.basename(sfiles[-1])
+        except Exception:  # pragma: no cover
+            pass
+    return {"kind": "microbench of the stand-alone kernels (scatter_hbm_frac, attn_mfma_util); in_step: counters over the replayed steps",
+            "scatter_hbm_frac": rec.get("scatter_hbm_frac"), "attn_mfma_util": rec.get("attn_mfma_util"), "in_step": in_step,
             "source": f"{name} (rocprofv3 --pmc, git {str(rec.get('git_head', '?'))[:12]})"}
 
 
@@ -257,7 +295,7 @@ def compact_record(out: dict, sites: list, budget: int = LINE_BUDGET) -> dict:
     rec = dict(out)
     rec["top_sites"] = [{"site": r["site"][:48], "frac": r["frac"], "us_per_step": r.get("us_per_step"), "bound": r["bound"]}
                         for r in sites[:5]]
-    for drop in (None, "top_sites", "traffic_source", "slots", "dp", "secondary"):
+    for drop in (None, "top_sites", "traffic_source", "slots", "env", "dp", "secondary"):
         if drop is not None:
             rec.pop(drop, None)
         if len(json.dumps(rec)) <= budget:
@@ -734,16 +772,24 @@ def main():
         n_inst = r["n_inst"]
         kernels, traffic_src = load_traffic(args.config) if (world == 1 and not args.shuffle) \
             else ({}, "traffic is profiled for the single-GPU fixed-batch runs only")
+        kernel_only = load_kernel_only(args.config) if (world == 1 and not args.shuffle) else {}
         for rec in roof["all"] + ([roof["dominant"]] if roof["dominant"] else []):
             rec["traffic"] = traffic_of(kernels, rec["kernel"])
             rec["us_per_step"] = round(1e3 * rec["total_ms"] / max(n_inst, 1), 2)
-            rec["launches_per_step"] = round(rec["launches"] / max(n_inst, 1), 2)
+            # launches_per_step: device KERNELS per step (rocprofv3's call count); brackets_per_step: the timed event pairs - a
+            # dosx_grad_flush bracket holds one kernel per table of 8 jobs (6 brackets = 7 kernels)
+            rec["launches_per_step"] = round(rec.get("kernel_launches", rec["launches"]) / max(n_inst, 1), 2)
+            rec["brackets_per_step"] = round(rec["launches"] / max(n_inst, 1), 2)
+            ko = kernel_only.get(rec["site"])
+            rec["kernel_only_frac"] = ko["frac"] if ko else None
+            rec["kernel_only_us_per_step"] = ko["us_per_step"] if ko else None
         ms_step = 1e3 * elapsed / args.steps
         flops_step = r["flops_step"]
         dom = roof["dominant"]
         if dom is not None:          # the roofline object of the contract: dominant site only, compact
             dom = {k: _round_sig(dom[k], 5) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "site", "kernel",
-                                                       "avg_us", "launches_per_step", "us_per_step", "work_per_launch")}
+                                                       "avg_us", "launches_per_step", "brackets_per_step", "us_per_step", "work_per_launch",
+                                                       "kernel_only_frac", "kernel_only_us_per_step")}
             dom["timing"] = "HIP event pair per launch inside the replayed step, on the launching stream" if mode == "replay" \
                 else "HIP events per launch"
         out = {

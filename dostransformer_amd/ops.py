@@ -42,26 +42,28 @@ class _KernelTimer:
         ev.record()
         return ev
 
-    def stop(self, ev, tag: str, kernel: str, bound: str, work: float):
-        """work: algorithmic flops (bound == 'mfma') or bytes (bound == 'hbm') of this launch."""
+    def stop(self, ev, tag: str, kernel: str, bound: str, work: float, kernels: int = 1):
+        """work: algorithmic flops (bound == 'mfma') or bytes (bound == 'hbm') of this launch; kernels: device kernels the
+        bracketed call launched (dosx_grad_flush: one per table of 8 jobs)."""
         if ev is None:
             return
         end = torch.cuda.Event(enable_timing=True)
         end.record()
-        self.records.append((tag, kernel, bound, float(work), ev, end))
+        self.records.append((tag, kernel, bound, float(work), ev, end, int(kernels)))
 
-    def add_ms(self, tag: str, kernel: str, bound: str, work: float, ms: float):
+    def add_ms(self, tag: str, kernel: str, bound: str, work: float, ms: float, kernels: int = 1):
         """a launch whose duration was measured elsewhere (Program.run_timed)"""
-        self.records.append((tag, kernel, bound, float(work), None, float(ms)))
+        self.records.append((tag, kernel, bound, float(work), None, float(ms), int(kernels)))
 
     def roofline(self, hbm_peak_gbs: float, mfma_peak_tflops: float):
         agg = {}
-        for tag, kernel, bound, work, s, e in self.records:
+        for tag, kernel, bound, work, s, e, nk in self.records:
             ms = e if s is None else s.elapsed_time(e)
-            a = agg.setdefault(tag, {"kernel": kernel, "bound": bound, "work": 0.0, "ms": 0.0, "n": 0})
+            a = agg.setdefault(tag, {"kernel": kernel, "bound": bound, "work": 0.0, "ms": 0.0, "n": 0, "k": 0})
             a["work"] += work
             a["ms"] += ms
             a["n"] += 1
+            a["k"] += nk
         out = []
         for tag, a in agg.items():
             if a["ms"] <= 0:
@@ -72,7 +74,7 @@ class _KernelTimer:
                 ach, peak, unit = a["work"] / (a["ms"] * 1e-3) / 1e9, hbm_peak_gbs, "GB/s"
             out.append({"site": tag, "kernel": a["kernel"], "bound": a["bound"], "achieved": round(ach, 3),
                         "peak": peak, "unit": unit, "frac": round(ach / peak, 5), "traffic": None,
-                        "launches": a["n"], "avg_us": round(1e3 * a["ms"] / a["n"], 3),
+                        "launches": a["n"], "kernel_launches": a["k"], "avg_us": round(1e3 * a["ms"] / a["n"], 3),
                         "work_per_launch": a["work"] / a["n"], "total_ms": round(a["ms"], 3)})
         out.sort(key=lambda r: -r["total_ms"])
         dom = dict(out[0]) if out else None
@@ -221,7 +223,7 @@ class Program:
         for ci in range(self._n):
             w = self.work.get(self._entry_of[ci])
             if w is not None:
-                timer.add_ms(w[0], w[1], w[2], w[3], float(ms[ci]))
+                timer.add_ms(w[0], w[1], w[2], w[3], float(ms[ci]), w[4] if len(w) > 4 else 1)
 
     def run_python(self) -> None:
         """Reference implementation of run(): the same list issued entry by entry from Python."""
@@ -247,8 +249,8 @@ def _call(name: str, *args, w=None) -> None:
         COUNTERS.poison()
         _lib.check(rc, name)
     if ev is not None:
-        site, kernel, bound, work = w() if w is not None else (name[5:], name[5:] + "_kernel", "hbm", 0.0)
-        KERNEL_TIMER.stop(ev, site, kernel, bound, work)
+        rec = w() if w is not None else (name[5:], name[5:] + "_kernel", "hbm", 0.0)
+        KERNEL_TIMER.stop(ev, rec[0], rec[1], rec[2], rec[3], rec[4] if len(rec) > 4 else 1)
     if RECORDER.active:
         if w is not None:
             RECORDER.work[len(RECORDER.prog)] = w()
@@ -828,8 +830,10 @@ def grad_flush(descs: Sequence[Wgrad], rjobs: Sequence[tuple] = ()) -> None:
         return
     arr = (Wgrad * max(len(descs), 1))(*descs)
     rarr = _reduce_job_array(rjobs)
+    # (device kernels of this call: one per table of 8 weight-gradient jobs / 40 reductions, csrc/gemm.hip: dosx_grad_flush)
+    nk = max(-(-len(descs) // 8), -(-len(rjobs) // 40), 1)
     _call("dosx_grad_flush", arr, len(descs), rarr, len(rjobs), _stream(),
-          w=lambda: ("wgrad_grouped", "wgrad_grouped_kernel", "mfma", sum(2.0 * getattr(d, "_real_M", d.M) * d.N * d.K for d in descs)))
+          w=lambda: ("wgrad_grouped", "wgrad_grouped_kernel", "mfma", sum(2.0 * getattr(d, "_real_M", d.M) * d.N * d.K for d in descs), nk))
 
 
 def wgrad_grouped(descs: Sequence[Wgrad]) -> None:
