@@ -295,7 +295,7 @@ def compact_record(out: dict, sites: list, budget: int = LINE_BUDGET) -> dict:
     rec = dict(out)
     rec["top_sites"] = [{"site": r["site"][:48], "frac": r["frac"], "us_per_step": r.get("us_per_step"), "bound": r["bound"]}
                         for r in sites[:5]]
-    for drop in (None, "top_sites", "traffic_source", "slots", "env", "dp", "secondary"):
+    for drop in (None, "top_sites", "traffic_source", "slots", "dp", "secondary"):
         if drop is not None:
             rec.pop(drop, None)
         if len(json.dumps(rec)) <= budget:

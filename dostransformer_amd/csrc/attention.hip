@@ -96,7 +96,7 @@ __device__ __forceinline__ int row_of(int wave, int p, int lane) { return wave *
 //     dS . (k̂ γ+β)         =  (dS . k̂) ∘ γ                           (rows of dS sum to 0)
 // so both operands are the raw normalised keys k̂ (`kvhat`), fetched with buffer loads whose bounds return
 // zeros for the rows beyond Nk.  (Exact in real arithmetic; fp32 rounding differs from the resident-key
-// kernels at the 1e-7 level, tests/test_gpu_ops.py::test_attention_fwd_bwd covers both.)
+// kernels at the 1e-7 level, tests/test_gpu_attention.py::test_attention_fwd_bwd covers both.)
 constexpr int SKR = 10;    // 32-key row blocks per crystal (Nk <= 320): float4 per staging lane per K chunk
 constexpr int SVC = 8;     // 32-column blocks per row (H <= 256):      float4 per staging lane per V chunk
 

@@ -133,7 +133,7 @@ __device__ __forceinline__ float f4get(const float4& v, int i) {
 // the drain does for the write-through stores; acquire = later loads must not hit stale lines, which sc1 loads do not) -
 // instead of the whole-cache `buffer_wbl2 sc1` / `buffer_inv sc1` an __ATOMIC_ACQ_REL ticket would emit.  Build with
 // -DDOSX_TICKET_ORDER=__ATOMIC_ACQ_REL to get exactly that stronger form (measured cost: DESIGN.md §2, round 4); the stress
-// tests (tests/test_gpu_round4.py: thousands of launches under a bandwidth hog, every one compared bitwise) run on either.
+// tests (tests/test_gpu_gemm.py, tests/test_gpu_graph.py: thousands of launches under a bandwidth hog, every one compared bitwise) run on either.
 #ifndef DOSX_TICKET_ORDER
 #define DOSX_TICKET_ORDER __ATOMIC_RELAXED
 #endif

@@ -1539,7 +1539,7 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
 # three LayerNorm launches, scores / softmax / P.V from csrc/attention_kv.hip, the feed-forward half as two GEMMs) on the RAW
 # dense keys (dosx_dense_slots = to_dense_batch alone), plain GEMMs + row kernels for the 2H-wide LayerNorms of the GNN
 # blocks (mlp_ln_fwd / _bwd above).  One stream, no launch-saving tricks: a correctness path for rare shapes, pinned against
-# the oracle like every other path (tests/test_gpu_round4.py).  Limit: hidden <= 512 (LayerNorm prologues of dosx_gemm).
+# the oracle like every other path (tests/test_gpu_models.py).  Limit: hidden <= 512 (LayerNorm prologues of dosx_gemm).
 def _sum_rows(dev, terms, rows, H, keep):
     """sum of equally shaped [rows, H] tensors (ops.mask_residual: out = res + a)"""
     acc = terms[0]

@@ -148,7 +148,7 @@ class DeviceDataset:
         """Write the batch of crystals ``idx`` into the STATIC ghost-padded buffers of ``g`` (a bucket of
         ``train.Trainer``): one small host->device copy (selection + prefix sums) and one ``dosx_collate_padded`` call
         (3 launches).  The result is what ``pad_batch(self.collate(idx), N_pad, E_pad)`` holds in the fields the kernels read
-        (tests/test_gpu_round2.py::test_collate_into_matches_pad_batch)."""
+        (tests/test_gpu_graph.py::test_collate_into_matches_pad_batch)."""
         from ._lib import Collate
         import ctypes as C
         t = self._f32_tables()

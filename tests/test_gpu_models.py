@@ -7,6 +7,10 @@ import torch
 
 from tests.util import batch_from, load, maxabs, rmse, sub
 
+import ctypes as C
+import math
+import torch.nn.functional as F
+from tests.gpu_util import (DEV, TOL, _FakeDist, _Hog, _attn_ref, _descs, _fat_crystals, _fatten, _graph, _mixed_jobs, _node_block, _philox_mask_numpy, _phonon, _random_crystals, _reduce, _ref, _scratch, _sliver_case, err, ops, prelu, rnd)  # noqa: F401
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 DOS_RMSE = 1e-4          # north_star tolerance on the predicted DOS vector
@@ -572,3 +576,513 @@ def test_example_driver_end_to_end(tmp_path):
     assert np.isfinite(res["best_valid_rmse"]) and os.path.exists(out)
     fresh = DOSTransformer_phonon(3, 1, 118, 4, 32, DEV, 0.0).to(DEV)
     checkpoint.load(out, fresh)
+
+
+def test_build_data_all_feeds_the_model():
+    """structures -> featurize.build_data_all -> collate -> model: schema of `utils.py:291-301`, x = mass one-hot."""
+    from dostransformer_amd import featurize
+    from dostransformer_amd.batch import collate
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    from oracle.dos_oracle import neighbor_list_bruteforce
+    rng = np.random.default_rng(3)
+    pos, cells = _random_crystals(11, [2, 5, 3])
+    entries = [{"symbols": [featurize.SYMBOLS[k] for k in rng.integers(0, 90, p.shape[0])], "positions": p, "cell": c,
+                "phdos": rng.uniform(0, 1, 51), "crystal_system": cs, "mp_id": f"mp-{k}"}
+               for k, (p, c, cs) in enumerate(zip(pos, cells, ["Cubic", "Monoclinic", "Triclinic"]))]
+    data = featurize.build_data_all(entries, r_max=4.0, device=DEV, dtype=torch.float32)
+    assert [int(d["system"]) for d in data] == [0, 5, 6]
+    for d, e in zip(data, entries):
+        i, j, S, D = neighbor_list_bruteforce(e["positions"], e["cell"], 4.0, True)
+        assert d["edge_index"].shape == (2, len(i)) and np.array_equal(d["edge_index"].numpy(), np.stack([i, j]))
+        assert np.allclose(d["edge_vec"].numpy(), D, atol=1e-6)
+        z = [featurize.SYMBOLS.index(s) for s in e["symbols"]]
+        assert d["x"].shape == (len(z), 118) and (d["x"] != 0).sum() == len(z)
+        assert np.allclose(d["x"][range(len(z)), z].numpy(), [featurize.ATOMIC_MASSES[k] for k in z], rtol=1e-6)
+        assert d["phdos"].shape == (1, 51)
+    torch.manual_seed(0)
+    model = DOSTransformer_phonon(2, 1, 118, 4, 32, DEV, 0.0).to(DEV)
+    g = collate(data).to(DEV)
+    with torch.no_grad():
+        dg, x, ds = model(g)
+    assert dg.shape == (3, 51) and torch.isfinite(dg).all() and torch.isfinite(ds).all()
+
+
+@pytest.mark.parametrize("H,T,B,steps,every", [(64, 1, 8, 200, 10), (128, 2, 64, 100, 10)])
+def test_fp32_training_trajectory_tracks_fp64_oracle(H, T, B, steps, every):
+    """The precision question of VERDICT r1: fp32 kernels against the reference's fp64 phonon arithmetic over a
+    TRAJECTORY, not 1-3 steps.  BASELINE configs[0] (H64 T1 B8), 200 AdamW steps, and configs[1] (H128 T2 B64, the benchmark
+    configuration), 100 steps (round 5 ran 200 there: 77 s of CPU oracle inside the GPU suite's wall time; round 4: 50).
+
+    Three runs from the same initial weights on the same batches: the oracle in fp64 on the CPU (the reference's
+    arithmetic, main_phDOS.py:15-16), the oracle in fp32 on the CPU (plain torch fp32: what `torch.float32` upstream
+    would give), and the HIP path (fp32).  Checked at every `every`-th step on a held-out batch:
+      * the loss curves of HIP-fp32 and fp64 agree within 1e-4 at EVERY step;
+      * early on (<= 10 steps) the predicted DOS vectors agree within the north_star tolerance (1e-4 RMSE);
+      * later the two fp32 runs both wander from the fp64 one — AdamW divides by sqrt(v): where a gradient element is at
+        the fp32 noise floor its normalised update is O(lr) with a noise-determined sign, so ANY fp32 implementation
+        decorrelates from fp64 on those elements at ~lr per step.  What is asserted is that the HIP path drifts no more
+        than torch's own fp32 does (within 3x; measured on MI355X in round 2: see the printed line), i.e. the deviation
+        is the arithmetic width, not the kernels.  DESIGN.md §4 carries the measured numbers."""
+    from oracle import dos_oracle as O
+    from dostransformer_amd import synth
+    from dostransformer_amd.train import Trainer
+    torch.manual_seed(0)
+    model = _phonon(H, T)
+    p64 = {k: (v.detach().clone().double() if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
+    p32 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    n_b = 4
+    b64 = [synth.phonon_batch(B, seed=500 + k, dtype=torch.float64) for k in range(n_b)]
+    b32 = [synth.phonon_batch(B, seed=500 + k, dtype=torch.float32) for k in range(n_b)]
+    gpu_b = [b.clone().to(DEV) for b in b32]
+    probe64 = synth.phonon_batch(B, seed=599, dtype=torch.float64)
+    probe32 = synth.phonon_batch(B, seed=599, dtype=torch.float32)
+    probe_gpu = probe32.clone().to(DEV)
+    tr = Trainer(model, lr=1e-4, beta=1.0, replay=True)
+    s64, s32 = {}, {}
+    hip_dos, cpu_dos, hip_loss, cpu_loss, early = 0.0, 0.0, 0.0, 0.0, 0.0
+    torch.set_num_threads(8)
+    for i in range(steps):
+        lg = float(tr.step(gpu_b[i % n_b]))
+        l64, _ = O.train_step("phonon", p64, s64, b64[i % n_b], 3, T, lr=1e-4, beta=1.0)
+        l32, _ = O.train_step("phonon", p32, s32, b32[i % n_b], 3, T, lr=1e-4, beta=1.0)
+        hip_loss = max(hip_loss, abs(lg - float(l64)))
+        cpu_loss = max(cpu_loss, abs(float(l32) - float(l64)))
+        if (i + 1) % every == 0:
+            with torch.no_grad():
+                dg, _, ds = model(probe_gpu)
+                rg, _, rs = O.dostransformer_phonon_forward(p64, probe64, 3, T)
+                cg, _, cs = O.dostransformer_phonon_forward(p32, probe32, 3, T)
+            h = max(rmse(dg.cpu(), rg), rmse(ds.cpu(), rs))
+            hip_dos = max(hip_dos, h)
+            cpu_dos = max(cpu_dos, rmse(cg, rg), rmse(cs, rs))
+            if i + 1 <= 10:
+                early = h
+    print(f"drift H{H} T{T} B{B}, {steps} AdamW steps vs the fp64 oracle: HIP fp32 DOS rmse {hip_dos:.3e} (at step 10: {early:.3e}), "
+          f"torch-CPU fp32 DOS rmse {cpu_dos:.3e}; |loss diff| HIP {hip_loss:.3e}, torch-CPU fp32 {cpu_loss:.3e}")
+    assert hip_loss < 1e-4, hip_loss
+    assert early < 1e-4, early
+    assert hip_dos < 3.0 * cpu_dos + 2e-5, (hip_dos, cpu_dos)
+
+
+def test_model_attention_dropout_train_step_matches_oracle():
+    """DOSTransformer_phonon(attn_drop=0.25): one training step through Trainer == the oracle with the same masks (loss and
+    every gradient); replayed steps draw fresh masks each time (the seed lives on the device, outside the recording)."""
+    from oracle import dos_oracle as O
+    from dostransformer_amd import functional as Fn, synth
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    from dostransformer_amd.train import Trainer
+    torch.manual_seed(0)
+    model = DOSTransformer_phonon(3, 2, 118, 4, 32, DEV, 0.25)
+    p64 = {k: (v.detach().clone().double() if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
+    model = model.to(DEV).train()
+    g64 = synth.phonon_batch(5, seed=21, dtype=torch.float64)
+    g = synth.phonon_batch(5, seed=21, dtype=torch.float32).to(DEV)
+    tr = Trainer(model, lr=1e-4)
+    Fn.DROP_MASK_LOG = []
+    try:
+        loss = tr.forward_backward(g)
+        log = list(Fn.DROP_MASK_LOG)
+    finally:
+        Fn.DROP_MASK_LOG = None
+    masks = {}
+    for pre, t, m in log:
+        masks.setdefault(pre, []).append(m.double().cpu())
+    assert sorted(masks) == ["transformer", "transformer_self", "transformer_source"] and all(len(v) == 2 for v in masks.values())
+    for k in p64:
+        if p64[k].is_floating_point():
+            p64[k].requires_grad_(True)
+    dg, _, dsys = O.dostransformer_phonon_forward(p64, g64, 3, 2, drop_masks=masks)
+    ref = O.loss_phonon(dg, dsys, g64.phdos, 1.0)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 2e-5
+    fp = model.flat_params()
+    for k, v in p64.items():
+        if k in fp.G:
+            e = float((fp.G[k].cpu().double() - v.grad).abs().max() / (v.grad.abs().max() + 1e-9))
+            assert e < 3e-3, (k, e)
+    # replay: every step must see a new mask (same batch, lr = 0 -> identical weights; the loss changes only through dropout)
+    tr2 = Trainer(model, lr=0.0, weight_decay=0.0, replay=True)
+    losses = [float(tr2.step(g)) for _ in range(4)]
+    assert len(set(losses)) == 4, losses
+    model.eval()
+    with torch.no_grad():
+        a = model(g)[0].clone()
+        b = model(g)[0].clone()
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("kind", ["phonon", "edos"])
+def test_encoder_decoder_blocks_match_oracle(kind):
+    """Encoder / Decoder called on their own (`DOSTransformer_phonon.py:126-145,174-183`, `DOSTransformer.py:100-122,151-161`)."""
+    from oracle import dos_oracle as O
+    from dostransformer_amd import synth
+    from dostransformer_amd._blocks import Decoder, Encoder
+    torch.manual_seed(0)
+    H = 32
+    if kind == "phonon":
+        enc, dec = Encoder(118, 4, H), Decoder(H, H)
+        g = synth.phonon_batch(4, seed=7, dtype=torch.float32)
+        ea = O.edge_features_sh1(g.edge_vec)
+    else:
+        enc, dec = Encoder(200, 41, H, n_global_feats=2), Decoder(2 * H, H)
+        g = synth.edos_batch(3, seed=8, dtype=torch.float32)
+        ea = g.edge_attr
+    pe = {"GN_encoder." + k: v.detach().clone() for k, v in enc.state_dict().items()}
+    pd = {"GN_decoder." + k: v.detach().clone() for k, v in dec.state_dict().items()}
+    enc, dec = enc.to(DEV), dec.to(DEV)
+    energies = torch.randn(51, H).to(DEV)
+    args = (g.x.to(DEV), ea.to(DEV)) + ((g.glob.to(DEV),) if kind == "edos" else ()) + (g.batch.to(DEV), energies)
+    outs = enc(*args)
+    x_ref = O._mlp_prelu(pe, "GN_encoder.node_encoder", g.x)
+    e_ref = O._mlp_prelu(pe, "GN_encoder.edge_encoder", ea)
+    assert float((outs[0].cpu() - x_ref).abs().max()) < 2e-5 and float((outs[1].cpu() - e_ref).abs().max()) < 2e-5
+    assert outs[-1].shape == (51, g.num_graphs, H) and torch.equal(outs[-1][:, 0], energies)
+    xs = outs[0]
+    if kind == "edos":
+        u_ref = O._mlp_prelu(pe, "GN_encoder.global_encoder", g.glob.reshape(-1, 2))
+        assert float((outs[2].cpu() - u_ref).abs().max()) < 2e-5
+        y = dec(xs, outs[2], g.batch.to(DEV))
+        y_ref = O._linear(pd, "GN_decoder.mlp.0", torch.cat([u_ref, O.scatter_sum(x_ref, g.batch, g.num_graphs)], 1))
+    else:
+        y = dec(xs, g.batch.to(DEV))
+        y_ref = O._linear(pd, "GN_decoder.mlp.0", O.scatter_sum(x_ref, g.batch, g.num_graphs))
+    assert float((y.cpu() - y_ref).abs().max()) < 5e-5
+    y.sum().backward()
+    assert enc.node_encoder[0].weight.grad is not None and dec.mlp[0].weight.grad is not None
+
+
+def test_graphnetwork_prompt_branch():
+    """Graphnetwork_phonon with 118 + H/2 wide node features takes `node_encoder_prompt` (`graphnetwork_phonon.py:150-153`);
+    the plain `node_encoder` then stays without a gradient."""
+    from oracle import dos_oracle as O
+    from dostransformer_amd import synth
+    from dostransformer_amd.embedder_phDOS.graphnetwork_phonon import Graphnetwork_phonon
+    torch.manual_seed(0)
+    H = 32
+    model = Graphnetwork_phonon(3, 118, 4, H, 51, DEV)
+    p = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    g = synth.phonon_batch(4, seed=9, dtype=torch.float32)
+    g.x = torch.cat([g.x, torch.randn(g.x.shape[0], H // 2, generator=torch.Generator().manual_seed(1))], 1)
+    ref = O.graphnetwork_phonon_forward(p, g, 3)
+    gg = g.clone().to(DEV)
+    out = model(gg)
+    assert rmse(out.detach().cpu(), ref) < 1e-4
+    out.sum().backward()
+    assert model.GN_encoder.node_encoder_prompt[0].weight.grad is not None
+    assert model.GN_encoder.node_encoder[0].weight.grad is None
+    pr = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in p.items()}
+    O.graphnetwork_phonon_forward(pr, g, 3).sum().backward()
+    w = "GN_encoder.node_encoder_prompt.0.weight"
+    gr = dict(model.named_parameters())[w].grad.cpu()
+    assert float((gr - pr[w].grad).abs().max() / pr[w].grad.abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("kind", ["phonon", "edos"])
+def test_models_with_overfull_nodes_match_the_oracle(kind):
+    """Full models (mean aggregation: phonon, sum: eDOS) on a batch with 60- / 96- / 200-in-degree nodes against the oracle:
+    outputs, loss, gradients; eager == replay bitwise; the crystal-aligned tile table of the device collate
+    (Trainer.step_dataset) gives bitwise the step on the host-collated batch (greedy table over the whole batch): an
+    over-full node is cut the same way whatever shares the batch."""
+    from oracle import dos_oracle as O
+    from dostransformer_amd.batch import collate
+    from dostransformer_amd.loader import DeviceDataset
+    from dostransformer_amd.train import Trainer
+    torch.manual_seed(0)
+    B = 6
+    if kind == "phonon":
+        from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+        mk = lambda: DOSTransformer_phonon(3, 1, 118, 4, 64, DEV, 0.0)
+        ref_dt, fwd = torch.float64, O.dostransformer_phonon_forward
+    else:
+        from dostransformer_amd.embedder_eDOS.DOSTransformer import DOSTransformer
+        mk = lambda: DOSTransformer(3, 1, 200, 41, 2, 64, DEV, 0.0)
+        ref_dt, fwd = torch.float32, O.dostransformer_forward
+    cs32 = _fat_crystals(kind, B, 9, torch.float32)
+    cs_ref = _fat_crystals(kind, B, 9, ref_dt)
+    g_ref, g = collate(cs_ref), collate(cs32)
+    assert int((g.meta.seg_tile[2] != 0).sum()) >= 9
+    model = mk()
+    params = {k: (v.detach().clone().to(ref_dt) if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    with torch.no_grad():
+        rg, rx, rs = fwd(params, g_ref, 3, 1)
+    tr = Trainer(model, lr=1e-3, beta=1.0)
+    loss = tr.forward_backward(g.to(DEV))
+    dg, xn, ds_ = tr.last_outputs
+    rmse = lambda a, b: float(torch.sqrt(((a.double().cpu() - b.double()) ** 2).mean()))
+    assert rmse(dg, rg) < 1e-4 and rmse(ds_, rs) < 1e-4 and rmse(xn, rx) < 1e-4 * max(1.0, float(rx.abs().max()))
+    ref_loss, grads = O.train_step(kind, params, {}, g_ref, 3, 1, lr=1e-3, beta=1.0)
+    assert abs(float(loss) - float(ref_loss)) < 2e-4
+    fp = model.flat_params()
+    for k, gr in grads.items():
+        if gr is not None:
+            e = float((fp.G[k].cpu().double() - gr.double()).abs().max() / (gr.abs().max() + 1e-6))
+            assert e < 3e-3, (k, e)
+    # eager, replay and device-collated replay: same trajectory, bit for bit
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    outs = []
+    dsd = DeviceDataset(cs32, DEV)
+    nmax = max(int(c["x"].shape[0]) for c in cs32)
+    from dostransformer_amd.batch import bucket_sizes, pad_batch
+    gh = collate(cs32, n_max=nmax)
+    gp = pad_batch(gh, *bucket_sizes(gh.meta.num_nodes, gh.meta.num_edges, 16, 256)).to(DEV)   # (eager on the same padded batch)
+    for mode in ("eager", "replay", "dataset"):
+        m2 = mk()
+        m2.load_state_dict(sd0)
+        m2 = m2.to(DEV)
+        t2 = Trainer(m2, lr=1e-3, beta=1.0, replay=(mode != "eager"), bucket=(16, 256))
+        for _ in range(3):
+            if mode == "dataset":
+                t2.step_dataset(dsd, list(range(B)), n_max=nmax)
+            elif mode == "eager":
+                t2.step(gp)
+            else:
+                t2.step(collate(cs32, n_max=nmax).to(DEV))
+        torch.cuda.synchronize()
+        outs.append({k: v.detach().cpu().clone() for k, v in m2.state_dict().items()})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), ("eager vs replay", k)
+        # host-greedy vs crystal-aligned tile table: every aggregate is the same sum in the same order (over-full nodes are cut
+        # identically), so rounds 3-4 had bitwise equal trajectories here.  Round 5: the one-launch EdgeModel backward
+        # (csrc/edge_mlp.hip) leaves ONE partial row of the LayerNorm / PReLU parameter gradients per TILE, so those three
+        # gradients are the same sums grouped by another tiling - equal to rounding, and AdamW turns a rounding difference of a
+        # near-zero gradient element into up to lr per step: the promotion test's bounds (3 steps of lr 1e-3)
+        a, b = outs[1][k], outs[2][k]
+        if a.is_floating_point():
+            assert float((a - b).abs().max()) < 7e-3, ("host table vs crystal-aligned table", k)
+            assert float((a - b).abs().median()) < 1e-5, ("host table vs crystal-aligned table", k)
+        else:
+            assert torch.equal(a, b), k
+
+
+def test_shape_limits_are_explicit_errors():
+    """The shape limits fail LOUDLY, with the limit in the message, and leave the library usable: the MFMA
+    attention kernels stop at 256-wide rows (wider models take the unfused path, round 4: tests/test_gpu_models.py), and
+    hidden > 512 exceeds the LayerNorm prologue of dosx_gemm.  The number of keys has no limit: more than 320 (the
+    LDS-resident score row of the MFMA kernels) take the general kernels of csrc/attention_general.hip behind the same
+    descriptor (tests/test_gpu_attention.py::test_attention_fwd_bwd)."""
+    from dostransformer_amd._lib import DosxError, Attn
+    o = ops()
+    H, Sq, Bq = 32, 51, 2
+    for Nk in (320, 321, 1000):                          # no limit on the keys: 321+ take the general kernels (same contract)
+        x, kv = torch.randn(Sq * Bq, H, device=DEV), torch.randn(Nk * Bq, H, device=DEV)
+        ones, zeros = torch.ones(H, device=DEV), torch.zeros(H, device=DEV)
+        out, probs = torch.empty(Sq * Bq, H, device=DEV), torch.empty(Bq, Sq, Nk, device=DEV)
+        a = Attn()
+        a.Sq, a.Bq, a.Nk, a.Bk, a.H, a.q_stride_s, a.q_stride_b, a.flags = Sq, Bq, Nk, Bq, H, Bq, 1, 1 | 2
+        a.x, a.kvhat, a.gamma0, a.beta0 = x.data_ptr(), kv.data_ptr(), ones.data_ptr(), zeros.data_ptr()
+        a.out, a.probs = out.data_ptr(), probs.data_ptr()
+        o.attention_fwd(a)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(out).all()) and float((probs.sum(-1) - 1).abs().max()) < 1e-5
+    a.H = 260                                            # ... but the row kernels stop at 256 columns
+    with pytest.raises(DosxError, match="H=260"):
+        o.attention_fwd(a)
+    from dostransformer_amd import synth
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    torch.manual_seed(0)
+    model = DOSTransformer_phonon(1, 1, 118, 4, 640, DEV, 0.0).to(DEV)
+    g = synth.phonon_batch(2, seed=1, dtype=torch.float32).to(DEV)
+    with pytest.raises(DosxError, match="hidden <= 512"):
+        model(g)
+    small = DOSTransformer_phonon(1, 1, 118, 4, 32, DEV, 0.0).to(DEV)
+    assert bool(torch.isfinite(small(g)[0]).all())
+
+
+@pytest.mark.parametrize("mode", ["eager", "replay"])
+def test_crystal_with_more_than_320_atoms(mode):
+    """A crystal of 330 atoms next to one of 5: the cross attention over atoms runs over 330 keys (zero-padded for the small
+    crystal, `DOSTransformer_phonon.py:86-88`) - beyond the MFMA attention kernels, through csrc/attention_general.hip behind the
+    same descriptor.  Outputs, loss and every gradient against the oracle in float64; replay = eager bitwise."""
+    from oracle import dos_oracle as O
+    from dostransformer_amd import synth
+    from dostransformer_amd.batch import collate
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    from dostransformer_amd.train import Trainer
+    torch.manual_seed(0)
+    H, T = 32, 2
+    model = DOSTransformer_phonon(2, T, 118, 4, H, DEV, 0.0)
+    params = {k: (v.detach().clone().double() if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    gen = torch.Generator().manual_seed(4)
+    cr = [synth.phonon_crystal(gen, n_atoms=330, n_out=4), synth.phonon_crystal(gen, n_atoms=5, n_out=4)]
+    g_ref = collate(cr)
+    g = collate([{k: (v.float() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in c.items()} for c in cr]).to(DEV)
+    with torch.no_grad():
+        rg, rx, rs = O.dostransformer_phonon_forward(params, g_ref, 2, T)
+    tr = Trainer(model, lr=1e-4, beta=1.0, replay=(mode == "replay"))
+    if mode == "replay":
+        losses = [float(tr.step(g)) for _ in range(2)]     # the second step replays the recorded program
+        model2 = DOSTransformer_phonon(2, T, 118, 4, H, DEV, 0.0)
+        model2.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in params.items()})
+        tr2 = Trainer(model2.to(DEV), lr=1e-4, beta=1.0)
+        # (eager on the SAME ghost-padded batch the replayed bucket holds: the number of M-splits of a weight gradient
+        #  depends on its row count, so the padding decides the summation order of the last bits)
+        from dostransformer_amd.batch import bucket_sizes, pad_batch
+        gp = pad_batch(g, *bucket_sizes(g.meta.num_nodes, g.meta.num_edges, *tr.bucket))
+        eager = [float(tr2.step(gp)) for _ in range(2)]
+        assert losses == eager
+        for (k, v), (_, v2) in zip(model.state_dict().items(), model2.state_dict().items()):
+            assert torch.equal(v, v2), k
+        return
+    loss = tr.forward_backward(g)
+    dg, xn, ds = tr.last_outputs
+    rm = lambda a_, b_: float(torch.sqrt(((a_.double() - b_.double()) ** 2).mean()))
+    assert rm(dg.cpu(), rg) < 1e-4 and rm(ds.cpu(), rs) < 1e-4
+    ref_loss, grads = O.train_step("phonon", params, {}, g_ref, 2, T, lr=1e-4, beta=1.0)
+    assert abs(float(loss) - float(ref_loss)) < 2e-4
+    fp = model.flat_params()
+    for k, gr in grads.items():
+        if gr is None:
+            assert k not in fp.G, k
+        else:
+            e = float((fp.G[k].cpu().double() - gr.double()).abs().max() / (gr.abs().max() + 1e-6))
+            assert e < 2e-3, (k, e)
+
+
+def test_standalone_modules_with_parameters_far_apart():
+    """The fused feed-forward / NodeModel kernels reach both weight matrices of a layer through one 2 GiB buffer window.  A
+    standalone module's parameters are separate torch allocations: put fc1 and fc2 (and the NodeModel's two Linears) at the two
+    ends of a 3 GiB buffer - the modules pack them into one buffer for the call (functional.pack_params) and give the same
+    bits as before."""
+    from dostransformer_amd.layers import TransformerEncoder
+    from dostransformer_amd._blocks import NodeModel
+    torch.manual_seed(0)
+    H = 64
+    enc = TransformerEncoder(embed_dim=H, num_heads=1, layers=2).to(DEV)
+    node = NodeModel(H).to(DEV)
+    x = torch.randn(51, 3, H, device=DEV, requires_grad=True)
+    kv = torch.randn(9, 3, H, device=DEV)
+    xn = torch.randn(10, H, device=DEV, requires_grad=True)
+    ei = torch.randint(0, 10, (2, 40), device=DEV)
+    ea = torch.randn(40, H, device=DEV)
+
+    def run():
+        for t in (x, xn):
+            t.grad = None
+        enc.zero_grad(); node.zero_grad()
+        y = enc(x, kv, kv)
+        z = node(xn, ei, ea)
+        (y.sum() + z.sum()).backward()
+        return [y.detach().clone(), z.detach().clone(), x.grad.clone(), xn.grad.clone()] + \
+            [p.grad.clone() for p in list(enc.parameters()) + list(node.parameters()) if p.grad is not None]
+    ref = run()
+    big = torch.empty(3 * 2 ** 30 // 4, device=DEV)
+    with torch.no_grad():
+        pairs = [(lay.fc1.weight, lay.fc2.weight) for lay in enc.layers] + [(node.node_mlp_2[0].weight, node.node_mlp_2[3].weight)]
+        lo, hi = 0, big.numel()
+        for w1, w2 in pairs:                              # first matrix from the front of the buffer, second from its end
+            a_, b_ = big[lo:lo + w1.numel()].view_as(w1), big[hi - w2.numel():hi].view_as(w2)
+            a_.copy_(w1); b_.copy_(w2)
+            w1.data, w2.data = a_, b_
+            lo, hi = lo + w1.numel(), hi - w2.numel()
+    assert abs(enc.layers[0].fc1.weight.data_ptr() - enc.layers[0].fc2.weight.data_ptr()) > 2 ** 31
+    far = run()
+    assert len(ref) == len(far)
+    for a_, b_ in zip(ref, far):
+        assert torch.equal(a_, b_)
+
+
+@pytest.mark.parametrize("kind,H", [("phonon", 384), ("edos", 384), ("phonon", 512)])
+def test_models_with_hidden_beyond_256_match_the_oracle(kind, H):
+    """DOSTransformer_phonon / DOSTransformer with hidden 384 and 512 (the unfused path: K != V encoder building blocks on
+    the raw dense keys, row kernels for the 2H-wide LayerNorms of the GNN blocks) against the oracle: the three outputs, the
+    loss, every live gradient; dead parameters stay dead; eager and replay give the same trajectory bit for bit."""
+    from oracle import dos_oracle as O
+    from dostransformer_amd import synth
+    from dostransformer_amd.batch import collate
+    from dostransformer_amd.train import Trainer
+    torch.manual_seed(0)
+    B, L, T = 5, 2, 2
+    if kind == "phonon":
+        from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+        mk = lambda: DOSTransformer_phonon(L, T, 118, 4, H, DEV, 0.0)
+        ref_dt, fwd, cs_of = torch.float64, O.dostransformer_phonon_forward, synth.phonon_crystals
+    else:
+        from dostransformer_amd.embedder_eDOS.DOSTransformer import DOSTransformer
+        mk = lambda: DOSTransformer(L, T, 200, 41, 2, H, DEV, 0.0)
+        ref_dt, fwd, cs_of = torch.float32, O.dostransformer_forward, synth.edos_crystals
+    g_ref, g = collate(cs_of(B, 11, ref_dt)), collate(cs_of(B, 11, torch.float32))
+    model = mk()
+    params = {k: (v.detach().clone().to(ref_dt) if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    with torch.no_grad():
+        rg, rx, rs = fwd(params, g_ref, L, T)
+    tr = Trainer(model, lr=1e-3, beta=1.0)
+    loss = tr.forward_backward(g.to(DEV))
+    dg, xn, ds_ = tr.last_outputs
+    rmse = lambda a, b: float(torch.sqrt(((a.double().cpu() - b.double()) ** 2).mean()))
+    assert rmse(dg, rg) < 1e-4 and rmse(ds_, rs) < 1e-4 and rmse(xn, rx) < 1e-4 * max(1.0, float(rx.abs().max()))
+    clone = lambda d, dt=None: {k: (v.clone().to(dt) if (dt is not None and v.is_floating_point()) else v.clone()) for k, v in d.items()}
+    ref_loss, grads = O.train_step(kind, clone(params), {}, g_ref, L, T, lr=1e-3, beta=1.0)      # (the step updates its params)
+    assert abs(float(loss) - float(ref_loss)) < 2e-4
+    fp = model.flat_params()
+    errs = []
+    for k, gr in grads.items():
+        if gr is not None:
+            assert k in fp.G, k
+            e = float((fp.G[k].cpu().double() - gr.double()).abs().max() / (gr.abs().max() + 1e-6))
+            errs.append((e, k, float(torch.quantile((fp.G[k].cpu().double() - gr.double()).abs().flatten()[:1000000], 0.99) / (gr.abs().max() + 1e-6))))
+        else:
+            assert k not in fp.G, k
+    errs.sort(reverse=True)
+    print(f"hidden {H} {kind}: largest gradient errors / tensor max (max, p99): " + ", ".join(f"{k} {e:.1e}/{q:.1e}" for e, k, q in errs[:4]))
+    if kind == "phonon":            # the same step in plain torch fp32 on the CPU: how far fp32 itself is from the fp64 oracle
+        _, g32 = O.train_step(kind, clone(params, torch.float32), {}, collate(cs_of(B, 11, torch.float32)), L, T, lr=1e-3, beta=1.0)
+        e32 = sorted(((float((g32[k].double() - gr.double()).abs().max() / (gr.abs().max() + 1e-6)), k)
+                      for k, gr in grads.items() if gr is not None), reverse=True)
+        print(f"            torch-CPU fp32 against the same fp64 oracle: " + ", ".join(f"{k} {e:.1e}" for e, k in e32[:4]))
+    # max: isolated activation-gate flips (a ReLU / PReLU input at fp32 resolution on one side of zero here, on the other in
+    # the oracle) move single rows - DESIGN.md §4; the 99th percentile bounds the typical error
+    #  (printed above for the phonon case: plain torch fp32 on the CPU shows maxima of the same size against the fp64 oracle)
+    assert errs[0][0] < 3e-2, errs[:3]
+    big = [t for t in errs if t[2] > 1e-3 and fp.G[t[1]].numel() > 100000]
+    assert not big, big                     # a large tensor whose TYPICAL error is large would be a kernel bug
+    assert sum(1 for t in errs if t[0] > 3e-3) <= 6, errs[:8]
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    outs = []
+    gd = g.to(DEV)
+    for replay in (False, True):
+        m2 = mk()
+        m2.load_state_dict(sd0)
+        m2 = m2.to(DEV)
+        t2 = Trainer(m2, lr=1e-3, beta=1.0, replay=replay)
+        from dostransformer_amd.batch import bucket_sizes, pad_batch
+        gp = pad_batch(collate(cs_of(B, 11, torch.float32)), *bucket_sizes(g.meta.num_nodes, g.meta.num_edges, 8, 128)).to(DEV)
+        for _ in range(3):
+            t2.step(gp)
+        torch.cuda.synchronize()
+        outs.append({k: v.detach().cpu().clone() for k, v in m2.state_dict().items()})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), ("eager vs replay", k)
+
+
+def test_graphnetwork_with_hidden_384_matches_the_oracle():
+    """The GNN-only variant (graphnetwork_phonon.py:48-72) at hidden 384: outputs and gradients against the oracle."""
+    from oracle import dos_oracle as O
+    from dostransformer_amd import synth
+    from dostransformer_amd.batch import collate
+    from dostransformer_amd.embedder_phDOS.graphnetwork_phonon import Graphnetwork_phonon
+    torch.manual_seed(0)
+    H, L, B = 384, 2, 4
+    model = Graphnetwork_phonon(L, 118, 4, H, 51, DEV)
+    params = {k: (v.detach().clone().double() if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    g64, g = collate(synth.phonon_crystals(B, 13, torch.float64)), collate(synth.phonon_crystals(B, 13, torch.float32)).to(DEV)
+    out = model(g)
+    p = {k: v.clone().requires_grad_(True) if v.is_floating_point() else v for k, v in params.items()}
+    ref = O.graphnetwork_phonon_forward(p, g64, L)
+    ref = ref[0] if isinstance(ref, tuple) else ref
+    assert float(torch.sqrt(((out.detach().cpu().double() - ref.detach()) ** 2).mean())) < 1e-4
+    w = torch.randn(ref.shape, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
+    (ref * w).sum().backward()
+    (out * w.float().to(DEV)).sum().backward()
+    for k, v in model.named_parameters():
+        rgd = p[k].grad
+        if rgd is None:
+            assert v.grad is None, k
+            continue
+        e = float((v.grad.cpu().double() - rgd).abs().max() / (rgd.abs().max() + 1e-6))
+        assert e < 3e-3, (k, e)

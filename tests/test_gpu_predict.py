@@ -5,6 +5,11 @@ import torch
 
 from tests.util import batch_from, load, sub
 
+import copy
+import ctypes as C
+import math
+import torch.nn.functional as F
+from tests.gpu_util import (DEV, TOL, _FakeDist, _Hog, _attn_ref, _descs, _fat_crystals, _fatten, _graph, _mixed_jobs, _node_block, _philox_mask_numpy, _phonon, _random_crystals, _reduce, _ref, _scratch, _sliver_case, err, ops, prelu, rnd)  # noqa: F401
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
@@ -105,3 +110,98 @@ def test_per_crystal_keys_is_refused_where_it_does_not_apply():
     model.train()
     with pytest.raises((DosxError, RuntimeError)):
         Predictor(model, per_crystal_keys=True)(g)
+
+
+def test_predictor_takes_fp64_batches():
+    from dostransformer_amd import synth
+    from dostransformer_amd.predict import Predictor
+    torch.manual_seed(0)
+    model = _phonon().to(DEV).eval()
+    pred = Predictor(model)
+    n_atoms = [4, 4, 9]
+    for k in range(4):
+        g64 = synth.phonon_batch(3, seed=80 + k, dtype=torch.float64, n_atoms=n_atoms).to(DEV)
+        g32 = synth.phonon_batch(3, seed=80 + k, dtype=torch.float32, n_atoms=n_atoms).to(DEV)
+        with torch.no_grad():
+            ref = [t.clone() for t in model(g32)]
+        out = pred(g64)
+        torch.cuda.synchronize()
+        for a, b in zip(ref, out):
+            assert torch.equal(a, b), k
+    assert len(pred._slots) == 1
+
+
+def test_predictor_cache_follows_field_assignment():
+    """the ghost-padded copy cached on the batch must not survive `g.x = ...` / `g['edge_vec'] = ...`."""
+    from dostransformer_amd import synth
+    from dostransformer_amd.predict import Predictor
+    torch.manual_seed(0)
+    model = _phonon().to(DEV).eval()
+    pred = Predictor(model)
+    g = synth.phonon_batch(3, seed=90, dtype=torch.float32).to(DEV)
+    a = [t.clone() for t in pred(g)]
+    g.x = g.x * 0.5
+    g["edge_vec"] = g.edge_vec * 0.9
+    b = [t.clone() for t in pred(g)]
+    with torch.no_grad():
+        ref = model(g)
+    assert not torch.equal(a[0], b[0])
+    for u, v in zip(ref, b):
+        assert torch.equal(u, v)
+    g.to(DEV)                       # nothing moves: the cached padded copy stays
+    assert getattr(g, "_dosx_padded", None) is not None
+
+
+def test_wide_hidden_through_predictor_dataset_and_edos_graphnetwork():
+    """hidden 384 on the surrounding paths: replayed inference (predict.Predictor) == the eager forward bit for bit,
+    Trainer.step_dataset (device collate straight into the bucket) == step(collate(...)) bit for bit, and the Electron-DOS
+    GNN-only variant (graphnetwork.py:26-43) against the oracle."""
+    from oracle import dos_oracle as O
+    from dostransformer_amd import synth
+    from dostransformer_amd.batch import collate
+    from dostransformer_amd.embedder_eDOS.graphnetwork import Graphnetwork
+    from dostransformer_amd.embedder_phDOS.DOSTransformer_phonon import DOSTransformer_phonon
+    from dostransformer_amd.loader import DeviceDataset
+    from dostransformer_amd.predict import Predictor
+    from dostransformer_amd.train import Trainer
+    torch.manual_seed(0)
+    H = 384
+    model = DOSTransformer_phonon(2, 1, 118, 4, H, DEV, 0.0).to(DEV)
+    cs = synth.phonon_crystals(6, 21, torch.float32)
+    g = collate(cs).to(DEV)
+    model.eval()
+    with torch.no_grad():
+        a = [t.clone() for t in model(g)]
+    pred = Predictor(model)
+    b1 = [t.clone() for t in pred(g)]
+    b2 = [t.clone() for t in pred(g)]                  # second call: the recorded program
+    for x, y, z in zip(a, b1, b2):
+        assert torch.equal(x, y) and torch.equal(x, z)
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    outs = []
+    ds = DeviceDataset(cs, DEV)
+    nmax = max(int(c["x"].shape[0]) for c in cs)
+    for mode in ("batch", "dataset"):
+        m2 = DOSTransformer_phonon(2, 1, 118, 4, H, DEV, 0.0)
+        m2.load_state_dict(sd0)
+        m2 = m2.to(DEV)
+        t2 = Trainer(m2, lr=1e-3, replay=True, bucket=(16, 256))
+        for _ in range(3):
+            if mode == "dataset":
+                t2.step_dataset(ds, list(range(6)), n_max=nmax)
+            else:
+                t2.step(ds.collate(list(range(6)), n_max=nmax))
+        torch.cuda.synchronize()
+        outs.append({k: v.detach().cpu().clone() for k, v in m2.state_dict().items()})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    # Electron-DOS GNN-only model
+    gm = Graphnetwork(2, 200, 41, 2, H, 201, DEV)
+    params = {k: v.detach().clone() for k, v in gm.state_dict().items()}
+    gm = gm.to(DEV)
+    ge = collate(synth.edos_crystals(3, 5, torch.float32))                 # (CrystalBatch.to moves in place: one per side)
+    out, xn = gm(collate(synth.edos_crystals(3, 5, torch.float32)).to(DEV))
+    with torch.no_grad():
+        ref, rx = O.graphnetwork_forward(params, ge, 2)
+    rmse = lambda u, v: float(torch.sqrt(((u.detach().cpu().double() - v.double()) ** 2).mean()))
+    assert rmse(out, ref) < 1e-4 and rmse(xn, rx) < 1e-4 * max(1.0, float(rx.abs().max()))
