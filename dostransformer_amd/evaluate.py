@@ -17,9 +17,16 @@ def r2(x1: torch.Tensor, x2: torch.Tensor) -> float:
     return float(1.0 - ((t - p) ** 2).sum() / ((t - t.mean()) ** 2).sum())
 
 
-def _pool_sum(x: torch.Tensor, batch: torch.Tensor, num_graphs: int) -> torch.Tensor:
-    out = torch.zeros(num_graphs, x.shape[1], dtype=x.dtype, device=x.device)
-    return out.index_add_(0, batch.long(), x)
+def _pool_sum(x: torch.Tensor, g, num_graphs: int) -> torch.Tensor:
+    """scatter_sum(x, batch) of `utils.py:96-99` (the per-crystal embedding the reference stores): dosx_graph_pool on the batch's
+    graph_ptr - the kernel the decoder's own sum-pooling uses (`DOSTransformer.py:151-161`)."""
+    from . import ops
+    from .batch import graph_meta
+    m = graph_meta(g, x.device)
+    xf = x.detach().to(torch.float32).contiguous()
+    out = torch.empty(num_graphs, xf.shape[1], dtype=torch.float32, device=x.device)
+    ops.graph_pool(xf, m.graph_ptr, out.data_ptr(), xf.shape[1], num_graphs, xf.shape[1])
+    return out.to(x.dtype)
 
 
 def test_phonon(model, data_loader: Iterable, criterion: Optional[Callable] = None, r2: Callable = r2, device=None):
@@ -67,7 +74,7 @@ def test(model, data_loader: Iterable, criterion: Optional[Callable] = None, r2:
             ids += list(batch.mp_id)
             preds.append(preds_system)
             ys.append(y)
-            embs.append(_pool_sum(embeddings, batch.batch, nb))
+            embs.append(_pool_sum(embeddings, batch, nb))
             n += 1
     preds_y = [[ids, torch.cat(preds).cpu().numpy(), torch.cat(ys).cpu().numpy(), torch.cat(embs).cpu().numpy()]]
     return float(rmse) / n, float(mse) / n, float(mae) / n, r2s / n, preds_y

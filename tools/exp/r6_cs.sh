@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O="$R/gpurun_out/r6_cs"
 mkdir -p "$O"
 cd "$R"
-timeout 900 python -m pytest tests/test_gpu_mlp_ln.py -x -q > "$O/pytest.log" 2>&1
+timeout 900 python -m pytest tests/test_gpu_graph.py -k "mlp_ln or column_split or node_side or dense_key" -x -q > "$O/pytest.log" 2>&1
 echo "pytest rc=$?" >> "$O/pytest.log"
 tail -5 "$O/pytest.log"
 export TMPDIR=/tmp

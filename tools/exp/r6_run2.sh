@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O="$R/gpurun_out/r6_run2"
 mkdir -p "$O"
 cd "$R"
-timeout 1200 python -m pytest tests/test_gpu_mlp_ln.py tests/test_gpu_step.py tests/test_gpu_models.py tests/test_gpu_round5.py -x -q > "$O/pytest.log" 2>&1
+timeout 1200 python -m pytest tests/test_gpu_graph.py -k "mlp_ln or column_split or node_side or dense_key" tests/test_gpu_step.py tests/test_gpu_models.py  -x -q > "$O/pytest.log" 2>&1
 echo "pytest rc=$?" >> "$O/pytest.log"
 tail -6 "$O/pytest.log"
 for i in 1 2 3; do

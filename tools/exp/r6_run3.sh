@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 O="$R/gpurun_out/r6_run3"
 mkdir -p "$O"
 cd "$R"
-timeout 600 python -m pytest tests/test_gpu_round5.py -x -q -k "residual_path" 2>&1 | tail -2
+timeout 600 python -m pytest tests/test_gpu_graph.py -x -q -k "residual_path" 2>&1 | tail -2
 run() {   # name, env...
   name=$1; shift
   env "$@" timeout 300 python bench.py --allow-env --no-secondary --no-cpu-baseline --steps 200 2> /dev/null | \
