@@ -178,6 +178,18 @@ class MlpLnBwd(C.Structure):
     ]
 
 
+class HeadsBwd(C.Structure):
+    _fields_ = [
+        ("S", C.c_int32), ("B", C.c_int32), ("H", C.c_int32),
+        ("dkvs", C.c_void_p), ("kvs", C.c_void_p), ("rstd", C.c_void_p),
+        ("ddosin", C.c_void_p), ("dosin", C.c_void_p),
+        ("slope", C.c_float),
+        ("dpre", C.c_void_p),
+        ("wg", C.c_void_p), ("ldwg", C.c_int32), ("ws", C.c_void_p), ("ldws", C.c_int32),
+        ("de1", C.c_void_p), ("ldde1", C.c_int32),
+    ]
+
+
 class EdgeMlp(C.Structure):
     _fields_ = [
         ("E", C.c_int32), ("H", C.c_int32),
@@ -321,6 +333,8 @@ _SIGS = {
     "dosx_mlp_ln_fwd": [C.POINTER(MlpLn), _P],
     "dosx_mlp_ln_bwd_partial_rows": [_I],
     "dosx_mlp_ln_bwd": [C.POINTER(MlpLnBwd), _P],
+    "dosx_heads_bwd_supported": [_I],
+    "dosx_heads_bwd": [C.POINTER(HeadsBwd), _P],
     "dosx_edge_mlp_supported": [_I],
     "dosx_edge_mlp_fwd": [C.POINTER(EdgeMlp), _P],
     "dosx_edge_mlp_bwd": [C.POINTER(EdgeMlpBwd), _P],

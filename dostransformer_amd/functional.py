@@ -427,6 +427,7 @@ _DENSE_CHAIN = __import__("os").environ.get("DOSX_DENSE_CHAIN", "1") == "1"
 # in front of it - that launch then does not start under a freshly launched weight-gradient group: 1.0726 -> 1.0690 ms per cfg2
 # step, three interleaved rounds (tools/exp/r6_run4.sh)
 _MID_HOOK_LATE = __import__("os").environ.get("DOSX_MID_HOOK_LATE", "1") == "1"
+_HEADS_BWD_ONE_LAUNCH = __import__("os").environ.get("DOSX_HEADS_BWD_ONE_LAUNCH", "1") == "1"
 _FLUSH_AFTER_CHAIN = __import__("os").environ.get("DOSX_FLUSH_AFTER_CHAIN", "0") == "1"
 
 
@@ -1451,7 +1452,15 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
         sink.flush_on_side()
     sink.join()          # dkvs is produced on the side stream
     dpre = _empty(dev, rows2, H)         # key-side LN backward + the LeakyReLU backward behind it, one launch
-    ops.rownorm_bwd_act(dkvs, kvs, rstd_s, ddosin, dosin, 0.01, dpre, rows2, H)
+    Wfc, Wfp = P["fc.weight"], P["fc_prompt.weight"]
+    # round 6: ... and the two heads' input-gradient products behind it in the SAME launch (csrc/heads.hip): three launch-bound
+    # kernels between two encoders' backward as one
+    heads_one = _HEADS_BWD_ONE_LAUNCH and ops.heads_bwd_supported(H) and ddosin.is_contiguous() and dkvs.is_contiguous()
+    dE1 = _empty(dev, S * B, H)
+    if heads_one:
+        ops.heads_bwd(S, B, H, dkvs, kvs, rstd_s, ddosin, dosin, 0.01, dpre, Wfc, Wfp, dE1)
+    else:
+        ops.rownorm_bwd_act(dkvs, kvs, rstd_s, ddosin, dosin, 0.01, dpre, rows2, H)
     map0, map1 = rowmap(d=B, m=2 * B, c=1, off=0), rowmap(d=B, m=2 * B, c=1, off=B)
     R = _empty(dev, 2 * B, H)            # sum over the energy axis of dpre (filled on the side stream below)
     # (forward factored; R is filled later, on the side stream: deferred jobs only - and not with the late-flush experiment,
@@ -1469,10 +1478,9 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
     else:
         _wgrad_linear(sink, G, "fc.weight", "fc.bias", S * B, H, seg(dpre, rmap=map0), a_g.segs, keep=(dpre,))
         _wgrad_linear(sink, G, "fc_prompt.weight", "fc_prompt.bias", S * B, H, seg(dpre, rmap=map1), a_s.segs, keep=(dpre,))
-    Wfc, Wfp = P["fc.weight"], P["fc_prompt.weight"]
-    dE1 = _empty(dev, S * B, H)
-    ops.gemm(S * B, H, [seg(dpre, rmap=map0)], Wfc[:, :H], dE1, w_layout=1)
-    ops.gemm(S * B, H, [seg(dpre, rmap=map1)], Wfp[:, :H], dE1, w_layout=1, res=dE1)
+    if not heads_one:
+        ops.gemm(S * B, H, [seg(dpre, rmap=map0)], Wfc[:, :H], dE1, w_layout=1)
+        ops.gemm(S * B, H, [seg(dpre, rmap=map1)], Wfp[:, :H], dE1, w_layout=1, res=dE1)
     if sink.wside is not None and late_flush and _LATE_SELF_FLUSH != "2":
         # experiment: the self encoder's weight gradients (+ the two heads') start behind the small head kernels above
         # instead of in front of them (where the group's long-lived workgroups make these 8-15 us kernels wait)

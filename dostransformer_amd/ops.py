@@ -1224,6 +1224,27 @@ def rownorm_bwd_act(dxhat, xhat, rstd, dx_in, y, slope, out, M, H):
           w=lambda: ("rownorm_bwd_act", "rownorm_bwd_act_kernel", "hbm", 20.0 * M * H))
 
 
+def heads_bwd_supported(H: int) -> bool:
+    return bool(_lib.load().dosx_heads_bwd_supported(int(H)))
+
+
+def heads_bwd(S: int, B: int, H: int, dkvs, kvs, rstd, ddosin, dosin, slope: float, dpre, wg, ws, de1) -> None:
+    """dpre = (ddosin + rownorm_bwd(dkvs, kvs, rstd)) * leaky'(dosin) [S*2B, H]; de1 = dpre[global rows] wg[:, :H] + dpre[system rows]
+    ws[:, :H] [S*B, H] - one launch (include/dosx.h: DosxHeadsBwd).  wg / ws: the heads' weights (or views of their first columns)."""
+    d = _lib.HeadsBwd()
+    d.S, d.B, d.H = int(S), int(B), int(H)
+    for t in (dkvs, kvs, ddosin, dosin, dpre):
+        assert t.is_contiguous() and t.shape == (S * 2 * B, H)
+    assert wg.stride(1) == 1 and ws.stride(1) == 1 and de1.stride(1) == 1
+    d.dkvs, d.kvs, d.rstd, d.ddosin, d.dosin = dkvs.data_ptr(), kvs.data_ptr(), rstd.data_ptr(), ddosin.data_ptr(), dosin.data_ptr()
+    d.slope = float(slope)
+    d.dpre = dpre.data_ptr()
+    d.wg, d.ldwg, d.ws, d.ldws = wg.data_ptr(), int(wg.stride(0)), ws.data_ptr(), int(ws.stride(0))
+    d.de1, d.ldde1 = de1.data_ptr(), int(de1.stride(0))
+    _call("dosx_heads_bwd", C.byref(d), _stream(),
+          w=lambda: (f"heads_bwd[H{H}]", f"heads_bwd_kernel<{H}>", "mfma", 2.0 * S * B * H * 2 * H))
+
+
 def mask_residual(a, mask, res, out, stats, M, H):
     """out = (res or 0) + a o (mask or 1), optionally with the LayerNorm statistics [M,2] of out (include/dosx.h)."""
     _call("dosx_mask_residual", _p(a), int(a.stride(0)), _p(mask), _p(res), int(res.stride(0)) if res is not None else 0,

@@ -599,6 +599,24 @@ int dosx_ffn_att_bwd_partial_rows(int Sq, int Bq);               /* workgroups =
 int dosx_ffn_att_aligned_rows(int Sq, int Bq);                   /* rows per workgroup (16 / 32) of a crystal-aligned launch, fwd and bwd */
 int dosx_ffn_bwd(const DosxFfnBwd* a, dosx_stream_t stream);
 
+/* The backward of the two output heads (DOSTransformer_phonon.py:93-109, DOSTransformer.py:67-83: `fc`, `fc_prompt`, F.leaky_relu)
+ * between the self encoder's and the first encoder's backward, in ONE launch (round 6; csrc/heads.hip):
+ *     dpre[(s, bq)] = ( ddosin + rownorm_bwd(dkvs, kvs, rstd) )[(s, bq)] * leaky_relu'(dosin[(s, bq)])       rows (s, bq) at s * 2B + bq
+ *     de1[(s, b)]   = dpre[(s, b)] . wg[:, :H] + dpre[(s, B + b)] . ws[:, :H]                                rows (s, b) at s * B + b
+ * wg = fc.weight [H, ldwg], ws = fc_prompt.weight [H, ldws] (nn.Linear layout: only their first H columns - the E1 inputs - are
+ * read).  What dosx_rownorm_bwd_act followed by two dosx_gemm calls (w_layout 1, row-mapped A) compute; hidden 64 / 128 / 256. */
+typedef struct DosxHeadsBwd {
+  int32_t S, B, H;
+  const float* dkvs; const float* kvs; const float* rstd;     /* [S*2B, H], [S*2B, H], [S*2B] */
+  const float* ddosin; const float* dosin;                    /* [S*2B, H] */
+  float slope;                                                /* leaky_relu negative slope (0.01) */
+  float* dpre;                                                /* [S*2B, H] OUT */
+  const float* wg; int32_t ldwg; const float* ws; int32_t ldws;
+  float* de1; int32_t ldde1;                                  /* [S*B, H] OUT */
+} DosxHeadsBwd;
+int dosx_heads_bwd_supported(int H);
+int dosx_heads_bwd(const DosxHeadsBwd* a, dosx_stream_t stream);
+
 /* Linear -> LayerNorm -> PReLU -> Linear (+ residual) in ONE launch for small row counts: the NodeModel MLP of a GNN layer
  * (DOSTransformer_phonon.py:200-212 `node_mlp_2(cat[x, agg])`, DOSTransformer.py:178-190).
  *     z    = [a0 | a1] . W1^T + b1                  [M,NH]     (a0: k0 columns, a1: K - k0 columns, plain row-major)

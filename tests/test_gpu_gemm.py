@@ -756,3 +756,32 @@ def test_the_two_encoders_backward_products_as_one_launch(Mn, Me, H):
     assert err(outs[0][0], ref_dz) < 1e-5 and abs(float(outs[0][1].sum()) - ref_al) < 1e-3 * max(1.0, abs(ref_al))
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("S,B,H", [(51, 64, 128), (51, 3, 64), (201, 5, 256), (7, 1, 128), (201, 64, 256)])
+def test_heads_backward_in_one_launch(S, B, H):
+    """dosx_heads_bwd (round 6, csrc/heads.hip): the key-side LayerNorm backward + LeakyReLU backward of the heads' outputs and the
+    two heads' input-gradient products (DOSTransformer_phonon.py:93-109 differentiated w.r.t. E1) as ONE launch, against the three
+    launches it replaces (dosx_rownorm_bwd_act, two dosx_gemm with row-mapped A, the second accumulating) and float64."""
+    o = ops()
+    from dostransformer_amd.ops import rowmap, seg
+    rows2 = S * 2 * B
+    dkvs, kvs, ddosin, dosin = rnd(rows2, H, seed=1), rnd(rows2, H, seed=2), rnd(rows2, H, seed=3), rnd(rows2, H, seed=4)
+    rstd = rnd(rows2, seed=5).abs() + 0.5
+    Wfc, Wfp = rnd(H, 2 * H, seed=6, scale=H ** -0.5), rnd(H, 2 * H + H // 2, seed=7, scale=H ** -0.5)
+    dpre0, dE0 = torch.full((rows2, H), float("nan"), device=DEV), torch.full((S * B, H), float("nan"), device=DEV)
+    o.rownorm_bwd_act(dkvs, kvs, rstd, ddosin, dosin, 0.01, dpre0, rows2, H)
+    map0, map1 = rowmap(d=B, m=2 * B, c=1, off=0), rowmap(d=B, m=2 * B, c=1, off=B)
+    o.gemm(S * B, H, [seg(dpre0, rmap=map0)], Wfc[:, :H], dE0, w_layout=1)
+    o.gemm(S * B, H, [seg(dpre0, rmap=map1)], Wfp[:, :H], dE0, w_layout=1, res=dE0)
+    dpre1, dE1 = torch.full((rows2, H), float("nan"), device=DEV), torch.full((S * B, H), float("nan"), device=DEV)
+    o.heads_bwd(S, B, H, dkvs, kvs, rstd, ddosin, dosin, 0.01, dpre1, Wfc, Wfp, dE1)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(dpre1).all()) and bool(torch.isfinite(dE1).all())
+    assert err(dpre1, dpre0) < 2e-6 and err(dE1, dE0) < 1e-5
+    # float64
+    g, xh = dkvs.double(), kvs.double()
+    t = ddosin.double() + rstd.double()[:, None] * (g - g.mean(1, keepdim=True) - xh * (g * xh).mean(1, keepdim=True))
+    dp = torch.where(dosin.double() > 0, t, 0.01 * t).reshape(S, 2 * B, H)
+    ref = (dp[:, :B] @ Wfc[:, :H].double() + dp[:, B:] @ Wfp[:, :H].double()).reshape(S * B, H)
+    assert err(dpre1, dp.reshape(rows2, H)) < 2e-5 and err(dE1, ref) < 2e-5
