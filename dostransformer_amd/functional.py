@@ -428,6 +428,7 @@ _DENSE_CHAIN = __import__("os").environ.get("DOSX_DENSE_CHAIN", "1") == "1"
 # step, three interleaved rounds (tools/exp/r6_run4.sh)
 _MID_HOOK_LATE = __import__("os").environ.get("DOSX_MID_HOOK_LATE", "1") == "1"
 _HEADS_BWD_ONE_LAUNCH = __import__("os").environ.get("DOSX_HEADS_BWD_ONE_LAUNCH", "1") == "1"
+_HEADS_BWD_MAX_H = int(__import__("os").environ.get("DOSX_HEADS_BWD_MAX_H", "128"))
 _FLUSH_AFTER_CHAIN = __import__("os").environ.get("DOSX_FLUSH_AFTER_CHAIN", "0") == "1"
 
 
@@ -1455,7 +1456,10 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
     Wfc, Wfp = P["fc.weight"], P["fc_prompt.weight"]
     # round 6: ... and the two heads' input-gradient products behind it in the SAME launch (csrc/heads.hip): three launch-bound
     # kernels between two encoders' backward as one
-    heads_one = _HEADS_BWD_ONE_LAUNCH and ops.heads_bwd_supported(H) and ddosin.is_contiguous() and dkvs.is_contiguous()
+    # (measured, tools/exp/r6_run5.sh, three interleaved rounds: cfg2 1.0672 -> 1.0576 ms; Electron-DOS hidden 256 6.971 -> 7.009 ms -
+    #  at 12864 rows x 512 k the 64-row-tile GEMMs re-use the weights better than 3216 16-row workgroups: hidden <= 128 only)
+    heads_one = (_HEADS_BWD_ONE_LAUNCH and H <= _HEADS_BWD_MAX_H and ops.heads_bwd_supported(H) and ddosin.is_contiguous()
+                 and dkvs.is_contiguous())
     dE1 = _empty(dev, S * B, H)
     if heads_one:
         ops.heads_bwd(S, B, H, dkvs, kvs, rstd_s, ddosin, dosin, 0.01, dpre, Wfc, Wfp, dE1)
