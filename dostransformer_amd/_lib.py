@@ -178,6 +178,20 @@ class MlpLnBwd(C.Structure):
     ]
 
 
+class EncCs(C.Structure):
+    _fields_ = [
+        ("M", C.c_int32), ("Fa", C.c_int32), ("H", C.c_int32),
+        ("x", C.c_void_p), ("ldx", C.c_int32),
+        ("w0", C.c_void_p), ("ldw0", C.c_int32), ("b0", C.c_void_p),
+        ("alpha", C.c_void_p),
+        ("w2", C.c_void_p), ("b2", C.c_void_p),
+        ("z", C.c_void_p), ("out", C.c_void_p), ("ldo", C.c_int32),
+        ("w3", C.c_void_p), ("ldw3", C.c_int32), ("n3", C.c_int32), ("nb3", C.c_int32),
+        ("pq", C.c_void_p), ("ldpq", C.c_int32),
+        ("cs_cnt", C.c_void_p),
+    ]
+
+
 class HeadsBwd(C.Structure):
     _fields_ = [
         ("S", C.c_int32), ("B", C.c_int32), ("H", C.c_int32),
@@ -321,6 +335,7 @@ _SIGS = {
     "dosx_ffn_att_supported": [_I, _I],
     "dosx_ffn_att_aligned_supported": [_I, _I],
     "dosx_ffn_fwd": [C.POINTER(Ffn), _P],
+    "dosx_ffn_fwd_multi": [C.POINTER(Ffn), _I, _P],
     "dosx_ffn_bwd_partial_rows": [_I],
     "dosx_ffn_att_bwd_supported": [_I, _I, _I, _I],
     "dosx_ffn_att_bwd_partial_rows": [_I, _I],
@@ -333,6 +348,8 @@ _SIGS = {
     "dosx_mlp_ln_fwd": [C.POINTER(MlpLn), _P],
     "dosx_mlp_ln_bwd_partial_rows": [_I],
     "dosx_mlp_ln_bwd": [C.POINTER(MlpLnBwd), _P],
+    "dosx_enc_cs_supported": [_I, _I],
+    "dosx_enc_cs_fwd": [C.POINTER(EncCs), _P],
     "dosx_heads_bwd_supported": [_I],
     "dosx_heads_bwd": [C.POINTER(HeadsBwd), _P],
     "dosx_edge_mlp_supported": [_I],

@@ -373,9 +373,7 @@ __device__ __forceinline__ void ffn_att_tile(const DosxFfn& a, float* __restrict
 // self attention and the 32-row launches, where the per-row global key fetch of ATT = 1 does not pay, take this form while the
 // grid stays one round of workgroups.
 template <bool HALF, int KB, int ATT>
-__global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
-  DOSX_SET_MAIN_PRIO();
-  extern __shared__ __align__(16) float sm[];
+__device__ __forceinline__ void ffn_fwd_body(const DosxFfn& a, float* __restrict__ sm) {
   constexpr int FBK = KB, FLDW = KB + 4;           // chunk width, padded row of a staged weight chunk
   constexpr int R = HALF ? 16 : 32;                // rows per workgroup
   constexpr int ER = R / 8;                        // epilogue rows per wave
@@ -697,6 +695,37 @@ __global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
     }
   }
   FSTAMP(6);
+}
+
+template <bool HALF, int KB, int ATT>
+__global__ __launch_bounds__(512) void ffn_fwd_kernel(const DosxFfn a) {
+  DOSX_SET_MAIN_PRIO();
+  extern __shared__ __align__(16) float sm[];
+  ffn_fwd_body<HALF, KB, ATT>(a, sm);
+}
+
+// Round 6: the layers of ONE encoder stack in one launch.  Every transformer layer attends over the ORIGINAL keys
+// (layers/transformer.py:72-73), so with the attention half inside the feed-forward launch a layer is ROW-LOCAL per tile: the
+// rows a workgroup writes as layer t's output are exactly the rows it reads as layer t + 1's input (same tiles in every layer:
+// same Sq / Bq / tile height).  The workgroup therefore runs the layers back to back - its own stores drained (vmcnt(0)) and a
+// workgroup barrier in between; the rows were never read before in this launch, so no stale line can sit in the CU's L1 - and the
+// stack costs one launch instead of T.  All layers of a call share the template instance, grid and LDS size.
+// (two layers per launch - the reference's default depth, `--transformer 2`; deeper stacks go pair by pair.  The two bodies are two
+//  inlined copies with compile-time descriptor offsets: a loop over a descriptor array made the compiler hold the descriptor in
+//  vector registers - 256 VGPRs and scratch where the single-layer kernel needs 220.)
+constexpr int FFN_MULTI_MAX = 2;
+struct FfnMulti {
+  DosxFfn d[FFN_MULTI_MAX];
+  int n;
+};
+template <bool HALF, int KB, int ATT>
+__global__ __launch_bounds__(512) void ffn_fwd_multi_kernel(const FfnMulti A) {
+  DOSX_SET_MAIN_PRIO();
+  extern __shared__ __align__(16) float sm[];
+  ffn_fwd_body<HALF, KB, ATT>(A.d[0], sm);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  ffn_fwd_body<HALF, KB, ATT>(A.d[1], sm);
 }
 
 
@@ -1457,10 +1486,9 @@ extern "C" int dosx_ffn_att_aligned_supported(int H, int Nk) {
   return (size_t)((Nk + 15) & ~15) * (H + 4) + 32 * 68 <= 2 * (size_t)128 * (kb + 4);
 }
 
-extern "C" int dosx_ffn_fwd(const DosxFfn* ap, dosx_stream_t stream) {
-  DOSX_CHECK_ARG(ap != nullptr, "dosx_ffn_fwd: null descriptor");
-  const DosxFfn& a = *ap;
-  if (a.M <= 0) return 0;
+// validation + launch plan of one forward descriptor (shared by dosx_ffn_fwd and dosx_ffn_fwd_multi)
+struct FfnPlan { bool half; int kb, mode, grid; size_t smem; };
+static int ffn_fwd_prepare(const DosxFfn& a, FfnPlan& pl) {
   DOSX_CHECK_ARG(dosx_ffn_supported(a.H), "dosx_ffn_fwd: H=%d unsupported (multiple of 32, <= 128)", a.H);
   const bool att = a.att_kvhat != nullptr;
   DOSX_CHECK_ARG(a.x && (a.stats || att) && a.gamma && a.beta && a.w1 && a.b1 && a.w2 && a.b2 && a.h && (a.out || a.fin_dos), "dosx_ffn_fwd: null operand");
@@ -1479,33 +1507,90 @@ extern "C" int dosx_ffn_fwd(const DosxFfn* ap, dosx_stream_t stream) {
   static int half_max = -1;
   if (half_max < 0) { const char* e = getenv("DOSX_FFN_HALF_MAX"); half_max = e ? atoi(e) : 128; }
   const bool aligned = att && a.att_aligned != 0;        // crystal-aligned tiles (ATT = 2): grid = Bq x ceil(Sq / R)
-  const bool half = aligned ? ffn_bwd_att_rows(a.att_Sq, a.att_Bq) == 16 : ceil_div(a.M, 32) <= half_max;   // 16-row workgroups while the 32-row grid is one partial round
-  const int R = half ? 16 : 32;
-  const int kb = ffn_chunk(H);
-  const size_t smem = sizeof(float) * ((size_t)R * (H + 4) + (size_t)R * (H4 + 4) + 2 * (size_t)FBN * (kb + 4));
+  pl.half = aligned ? ffn_bwd_att_rows(a.att_Sq, a.att_Bq) == 16 : ceil_div(a.M, 32) <= half_max;   // 16-row workgroups while the 32-row grid is one partial round
+  const int R = pl.half ? 16 : 32;
+  pl.kb = ffn_chunk(H);
+  pl.mode = aligned ? 2 : (att ? 1 : 0);
+  pl.smem = sizeof(float) * ((size_t)R * (H + 4) + (size_t)R * (H4 + 4) + 2 * (size_t)FBN * (pl.kb + 4));
   if (aligned)
-    DOSX_CHECK_ARG(a.att_Nk <= 64 && ((size_t)((a.att_Nk + 15) & ~15) * (H + 4) + (size_t)R * 68) <= 2 * (size_t)FBN * (kb + 4),
+    DOSX_CHECK_ARG(a.att_Nk <= 64 && ((size_t)((a.att_Nk + 15) & ~15) * (H + 4) + (size_t)R * 68) <= 2 * (size_t)FBN * (pl.kb + 4),
                    "dosx_ffn_fwd: crystal-aligned attention needs <= 64 keys that fit the stage buffers (Nk=%d, H=%d)", a.att_Nk, H);
+  pl.grid = aligned ? a.att_Bq * ceil_div(a.att_Sq, R) : ceil_div(a.M, R);
   static bool attr_set = false;
   if (!attr_set) {
 #define DOSX_FFN_ATTR(HALF_, KB_, ATT_) \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fwd_kernel<HALF_, KB_, ATT_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+#define DOSX_FFN_ATTR2(HALF_, KB_, ATT_) \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_fwd_multi_kernel<HALF_, KB_, ATT_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
     DOSX_FFN_ATTR(false, 32, 0); DOSX_FFN_ATTR(true, 32, 0); DOSX_FFN_ATTR(false, 64, 0); DOSX_FFN_ATTR(true, 64, 0);
     DOSX_FFN_ATTR(false, 32, 1); DOSX_FFN_ATTR(true, 32, 1); DOSX_FFN_ATTR(false, 64, 1); DOSX_FFN_ATTR(true, 64, 1);
     DOSX_FFN_ATTR(false, 32, 2); DOSX_FFN_ATTR(true, 32, 2); DOSX_FFN_ATTR(false, 64, 2); DOSX_FFN_ATTR(true, 64, 2);
+    DOSX_FFN_ATTR2(false, 32, 1); DOSX_FFN_ATTR2(true, 32, 1); DOSX_FFN_ATTR2(false, 64, 1); DOSX_FFN_ATTR2(true, 64, 1);
+    DOSX_FFN_ATTR2(false, 32, 2); DOSX_FFN_ATTR2(true, 32, 2); DOSX_FFN_ATTR2(false, 64, 2); DOSX_FFN_ATTR2(true, 64, 2);
 #undef DOSX_FFN_ATTR
+#undef DOSX_FFN_ATTR2
     attr_set = true;
   }
-  const dim3 grid(aligned ? a.att_Bq * ceil_div(a.att_Sq, R) : ceil_div(a.M, R));
-#define DOSX_FFN_GO(HALF_, KB_) \
-  do { if (aligned) hipLaunchKernelGGL((ffn_fwd_kernel<HALF_, KB_, 2>), grid, dim3(512), smem, to_stream(stream), a); \
-       else if (att) hipLaunchKernelGGL((ffn_fwd_kernel<HALF_, KB_, 1>), grid, dim3(512), smem, to_stream(stream), a); \
-       else hipLaunchKernelGGL((ffn_fwd_kernel<HALF_, KB_, 0>), grid, dim3(512), smem, to_stream(stream), a); } while (0)
-  if (half && kb == 64) DOSX_FFN_GO(true, 64);
-  else if (half) DOSX_FFN_GO(true, 32);
-  else if (kb == 64) DOSX_FFN_GO(false, 64);
-  else DOSX_FFN_GO(false, 32);
-#undef DOSX_FFN_GO
+  return 0;
+}
+
+#define DOSX_FFN_DISPATCH(KERNEL, ARG)                                                                                    \
+  do {                                                                                                                     \
+    const dim3 grid_(pl.grid);                                                                                             \
+    hipStream_t st_ = to_stream(stream);                                                                                   \
+    if (pl.half && pl.kb == 64) { if (pl.mode == 2) hipLaunchKernelGGL((KERNEL<true, 64, 2>), grid_, dim3(512), pl.smem, st_, ARG); else if (pl.mode == 1) hipLaunchKernelGGL((KERNEL<true, 64, 1>), grid_, dim3(512), pl.smem, st_, ARG); else hipLaunchKernelGGL((KERNEL<true, 64, 0>), grid_, dim3(512), pl.smem, st_, ARG); } \
+    else if (pl.half) { if (pl.mode == 2) hipLaunchKernelGGL((KERNEL<true, 32, 2>), grid_, dim3(512), pl.smem, st_, ARG); else if (pl.mode == 1) hipLaunchKernelGGL((KERNEL<true, 32, 1>), grid_, dim3(512), pl.smem, st_, ARG); else hipLaunchKernelGGL((KERNEL<true, 32, 0>), grid_, dim3(512), pl.smem, st_, ARG); } \
+    else if (pl.kb == 64) { if (pl.mode == 2) hipLaunchKernelGGL((KERNEL<false, 64, 2>), grid_, dim3(512), pl.smem, st_, ARG); else if (pl.mode == 1) hipLaunchKernelGGL((KERNEL<false, 64, 1>), grid_, dim3(512), pl.smem, st_, ARG); else hipLaunchKernelGGL((KERNEL<false, 64, 0>), grid_, dim3(512), pl.smem, st_, ARG); } \
+    else { if (pl.mode == 2) hipLaunchKernelGGL((KERNEL<false, 32, 2>), grid_, dim3(512), pl.smem, st_, ARG); else if (pl.mode == 1) hipLaunchKernelGGL((KERNEL<false, 32, 1>), grid_, dim3(512), pl.smem, st_, ARG); else hipLaunchKernelGGL((KERNEL<false, 32, 0>), grid_, dim3(512), pl.smem, st_, ARG); } \
+  } while (0)
+
+extern "C" int dosx_ffn_fwd(const DosxFfn* ap, dosx_stream_t stream) {
+  DOSX_CHECK_ARG(ap != nullptr, "dosx_ffn_fwd: null descriptor");
+  const DosxFfn& a = *ap;
+  if (a.M <= 0) return 0;
+  FfnPlan pl;
+  if (int rc = ffn_fwd_prepare(a, pl)) return rc;
+  DOSX_FFN_DISPATCH(ffn_fwd_kernel, a);
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
+
+// The n <= 4 layers of ONE encoder stack in one launch (see ffn_fwd_multi_kernel): descs[l + 1] reads descs[l]'s output rows as its
+// input rows (dense: row (s, bq) at s * Bq + bq), every layer carries the attention half (att_* set), all share the launch plan.
+extern "C" int dosx_ffn_fwd_multi(const DosxFfn* descs, int n, dosx_stream_t stream) {
+  DOSX_CHECK_ARG(descs != nullptr && n >= 1 && n <= FFN_MULTI_MAX, "dosx_ffn_fwd_multi: 1 .. %d layers per launch", FFN_MULTI_MAX);
+  if (descs[0].M <= 0) return 0;
+  if (n == 1) return dosx_ffn_fwd(descs, stream);
+  FfnMulti A;
+  A.n = n;
+  FfnPlan pl;
+  for (int l = 0; l < n; ++l) {
+    FfnPlan p2;
+    if (int rc = ffn_fwd_prepare(descs[l], p2)) return rc;
+    if (l == 0) pl = p2;
+    DOSX_CHECK_ARG(p2.half == pl.half && p2.kb == pl.kb && p2.mode == pl.mode && p2.grid == pl.grid && p2.smem == pl.smem && descs[l].M == descs[0].M,
+                   "dosx_ffn_fwd_multi: layer %d has another launch plan than layer 0", l);
+    DOSX_CHECK_ARG(p2.mode != 0, "dosx_ffn_fwd_multi: every layer must carry its attention half (row-local layers only)");
+    if (l > 0) {
+      const DosxFfn& p = descs[l - 1];
+      const DosxFfn& c = descs[l];
+      DOSX_CHECK_ARG(p.out != nullptr && c.x == p.out && c.ldx == p.ldo && c.att_qs == c.att_Bq && c.att_qb == 1,
+                     "dosx_ffn_fwd_multi: layer %d must read layer %d's output rows (dense query rows)", l, l - 1);
+    }
+    A.d[l] = descs[l];
+  }
+  {
+    const dim3 grid_(pl.grid);
+    hipStream_t st_ = to_stream(stream);
+#define DOSX_FFN_GO2(HALF_, KB_) \
+    do { if (pl.mode == 2) hipLaunchKernelGGL((ffn_fwd_multi_kernel<HALF_, KB_, 2>), grid_, dim3(512), pl.smem, st_, A); \
+         else hipLaunchKernelGGL((ffn_fwd_multi_kernel<HALF_, KB_, 1>), grid_, dim3(512), pl.smem, st_, A); } while (0)
+    if (pl.half && pl.kb == 64) DOSX_FFN_GO2(true, 64);
+    else if (pl.half) DOSX_FFN_GO2(true, 32);
+    else if (pl.kb == 64) DOSX_FFN_GO2(false, 64);
+    else DOSX_FFN_GO2(false, 32);
+#undef DOSX_FFN_GO2
+  }
   DOSX_LAUNCH_CHECK();
   return 0;
 }

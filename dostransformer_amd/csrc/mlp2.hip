@@ -706,6 +706,135 @@ __global__ __launch_bounds__(256) void mlp_ln_cs_fwd_kernel(const DosxMlpLn a) {
   cs_exit(cnt, 3 * NS - 1);
 }
 
+// The node ENCODER (Linear(Fa, H) -> PReLU -> Linear(H, H): DOSTransformer_phonon.py:129,141) + the first message-passing
+// layer's node products pq = x0 . [Wa | Wb]^T, column-split like the NodeModel kernel above: three launch-bound N-row launches
+// (two dosx_gemm + dosx_gemm_pair) as one, two in-launch exchanges (z: the saved pre-activation; x0: the output - both are outputs
+// anyway and serve as the exchange media).  Fa is any width (phonon: 118 - rows of 472 bytes, so the first product's fragments are
+// 8-byte loads with the tail zeroed); the k range of the first product is Fa rounded up to 64, split over the 4 waves.
+template <int H, int KP>                            // KP: Fa rounded up to a multiple of 64
+__global__ __launch_bounds__(256) void enc_cs_fwd_kernel(const DosxEncCs a) {
+  DOSX_SET_MAIN_PRIO();
+  constexpr int NS = H / 16, KW1 = KP / 4, S1 = KW1 / 16, KW2 = H / 4, S2 = KW2 / 16 > 0 ? KW2 / 16 : 1;
+  constexpr int LDT = H + 4, LDR = 20, OG = H / 64, LDR3 = 68;
+  static_assert(KW2 >= 16, "hidden >= 64");
+  __shared__ __align__(16) float T[16 * LDT];
+  __shared__ __align__(16) float Rd[4 * 16 * LDR3];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+  const int row = tid >> 4, q = tid & 15;
+  const int tile = (int)blockIdx.x / NS, j = (int)blockIdx.x - tile * NS;
+  const int m0 = tile * 16, M = a.M, Fa = a.Fa;
+  int* cnt = a.cs_cnt + tile;
+  const int rowA = min(m0 + l15, M - 1), grow = m0 + row, rc = min(grow, M - 1);
+  const bool rvalid = grow < M;
+  // ---- first product's fragments: x rows and W0 rows, both [*, Fa] with 8-byte aligned rows; k beyond Fa reads as zero ----
+  float4 av[S1], bw0[S1];
+  {
+    const float* xp = a.x + (size_t)rowA * a.ldx;
+    const float* wp = a.w0 + (size_t)(16 * j + l15) * a.ldw0;
+#pragma unroll
+    for (int s = 0; s < S1; ++s) {
+      const int k = wave * KW1 + 16 * s + 4 * g4;
+      float2 x0 = make_float2(0.f, 0.f), x1 = x0, w0_ = x0, w1_ = x0;
+      if (k + 1 < Fa) { x0 = *reinterpret_cast<const float2*>(xp + k); w0_ = *reinterpret_cast<const float2*>(wp + k); }
+      else if (k < Fa) { x0.x = xp[k]; w0_.x = wp[k]; }
+      if (k + 3 < Fa) { x1 = *reinterpret_cast<const float2*>(xp + k + 2); w1_ = *reinterpret_cast<const float2*>(wp + k + 2); }
+      else if (k + 2 < Fa) { x1.x = xp[k + 2]; w1_.x = wp[k + 2]; }
+      av[s] = make_float4(x0.x, x0.y, x1.x, x1.y);
+      bw0[s] = make_float4(w0_.x, w0_.y, w1_.x, w1_.y);
+    }
+  }
+  const float b0v = a.b0[16 * j + q], b2v = a.b2[16 * j + q], alpha = *a.alpha;
+  float4 bw2[S2];
+  {
+    const float* w2p = a.w2 + (size_t)(16 * j + l15) * H + wave * KW2 + 4 * g4;
+#pragma unroll
+    for (int s = 0; s < S2; ++s) bw2[s] = ld4(w2p + 16 * s);
+  }
+  float4 bw3[4][S2];
+  {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int c = 64 * j + 16 * t + l15, b = c / a.n3, n = c - b * a.n3;
+      const float* wp = a.w3 + (size_t)n * a.ldw3 + b * H + wave * KW2 + 4 * g4;
+#pragma unroll
+      for (int s = 0; s < S2; ++s) bw3[t][s] = ld4(wp + 16 * s);
+    }
+  }
+  // ---- z slice (16 columns) ----
+  {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < S1; ++s) CS_MFMA4(acc, av[s], bw0[s]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Rd[(wave * 16 + 4 * g4 + r) * LDR + l15] = acc[r];
+  }
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t rZ = __builtin_amdgcn_make_buffer_rsrc((void*)a.z, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, 0x7fffffff, 0x00020000);
+  {
+    float z = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) z += Rd[(w * 16 + row) * LDR + q];
+    z += b0v;
+    if (rvalid) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, z), rZ, (uint32_t)(((size_t)grow * H + 16 * j + q) * 4), 0, 16);   // sc1
+  }
+  cs_publish_done_and_wait(cnt, NS);
+  // ---- PReLU(z tile) -> T ----
+#pragma unroll
+  for (int i = 0; i < OG; ++i) {
+    float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rZ, (uint32_t)(((size_t)rc * H + 4 * q + 64 * i) * 4), 0, 16));   // sc1
+    v.x = v.x >= 0.f ? v.x : alpha * v.x; v.y = v.y >= 0.f ? v.y : alpha * v.y;
+    v.z = v.z >= 0.f ? v.z : alpha * v.z; v.w = v.w >= 0.f ? v.w : alpha * v.w;
+    st4(T + row * LDT + 4 * q + 64 * i, v);
+  }
+  __syncthreads();
+  // ---- x0 slice (16 columns) ----
+  {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < S2; ++s) {
+      const float4 t4 = ld4(T + l15 * LDT + wave * KW2 + 16 * s + 4 * g4);
+      CS_MFMA4(acc, t4, bw2[s]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Rd[(wave * 16 + 4 * g4 + r) * LDR + l15] = acc[r];
+  }
+  __syncthreads();
+  {
+    float o = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) o += Rd[(w * 16 + row) * LDR + q];
+    o += b2v;
+    if (rvalid) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, o), rO, (uint32_t)(((size_t)grow * a.ldo + 16 * j + q) * 4), 0, 16);   // sc1
+  }
+  cs_publish_done_and_wait(cnt, 2 * NS);
+  // ---- pq: 64 columns of x0 . [Wa | Wb]^T ----
+  {
+#pragma unroll
+    for (int i = 0; i < OG; ++i)
+      st4(T + row * LDT + 4 * q + 64 * i,
+          __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rO, (uint32_t)(((size_t)rc * a.ldo + 4 * q + 64 * i) * 4), 0, 16)));   // sc1
+    __syncthreads();
+    f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < S2; ++s) {
+      const float4 t4 = ld4(T + l15 * LDT + wave * KW2 + 16 * s + 4 * g4);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) CS_MFMA4(acc[t], t4, bw3[t][s]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Rd[(wave * 16 + 4 * g4 + r) * LDR3 + 16 * t + l15] = acc[t][r];
+    __syncthreads();
+    float4 p = f4zero();
+#pragma unroll
+    for (int w = 0; w < 4; ++w) p = f4add(p, ld4(Rd + (w * 16 + row) * LDR3 + 4 * q));
+    if (rvalid) st4(a.pq + (size_t)grow * a.ldpq + 64 * j + 4 * q, p);
+  }
+  cs_exit(cnt, 3 * NS - 1);
+}
+
 // Backward, column-split the same way: da slice (32 columns) -> exchange -> PReLU / LayerNorm backward of the whole tile by every
 // sibling (dz rows dealt over the siblings; column sums of this workgroup's 32 columns; dalpha by sibling 0) -> 32 columns of dcat.
 // PRE: what PRODUCES dy, in the same launch (DosxMlpLnBwd.pre) - the N-row kernel that used to run in front of this one:
@@ -1034,6 +1163,29 @@ extern "C" int dosx_mlp_ln_cs_supported(int K, int NH, int NO) {
 }
 extern "C" int dosx_mlp_ln_cs_tiles(int M) { return M <= 0 ? 0 : ceil_div(M, MR); }
 extern "C" int64_t dosx_mlp_ln_cs_scratch_floats(int M, int NH) { return M <= 0 ? 0 : (int64_t)ceil_div(M, MR) * MR * NH; }
+
+extern "C" int dosx_enc_cs_supported(int Fa, int H) { return (H == 64 || H == 128) && Fa >= 2 && Fa <= 256 && (Fa & 1) == 0; }
+
+extern "C" int dosx_enc_cs_fwd(const DosxEncCs* ap, dosx_stream_t stream) {
+  DOSX_CHECK_ARG(ap != nullptr, "dosx_enc_cs_fwd: null descriptor");
+  const DosxEncCs& a = *ap;
+  if (a.M <= 0) return 0;
+  DOSX_CHECK_ARG(dosx_enc_cs_supported(a.Fa, a.H), "dosx_enc_cs_fwd: Fa=%d H=%d unsupported (even Fa <= 256, hidden 64 / 128)", a.Fa, a.H);
+  DOSX_CHECK_ARG(a.x && a.w0 && a.b0 && a.alpha && a.w2 && a.b2 && a.z && a.out && a.w3 && a.pq && a.cs_cnt, "dosx_enc_cs_fwd: null operand");
+  DOSX_CHECK_ARG((a.ldx & 1) == 0 && (a.ldw0 & 1) == 0 && (reinterpret_cast<uintptr_t>(a.x) & 7) == 0 && (reinterpret_cast<uintptr_t>(a.w0) & 7) == 0 &&
+                     aligned16(a.w2) && aligned16(a.w3) && aligned16(a.z) && aligned16(a.out) && aligned16(a.pq) && (a.ldo & 3) == 0 && a.ldo >= a.H &&
+                     (a.ldw3 & 3) == 0 && (a.ldpq & 3) == 0 && a.nb3 * a.n3 == 4 * a.H && a.ldw3 >= a.nb3 * a.H,
+                 "dosx_enc_cs_fwd: x / w0 rows 8-byte aligned (even leading dimensions), the rest 16-byte aligned; nb3 * n3 == 4 * H");
+  const dim3 grid(ceil_div(a.M, MR) * (a.H / 16));
+  hipStream_t st = to_stream(stream);
+  const int kp = (a.Fa + 63) / 64 * 64;
+#define DOSX_ENC(HH, KK) hipLaunchKernelGGL((enc_cs_fwd_kernel<HH, KK>), grid, dim3(256), 0, st, a)
+  if (a.H == 64) { if (kp == 64) DOSX_ENC(64, 64); else if (kp == 128) DOSX_ENC(64, 128); else if (kp == 192) DOSX_ENC(64, 192); else DOSX_ENC(64, 256); }
+  else { if (kp == 64) DOSX_ENC(128, 64); else if (kp == 128) DOSX_ENC(128, 128); else if (kp == 192) DOSX_ENC(128, 192); else DOSX_ENC(128, 256); }
+#undef DOSX_ENC
+  DOSX_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int dosx_mlp_ln_fwd(const DosxMlpLn* ap, dosx_stream_t stream) {
   DOSX_CHECK_ARG(ap != nullptr, "dosx_mlp_ln_fwd: null descriptor");

@@ -427,6 +427,14 @@ _DENSE_CHAIN = __import__("os").environ.get("DOSX_DENSE_CHAIN", "1") == "1"
 # in front of it - that launch then does not start under a freshly launched weight-gradient group: 1.0726 -> 1.0690 ms per cfg2
 # step, three interleaved rounds (tools/exp/r6_run4.sh)
 _MID_HOOK_LATE = __import__("os").environ.get("DOSX_MID_HOOK_LATE", "1") == "1"
+_FFN_MULTI = __import__("os").environ.get("DOSX_FFN_MULTI", "1") == "1"   # an encoder stack's layers in one forward launch
+_ENC_CS = __import__("os").environ.get("DOSX_ENC_CS", "1") == "1"        # node encoder + layer 0's node products: one column-split launch
+
+
+def dev_of(P: Params):
+    return next(iter(P.values())).device
+
+
 _HEADS_BWD_ONE_LAUNCH = __import__("os").environ.get("DOSX_HEADS_BWD_ONE_LAUNCH", "1") == "1"
 _HEADS_BWD_MAX_H = int(__import__("os").environ.get("DOSX_HEADS_BWD_MAX_H", "128"))
 _FLUSH_AFTER_CHAIN = __import__("os").environ.get("DOSX_FLUSH_AFTER_CHAIN", "0") == "1"
@@ -492,12 +500,13 @@ def edge_mlp_bwd_one_launch(P: Params, G: Params, key: str, ctx, dagg: torch.Ten
 # ------------------------------------------------------------------------------------------------
 # Message passing stack       (DOSTransformer_phonon.py:81-84,148-171 / DOSTransformer.py:56-59)
 # ------------------------------------------------------------------------------------------------
-def gnn_fwd(P: Params, m: GraphMeta, x: torch.Tensor, e: torch.Tensor, L: int, mean: bool, H: int):
+def gnn_fwd(P: Params, m: GraphMeta, x: torch.Tensor, e: torch.Tensor, L: int, mean: bool, H: int, pq0=None):
+    """pq0: layer 0's node products [N, 4H] when the node encoder's launch already multiplied them (ops.enc_cs_fwd)."""
     N, E = m.num_nodes, m.num_edges
     dev = x.device
     scale = m.inv_deg if mean else None
     ctxs = []
-    pq_ready = None
+    pq_ready = pq0
     for l in range(L):
         pre = f"stacked_processor.{l}"
         a_e = SegList([seg(x, rmap=rowmap(idx=m.src)), seg(x, rmap=rowmap(idx=m.dst)), seg(e)], [x, e])
@@ -689,6 +698,7 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
     if fdrop is not None and not (fdrop[0] > 0.0 or fdrop[1] > 0.0):
         fdrop = None
     assert fdrop is None or head is None
+    stack = [] if _FFN_MULTI else None      # round 6: the stack's layers in one launch when every layer is row-local (see below)
     for t in range(T):
         lp = f"{pre}.layers.{t}"
         g0, b0 = P[lp + ".layer_norms.0.weight"], P[lp + ".layer_norms.0.bias"]
@@ -759,6 +769,9 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
                 att_fused = att_aligned = True
         xln = None
         if not att_fused:
+            if stack:                       # (this layer launches its attention on its own: what is pending goes first)
+                ops.ffn_fwd_multi(stack)
+                stack.clear()
             if _LN1_IN_ATTN and not ops.ffn_supported(H) and Nk <= 320:
                 # unfused feed-forward half (hidden > 128): the attention kernel also writes LN1 of its output rows - they are
                 # in its registers with their statistics - and fc1 reads a plain operand instead of normalising its A tile in the
@@ -788,7 +801,7 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
                                 qstats=qstats, x1=x1, st1=st1, mask=mask, aligned=att_aligned, key_ptr=key_ptr)
             ops.ffn_fwd(rows, H, x if att_fused else x1, None if att_fused else st1, P[lp + ".layer_norms.1.weight"],
                         P[lp + ".layer_norms.1.bias"], P[lp + ".fc1.weight"], P[lp + ".fc1.bias"], P[lp + ".fc2.weight"],
-                        P[lp + ".fc2.bias"], h, x2, fin=fin_args, att=att_args)
+                        P[lp + ".fc2.bias"], h, x2, fin=fin_args, att=att_args, defer=stack if att_fused else None)
         else:
             def ffn_rows(r0, r1, x1=x1, st1=st1, h=h, x2=x2, lp=lp, xln=xln):
                 if xln is not None:
@@ -807,6 +820,10 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
                 ffn_rows(0, rows)
         lay.append((x, qs, qb, x1, probs, qstats, st1, h, mask, None))
         x, qs, qb = x2, Bq, 1
+    if stack:
+        # every transformer layer attends over the ORIGINAL keys (transformer.py:72-73): with the attention half inside the launch a
+        # layer is row-local per tile, so the stack's layers run back to back in ONE launch (dosx_ffn_fwd_multi, two per launch)
+        ops.ffn_fwd_multi(stack)
     fin = None
     if final_ln and fin_fused is not None:
         fin = fin_fused                  # x already is the normalised output
@@ -1247,7 +1264,16 @@ def gnn_trunk_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta, node_key: str = "GN
 def _gnn_trunk_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta, node_key: str):
     H, N, E, B = cfg.H, m.num_nodes, m.num_edges, m.num_graphs
     xin = _f32(g.x)
-    x0, cn = mlp_prelu_fwd(P, node_key, SegList([seg(xin)], [xin]), N, H)
+    pq0 = None
+    if (_ENC_CS and cfg.L >= 1 and m.seg_tile is not None and _factor_edge(E, H, m) and xin.shape[1] == P[node_key + ".0.weight"].shape[1]
+            and ops.enc_cs_supported(N, xin.shape[1], H)):
+        # round 6: Linear -> PReLU -> Linear of the node encoder AND layer 0's node products in one column-split launch
+        z0, x0, pq0 = _empty(dev_of(P), N, H), _empty(dev_of(P), N, H), _empty(dev_of(P), N, 4 * H)
+        ops.enc_cs_fwd(N, xin, P[node_key + ".0.weight"], P[node_key + ".0.bias"], P[node_key + ".1.weight"], P[node_key + ".2.weight"],
+                       P[node_key + ".2.bias"], z0, x0, P["stacked_processor.0.edge_model.edge_mlp.0.weight"], pq0)
+        cn = (SegList([seg(xin)], [xin]), z0, N, H)
+    else:
+        x0, cn = mlp_prelu_fwd(P, node_key, SegList([seg(xin)], [xin]), N, H)
     if cfg.kind == "phonon" and P["GN_encoder.edge_encoder.0.weight"].shape[1] == 4:
         # SH(l<=1) * cutoff features (r_max = 4, DOSTransformer_phonon.py:77) and the K = 4 Linear on them in one launch
         vec = _f32(g.edge_vec)
@@ -1263,7 +1289,7 @@ def _gnn_trunk_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta, node_key: str):
         glob = _f32(g.glob).reshape(B, 2)
         u, cu = mlp_prelu_fwd(P, "GN_encoder.global_encoder", SegList([seg(glob)], [glob]), B, H)
 
-    xL, cg = gnn_fwd(P, m, x0, e0, cfg.L, cfg.mean, H)
+    xL, cg = gnn_fwd(P, m, x0, e0, cfg.L, cfg.mean, H, pq0=pq0)
     return xL, u, (cn, ce, cu, cg, node_key)
 
 

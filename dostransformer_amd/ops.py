@@ -410,7 +410,7 @@ def ffn_att_aligned_supported(H: int, Nk: int) -> bool:
 
 
 def ffn_fwd(M: int, H: int, x: torch.Tensor, stats: Optional[torch.Tensor], gamma, beta, w1, b1, w2, b2, h: torch.Tensor,
-            out: torch.Tensor, fin=None, att=None) -> None:
+            out: torch.Tensor, fin=None, att=None, defer: Optional[list] = None) -> None:
     """out = x + fc2(relu(fc1(LN1(x)))), h = relu(fc1(LN1(x))) in one launch (include/dosx.h: DosxFfn).
     ``fin = (gamma, beta, xhat, rstd)``: also apply the encoder's final LayerNorm (out = LN(...), xhat / rstd saved);
     ``fin = (gamma, beta, xhat, rstd, w, b, dos, S, Bq)``: ... and the H -> 1 output layer behind it (``out`` may be None)."""
@@ -441,8 +441,29 @@ def ffn_fwd(M: int, H: int, x: torch.Tensor, stats: Optional[torch.Tensor], gamm
         a.fin_gamma, a.fin_beta, a.fin_xhat, a.fin_rstd = (t.data_ptr() for t in fin[:4])
         if len(fin) > 4:          # (.., w, b, dos [Bq,S], S, Bq): the model head's H -> 1 output layer on the normalised rows
             a.fin_w, a.fin_b, a.fin_dos, a.fin_S, a.fin_Bq = fin[4].data_ptr(), fin[5].data_ptr(), fin[6].data_ptr(), int(fin[7]), int(fin[8])
+    if defer is not None:            # (encoder_fwd: the layers of a stack go out together, ffn_fwd_multi)
+        defer.append((a, 16.0 * M * H * H + 4.0 * M * nk_att * H))
+        return
     _call("dosx_ffn_fwd", C.byref(a), _stream(),
           w=lambda: (f"ffn_fwd[H{H}{',att' if nk_att else ''}]", "ffn_fwd_kernel", "mfma", 16.0 * M * H * H + 4.0 * M * nk_att * H))
+
+
+FFN_MULTI_MAX = 2          # layers per dosx_ffn_fwd_multi launch (csrc/ffn.hip)
+
+
+def ffn_fwd_multi(deferred: list) -> None:
+    """The deferred layers of ONE encoder stack (ffn_fwd(..., defer=list)), FFN_MULTI_MAX per launch (include/dosx.h:
+    dosx_ffn_fwd_multi): every layer carries its attention half and reads the previous one's output rows."""
+    for i in range(0, len(deferred), FFN_MULTI_MAX):
+        grp = deferred[i:i + FFN_MULTI_MAX]
+        arr = (Ffn * len(grp))(*[d for d, _ in grp])
+        work = sum(w for _, w in grp)
+        H = grp[0][0].H
+        if len(grp) == 1:
+            _call("dosx_ffn_fwd", C.byref(arr[0]), _stream(), w=lambda H=H, work=work: (f"ffn_fwd[H{H},att]", "ffn_fwd_kernel", "mfma", work))
+        else:
+            _call("dosx_ffn_fwd_multi", arr, len(grp), _stream(),
+                  w=lambda H=H, work=work, n=len(grp): (f"ffn_fwd[H{H},att,x{n}]", "ffn_fwd_multi_kernel", "mfma", work))
 
 
 def ffn_bwd_partial_rows(M: int) -> int:
@@ -1222,6 +1243,29 @@ def rownorm_bwd_act(dxhat, xhat, rstd, dx_in, y, slope, out, M, H):
     """out = (dx_in + rownorm_bwd(dxhat, xhat, rstd)) * (y > 0 ? 1 : slope)   (include/dosx.h: dosx_rownorm_bwd_act)."""
     _call("dosx_rownorm_bwd_act", _p(dxhat), _p(xhat), _p(rstd), _p(dx_in), _p(y), float(slope), _p(out), M, H, _stream(),
           w=lambda: ("rownorm_bwd_act", "rownorm_bwd_act_kernel", "hbm", 20.0 * M * H))
+
+
+def enc_cs_supported(M: int, Fa: int, H: int) -> bool:
+    """Whether the node encoder + first node products run as ONE column-split launch (include/dosx.h: DosxEncCs)."""
+    return bool(MLP_LN_CS and M > 0 and _lib.load().dosx_enc_cs_supported(int(Fa), int(H))
+                and ((int(M) + 15) // 16) * (int(H) // 16) <= MLP_LN_CS_MAX_WGS)
+
+
+def enc_cs_fwd(M: int, x, w0, b0, alpha, w2, b2, z, out, w3, pq) -> None:
+    """z = x w0^T + b0; out = prelu(z) w2^T + b2; pq = out [w3[:, :H] | w3[:, H:2H]]^T - one launch (DosxEncCs)."""
+    d = _lib.EncCs()
+    H, Fa = int(w2.shape[0]), int(x.shape[1])
+    assert x.stride(1) == 1 and w0.stride(1) == 1 and w2.is_contiguous() and z.is_contiguous() and out.stride(1) == 1 and w3.stride(1) == 1
+    d.M, d.Fa, d.H = int(M), Fa, H
+    d.x, d.ldx = x.data_ptr(), int(x.stride(0))
+    d.w0, d.ldw0, d.b0, d.alpha = w0.data_ptr(), int(w0.stride(0)), b0.data_ptr(), alpha.data_ptr()
+    d.w2, d.b2 = w2.data_ptr(), b2.data_ptr()
+    d.z, d.out, d.ldo = z.data_ptr(), out.data_ptr(), int(out.stride(0))
+    d.w3, d.ldw3, d.n3, d.nb3 = w3.data_ptr(), int(w3.stride(0)), int(w3.shape[0]), 2
+    d.pq, d.ldpq = pq.data_ptr(), int(pq.stride(0))
+    d.cs_cnt = COUNTERS.take(out.device, _lib.load().dosx_mlp_ln_cs_tiles(int(M)))
+    _call("dosx_enc_cs_fwd", C.byref(d), _stream(),
+          w=lambda: (f"enc_cs_fwd[Fa{Fa},H{H}]", "enc_cs_fwd_kernel", "mfma", 2.0 * _real(M) * H * (Fa + H + 4 * H)))
 
 
 def heads_bwd_supported(H: int) -> bool:

@@ -544,6 +544,11 @@ int dosx_ffn_supported(int H);
 int dosx_ffn_att_supported(int H, int Nk);   /* whether dosx_ffn_fwd takes the att_* fields for this shape (H, Nk <= 16) */
 int dosx_ffn_att_aligned_supported(int H, int Nk);   /* ... with att_aligned (Nk <= 64 and the key rows fit the stage buffers) */
 int dosx_ffn_fwd(const DosxFfn* a, dosx_stream_t stream);
+/* n <= 2 consecutive layers of ONE encoder stack (layers/transformer.py:70-79) in one launch (round 6): with the attention half inside the
+ * launch a layer is row-local per tile - every layer attends over the ORIGINAL keys (transformer.py:72-73) - so a workgroup runs the
+ * layers back to back on its own rows.  descs[l + 1].x must be descs[l].out (dense query rows), every descriptor carries att_*, all
+ * share one launch plan (same M, H, tile form); same outputs as n dosx_ffn_fwd calls, bitwise. */
+int dosx_ffn_fwd_multi(const DosxFfn* descs, int n, dosx_stream_t stream);
 
 /* Backward of the same half layer in one launch (what autograd derives from layers/transformer.py:141-148):
  *     dh = (dy . W2) o [h > 0]            [M,4H]  (written out: the fc1 weight gradient reads it)
@@ -657,6 +662,25 @@ int dosx_mlp_ln_cs_supported(int K, int NH, int NO);      /* whether the column-
 int dosx_mlp_ln_cs_tiles(int M);                          /* counters it needs (= 16-row tiles) */
 int64_t dosx_mlp_ln_cs_scratch_floats(int M, int NH);     /* floats of cs_buf */
 int dosx_mlp_ln_fwd(const DosxMlpLn* a, dosx_stream_t stream);
+
+/* The node ENCODER + the first message-passing layer's node products in ONE column-split launch (round 6; csrc/mlp2.hip):
+ *     z   = x . W0^T + b0            [M,H]  written (the saved pre-activation: the backward reads it)        x [M,Fa], W0 [H,Fa]
+ *     out = prelu(z) . W2^T + b2     [M,H]  (DOSTransformer_phonon.py:129,141: Linear -> PReLU -> Linear)
+ *     pq[r, b * n3 + n] = sum_k out[r, k] * w3[n * ldw3 + b * H + k]      b < nb3, nb3 * n3 == 4H (DosxMlpLn.w3)
+ * What two dosx_gemm calls and dosx_gemm_pair compute; hidden 64 / 128, even Fa <= 256; cs_cnt: dosx_mlp_ln_cs_tiles(M) counters. */
+typedef struct DosxEncCs {
+  int32_t M, Fa, H;
+  const float* x; int32_t ldx;
+  const float* w0; int32_t ldw0; const float* b0;
+  const float* alpha;
+  const float* w2; const float* b2;
+  float* z; float* out; int32_t ldo;
+  const float* w3; int32_t ldw3, n3, nb3;
+  float* pq; int32_t ldpq;
+  int32_t* cs_cnt;
+} DosxEncCs;
+int dosx_enc_cs_supported(int Fa, int H);
+int dosx_enc_cs_fwd(const DosxEncCs* a, dosx_stream_t stream);
 
 /* Backward of the same block in one launch:
  *     da = dy . W2 ; dy' = da o prelu'(xhat*gamma+beta) ; dz = LayerNorm_bwd(dy' o gamma)  [M,NH] (written: the W1 weight

@@ -440,3 +440,43 @@ def test_concurrent_feed_forward_tail_is_bitwise_in_every_launch_mode(mode):
     for (k, a), (_, c) in zip(m_e.state_dict().items(), m_r.state_dict().items()):
         if a.is_floating_point():
             assert torch.equal(a, c), k
+
+
+@pytest.mark.parametrize("Sq,Bq,Nk,Bk,H,T,bcast,final", [(51, 64, 12, 64, 128, 2, True, True), (51, 128, 51, 128, 128, 2, False, True),
+                                                         (51, 128, 12, 64, 128, 2, False, False), (51, 6, 9, 3, 64, 3, False, True),
+                                                         (51, 8, 51, 8, 64, 1, False, True)])
+def test_encoder_stack_layers_in_one_launch(Sq, Bq, Nk, Bk, H, T, bcast, final):
+    """dosx_ffn_fwd_multi (round 6): the layers of one encoder stack - each attending over the ORIGINAL keys, transformer.py:72-73,
+    so row-local per tile once the attention half is inside the launch - run back to back in ONE launch (two per launch): output,
+    every saved tensor of every layer (x1, P, statistics, h) and the final LayerNorm's xhat / rstd BITWISE the per-layer launches."""
+    from dostransformer_amd import functional as Fn
+    gen = torch.Generator().manual_seed(Sq + Bq + Nk + H)
+    P = {}
+    for t in range(T):
+        lp = f"e.layers.{t}"
+        for k, shp in ((".layer_norms.0.weight", (H,)), (".layer_norms.0.bias", (H,)), (".layer_norms.1.weight", (H,)), (".layer_norms.1.bias", (H,)),
+                       (".fc1.weight", (4 * H, H)), (".fc1.bias", (4 * H,)), (".fc2.weight", (H, 4 * H)), (".fc2.bias", (H,))):
+            v = torch.randn(*shp, generator=gen) * (0.1 if "bias" in k else (shp[-1] ** -0.5 if len(shp) == 2 else 1.0))
+            P[lp + k] = (1.0 + 0.1 * v if "layer_norms" in k and "weight" in k else v)
+    P["e.layer_norm.weight"], P["e.layer_norm.bias"] = 1 + 0.1 * torch.randn(H, generator=gen), 0.1 * torch.randn(H, generator=gen)
+    P = Fn.pack_params({k: v.to(DEV) for k, v in P.items()})
+    x = (torch.randn(Sq, H, generator=gen) if bcast else torch.randn(Sq * Bq, H, generator=gen)).to(DEV)
+    kvhat = torch.randn(Nk * Bk, H, generator=gen).to(DEV)
+    qs, qb = (1, 0) if bcast else (Bq, 1)
+    res = {}
+    saved = Fn._FFN_MULTI
+    try:
+        for multi in (False, True):
+            Fn._FFN_MULTI = multi
+            y, ctx = Fn.encoder_fwd(P, "e", x, Sq, Bq, qs, qb, kvhat, Nk, Bk, H, T, final_ln=final)
+            torch.cuda.synchronize()
+            res[multi] = (y, ctx)
+    finally:
+        Fn._FFN_MULTI = saved
+    (y0, c0), (y1, c1) = res[False], res[True]
+    assert bool(torch.isfinite(y1).all()) and torch.equal(y0, y1)
+    for l0, l1 in zip(c0[0], c1[0]):
+        for u, v in zip(l0[3:8], l1[3:8]):              # x1, probs, qstats, st1, h
+            assert torch.equal(u, v)
+    if final:
+        assert torch.equal(c0[1][0], c1[1][0]) and torch.equal(c0[1][1], c1[1][1])

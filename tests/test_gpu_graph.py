@@ -1278,3 +1278,36 @@ def test_dense_key_backward_inside_the_column_split_backward_launch(n, H, B):
         assert bool(torch.isfinite(a_).all()), name
         assert float((a_ - b_).abs().max()) <= 2e-6 * sc(b_), name          # (row sums over 16 instead of 64 lanes: rounding)
     assert float(got[0][n_real:].abs().max()) == 0.0 if n_ghost else True    # ghost nodes: zero gradient
+
+
+@pytest.mark.parametrize("M,Fa,H", [(450, 118, 128), (1, 118, 128), (37, 118, 64), (255, 200, 128), (1000, 64, 64), (16, 6, 128)])
+def test_node_encoder_and_first_node_products_in_one_column_split_launch(M, Fa, H):
+    """dosx_enc_cs_fwd (round 6): Linear(Fa, H) -> PReLU -> Linear(H, H) of the node encoder (DOSTransformer_phonon.py:129,141) and
+    layer 0's node products x0 [Wa | Wb]^T as ONE column-split launch with two in-launch exchanges, against the two dosx_gemm +
+    dosx_gemm_pair launches and float64; Fa = 118 (rows of 472 bytes: 8-byte fragment loads, zeroed tail); twice (same bits)."""
+    from dostransformer_amd import functional as Fn
+    o = ops()
+    x = rnd(M, Fa, seed=1)
+    P = {"k.0.weight": rnd(H, Fa, seed=2, scale=Fa ** -0.5), "k.0.bias": rnd(H, seed=3, scale=0.1), "k.1.weight": torch.tensor([0.25], device=DEV),
+         "k.2.weight": rnd(H, H, seed=4, scale=H ** -0.5), "k.2.bias": rnd(H, seed=5, scale=0.1)}
+    W1 = rnd(2 * H, 3 * H, seed=6, scale=(3 * H) ** -0.5)
+    assert o.enc_cs_supported(M, Fa, H)
+    y0, ctx0 = Fn.mlp_prelu_fwd(P, "k", Fn.SegList([o.seg(x)], [x]), M, H)
+    pq0 = torch.empty(M, 4 * H, device=DEV)
+    o.gemm_pair(dict(M=M, N=2 * H, segs=[o.seg(y0)], w=W1[:, :H], out=pq0[:, :2 * H]),
+                dict(M=M, N=2 * H, segs=[o.seg(y0)], w=W1[:, H:2 * H], out=pq0[:, 2 * H:]))
+    got = []
+    for _ in range(3):
+        z, y, pq = (torch.full((M, H), float("nan"), device=DEV), torch.full((M, H), float("nan"), device=DEV),
+                    torch.full((M, 4 * H), float("nan"), device=DEV))
+        o.enc_cs_fwd(M, x, P["k.0.weight"], P["k.0.bias"], P["k.1.weight"], P["k.2.weight"], P["k.2.bias"], z, y, W1, pq)
+        torch.cuda.synchronize()
+        got.append((z, y, pq))
+    z, y, pq = got[0]
+    assert all(torch.equal(u, v) for g_ in got[1:] for u, v in zip(g_, got[0]))
+    assert bool(torch.isfinite(z).all()) and bool(torch.isfinite(y).all()) and bool(torch.isfinite(pq).all())
+    assert err(z, ctx0[1]) < 5e-6 and err(y, y0) < 5e-6 and err(pq, pq0) < 1e-5
+    z64 = x.double() @ P["k.0.weight"].double().T + P["k.0.bias"].double()
+    y64 = torch.where(z64 >= 0, z64, 0.25 * z64) @ P["k.2.weight"].double().T + P["k.2.bias"].double()
+    pq64 = torch.cat([y64 @ W1[:, :H].double().T, y64 @ W1[:, H:2 * H].double().T], 1)
+    assert err(z, z64) < 2e-5 and err(y, y64) < 2e-5 and err(pq, pq64) < 2e-5
