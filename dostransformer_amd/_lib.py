@@ -192,6 +192,17 @@ class EncCs(C.Structure):
     ]
 
 
+class EdgeEnc(C.Structure):
+    _fields_ = [
+        ("E", C.c_int32), ("H", C.c_int32),
+        ("vec", C.c_void_p), ("inv_rmax", C.c_float),
+        ("w0", C.c_void_p), ("b0", C.c_void_p), ("alpha", C.c_void_p),
+        ("w2", C.c_void_p), ("b2", C.c_void_p),
+        ("attr", C.c_void_p), ("z", C.c_void_p),
+        ("out", C.c_void_p), ("ldo", C.c_int32),
+    ]
+
+
 class HeadsBwd(C.Structure):
     _fields_ = [
         ("S", C.c_int32), ("B", C.c_int32), ("H", C.c_int32),
@@ -350,6 +361,8 @@ _SIGS = {
     "dosx_mlp_ln_bwd": [C.POINTER(MlpLnBwd), _P],
     "dosx_enc_cs_supported": [_I, _I],
     "dosx_enc_cs_fwd": [C.POINTER(EncCs), _P],
+    "dosx_edge_enc_supported": [_I],
+    "dosx_edge_enc_fwd": [C.POINTER(EdgeEnc), _P],
     "dosx_heads_bwd_supported": [_I],
     "dosx_heads_bwd": [C.POINTER(HeadsBwd), _P],
     "dosx_edge_mlp_supported": [_I],

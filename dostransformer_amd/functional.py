@@ -427,6 +427,7 @@ _DENSE_CHAIN = __import__("os").environ.get("DOSX_DENSE_CHAIN", "1") == "1"
 # in front of it - that launch then does not start under a freshly launched weight-gradient group: 1.0726 -> 1.0690 ms per cfg2
 # step, three interleaved rounds (tools/exp/r6_run4.sh)
 _MID_HOOK_LATE = __import__("os").environ.get("DOSX_MID_HOOK_LATE", "1") == "1"
+_EDGE_ENC_ONE_LAUNCH = __import__("os").environ.get("DOSX_EDGE_ENC_ONE_LAUNCH", "1") == "1"
 _FFN_MULTI = __import__("os").environ.get("DOSX_FFN_MULTI", "1") == "1"   # an encoder stack's layers in one forward launch
 _ENC_CS = __import__("os").environ.get("DOSX_ENC_CS", "1") == "1"        # node encoder + layer 0's node products: one column-split launch
 
@@ -1279,8 +1280,14 @@ def _gnn_trunk_fwd(P: Params, cfg: ModelCfg, g, m: GraphMeta, node_key: str):
         vec = _f32(g.edge_vec)
         if m.edge_perm is not None:
             vec = vec[m.edge_perm]
-        ea, z0 = ops.edge_embed_sh1(vec, P["GN_encoder.edge_encoder.0.weight"], P["GN_encoder.edge_encoder.0.bias"], 4.0)
-        e0, ce = mlp_prelu_fwd(P, "GN_encoder.edge_encoder", SegList([seg(ea)], [ea]), E, H, z=z0)
+        ek = "GN_encoder.edge_encoder"
+        if _EDGE_ENC_ONE_LAUNCH and ops.edge_enc_supported(H):
+            # round 6: features, both Linear layers and the PReLU between them in ONE launch (csrc/heads.hip: edge_enc_fwd_kernel)
+            ea, z0, e0 = ops.edge_enc_fwd(vec, P[ek + ".0.weight"], P[ek + ".0.bias"], P[ek + ".1.weight"], P[ek + ".2.weight"], P[ek + ".2.bias"], 4.0)
+            ce = (SegList([seg(ea)], [ea]), z0, E, H)
+        else:
+            ea, z0 = ops.edge_embed_sh1(vec, P[ek + ".0.weight"], P[ek + ".0.bias"], 4.0)
+            e0, ce = mlp_prelu_fwd(P, ek, SegList([seg(ea)], [ea]), E, H, z=z0)
     else:
         ea = _edge_inputs(cfg, g, m)
         e0, ce = mlp_prelu_fwd(P, "GN_encoder.edge_encoder", SegList([seg(ea)], [ea]), E, H)

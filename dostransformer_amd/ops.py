@@ -1118,6 +1118,28 @@ def edge_embed_sh1(edge_vec: torch.Tensor, w0: torch.Tensor, b0: torch.Tensor, r
     return attr, z
 
 
+def edge_enc_supported(H: int) -> bool:
+    return bool(_lib.load().dosx_edge_enc_supported(int(H)))
+
+
+def edge_enc_fwd(edge_vec: torch.Tensor, w0, b0, alpha, w2, b2, r_max: float = 4.0):
+    """(attr [E,4], z [E,H], out [E,H]): SH * cutoff features, the K = 4 Linear, PReLU, the second Linear of the phonon edge
+    encoder in one launch (include/dosx.h: DosxEdgeEnc)."""
+    _chk_f32(edge_vec, w0, b0, w2, b2)
+    e, H = int(edge_vec.shape[0]), int(w2.shape[0])
+    assert w0.shape == (H, 4) and w0.is_contiguous() and w2.is_contiguous() and edge_vec.is_contiguous()
+    dev = edge_vec.device
+    attr, z, out = alloc(dev, e, 4), alloc(dev, e, H), alloc(dev, e, H)
+    d = _lib.EdgeEnc()
+    d.E, d.H = e, H
+    d.vec, d.inv_rmax = edge_vec.data_ptr(), 1.0 / float(r_max)
+    d.w0, d.b0, d.alpha, d.w2, d.b2 = w0.data_ptr(), b0.data_ptr(), alpha.data_ptr(), w2.data_ptr(), b2.data_ptr()
+    d.attr, d.z, d.out, d.ldo = attr.data_ptr(), z.data_ptr(), out.data_ptr(), H
+    _call("dosx_edge_enc_fwd", C.byref(d), _stream(),
+          w=lambda: (f"edge_enc_fwd[H{H}]", f"edge_enc_fwd_kernel<{H}>", "mfma", 2.0 * _real(e) * H * (H + 4)))
+    return attr, z, out
+
+
 def segment_reduce(msg, rowptr, scale, agg, e_in, e_out, N, E, H):
     # algorithmic bytes: messages + CSR row pointers + aggregated output (+ the fused edge residual e_out = e_in + msg:
     # one more read and one write of [E,H])

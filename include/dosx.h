@@ -604,6 +604,22 @@ int dosx_ffn_att_bwd_partial_rows(int Sq, int Bq);               /* workgroups =
 int dosx_ffn_att_aligned_rows(int Sq, int Bq);                   /* rows per workgroup (16 / 32) of a crystal-aligned launch, fwd and bwd */
 int dosx_ffn_bwd(const DosxFfnBwd* a, dosx_stream_t stream);
 
+/* The phonon EDGE ENCODER in one launch (round 6; csrc/heads.hip): attr = SH(l <= 1)(vec) * smooth_cutoff(|vec| / r_max)
+ * (DOSTransformer_phonon.py:74-77; [E,4]), z = attr . w0^T + b0 ([E,H]: the saved pre-activation), out = prelu(z) . w2^T + b2
+ * (GN_encoder.edge_encoder, :129,142).  What dosx_edge_embed_sh1 + dosx_gemm (PReLU prologue) compute; hidden 64 / 128. */
+typedef struct DosxEdgeEnc {
+  int32_t E, H;
+  const float* vec;                         /* [E,3] */
+  float inv_rmax;
+  const float* w0; const float* b0;         /* [H,4], [H] */
+  const float* alpha;
+  const float* w2; const float* b2;         /* [H,H], [H] */
+  float* attr; float* z;                    /* [E,4], [E,H] OUT */
+  float* out; int32_t ldo;                  /* [E,H] OUT */
+} DosxEdgeEnc;
+int dosx_edge_enc_supported(int H);
+int dosx_edge_enc_fwd(const DosxEdgeEnc* a, dosx_stream_t stream);
+
 /* The backward of the two output heads (DOSTransformer_phonon.py:93-109, DOSTransformer.py:67-83: `fc`, `fc_prompt`, F.leaky_relu)
  * between the self encoder's and the first encoder's backward, in ONE launch (round 6; csrc/heads.hip):
  *     dpre[(s, bq)] = ( ddosin + rownorm_bwd(dkvs, kvs, rstd) )[(s, bq)] * leaky_relu'(dosin[(s, bq)])       rows (s, bq) at s * 2B + bq

@@ -1311,3 +1311,25 @@ def test_node_encoder_and_first_node_products_in_one_column_split_launch(M, Fa, 
     y64 = torch.where(z64 >= 0, z64, 0.25 * z64) @ P["k.2.weight"].double().T + P["k.2.bias"].double()
     pq64 = torch.cat([y64 @ W1[:, :H].double().T, y64 @ W1[:, H:2 * H].double().T], 1)
     assert err(z, z64) < 2e-5 and err(y, y64) < 2e-5 and err(pq, pq64) < 2e-5
+
+
+@pytest.mark.parametrize("E,H", [(9000, 128), (1, 128), (37, 64), (1281, 64)])
+def test_phonon_edge_encoder_in_one_launch(E, H):
+    """dosx_edge_enc_fwd (round 6): SH(l <= 1) * smooth_cutoff features, the K = 4 Linear, PReLU and the second Linear of the phonon edge
+    encoder (DOSTransformer_phonon.py:74-77,129,142) as ONE launch == dosx_edge_embed_sh1 + dosx_gemm (PReLU prologue): the features
+    and the pre-activation bitwise (the same fma chains), the output to rounding; zero-length self edges and all cutoff regimes."""
+    from dostransformer_amd import functional as Fn
+    o = ops()
+    vec = rnd(E, 3, seed=1, scale=4.0 / 3 ** 0.5)
+    vec[::7] = 0.0                                      # self-interaction edges: zero vectors
+    P = {"k.0.weight": rnd(H, 4, seed=2, scale=0.5), "k.0.bias": rnd(H, seed=3, scale=0.1), "k.1.weight": torch.tensor([0.25], device=DEV),
+         "k.2.weight": rnd(H, H, seed=4, scale=H ** -0.5), "k.2.bias": rnd(H, seed=5, scale=0.1)}
+    ea0, z0 = o.edge_embed_sh1(vec, P["k.0.weight"], P["k.0.bias"], 4.0)
+    e0, _ = Fn.mlp_prelu_fwd(P, "k", Fn.SegList([o.seg(ea0)], [ea0]), E, H, z=z0)
+    ea1, z1, e1 = o.edge_enc_fwd(vec, P["k.0.weight"], P["k.0.bias"], P["k.1.weight"], P["k.2.weight"], P["k.2.bias"], 4.0)
+    torch.cuda.synchronize()
+    assert torch.equal(ea1, ea0) and torch.equal(z1, z0)
+    assert bool(torch.isfinite(e1).all()) and err(e1, e0) < 5e-6
+    z64 = z0.double()
+    ref = torch.where(z64 >= 0, z64, 0.25 * z64) @ P["k.2.weight"].double().T + P["k.2.bias"].double()
+    assert err(e1, ref) < 2e-5
