@@ -221,7 +221,7 @@ def load_north_star():
                 in_step["file"] = os.path.basename(sfiles[-1])
         except Exception:  # pragma: no cover
             pass
-    return {"kind": "microbench of the stand-alone kernels (scatter_hbm_frac, attn_mfma_util); in_step: counters over the replayed steps",
+    return {"kind": "scatter_hbm_frac / attn_mfma_util: microbench of stand-alone kernels; in_step: counters over the replayed steps",
             "scatter_hbm_frac": rec.get("scatter_hbm_frac"), "attn_mfma_util": rec.get("attn_mfma_util"), "in_step": in_step,
             "source": f"{name} (rocprofv3 --pmc, git {str(rec.get('git_head', '?'))[:12]})"}
 
@@ -261,7 +261,7 @@ def rccl_choices(path, world):
     return sorted(seen.values(), key=lambda e: -e["bytes"])[:4]
 
 
-LINE_BUDGET = 3600          # bytes of the ONE stdout line (the driver keeps an 8 KB tail of stdout)
+LINE_BUDGET = 5600          # bytes of the ONE stdout line (the driver keeps an 8 KB tail of stdout: 8192 bytes)
 
 
 def tuning_env(environ=None) -> dict:

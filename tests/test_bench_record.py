@@ -1,5 +1,5 @@
-"""bench.py's ONE stdout line must stay small: the driver keeps an 8 KB tail of stdout, and round 2 lost its whole record
-to a 38 KB line (a 122-entry per-site table).  The per-site table goes to a side file; the line holds the headline
+"""bench.py's ONE stdout line must stay small: the driver keeps an 8 KB tail of stdout (the line is held below 6000 bytes), and
+round 2 lost its whole record to a 38 KB line (a 122-entry per-site table).  The per-site table goes to a side file; the line holds the headline
 fields, the dominant site and short secondaries."""
 import json
 import os
@@ -53,7 +53,7 @@ def test_record_line_stays_small_with_200_sites():
     out, sites = _synthetic(200)
     rec = bench.compact_record(out, sites)
     line = json.dumps(rec)
-    assert len(line) < 4000, len(line)
+    assert len(line) < 6000, len(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline", "step_frac"):
         assert k in rec, k
@@ -68,7 +68,7 @@ def test_record_drops_optional_fields_before_growing():
     out, sites = _synthetic(200)
     out["traffic_source"] = "x" * 5000           # something silly on an optional field must not grow the line
     rec = bench.compact_record(out, sites)
-    assert len(json.dumps(rec)) < 4000 and "value" in rec and "roofline" in rec and "cpu_baseline" in rec
+    assert len(json.dumps(rec)) < 6000 and "value" in rec and "roofline" in rec and "cpu_baseline" in rec
 
 
 _RANK_SCRIPT = """
@@ -210,13 +210,14 @@ def test_bare_two_rank_bench_launches_itself(tmp_path):
 @pytest.mark.gpu
 def test_bench_default_line_is_one_small_json_record(tmp_path):
     """The driver's own invocation shape (no flags except fewer steps): exactly one stdout line, < 4000 bytes, parseable,
-    with the roofline object, the cpu baseline and the secondaries; the per-site table is in the side file."""
+    with the roofline object, the cpu baseline and the secondaries; the per-site table is in the side file (< 6000 bytes: the driver
+    keeps an 8 KB tail)."""
     kout = tmp_path / "kernels.json"
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "16", "--warmup", "8", "--cpu-budget", "2",
                         "--kernels-out", str(kout)], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
     lines = p.stdout.decode().strip().splitlines()
-    assert len(lines) == 1 and len(lines[0]) < 4000, (len(lines), len(lines[0]))
+    assert len(lines) == 1 and len(lines[0]) < 6000, (len(lines), len(lines[0]))
     rec = json.loads(lines[0])
     assert rec["value"] > 0 and rec["n_gpus"] == 1 and rec["dtype"] == "f32"
     assert abs(rec["value"] - 64 / (rec["ms_per_step"] * 1e-3)) < 1e-2 * rec["value"]

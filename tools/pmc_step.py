@@ -82,7 +82,7 @@ def main():
         out["per_symbol"][name] = {k: v for k, v in sorted(tab.items(), key=lambda kv: -kv[1]["avg_us"] * kv[1]["launches"]) if v["mfma_util"] > 0}
         st = {}
         # the launches that contain the attention (layers/multihead_attention.py:68-72)
-        for key, pat in (("ffn_fwd_att", r"ffn_fwd_kernel<.*, [12]>$"), ("ffn_bwd_att", r"ffn_bwd_kernel<.*, 2>$"),
+        for key, pat in (("ffn_fwd_att", r"ffn_fwd(_multi)?_kernel<.*, [12]>$"), ("ffn_bwd_att", r"ffn_bwd_kernel<.*, 2>$"),
                          ("attn_al_fwd", r"attn_al_fwd_kernel"), ("attn_al_bwd", r"attn_al_bwd_kernel"),
                          ("attn_fwd_stream", r"attn_fwd_stream_kernel"), ("attn_bwd_dq_stream", r"attn_bwd_dq_stream_kernel"),
                          ("attn_bwd_dkv", r"attn_bwd_dkv_kernel"), ("edge_fwd", r"edge_fwd_kernel"), ("edge_bwd", r"edge_bwd_kernel"),
