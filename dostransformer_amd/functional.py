@@ -425,8 +425,10 @@ _DENSE_CHAIN = __import__("os").environ.get("DOSX_DENSE_CHAIN", "1") == "1"
 # ... and the layer's weight-gradient group is then flushed BEHIND that launch (it runs alone, all CUs) instead of in front of it
 # the early gradient bucket's flush (transformers / heads: `mid_hook`) BEHIND the last layer's NodeModel backward launch instead of
 # in front of it - that launch then does not start under a freshly launched weight-gradient group: 1.0726 -> 1.0690 ms per cfg2
-# step, three interleaved rounds (tools/exp/r6_run4.sh)
+# step, three interleaved rounds (tools/exp/r6_run4.sh).  Hidden 256 (cfg3 / its T4 shard, tools/exp/r6_run9.sh): 6.968 -> 6.997
+# and 6.875 -> 6.912 ms - the NodeModel backward is a row-tile kernel there and the early group is 4x the work: hidden <= 128 only
 _MID_HOOK_LATE = __import__("os").environ.get("DOSX_MID_HOOK_LATE", "1") == "1"
+_MID_HOOK_LATE_MAX_H = 128
 _EDGE_ENC_ONE_LAUNCH = __import__("os").environ.get("DOSX_EDGE_ENC_ONE_LAUNCH", "1") == "1"
 _FFN_MULTI = __import__("os").environ.get("DOSX_FFN_MULTI", "1") == "1"   # an encoder stack's layers in one forward launch
 _ENC_CS = __import__("os").environ.get("DOSX_ENC_CS", "1") == "1"        # node encoder + layer 0's node products: one column-split launch
@@ -1551,7 +1553,7 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
     sink.on_side(lambda: ops.reduce_rows(dX1.data_ptr(), H, G["embeddings.weight"].data_ptr(), H, S, B, B, 1, H), (dX1,))
     late_hook = None
     if mid_hook is not None:          # (after the join: the early bucket's reduction must not sit between the main
-        if _MID_HOOK_LATE and dx_ext is None and cfg.L >= 1:
+        if _MID_HOOK_LATE and H <= _MID_HOOK_LATE_MAX_H and dx_ext is None and cfg.L >= 1:
             late_hook = mid_hook      # (experiment: behind the last layer's NodeModel backward launch, gnn_bwd)
         else:
             mid_hook(sink)            #  stream and the dk/dv kernels it is waiting for)
