@@ -855,6 +855,27 @@ def test_models_with_overfull_nodes_match_the_oracle(kind):
             assert float((a - b).abs().median()) < 1e-5, ("host table vs crystal-aligned table", k)
         else:
             assert torch.equal(a, b), k
+    # ... and tightly where the two tables can be told apart: the RAW gradients of one step.  Everything except the EdgeModel's
+    # LayerNorm / PReLU parameter gradients (one partial row per TILE: another grouping of the same sums) is bitwise equal; those
+    # three agree to fp32 rounding of their own scale - a dropped or doubled tile's partial row would be a 1e-2-level error
+    grads = []
+    for table in ("host", "crystal"):
+        m3 = mk()
+        m3.load_state_dict(sd0)
+        m3 = m3.to(DEV)
+        t3 = Trainer(m3, lr=1e-3, beta=1.0)
+        t3.forward_backward(collate(cs32, n_max=nmax).to(DEV) if table == "host" else dsd.collate(list(range(B)), n_max=nmax))
+        torch.cuda.synchronize()
+        fp3 = m3.flat_params()
+        grads.append({k: fp3.G[k].detach().cpu().clone() for k in fp3.names})
+    per_tile = lambda k: "edge_mlp.1." in k or k.endswith("edge_mlp.2.weight")
+    assert any(per_tile(k) for k in grads[0])
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        if per_tile(k):
+            assert float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-3), ("per-tile partial rows", k)
+        else:
+            assert torch.equal(a, b), ("host table vs crystal-aligned table, raw gradient", k)
 
 
 def test_shape_limits_are_explicit_errors():

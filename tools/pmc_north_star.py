@@ -83,6 +83,15 @@ def attn_classes(path):
         a[0] += d["SQ_VALU_MFMA_BUSY_CYCLES"]
         a[1] += d["ns"]
         a[2] += 1
+    # structural check of the work-threshold classification above: tools/bench_kernels.py --what attn runs two 12-key
+    # cross cases, one 51-key self case and three Electron-DOS cross cases, each the same number of aligned launches - a launch filed
+    # under the wrong class breaks the 2 : 1 : 3 ratio
+    n_self = agg["cfg2_self_aligned"][2] if "cfg2_self_aligned" in agg else 0
+    if n_self:
+        got = (agg["cfg2_cross_aligned"][2], n_self, agg["edos_cross_aligned"][2])
+        if got != (2 * n_self, n_self, 3 * n_self):
+            raise SystemExit(f"pmc_north_star: aligned attention launches per class {got}, expected the ratio 2 : 1 : 3 - "
+                             "the self / cross classification thresholds no longer fit the kernels")
     return {k: {"util": round(b / (SIMDS * ns * GHZ), 4), "launches": n} for k, (b, ns, n) in sorted(agg.items())}
 
 
