@@ -3,7 +3,9 @@
 per-site table) / the summed durations of its kernel symbol per step in the rocprofv3 --kernel-trace --stats run of the same
 command - no event brackets, no dispatch gaps, no waiting for CUs under another stream's kernels.  Steps of the traced run = calls
 of adamw_kernel (one per step).  Sites that share a kernel symbol (dosx_gemm's template instantiations are one symbol each; the
-ffn kernels have one symbol per tile form) are matched by the longest symbol prefix the site names.
+ffn kernels have one symbol per tile form) are matched by the symbol prefix the site names, share ONE fraction (their summed work
+over the symbol's summed time) and say so in `shares_symbol_with`; a gemm site also owns the mixed-tile-height instantiation
+of its template arguments (gemm_mixed_kernel).
 
 usage: kernel_only.py <kernel_stats.csv> <sites.json> <out.json> [git_head]"""
 import csv
@@ -34,8 +36,17 @@ def main():
         by_kernel.setdefault(s["kernel"], []).append(s)
     out = {"_note": __doc__.split("usage:")[0].strip(), "source_hash": source_hash(), "git_head": head, "config": sites.get("config"),
            "steps_traced": steps, "sites": {}}
+    def runs_as(kernel, name):
+        """Whether the traced symbol ``name`` is a launch of the site kernel ``kernel``.  dosx_gemm runs a problem whose last round
+        of workgroups is partial as gemm_mixed_kernel<RT, RT_tail, ...rest> - the site table names the plain instantiation
+        gemm_kernel<RT, ...rest> (ops.gemm cannot see the library's choice)."""
+        if name.startswith(kernel):
+            return True
+        m = re.match(r"gemm_kernel<(\d+), (.*)>$", kernel)
+        return bool(m and re.match(r"gemm_mixed_kernel<%s, \d+, %s>" % (m.group(1), re.escape(m.group(2))), name))
+
     for kernel, group in by_kernel.items():
-        sel = [(n, c, t) for n, c, t in rows if n.startswith(kernel)]
+        sel = [(n, c, t) for n, c, t in rows if runs_as(kernel, n)]
         if not sel:
             continue
         calls, total = sum(c for _, c, _ in sel), sum(t for _, _, t in sel)
