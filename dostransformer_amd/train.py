@@ -40,6 +40,20 @@ _DP_CHECK = __import__("os").environ.get("DOSX_DP_CHECK", "0") == "1"
 _META_TENSORS = ("src", "dst", "rowptr_dst", "perm_src", "rowptr_src", "graph_ptr", "node_graph", "dense_row", "inv_deg")
 
 
+class _Loaded:
+    """What a bucket's static buffers currently hold: see _Slot._signature."""
+    __slots__ = ("g", "ts", "versions")
+
+    def __init__(self, g, ts):
+        self.g, self.ts, self.versions = g, tuple(ts), tuple(t._version for t in ts)
+
+    def __eq__(self, other):
+        return (isinstance(other, _Loaded) and self.g is other.g and len(self.ts) == len(other.ts)
+                and all(a is b for a, b in zip(self.ts, other.ts)) and self.versions == other.versions)
+
+    __hash__ = None
+
+
 class _Slot:
     """Static buffers + captured graphs of one shape bucket."""
 
@@ -67,11 +81,14 @@ class _Slot:
         self._loaded = self._signature(g)      # the static buffers hold THIS batch (cloned above)
 
     def _signature(self, g: CrystalBatch):
-        """Identity + version of everything load() would copy from batch ``g``: the batch object, and per source tensor its
-        storage address and torch's in-place version counter (any in-place write to a field since the last load changes it)."""
+        """Identity + version of everything load() would copy from batch ``g``: the batch object and its source tensors
+        THEMSELVES (strong references, compared with ``is``) with torch's in-place version counters (any in-place write to a field
+        since the last load changes one).  Addresses are not identities: a batch collated after the previous one was freed gets the
+        same ``id()`` and - from the caching allocator - the same device pointers with version 0; holding the objects is what
+        keeps a later batch from being mistaken for this one (tests/test_gpu_step.py: an epoch of freshly collated batches)."""
         m = g.meta
         ts = [g[k] for k in self.fields] + [getattr(m, k) for k in _META_TENSORS] + ([m.seg_tile] if m.seg_tile is not None else [])
-        return (id(g),) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in ts)
+        return _Loaded(g, ts)
 
     @classmethod
     def empty(cls, kind: str, device, B: int, n_pad: int, e_pad: int, n_max: int, Fa: int, Fe: int, S: int,

@@ -201,7 +201,7 @@ def test_eight_rank_full_size_configs_match_single_process(eight_rank_full_run, 
     fp = model.flat_params()
     off = dict(zip(fp.names, fp.offsets))
     bad = []
-    worst_t = (0.0, None)
+    worst_t = worst_p = (0.0, None)
     for k, v in model.state_dict().items():
         if not v.is_floating_point():
             continue
@@ -212,6 +212,8 @@ def test_eight_rank_full_size_configs_match_single_process(eight_rank_full_run, 
             # per TENSOR: the 8-way sharded, all-reduced gradient against the full-batch one, relative to the tensor's maximum
             rel_t = float(np.abs(g0d - g0s).max() / (np.abs(g0s).max() + 1e-12))
             worst_t = max(worst_t, (rel_t, k))
+            if n >= 1000:           # ... and its TYPICAL element: 99 % of a tensor's elements agree to 1e-3 of its maximum
+                worst_p = max(worst_p, (float(np.percentile(np.abs(g0d - g0s), 99) / (np.abs(g0s).max() + 1e-12)), k))
             # Adam moves an element by ~lr*sign(g) per step, so parameters are compared where the gradient is resolved in
             # BOTH steps (an element whose step-0 gradient is at the noise floor of the two summation orders may legitimately
             # go the other way in step 0) and bounded by the two steps' movement elsewhere
@@ -225,8 +227,16 @@ def test_eight_rank_full_size_configs_match_single_process(eight_rank_full_run, 
                 bad.append((k, "bound", float(np.abs(a - b).max())))
         elif not np.array_equal(a, b):                                    # dead parameters: untouched everywhere
             bad.append((k, "dead", 0.0))
-    print(f"8-rank {kind}: worst per-tensor gradient error {worst_t[0]:.3e} at {worst_t[1]}")
-    assert worst_t[0] <= 1e-3, worst_t
+    print(f"8-rank {kind}: worst per-tensor gradient error {worst_t[0]:.3e} at {worst_t[1]}, worst 99th percentile {worst_p[0]:.3e} at {worst_p[1]}")
+    # The ranks' 64-crystal shards and the 512-crystal reference run take different kernel forms for the same layer (attention
+    # inside / outside the feed-forward launch, tile heights: functional.encoder_fwd's size policies), i.e. other fp32 summation
+    # orders - and a pre-activation within rounding of zero then gates its ReLU differently in the two runs: single ELEMENTS of a
+    # weight gradient differ by a finite amount (DESIGN.md 6 / HISTORY.md 4: the gate-flip analysis; 1.3e-3 .. 1.4e-3 of the tensor's
+    # maximum observed in rounds 4 and 6).  So the MAXIMUM is held to the tolerance of the fp32-vs-fp64 oracle comparison
+    # (tests/test_gpu_models.py: GRAD_TOL), 99 % of a tensor's elements to GRAD_TOL_P99 - a wrong shard weight or a missing rank
+    # moves every element by ~1/8 of its value
+    assert worst_t[0] <= 3e-3, worst_t
+    assert worst_p[0] <= 1e-3, worst_p          # (tests/test_gpu_models.py: GRAD_TOL_P99; observed 2.6e-4 at embeddings.weight)
     assert not bad, bad
 
 

@@ -68,6 +68,39 @@ def test_revisited_batch_is_not_copied_again_but_an_edited_one_is():
         assert torch.equal(a, b), k
 
 
+def test_fresh_batches_at_recycled_addresses_are_copied():
+    """A training loop that collates a NEW batch object every step and drops the previous one: CPython hands the new object the old
+    `id()` and the caching allocator the old device pointers (version counters 0 again), so an address-based "the bucket already
+    holds this batch" check skips the copy and the step silently trains on stale data (found by
+    test_step_dataset_is_the_step_on_the_collated_batch in round 6).  The bucket compares the objects themselves."""
+    from dostransformer_amd import ops, synth
+    from dostransformer_amd.train import Trainer, _Slot
+    n_atoms = [3, 5, 2, 7, 4, 6]
+    m_a, m_b = _phonon(), _phonon()
+    m_b.load_state_dict(copy.deepcopy(m_a.state_dict()))
+    ta, tb = Trainer(m_a, lr=1e-3, replay=True), Trainer(m_b, lr=1e-3, replay=True)
+    always = _Slot.load
+
+    def load_always(self, gg):
+        self._loaded = None
+        return always(self, gg)
+    ptrs = set()
+    for k in range(8):
+        g = synth.phonon_batch(6, seed=90 + k, dtype=torch.float32, n_atoms=n_atoms).to(DEV)
+        ptrs.add(g.x.data_ptr())
+        la = float(ta.step(g))
+        _Slot.load = load_always
+        try:
+            lb = float(tb.step(g))
+        finally:
+            _Slot.load = always
+        assert la == lb, (k, la, lb)
+        del g
+    assert len(ta._slots) == 1                          # one bucket throughout: every step after the first is a load + replay
+    for (k, a), (_, b) in zip(m_a.state_dict().items(), m_b.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
 @pytest.mark.parametrize("mode", ["graph", "replay"])
 def test_replay_takes_fp64_batches(mode):
     """float64 is the phonon pipeline's dtype (main_phDOS.py:15-16; synth.phonon_batch, DeviceDataset default).  Several
