@@ -1504,7 +1504,8 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
     R = _empty(dev, 2 * B, H)            # sum over the energy axis of dpre (filled on the side stream below)
     # (forward factored; R is filled later, on the side stream: deferred jobs only - and not with the late-flush experiment,
     #  whose flush_on_side() below would launch the B-row jobs before the reduce_rows that writes R is even queued)
-    if len(a_g.keep) > 2 and "fc.weight" in G and "fc_prompt.weight" in G and not late_flush:
+    r_jobs = None
+    if len(a_g.keep) > 2 and "fc.weight" in G and "fc_prompt.weight" in G:
         # the same factoring for the weight gradients: the column blocks that multiply the per-crystal inputs are
         # (sum_s dpre[s, b]) (x) [graph_b (| prompt_b)] - B-row jobs on R - and only the E1 block keeps its S * B rows
         E1_, graph_ = a_g.keep[0], a_g.keep[1]
@@ -1512,8 +1513,13 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
         _wgrad_linear(sink, G, "fc.weight", "fc.bias", S * B, H, seg(dpre, rmap=map0), [seg(E1_)], keep=(dpre, E1_), dst=Gfc[:, :H])
         _wgrad_linear(sink, G, "fc_prompt.weight", "fc_prompt.bias", S * B, H, seg(dpre, rmap=map1), [seg(E1_)], keep=(dpre,),
                       dst=Gfp[:, :H])
-        _wgrad_linear(sink, G, "fc.weight", None, B, H, seg(R[:B]), [seg(graph_)], keep=(R, graph_), dst=Gfc[:, H:])
-        _wgrad_linear(sink, G, "fc_prompt.weight", None, B, H, seg(R[B:]), [seg(graph_), seg(prow)], keep=(R, prow), dst=Gfp[:, H:])
+
+        def r_jobs():
+            _wgrad_linear(sink, G, "fc.weight", None, B, H, seg(R[:B]), [seg(graph_)], keep=(R, graph_), dst=Gfc[:, H:])
+            _wgrad_linear(sink, G, "fc_prompt.weight", None, B, H, seg(R[B:]), [seg(graph_), seg(prow)], keep=(R, prow), dst=Gfp[:, H:])
+        if not late_flush:
+            r_jobs()
+            r_jobs = None
     else:
         _wgrad_linear(sink, G, "fc.weight", "fc.bias", S * B, H, seg(dpre, rmap=map0), a_g.segs, keep=(dpre,))
         _wgrad_linear(sink, G, "fc_prompt.weight", "fc_prompt.bias", S * B, H, seg(dpre, rmap=map1), a_s.segs, keep=(dpre,))
@@ -1524,6 +1530,10 @@ def dostransformer_bwd(P: Params, G: Params, cfg: ModelCfg, m: GraphMeta, ctx, d
         # experiment: the self encoder's weight gradients (+ the two heads') start behind the small head kernels above
         # instead of in front of them (where the group's long-lived workgroups make these 8-15 us kernels wait)
         sink.flush_on_side()
+    if r_jobs is not None:
+        # (late flush: the B-row jobs read R, which the side stream fills below - they are described BEHIND that flush and go with
+        #  the next one, which every mode places behind the join with the side stream)
+        r_jobs()
     # graph / prompt inputs are constant over the energy axis: reduce over s first, then a [2B,H] GEMM.  Their
     # consumers (decoder backward, prompt-embedding gradient) come after the first encoder's backward: side stream.
     dgraph = _empty(dev, B, H)
