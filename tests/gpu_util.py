@@ -21,6 +21,7 @@ def rnd(*shape, seed=0, scale=1.0):
     return (torch.randn(*shape, generator=g, dtype=torch.float64) * scale).to(torch.float32).to(DEV)
 
 def err(a, b):
+    a, b = a.detach(), b.detach()
     return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-12))
 
 def prelu(x, a):
