@@ -1311,6 +1311,22 @@ def heads_bwd(S: int, B: int, H: int, dkvs, kvs, rstd, ddosin, dosin, slope: flo
           w=lambda: (f"heads_bwd[H{H}]", f"heads_bwd_kernel<{H}>", "mfma", 2.0 * S * B * H * 2 * H))
 
 
+def gemm_bf16x3_supported(M: int, N: int, K: int) -> bool:
+    return bool(_lib.load().dosx_gemm_bf16x3_supported(int(M), int(N), int(K)))
+
+
+def gemm_bf16x3(a, w, out, bias=None, w_layout: int = 0) -> None:
+    """out[M,N] = a[M,K] . op(w) (+ bias) with the split-bf16 kernel (include/dosx.h: dosx_gemm_bf16x3) - a measurement next to
+    `gemm`, not used by any program.  w: [N,K] (w_layout 0) or [K,N] (1); fp32, unit inner strides."""
+    M, K = a.shape
+    N = out.shape[1]
+    assert a.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1 and out.shape[0] == M
+    assert tuple(w.shape) == ((N, K) if w_layout == 0 else (K, N))
+    _call("dosx_gemm_bf16x3", _p(a), int(a.stride(0)), _p(w), int(w.stride(0)), int(w_layout), _p(bias), _p(out), int(out.stride(0)),
+          int(M), int(N), int(K), _stream(),
+          w=lambda: (f"gemm_bf16x3[N{N},K{K},wl{w_layout}]", "gemm_bf16x3_kernel", "mfma", 2.0 * M * N * K))
+
+
 def mask_residual(a, mask, res, out, stats, M, H):
     """out = (res or 0) + a o (mask or 1), optionally with the LayerNorm statistics [M,2] of out (include/dosx.h)."""
     _call("dosx_mask_residual", _p(a), int(a.stride(0)), _p(mask), _p(res), int(res.stride(0)) if res is not None else 0,

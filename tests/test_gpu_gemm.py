@@ -35,6 +35,46 @@ def test_gemm_plain(M, N, K, wl):
     assert err(out, ref) < TOL
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 256, 256), (128, 128, 32), (5000, 1024, 256), (4111, 256, 1024), (12864, 1024, 256)])
+@pytest.mark.parametrize("wl", [0, 1])
+def test_gemm_bf16x3_meets_the_fp32_tolerance(M, N, K, wl):
+    """The split-bf16 GEMM (csrc/gemm_bf16x3.hip; a measurement next to dosx_gemm): fp32 operands split into three
+    bf16 terms on the fly, six products on the bf16 matrix pipe, fp32 accumulation - held to dosx_gemm's OWN tolerance against
+    float64 (TOL, unchanged) and to a small multiple of the exact-fp32 kernel's error on the same operands; ragged M, both weight
+    layouts, bias."""
+    o = ops()
+    a = rnd(M, K, seed=1)
+    w = rnd(N, K, seed=2) if wl == 0 else rnd(K, N, seed=2)
+    b = rnd(N, seed=3)
+    assert o.gemm_bf16x3_supported(M, N, K)
+    out = torch.empty(M, N, device=DEV)
+    o.gemm_bf16x3(a, w, out, bias=b, w_layout=wl)
+    ref = a.double() @ (w.double().T if wl == 0 else w.double()) + b.double()
+    e3 = err(out, ref)
+    out32 = torch.empty(M, N, device=DEV)
+    o.gemm(M, N, [o.seg(a)], w, out32, w_layout=wl, bias=b)
+    e32 = err(out32, ref)
+    assert e3 < TOL, (e3, e32)
+    assert e3 <= 4.0 * e32 + 1e-7, (e3, e32)
+    # A = I with an asymmetric W: no transposed tile, and the three terms of every weight element add up to it
+    if M == 300:
+        eye = torch.zeros(M, K, device=DEV)
+        eye[:K] = torch.eye(K, device=DEV)
+        wa = (torch.arange(N * K, device=DEV, dtype=torch.float32).reshape(w.shape) % 97) / 7.0
+        o.gemm_bf16x3(eye, wa, out, w_layout=wl)
+        want = wa.T if wl == 0 else wa
+        assert err(out[:K], want.contiguous()) < 2e-7 and float(out[K:].abs().max()) == 0.0
+
+
+def test_gemm_bf16x3_rejects_shapes_it_does_not_tile():
+    from dostransformer_amd._lib import DosxError
+    o = ops()
+    a, w, out = rnd(64, 40, seed=1), rnd(128, 40, seed=2), torch.empty(64, 128, device=DEV)
+    assert not o.gemm_bf16x3_supported(64, 128, 40) and not o.gemm_bf16x3_supported(64, 100, 64)
+    with pytest.raises(DosxError):
+        o.gemm_bf16x3(a, w, out)
+
+
 def test_gemm_asymmetric_identity():
     # A = I with an asymmetric B catches a transposed C write (guide: "A=I-check with ASYMMETRIC B")
     o = ops()

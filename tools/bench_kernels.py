@@ -27,6 +27,21 @@ def timeit(fn, iters=50, warm=5):
     return s.elapsed_time(e) * 1e3 / iters     # us
 
 
+def bf16x3_case(name, M, N, K, wl):
+    a = torch.randn(M, K, device=DEV)
+    w = torch.randn(N, K, device=DEV) if wl == 0 else torch.randn(K, N, device=DEV)
+    out, out32 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    us3 = timeit(lambda: ops.gemm_bf16x3(a, w, out, w_layout=wl))
+    us32 = timeit(lambda: ops.gemm(M, N, [ops.seg(a)], w, out32, w_layout=wl))
+    rows = slice(0, min(M, 4096))
+    ref = a[rows].double() @ (w.double().T if wl == 0 else w.double())
+    e3 = float((out[rows].double() - ref).abs().max() / ref.abs().max())
+    e32 = float((out32[rows].double() - ref).abs().max() / ref.abs().max())
+    fl = 2.0 * M * N * K
+    print(f"bf16x3 {name:18s} M={M:6d} N={N:5d} K={K:5d} wl={wl}: split-bf16 {us3:8.1f} us {fl / us3 / 1e6:6.1f} TF/s(fp32-equivalent) | "
+          f"fp32 MFMA {us32:8.1f} us {fl / us32 / 1e6:6.1f} TF/s | x{us32 / us3:4.2f} | max err vs fp64: {e3:.2e} / {e32:.2e}", flush=True)
+
+
 def gemm_case(name, M, N, K, wl=0, pro=0, epi=0, nseg=1, gather=False):
     a = torch.randn(M, K // nseg, device=DEV)
     segs = [ops.seg(a)] * nseg
@@ -365,6 +380,11 @@ def main():
         gemm_case("cfg2 edge da (PRELU_LN_BWD epi)", 9000, 256, 128, wl=1, epi=ops.EPI_PRELU_LN_BWD)
         gemm_case("node encoder dz (PRELU_BWD epi)", 424, 128, 128, wl=1, epi=ops.EPI_PRELU_BWD)
         gemm_case("edge encoder dz (PRELU_BWD epi)", 9344, 128, 128, wl=1, epi=ops.EPI_PRELU_BWD)
+    if w in ("all", "bf16x3"):     # split-bf16 next to the exact-fp32 kernel: the Electron-DOS feed-forward shapes + roofline scale
+        for name, M_, N_, K_, wl_ in (("eDOS fc1 fwd", 25728, 1024, 256, 0), ("eDOS fc2 dgrad", 25728, 1024, 256, 1),
+                                      ("eDOS fc2 fwd", 25728, 256, 1024, 0), ("eDOS fc1 dgrad", 25728, 256, 1024, 1),
+                                      ("roofline scale", 262144, 512, 128, 0), ("square 8192", 8192, 8192, 8192, 0)):
+            bf16x3_case(name, M_, N_, K_, wl_)
     if w == "edosffn":      # the four feed-forward GEMMs of the Electron-DOS step (tile-policy experiments: DOSX_GEMM_RT / _BN)
         for M_ in (201 * 128, 24576, 201 * 64):
             gemm_case("eDOS fc1 fwd (rowLN pro)", M_, 1024, 256, pro=ops.PRO_ROWLN)
