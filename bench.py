@@ -549,6 +549,41 @@ def eval_throughput(device, B=64, n_batches=4, iters=100):
             "batch1_loop": round(iters / el1, 1)}
 
 
+def split_bf16_gemms(device, iters=30):
+    """VERDICT r5 item 9 (secondary only; the headline and every program stay exact fp32): the split-bf16 GEMM (csrc/gemm_bf16x3.hip -
+    three bf16 terms per fp32 operand element, six products on the bf16 matrix pipe, fp32 accumulation) next to dosx_gemm on the two
+    largest GEMM shapes of the Electron-DOS step (fc1 forward, fc2 input gradient: M = 201 * 128 rows, N = 1024, K = 256).  Errors
+    are max |C - C64| / max |C64| against float64 on the first 4096 rows, for both kernels on the same operands."""
+    from dostransformer_amd import ops
+    out = {"dtype": "fp32 in / out; arithmetic bf16 x 3 (hi + mid + lo split, 6 products, fp32 accumulate) vs fp32 MFMA"}
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for name, M, N, K, wl in (("fc1_fwd", 25728, 1024, 256, 0), ("fc2_dgrad", 25728, 1024, 256, 1)):
+        a = torch.randn(M, K, generator=g).to(device)
+        w = (torch.randn(N, K, generator=g) if wl == 0 else torch.randn(K, N, generator=g)).to(device)
+        c3, c32 = torch.empty(M, N, device=device), torch.empty(M, N, device=device)
+
+        def timed(fn):
+            for _ in range(3):
+                fn()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            s.record()
+            for _ in range(iters):
+                fn()
+            e.record()
+            torch.cuda.synchronize()
+            return s.elapsed_time(e) * 1e3 / iters
+        us3 = timed(lambda: ops.gemm_bf16x3(a, w, c3, w_layout=wl))
+        us32 = timed(lambda: ops.gemm(M, N, [ops.seg(a)], w, c32, w_layout=wl))
+        ref = a[:4096].double() @ (w.double().T if wl == 0 else w.double())
+        sc = float(ref.abs().max())
+        out[name] = {"M": M, "N": N, "K": K, "us": round(us3, 1), "us_fp32": round(us32, 1), "speedup": round(us32 / us3, 3),
+                     "tflops_fp32_equiv": round(2.0 * M * N * K / us3 / 1e6, 1),
+                     "err": float(f"{float((c3[:4096].double() - ref).abs().max()) / sc:.3g}"),
+                     "err_fp32": float(f"{float((c32[:4096].double() - ref).abs().max()) / sc:.3g}")}
+    return out
+
+
 def _free_port() -> int:
     import socket
     with socket.socket() as s:
@@ -744,6 +779,10 @@ def main():
             secondary["eval_per_crystal_b64"] = eval_throughput(device)
         except Exception as ex:
             secondary["eval_per_crystal_b64"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
+        try:
+            secondary["split_bf16"] = split_bf16_gemms(device)
+        except Exception as ex:
+            secondary["split_bf16"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
         # the same headline workload through the DATA-PARALLEL step on a 1-rank RCCL group: the replay plan split around
         # the collectives (SSE pair, early gradient bucket, late bucket), i.e. what data parallelism costs a rank before
         # any byte crosses xGMI - the figure a 1-GPU box can give about the N > 1 path

@@ -240,6 +240,10 @@ def test_bench_default_line_is_one_small_json_record(tmp_path):
     assert d1["exposed_bytes"] == d1["grad_bucket_bytes"]["late"]
     ev = rec["secondary"]["eval_per_crystal_b64"]                     # >= 50 k crystals/s at B = 64
     assert "error" not in ev and ev["value"] >= 50000 and ev["value"] > 10 * ev["batch1_loop"], ev
+    sb = rec["secondary"]["split_bf16"]                               # secondary only, dtype spelled out,
+    assert "error" not in sb and "bf16 x 3" in sb["dtype"]            # held to the exact-fp32 kernel's own error level
+    for k in ("fc1_fwd", "fc2_dgrad"):
+        assert sb[k]["us"] > 0 and sb[k]["speedup"] > 0.9 and sb[k]["err"] <= max(2e-5, 4 * sb[k]["err_fp32"]), sb[k]
     table = json.loads(kout.read_text())
     assert len(table["sites"]) >= 10 and not any(s["site"].startswith("gemm[M") for s in table["sites"])
 
