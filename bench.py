@@ -555,7 +555,7 @@ def split_bf16_gemms(device, iters=30):
     largest GEMM shapes of the Electron-DOS step (fc1 forward, fc2 input gradient: M = 201 * 128 rows, N = 1024, K = 256).  Errors
     are max |C - C64| / max |C64| against float64 on the first 4096 rows, for both kernels on the same operands."""
     from dostransformer_amd import ops
-    out = {"dtype": "fp32 in / out; arithmetic bf16 x 3 (hi + mid + lo split, 6 products, fp32 accumulate) vs fp32 MFMA"}
+    out = {"dtype": "fp32 in/out; bf16 x 3 split (6 products, fp32 accumulate) vs fp32 MFMA"}
     g = torch.Generator(device="cpu").manual_seed(5)
     for name, M, N, K, wl in (("fc1_fwd", 25728, 1024, 256, 0), ("fc2_dgrad", 25728, 1024, 256, 1)):
         a = torch.randn(M, K, generator=g).to(device)
@@ -781,6 +781,15 @@ def main():
             secondary["eval_per_crystal_b64"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
         try:
             secondary["split_bf16"] = split_bf16_gemms(device)
+            # ... and the Electron-DOS step with its plain feed-forward GEMMs on that kernel (opt-in functional._FFN_BF16X3; the
+            # default programs - everything else on this line - are exact fp32)
+            from dostransformer_amd import functional as _Fn
+            _Fn._FFN_BF16X3 = True
+            try:
+                e3 = run_workload("edos_h256_b64", shuffle=False, steps=40, warmup=8, bucket=(8, 128), instrument=False, **common)
+            finally:
+                _Fn._FFN_BF16X3 = False
+            secondary["split_bf16"]["edos_h256_b64_step_ms"] = round(1e3 * e3["elapsed"] / 40, 4)
         except Exception as ex:
             secondary["split_bf16"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
         # the same headline workload through the DATA-PARALLEL step on a 1-rank RCCL group: the replay plan split around

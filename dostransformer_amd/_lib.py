@@ -366,7 +366,7 @@ _SIGS = {
     "dosx_heads_bwd_supported": [_I],
     "dosx_heads_bwd": [C.POINTER(HeadsBwd), _P],
     "dosx_gemm_bf16x3_supported": [_I, _I, _I],
-    "dosx_gemm_bf16x3": [_P, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _P],
+    "dosx_gemm_bf16x3": [_P, _I, _P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P],
     "dosx_edge_mlp_supported": [_I],
     "dosx_edge_mlp_fwd": [C.POINTER(EdgeMlp), _P],
     "dosx_edge_mlp_bwd": [C.POINTER(EdgeMlpBwd), _P],

@@ -55,7 +55,9 @@ __device__ __forceinline__ Split3 split4(const float4 v) {
 template <int WL, int BM>
 __global__ __launch_bounds__(2 * BM) void gemm_bf16x3_kernel(const float* __restrict__ A, const int lda, const float* __restrict__ W,
                                                           const int ldw, const float* __restrict__ bias, float* __restrict__ C,
-                                                          const int ldc, const int M, const int N, const int K) {
+                                                          const int ldc, const int M, const int N, const int K, const int act,
+                                                          const float* __restrict__ res, const int ldres,
+                                                          const float* __restrict__ mask, const int ldmask) {
   constexpr int BK = BX_BK, LDK = BX_LDK, NT = 2 * BM;
   constexpr int PA = BM * LDK, PW = BX_BN * LDK, STAGE = 3 * (PA + PW);      // one bf16 plane of the A / W tile; a stage = 3 + 3 planes
   constexpr int F4R = BK / 4;                       // float4 per tile row (4)
@@ -188,14 +190,20 @@ __global__ __launch_bounds__(2 * BM) void gemm_bf16x3_kernel(const float* __rest
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (m < M) C[(size_t)m * ldc + n] = acc[i][j][r] + bv;
+        if (m < M) {
+          float v = acc[i][j][r] + bv;
+          if (act) v = fmaxf(v, 0.f);
+          if (res) v += res[(size_t)m * ldres + n];
+          if (mask) v = mask[(size_t)m * ldmask + n] > 0.f ? v : 0.f;
+          C[(size_t)m * ldc + n] = v;
+        }
       }
   }
 }
 
 template <int WL, int BM>
 int launch_bf16x3(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, int M, int N, int K,
-                  hipStream_t s) {
+                  int act, const float* res, int ldres, const float* mask, int ldmask, hipStream_t s) {
   constexpr size_t smem = 2 * (size_t)(3 * (BM + BX_BN) * BX_LDK) * sizeof(__bf16);
   static_assert(smem <= 160 * 1024, "gemm_bf16x3_kernel: LDS");
   static bool attr_set = false;
@@ -204,7 +212,7 @@ int launch_bf16x3(const float* A, int lda, const float* W, int ldw, const float*
     attr_set = true;
   }
   const int ntiles = (N / BX_BN) * ceil_div(M, BM);
-  hipLaunchKernelGGL((gemm_bf16x3_kernel<WL, BM>), dim3(8 * ceil_div(ntiles, 8)), dim3(2 * BM), smem, s, A, lda, W, ldw, bias, C, ldc, M, N, K);
+  hipLaunchKernelGGL((gemm_bf16x3_kernel<WL, BM>), dim3(8 * ceil_div(ntiles, 8)), dim3(2 * BM), smem, s, A, lda, W, ldw, bias, C, ldc, M, N, K, act, res, ldres, mask, ldmask);
   DOSX_LAUNCH_CHECK();
   return 0;
 }
@@ -213,13 +221,17 @@ int launch_bf16x3(const float* A, int lda, const float* W, int ldw, const float*
 
 extern "C" int dosx_gemm_bf16x3_supported(int M, int N, int K) { return M > 0 && N > 0 && (N % 128) == 0 && K > 0 && (K % 32) == 0; }
 
-// C[M,N] = A[M,K] . op(W) (+ bias[N]);  w_layout 0: W is [N][K], 1: W is [K][N].  fp32 in, fp32 out, split-bf16 arithmetic (see top).
+// C[M,N] = epi( A[M,K] . op(W) + bias[N] );  w_layout 0: W is [N][K], 1: W is [K][N].  fp32 in, fp32 out, split-bf16 arithmetic
+// (see top).  epi: relu when act == 1, then + res[M,N] when given, then zero where mask[M,N] <= 0 when given (the ReLU-mask
+// epilogue of an input gradient: dosx_gemm's EPI_RELU_MASK) - what the feed-forward half of an encoder layer needs.
 extern "C" int dosx_gemm_bf16x3(const float* A, int lda, const float* W, int ldw, int w_layout, const float* bias, float* C, int ldc,
-                                int M, int N, int K, dosx_stream_t stream) {
+                                int M, int N, int K, int act, const float* res, int ldres, const float* mask, int ldmask,
+                                dosx_stream_t stream) {
   if (M <= 0) return 0;
   DOSX_CHECK_ARG(A && W && C, "dosx_gemm_bf16x3: null operand");
   DOSX_CHECK_ARG(dosx_gemm_bf16x3_supported(M, N, K), "dosx_gemm_bf16x3: N=%d must be a multiple of 128 and K=%d of 32", N, K);
   DOSX_CHECK_ARG(w_layout == 0 || w_layout == 1, "dosx_gemm_bf16x3: w_layout %d", w_layout);
+  DOSX_CHECK_ARG((act == 0 || act == 1) && (!res || ldres >= N) && (!mask || ldmask >= N), "dosx_gemm_bf16x3: act 0 / 1, ldres / ldmask >= N");
   DOSX_CHECK_ARG((lda & 3) == 0 && (ldw & 3) == 0 && lda >= K && ldw >= (w_layout ? N : K) && ldc >= N &&
                      (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0,
                  "dosx_gemm_bf16x3: operands must be 16-byte aligned with leading dimensions that are multiples of 4");
@@ -229,6 +241,6 @@ extern "C" int dosx_gemm_bf16x3(const float* A, int lda, const float* W, int ldw
   static int force = -1;
   if (force < 0) { const char* e = getenv("DOSX_BF16X3_BM"); force = e ? atoi(e) : 0; }
   const bool tall = force ? force == 256 : K > 512;
-  if (tall) return w_layout ? launch_bf16x3<1, 256>(A, lda, W, ldw, bias, C, ldc, M, N, K, s) : launch_bf16x3<0, 256>(A, lda, W, ldw, bias, C, ldc, M, N, K, s);
-  return w_layout ? launch_bf16x3<1, 128>(A, lda, W, ldw, bias, C, ldc, M, N, K, s) : launch_bf16x3<0, 128>(A, lda, W, ldw, bias, C, ldc, M, N, K, s);
+  if (tall) return w_layout ? launch_bf16x3<1, 256>(A, lda, W, ldw, bias, C, ldc, M, N, K, act, res, ldres, mask, ldmask, s) : launch_bf16x3<0, 256>(A, lda, W, ldw, bias, C, ldc, M, N, K, act, res, ldres, mask, ldmask, s);
+  return w_layout ? launch_bf16x3<1, 128>(A, lda, W, ldw, bias, C, ldc, M, N, K, act, res, ldres, mask, ldmask, s) : launch_bf16x3<0, 128>(A, lda, W, ldw, bias, C, ldc, M, N, K, act, res, ldres, mask, ldmask, s);
 }

@@ -807,13 +807,18 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
                         P[lp + ".fc2.bias"], h, x2, fin=fin_args, att=att_args, defer=stack if att_fused else None)
         else:
             def ffn_rows(r0, r1, x1=x1, st1=st1, h=h, x2=x2, lp=lp, xln=xln):
-                if xln is not None:
+                if xln is not None and _bf16x3_ok(r1 - r0, 4 * H, H):
+                    ops.gemm_bf16x3(xln[r0:r1], P[lp + ".fc1.weight"], h[r0:r1], bias=P[lp + ".fc1.bias"], act=ACT_RELU)
+                elif xln is not None:
                     ops.gemm(r1 - r0, 4 * H, [seg(xln[r0:r1])], P[lp + ".fc1.weight"], h[r0:r1], bias=P[lp + ".fc1.bias"], act=ACT_RELU)
                 else:
                     ops.gemm(r1 - r0, 4 * H, [seg(x1[r0:r1])], P[lp + ".fc1.weight"], h[r0:r1], pro=PRO_ROWLN,
                              pro_gamma=P[lp + ".layer_norms.1.weight"], pro_beta=P[lp + ".layer_norms.1.bias"], pro_stats=st1[r0:r1],
                              bias=P[lp + ".fc1.bias"], act=ACT_RELU)
-                ops.gemm(r1 - r0, H, [seg(h[r0:r1])], P[lp + ".fc2.weight"], x2[r0:r1], bias=P[lp + ".fc2.bias"], res=x1[r0:r1])
+                if _bf16x3_ok(r1 - r0, H, 4 * H):
+                    ops.gemm_bf16x3(h[r0:r1], P[lp + ".fc2.weight"], x2[r0:r1], bias=P[lp + ".fc2.bias"], res=x1[r0:r1])
+                else:
+                    ops.gemm(r1 - r0, H, [seg(h[r0:r1])], P[lp + ".fc2.weight"], x2[r0:r1], bias=P[lp + ".fc2.bias"], res=x1[r0:r1])
             mt = _ffn_tail_start(rows, H)
             if mt:
                 # the rows beyond the last FULL round of 64-row tiles (25728 = 3 x 8192 + 1152) as their own two-GEMM chain on
@@ -843,6 +848,18 @@ def encoder_fwd(P: Params, pre: str, x: torch.Tensor, Sq: int, Bq: int, qs: int,
 # Unfused feed-forward layers (hidden > 128), FORWARD: tail rows as a concurrent two-GEMM chain.  Electron-DOS step 7.535 ->
 # 7.473 ms (four interleaved rounds, profiles/r04_ab_ffn_tail.log); the same split in the backward pass, where the weight-
 # gradient groups already fill every gap, gave the gain back (7.526 ms) and is not built in.
+# OPT-IN (off by default; every default program is exact fp32): the plain GEMMs of an UNFUSED feed-forward half (hidden > 128:
+# fc1 forward on the LayerNorm-1 rows the attention kernel left behind, fc2 forward, fc2's input gradient with the ReLU mask) on the
+# split-bf16 kernel (csrc/gemm_bf16x3.hip: three bf16 terms per fp32 element, fp32 accumulate - fp32-level accuracy, not bitwise the
+# fp32-FMA chain).  bench.py reports the Electron-DOS step under it as `secondary.edos_h256_b64_split_bf16`; the oracle-live tests run
+# under it with their tolerances unchanged (tests/test_gpu_models.py).  fc1's input gradient keeps dosx_gemm (LayerNorm-backward epilogue).
+_FFN_BF16X3 = __import__("os").environ.get("DOSX_FFN_BF16X3", "0") == "1"
+
+
+def _bf16x3_ok(rows: int, n: int, k: int) -> bool:
+    return _FFN_BF16X3 and ops.gemm_bf16x3_supported(rows, n, k)
+
+
 _FFN_TAIL = int(__import__("os").environ.get("DOSX_FFN_TAIL", "1"))
 _FFN_TAIL_MAX = int(__import__("os").environ.get("DOSX_FFN_TAIL_MAX", "2048"))
 
@@ -981,7 +998,10 @@ def encoder_bwd(P: Params, G: Params, pre: str, ctx, dy: Optional[torch.Tensor],
                     sink.add(part, 4 * H, G[fin_keys[2]], rgp, pld, H)
                     sink.add(part, 5 * H, G[fin_keys[3]], rgp, pld, 1)
         else:
-            ops.gemm(rows, 4 * H, [seg(dx)], P[lp + ".fc2.weight"], dh, w_layout=1, epi=EPI_RELU_MASK, aux=h)
+            if _bf16x3_ok(rows, 4 * H, H) and dx.is_contiguous():
+                ops.gemm_bf16x3(dx, P[lp + ".fc2.weight"], dh, w_layout=1, mask=h)
+            else:
+                ops.gemm(rows, 4 * H, [seg(dx)], P[lp + ".fc2.weight"], dh, w_layout=1, epi=EPI_RELU_MASK, aux=h)
             if fm is not None and fm[1] is not None:       # h is the dropped activation: [h > 0] = [relu > 0][M2 > 0]; x 1/(1-p)
                 ops.mask_residual(dh, fm[1], None, dh, None, rows, 4 * H)
         # fc1 (+ LN1 backward + residual)

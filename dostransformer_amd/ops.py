@@ -1315,15 +1315,18 @@ def gemm_bf16x3_supported(M: int, N: int, K: int) -> bool:
     return bool(_lib.load().dosx_gemm_bf16x3_supported(int(M), int(N), int(K)))
 
 
-def gemm_bf16x3(a, w, out, bias=None, w_layout: int = 0) -> None:
-    """out[M,N] = a[M,K] . op(w) (+ bias) with the split-bf16 kernel (include/dosx.h: dosx_gemm_bf16x3) - a measurement next to
-    `gemm`, not used by any program.  w: [N,K] (w_layout 0) or [K,N] (1); fp32, unit inner strides."""
+def gemm_bf16x3(a, w, out, bias=None, w_layout: int = 0, act: int = 0, res=None, mask=None) -> None:
+    """out[M,N] = epi(a[M,K] . op(w) + bias) with the split-bf16 kernel (include/dosx.h: dosx_gemm_bf16x3).  w: [N,K] (w_layout 0) or
+    [K,N] (1); fp32, unit inner strides.  epi: relu (act = ACT_RELU), + res, zero where mask <= 0."""
     M, K = a.shape
     N = out.shape[1]
     assert a.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1 and out.shape[0] == M
-    assert tuple(w.shape) == ((N, K) if w_layout == 0 else (K, N))
+    assert tuple(w.shape) == ((N, K) if w_layout == 0 else (K, N)) and act in (0, ACT_RELU)
+    for t in (res, mask):
+        assert t is None or (t.stride(1) == 1 and tuple(t.shape) == (M, N))
     _call("dosx_gemm_bf16x3", _p(a), int(a.stride(0)), _p(w), int(w.stride(0)), int(w_layout), _p(bias), _p(out), int(out.stride(0)),
-          int(M), int(N), int(K), _stream(),
+          int(M), int(N), int(K), 1 if act == ACT_RELU else 0, _p(res), int(res.stride(0)) if res is not None else 0,
+          _p(mask), int(mask.stride(0)) if mask is not None else 0, _stream(),
           w=lambda: (f"gemm_bf16x3[N{N},K{K},wl{w_layout}]", "gemm_bf16x3_kernel", "mfma", 2.0 * M * N * K))
 
 

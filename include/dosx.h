@@ -639,7 +639,8 @@ int dosx_heads_bwd_supported(int H);
 int dosx_heads_bwd(const DosxHeadsBwd* a, dosx_stream_t stream);
 
 /* Split-bf16 GEMM (round 6, csrc/gemm_bf16x3.hip) - a MEASUREMENT next to dosx_gemm, not part of any training / inference program:
- *     C[M,N] = A[M,K] . op(W) (+ bias[N])      w_layout 0: W is [N][K] (nn.Linear), 1: W is [K][N]
+ *     C[M,N] = epi( A[M,K] . op(W) + bias[N] )      w_layout 0: W is [N][K] (nn.Linear), 1: W is [K][N]
+ *     epi: relu (act = 1), then + res[M,N] (optional), then zero where mask[M,N] <= 0 (optional: dosx_gemm's EPI_RELU_MASK)
  * fp32 operands and result; every element is split into three bf16 terms on the fly and the six leading products run on the
  * bf16 matrix pipe with fp32 accumulation (error of the size of one fp32 rounding per product; tests hold it to dosx_gemm's
  * tolerance against float64).  N % 128 == 0, K % 32 == 0, 16-byte aligned operands, leading dimensions multiples of 4.
@@ -647,7 +648,8 @@ int dosx_heads_bwd(const DosxHeadsBwd* a, dosx_stream_t stream);
  * reference computes in fp32 / fp64, main_phDOS.py:15-16). */
 int dosx_gemm_bf16x3_supported(int M, int N, int K);
 int dosx_gemm_bf16x3(const float* A, int lda, const float* W, int ldw, int w_layout, const float* bias, float* C, int ldc,
-                     int M, int N, int K, dosx_stream_t stream);
+                     int M, int N, int K, int act, const float* res, int ldres, const float* mask, int ldmask,
+                     dosx_stream_t stream);
 
 /* Linear -> LayerNorm -> PReLU -> Linear (+ residual) in ONE launch for small row counts: the NodeModel MLP of a GNN layer
  * (DOSTransformer_phonon.py:200-212 `node_mlp_2(cat[x, agg])`, DOSTransformer.py:178-190).

@@ -66,6 +66,29 @@ def test_gemm_bf16x3_meets_the_fp32_tolerance(M, N, K, wl):
         assert err(out[:K], want.contiguous()) < 2e-7 and float(out[K:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("wl", [0, 1])
+def test_gemm_bf16x3_epilogues(wl):
+    """relu, residual and the ReLU-mask epilogue (what the feed-forward half of an encoder layer asks of its GEMMs) against float64
+    and against dosx_gemm's own epilogues."""
+    o = ops()
+    M, N, K = 777, 256, 128
+    a, b = rnd(M, K, seed=1), rnd(N, seed=3)
+    w = rnd(N, K, seed=2) if wl == 0 else rnd(K, N, seed=2)
+    res, h = rnd(M, N, seed=4), rnd(M, N, seed=5)
+    z = a.double() @ (w.double().T if wl == 0 else w.double())
+    out = torch.empty(M, N, device=DEV)
+    o.gemm_bf16x3(a, w, out, bias=b, w_layout=wl, act=o.ACT_RELU)
+    assert err(out, torch.relu(z + b.double())) < TOL
+    o.gemm_bf16x3(a, w, out, bias=b, w_layout=wl, res=res)
+    assert err(out, z + b.double() + res.double()) < TOL
+    o.gemm_bf16x3(a, w, out, w_layout=wl, mask=h)
+    assert err(out, z * (h.double() > 0)) < TOL
+    if wl == 1:                                         # (dosx_gemm has the ReLU-mask epilogue for input gradients only)
+        out32 = torch.empty(M, N, device=DEV)
+        o.gemm(M, N, [o.seg(a)], w, out32, w_layout=wl, epi=o.EPI_RELU_MASK, aux=h)
+        assert torch.equal(out == 0, out32 == 0)        # the same gate, element for element
+
+
 def test_gemm_bf16x3_rejects_shapes_it_does_not_tile():
     from dostransformer_amd._lib import DosxError
     o = ops()

@@ -337,6 +337,25 @@ def test_ghost_padding_is_exact(kind):
     assert float((g0 - g1).abs().max()) <= 1e-6 * float(g0.abs().max())      # slab split points move, math does not
 
 
+@pytest.mark.parametrize("B", [4, 64])
+def test_against_oracle_live_with_split_bf16_feed_forward(monkeypatch, B):
+    """the opt-in split-bf16 kernel under the plain feed-forward GEMMs of the Electron-DOS model (hidden 256:
+    fc1 forward, fc2 forward, fc2's ReLU-masked input gradient - functional._FFN_BF16X3) against the oracle with EVERY tolerance of
+    test_against_oracle_live unchanged (outputs, loss, every gradient's maximum / 99th percentile / median, one AdamW step)."""
+    from dostransformer_amd import functional as Fn, ops as O_
+    calls = []
+    real = O_.gemm_bf16x3
+
+    def counting(*a, **k):
+        calls.append(k.get("w_layout", 0))
+        return real(*a, **k)
+    monkeypatch.setattr(Fn, "_FFN_BF16X3", True)
+    monkeypatch.setattr(O_, "gemm_bf16x3", counting)
+    test_against_oracle_live("edos", 256, 2, B)
+    # three encoder stacks x 2 layers: fc1 + fc2 forward (+ the tail-row chains at 64 crystals), fc2's input gradient
+    assert calls.count(0) >= 12 and calls.count(1) >= 6, calls
+
+
 @pytest.mark.parametrize("mode", ["graph", "replay"])
 @pytest.mark.parametrize("kind", ["phonon", "edos"])
 def test_graph_replay_matches_eager(kind, mode):
