@@ -180,24 +180,36 @@ __global__ __launch_bounds__(2 * BM) void gemm_bf16x3_kernel(const float* __rest
   step(0, true, ra[1], rw[1]);
   __syncthreads();
   step(1, false, ra[0], rw[0]);
-  // C: lane = column, 16 registers = rows (r & 3) + 8 (r >> 2) + 4 hh of the 32 x 32 tile
+  // C: lane = column, 16 registers = rows (r & 3) + 8 (r >> 2) + 4 hh of the 32 x 32 tile.  The plain form (bias only) has its own
+  // store loop: three per-element conditions in front of 64 stores per lane cost the K = 256 shapes 5 %.
+  const bool plain = !act && !res && !mask;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = n0 + 64 * wc + 32 * j + r31;
     const float bv = bias ? bias[n] : 0.f;
+    if (plain) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (m < M) {
-          float v = acc[i][j][r] + bv;
-          if (act) v = fmaxf(v, 0.f);
-          if (res) v += res[(size_t)m * ldres + n];
-          if (mask) v = mask[(size_t)m * ldmask + n] > 0.f ? v : 0.f;
-          C[(size_t)m * ldc + n] = v;
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (m < M) C[(size_t)m * ldc + n] = acc[i][j][r] + bv;
         }
-      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (m < M) {
+            float v = acc[i][j][r] + bv;
+            if (act) v = fmaxf(v, 0.f);
+            if (res) v += res[(size_t)m * ldres + n];
+            if (mask) v = mask[(size_t)m * ldmask + n] > 0.f ? v : 0.f;
+            C[(size_t)m * ldc + n] = v;
+          }
+        }
+    }
   }
 }
 
