@@ -1261,6 +1261,7 @@ __global__ __launch_bounds__(512, DOSX_FFN_BWD_OCC) void ffn_bwd_kernel(const Do
       for (int c = (tid & 7) * 4; c < H && r < R; c += 32) st4(Ys + r * LDX + c, ld4(a.dy + (size_t)rr * a.lddy + c));
     }
     __syncthreads();
+    FSTAMP(1);
     int c = 0;
     // C-fragment coordinates of this lane inside a 128-column block: rows crow(v), columns ccol(v)
     auto crow = [&](int v) { return HALF ? 4 * g4 + (v & 3) : (v & 3) + 8 * (v >> 2) + 4 * hh; };
@@ -1321,7 +1322,9 @@ __global__ __launch_bounds__(512, DOSX_FFN_BWD_OCC) void ffn_bwd_kernel(const Do
         if (gr >= 0) a.dh[(size_t)gr * a.lddh + cb * FBN + ccol(v)] = d;     // (see ffn_fwd_kernel)
       }
     }
+    FSTAMP(2);
     __syncthreads();                               // T complete (the staging waves copy it out from here on)
+    FSTAMP(3);
     // ---- phase 2: dyl = dh . W1, one 128-column block, n2 chunks, A operand = T ----
     if constexpr (HALF) {
       f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
@@ -1364,11 +1367,13 @@ __global__ __launch_bounds__(512, DOSX_FFN_BWD_OCC) void ffn_bwd_kernel(const Do
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[v] = a0[v];
     }
+    FSTAMP(4);
     float* Cs = ST;                                // C tile (the stage buffers are dead: the last chunk ended with a barrier)
 #pragma unroll
     for (int v = 0; v < NV; ++v) Cs[crow(v) * BLDW + ccol(v)] = acc[v];
   }
   __syncthreads();
+  FSTAMP(5);
   // ---- row epilogue (8 waves x ER rows): LayerNorm backward over the row + residual; column sums for dgamma / dbeta ----
   float4 pg = f4zero(), pb = f4zero();
   {

@@ -1,6 +1,7 @@
 """Diagnostic: phase stamps of ffn_bwd_kernel<false, 64, 2> - the feed-forward half's backward + the crystal-aligned attention
 backward behind it (ffn_att_bwd_tile) - through a real encoder layer (needs DOSX_LIB=.../build/libdosx_stamps.so).
-Slots: 0 kernel start, 16 attention epilogue start, 17 operands requested / keys stored, 18-19 phase a + barrier, 20 dP, 21 dS,
+Slots: 0 kernel start, 1 dy tile + first chunk staged, 2 fc2 input-gradient loop done (4 column blocks), 3 dh tile barrier, 4 fc1
+input-gradient loop done, 5 C tile barrier, 16 attention epilogue start (= row epilogue done), 17 operands requested / keys stored, 18-19 phase a + barrier, 20 dP, 21 dS,
 22-23 dq + barrier, 24 LayerNorm-0 backward / query partial rows, 25 dK + dV product, 26 drained, 27 ticket known, 28 reduction
 (last arriver only), 29 end."""
 import ctypes as C, os, sys, torch
