@@ -15,6 +15,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -312,6 +313,120 @@ __global__ void collate_pad_tiles_kernel(const DosxCollate d) {
   d.seg_tile[2 * (d.T + 1) + t] = pi;
 }
 
+// The same table by the HOST's rule - greedy over the whole batch, tiles may span crystal boundaries (batch.seg_tiles_host is the
+// twin, tile for tile) - in one workgroup (round 6).  The crystal-aligned table above ends every crystal with a partial tile:
+// 256 tiles for 64 seven-atom crystals where the greedy packing makes 212, i.e. 20 % more workgroups (and weight streams) for the
+// EdgeModel launches of every step that collates on the device.  A greedy packing is a chain - each tile starts where the previous
+// one ends - so: (1) every node k computes, as if a tile started at it, where that tile (or, for a node of more than `rows`
+// incoming edges, its run of chunk tiles) ends: nxt[k]; (2) the starts actually reached from node 0 are marked by pointer
+// doubling (round r marks what is 2^r .. 2^(r+1) - 1 tiles away); (3) a prefix sum over the marked nodes' tile counts places them.
+// LDS: four int arrays of N + 1 entries; N <= GT_MAXN, larger batches keep the crystal-aligned table.
+constexpr int GT_MAXN = 8192, GT_THREADS = 1024;
+__global__ __launch_bounds__(GT_THREADS) void collate_greedy_tiles_kernel(const DosxCollate d) {
+  extern __shared__ int gsm[];
+  const int N = d.N, E = d.E, rows = d.tile_rows, tid = threadIdx.x;
+  int* rp = gsm;                 // [N + 1] destination row pointers of the real nodes
+  int* nxt = rp + (N + 1);       // [N + 1] start of the tile behind the tile(s) that start at k; later the jump table
+  int* jm2 = nxt + (N + 1);      // [N + 1] second jump buffer
+  int* mark = jm2 + (N + 1);     // [N + 1] 1: a tile starts at node k; later the exclusive prefix of the tile counts
+  __shared__ int wsum[GT_THREADS / 64 + 1];
+  for (int k = tid; k <= N; k += GT_THREADS) rp[k] = d.rowptr_dst[k];
+  __syncthreads();
+  auto last_le = [&](const int lim) {            // largest j in [0, N] with rp[j] <= lim (rp is non-decreasing, rp[0] = 0 <= lim)
+    int lo = 0, hi = N;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (rp[mid] <= lim) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+  };
+  auto ntiles = [&](const int k) {               // tiles that start at node k: 1, or its chunk tiles
+    const int deg = rp[k + 1] - rp[k];
+    return deg > rows ? (deg + rows - 1) / rows : 1;
+  };
+  for (int k = tid; k < N; k += GT_THREADS) {
+    const int deg = rp[k + 1] - rp[k];
+    int j;
+    if (deg > rows) {
+      const int nfull = deg / rows, r = deg - nfull * rows;
+      if (r) {                                   // the remainder's tile goes on with whole nodes
+        j = min(max(last_le(rp[k] + nfull * rows + rows), k + 1), N);
+      } else {
+        // full last chunk: when the tile behind it would hold no rows (isolated nodes in front of the next over-full node, or
+        // of the end), the chunk tile takes those nodes (seg_tiles_host: a tile without rows breaks seg_tile_bound's pairing)
+        j = k + 1;
+        if (j < N && rp[j + 1] - rp[j] <= rows) {
+          const int j2 = min(max(last_le(rp[j] + rows), j + 1), N);
+          if (rp[j2] == rp[j]) j = j2;
+        }
+      }
+    } else {
+      j = min(max(last_le(rp[k] + rows), k + 1), N);
+    }
+    nxt[k] = j;
+    mark[k] = k == 0 ? 1 : 0;
+  }
+  if (tid == 0) { nxt[N] = N; mark[N] = 0; }
+  __syncthreads();
+  int* ja = nxt;
+  int* jb = jm2;
+  for (int span = 1; span < N; span <<= 1) {     // after the round: every start fewer than 2 * span tiles from node 0 is marked
+    for (int k = tid; k <= N; k += GT_THREADS) jb[k] = ja[ja[k]];
+    __syncthreads();
+    for (int k = tid; k < N; k += GT_THREADS)
+      if (mark[k] && ja[k] < N) mark[ja[k]] = 1;           // (several writers, one value)
+    __syncthreads();
+    int* t_ = ja; ja = jb; jb = t_;
+  }
+  // exclusive prefix of the marked nodes' tile counts: a contiguous run of nodes per thread, wave scan, wave totals
+  const int per = (N + GT_THREADS - 1) / GT_THREADS, k0 = tid * per, k1 = min(k0 + per, N);
+  int mine = 0;
+  for (int k = k0; k < k1; ++k) mine += mark[k] ? ntiles(k) : 0;
+  int incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o);
+    if ((tid & 63) >= o) incl += v;
+  }
+  if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+  __syncthreads();
+  if (tid == 0) {
+    int a = 0;
+    for (int w = 0; w < GT_THREADS / 64; ++w) { const int v = wsum[w]; wsum[w] = a; a += v; }
+    wsum[GT_THREADS / 64] = a;
+  }
+  __syncthreads();
+  const int real = wsum[GT_THREADS / 64];
+  int base = wsum[tid >> 6] + incl - mine;
+  int* seb = d.seg_tile;
+  int* snb = d.seg_tile + (d.T + 1);
+  int* spi = d.seg_tile + 2 * (d.T + 1);
+  for (int k = k0; k < k1; ++k) {
+    if (!mark[k]) continue;
+    const int deg = rp[k + 1] - rp[k];
+    if (deg > rows) {
+      const int nc = (deg + rows - 1) / rows;
+      for (int i = 0; i < nc && base + i <= d.T; ++i) {
+        seb[base + i] = rp[k] + i * rows;
+        snb[base + i] = k;
+        spi[base + i] = (i << 16) | nc;
+      }
+      base += nc;
+    } else {
+      if (base <= d.T) { seb[base] = rp[k]; snb[base] = k; spi[base] = 0; }
+      ++base;
+    }
+  }
+  // the boundary behind the last real tile, then the ghost edges in `rows`-row tiles (the first owns every ghost node), then
+  // empty slots: batch.pad_seg_tiles
+  for (int t = real + tid; t <= d.T; t += GT_THREADS) {
+    const int kk = t - real;
+    seb[t] = min(E + kk * rows, d.E_pad);
+    snb[t] = kk == 0 ? N : d.N_pad;
+    spi[t] = 0;
+  }
+}
+
 // feature rows: x [N_pad,Fa], edge features [E_pad,Fe], per-crystal targets [B,S] / globals [B,n_glob] / system [B]
 __global__ void collate_pad_gather_kernel(const DosxCollate d) {
   const size_t nx = (size_t)d.N_pad * d.Fa, ne = (size_t)d.E_pad * d.Fe, nt = (size_t)d.B * d.S, ng = (size_t)d.B * d.n_glob;
@@ -360,7 +475,19 @@ extern "C" int dosx_collate_padded(const DosxCollate* dp, dosx_stream_t stream) 
   if (d.seg_tile) {
     DOSX_CHECK_ARG(d.T > 0 && d.tile_rows > 0 && d.out_tile_ptr && d.tile_off_all && d.tile_e_all && d.tile_n_all && d.tile_p_all,
                    "dosx_collate_padded: seg_tile needs T, tile_rows and the per-crystal tile tables");
-    hipLaunchKernelGGL(collate_pad_tiles_kernel, dim3(ceil_div(d.T + 1, 256)), dim3(256), 0, s, d);
+    static int greedy = -1;
+    if (greedy < 0) { const char* e = getenv("DOSX_COLLATE_GREEDY_TILES"); greedy = e ? atoi(e) : 1; }
+    if (greedy && d.N <= GT_MAXN) {
+      const size_t smem = sizeof(int) * 4 * (size_t)(d.N + 1);
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&collate_greedy_tiles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4 * (GT_MAXN + 1));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(collate_greedy_tiles_kernel, dim3(1), dim3(GT_THREADS), smem, s, d);      // (behind collate_pad_nodes_kernel: rowptr_dst)
+    } else {
+      hipLaunchKernelGGL(collate_pad_tiles_kernel, dim3(ceil_div(d.T + 1, 256)), dim3(256), 0, s, d);
+    }
   }
   const size_t total = (size_t)d.N_pad * d.Fa + (size_t)d.E_pad * d.Fe + (size_t)d.B * (d.S + d.n_glob + 1);
   size_t blocks = (total + 255) / 256;
